@@ -1,0 +1,343 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native GEMM / reduce hot path.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver starts one
+process per GPU with torch.distributed.run.  Rank 0 prints ONE JSON line.
+
+  metric  : BASELINE.json -- "GEMM TFLOP/s (8192^3 bf16) + reduce GB/s vs roofline"
+  step    : one 8192 x 8192 x 8192 bf16 GEMM (f32 accumulate, bf16 C) per rank on synthetic
+            operands already resident in HBM (config C3).  N ranks = a batch of N such GEMMs,
+            batch-sharded one per GPU with no data-path collective => "scaling": "weak".
+  value   : whole-job TFLOP/s = N * 2*8192^3 * K / (max over ranks of the timed region).
+  roofline: the GEMM kernel against the dense bf16 MFMA peak (2.5 PFLOP/s), from HIP events
+            recorded on the stream the kernel is launched on.
+  cpu_baseline : the CPU restatement (oracle/, cubecl-cpu execution model) timed on this box's
+            cores on a bounded sample of the same workload.  Reported, never the thing measured.
+  extra   : the other BASELINE.json configs (f32 4096^3, 1 GiB sum/argmax (+ RCCL all-reduce when
+            N > 1), batched 2048^3 shard, skinny GEMMs) and the measured HBM / MFMA ceilings.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+SEED = 0x5EEDC0BE
+PEAK_BF16_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0       # HBM3E spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=8192, help="M=N=K of the headline GEMM (8192 = config C3)")
+    ap.add_argument("--no-extras", action="store_true", help="headline + roofline + cpu_baseline only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--algo", type=int, default=0, help="MI355_GEMM_ALGO_* override for the headline GEMM")
+    return ap.parse_args()
+
+
+class Events:
+    """Two HIP events on the library's compute stream (the stream the kernels are launched on)."""
+
+    def __init__(self, client):
+        self.c = client
+        self.a, self.b = C.c_void_p(), C.c_void_p()
+        client._s.check(client.lib.mi355_event_create(client.ctx, C.byref(self.a)))
+        client._s.check(client.lib.mi355_event_create(client.ctx, C.byref(self.b)))
+
+    def start(self):
+        self.c._s.check(self.c.lib.mi355_event_record(self.c.ctx, self.a, None))
+
+    def stop_ms(self) -> float:
+        c = self.c
+        c._s.check(c.lib.mi355_event_record(c.ctx, self.b, None))
+        c._s.check(c.lib.mi355_event_sync(c.ctx, self.b))
+        ms = C.c_float()
+        c._s.check(c.lib.mi355_event_elapsed_ms(c.ctx, self.a, self.b, C.byref(ms)))
+        return float(ms.value)
+
+
+def time_op(client, ev, fn, iters, warmup=3):
+    """Median-free simple protocol for the extras: `warmup` untimed + `iters` timed launches
+    between two events; returns average ms per launch."""
+    for _ in range(warmup):
+        fn()
+    client.sync()
+    ev.start()
+    for _ in range(iters):
+        fn()
+    return ev.stop_ms() / iters
+
+
+def samples_op(client, ev, fn, samples=15, warmup=5):
+    """The reference's Benchmark protocol (crates/cubecl-common/src/benchmark.rs:183,268): 5 warm-ups,
+    15 samples, sync on both sides of each sample; returns (median_ms, min_ms)."""
+    for _ in range(warmup):
+        fn()
+    client.sync()
+    out = []
+    for _ in range(samples):
+        ev.start()
+        fn()
+        out.append(ev.stop_ms())
+    out.sort()
+    return out[len(out) // 2], out[0]
+
+
+def gemm_desc(N, m, n, k, dtype_ab, dtype_c, trans_b=1, batch=1, algo=0):
+    return N.GemmDesc(m=m, n=n, k=k, batch=batch, lda=k, ldb=(k if trans_b else n), ldc=n, stride_a=m * k,
+                      stride_b=n * k, stride_c=m * n, dtype_ab=dtype_ab, dtype_c=dtype_c, trans_a=0, trans_b=trans_b,
+                      algo=algo)
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1) and world > 1:
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (MI355X); none visible")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from cubecl_amd import DeviceId, ElemType, Mi355Runtime, TensorHandle, ops
+    from cubecl_amd import _native as N
+
+    client = Mi355Runtime.client(DeviceId(0, local_rank))
+    lib, ctx = client.lib, client.ctx
+    props = client.properties()
+    ev = Events(client)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    # ------------------------------------------------------------------ headline: C3 ------------------
+    S = args.size
+    a = TensorHandle.uniform(client, (S, S), ElemType.BF16, SEED, 100 + rank, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (S, S), ElemType.BF16, SEED, 200 + rank, -1.0, 1.0)   # stored [N][K]
+    c = TensorHandle.new_contiguous((S, S), client.empty(S * S * 2), ElemType.BF16)
+    desc = gemm_desc(N, S, S, S, N.DTYPE_BF16, N.DTYPE_BF16, trans_b=1, algo=args.algo)
+    sel = C.c_int32(args.algo)
+    if args.algo == 0:
+        client._s.check(lib.mi355_gemm_select(ctx, C.byref(desc), C.byref(sel)))
+    pa, pb, pc = C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()), C.c_void_p(c.device_ptr())
+
+    def step():
+        client._s.check(lib.mi355_gemm(ctx, None, C.byref(desc), pa, pb, pc))
+
+    for _ in range(args.warmup):
+        step()
+    client.sync()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev.start()
+    for _ in range(args.steps):
+        step()
+    kernel_ms = ev.stop_ms()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+    flop = 2.0 * S * S * S
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = world * flop * args.steps / elapsed / 1e12
+    achieved = flop / (kernel_ms / args.steps * 1e-3) / 1e12
+
+    result = {
+        "metric": "GEMM TFLOP/s (8192^3 bf16) + reduce GB/s vs roofline",
+        "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{S}x{S}x{S} bf16 GEMM, f32 accumulate, bf16 C (BASELINE config C3), one per GPU",
+                   "layout": "A[M,K] row-major; B stored [N][K] (Out = Lhs*Rhs^T, the cmma tests' ColMajor-B form)",
+                   "operands": "uniform[-1,1) counter RNG seed 0x5EEDC0BE, generated in HBM",
+                   "kernel": {2: "f32_mfma", 3: "lp128", 4: "lp256", 1: "generic"}.get(sel.value, str(sel.value)),
+                   "parallelism": f"batch-sharded x{world}, no data-path collective"},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                     "kernel_ms": round(kernel_ms / args.steps, 4), "flop_per_launch": flop},
+        "device": props.name.decode() + " " + props.gcn_arch_name.decode(),
+    }
+
+    extra, errors = {}, {}
+
+    def guarded(name, fn):
+        try:
+            extra[name] = fn()
+        except Exception as exc:  # keep the headline line even if an extra fails
+            errors[name] = f"{type(exc).__name__}: {exc}"[:300]
+
+    # ------------------------------------------------------------------ CPU baseline ---------------------
+    if rank == 0 and not args.no_cpu_baseline:
+        def cpu_baseline():
+            import numpy as np
+            import oracle
+            cores = os.cpu_count() or 1
+            size = 1024
+            secs = None
+            while True:
+                x = oracle.fill_uniform(size * size, 100, -1.0, 1.0)
+                y = oracle.fill_uniform(size * size, 200, -1.0, 1.0)
+                s, _ = oracle.cpu_gemm(oracle.to_bf16(x), oracle.to_bf16(y), size, size, size, dtype_ab=oracle.DT_BF16,
+                                       dtype_c=oracle.DT_BF16, trans_b=True, units=cores)
+                secs = s
+                if s > 4.0 or size >= 4096:
+                    break
+                size *= 2
+            return {"value": round(2.0 * size ** 3 / secs / 1e12, 5), "unit": "TFLOP/s", "cores": cores, "kind": "port",
+                    "sample": f"{size}^3 bf16 GEMM (same RNG/layout), {secs:.2f} s, oracle_cpu_gemm: one worker per "
+                              "cube unit as cubecl-cpu schedules (threadpool/mod.rs:80-99)"}
+        try:
+            result["cpu_baseline"] = cpu_baseline()
+        except Exception as exc:
+            result["cpu_baseline"] = {"value": None, "unit": "TFLOP/s", "cores": os.cpu_count(), "kind": "port",
+                                      "sample": f"failed: {exc}"[:200]}
+
+    # ------------------------------------------------------------------ extras ---------------------------
+    if not args.no_extras:
+        del c
+        sink = client.empty(256)
+
+        def probes():
+            buf = client.empty(1 << 30)
+            client._s.check(lib.mi355_memset(ctx, None, buf.device_ptr(), 0, 1 << 30))
+            ms = time_op(client, ev, lambda: client._s.check(
+                lib.mi355_probe_memory_read(ctx, None, buf.device_ptr(), 1 << 30, 1, sink.device_ptr())), 20)
+            out = {"hbm_read_GBs": round((1 << 30) / ms / 1e6, 1)}
+            for name, dt, peak in (("mfma_bf16_TFLOPs", N.DTYPE_BF16, PEAK_BF16_TFLOPS), ("mfma_f32_TFLOPs", N.DTYPE_F32, PEAK_F32_TFLOPS)):
+                n_ops = C.c_uint64()
+                iters = 20000 if dt == N.DTYPE_BF16 else 4000
+                ms = time_op(client, ev, lambda: client._s.check(
+                    lib.mi355_probe_mfma(ctx, None, dt, iters, sink.device_ptr(), C.byref(n_ops))), 5)
+                out[name] = round(n_ops.value / ms / 1e9, 1)
+            return out
+        guarded("measured_ceilings", probes)
+
+        def reduce_c4():
+            n_total = 1 << 28                      # 1 GiB of f32 (config C4)
+            n_local = n_total // world
+            x = TensorHandle.uniform(client, (n_local,), ElemType.F32, SEED, 300 + rank, 0.0, 1.0)
+            ws = client.empty(1 << 17)
+            outs = client.empty(64)
+            p_in, p_ws = C.c_void_p(x.device_ptr()), C.c_void_p(ws.device_ptr())
+            p_sum, p_val, p_idx = (C.c_void_p(outs.device_ptr() + o) for o in (0, 8, 16))
+            res = {"elements_per_gpu": n_local, "bytes_per_gpu": n_local * 4}
+            for name, fn in (
+                ("sum", lambda: lib.mi355_reduce_sum_f32(ctx, None, p_in, n_local, p_sum, p_ws, ws.size)),
+                ("argmax", lambda: lib.mi355_argmax_f32(ctx, None, p_in, n_local, p_val, p_idx, p_ws, ws.size)),
+                ("sum_argmax_fused", lambda: lib.mi355_sum_argmax_f32(ctx, None, p_in, n_local, p_sum, p_val, p_idx, p_ws, ws.size)),
+            ):
+                med, best = samples_op(client, ev, lambda: client._s.check(fn()))
+                gbs = n_local * 4 / med / 1e6
+                res[name] = {"median_ms": round(med, 4), "min_ms": round(best, 4), "GBs_per_gpu": round(gbs, 1),
+                             "GBs_total": round(gbs * world, 1), "frac_of_8TBs": round(gbs / PEAK_HBM_GBS, 4)}
+            if world > 1:
+                # C4 end to end: local fused pass + RCCL all-reduce of the partial sums (ServerCommunication)
+                ids = [DeviceId(0, i) for i in range(world)]
+                box = [client.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                client.comm_init(ids, box[0], rank=rank)
+                from cubecl_amd import Handle, ReduceOperation
+                from cubecl_amd.runtime import _Memory
+                part = outs.offset_end_by(outs.size - 4)
+
+                def e2e():
+                    client._s.check(lib.mi355_sum_argmax_f32(ctx, None, p_in, n_local, p_sum, p_val, p_idx, p_ws, ws.size))
+                    client.all_reduce(part, part, ElemType.F32, ids, ReduceOperation.Sum)
+                    client.sync_collective()
+                for _ in range(3):
+                    e2e()
+                client.sync(); barrier(); torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(20):
+                    e2e()
+                client.sync(); torch.cuda.synchronize(); barrier()
+                dt = (time.perf_counter() - t1) / 20
+                tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                res["sharded_sum_argmax_allreduce"] = {"ms": round(float(tt[0]) * 1e3, 4),
+                                                       "GBs_total": round(n_total * 4 / float(tt[0]) / 1e9, 1)}
+            return res
+        guarded("reduce_1GiB_f32", reduce_c4)
+
+        def gemm_f32_c2():
+            M = 4096
+            fa = TensorHandle.uniform(client, (M, M), ElemType.F32, SEED, 400, -1.0, 1.0)
+            fb = TensorHandle.uniform(client, (M, M), ElemType.F32, SEED, 401, -1.0, 1.0)
+            fc = client.empty(M * M * 4)
+            out = {}
+            for name, tb in (("NT", 1), ("NN", 0)):
+                d = gemm_desc(N, M, M, M, N.DTYPE_F32, N.DTYPE_F32, trans_b=tb)
+                med, best = samples_op(client, ev, lambda: client._s.check(
+                    lib.mi355_gemm(ctx, None, C.byref(d), fa.device_ptr(), fb.device_ptr(), fc.device_ptr())))
+                tf = 2.0 * M ** 3 / med / 1e9
+                out[name] = {"median_ms": round(med, 4), "TFLOPs": round(tf, 1), "frac_of_157TF": round(tf / PEAK_F32_TFLOPS, 4)}
+            return out
+        guarded("gemm_f32_4096", gemm_f32_c2)
+
+        def batched_c5():
+            per_gpu = 64                      # 512 matrices / 8 GPUs
+            M = 2048
+            ba = TensorHandle.uniform(client, (per_gpu, M, M), ElemType.BF16, SEED, 500 + rank, -1.0, 1.0)
+            bb = TensorHandle.uniform(client, (per_gpu, M, M), ElemType.BF16, SEED, 600 + rank, -1.0, 1.0)
+            bc = client.empty(per_gpu * M * M * 2)
+            d = gemm_desc(N, M, M, M, N.DTYPE_BF16, N.DTYPE_BF16, trans_b=1, batch=per_gpu)
+            med, best = samples_op(client, ev, lambda: client._s.check(
+                lib.mi355_gemm(ctx, None, C.byref(d), ba.device_ptr(), bb.device_ptr(), bc.device_ptr())), samples=7, warmup=2)
+            tf = 2.0 * M ** 3 * per_gpu / med / 1e9
+            return {"batch_per_gpu": per_gpu, "median_ms": round(med, 3), "TFLOPs_per_gpu": round(tf, 1),
+                    "TFLOPs_total": round(tf * world, 1), "frac_of_2.5PF": round(tf / PEAK_BF16_TFLOPS, 4)}
+        guarded("batched_gemm_2048_bf16", batched_c5)
+
+        def skinny():
+            out = {}
+            for (m, n, k) in ((8192, 8192, 64), (64, 8192, 8192), (8192, 64, 8192), (1, 8192, 8192), (4096, 4096, 4096)):
+                sa = TensorHandle.uniform(client, (m, k), ElemType.BF16, SEED, 700, -1.0, 1.0)
+                sb = TensorHandle.uniform(client, (n, k), ElemType.BF16, SEED, 701, -1.0, 1.0)
+                sc = client.empty(m * n * 2)
+                d = gemm_desc(N, m, n, k, N.DTYPE_BF16, N.DTYPE_BF16, trans_b=1)
+                alg = C.c_int32()
+                lib.mi355_gemm_select(ctx, C.byref(d), C.byref(alg))
+                med, _ = samples_op(client, ev, lambda: client._s.check(
+                    lib.mi355_gemm(ctx, None, C.byref(d), sa.device_ptr(), sb.device_ptr(), sc.device_ptr())), samples=7, warmup=2)
+                out[f"{m}x{n}x{k}"] = {"median_ms": round(med, 4), "TFLOPs": round(2.0 * m * n * k / med / 1e9, 1), "algo": alg.value}
+            return out
+        guarded("gemm_bf16_shapes", skinny)
+
+    if extra:
+        result["extra"] = extra
+    if errors:
+        result["extra_errors"] = errors
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

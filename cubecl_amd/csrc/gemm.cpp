@@ -1,0 +1,75 @@
+// gemm.cpp -- mi355_gemm: descriptor validation and kernel selection.
+#include "gemm_common.hpp"
+
+using namespace mi355;
+
+namespace {
+
+int32_t validate(mi355_ctx *ctx, const mi355_gemm_desc *d, const void *a, const void *b, const void *c)
+{
+    if (!d) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_gemm: descriptor is NULL");
+    if (d->m < 0 || d->n < 0 || d->k < 0 || d->batch < 0)
+        return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_gemm: negative dimension");
+    if (d->dtype_ab != MI355_DTYPE_F32 && d->dtype_ab != MI355_DTYPE_BF16 && d->dtype_ab != MI355_DTYPE_F16)
+        return fail(ctx, MI355_E_UNSUPPORTED, "mi355_gemm: unsupported input dtype %d", d->dtype_ab);
+    if (d->dtype_c != MI355_DTYPE_F32 && d->dtype_c != d->dtype_ab)
+        return fail(ctx, MI355_E_UNSUPPORTED, "mi355_gemm: output dtype %d must be f32 or the input dtype", d->dtype_c);
+    if (d->m == 0 || d->n == 0 || d->batch == 0) return MI355_OK;
+    if (!c || (d->k > 0 && (!a || !b))) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_gemm: NULL operand");
+    const int64_t a_min = d->trans_a ? d->m : d->k, b_min = d->trans_b ? d->k : d->n;
+    if (d->lda < a_min || d->ldb < b_min || d->ldc < d->n)
+        return fail(ctx, MI355_E_UNSUPPORTED_STRIDES, "mi355_gemm: leading dimension smaller than the row (lda %lld ldb %lld ldc %lld)",
+                    (long long)d->lda, (long long)d->ldb, (long long)d->ldc);
+    if (d->stride_a < 0 || d->stride_b < 0 || d->stride_c < 0)
+        return fail(ctx, MI355_E_UNSUPPORTED_STRIDES, "mi355_gemm: negative batch stride");
+    if (d->batch > 1 && d->stride_c < d->m * d->ldc - (d->ldc - d->n))
+        return fail(ctx, MI355_E_UNSUPPORTED_STRIDES, "mi355_gemm: output batches overlap");
+    return -1;  // proceed
+}
+
+int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
+{
+    if (d.k == 0) return MI355_GEMM_ALGO_GENERIC;  // writes zeros
+    if (d.dtype_ab == MI355_DTYPE_F32) {
+        if (gemm_f32_mfma_supports(d, a, b, c)) return MI355_GEMM_ALGO_F32_MFMA;
+        return MI355_GEMM_ALGO_GENERIC;
+    }
+    const bool big = gemm_lp256_supports(d, a, b, c);
+    const bool mid = gemm_lp128_supports(d, a, b, c);
+    if (big) {
+        // 256x256 tiles only when they still give every CU work
+        const int64_t tiles256 = ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch;
+        if (tiles256 >= 192 || !mid) return MI355_GEMM_ALGO_LP_256;
+    }
+    if (mid) return MI355_GEMM_ALGO_LP_128;
+    return MI355_GEMM_ALGO_GENERIC;
+}
+
+}  // namespace
+
+MI355_API int32_t mi355_gemm_select(mi355_ctx *ctx, const mi355_gemm_desc *desc, int32_t *out_algo)
+{
+    if (!ctx || !desc || !out_algo) return MI355_E_INVALID_ARGUMENT;
+    // alignment-dependent choices are evaluated for 16-byte aligned operands
+    static const char aligned_dummy __attribute__((aligned(16))) = 0;
+    *out_algo = select(*desc, &aligned_dummy, &aligned_dummy, &aligned_dummy);
+    return MI355_OK;
+}
+
+MI355_API int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_gemm_desc *desc, const void *a,
+                             const void *b, void *c)
+{
+    MI355_REQUIRE_CTX(ctx);
+    int32_t rc = validate(ctx, desc, a, b, c);
+    if (rc != -1) return rc;
+    hipStream_t s = stream_of(ctx, stream);
+    const mi355_gemm_desc &d = *desc;
+    int32_t algo = d.algo == MI355_GEMM_ALGO_AUTO ? select(d, a, b, c) : d.algo;
+    switch (algo) {
+    case MI355_GEMM_ALGO_GENERIC: return launch_gemm_generic(ctx, s, d, a, b, c);
+    case MI355_GEMM_ALGO_F32_MFMA: return launch_gemm_f32_mfma(ctx, s, d, a, b, c);
+    case MI355_GEMM_ALGO_LP_128: return launch_gemm_lp128(ctx, s, d, a, b, c);
+    case MI355_GEMM_ALGO_LP_256: return launch_gemm_lp256(ctx, s, d, a, b, c);
+    default: return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_gemm: unknown algo %d", algo);
+    }
+}

@@ -1,0 +1,84 @@
+// gemm_common.hpp -- pieces shared by the GEMM kernels (device helpers + launch plumbing).
+#pragma once
+
+#include "internal.hpp"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+namespace mi355 {
+
+struct gemm_args {
+    const void *a;
+    const void *b;
+    void *c;
+    int64_t m, n, k;
+    int64_t lda, ldb, ldc;
+    int64_t stride_a, stride_b, stride_c;
+    uint32_t tiles_m, tiles_n;
+    uint32_t group_m;
+};
+
+// MI355X dispatches workgroup b to XCD b % 8, each XCD with a private 4 MiB L2
+// (MI355X_MICROARCH.md "Workgroup dispatch").  Remap the linear id so that every XCD walks one
+// CONTIGUOUS chunk of the tile sequence (neighbouring tiles share A/B panels through that L2).
+// Bijective for any nwg (guide section 5, "XCD swizzle must be bijective"); speed only.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg)
+{
+    constexpr uint32_t NX = 8;
+    const uint32_t q = nwg / NX, r = nwg % NX;
+    const uint32_t xcd = bid % NX, local = bid / NX;
+    const uint32_t base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + local;
+}
+
+// Grouped rasterisation: `group_m` tile-rows are swept column by column before moving down, so
+// concurrently resident workgroups cover a compact block of the output.
+__device__ __forceinline__ void tile_coords(uint32_t lin, uint32_t tiles_m, uint32_t tiles_n, uint32_t group_m,
+                                            uint32_t &tm, uint32_t &tn)
+{
+    const uint32_t per_group = group_m * tiles_n;
+    const uint32_t group = lin / per_group;
+    const uint32_t first_m = group * group_m;
+    const uint32_t gsize = min(tiles_m - first_m, group_m);
+    const uint32_t in_group = lin % per_group;
+    tm = first_m + in_group % gsize;
+    tn = in_group / gsize;
+}
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x0040u);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint16_t f32_to_f16_rne(float f)
+{
+    const _Float16 h = (_Float16)f;  // v_cvt_f16_f32, round-to-nearest-even
+    uint16_t bits;
+    __builtin_memcpy(&bits, &h, 2);
+    return bits;
+}
+
+template <int DT>
+__device__ __forceinline__ uint16_t f32_to_lp(float f)
+{
+    return DT == MI355_DTYPE_BF16 ? f32_to_bf16_rne(f) : f32_to_f16_rne(f);
+}
+
+// host-side kernel launchers (one per translation unit)
+int32_t launch_gemm_generic(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
+int32_t launch_gemm_f32_mfma(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
+int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
+int32_t launch_gemm_lp256(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
+bool gemm_f32_mfma_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
+bool gemm_lp128_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
+bool gemm_lp256_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
+
+}  // namespace mi355

@@ -1,0 +1,239 @@
+// gemm_lp128.hip -- bf16 / f16 GEMM, 128x128x64 workgroup tile, v_mfma_f32_32x32x16_{bf16,f16}.
+//
+// Roofline: MFMA bf16/f16, ~2.5 PFLOP/s dense.  This is the medium-tile kernel: 4 waves (2x2),
+// each a 64x64 output (2x2 MFMA tiles of 32x32, 64 accumulator registers), 2 workgroups per CU.
+// It serves shapes too small to fill the chip with 256x256 tiles and is the validated base of
+// the staging scheme the 256x256 kernel (gemm_lp256.hip) reuses:
+//
+//  * HBM -> LDS by LDS-DMA (`global_load_lds_dwordx4`, 16 B per lane, no VGPR round trip;
+//    cdna_hip_programming.md section 5).  One wave instruction fills 1 KiB = 8 tile rows of
+//    64 x 16-bit.  The LDS image is lane-linear, so the bank swizzle is applied to the per-lane
+//    SOURCE address and, identically, to the fragment read (guide rule 21):
+//        physical 16-byte chunk = logical chunk ^ ((row >> 1) & 7)      (within a 128-byte row)
+//    With MFMA 32x32x16 fragment reads (lane -> row, lane-half -> chunk) every 16-lane group of a
+//    ds_read_b128 then touches all 16 distinct 16-byte slots of the 256-byte bank row: conflict
+//    free.  The source permutation stays inside one 128-byte line, so coalescing is unchanged.
+//  * double-buffered LDS, the next tile's DMA issued before the current tile's MFMAs, one
+//    vmcnt(0)+barrier per K-tile (guide T3+T4 "minimum 2-phase" recipe).
+//  * both operands K-contiguous: A row-major [M][K], B as [N][K] (trans_b = 1, the cmma tests'
+//    ColMajor-B form, runtime_tests/cmma.rs:23).
+//  * MFMA operands swapped (first = B fragment, second = A fragment): each lane then owns 4
+//    consecutive N-columns of one C row per register quad -> 16-byte (f32) / 8-byte (16-bit) stores.
+#include "gemm_common.hpp"
+
+using namespace mi355;
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int ROW_BYTES = BK * 2;              // 128
+constexpr int TILE_BYTES = BM * ROW_BYTES;     // 16 KiB per operand per stage
+
+template <int DT> struct lp;
+template <> struct lp<MI355_DTYPE_BF16> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c)
+    { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct lp<MI355_DTYPE_F16> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c)
+    { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+__device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
+}
+
+template <int DT, int DT_C>
+__global__ void __launch_bounds__(256, 2)
+gemm_lp128_kernel(gemm_args g)
+{
+    // [stage][operand][16 KiB]; one array only (a second __shared__ object de-pipelines LDS-DMA
+    // loops: guide section 5, ".s-level traps" (a))
+    __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * TILE_BYTES];
+    typedef typename lp<DT>::frag frag;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    uint32_t tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n), g.tiles_m, g.tiles_n, g.group_m, tm, tn);
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    const int64_t batch = blockIdx.y;
+    const char *__restrict__ A = static_cast<const char *>(g.a) + batch * g.stride_a * 2;
+    const char *__restrict__ B = static_cast<const char *>(g.b) + batch * g.stride_b * 2;
+
+    // ---- DMA map: wave w, instruction j fills rows (j*4+w)*8 .. +7 of the tile ----------------
+    const char *ga[4];
+    const char *gb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (j * 4 + wave) * 8 + (lane >> 3);    // tile row this lane fills
+        const int q = (lane & 7) ^ ((r >> 1) & 7);          // logical chunk fetched into physical chunk lane&7
+        const int64_t m = min(m0 + r, g.m - 1);
+        const int64_t n = min(n0 + r, g.n - 1);
+        ga[j] = A + (m * g.lda + q * 8) * 2;
+        gb[j] = B + (n * g.ldb + q * 8) * 2;
+    }
+
+    // ---- fragment read offsets (bytes inside one operand tile) --------------------------------
+    int ra[2], rb[2], fa[2], fb[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int rowa = wm * 64 + t * 32 + l31;
+        const int rowb = wn * 64 + t * 32 + l31;
+        ra[t] = rowa * ROW_BYTES; fa[t] = (rowa >> 1) & 7;
+        rb[t] = rowb * ROW_BYTES; fb[t] = (rowb >> 1) & 7;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (int)(g.k / BK);
+
+    auto stage = [&](int buf, int kt) {
+        char *la = smem + buf * 2 * TILE_BYTES;
+        char *lb = la + TILE_BYTES;
+        const int64_t koff = (int64_t)kt * BK * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds16(ga[j] + koff, la + (j * 4 + wave) * 1024);
+            glds16(gb[j] + koff, lb + (j * 4 + wave) * 1024);
+        }
+    };
+
+    stage(0, 0);
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) lgkmcnt(0) expcnt(0)
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char *la = smem + cur * 2 * TILE_BYTES;
+        const char *lb = la + TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            frag af[2], bf[2];
+            const int q = kk * 2 + h;  // logical 16-byte chunk: 8 k-values
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const frag *>(la + ra[i] + ((q ^ fa[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const frag *>(lb + rb[j] + ((q ^ fb[j]) << 4));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i][j] = lp<DT>::mfma(bf[j], af[i], acc[i][j]);
+        }
+        // the DMA for tile kt+1 must have landed and every wave must be done reading `cur`
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------
+    char *__restrict__ C = static_cast<char *>(g.c);
+    constexpr int CSZ = (DT_C == MI355_DTYPE_F32) ? 4 : 2;
+    const int64_t cbase = batch * g.stride_c;
+    const bool vec_ok = (((g.ldc * CSZ) & (4 * CSZ - 1)) == 0) &&
+                        (((reinterpret_cast<uintptr_t>(C) + (uint64_t)cbase * CSZ) & (4 * CSZ - 1)) == 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t m = m0 + wm * 64 + i * 32 + l31;
+        if (m >= g.m) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t n = n0 + wn * 64 + j * 32 + 8 * q + 4 * h;
+                const int64_t idx = cbase + m * g.ldc + n;
+                if (DT_C == MI355_DTYPE_F32) {
+                    float *dst = reinterpret_cast<float *>(C) + idx;
+                    if (vec_ok && n + 3 < g.n) {
+                        f32x4 v = {acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        *reinterpret_cast<f32x4 *>(dst) = v;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n + r < g.n) dst[r] = acc[i][j][4 * q + r];
+                    }
+                } else {
+                    uint16_t *dst = reinterpret_cast<uint16_t *>(C) + idx;
+                    uint16_t o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = f32_to_lp<DT_C>(acc[i][j][4 * q + r]);
+                    if (vec_ok && n + 3 < g.n) {
+                        u32x2 v = {(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16)};
+                        *reinterpret_cast<u32x2 *>(dst) = v;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n + r < g.n) dst[r] = o[r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int DT, int DT_C>
+void launch(hipStream_t s, const gemm_args &g, uint32_t batch)
+{
+    hipLaunchKernelGGL((gemm_lp128_kernel<DT, DT_C>), dim3(g.tiles_m * g.tiles_n, batch), dim3(256), 0, s, g);
+}
+
+}  // namespace
+
+namespace mi355 {
+
+bool gemm_lp128_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
+{
+    (void)c;
+    if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16) return false;
+    if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != d.dtype_ab) return false;
+    if (d.trans_a || !d.trans_b) return false;
+    if (d.k < BK || d.k % BK != 0) return false;
+    if (d.m < 1 || d.n < 1) return false;
+    if ((d.lda & 7) || (d.ldb & 7) || (d.stride_a & 7) || (d.stride_b & 7)) return false;
+    if ((reinterpret_cast<uintptr_t>(a) & 15u) || (reinterpret_cast<uintptr_t>(b) & 15u)) return false;
+    if (d.batch > 65535) return false;
+    const int64_t tiles = ((d.m + BM - 1) / BM) * ((d.n + BN - 1) / BN);
+    if (tiles > 0x7FFFFFFF) return false;
+    return true;
+}
+
+int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b,
+                          void *c)
+{
+    if (!gemm_lp128_supports(d, a, b, c))
+        return fail(ctx, MI355_E_UNSUPPORTED, "lp128 GEMM: shape/layout not supported by this kernel");
+    gemm_args g{};
+    g.a = a; g.b = b; g.c = c;
+    g.m = d.m; g.n = d.n; g.k = d.k;
+    g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc;
+    g.stride_a = d.stride_a; g.stride_b = d.stride_b; g.stride_c = d.stride_c;
+    g.tiles_m = (uint32_t)((d.m + BM - 1) / BM);
+    g.tiles_n = (uint32_t)((d.n + BN - 1) / BN);
+    g.group_m = 8;
+    const uint32_t batch = (uint32_t)d.batch;
+    if (d.dtype_ab == MI355_DTYPE_BF16) {
+        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(s, g, batch);
+        else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16>(s, g, batch);
+    } else {
+        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(s, g, batch);
+        else launch<MI355_DTYPE_F16, MI355_DTYPE_F16>(s, g, batch);
+    }
+    check_launch(ctx, "mi355_gemm(lp128)");
+    return MI355_OK;
+}
+
+}  // namespace mi355

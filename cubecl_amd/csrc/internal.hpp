@@ -1,0 +1,93 @@
+// internal.hpp -- shared state of libmi355cube.so (not part of the ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "../../include/mi355cube.h"
+
+#define MI355_API extern "C" __attribute__((visibility("default")))
+
+struct mi355_queued_error {
+    int32_t code;
+    uint64_t requested;
+    uint64_t max;
+    std::string message;
+};
+
+struct mi355_profile_slot {
+    hipEvent_t start;
+    hipEvent_t stop;
+    bool live;
+};
+
+// One per DeviceId; the reference's HipServer + HipContext
+// (crates/cubecl-hip/src/compute/server.rs:151-161).
+struct mi355_ctx {
+    int device = 0;
+    hipStream_t compute_stream = nullptr;  // hipStreamNonBlocking (stream.rs:91-99)
+    hipStream_t comm_stream = nullptr;     // dedicated collective stream (cuda server.rs:749)
+    mi355_device_props_t props{};
+    std::string last_error;
+    std::deque<mi355_queued_error> errors;  // per-stream error queue collapsed to per-server
+    std::vector<void *> pending_free;       // PendingDropQueue (stream.rs:134-150)
+    std::vector<mi355_profile_slot> profiles;
+    hipEvent_t fence_a = nullptr;  // reusable fences for the comm <-> compute hand-offs
+    hipEvent_t fence_b = nullptr;
+    bool comm_dirty = false;
+    uint64_t func_attr_mask = 0;  // kernels whose dynamic-LDS attribute is already raised on this device
+};
+
+namespace mi355 {
+
+int32_t fail(mi355_ctx *ctx, int32_t code, const char *fmt, ...) __attribute__((format(printf, 3, 4)));
+void queue_error(mi355_ctx *ctx, int32_t code, uint64_t requested, uint64_t max, const char *fmt, ...)
+    __attribute__((format(printf, 5, 6)));
+int32_t map_hip_error(hipError_t e);
+// Checks the sticky/last launch error after a kernel launch and queues it (fire-and-forget
+// contract: crates/cubecl-hip/src/compute/server.rs:263-269).
+void check_launch(mi355_ctx *ctx, const char *what);
+bool rccl_available();  // comm.cpp
+inline hipStream_t stream_of(mi355_ctx *ctx, mi355_stream s)
+{
+    return s ? reinterpret_cast<hipStream_t>(s) : ctx->compute_stream;
+}
+inline size_t dtype_size(int32_t dtype)
+{
+    switch (dtype) {
+    case MI355_DTYPE_F32: case MI355_DTYPE_I32: case MI355_DTYPE_U32: return 4;
+    case MI355_DTYPE_BF16: case MI355_DTYPE_F16: return 2;
+    case MI355_DTYPE_F64: case MI355_DTYPE_I64: case MI355_DTYPE_U64: return 8;
+    case MI355_DTYPE_U8: case MI355_DTYPE_I8: return 1;
+    default: return 0;
+    }
+}
+
+}  // namespace mi355
+
+#define MI355_REQUIRE_CTX(ctx)                                          \
+    do {                                                                \
+        if (!(ctx)) return MI355_E_INVALID_ARGUMENT;                    \
+        hipError_t _e = hipSetDevice((ctx)->device);                    \
+        if (_e != hipSuccess)                                           \
+            return mi355::fail((ctx), MI355_E_NO_DEVICE, "hipSetDevice(%d): %s", (ctx)->device, \
+                               hipGetErrorString(_e));                  \
+    } while (0)
+
+#define MI355_HIP(ctx, expr)                                                               \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return mi355::fail((ctx), mi355::map_hip_error(_e), "%s: %s", #expr,           \
+                               hipGetErrorString(_e));                                     \
+    } while (0)

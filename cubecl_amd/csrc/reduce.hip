@@ -1,0 +1,447 @@
+// reduce.hip -- array-wide and last-axis reductions for gfx950 (HBM-bound streaming kernels).
+//
+// Roofline: HBM read bandwidth (8.0 TB/s spec).  Algorithmic traffic = 4 bytes per element read
+// once (+16 B per workgroup of partials, ignored).  Design rules followed
+// (/opt/skills/guides/cdna_hip_programming.md G2/G7/G11/G13, Appendix B "Reduction"):
+//   - 16 B per lane coalesced loads (global_load_dwordx4, non-temporal: the data is read once),
+//     RED_UNROLL independent loads in flight per lane, one independent accumulator per load slot;
+//   - grid = a few workgroups per CU, grid-stride over 32 KiB tiles (no XCD remap: there is no
+//     inter-workgroup reuse, guide T1 "Transfer: 0% on LayerNorm");
+//   - wave64 xor butterfly in the reference's plane_reduce order
+//     (crates/cubecl-cpp/src/shared/plane.rs:60-70), then LDS across the 4 waves, one partial
+//     record per workgroup, and a second tiny launch that folds the records in index order:
+//     the summation tree is a pure function of (n, grid) => bit-reproducible run to run, and no
+//     float atomics.
+#include "internal.hpp"
+
+#include <algorithm>
+
+using namespace mi355;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int RED_BLOCK = 256;                              // 4 waves
+constexpr int RED_UNROLL = 8;                               // 16-B loads in flight per lane
+constexpr int RED_TILE = RED_BLOCK * RED_UNROLL * 4;        // 8192 floats = 32 KiB per tile
+constexpr int RED_MAX_GRID = 4096;
+
+struct __attribute__((aligned(16))) red_record {
+    float sum;
+    uint32_t key;
+    uint64_t idx;
+};
+
+// Order-preserving key for the argmax rule (oracle/oracle.c argmax_key): IEEE order, -0 == +0,
+// NaN above everything.
+__device__ __forceinline__ uint32_t argmax_key(float v)
+{
+    uint32_t u = __float_as_uint(v);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return 0xFFFFFFFFu;
+    if (u == 0x80000000u) u = 0u;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// (key, idx) combine: larger key wins, equal keys keep the LOWER index.
+__device__ __forceinline__ void arg_combine(uint32_t &key, uint64_t &idx, uint32_t okey, uint64_t oidx)
+{
+    const bool take = (okey > key) || (okey == key && oidx < idx);
+    key = take ? okey : key;
+    idx = take ? oidx : idx;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ void wave_argmax(uint32_t &key, uint64_t &idx)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t okey = __shfl_xor(key, off, 64);
+        const uint32_t olo = __shfl_xor((uint32_t)idx, off, 64);
+        const uint32_t ohi = __shfl_xor((uint32_t)(idx >> 32), off, 64);
+        arg_combine(key, idx, okey, ((uint64_t)ohi << 32) | olo);
+    }
+}
+
+// Stage 1: every workgroup folds its tiles into one record.
+//   in      : 16-byte aligned body of the array (host peels a misaligned head into `head`)
+//   head    : up to 3 leading elements (global indices 0..head_n-1), body index i maps to
+//             global index i + head_n
+template <bool SUM, bool ARG>
+__global__ void __launch_bounds__(RED_BLOCK)
+reduce_stage1(const float *__restrict__ head, uint32_t head_n, const float *__restrict__ in, uint64_t n,
+              red_record *__restrict__ records)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint64_t full_tiles = n / RED_TILE;
+    const uint32_t G = gridDim.x;
+
+    f32x4 acc[RED_UNROLL];
+#pragma unroll
+    for (int u = 0; u < RED_UNROLL; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float tail_acc = 0.f;
+    uint32_t best_key = 0u;          // 0 = "nothing yet": every real key is >= 0x007FFFFF (-inf)
+    uint64_t best_idx = ~0ull;
+
+    // peeled head: lowest global indices, block 0 only
+    if (blockIdx.x == 0 && tid < head_n) {
+        const float v = head[tid];
+        if (SUM) tail_acc += v;
+        if (ARG) { best_key = argmax_key(v); best_idx = tid; }
+    }
+
+    const f32x4 *__restrict__ vin = reinterpret_cast<const f32x4 *>(in);
+    for (uint64_t tile = blockIdx.x; tile < full_tiles; tile += G) {
+        const uint64_t vbase = tile * (RED_TILE / 4) + tid;
+        f32x4 v[RED_UNROLL];
+#pragma unroll
+        for (int u = 0; u < RED_UNROLL; ++u) v[u] = __builtin_nontemporal_load(vin + vbase + (uint64_t)u * RED_BLOCK);
+#pragma unroll
+        for (int u = 0; u < RED_UNROLL; ++u) {
+            if (SUM) acc[u] += v[u];
+            if (ARG) {
+                const uint64_t e0 = (vbase + (uint64_t)u * RED_BLOCK) * 4 + head_n;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t k = argmax_key(v[u][c]);
+                    // strict > : within one lane indices only grow, so the first maximum is kept
+                    if (k > best_key) { best_key = k; best_idx = e0 + c; }
+                }
+            }
+        }
+    }
+
+    // ragged tail (< one tile): the workgroup next in rotation, guarded scalar loads
+    const uint64_t tail_base = full_tiles * RED_TILE;
+    if (tail_base < n && blockIdx.x == (uint32_t)(full_tiles % G)) {
+        for (uint64_t i = tail_base + tid; i < n; i += RED_BLOCK) {
+            const float v = in[i];
+            if (SUM) tail_acc += v;
+            if (ARG) {
+                const uint32_t k = argmax_key(v);
+                if (k > best_key) { best_key = k; best_idx = i + head_n; }
+            }
+        }
+    }
+
+    __shared__ float s_sum[RED_BLOCK / 64];
+    __shared__ uint32_t s_key[RED_BLOCK / 64];
+    __shared__ uint64_t s_idx[RED_BLOCK / 64];
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+
+    float total = 0.f;
+    if (SUM) {
+        // fixed tree: slots pairwise, then the 4 vector components, then tail, then lanes
+        f32x4 a = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        f32x4 b = (acc[4] + acc[5]) + (acc[6] + acc[7]);
+        f32x4 s = a + b;
+        float lane_sum = ((s[0] + s[1]) + (s[2] + s[3])) + tail_acc;
+        lane_sum = wave_sum(lane_sum);
+        if (lane == 0) s_sum[wave] = lane_sum;
+    }
+    if (ARG) {
+        wave_argmax(best_key, best_idx);
+        if (lane == 0) { s_key[wave] = best_key; s_idx[wave] = best_idx; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        red_record r;
+        r.sum = 0.f; r.key = 0u; r.idx = ~0ull;
+        if (SUM) { total = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]); r.sum = total; }
+        if (ARG) {
+            uint32_t k = s_key[0]; uint64_t ix = s_idx[0];
+#pragma unroll
+            for (int w = 1; w < RED_BLOCK / 64; ++w) arg_combine(k, ix, s_key[w], s_idx[w]);
+            r.key = k; r.idx = ix;
+        }
+        records[blockIdx.x] = r;
+    }
+}
+
+// Stage 2: one workgroup folds the G records in index order (G <= RED_MAX_GRID).
+template <bool SUM, bool ARG>
+__global__ void __launch_bounds__(RED_BLOCK)
+reduce_stage2(const red_record *__restrict__ records, uint32_t G, const float *__restrict__ base, uint32_t head_n,
+              const float *__restrict__ head, uint64_t n_total, float *__restrict__ out_sum,
+              float *__restrict__ out_val, uint64_t *__restrict__ out_idx)
+{
+    const uint32_t tid = threadIdx.x;
+    float acc = 0.f;
+    uint32_t key = 0u;
+    uint64_t idx = ~0ull;
+    // thread t owns records t, t+256, ...: a fixed assignment
+    for (uint32_t g = tid; g < G; g += RED_BLOCK) {
+        const red_record r = records[g];
+        if (SUM) acc += r.sum;
+        if (ARG) arg_combine(key, idx, r.key, r.idx);
+    }
+    __shared__ float s_sum[RED_BLOCK / 64];
+    __shared__ uint32_t s_key[RED_BLOCK / 64];
+    __shared__ uint64_t s_idx[RED_BLOCK / 64];
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    if (SUM) { acc = wave_sum(acc); if (lane == 0) s_sum[wave] = acc; }
+    if (ARG) { wave_argmax(key, idx); if (lane == 0) { s_key[wave] = key; s_idx[wave] = idx; } }
+    __syncthreads();
+    if (tid == 0) {
+        if (SUM && out_sum) *out_sum = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+        if (ARG) {
+            uint32_t k = s_key[0]; uint64_t ix = s_idx[0];
+#pragma unroll
+            for (int w = 1; w < RED_BLOCK / 64; ++w) arg_combine(k, ix, s_key[w], s_idx[w]);
+            if (n_total == 0) {
+                if (out_idx) *out_idx = 0;
+                if (out_val) *out_val = -__builtin_inff();
+            } else {
+                if (out_idx) *out_idx = ix;
+                // bit-exact copy of the winning element
+                if (out_val) *out_val = (ix < head_n) ? head[ix] : base[ix - head_n];
+            }
+        }
+    }
+}
+
+uint32_t pick_grid(const mi355_ctx *ctx, uint64_t n)
+{
+    const uint64_t tiles = (n + RED_TILE - 1) / RED_TILE;
+    const uint64_t cap = std::min<uint64_t>((uint64_t)ctx->props.num_streaming_multiprocessors * 8, RED_MAX_GRID);
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(tiles, cap));
+}
+
+template <bool SUM, bool ARG>
+int32_t run_reduce(mi355_ctx *ctx, mi355_stream stream, const float *in, uint64_t n, float *out_sum,
+                   float *out_val, uint64_t *out_idx, void *workspace, uint64_t workspace_bytes, const char *what)
+{
+    MI355_REQUIRE_CTX(ctx);
+    if (n && !in) return fail(ctx, MI355_E_INVALID_ARGUMENT, "%s: input is NULL", what);
+    if ((reinterpret_cast<uintptr_t>(in) & 3u) != 0)
+        return fail(ctx, MI355_E_INVALID_ARGUMENT, "%s: input must be 4-byte aligned", what);
+    uint64_t need = 0;
+    mi355_reduce_workspace_bytes(ctx, n, &need);
+    if (!workspace || workspace_bytes < need)
+        return fail(ctx, MI355_E_INVALID_ARGUMENT, "%s: workspace too small (%llu < %llu bytes)", what,
+                    (unsigned long long)workspace_bytes, (unsigned long long)need);
+    if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0)
+        return fail(ctx, MI355_E_INVALID_ARGUMENT, "%s: workspace must be 16-byte aligned", what);
+    hipStream_t s = stream_of(ctx, stream);
+    // peel a misaligned head so the body is 16-byte aligned
+    uint32_t head_n = (uint32_t)(((16u - (reinterpret_cast<uintptr_t>(in) & 15u)) & 15u) / 4u);
+    if (head_n > n) head_n = (uint32_t)n;
+    const float *body = in + head_n;
+    const uint64_t body_n = n - head_n;
+    const uint32_t G = pick_grid(ctx, body_n);
+    red_record *records = static_cast<red_record *>(workspace);
+    hipLaunchKernelGGL((reduce_stage1<SUM, ARG>), dim3(G), dim3(RED_BLOCK), 0, s, in, head_n, body, body_n, records);
+    check_launch(ctx, what);
+    hipLaunchKernelGGL((reduce_stage2<SUM, ARG>), dim3(1), dim3(RED_BLOCK), 0, s, records, G, body, head_n, in, n,
+                       out_sum, out_val, out_idx);
+    check_launch(ctx, what);
+    return MI355_OK;
+}
+
+// ---- last-axis reductions --------------------------------------------------------------------
+// One wave per row (THREADS=64) or one workgroup per row (THREADS=256/1024).  Rows are
+// independent; the row is streamed with 16-B loads when its base and stride allow it.
+template <int THREADS, bool ARG>
+__global__ void __launch_bounds__(THREADS)
+reduce_rows(const float *__restrict__ in, float *__restrict__ out_sum, uint32_t *__restrict__ out_idx, uint64_t rows,
+            uint64_t cols, uint64_t row_stride, int vec_ok)
+{
+    constexpr int WAVES = THREADS / 64;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    __shared__ float s_sum[WAVES];
+    __shared__ uint32_t s_key[WAVES];
+    __shared__ uint64_t s_idx[WAVES];
+    for (uint64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float *__restrict__ p = in + row * row_stride;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        uint32_t key = 0u; uint64_t idx = ~0ull;
+        uint64_t done = 0;
+        if (vec_ok) {
+            const f32x4 *__restrict__ vp = reinterpret_cast<const f32x4 *>(p);
+            const uint64_t nv = cols / 4;
+            for (uint64_t i = tid; i < nv; i += THREADS) {
+                const f32x4 v = vp[i];
+                if (!ARG) { a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3]; }
+                else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const uint32_t k = argmax_key(v[c]);
+                        if (k > key) { key = k; idx = i * 4 + c; }
+                    }
+                }
+            }
+            done = nv * 4;
+        }
+        for (uint64_t i = done + tid; i < cols; i += THREADS) {
+            const float v = p[i];
+            if (!ARG) a0 += v;
+            else { const uint32_t k = argmax_key(v); if (k > key) { key = k; idx = i; } }
+        }
+        if (!ARG) {
+            float s = wave_sum((a0 + a1) + (a2 + a3));
+            if (WAVES == 1) { if (lane == 0) out_sum[row] = s; }
+            else {
+                if (lane == 0) s_sum[wave] = s;
+                __syncthreads();
+                if (tid == 0) { float t = 0.f; for (int w = 0; w < WAVES; ++w) t += s_sum[w]; out_sum[row] = t; }
+                __syncthreads();
+            }
+        } else {
+            wave_argmax(key, idx);
+            if (WAVES == 1) { if (lane == 0) out_idx[row] = cols ? (uint32_t)idx : 0u; }
+            else {
+                if (lane == 0) { s_key[wave] = key; s_idx[wave] = idx; }
+                __syncthreads();
+                if (tid == 0) {
+                    uint32_t k = s_key[0]; uint64_t ix = s_idx[0];
+                    for (int w = 1; w < WAVES; ++w) arg_combine(k, ix, s_key[w], s_idx[w]);
+                    out_idx[row] = cols ? (uint32_t)ix : 0u;
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+template <bool ARG>
+int32_t run_rows(mi355_ctx *ctx, mi355_stream stream, const float *in, float *out_sum, uint32_t *out_idx,
+                 uint64_t rows, uint64_t cols, uint64_t row_stride, const char *what)
+{
+    MI355_REQUIRE_CTX(ctx);
+    if (rows == 0) return MI355_OK;
+    if ((cols && !in) || (!ARG && !out_sum) || (ARG && !out_idx))
+        return fail(ctx, MI355_E_INVALID_ARGUMENT, "%s: NULL pointer", what);
+    if (row_stride < cols && rows > 1)
+        return fail(ctx, MI355_E_UNSUPPORTED_STRIDES, "%s: row stride %llu < cols %llu", what,
+                    (unsigned long long)row_stride, (unsigned long long)cols);
+    if (ARG && cols > 0xFFFFFFFFull)
+        return fail(ctx, MI355_E_UNSUPPORTED, "%s: cols exceed u32 index range", what);
+    hipStream_t s = stream_of(ctx, stream);
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(in) & 15u) == 0 && (row_stride % 4) == 0) ? 1 : 0;
+    const uint64_t cus = ctx->props.num_streaming_multiprocessors;
+    if (cols <= 2048) {
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(rows, cus * 32);
+        hipLaunchKernelGGL((reduce_rows<64, ARG>), dim3(grid), dim3(64), 0, s, in, out_sum, out_idx, rows, cols,
+                           row_stride, vec_ok);
+    } else if (cols <= 65536) {
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(rows, cus * 8);
+        hipLaunchKernelGGL((reduce_rows<256, ARG>), dim3(grid), dim3(256), 0, s, in, out_sum, out_idx, rows, cols,
+                           row_stride, vec_ok);
+    } else {
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(rows, cus * 2);
+        hipLaunchKernelGGL((reduce_rows<1024, ARG>), dim3(grid), dim3(1024), 0, s, in, out_sum, out_idx, rows, cols,
+                           row_stride, vec_ok);
+    }
+    check_launch(ctx, what);
+    return MI355_OK;
+}
+
+// ---- plane ops: one 64-lane plane per 64 inputs ---------------------------------------------
+__global__ void __launch_bounds__(64)
+plane_reduce_kernel(const float *__restrict__ in, float *__restrict__ out, uint64_t n, uint32_t active, int op)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + lane;
+    float v = (i < n) ? in[i] : 0.f;
+    if (op == 101 || op == 102) {
+        // plane_reduce_inclusive / exclusive (shared/plane.rs:72-97): Hillis-Steele with shuffle_up
+        float acc = v;
+        for (uint32_t off = 1; off < active; off <<= 1) {
+            const float up = __shfl_up(acc, off, 64);
+            if ((lane & (active - 1)) >= off) acc += up;
+        }
+        if (op == 102) {
+            const float prev = __shfl_up(acc, 1, 64);
+            acc = ((lane & (active - 1)) == 0) ? 0.f : prev;
+        }
+        v = acc;
+    } else {
+        // plane_reduce (shared/plane.rs:60-70): xor butterfly, offsets 1,2,4,.. < active
+        for (uint32_t off = 1; off < active; off <<= 1) {
+            const float o = __shfl_xor(v, off, 64);
+            switch (op) {
+            case MI355_REDUCE_SUM: v = v + o; break;
+            case MI355_REDUCE_MAX: v = v > o ? v : o; break;
+            case MI355_REDUCE_MIN: v = v < o ? v : o; break;
+            default: v = v * o; break;  // 100: product
+            }
+        }
+    }
+    if (i < n) out[i] = v;
+}
+
+}  // namespace
+
+MI355_API int32_t mi355_reduce_workspace_bytes(mi355_ctx *ctx, uint64_t n, uint64_t *out_bytes)
+{
+    if (!ctx || !out_bytes) return MI355_E_INVALID_ARGUMENT;
+    (void)n;
+    *out_bytes = (uint64_t)RED_MAX_GRID * sizeof(red_record) + 256;
+    return MI355_OK;
+}
+
+MI355_API int32_t mi355_reduce_sum_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, uint64_t n, float *out,
+                                       void *workspace, uint64_t workspace_bytes)
+{
+    if (ctx && !out) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_reduce_sum_f32: out is NULL");
+    return run_reduce<true, false>(ctx, stream, in, n, out, nullptr, nullptr, workspace, workspace_bytes,
+                                   "mi355_reduce_sum_f32");
+}
+
+MI355_API int32_t mi355_argmax_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, uint64_t n, float *out_val,
+                                   uint64_t *out_idx, void *workspace, uint64_t workspace_bytes)
+{
+    if (ctx && !out_idx && !out_val) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_argmax_f32: no output");
+    return run_reduce<false, true>(ctx, stream, in, n, nullptr, out_val, out_idx, workspace, workspace_bytes,
+                                   "mi355_argmax_f32");
+}
+
+MI355_API int32_t mi355_sum_argmax_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, uint64_t n,
+                                       float *out_sum, float *out_val, uint64_t *out_idx, void *workspace,
+                                       uint64_t workspace_bytes)
+{
+    if (ctx && !out_sum && !out_idx && !out_val)
+        return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_sum_argmax_f32: no output");
+    return run_reduce<true, true>(ctx, stream, in, n, out_sum, out_val, out_idx, workspace, workspace_bytes,
+                                  "mi355_sum_argmax_f32");
+}
+
+MI355_API int32_t mi355_reduce_last_axis_sum_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, float *out,
+                                                 uint64_t rows, uint64_t cols, uint64_t row_stride)
+{
+    return run_rows<false>(ctx, stream, in, out, nullptr, rows, cols, row_stride, "mi355_reduce_last_axis_sum_f32");
+}
+
+MI355_API int32_t mi355_reduce_last_axis_argmax_f32(mi355_ctx *ctx, mi355_stream stream, const float *in,
+                                                    uint32_t *out_idx, uint64_t rows, uint64_t cols,
+                                                    uint64_t row_stride)
+{
+    return run_rows<true>(ctx, stream, in, nullptr, out_idx, rows, cols, row_stride,
+                          "mi355_reduce_last_axis_argmax_f32");
+}
+
+MI355_API int32_t mi355_plane_reduce_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, float *out, uint64_t n,
+                                         uint32_t active, int32_t op)
+{
+    MI355_REQUIRE_CTX(ctx);
+    if (n == 0) return MI355_OK;
+    if (!in || !out) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_plane_reduce_f32: NULL pointer");
+    if (active == 0 || active > 64 || (active & (active - 1)) != 0)
+        return fail(ctx, MI355_E_INVALID_ARGUMENT, "active lanes must be a power of two <= 64 (got %u)", active);
+    const bool known = op == MI355_REDUCE_SUM || op == MI355_REDUCE_MAX || op == MI355_REDUCE_MIN || op == 100 ||
+                       op == 101 || op == 102;
+    if (!known) return fail(ctx, MI355_E_UNSUPPORTED, "unknown plane op %d", op);
+    const uint64_t blocks = (n + 63) / 64;
+    if (blocks > 0x7FFFFFFFull) return fail(ctx, MI355_E_UNSUPPORTED, "too many planes");
+    hipLaunchKernelGGL(plane_reduce_kernel, dim3((uint32_t)blocks), dim3(64), 0, stream_of(ctx, stream), in, out, n,
+                       active, op);
+    check_launch(ctx, "mi355_plane_reduce_f32");
+    return MI355_OK;
+}

@@ -1,0 +1,185 @@
+"""Launch entry points of the hot path: tiled matmul and reductions over TensorHandles.
+
+The reference keeps these launchers in the out-of-tree `cubek` crates (README.md:161-165); what
+the snapshot pins is the operand contract -- TensorHandle {handle, shape, strides, dtype}
+(crates/cubecl-std/src/tensor/handle.rs:13-23), strides in elements, transposition / broadcast
+expressed through strides and classified by matrix_batch_layout
+(crates/cubecl-std/src/tensor/matrix_batch_layout.rs:21-79) -- and the arithmetic
+(runtime_tests/cmma.rs:695-722 for matmul; examples/sum_things/src/lib.rs:6-19 and the book's
+reduce_matrix for sums).  These functions take exactly that contract and forward to the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+from . import _native as N
+from .runtime import ComputeClient, ElemType, Handle, ServerError
+from .tensor import TensorHandle, matrix_batch_layout
+
+
+def _matrix_operand(t: TensorHandle, name: str):
+    """-> (transposed, leading dimension, batch count, batch stride)."""
+    if t.rank() < 2:
+        raise ServerError(N.E_INVALID_ARGUMENT, f"matmul: {name} must have rank >= 2")
+    if t.shape[-2] == 0 or t.shape[-1] == 0:   # empty operand (K == 0 or empty output): nothing is read
+        batch = 1
+        for d in t.shape[:-2]:
+            batch *= d
+        return False, max(t.shape[-1], 1), batch, 0
+    layout = matrix_batch_layout(t.strides)
+    if layout.kind == "HighlyPermuted":
+        # the reference launcher would call into_contiguous first (next tier)
+        raise ServerError(N.E_UNSUPPORTED_STRIDES, f"matmul: {name} is HighlyPermuted; make it contiguous first")
+    rows, cols = t.shape[-2], t.shape[-1]
+    rs, cs = t.strides[-2], t.strides[-1]
+    if cs == 1:
+        transposed, ld = False, rs
+    elif rs == 1:
+        transposed, ld = True, cs
+    else:
+        raise ServerError(N.E_UNSUPPORTED_STRIDES, f"matmul: {name} has no unit stride in its last two dims")
+    if (rows == 1 or cols == 1) and ld < (rows if transposed else cols):
+        ld = rows if transposed else cols
+    batch_dims, batch_strides = t.shape[:-2], t.strides[:-2]
+    batch = 1
+    for d in batch_dims:
+        batch *= d
+    nontrivial = [(d, s) for d, s in zip(batch_dims, batch_strides) if d != 1]
+    if not nontrivial:
+        bstride = 0
+    else:
+        # collapsible iff each outer stride = inner stride * inner dim (or everything broadcast)
+        bstride = nontrivial[-1][1]
+        for (d_out, s_out), (d_in, s_in) in zip(nontrivial[:-1], nontrivial[1:]):
+            if s_out != s_in * d_in:
+                raise ServerError(N.E_UNSUPPORTED_STRIDES, f"matmul: {name} batch dims are not collapsible")
+    return transposed, ld, batch, bstride
+
+
+def matmul(client: ComputeClient, lhs: TensorHandle, rhs: TensorHandle, out: TensorHandle,
+           algo: int = N.GEMM_ALGO_AUTO) -> None:
+    """out[.., m, n] = sum_k lhs[.., m, k] * rhs[.., k, n]   (f32 accumulate).
+
+    Layouts come from strides alone: a `rhs` of logical shape [k, n] with strides [1, k] is the
+    reference tests' "ColMajor B" / Out = Lhs * Rhs^T form (cmma.rs:23) and takes the fast
+    K-contiguous MFMA path; strides [n, 1] is row-major B.
+    """
+    m, k = lhs.shape[-2], lhs.shape[-1]
+    k2, n = rhs.shape[-2], rhs.shape[-1]
+    if k != k2 or out.shape[-2] != m or out.shape[-1] != n:
+        raise ServerError(N.E_INVALID_ARGUMENT, f"matmul: shape mismatch {lhs.shape} x {rhs.shape} -> {out.shape}")
+    if lhs.dtype != rhs.dtype:
+        raise ServerError(N.E_INVALID_ARGUMENT, "matmul: lhs/rhs dtypes differ")
+    ta, lda, ba, sa = _matrix_operand(lhs, "lhs")
+    tb, ldb, bb, sb = _matrix_operand(rhs, "rhs")
+    tc, ldc, bc, sc = _matrix_operand(out, "out")
+    if tc:
+        raise ServerError(N.E_UNSUPPORTED_STRIDES, "matmul: out must be row-major")
+    batch = bc
+    for b, name in ((ba, "lhs"), (bb, "rhs")):
+        if b not in (1, batch):
+            raise ServerError(N.E_INVALID_ARGUMENT, f"matmul: {name} batch {b} does not broadcast to {batch}")
+    desc = N.GemmDesc(m=m, n=n, k=k, batch=batch, lda=lda, ldb=ldb, ldc=ldc,
+                      stride_a=sa if ba == batch else 0, stride_b=sb if bb == batch else 0, stride_c=sc,
+                      dtype_ab=int(lhs.dtype), dtype_c=int(out.dtype), trans_a=int(ta), trans_b=int(tb), algo=algo)
+    client._s.check(client.lib.mi355_gemm(client.ctx, client.stream, C.byref(desc), C.c_void_p(lhs.device_ptr()),
+                                          C.c_void_p(rhs.device_ptr()), C.c_void_p(out.device_ptr())))
+
+
+def gemm_select(client: ComputeClient, desc: N.GemmDesc) -> int:
+    algo = C.c_int32()
+    client._s.check(client.lib.mi355_gemm_select(client.ctx, C.byref(desc), C.byref(algo)))
+    return algo.value
+
+
+_WORKSPACES: dict = {}
+
+
+def _workspace(client: ComputeClient, n: int) -> Handle:
+    key = id(client._s)
+    need = C.c_uint64()
+    client._s.check(client.lib.mi355_reduce_workspace_bytes(client.ctx, n, C.byref(need)))
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.size < need.value or ws.memory.server is not client._s:
+        ws = client.empty(need.value)
+        _WORKSPACES[key] = ws
+    return ws
+
+
+def _require_flat_f32(t: TensorHandle, what: str) -> int:
+    if t.dtype != ElemType.F32:
+        raise ServerError(N.E_UNSUPPORTED, f"{what}: only f32 input is implemented")
+    if not t.is_contiguous():
+        raise ServerError(N.E_UNSUPPORTED_STRIDES, f"{what}: input must be contiguous")
+    return t.num_elems()
+
+
+def reduce_sum(client: ComputeClient, input: TensorHandle, output: TensorHandle) -> None:
+    """Array-wide sum into output[0] (f32)."""
+    n = _require_flat_f32(input, "reduce_sum")
+    ws = _workspace(client, n)
+    client._s.check(client.lib.mi355_reduce_sum_f32(client.ctx, client.stream, C.c_void_p(input.device_ptr()), n,
+                                                    C.c_void_p(output.device_ptr()), C.c_void_p(ws.device_ptr()), ws.size))
+
+
+def argmax(client: ComputeClient, input: TensorHandle, out_index: TensorHandle,
+           out_value: Optional[TensorHandle] = None) -> None:
+    """Array-wide argmax: out_index[0] (u64) = lowest index of the maximum; NaN ranks highest."""
+    n = _require_flat_f32(input, "argmax")
+    ws = _workspace(client, n)
+    client._s.check(client.lib.mi355_argmax_f32(
+        client.ctx, client.stream, C.c_void_p(input.device_ptr()), n,
+        C.c_void_p(out_value.device_ptr()) if out_value is not None else None,
+        C.c_void_p(out_index.device_ptr()), C.c_void_p(ws.device_ptr()), ws.size))
+
+
+def sum_argmax(client: ComputeClient, input: TensorHandle, out_sum: TensorHandle, out_index: TensorHandle,
+               out_value: Optional[TensorHandle] = None) -> None:
+    """Sum and argmax in one pass over the data."""
+    n = _require_flat_f32(input, "sum_argmax")
+    ws = _workspace(client, n)
+    client._s.check(client.lib.mi355_sum_argmax_f32(
+        client.ctx, client.stream, C.c_void_p(input.device_ptr()), n, C.c_void_p(out_sum.device_ptr()),
+        C.c_void_p(out_value.device_ptr()) if out_value is not None else None,
+        C.c_void_p(out_index.device_ptr()), C.c_void_p(ws.device_ptr()), ws.size))
+
+
+def _rows_view(t: TensorHandle, what: str):
+    if t.dtype != ElemType.F32:
+        raise ServerError(N.E_UNSUPPORTED, f"{what}: only f32 input is implemented")
+    if t.rank() == 0:
+        raise ServerError(N.E_INVALID_ARGUMENT, f"{what}: rank-0 input")
+    cols = t.shape[-1]
+    rows = t.num_elems() // cols if cols else 0
+    if t.strides[-1] != 1 and cols > 1:
+        raise ServerError(N.E_UNSUPPORTED_STRIDES, f"{what}: last axis must have unit stride")
+    row_stride = t.strides[-2] if t.rank() >= 2 else cols
+    # leading dims must collapse onto one row stride (pitched row-major is fine)
+    acc = row_stride
+    for i in range(t.rank() - 3, -1, -1):
+        acc *= t.shape[i + 1]
+        if t.strides[i] != acc and t.shape[i] != 1:
+            raise ServerError(N.E_UNSUPPORTED_STRIDES, f"{what}: leading dims are not collapsible")
+    return rows, cols, row_stride
+
+
+def reduce_sum_last_axis(client: ComputeClient, input: TensorHandle, output: TensorHandle) -> None:
+    """The book's reduce_matrix (cubecl-book/src/getting-started/src/bin/v1-cpu.rs:7-15):
+    output shape = input shape minus the last axis."""
+    rows, cols, stride = _rows_view(input, "reduce_sum_last_axis")
+    client._s.check(client.lib.mi355_reduce_last_axis_sum_f32(
+        client.ctx, client.stream, C.c_void_p(input.device_ptr()), C.c_void_p(output.device_ptr()), rows, cols, stride))
+
+
+def argmax_last_axis(client: ComputeClient, input: TensorHandle, output: TensorHandle) -> None:
+    rows, cols, stride = _rows_view(input, "argmax_last_axis")
+    client._s.check(client.lib.mi355_reduce_last_axis_argmax_f32(
+        client.ctx, client.stream, C.c_void_p(input.device_ptr()), C.c_void_p(output.device_ptr()), rows, cols, stride))
+
+
+def plane_reduce(client: ComputeClient, input: TensorHandle, output: TensorHandle, op: int, active: int = 64) -> None:
+    """plane_sum / plane_prod / plane_max / plane_min / inclusive / exclusive sum over 64-lane planes."""
+    n = input.num_elems()
+    client._s.check(client.lib.mi355_plane_reduce_f32(client.ctx, client.stream, C.c_void_p(input.device_ptr()),
+                                                      C.c_void_p(output.device_ptr()), n, active, op))

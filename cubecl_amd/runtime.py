@@ -1,0 +1,486 @@
+"""Host-side mirror of the reference's runtime surface for the MI355X backend.
+
+Names, argument meaning and error behaviour follow the reference (file:line under the
+tracel-ai/cubecl checkout) so the parity tests read like the reference's own tests:
+
+  Runtime           crates/cubecl-runtime/src/runtime.rs:14-52      -> Mi355Runtime
+  ComputeClient     crates/cubecl-runtime/src/client.rs:44-48       -> ComputeClient
+  Handle            crates/cubecl-runtime/src/server/handle.rs:10   -> Handle
+  CopyDescriptor    crates/cubecl-runtime/src/server/base.rs:1102   -> CopyDescriptor
+  CubeCount/CubeDim crates/cubecl-runtime/src/server/base.rs:1148,1251
+  ReduceOperation   crates/cubecl-runtime/src/server/base.rs:623-628
+  ServerError       crates/cubecl-runtime/src/server/base.rs:286-332
+  DeviceId          crates/cubecl-common/src/device/base.rs:6
+
+Everything here forwards to libmi355cube.so through the C ABI (include/mi355cube.h).  PyTorch
+is not involved; there is no CPU fallback.  (The Rust shim a maintainer would compile instead
+of this module lives in rust/cubecl-mi355; see INTEGRATION.md.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from dataclasses import dataclass, field
+from typing import Iterable, Optional, Sequence
+
+import numpy as np
+
+from . import _native as N
+
+
+# ----------------------------------------------------------------------------------------------
+# value types
+# ----------------------------------------------------------------------------------------------
+class ElemType(enum.IntEnum):
+    """cubecl_ir::ElemType restricted to what this path moves."""
+    F32 = N.DTYPE_F32
+    BF16 = N.DTYPE_BF16
+    F16 = N.DTYPE_F16
+    F64 = N.DTYPE_F64
+    I32 = N.DTYPE_I32
+    U32 = N.DTYPE_U32
+    I64 = N.DTYPE_I64
+    U64 = N.DTYPE_U64
+    U8 = N.DTYPE_U8
+    I8 = N.DTYPE_I8
+
+    def size(self) -> int:
+        return N.DTYPE_SIZE[int(self)]
+
+
+class ReduceOperation(enum.IntEnum):
+    """server/base.rs:623-628 (Sum, Mean) + Max/Min (API delta for argmax)."""
+    Sum = N.REDUCE_SUM
+    Mean = N.REDUCE_MEAN
+    Max = N.REDUCE_MAX
+    Min = N.REDUCE_MIN
+
+
+@dataclass(frozen=True, order=True)
+class DeviceId:
+    type_id: int = 0
+    index_id: int = 0
+
+
+@dataclass(frozen=True)
+class CubeDim:
+    x: int = 1
+    y: int = 1
+    z: int = 1
+
+    @staticmethod
+    def new_1d(x: int) -> "CubeDim":
+        return CubeDim(x, 1, 1)
+
+    def num_elems(self) -> int:
+        return self.x * self.y * self.z
+
+
+@dataclass(frozen=True)
+class CubeCount:
+    """CubeCount::Static(x, y, z)."""
+    x: int = 1
+    y: int = 1
+    z: int = 1
+
+    @staticmethod
+    def Static(x: int, y: int = 1, z: int = 1) -> "CubeCount":
+        return CubeCount(x, y, z)
+
+
+class ServerError(RuntimeError):
+    """ServerError / LaunchError / IoError carried across the C ABI as (code, message)."""
+
+    def __init__(self, code: int, message: str, errors: Optional[list] = None):
+        self.code = code
+        self.kind = N.ERROR_NAMES.get(code, f"code {code}")
+        self.errors = errors or []      # ServerUnhealthy { errors }
+        detail = "".join(f"\n  - {e.kind}: {e}" for e in self.errors)
+        super().__init__(f"{self.kind}: {message}{detail}")
+        self.message = message
+        self.requested = 0
+        self.max = 0
+
+
+# ----------------------------------------------------------------------------------------------
+# handles
+# ----------------------------------------------------------------------------------------------
+class _Memory:
+    """Server-side storage slot (GpuStorage resource); freed when the last Handle drops."""
+
+    __slots__ = ("server", "ptr", "size", "__weakref__")
+
+    def __init__(self, server: "_Server", ptr: int, size: int):
+        self.server, self.ptr, self.size = server, ptr, size
+
+    def __del__(self):
+        try:
+            if self.ptr and self.server is not None and self.server.ctx:
+                self.server.lib.mi355_free(self.server.ctx, C.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+@dataclass
+class Handle:
+    """server::Handle: ref-counted memory + byte offsets (handle.rs:10-21). Not a raw pointer."""
+    memory: _Memory
+    offset_start: Optional[int] = None
+    offset_end: Optional[int] = None
+    size: int = 0
+
+    def clone(self) -> "Handle":
+        return Handle(self.memory, self.offset_start, self.offset_end, self.size)
+
+    def offset_start_by(self, offset: int) -> "Handle":
+        return Handle(self.memory, (self.offset_start or 0) + offset, self.offset_end, self.size)
+
+    def offset_end_by(self, offset: int) -> "Handle":
+        return Handle(self.memory, self.offset_start, (self.offset_end or 0) + offset, self.size)
+
+    def size_in_used(self) -> int:
+        return self.size - (self.offset_start or 0) - (self.offset_end or 0)
+
+    def binding(self) -> "Handle":
+        return self
+
+    # resolved server-side, like command.resource() (crates/cubecl-hip/src/compute/command.rs:57-62)
+    def device_ptr(self) -> int:
+        return self.memory.ptr + (self.offset_start or 0)
+
+    def copy_descriptor(self, shape: Sequence[int], strides: Sequence[int], elem_size: int) -> "CopyDescriptor":
+        return CopyDescriptor(self, tuple(shape), tuple(strides), elem_size)
+
+
+@dataclass
+class CopyDescriptor:
+    handle: Handle
+    shape: tuple
+    strides: tuple
+    elem_size: int
+
+
+@dataclass
+class MemoryLayout:
+    """server::MemoryLayout { memory, strides } returned by empty_tensor / create_tensor."""
+    memory: Handle
+    strides: tuple
+
+
+def contiguous_strides(shape: Sequence[int]) -> tuple:
+    strides, acc = [], 1
+    for d in reversed(tuple(shape)):
+        strides.append(acc)
+        acc *= d
+    return tuple(reversed(strides))
+
+
+def has_pitched_row_major_strides(shape: Sequence[int], strides: Sequence[int]) -> bool:
+    """crates/cubecl-zspace/src/striding/layout_validation.rs:84-98: contiguous except for a
+    padded second-to-last stride."""
+    shape, strides = tuple(shape), tuple(strides)
+    if len(shape) != len(strides):
+        return False
+    if len(shape) == 0:
+        return True
+    if strides[-1] != 1:
+        return False
+    if len(shape) == 1:
+        return True
+    if strides[-2] < shape[-1]:
+        return False
+    acc = strides[-2]
+    for i in range(len(shape) - 3, -1, -1):
+        acc *= shape[i + 1]
+        if strides[i] != acc:
+            return False
+    return True
+
+
+# ----------------------------------------------------------------------------------------------
+# server + client
+# ----------------------------------------------------------------------------------------------
+class _Server:
+    """One per DeviceId (HipServer analogue); owns the C context."""
+
+    def __init__(self, device: DeviceId):
+        self.lib = N.load()
+        self.device = device
+        ctx = C.c_void_p()
+        rc = self.lib.mi355_ctx_create(device.index_id, C.byref(ctx))
+        if rc != N.OK:
+            raise ServerError(rc, self.lib.mi355_last_global_error().decode())
+        self.ctx = ctx
+        props = N.DeviceProps()
+        self.check(self.lib.mi355_device_props(self.ctx, C.byref(props)))
+        self.props = props
+        self.comms: dict = {}
+
+    def check(self, rc: int) -> None:
+        if rc == N.OK:
+            return
+        msg = self.lib.mi355_last_error(self.ctx).decode(errors="replace")
+        if rc == N.E_SERVER_UNHEALTHY:
+            errors = []
+            while True:
+                code, req, mx = C.c_int32(), C.c_uint64(), C.c_uint64()
+                buf = C.create_string_buffer(512)
+                if self.lib.mi355_error_pop(self.ctx, C.byref(code), C.byref(req), C.byref(mx), buf, 512) != N.OK:
+                    break
+                err = ServerError(code.value, buf.value.decode(errors="replace"))
+                err.requested, err.max = req.value, mx.value
+                errors.append(err)
+            raise ServerError(rc, msg, errors)
+        raise ServerError(rc, msg)
+
+    def close(self) -> None:
+        if self.ctx:
+            for comm in self.comms.values():
+                self.lib.mi355_comm_destroy(self.ctx, comm)
+            self.comms.clear()
+            self.lib.mi355_ctx_destroy(self.ctx)
+            self.ctx = None
+
+
+_SERVERS: dict = {}
+
+
+class Mi355Runtime:
+    """`impl Runtime` for MI355X (counterpart of HipRuntime, crates/cubecl-hip/src/runtime.rs:254-328)."""
+
+    @staticmethod
+    def name() -> str:
+        return "mi355"
+
+    @staticmethod
+    def require_array_lengths() -> bool:
+        return True  # crates/cubecl-hip/src/runtime.rs:267-269
+
+    @staticmethod
+    def max_cube_count() -> tuple:
+        return (2 ** 31 - 1, 65535, 65535)  # :271-273
+
+    @staticmethod
+    def can_read_tensor(shape: Sequence[int], strides: Sequence[int]) -> bool:
+        return has_pitched_row_major_strides(shape, strides)  # :275-280
+
+    @staticmethod
+    def enumerate_devices() -> list:
+        lib = N.load()
+        n = C.c_int32(0)
+        lib.mi355_device_count(C.byref(n))
+        return [DeviceId(0, i) for i in range(n.value)]
+
+    @staticmethod
+    def client(device: DeviceId = DeviceId(0, 0)) -> "ComputeClient":
+        server = _SERVERS.get(device)
+        if server is None or not server.ctx:
+            server = _Server(device)
+            _SERVERS[device] = server
+        return ComputeClient(server)
+
+
+class ComputeClient:
+    """ComputeClient<R> (client.rs:169-1369) over the C ABI.  Calls are issued directly on the
+    calling thread: the C context is single-threaded per device, as the runner-thread contract
+    requires."""
+
+    def __init__(self, server: _Server):
+        self._s = server
+        self.lib = server.lib
+        self.ctx = server.ctx
+        self.stream = C.c_void_p(None)  # NULL = the context's compute stream
+
+    # -- properties --------------------------------------------------------------------------
+    def properties(self) -> N.DeviceProps:
+        return self._s.props
+
+    def features(self) -> dict:
+        p = self._s.props
+        cfgs = [(c.a_type, c.b_type, c.cd_type, c.m, c.n, c.k) for c in p.mma_configs[: p.num_mma_configs]]
+        return {"plane": {"Ops", "NonUniformControlFlow"} if p.plane_ops else set(), "cmma": set(cfgs), "mma": set(cfgs)}
+
+    def io_optimized_vector_sizes(self, elem_size: int) -> list:
+        width = self._s.props.load_width_bits // 8  # client.rs:1339
+        out, v = [], max(width // elem_size, 1)
+        while v >= 1:
+            out.append(v)
+            v //= 2
+        return out
+
+    # -- memory ------------------------------------------------------------------------------
+    def empty(self, size: int) -> Handle:
+        ptr = C.c_void_p()
+        self._s.check(self.lib.mi355_alloc(self.ctx, size, C.byref(ptr)))
+        return Handle(_Memory(self._s, ptr.value or 0, size), None, None, size)
+
+    def create_from_slice(self, data) -> Handle:
+        buf = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+        handle = self.empty(buf.nbytes)
+        self.write(handle, buf)
+        return handle
+
+    create = create_from_slice
+
+    def write(self, handle: Handle, data) -> None:
+        buf = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+        if buf.nbytes > handle.size_in_used():
+            raise ServerError(N.E_INVALID_ARGUMENT, "write larger than the handle")
+        self._s.check(self.lib.mi355_write(self.ctx, self.stream, C.c_void_p(handle.device_ptr()),
+                                           buf.ctypes.data_as(C.c_void_p), buf.nbytes))
+        # the host buffer must outlive the copy (command.rs:402): complete it before returning
+        self._s.check(self.lib.mi355_sync(self.ctx, self.stream))
+
+    def empty_tensor(self, shape: Sequence[int], elem_size: int) -> MemoryLayout:
+        """PitchedMemoryLayoutPolicy::apply (allocator.rs:21-72)."""
+        shape = tuple(int(d) for d in shape)
+        if len(shape) < 2:
+            n = int(np.prod(shape)) if shape else 1
+            return MemoryLayout(self.empty(n * elem_size), contiguous_strides(shape))
+        width = shape[-1] * elem_size
+        pitch = C.c_uint64()
+        self._s.check(self.lib.mi355_pitched_row_bytes(self.ctx, width, C.byref(pitch)))
+        height = int(np.prod(shape[:-1]))
+        strides = [1] * len(shape)
+        strides[-2] = pitch.value // elem_size
+        for i in range(len(shape) - 3, -1, -1):
+            strides[i] = strides[i + 1] * shape[i + 1]
+        return MemoryLayout(self.empty(max(height, 1) * pitch.value), tuple(strides))
+
+    def create_tensor(self, data: np.ndarray) -> MemoryLayout:
+        layout = self.empty_tensor(data.shape, data.dtype.itemsize)
+        self.write_tensor(CopyDescriptor(layout.memory, data.shape, layout.strides, data.dtype.itemsize), data)
+        return layout
+
+    def write_tensor(self, desc: CopyDescriptor, data: np.ndarray) -> None:
+        data = np.ascontiguousarray(data)
+        if not has_pitched_row_major_strides(desc.shape, desc.strides):
+            raise ServerError(N.E_UNSUPPORTED_STRIDES, f"unsupported strides {desc.strides} for shape {desc.shape}")
+        if len(desc.shape) < 2 or desc.strides[-2] == desc.shape[-1]:
+            return self.write(desc.handle, data)
+        width = desc.shape[-1] * desc.elem_size
+        rows = int(np.prod(desc.shape[:-1]))
+        self._s.check(self.lib.mi355_write_2d(self.ctx, self.stream, C.c_void_p(desc.handle.device_ptr()),
+                                              desc.strides[-2] * desc.elem_size, data.ctypes.data_as(C.c_void_p),
+                                              width, width, rows))
+        self._s.check(self.lib.mi355_sync(self.ctx, self.stream))
+
+    def read_one(self, handle: Handle) -> np.ndarray:
+        """Returns the bytes; raises ServerError (incl. queued launch errors) like read_one."""
+        n = handle.size_in_used()
+        out = np.empty(n, dtype=np.uint8)
+        self._s.check(self.lib.mi355_read(self.ctx, self.stream, out.ctypes.data_as(C.c_void_p),
+                                          C.c_void_p(handle.device_ptr()), n))
+        return out
+
+    read_one_unchecked = read_one
+
+    def read(self, handles: Iterable[Handle]) -> list:
+        return [self.read_one(h) for h in handles]
+
+    def read_tensor(self, desc: CopyDescriptor) -> np.ndarray:
+        """read_one_tensor: gathers a (possibly pitched) tensor into contiguous bytes."""
+        if not has_pitched_row_major_strides(desc.shape, desc.strides):
+            raise ServerError(N.E_UNSUPPORTED_STRIDES, f"unsupported strides {desc.strides} for shape {desc.shape}")
+        n = int(np.prod(desc.shape)) * desc.elem_size
+        out = np.empty(n, dtype=np.uint8)
+        if n == 0:
+            return out
+        if len(desc.shape) < 2 or desc.strides[-2] == desc.shape[-1]:
+            self._s.check(self.lib.mi355_read(self.ctx, self.stream, out.ctypes.data_as(C.c_void_p),
+                                              C.c_void_p(desc.handle.device_ptr()), n))
+            return out
+        width = desc.shape[-1] * desc.elem_size
+        rows = int(np.prod(desc.shape[:-1]))
+        self._s.check(self.lib.mi355_read_2d(self.ctx, self.stream, out.ctypes.data_as(C.c_void_p), width,
+                                             C.c_void_p(desc.handle.device_ptr()), desc.strides[-2] * desc.elem_size,
+                                             width, rows))
+        return out
+
+    # -- execution ---------------------------------------------------------------------------
+    def launch(self, function, cube_count: CubeCount, cube_dim: CubeDim, resources: Sequence[Handle],
+               info: Optional[Handle] = None, shared_mem_bytes: int = 0) -> None:
+        """ComputeClient::launch for an externally built kernel: one pointer per binding, the
+        `info` buffer last (crates/cubecl-cpp/src/hip/signature.rs:28-62).  Fire and forget:
+        errors surface at flush/sync/read."""
+        ptrs = [h.device_ptr() for h in resources]
+        if info is not None:
+            ptrs.append(info.device_ptr())
+        arr = (C.c_void_p * max(len(ptrs), 1))(*ptrs)
+        grid = (C.c_uint32 * 3)(cube_count.x, cube_count.y, cube_count.z)
+        block = (C.c_uint32 * 3)(cube_dim.x, cube_dim.y, cube_dim.z)
+        self._s.check(self.lib.mi355_launch(self.ctx, self.stream, function, grid, block, shared_mem_bytes, arr, len(ptrs)))
+
+    def load_module(self, image: bytes):
+        mod = C.c_void_p()
+        self._s.check(self.lib.mi355_module_load(self.ctx, image, len(image), C.byref(mod)))
+        return mod
+
+    def get_function(self, module, name: str):
+        fn = C.c_void_p()
+        self._s.check(self.lib.mi355_module_get_function(self.ctx, module, name.encode(), C.byref(fn)))
+        return fn
+
+    def flush(self) -> None:
+        self._s.check(self.lib.mi355_flush(self.ctx))
+
+    def sync(self) -> None:
+        self._s.check(self.lib.mi355_sync(self.ctx, self.stream))
+
+    def memory_usage(self) -> dict:
+        free, total = C.c_uint64(), C.c_uint64()
+        self._s.check(self.lib.mi355_mem_info(self.ctx, C.byref(free), C.byref(total)))
+        return {"bytes_free": free.value, "bytes_total": total.value, "bytes_in_use": total.value - free.value}
+
+    def profile(self, fn, name: str = ""):
+        """client.profile(closure, name): returns (result, device nanoseconds)."""
+        token, nanos = C.c_uint64(), C.c_uint64()
+        self._s.check(self.lib.mi355_profile_start(self.ctx, self.stream, C.byref(token)))
+        result = fn()
+        self._s.check(self.lib.mi355_profile_stop(self.ctx, self.stream, token, C.byref(nanos)))
+        return result, nanos.value
+
+    # -- collectives (ServerCommunication) ------------------------------------------------------
+    def comm_init(self, device_ids: Sequence[DeviceId], unique_id: bytes, rank: Optional[int] = None) -> None:
+        """comm_init: one communicator per sorted device set; rank = position of this device
+        (crates/cubecl-cuda/src/compute/server.rs:669-703)."""
+        ids = tuple(sorted(device_ids))
+        if ids in self._s.comms:
+            return
+        if rank is None:
+            rank = ids.index(self._s.device)
+        uid = (C.c_uint8 * N.UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        comm = C.c_void_p()
+        self._s.check(self.lib.mi355_comm_init(self.ctx, uid, rank, len(ids), C.byref(comm)))
+        self._s.comms[ids] = comm
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        lib = N.load()
+        uid = (C.c_uint8 * N.UNIQUE_ID_BYTES)()
+        rc = lib.mi355_comm_unique_id(uid)
+        if rc != N.OK:
+            raise ServerError(rc, lib.mi355_last_global_error().decode())
+        return bytes(uid)
+
+    def all_reduce(self, src: Handle, dst: Handle, dtype: ElemType, device_ids: Sequence[DeviceId],
+                   op: ReduceOperation) -> None:
+        ids = tuple(sorted(device_ids))
+        comm = self._s.comms.get(ids)
+        if comm is None:
+            raise ServerError(N.E_COMM, "all_reduce before comm_init for this device set")
+        count = src.size_in_used() // ElemType(dtype).size()  # get_nccl_dtype_count
+        self._s.check(self.lib.mi355_all_reduce(self.ctx, comm, self.stream, C.c_void_p(src.device_ptr()),
+                                                C.c_void_p(dst.device_ptr()), count, int(dtype), int(op)))
+
+    def all_gather(self, src: Handle, dst: Handle, dtype: ElemType, device_ids: Sequence[DeviceId]) -> None:
+        ids = tuple(sorted(device_ids))
+        comm = self._s.comms.get(ids)
+        if comm is None:
+            raise ServerError(N.E_COMM, "all_gather before comm_init for this device set")
+        count = src.size_in_used() // ElemType(dtype).size()
+        self._s.check(self.lib.mi355_all_gather(self.ctx, comm, self.stream, C.c_void_p(src.device_ptr()),
+                                                C.c_void_p(dst.device_ptr()), count, int(dtype)))
+
+    def sync_collective(self) -> None:
+        self._s.check(self.lib.mi355_sync_collective(self.ctx, self.stream))

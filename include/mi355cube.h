@@ -1,0 +1,374 @@
+/*
+ * mi355cube.h -- C ABI of libmi355cube.so: an MI355X (gfx950 / CDNA4) native backend for the
+ * tiled-matmul + reduction hot path of tracel-ai/cubecl.
+ *
+ * This header IS the drop-in boundary.  Each entry point replaces one operation of the
+ * reference's backend trait surface (citations are file:line under the reference checkout):
+ *
+ *   Runtime                crates/cubecl-runtime/src/runtime.rs:14-52
+ *   ComputeServer          crates/cubecl-runtime/src/server/base.rs:372-601
+ *   ServerCommunication    crates/cubecl-runtime/src/server/base.rs:632-737
+ *   ComputeStorage         crates/cubecl-runtime/src/storage/base.rs:74-101
+ *   HIP launch leaf        crates/cubecl-hip/src/compute/context.rs:390-440
+ *
+ * A Rust `cubecl-mi355` crate (rust/cubecl-mi355) implements those traits by
+ * forwarding to these functions; tests and benches drive the same functions from Python
+ * (ctypes) and C++.
+ *
+ * Conventions
+ *  - Plain C: opaque pointers, integers, caller-owned buffers.  No exceptions or panics cross
+ *    the boundary.  Every function returns an int32 status (MI355_OK == 0).
+ *  - Threading: one `mi355_ctx` per device, used by one thread at a time (the reference runs
+ *    one runner thread per DeviceId: crates/cubecl-common/src/device/handle/channel.rs:24-37).
+ *    Different contexts may be used concurrently.  Each call re-selects its device
+ *    (hipSetDevice), so a context may migrate between threads.
+ *  - Asynchrony and errors: `launch`, copies and the op entry points are stream-ordered and
+ *    fire-and-forget like ComputeServer::launch/write.  Failures discovered at submission
+ *    (resource limits, bad launch) are QUEUED on the context and reported by the next
+ *    mi355_flush / mi355_sync / mi355_read as MI355_E_SERVER_UNHEALTHY (the reference's
+ *    ServerError::ServerUnhealthy{errors}, server/base.rs:286-332); drain the queue with
+ *    mi355_error_pop.  Argument errors (NULL pointers, unsupported dtype/shape) are returned
+ *    immediately and also recorded for mi355_last_error.
+ *  - Ownership: the caller owns every device pointer it gets from mi355_alloc and every
+ *    workspace it passes in; the library never frees caller memory.  mi355_free defers the
+ *    hipFree to the next mi355_flush, as GpuStorage does
+ *    (crates/cubecl-hip/src/compute/storage/gpu.rs:136-169).
+ *  - Strides are in ELEMENTS, row-major (TensorHandle, crates/cubecl-std/src/tensor/handle.rs:13-23).
+ */
+#ifndef MI355CUBE_H
+#define MI355CUBE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_ABI_VERSION 1
+
+/* ---- status codes (map onto LaunchError / IoError / ServerError, server/base.rs:177-332,
+ *      :884-1019; the Rust shim performs the conversion) ------------------------------- */
+enum {
+    MI355_OK = 0,
+    MI355_E_INVALID_ARGUMENT = 1,      /* ServerError::Validation                              */
+    MI355_E_OUT_OF_MEMORY = 2,         /* IoError::OutOfMemory / LaunchError::OutOfMemory      */
+    MI355_E_BUFFER_TOO_BIG = 3,        /* IoError::BufferTooBig (> memory.max_page_size)       */
+    MI355_E_UNSUPPORTED_STRIDES = 4,   /* IoError::UnsupportedStrides                          */
+    MI355_E_NOT_FOUND = 5,             /* IoError::NotFound (unknown symbol / handle)          */
+    MI355_E_SHARED_MEMORY = 6,         /* ResourceLimitError::SharedMemory{requested,max}      */
+    MI355_E_UNITS = 7,                 /* ResourceLimitError::Units                            */
+    MI355_E_CUBE_DIM = 8,              /* ResourceLimitError::CubeDim                          */
+    MI355_E_MAX_UNITS_PER_CUBE = 9,    /* ResourceLimitError::MaxUnitPerCube                   */
+    MI355_E_COMPILATION = 10,          /* LaunchError::CompilationError (module load failed)   */
+    MI355_E_LAUNCH = 11,               /* LaunchError::Unknown                                 */
+    MI355_E_EXECUTION = 12,            /* IoError::Execution / ServerError::Generic            */
+    MI355_E_UNSUPPORTED = 13,          /* IoError::UnsupportedIoOperation / unsupported op     */
+    MI355_E_SERVER_UNHEALTHY = 14,     /* ServerError::ServerUnhealthy{errors}: pop the queue  */
+    MI355_E_COMM = 15,                 /* collective failure (RCCL)                            */
+    MI355_E_NO_DEVICE = 16,            /* no HIP device / HIP runtime unusable                 */
+    MI355_E_PROFILE = 17               /* ProfileError                                         */
+};
+
+/* ---- element types (subset of cubecl_ir::ElemType this path moves) ---------------------- */
+enum {
+    MI355_DTYPE_F32 = 0,
+    MI355_DTYPE_BF16 = 1,
+    MI355_DTYPE_F16 = 2,
+    MI355_DTYPE_F64 = 3,
+    MI355_DTYPE_I32 = 4,
+    MI355_DTYPE_U32 = 5,
+    MI355_DTYPE_I64 = 6,
+    MI355_DTYPE_U64 = 7,
+    MI355_DTYPE_U8 = 8,
+    MI355_DTYPE_I8 = 9
+};
+
+/* ReduceOperation (server/base.rs:623-628) + the two extra ops array-wide argmax needs.
+ * Sum and Mean are the reference's; Max/Min are an API delta. */
+enum { MI355_REDUCE_SUM = 0, MI355_REDUCE_MEAN = 1, MI355_REDUCE_MAX = 2, MI355_REDUCE_MIN = 3 };
+
+typedef struct mi355_ctx mi355_ctx;
+typedef void *mi355_stream;   /* hipStream_t; NULL = the context's compute stream */
+typedef void *mi355_event;    /* hipEvent_t */
+typedef void *mi355_module;   /* hipModule_t */
+typedef void *mi355_function; /* hipFunction_t */
+typedef struct mi355_comm mi355_comm;
+
+/* ---- device description: HardwareProperties / MemoryDeviceProperties / DeviceIdentity /
+ *      Features (crates/cubecl-ir/src/properties.rs:26-108, features.rs:10-32); values for
+ *      gfx950 follow SURVEY.md Appendix C ------------------------------------------------ */
+typedef struct {
+    uint32_t m, n, k;
+    int32_t a_type, b_type, cd_type; /* MI355_DTYPE_* */
+} mi355_mma_config;                  /* cubecl_ir::features::MmaConfig (features.rs:145) */
+
+typedef struct {
+    uint32_t abi_version;
+    int32_t device_index;
+    char name[64];                /* hipDeviceProp_t.name                                   */
+    char gcn_arch_name[64];       /* "gfx950:sramecc+:xnack-"                               */
+    char fingerprint[96];         /* DeviceIdentity.fingerprint: "mi355-aot_<gcnArchName>"  */
+    uint32_t load_width_bits;     /* 128                                                    */
+    uint32_t plane_size_min;      /* 64                                                     */
+    uint32_t plane_size_max;      /* 64                                                     */
+    uint32_t max_bindings;        /* 1024                                                   */
+    uint64_t max_shared_memory_size;   /* bytes of LDS one cube may use                    */
+    uint32_t max_cube_count[3];
+    uint32_t max_units_per_cube;
+    uint32_t max_cube_dim[3];
+    uint32_t num_streaming_multiprocessors; /* CUs (256 on MI355X)                         */
+    uint32_t num_tensor_cores;              /* matrix pipes per CU (4)                     */
+    uint32_t min_tensor_cores_dim;
+    uint32_t num_xcd;                       /* 8: private-L2 chiplets, for XCD-aware grids  */
+    uint64_t total_memory;
+    uint64_t max_page_size;       /* total/4 (crates/cubecl-hip/src/runtime.rs:155-158)     */
+    uint64_t mem_alignment;       /* max(32, texture/surface alignment) (:82,115-116)       */
+    uint32_t clock_khz;
+    uint32_t memory_clock_khz;
+    uint32_t memory_bus_width_bits;
+    uint32_t l2_cache_bytes;
+    uint32_t plane_ops;               /* 1: features.plane has Ops                          */
+    uint32_t plane_non_uniform;       /* 1: NonUniformControlFlow                           */
+    uint32_t timing_method_device;    /* 1: profile() reports GPU time from hipEvents       */
+    uint32_t server_comm_enabled;     /* ServerCommunication::SERVER_COMM_ENABLED (RCCL found) */
+    uint32_t num_mma_configs;
+    mi355_mma_config mma_configs[16]; /* features.matmul.cmma / .mma for gfx950 MFMA        */
+} mi355_device_props_t;
+
+/* =================================== Runtime ============================================= */
+
+int32_t mi355_abi_version(void);
+/* Runtime::enumerate_devices (crates/cubecl-hip/src/runtime.rs:306-327). */
+int32_t mi355_device_count(int32_t *out_count);
+/* DeviceService::init for one DeviceId (crates/cubecl-hip/src/runtime.rs:61-247): selects the
+ * device, refuses anything that is not wave64 gfx950, creates the non-blocking compute stream
+ * and the communication stream, fills the property block. */
+int32_t mi355_ctx_create(int32_t device_index, mi355_ctx **out_ctx);
+int32_t mi355_ctx_destroy(mi355_ctx *ctx);
+int32_t mi355_device_props(mi355_ctx *ctx, mi355_device_props_t *out_props);
+/* message of the most recent failing call on this context (never NULL) */
+const char *mi355_last_error(mi355_ctx *ctx);
+/* ctx == NULL variant for failures of mi355_ctx_create itself */
+const char *mi355_last_global_error(void);
+
+/* ---- queued (asynchronous) errors ------------------------------------------------------- */
+int32_t mi355_error_count(mi355_ctx *ctx, int32_t *out_count);
+/* pops the oldest queued error: code, two numeric details (e.g. requested / max) and text */
+int32_t mi355_error_pop(mi355_ctx *ctx, int32_t *out_code, uint64_t *out_requested,
+                        uint64_t *out_max, char *msg, size_t msg_capacity);
+
+/* =================================== Storage ============================================= */
+
+/* ComputeStorage::alloc (storage/gpu.rs:136-169): plain hipMalloc.  A driver OOM maps to
+ * MI355_E_OUT_OF_MEMORY, a request above max_page_size to MI355_E_BUFFER_TOO_BIG
+ * (server/base.rs:895-911).  bytes == 0 returns a NULL pointer and MI355_OK. */
+int32_t mi355_alloc(mi355_ctx *ctx, uint64_t bytes, void **out_dptr);
+/* ComputeStorage::dealloc: deferred until mi355_flush. */
+int32_t mi355_free(mi355_ctx *ctx, void *dptr);
+int32_t mi355_mem_info(mi355_ctx *ctx, uint64_t *out_free, uint64_t *out_total);
+/* MemoryLayoutPolicy::apply for a rank>=2 tensor (crates/cubecl-runtime/src/allocator.rs:21-72):
+ * returns the row pitch in bytes for rows of `width_bytes`. */
+int32_t mi355_pitched_row_bytes(mi355_ctx *ctx, uint64_t width_bytes, uint64_t *out_pitch);
+/* pinned host staging (crates/cubecl-hip/src/compute/storage/cpu.rs:96-140) */
+int32_t mi355_pinned_alloc(mi355_ctx *ctx, uint64_t bytes, void **out_hptr);
+int32_t mi355_pinned_free(mi355_ctx *ctx, void *hptr);
+
+/* =================================== Streams / events ==================================== */
+
+int32_t mi355_stream_create(mi355_ctx *ctx, mi355_stream *out_stream); /* hipStreamNonBlocking */
+int32_t mi355_stream_destroy(mi355_ctx *ctx, mi355_stream stream);
+int32_t mi355_default_stream(mi355_ctx *ctx, mi355_stream *out_stream);
+int32_t mi355_comm_stream(mi355_ctx *ctx, mi355_stream *out_stream);
+int32_t mi355_event_create(mi355_ctx *ctx, mi355_event *out_event);
+int32_t mi355_event_destroy(mi355_ctx *ctx, mi355_event event);
+int32_t mi355_event_record(mi355_ctx *ctx, mi355_event event, mi355_stream stream);
+/* Fence::wait_async (crates/cubecl-hip/src/compute/fence.rs): hipStreamWaitEvent */
+int32_t mi355_stream_wait_event(mi355_ctx *ctx, mi355_stream stream, mi355_event event);
+/* Fence::wait_sync: hipEventSynchronize */
+int32_t mi355_event_sync(mi355_ctx *ctx, mi355_event event);
+int32_t mi355_event_elapsed_ms(mi355_ctx *ctx, mi355_event start, mi355_event stop,
+                               float *out_ms);
+
+/* =================================== IO =================================================== */
+
+/* ComputeServer::write (command.rs:347-411).  Stream-ordered; `src` must stay valid until the
+ * stream passed the copy (mi355_sync / an event).  bytes == 0 is a no-op. */
+int32_t mi355_write(mi355_ctx *ctx, mi355_stream stream, void *dst_dptr, const void *src_host,
+                    uint64_t bytes);
+/* ComputeServer::read (command.rs:244-265, :538-614): enqueues the D2H copy, waits for it and
+ * reports queued errors (MI355_E_SERVER_UNHEALTHY). */
+int32_t mi355_read(mi355_ctx *ctx, mi355_stream stream, void *dst_host, const void *src_dptr,
+                   uint64_t bytes);
+int32_t mi355_read_async(mi355_ctx *ctx, mi355_stream stream, void *dst_host,
+                         const void *src_dptr, uint64_t bytes);
+/* pitched (2-D) forms used when PitchedMemoryLayoutPolicy padded the rows (command.rs:318-322);
+ * pitches in bytes. */
+int32_t mi355_write_2d(mi355_ctx *ctx, mi355_stream stream, void *dst_dptr, uint64_t dst_pitch,
+                       const void *src_host, uint64_t src_pitch, uint64_t width_bytes,
+                       uint64_t rows);
+int32_t mi355_read_2d(mi355_ctx *ctx, mi355_stream stream, void *dst_host, uint64_t dst_pitch,
+                      const void *src_dptr, uint64_t src_pitch, uint64_t width_bytes,
+                      uint64_t rows);
+int32_t mi355_copy_d2d(mi355_ctx *ctx, mi355_stream stream, void *dst_dptr,
+                       const void *src_dptr, uint64_t bytes);
+int32_t mi355_memset(mi355_ctx *ctx, mi355_stream stream, void *dptr, int32_t byte_value,
+                     uint64_t bytes); /* zeros_array, tensor/handle.rs:199-207 */
+/* ComputeServer::sync: waits for the stream, then reports queued errors. */
+int32_t mi355_sync(mi355_ctx *ctx, mi355_stream stream);
+/* ComputeServer::flush: releases deferred frees whose work has completed, reports queued
+ * errors. Does not block on the device unless frees are pending. */
+int32_t mi355_flush(mi355_ctx *ctx);
+
+/* =================================== Generic launch ====================================== */
+
+/* Loads a gfx950 code object (what hiprtcGetCode would have produced,
+ * crates/cubecl-hip/src/compute/context.rs:334-387).  Failure -> MI355_E_COMPILATION. */
+int32_t mi355_module_load(mi355_ctx *ctx, const void *image, size_t image_bytes,
+                          mi355_module *out_module);
+int32_t mi355_module_unload(mi355_ctx *ctx, mi355_module module);
+int32_t mi355_module_get_function(mi355_ctx *ctx, mi355_module module, const char *name,
+                                  mi355_function *out_function);
+/* ComputeServer::launch -> HipContext::execute_task (context.rs:390-440): the reference device
+ * ABI -- one pointer per buffer binding followed by the `info` pointer
+ * (crates/cubecl-cpp/src/hip/signature.rs:28-62), passed as an array of pointers.
+ * A zero in `grid` makes the launch a no-op (client.rs:880-884).  Resource-limit violations are
+ * queued, not returned (runtime_tests/launch.rs:226-348). */
+int32_t mi355_launch(mi355_ctx *ctx, mi355_stream stream, mi355_function function,
+                     const uint32_t grid[3], const uint32_t block[3], uint32_t shared_mem_bytes,
+                     void *const *buffer_ptrs, uint32_t num_ptrs);
+
+/* =================================== Data generation / casts ============================== */
+
+/* Counter-based uniform fill, bit-identical to oracle_fill_uniform_f32 (oracle/oracle.c):
+ * dst[i] = lo + (hi-lo) * u(seed, tensor, i); output dtype f32 / bf16 / f16 (RNE cast). */
+int32_t mi355_fill_uniform(mi355_ctx *ctx, mi355_stream stream, void *dst, int32_t dtype,
+                           uint64_t n, uint64_t seed, uint64_t tensor, float lo, float hi);
+/* cmma::cast (frontend/cmma.rs:1113-1213) widened to whole buffers: f32 <-> bf16 / f16. */
+int32_t mi355_cast(mi355_ctx *ctx, mi355_stream stream, const void *src, int32_t src_dtype,
+                   void *dst, int32_t dst_dtype, uint64_t n);
+
+/* =================================== GEMM ================================================ */
+
+/* Tiled matmul launch: C[b] = A[b] * B[b] (f32 accumulate), the operation cubek-matmul's
+ * launcher hands to a backend and `cmma::execute` defines per fragment
+ * (crates/cubecl-core/src/frontend/cmma.rs:1066-1110; semantics pinned by
+ * runtime_tests/cmma.rs:695-722).
+ *   trans_a == 0: A is row-major [M][K] (lda >= K)      trans_a == 1: A stored [K][M] (lda >= M)
+ *   trans_b == 0: B is row-major [K][N] (ldb >= N)      trans_b == 1: B stored [N][K] (ldb >= K)
+ *                                                        i.e. Out = Lhs * Rhs^T, the ColMajor-B
+ *                                                        form of the cmma tests (cmma.rs:23)
+ * Batch strides are in elements; 0 broadcasts an operand
+ * (crates/cubecl-std/src/tensor/matrix_batch_layout.rs:21-79).
+ * dtype_ab: F32 (MFMA f32, exact-f32 products), BF16 or F16 (MFMA, f32 accumulate).
+ * dtype_c: F32, or the same 16-bit type as the inputs (RNE on store). */
+typedef struct {
+    int64_t m, n, k, batch;
+    int64_t lda, ldb, ldc;
+    int64_t stride_a, stride_b, stride_c;
+    int32_t dtype_ab, dtype_c;
+    int32_t trans_a, trans_b;
+    int32_t algo;   /* MI355_GEMM_ALGO_*; 0 = pick the fastest kernel that supports the shape */
+    int32_t reserved;
+} mi355_gemm_desc;
+
+enum {
+    MI355_GEMM_ALGO_AUTO = 0,
+    MI355_GEMM_ALGO_GENERIC = 1,  /* bounds-checked scalar-FMA kernel, any shape / layout     */
+    MI355_GEMM_ALGO_F32_MFMA = 2, /* 128x128 LDS-tiled v_mfma_f32_32x32x2_f32                 */
+    MI355_GEMM_ALGO_LP_128 = 3,   /* bf16/f16 128x128x64 LDS-DMA tile, v_mfma_f32_32x32x16     */
+    MI355_GEMM_ALGO_LP_256 = 4    /* bf16/f16 256x256x64 deep-pipelined tile                   */
+};
+
+int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_gemm_desc *desc,
+                   const void *a, const void *b, void *c);
+/* which kernel AUTO resolves to for a descriptor (for tests / logs) */
+int32_t mi355_gemm_select(mi355_ctx *ctx, const mi355_gemm_desc *desc, int32_t *out_algo);
+
+/* =================================== Reductions ========================================== */
+
+/* Bytes of device workspace the array-wide reductions need for `n` elements (one partial
+ * record per workgroup + a ticket word); caller allocates, library never does. */
+int32_t mi355_reduce_workspace_bytes(mi355_ctx *ctx, uint64_t n, uint64_t *out_bytes);
+
+/* Array-wide f32 sum: out[0] = sum_i in[i].  Semantics: examples/sum_things/src/lib.rs:6-19
+ * (acc from 0.0f32) with the summation re-associated as a fixed tree (per-lane chunks ->
+ * wave64 xor butterfly in the order of crates/cubecl-cpp/src/shared/plane.rs:60-70 -> waves ->
+ * workgroups in index order); deterministic run to run.  n == 0 writes 0.0. */
+int32_t mi355_reduce_sum_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, uint64_t n,
+                             float *out, void *workspace, uint64_t workspace_bytes);
+/* Array-wide argmax: out_idx[0] = lowest index of the maximum, out_val[0] = in[out_idx]
+ * (bit copy).  NaN ranks above every number, first NaN wins; -0.0 == +0.0.  n == 0 writes
+ * index 0 and -inf.  Indices are u64 (arrays may exceed 2^32 elements in 288 GB). */
+int32_t mi355_argmax_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, uint64_t n,
+                         float *out_val, uint64_t *out_idx, void *workspace,
+                         uint64_t workspace_bytes);
+/* Both in ONE pass over the data (1x the HBM bytes). Any of out_sum/out_val/out_idx non-NULL. */
+int32_t mi355_sum_argmax_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, uint64_t n,
+                             float *out_sum, float *out_val, uint64_t *out_idx, void *workspace,
+                             uint64_t workspace_bytes);
+/* Sum over the last axis of a [rows, cols] view with row stride `row_stride` elements: the
+ * book's reduce_matrix (cubecl-book/src/getting-started/src/bin/v1-cpu.rs:7-15). */
+int32_t mi355_reduce_last_axis_sum_f32(mi355_ctx *ctx, mi355_stream stream, const float *in,
+                                       float *out, uint64_t rows, uint64_t cols,
+                                       uint64_t row_stride);
+int32_t mi355_reduce_last_axis_argmax_f32(mi355_ctx *ctx, mi355_stream stream, const float *in,
+                                          uint32_t *out_idx, uint64_t rows, uint64_t cols,
+                                          uint64_t row_stride);
+/* plane_sum & friends for one 64-lane plane per 64 inputs (frontend/plane.rs:218-240): every
+ * lane receives the butterfly result over the first `active` lanes (power of two <= 64),
+ * matching plane_dim_checked = min(PLANE_DIM, CUBE_DIM) (shared/plane.rs:55-58).
+ * op = MI355_REDUCE_SUM / MAX / MIN, or 100 for product, 101 inclusive sum, 102 exclusive sum. */
+int32_t mi355_plane_reduce_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, float *out,
+                               uint64_t n, uint32_t active, int32_t op);
+
+/* =================================== Throughput probes =================================== */
+
+/* memory_read_throughput (crates/cubecl-std/src/throughput/runners/memory_read.rs:69-154):
+ * streaming read of `bytes` with a guarded store; returns after enqueueing `iters` passes. */
+int32_t mi355_probe_memory_read(mi355_ctx *ctx, mi355_stream stream, const void *buf,
+                                uint64_t bytes, uint32_t iters, void *sink);
+/* compute_cmma_throughput (runners/compute_cmma.rs:48-91): `iters` dependent MFMAs per wave on
+ * constant fragments; *out_ops receives the op count of one call (2*m*n*k per MFMA). */
+int32_t mi355_probe_mfma(mi355_ctx *ctx, mi355_stream stream, int32_t dtype_ab, uint32_t iters,
+                         void *sink, uint64_t *out_ops);
+
+/* =================================== Collectives (RCCL over xGMI) ======================== */
+
+#define MI355_UNIQUE_ID_BYTES 128
+/* get_nccl_comm_id (crates/cubecl-cuda/src/compute/communication.rs:14-25): rank 0 creates the
+ * id, every rank receives the same bytes out of band. */
+int32_t mi355_comm_unique_id(uint8_t id[MI355_UNIQUE_ID_BYTES]);
+/* ServerCommunication::comm_init (crates/cubecl-cuda/src/compute/server.rs:669-703): rank =
+ * position of this device in the sorted id list. */
+int32_t mi355_comm_init(mi355_ctx *ctx, const uint8_t id[MI355_UNIQUE_ID_BYTES], int32_t rank,
+                        int32_t world_size, mi355_comm **out_comm);
+int32_t mi355_comm_destroy(mi355_ctx *ctx, mi355_comm *comm);
+/* ServerCommunication::all_reduce (server.rs:705-780): fences the compute stream into the comm
+ * stream, then ncclAllReduce on the comm stream.  count in elements of `dtype`. */
+int32_t mi355_all_reduce(mi355_ctx *ctx, mi355_comm *comm, mi355_stream compute_stream,
+                         const void *src, void *dst, uint64_t count, int32_t dtype, int32_t op);
+/* all-gather of `count` elements per rank (argmax pairs) */
+int32_t mi355_all_gather(mi355_ctx *ctx, mi355_comm *comm, mi355_stream compute_stream,
+                         const void *src, void *dst, uint64_t count, int32_t dtype);
+/* ServerCommunication::send / recv (server.rs:799-926) */
+int32_t mi355_send(mi355_ctx *ctx, mi355_comm *comm, mi355_stream compute_stream,
+                   const void *src, uint64_t count, int32_t dtype, int32_t peer);
+int32_t mi355_recv(mi355_ctx *ctx, mi355_comm *comm, mi355_stream compute_stream, void *dst,
+                   uint64_t count, int32_t dtype, int32_t peer);
+/* ServerCommunication::sync_collective (server.rs:782-797): the compute stream waits for the
+ * comm stream. */
+int32_t mi355_sync_collective(mi355_ctx *ctx, mi355_stream compute_stream);
+
+/* =================================== Profiling =========================================== */
+
+/* ComputeServer::start_profile / end_profile (server/base.rs:590-597) with device timing:
+ * brackets the stream with two events; stop returns the elapsed GPU time in nanoseconds. */
+int32_t mi355_profile_start(mi355_ctx *ctx, mi355_stream stream, uint64_t *out_token);
+int32_t mi355_profile_stop(mi355_ctx *ctx, mi355_stream stream, uint64_t token,
+                           uint64_t *out_nanos);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355CUBE_H */

@@ -1,0 +1,197 @@
+"""ctypes + numpy front-end of oracle/liboracle.so (the C restatement of the reference path).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg -- never by cubecl_amd (the product path).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_DIR = Path(__file__).resolve().parent
+LIB_PATH = _DIR / "liboracle.so"
+SEED = 0x5EEDC0BE
+DT_F32, DT_BF16, DT_F16 = 0, 1, 2
+
+_lib = None
+
+
+def build() -> None:
+    subprocess.run(["make", "-C", str(_DIR), "-s"], check=True)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        build()
+    L = C.CDLL(str(LIB_PATH))
+    P, u64, i64, i32, f32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_int, C.c_float
+    L.oracle_fill_uniform_f32.argtypes = [P, u64, u64, u64, f32, f32]
+    L.oracle_fill_uniform_f32.restype = None
+    for name in ("oracle_convert_f32_to_bf16", "oracle_convert_f32_to_f16", "oracle_convert_bf16_to_f32",
+                 "oracle_convert_f16_to_f32"):
+        getattr(L, name).argtypes = [P, P, u64]
+        getattr(L, name).restype = None
+    L.oracle_gemm.argtypes = [P, P, P, i32, i32, i64, i64, i64, i64, i64, i64, i32, i64, i64, i64, i64, i32]
+    L.oracle_gemm.restype = None
+    L.oracle_sum_f32_sequential.argtypes = [P, u64]
+    L.oracle_sum_f32_sequential.restype = f32
+    L.oracle_sum_f32_f64.argtypes = [P, u64]
+    L.oracle_sum_f32_f64.restype = C.c_double
+    L.oracle_sum_abs_f32_f64.argtypes = [P, u64]
+    L.oracle_sum_abs_f32_f64.restype = C.c_double
+    L.oracle_reduce_last_axis_sum_f32.argtypes = [P, P, u64, u64, u64]
+    L.oracle_reduce_last_axis_sum_f32.restype = None
+    L.oracle_reduce_last_axis_sum_f64.argtypes = [P, P, u64, u64, u64]
+    L.oracle_reduce_last_axis_sum_f64.restype = None
+    L.oracle_argmax_f32.argtypes = [P, u64, C.POINTER(f32)]
+    L.oracle_argmax_f32.restype = u64
+    L.oracle_argmax_key.argtypes = [f32]
+    L.oracle_argmax_key.restype = C.c_uint32
+    L.oracle_reduce_last_axis_argmax_f32.argtypes = [P, P, u64, u64, u64]
+    L.oracle_reduce_last_axis_argmax_f32.restype = None
+    L.oracle_plane_reduce_f32.argtypes = [P, C.c_uint32, i32]
+    L.oracle_plane_reduce_f32.restype = None
+    L.oracle_plane_inclusive_sum_f32.argtypes = [P, C.c_uint32]
+    L.oracle_plane_inclusive_sum_f32.restype = None
+    L.oracle_cpu_sum_argmax_f32.argtypes = [P, u64, i32, C.POINTER(f32), C.POINTER(u64)]
+    L.oracle_cpu_sum_argmax_f32.restype = C.c_double
+    L.oracle_cpu_gemm.argtypes = [P, P, P, i32, i32, i64, i64, i64, i64, i64, i64, i32, i32]
+    L.oracle_cpu_gemm.restype = C.c_double
+    _lib = L
+    return L
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def fill_uniform(n: int, tensor: int, lo: float, hi: float, seed: int = SEED) -> np.ndarray:
+    out = np.empty(n, dtype=np.float32)
+    lib().oracle_fill_uniform_f32(_p(out), n, seed, tensor, lo, hi)
+    return out
+
+
+def to_bf16(x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty(x.shape, dtype=np.uint16)
+    lib().oracle_convert_f32_to_bf16(_p(x), _p(out), x.size)
+    return out
+
+
+def to_f16(x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty(x.shape, dtype=np.uint16)
+    lib().oracle_convert_f32_to_f16(_p(x), _p(out), x.size)
+    return out
+
+
+def from_bf16(x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.uint16)
+    out = np.empty(x.shape, dtype=np.float32)
+    lib().oracle_convert_bf16_to_f32(_p(x), _p(out), x.size)
+    return out
+
+
+def from_f16(x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.uint16)
+    out = np.empty(x.shape, dtype=np.float32)
+    lib().oracle_convert_f16_to_f32(_p(x), _p(out), x.size)
+    return out
+
+
+_NP_OF = {DT_F32: np.float32, DT_BF16: np.uint16, DT_F16: np.uint16}
+
+
+def gemm(a: np.ndarray, b: np.ndarray, m: int, n: int, k: int, *, dtype_ab: int = DT_F32, dtype_c: int = DT_F32,
+         lda: int | None = None, ldb: int | None = None, ldc: int | None = None, trans_b: bool = False,
+         batch: int = 1, stride_a: int | None = None, stride_b: int | None = None, stride_c: int | None = None,
+         acc_f64: bool = False) -> np.ndarray:
+    """C = A * B (or A * B^T with trans_b) following runtime_tests/cmma.rs:695-722."""
+    a = np.ascontiguousarray(a, dtype=_NP_OF[dtype_ab]).reshape(-1)
+    b = np.ascontiguousarray(b, dtype=_NP_OF[dtype_ab]).reshape(-1)
+    lda = k if lda is None else lda
+    ldb = (k if trans_b else n) if ldb is None else ldb
+    ldc = n if ldc is None else ldc
+    stride_a = m * lda if stride_a is None else stride_a
+    stride_b = ((n if trans_b else k) * ldb) if stride_b is None else stride_b
+    stride_c = m * ldc if stride_c is None else stride_c
+    c = np.zeros(max(batch * stride_c, m * ldc), dtype=_NP_OF[dtype_c])
+    lib().oracle_gemm(_p(a), _p(b), _p(c), dtype_ab, dtype_c, m, n, k, lda, ldb, ldc, int(trans_b), batch,
+                      stride_a, stride_b, stride_c, int(acc_f64))
+    return c
+
+
+def sum_sequential(x: np.ndarray) -> float:
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    return float(lib().oracle_sum_f32_sequential(_p(x), x.size))
+
+
+def sum_f64(x: np.ndarray) -> float:
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    return float(lib().oracle_sum_f32_f64(_p(x), x.size))
+
+
+def sum_abs_f64(x: np.ndarray) -> float:
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    return float(lib().oracle_sum_abs_f32_f64(_p(x), x.size))
+
+
+def argmax(x: np.ndarray):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    val = C.c_float()
+    idx = lib().oracle_argmax_f32(_p(x), x.size, C.byref(val))
+    return int(idx), np.float32(val.value)
+
+
+def reduce_last_axis_sum(x: np.ndarray, f64: bool = False) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    rows, cols = (int(np.prod(x.shape[:-1])), x.shape[-1])
+    if f64:
+        out = np.empty(rows, dtype=np.float64)
+        lib().oracle_reduce_last_axis_sum_f64(_p(x), _p(out), rows, cols, cols)
+    else:
+        out = np.empty(rows, dtype=np.float32)
+        lib().oracle_reduce_last_axis_sum_f32(_p(x), _p(out), rows, cols, cols)
+    return out.reshape(x.shape[:-1])
+
+
+def reduce_last_axis_argmax(x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    rows, cols = (int(np.prod(x.shape[:-1])), x.shape[-1])
+    out = np.empty(rows, dtype=np.uint32)
+    lib().oracle_reduce_last_axis_argmax_f32(_p(x), _p(out), rows, cols, cols)
+    return out.reshape(x.shape[:-1])
+
+
+def plane_reduce(vals: np.ndarray, op: int) -> np.ndarray:
+    v = np.ascontiguousarray(vals, dtype=np.float32).copy()
+    lib().oracle_plane_reduce_f32(_p(v), v.size, op)
+    return v
+
+
+def plane_inclusive_sum(vals: np.ndarray) -> np.ndarray:
+    v = np.ascontiguousarray(vals, dtype=np.float32).copy()
+    lib().oracle_plane_inclusive_sum_f32(_p(v), v.size)
+    return v
+
+
+def cpu_sum_argmax(x: np.ndarray, units: int):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    s, i = C.c_float(), C.c_uint64()
+    secs = lib().oracle_cpu_sum_argmax_f32(_p(x), x.size, units, C.byref(s), C.byref(i))
+    return secs, float(s.value), int(i.value)
+
+
+def cpu_gemm(a, b, m, n, k, *, dtype_ab=DT_F32, dtype_c=DT_F32, trans_b=False, units=1):
+    a = np.ascontiguousarray(a, dtype=_NP_OF[dtype_ab]).reshape(-1)
+    b = np.ascontiguousarray(b, dtype=_NP_OF[dtype_ab]).reshape(-1)
+    c = np.zeros(m * n, dtype=_NP_OF[dtype_c])
+    secs = lib().oracle_cpu_gemm(_p(a), _p(b), _p(c), dtype_ab, dtype_c, m, n, k, k, (k if trans_b else n), n,
+                                 int(trans_b), units)
+    return secs, c

@@ -1,0 +1,66 @@
+"""CPU-side checks of the drop-in boundary: the library loads without a GPU, exports every symbol
+include/mi355cube.h declares, and refuses to run (loudly) when there is no device."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from cubecl_amd import _native as N
+
+
+def test_library_loads_and_exports_every_header_symbol():
+    lib = N.load()
+    declared = N.header_symbols()
+    assert len(declared) >= 55
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/mi355cube.h but not exported"
+    assert set(declared) == set(N.PROTOTYPES), set(declared) ^ set(N.PROTOTYPES)
+    assert lib.mi355_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    # sizes the C side computes for the same structs (guards against ctypes/header drift)
+    assert C.sizeof(N.GemmDesc) == 10 * 8 + 6 * 4
+    assert C.sizeof(N.MmaConfig) == 24
+    assert C.sizeof(N.DeviceProps) % 8 == 0
+    assert N.DeviceProps.mma_configs.offset % 4 == 0
+
+
+def test_no_device_is_a_loud_error_not_a_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = N.load()
+    ctx = C.c_void_p()
+    rc = lib.mi355_ctx_create(0, C.byref(ctx))
+    assert rc == N.E_NO_DEVICE and not ctx.value
+    assert b"HIP device" in lib.mi355_last_global_error() or b"hip" in lib.mi355_last_global_error().lower()
+    from cubecl_amd import Mi355Runtime, ServerError
+    with pytest.raises(ServerError):
+        Mi355Runtime.client()
+
+
+def test_null_context_is_rejected():
+    lib = N.load()
+    out = C.c_void_p()
+    assert lib.mi355_alloc(None, 16, C.byref(out)) == N.E_INVALID_ARGUMENT
+    assert lib.mi355_flush(None) == N.E_INVALID_ARGUMENT
+    assert lib.mi355_gemm(None, None, None, None, None, None) == N.E_INVALID_ARGUMENT
+
+
+def test_missing_library_raises(monkeypatch, tmp_path):
+    monkeypatch.setattr(N, "_lib", None)
+    monkeypatch.setenv("MI355CUBE_LIB", str(tmp_path / "nope.so"))
+    with pytest.raises(N.NativeLibraryError):
+        N.load()
+    monkeypatch.delenv("MI355CUBE_LIB")
+    monkeypatch.setattr(N, "_lib", None)
+    N.load()
+
+
+def test_product_package_never_imports_the_oracle():
+    import pathlib
+    root = pathlib.Path(N.__file__).resolve().parent
+    for path in list(root.rglob("*.py")) + list(root.rglob("*.hip")) + list(root.rglob("*.cpp")) + list(root.rglob("*.hpp")):
+        text = path.read_text()
+        assert "import oracle" not in text and "from oracle" not in text and "liboracle" not in text, path

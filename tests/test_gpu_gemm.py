@@ -1,0 +1,229 @@
+"""Parity of the HIP GEMM kernels with the CPU oracle through the C ABI.
+
+Tolerances (written here, per BASELINE.json "within 1e-5 relative for f32"):
+  * integer-valued known-answer vectors of the reference: exact (assert_eq! in the reference);
+  * f32 outputs: |C - C_ref| <= 1e-5 * (|A| |B|)_ij, C_ref accumulated in f64 from the same
+    (already rounded) inputs -- MFMA products are exact in f32, only the summation order differs;
+  * 16-bit outputs: within one unit in the last place of the 16-bit format.
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from cubecl_amd import ElemType, ServerError, TensorHandle, ops
+from cubecl_amd import _native as N
+
+pytestmark = pytest.mark.gpu
+GOLD = json.loads((Path(__file__).parent / "golden" / "reference_goldens.json").read_text())
+REL = 1e-5
+ALGOS = {"auto": N.GEMM_ALGO_AUTO, "generic": N.GEMM_ALGO_GENERIC, "f32": N.GEMM_ALGO_F32_MFMA,
+         "lp128": N.GEMM_ALGO_LP_128, "lp256": N.GEMM_ALGO_LP_256}
+
+
+def _to_dev(client, oracle, x, dtype):
+    if dtype == ElemType.F32:
+        return TensorHandle.from_numpy(client, x.astype(np.float32)), x.astype(np.float32)
+    bits = oracle.to_bf16(x) if dtype == ElemType.BF16 else oracle.to_f16(x)
+    back = oracle.from_bf16(bits) if dtype == ElemType.BF16 else oracle.from_f16(bits)
+    return TensorHandle.from_numpy(client, bits, dtype), back
+
+
+def _decode(oracle, arr, dtype):
+    if dtype == ElemType.F32:
+        return arr.astype(np.float64)
+    return (oracle.from_bf16(arr) if dtype == ElemType.BF16 else oracle.from_f16(arr.view(np.uint16))).astype(np.float64)
+
+
+def run_case(client, oracle, m, n, k, dtype, out_dtype, trans_b, algo, *, lda=None, ldb=None, ldc=None, batch=1,
+             bcast_b=False, seed_t=50):
+    """Random [-1,1) operands; returns nothing, asserts parity."""
+    lda = lda or k
+    ldb = ldb or (k if trans_b else n)
+    ldc = ldc or n
+    rows_b = n if trans_b else k
+    a_host = oracle.fill_uniform(batch * m * lda, seed_t, -1.0, 1.0).reshape(batch, m, lda)
+    b_host = oracle.fill_uniform((1 if bcast_b else batch) * rows_b * ldb, seed_t + 1, -1.0, 1.0).reshape(-1, rows_b, ldb)
+    ta, a_val = _to_dev(client, oracle, a_host, dtype)
+    tb, b_val = _to_dev(client, oracle, b_host, dtype)
+    a_t = TensorHandle.new(ta.handle, (batch, m, k), (m * lda, lda, 1), dtype)
+    if trans_b:   # logical [k, n] stored [n][k]
+        b_t = TensorHandle.new(tb.handle, (batch, k, n), (0 if bcast_b else n * ldb, 1, ldb), dtype)
+    else:
+        b_t = TensorHandle.new(tb.handle, (batch, k, n), (0 if bcast_b else k * ldb, ldb, 1), dtype)
+    c_h = client.empty(batch * m * ldc * out_dtype.size())
+    client._s.check(client.lib.mi355_memset(client.ctx, None, c_h.device_ptr(), 0xEE, c_h.size))
+    c_t = TensorHandle.new(c_h, (batch, m, n), (m * ldc, ldc, 1), out_dtype)
+    ops.matmul(client, a_t, b_t, c_t, algo=algo)
+    raw = client.read_one(c_h)
+    np_dt = np.float32 if out_dtype == ElemType.F32 else np.uint16
+    got_all = raw.view(np_dt).reshape(batch, m, ldc)
+    for b in range(batch):
+        A = a_val[b][:, :k].astype(np.float64)
+        Bm = b_val[0 if bcast_b else b]
+        Bm = (Bm[:, :k].T if trans_b else Bm[:, :n]).astype(np.float64)
+        ref = A @ Bm
+        bound = np.abs(A) @ np.abs(Bm)
+        got = _decode(oracle, got_all[b][:, :n], out_dtype)
+        if out_dtype == ElemType.F32:
+            err = np.abs(got - ref)
+            assert np.all(err <= REL * bound + 1e-30), (float(err.max()), float((err / (bound + 1e-30)).max()))
+        else:
+            ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(ref), 1e-30))) - (7 if out_dtype == ElemType.BF16 else 10))
+            assert np.all(np.abs(got - ref) <= ulp + REL * bound)
+        if ldc > n:   # padding columns untouched
+            pad = got_all[b][:, n:]
+            assert np.all(pad.view(np.uint8) == 0xEE)
+
+
+# ---- the reference's own known-answer vectors through the device path ------------------------------------
+@pytest.mark.parametrize("algo", ["auto", "generic"])
+def test_cmma_simple_1_golden(client, oracle, algo):
+    lhs = oracle.to_f16(np.arange(256, dtype=np.float32))
+    rhs = oracle.to_f16((np.arange(256) % 8).astype(np.float32))
+    a = TensorHandle.new(client.create_from_slice(lhs), (16, 16), (16, 1), ElemType.F16)
+    b = TensorHandle.new(client.create_from_slice(rhs), (16, 16), (1, 16), ElemType.F16)   # ColMajor B (cmma.rs:23)
+    c = TensorHandle.new_contiguous((16, 16), client.empty(1024), ElemType.F32)
+    ops.matmul(client, a, b, c, algo=ALGOS[algo])
+    assert c.to_numpy(client).reshape(-1).tolist() == GOLD["cmma_simple_1_f16_16x16x16_nt"]
+
+
+def test_cmma_tf32_golden_runs_as_exact_f32(client):
+    lhs = np.arange(128, dtype=np.float32)
+    rhs = (np.arange(128) % 8).astype(np.float32)
+    a = TensorHandle.new(client.create_from_slice(lhs), (16, 8), (8, 1), ElemType.F32)
+    b = TensorHandle.new(client.create_from_slice(rhs), (8, 16), (16, 1), ElemType.F32)
+    c = TensorHandle.new_contiguous((16, 16), client.empty(1024), ElemType.F32)
+    ops.matmul(client, a, b, c)
+    assert c.to_numpy(client).reshape(-1).tolist() == GOLD["cmma_simple_tf32_16x16x8_nn"]
+
+
+def test_cmma_strided_golden(client, oracle):
+    m, n, k, tk = 16, 16, 32, 16
+    i = np.arange(m * k)
+    lhs = np.where((i % k) < tk, i - (i // k) * tk, 0).astype(np.float32)
+    rhs = (np.arange(n * k) % 8).astype(np.float32)
+    a = TensorHandle.new(client.create_from_slice(oracle.to_f16(lhs)), (16, 16), (32, 1), ElemType.F16)
+    b = TensorHandle.new(client.create_from_slice(oracle.to_f16(rhs)), (16, 16), (1, 16), ElemType.F16)
+    c = TensorHandle.new_contiguous((16, 16), client.empty(1024), ElemType.F32)
+    ops.matmul(client, a, b, c)
+    assert c.to_numpy(client).reshape(-1).tolist() == GOLD["cmma_strided_f16_16x16x16_nt"]
+
+
+@pytest.mark.parametrize("dtype", [ElemType.F16, ElemType.BF16])
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 128, 128), (64, 64, 64)])
+def test_cmma_cube_expectation_on_mfma(client, oracle, dtype, m, n, k):
+    # test_simple_cube_expected (cmma.rs:695-722) at MFMA-kernel sizes; values stay exactly
+    # representable (lhs = i % 64, rhs = i % 8) so the comparison is exact like assert_eq!
+    lhs = (np.arange(m * k) % 64).astype(np.float32)
+    rhs = (np.arange(n * k) % 8).astype(np.float32)
+    conv = oracle.to_f16 if dtype == ElemType.F16 else oracle.to_bf16
+    a = TensorHandle.new(client.create_from_slice(conv(lhs)), (m, k), (k, 1), dtype)
+    b = TensorHandle.new(client.create_from_slice(conv(rhs)), (k, n), (1, k), dtype)
+    c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 4), ElemType.F32)
+    ops.matmul(client, a, b, c)
+    expected = oracle.gemm(conv(lhs), conv(rhs), m, n, k, dtype_ab=int(dtype), trans_b=True)
+    assert np.array_equal(c.to_numpy(client).reshape(-1), expected)
+
+
+@pytest.mark.parametrize("dtype", [ElemType.F32, ElemType.BF16])
+def test_cmma_manual_row_major_values(client, oracle, dtype):
+    # test_cmma_manual (cmma.rs:1127-1177): (2i + j) x (3i + j), row-major B
+    m, n, k = 32, 32, 16
+    lhs = np.array([[2 * i + j for j in range(k)] for i in range(m)], dtype=np.float32)
+    rhs = np.array([[3 * i + j for j in range(n)] for i in range(k)], dtype=np.float32)
+    ta, _ = _to_dev(client, oracle, lhs, dtype)
+    tb, _ = _to_dev(client, oracle, rhs, dtype)
+    c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 4), ElemType.F32)
+    ops.matmul(client, TensorHandle.new(ta.handle, (m, k), (k, 1), dtype), TensorHandle.new(tb.handle, (k, n), (n, 1), dtype), c)
+    expected = (lhs.astype(np.int64) @ rhs.astype(np.int64)).astype(np.float64)
+    got = c.to_numpy(client).astype(np.float64)
+    assert np.all(np.abs(got - expected) <= 0.03 * expected + 1e-9)      # the reference's 3 % (:1183)
+    if dtype == ElemType.F32:
+        assert np.array_equal(got, expected)
+
+
+# ---- transpose-detecting structural checks (guide: "A=I with ASYMMETRIC B") --------------------------------
+@pytest.mark.parametrize("algo,dtype,trans_b", [("f32", ElemType.F32, True), ("f32", ElemType.F32, False),
+                                                 ("lp128", ElemType.BF16, True), ("lp128", ElemType.F16, True),
+                                                 ("generic", ElemType.BF16, False)])
+def test_identity_times_asymmetric(client, oracle, algo, dtype, trans_b):
+    m = n = k = 256
+    eye = np.eye(m, dtype=np.float32)
+    bmat = (np.arange(k)[:, None] * 3 + np.arange(n)[None, :] * 7) % 251       # [k][n], asymmetric, exact in bf16
+    bmat = bmat.astype(np.float32)
+    ta, _ = _to_dev(client, oracle, eye, dtype)
+    stored = np.ascontiguousarray(bmat.T) if trans_b else bmat
+    tb, _ = _to_dev(client, oracle, stored, dtype)
+    b_t = TensorHandle.new(tb.handle, (k, n), (1, k) if trans_b else (n, 1), dtype)
+    c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 4), ElemType.F32)
+    ops.matmul(client, TensorHandle.new(ta.handle, (m, k), (k, 1), dtype), b_t, c, algo=ALGOS[algo])
+    assert np.array_equal(c.to_numpy(client), bmat)
+
+
+# ---- random-data parity per kernel -----------------------------------------------------------------------------
+F32_CASES = [(128, 128, 32), (256, 384, 128), (512, 512, 512), (200, 136, 64), (1, 128, 64), (129, 1, 96), (64, 520, 32)]
+
+
+@pytest.mark.parametrize("m,n,k", F32_CASES)
+@pytest.mark.parametrize("trans_b", [True, False])
+def test_f32_mfma_parity(client, oracle, m, n, k, trans_b):
+    if not trans_b and n % 4:
+        pytest.skip("row-major B needs N % 4 == 0 on the MFMA kernel (falls back to generic)")
+    run_case(client, oracle, m, n, k, ElemType.F32, ElemType.F32, trans_b, ALGOS["f32"])
+
+
+LP_CASES = [(128, 128, 64), (256, 256, 128), (384, 256, 512), (200, 136, 64), (1, 128, 128), (130, 2, 64), (64, 520, 192)]
+
+
+@pytest.mark.parametrize("m,n,k", LP_CASES)
+@pytest.mark.parametrize("dtype", [ElemType.BF16, ElemType.F16])
+@pytest.mark.parametrize("out", ["f32", "same"])
+def test_lp128_parity(client, oracle, m, n, k, dtype, out):
+    run_case(client, oracle, m, n, k, dtype, ElemType.F32 if out == "f32" else dtype, True, ALGOS["lp128"])
+
+
+@pytest.mark.parametrize("dtype,out,trans_b", [(ElemType.F32, ElemType.F32, False), (ElemType.F32, ElemType.F32, True),
+                                               (ElemType.BF16, ElemType.F32, False), (ElemType.BF16, ElemType.BF16, True),
+                                               (ElemType.F16, ElemType.F16, False)])
+@pytest.mark.parametrize("m,n,k", [(65, 67, 19), (3, 5, 1), (130, 64, 100)])
+def test_generic_parity_any_shape(client, oracle, dtype, out, trans_b, m, n, k):
+    run_case(client, oracle, m, n, k, dtype, out, trans_b, ALGOS["generic"])
+
+
+def test_padded_leading_dimensions_and_untouched_padding(client, oracle):
+    run_case(client, oracle, 256, 128, 128, ElemType.F32, ElemType.F32, True, ALGOS["auto"], lda=136, ldb=132, ldc=140)
+    run_case(client, oracle, 256, 128, 128, ElemType.BF16, ElemType.F32, True, ALGOS["auto"], lda=136, ldb=144, ldc=132)
+    run_case(client, oracle, 128, 256, 64, ElemType.BF16, ElemType.BF16, True, ALGOS["auto"], lda=72, ldb=64, ldc=264)
+    run_case(client, oracle, 128, 128, 64, ElemType.F32, ElemType.F32, False, ALGOS["auto"], lda=64, ldb=132, ldc=128)
+
+
+def test_batched_and_broadcast(client, oracle):
+    run_case(client, oracle, 128, 128, 64, ElemType.BF16, ElemType.F32, True, ALGOS["auto"], batch=5)
+    run_case(client, oracle, 128, 256, 64, ElemType.BF16, ElemType.BF16, True, ALGOS["auto"], batch=3, bcast_b=True)
+    run_case(client, oracle, 128, 128, 32, ElemType.F32, ElemType.F32, False, ALGOS["auto"], batch=4)
+    run_case(client, oracle, 40, 24, 20, ElemType.F32, ElemType.F32, True, ALGOS["auto"], batch=2, bcast_b=True)
+
+
+def test_auto_selection_and_errors(client):
+    d = N.GemmDesc(m=4096, n=4096, k=4096, batch=1, lda=4096, ldb=4096, ldc=4096, dtype_ab=N.DTYPE_F32,
+                   dtype_c=N.DTYPE_F32, trans_b=1)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_F32_MFMA
+    d = N.GemmDesc(m=2048, n=2048, k=2048, batch=1, lda=2048, ldb=2048, ldc=2048, dtype_ab=N.DTYPE_BF16,
+                   dtype_c=N.DTYPE_BF16, trans_b=1)
+    assert ops.gemm_select(client, d) in (N.GEMM_ALGO_LP_128, N.GEMM_ALGO_LP_256)
+    d = N.GemmDesc(m=100, n=100, k=7, batch=1, lda=7, ldb=7, ldc=100, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_F32, trans_b=1)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_GENERIC
+    a = TensorHandle.new_contiguous((8, 8), client.empty(256), ElemType.F32)
+    with pytest.raises(ServerError) as e:
+        ops.matmul(client, a, TensorHandle.new_contiguous((4, 8), client.empty(128), ElemType.F32), a)
+    assert e.value.code == N.E_INVALID_ARGUMENT
+    with pytest.raises(ServerError) as e:   # lda smaller than the row
+        ops.matmul(client, TensorHandle.new(a.handle, (8, 8), (4, 1), ElemType.F32), a, a)
+    assert e.value.code in (N.E_UNSUPPORTED_STRIDES, N.E_INVALID_ARGUMENT)
+    # K == 0 writes zeros
+    c = TensorHandle.new_contiguous((8, 8), client.create_from_slice(np.ones(64, dtype=np.float32)), ElemType.F32)
+    ops.matmul(client, TensorHandle.new_contiguous((8, 0), client.empty(0), ElemType.F32),
+               TensorHandle.new_contiguous((0, 8), client.empty(0), ElemType.F32), c)
+    assert not c.to_numpy(client).any()

@@ -1,0 +1,215 @@
+"""Parity of the HIP reductions with the CPU oracle through the C ABI (bit-exact indices,
+1e-5 relative sums -- BASELINE.json)."""
+import numpy as np
+import pytest
+
+from cubecl_amd import ElemType, ServerError, TensorHandle, ops
+from cubecl_amd import _native as N
+
+pytestmark = pytest.mark.gpu
+SEED = 0x5EEDC0BE
+REL = 1e-5   # BASELINE.json: f32 outputs within 1e-5 relative of the CPU oracle
+
+SIZES = [0, 1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 1023, 8191, 8192, 8193, 100_003, 1 << 20, 3_000_001]
+
+
+def _scalar(client, dtype):
+    return TensorHandle.new_contiguous((1,), client.empty(8), dtype)
+
+
+def test_fill_uniform_is_bit_identical_to_oracle(client, oracle):
+    n = 1_000_003
+    for tensor, lo, hi in ((1, 0.0, 1.0), (2, -1.0, 1.0), (9, -3.5, 0.25)):
+        ref = oracle.fill_uniform(n, tensor, lo, hi)
+        t = TensorHandle.uniform(client, (n,), ElemType.F32, SEED, tensor, lo, hi)
+        assert np.array_equal(t.to_numpy(client).view(np.uint32), ref.view(np.uint32))
+    ref = oracle.fill_uniform(n, 4, -1.0, 1.0)
+    t = TensorHandle.uniform(client, (n,), ElemType.BF16, SEED, 4, -1.0, 1.0)
+    assert np.array_equal(t.to_numpy(client), oracle.to_bf16(ref))
+    t = TensorHandle.uniform(client, (n,), ElemType.F16, SEED, 4, -1.0, 1.0)
+    assert np.array_equal(t.to_numpy(client).view(np.uint16), oracle.to_f16(ref))
+
+
+def test_cast_matches_oracle(client, oracle):
+    import ctypes as C
+    x = np.concatenate([oracle.fill_uniform(100_000, 5, -1000.0, 1000.0), np.arange(256, dtype=np.float32)])
+    src = TensorHandle.from_numpy(client, x)
+    for dt, conv in ((ElemType.BF16, oracle.to_bf16), (ElemType.F16, oracle.to_f16)):
+        dst = client.empty(x.size * 2)
+        client._s.check(client.lib.mi355_cast(client.ctx, None, C.c_void_p(src.device_ptr()), N.DTYPE_F32,
+                                              C.c_void_p(dst.device_ptr()), int(dt), x.size))
+        assert np.array_equal(client.read_one(dst).view(np.uint16), conv(x))  # cmma.rs:766-832
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_sum_matches_f64_oracle(client, oracle, n):
+    x = oracle.fill_uniform(n, 11, 0.0, 1.0)
+    t = TensorHandle.from_numpy(client, x) if n else TensorHandle.new_contiguous((0,), client.empty(0), ElemType.F32)
+    out = _scalar(client, ElemType.F32)
+    ops.reduce_sum(client, t, out)
+    got = float(out.to_numpy(client)[0])
+    exact = oracle.sum_f64(x)
+    assert abs(got - exact) <= REL * max(abs(exact), 1e-30) or n == 0 and got == 0.0
+    # signed data: error relative to sum |x|
+    y = oracle.fill_uniform(n, 12, -1.0, 1.0)
+    if n:
+        ops.reduce_sum(client, TensorHandle.from_numpy(client, y), out)
+        assert abs(float(out.to_numpy(client)[0]) - oracle.sum_f64(y)) <= REL * oracle.sum_abs_f64(y)
+
+
+def test_sum_things_config_c1(client, oracle):
+    # BASELINE config 1: 1 Mi-element f32 sum; and the example's own input
+    x = (np.arange(1 << 20) % 17).astype(np.float32)
+    out = _scalar(client, ElemType.F32)
+    ops.reduce_sum(client, TensorHandle.from_numpy(client, x), out)
+    assert float(out.to_numpy(client)[0]) == float(x.astype(np.float64).sum())  # integers: exact
+    ops.reduce_sum(client, TensorHandle.from_numpy(client, np.array([-1, 10, 1, 5], dtype=np.float32)), out)
+    assert float(out.to_numpy(client)[0]) == 15.0
+
+
+def test_sum_is_deterministic_and_handles_misaligned_views(client, oracle):
+    x = oracle.fill_uniform(2_000_000, 13, -1.0, 1.0)
+    t = TensorHandle.from_numpy(client, x)
+    out = _scalar(client, ElemType.F32)
+    bits = set()
+    for _ in range(5):
+        ops.reduce_sum(client, t, out)
+        bits.add(int(out.to_numpy(client).view(np.uint32)[0]))
+    assert len(bits) == 1
+    for skip in (1, 2, 3, 5):
+        view = TensorHandle.new_contiguous((x.size - skip,), t.handle.offset_start_by(4 * skip), ElemType.F32)
+        ops.reduce_sum(client, view, out)
+        ref = oracle.sum_f64(x[skip:])
+        assert abs(float(out.to_numpy(client)[0]) - ref) <= REL * oracle.sum_abs_f64(x[skip:])
+        idx = _scalar(client, ElemType.U64)
+        ops.argmax(client, view, idx)
+        assert int(idx.to_numpy(client)[0]) == oracle.argmax(x[skip:])[0]
+
+
+@pytest.mark.parametrize("n", [s for s in SIZES if s])
+def test_argmax_bit_exact(client, oracle, n):
+    x = oracle.fill_uniform(n, 21, -1.0, 1.0)
+    idx, val = _scalar(client, ElemType.U64), _scalar(client, ElemType.F32)
+    ops.argmax(client, TensorHandle.from_numpy(client, x), idx, val)
+    ref_i, ref_v = oracle.argmax(x)
+    assert int(idx.to_numpy(client)[0]) == ref_i
+    assert val.to_numpy(client).view(np.uint32)[0] == np.float32(ref_v).view(np.uint32)
+
+
+def test_argmax_tie_nan_and_zero_rules(client, oracle):
+    idx, val = _scalar(client, ElemType.U64), _scalar(client, ElemType.F32)
+
+    def run(x):
+        ops.argmax(client, TensorHandle.from_numpy(client, np.asarray(x, dtype=np.float32)), idx, val)
+        return int(idx.to_numpy(client)[0])
+
+    n = 1_000_003
+    x = oracle.fill_uniform(n, 22, 0.0, 1.0)
+    for a, b in ((17, 900_001), (900_001, 17), (8191, 8192), (n - 1, 0), (123_456, 123_457)):
+        y = x.copy(); y[a] = 2.0; y[b] = 2.0          # planted maximum duplicated at two indices
+        assert run(y) == min(a, b) == oracle.argmax(y)[0]
+    y = x.copy(); y[777_777] = np.nan; y[999_999] = np.nan; y[5] = 3.0
+    assert run(y) == 777_777 == oracle.argmax(y)[0]    # NaN ranks highest, first NaN wins
+    y = -x - 1.0; y[300] = -0.0; y[100_000] = 0.0
+    assert run(y) == 300 == oracle.argmax(y)[0]        # -0.0 == +0.0 -> lowest index
+    assert run(np.full(70_001, -np.inf)) == 0
+    assert run(np.full(70_001, 4.25)) == 0
+    y = np.full(100_000, -np.inf, dtype=np.float32); y[99_999] = -3.4e38
+    assert run(y) == 99_999
+    # empty input: identity
+    ops.argmax(client, TensorHandle.new_contiguous((0,), client.empty(0), ElemType.F32), idx, val)
+    assert int(idx.to_numpy(client)[0]) == 0 and val.to_numpy(client)[0] == -np.inf
+
+
+def test_fused_sum_argmax_equals_separate(client, oracle):
+    x = oracle.fill_uniform(5_000_011, 23, -1.0, 1.0)
+    t = TensorHandle.from_numpy(client, x)
+    s1, s2 = _scalar(client, ElemType.F32), _scalar(client, ElemType.F32)
+    i1, i2 = _scalar(client, ElemType.U64), _scalar(client, ElemType.U64)
+    v2 = _scalar(client, ElemType.F32)
+    ops.reduce_sum(client, t, s1)
+    ops.argmax(client, t, i1)
+    ops.sum_argmax(client, t, s2, i2, v2)
+    assert s1.to_numpy(client).view(np.uint32)[0] == s2.to_numpy(client).view(np.uint32)[0]
+    assert int(i1.to_numpy(client)[0]) == int(i2.to_numpy(client)[0]) == oracle.argmax(x)[0]
+    assert v2.to_numpy(client)[0] == x[oracle.argmax(x)[0]]
+
+
+@pytest.mark.parametrize("shape", [(512, 8192), (128, 32768), (64, 256, 1024), (64, 64, 4096), (37, 1001),
+                                   (3, 3), (1, 200_000), (1000, 1), (5, 70_001)])
+def test_last_axis_reductions(client, oracle, shape):
+    # book shapes: benchmark.md:58-79, parallel_reduction_3d.md:31-47
+    n = int(np.prod(shape))
+    x = oracle.fill_uniform(n, 31, -1.0, 1.0).reshape(shape)
+    t = TensorHandle.from_numpy(client, x)
+    out = TensorHandle.empty(client, shape[:-1] if len(shape) > 1 else (1,), ElemType.F32)
+    out = TensorHandle.new_contiguous(shape[:-1], client.empty(max(n // shape[-1], 1) * 4), ElemType.F32)
+    ops.reduce_sum_last_axis(client, t, out)
+    got = out.to_numpy(client)
+    exact = oracle.reduce_last_axis_sum(x, f64=True)
+    scale = np.abs(x).sum(axis=-1, dtype=np.float64)
+    assert np.all(np.abs(got - exact) <= REL * np.maximum(scale, 1e-30))
+    oi = TensorHandle.new_contiguous(shape[:-1], client.empty(max(n // shape[-1], 1) * 4), ElemType.U32)
+    ops.argmax_last_axis(client, t, oi)
+    assert np.array_equal(oi.to_numpy(client), oracle.reduce_last_axis_argmax(x))
+
+
+def test_last_axis_on_pitched_rows(client, oracle):
+    x = oracle.fill_uniform(300 * 30, 32, -1.0, 1.0).reshape(300, 30)
+    layout = client.create_tensor(x)                      # stride 32
+    t = TensorHandle.new(layout.memory, x.shape, layout.strides, ElemType.F32)
+    out = TensorHandle.new_contiguous((300,), client.empty(1200), ElemType.F32)
+    ops.reduce_sum_last_axis(client, t, out)
+    assert np.allclose(out.to_numpy(client), oracle.reduce_last_axis_sum(x, f64=True), rtol=0, atol=1e-5 * 30)
+    arange = TensorHandle.from_numpy(client, np.arange(9, dtype=np.float32).reshape(3, 3))
+    o3 = TensorHandle.new_contiguous((3,), client.empty(12), ElemType.F32)
+    ops.reduce_sum_last_axis(client, arange, o3)
+    assert o3.to_numpy(client).tolist() == [3.0, 12.0, 21.0]   # v1-cpu.rs:3-6
+
+
+@pytest.mark.parametrize("vec", [1, 2, 4])
+def test_plane_ops_reference_vectors(client, oracle, vec):
+    # runtime_tests/plane.rs:154-525: plane_size hard-coded 32 => half a wave64 active
+    plane = 32
+    x = np.arange(plane * vec, dtype=np.float32).reshape(plane, vec)
+    for v in range(vec):
+        col = np.zeros(64, dtype=np.float32); col[:32] = x[:, v]
+        t = TensorHandle.from_numpy(client, col)
+        out = TensorHandle.new_contiguous((64,), client.empty(256), ElemType.F32)
+        ops.plane_reduce(client, t, out, N.REDUCE_SUM, active=32)
+        got = out.to_numpy(client)[:32]
+        assert np.allclose(got, x[:, v].sum(dtype=np.float64), rtol=1e-5)
+        assert np.array_equal(got, oracle.plane_reduce(x[:, v], 0))   # same butterfly order, bitwise
+        ops.plane_reduce(client, t, out, N.REDUCE_MAX, active=32)
+        assert np.all(out.to_numpy(client)[:32] == x[:, v].max())
+        ops.plane_reduce(client, t, out, N.REDUCE_MIN, active=32)
+        assert np.all(out.to_numpy(client)[:32] == x[:, v].min())
+        ops.plane_reduce(client, t, out, N.PLANE_INCLUSIVE_SUM, active=32)
+        assert np.array_equal(out.to_numpy(client)[:32], np.cumsum(x[:, v], dtype=np.float64).astype(np.float32))
+        ops.plane_reduce(client, t, out, N.PLANE_EXCLUSIVE_SUM, active=32)
+        assert np.array_equal(out.to_numpy(client)[:32], (np.cumsum(x[:, v], dtype=np.float64) - x[:, v]).astype(np.float32))
+
+
+def test_plane_sum_full_wave_matches_oracle_bitwise(client, oracle):
+    x = oracle.fill_uniform(64 * 50, 41, -1.0, 1.0)
+    t = TensorHandle.from_numpy(client, x)
+    out = TensorHandle.new_contiguous((x.size,), client.empty(x.size * 4), ElemType.F32)
+    ops.plane_reduce(client, t, out, N.REDUCE_SUM, active=64)
+    got = out.to_numpy(client).reshape(50, 64)
+    for p in range(50):
+        assert np.array_equal(got[p], oracle.plane_reduce(x[p * 64:(p + 1) * 64], 0))
+    ops.plane_reduce(client, t, out, N.PLANE_PROD, active=64)
+    y = TensorHandle.from_numpy(client, np.full(64, 1.0625, dtype=np.float32))
+    o = TensorHandle.new_contiguous((64,), client.empty(256), ElemType.F32)
+    ops.plane_reduce(client, y, o, N.PLANE_PROD, active=64)
+    assert np.array_equal(o.to_numpy(client), oracle.plane_reduce(np.full(64, 1.0625, dtype=np.float32), 1))
+
+
+def test_workspace_contract(client):
+    import ctypes as C
+    x = TensorHandle.uniform(client, (10_000,), ElemType.F32, SEED, 1, 0.0, 1.0)
+    out = client.empty(8)
+    small = client.empty(64)
+    rc = client.lib.mi355_reduce_sum_f32(client.ctx, None, C.c_void_p(x.device_ptr()), 10_000,
+                                         C.c_void_p(out.device_ptr()), C.c_void_p(small.device_ptr()), 64)
+    assert rc == N.E_INVALID_ARGUMENT and b"workspace" in client.lib.mi355_last_error(client.ctx)

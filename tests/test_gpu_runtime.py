@@ -1,0 +1,164 @@
+"""Runtime / ComputeServer surface through the C ABI on a real MI355X.
+Mirrors runtime_tests/{launch,metadata,to_client}.rs and crates/cubecl-hip/tests/empty_read.rs."""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from cubecl_amd import CubeCount, CubeDim, ElemType, Mi355Runtime, ServerError, TensorHandle
+from cubecl_amd import _native as N
+
+pytestmark = pytest.mark.gpu
+HSACO = Path(__file__).parent / "kernels" / "abi_probe.hsaco"
+
+
+def test_device_properties(client):
+    p = client.properties()
+    assert p.gcn_arch_name.startswith(b"gfx950")
+    assert p.plane_size_min == 64 and p.plane_size_max == 64      # wave64
+    assert p.load_width_bits == 128 and p.max_bindings == 1024
+    assert p.num_streaming_multiprocessors == 256
+    assert p.max_units_per_cube == 1024
+    assert p.max_shared_memory_size >= 64 * 1024
+    assert p.total_memory > 200 * 2 ** 30 and p.max_page_size == p.total_memory // 4
+    assert p.fingerprint.startswith(b"mi355-aot_gfx950")
+    feats = client.features()
+    assert (N.DTYPE_BF16, N.DTYPE_BF16, N.DTYPE_F32, 32, 32, 16) in feats["cmma"]
+    assert (N.DTYPE_F32, N.DTYPE_F32, N.DTYPE_F32, 32, 32, 2) in feats["cmma"]
+    assert "Ops" in feats["plane"]
+    assert client.io_optimized_vector_sizes(4) == [4, 2, 1]
+    assert len(Mi355Runtime.enumerate_devices()) >= 1
+
+
+def test_create_read_roundtrip(client):
+    data = np.arange(1000, dtype=np.float32)
+    h = client.create_from_slice(data)
+    assert np.array_equal(client.read_one(h).view(np.float32), data)
+    # offsets select the in-use window (handle.rs:85-121)
+    window = h.offset_start_by(40).offset_end_by(400)
+    assert np.array_equal(client.read_one(window).view(np.float32), data[10:900])
+
+
+def test_empty_read(client):
+    # crates/cubecl-hip/tests/empty_read.rs: zero-sized handles read back as empty
+    h = client.empty(0)
+    assert client.read_one(h).size == 0
+
+
+def test_pitched_tensor_roundtrip(client):
+    # PitchedMemoryLayoutPolicy: rows of 30 f32 = 120 B -> pitch 128 B -> stride 32 elements
+    data = np.arange(7 * 30, dtype=np.float32).reshape(7, 30)
+    layout = client.create_tensor(data)
+    assert layout.strides == (32, 1)
+    t = TensorHandle.new(layout.memory, data.shape, layout.strides, ElemType.F32)
+    assert np.array_equal(t.to_numpy(client), data)
+    # power-of-two rows stay contiguous
+    assert client.empty_tensor((4096, 4096), 4).strides == (4096, 1)
+    assert client.empty_tensor((512, 2048, 2048), 2).strides == (4194304, 2048, 1)
+    with pytest.raises(ServerError) as e:
+        client.read_tensor(layout.memory.copy_descriptor((30, 7), (1, 32), 4))
+    assert e.value.code == N.E_UNSUPPORTED_STRIDES
+
+
+def test_zeros_and_memory_usage(client):
+    t = TensorHandle.zeros(client, (33, 17), ElemType.F32)
+    assert not t.to_numpy(client).any()
+    usage = client.memory_usage()
+    assert usage["bytes_total"] > 0 and usage["bytes_in_use"] > 0
+    client.flush()
+
+
+def test_oom_is_out_of_memory_not_buffer_too_big(client):
+    p = client.properties()
+    with pytest.raises(ServerError) as e:
+        client.empty(p.max_page_size + 1)
+    assert e.value.code == N.E_BUFFER_TOO_BIG
+
+
+def _info(client, scalars, lens):
+    return client.create_from_slice(np.array(list(scalars) + list(lens), dtype=np.uint32))
+
+
+def test_external_kernel_pointer_array_abi(client):
+    # launch path of runtime_tests/launch.rs with an externally built kernel (README.md:222-224)
+    mod = client.load_module(HSACO.read_bytes())
+    fn = client.get_function(mod, "abi_axpb")
+    n = 1000
+    x = np.arange(n, dtype=np.uint32)
+    hin, hout = client.create_from_slice(x), client.empty(n * 4)
+    client.launch(fn, CubeCount.Static(4), CubeDim.new_1d(256), [hin, hout], _info(client, (3, 7), (n, n)))
+    assert np.array_equal(client.read_one(hout).view(np.uint32), x * 3 + 7)
+    # sum_things: [-1, 10, 1, 5] -> 15 on every unit (examples/sum_things/src/lib.rs:180)
+    fs = client.get_function(mod, "abi_sum_basic")
+    hin = client.create_from_slice(np.array([-1, 10, 1, 5], dtype=np.float32))
+    hout = client.empty(16)
+    client.launch(fs, CubeCount.Static(1), CubeDim.new_1d(4), [hin, hout], _info(client, (0, 0), (4, 4)))
+    assert client.read_one(hout).view(np.float32).tolist() == [15.0] * 4
+
+
+def test_zero_cube_count_is_a_noop(client):
+    # runtime_tests/launch.rs:165-200
+    mod = client.load_module(HSACO.read_bytes())
+    fn = client.get_function(mod, "abi_axpb")
+    out = client.create_from_slice(np.full(8, 5, dtype=np.uint32))
+    for count in (CubeCount.Static(0, 1, 1), CubeCount.Static(1, 0, 1), CubeCount.Static(1, 1, 0)):
+        client.launch(fn, count, CubeDim.new_1d(8), [out, out], _info(client, (9, 9), (8, 8)))
+    client.flush()
+    assert client.read_one(out).view(np.uint32).tolist() == [5] * 8
+
+
+def test_resource_limit_errors_surface_at_flush(client):
+    # runtime_tests/launch.rs:226-348: errors are queued and reported as ServerUnhealthy{errors}
+    mod = client.load_module(HSACO.read_bytes())
+    fn = client.get_function(mod, "abi_lds_fill")
+    out = client.empty(4)
+    p = client.properties()
+    too_much = int(p.max_shared_memory_size) + 1
+    client.launch(fn, CubeCount.Static(1), CubeDim.new_1d(64), [out], _info(client, (16, 0), (1, 1)), shared_mem_bytes=too_much)
+    with pytest.raises(ServerError) as e:
+        client.flush()
+    assert e.value.code == N.E_SERVER_UNHEALTHY
+    first = e.value.errors[0]
+    assert first.code == N.E_SHARED_MEMORY and first.requested == too_much and first.max == p.max_shared_memory_size
+    client.flush()  # queue drained: healthy again
+
+    client.launch(fn, CubeCount.Static(1), CubeDim(2048, 1, 1), [out], _info(client, (16, 0), (1, 1)))
+    with pytest.raises(ServerError) as e:
+        client.sync()
+    assert e.value.errors[0].code == N.E_CUBE_DIM
+    client.launch(fn, CubeCount.Static(1), CubeDim(1024, 2, 1), [out], _info(client, (16, 0), (1, 1)))
+    with pytest.raises(ServerError) as e:
+        client.read_one(out)
+    assert e.value.errors[0].code == N.E_UNITS and e.value.errors[0].requested == 2048
+
+
+def test_large_lds_kernel_runs(client):
+    # runtime_tests/launch.rs:202-224 (reduced to the default 64 KiB dynamic limit first)
+    mod = client.load_module(HSACO.read_bytes())
+    fn = client.get_function(mod, "abi_lds_fill")
+    out = client.empty(4)
+    words = 64 * 1024 // 4
+    client.launch(fn, CubeCount.Static(1), CubeDim.new_1d(256), [out], _info(client, (words, 0), (1, 1)),
+                  shared_mem_bytes=words * 4)
+    got = int(client.read_one(out).view(np.uint32)[0])
+    assert got == (words * (words - 1) // 2) % (1 << 32)
+
+
+def test_profile_reports_device_time(client):
+    t = TensorHandle.uniform(client, (1 << 24,), ElemType.F32, 1, 1, 0.0, 1.0)
+    out = client.empty(4)
+    from cubecl_amd import ops
+    o = TensorHandle.new_contiguous((1,), out, ElemType.F32)
+    _, nanos = client.profile(lambda: ops.reduce_sum(client, t, o), "sum")
+    assert 1_000 < nanos < 50_000_000
+
+
+def test_unknown_symbol_and_bad_image(client):
+    mod = client.load_module(HSACO.read_bytes())
+    with pytest.raises(ServerError) as e:
+        client.get_function(mod, "does_not_exist")
+    assert e.value.code == N.E_NOT_FOUND
+    with pytest.raises(ServerError) as e:
+        client.load_module(b"not a code object" * 10)
+    assert e.value.code == N.E_COMPILATION

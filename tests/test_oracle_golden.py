@@ -1,0 +1,180 @@
+"""Pins the CPU oracle (oracle/oracle.c) against every known-answer vector the reference's own
+tests hold for this path plus independent numpy restatements.  CPU only."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+GOLD = json.loads((Path(__file__).parent / "golden" / "reference_goldens.json").read_text())
+
+
+def f16_bits(x, oracle):
+    return oracle.to_f16(np.asarray(x, dtype=np.float32))
+
+
+# ---- cmma fragment known answers ------------------------------------------------------------------
+def test_cmma_simple_1_f16_nt(oracle):
+    # runtime_tests/cmma.rs:500-501 inputs, :552-576 expectation; Out = Lhs @ Rhs.T (:23)
+    lhs = f16_bits(np.arange(256), oracle)
+    rhs = f16_bits(np.arange(256) % 8, oracle)
+    out = oracle.gemm(lhs, rhs, 16, 16, 16, dtype_ab=oracle.DT_F16, trans_b=True)
+    assert out.tolist() == GOLD["cmma_simple_1_f16_16x16x16_nt"]
+    # closed form quoted in SURVEY.md: row r = 504 + 896 r
+    assert out.reshape(16, 16)[:, 0].tolist() == [504.0 + 896.0 * r for r in range(16)]
+
+
+def test_cmma_simple_tf32_nn(oracle):
+    # cmma.rs:848-849 inputs; A 16x8 row-major, B 8x16 row-major (stride 16) (:219-237)
+    lhs = np.arange(128, dtype=np.float32)
+    rhs = (np.arange(128) % 8).astype(np.float32)
+    out = oracle.gemm(lhs, rhs, 16, 16, 8, trans_b=False)
+    assert out.tolist() == GOLD["cmma_simple_tf32_16x16x8_nn"]
+
+
+def test_cmma_strided_lhs(oracle):
+    # cmma.rs:946-956: (m, n, k) = (16, 16, 32), tiles 16^3, left K-half filled, lda = 32, ldb = 16
+    m, n, k, tk = 16, 16, 32, 16
+    i = np.arange(m * k)
+    lhs = np.where((i % k) < tk, i - (i // k) * tk, 0).astype(np.float32)
+    rhs = (np.arange(n * k) % 8).astype(np.float32)
+    out = oracle.gemm(f16_bits(lhs, oracle), f16_bits(rhs, oracle), 16, 16, 16, dtype_ab=oracle.DT_F16,
+                      lda=k, ldb=n, trans_b=True)
+    assert out.tolist() == GOLD["cmma_strided_f16_16x16x16_nt"]
+
+
+@pytest.mark.parametrize("m,n,k", [(16, 16, 16), (32, 32, 16), (32, 32, 32), (64, 64, 32), (16, 16, 64)])
+def test_cmma_cube_expected(oracle, m, n, k):
+    # test_simple_cube_expected (cmma.rs:695-722) restated in numpy with the same f32 loop order
+    lhs = np.arange(m * k, dtype=np.float32)
+    rhs = (np.arange(k * n) % 8).astype(np.float32)
+    lhs16, rhs16 = f16_bits(lhs, oracle), f16_bits(rhs, oracle)
+    lhs_f = lhs16.view(np.float16).astype(np.float32).reshape(m, k)
+    rhs_f = rhs16.view(np.float16).astype(np.float32).reshape(n, k)
+    expected = np.zeros((m, n), dtype=np.float32)
+    for kk in range(k):
+        expected += lhs_f[:, kk:kk + 1] * rhs_f[None, :, kk]
+    out = oracle.gemm(lhs16, rhs16, m, n, k, dtype_ab=oracle.DT_F16, trans_b=True)
+    assert np.array_equal(out.reshape(m, n), expected)
+
+
+@pytest.mark.parametrize("m,n,k", [(16, 16, 16), (32, 32, 8), (16, 8, 16)])
+def test_cmma_manual_row_major(oracle, m, n, k):
+    # test_cmma_manual (cmma.rs:1127-1177): lhs[i,j] = 2i + j, rhs[i,j] = 3i + j, integer dot product
+    lhs = np.array([[2 * i + j for j in range(k)] for i in range(m)], dtype=np.float32)
+    rhs = np.array([[3 * i + j for j in range(n)] for i in range(k)], dtype=np.float32)
+    expected = (lhs.astype(np.int64) @ rhs.astype(np.int64)).astype(np.float32)
+    out = oracle.gemm(lhs, rhs, m, n, k, trans_b=False).reshape(m, n)
+    assert np.array_equal(out, expected)
+    out16 = oracle.gemm(oracle.to_bf16(lhs), oracle.to_bf16(rhs), m, n, k, dtype_ab=oracle.DT_BF16).reshape(m, n)
+    assert np.allclose(out16, expected, rtol=0.03)  # the reference's own 3 % tolerance (:1183-1191)
+
+
+def test_cmma_cast(oracle):
+    # test_cmma_cast_f16 / _bf16 (cmma.rs:766-832): f32 0..255 -> 16-bit, exact
+    x = np.arange(256, dtype=np.float32)
+    assert np.array_equal(oracle.to_f16(x).view(np.float16), x.astype(np.float16))
+    assert np.array_equal(oracle.from_bf16(oracle.to_bf16(x)), x)
+
+
+# ---- 16-bit conversions against independent implementations ------------------------------------------
+def test_f16_conversion_matches_numpy(oracle):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(20000).astype(np.float32) * 10.0 ** rng.integers(-9, 6, 20000),
+                        np.array([0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e-8, 5.96e-8, 2.98e-8, 2.9802322e-8,
+                                  6.1e-5, np.inf, -np.inf], dtype=np.float32)]).astype(np.float32)
+    with np.errstate(over="ignore"):
+        assert np.array_equal(oracle.to_f16(x), x.astype(np.float16).view(np.uint16))
+    h = np.arange(65536, dtype=np.uint16)
+    ref = h.view(np.float16).astype(np.float32)
+    got = oracle.from_f16(h)
+    assert np.array_equal(np.isnan(ref), np.isnan(got))
+    assert np.array_equal(ref[~np.isnan(ref)], got[~np.isnan(ref)])
+
+
+def test_bf16_conversion_matches_torch(oracle):
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(1)
+    x = (rng.standard_normal(50000) * 10.0 ** rng.integers(-20, 20, 50000)).astype(np.float32)
+    ref = torch.from_numpy(x).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+    assert np.array_equal(oracle.to_bf16(x), ref)
+
+
+# ---- reductions -----------------------------------------------------------------------------------------
+def test_sum_things_input(oracle):
+    # examples/sum_things/src/lib.rs:180: [-1, 10, 1, 5] -> 15
+    x = np.array([-1.0, 10.0, 1.0, 5.0], dtype=np.float32)
+    assert oracle.sum_sequential(x) == 15.0
+    assert oracle.sum_f64(x) == 15.0
+
+
+def test_book_reduce_matrix(oracle):
+    # cubecl-book/src/getting-started/src/bin/v1-cpu.rs:3-6: arange 3x3 -> [3, 12, 21]
+    x = np.arange(9, dtype=np.float32).reshape(3, 3)
+    assert oracle.reduce_last_axis_sum(x).tolist() == [3.0, 12.0, 21.0]
+
+
+@pytest.mark.parametrize("vec", [1, 2, 4])
+def test_plane_sum_reference_vectors(oracle, vec):
+    # test_plane_sum (runtime_tests/plane.rs:154-190): plane_size 32, input 0..32*vec,
+    # expected[v] = sum_k input[v + k*vec]; tolerance 1e-5 relative (binary.rs:15-53)
+    plane = 32
+    x = np.arange(plane * vec, dtype=np.float32).reshape(plane, vec)
+    for v in range(vec):
+        lanes = oracle.plane_reduce(x[:, v], 0)
+        expected = x[:, v].sum(dtype=np.float64)
+        assert np.allclose(lanes, expected, rtol=1e-5)
+        assert np.all(lanes == lanes[0])  # every lane holds the result
+
+
+def test_plane_ops_butterfly(oracle):
+    rng = np.random.default_rng(2)
+    v = rng.standard_normal(64).astype(np.float32)
+    assert np.allclose(oracle.plane_reduce(v, 0), v.sum(dtype=np.float64), rtol=1e-5)
+    assert np.all(oracle.plane_reduce(v, 2) == v.max())
+    assert np.all(oracle.plane_reduce(v, 3) == v.min())
+    inc = oracle.plane_inclusive_sum(np.arange(32, dtype=np.float32))
+    assert inc.tolist() == np.cumsum(np.arange(32)).astype(np.float32).tolist()  # plane.rs:192-230
+
+
+def test_argmax_rules(oracle):
+    x = np.array([1.0, 7.0, 3.0, 7.0, -2.0], dtype=np.float32)
+    assert oracle.argmax(x) == (1, np.float32(7.0))            # lowest index among equal maxima
+    x = np.array([-0.0, 0.0, -1.0], dtype=np.float32)
+    assert oracle.argmax(x)[0] == 0                             # -0.0 == +0.0
+    x = np.array([1.0, np.nan, 5.0, np.nan], dtype=np.float32)
+    assert oracle.argmax(x)[0] == 1                             # NaN ranks highest, first NaN wins
+    x = np.array([-np.inf, -np.inf], dtype=np.float32)
+    assert oracle.argmax(x)[0] == 0
+    rng = np.random.default_rng(3)
+    y = rng.standard_normal(100003).astype(np.float32)
+    assert oracle.argmax(y)[0] == int(np.argmax(y))
+
+
+def test_all_reduce_closed_form():
+    # runtime_tests/all_reduce.rs:24-59: device i holds handles filled with (i + j); after
+    # all_reduce(Sum) every device reads sum(ids) + j * device_count
+    for ndev in (2, 4, 8):
+        for j in range(8):
+            contributions = [np.full(100, i + j, dtype=np.float32) for i in range(ndev)]
+            total = np.sum(contributions, axis=0)
+            assert np.all(total == sum(range(ndev)) + j * ndev)
+
+
+# ---- synthetic data generator pin ------------------------------------------------------------------------
+def test_rng_pinned(oracle):
+    x = oracle.fill_uniform(8, 1, 0.0, 1.0)
+    pinned = json.loads((Path(__file__).parent / "golden" / "oracle_pins.json").read_text())
+    assert x.view(np.uint32).tolist() == pinned["fill_uniform_t1_0_1_first8_bits"]
+    y = oracle.fill_uniform(1 << 16, 7, -1.0, 1.0)
+    assert y.min() >= -1.0 and y.max() < 1.0 and abs(float(y.mean())) < 0.02
+    z = oracle.fill_uniform(1 << 16, 8, -1.0, 1.0)
+    assert not np.array_equal(y, z)  # tensor id decorrelates streams
+
+
+def test_sequential_vs_f64_sum_gap(oracle):
+    # a literal sequential-f32 sum drifts; the f64 oracle is the one of record
+    x = oracle.fill_uniform(1 << 20, 3, 0.0, 1.0)
+    exact = oracle.sum_f64(x)
+    assert abs(exact - float(np.sum(x, dtype=np.float64))) < 1e-6 * exact
+    assert abs(oracle.sum_sequential(x) - exact) / exact < 1e-3
