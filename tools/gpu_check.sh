@@ -1,0 +1,19 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): GPU tests, smoke, bench, rocprof summary. Outputs -> gpurun_out/.
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+OUT=gpurun_out; mkdir -p $OUT
+TAG=${1:-run}
+echo "== rocm-smi"; rocm-smi --showproductname 2>/dev/null | head -8
+echo "== pytest -m gpu"
+timeout 1200 python -m pytest tests -m gpu -q --no-header --timeout 300 -p no:cacheprovider --maxfail=60 > $OUT/${TAG}_pytest.log 2>&1
+echo "pytest exit $?"; tail -n 40 $OUT/${TAG}_pytest.log
+echo "== smoke"
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/${TAG}_smoke.log 2>&1; echo "smoke exit $?"; tail -n 5 $OUT/${TAG}_smoke.log
+echo "== bench"
+timeout 900 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; echo "bench exit $?"; cat $OUT/${TAG}_bench.json; tail -n 5 $OUT/${TAG}_bench.err
+echo "== rocprof"
+export TMPDIR=/tmp
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/${TAG}_prof" -o bench -- python "$OLDPWD/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OLDPWD/$OUT/${TAG}_prof.log" 2>&1 ); echo "rocprof exit $?"
+find $OUT/${TAG}_prof -name "*kernel_stats*" | head -3
+f=$(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -n 25 "$f"
