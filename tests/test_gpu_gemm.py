@@ -192,6 +192,54 @@ def test_generic_parity_any_shape(client, oracle, dtype, out, trans_b, m, n, k):
     run_case(client, oracle, m, n, k, dtype, out, trans_b, ALGOS["generic"])
 
 
+LP256_CASES = [(256, 256, 64), (256, 256, 128), (256, 512, 192), (512, 512, 512), (300, 260, 128), (1, 256, 64),
+               (257, 255, 320), (768, 256, 1024)]
+
+
+@pytest.mark.parametrize("m,n,k", LP256_CASES)
+@pytest.mark.parametrize("dtype", [ElemType.BF16, ElemType.F16])
+@pytest.mark.parametrize("out", ["f32", "same"])
+def test_lp256_parity(client, oracle, m, n, k, dtype, out):
+    run_case(client, oracle, m, n, k, dtype, ElemType.F32 if out == "f32" else dtype, True, ALGOS["lp256"])
+
+
+def test_lp256_identity_and_batch(client, oracle):
+    run_case(client, oracle, 256, 256, 128, ElemType.BF16, ElemType.BF16, True, ALGOS["lp256"], batch=3)
+    run_case(client, oracle, 512, 256, 64, ElemType.BF16, ElemType.F32, True, ALGOS["lp256"], batch=2, bcast_b=True,
+             lda=72, ldb=64, ldc=260)
+    m = n = k = 512
+    eye = np.eye(m, dtype=np.float32)
+    bmat = ((np.arange(k)[:, None] * 3 + np.arange(n)[None, :] * 7) % 251).astype(np.float32)
+    ta, _ = _to_dev(client, oracle, eye, ElemType.BF16)
+    tb, _ = _to_dev(client, oracle, np.ascontiguousarray(bmat.T), ElemType.BF16)
+    c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 4), ElemType.F32)
+    ops.matmul(client, TensorHandle.new(ta.handle, (m, k), (k, 1), ElemType.BF16),
+               TensorHandle.new(tb.handle, (k, n), (1, k), ElemType.BF16), c, algo=ALGOS["lp256"])
+    assert np.array_equal(c.to_numpy(client), bmat)
+
+
+@pytest.mark.parametrize("algo", ["lp128", "lp256", "f32"])
+def test_race_screen_bitwise_repeatability(client, oracle, algo):
+    # the counted-vmcnt / barrier pipeline must give the same bits on every launch (guide: "place reads by
+    # the vmcnt/barrier count, never by clean runs") -- 25 launches at a multi-wave-per-CU size
+    m = n = 2048
+    k = 1024
+    dtype = ElemType.F32 if algo == "f32" else ElemType.BF16
+    a = TensorHandle.uniform(client, (m, k), dtype, 0x5EEDC0BE, 71, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (n, k), dtype, 0x5EEDC0BE, 72, -1.0, 1.0)
+    bt = TensorHandle.new(b.handle, (k, n), (1, k), dtype)
+    c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 4), ElemType.F32)
+    ops.matmul(client, a, bt, c, algo=ALGOS[algo])
+    first = c.to_numpy(client).copy()
+    ref = TensorHandle.new_contiguous((m, n), client.empty(m * n * 4), ElemType.F32)
+    ops.matmul(client, a, bt, ref, algo=ALGOS["generic"])
+    bound = 1e-5 * k  # |a||b| <= 1 per product
+    assert np.max(np.abs(first - ref.to_numpy(client))) <= bound
+    for _ in range(25):
+        ops.matmul(client, a, bt, c, algo=ALGOS[algo])
+        assert np.array_equal(c.to_numpy(client), first)
+
+
 def test_padded_leading_dimensions_and_untouched_padding(client, oracle):
     run_case(client, oracle, 256, 128, 128, ElemType.F32, ElemType.F32, True, ALGOS["auto"], lda=136, ldb=132, ldc=140)
     run_case(client, oracle, 256, 128, 128, ElemType.BF16, ElemType.F32, True, ALGOS["auto"], lda=136, ldb=144, ldc=132)
