@@ -1,0 +1,20 @@
+#!/bin/bash
+# Builds side copies of libmi355cube.so with development switches for A/B and ablation runs:
+#   tools/dev/build_variants.sh NAME "-DLP256_ABL=1" [file.hip ...]   -> cubecl_amd/csrc/variants/libmi355cube_NAME.so
+set -e
+cd "$(dirname "$0")/../../cubecl_amd/csrc"
+NAME=$1; FLAGS=$2; shift 2
+FILES=${@:-gemm_lp256.hip}
+mkdir -p variants/obj_$NAME
+OBJS=""
+for f in runtime.cpp comm.cpp gemm.cpp fill.hip reduce.hip probes.hip gemm_generic.hip gemm_f32.hip gemm_lp128.hip gemm_lp256.hip; do
+  base=${f%.*}
+  if echo " $FILES " | grep -q " $f "; then
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-value --offload-arch=gfx950 $FLAGS -x hip -c $f -o variants/obj_$NAME/$base.o
+    OBJS="$OBJS variants/obj_$NAME/$base.o"
+  else
+    OBJS="$OBJS build/$base.o"
+  fi
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libmi355cube_$NAME.so $OBJS -ldl -lpthread
+echo built variants/libmi355cube_$NAME.so
