@@ -35,11 +35,12 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
         return MI355_GEMM_ALGO_GENERIC;
     }
     const bool big = gemm_lp256_supports(d, a, b, c);
+    const bool big4 = gemm_lp256w4_supports(d, a, b, c);
     const bool mid = gemm_lp128_supports(d, a, b, c);
     if (big) {
         // 256x256 tiles only when they still give every CU work
         const int64_t tiles256 = ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch;
-        if (tiles256 >= 192 || !mid) return MI355_GEMM_ALGO_LP_256;
+        if (tiles256 >= 192 || !mid) return big4 ? MI355_GEMM_ALGO_LP_256W4 : MI355_GEMM_ALGO_LP_256;
     }
     if (mid) return MI355_GEMM_ALGO_LP_128;
     return MI355_GEMM_ALGO_GENERIC;
@@ -70,6 +71,7 @@ MI355_API int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_ge
     case MI355_GEMM_ALGO_F32_MFMA: return launch_gemm_f32_mfma(ctx, s, d, a, b, c);
     case MI355_GEMM_ALGO_LP_128: return launch_gemm_lp128(ctx, s, d, a, b, c);
     case MI355_GEMM_ALGO_LP_256: return launch_gemm_lp256(ctx, s, d, a, b, c);
+    case MI355_GEMM_ALGO_LP_256W4: return launch_gemm_lp256w4(ctx, s, d, a, b, c);
     default: return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_gemm: unknown algo %d", algo);
     }
 }

@@ -77,6 +77,8 @@ int32_t launch_gemm_generic(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc
 int32_t launch_gemm_f32_mfma(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 int32_t launch_gemm_lp256(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
+int32_t launch_gemm_lp256w4(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
+bool gemm_lp256w4_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 bool gemm_f32_mfma_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 bool gemm_lp128_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 bool gemm_lp256_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);

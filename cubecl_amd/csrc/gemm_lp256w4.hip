@@ -1,0 +1,338 @@
+// gemm_lp256w4.hip -- bf16 / f16 GEMM, 256x256x64 workgroup tile, FOUR waves, one per SIMD.
+//
+// Roofline: MFMA bf16/f16, ~2.5 PFLOP/s dense (MI355X_MICROARCH.md).  This is the headline kernel
+// for BASELINE config C3 (8192^3 bf16) and C5 (batched 2048^3).
+//
+// Why one wave per SIMD.  The 8-wave ping-pong kernel (gemm_lp256.hip) hands the matrix pipe of a
+// SIMD back and forth between two waves through s_barrier; its ablations (profiles/) show the
+// hand-over itself costs ~16 % with every load removed, and the load phases barely overlap the
+// MFMA phases.  Here each SIMD hosts ONE wave that owns a 128 x 128 output (4 x 4 MFMA tiles of
+// 32x32x16, 256 accumulator registers in the AGPR half of the unified 512-entry file) and never
+// gives the pipe away: fragment reads and LDS-DMA issues are slotted BETWEEN its own MFMAs (an
+// MFMA occupies the pipe for 32 cycles; up to ~5 other instructions issue for free meanwhile --
+// MI355X_MICROARCH.md "one wave per SIMD").  Per K-tile and wave: 64 MFMA, 32 ds_read_b128,
+// 16 LDS-DMA, ONE s_barrier.  LDS fragment traffic drops from 192 KiB to 128 KiB per K-tile
+// against the 2x4 wave grid (each operand half is read by 2 waves instead of 4 / 2).
+//
+// LDS: 160 KiB = ring of 5 slots x 32 KiB.  "Unit" u = 2t is the A tile (256 rows x 128 B) of
+// K-tile t, u = 2t+1 its B tile; unit u lives in slot u % 5.  Rows are one 128-byte line (64
+// k-values); filled by LDS-DMA (global_load_lds_dwordx4: 1 KiB = 8 rows per wave instruction) with
+// the XOR swizzle on the SOURCE address and on the fragment read (conflict-free ds_read_b128, as
+// gemm_lp128.hip).
+//
+// Schedule of K-tile t (k-steps s = 0..3 of 16 MFMAs; fragments double-buffered in registers):
+//     s=0: read frags(t,1)   DMA unit 2t+4, pieces 0-3      MFMA(t,0)
+//     s=1: read frags(t,2)   DMA unit 2t+4, pieces 4-7      MFMA(t,1)
+//     s=2: read frags(t,3)                                   MFMA(t,2)
+//          vmcnt(8): my share of units <= 2t+3 (K-tile t+1) has landed; lgkmcnt(0): my reads of
+//          K-tile t are complete;   s_barrier  (BAR_t)
+//     s=3: read frags(t+1,0) DMA unit 2t+5, pieces 0-7      MFMA(t,3)
+//   After BAR_t every wave's K-tile t+1 data is visible and nobody reads K-tile t's slots again,
+//   so unit 2t+5 may overwrite slot (2t+5)%5 == slot of unit 2t, and the first fragments of
+//   K-tile t+1 are fetched under the last 16 MFMAs of K-tile t: the barrier is the only point
+//   where the pipe can drain.  Unit 2t+4 reuses the slot of unit 2t-1 (dead since BAR_{t-1}).
+//   Every DMA is issued >= 3 k-steps (~1500 cycles) before the barrier that needs it; vmcnt
+//   never reaches 0 in the loop.  Past the last K-tile the same instructions run against a clamped
+//   tile index (harmless re-reads into dead slots), keeping the counts uniform.
+//
+// Restrictions (the dispatcher falls back to gemm_lp256.hip / gemm_lp128.hip otherwise):
+//   M % 256 == 0, N % 256 == 0, K % 64 == 0, A row-major [M][K], B stored [N][K] (trans_b = 1).
+#include <type_traits>
+
+#include "gemm_common.hpp"
+
+using namespace mi355;
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int ROW_BYTES = BK * 2;                 // 128
+constexpr int UNIT_BYTES = BM * ROW_BYTES;        // 32 KiB: one ring slot
+constexpr int NSLOT = 5;
+constexpr int LDS_BYTES = NSLOT * UNIT_BYTES;     // 160 KiB
+
+template <int DT> struct lp;
+template <> struct lp<MI355_DTYPE_BF16> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c)
+    { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct lp<MI355_DTYPE_F16> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c)
+    { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+__device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
+}
+
+#ifndef W4_ABL
+#define W4_ABL 0          // dev ablations: 1 no DMA, 2 no fragment reads, 4 no MFMA, 16 no interleave pins
+#endif
+
+#define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+template <int V> using IC = std::integral_constant<int, V>;
+
+template <int DT, int DT_C>
+__global__ void __launch_bounds__(256)
+gemm_lp256w4_kernel(gemm_args g)
+{
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    typedef typename lp<DT>::frag frag;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    uint32_t tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n), g.tiles_m, g.tiles_n, g.group_m, tm, tn);
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    const int64_t batch = blockIdx.y;
+    const char *__restrict__ A = static_cast<const char *>(g.a) + batch * g.stride_a * 2;
+    const char *__restrict__ B = static_cast<const char *>(g.b) + batch * g.stride_b * 2;
+    const int nk = (int)(g.k / BK);
+
+    // ---- DMA map: a unit is 32 pieces of 1 KiB (8 rows); this wave fills pieces wave*8 + j.
+    //   lane -> (row = piece*8 + lane/8, physical chunk c = lane%8), source chunk = c ^ ((row>>1)&7).
+    //   ((row>>1)&7 depends on j only through its parity, so two per-lane pointers per operand
+    //   suffice; the (j>>1) step is a wave-uniform byte offset.)
+    const int sub = lane >> 3, c8 = lane & 7;
+    const char *src_a[2], *src_b[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = wave * 64 + p * 8 + sub;
+        const int q = c8 ^ ((r >> 1) & 7);
+        src_a[p] = A + ((m0 + r) * g.lda + q * 8) * 2;
+        src_b[p] = B + ((n0 + r) * g.ldb + q * 8) * 2;
+    }
+    const int64_t step_a = 16 * g.lda * 2, step_b = 16 * g.ldb * 2;   // bytes between pieces j and j+2
+    const int dst_piece = wave * 8 * 1024;                            // + j*1024 within the slot
+
+    // ---- fragment read offsets: row*128 + ((2s+h) ^ f) * 16, f = (row>>1)&7 = (l31>>1)&7 for every tile row
+    const int f = (l31 >> 1) & 7;
+    const int rowoff_a = (wm * 128 + l31) * ROW_BYTES;
+    const int rowoff_b = (wn * 128 + l31) * ROW_BYTES;
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    frag fa[2][4], fb[2][4];
+
+    // fragment load order == order of first use by the next k-step's MFMAs (j outer, i inner)
+    auto read_one = [&](auto buf, auto idx, const char *pa, const char *pb) {
+        constexpr int BUF = decltype(buf)::value, R = decltype(idx)::value;
+        if (W4_ABL & 2) return;
+        if (R == 0) fb[BUF][0] = *reinterpret_cast<const frag *>(pb);
+        else if (R <= 4) fa[BUF][R - 1] = *reinterpret_cast<const frag *>(pa + (R - 1) * 32 * ROW_BYTES);
+        else fb[BUF][R - 4] = *reinterpret_cast<const frag *>(pb + (R - 4) * 32 * ROW_BYTES);
+    };
+    auto dma_one = [&](auto is_b, auto jj, int64_t koff, char *base) {
+        constexpr int J = decltype(jj)::value;
+        if (W4_ABL & 1) return;
+        const char *s = decltype(is_b)::value ? src_b[J & 1] + (J >> 1) * step_b : src_a[J & 1] + (J >> 1) * step_a;
+        glds16(s + koff, base + J * 1024);
+    };
+    auto mfma_one = [&](auto buf, auto idx) {
+        constexpr int BUF = decltype(buf)::value, I = decltype(idx)::value & 3, J = decltype(idx)::value >> 2;
+        if (W4_ABL & 4) {
+            asm volatile("" ::"v"(fb[BUF][J]), "v"(fa[BUF][I]));
+            return;
+        }
+        acc[I][J] = lp<DT>::mfma(fb[BUF][J], fa[BUF][I], acc[I][J]);
+    };
+
+    // One k-step, instruction order pinned by hand (sched_barrier(0) after every MFMA group):
+    //   MFMA idx, then at most one fragment read of the NEXT k-step (into the other register
+    //   buffer) or one DMA piece.  RMASK / DMASK: bit idx set = a read / a DMA follows MFMA idx.
+    //   DMA pieces are J0, J0+1, ... in mask order.
+#define W4_STEP_BODY(CUR, NXT, RMASK, DMASK, IS_B, J0)                                               \
+    {                                                                                                \
+        constexpr unsigned rmask_ = (RMASK), dmask_ = (DMASK);                                       \
+        W4_GROUP(CUR, NXT, 0, rmask_, dmask_, IS_B, J0)  W4_GROUP(CUR, NXT, 1, rmask_, dmask_, IS_B, J0)   \
+        W4_GROUP(CUR, NXT, 2, rmask_, dmask_, IS_B, J0)  W4_GROUP(CUR, NXT, 3, rmask_, dmask_, IS_B, J0)   \
+        W4_GROUP(CUR, NXT, 4, rmask_, dmask_, IS_B, J0)  W4_GROUP(CUR, NXT, 5, rmask_, dmask_, IS_B, J0)   \
+        W4_GROUP(CUR, NXT, 6, rmask_, dmask_, IS_B, J0)  W4_GROUP(CUR, NXT, 7, rmask_, dmask_, IS_B, J0)   \
+        W4_GROUP(CUR, NXT, 8, rmask_, dmask_, IS_B, J0)  W4_GROUP(CUR, NXT, 9, rmask_, dmask_, IS_B, J0)   \
+        W4_GROUP(CUR, NXT, 10, rmask_, dmask_, IS_B, J0) W4_GROUP(CUR, NXT, 11, rmask_, dmask_, IS_B, J0)  \
+        W4_GROUP(CUR, NXT, 12, rmask_, dmask_, IS_B, J0) W4_GROUP(CUR, NXT, 13, rmask_, dmask_, IS_B, J0)  \
+        W4_GROUP(CUR, NXT, 14, rmask_, dmask_, IS_B, J0) W4_GROUP(CUR, NXT, 15, rmask_, dmask_, IS_B, J0)  \
+    }
+#define W4_GROUP(CUR, NXT, IDX, rmask_, dmask_, IS_B, J0)                                            \
+    mfma_one(IC<CUR>{}, IC<IDX>{});                                                                  \
+    if constexpr ((rmask_ >> IDX) & 1u)                                                              \
+        read_one(IC<NXT>{}, IC<__builtin_popcount(rmask_ & ((1u << IDX) - 1u))>{}, rd_a, rd_b);      \
+    if constexpr ((dmask_ >> IDX) & 1u)                                                              \
+        dma_one(IC<IS_B>{}, IC<J0 + __builtin_popcount(dmask_ & ((1u << IDX) - 1u))>{}, dma_koff, dma_base); \
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- prologue: units 0..3 (K-tiles 0 and 1), then the first fragments ---------------------------
+    {
+        const int64_t k0 = 0, k1 = (int64_t)min(1, nk - 1) * (BK * 2);
+        char *b0 = smem + dst_piece;
+#define W4_PRO(IS_B, KOFF, SLOT)                                                                     \
+        dma_one(IC<IS_B>{}, IC<0>{}, KOFF, b0 + SLOT * UNIT_BYTES); dma_one(IC<IS_B>{}, IC<1>{}, KOFF, b0 + SLOT * UNIT_BYTES); \
+        dma_one(IC<IS_B>{}, IC<2>{}, KOFF, b0 + SLOT * UNIT_BYTES); dma_one(IC<IS_B>{}, IC<3>{}, KOFF, b0 + SLOT * UNIT_BYTES); \
+        dma_one(IC<IS_B>{}, IC<4>{}, KOFF, b0 + SLOT * UNIT_BYTES); dma_one(IC<IS_B>{}, IC<5>{}, KOFF, b0 + SLOT * UNIT_BYTES); \
+        dma_one(IC<IS_B>{}, IC<6>{}, KOFF, b0 + SLOT * UNIT_BYTES); dma_one(IC<IS_B>{}, IC<7>{}, KOFF, b0 + SLOT * UNIT_BYTES);
+        W4_PRO(0, k0, 0) W4_PRO(1, k0, 1) W4_PRO(0, k1, 2) W4_PRO(1, k1, 3)
+#undef W4_PRO
+    }
+    WAIT_VMCNT(16);                      // units 0, 1 landed (this wave's share)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const int x = (h ^ f) << 4;
+        const char *rd_a = smem + rowoff_a + x, *rd_b = smem + UNIT_BYTES + rowoff_b + x;
+        read_one(IC<0>{}, IC<0>{}, rd_a, rd_b); read_one(IC<0>{}, IC<1>{}, rd_a, rd_b);
+        read_one(IC<0>{}, IC<2>{}, rd_a, rd_b); read_one(IC<0>{}, IC<3>{}, rd_a, rd_b);
+        read_one(IC<0>{}, IC<4>{}, rd_a, rd_b); read_one(IC<0>{}, IC<5>{}, rd_a, rd_b);
+        read_one(IC<0>{}, IC<6>{}, rd_a, rd_b); read_one(IC<0>{}, IC<7>{}, rd_a, rd_b);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    int sa = 0;                          // ring byte offset of unit 2t   (A of K-tile t)
+    int sb = UNIT_BYTES;                 // ring byte offset of unit 2t+1 (B of K-tile t)
+    auto adv = [](int x, int n) { x += n * UNIT_BYTES; return x >= LDS_BYTES ? x - LDS_BYTES : x; };
+    const int x1 = ((2 + h) ^ f) << 4, x2 = ((4 + h) ^ f) << 4, x3 = ((6 + h) ^ f) << 4, x0 = (h ^ f) << 4;
+
+    for (int t = 0; t < nk; ++t) {
+        const int sa1 = adv(sa, 2), sb1 = adv(sb, 2);     // units 2t+2, 2t+3 (K-tile t+1)
+        const int s4 = adv(sa, 4);                        // unit 2t+4 -> slot of unit 2t-1
+        const int s5 = sa;                                // unit 2t+5 -> slot of unit 2t
+        const int64_t dma_koff = (int64_t)min(t + 2, nk - 1) * (BK * 2);
+        const char *rd_a, *rd_b;
+        char *dma_base;
+        // ---- k-step 0: reads of step 1 after MFMA 0-7, unit 2t+4 pieces 0-3 after MFMA 9,11,13,15
+        rd_a = smem + sa + rowoff_a + x1; rd_b = smem + sb + rowoff_b + x1; dma_base = smem + s4 + dst_piece;
+        W4_STEP_BODY(0, 1, 0x00FFu, 0xAA00u, 0, 0)
+        // ---- k-step 1: reads of step 2, unit 2t+4 pieces 4-7
+        rd_a = smem + sa + rowoff_a + x2; rd_b = smem + sb + rowoff_b + x2;
+        W4_STEP_BODY(1, 0, 0x00FFu, 0xAA00u, 0, 4)
+        // ---- k-step 2: reads of step 3, no DMA; then the K-tile hand-over
+        rd_a = smem + sa + rowoff_a + x3; rd_b = smem + sb + rowoff_b + x3;
+        W4_STEP_BODY(0, 1, 0x00FFu, 0x0000u, 0, 0)
+        WAIT_VMCNT(8);                   // my share of K-tile t+1 landed; unit 2t+4 may still fly
+        WAIT_LGKM0();                    // my reads of K-tile t are complete
+        __builtin_amdgcn_s_barrier();    // BAR_t
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- k-step 3: reads of step 0 of K-tile t+1 after even MFMAs, unit 2t+5 pieces 0-7 after odd ones
+        rd_a = smem + sa1 + rowoff_a + x0; rd_b = smem + sb1 + rowoff_b + x0; dma_base = smem + s5 + dst_piece;
+        W4_STEP_BODY(1, 0, 0x5555u, 0xAAAAu, 1, 0)
+        sa = sa1;
+        sb = sb1;
+    }
+#undef W4_STEP_BODY
+#undef W4_GROUP
+    WAIT_VMCNT(0);                       // drain the clamped tail DMA before the workgroup retires
+
+    // ---- epilogue: lane owns C[m][n .. n+3] per register quad -----------------------------------------
+    char *__restrict__ C = static_cast<char *>(g.c);
+    constexpr int CSZ = (DT_C == MI355_DTYPE_F32) ? 4 : 2;
+    const int64_t cbase = batch * g.stride_c;
+    const bool vec_ok = (((g.ldc * CSZ) & (4 * CSZ - 1)) == 0) &&
+                        (((reinterpret_cast<uintptr_t>(C) + (uint64_t)cbase * CSZ) & (4 * CSZ - 1)) == 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + wm * 128 + i * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t n = n0 + wn * 128 + j * 32 + 8 * q + 4 * h;
+                const int64_t idx = cbase + m * g.ldc + n;
+                if (DT_C == MI355_DTYPE_F32) {
+                    float *dst = reinterpret_cast<float *>(C) + idx;
+                    if (vec_ok) {
+                        f32x4 v = {acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        *reinterpret_cast<f32x4 *>(dst) = v;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dst[r] = acc[i][j][4 * q + r];
+                    }
+                } else {
+                    uint16_t *dst = reinterpret_cast<uint16_t *>(C) + idx;
+                    uint16_t o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = f32_to_lp<DT_C>(acc[i][j][4 * q + r]);
+                    if (vec_ok) {
+                        u32x2 v = {(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16)};
+                        *reinterpret_cast<u32x2 *>(dst) = v;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dst[r] = o[r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int DT, int DT_C>
+void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch, int slot)
+{
+    if (!(ctx->func_attr_mask & (1ull << slot))) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_lp256w4_kernel<DT, DT_C>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        ctx->func_attr_mask |= (1ull << slot);
+    }
+    hipLaunchKernelGGL((gemm_lp256w4_kernel<DT, DT_C>), dim3(g.tiles_m * g.tiles_n, batch), dim3(256), LDS_BYTES, s, g);
+}
+
+}  // namespace
+
+namespace mi355 {
+
+bool gemm_lp256w4_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
+{
+    (void)c;
+    if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16) return false;
+    if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != d.dtype_ab) return false;
+    if (d.trans_a || !d.trans_b) return false;
+    if (d.k < BK || d.k % BK != 0) return false;
+    if (d.m < BM || d.m % BM != 0 || d.n < BN || d.n % BN != 0) return false;
+    if ((d.lda & 7) || (d.ldb & 7) || (d.stride_a & 7) || (d.stride_b & 7)) return false;
+    if ((reinterpret_cast<uintptr_t>(a) & 15u) || (reinterpret_cast<uintptr_t>(b) & 15u)) return false;
+    if (d.batch > 65535) return false;
+    const int64_t tiles = (d.m / BM) * (d.n / BN);
+    if (tiles > 0x7FFFFFFF) return false;
+    return true;
+}
+
+int32_t launch_gemm_lp256w4(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b,
+                            void *c)
+{
+    if (!gemm_lp256w4_supports(d, a, b, c))
+        return fail(ctx, MI355_E_UNSUPPORTED, "lp256w4 GEMM: shape/layout not supported by this kernel");
+    gemm_args g{};
+    g.a = a; g.b = b; g.c = c;
+    g.m = d.m; g.n = d.n; g.k = d.k;
+    g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc;
+    g.stride_a = d.stride_a; g.stride_b = d.stride_b; g.stride_c = d.stride_c;
+    g.tiles_m = (uint32_t)(d.m / BM);
+    g.tiles_n = (uint32_t)(d.n / BN);
+    g.group_m = 8;
+    const uint32_t batch = (uint32_t)d.batch;
+    if (d.dtype_ab == MI355_DTYPE_BF16) {
+        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, g, batch, 12);
+        else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16>(ctx, s, g, batch, 13);
+    } else {
+        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(ctx, s, g, batch, 14);
+        else launch<MI355_DTYPE_F16, MI355_DTYPE_F16>(ctx, s, g, batch, 15);
+    }
+    check_launch(ctx, "mi355_gemm(lp256w4)");
+    return MI355_OK;
+}
+
+}  // namespace mi355

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 GOLD = json.loads((Path(__file__).parent / "golden" / "reference_goldens.json").read_text())
 REL = 1e-5
 ALGOS = {"auto": N.GEMM_ALGO_AUTO, "generic": N.GEMM_ALGO_GENERIC, "f32": N.GEMM_ALGO_F32_MFMA,
-         "lp128": N.GEMM_ALGO_LP_128, "lp256": N.GEMM_ALGO_LP_256}
+         "lp128": N.GEMM_ALGO_LP_128, "lp256": N.GEMM_ALGO_LP_256, "lp256w4": N.GEMM_ALGO_LP_256W4}
 
 
 def _to_dev(client, oracle, x, dtype):
@@ -218,7 +218,37 @@ def test_lp256_identity_and_batch(client, oracle):
     assert np.array_equal(c.to_numpy(client), bmat)
 
 
-@pytest.mark.parametrize("algo", ["lp128", "lp256", "f32"])
+W4_CASES = [(256, 256, 64), (256, 256, 128), (256, 512, 192), (512, 512, 512), (768, 256, 1024), (512, 1024, 320),
+            (256, 256, 2048)]
+
+
+@pytest.mark.parametrize("m,n,k", W4_CASES)
+@pytest.mark.parametrize("dtype", [ElemType.BF16, ElemType.F16])
+@pytest.mark.parametrize("out", ["f32", "same"])
+def test_lp256w4_parity(client, oracle, m, n, k, dtype, out):
+    run_case(client, oracle, m, n, k, dtype, ElemType.F32 if out == "f32" else dtype, True, ALGOS["lp256w4"])
+
+
+def test_lp256w4_identity_batch_and_fallback(client, oracle):
+    run_case(client, oracle, 256, 256, 128, ElemType.BF16, ElemType.BF16, True, ALGOS["lp256w4"], batch=3)
+    run_case(client, oracle, 512, 256, 64, ElemType.BF16, ElemType.F32, True, ALGOS["lp256w4"], batch=2, bcast_b=True,
+             lda=72, ldb=64, ldc=260)
+    m = n = k = 512
+    eye = np.eye(m, dtype=np.float32)
+    bmat = ((np.arange(k)[:, None] * 3 + np.arange(n)[None, :] * 7) % 251).astype(np.float32)   # asymmetric
+    ta, _ = _to_dev(client, oracle, eye, ElemType.BF16)
+    tb, _ = _to_dev(client, oracle, np.ascontiguousarray(bmat.T), ElemType.BF16)
+    c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 4), ElemType.F32)
+    ops.matmul(client, TensorHandle.new(ta.handle, (m, k), (k, 1), ElemType.BF16),
+               TensorHandle.new(tb.handle, (k, n), (1, k), ElemType.BF16), c, algo=ALGOS["lp256w4"])
+    assert np.array_equal(c.to_numpy(client), bmat)
+    # ragged shapes are refused by this kernel (the dispatcher routes them to lp256 / lp128)
+    with pytest.raises(ServerError) as e:
+        run_case(client, oracle, 300, 256, 64, ElemType.BF16, ElemType.F32, True, ALGOS["lp256w4"])
+    assert e.value.code == N.E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("algo", ["lp128", "lp256", "lp256w4", "f32"])
 def test_race_screen_bitwise_repeatability(client, oracle, algo):
     # the counted-vmcnt / barrier pipeline must give the same bits on every launch (guide: "place reads by
     # the vmcnt/barrier count, never by clean runs") -- 25 launches at a multi-wave-per-CU size
@@ -260,7 +290,13 @@ def test_auto_selection_and_errors(client):
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_F32_MFMA
     d = N.GemmDesc(m=2048, n=2048, k=2048, batch=1, lda=2048, ldb=2048, ldc=2048, dtype_ab=N.DTYPE_BF16,
                    dtype_c=N.DTYPE_BF16, trans_b=1)
-    assert ops.gemm_select(client, d) in (N.GEMM_ALGO_LP_128, N.GEMM_ALGO_LP_256)
+    assert ops.gemm_select(client, d) in (N.GEMM_ALGO_LP_128, N.GEMM_ALGO_LP_256, N.GEMM_ALGO_LP_256W4)
+    d = N.GemmDesc(m=8192, n=8192, k=8192, batch=1, lda=8192, ldb=8192, ldc=8192, dtype_ab=N.DTYPE_BF16,
+                   dtype_c=N.DTYPE_BF16, trans_b=1)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    d = N.GemmDesc(m=8192 + 8, n=8192, k=8192, batch=1, lda=8192, ldb=8192, ldc=8192, dtype_ab=N.DTYPE_BF16,
+                   dtype_c=N.DTYPE_BF16, trans_b=1)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256
     d = N.GemmDesc(m=100, n=100, k=7, batch=1, lda=7, ldb=7, ldc=100, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_F32, trans_b=1)
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_GENERIC
     a = TensorHandle.new_contiguous((8, 8), client.empty(256), ElemType.F32)
