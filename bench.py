@@ -95,6 +95,19 @@ def samples_op(client, ev, fn, samples=15, warmup=5):
     return out[len(out) // 2], out[0]
 
 
+def pmc_traffic(size, algo):
+    """HBM bytes per launch of the headline kernel from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json, written by tools/pmc_traffic.sh: separate --pmc passes for FETCH_SIZE
+    and WRITE_SIZE, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when no
+    pass exists for this size / kernel."""
+    try:
+        table = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+        ent = table.get(f"gemm_bf16_{size}_algo{algo}")
+        return ent["hbm_bytes_per_launch"] if ent else None
+    except Exception:
+        return None
+
+
 def gemm_desc(N, m, n, k, dtype_ab, dtype_c, trans_b=1, batch=1, algo=0):
     return N.GemmDesc(m=m, n=n, k=k, batch=batch, lda=k, ldb=(k if trans_b else n), ldc=n, stride_a=m * k,
                       stride_b=n * k, stride_c=m * n, dtype_ab=dtype_ab, dtype_c=dtype_c, trans_a=0, trans_b=trans_b,
@@ -145,19 +158,27 @@ def main():
     def step():
         client._s.check(lib.mi355_gemm(ctx, None, C.byref(desc), pa, pb, pc))
 
+    clk = client.empty(64)           # two {shader ticks, 100 MHz ticks} samples bracketing the timed region
+    p_clk0, p_clk1 = C.c_void_p(clk.device_ptr()), C.c_void_p(clk.device_ptr() + 16)
     for _ in range(args.warmup):
         step()
     client.sync()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    lib.mi355_probe_clock(ctx, None, p_clk0)
     ev.start()
     for _ in range(args.steps):
         step()
     kernel_ms = ev.stop_ms()
+    lib.mi355_probe_clock(ctx, None, p_clk1)
     torch.cuda.synchronize()
+    client.sync()
     barrier()
     elapsed = time.perf_counter() - t0
+    import numpy as _np
+    ticks = _np.frombuffer(client.read_one(clk), dtype=_np.uint64)
+    eff_clock_ghz = float(ticks[2] - ticks[0]) / max(float(ticks[3] - ticks[1]), 1.0) * 0.1   # 100 MHz reference
     if world > 1:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -178,8 +199,13 @@ def main():
                    "kernel": {2: "f32_mfma", 3: "lp128", 4: "lp256", 5: "lp256w4", 1: "generic"}.get(sel.value, str(sel.value)),
                    "parallelism": f"batch-sharded x{world}, no data-path collective"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                     "kernel_ms": round(kernel_ms / args.steps, 4), "flop_per_launch": flop},
+                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(S, sel.value),
+                     "kernel_ms": round(kernel_ms / args.steps, 4), "flop_per_launch": flop,
+                     # the chip clocks down to its power budget on random operands (MI355X_MICROARCH.md "DVFS
+                     # give-back"): the 2.5 PFLOP/s peak assumes 2.4 GHz; these two lines price the kernel
+                     # against the matrix-pipe rate at the clock it actually ran at
+                     "shader_clock_GHz": round(eff_clock_ghz, 3),
+                     "frac_of_peak_at_clock": round(achieved / (PEAK_BF16_TFLOPS * eff_clock_ghz / 2.4), 4)},
         "device": props.name.decode() + " " + props.gcn_arch_name.decode(),
     }
 
@@ -234,6 +260,11 @@ def main():
                 ms = time_op(client, ev, lambda: client._s.check(
                     lib.mi355_probe_mfma(ctx, None, dt, iters, sink.device_ptr(), C.byref(n_ops))), 5)
                 out[name] = round(n_ops.value / ms / 1e9, 1)
+            # matrix-pipe ceiling on the benchmark's operand distribution (register-resident, no memory traffic)
+            n_ops = C.c_uint64()
+            ms = time_op(client, ev, lambda: client._s.check(
+                lib.mi355_probe_mfma_data(ctx, None, 1, 20000, sink.device_ptr(), C.byref(n_ops))), 5)
+            out["mfma_bf16_uniform_operands_TFLOPs"] = round(n_ops.value / ms / 1e9, 1)
             return out
         guarded("measured_ceilings", probes)
 

@@ -32,11 +32,14 @@
 //   K-tile t+1 are fetched under the last 16 MFMAs of K-tile t: the barrier is the only point
 //   where the pipe can drain.  Unit 2t+4 reuses the slot of unit 2t-1 (dead since BAR_{t-1}).
 //   Every DMA is issued >= 3 k-steps (~1500 cycles) before the barrier that needs it; vmcnt
-//   never reaches 0 in the loop.  Past the last K-tile the same instructions run against a clamped
+//   never reaches 0 in the loop.  After the last DMA of k-step 3 each wave issues one L2 prefetch
+//   load for K-tile t+4 (see "L2 prefetch map" below); it is the oldest of the 9 VMEM operations
+//   allowed in flight at the next hand-over, so it has ~1.75 K-tiles to come back.  Past the last K-tile the same instructions run against a clamped
 //   tile index (harmless re-reads into dead slots), keeping the counts uniform.
 //
 // Restrictions (the dispatcher falls back to gemm_lp256.hip / gemm_lp128.hip otherwise):
-//   M % 256 == 0, N % 256 == 0, K % 64 == 0, A row-major [M][K], B stored [N][K] (trans_b = 1).
+//   M % 256 == 0, N % 256 == 0, K % 64 == 0, A row-major [M][K], B stored [N][K] (trans_b = 1),
+//   C rows 16-byte aligned.
 #include <type_traits>
 
 #include "gemm_common.hpp"
@@ -73,7 +76,15 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
 #define W4_ABL 0          // dev ablations: 1 no DMA, 2 no fragment reads, 4 no MFMA, 16 no interleave pins
 #endif
 
-#define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" W4_STR(n) ")" ::: "memory")
+#ifndef W4_PF
+#define W4_PF 1       // L2 prefetch of K-tile t+4 (one global_load_dword per wave and K-tile)
+#endif
+#ifndef W4_VMW
+#define W4_VMW (8 + W4_PF)   // outstanding VMEM instructions allowed at the K-tile hand-over
+#endif
+#define W4_STR_(x) #x
+#define W4_STR(x) W4_STR_(x)
 #define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 template <int V> using IC = std::integral_constant<int, V>;
 
@@ -113,6 +124,32 @@ gemm_lp256w4_kernel(gemm_args g)
     }
     const int64_t step_a = 16 * g.lda * 2, step_b = 16 * g.ldb * 2;   // bytes between pieces j and j+2
     const int dst_piece = wave * 8 * 1024;                            // + j*1024 within the slot
+
+    // ---- L2 prefetch map.  Every unique 128-byte line of a K-tile is wanted by the 4 (A) or 8 (B)
+    //   workgroups of this XCD that share the panel, all at about the same time: the first request
+    //   misses L2 and the others queue behind the same fill, so every sharer pays the miss latency,
+    //   and the per-CU cap on outstanding vector-memory requests turns that latency into a
+    //   throughput limit (measured: LDS-DMA streams 125 GB/s/CU from a warm L2, 62 GB/s/CU in this
+    //   GEMM with no MFMA at all).  So each workgroup touches ITS SHARE of its panels' lines ~2
+    //   K-tiles ahead with one 4-byte load per line (sc1: served by L2, not allocated in L1): the
+    //   tile at (tm, tn) covers quarter tn%4 of A panel tm and eighth tm%8 of B panel tn -- the
+    //   sharers of a panel are consecutive in tn (A) / tm (B) under the grouped rasterisation, so
+    //   together they cover every line.  Placement only affects speed: an un-prefetched line is
+    //   simply demand-missed by the DMA as before.  Lane map per wave: lanes 0-15 -> 16 A rows,
+    //   lanes 16-23 -> 8 B rows, lanes 24-63 repeat lane 0's line (coalesced away).
+    const char *pf_src;
+    {
+        const int la = lane & 15, lb = lane & 7;
+        const int64_t row_a = m0 + (tn & 3) * 64 + wave * 16 + (lane < 16 ? la : 0);
+        const int64_t row_b = n0 + (tm & 7) * 32 + wave * 8 + lb;
+        pf_src = (lane >= 16 && lane < 24) ? B + row_b * g.ldb * 2 : A + row_a * g.lda * 2;
+    }
+    unsigned pf_sink = 0;
+    auto prefetch = [&](int tile) {
+        if (!W4_PF || (W4_ABL & 1)) return;
+        const char *p = pf_src + (int64_t)min(tile, nk - 1) * (BK * 2);
+        asm volatile("global_load_dword %0, %1, off sc1" : "+v"(pf_sink) : "v"(p) : "memory");
+    };
 
     // ---- fragment read offsets: row*128 + ((2s+h) ^ f) * 16, f = (row>>1)&7 = (l31>>1)&7 for every tile row
     const int f = (l31 >> 1) & 7;
@@ -188,7 +225,8 @@ gemm_lp256w4_kernel(gemm_args g)
         W4_PRO(0, k0, 0) W4_PRO(1, k0, 1) W4_PRO(0, k1, 2) W4_PRO(1, k1, 3)
 #undef W4_PRO
     }
-    WAIT_VMCNT(16);                      // units 0, 1 landed (this wave's share)
+    prefetch(3);
+    WAIT_VMCNT(16 + W4_PF);              // units 0, 1 landed (this wave's share)
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -223,58 +261,74 @@ gemm_lp256w4_kernel(gemm_args g)
         // ---- k-step 2: reads of step 3, no DMA; then the K-tile hand-over
         rd_a = smem + sa + rowoff_a + x3; rd_b = smem + sb + rowoff_b + x3;
         W4_STEP_BODY(0, 1, 0x00FFu, 0x0000u, 0, 0)
-        WAIT_VMCNT(8);                   // my share of K-tile t+1 landed; unit 2t+4 may still fly
+        WAIT_VMCNT(W4_VMW);              // my share of K-tile t+1 landed; unit 2t+4 may still fly
         WAIT_LGKM0();                    // my reads of K-tile t are complete
         __builtin_amdgcn_s_barrier();    // BAR_t
         __builtin_amdgcn_sched_barrier(0);
         // ---- k-step 3: reads of step 0 of K-tile t+1 after even MFMAs, unit 2t+5 pieces 0-7 after odd ones
         rd_a = smem + sa1 + rowoff_a + x0; rd_b = smem + sb1 + rowoff_b + x0; dma_base = smem + s5 + dst_piece;
         W4_STEP_BODY(1, 0, 0x5555u, 0xAAAAu, 1, 0)
+        prefetch(t + 4);
+        __builtin_amdgcn_sched_barrier(0);
         sa = sa1;
         sb = sb1;
     }
 #undef W4_STEP_BODY
 #undef W4_GROUP
     WAIT_VMCNT(0);                       // drain the clamped tail DMA before the workgroup retires
+    asm volatile("" ::"v"(pf_sink));     // the prefetch destination register stays reserved until here
 
-    // ---- epilogue: lane owns C[m][n .. n+3] per register quad -----------------------------------------
+    // ---- epilogue ----------------------------------------------------------------------------------
+    // With the operands swapped in the MFMA (first = B fragment), lane (l31, h) of a wave holds, for
+    // every 32-row block i, row l31 of the block and the column groups n = j*32 + 8q + 4h .. +3.
+    // Stored straight from registers that is 8 B per lane on 32 different rows per instruction: every
+    // 128-byte line of C is assembled from 16 partial writes (measured: ~39k cycles of fixed cost per
+    // output tile).  Instead each wave transposes its 128 x 128 block through its own LDS scratch, 32
+    // rows at a time, and writes whole rows: 16 B per lane, 256 (16-bit) / 512 (f32) contiguous bytes
+    // per row, every line written once.  Row pitch +16 B keeps the b128 accesses aligned and the
+    // writes at most 2-way bank conflicted.
     char *__restrict__ C = static_cast<char *>(g.c);
     constexpr int CSZ = (DT_C == MI355_DTYPE_F32) ? 4 : 2;
     const int64_t cbase = batch * g.stride_c;
-    const bool vec_ok = (((g.ldc * CSZ) & (4 * CSZ - 1)) == 0) &&
-                        (((reinterpret_cast<uintptr_t>(C) + (uint64_t)cbase * CSZ) & (4 * CSZ - 1)) == 0);
+    {
+        constexpr int RS = 128 * CSZ + 16;                 // staged row pitch in bytes
+        constexpr int STAGE = 32 * RS;                     // per-wave scratch: 8.5 KiB (16-bit) / 16.5 KiB (f32)
+        constexpr int LPR = 128 * CSZ / 16;                // lanes per output row: 16 / 32
+        constexpr int RPI = 64 / LPR;                      // rows per store instruction: 4 / 2
+        __builtin_amdgcn_s_barrier();                      // every wave's tail DMA has landed; LDS is free
+        char *stage = smem + wave * ((STAGE + 1023) & ~1023);
+        char *wr = stage + l31 * RS + 4 * h * CSZ;
+        const char *rd = stage + (lane / LPR) * RS + (lane % LPR) * 16;
+        char *crow = C + (cbase + (m0 + wm * 128 + lane / LPR) * g.ldc + n0 + wn * 128) * CSZ + (lane % LPR) * 16;
+        const int64_t cstep = (int64_t)RPI * g.ldc * CSZ;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t m = m0 + wm * 128 + i * 32 + l31;
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int64_t n = n0 + wn * 128 + j * 32 + 8 * q + 4 * h;
-                const int64_t idx = cbase + m * g.ldc + n;
-                if (DT_C == MI355_DTYPE_F32) {
-                    float *dst = reinterpret_cast<float *>(C) + idx;
-                    if (vec_ok) {
+                for (int q = 0; q < 4; ++q) {
+                    char *d = wr + (j * 32 + 8 * q) * CSZ;
+                    if constexpr (DT_C == MI355_DTYPE_F32) {
                         f32x4 v = {acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                        *reinterpret_cast<f32x4 *>(dst) = v;
+                        *reinterpret_cast<f32x4 *>(d) = v;
+                    } else if constexpr (DT_C == MI355_DTYPE_BF16) {
+                        bf16x4 v = {(__bf16)acc[i][j][4 * q + 0], (__bf16)acc[i][j][4 * q + 1], (__bf16)acc[i][j][4 * q + 2],
+                                    (__bf16)acc[i][j][4 * q + 3]};
+                        *reinterpret_cast<bf16x4 *>(d) = v;
                     } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) dst[r] = acc[i][j][4 * q + r];
-                    }
-                } else {
-                    uint16_t *dst = reinterpret_cast<uint16_t *>(C) + idx;
-                    uint16_t o[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = f32_to_lp<DT_C>(acc[i][j][4 * q + r]);
-                    if (vec_ok) {
-                        u32x2 v = {(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16)};
-                        *reinterpret_cast<u32x2 *>(dst) = v;
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) dst[r] = o[r];
+                        f16x4 v = {(_Float16)acc[i][j][4 * q + 0], (_Float16)acc[i][j][4 * q + 1], (_Float16)acc[i][j][4 * q + 2],
+                                   (_Float16)acc[i][j][4 * q + 3]};
+                        *reinterpret_cast<f16x4 *>(d) = v;
                     }
                 }
+            WAIT_LGKM0();                                  // same-wave hand-over: DS ops of one wave execute in order
+            char *cdst = crow + (int64_t)i * 32 * g.ldc * CSZ;
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) {
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(rd + it * RPI * RS);
+                *reinterpret_cast<u32x4 *>(cdst + it * cstep) = v;
             }
+            __builtin_amdgcn_sched_barrier(0);             // keep the accumulator reads of block i+1 below this point
         }
     }
 }
@@ -296,11 +350,12 @@ namespace mi355 {
 
 bool gemm_lp256w4_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
 {
-    (void)c;
     if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16) return false;
     if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != d.dtype_ab) return false;
     if (d.trans_a || !d.trans_b) return false;
     if (d.k < BK || d.k % BK != 0) return false;
+    const int64_t csz = d.dtype_c == MI355_DTYPE_F32 ? 4 : 2;      // the epilogue writes C in 16-byte pieces
+    if (((d.ldc * csz) & 15) || ((d.stride_c * csz) & 15) || (reinterpret_cast<uintptr_t>(c) & 15u)) return false;
     if (d.m < BM || d.m % BM != 0 || d.n < BN || d.n % BN != 0) return false;
     if ((d.lda & 7) || (d.ldb & 7) || (d.stride_a & 7) || (d.stride_b & 7)) return false;
     if ((reinterpret_cast<uintptr_t>(a) & 15u) || (reinterpret_cast<uintptr_t>(b) & 15u)) return false;

@@ -81,7 +81,97 @@ probe_mfma_kernel(uint32_t iters, float *__restrict__ sink)
     if (t == 1.2345e38f) sink[0] = t;
 }
 
+// MFMA issue loop on 4x4 accumulator tiles (the GEMM kernels' register shape) with operands that are
+// either all ones (MODE 0) or uniform[-1,1) values that differ per lane, per fragment and rotate every
+// iteration (MODE 1).  No LDS or memory traffic: MODE 1 is the ceiling the matrix pipe itself reaches on
+// the benchmark's operand distribution once the chip clocks down to its power budget
+// (MI355X_MICROARCH.md "DVFS give-back").
+__device__ __forceinline__ uint32_t probe_mix(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256)
+probe_mfma_data_kernel(uint32_t iters, float *__restrict__ sink)
+{
+    const uint32_t tid = threadIdx.x;
+    bf16x8 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float va = 1.f, vb = 1.f;
+            if (MODE == 1) {
+                va = (probe_mix(tid * 977u + i * 131u + e * 7u + blockIdx.x * 7919u) >> 8) * (2.0f / 16777216.0f) - 1.0f;
+                vb = (probe_mix(tid * 613u + i * 257u + e * 11u + 99991u + blockIdx.x * 104729u) >> 8) * (2.0f / 16777216.0f) - 1.0f;
+            }
+            a[i][e] = (__bf16)va;
+            b[i][e] = (__bf16)vb;
+        }
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (uint32_t it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        if (MODE == 1) {
+            const bf16x8 t = a[0];
+            a[0] = a[1]; a[1] = a[2]; a[2] = a[3]; a[3] = t;
+        }
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+    if (t == 1.2345e38f) sink[0] = t;
+}
+
+// {shader-clock ticks, constant 100 MHz ticks} of one CU: two samples bracket a region, and
+// d(shader) / d(constant) * 100 MHz is the clock the chip actually sustained over it.
+__global__ void __launch_bounds__(64) probe_clock_kernel(uint64_t *__restrict__ out)
+{
+    if (threadIdx.x == 0) {
+        out[0] = __builtin_amdgcn_s_memtime();
+        out[1] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
 }  // namespace
+
+MI355_API int32_t mi355_probe_clock(mi355_ctx *ctx, mi355_stream stream, uint64_t *dev_out)
+{
+    MI355_REQUIRE_CTX(ctx);
+    if (!dev_out) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_probe_clock: output pointer is NULL");
+    hipLaunchKernelGGL(probe_clock_kernel, dim3(1), dim3(64), 0, stream_of(ctx, stream), dev_out);
+    check_launch(ctx, "mi355_probe_clock");
+    return MI355_OK;
+}
+
+MI355_API int32_t mi355_probe_mfma_data(mi355_ctx *ctx, mi355_stream stream, int32_t mode, uint32_t iters, void *sink,
+                                        uint64_t *out_ops)
+{
+    MI355_REQUIRE_CTX(ctx);
+    if (!sink) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_probe_mfma_data: sink is NULL");
+    if (mode != 0 && mode != 1) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_probe_mfma_data: mode must be 0 or 1");
+    const uint32_t grid = ctx->props.num_streaming_multiprocessors;   // one 4-wave workgroup per CU, one wave per SIMD
+    hipStream_t s = stream_of(ctx, stream);
+    if (mode == 0) hipLaunchKernelGGL(probe_mfma_data_kernel<0>, dim3(grid), dim3(256), 0, s, iters, static_cast<float *>(sink));
+    else hipLaunchKernelGGL(probe_mfma_data_kernel<1>, dim3(grid), dim3(256), 0, s, iters, static_cast<float *>(sink));
+    check_launch(ctx, "mi355_probe_mfma_data");
+    if (out_ops) *out_ops = (uint64_t)grid * 4ull * iters * 16ull * (2ull * 32 * 32 * 16);
+    return MI355_OK;
+}
 
 MI355_API int32_t mi355_probe_memory_read(mi355_ctx *ctx, mi355_stream stream, const void *buf, uint64_t bytes,
                                           uint32_t iters, void *sink)

@@ -334,6 +334,17 @@ int32_t mi355_probe_memory_read(mi355_ctx *ctx, mi355_stream stream, const void 
 int32_t mi355_probe_mfma(mi355_ctx *ctx, mi355_stream stream, int32_t dtype_ab, uint32_t iters,
                          void *sink, uint64_t *out_ops);
 
+/* The same issue loop on the GEMM kernels' 4x4 accumulator shape (bf16), register-resident, with
+ * mode 0 = all-ones operands, mode 1 = uniform[-1,1) operands rotating every iteration.  Mode 1 is
+ * the matrix-pipe ceiling for the benchmark's operand distribution once DVFS has clocked the chip
+ * down to its power budget; bench.py reports it beside the spec peak (not a reference probe). */
+int32_t mi355_probe_mfma_data(mi355_ctx *ctx, mi355_stream stream, int32_t mode, uint32_t iters,
+                              void *sink, uint64_t *out_ops);
+/* Samples {shader-clock ticks, constant 100 MHz ticks} into dev_out[0..1] (device memory) on the
+ * stream: two samples bracketing a region give the shader clock sustained over it
+ * (timing_method Device, crates/cubecl-hip/src/runtime.rs:198 analogue). */
+int32_t mi355_probe_clock(mi355_ctx *ctx, mi355_stream stream, uint64_t *dev_out);
+
 /* =================================== Collectives (RCCL over xGMI) ======================== */
 
 #define MI355_UNIQUE_ID_BYTES 128
