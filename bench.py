@@ -158,8 +158,9 @@ def main():
     def step():
         client._s.check(lib.mi355_gemm(ctx, None, C.byref(desc), pa, pb, pc))
 
-    clk = client.empty(64)           # two {shader ticks, 100 MHz ticks} samples bracketing the timed region
-    p_clk0, p_clk1 = C.c_void_p(clk.device_ptr()), C.c_void_p(clk.device_ptr() + 16)
+    clk = client.empty(256)          # two samples of {shader ticks, 100 MHz ticks} x 8 XCDs bracketing the timed region
+    lib.mi355_memset(ctx, None, C.c_void_p(clk.device_ptr()), 0, 256)
+    p_clk0, p_clk1 = C.c_void_p(clk.device_ptr()), C.c_void_p(clk.device_ptr() + 128)
     for _ in range(args.warmup):
         step()
     client.sync()
@@ -177,8 +178,11 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     import numpy as _np
-    ticks = _np.frombuffer(client.read_one(clk), dtype=_np.uint64)
-    eff_clock_ghz = float(ticks[2] - ticks[0]) / max(float(ticks[3] - ticks[1]), 1.0) * 0.1   # 100 MHz reference
+    ticks = _np.frombuffer(client.read_one(clk), dtype=_np.uint64).reshape(2, 8, 2).astype(_np.float64)
+    per_xcd = [(ticks[1, x, 0] - ticks[0, x, 0]) / (ticks[1, x, 1] - ticks[0, x, 1]) * 0.1      # 100 MHz reference
+               for x in range(8) if ticks[0, x, 1] > 0 and ticks[1, x, 1] > ticks[0, x, 1]]
+    per_xcd.sort()
+    eff_clock_ghz = per_xcd[len(per_xcd) // 2] if per_xcd else float("nan")
     if world > 1:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -73,12 +73,14 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
 }
 
 #ifndef W4_ABL
-#define W4_ABL 0          // dev ablations: 1 no DMA, 2 no fragment reads, 4 no MFMA, 16 no interleave pins
+#define W4_ABL 0          // dev ablations: 1 no DMA, 2 no fragment reads, 4 no MFMA, 32 DMA re-reads K-tiles 0-2, 64 DMA off after K-tile 2
 #endif
 
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" W4_STR(n) ")" ::: "memory")
 #ifndef W4_PF
-#define W4_PF 1       // L2 prefetch of K-tile t+4 (one global_load_dword per wave and K-tile)
+#define W4_PF 0       // 1: L2 prefetch of K-tile t+4 (one global_load_dword per wave and K-tile).  Measured:
+                      // +16 % on the DMA-only ablation, -1.5 % on the full kernel (12.7 M extra L2 requests for
+                      // nothing: with MFMAs in the stream the DMA latency is already covered) => off.
 #endif
 #ifndef W4_VMW
 #define W4_VMW (8 + W4_PF)   // outstanding VMEM instructions allowed at the K-tile hand-over
@@ -174,9 +176,10 @@ gemm_lp256w4_kernel(gemm_args g)
         else if (R <= 4) fa[BUF][R - 1] = *reinterpret_cast<const frag *>(pa + (R - 1) * 32 * ROW_BYTES);
         else fb[BUF][R - 4] = *reinterpret_cast<const frag *>(pb + (R - 4) * 32 * ROW_BYTES);
     };
+    bool dma_on = true;   // dev ablation 64 switches the DMA off after the ring is filled with real data
     auto dma_one = [&](auto is_b, auto jj, int64_t koff, char *base) {
         constexpr int J = decltype(jj)::value;
-        if (W4_ABL & 1) return;
+        if ((W4_ABL & 1) || !dma_on) return;
         const char *s = decltype(is_b)::value ? src_b[J & 1] + (J >> 1) * step_b : src_a[J & 1] + (J >> 1) * step_a;
         glds16(s + koff, base + J * 1024);
     };
@@ -249,7 +252,8 @@ gemm_lp256w4_kernel(gemm_args g)
         const int sa1 = adv(sa, 2), sb1 = adv(sb, 2);     // units 2t+2, 2t+3 (K-tile t+1)
         const int s4 = adv(sa, 4);                        // unit 2t+4 -> slot of unit 2t-1
         const int s5 = sa;                                // unit 2t+5 -> slot of unit 2t
-        const int64_t dma_koff = (int64_t)min(t + 2, nk - 1) * (BK * 2);
+        const int64_t dma_koff = (int64_t)min(t + 2, (W4_ABL & 32) ? 2 : nk - 1) * (BK * 2);
+        if ((W4_ABL & 64) && t >= 2) dma_on = false;
         const char *rd_a, *rd_b;
         char *dma_base;
         // ---- k-step 0: reads of step 1 after MFMA 0-7, unit 2t+4 pieces 0-3 after MFMA 9,11,13,15

@@ -45,6 +45,9 @@ struct mi355_ctx {
     hipEvent_t fence_a = nullptr;  // reusable fences for the comm <-> compute hand-offs
     hipEvent_t fence_b = nullptr;
     bool comm_dirty = false;
+    void *ticket_buf = nullptr;            // library-owned device scratch: arrival tickets of the reductions
+    std::unordered_map<hipStream_t, uint32_t> ticket_slots;
+    bool tickets_dirty = false;
     uint64_t func_attr_mask = 0;  // kernels whose dynamic-LDS attribute is already raised on this device
 };
 

@@ -139,11 +139,16 @@ probe_mfma_data_kernel(uint32_t iters, float *__restrict__ sink)
 
 // {shader-clock ticks, constant 100 MHz ticks} of one CU: two samples bracket a region, and
 // d(shader) / d(constant) * 100 MHz is the clock the chip actually sustained over it.
+// The shader-clock counter is per XCD, so every XCD records its own pair (slot = HW_REG_XCC_ID).
 __global__ void __launch_bounds__(64) probe_clock_kernel(uint64_t *__restrict__ out)
 {
     if (threadIdx.x == 0) {
-        out[0] = __builtin_amdgcn_s_memtime();
-        out[1] = __builtin_amdgcn_s_memrealtime();
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 7u;
+        const uint64_t t = __builtin_amdgcn_s_memtime(), r = __builtin_amdgcn_s_memrealtime();
+        out[2 * xcc] = t;
+        out[2 * xcc + 1] = r;
     }
 }
 
@@ -153,7 +158,7 @@ MI355_API int32_t mi355_probe_clock(mi355_ctx *ctx, mi355_stream stream, uint64_
 {
     MI355_REQUIRE_CTX(ctx);
     if (!dev_out) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_probe_clock: output pointer is NULL");
-    hipLaunchKernelGGL(probe_clock_kernel, dim3(1), dim3(64), 0, stream_of(ctx, stream), dev_out);
+    hipLaunchKernelGGL(probe_clock_kernel, dim3(4 * ctx->props.num_xcd), dim3(64), 0, stream_of(ctx, stream), dev_out);
     check_launch(ctx, "mi355_probe_clock");
     return MI355_OK;
 }

@@ -5,16 +5,24 @@
 // (/opt/skills/guides/cdna_hip_programming.md G2/G7/G11/G13, Appendix B "Reduction"):
 //   - 16 B per lane coalesced loads (global_load_dwordx4, non-temporal: the data is read once),
 //     RED_UNROLL independent loads in flight per lane, one independent accumulator per load slot;
-//   - grid = a few workgroups per CU, grid-stride over 32 KiB tiles (no XCD remap: there is no
-//     inter-workgroup reuse, guide T1 "Transfer: 0% on LayerNorm");
+//   - grid = 3 workgroups per CU (measured on the 1 GiB sum: 1/2/3/4/8/16 per CU = 176/156/157/162/181/183 us, and 3 is
+//     the best for the VALU-heavier argmax: 169/161/167 us at 2/3/4;
+//     fewer workgroups = fewer partial records and arrival atomics at the tail), grid-stride over
+//     32 KiB tiles (no XCD remap: there is no inter-workgroup reuse, guide T1 "Transfer: 0% on LayerNorm");
 //   - wave64 xor butterfly in the reference's plane_reduce order
 //     (crates/cubecl-cpp/src/shared/plane.rs:60-70), then LDS across the 4 waves, one partial
-//     record per workgroup, and a second tiny launch that folds the records in index order:
-//     the summation tree is a pure function of (n, grid) => bit-reproducible run to run, and no
-//     float atomics.
+//     record per workgroup; the LAST workgroup to arrive (ticket word) folds the records in index
+//     order inside the same launch: the summation tree is a pure function of (n, grid) =>
+//     bit-reproducible run to run, no float atomics, and no second launch (the separate fold
+//     kernel + stream boundary cost ~6 us of a ~160 us pass);
+//   - inter-workgroup hand-off by 8-byte agent-scope atomics on both sides (write-through sc1
+//     stores, per-wave vmcnt(0) drain, then the ticket; sc1 loads in the folding workgroup) --
+//     placement independent (guide section 6, Guideline 16).  The ticket word is library-owned
+//     scratch (one per stream), zero between calls because the last arriver resets it.
 #include "internal.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 using namespace mi355;
 
@@ -69,14 +77,45 @@ __device__ __forceinline__ void wave_argmax(uint32_t &key, uint64_t &idx)
     }
 }
 
-// Stage 1: every workgroup folds its tiles into one record.
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+
+__device__ __forceinline__ void record_store(red_record *slot, float sum, uint32_t key, uint64_t idx)
+{
+    gu64 *p = (gu64 *)(unsigned long long *)slot;
+    __hip_atomic_store(p, ((unsigned long long)key << 32) | __float_as_uint(sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 1, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ red_record record_load(const red_record *slot)
+{
+    gu64 *p = (gu64 *)(unsigned long long *)const_cast<red_record *>(slot);
+    const unsigned long long a = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red_record r;
+    r.sum = __uint_as_float((uint32_t)a);
+    r.key = (uint32_t)(a >> 32);
+    r.idx = b;
+    return r;
+}
+
+// Arrival ticket: one returning agent-scope fetch_add per workgroup (a compare-and-swap loop here costs
+// one L2 round trip per CONTENDER: 2048 workgroups finishing together took 8 ms).  The word lives in
+// library-owned device scratch that is zero between calls: the last arriver puts the zero back.
+__device__ __forceinline__ bool arrive_is_last(unsigned int *ticket, uint32_t G)
+{
+    typedef __attribute__((address_space(1))) unsigned int gu32;
+    const unsigned int old = __hip_atomic_fetch_add((gu32 *)ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return old == G - 1;
+}
+
+// Every workgroup folds its tiles into one record; the last one to arrive folds the G records.
 //   in      : 16-byte aligned body of the array (host peels a misaligned head into `head`)
 //   head    : up to 3 leading elements (global indices 0..head_n-1), body index i maps to
 //             global index i + head_n
 template <bool SUM, bool ARG>
 __global__ void __launch_bounds__(RED_BLOCK)
-reduce_stage1(const float *__restrict__ head, uint32_t head_n, const float *__restrict__ in, uint64_t n,
-              red_record *__restrict__ records)
+reduce_kernel(const float *__restrict__ head, uint32_t head_n, const float *__restrict__ in, uint64_t n,
+              red_record *__restrict__ records, unsigned int *__restrict__ ticket, uint64_t n_total, float *__restrict__ out_sum, float *__restrict__ out_val, uint64_t *__restrict__ out_idx)
 {
     const uint32_t tid = threadIdx.x;
     const uint64_t full_tiles = n / RED_TILE;
@@ -88,12 +127,13 @@ reduce_stage1(const float *__restrict__ head, uint32_t head_n, const float *__re
     float tail_acc = 0.f;
     uint32_t best_key = 0u;          // 0 = "nothing yet": every real key is >= 0x007FFFFF (-inf)
     uint64_t best_idx = ~0ull;
+    float best_val = -__builtin_inff();   // value behind best_key (+inf once a NaN leads): the fast-reject threshold
 
     // peeled head: lowest global indices, block 0 only
     if (blockIdx.x == 0 && tid < head_n) {
         const float v = head[tid];
         if (SUM) tail_acc += v;
-        if (ARG) { best_key = argmax_key(v); best_idx = tid; }
+        if (ARG) { best_key = argmax_key(v); best_idx = tid; best_val = (best_key == 0xFFFFFFFFu) ? __builtin_inff() : v; }
     }
 
     const f32x4 *__restrict__ vin = reinterpret_cast<const f32x4 *>(in);
@@ -106,12 +146,21 @@ reduce_stage1(const float *__restrict__ head, uint32_t head_n, const float *__re
         for (int u = 0; u < RED_UNROLL; ++u) {
             if (SUM) acc[u] += v[u];
             if (ARG) {
-                const uint64_t e0 = (vbase + (uint64_t)u * RED_BLOCK) * 4 + head_n;
+                // Fast reject: a 16-byte vector can only matter if it holds a NaN or a value above this
+                // lane's running maximum (new maxima get rare quickly: ~ln(n) per lane), so the exact
+                // key/index update below runs on a few percent of the vectors.  v_max ignores NaNs,
+                // hence the separate unordered test; -0 vs +0 never compares greater, which is the
+                // tie rule (equal keys keep the lower index).
+                const float m4 = fmaxf(fmaxf(v[u][0], v[u][1]), fmaxf(v[u][2], v[u][3]));
+                const bool has_nan = __builtin_isunordered(v[u][0], v[u][1]) | __builtin_isunordered(v[u][2], v[u][3]);
+                if ((m4 > best_val) | has_nan | (best_key == 0u)) {
+                    const uint64_t e0 = (vbase + (uint64_t)u * RED_BLOCK) * 4 + head_n;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const uint32_t k = argmax_key(v[u][c]);
-                    // strict > : within one lane indices only grow, so the first maximum is kept
-                    if (k > best_key) { best_key = k; best_idx = e0 + c; }
+                    for (int c = 0; c < 4; ++c) {
+                        const uint32_t k = argmax_key(v[u][c]);
+                        // strict > : within one lane indices only grow, so the first maximum is kept
+                        if (k > best_key) { best_key = k; best_idx = e0 + c; best_val = (k == 0xFFFFFFFFu) ? __builtin_inff() : v[u][c]; }
+                    }
                 }
             }
         }
@@ -130,12 +179,10 @@ reduce_stage1(const float *__restrict__ head, uint32_t head_n, const float *__re
         }
     }
 
-    __shared__ float s_sum[RED_BLOCK / 64];
-    __shared__ uint32_t s_key[RED_BLOCK / 64];
-    __shared__ uint64_t s_idx[RED_BLOCK / 64];
+    // all LDS scratch in one object (hand-off flag included)
+    __shared__ struct { float sum[RED_BLOCK / 64]; uint32_t key[RED_BLOCK / 64]; uint64_t idx[RED_BLOCK / 64]; uint32_t last; } sh;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
 
-    float total = 0.f;
     if (SUM) {
         // fixed tree: slots pairwise, then the 4 vector components, then tail, then lanes
         f32x4 a = (acc[0] + acc[1]) + (acc[2] + acc[3]);
@@ -143,73 +190,90 @@ reduce_stage1(const float *__restrict__ head, uint32_t head_n, const float *__re
         f32x4 s = a + b;
         float lane_sum = ((s[0] + s[1]) + (s[2] + s[3])) + tail_acc;
         lane_sum = wave_sum(lane_sum);
-        if (lane == 0) s_sum[wave] = lane_sum;
+        if (lane == 0) sh.sum[wave] = lane_sum;
     }
     if (ARG) {
         wave_argmax(best_key, best_idx);
-        if (lane == 0) { s_key[wave] = best_key; s_idx[wave] = best_idx; }
+        if (lane == 0) { sh.key[wave] = best_key; sh.idx[wave] = best_idx; }
     }
     __syncthreads();
     if (tid == 0) {
-        red_record r;
-        r.sum = 0.f; r.key = 0u; r.idx = ~0ull;
-        if (SUM) { total = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]); r.sum = total; }
+        float rs = 0.f; uint32_t rk = 0u; uint64_t ri = ~0ull;
+        if (SUM) rs = (sh.sum[0] + sh.sum[1]) + (sh.sum[2] + sh.sum[3]);
         if (ARG) {
-            uint32_t k = s_key[0]; uint64_t ix = s_idx[0];
+            rk = sh.key[0]; ri = sh.idx[0];
 #pragma unroll
-            for (int w = 1; w < RED_BLOCK / 64; ++w) arg_combine(k, ix, s_key[w], s_idx[w]);
-            r.key = k; r.idx = ix;
+            for (int w = 1; w < RED_BLOCK / 64; ++w) arg_combine(rk, ri, sh.key[w], sh.idx[w]);
         }
-        records[blockIdx.x] = r;
+        record_store(records + blockIdx.x, rs, rk, ri);            // write-through (sc1) 8-byte stores
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // ... drained before the ticket
+        sh.last = arrive_is_last(ticket, G) ? 1u : 0u;
     }
-}
+    __syncthreads();
+    if (!sh.last) return;
 
-// Stage 2: one workgroup folds the G records in index order (G <= RED_MAX_GRID).
-template <bool SUM, bool ARG>
-__global__ void __launch_bounds__(RED_BLOCK)
-reduce_stage2(const red_record *__restrict__ records, uint32_t G, const float *__restrict__ base, uint32_t head_n,
-              const float *__restrict__ head, uint64_t n_total, float *__restrict__ out_sum,
-              float *__restrict__ out_val, uint64_t *__restrict__ out_idx)
-{
-    const uint32_t tid = threadIdx.x;
-    float acc = 0.f;
+    // ---- the last workgroup folds the G records in index order (thread t owns t, t+256, ...) ----
+    float facc = 0.f;
     uint32_t key = 0u;
     uint64_t idx = ~0ull;
-    // thread t owns records t, t+256, ...: a fixed assignment
-    for (uint32_t g = tid; g < G; g += RED_BLOCK) {
-        const red_record r = records[g];
-        if (SUM) acc += r.sum;
+    for (uint32_t gi = tid; gi < G; gi += RED_BLOCK) {
+        const red_record r = record_load(records + gi);            // sc1 loads: served by L2, never a stale L1 line
+        if (SUM) facc += r.sum;
         if (ARG) arg_combine(key, idx, r.key, r.idx);
     }
-    __shared__ float s_sum[RED_BLOCK / 64];
-    __shared__ uint32_t s_key[RED_BLOCK / 64];
-    __shared__ uint64_t s_idx[RED_BLOCK / 64];
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
-    if (SUM) { acc = wave_sum(acc); if (lane == 0) s_sum[wave] = acc; }
-    if (ARG) { wave_argmax(key, idx); if (lane == 0) { s_key[wave] = key; s_idx[wave] = idx; } }
+    __syncthreads();                                                // sh.* is reused below
+    if (SUM) { facc = wave_sum(facc); if (lane == 0) sh.sum[wave] = facc; }
+    if (ARG) { wave_argmax(key, idx); if (lane == 0) { sh.key[wave] = key; sh.idx[wave] = idx; } }
     __syncthreads();
     if (tid == 0) {
-        if (SUM && out_sum) *out_sum = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+        typedef __attribute__((address_space(1))) unsigned int gu32;
+        __hip_atomic_store((gu32 *)ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
+        if (SUM && out_sum) *out_sum = (sh.sum[0] + sh.sum[1]) + (sh.sum[2] + sh.sum[3]);
         if (ARG) {
-            uint32_t k = s_key[0]; uint64_t ix = s_idx[0];
+            uint32_t k = sh.key[0]; uint64_t ix = sh.idx[0];
 #pragma unroll
-            for (int w = 1; w < RED_BLOCK / 64; ++w) arg_combine(k, ix, s_key[w], s_idx[w]);
+            for (int w = 1; w < RED_BLOCK / 64; ++w) arg_combine(k, ix, sh.key[w], sh.idx[w]);
             if (n_total == 0) {
                 if (out_idx) *out_idx = 0;
                 if (out_val) *out_val = -__builtin_inff();
             } else {
                 if (out_idx) *out_idx = ix;
                 // bit-exact copy of the winning element
-                if (out_val) *out_val = (ix < head_n) ? head[ix] : base[ix - head_n];
+                if (out_val) *out_val = (ix < head_n) ? head[ix] : in[ix - head_n];
             }
         }
     }
 }
 
+// One arrival-ticket word per stream in library-owned device scratch (zeroed when created, left zero by
+// every completed call).  Calls on one stream are stream-ordered, so a word is never shared by two
+// launches in flight.
+int32_t ticket_for_stream(mi355_ctx *ctx, hipStream_t s, unsigned int **out)
+{
+    constexpr uint32_t SLOTS = 1024;
+    if (!ctx->ticket_buf) {
+        MI355_HIP(ctx, hipMalloc(&ctx->ticket_buf, SLOTS * 64));
+        MI355_HIP(ctx, hipMemset(ctx->ticket_buf, 0, SLOTS * 64));
+    } else if (ctx->tickets_dirty) {
+        MI355_HIP(ctx, hipDeviceSynchronize());
+        MI355_HIP(ctx, hipMemset(ctx->ticket_buf, 0, SLOTS * 64));
+    }
+    ctx->tickets_dirty = false;
+    auto it = ctx->ticket_slots.find(s);
+    if (it == ctx->ticket_slots.end()) {
+        if (ctx->ticket_slots.size() >= SLOTS)
+            return fail(ctx, MI355_E_UNSUPPORTED, "reductions were issued on more than %u distinct streams of one context", SLOTS);
+        it = ctx->ticket_slots.emplace(s, (uint32_t)ctx->ticket_slots.size()).first;
+    }
+    *out = reinterpret_cast<unsigned int *>(static_cast<char *>(ctx->ticket_buf) + (size_t)it->second * 64);   // one line each
+    return MI355_OK;
+}
+
 uint32_t pick_grid(const mi355_ctx *ctx, uint64_t n)
 {
     const uint64_t tiles = (n + RED_TILE - 1) / RED_TILE;
-    const uint64_t cap = std::min<uint64_t>((uint64_t)ctx->props.num_streaming_multiprocessors * 8, RED_MAX_GRID);
+    static const int per_cu = [] { const char *e = getenv("MI355_REDUCE_WG_PER_CU"); int v = e ? atoi(e) : 3; return v > 0 ? v : 3; }();
+    const uint64_t cap = std::min<uint64_t>((uint64_t)ctx->props.num_streaming_multiprocessors * per_cu, RED_MAX_GRID);
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(tiles, cap));
 }
 
@@ -236,10 +300,12 @@ int32_t run_reduce(mi355_ctx *ctx, mi355_stream stream, const float *in, uint64_
     const uint64_t body_n = n - head_n;
     const uint32_t G = pick_grid(ctx, body_n);
     red_record *records = static_cast<red_record *>(workspace);
-    hipLaunchKernelGGL((reduce_stage1<SUM, ARG>), dim3(G), dim3(RED_BLOCK), 0, s, in, head_n, body, body_n, records);
-    check_launch(ctx, what);
-    hipLaunchKernelGGL((reduce_stage2<SUM, ARG>), dim3(1), dim3(RED_BLOCK), 0, s, records, G, body, head_n, in, n,
-                       out_sum, out_val, out_idx);
+    unsigned int *ticket = nullptr;
+    const int32_t trc = ticket_for_stream(ctx, s, &ticket);
+    if (trc != MI355_OK) return trc;
+    hipLaunchKernelGGL((reduce_kernel<SUM, ARG>), dim3(G), dim3(RED_BLOCK), 0, s, in, head_n, body, body_n, records,
+                       ticket, n, out_sum, out_val, out_idx);
+    if (hipPeekAtLastError() != hipSuccess) ctx->tickets_dirty = true;   // a refused launch never resets its ticket
     check_launch(ctx, what);
     return MI355_OK;
 }

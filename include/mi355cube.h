@@ -340,8 +340,9 @@ int32_t mi355_probe_mfma(mi355_ctx *ctx, mi355_stream stream, int32_t dtype_ab, 
  * down to its power budget; bench.py reports it beside the spec peak (not a reference probe). */
 int32_t mi355_probe_mfma_data(mi355_ctx *ctx, mi355_stream stream, int32_t mode, uint32_t iters,
                               void *sink, uint64_t *out_ops);
-/* Samples {shader-clock ticks, constant 100 MHz ticks} into dev_out[0..1] (device memory) on the
- * stream: two samples bracketing a region give the shader clock sustained over it
+/* Samples {shader-clock ticks, constant 100 MHz ticks} of every XCD into dev_out[2*xcd .. 2*xcd+1]
+ * (device memory, 16 uint64 for the 8 XCDs of an MI355X; the shader counter is per XCD) on the
+ * stream: two samples bracketing a region give the shader clock each XCD sustained over it
  * (timing_method Device, crates/cubecl-hip/src/runtime.rs:198 analogue). */
 int32_t mi355_probe_clock(mi355_ctx *ctx, mi355_stream stream, uint64_t *dev_out);
 
