@@ -291,18 +291,25 @@ def main():
                 res[name] = {"median_ms": round(med, 4), "min_ms": round(best, 4), "GBs_per_gpu": round(gbs, 1),
                              "GBs_total": round(gbs * world, 1), "frac_of_8TBs": round(gbs / PEAK_HBM_GBS, 4)}
             if world > 1:
-                # C4 end to end: local fused pass + RCCL all-reduce of the partial sums (ServerCommunication)
+                # C4 end to end (cubecl_amd/sharded.py): local fused pass over this rank's slice, then the
+                # exchange step -- RCCL all-reduce of the f32 partial sums (ServerCommunication::all_reduce)
+                # and an all-gather of the (max value, index) records; every rank runs the same combine.
+                from cubecl_amd import sharded
                 ids = [DeviceId(0, i) for i in range(world)]
                 box = [client.comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(box, src=0)
                 client.comm_init(ids, box[0], rank=rank)
-                from cubecl_amd import Handle, ReduceOperation
-                from cubecl_amd.runtime import _Memory
-                part = outs.offset_end_by(outs.size - 4)
+                from cubecl_amd import ReduceOperation
+                start, count = sharded.shard_aligned_range(n_total, rank, world, 4)
+                assert count == n_local
+                part = outs.offset_end_by(outs.size - 4)                           # f32 partial sum, reduced in place
+                rec = outs.offset_start_by(8).offset_end_by(outs.size - 24)       # {f32 value, pad, u64 local index}
+                gathered = client.empty(16 * world)
 
                 def e2e():
                     client._s.check(lib.mi355_sum_argmax_f32(ctx, None, p_in, n_local, p_sum, p_val, p_idx, p_ws, ws.size))
                     client.all_reduce(part, part, ElemType.F32, ids, ReduceOperation.Sum)
+                    client.all_gather(rec, gathered, ElemType.U64, ids)
                     client.sync_collective()
                 for _ in range(3):
                     e2e()
@@ -314,8 +321,19 @@ def main():
                 dt = (time.perf_counter() - t1) / 20
                 tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                res["sharded_sum_argmax_allreduce"] = {"ms": round(float(tt[0]) * 1e3, 4),
-                                                       "GBs_total": round(n_total * 4 / float(tt[0]) / 1e9, 1)}
+                import numpy as np
+                raw = np.frombuffer(client.read_one(gathered), dtype=np.uint8).reshape(world, 16)
+                pairs = []
+                for r in range(world):
+                    v = float(raw[r, 0:4].copy().view(np.float32)[0])
+                    i = int(raw[r, 8:16].copy().view(np.uint64)[0])
+                    pairs.append((v, sharded.shard_aligned_range(n_total, r, world, 4)[0] + i))
+                gval, gidx = sharded.combine_argmax(pairs)
+                gsum = float(np.frombuffer(client.read_one(part), dtype=np.float32)[0])
+                res["sharded_sum_argmax_exchange"] = {"ms": round(float(tt[0]) * 1e3, 4),
+                                                      "GBs_total": round(n_total * 4 / float(tt[0]) / 1e9, 1),
+                                                      "sum": gsum, "argmax_index": gidx, "argmax_value": gval,
+                                                      "exchange": "RCCL all-reduce (1 x f32) + all-gather (16 B per rank)"}
             return res
         guarded("reduce_1GiB_f32", reduce_c4)
 

@@ -1,0 +1,190 @@
+//! Raw bindings of `include/mi355cube.h` (ABI version 1).  One declaration per C entry point; the
+//! trait each one serves is named in the header next to its prototype.
+#![allow(non_camel_case_types)]
+
+use core::ffi::{c_char, c_void};
+
+pub const MI355_OK: i32 = 0;
+pub const MI355_E_INVALID_ARGUMENT: i32 = 1;
+pub const MI355_E_OUT_OF_MEMORY: i32 = 2;
+pub const MI355_E_BUFFER_TOO_BIG: i32 = 3;
+pub const MI355_E_UNSUPPORTED_STRIDES: i32 = 4;
+pub const MI355_E_NOT_FOUND: i32 = 5;
+pub const MI355_E_SHARED_MEMORY: i32 = 6;
+pub const MI355_E_UNITS: i32 = 7;
+pub const MI355_E_CUBE_DIM: i32 = 8;
+pub const MI355_E_MAX_UNITS_PER_CUBE: i32 = 9;
+pub const MI355_E_COMPILATION: i32 = 10;
+pub const MI355_E_LAUNCH: i32 = 11;
+pub const MI355_E_EXECUTION: i32 = 12;
+pub const MI355_E_UNSUPPORTED: i32 = 13;
+pub const MI355_E_SERVER_UNHEALTHY: i32 = 14;
+pub const MI355_E_COMM: i32 = 15;
+pub const MI355_E_NO_DEVICE: i32 = 16;
+pub const MI355_E_PROFILE: i32 = 17;
+
+pub const MI355_DTYPE_F32: i32 = 0;
+pub const MI355_DTYPE_BF16: i32 = 1;
+pub const MI355_DTYPE_F16: i32 = 2;
+pub const MI355_DTYPE_F64: i32 = 3;
+pub const MI355_DTYPE_I32: i32 = 4;
+pub const MI355_DTYPE_U32: i32 = 5;
+pub const MI355_DTYPE_I64: i32 = 6;
+pub const MI355_DTYPE_U64: i32 = 7;
+pub const MI355_DTYPE_U8: i32 = 8;
+pub const MI355_DTYPE_I8: i32 = 9;
+
+pub const MI355_REDUCE_SUM: i32 = 0;
+pub const MI355_REDUCE_MEAN: i32 = 1;
+pub const MI355_UNIQUE_ID_BYTES: usize = 128;
+
+#[repr(C)]
+pub struct mi355_ctx {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct mi355_comm {
+    _private: [u8; 0],
+}
+pub type mi355_stream = *mut c_void;
+pub type mi355_event = *mut c_void;
+pub type mi355_module = *mut c_void;
+pub type mi355_function = *mut c_void;
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct mi355_mma_config {
+    pub m: u32,
+    pub n: u32,
+    pub k: u32,
+    pub a_type: i32,
+    pub b_type: i32,
+    pub cd_type: i32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct mi355_device_props_t {
+    pub abi_version: u32,
+    pub device_index: i32,
+    pub name: [c_char; 64],
+    pub gcn_arch_name: [c_char; 64],
+    pub fingerprint: [c_char; 96],
+    pub load_width_bits: u32,
+    pub plane_size_min: u32,
+    pub plane_size_max: u32,
+    pub max_bindings: u32,
+    pub max_shared_memory_size: u64,
+    pub max_cube_count: [u32; 3],
+    pub max_units_per_cube: u32,
+    pub max_cube_dim: [u32; 3],
+    pub num_streaming_multiprocessors: u32,
+    pub num_tensor_cores: u32,
+    pub min_tensor_cores_dim: u32,
+    pub num_xcd: u32,
+    pub total_memory: u64,
+    pub max_page_size: u64,
+    pub mem_alignment: u64,
+    pub clock_khz: u32,
+    pub memory_clock_khz: u32,
+    pub memory_bus_width_bits: u32,
+    pub l2_cache_bytes: u32,
+    pub plane_ops: u32,
+    pub plane_non_uniform: u32,
+    pub timing_method_device: u32,
+    pub server_comm_enabled: u32,
+    pub num_mma_configs: u32,
+    pub mma_configs: [mi355_mma_config; 16],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct mi355_gemm_desc {
+    pub m: i64,
+    pub n: i64,
+    pub k: i64,
+    pub batch: i64,
+    pub lda: i64,
+    pub ldb: i64,
+    pub ldc: i64,
+    pub stride_a: i64,
+    pub stride_b: i64,
+    pub stride_c: i64,
+    pub dtype_ab: i32,
+    pub dtype_c: i32,
+    pub trans_a: i32,
+    pub trans_b: i32,
+    pub algo: i32,
+    pub reserved: i32,
+}
+
+unsafe extern "C" {
+    // Runtime
+    pub fn mi355_abi_version() -> i32;
+    pub fn mi355_device_count(out_count: *mut i32) -> i32;
+    pub fn mi355_ctx_create(device_index: i32, out_ctx: *mut *mut mi355_ctx) -> i32;
+    pub fn mi355_ctx_destroy(ctx: *mut mi355_ctx) -> i32;
+    pub fn mi355_device_props(ctx: *mut mi355_ctx, out: *mut mi355_device_props_t) -> i32;
+    pub fn mi355_last_error(ctx: *mut mi355_ctx) -> *const c_char;
+    pub fn mi355_last_global_error() -> *const c_char;
+    pub fn mi355_error_count(ctx: *mut mi355_ctx, out_count: *mut i32) -> i32;
+    pub fn mi355_error_pop(ctx: *mut mi355_ctx, out_code: *mut i32, out_requested: *mut u64, out_max: *mut u64,
+                           msg: *mut c_char, msg_capacity: usize) -> i32;
+    // Storage
+    pub fn mi355_alloc(ctx: *mut mi355_ctx, bytes: u64, out_dptr: *mut *mut c_void) -> i32;
+    pub fn mi355_free(ctx: *mut mi355_ctx, dptr: *mut c_void) -> i32;
+    pub fn mi355_mem_info(ctx: *mut mi355_ctx, out_free: *mut u64, out_total: *mut u64) -> i32;
+    pub fn mi355_pitched_row_bytes(ctx: *mut mi355_ctx, width_bytes: u64, out_pitch: *mut u64) -> i32;
+    pub fn mi355_pinned_alloc(ctx: *mut mi355_ctx, bytes: u64, out_hptr: *mut *mut c_void) -> i32;
+    pub fn mi355_pinned_free(ctx: *mut mi355_ctx, hptr: *mut c_void) -> i32;
+    // Streams / events
+    pub fn mi355_stream_create(ctx: *mut mi355_ctx, out: *mut mi355_stream) -> i32;
+    pub fn mi355_stream_destroy(ctx: *mut mi355_ctx, stream: mi355_stream) -> i32;
+    pub fn mi355_event_create(ctx: *mut mi355_ctx, out: *mut mi355_event) -> i32;
+    pub fn mi355_event_destroy(ctx: *mut mi355_ctx, event: mi355_event) -> i32;
+    pub fn mi355_event_record(ctx: *mut mi355_ctx, event: mi355_event, stream: mi355_stream) -> i32;
+    pub fn mi355_stream_wait_event(ctx: *mut mi355_ctx, stream: mi355_stream, event: mi355_event) -> i32;
+    pub fn mi355_event_sync(ctx: *mut mi355_ctx, event: mi355_event) -> i32;
+    // IO
+    pub fn mi355_write(ctx: *mut mi355_ctx, stream: mi355_stream, dst: *mut c_void, src: *const c_void, bytes: u64) -> i32;
+    pub fn mi355_read(ctx: *mut mi355_ctx, stream: mi355_stream, dst: *mut c_void, src: *const c_void, bytes: u64) -> i32;
+    pub fn mi355_write_2d(ctx: *mut mi355_ctx, stream: mi355_stream, dst: *mut c_void, dst_pitch: u64, src: *const c_void,
+                          src_pitch: u64, width_bytes: u64, rows: u64) -> i32;
+    pub fn mi355_read_2d(ctx: *mut mi355_ctx, stream: mi355_stream, dst: *mut c_void, dst_pitch: u64, src: *const c_void,
+                         src_pitch: u64, width_bytes: u64, rows: u64) -> i32;
+    pub fn mi355_memset(ctx: *mut mi355_ctx, stream: mi355_stream, dptr: *mut c_void, byte_value: i32, bytes: u64) -> i32;
+    pub fn mi355_sync(ctx: *mut mi355_ctx, stream: mi355_stream) -> i32;
+    pub fn mi355_flush(ctx: *mut mi355_ctx) -> i32;
+    // Generic launch (the reference device ABI: one pointer per binding + the info pointer)
+    pub fn mi355_module_load(ctx: *mut mi355_ctx, image: *const c_void, image_bytes: usize, out: *mut mi355_module) -> i32;
+    pub fn mi355_module_get_function(ctx: *mut mi355_ctx, module: mi355_module, name: *const c_char,
+                                     out: *mut mi355_function) -> i32;
+    pub fn mi355_launch(ctx: *mut mi355_ctx, stream: mi355_stream, function: mi355_function, grid: *const u32,
+                        block: *const u32, shared_mem_bytes: u32, buffer_ptrs: *const *mut c_void, num_ptrs: u32) -> i32;
+    // Hot-path operations
+    pub fn mi355_gemm(ctx: *mut mi355_ctx, stream: mi355_stream, desc: *const mi355_gemm_desc, a: *const c_void,
+                      b: *const c_void, c: *mut c_void) -> i32;
+    pub fn mi355_reduce_workspace_bytes(ctx: *mut mi355_ctx, n: u64, out_bytes: *mut u64) -> i32;
+    pub fn mi355_reduce_sum_f32(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const f32, n: u64, out: *mut f32,
+                                workspace: *mut c_void, workspace_bytes: u64) -> i32;
+    pub fn mi355_argmax_f32(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const f32, n: u64, out_val: *mut f32,
+                            out_idx: *mut u64, workspace: *mut c_void, workspace_bytes: u64) -> i32;
+    pub fn mi355_sum_argmax_f32(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const f32, n: u64, out_sum: *mut f32,
+                                out_val: *mut f32, out_idx: *mut u64, workspace: *mut c_void, workspace_bytes: u64) -> i32;
+    pub fn mi355_reduce_last_axis_sum_f32(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const f32, out: *mut f32,
+                                          rows: u64, cols: u64, row_stride: u64) -> i32;
+    // Collectives (RCCL over xGMI)
+    pub fn mi355_comm_unique_id(id: *mut u8) -> i32;
+    pub fn mi355_comm_init(ctx: *mut mi355_ctx, id: *const u8, rank: i32, world_size: i32, out: *mut *mut mi355_comm) -> i32;
+    pub fn mi355_comm_destroy(ctx: *mut mi355_ctx, comm: *mut mi355_comm) -> i32;
+    pub fn mi355_all_reduce(ctx: *mut mi355_ctx, comm: *mut mi355_comm, compute_stream: mi355_stream, src: *const c_void,
+                            dst: *mut c_void, count: u64, dtype: i32, op: i32) -> i32;
+    pub fn mi355_send(ctx: *mut mi355_ctx, comm: *mut mi355_comm, compute_stream: mi355_stream, src: *const c_void,
+                      count: u64, dtype: i32, peer: i32) -> i32;
+    pub fn mi355_recv(ctx: *mut mi355_ctx, comm: *mut mi355_comm, compute_stream: mi355_stream, dst: *mut c_void,
+                      count: u64, dtype: i32, peer: i32) -> i32;
+    pub fn mi355_sync_collective(ctx: *mut mi355_ctx, compute_stream: mi355_stream) -> i32;
+    // Profiling
+    pub fn mi355_profile_start(ctx: *mut mi355_ctx, stream: mi355_stream, out_token: *mut u64) -> i32;
+    pub fn mi355_profile_stop(ctx: *mut mi355_ctx, stream: mi355_stream, token: u64, out_nanos: *mut u64) -> i32;
+}
