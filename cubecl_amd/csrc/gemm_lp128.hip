@@ -19,6 +19,8 @@
 //    ColMajor-B form, runtime_tests/cmma.rs:23).
 //  * MFMA operands swapped (first = B fragment, second = A fragment): each lane then owns 4
 //    consecutive N-columns of one C row per register quad -> 16-byte (f32) / 8-byte (16-bit) stores.
+#include <algorithm>
+
 #include "gemm_common.hpp"
 
 using namespace mi355;
@@ -100,9 +102,15 @@ gemm_lp128_kernel(gemm_args g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (int)(g.k / BK);
+    // split-K: K slice z of g.split_k covers K-tiles [kt0, kt0 + nk); its partial goes to slab z
+    const int nk_total = (int)(g.k / BK);
+    const int z = (g.split_k > 1) ? (int)blockIdx.z : 0;
+    const int per = (nk_total + (int)g.split_k - 1) / (int)max(g.split_k, 1u);
+    const int kt0 = z * per;
+    const int nk = max(0, min(per, nk_total - kt0));
 
-    auto stage = [&](int buf, int kt) {
+    auto stage = [&](int buf, int kt_rel) {
+        const int kt = kt0 + kt_rel;
         char *la = smem + buf * 2 * TILE_BYTES;
         char *lb = la + TILE_BYTES;
         const int64_t koff = (int64_t)kt * BK * 2;
@@ -113,7 +121,7 @@ gemm_lp128_kernel(gemm_args g)
         }
     };
 
-    stage(0, 0);
+    if (nk > 0) stage(0, 0);
     __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) lgkmcnt(0) expcnt(0)
     __syncthreads();
 
@@ -143,7 +151,7 @@ gemm_lp128_kernel(gemm_args g)
     // ---- epilogue ---------------------------------------------------------------------------
     char *__restrict__ C = static_cast<char *>(g.c);
     constexpr int CSZ = (DT_C == MI355_DTYPE_F32) ? 4 : 2;
-    const int64_t cbase = batch * g.stride_c;
+    const int64_t cbase = batch * g.stride_c + (int64_t)z * g.split_c_stride;
     const bool vec_ok = (((g.ldc * CSZ) & (4 * CSZ - 1)) == 0) &&
                         (((reinterpret_cast<uintptr_t>(C) + (uint64_t)cbase * CSZ) & (4 * CSZ - 1)) == 0);
 #pragma unroll
@@ -188,7 +196,8 @@ gemm_lp128_kernel(gemm_args g)
 template <int DT, int DT_C>
 void launch(hipStream_t s, const gemm_args &g, uint32_t batch)
 {
-    hipLaunchKernelGGL((gemm_lp128_kernel<DT, DT_C>), dim3(g.tiles_m * g.tiles_n, batch), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_lp128_kernel<DT, DT_C>), dim3(g.tiles_m * g.tiles_n, batch, g.split_k > 1 ? g.split_k : 1),
+                       dim3(256), 0, s, g);
 }
 
 }  // namespace
@@ -224,7 +233,35 @@ int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
     g.tiles_m = (uint32_t)((d.m + BM - 1) / BM);
     g.tiles_n = (uint32_t)((d.n + BN - 1) / BN);
     g.group_m = 8;
+    g.split_k = 1;
+    g.split_c_stride = 0;
     const uint32_t batch = (uint32_t)d.batch;
+    // Split-K for shapes whose tile count cannot fill the chip (skinny M or N, GEMV-like): K is cut into slices,
+    // every slice writes an f32 partial slab, a small kernel folds the slabs in slice order (deterministic) and
+    // converts.  The slab traffic (2 x splits x M x N x 4 B) must stay small against the operand stream.
+    const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * batch;
+    const int64_t nk = d.k / BK;
+    const int64_t want = 2 * (int64_t)ctx->props.num_streaming_multiprocessors;
+    if (tiles < want / 2 && nk >= 8 && batch <= 65535) {
+        int64_t splits = std::min<int64_t>({(want + tiles - 1) / tiles, nk / 4, 32});
+        const int64_t per = (nk + splits - 1) / splits;
+        splits = (nk + per - 1) / per;                                      // no empty slices
+        const int64_t slab = d.batch * d.m * d.n;
+        const int64_t operand_bytes = (d.m * d.k + d.n * d.k) * 2 * d.batch;
+        float *ws = nullptr;
+        if (splits > 1 && splits * slab * 8 <= 2 * operand_bytes &&
+            splitk_scratch(ctx, s, (size_t)(splits * slab) * sizeof(float), &ws) == MI355_OK) {
+            gemm_args gs = g;
+            gs.c = ws; gs.ldc = d.n; gs.stride_c = d.m * d.n;
+            gs.split_k = (uint32_t)splits; gs.split_c_stride = slab;
+            if (d.dtype_ab == MI355_DTYPE_BF16) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(s, gs, batch);
+            else launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(s, gs, batch);
+            check_launch(ctx, "mi355_gemm(lp128 split-K)");
+            launch_splitk_fold(s, ws, (uint32_t)splits, slab, d.batch, d.m, d.n, c, d.dtype_c, d.ldc, d.stride_c);
+            check_launch(ctx, "mi355_gemm(split-K fold)");
+            return MI355_OK;
+        }
+    }
     if (d.dtype_ab == MI355_DTYPE_BF16) {
         if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(s, g, batch);
         else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16>(s, g, batch);

@@ -48,6 +48,7 @@ struct mi355_ctx {
     void *ticket_buf = nullptr;            // library-owned device scratch: arrival tickets of the reductions
     std::unordered_map<hipStream_t, uint32_t> ticket_slots;
     bool tickets_dirty = false;
+    std::unordered_map<hipStream_t, std::pair<void *, size_t>> splitk_scratch;   // library-owned split-K slabs, per stream
     uint64_t func_attr_mask = 0;  // kernels whose dynamic-LDS attribute is already raised on this device
 };
 

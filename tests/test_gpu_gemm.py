@@ -218,6 +218,30 @@ def test_lp256_identity_and_batch(client, oracle):
     assert np.array_equal(c.to_numpy(client), bmat)
 
 
+SPLITK_CASES = [(64, 1024, 4096), (1, 512, 2048), (128, 128, 8192), (200, 130, 1024), (64, 256, 576)]
+
+
+@pytest.mark.parametrize("m,n,k", SPLITK_CASES)
+@pytest.mark.parametrize("out", ["f32", "same"])
+def test_split_k_skinny_shapes(client, oracle, m, n, k, out):
+    # few 128x128 tiles + long K: the lp128 launcher cuts K into slices and folds f32 partial slabs in slice order
+    run_case(client, oracle, m, n, k, ElemType.BF16, ElemType.F32 if out == "f32" else ElemType.BF16, True, ALGOS["lp128"])
+
+
+def test_split_k_batched_padded_and_repeatable(client, oracle):
+    run_case(client, oracle, 64, 256, 2048, ElemType.F16, ElemType.F16, True, ALGOS["lp128"], batch=2, lda=2056, ldb=2048, ldc=264)
+    m, n, k = 64, 1024, 4096
+    a = TensorHandle.uniform(client, (m, k), ElemType.BF16, 0x5EEDC0BE, 81, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (n, k), ElemType.BF16, 0x5EEDC0BE, 82, -1.0, 1.0)
+    bt = TensorHandle.new(b.handle, (k, n), (1, k), ElemType.BF16)
+    c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 4), ElemType.F32)
+    ops.matmul(client, a, bt, c, algo=ALGOS["lp128"])
+    first = c.to_numpy(client).copy()
+    for _ in range(10):      # slabs are folded in slice order: same bits every launch
+        ops.matmul(client, a, bt, c, algo=ALGOS["lp128"])
+        assert np.array_equal(c.to_numpy(client), first)
+
+
 W4_CASES = [(256, 256, 64), (256, 256, 128), (256, 512, 192), (512, 512, 512), (768, 256, 1024), (512, 1024, 320),
             (256, 256, 2048)]
 
