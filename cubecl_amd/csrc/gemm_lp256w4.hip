@@ -1,7 +1,9 @@
-// gemm_lp256w4.hip -- bf16 / f16 GEMM, 256x256x64 workgroup tile, FOUR waves, one per SIMD.
+// gemm_lp256w4.hip -- bf16 / f16 / f32 GEMM, 256x256 workgroup tile x one 128-byte K line (64 16-bit or
+// 32 f32 k-values), FOUR waves, one per SIMD.
 //
-// Roofline: MFMA bf16/f16, ~2.5 PFLOP/s dense (MI355X_MICROARCH.md).  This is the headline kernel
-// for BASELINE config C3 (8192^3 bf16) and C5 (batched 2048^3).
+// Roofline: MFMA bf16/f16, ~2.5 PFLOP/s dense; MFMA f32 (v_mfma_f32_32x32x2_f32, exact f32), 157.3 TFLOP/s
+// (MI355X_MICROARCH.md).  This is the headline kernel for BASELINE configs C3 (8192^3 bf16), C5 (batched
+// 2048^3 bf16) and C2 (4096^3 f32, K-contiguous operands).
 //
 // Why one wave per SIMD.  The 8-wave ping-pong kernel (gemm_lp256.hip) hands the matrix pipe of a
 // SIMD back and forth between two waves through s_barrier; its ablations (profiles/) show the
@@ -48,22 +50,38 @@ using namespace mi355;
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int ROW_BYTES = BK * 2;                 // 128
+constexpr int BM = 256, BN = 256;
+constexpr int ROW_BYTES = 128;                    // one K-tile row = one 128-byte line: 64 x 16-bit or 32 x f32
 constexpr int UNIT_BYTES = BM * ROW_BYTES;        // 32 KiB: one ring slot
 constexpr int NSLOT = 5;
 constexpr int LDS_BYTES = NSLOT * UNIT_BYTES;     // 160 KiB
 
+// A "fragment" is the 16 bytes one lane reads per 32-row block and k-step: 8 x 16-bit values feeding ONE
+// v_mfma_f32_32x32x16, or 4 x f32 feeding FOUR v_mfma_f32_32x32x2_f32 (element c of the A and of the B
+// fragment go to MFMA c: lane-half h then supplies k = 8s + 4h + c for both operands, so every k of the
+// K-tile is used exactly once -- only the order of the exact-f32 accumulation changes).
 template <int DT> struct lp;
 template <> struct lp<MI355_DTYPE_BF16> {
     typedef bf16x8 frag;
+    static constexpr int ESZ = 2;
     static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c)
     { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
 template <> struct lp<MI355_DTYPE_F16> {
     typedef f16x8 frag;
+    static constexpr int ESZ = 2;
     static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c)
     { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct lp<MI355_DTYPE_F32> {
+    typedef f32x4 frag;
+    static constexpr int ESZ = 4;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c)
+    {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], c, 0, 0, 0);
+        return c;
+    }
 };
 
 __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
@@ -81,6 +99,9 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
 #define W4_PF 0       // 1: L2 prefetch of K-tile t+4 (one global_load_dword per wave and K-tile).  Measured:
                       // +16 % on the DMA-only ablation, -1.5 % on the full kernel (12.7 M extra L2 requests for
                       // nothing: with MFMAs in the stream the DMA latency is already covered) => off.
+#endif
+#ifndef W4_NT_C
+#define W4_NT_C 1     // 1: non-temporal C stores (+1 % at 8192^3, neutral at 4096^3) (keep A/B rather than C in the 256 MiB Infinity Cache)
 #endif
 #ifndef W4_VMW
 #define W4_VMW (8 + W4_PF)   // outstanding VMEM instructions allowed at the K-tile hand-over
@@ -107,8 +128,10 @@ gemm_lp256w4_kernel(gemm_args g)
     tile_coords(xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n), g.tiles_m, g.tiles_n, g.group_m, tm, tn);
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
     const int64_t batch = blockIdx.y;
-    const char *__restrict__ A = static_cast<const char *>(g.a) + batch * g.stride_a * 2;
-    const char *__restrict__ B = static_cast<const char *>(g.b) + batch * g.stride_b * 2;
+    constexpr int ESZ = lp<DT>::ESZ;
+    constexpr int BK = ROW_BYTES / ESZ;                 // 64 (16-bit) / 32 (f32) k-values per K-tile
+    const char *__restrict__ A = static_cast<const char *>(g.a) + batch * g.stride_a * ESZ;
+    const char *__restrict__ B = static_cast<const char *>(g.b) + batch * g.stride_b * ESZ;
     const int nk = (int)(g.k / BK);
 
     // ---- DMA map: a unit is 32 pieces of 1 KiB (8 rows); this wave fills pieces wave*8 + j.
@@ -121,10 +144,10 @@ gemm_lp256w4_kernel(gemm_args g)
     for (int p = 0; p < 2; ++p) {
         const int r = wave * 64 + p * 8 + sub;
         const int q = c8 ^ ((r >> 1) & 7);
-        src_a[p] = A + ((m0 + r) * g.lda + q * 8) * 2;
-        src_b[p] = B + ((n0 + r) * g.ldb + q * 8) * 2;
+        src_a[p] = A + (m0 + r) * g.lda * ESZ + q * 16;
+        src_b[p] = B + (n0 + r) * g.ldb * ESZ + q * 16;
     }
-    const int64_t step_a = 16 * g.lda * 2, step_b = 16 * g.ldb * 2;   // bytes between pieces j and j+2
+    const int64_t step_a = 16 * g.lda * ESZ, step_b = 16 * g.ldb * ESZ;   // bytes between pieces j and j+2
     const int dst_piece = wave * 8 * 1024;                            // + j*1024 within the slot
 
     // ---- L2 prefetch map.  Every unique 128-byte line of a K-tile is wanted by the 4 (A) or 8 (B)
@@ -144,12 +167,12 @@ gemm_lp256w4_kernel(gemm_args g)
         const int la = lane & 15, lb = lane & 7;
         const int64_t row_a = m0 + (tn & 3) * 64 + wave * 16 + (lane < 16 ? la : 0);
         const int64_t row_b = n0 + (tm & 7) * 32 + wave * 8 + lb;
-        pf_src = (lane >= 16 && lane < 24) ? B + row_b * g.ldb * 2 : A + row_a * g.lda * 2;
+        pf_src = (lane >= 16 && lane < 24) ? B + row_b * g.ldb * ESZ : A + row_a * g.lda * ESZ;
     }
     unsigned pf_sink = 0;
     auto prefetch = [&](int tile) {
         if (!W4_PF || (W4_ABL & 1)) return;
-        const char *p = pf_src + (int64_t)min(tile, nk - 1) * (BK * 2);
+        const char *p = pf_src + (int64_t)min(tile, nk - 1) * ROW_BYTES;
         asm volatile("global_load_dword %0, %1, off sc1" : "+v"(pf_sink) : "v"(p) : "memory");
     };
 
@@ -189,7 +212,20 @@ gemm_lp256w4_kernel(gemm_args g)
             asm volatile("" ::"v"(fb[BUF][J]), "v"(fa[BUF][I]));
             return;
         }
-        acc[I][J] = lp<DT>::mfma(fb[BUF][J], fa[BUF][I], acc[I][J]);
+        if constexpr (DT == MI355_DTYPE_F32) {
+            // f32: 64 MFMAs per k-step, ordered element-major so that consecutive MFMAs hit different
+            // accumulators (group IDX = element IDX/4 of the fragments x accumulator pairs 4*(IDX%4)..+3;
+            // an accumulator is revisited after 16 MFMAs).  Four dependent 32x32x2 MFMAs in a row measured
+            // ~10 % slower than the issue rate.
+            constexpr int E = decltype(idx)::value >> 2;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int pair = (decltype(idx)::value & 3) * 4 + t, i = pair & 3, j = pair >> 2;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[BUF][j][E], fa[BUF][i][E], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            acc[I][J] = lp<DT>::mfma(fb[BUF][J], fa[BUF][I], acc[I][J]);
+        }
     };
 
     // One k-step, instruction order pinned by hand (sched_barrier(0) after every MFMA group):
@@ -218,7 +254,7 @@ gemm_lp256w4_kernel(gemm_args g)
 
     // ---- prologue: units 0..3 (K-tiles 0 and 1), then the first fragments ---------------------------
     {
-        const int64_t k0 = 0, k1 = (int64_t)min(1, nk - 1) * (BK * 2);
+        const int64_t k0 = 0, k1 = (int64_t)min(1, nk - 1) * ROW_BYTES;
         char *b0 = smem + dst_piece;
 #define W4_PRO(IS_B, KOFF, SLOT)                                                                     \
         dma_one(IC<IS_B>{}, IC<0>{}, KOFF, b0 + SLOT * UNIT_BYTES); dma_one(IC<IS_B>{}, IC<1>{}, KOFF, b0 + SLOT * UNIT_BYTES); \
@@ -252,7 +288,7 @@ gemm_lp256w4_kernel(gemm_args g)
         const int sa1 = adv(sa, 2), sb1 = adv(sb, 2);     // units 2t+2, 2t+3 (K-tile t+1)
         const int s4 = adv(sa, 4);                        // unit 2t+4 -> slot of unit 2t-1
         const int s5 = sa;                                // unit 2t+5 -> slot of unit 2t
-        const int64_t dma_koff = (int64_t)min(t + 2, (W4_ABL & 32) ? 2 : nk - 1) * (BK * 2);
+        const int64_t dma_koff = (int64_t)min(t + 2, (W4_ABL & 32) ? 2 : nk - 1) * ROW_BYTES;
         if ((W4_ABL & 64) && t >= 2) dma_on = false;
         const char *rd_a, *rd_b;
         char *dma_base;
@@ -330,7 +366,11 @@ gemm_lp256w4_kernel(gemm_args g)
 #pragma unroll
             for (int it = 0; it < 32 / RPI; ++it) {
                 const u32x4 v = *reinterpret_cast<const u32x4 *>(rd + it * RPI * RS);
+#if W4_NT_C
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(cdst + it * cstep));
+#else
                 *reinterpret_cast<u32x4 *>(cdst + it * cstep) = v;
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);             // keep the accumulator reads of block i+1 below this point
         }
@@ -354,14 +394,17 @@ namespace mi355 {
 
 bool gemm_lp256w4_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
 {
-    if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16) return false;
+    if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16 && d.dtype_ab != MI355_DTYPE_F32) return false;
     if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != d.dtype_ab) return false;
     if (d.trans_a || !d.trans_b) return false;
+    const int64_t esz = d.dtype_ab == MI355_DTYPE_F32 ? 4 : 2;
+    const int64_t BK = ROW_BYTES / esz;
     if (d.k < BK || d.k % BK != 0) return false;
     const int64_t csz = d.dtype_c == MI355_DTYPE_F32 ? 4 : 2;      // the epilogue writes C in 16-byte pieces
     if (((d.ldc * csz) & 15) || ((d.stride_c * csz) & 15) || (reinterpret_cast<uintptr_t>(c) & 15u)) return false;
     if (d.m < BM || d.m % BM != 0 || d.n < BN || d.n % BN != 0) return false;
-    if ((d.lda & 7) || (d.ldb & 7) || (d.stride_a & 7) || (d.stride_b & 7)) return false;
+    const int64_t amask = 16 / esz - 1;                               // operand rows must be 16-byte aligned
+    if ((d.lda & amask) || (d.ldb & amask) || (d.stride_a & amask) || (d.stride_b & amask)) return false;
     if ((reinterpret_cast<uintptr_t>(a) & 15u) || (reinterpret_cast<uintptr_t>(b) & 15u)) return false;
     if (d.batch > 65535) return false;
     const int64_t tiles = (d.m / BM) * (d.n / BN);
@@ -383,7 +426,9 @@ int32_t launch_gemm_lp256w4(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc
     g.tiles_n = (uint32_t)(d.n / BN);
     g.group_m = 8;
     const uint32_t batch = (uint32_t)d.batch;
-    if (d.dtype_ab == MI355_DTYPE_BF16) {
+    if (d.dtype_ab == MI355_DTYPE_F32) {
+        launch<MI355_DTYPE_F32, MI355_DTYPE_F32>(ctx, s, g, batch, 16);
+    } else if (d.dtype_ab == MI355_DTYPE_BF16) {
         if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, g, batch, 12);
         else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16>(ctx, s, g, batch, 13);
     } else {

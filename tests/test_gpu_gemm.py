@@ -253,6 +253,28 @@ def test_lp256w4_parity(client, oracle, m, n, k, dtype, out):
     run_case(client, oracle, m, n, k, dtype, ElemType.F32 if out == "f32" else dtype, True, ALGOS["lp256w4"])
 
 
+@pytest.mark.parametrize("m,n,k", [(256, 256, 32), (256, 256, 64), (256, 512, 96), (512, 512, 512), (768, 256, 1024),
+                                   (512, 1024, 160)])
+def test_lp256w4_f32_parity(client, oracle, m, n, k):
+    # f32 inputs on v_mfma_f32_32x32x2_f32: exact-f32 products, an fmaf chain in a permuted k order
+    run_case(client, oracle, m, n, k, ElemType.F32, ElemType.F32, True, ALGOS["lp256w4"])
+
+
+def test_lp256w4_f32_identity_batch_padding(client, oracle):
+    run_case(client, oracle, 256, 256, 64, ElemType.F32, ElemType.F32, True, ALGOS["lp256w4"], batch=3)
+    run_case(client, oracle, 512, 256, 32, ElemType.F32, ElemType.F32, True, ALGOS["lp256w4"], batch=2, bcast_b=True,
+             lda=36, ldb=32, ldc=260)
+    m = n = k = 512
+    eye = np.eye(m, dtype=np.float32)
+    bmat = ((np.arange(k)[:, None] * 3 + np.arange(n)[None, :] * 7) % 1021).astype(np.float32) + 0.25   # asymmetric
+    ta = TensorHandle.from_numpy(client, eye)
+    tb = TensorHandle.from_numpy(client, np.ascontiguousarray(bmat.T))
+    c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 4), ElemType.F32)
+    ops.matmul(client, TensorHandle.new(ta.handle, (m, k), (k, 1), ElemType.F32),
+               TensorHandle.new(tb.handle, (k, n), (1, k), ElemType.F32), c, algo=ALGOS["lp256w4"])
+    assert np.array_equal(c.to_numpy(client), bmat)      # exact: one non-zero product per output
+
+
 def test_lp256w4_identity_batch_and_fallback(client, oracle):
     run_case(client, oracle, 256, 256, 128, ElemType.BF16, ElemType.BF16, True, ALGOS["lp256w4"], batch=3)
     run_case(client, oracle, 512, 256, 64, ElemType.BF16, ElemType.F32, True, ALGOS["lp256w4"], batch=2, bcast_b=True,
@@ -311,6 +333,8 @@ def test_batched_and_broadcast(client, oracle):
 def test_auto_selection_and_errors(client):
     d = N.GemmDesc(m=4096, n=4096, k=4096, batch=1, lda=4096, ldb=4096, ldc=4096, dtype_ab=N.DTYPE_F32,
                    dtype_c=N.DTYPE_F32, trans_b=1)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    d.trans_b = 0
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_F32_MFMA
     d = N.GemmDesc(m=2048, n=2048, k=2048, batch=1, lda=2048, ldb=2048, ldc=2048, dtype_ab=N.DTYPE_BF16,
                    dtype_c=N.DTYPE_BF16, trans_b=1)

@@ -20,4 +20,8 @@ for name, tb in (("NT", 1), ("NN", 0)):
         lib.mi355_event_record(ctx, ea, None); fn(); lib.mi355_event_record(ctx, eb, None); lib.mi355_event_sync(ctx, eb)
         ms = C.c_float(); lib.mi355_event_elapsed_ms(ctx, ea, eb, C.byref(ms)); t.append(ms.value)
     t.sort()
-    print(f"f32 {name} {M}^3: median {t[5]:.4f} ms {2.0*M**3/t[5]/1e9:6.1f} TF   min {t[0]:.4f} ms {2.0*M**3/t[0]/1e9:6.1f} TF", flush=True)
+    lib.mi355_event_record(ctx, ea, None)
+    for _ in range(10): fn()
+    lib.mi355_event_record(ctx, eb, None); lib.mi355_event_sync(ctx, eb)
+    ms = C.c_float(); lib.mi355_event_elapsed_ms(ctx, ea, eb, C.byref(ms)); b2b = ms.value / 10
+    print(f"f32 {name} {M}^3: median {t[5]:.4f} ms {2.0*M**3/t[5]/1e9:6.1f} TF   min {t[0]:.4f} ms {2.0*M**3/t[0]/1e9:6.1f} TF   back-to-back x10 {b2b:.4f} ms {2.0*M**3/b2b/1e9:6.1f} TF", flush=True)
