@@ -40,8 +40,8 @@
 //   tile index (harmless re-reads into dead slots), keeping the counts uniform.
 //
 // Restrictions (the dispatcher falls back to gemm_lp256.hip / gemm_lp128.hip otherwise):
-//   M % 256 == 0, N % 256 == 0, K % 64 == 0, A row-major [M][K], B stored [N][K] (trans_b = 1),
-//   C rows 16-byte aligned.
+//   M % 256 == 0, N % 256 == 0, K % 64 (16-bit) / 32 (f32) == 0, A row-major [M][K], B stored [N][K]
+//   (trans_b = 1; f32 also takes row-major [K][N]), C rows 16-byte aligned.
 #include <type_traits>
 
 #include "gemm_common.hpp"
@@ -111,10 +111,15 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
 #define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 template <int V> using IC = std::integral_constant<int, V>;
 
-template <int DT, int DT_C>
+// BNN (f32 only): B is row-major [K][N] instead of [N][K].  Its K-tile is then 32 k-rows of 256 n-values
+// (1 KiB each = one DMA piece, no swizzle), and a B fragment is four ds_read_b32 (consecutive lanes ->
+// consecutive n: conflict free) instead of one ds_read_b128 -- affordable because an f32 k-step holds 64
+// MFMAs of 64 cycles.
+template <int DT, int DT_C, bool BNN = false>
 __global__ void __launch_bounds__(256)
 gemm_lp256w4_kernel(gemm_args g)
 {
+    static_assert(!BNN || DT == MI355_DTYPE_F32, "row-major B is implemented for f32 only");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     typedef typename lp<DT>::frag frag;
 
@@ -148,6 +153,9 @@ gemm_lp256w4_kernel(gemm_args g)
         src_b[p] = B + (n0 + r) * g.ldb * ESZ + q * 16;
     }
     const int64_t step_a = 16 * g.lda * ESZ, step_b = 16 * g.ldb * ESZ;   // bytes between pieces j and j+2
+    // BNN: piece j of this wave is k-row wave*8 + j of the K-tile, 256 n-values = 64 lanes x 16 B
+    const char *src_bnn = B + (int64_t)(wave * 8) * g.ldb * ESZ + n0 * ESZ + lane * 16;
+    const int64_t step_bnn = g.ldb * ESZ;
     const int dst_piece = wave * 8 * 1024;                            // + j*1024 within the slot
 
     // ---- L2 prefetch map.  Every unique 128-byte line of a K-tile is wanted by the 4 (A) or 8 (B)
@@ -171,7 +179,7 @@ gemm_lp256w4_kernel(gemm_args g)
     }
     unsigned pf_sink = 0;
     auto prefetch = [&](int tile) {
-        if (!W4_PF || (W4_ABL & 1)) return;
+        if (!W4_PF || BNN || (W4_ABL & 1)) return;
         const char *p = pf_src + (int64_t)min(tile, nk - 1) * ROW_BYTES;
         asm volatile("global_load_dword %0, %1, off sc1" : "+v"(pf_sink) : "v"(p) : "memory");
     };
@@ -179,7 +187,7 @@ gemm_lp256w4_kernel(gemm_args g)
     // ---- fragment read offsets: row*128 + ((2s+h) ^ f) * 16, f = (row>>1)&7 = (l31>>1)&7 for every tile row
     const int f = (l31 >> 1) & 7;
     const int rowoff_a = (wm * 128 + l31) * ROW_BYTES;
-    const int rowoff_b = (wn * 128 + l31) * ROW_BYTES;
+    const int rowoff_b = BNN ? (wn * 128 + l31) * 4 : (wn * 128 + l31) * ROW_BYTES;
 
     f32x16 acc[4][4];
 #pragma unroll
@@ -195,16 +203,30 @@ gemm_lp256w4_kernel(gemm_args g)
     auto read_one = [&](auto buf, auto idx, const char *pa, const char *pb) {
         constexpr int BUF = decltype(buf)::value, R = decltype(idx)::value;
         if (W4_ABL & 2) return;
-        if (R == 0) fb[BUF][0] = *reinterpret_cast<const frag *>(pb);
-        else if (R <= 4) fa[BUF][R - 1] = *reinterpret_cast<const frag *>(pa + (R - 1) * 32 * ROW_BYTES);
-        else fb[BUF][R - 4] = *reinterpret_cast<const frag *>(pb + (R - 4) * 32 * ROW_BYTES);
+        if constexpr (BNN) {
+            if (R >= 1 && R <= 4) fa[BUF][R - 1] = *reinterpret_cast<const frag *>(pa + (R - 1) * 32 * ROW_BYTES);
+            else {
+                constexpr int JB = (R == 0) ? 0 : R - 4;       // element e of B fragment JB: k-row e of this lane-half's four
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fb[BUF][JB][e] = *reinterpret_cast<const float *>(pb + e * 1024 + JB * 128);
+            }
+        } else {
+            if (R == 0) fb[BUF][0] = *reinterpret_cast<const frag *>(pb);
+            else if (R <= 4) fa[BUF][R - 1] = *reinterpret_cast<const frag *>(pa + (R - 1) * 32 * ROW_BYTES);
+            else fb[BUF][R - 4] = *reinterpret_cast<const frag *>(pb + (R - 4) * 32 * ROW_BYTES);
+        }
     };
     bool dma_on = true;   // dev ablation 64 switches the DMA off after the ring is filled with real data
     auto dma_one = [&](auto is_b, auto jj, int64_t koff, char *base) {
         constexpr int J = decltype(jj)::value;
         if ((W4_ABL & 1) || !dma_on) return;
-        const char *s = decltype(is_b)::value ? src_b[J & 1] + (J >> 1) * step_b : src_a[J & 1] + (J >> 1) * step_a;
-        glds16(s + koff, base + J * 1024);
+        if constexpr (BNN && decltype(is_b)::value) {
+            // koff = tile * 128 bytes along K for the K-contiguous layout; here a K-tile is 32 rows of ldb elements
+            glds16(src_bnn + J * step_bnn + koff * g.ldb, base + J * 1024);
+        } else {
+            const char *s = decltype(is_b)::value ? src_b[J & 1] + (J >> 1) * step_b : src_a[J & 1] + (J >> 1) * step_a;
+            glds16(s + koff, base + J * 1024);
+        }
     };
     auto mfma_one = [&](auto buf, auto idx) {
         constexpr int BUF = decltype(buf)::value, I = decltype(idx)::value & 3, J = decltype(idx)::value >> 2;
@@ -271,7 +293,7 @@ gemm_lp256w4_kernel(gemm_args g)
     __builtin_amdgcn_sched_barrier(0);
     {
         const int x = (h ^ f) << 4;
-        const char *rd_a = smem + rowoff_a + x, *rd_b = smem + UNIT_BYTES + rowoff_b + x;
+        const char *rd_a = smem + rowoff_a + x, *rd_b = smem + UNIT_BYTES + rowoff_b + (BNN ? (4 * h) * 1024 : x);
         read_one(IC<0>{}, IC<0>{}, rd_a, rd_b); read_one(IC<0>{}, IC<1>{}, rd_a, rd_b);
         read_one(IC<0>{}, IC<2>{}, rd_a, rd_b); read_one(IC<0>{}, IC<3>{}, rd_a, rd_b);
         read_one(IC<0>{}, IC<4>{}, rd_a, rd_b); read_one(IC<0>{}, IC<5>{}, rd_a, rd_b);
@@ -283,6 +305,9 @@ gemm_lp256w4_kernel(gemm_args g)
     int sb = UNIT_BYTES;                 // ring byte offset of unit 2t+1 (B of K-tile t)
     auto adv = [](int x, int n) { x += n * UNIT_BYTES; return x >= LDS_BYTES ? x - LDS_BYTES : x; };
     const int x1 = ((2 + h) ^ f) << 4, x2 = ((4 + h) ^ f) << 4, x3 = ((6 + h) ^ f) << 4, x0 = (h ^ f) << 4;
+    // B fragment offsets per k-step: same chunks as A for [N][K]; k-rows 8s + 4h (.. +3) for row-major B
+    const int y0 = BNN ? (4 * h) * 1024 : x0, y1 = BNN ? (8 + 4 * h) * 1024 : x1, y2 = BNN ? (16 + 4 * h) * 1024 : x2,
+              y3 = BNN ? (24 + 4 * h) * 1024 : x3;
 
     for (int t = 0; t < nk; ++t) {
         const int sa1 = adv(sa, 2), sb1 = adv(sb, 2);     // units 2t+2, 2t+3 (K-tile t+1)
@@ -293,20 +318,20 @@ gemm_lp256w4_kernel(gemm_args g)
         const char *rd_a, *rd_b;
         char *dma_base;
         // ---- k-step 0: reads of step 1 after MFMA 0-7, unit 2t+4 pieces 0-3 after MFMA 9,11,13,15
-        rd_a = smem + sa + rowoff_a + x1; rd_b = smem + sb + rowoff_b + x1; dma_base = smem + s4 + dst_piece;
+        rd_a = smem + sa + rowoff_a + x1; rd_b = smem + sb + rowoff_b + y1; dma_base = smem + s4 + dst_piece;
         W4_STEP_BODY(0, 1, 0x00FFu, 0xAA00u, 0, 0)
         // ---- k-step 1: reads of step 2, unit 2t+4 pieces 4-7
-        rd_a = smem + sa + rowoff_a + x2; rd_b = smem + sb + rowoff_b + x2;
+        rd_a = smem + sa + rowoff_a + x2; rd_b = smem + sb + rowoff_b + y2;
         W4_STEP_BODY(1, 0, 0x00FFu, 0xAA00u, 0, 4)
         // ---- k-step 2: reads of step 3, no DMA; then the K-tile hand-over
-        rd_a = smem + sa + rowoff_a + x3; rd_b = smem + sb + rowoff_b + x3;
+        rd_a = smem + sa + rowoff_a + x3; rd_b = smem + sb + rowoff_b + y3;
         W4_STEP_BODY(0, 1, 0x00FFu, 0x0000u, 0, 0)
         WAIT_VMCNT(W4_VMW);              // my share of K-tile t+1 landed; unit 2t+4 may still fly
         WAIT_LGKM0();                    // my reads of K-tile t are complete
         __builtin_amdgcn_s_barrier();    // BAR_t
         __builtin_amdgcn_sched_barrier(0);
         // ---- k-step 3: reads of step 0 of K-tile t+1 after even MFMAs, unit 2t+5 pieces 0-7 after odd ones
-        rd_a = smem + sa1 + rowoff_a + x0; rd_b = smem + sb1 + rowoff_b + x0; dma_base = smem + s5 + dst_piece;
+        rd_a = smem + sa1 + rowoff_a + x0; rd_b = smem + sb1 + rowoff_b + y0; dma_base = smem + s5 + dst_piece;
         W4_STEP_BODY(1, 0, 0x5555u, 0xAAAAu, 1, 0)
         prefetch(t + 4);
         __builtin_amdgcn_sched_barrier(0);
@@ -377,15 +402,15 @@ gemm_lp256w4_kernel(gemm_args g)
     }
 }
 
-template <int DT, int DT_C>
+template <int DT, int DT_C, bool BNN = false>
 void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch, int slot)
 {
     if (!(ctx->func_attr_mask & (1ull << slot))) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_lp256w4_kernel<DT, DT_C>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_lp256w4_kernel<DT, DT_C, BNN>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         ctx->func_attr_mask |= (1ull << slot);
     }
-    hipLaunchKernelGGL((gemm_lp256w4_kernel<DT, DT_C>), dim3(g.tiles_m * g.tiles_n, batch), dim3(256), LDS_BYTES, s, g);
+    hipLaunchKernelGGL((gemm_lp256w4_kernel<DT, DT_C, BNN>), dim3(g.tiles_m * g.tiles_n, batch), dim3(256), LDS_BYTES, s, g);
 }
 
 }  // namespace
@@ -396,7 +421,8 @@ bool gemm_lp256w4_supports(const mi355_gemm_desc &d, const void *a, const void *
 {
     if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16 && d.dtype_ab != MI355_DTYPE_F32) return false;
     if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != d.dtype_ab) return false;
-    if (d.trans_a || !d.trans_b) return false;
+    if (d.trans_a) return false;
+    if (!d.trans_b && d.dtype_ab != MI355_DTYPE_F32) return false;          // row-major B: f32 only
     const int64_t esz = d.dtype_ab == MI355_DTYPE_F32 ? 4 : 2;
     const int64_t BK = ROW_BYTES / esz;
     if (d.k < BK || d.k % BK != 0) return false;
@@ -427,7 +453,8 @@ int32_t launch_gemm_lp256w4(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc
     g.group_m = 8;
     const uint32_t batch = (uint32_t)d.batch;
     if (d.dtype_ab == MI355_DTYPE_F32) {
-        launch<MI355_DTYPE_F32, MI355_DTYPE_F32>(ctx, s, g, batch, 16);
+        if (d.trans_b) launch<MI355_DTYPE_F32, MI355_DTYPE_F32, false>(ctx, s, g, batch, 16);
+        else launch<MI355_DTYPE_F32, MI355_DTYPE_F32, true>(ctx, s, g, batch, 17);
     } else if (d.dtype_ab == MI355_DTYPE_BF16) {
         if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, g, batch, 12);
         else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16>(ctx, s, g, batch, 13);

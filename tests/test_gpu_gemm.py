@@ -255,9 +255,11 @@ def test_lp256w4_parity(client, oracle, m, n, k, dtype, out):
 
 @pytest.mark.parametrize("m,n,k", [(256, 256, 32), (256, 256, 64), (256, 512, 96), (512, 512, 512), (768, 256, 1024),
                                    (512, 1024, 160)])
-def test_lp256w4_f32_parity(client, oracle, m, n, k):
-    # f32 inputs on v_mfma_f32_32x32x2_f32: exact-f32 products, an fmaf chain in a permuted k order
-    run_case(client, oracle, m, n, k, ElemType.F32, ElemType.F32, True, ALGOS["lp256w4"])
+@pytest.mark.parametrize("trans_b", [True, False])
+def test_lp256w4_f32_parity(client, oracle, m, n, k, trans_b):
+    # f32 inputs on v_mfma_f32_32x32x2_f32: exact-f32 products, an fmaf chain in a permuted k order;
+    # trans_b False = row-major B [K][N] (the DMA'd K-tile is then 32 k-rows x 256 n)
+    run_case(client, oracle, m, n, k, ElemType.F32, ElemType.F32, trans_b, ALGOS["lp256w4"])
 
 
 def test_lp256w4_f32_identity_batch_padding(client, oracle):
@@ -273,6 +275,11 @@ def test_lp256w4_f32_identity_batch_padding(client, oracle):
     ops.matmul(client, TensorHandle.new(ta.handle, (m, k), (k, 1), ElemType.F32),
                TensorHandle.new(tb.handle, (k, n), (1, k), ElemType.F32), c, algo=ALGOS["lp256w4"])
     assert np.array_equal(c.to_numpy(client), bmat)      # exact: one non-zero product per output
+    tbn = TensorHandle.from_numpy(client, bmat)           # the same product with row-major B
+    ops.matmul(client, TensorHandle.new(ta.handle, (m, k), (k, 1), ElemType.F32),
+               TensorHandle.new(tbn.handle, (k, n), (n, 1), ElemType.F32), c, algo=ALGOS["lp256w4"])
+    assert np.array_equal(c.to_numpy(client), bmat)
+    run_case(client, oracle, 256, 512, 64, ElemType.F32, ElemType.F32, False, ALGOS["lp256w4"], batch=2, lda=68, ldb=516, ldc=512)
 
 
 def test_lp256w4_identity_batch_and_fallback(client, oracle):
@@ -334,7 +341,9 @@ def test_auto_selection_and_errors(client):
     d = N.GemmDesc(m=4096, n=4096, k=4096, batch=1, lda=4096, ldb=4096, ldc=4096, dtype_ab=N.DTYPE_F32,
                    dtype_c=N.DTYPE_F32, trans_b=1)
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
-    d.trans_b = 0
+    d.trans_b, d.ldb = 0, 4096
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    d.m = 4096 + 64
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_F32_MFMA
     d = N.GemmDesc(m=2048, n=2048, k=2048, batch=1, lda=2048, ldb=2048, ldc=2048, dtype_ab=N.DTYPE_BF16,
                    dtype_c=N.DTYPE_BF16, trans_b=1)
