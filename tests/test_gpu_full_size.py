@@ -1,0 +1,169 @@
+"""Parity at BASELINE.json's FULL sizes (C2 4096^3 f32, C3 8192^3 bf16, C4 1 GiB f32, C5 2048^3 batch)
+through properties that do not need a full CPU recomputation, plus oracle checks on samples the CPU
+finishes in seconds:
+
+  * GEMM: exact identity (A = I returns the B operand bit for bit), exact power-of-two linearity
+    (C(2A) == 2 C(A) bit for bit in f32), sampled rows against the f64-accumulating oracle (1e-5
+    relative to sum|a||b|, BASELINE.json), agreement between independent kernels.
+  * reduce: checksum of checksums (the full-array sum against the sum of 8 shard sums, i.e. the
+    multi-GPU partition), the exact f64 oracle over the same counter-RNG data, run-to-run bit
+    determinism, planted maxima / ties / NaN for the argmax rule at 2^28 elements.
+"""
+import numpy as np
+import pytest
+
+from cubecl_amd import ElemType, TensorHandle, ops, sharded
+from cubecl_amd import _native as N
+
+pytestmark = pytest.mark.gpu
+SEED = 0x5EEDC0BE
+REL = 1e-5
+
+
+def _rows_check(oracle, a_bits, b_bits, got_rows, rows, k, n, dtype, trans_b=True):
+    """got_rows[i] == A[rows[i], :] . B^T (or B) within REL * sum|a||b| (f32) / one ulp (16-bit out is not used here)."""
+    if dtype == ElemType.F32:
+        a_val, b_val = a_bits, b_bits
+    else:
+        a_val = oracle.from_bf16(a_bits)
+        b_val = oracle.from_bf16(b_bits)
+    A = a_val.reshape(-1, k)[rows].astype(np.float64)
+    Bm = b_val.reshape(n, k).astype(np.float64).T if trans_b else b_val.reshape(k, n).astype(np.float64)
+    ref = A @ Bm
+    bound = np.abs(A) @ np.abs(Bm)
+    err = np.abs(got_rows.astype(np.float64) - ref)
+    assert np.all(err <= REL * bound + 1e-30), float((err / (bound + 1e-30)).max())
+
+
+def test_c3_bf16_8192_sampled_rows_linearity_and_kernel_agreement(client, oracle):
+    S = 8192
+    a = TensorHandle.uniform(client, (S, S), ElemType.BF16, SEED, 100, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (S, S), ElemType.BF16, SEED, 200, -1.0, 1.0)        # stored [N][K]
+    bt = TensorHandle.new(b.handle, (S, S), (1, S), ElemType.BF16)
+    c = TensorHandle.new_contiguous((S, S), client.empty(S * S * 4), ElemType.F32)
+    d = N.GemmDesc(m=S, n=S, k=S, batch=1, lda=S, ldb=S, ldc=S, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_F32, trans_b=1)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    ops.matmul(client, a, bt, c)
+    got = c.to_numpy(client)
+    rows = np.array([0, 1, 255, 256, 4095, 4096, 8191, 5003])
+    a_bits = oracle.to_bf16(oracle.fill_uniform(S * S, 100, -1.0, 1.0))
+    b_bits = oracle.to_bf16(oracle.fill_uniform(S * S, 200, -1.0, 1.0))
+    assert np.array_equal(a.to_numpy(client).reshape(-1)[: 1 << 16], a_bits[: 1 << 16])   # device RNG == oracle RNG
+    _rows_check(oracle, a_bits, b_bits, got[rows], rows, S, S, ElemType.BF16)
+    # exact linearity under a power of two: scaling A by 2 is exact in bf16, so C doubles bit for bit
+    a2 = TensorHandle.from_numpy(client, oracle.to_bf16(2.0 * oracle.from_bf16(a_bits)), ElemType.BF16)
+    c2 = TensorHandle.new_contiguous((S, S), client.empty(S * S * 4), ElemType.F32)
+    ops.matmul(client, TensorHandle.new(a2.handle, (S, S), (S, 1), ElemType.BF16), bt, c2)
+    assert np.array_equal(c2.to_numpy(client), 2.0 * got)
+    # an independent kernel (8 waves, different summation order) agrees within the f32 bound |a||b| <= 1 per product
+    ops.matmul(client, a, bt, c2, algo=N.GEMM_ALGO_LP_256)
+    assert np.max(np.abs(c2.to_numpy(client) - got)) <= REL * S
+    # bit-reproducible from launch to launch
+    ops.matmul(client, a, bt, c2)
+    assert np.array_equal(c2.to_numpy(client), got)
+
+
+def test_c3_bf16_8192_identity_returns_operand_bits(client, oracle):
+    S = 8192
+    eye = np.zeros((S, S), dtype=np.uint16)
+    eye[np.arange(S), np.arange(S)] = 0x3F80                                              # bf16 1.0
+    a = TensorHandle.from_numpy(client, eye, ElemType.BF16)
+    b = TensorHandle.uniform(client, (S, S), ElemType.BF16, SEED, 201, -1.0, 1.0)        # [N][K]
+    c = TensorHandle.new_contiguous((S, S), client.empty(S * S * 2), ElemType.BF16)
+    ops.matmul(client, TensorHandle.new(a.handle, (S, S), (S, 1), ElemType.BF16),
+               TensorHandle.new(b.handle, (S, S), (1, S), ElemType.BF16), c)
+    # Out = I . B^T, so Out[m][n] = B[n][m]: exactly one non-zero product per output, no rounding anywhere
+    assert np.array_equal(c.to_numpy(client).reshape(S, S), b.to_numpy(client).reshape(S, S).T)
+
+
+def test_c2_f32_4096_sampled_rows_both_layouts(client, oracle):
+    M = 4096
+    a = TensorHandle.uniform(client, (M, M), ElemType.F32, SEED, 400, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (M, M), ElemType.F32, SEED, 401, -1.0, 1.0)
+    a_host = oracle.fill_uniform(M * M, 400, -1.0, 1.0)
+    b_host = oracle.fill_uniform(M * M, 401, -1.0, 1.0)
+    rows = np.array([0, 31, 32, 2047, 2048, 4095])
+    c = TensorHandle.new_contiguous((M, M), client.empty(M * M * 4), ElemType.F32)
+    for trans_b in (True, False):
+        bt = TensorHandle.new(b.handle, (M, M), (1, M) if trans_b else (M, 1), ElemType.F32)
+        ops.matmul(client, a, bt, c)
+        got = c.to_numpy(client)
+        _rows_check(oracle, a_host, b_host, got[rows], rows, M, M, ElemType.F32, trans_b=trans_b)
+        ref = TensorHandle.new_contiguous((M, M), client.empty(M * M * 4), ElemType.F32)
+        ops.matmul(client, a, bt, ref, algo=N.GEMM_ALGO_F32_MFMA)                        # the 128x128 kernel
+        assert np.max(np.abs(ref.to_numpy(client) - got)) <= REL * M
+
+
+def test_c5_batched_2048_bf16_shard(client, oracle):
+    B, M = 8, 2048            # one GPU's shard is 64 matrices; 8 keep the host check short, same launch path (grid.y = batch)
+    a = TensorHandle.uniform(client, (B, M, M), ElemType.BF16, SEED, 500, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (B, M, M), ElemType.BF16, SEED, 600, -1.0, 1.0)
+    c = TensorHandle.new_contiguous((B, M, M), client.empty(B * M * M * 4), ElemType.F32)
+    ops.matmul(client, a, TensorHandle.new(b.handle, (B, M, M), (M * M, 1, M), ElemType.BF16), c)
+    got = c.to_numpy(client).reshape(B, M, M)
+    a_bits = oracle.to_bf16(oracle.fill_uniform(B * M * M, 500, -1.0, 1.0)).reshape(B, M * M)
+    b_bits = oracle.to_bf16(oracle.fill_uniform(B * M * M, 600, -1.0, 1.0)).reshape(B, M * M)
+    rows = np.array([0, 1023, 2047])
+    for bi in (0, 3, 7):
+        _rows_check(oracle, a_bits[bi], b_bits[bi], got[bi][rows], rows, M, M, ElemType.BF16)
+    # shards of the batch are contiguous runs that tile it exactly once (what bench.py --gpus N launches per rank)
+    spans = [sharded.shard_range(512, r, 8) for r in range(8)]
+    assert spans == [(64 * r, 64) for r in range(8)]
+
+
+def test_c4_one_gib_sum_checksum_of_checksums_and_oracle(client, oracle):
+    n = 1 << 28
+    x = TensorHandle.uniform(client, (n,), ElemType.F32, SEED, 300, 0.0, 1.0)
+    out = TensorHandle.new_contiguous((1,), client.empty(8), ElemType.F32)
+    ops.reduce_sum(client, x, out)
+    total = out.to_numpy(client).copy()
+    ops.reduce_sum(client, x, out)
+    assert np.array_equal(out.to_numpy(client).view(np.uint32), total.view(np.uint32))   # deterministic tree
+    # checksum of checksums: the 8-GPU partition of config C4, each shard reduced on its own
+    parts = []
+    for r in range(8):
+        start, count = sharded.shard_aligned_range(n, r, 8, 4)
+        view = TensorHandle.new_contiguous((count,), x.handle.offset_start_by(4 * start).offset_end_by(4 * (n - start - count)),
+                                           ElemType.F32)
+        ops.reduce_sum(client, view, out)
+        parts.append(float(out.to_numpy(client)[0]))
+    assert abs(sum(parts) - float(total[0])) <= REL * float(total[0])
+    # the exact value: f64 sum of the identical counter-RNG stream on the CPU (seconds)
+    exact = oracle.sum_f64(oracle.fill_uniform(n, 300, 0.0, 1.0))
+    assert abs(float(total[0]) - exact) <= REL * exact
+    assert abs(sum(parts) - exact) <= REL * exact
+
+
+def test_c4_one_gib_argmax_planted_maxima(client, oracle):
+    n = 1 << 28
+    x = TensorHandle.uniform(client, (n,), ElemType.F32, SEED, 301, 0.0, 1.0)
+    idx = TensorHandle.new_contiguous((1,), client.empty(8), ElemType.U64)
+    val = TensorHandle.new_contiguous((1,), client.empty(8), ElemType.F32)
+    s = TensorHandle.new_contiguous((1,), client.empty(8), ElemType.F32)
+
+    def poke(i, v):
+        client.write(x.handle.offset_start_by(4 * i).offset_end_by(4 * (n - i - 1)), np.array([v], dtype=np.float32))
+
+    # a maximum planted twice, in different shards of the 8-way partition: the lower index wins
+    poke(200_000_003, 2.5)
+    poke(17_000_001, 2.5)
+    ops.argmax(client, x, idx, val)
+    assert int(idx.to_numpy(client)[0]) == 17_000_001 and float(val.to_numpy(client)[0]) == 2.5
+    ops.sum_argmax(client, x, s, idx, val)                                                # fused pass agrees
+    assert int(idx.to_numpy(client)[0]) == 17_000_001
+    # the multi-GPU combine over per-shard winners gives the same answer
+    pairs = []
+    for r in range(8):
+        start, count = sharded.shard_aligned_range(n, r, 8, 4)
+        view = TensorHandle.new_contiguous((count,), x.handle.offset_start_by(4 * start).offset_end_by(4 * (n - start - count)),
+                                           ElemType.F32)
+        ops.argmax(client, view, idx, val)
+        pairs.append((float(val.to_numpy(client)[0]), start + int(idx.to_numpy(client)[0])))
+    assert sharded.combine_argmax(pairs) == (2.5, 17_000_001)
+    # NaN ranks above everything, first NaN wins; the last element is reachable
+    poke(n - 1, np.float32("nan"))
+    ops.argmax(client, x, idx, val)
+    assert int(idx.to_numpy(client)[0]) == n - 1 and np.isnan(val.to_numpy(client)[0])
+    poke(123, np.float32("nan"))
+    ops.argmax(client, x, idx, val)
+    assert int(idx.to_numpy(client)[0]) == 123
