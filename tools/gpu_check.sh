@@ -14,6 +14,9 @@ echo "== bench"
 timeout 900 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; echo "bench exit $?"; cat $OUT/${TAG}_bench.json; tail -n 5 $OUT/${TAG}_bench.err
 echo "== rocprof"
 export TMPDIR=/tmp
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/${TAG}_prof" -o bench -- python "$OLDPWD/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OLDPWD/$OUT/${TAG}_prof.log" 2>&1 ); echo "rocprof exit $?"
+# headline only, the default step counts: the GEMM kernel's average duration in the stats must agree with roofline.kernel_ms
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/${TAG}_prof" -o bench -- python "$OLDPWD/bench.py" --no-extras --no-cpu-baseline > "$OLDPWD/$OUT/${TAG}_prof.log" 2>&1 ); echo "rocprof exit $?"
+# everything (extras included), fewer steps: per-kernel time of the other configs
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/${TAG}_prof_all" -o bench -- python "$OLDPWD/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OLDPWD/$OUT/${TAG}_prof_all.log" 2>&1 ); echo "rocprof(all) exit $?"
 find $OUT/${TAG}_prof -name "*kernel_stats*" | head -3
 f=$(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -n 25 "$f"
