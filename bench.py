@@ -29,6 +29,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL across processes)
 SEED = 0x5EEDC0BE
 PEAK_BF16_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)"
@@ -43,6 +44,7 @@ def parse_args():
     ap.add_argument("--size", type=int, default=8192, help="M=N=K of the headline GEMM (8192 = config C3)")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline + cpu_baseline only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-plateau-warmup", action="store_true", help="only the W warm-up steps (measures the DVFS ramp too)")
     ap.add_argument("--algo", type=int, default=0, help="MI355_GEMM_ALGO_* override for the headline GEMM")
     return ap.parse_args()
 
@@ -163,6 +165,22 @@ def main():
     p_clk0, p_clk1 = C.c_void_p(clk.device_ptr()), C.c_void_p(clk.device_ptr() + 128)
     for _ in range(args.warmup):
         step()
+    # Plateau warm-up, as the reference's ThroughputBenchmarker does before sampling
+    # (crates/cubecl-runtime/src/throughput/benchmarker.rs:40-143: grow the warm-up until the rate stops
+    # moving): from idle the chip needs ~25 ms of this kernel before DVFS settles (first 30 launches
+    # 1 290 TFLOP/s, every later block 1 425-1 430, flat for 1.5 s -- profiles/r01_power_ablation.md).  Blocks
+    # of 20 untimed launches until two consecutive blocks agree within 1.5 %, at most 12 blocks.
+    plateau_steps, last = 0, None
+    if not args.no_plateau_warmup:
+        for _ in range(12):
+            ev.start()
+            for _ in range(20):
+                step()
+            cur = ev.stop_ms()
+            plateau_steps += 20
+            if last is not None and abs(cur - last) <= 0.015 * last:
+                break
+            last = cur
     client.sync()
     barrier()
     torch.cuda.synchronize()
@@ -181,8 +199,10 @@ def main():
     ticks = _np.frombuffer(client.read_one(clk), dtype=_np.uint64).reshape(2, 8, 2).astype(_np.float64)
     per_xcd = [(ticks[1, x, 0] - ticks[0, x, 0]) / (ticks[1, x, 1] - ticks[0, x, 1]) * 0.1      # 100 MHz reference
                for x in range(8) if ticks[0, x, 1] > 0 and ticks[1, x, 1] > ticks[0, x, 1]]
+    # every XCD has its own clock domain and single readings scatter by +-10 %: trimmed mean over the 8 XCDs
     per_xcd.sort()
-    eff_clock_ghz = per_xcd[len(per_xcd) // 2] if per_xcd else float("nan")
+    core = per_xcd[1:-1] if len(per_xcd) > 4 else per_xcd
+    eff_clock_ghz = sum(core) / len(core) if core else float("nan")
     if world > 1:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -201,7 +221,8 @@ def main():
                    "layout": "A[M,K] row-major; B stored [N][K] (Out = Lhs*Rhs^T, the cmma tests' ColMajor-B form)",
                    "operands": "uniform[-1,1) counter RNG seed 0x5EEDC0BE, generated in HBM",
                    "kernel": {2: "f32_mfma", 3: "lp128", 4: "lp256", 5: "lp256w4", 1: "generic"}.get(sel.value, str(sel.value)),
-                   "parallelism": f"batch-sharded x{world}, no data-path collective"},
+                   "parallelism": f"batch-sharded x{world}, no data-path collective",
+                   "plateau_warmup_steps": plateau_steps},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(S, sel.value),
                      "kernel_ms": round(kernel_ms / args.steps, 4), "flop_per_launch": flop,
@@ -269,6 +290,19 @@ def main():
             ms = time_op(client, ev, lambda: client._s.check(
                 lib.mi355_probe_mfma_data(ctx, None, 1, 20000, sink.device_ptr(), C.byref(n_ops))), 5)
             out["mfma_bf16_uniform_operands_TFLOPs"] = round(n_ops.value / ms / 1e9, 1)
+            # the reference's remaining throughput probes (examples/throughput: copy, write, compute-direct, launch)
+            buf2 = client.empty(1 << 30)
+            ms = time_op(client, ev, lambda: client._s.check(
+                lib.mi355_probe_memory_copy(ctx, None, buf.device_ptr(), buf2.device_ptr(), 1 << 30)), 20)
+            out["hbm_copy_GBs_read_plus_write"] = round(2 * (1 << 30) / ms / 1e6, 1)
+            ms = time_op(client, ev, lambda: client._s.check(lib.mi355_probe_memory_write(ctx, None, buf2.device_ptr(), 1 << 30)), 20)
+            out["hbm_write_GBs"] = round((1 << 30) / ms / 1e6, 1)
+            n_ops = C.c_uint64()
+            ms = time_op(client, ev, lambda: client._s.check(
+                lib.mi355_probe_compute_direct(ctx, None, 20000, sink.device_ptr(), C.byref(n_ops))), 5)
+            out["fma_f32_TFLOPs"] = round(n_ops.value / ms / 1e9, 1)
+            ms = time_op(client, ev, lambda: client._s.check(lib.mi355_probe_launch_overhead(ctx, None, 1000, sink.device_ptr())), 3, warmup=1)
+            out["launch_overhead_us"] = round(ms, 3)          # ms per 1000 launches = us per launch
             return out
         guarded("measured_ceilings", probes)
 

@@ -142,6 +142,10 @@ PROTOTYPES = {
     "mi355_probe_mfma": (C.c_int32, [_P, _P, C.c_int32, C.c_uint32, _P, _U64P]),
     "mi355_probe_mfma_data": (C.c_int32, [_P, _P, C.c_int32, C.c_uint32, _P, _U64P]),
     "mi355_probe_clock": (C.c_int32, [_P, _P, _P]),
+    "mi355_probe_memory_copy": (C.c_int32, [_P, _P, _P, _P, C.c_uint64]),
+    "mi355_probe_memory_write": (C.c_int32, [_P, _P, _P, C.c_uint64]),
+    "mi355_probe_compute_direct": (C.c_int32, [_P, _P, C.c_uint32, _P, _U64P]),
+    "mi355_probe_launch_overhead": (C.c_int32, [_P, _P, C.c_uint32, _P]),
     "mi355_comm_unique_id": (C.c_int32, [C.POINTER(C.c_uint8)]),
     "mi355_comm_init": (C.c_int32, [_P, C.POINTER(C.c_uint8), C.c_int32, C.c_int32, _PP]),
     "mi355_comm_destroy": (C.c_int32, [_P, _P]),

@@ -84,10 +84,16 @@ template <> struct lp<MI355_DTYPE_F32> {
     }
 };
 
+#ifndef W4_DMA_AUX
+#define W4_DMA_AUX 0   // cache-policy bits of the LDS-DMA loads (dev: 2 = nt)
+#endif
+#ifndef W4_GROUP_M
+#define W4_GROUP_M 8   // tile rows per rasterisation group: each XCD's 32 resident tiles form a GROUP_M x 32/GROUP_M patch
+#endif
 __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
 {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                     (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void *)lds_dst, 16, 0, W4_DMA_AUX);
 }
 
 #ifndef W4_ABL
@@ -450,7 +456,7 @@ int32_t launch_gemm_lp256w4(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc
     g.stride_a = d.stride_a; g.stride_b = d.stride_b; g.stride_c = d.stride_c;
     g.tiles_m = (uint32_t)(d.m / BM);
     g.tiles_n = (uint32_t)(d.n / BN);
-    g.group_m = 8;
+    g.group_m = W4_GROUP_M;
     const uint32_t batch = (uint32_t)d.batch;
     if (d.dtype_ab == MI355_DTYPE_F32) {
         if (d.trans_b) launch<MI355_DTYPE_F32, MI355_DTYPE_F32, false>(ctx, s, g, batch, 16);

@@ -137,6 +137,64 @@ probe_mfma_data_kernel(uint32_t iters, float *__restrict__ sink)
     if (t == 1.2345e38f) sink[0] = t;
 }
 
+// memory_direct_throughput (runners/memory_direct.rs:55-117): streaming copy, 16 B per lane, read + write counted.
+__global__ void __launch_bounds__(PR_BLOCK)
+probe_copy_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, uint64_t nvec)
+{
+    const uint64_t tile = (uint64_t)PR_BLOCK * PR_UNROLL, tiles = nvec / tile;
+    for (uint64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const uint64_t base = t * tile + threadIdx.x;
+        f32x4 v[PR_UNROLL];
+#pragma unroll
+        for (int u = 0; u < PR_UNROLL; ++u) v[u] = __builtin_nontemporal_load(src + base + (uint64_t)u * PR_BLOCK);
+#pragma unroll
+        for (int u = 0; u < PR_UNROLL; ++u) __builtin_nontemporal_store(v[u], dst + base + (uint64_t)u * PR_BLOCK);
+    }
+}
+
+// memory_write_throughput (runners/memory_write.rs:65-139): write-only stream of a lane-dependent value.
+__global__ void __launch_bounds__(PR_BLOCK)
+probe_write_kernel(f32x4 *__restrict__ dst, uint64_t nvec)
+{
+    const uint64_t tile = (uint64_t)PR_BLOCK * PR_UNROLL, tiles = nvec / tile;
+    const float s = (float)threadIdx.x;
+    const f32x4 v = {s, s + 1.f, s + 2.f, s + 3.f};
+    for (uint64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const uint64_t base = t * tile + threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < PR_UNROLL; ++u) __builtin_nontemporal_store(v, dst + base + (uint64_t)u * PR_BLOCK);
+    }
+}
+
+// compute_direct_throughput (runners/compute_direct.rs:50-103): four independent fma chains of 4-wide
+// vectors per lane, every lane and chain seeded differently so nothing folds; 2 flops per fma.
+__global__ void __launch_bounds__(256)
+probe_fma_kernel(uint32_t iters, f32x4 *__restrict__ out)
+{
+    const float tid = (float)(blockIdx.x * 256 + threadIdx.x);
+    const f32x4 b = {tid + 1.f, tid + 2.f, tid + 3.f, tid + 4.f};
+    const f32x4 c = {tid, tid + 1.f, tid + 2.f, tid + 3.f};
+    f32x4 s0 = {1.f, 2.f, 3.f, 4.f}, s1 = {2.f, 3.f, 4.f, 5.f}, s2 = {3.f, 4.f, 5.f, 6.f}, s3 = {4.f, 5.f, 6.f, 7.f};
+    const f32x4 scale = b * 1e-9f;    // keeps the chains finite
+    for (uint32_t i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s0[e] = __builtin_fmaf(s0[e], scale[e], c[e]);
+            s1[e] = __builtin_fmaf(s1[e], scale[e], c[e]);
+            s2[e] = __builtin_fmaf(s2[e], scale[e], c[e]);
+            s3[e] = __builtin_fmaf(s3[e], scale[e], c[e]);
+        }
+    }
+    const f32x4 r = (s0 + s1) + (s2 + s3);
+    if (r[0] + r[1] + r[2] + r[3] == 1.2345e38f) out[0] = r;
+}
+
+// launch_overhead (runners/launch_overhead.rs:43-51): a kernel that does nothing.
+__global__ void probe_empty_kernel(float *out)
+{
+    if (out == nullptr && threadIdx.x == 1024) __builtin_trap();
+}
+
 // {shader-clock ticks, constant 100 MHz ticks} of one CU: two samples bracket a region, and
 // d(shader) / d(constant) * 100 MHz is the clock the chip actually sustained over it.
 // The shader-clock counter is per XCD, so every XCD records its own pair (slot = HW_REG_XCC_ID).
@@ -153,6 +211,55 @@ __global__ void __launch_bounds__(64) probe_clock_kernel(uint64_t *__restrict__ 
 }
 
 }  // namespace
+
+MI355_API int32_t mi355_probe_memory_copy(mi355_ctx *ctx, mi355_stream stream, const void *src, void *dst, uint64_t bytes)
+{
+    MI355_REQUIRE_CTX(ctx);
+    if (!src || !dst) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_probe_memory_copy: NULL pointer");
+    if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u)
+        return fail(ctx, MI355_E_INVALID_ARGUMENT, "buffers must be 16-byte aligned");
+    const uint64_t nvec = bytes / 16, tiles = nvec / ((uint64_t)PR_BLOCK * PR_UNROLL);
+    if (tiles == 0) return fail(ctx, MI355_E_INVALID_ARGUMENT, "buffer smaller than one 32 KiB tile");
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, (uint64_t)ctx->props.num_streaming_multiprocessors * 8);
+    hipLaunchKernelGGL(probe_copy_kernel, dim3(grid), dim3(PR_BLOCK), 0, stream_of(ctx, stream),
+                       static_cast<const f32x4 *>(src), static_cast<f32x4 *>(dst), nvec);
+    check_launch(ctx, "mi355_probe_memory_copy");
+    return MI355_OK;
+}
+
+MI355_API int32_t mi355_probe_memory_write(mi355_ctx *ctx, mi355_stream stream, void *dst, uint64_t bytes)
+{
+    MI355_REQUIRE_CTX(ctx);
+    if (!dst) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_probe_memory_write: NULL pointer");
+    if (reinterpret_cast<uintptr_t>(dst) & 15u) return fail(ctx, MI355_E_INVALID_ARGUMENT, "buffer must be 16-byte aligned");
+    const uint64_t nvec = bytes / 16, tiles = nvec / ((uint64_t)PR_BLOCK * PR_UNROLL);
+    if (tiles == 0) return fail(ctx, MI355_E_INVALID_ARGUMENT, "buffer smaller than one 32 KiB tile");
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, (uint64_t)ctx->props.num_streaming_multiprocessors * 8);
+    hipLaunchKernelGGL(probe_write_kernel, dim3(grid), dim3(PR_BLOCK), 0, stream_of(ctx, stream), static_cast<f32x4 *>(dst), nvec);
+    check_launch(ctx, "mi355_probe_memory_write");
+    return MI355_OK;
+}
+
+MI355_API int32_t mi355_probe_compute_direct(mi355_ctx *ctx, mi355_stream stream, uint32_t iters, void *sink, uint64_t *out_ops)
+{
+    MI355_REQUIRE_CTX(ctx);
+    if (!sink) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_probe_compute_direct: sink is NULL");
+    const uint32_t grid = ctx->props.num_streaming_multiprocessors * 8;     // 8 workgroups of 4 waves per CU
+    hipLaunchKernelGGL(probe_fma_kernel, dim3(grid), dim3(256), 0, stream_of(ctx, stream), iters, static_cast<f32x4 *>(sink));
+    check_launch(ctx, "mi355_probe_compute_direct");
+    if (out_ops) *out_ops = 2ull * 4 * 4 * (uint64_t)grid * 256 * iters;     // 2 flops x 4 chains x 4 lanes-of-vector
+    return MI355_OK;
+}
+
+MI355_API int32_t mi355_probe_launch_overhead(mi355_ctx *ctx, mi355_stream stream, uint32_t launches, void *sink)
+{
+    MI355_REQUIRE_CTX(ctx);
+    if (!sink) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_probe_launch_overhead: sink is NULL");
+    hipStream_t s = stream_of(ctx, stream);
+    for (uint32_t i = 0; i < launches; ++i) hipLaunchKernelGGL(probe_empty_kernel, dim3(1), dim3(64), 0, s, static_cast<float *>(sink));
+    check_launch(ctx, "mi355_probe_launch_overhead");
+    return MI355_OK;
+}
 
 MI355_API int32_t mi355_probe_clock(mi355_ctx *ctx, mi355_stream stream, uint64_t *dev_out)
 {

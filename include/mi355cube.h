@@ -334,6 +334,19 @@ int32_t mi355_probe_memory_read(mi355_ctx *ctx, mi355_stream stream, const void 
 int32_t mi355_probe_mfma(mi355_ctx *ctx, mi355_stream stream, int32_t dtype_ab, uint32_t iters,
                          void *sink, uint64_t *out_ops);
 
+/* memory_direct_throughput (runners/memory_direct.rs:55-117): one streaming copy of `bytes`
+ * (read + written bytes both count: 2 x bytes of traffic per call). */
+int32_t mi355_probe_memory_copy(mi355_ctx *ctx, mi355_stream stream, const void *src, void *dst,
+                                uint64_t bytes);
+/* memory_write_throughput (runners/memory_write.rs:65-139): write-only stream of `bytes`. */
+int32_t mi355_probe_memory_write(mi355_ctx *ctx, mi355_stream stream, void *dst, uint64_t bytes);
+/* compute_direct_throughput (runners/compute_direct.rs:50-103): four independent f32 fma chains
+ * of 4-wide vectors per lane, `iters` steps; *out_ops = flops of one call. */
+int32_t mi355_probe_compute_direct(mi355_ctx *ctx, mi355_stream stream, uint32_t iters, void *sink,
+                                   uint64_t *out_ops);
+/* launch_overhead (runners/launch_overhead.rs:43-51): enqueues `launches` empty kernels. */
+int32_t mi355_probe_launch_overhead(mi355_ctx *ctx, mi355_stream stream, uint32_t launches,
+                                    void *sink);
 /* The same issue loop on the GEMM kernels' 4x4 accumulator shape (bf16), register-resident, with
  * mode 0 = all-ones operands, mode 1 = uniform[-1,1) operands rotating every iteration.  Mode 1 is
  * the matrix-pipe ceiling for the benchmark's operand distribution once DVFS has clocked the chip

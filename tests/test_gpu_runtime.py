@@ -162,3 +162,44 @@ def test_unknown_symbol_and_bad_image(client):
     with pytest.raises(ServerError) as e:
         client.load_module(b"not a code object" * 10)
     assert e.value.code == N.E_COMPILATION
+
+
+def test_throughput_probes_run_and_are_sane(client):
+    """The reference's throughput probes (examples/throughput) against this backend: every probe runs and lands
+    in a physically possible band for an MI355X (HBM <= 8 TB/s, f32 FMA <= 157 TF, launch overhead < 50 us)."""
+    import ctypes as C
+    lib, ctx = client.lib, client.ctx
+    n = 256 << 20
+    a, b, sink = client.empty(n), client.empty(n), client.empty(256)
+    ea, eb = C.c_void_p(), C.c_void_p()
+    lib.mi355_event_create(ctx, C.byref(ea)); lib.mi355_event_create(ctx, C.byref(eb))
+
+    def timed(fn, reps):
+        fn(); client.sync()
+        lib.mi355_event_record(ctx, ea, None)
+        for _ in range(reps):
+            client._s.check(fn())
+        lib.mi355_event_record(ctx, eb, None); lib.mi355_event_sync(ctx, eb)
+        ms = C.c_float(); lib.mi355_event_elapsed_ms(ctx, ea, eb, C.byref(ms))
+        return ms.value / reps
+
+    client._s.check(lib.mi355_memset(ctx, None, C.c_void_p(a.device_ptr()), 0x3C, n))
+    ms = timed(lambda: lib.mi355_probe_memory_copy(ctx, None, C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()), n), 5)
+    assert np.array_equal(client.read_one(b.offset_end_by(n - 4096)), np.full(4096, 0x3C, dtype=np.uint8))   # it really copied
+    assert 1000.0 < 2 * n / ms / 1e6 < 8000.0
+    ms = timed(lambda: lib.mi355_probe_memory_write(ctx, None, C.c_void_p(b.device_ptr()), n), 5)
+    assert 1000.0 < n / ms / 1e6 < 8000.0
+    assert client.read_one(b.offset_end_by(n - 16)).view(np.float32).tolist() == [0.0, 1.0, 2.0, 3.0]          # lane 0's value
+    ops_ = C.c_uint64()
+    ms = timed(lambda: lib.mi355_probe_compute_direct(ctx, None, 4000, C.c_void_p(sink.device_ptr()), C.byref(ops_)), 3)
+    assert 20.0 < ops_.value / ms / 1e9 < 160.0
+    ms = timed(lambda: lib.mi355_probe_launch_overhead(ctx, None, 500, C.c_void_p(sink.device_ptr())), 2)
+    assert ms / 500 * 1e3 < 50.0
+    clk = client.empty(256)
+    client._s.check(lib.mi355_memset(ctx, None, C.c_void_p(clk.device_ptr()), 0, 256))
+    client._s.check(lib.mi355_probe_clock(ctx, None, C.c_void_p(clk.device_ptr())))
+    lib.mi355_probe_mfma_data(ctx, None, 1, 2000, C.c_void_p(sink.device_ptr()), None)
+    client._s.check(lib.mi355_probe_clock(ctx, None, C.c_void_p(clk.device_ptr() + 128)))
+    t = client.read_one(clk).view(np.uint64).reshape(2, 8, 2).astype(np.float64)
+    ghz = [(t[1, x, 0] - t[0, x, 0]) / (t[1, x, 1] - t[0, x, 1]) * 0.1 for x in range(8) if t[1, x, 1] > t[0, x, 1] > 0]
+    assert ghz and 0.3 < max(ghz) < 2.6          # a shader clock, not the 100 MHz reference
