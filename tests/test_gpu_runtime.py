@@ -203,3 +203,44 @@ def test_throughput_probes_run_and_are_sane(client):
     t = client.read_one(clk).view(np.uint64).reshape(2, 8, 2).astype(np.float64)
     ghz = [(t[1, x, 0] - t[0, x, 0]) / (t[1, x, 1] - t[0, x, 1]) * 0.1 for x in range(8) if t[1, x, 1] > t[0, x, 1] > 0]
     assert ghz and 0.3 < max(ghz) < 2.6          # a shader clock, not the 100 MHz reference
+
+
+def test_rccl_collectives_single_rank_communicator(client):
+    """ServerCommunication over RCCL on the one GPU this box has: a world_size-1 communicator exercises the
+    dlopen'ed RCCL entry points, the dtype/op mapping and the two stream fences.  The closed form of the
+    reference's test (runtime_tests/all_reduce.rs:52-59: sum of the contributions) degenerates to identity."""
+    from cubecl_amd import DeviceId, ReduceOperation, sharded
+    ids = [DeviceId(0, 0)]
+    client.comm_init(ids, client.comm_unique_id(), rank=0)
+    x = np.arange(1024, dtype=np.float32) * 0.5 - 7.0
+    src = client.create_from_slice(x)
+    dst = client.empty(x.nbytes)
+    client.all_reduce(src, dst, ElemType.F32, ids, ReduceOperation.Sum)
+    client.sync_collective()
+    assert np.array_equal(client.read_one(dst).view(np.float32), x)
+    client.all_reduce(src, src, ElemType.F32, ids, ReduceOperation.Mean)          # in place, mean over 1 rank
+    client.sync_collective()
+    assert np.array_equal(client.read_one(src).view(np.float32), x)
+    g = client.empty(x.nbytes)
+    client.all_gather(src, g, ElemType.F32, ids)
+    client.sync_collective()
+    assert np.array_equal(client.read_one(g).view(np.float32), x)
+    # the fence: a kernel queued on the compute stream BEFORE the collective is visible to it, and work queued
+    # after sync_collective sees the collective's result
+    t = TensorHandle.uniform(client, (1 << 20,), ElemType.F32, 0x5EEDC0BE, 77, 0.0, 1.0)
+    from cubecl_amd import ops
+    out = TensorHandle.new_contiguous((1,), client.empty(8), ElemType.F32)
+    ops.reduce_sum(client, t, out)
+    part = out.handle.offset_end_by(4)
+    client.all_reduce(part, part, ElemType.F32, ids, ReduceOperation.Sum)
+    client.sync_collective()
+    local = float(out.to_numpy(client)[0])
+    assert abs(local - (1 << 19)) < 2000.0
+    # the transport object bench.py uses at N > 1, with one rank
+    ex = sharded.RcclExchange(client, ids, rank=0)
+    assert ex.all_reduce_sum_f32(3.25) == 3.25
+    assert ex.all_gather_pairs(-0.0, 12345678901) == [(-0.0, 12345678901)]
+    v, i = ex.all_gather_pairs(float("nan"), -1)[0]
+    assert np.isnan(v) and i == -1
+    res = sharded.sharded_sum_argmax(1 << 20, ex, lambda s, c: (local, 0.75, 99))
+    assert (res.total, res.max_value, res.max_index) == (np.float32(local), 0.75, 99)
