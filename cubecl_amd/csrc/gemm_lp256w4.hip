@@ -106,6 +106,9 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
                       // +16 % on the DMA-only ablation, -1.5 % on the full kernel (12.7 M extra L2 requests for
                       // nothing: with MFMAs in the stream the DMA latency is already covered) => off.
 #endif
+#ifndef W4_EVEN
+#define W4_EVEN 0     // 1: DMA pieces spread 4 per k-step (dev A/B)
+#endif
 #ifndef W4_NT_C
 #define W4_NT_C 1     // 1: non-temporal C stores (+1 % at 8192^3, neutral at 4096^3) (keep A/B rather than C in the 256 MiB Infinity Cache)
 #endif
@@ -231,6 +234,7 @@ gemm_lp256w4_kernel(gemm_args g)
             glds16(src_bnn + J * step_bnn + koff * g.ldb, base + J * 1024);
         } else {
             const char *s = decltype(is_b)::value ? src_b[J & 1] + (J >> 1) * step_b : src_a[J & 1] + (J >> 1) * step_a;
+            if (W4_ABL & 128) { glds16(src_a[0], base + J * 1024); return; }   // dev: every piece re-reads one L1-resident KiB
             glds16(s + koff, base + J * 1024);
         }
     };
@@ -289,11 +293,21 @@ gemm_lp256w4_kernel(gemm_args g)
         dma_one(IC<IS_B>{}, IC<2>{}, KOFF, b0 + SLOT * UNIT_BYTES); dma_one(IC<IS_B>{}, IC<3>{}, KOFF, b0 + SLOT * UNIT_BYTES); \
         dma_one(IC<IS_B>{}, IC<4>{}, KOFF, b0 + SLOT * UNIT_BYTES); dma_one(IC<IS_B>{}, IC<5>{}, KOFF, b0 + SLOT * UNIT_BYTES); \
         dma_one(IC<IS_B>{}, IC<6>{}, KOFF, b0 + SLOT * UNIT_BYTES); dma_one(IC<IS_B>{}, IC<7>{}, KOFF, b0 + SLOT * UNIT_BYTES);
+#if W4_EVEN
+        W4_PRO(0, k0, 0) W4_PRO(1, k0, 1) W4_PRO(0, k1, 2)
+        dma_one(IC<1>{}, IC<0>{}, k1, b0 + 3 * UNIT_BYTES); dma_one(IC<1>{}, IC<1>{}, k1, b0 + 3 * UNIT_BYTES);
+        dma_one(IC<1>{}, IC<2>{}, k1, b0 + 3 * UNIT_BYTES); dma_one(IC<1>{}, IC<3>{}, k1, b0 + 3 * UNIT_BYTES);
+#else
         W4_PRO(0, k0, 0) W4_PRO(1, k0, 1) W4_PRO(0, k1, 2) W4_PRO(1, k1, 3)
+#endif
 #undef W4_PRO
     }
     prefetch(3);
+#if W4_EVEN
+    WAIT_VMCNT(12);                      // units 0, 1 landed; unit 2 and the first half of unit 3 may fly
+#else
     WAIT_VMCNT(16 + W4_PF);              // units 0, 1 landed (this wave's share)
+#endif
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -319,10 +333,30 @@ gemm_lp256w4_kernel(gemm_args g)
         const int sa1 = adv(sa, 2), sb1 = adv(sb, 2);     // units 2t+2, 2t+3 (K-tile t+1)
         const int s4 = adv(sa, 4);                        // unit 2t+4 -> slot of unit 2t-1
         const int s5 = sa;                                // unit 2t+5 -> slot of unit 2t
-        const int64_t dma_koff = (int64_t)min(t + 2, (W4_ABL & 32) ? 2 : nk - 1) * ROW_BYTES;
         if ((W4_ABL & 64) && t >= 2) dma_on = false;
         const char *rd_a, *rd_b;
         char *dma_base;
+        int64_t dma_koff;
+#if W4_EVEN
+        // Even schedule: 4 DMA pieces per k-step (after MFMA 3, 7, 11, 15), 8 fragment reads after MFMA 0-7.
+        //   step 0: unit 2t+3 (B of K-tile t+1) pieces 4-7      step 1, 2: unit 2t+4 (A of K-tile t+2) pieces 0-3, 4-7
+        //   hand-over: vmcnt(8) = unit 2t+4 may fly             step 3: unit 2t+5 (B of K-tile t+2) pieces 0-3
+        const int64_t koff1 = (int64_t)min(t + 1, (W4_ABL & 32) ? 2 : nk - 1) * ROW_BYTES;
+        const int64_t koff2 = (int64_t)min(t + 2, (W4_ABL & 32) ? 2 : nk - 1) * ROW_BYTES;
+        rd_a = smem + sa + rowoff_a + x1; rd_b = smem + sb + rowoff_b + y1; dma_base = smem + sb1 + dst_piece; dma_koff = koff1;
+        W4_STEP_BODY(0, 1, 0x00FFu, 0x8888u, 1, 4)
+        rd_a = smem + sa + rowoff_a + x2; rd_b = smem + sb + rowoff_b + y2; dma_base = smem + s4 + dst_piece; dma_koff = koff2;
+        W4_STEP_BODY(1, 0, 0x00FFu, 0x8888u, 0, 0)
+        rd_a = smem + sa + rowoff_a + x3; rd_b = smem + sb + rowoff_b + y3;
+        W4_STEP_BODY(0, 1, 0x00FFu, 0x8888u, 0, 4)
+        WAIT_VMCNT(8);                   // my share of K-tile t+1 landed; unit 2t+4 may still fly
+        WAIT_LGKM0();                    // my reads of K-tile t are complete
+        __builtin_amdgcn_s_barrier();    // BAR_t
+        __builtin_amdgcn_sched_barrier(0);
+        rd_a = smem + sa1 + rowoff_a + x0; rd_b = smem + sb1 + rowoff_b + y0; dma_base = smem + s5 + dst_piece;
+        W4_STEP_BODY(1, 0, 0x00FFu, 0x8888u, 1, 0)
+#else
+        dma_koff = (int64_t)min(t + 2, (W4_ABL & 32) ? 2 : nk - 1) * ROW_BYTES;
         // ---- k-step 0: reads of step 1 after MFMA 0-7, unit 2t+4 pieces 0-3 after MFMA 9,11,13,15
         rd_a = smem + sa + rowoff_a + x1; rd_b = smem + sb + rowoff_b + y1; dma_base = smem + s4 + dst_piece;
         W4_STEP_BODY(0, 1, 0x00FFu, 0xAA00u, 0, 0)
@@ -339,6 +373,7 @@ gemm_lp256w4_kernel(gemm_args g)
         // ---- k-step 3: reads of step 0 of K-tile t+1 after even MFMAs, unit 2t+5 pieces 0-7 after odd ones
         rd_a = smem + sa1 + rowoff_a + x0; rd_b = smem + sb1 + rowoff_b + y0; dma_base = smem + s5 + dst_piece;
         W4_STEP_BODY(1, 0, 0x5555u, 0xAAAAu, 1, 0)
+#endif
         prefetch(t + 4);
         __builtin_amdgcn_sched_barrier(0);
         sa = sa1;
