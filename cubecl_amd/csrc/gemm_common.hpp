@@ -23,6 +23,7 @@ struct gemm_args {
     int64_t stride_a, stride_b, stride_c;
     uint32_t tiles_m, tiles_n;
     uint32_t group_m;
+    uint32_t batch_count;    // persistent kernel: tiles x batch form one linear tile sequence
     uint32_t split_k;        // > 1: blockIdx.z selects a K slice and an f32 partial slab (lp128 split-K)
     int64_t split_c_stride;  // elements between the partial slabs of consecutive K slices
 };
@@ -82,6 +83,8 @@ int32_t launch_gemm_f32_mfma(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_des
 int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 int32_t launch_gemm_lp256(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 int32_t launch_gemm_lp256w4(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
+int32_t launch_gemm_lp256p(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
+bool gemm_lp256p_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 bool gemm_lp256w4_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 // split-K plumbing (gemm_splitk.hip): per-stream library-owned f32 scratch + the slab fold kernel
 int32_t splitk_scratch(mi355_ctx *ctx, hipStream_t s, size_t bytes, float **out);

@@ -278,7 +278,9 @@ enum {
     MI355_GEMM_ALGO_F32_MFMA = 2, /* 128x128 LDS-tiled v_mfma_f32_32x32x2_f32                 */
     MI355_GEMM_ALGO_LP_128 = 3,   /* bf16/f16 128x128x64 LDS-DMA tile, v_mfma_f32_32x32x16     */
     MI355_GEMM_ALGO_LP_256 = 4,   /* bf16/f16 256x256x64 tile, 8 waves (ragged M/N allowed)    */
-    MI355_GEMM_ALGO_LP_256W4 = 5  /* bf16/f16 256x256x64 tile, 4 waves x 128x128, M,N % 256 == 0 */
+    MI355_GEMM_ALGO_LP_256W4 = 5, /* bf16/f16/f32 256x256 tile, 4 waves x 128x128, M,N % 256 == 0 */
+    MI355_GEMM_ALGO_LP_256P = 6   /* the same tile as a persistent kernel: one workgroup per CU walks
+                                     several output tiles with a continuous K-tile stream          */
 };
 
 int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_gemm_desc *desc,

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 GOLD = json.loads((Path(__file__).parent / "golden" / "reference_goldens.json").read_text())
 REL = 1e-5
 ALGOS = {"auto": N.GEMM_ALGO_AUTO, "generic": N.GEMM_ALGO_GENERIC, "f32": N.GEMM_ALGO_F32_MFMA,
-         "lp128": N.GEMM_ALGO_LP_128, "lp256": N.GEMM_ALGO_LP_256, "lp256w4": N.GEMM_ALGO_LP_256W4}
+         "lp128": N.GEMM_ALGO_LP_128, "lp256": N.GEMM_ALGO_LP_256, "lp256w4": N.GEMM_ALGO_LP_256W4, "lp256p": N.GEMM_ALGO_LP_256P}
 
 
 def _to_dev(client, oracle, x, dtype):
@@ -301,7 +301,65 @@ def test_lp256w4_identity_batch_and_fallback(client, oracle):
     assert e.value.code == N.E_UNSUPPORTED
 
 
-@pytest.mark.parametrize("algo", ["lp128", "lp256", "lp256w4", "f32"])
+# ---- the persistent form: one workgroup per CU walks several tiles with a continuous K-tile stream ----------------
+@pytest.mark.parametrize("m,n,k", [(256, 256, 128), (256, 512, 192), (512, 512, 512), (768, 256, 1024), (512, 1024, 320)])
+@pytest.mark.parametrize("dtype,out", [(ElemType.BF16, "f32"), (ElemType.BF16, "same"), (ElemType.F16, "same"), (ElemType.F32, "f32")])
+def test_lp256p_parity(client, oracle, m, n, k, dtype, out):
+    run_case(client, oracle, m, n, k if dtype != ElemType.F32 else k // 2, dtype, ElemType.F32 if out == "f32" else dtype, True,
+             ALGOS["lp256p"])
+
+
+@pytest.mark.parametrize("m,n,k,batch,dtype,out", [
+    (4352, 4352, 128, 1, ElemType.BF16, "same"),     # 289 tiles on 256 CUs: 33 workgroups take a second tile, K = 2 K-tiles
+    (4352, 4352, 192, 1, ElemType.BF16, "f32"),
+    (256, 256, 256, 300, ElemType.BF16, "same"),     # tiles of different batch entries in one workgroup's sequence
+    (512, 256, 128, 260, ElemType.F16, "f32"),
+    (4352, 4352, 64, 1, ElemType.F32, "f32"),
+    (256, 768, 2048, 130, ElemType.BF16, "same"),    # 390 tiles, long K
+])
+def test_lp256p_multi_tile_sequences(client, oracle, m, n, k, batch, dtype, out):
+    run_case(client, oracle, m, n, k, dtype, ElemType.F32 if out == "f32" else dtype, True, ALGOS["lp256p"], batch=batch)
+
+
+def test_lp256p_row_major_b_f32_and_padding_and_identity(client, oracle):
+    run_case(client, oracle, 4352, 4352, 64, ElemType.F32, ElemType.F32, False, ALGOS["lp256p"])
+    run_case(client, oracle, 512, 256, 128, ElemType.BF16, ElemType.BF16, True, ALGOS["lp256p"], batch=2, bcast_b=True,
+             lda=136, ldb=128, ldc=264)
+    m = n = 4352
+    k = 4352
+    eye = np.zeros((m, k), dtype=np.uint16)
+    eye[np.arange(m), np.arange(m)] = 0x3F80
+    bmat = oracle.to_bf16(oracle.fill_uniform(n * k, 91, -1.0, 1.0)).reshape(n, k)
+    ta = TensorHandle.from_numpy(client, eye, ElemType.BF16)
+    tb = TensorHandle.from_numpy(client, bmat, ElemType.BF16)
+    c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 2), ElemType.BF16)
+    ops.matmul(client, TensorHandle.new(ta.handle, (m, k), (k, 1), ElemType.BF16),
+               TensorHandle.new(tb.handle, (k, n), (1, k), ElemType.BF16), c, algo=ALGOS["lp256p"])
+    assert np.array_equal(c.to_numpy(client).reshape(m, n), bmat.T)       # every tile of every round, bit for bit
+    with pytest.raises(ServerError) as e:                                   # K must hold two K-tiles
+        run_case(client, oracle, 256, 256, 64, ElemType.BF16, ElemType.F32, True, ALGOS["lp256p"])
+    assert e.value.code == N.E_UNSUPPORTED
+
+
+def test_lp256p_race_screen_across_tile_boundaries(client, oracle):
+    # 289 tiles on 256 CUs, K = 8 K-tiles: the hand-over from one tile's stream to the next must give the same bits
+    # on every launch, and the same bits as the one-tile-per-workgroup kernel (identical per-tile arithmetic order)
+    m = n = 4352
+    k = 512
+    a = TensorHandle.uniform(client, (m, k), ElemType.BF16, 0x5EEDC0BE, 73, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (n, k), ElemType.BF16, 0x5EEDC0BE, 74, -1.0, 1.0)
+    bt = TensorHandle.new(b.handle, (k, n), (1, k), ElemType.BF16)
+    ref = TensorHandle.new_contiguous((m, n), client.empty(m * n * 4), ElemType.F32)
+    ops.matmul(client, a, bt, ref, algo=ALGOS["lp256w4"])
+    want = ref.to_numpy(client).copy()
+    c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 4), ElemType.F32)
+    for _ in range(15):
+        client._s.check(client.lib.mi355_memset(client.ctx, None, c.device_ptr(), 0xEE, m * n * 4))
+        ops.matmul(client, a, bt, c, algo=ALGOS["lp256p"])
+        assert np.array_equal(c.to_numpy(client), want)
+
+
+@pytest.mark.parametrize("algo", ["lp128", "lp256", "lp256w4", "lp256p", "f32"])
 def test_race_screen_bitwise_repeatability(client, oracle, algo):
     # the counted-vmcnt / barrier pipeline must give the same bits on every launch (guide: "place reads by
     # the vmcnt/barrier count, never by clean runs") -- 25 launches at a multi-wave-per-CU size
