@@ -34,10 +34,8 @@
 //   K-tile t+1 are fetched under the last 16 MFMAs of K-tile t: the barrier is the only point
 //   where the pipe can drain.  Unit 2t+4 reuses the slot of unit 2t-1 (dead since BAR_{t-1}).
 //   Every DMA is issued >= 3 k-steps (~1500 cycles) before the barrier that needs it; vmcnt
-//   never reaches 0 in the loop.  After the last DMA of k-step 3 each wave issues one L2 prefetch
-//   load for K-tile t+4 (see "L2 prefetch map" below); it is the oldest of the 9 VMEM operations
-//   allowed in flight at the next hand-over, so it has ~1.75 K-tiles to come back.  Past the last K-tile the same instructions run against a clamped
-//   tile index (harmless re-reads into dead slots), keeping the counts uniform.
+//   never reaches 0 in the steady state.  The last two K-tiles of a tile have nothing left to fetch: they run a
+//   second copy of the body without DMA and with vmcnt(0) at the hand-over.
 //
 // Restrictions (the dispatcher falls back to gemm_lp256.hip / gemm_lp128.hip otherwise):
 //   M % 256 == 0, N % 256 == 0, K % 64 (16-bit) / 32 (f32) == 0, A row-major [M][K], B stored [N][K]
@@ -97,23 +95,12 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
 }
 
 #ifndef W4_ABL
-#define W4_ABL 0          // dev ablations: 1 no DMA, 2 no fragment reads, 4 no MFMA, 32 DMA re-reads K-tiles 0-2, 64 DMA off after K-tile 2
+#define W4_ABL 0          // dev ablations: 1 no DMA, 2 no fragment reads, 4 no MFMA (results: profiles/r01_power_ablation.md)
 #endif
 
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" W4_STR(n) ")" ::: "memory")
-#ifndef W4_PF
-#define W4_PF 0       // 1: L2 prefetch of K-tile t+4 (one global_load_dword per wave and K-tile).  Measured:
-                      // +16 % on the DMA-only ablation, -1.5 % on the full kernel (12.7 M extra L2 requests for
-                      // nothing: with MFMAs in the stream the DMA latency is already covered) => off.
-#endif
-#ifndef W4_EVEN
-#define W4_EVEN 0     // 1: DMA pieces spread 4 per k-step (dev A/B)
-#endif
 #ifndef W4_NT_C
 #define W4_NT_C 1     // 1: non-temporal C stores (+1 % at 8192^3, neutral at 4096^3) (keep A/B rather than C in the 256 MiB Infinity Cache)
-#endif
-#ifndef W4_VMW
-#define W4_VMW (8 + W4_PF)   // outstanding VMEM instructions allowed at the K-tile hand-over
 #endif
 #define W4_STR_(x) #x
 #define W4_STR(x) W4_STR_(x)
@@ -167,32 +154,6 @@ gemm_lp256w4_kernel(gemm_args g)
     const int64_t step_bnn = g.ldb * ESZ;
     const int dst_piece = wave * 8 * 1024;                            // + j*1024 within the slot
 
-    // ---- L2 prefetch map.  Every unique 128-byte line of a K-tile is wanted by the 4 (A) or 8 (B)
-    //   workgroups of this XCD that share the panel, all at about the same time: the first request
-    //   misses L2 and the others queue behind the same fill, so every sharer pays the miss latency,
-    //   and the per-CU cap on outstanding vector-memory requests turns that latency into a
-    //   throughput limit (measured: LDS-DMA streams 125 GB/s/CU from a warm L2, 62 GB/s/CU in this
-    //   GEMM with no MFMA at all).  So each workgroup touches ITS SHARE of its panels' lines ~2
-    //   K-tiles ahead with one 4-byte load per line (sc1: served by L2, not allocated in L1): the
-    //   tile at (tm, tn) covers quarter tn%4 of A panel tm and eighth tm%8 of B panel tn -- the
-    //   sharers of a panel are consecutive in tn (A) / tm (B) under the grouped rasterisation, so
-    //   together they cover every line.  Placement only affects speed: an un-prefetched line is
-    //   simply demand-missed by the DMA as before.  Lane map per wave: lanes 0-15 -> 16 A rows,
-    //   lanes 16-23 -> 8 B rows, lanes 24-63 repeat lane 0's line (coalesced away).
-    const char *pf_src;
-    {
-        const int la = lane & 15, lb = lane & 7;
-        const int64_t row_a = m0 + (tn & 3) * 64 + wave * 16 + (lane < 16 ? la : 0);
-        const int64_t row_b = n0 + (tm & 7) * 32 + wave * 8 + lb;
-        pf_src = (lane >= 16 && lane < 24) ? B + row_b * g.ldb * ESZ : A + row_a * g.lda * ESZ;
-    }
-    unsigned pf_sink = 0;
-    auto prefetch = [&](int tile) {
-        if (!W4_PF || BNN || (W4_ABL & 1)) return;
-        const char *p = pf_src + (int64_t)min(tile, nk - 1) * ROW_BYTES;
-        asm volatile("global_load_dword %0, %1, off sc1" : "+v"(pf_sink) : "v"(p) : "memory");
-    };
-
     // ---- fragment read offsets: row*128 + ((2s+h) ^ f) * 16, f = (row>>1)&7 = (l31>>1)&7 for every tile row
     const int f = (l31 >> 1) & 7;
     const int rowoff_a = (wm * 128 + l31) * ROW_BYTES;
@@ -225,16 +186,14 @@ gemm_lp256w4_kernel(gemm_args g)
             else fb[BUF][R - 4] = *reinterpret_cast<const frag *>(pb + (R - 4) * 32 * ROW_BYTES);
         }
     };
-    bool dma_on = true;   // dev ablation 64 switches the DMA off after the ring is filled with real data
     auto dma_one = [&](auto is_b, auto jj, int64_t koff, char *base) {
         constexpr int J = decltype(jj)::value;
-        if ((W4_ABL & 1) || !dma_on) return;
+        if (W4_ABL & 1) return;
         if constexpr (BNN && decltype(is_b)::value) {
             // koff = tile * 128 bytes along K for the K-contiguous layout; here a K-tile is 32 rows of ldb elements
             glds16(src_bnn + J * step_bnn + koff * g.ldb, base + J * 1024);
         } else {
             const char *s = decltype(is_b)::value ? src_b[J & 1] + (J >> 1) * step_b : src_a[J & 1] + (J >> 1) * step_a;
-            if (W4_ABL & 128) { glds16(src_a[0], base + J * 1024); return; }   // dev: every piece re-reads one L1-resident KiB
             glds16(s + koff, base + J * 1024);
         }
     };
@@ -286,28 +245,17 @@ gemm_lp256w4_kernel(gemm_args g)
 
     // ---- prologue: units 0..3 (K-tiles 0 and 1), then the first fragments ---------------------------
     {
-        const int64_t k0 = 0, k1 = (int64_t)min(1, nk - 1) * ROW_BYTES;
+        const int64_t k0 = 0, k1 = (int64_t)min(1, nk - 1) * ROW_BYTES;   // nk == 1: K-tile 0 twice, drained at the hand-over
         char *b0 = smem + dst_piece;
 #define W4_PRO(IS_B, KOFF, SLOT)                                                                     \
         dma_one(IC<IS_B>{}, IC<0>{}, KOFF, b0 + SLOT * UNIT_BYTES); dma_one(IC<IS_B>{}, IC<1>{}, KOFF, b0 + SLOT * UNIT_BYTES); \
         dma_one(IC<IS_B>{}, IC<2>{}, KOFF, b0 + SLOT * UNIT_BYTES); dma_one(IC<IS_B>{}, IC<3>{}, KOFF, b0 + SLOT * UNIT_BYTES); \
         dma_one(IC<IS_B>{}, IC<4>{}, KOFF, b0 + SLOT * UNIT_BYTES); dma_one(IC<IS_B>{}, IC<5>{}, KOFF, b0 + SLOT * UNIT_BYTES); \
         dma_one(IC<IS_B>{}, IC<6>{}, KOFF, b0 + SLOT * UNIT_BYTES); dma_one(IC<IS_B>{}, IC<7>{}, KOFF, b0 + SLOT * UNIT_BYTES);
-#if W4_EVEN
-        W4_PRO(0, k0, 0) W4_PRO(1, k0, 1) W4_PRO(0, k1, 2)
-        dma_one(IC<1>{}, IC<0>{}, k1, b0 + 3 * UNIT_BYTES); dma_one(IC<1>{}, IC<1>{}, k1, b0 + 3 * UNIT_BYTES);
-        dma_one(IC<1>{}, IC<2>{}, k1, b0 + 3 * UNIT_BYTES); dma_one(IC<1>{}, IC<3>{}, k1, b0 + 3 * UNIT_BYTES);
-#else
         W4_PRO(0, k0, 0) W4_PRO(1, k0, 1) W4_PRO(0, k1, 2) W4_PRO(1, k1, 3)
-#endif
 #undef W4_PRO
     }
-    prefetch(3);
-#if W4_EVEN
-    WAIT_VMCNT(12);                      // units 0, 1 landed; unit 2 and the first half of unit 3 may fly
-#else
-    WAIT_VMCNT(16 + W4_PF);              // units 0, 1 landed (this wave's share)
-#endif
+    WAIT_VMCNT(16);                      // units 0, 1 landed (this wave's share)
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -329,60 +277,44 @@ gemm_lp256w4_kernel(gemm_args g)
     const int y0 = BNN ? (4 * h) * 1024 : x0, y1 = BNN ? (8 + 4 * h) * 1024 : x1, y2 = BNN ? (16 + 4 * h) * 1024 : x2,
               y3 = BNN ? (24 + 4 * h) * 1024 : x3;
 
-    for (int t = 0; t < nk; ++t) {
-        const int sa1 = adv(sa, 2), sb1 = adv(sb, 2);     // units 2t+2, 2t+3 (K-tile t+1)
-        const int s4 = adv(sa, 4);                        // unit 2t+4 -> slot of unit 2t-1
-        const int s5 = sa;                                // unit 2t+5 -> slot of unit 2t
-        if ((W4_ABL & 64) && t >= 2) dma_on = false;
-        const char *rd_a, *rd_b;
-        char *dma_base;
-        int64_t dma_koff;
-#if W4_EVEN
-        // Even schedule: 4 DMA pieces per k-step (after MFMA 3, 7, 11, 15), 8 fragment reads after MFMA 0-7.
-        //   step 0: unit 2t+3 (B of K-tile t+1) pieces 4-7      step 1, 2: unit 2t+4 (A of K-tile t+2) pieces 0-3, 4-7
-        //   hand-over: vmcnt(8) = unit 2t+4 may fly             step 3: unit 2t+5 (B of K-tile t+2) pieces 0-3
-        const int64_t koff1 = (int64_t)min(t + 1, (W4_ABL & 32) ? 2 : nk - 1) * ROW_BYTES;
-        const int64_t koff2 = (int64_t)min(t + 2, (W4_ABL & 32) ? 2 : nk - 1) * ROW_BYTES;
-        rd_a = smem + sa + rowoff_a + x1; rd_b = smem + sb + rowoff_b + y1; dma_base = smem + sb1 + dst_piece; dma_koff = koff1;
-        W4_STEP_BODY(0, 1, 0x00FFu, 0x8888u, 1, 4)
-        rd_a = smem + sa + rowoff_a + x2; rd_b = smem + sb + rowoff_b + y2; dma_base = smem + s4 + dst_piece; dma_koff = koff2;
-        W4_STEP_BODY(1, 0, 0x00FFu, 0x8888u, 0, 0)
-        rd_a = smem + sa + rowoff_a + x3; rd_b = smem + sb + rowoff_b + y3;
-        W4_STEP_BODY(0, 1, 0x00FFu, 0x8888u, 0, 4)
-        WAIT_VMCNT(8);                   // my share of K-tile t+1 landed; unit 2t+4 may still fly
-        WAIT_LGKM0();                    // my reads of K-tile t are complete
-        __builtin_amdgcn_s_barrier();    // BAR_t
-        __builtin_amdgcn_sched_barrier(0);
-        rd_a = smem + sa1 + rowoff_a + x0; rd_b = smem + sb1 + rowoff_b + y0; dma_base = smem + s5 + dst_piece;
-        W4_STEP_BODY(1, 0, 0x00FFu, 0x8888u, 1, 0)
-#else
-        dma_koff = (int64_t)min(t + 2, (W4_ABL & 32) ? 2 : nk - 1) * ROW_BYTES;
-        // ---- k-step 0: reads of step 1 after MFMA 0-7, unit 2t+4 pieces 0-3 after MFMA 9,11,13,15
-        rd_a = smem + sa + rowoff_a + x1; rd_b = smem + sb + rowoff_b + y1; dma_base = smem + s4 + dst_piece;
-        W4_STEP_BODY(0, 1, 0x00FFu, 0xAA00u, 0, 0)
-        // ---- k-step 1: reads of step 2, unit 2t+4 pieces 4-7
-        rd_a = smem + sa + rowoff_a + x2; rd_b = smem + sb + rowoff_b + y2;
-        W4_STEP_BODY(1, 0, 0x00FFu, 0xAA00u, 0, 4)
-        // ---- k-step 2: reads of step 3, no DMA; then the K-tile hand-over
-        rd_a = smem + sa + rowoff_a + x3; rd_b = smem + sb + rowoff_b + y3;
-        W4_STEP_BODY(0, 1, 0x00FFu, 0x0000u, 0, 0)
-        WAIT_VMCNT(W4_VMW);              // my share of K-tile t+1 landed; unit 2t+4 may still fly
-        WAIT_LGKM0();                    // my reads of K-tile t are complete
-        __builtin_amdgcn_s_barrier();    // BAR_t
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- k-step 3: reads of step 0 of K-tile t+1 after even MFMAs, unit 2t+5 pieces 0-7 after odd ones
-        rd_a = smem + sa1 + rowoff_a + x0; rd_b = smem + sb1 + rowoff_b + y0; dma_base = smem + s5 + dst_piece;
-        W4_STEP_BODY(1, 0, 0x5555u, 0xAAAAu, 1, 0)
-#endif
-        prefetch(t + 4);
-        __builtin_amdgcn_sched_barrier(0);
-        sa = sa1;
-        sb = sb1;
+    // One K-tile.  ISSUE = 1: the steady state (units 2t+4, 2t+5 are issued, vmcnt(8) at the hand-over).
+    // ISSUE = 0: the last two K-tiles of the tile -- there is nothing left to fetch, so no DMA is issued (the first
+    // version re-read the last K-tile into dead slots to keep the counts uniform: 2 K-tiles of useless L2 traffic
+    // per output tile and a vmcnt(0) stall on them before the epilogue) and the hand-over waits for everything.
+#define W4_KTILE(ISSUE)                                                                                     \
+    {                                                                                                       \
+        const int sa1 = adv(sa, 2), sb1 = adv(sb, 2);     /* units 2t+2, 2t+3 (K-tile t+1) */               \
+        const int s4 = adv(sa, 4);                        /* unit 2t+4 -> slot of unit 2t-1 */               \
+        const int s5 = sa;                                /* unit 2t+5 -> slot of unit 2t   */               \
+        const int64_t dma_koff = (int64_t)(t + 2) * ROW_BYTES;                                              \
+        const char *rd_a, *rd_b;                                                                            \
+        char *dma_base;                                                                                     \
+        /* k-step 0: reads of step 1 after MFMA 0-7, unit 2t+4 pieces 0-3 after MFMA 9,11,13,15 */          \
+        rd_a = smem + sa + rowoff_a + x1; rd_b = smem + sb + rowoff_b + y1; dma_base = smem + s4 + dst_piece; \
+        W4_STEP_BODY(0, 1, 0x00FFu, (ISSUE) ? 0xAA00u : 0u, 0, 0)                                            \
+        /* k-step 1: reads of step 2, unit 2t+4 pieces 4-7 */                                               \
+        rd_a = smem + sa + rowoff_a + x2; rd_b = smem + sb + rowoff_b + y2;                                 \
+        W4_STEP_BODY(1, 0, 0x00FFu, (ISSUE) ? 0xAA00u : 0u, 0, 4)                                            \
+        /* k-step 2: reads of step 3, no DMA; then the K-tile hand-over */                                  \
+        rd_a = smem + sa + rowoff_a + x3; rd_b = smem + sb + rowoff_b + y3;                                 \
+        W4_STEP_BODY(0, 1, 0x00FFu, 0x0000u, 0, 0)                                                          \
+        if (ISSUE) WAIT_VMCNT(8); else WAIT_VMCNT(0);     /* my share of K-tile t+1 landed (unit 2t+4 may fly) */ \
+        WAIT_LGKM0();                                     /* my reads of K-tile t are complete */           \
+        __builtin_amdgcn_s_barrier();                     /* BAR_t */                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        /* k-step 3: reads of step 0 of K-tile t+1 after even MFMAs, unit 2t+5 pieces 0-7 after odd ones */ \
+        rd_a = smem + sa1 + rowoff_a + x0; rd_b = smem + sb1 + rowoff_b + y0; dma_base = smem + s5 + dst_piece; \
+        W4_STEP_BODY(1, 0, 0x5555u, (ISSUE) ? 0xAAAAu : 0u, 1, 0)                                            \
+        sa = sa1;                                                                                           \
+        sb = sb1;                                                                                           \
     }
+    int t = 0;
+    for (; t + 2 < nk; ++t) W4_KTILE(1)
+    for (; t < nk; ++t) W4_KTILE(0)
+#undef W4_KTILE
 #undef W4_STEP_BODY
 #undef W4_GROUP
-    WAIT_VMCNT(0);                       // drain the clamped tail DMA before the workgroup retires
-    asm volatile("" ::"v"(pf_sink));     // the prefetch destination register stays reserved until here
+    // nothing is in flight here: the last hand-over waited for vmcnt(0) and no DMA was issued after it
 
     // ---- epilogue ----------------------------------------------------------------------------------
     // With the operands swapped in the MFMA (first = B fragment), lane (l31, h) of a wave holds, for
