@@ -371,6 +371,24 @@ def main():
             return res
         guarded("reduce_1GiB_f32", reduce_c4)
 
+        def book_reduce():
+            # the reference's only published reduce cases (cubecl-book getting-started: sum over the last axis;
+            # 1.085 ms / 3.124 ms / 1.483 ms / 0.924 ms on an unnamed wgpu device)
+            out = {}
+            for shape, ref_ms in (((512, 8192), 1.085), ((128, 32768), 3.124), ((64, 256, 1024), 1.483), ((64, 64, 4096), 0.924)):
+                n = 1
+                for d_ in shape:
+                    n *= d_
+                cols = shape[-1]
+                x = TensorHandle.uniform(client, (n,), ElemType.F32, SEED, 800, 0.0, 1.0)
+                y = client.empty(n // cols * 4)
+                med, best = samples_op(client, ev, lambda: client._s.check(lib.mi355_reduce_last_axis_sum_f32(
+                    ctx, None, x.device_ptr(), y.device_ptr(), n // cols, cols, cols)))
+                out["x".join(map(str, shape))] = {"median_us": round(med * 1e3, 2), "GBs": round(n * 4 / med / 1e6, 1),
+                                                   "book_wgpu_ms": ref_ms}
+            return out
+        guarded("book_reduce_last_axis_f32", book_reduce)
+
         def gemm_f32_c2():
             M = 4096
             fa = TensorHandle.uniform(client, (M, M), ElemType.F32, SEED, 400, -1.0, 1.0)
