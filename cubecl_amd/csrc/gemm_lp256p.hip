@@ -108,6 +108,14 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
 #define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 template <int V> using IC = std::integral_constant<int, V>;
 
+#ifdef P_TRACE
+__device__ unsigned long long p_trace_buf[256 * 16];
+__device__ __forceinline__ void p_stamp(int tid, int k) { if (tid == 0 && blockIdx.x < 256 && k < 16) p_trace_buf[blockIdx.x * 16 + k] = __builtin_amdgcn_s_memtime(); }
+#define P_STAMP(k) p_stamp(tid, k)
+#else
+#define P_STAMP(k)
+#endif
+
 // BNN (f32 only): B is row-major [K][N] instead of [N][K] (see gemm_lp256w4.hip).
 template <int DT, int DT_C, bool BNN = false>
 __global__ void __launch_bounds__(256)
@@ -275,6 +283,8 @@ gemm_lp256p_kernel(gemm_args g)
     char *__restrict__ C = static_cast<char *>(g.c);
     constexpr int CSZ = (DT_C == MI355_DTYPE_F32) ? 4 : 2;
 
+    int stamp_i = 1;
+    P_STAMP(0);
     for (;;) {
         const uint32_t Lnext = L + gridDim.x;
         const bool has_next = Lnext < total;
@@ -310,6 +320,7 @@ gemm_lp256p_kernel(gemm_args g)
             sb = sb1;
         }
 
+        P_STAMP(stamp_i); ++stamp_i;           // loop end
         // ---- epilogue of this tile ----------------------------------------------------------------------
         // Lane (l31, h) holds, for every 32-row block i, row l31 and the column groups n = j*32 + 8q + 4h .. +3.
         // Each wave transposes through ITS 8 KiB of the dead B slot: the accumulators go to LDS as f32 straight
@@ -369,6 +380,7 @@ gemm_lp256p_kernel(gemm_args g)
                 }
             }
         }
+        P_STAMP(stamp_i); ++stamp_i;           // epilogue end
         if (!has_next) break;
         zero_acc();
         cur = nxt;
@@ -394,6 +406,13 @@ void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch, i
 }
 
 }  // namespace
+
+#ifdef P_TRACE
+extern "C" __attribute__((visibility("default"))) int mi355_dev_p_trace(unsigned long long *host_out)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(p_trace_buf), sizeof(unsigned long long) * 256 * 16);
+}
+#endif
 
 namespace mi355 {
 

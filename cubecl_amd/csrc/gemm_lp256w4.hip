@@ -107,6 +107,16 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
 #define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 template <int V> using IC = std::integral_constant<int, V>;
 
+// Dev timing trace (-DW4_TRACE): per-workgroup shader-clock stamps {kernel entry, first MFMA, loop end, kernel end}
+// of wave 0, read back with mi355_dev_w4_trace (dev builds only; never in the product library).
+#ifdef W4_TRACE
+__device__ unsigned long long w4_trace_buf[4096 * 8];
+#define W4_STAMP(k) do { if (tid == 0 && blockIdx.x < 4096 && blockIdx.y == 0) { w4_trace_buf[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+        if ((k) == 0 || (k) == 3) w4_trace_buf[blockIdx.x * 8 + 4 + ((k) == 3)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define W4_STAMP(k)
+#endif
+
 // BNN (f32 only): B is row-major [K][N] instead of [N][K].  Its K-tile is then 32 k-rows of 256 n-values
 // (1 KiB each = one DMA piece, no swizzle), and a B fragment is four ds_read_b32 (consecutive lanes ->
 // consecutive n: conflict free) instead of one ds_read_b128 -- affordable because an f32 k-step holds 64
@@ -120,6 +130,7 @@ gemm_lp256w4_kernel(gemm_args g)
     typedef typename lp<DT>::frag frag;
 
     const int tid = threadIdx.x;
+    W4_STAMP(0);
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -308,10 +319,12 @@ gemm_lp256w4_kernel(gemm_args g)
         sa = sa1;                                                                                           \
         sb = sb1;                                                                                           \
     }
+    W4_STAMP(1);
     int t = 0;
     for (; t + 2 < nk; ++t) W4_KTILE(1)
     for (; t < nk; ++t) W4_KTILE(0)
 #undef W4_KTILE
+    W4_STAMP(2);
 #undef W4_STEP_BODY
 #undef W4_GROUP
     // nothing is in flight here: the last hand-over waited for vmcnt(0) and no DMA was issued after it
@@ -373,6 +386,10 @@ gemm_lp256w4_kernel(gemm_args g)
             __builtin_amdgcn_sched_barrier(0);             // keep the accumulator reads of block i+1 below this point
         }
     }
+#ifdef W4_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    W4_STAMP(3);
+#endif
 }
 
 template <int DT, int DT_C, bool BNN = false>
@@ -387,6 +404,13 @@ void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch, i
 }
 
 }  // namespace
+
+#ifdef W4_TRACE
+extern "C" __attribute__((visibility("default"))) int mi355_dev_w4_trace(unsigned long long *host_out)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(w4_trace_buf), sizeof(unsigned long long) * 4096 * 8);
+}
+#endif
 
 namespace mi355 {
 
