@@ -94,8 +94,22 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
                                      (__attribute__((address_space(3))) void *)lds_dst, 16, 0, W4_DMA_AUX);
 }
 
+// LDS-DMA with the address split the way the hardware wants it: 64-bit wave-uniform base in SGPRs + 32-bit
+// per-lane byte offset, LDS destination (wave-uniform) through M0.  Written as inline asm because hipcc
+// re-associates base + offset into per-lane 64-bit pointers (one 64-bit VALU add per piece in the K loop).
+// M0 is set in the same statement that uses it (guide 5.7); nothing else in this kernel touches M0.  The
+// compiler does not count these loads: every wait on them is an explicit counted s_waitcnt in this file.
+__device__ __forceinline__ void glds16_s(const void *ubase, uint32_t voff, uint32_t lds_byte_addr)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ubase), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void *p)
+{
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)p;
+}
+
 #ifndef W4_ABL
-#define W4_ABL 0          // dev ablations: 1 no DMA, 2 no fragment reads, 4 no MFMA (results: profiles/r01_power_ablation.md)
+#define W4_ABL 0          // dev ablations: 1 no DMA, 2 no fragment reads, 4 no MFMA, 8 no hand-over barrier (results: profiles/r01_power_ablation.md)
 #endif
 
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" W4_STR(n) ")" ::: "memory")
@@ -151,18 +165,24 @@ gemm_lp256w4_kernel(gemm_args g)
     //   ((row>>1)&7 depends on j only through its parity, so two per-lane pointers per operand
     //   suffice; the (j>>1) step is a wave-uniform byte offset.)
     const int sub = lane >> 3, c8 = lane & 7;
-    const char *src_a[2], *src_b[2];
+    // Addresses are split into a wave-uniform 64-bit base (kernel arguments, tile, wave: SGPRs, advanced with
+    // scalar adds) and a 32-bit per-lane byte offset that never changes, so that each DMA is
+    // `global_load_lds_dwordx4 v_off, s[base:base+1]` with no 64-bit vector add per piece.
+    const char *ubase_a = A + (m0 + wave * 64) * g.lda * ESZ;           // uniform: first row of this wave's pieces
+    const char *ubase_b = B + (n0 + wave * 64) * g.ldb * ESZ;
+    uint32_t voff_a[8], voff_b[8];                                        // piece j of this wave: rows j*8 + lane/8
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int r = wave * 64 + p * 8 + sub;
-        const int q = c8 ^ ((r >> 1) & 7);
-        src_a[p] = A + (m0 + r) * g.lda * ESZ + q * 16;
-        src_b[p] = B + (n0 + r) * g.ldb * ESZ + q * 16;
+    for (int j = 0; j < 8; ++j) {
+        const int r = j * 8 + sub;
+        const int q = c8 ^ (((wave * 64 + r) >> 1) & 7);
+        voff_a[j] = (uint32_t)(r * g.lda * ESZ + q * 16);
+        voff_b[j] = (uint32_t)(r * g.ldb * ESZ + q * 16);
     }
-    const int64_t step_a = 16 * g.lda * ESZ, step_b = 16 * g.ldb * ESZ;   // bytes between pieces j and j+2
     // BNN: piece j of this wave is k-row wave*8 + j of the K-tile, 256 n-values = 64 lanes x 16 B
-    const char *src_bnn = B + (int64_t)(wave * 8) * g.ldb * ESZ + n0 * ESZ + lane * 16;
-    const int64_t step_bnn = g.ldb * ESZ;
+    const char *ubase_bnn = B + (int64_t)(wave * 8) * g.ldb * ESZ + n0 * ESZ;
+    uint32_t voff_bnn[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) voff_bnn[j] = (uint32_t)(j * g.ldb * ESZ + lane * 16);
     const int dst_piece = wave * 8 * 1024;                            // + j*1024 within the slot
 
     // ---- fragment read offsets: row*128 + ((2s+h) ^ f) * 16, f = (row>>1)&7 = (l31>>1)&7 for every tile row
@@ -202,10 +222,10 @@ gemm_lp256w4_kernel(gemm_args g)
         if (W4_ABL & 1) return;
         if constexpr (BNN && decltype(is_b)::value) {
             // koff = tile * 128 bytes along K for the K-contiguous layout; here a K-tile is 32 rows of ldb elements
-            glds16(src_bnn + J * step_bnn + koff * g.ldb, base + J * 1024);
+            glds16_s(ubase_bnn + koff * g.ldb, voff_bnn[J], lds_addr_of(base) + J * 1024);
         } else {
-            const char *s = decltype(is_b)::value ? src_b[J & 1] + (J >> 1) * step_b : src_a[J & 1] + (J >> 1) * step_a;
-            glds16(s + koff, base + J * 1024);
+            glds16_s((decltype(is_b)::value ? ubase_b : ubase_a) + koff, decltype(is_b)::value ? voff_b[J] : voff_a[J],
+                     lds_addr_of(base) + J * 1024);
         }
     };
     auto mfma_one = [&](auto buf, auto idx) {
@@ -309,9 +329,11 @@ gemm_lp256w4_kernel(gemm_args g)
         /* k-step 2: reads of step 3, no DMA; then the K-tile hand-over */                                  \
         rd_a = smem + sa + rowoff_a + x3; rd_b = smem + sb + rowoff_b + y3;                                 \
         W4_STEP_BODY(0, 1, 0x00FFu, 0x0000u, 0, 0)                                                          \
+        if (!(W4_ABL & 8)) {                              /* dev ablation 8: no hand-over (timing only, races) */ \
         if (ISSUE) WAIT_VMCNT(8); else WAIT_VMCNT(0);     /* my share of K-tile t+1 landed (unit 2t+4 may fly) */ \
         WAIT_LGKM0();                                     /* my reads of K-tile t are complete */           \
         __builtin_amdgcn_s_barrier();                     /* BAR_t */                                        \
+        }                                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
         /* k-step 3: reads of step 0 of K-tile t+1 after even MFMAs, unit 2t+5 pieces 0-7 after odd ones */ \
         rd_a = smem + sa1 + rowoff_a + x0; rd_b = smem + sb1 + rowoff_b + y0; dma_base = smem + s5 + dst_piece; \
