@@ -99,9 +99,11 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
 // re-associates base + offset into per-lane 64-bit pointers (one 64-bit VALU add per piece in the K loop).
 // M0 is set in the same statement that uses it (guide 5.7); nothing else in this kernel touches M0.  The
 // compiler does not count these loads: every wait on them is an explicit counted s_waitcnt in this file.
+template <int IMM>
 __device__ __forceinline__ void glds16_s(const void *ubase, uint32_t voff, uint32_t lds_byte_addr)
 {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ubase), "s"(lds_byte_addr) : "memory");
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ubase), "s"(lds_byte_addr), "i"(IMM)
+                 : "memory", "scc");
 }
 __device__ __forceinline__ uint32_t lds_addr_of(const void *p)
 {
@@ -222,10 +224,10 @@ gemm_lp256w4_kernel(gemm_args g)
         if (W4_ABL & 1) return;
         if constexpr (BNN && decltype(is_b)::value) {
             // koff = tile * 128 bytes along K for the K-contiguous layout; here a K-tile is 32 rows of ldb elements
-            glds16_s(ubase_bnn + koff * g.ldb, voff_bnn[J], lds_addr_of(base) + J * 1024);
+            glds16_s<J * 1024>(ubase_bnn + koff * g.ldb, voff_bnn[J], lds_addr_of(base));
         } else {
-            glds16_s((decltype(is_b)::value ? ubase_b : ubase_a) + koff, decltype(is_b)::value ? voff_b[J] : voff_a[J],
-                     lds_addr_of(base) + J * 1024);
+            glds16_s<J * 1024>((decltype(is_b)::value ? ubase_b : ubase_a) + koff, decltype(is_b)::value ? voff_b[J] : voff_a[J],
+                               lds_addr_of(base));
         }
     };
     auto mfma_one = [&](auto buf, auto idx) {
