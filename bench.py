@@ -160,9 +160,9 @@ def main():
     def step():
         client._s.check(lib.mi355_gemm(ctx, None, C.byref(desc), pa, pb, pc))
 
-    clk = client.empty(256)          # two samples of {shader ticks, 100 MHz ticks} x 8 XCDs bracketing the timed region
-    lib.mi355_memset(ctx, None, C.c_void_p(clk.device_ptr()), 0, 256)
-    p_clk0, p_clk1 = C.c_void_p(clk.device_ptr()), C.c_void_p(clk.device_ptr() + 128)
+    clk = client.empty(2 * 8192)     # two samples of {shader ticks, 100 MHz ticks} per CU bracketing the timed region
+    lib.mi355_memset(ctx, None, C.c_void_p(clk.device_ptr()), 0, 2 * 8192)
+    p_clk0, p_clk1 = C.c_void_p(clk.device_ptr()), C.c_void_p(clk.device_ptr() + 8192)
     for _ in range(args.warmup):
         step()
     # Plateau warm-up, as the reference's ThroughputBenchmarker does before sampling
@@ -196,13 +196,11 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     import numpy as _np
-    ticks = _np.frombuffer(client.read_one(clk), dtype=_np.uint64).reshape(2, 8, 2).astype(_np.float64)
-    per_xcd = [(ticks[1, x, 0] - ticks[0, x, 0]) / (ticks[1, x, 1] - ticks[0, x, 1]) * 0.1      # 100 MHz reference
-               for x in range(8) if ticks[0, x, 1] > 0 and ticks[1, x, 1] > ticks[0, x, 1]]
-    # every XCD has its own clock domain and single readings scatter by +-10 %: trimmed mean over the 8 XCDs
-    per_xcd.sort()
-    core = per_xcd[1:-1] if len(per_xcd) > 4 else per_xcd
-    eff_clock_ghz = sum(core) / len(core) if core else float("nan")
+    ticks = _np.frombuffer(client.read_one(clk), dtype=_np.uint64).reshape(2, 512, 2).astype(_np.float64)
+    # s_memtime is local to a CU: pair the two samples slot by slot (same CU), median over the CUs seen twice
+    ok = (ticks[0, :, 1] > 0) & (ticks[1, :, 1] > ticks[0, :, 1]) & (ticks[1, :, 0] > ticks[0, :, 0])
+    per_cu = (ticks[1, ok, 0] - ticks[0, ok, 0]) / (ticks[1, ok, 1] - ticks[0, ok, 1]) * 0.1      # 100 MHz reference
+    eff_clock_ghz = float(_np.median(per_cu)) if per_cu.size else float("nan")
     if world > 1:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -197,16 +197,19 @@ __global__ void probe_empty_kernel(float *out)
 
 // {shader-clock ticks, constant 100 MHz ticks} of one CU: two samples bracket a region, and
 // d(shader) / d(constant) * 100 MHz is the clock the chip actually sustained over it.
-// The shader-clock counter is per XCD, so every XCD records its own pair (slot = HW_REG_XCC_ID).
+// The shader-clock counter (s_memtime) is local to a CU: counters of different CUs are not synchronised, so a
+// sample only pairs with a later sample taken ON THE SAME CU.  Every wave files its pair under
+// slot = XCC_ID * 64 + {SE, SH, CU} bits of HW_ID (512 slots of two uint64).
 __global__ void __launch_bounds__(64) probe_clock_kernel(uint64_t *__restrict__ out)
 {
     if (threadIdx.x == 0) {
-        uint32_t xcc;
+        uint32_t xcc, hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        xcc &= 7u;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        const uint32_t slot = (xcc & 7u) * 64u + ((hw >> 8) & 63u);      // HW_ID[13:8] = cu_id, sh_id, se_id
         const uint64_t t = __builtin_amdgcn_s_memtime(), r = __builtin_amdgcn_s_memrealtime();
-        out[2 * xcc] = t;
-        out[2 * xcc + 1] = r;
+        out[2 * slot] = t;
+        out[2 * slot + 1] = r;
     }
 }
 
@@ -265,7 +268,8 @@ MI355_API int32_t mi355_probe_clock(mi355_ctx *ctx, mi355_stream stream, uint64_
 {
     MI355_REQUIRE_CTX(ctx);
     if (!dev_out) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_probe_clock: output pointer is NULL");
-    hipLaunchKernelGGL(probe_clock_kernel, dim3(4 * ctx->props.num_xcd), dim3(64), 0, stream_of(ctx, stream), dev_out);
+    // enough single-wave workgroups that (nearly) every CU takes one
+    hipLaunchKernelGGL(probe_clock_kernel, dim3(16 * ctx->props.num_streaming_multiprocessors), dim3(64), 0, stream_of(ctx, stream), dev_out);
     check_launch(ctx, "mi355_probe_clock");
     return MI355_OK;
 }

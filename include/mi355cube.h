@@ -355,10 +355,12 @@ int32_t mi355_probe_launch_overhead(mi355_ctx *ctx, mi355_stream stream, uint32_
  * down to its power budget; bench.py reports it beside the spec peak (not a reference probe). */
 int32_t mi355_probe_mfma_data(mi355_ctx *ctx, mi355_stream stream, int32_t mode, uint32_t iters,
                               void *sink, uint64_t *out_ops);
-/* Samples {shader-clock ticks, constant 100 MHz ticks} of every XCD into dev_out[2*xcd .. 2*xcd+1]
- * (device memory, 16 uint64 for the 8 XCDs of an MI355X; the shader counter is per XCD) on the
- * stream: two samples bracketing a region give the shader clock each XCD sustained over it
- * (timing_method Device, crates/cubecl-hip/src/runtime.rs:198 analogue). */
+/* Samples {shader-clock ticks (s_memtime), constant 100 MHz ticks (s_memrealtime)} per CU into
+ * dev_out (device memory, MI355_CLOCK_PROBE_BYTES, zero it first): slot = XCC_ID * 64 + HW_ID[13:8], two
+ * uint64 per slot.  The shader counter is local to a CU, so two samples bracketing a region give the clock
+ * a CU sustained over it only when paired slot by slot (timing_method Device,
+ * crates/cubecl-hip/src/runtime.rs:198 analogue). */
+#define MI355_CLOCK_PROBE_BYTES 8192
 int32_t mi355_probe_clock(mi355_ctx *ctx, mi355_stream stream, uint64_t *dev_out);
 
 /* =================================== Collectives (RCCL over xGMI) ======================== */
