@@ -322,6 +322,14 @@ def main():
                 gbs = n_local * 4 / med / 1e6
                 res[name] = {"median_ms": round(med, 4), "min_ms": round(best, 4), "GBs_per_gpu": round(gbs, 1),
                              "GBs_total": round(gbs * world, 1), "frac_of_8TBs": round(gbs / PEAK_HBM_GBS, 4)}
+            # the second half of the metric ("reduce GB/s vs roofline"): same object shape as the headline roofline
+            try:
+                tr = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text()).get("reduce_1GiB_sum", {}).get("fetch_bytes")
+            except Exception:
+                tr = None
+            res["roofline"] = {"bound": "hbm", "achieved": res["sum"]["GBs_per_gpu"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": res["sum"]["frac_of_8TBs"], "traffic": tr if world == 1 else None,
+                               "algorithmic_bytes_per_launch": n_local * 4}
             if world > 1:
                 # C4 end to end (cubecl_amd/sharded.py): local fused pass over this rank's slice, then the
                 # exchange step -- RCCL all-reduce of the f32 partial sums (ServerCommunication::all_reduce)
