@@ -247,3 +247,64 @@ def test_rccl_collectives_single_rank_communicator(client):
     assert np.isnan(v) and i == -1
     res = sharded.sharded_sum_argmax(1 << 20, ex, lambda s, c: (local, 0.75, 99))
     assert (res.total, res.max_value, res.max_index) == (np.float32(local), 0.75, 99)
+
+
+def test_streams_events_pinned_async_io_and_misc_entry_points(client, oracle):
+    """Entry points the other tests do not reach: user streams + cross-stream fences (MultiStream / Fence analogue,
+    crates/cubecl-hip/src/compute/stream.rs:83-179, fence.rs), pinned staging + async read, d2d copy, module unload,
+    error_count, the reference probes, and the argument checks of send / recv."""
+    import ctypes as C
+    lib, ctx = client.lib, client.ctx
+    chk = client._s.check
+    s1, s2 = C.c_void_p(), C.c_void_p()
+    chk(lib.mi355_stream_create(ctx, C.byref(s1))); chk(lib.mi355_stream_create(ctx, C.byref(s2)))
+    d, c = C.c_void_p(), C.c_void_p()
+    chk(lib.mi355_default_stream(ctx, C.byref(d))); chk(lib.mi355_comm_stream(ctx, C.byref(c)))
+    assert d.value and c.value and d.value != c.value and s1.value not in (d.value, c.value)
+    n = 1 << 22
+    x = oracle.fill_uniform(n, 41, 0.0, 1.0)
+    src = client.create_from_slice(x)
+    dst = client.empty(n * 4)
+    out = client.empty(64)
+    ws = client.empty(1 << 17)
+    ev = C.c_void_p(); chk(lib.mi355_event_create(ctx, C.byref(ev)))
+    # stream 1 copies, stream 2 reduces the copy after waiting on stream 1's event
+    chk(lib.mi355_copy_d2d(ctx, s1, C.c_void_p(dst.device_ptr()), C.c_void_p(src.device_ptr()), n * 4))
+    chk(lib.mi355_event_record(ctx, ev, s1))
+    chk(lib.mi355_stream_wait_event(ctx, s2, ev))
+    chk(lib.mi355_reduce_sum_f32(ctx, s2, C.c_void_p(dst.device_ptr()), n, C.c_void_p(out.device_ptr()), C.c_void_p(ws.device_ptr()), ws.size))
+    # the same reduction concurrently on stream 1 (its own arrival ticket): both must be right
+    ws2, out2 = client.empty(1 << 17), client.empty(64)
+    chk(lib.mi355_reduce_sum_f32(ctx, s1, C.c_void_p(dst.device_ptr()), n, C.c_void_p(out2.device_ptr()), C.c_void_p(ws2.device_ptr()), ws2.size))
+    host = C.c_void_p(); chk(lib.mi355_pinned_alloc(ctx, 64, C.byref(host)))
+    chk(lib.mi355_read_async(ctx, s2, host, C.c_void_p(out.device_ptr()), 4))
+    chk(lib.mi355_sync(ctx, s2)); chk(lib.mi355_sync(ctx, s1))
+    got = C.cast(host, C.POINTER(C.c_float))[0]
+    exact = oracle.sum_f64(x)
+    assert abs(got - exact) <= 1e-5 * exact
+    assert abs(float(client.read_one(out2).view(np.float32)[0]) - exact) <= 1e-5 * exact
+    assert np.array_equal(client.read_one(dst).view(np.float32), x)
+    chk(lib.mi355_pinned_free(ctx, host))
+    chk(lib.mi355_event_destroy(ctx, ev))
+    chk(lib.mi355_stream_destroy(ctx, s1)); chk(lib.mi355_stream_destroy(ctx, s2))
+    cnt = C.c_int32(-1); chk(lib.mi355_error_count(ctx, C.byref(cnt)))
+    assert cnt.value == 0
+    # module load / unload of the externally built test code object
+    image = (Path(__file__).parent / "kernels" / "abi_probe.hsaco").read_bytes()
+    mod = C.c_void_p(); chk(lib.mi355_module_load(ctx, image, len(image), C.byref(mod)))
+    chk(lib.mi355_module_unload(ctx, mod))
+    # the reference's two probes run (their bands are checked in bench.py / the other probe test)
+    sink = client.empty(256)
+    chk(lib.mi355_probe_memory_read(ctx, None, C.c_void_p(dst.device_ptr()), n * 4, 1, C.c_void_p(sink.device_ptr())))
+    ops_ = C.c_uint64()
+    chk(lib.mi355_probe_mfma(ctx, None, N.DTYPE_BF16, 100, C.c_void_p(sink.device_ptr()), C.byref(ops_)))
+    assert ops_.value == 256 * 2 * 4 * 100 * 4 * 2 * 32 * 32 * 16
+    client.sync()
+    # send / recv: a world_size-1 communicator has no valid peer -> argument errors, never a hang
+    from cubecl_amd import DeviceId
+    ids = [DeviceId(0, 0)]
+    client.comm_init(ids, client.comm_unique_id(), rank=0)
+    comm = client._s.comms[tuple(ids)]
+    assert lib.mi355_send(ctx, comm, None, C.c_void_p(dst.device_ptr()), 4, N.DTYPE_F32, 0) == N.E_INVALID_ARGUMENT
+    assert lib.mi355_recv(ctx, comm, None, C.c_void_p(dst.device_ptr()), 4, N.DTYPE_F32, 1) == N.E_INVALID_ARGUMENT
+    assert lib.mi355_send(ctx, None, None, C.c_void_p(dst.device_ptr()), 4, N.DTYPE_F32, 0) == N.E_INVALID_ARGUMENT
