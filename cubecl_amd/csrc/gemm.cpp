@@ -32,7 +32,7 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
     if (d.k == 0) return MI355_GEMM_ALGO_GENERIC;  // writes zeros
     if (d.dtype_ab == MI355_DTYPE_F32) {
         // 256x256 tiles (one wave per SIMD) when they give (nearly) every CU a tile; else 128x128
-        if (gemm_lp256w4_supports(d, a, b, c) && (d.m / 256) * (d.n / 256) * d.batch >= 192) return MI355_GEMM_ALGO_LP_256W4;
+        if (gemm_lp256w4_supports(d, a, b, c) && ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch >= 192) return MI355_GEMM_ALGO_LP_256W4;
         if (gemm_f32_mfma_supports(d, a, b, c)) return MI355_GEMM_ALGO_F32_MFMA;
         return MI355_GEMM_ALGO_GENERIC;
     }

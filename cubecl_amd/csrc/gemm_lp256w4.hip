@@ -38,8 +38,10 @@
 //   second copy of the body without DMA and with vmcnt(0) at the hand-over.
 //
 // Restrictions (the dispatcher falls back to gemm_lp256.hip / gemm_lp128.hip otherwise):
-//   M % 256 == 0, N % 256 == 0, K % 64 (16-bit) / 32 (f32) == 0, A row-major [M][K], B stored [N][K]
-//   (trans_b = 1; f32 also takes row-major [K][N]), C rows 16-byte aligned.
+//   K % 64 (16-bit) / 32 (f32) == 0, A row-major [M][K], B stored [N][K] (trans_b = 1; f32 also takes row-major
+//   [K][N] with N % 4 == 0), operand and C rows 16-byte aligned.  M and N are arbitrary: edge tiles clamp their
+//   loads to the last valid row and skip the stores outside the matrix.
+#include <algorithm>
 #include <type_traits>
 
 #include "gemm_common.hpp"
@@ -170,21 +172,24 @@ gemm_lp256w4_kernel(gemm_args g)
     // Addresses are split into a wave-uniform 64-bit base (kernel arguments, tile, wave: SGPRs, advanced with
     // scalar adds) and a 32-bit per-lane byte offset that never changes, so that each DMA is
     // `global_load_lds_dwordx4 v_off, s[base:base+1]` with no 64-bit vector add per piece.
-    const char *ubase_a = A + (m0 + wave * 64) * g.lda * ESZ;           // uniform: first row of this wave's pieces
-    const char *ubase_b = B + (n0 + wave * 64) * g.ldb * ESZ;
+    // Ragged edges: rows past M (N) are clamped to the last valid row, so edge tiles read valid memory and compute
+    // garbage in accumulator rows/columns the epilogue never stores.
+    const char *ubase_a = A + m0 * g.lda * ESZ;                           // uniform: first row of the tile
+    const char *ubase_b = B + n0 * g.ldb * ESZ;
     uint32_t voff_a[8], voff_b[8];                                        // piece j of this wave: rows j*8 + lane/8
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int r = j * 8 + sub;
-        const int q = c8 ^ (((wave * 64 + r) >> 1) & 7);
-        voff_a[j] = (uint32_t)(r * g.lda * ESZ + q * 16);
-        voff_b[j] = (uint32_t)(r * g.ldb * ESZ + q * 16);
+        const int r = wave * 64 + j * 8 + sub;                            // tile row of this lane's 16 bytes
+        const int q = c8 ^ ((r >> 1) & 7);
+        voff_a[j] = (uint32_t)(min((int64_t)r, g.m - 1 - m0) * g.lda * ESZ + q * 16);
+        voff_b[j] = (uint32_t)(min((int64_t)r, g.n - 1 - n0) * g.ldb * ESZ + q * 16);
     }
     // BNN: piece j of this wave is k-row wave*8 + j of the K-tile, 256 n-values = 64 lanes x 16 B
     const char *ubase_bnn = B + (int64_t)(wave * 8) * g.ldb * ESZ + n0 * ESZ;
     uint32_t voff_bnn[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) voff_bnn[j] = (uint32_t)(j * g.ldb * ESZ + lane * 16);
+    for (int j = 0; j < 8; ++j)                                           // columns past N re-read the last 4 valid ones
+        voff_bnn[j] = (uint32_t)(j * g.ldb * ESZ + min((int64_t)lane * 4, g.n - 4 - n0) * ESZ);
     const int dst_piece = wave * 8 * 1024;                            // + j*1024 within the slot
 
     // ---- fragment read offsets: row*128 + ((2s+h) ^ f) * 16, f = (row>>1)&7 = (l31>>1)&7 for every tile row
@@ -376,6 +381,12 @@ gemm_lp256w4_kernel(gemm_args g)
         const char *rd = stage + (lane / LPR) * RS + (lane % LPR) * 16;
         char *crow = C + (cbase + (m0 + wm * 128 + lane / LPR) * g.ldc + n0 + wn * 128) * CSZ + (lane % LPR) * 16;
         const int64_t cstep = (int64_t)RPI * g.ldc * CSZ;
+        // edge tiles: rows >= M and columns >= N are not stored (a 16-byte piece straddling N is written element-wise)
+        constexpr int EPP = 16 / CSZ;                                     // elements per 16-byte piece
+        const int64_t row0 = m0 + wm * 128 + lane / LPR;                  // + i*32 + it*RPI
+        const int64_t col0 = n0 + wn * 128 + (lane % LPR) * EPP;
+        const int ncols = (int)max((int64_t)0, min((int64_t)EPP, g.n - col0));   // valid elements of my piece
+        const bool interior = (m0 + BM <= g.m) && (n0 + BN <= g.n);       // wave-uniform fast path
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -401,6 +412,18 @@ gemm_lp256w4_kernel(gemm_args g)
 #pragma unroll
             for (int it = 0; it < 32 / RPI; ++it) {
                 const u32x4 v = *reinterpret_cast<const u32x4 *>(rd + it * RPI * RS);
+                if (!interior) {
+                    if (row0 + i * 32 + it * RPI >= g.m || ncols <= 0) continue;
+                    if (ncols < EPP) {
+#pragma unroll
+                        for (int e = 0; e < EPP; ++e) {                    // static indices only (guide rule 20)
+                            if (e >= ncols) break;
+                            if constexpr (CSZ == 4) reinterpret_cast<uint32_t *>(cdst + it * cstep)[e] = v[e];
+                            else reinterpret_cast<uint16_t *>(cdst + it * cstep)[e] = (uint16_t)(v[e >> 1] >> ((e & 1) * 16));
+                        }
+                        continue;
+                    }
+                }
 #if W4_NT_C
                 __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(cdst + it * cstep));
 #else
@@ -449,13 +472,15 @@ bool gemm_lp256w4_supports(const mi355_gemm_desc &d, const void *a, const void *
     if (d.k < BK || d.k % BK != 0) return false;
     const int64_t csz = d.dtype_c == MI355_DTYPE_F32 ? 4 : 2;      // the epilogue writes C in 16-byte pieces
     if (((d.ldc * csz) & 15) || ((d.stride_c * csz) & 15) || (reinterpret_cast<uintptr_t>(c) & 15u)) return false;
-    if (d.m < BM || d.m % BM != 0 || d.n < BN || d.n % BN != 0) return false;
+    if (d.m < 1 || d.n < 1) return false;
+    if (!d.trans_b && (d.n < 4 || (d.n & 3))) return false;              // row-major B is fetched 4 columns at a time
     const int64_t amask = 16 / esz - 1;                               // operand rows must be 16-byte aligned
     if ((d.lda & amask) || (d.ldb & amask) || (d.stride_a & amask) || (d.stride_b & amask)) return false;
     if ((reinterpret_cast<uintptr_t>(a) & 15u) || (reinterpret_cast<uintptr_t>(b) & 15u)) return false;
     if (d.batch > 65535) return false;
-    const int64_t tiles = (d.m / BM) * (d.n / BN);
+    const int64_t tiles = ((d.m + BM - 1) / BM) * ((d.n + BN - 1) / BN);
     if (tiles > 0x7FFFFFFF) return false;
+    if ((int64_t)BM * std::max(d.lda, d.ldb) * esz >= (1ll << 32)) return false;   // per-lane DMA offsets are 32-bit
     return true;
 }
 
@@ -469,8 +494,8 @@ int32_t launch_gemm_lp256w4(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc
     g.m = d.m; g.n = d.n; g.k = d.k;
     g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc;
     g.stride_a = d.stride_a; g.stride_b = d.stride_b; g.stride_c = d.stride_c;
-    g.tiles_m = (uint32_t)(d.m / BM);
-    g.tiles_n = (uint32_t)(d.n / BN);
+    g.tiles_m = (uint32_t)((d.m + BM - 1) / BM);
+    g.tiles_n = (uint32_t)((d.n + BN - 1) / BN);
     g.group_m = W4_GROUP_M;
     const uint32_t batch = (uint32_t)d.batch;
     if (d.dtype_ab == MI355_DTYPE_F32) {

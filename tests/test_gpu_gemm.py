@@ -295,10 +295,33 @@ def test_lp256w4_identity_batch_and_fallback(client, oracle):
     ops.matmul(client, TensorHandle.new(ta.handle, (m, k), (k, 1), ElemType.BF16),
                TensorHandle.new(tb.handle, (k, n), (1, k), ElemType.BF16), c, algo=ALGOS["lp256w4"])
     assert np.array_equal(c.to_numpy(client), bmat)
-    # ragged shapes are refused by this kernel (the dispatcher routes them to lp256 / lp128)
+    # K must be a multiple of the K-tile
     with pytest.raises(ServerError) as e:
-        run_case(client, oracle, 300, 256, 64, ElemType.BF16, ElemType.F32, True, ALGOS["lp256w4"])
+        run_case(client, oracle, 256, 256, 96, ElemType.BF16, ElemType.F32, True, ALGOS["lp256w4"])
     assert e.value.code == N.E_UNSUPPORTED
+
+
+W4_RAGGED = [(300, 260, 128), (1, 256, 64), (257, 255, 320), (255, 513, 192), (700, 40, 256), (8, 8, 64), (513, 1000, 128)]
+
+
+@pytest.mark.parametrize("m,n,k", W4_RAGGED)
+@pytest.mark.parametrize("dtype,out", [(ElemType.BF16, "f32"), (ElemType.BF16, "same"), (ElemType.F16, "same"), (ElemType.F32, "f32")])
+def test_lp256w4_ragged_edges(client, oracle, m, n, k, dtype, out):
+    # edge tiles clamp their loads and skip stores outside the matrix; padded ldc so that untouched padding is checked
+    if out == "same" and n % 8:       # 16-bit C rows must stay 16-byte aligned: pad the leading dimension
+        ldc = (n + 7) // 8 * 8 + 8
+    elif out == "f32" and n % 4:
+        ldc = (n + 3) // 4 * 4 + 4
+    else:
+        ldc = n + (8 if out == "same" else 4)
+    run_case(client, oracle, m, n, k if dtype != ElemType.F32 else k // 2, dtype, ElemType.F32 if out == "f32" else dtype, True,
+             ALGOS["lp256w4"], ldc=ldc)
+
+
+def test_lp256w4_ragged_row_major_b_and_batch(client, oracle):
+    run_case(client, oracle, 300, 260, 64, ElemType.F32, ElemType.F32, False, ALGOS["lp256w4"])
+    run_case(client, oracle, 513, 1000, 96, ElemType.F32, ElemType.F32, False, ALGOS["lp256w4"], batch=2, ldb=1004, ldc=1000)
+    run_case(client, oracle, 257, 255, 128, ElemType.BF16, ElemType.BF16, True, ALGOS["lp256w4"], batch=3, ldc=256)
 
 
 # ---- the persistent form: one workgroup per CU walks several tiles with a continuous K-tile stream ----------------
@@ -402,7 +425,9 @@ def test_auto_selection_and_errors(client):
     d.trans_b, d.ldb = 0, 4096
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
     d.m = 4096 + 64
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_F32_MFMA
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    d.k = 4096 + 16                                                    # K not a multiple of the 32-wide f32 K-tile
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_GENERIC
     d = N.GemmDesc(m=2048, n=2048, k=2048, batch=1, lda=2048, ldb=2048, ldc=2048, dtype_ab=N.DTYPE_BF16,
                    dtype_c=N.DTYPE_BF16, trans_b=1)
     assert ops.gemm_select(client, d) in (N.GEMM_ALGO_LP_128, N.GEMM_ALGO_LP_256, N.GEMM_ALGO_LP_256W4)
@@ -411,6 +436,8 @@ def test_auto_selection_and_errors(client):
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
     d = N.GemmDesc(m=8192 + 8, n=8192, k=8192, batch=1, lda=8192, ldb=8192, ldc=8192, dtype_ab=N.DTYPE_BF16,
                    dtype_c=N.DTYPE_BF16, trans_b=1)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4          # ragged M / N stay on the fast kernel
+    d.ldc = 8192 + 3                                                   # C rows not 16-byte aligned -> 8-wave kernel
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256
     d = N.GemmDesc(m=100, n=100, k=7, batch=1, lda=7, ldb=7, ldc=100, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_F32, trans_b=1)
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_GENERIC
