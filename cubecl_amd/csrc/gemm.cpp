@@ -55,9 +55,57 @@ MI355_API int32_t mi355_gemm_select(mi355_ctx *ctx, const mi355_gemm_desc *desc,
     if (!ctx || !desc || !out_algo) return MI355_E_INVALID_ARGUMENT;
     // alignment-dependent choices are evaluated for 16-byte aligned operands
     static const char aligned_dummy __attribute__((aligned(16))) = 0;
-    *out_algo = select(*desc, &aligned_dummy, &aligned_dummy, &aligned_dummy);
+    const mi355_gemm_desc &d = *desc;
+    int32_t algo = select(d, &aligned_dummy, &aligned_dummy, &aligned_dummy);
+    const bool fix_a = d.trans_a != 0, fix_b = !d.trans_b && d.dtype_ab != MI355_DTYPE_F32;
+    if (algo == MI355_GEMM_ALGO_GENERIC && (fix_a || fix_b) && d.k > 0 && d.m * d.n * d.k >= (int64_t)1 << 21) {
+        // what mi355_gemm does: re-lay the operand(s) out K-contiguous, then the MFMA kernel (relayout_for_mfma)
+        mi355_gemm_desc nd = d;
+        const int64_t kpad = (d.k + 7) / 8 * 8;
+        if (fix_a) { nd.trans_a = 0; nd.lda = kpad; nd.stride_a = d.stride_a == 0 ? 0 : d.m * kpad; }
+        if (fix_b) { nd.trans_b = 1; nd.ldb = kpad; nd.stride_b = d.stride_b == 0 ? 0 : d.n * kpad; }
+        algo = select(nd, &aligned_dummy, &aligned_dummy, &aligned_dummy);
+    }
+    *out_algo = algo;
     return MI355_OK;
 }
+
+namespace {
+
+// When AUTO would land on the generic scalar kernel only because of the operand LAYOUT (transposed A, 16-bit
+// row-major B), re-lay the operand out into K-contiguous scratch first -- what the reference's launchers do with
+// into_contiguous after matrix_batch_layout -- and run the MFMA kernel on it.  Returns MI355_OK and fills `nd`,
+// `na`, `nb` when it did; MI355_E_UNSUPPORTED when the layout was not the obstacle (the caller proceeds as before).
+int32_t relayout_for_mfma(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c,
+                          mi355_gemm_desc &nd, const void *&na, const void *&nb)
+{
+    const int esz = d.dtype_ab == MI355_DTYPE_F32 ? 4 : 2;
+    const bool fix_a = d.trans_a != 0;
+    const bool fix_b = !d.trans_b && d.dtype_ab != MI355_DTYPE_F32;       // f32 row-major B has a native kernel
+    if (!fix_a && !fix_b) return MI355_E_UNSUPPORTED;
+    if (d.k == 0 || d.m * d.n * d.k < (int64_t)1 << 21) return MI355_E_UNSUPPORTED;   // tiny: not worth two launches
+    nd = d; na = a; nb = b;
+    const int64_t kpad = (d.k + 7) / 8 * 8;                                // 16-byte aligned rows in the scratch
+    if (fix_a) {
+        const int64_t nba = d.stride_a == 0 ? 1 : d.batch;
+        void *p = nullptr;
+        if (scratch_get(ctx, s, SCRATCH_RELAYOUT_A, (size_t)(nba * d.m * kpad * esz), &p) != MI355_OK) return MI355_E_UNSUPPORTED;
+        launch_transpose(s, a, p, d.k, d.m, d.lda, kpad, nba, d.stride_a, d.m * kpad, esz);    // [K][M] -> [M][K]
+        na = p; nd.trans_a = 0; nd.lda = kpad; nd.stride_a = d.stride_a == 0 ? 0 : d.m * kpad;
+    }
+    if (fix_b) {
+        const int64_t nbb = d.stride_b == 0 ? 1 : d.batch;
+        void *p = nullptr;
+        if (scratch_get(ctx, s, SCRATCH_RELAYOUT_B, (size_t)(nbb * d.n * kpad * esz), &p) != MI355_OK) return MI355_E_UNSUPPORTED;
+        launch_transpose(s, b, p, d.k, d.n, d.ldb, kpad, nbb, d.stride_b, d.n * kpad, esz);    // [K][N] -> [N][K]
+        nb = p; nd.trans_b = 1; nd.ldb = kpad; nd.stride_b = d.stride_b == 0 ? 0 : d.n * kpad;
+    }
+    check_launch(ctx, "mi355_gemm(operand re-layout)");
+    if (select(nd, na, nb, c) == MI355_GEMM_ALGO_GENERIC) return MI355_E_UNSUPPORTED;   // e.g. ragged K: nothing gained
+    return MI355_OK;
+}
+
+}  // namespace
 
 MI355_API int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_gemm_desc *desc, const void *a,
                              const void *b, void *c)
@@ -66,8 +114,16 @@ MI355_API int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_ge
     int32_t rc = validate(ctx, desc, a, b, c);
     if (rc != -1) return rc;
     hipStream_t s = stream_of(ctx, stream);
-    const mi355_gemm_desc &d = *desc;
+    mi355_gemm_desc d = *desc;
     int32_t algo = d.algo == MI355_GEMM_ALGO_AUTO ? select(d, a, b, c) : d.algo;
+    if (d.algo == MI355_GEMM_ALGO_AUTO && algo == MI355_GEMM_ALGO_GENERIC) {
+        mi355_gemm_desc nd;
+        const void *na, *nb;
+        if (relayout_for_mfma(ctx, s, d, a, b, c, nd, na, nb) == MI355_OK) {
+            d = nd; a = na; b = nb;
+            algo = select(d, a, b, c);
+        }
+    }
     switch (algo) {
     case MI355_GEMM_ALGO_GENERIC: return launch_gemm_generic(ctx, s, d, a, b, c);
     case MI355_GEMM_ALGO_F32_MFMA: return launch_gemm_f32_mfma(ctx, s, d, a, b, c);

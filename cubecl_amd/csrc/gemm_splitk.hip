@@ -64,23 +64,10 @@ namespace mi355 {
 
 int32_t splitk_scratch(mi355_ctx *ctx, hipStream_t s, size_t bytes, float **out)
 {
-    auto &slot = ctx->splitk_scratch[s];
-    if (slot.second < bytes) {
-        // growing is rare (first call per shape class); the old slab may still be in use by queued work
-        if (slot.first) {
-            if (hipStreamSynchronize(s) != hipSuccess) return MI355_E_EXECUTION;
-            hipFree(slot.first);
-            slot = {nullptr, 0};
-        }
-        void *p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            return MI355_E_OUT_OF_MEMORY;   // the caller falls back to the unsplit kernel
-        }
-        slot = {p, bytes};
-    }
-    *out = static_cast<float *>(slot.first);
-    return MI355_OK;
+    void *p = nullptr;
+    const int32_t rc = scratch_get(ctx, s, SCRATCH_SPLITK, bytes, &p);   // a failure makes the caller fall back to the unsplit kernel
+    *out = static_cast<float *>(p);
+    return rc;
 }
 
 void launch_splitk_fold(hipStream_t s, const float *slabs, uint32_t splits, int64_t slab_stride, int64_t batch, int64_t m,

@@ -229,7 +229,7 @@ MI355_API int32_t mi355_ctx_destroy(mi355_ctx *ctx)
     if (ctx->fence_a) hipEventDestroy(ctx->fence_a);
     if (ctx->fence_b) hipEventDestroy(ctx->fence_b);
     if (ctx->ticket_buf) hipFree(ctx->ticket_buf);
-    for (auto &kv : ctx->splitk_scratch) hipFree(kv.second.first);
+    for (auto &kv : ctx->scratch) hipFree(kv.second.first);
     if (ctx->compute_stream) hipStreamDestroy(ctx->compute_stream);
     if (ctx->comm_stream) hipStreamDestroy(ctx->comm_stream);
     delete ctx;

@@ -261,7 +261,12 @@ int32_t mi355_cast(mi355_ctx *ctx, mi355_stream stream, const void *src, int32_t
  * Batch strides are in elements; 0 broadcasts an operand
  * (crates/cubecl-std/src/tensor/matrix_batch_layout.rs:21-79).
  * dtype_ab: F32 (MFMA f32, exact-f32 products), BF16 or F16 (MFMA, f32 accumulate).
- * dtype_c: F32, or the same 16-bit type as the inputs (RNE on store). */
+ * dtype_c: F32, or the same 16-bit type as the inputs (RNE on store).
+ * Layouts the MFMA kernels do not stage directly (trans_a == 1; 16-bit row-major B) are re-laid out
+ * K-contiguous into library-owned per-stream scratch first, as the reference's launchers do with
+ * into_contiguous; shapes no MFMA kernel takes (K not a multiple of the K-tile, unaligned rows) run
+ * on the bounds-checked generic kernel.  The library owns: that scratch, the split-K slabs of skinny
+ * shapes, and the reductions' arrival tickets -- never caller memory. */
 typedef struct {
     int64_t m, n, k, batch;
     int64_t lda, ldb, ldc;

@@ -404,6 +404,39 @@ def test_race_screen_bitwise_repeatability(client, oracle, algo):
         assert np.array_equal(c.to_numpy(client), first)
 
 
+# ---- layouts the MFMA kernels do not stage directly: re-laid out K-contiguous into library scratch first ------------
+@pytest.mark.parametrize("m,n,k", [(512, 512, 512), (300, 260, 128), (256, 1024, 320), (1000, 513, 192)])
+@pytest.mark.parametrize("dtype,out", [(ElemType.BF16, "f32"), (ElemType.BF16, "same"), (ElemType.F16, "f32")])
+def test_row_major_b_16bit_goes_through_relayout(client, oracle, m, n, k, dtype, out):
+    ldb = (n + 7) // 8 * 8
+    d = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=ldb, ldc=n, dtype_ab=int(dtype), dtype_c=N.DTYPE_F32, trans_b=0)
+    assert ops.gemm_select(client, d) != N.GEMM_ALGO_GENERIC            # an MFMA kernel after the transpose
+    ldc = n if out == "f32" and n % 4 == 0 else (n + 7) // 8 * 8 + 8
+    run_case(client, oracle, m, n, k, dtype, ElemType.F32 if out == "f32" else dtype, False, ALGOS["auto"], ldb=ldb, ldc=ldc)
+
+
+def test_relayout_batched_broadcast_and_transposed_a(client, oracle):
+    run_case(client, oracle, 256, 512, 256, ElemType.BF16, ElemType.F32, False, ALGOS["auto"], batch=3, ldb=512)
+    run_case(client, oracle, 256, 512, 256, ElemType.BF16, ElemType.BF16, False, ALGOS["auto"], batch=3, bcast_b=True, ldb=520)
+    # transposed A (stored [K][M]) x row-major B, f32 and bf16: both operands are re-laid out
+    for dtype in (ElemType.F32, ElemType.BF16):
+        m, n, k = 384, 512, 256
+        a = oracle.fill_uniform(m * k, 61, -1.0, 1.0).reshape(m, k)
+        b = oracle.fill_uniform(k * n, 62, -1.0, 1.0).reshape(k, n)
+        ta, a_val = _to_dev(client, oracle, np.ascontiguousarray(a.T), dtype)        # device holds A^T: [K][M]
+        tb, b_val = _to_dev(client, oracle, b, dtype)
+        lhs = TensorHandle.new(ta.handle, (m, k), (1, m), dtype)                      # logical [M][K], column-major storage
+        rhs = TensorHandle.new(tb.handle, (k, n), (n, 1), dtype)
+        c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 4), ElemType.F32)
+        ops.matmul(client, lhs, rhs, c)
+        A = a_val.reshape(k, m).T.astype(np.float64)
+        Bm = b_val.reshape(k, n).astype(np.float64)
+        ref, bound = A @ Bm, np.abs(A) @ np.abs(Bm)
+        assert np.all(np.abs(c.to_numpy(client) - ref) <= REL * bound)
+    # below the size threshold the generic kernel still answers (and agrees)
+    run_case(client, oracle, 40, 24, 16, ElemType.BF16, ElemType.F32, False, ALGOS["auto"])
+
+
 def test_padded_leading_dimensions_and_untouched_padding(client, oracle):
     run_case(client, oracle, 256, 128, 128, ElemType.F32, ElemType.F32, True, ALGOS["auto"], lda=136, ldb=132, ldc=140)
     run_case(client, oracle, 256, 128, 128, ElemType.BF16, ElemType.F32, True, ALGOS["auto"], lda=136, ldb=144, ldc=132)

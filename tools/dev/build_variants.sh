@@ -7,7 +7,7 @@ NAME=$1; FLAGS=$2; shift 2
 FILES=${@:-gemm_lp256.hip}
 mkdir -p variants/obj_$NAME
 OBJS=""
-for f in runtime.cpp comm.cpp gemm.cpp fill.hip reduce.hip probes.hip gemm_generic.hip gemm_f32.hip gemm_lp128.hip gemm_lp256.hip gemm_lp256w4.hip gemm_lp256p.hip gemm_splitk.hip; do
+for f in runtime.cpp comm.cpp gemm.cpp fill.hip reduce.hip probes.hip gemm_generic.hip gemm_f32.hip gemm_lp128.hip gemm_lp256.hip gemm_lp256w4.hip gemm_lp256p.hip gemm_splitk.hip gemm_relayout.hip; do
   base=${f%.*}
   if echo " $FILES " | grep -q " $f "; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-value --offload-arch=gfx950 $FLAGS -x hip -c $f -o variants/obj_$NAME/$base.o
