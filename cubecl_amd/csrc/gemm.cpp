@@ -50,58 +50,72 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
 
 }  // namespace
 
-MI355_API int32_t mi355_gemm_select(mi355_ctx *ctx, const mi355_gemm_desc *desc, int32_t *out_algo)
-{
-    if (!ctx || !desc || !out_algo) return MI355_E_INVALID_ARGUMENT;
-    // alignment-dependent choices are evaluated for 16-byte aligned operands
-    static const char aligned_dummy __attribute__((aligned(16))) = 0;
-    const mi355_gemm_desc &d = *desc;
-    int32_t algo = select(d, &aligned_dummy, &aligned_dummy, &aligned_dummy);
-    const bool fix_a = d.trans_a != 0, fix_b = !d.trans_b && d.dtype_ab != MI355_DTYPE_F32;
-    if (algo == MI355_GEMM_ALGO_GENERIC && (fix_a || fix_b) && d.k > 0 && d.m * d.n * d.k >= (int64_t)1 << 21) {
-        // what mi355_gemm does: re-lay the operand(s) out K-contiguous, then the MFMA kernel (relayout_for_mfma)
-        mi355_gemm_desc nd = d;
-        const int64_t kpad = (d.k + 7) / 8 * 8;
-        if (fix_a) { nd.trans_a = 0; nd.lda = kpad; nd.stride_a = d.stride_a == 0 ? 0 : d.m * kpad; }
-        if (fix_b) { nd.trans_b = 1; nd.ldb = kpad; nd.stride_b = d.stride_b == 0 ? 0 : d.n * kpad; }
-        algo = select(nd, &aligned_dummy, &aligned_dummy, &aligned_dummy);
-    }
-    *out_algo = algo;
-    return MI355_OK;
-}
-
 namespace {
 
-// When AUTO would land on the generic scalar kernel only because of the operand LAYOUT (transposed A, 16-bit
-// row-major B), re-lay the operand out into K-contiguous scratch first -- what the reference's launchers do with
-// into_contiguous after matrix_batch_layout -- and run the MFMA kernel on it.  Returns MI355_OK and fills `nd`,
-// `na`, `nb` when it did; MI355_E_UNSUPPORTED when the layout was not the obstacle (the caller proceeds as before).
+// When AUTO would land on the generic scalar kernel because of an operand's LAYOUT (transposed A, 16-bit row-major
+// B), its K extent (not a multiple of the K-tile) or its alignment (rows / base not 16-byte aligned), the operand is
+// first re-laid out into K-contiguous, zero-padded, aligned library scratch -- what the reference's launchers do
+// with into_contiguous after matrix_batch_layout -- and the MFMA kernel runs on that.  `plan_relayout` is the pure
+// part (also used by mi355_gemm_select); it returns false when nothing would be gained.
+struct relayout_plan {
+    bool a, b;              // which operands get a scratch copy
+    int64_t kpad;           // K rounded up to the K-tile (zero columns add nothing)
+    mi355_gemm_desc nd;     // the descriptor the MFMA kernel sees
+};
+
+bool plan_relayout(const mi355_gemm_desc &d, const void *a, const void *b, const void *c, relayout_plan &p)
+{
+    if (d.k == 0 || d.m * d.n * d.k < (int64_t)1 << 21) return false;           // tiny: not worth extra launches
+    const int64_t esz = d.dtype_ab == MI355_DTYPE_F32 ? 4 : 2;
+    const int64_t ktile = 128 / esz, ve = 16 / esz;
+    p.kpad = (d.k + ktile - 1) / ktile * ktile;
+    const bool ragged_k = p.kpad != d.k;
+    const bool a_misaligned = (d.lda % ve) || (d.stride_a % ve) || (reinterpret_cast<uintptr_t>(a) & 15u);
+    const bool b_misaligned = (d.ldb % ve) || (d.stride_b % ve) || (reinterpret_cast<uintptr_t>(b) & 15u);
+    p.a = d.trans_a != 0 || ragged_k || a_misaligned;
+    p.b = (!d.trans_b && (d.dtype_ab != MI355_DTYPE_F32 || ragged_k || b_misaligned || (d.n & 3))) ||
+          (d.trans_b && (ragged_k || b_misaligned));
+    if (!p.a && !p.b) return false;
+    p.nd = d;
+    p.nd.k = p.kpad;
+    if (p.a) { p.nd.trans_a = 0; p.nd.lda = p.kpad; p.nd.stride_a = d.stride_a == 0 ? 0 : d.m * p.kpad; }
+    if (p.b) { p.nd.trans_b = 1; p.nd.ldb = p.kpad; p.nd.stride_b = d.stride_b == 0 ? 0 : d.n * p.kpad; }
+    static const char aligned_dummy __attribute__((aligned(16))) = 0;
+    return select(p.nd, p.a ? &aligned_dummy : a, p.b ? &aligned_dummy : b, c) != MI355_GEMM_ALGO_GENERIC;
+}
+
 int32_t relayout_for_mfma(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c,
                           mi355_gemm_desc &nd, const void *&na, const void *&nb)
 {
+    relayout_plan p;
+    if (!plan_relayout(d, a, b, c, p)) return MI355_E_UNSUPPORTED;
     const int esz = d.dtype_ab == MI355_DTYPE_F32 ? 4 : 2;
-    const bool fix_a = d.trans_a != 0;
-    const bool fix_b = !d.trans_b && d.dtype_ab != MI355_DTYPE_F32;       // f32 row-major B has a native kernel
-    if (!fix_a && !fix_b) return MI355_E_UNSUPPORTED;
-    if (d.k == 0 || d.m * d.n * d.k < (int64_t)1 << 21) return MI355_E_UNSUPPORTED;   // tiny: not worth two launches
-    nd = d; na = a; nb = b;
-    const int64_t kpad = (d.k + 7) / 8 * 8;                                // 16-byte aligned rows in the scratch
-    if (fix_a) {
+    nd = p.nd; na = a; nb = b;
+    if (p.a) {
         const int64_t nba = d.stride_a == 0 ? 1 : d.batch;
-        void *p = nullptr;
-        if (scratch_get(ctx, s, SCRATCH_RELAYOUT_A, (size_t)(nba * d.m * kpad * esz), &p) != MI355_OK) return MI355_E_UNSUPPORTED;
-        launch_transpose(s, a, p, d.k, d.m, d.lda, kpad, nba, d.stride_a, d.m * kpad, esz);    // [K][M] -> [M][K]
-        na = p; nd.trans_a = 0; nd.lda = kpad; nd.stride_a = d.stride_a == 0 ? 0 : d.m * kpad;
+        void *q = nullptr;
+        if (scratch_get(ctx, s, SCRATCH_RELAYOUT_A, (size_t)(nba * d.m * p.kpad * esz), &q) != MI355_OK) return MI355_E_UNSUPPORTED;
+        if (d.trans_a) {                                                       // [K][M] -> [M][kpad], pad columns zeroed first
+            if (p.kpad != d.k) (void)hipMemsetAsync(q, 0, (size_t)(nba * d.m * p.kpad * esz), s);
+            launch_transpose(s, a, q, d.k, d.m, d.lda, p.kpad, nba, d.stride_a, d.m * p.kpad, esz);
+        } else {
+            launch_pad_copy(s, a, q, d.m, d.k, p.kpad, d.lda, p.kpad, nba, d.stride_a, d.m * p.kpad, esz);
+        }
+        na = q;
     }
-    if (fix_b) {
+    if (p.b) {
         const int64_t nbb = d.stride_b == 0 ? 1 : d.batch;
-        void *p = nullptr;
-        if (scratch_get(ctx, s, SCRATCH_RELAYOUT_B, (size_t)(nbb * d.n * kpad * esz), &p) != MI355_OK) return MI355_E_UNSUPPORTED;
-        launch_transpose(s, b, p, d.k, d.n, d.ldb, kpad, nbb, d.stride_b, d.n * kpad, esz);    // [K][N] -> [N][K]
-        nb = p; nd.trans_b = 1; nd.ldb = kpad; nd.stride_b = d.stride_b == 0 ? 0 : d.n * kpad;
+        void *q = nullptr;
+        if (scratch_get(ctx, s, SCRATCH_RELAYOUT_B, (size_t)(nbb * d.n * p.kpad * esz), &q) != MI355_OK) return MI355_E_UNSUPPORTED;
+        if (!d.trans_b) {                                                      // [K][N] -> [N][kpad]
+            if (p.kpad != d.k) (void)hipMemsetAsync(q, 0, (size_t)(nbb * d.n * p.kpad * esz), s);
+            launch_transpose(s, b, q, d.k, d.n, d.ldb, p.kpad, nbb, d.stride_b, d.n * p.kpad, esz);
+        } else {
+            launch_pad_copy(s, b, q, d.n, d.k, p.kpad, d.ldb, p.kpad, nbb, d.stride_b, d.n * p.kpad, esz);
+        }
+        nb = q;
     }
     check_launch(ctx, "mi355_gemm(operand re-layout)");
-    if (select(nd, na, nb, c) == MI355_GEMM_ALGO_GENERIC) return MI355_E_UNSUPPORTED;   // e.g. ragged K: nothing gained
     return MI355_OK;
 }
 
@@ -133,4 +147,20 @@ MI355_API int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_ge
     case MI355_GEMM_ALGO_LP_256P: return launch_gemm_lp256p(ctx, s, d, a, b, c);
     default: return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_gemm: unknown algo %d", algo);
     }
+}
+
+MI355_API int32_t mi355_gemm_select(mi355_ctx *ctx, const mi355_gemm_desc *desc, int32_t *out_algo)
+{
+    if (!ctx || !desc || !out_algo) return MI355_E_INVALID_ARGUMENT;
+    // alignment-dependent choices are evaluated for 16-byte aligned operands
+    static const char aligned_dummy __attribute__((aligned(16))) = 0;
+    const mi355_gemm_desc &d = *desc;
+    int32_t algo = select(d, &aligned_dummy, &aligned_dummy, &aligned_dummy);
+    if (algo == MI355_GEMM_ALGO_GENERIC) {
+        relayout_plan p;                  // what mi355_gemm does before it settles for the scalar kernel
+        if (plan_relayout(d, &aligned_dummy, &aligned_dummy, &aligned_dummy, p))
+            algo = select(p.nd, &aligned_dummy, &aligned_dummy, &aligned_dummy);
+    }
+    *out_algo = algo;
+    return MI355_OK;
 }

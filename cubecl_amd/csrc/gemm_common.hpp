@@ -91,6 +91,8 @@ enum { SCRATCH_SPLITK = 0, SCRATCH_RELAYOUT_A = 1, SCRATCH_RELAYOUT_B = 2 };
 int32_t scratch_get(mi355_ctx *ctx, hipStream_t s, int kind, size_t bytes, void **out);
 void launch_transpose(hipStream_t s, const void *src, void *dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst,
                       int64_t batch, int64_t stride_src, int64_t stride_dst, int esz);
+void launch_pad_copy(hipStream_t s, const void *src, void *dst, int64_t rows, int64_t cols, int64_t cols_pad, int64_t ld_src,
+                     int64_t ld_dst, int64_t batch, int64_t stride_src, int64_t stride_dst, int esz);
 // split-K plumbing (gemm_splitk.hip): per-stream library-owned f32 scratch + the slab fold kernel
 int32_t splitk_scratch(mi355_ctx *ctx, hipStream_t s, size_t bytes, float **out);
 void launch_splitk_fold(hipStream_t s, const float *slabs, uint32_t splits, int64_t slab_stride, int64_t batch, int64_t m,

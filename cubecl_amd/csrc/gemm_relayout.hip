@@ -66,6 +66,33 @@ transpose_kernel(const T *__restrict__ src, T *__restrict__ dst, int64_t rows, i
     }
 }
 
+// dst[r][0..cols) = src[r][0..cols), dst[r][cols..cols_pad) = 0: gives ragged-K or unaligned operands the
+// K-tile-multiple, 16-byte-aligned rows the MFMA kernels need (zero k-columns add nothing to the products).
+template <typename T>
+__global__ void __launch_bounds__(256)
+pad_copy_kernel(const T *__restrict__ src, T *__restrict__ dst, int64_t rows, int64_t cols, int64_t cols_pad, int64_t ld_src,
+                int64_t ld_dst, int64_t stride_src, int64_t stride_dst, int vec_ok)
+{
+    constexpr int VE = 16 / sizeof(T);
+    typedef T vec __attribute__((ext_vector_type(VE)));
+    const T *s = src + (int64_t)blockIdx.z * stride_src;
+    T *d = dst + (int64_t)blockIdx.z * stride_dst;
+    for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+        const T *sr = s + r * ld_src;
+        T *dr = d + r * ld_dst;
+        const int64_t full = vec_ok ? cols / VE : 0;                   // whole 16-byte pieces of valid data
+        for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < cols_pad / VE; q += (int64_t)gridDim.x * 256) {
+            vec v;
+            if (q < full) v = *reinterpret_cast<const vec *>(sr + q * VE);
+            else {
+#pragma unroll
+                for (int e = 0; e < VE; ++e) v[e] = (q * VE + e < cols) ? sr[q * VE + e] : (T)0;
+            }
+            *reinterpret_cast<vec *>(dr + q * VE) = v;
+        }
+    }
+}
+
 }  // namespace
 
 namespace mi355 {
@@ -90,6 +117,22 @@ int32_t scratch_get(mi355_ctx *ctx, hipStream_t s, int kind, size_t bytes, void 
     }
     *out = slot.first;
     return MI355_OK;
+}
+
+void launch_pad_copy(hipStream_t s, const void *src, void *dst, int64_t rows, int64_t cols, int64_t cols_pad, int64_t ld_src,
+                     int64_t ld_dst, int64_t batch, int64_t stride_src, int64_t stride_dst, int esz)
+{
+    if (rows <= 0 || cols_pad <= 0 || batch <= 0) return;
+    const int64_t ve = 16 / esz;
+    const int vec_ok = (reinterpret_cast<uintptr_t>(src) & 15u) == 0 && (ld_src % ve) == 0 && (stride_src % ve) == 0;
+    const dim3 grid((uint32_t)std::max<int64_t>(1, std::min<int64_t>((cols_pad / ve + 255) / 256, 16)),
+                    (uint32_t)std::min<int64_t>(rows, 4096), (uint32_t)batch);
+    if (esz == 2)
+        hipLaunchKernelGGL(pad_copy_kernel<uint16_t>, grid, dim3(256), 0, s, static_cast<const uint16_t *>(src),
+                           static_cast<uint16_t *>(dst), rows, cols, cols_pad, ld_src, ld_dst, stride_src, stride_dst, vec_ok);
+    else
+        hipLaunchKernelGGL(pad_copy_kernel<uint32_t>, grid, dim3(256), 0, s, static_cast<const uint32_t *>(src),
+                           static_cast<uint32_t *>(dst), rows, cols, cols_pad, ld_src, ld_dst, stride_src, stride_dst, vec_ok);
 }
 
 void launch_transpose(hipStream_t s, const void *src, void *dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst,

@@ -437,6 +437,27 @@ def test_relayout_batched_broadcast_and_transposed_a(client, oracle):
     run_case(client, oracle, 40, 24, 16, ElemType.BF16, ElemType.F32, False, ALGOS["auto"])
 
 
+@pytest.mark.parametrize("m,n,k,dtype,trans_b", [
+    (512, 512, 520, ElemType.BF16, True),      # K not a multiple of the 64-wide K-tile: zero-padded copies of A and B
+    (512, 512, 1000, ElemType.F16, True),
+    (300, 260, 200, ElemType.BF16, False),     # ragged K AND row-major B
+    (512, 512, 100, ElemType.F32, True),       # f32: K-tile is 32
+    (384, 512, 250, ElemType.F32, False),
+    (512, 512, 515, ElemType.BF16, True),      # odd K: rows not even 4-byte multiples
+])
+def test_ragged_k_goes_through_zero_padded_relayout(client, oracle, m, n, k, dtype, trans_b):
+    ldb = k if trans_b else (n + 7) // 8 * 8
+    d = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=ldb, ldc=n, dtype_ab=int(dtype), dtype_c=N.DTYPE_F32, trans_b=int(trans_b))
+    assert ops.gemm_select(client, d) not in (N.GEMM_ALGO_GENERIC,)
+    run_case(client, oracle, m, n, k, dtype, ElemType.F32, trans_b, ALGOS["auto"], ldb=ldb)
+
+
+def test_unaligned_operand_rows_go_through_relayout(client, oracle):
+    # lda / ldb that break the 16-byte row alignment the DMA needs
+    run_case(client, oracle, 512, 512, 256, ElemType.BF16, ElemType.F32, True, ALGOS["auto"], lda=259, ldb=261)
+    run_case(client, oracle, 512, 512, 128, ElemType.F32, ElemType.F32, True, ALGOS["auto"], lda=131, ldb=129, batch=2)
+
+
 def test_padded_leading_dimensions_and_untouched_padding(client, oracle):
     run_case(client, oracle, 256, 128, 128, ElemType.F32, ElemType.F32, True, ALGOS["auto"], lda=136, ldb=132, ldc=140)
     run_case(client, oracle, 256, 128, 128, ElemType.BF16, ElemType.F32, True, ALGOS["auto"], lda=136, ldb=144, ldc=132)
@@ -459,8 +480,8 @@ def test_auto_selection_and_errors(client):
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
     d.m = 4096 + 64
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
-    d.k = 4096 + 16                                                    # K not a multiple of the 32-wide f32 K-tile
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_GENERIC
+    d.k = 4096 + 16                                                    # K not a multiple of the 32-wide f32 K-tile:
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4          # zero-padded scratch copies, still the MFMA kernel
     d = N.GemmDesc(m=2048, n=2048, k=2048, batch=1, lda=2048, ldb=2048, ldc=2048, dtype_ab=N.DTYPE_BF16,
                    dtype_c=N.DTYPE_BF16, trans_b=1)
     assert ops.gemm_select(client, d) in (N.GEMM_ALGO_LP_128, N.GEMM_ALGO_LP_256, N.GEMM_ALGO_LP_256W4)
