@@ -137,6 +137,8 @@ PROTOTYPES = {
     "mi355_sum_argmax_f32": (C.c_int32, [_P, _P, _P, C.c_uint64, _P, _P, _P, _P, C.c_uint64]),
     "mi355_reduce_last_axis_sum_f32": (C.c_int32, [_P, _P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint64]),
     "mi355_reduce_last_axis_argmax_f32": (C.c_int32, [_P, _P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "mi355_reduce_axis_sum_f32": (C.c_int32, [_P, _P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "mi355_reduce_axis_argmax_f32": (C.c_int32, [_P, _P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint64]),
     "mi355_plane_reduce_f32": (C.c_int32, [_P, _P, _P, _P, C.c_uint64, C.c_uint32, C.c_int32]),
     "mi355_probe_memory_read": (C.c_int32, [_P, _P, _P, C.c_uint64, C.c_uint32, _P]),
     "mi355_probe_mfma": (C.c_int32, [_P, _P, C.c_int32, C.c_uint32, _P, _U64P]),

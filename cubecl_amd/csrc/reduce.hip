@@ -376,6 +376,79 @@ reduce_rows(const float *__restrict__ in, float *__restrict__ out_sum, uint32_t 
     }
 }
 
+// ---- reductions over a NON-last axis: in is [outer][reduce][inner] (contiguous), out is [outer][inner] ------------
+// Consecutive lanes own consecutive `inner` positions, so every load of the r-loop is a coalesced row segment;
+// each thread folds `reduce` values sequentially (the book's per-unit loop, v4-gpu.rs:47-54, along a strided axis),
+// split into RSPLIT interleaved partial chains when `reduce` is long and outer*inner is too small to fill the chip;
+// the chains are folded in order through LDS.  Roofline: HBM, 4 bytes per input element read once.
+template <bool ARG, int RSPLIT>
+__global__ void __launch_bounds__(256)
+reduce_mid_axis(const float *__restrict__ in, float *__restrict__ out_sum, uint32_t *__restrict__ out_idx, uint64_t outer,
+                uint64_t red, uint64_t inner)
+{
+    constexpr int IW = 256 / RSPLIT;                       // inner positions per workgroup
+    const uint32_t tid = threadIdx.x, il = tid % IW, rs = tid / IW;
+    const uint64_t blocks_i = (inner + IW - 1) / IW;
+    __shared__ float s_sum[RSPLIT][IW];
+    __shared__ uint32_t s_key[RSPLIT][IW];
+    __shared__ uint32_t s_idx[RSPLIT][IW];
+    for (uint64_t blk = blockIdx.x; blk < outer * blocks_i; blk += gridDim.x) {
+        const uint64_t o = blk / blocks_i, i = (blk % blocks_i) * IW + il;
+        float acc = 0.f;
+        uint32_t key = 0u, idx = 0u;
+        if (i < inner) {
+            const float *p = in + (o * red) * inner + i;
+            for (uint64_t r = rs; r < red; r += RSPLIT) {
+                const float v = p[r * inner];
+                if (!ARG) acc += v;
+                else { const uint32_t k = argmax_key(v); if (k > key) { key = k; idx = (uint32_t)r; } }
+            }
+        }
+        if (RSPLIT == 1) {
+            if (i < inner) { if (!ARG) out_sum[o * inner + i] = acc; else out_idx[o * inner + i] = idx; }
+        } else {
+            if (!ARG) s_sum[rs][il] = acc; else { s_key[rs][il] = key; s_idx[rs][il] = idx; }
+            __syncthreads();
+            if (rs == 0 && i < inner) {
+                if (!ARG) {
+                    float t = s_sum[0][il];
+                    for (int q = 1; q < RSPLIT; ++q) t += s_sum[q][il];
+                    out_sum[o * inner + i] = t;
+                } else {
+                    uint32_t k = s_key[0][il]; uint64_t ix = s_idx[0][il];
+                    for (int q = 1; q < RSPLIT; ++q) arg_combine(k, ix, s_key[q][il], s_idx[q][il]);
+                    out_idx[o * inner + i] = (uint32_t)ix;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <bool ARG>
+int32_t run_mid(mi355_ctx *ctx, mi355_stream stream, const float *in, float *out_sum, uint32_t *out_idx, uint64_t outer,
+                uint64_t red, uint64_t inner, const char *what)
+{
+    MI355_REQUIRE_CTX(ctx);
+    if (outer == 0 || inner == 0) return MI355_OK;
+    if ((red && !in) || (!ARG && !out_sum) || (ARG && !out_idx)) return fail(ctx, MI355_E_INVALID_ARGUMENT, "%s: NULL pointer", what);
+    if (ARG && red > 0xFFFFFFFFull) return fail(ctx, MI355_E_UNSUPPORTED, "%s: reduced axis exceeds the u32 index range", what);
+    hipStream_t s = stream_of(ctx, stream);
+    const uint64_t cus = ctx->props.num_streaming_multiprocessors;
+    const uint64_t threads = outer * inner;                 // one per output with RSPLIT = 1
+    const bool split = threads < cus * 256 * 4 && red >= 64;
+#define MID(R)                                                                                                          \
+    do {                                                                                                                \
+        const uint64_t blocks = outer * ((inner + 256 / R - 1) / (256 / R));                                            \
+        const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, cus * 16));                    \
+        hipLaunchKernelGGL((reduce_mid_axis<ARG, R>), dim3(grid), dim3(256), 0, s, in, out_sum, out_idx, outer, red, inner); \
+    } while (0)
+    if (split) MID(8); else MID(1);
+#undef MID
+    check_launch(ctx, what);
+    return MI355_OK;
+}
+
 template <bool ARG>
 int32_t run_rows(mi355_ctx *ctx, mi355_stream stream, const float *in, float *out_sum, uint32_t *out_idx,
                  uint64_t rows, uint64_t cols, uint64_t row_stride, const char *what)
@@ -491,6 +564,20 @@ MI355_API int32_t mi355_reduce_last_axis_argmax_f32(mi355_ctx *ctx, mi355_stream
 {
     return run_rows<true>(ctx, stream, in, nullptr, out_idx, rows, cols, row_stride,
                           "mi355_reduce_last_axis_argmax_f32");
+}
+
+MI355_API int32_t mi355_reduce_axis_sum_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, float *out, uint64_t outer,
+                                            uint64_t reduce, uint64_t inner)
+{
+    if (inner == 1) return run_rows<false>(ctx, stream, in, out, nullptr, outer, reduce, reduce, "mi355_reduce_axis_sum_f32");
+    return run_mid<false>(ctx, stream, in, out, nullptr, outer, reduce, inner, "mi355_reduce_axis_sum_f32");
+}
+
+MI355_API int32_t mi355_reduce_axis_argmax_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, uint32_t *out_idx,
+                                               uint64_t outer, uint64_t reduce, uint64_t inner)
+{
+    if (inner == 1) return run_rows<true>(ctx, stream, in, nullptr, out_idx, outer, reduce, reduce, "mi355_reduce_axis_argmax_f32");
+    return run_mid<true>(ctx, stream, in, nullptr, out_idx, outer, reduce, inner, "mi355_reduce_axis_argmax_f32");
 }
 
 MI355_API int32_t mi355_plane_reduce_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, float *out, uint64_t n,

@@ -178,6 +178,37 @@ def argmax_last_axis(client: ComputeClient, input: TensorHandle, output: TensorH
         client.ctx, client.stream, C.c_void_p(input.device_ptr()), C.c_void_p(output.device_ptr()), rows, cols, stride))
 
 
+def _axis_view(t: TensorHandle, axis: int, what: str):
+    if t.dtype != ElemType.F32:
+        raise ServerError(N.E_UNSUPPORTED, f"{what}: only f32 input is implemented")
+    if not t.is_contiguous():
+        raise ServerError(N.E_UNSUPPORTED_STRIDES, f"{what}: input must be contiguous")
+    rank = t.rank()
+    if not -rank <= axis < rank:
+        raise ServerError(N.E_INVALID_ARGUMENT, f"{what}: axis {axis} out of range for rank {rank}")
+    axis %= rank
+    outer = inner = 1
+    for d in t.shape[:axis]:
+        outer *= d
+    for d in t.shape[axis + 1:]:
+        inner *= d
+    return outer, t.shape[axis], inner
+
+
+def reduce_sum_axis(client: ComputeClient, input: TensorHandle, output: TensorHandle, axis: int) -> None:
+    """Sum over one axis: output shape = input shape minus that axis (any axis, contiguous input)."""
+    outer, red, inner = _axis_view(input, axis, "reduce_sum_axis")
+    client._s.check(client.lib.mi355_reduce_axis_sum_f32(client.ctx, client.stream, C.c_void_p(input.device_ptr()),
+                                                         C.c_void_p(output.device_ptr()), outer, red, inner))
+
+
+def argmax_axis(client: ComputeClient, input: TensorHandle, output: TensorHandle, axis: int) -> None:
+    """Argmax over one axis (u32 indices along that axis; lowest index wins ties, NaN ranks highest)."""
+    outer, red, inner = _axis_view(input, axis, "argmax_axis")
+    client._s.check(client.lib.mi355_reduce_axis_argmax_f32(client.ctx, client.stream, C.c_void_p(input.device_ptr()),
+                                                            C.c_void_p(output.device_ptr()), outer, red, inner))
+
+
 def plane_reduce(client: ComputeClient, input: TensorHandle, output: TensorHandle, op: int, active: int = 64) -> None:
     """plane_sum / plane_prod / plane_max / plane_min / inclusive / exclusive sum over 64-lane planes."""
     n = input.num_elems()

@@ -323,6 +323,15 @@ int32_t mi355_reduce_last_axis_sum_f32(mi355_ctx *ctx, mi355_stream stream, cons
 int32_t mi355_reduce_last_axis_argmax_f32(mi355_ctx *ctx, mi355_stream stream, const float *in,
                                           uint32_t *out_idx, uint64_t rows, uint64_t cols,
                                           uint64_t row_stride);
+/* Sum / argmax over ANY one axis of a contiguous tensor viewed as [outer][reduce][inner] (inner == 1 is the
+ * last-axis case above): out is [outer][inner].  The book's reduce_dim generalisation
+ * (cubecl-book/src/getting-started/src/bin/v7-gpu.rs:59-77 reduces the last axis of a 3-D tensor; cubek's
+ * reduce takes the axis as a parameter).  argmax: lowest index of the maximum along the axis, same NaN / -0
+ * rules as mi355_argmax_f32. */
+int32_t mi355_reduce_axis_sum_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, float *out,
+                                  uint64_t outer, uint64_t reduce, uint64_t inner);
+int32_t mi355_reduce_axis_argmax_f32(mi355_ctx *ctx, mi355_stream stream, const float *in,
+                                     uint32_t *out_idx, uint64_t outer, uint64_t reduce, uint64_t inner);
 /* plane_sum & friends for one 64-lane plane per 64 inputs (frontend/plane.rs:218-240): every
  * lane receives the butterfly result over the first `active` lanes (power of two <= 64),
  * matching plane_dim_checked = min(PLANE_DIM, CUBE_DIM) (shared/plane.rs:55-58).

@@ -169,6 +169,18 @@ def reduce_last_axis_argmax(x: np.ndarray) -> np.ndarray:
     return out.reshape(x.shape[:-1])
 
 
+def reduce_axis_sum(x: np.ndarray, axis: int) -> np.ndarray:
+    """f64 sum over one axis (numpy restatement of the per-unit loop of the book's reduce kernels along `axis`)."""
+    return np.asarray(x, dtype=np.float32).astype(np.float64).sum(axis=axis)
+
+
+def reduce_axis_argmax(x: np.ndarray, axis: int) -> np.ndarray:
+    """Lowest index of the maximum along `axis` with the argmax_key order (NaN highest, -0 == +0)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    moved = np.ascontiguousarray(np.moveaxis(x, axis, -1))
+    return reduce_last_axis_argmax(moved)
+
+
 def plane_reduce(vals: np.ndarray, op: int) -> np.ndarray:
     v = np.ascontiguousarray(vals, dtype=np.float32).copy()
     lib().oracle_plane_reduce_f32(_p(v), v.size, op)

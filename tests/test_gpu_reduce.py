@@ -213,3 +213,42 @@ def test_workspace_contract(client):
     rc = client.lib.mi355_reduce_sum_f32(client.ctx, None, C.c_void_p(x.device_ptr()), 10_000,
                                          C.c_void_p(out.device_ptr()), C.c_void_p(small.device_ptr()), 64)
     assert rc == N.E_INVALID_ARGUMENT and b"workspace" in client.lib.mi355_last_error(client.ctx)
+
+
+@pytest.mark.parametrize("shape,axis", [((64, 256, 1024), 1), ((64, 256, 1024), 0), ((64, 64, 4096), 1), ((512, 8192), 0),
+                                        ((3, 1000, 7), 1), ((1, 5, 1), 1), ((2048, 33), 0), ((4, 100000, 3), 1),
+                                        ((64, 256, 1024), 2), ((37, 1001), -1), ((5, 4, 3, 2), 2)])
+def test_reductions_over_any_axis(client, oracle, shape, axis):
+    # the callers either side of the array-wide reduce: sum / argmax over a non-last axis
+    n = int(np.prod(shape))
+    x = oracle.fill_uniform(n, 51, -1.0, 1.0).reshape(shape)
+    t = TensorHandle.from_numpy(client, x)
+    out_shape = tuple(d for i, d in enumerate(shape) if i != axis % len(shape))
+    m = int(np.prod(out_shape)) if out_shape else 1
+    s = TensorHandle.new_contiguous(out_shape or (1,), client.empty(max(m, 1) * 4), ElemType.F32)
+    ops.reduce_sum_axis(client, t, s, axis)
+    ref = oracle.reduce_axis_sum(x, axis)
+    bound = np.abs(x).astype(np.float64).sum(axis=axis)
+    assert np.all(np.abs(s.to_numpy(client).reshape(ref.shape).astype(np.float64) - ref) <= REL * bound + 1e-30)
+    a = TensorHandle.new_contiguous(out_shape or (1,), client.empty(max(m, 1) * 4), ElemType.U32)
+    ops.argmax_axis(client, t, a, axis)
+    assert np.array_equal(a.to_numpy(client).reshape(ref.shape), oracle.reduce_axis_argmax(x, axis))
+
+
+def test_axis_argmax_ties_and_nan(client, oracle):
+    x = np.zeros((4, 6, 5), dtype=np.float32)
+    x[:, 2, :] = 3.0
+    x[:, 4, :] = 3.0                      # tie along axis 1: index 2 wins
+    x[1, 5, 3] = np.float32("nan")        # NaN outranks everything
+    x[2, 0, 0] = np.float32("nan")
+    x[2, 3, 0] = np.float32("nan")        # first NaN wins
+    t = TensorHandle.from_numpy(client, x)
+    a = TensorHandle.new_contiguous((4, 5), client.empty(80), ElemType.U32)
+    ops.argmax_axis(client, t, a, 1)
+    got = a.to_numpy(client).reshape(4, 5)
+    want = np.full((4, 5), 2, dtype=np.uint32)
+    want[1, 3] = 5
+    want[2, 0] = 0
+    assert np.array_equal(got, want) and np.array_equal(got, oracle.reduce_axis_argmax(x, 1))
+    with pytest.raises(ServerError):
+        ops.reduce_sum_axis(client, t, a, 3)
