@@ -156,6 +156,10 @@ PROTOTYPES = {
     "mi355_send": (C.c_int32, [_P, _P, _P, _P, C.c_uint64, C.c_int32, C.c_int32]),
     "mi355_recv": (C.c_int32, [_P, _P, _P, _P, C.c_uint64, C.c_int32, C.c_int32]),
     "mi355_sync_collective": (C.c_int32, [_P, _P]),
+    "mi355_graph_begin_capture": (C.c_int32, [_P, _P]),
+    "mi355_graph_end_capture": (C.c_int32, [_P, _P, _PP]),
+    "mi355_graph_replay": (C.c_int32, [_P, _P, _P]),
+    "mi355_graph_destroy": (C.c_int32, [_P, _P]),
     "mi355_profile_start": (C.c_int32, [_P, _P, _U64P]),
     "mi355_profile_stop": (C.c_int32, [_P, _P, C.c_uint64, _U64P]),
 }

@@ -49,6 +49,7 @@ struct mi355_ctx {
     void *ticket_buf = nullptr;            // library-owned device scratch: arrival tickets of the reductions
     std::unordered_map<hipStream_t, uint32_t> ticket_slots;
     bool tickets_dirty = false;
+    bool capturing = false;                // a hipStream capture window is open (graph API)
     // library-owned device scratch per (stream, kind): split-K slabs, re-laid-out GEMM operands
     std::map<std::pair<hipStream_t, int>, std::pair<void *, size_t>> scratch;
     uint64_t func_attr_mask = 0;  // kernels whose dynamic-LDS attribute is already raised on this device

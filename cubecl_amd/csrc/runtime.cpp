@@ -663,3 +663,71 @@ MI355_API int32_t mi355_profile_stop(mi355_ctx *ctx, mi355_stream stream, uint64
     // a profiled region that hit an execution error poisons the measurement (server.rs:728-735)
     return report_queue(ctx);
 }
+
+// =================================== Graph capture ==========================================
+// ComputeServer::{begin_capture, end_capture, replay, graph_destroy}
+// (crates/cubecl-runtime/src/server/base.rs:472-532; the HIP backend's implementation over
+// hipStreamBeginCapture / hipGraphInstantiate / hipGraphLaunch: crates/cubecl-hip/src/compute/server.rs:288-521).
+// Everything this library launches is capturable once its lazily created scratch exists (run the sequence once
+// before capturing -- the reference asks for the same warm-up, base.rs:453-470): kernels take their state from
+// arguments, the reductions' arrival tickets are reset by the kernels themselves, nothing synchronises the host.
+
+struct mi355_graph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+
+MI355_API int32_t mi355_graph_begin_capture(mi355_ctx *ctx, mi355_stream stream)
+{
+    MI355_REQUIRE_CTX(ctx);
+    if (ctx->capturing) return fail(ctx, MI355_E_INVALID_ARGUMENT, "begin_capture: a capture is already open on this context");
+    MI355_HIP(ctx, hipStreamBeginCapture(stream_of(ctx, stream), hipStreamCaptureModeThreadLocal));
+    ctx->capturing = true;
+    return MI355_OK;
+}
+
+MI355_API int32_t mi355_graph_end_capture(mi355_ctx *ctx, mi355_stream stream, mi355_graph **out_graph)
+{
+    MI355_REQUIRE_CTX(ctx);
+    if (!out_graph) return fail(ctx, MI355_E_INVALID_ARGUMENT, "end_capture: out_graph is NULL");
+    *out_graph = nullptr;
+    if (!ctx->capturing) return fail(ctx, MI355_E_INVALID_ARGUMENT, "end_capture without begin_capture");
+    ctx->capturing = false;
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(stream_of(ctx, stream), &g);
+    if (e != hipSuccess || !g) {
+        (void)hipGetLastError();
+        return fail(ctx, MI355_E_EXECUTION, "hipStreamEndCapture: %s (an operation in the window was not capturable: "
+                    "run the sequence once before capturing so that library scratch exists)", hipGetErrorString(e));
+    }
+    hipGraphExec_t x = nullptr;
+    e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        hipGraphDestroy(g);
+        return fail(ctx, MI355_E_EXECUTION, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    }
+    *out_graph = new mi355_graph{g, x};
+    return MI355_OK;
+}
+
+MI355_API int32_t mi355_graph_replay(mi355_ctx *ctx, mi355_stream stream, mi355_graph *graph)
+{
+    MI355_REQUIRE_CTX(ctx);
+    if (!graph) return fail(ctx, MI355_E_NOT_FOUND, "replay: unknown graph");
+    hipError_t e = hipGraphLaunch(graph->exec, stream_of(ctx, stream));
+    if (e != hipSuccess) {                       // fire-and-forget like launch: queued, reported by flush / sync
+        (void)hipGetLastError();
+        queue_error(ctx, MI355_E_LAUNCH, 0, 0, "hipGraphLaunch: %s", hipGetErrorString(e));
+    }
+    return MI355_OK;
+}
+
+MI355_API int32_t mi355_graph_destroy(mi355_ctx *ctx, mi355_graph *graph)
+{
+    MI355_REQUIRE_CTX(ctx);
+    if (!graph) return MI355_OK;
+    hipGraphExecDestroy(graph->exec);
+    hipGraphDestroy(graph->graph);
+    delete graph;
+    return MI355_OK;
+}

@@ -440,6 +440,25 @@ class ComputeClient:
         self._s.check(self.lib.mi355_profile_stop(self.ctx, self.stream, token, C.byref(nanos)))
         return result, nanos.value
 
+    # -- graph capture (ComputeServer::begin_capture / end_capture / replay, server/base.rs:472-532) -----
+    def capture(self, fn):
+        """Runs `fn` (which enqueues work on this client's stream) inside a capture window and returns the
+        instantiated graph.  Warm the sequence up once before capturing (base.rs:453-470)."""
+        self._s.check(self.lib.mi355_graph_begin_capture(self.ctx, self.stream))
+        try:
+            fn()
+        finally:
+            g = C.c_void_p()
+            rc = self.lib.mi355_graph_end_capture(self.ctx, self.stream, C.byref(g))
+        self._s.check(rc)
+        return g
+
+    def replay(self, graph) -> None:
+        self._s.check(self.lib.mi355_graph_replay(self.ctx, self.stream, graph))
+
+    def graph_destroy(self, graph) -> None:
+        self._s.check(self.lib.mi355_graph_destroy(self.ctx, graph))
+
     # -- collectives (ServerCommunication) ------------------------------------------------------
     def comm_init(self, device_ids: Sequence[DeviceId], unique_id: bytes, rank: Optional[int] = None) -> None:
         """comm_init: one communicator per sorted device set; rank = position of this device

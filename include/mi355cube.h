@@ -404,6 +404,20 @@ int32_t mi355_recv(mi355_ctx *ctx, mi355_comm *comm, mi355_stream compute_stream
  * comm stream. */
 int32_t mi355_sync_collective(mi355_ctx *ctx, mi355_stream compute_stream);
 
+/* =================================== Graph capture ======================================= */
+
+/* ComputeServer::begin_capture / end_capture / replay / graph_destroy (server/base.rs:472-532; HIP
+ * implementation crates/cubecl-hip/src/compute/server.rs:288-521): records what is enqueued on the
+ * stream between begin and end into a hipGraph and replays it with one launch -- for launch-bound
+ * sequences (an empty kernel costs ~2.7 us of host time here).  Run the sequence once before capturing
+ * (graph_prepare + warm-up in the reference, base.rs:453-470) so that lazily created library scratch
+ * exists; nothing the library enqueues synchronises the host or allocates after that. */
+typedef struct mi355_graph mi355_graph;
+int32_t mi355_graph_begin_capture(mi355_ctx *ctx, mi355_stream stream);
+int32_t mi355_graph_end_capture(mi355_ctx *ctx, mi355_stream stream, mi355_graph **out_graph);
+int32_t mi355_graph_replay(mi355_ctx *ctx, mi355_stream stream, mi355_graph *graph);
+int32_t mi355_graph_destroy(mi355_ctx *ctx, mi355_graph *graph);
+
 /* =================================== Profiling =========================================== */
 
 /* ComputeServer::start_profile / end_profile (server/base.rs:590-597) with device timing:

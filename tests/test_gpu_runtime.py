@@ -308,3 +308,61 @@ def test_streams_events_pinned_async_io_and_misc_entry_points(client, oracle):
     assert lib.mi355_send(ctx, comm, None, C.c_void_p(dst.device_ptr()), 4, N.DTYPE_F32, 0) == N.E_INVALID_ARGUMENT
     assert lib.mi355_recv(ctx, comm, None, C.c_void_p(dst.device_ptr()), 4, N.DTYPE_F32, 1) == N.E_INVALID_ARGUMENT
     assert lib.mi355_send(ctx, None, None, C.c_void_p(dst.device_ptr()), 4, N.DTYPE_F32, 0) == N.E_INVALID_ARGUMENT
+
+
+def test_graph_capture_and_replay_of_a_launch_bound_sequence(client, oracle):
+    """begin_capture / end_capture / replay (crates/cubecl-hip/tests/graph.rs is the reference's counterpart): a chain
+    of small GEMMs + a reduction, captured once after a warm-up run, replayed, and compared bit for bit with eager."""
+    import ctypes as C
+    import time
+    from cubecl_amd import ops
+    lib, ctx = client.lib, client.ctx
+    chk = client._s.check
+    m = 256
+    a = TensorHandle.uniform(client, (m, m), ElemType.BF16, 0x5EEDC0BE, 91, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (m, m), ElemType.BF16, 0x5EEDC0BE, 92, -1.0, 1.0)
+    bt = TensorHandle.new(b.handle, (m, m), (1, m), ElemType.BF16)
+    tmp = [TensorHandle.new_contiguous((m, m), client.empty(m * m * 2), ElemType.BF16) for _ in range(2)]
+    cf = TensorHandle.new_contiguous((m, m), client.empty(m * m * 4), ElemType.F32)
+    out = TensorHandle.new_contiguous((1,), client.empty(8), ElemType.F32)
+
+    def sequence():                       # 16 dependent 256^3 GEMMs (each a few us: launch-bound), then sum the result
+        src = a
+        for i in range(15):
+            ops.matmul(client, src, bt, tmp[i & 1])
+            src = tmp[i & 1]
+        ops.matmul(client, src, bt, cf)
+        ops.reduce_sum(client, TensorHandle.new_contiguous((m * m,), cf.handle, ElemType.F32), out)
+
+    sequence()                            # warm-up: creates the library scratch (tickets) the capture must not allocate
+    client.sync()
+    eager = (cf.to_numpy(client).copy(), out.to_numpy(client).copy())
+    chk(lib.mi355_graph_begin_capture(ctx, None))
+    sequence()
+    g = C.c_void_p()
+    chk(lib.mi355_graph_end_capture(ctx, None, C.byref(g)))
+    chk(lib.mi355_memset(ctx, None, C.c_void_p(cf.device_ptr()), 0xEE, m * m * 4))
+    chk(lib.mi355_graph_replay(ctx, None, g))
+    client.sync()
+    assert np.array_equal(cf.to_numpy(client), eager[0]) and np.array_equal(out.to_numpy(client), eager[1])
+    # replay is not slower than issuing the 17 launches eagerly (host-bound regime)
+    def timed(fn, reps=20):
+        fn(); client.sync(); t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        client.sync()
+        return (time.perf_counter() - t0) / reps
+    t_eager, t_graph = timed(sequence), timed(lambda: chk(lib.mi355_graph_replay(ctx, None, g)))
+    assert t_graph < 1.5 * t_eager, (t_graph, t_eager)
+    print(f"17 launches: eager {t_eager*1e6:.1f} us, graph replay {t_graph*1e6:.1f} us")
+    # misuse is an error, not a hang
+    assert lib.mi355_graph_end_capture(ctx, None, C.byref(C.c_void_p())) == N.E_INVALID_ARGUMENT
+    assert lib.mi355_graph_replay(ctx, None, None) == N.E_NOT_FOUND
+    chk(lib.mi355_graph_destroy(ctx, g))
+    # the client-level wrappers
+    g2 = client.capture(sequence)
+    chk(lib.mi355_memset(ctx, None, C.c_void_p(cf.device_ptr()), 0x11, m * m * 4))
+    client.replay(g2)
+    client.sync()
+    assert np.array_equal(cf.to_numpy(client), eager[0])
+    client.graph_destroy(g2)
