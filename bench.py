@@ -288,6 +288,14 @@ def main():
             ms = time_op(client, ev, lambda: client._s.check(
                 lib.mi355_probe_mfma_data(ctx, None, 1, 20000, sink.device_ptr(), C.byref(n_ops))), 5)
             out["mfma_bf16_uniform_operands_TFLOPs"] = round(n_ops.value / ms / 1e9, 1)
+            # fp8 (v_mfma_f32_32x32x64_f8f6f4, e4m3): all-ones operands, then uniform[-1,1) operands
+            n_ops = C.c_uint64()
+            ms = time_op(client, ev, lambda: client._s.check(
+                lib.mi355_probe_mfma(ctx, None, N.DTYPE_F8E4M3, 10000, sink.device_ptr(), C.byref(n_ops))), 5)
+            out["mfma_fp8_TFLOPs"] = round(n_ops.value / ms / 1e9, 1)
+            ms = time_op(client, ev, lambda: client._s.check(
+                lib.mi355_probe_mfma_data(ctx, None, 2, 10000, sink.device_ptr(), C.byref(n_ops))), 5)
+            out["mfma_fp8_uniform_operands_TFLOPs"] = round(n_ops.value / ms / 1e9, 1)
             # the reference's remaining throughput probes (examples/throughput: copy, write, compute-direct, launch)
             buf2 = client.empty(1 << 30)
             ms = time_op(client, ev, lambda: client._s.check(
@@ -417,6 +425,22 @@ def main():
                              "algo": alg.value}
             return out
         guarded("gemm_f32_4096", gemm_f32_c2)
+
+        def gemm_fp8():
+            # not a BASELINE config: the fp8 variant of the headline shape, e4m3 in, bf16 out
+            out = {}
+            for S_ in (8192, 4096):
+                qa = TensorHandle.uniform(client, (S_, S_), ElemType.F8E4M3, SEED, 900, -1.0, 1.0)
+                qb = TensorHandle.uniform(client, (S_, S_), ElemType.F8E4M3, SEED, 901, -1.0, 1.0)
+                qc = client.empty(S_ * S_ * 2)
+                d = gemm_desc(N, S_, S_, S_, N.DTYPE_F8E4M3, N.DTYPE_BF16, trans_b=1)
+                call = lambda: client._s.check(lib.mi355_gemm(ctx, None, C.byref(d), qa.device_ptr(), qb.device_ptr(), qc.device_ptr()))
+                time_op(client, ev, call, 40)                                  # past the DVFS ramp
+                b2b = time_op(client, ev, call, 30)
+                tf = 2.0 * S_ ** 3 / b2b / 1e9
+                out[f"{S_}^3"] = {"back_to_back_ms": round(b2b, 4), "TFLOPs": round(tf, 1), "frac_of_5PF": round(tf / 5000.0, 4)}
+            return out
+        guarded("gemm_fp8_e4m3", gemm_fp8)
 
         def batched_c5():
             per_gpu = 64                      # 512 matrices / 8 GPUs

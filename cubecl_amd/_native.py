@@ -41,6 +41,8 @@ ERROR_NAMES = {
 DTYPE_F32, DTYPE_BF16, DTYPE_F16, DTYPE_F64, DTYPE_I32, DTYPE_U32, DTYPE_I64, DTYPE_U64, DTYPE_U8, DTYPE_I8 = range(10)
 DTYPE_SIZE = {DTYPE_F32: 4, DTYPE_BF16: 2, DTYPE_F16: 2, DTYPE_F64: 8, DTYPE_I32: 4, DTYPE_U32: 4, DTYPE_I64: 8,
               DTYPE_U64: 8, DTYPE_U8: 1, DTYPE_I8: 1}
+DTYPE_F8E4M3, DTYPE_F8E5M2 = 10, 11            # OCP FP8 (fp8_e4m3.rs / fp8_e5m2.rs of the reference)
+DTYPE_SIZE.update({DTYPE_F8E4M3: 1, DTYPE_F8E5M2: 1})
 
 REDUCE_SUM, REDUCE_MEAN, REDUCE_MAX, REDUCE_MIN = 0, 1, 2, 3
 PLANE_PROD, PLANE_INCLUSIVE_SUM, PLANE_EXCLUSIVE_SUM = 100, 101, 102

@@ -3,6 +3,7 @@
 // the timed region never includes PCIe ("uploads dominate unless inputs
 // are generated on-device").
 #include "internal.hpp"
+#include "fp8.hpp"
 
 #include <hip/hip_fp16.h>
 
@@ -51,6 +52,8 @@ __global__ void __launch_bounds__(256) fill_uniform_kernel(void *__restrict__ ds
         const float v = rng_value(key, i, lo, scale);
         if (DTYPE == MI355_DTYPE_F32) static_cast<float *>(dst)[i] = v;
         else if (DTYPE == MI355_DTYPE_BF16) static_cast<uint16_t *>(dst)[i] = f32_to_bf16(v);
+        else if (DTYPE == MI355_DTYPE_F8E4M3) static_cast<uint8_t *>(dst)[i] = f32_to_e4m3(v);
+        else if (DTYPE == MI355_DTYPE_F8E5M2) static_cast<uint8_t *>(dst)[i] = f32_to_e5m2(v);
         else static_cast<uint16_t *>(dst)[i] = f32_to_f16(v);
     }
 }
@@ -63,9 +66,13 @@ __global__ void __launch_bounds__(256) cast_kernel(const void *__restrict__ src,
         float v;
         if (SRC == MI355_DTYPE_F32) v = static_cast<const float *>(src)[i];
         else if (SRC == MI355_DTYPE_BF16) v = __uint_as_float((uint32_t)static_cast<const uint16_t *>(src)[i] << 16);
+        else if (SRC == MI355_DTYPE_F8E4M3) v = e4m3_to_f32(static_cast<const uint8_t *>(src)[i]);
+        else if (SRC == MI355_DTYPE_F8E5M2) v = e5m2_to_f32(static_cast<const uint8_t *>(src)[i]);
         else v = __half2float(__ushort_as_half(static_cast<const uint16_t *>(src)[i]));
         if (DST == MI355_DTYPE_F32) static_cast<float *>(dst)[i] = v;
         else if (DST == MI355_DTYPE_BF16) static_cast<uint16_t *>(dst)[i] = f32_to_bf16(v);
+        else if (DST == MI355_DTYPE_F8E4M3) static_cast<uint8_t *>(dst)[i] = f32_to_e4m3(v);
+        else if (DST == MI355_DTYPE_F8E5M2) static_cast<uint8_t *>(dst)[i] = f32_to_e5m2(v);
         else static_cast<uint16_t *>(dst)[i] = f32_to_f16(v);
     }
 }
@@ -106,6 +113,12 @@ MI355_API int32_t mi355_fill_uniform(mi355_ctx *ctx, mi355_stream stream, void *
     case MI355_DTYPE_F16:
         hipLaunchKernelGGL(fill_uniform_kernel<MI355_DTYPE_F16>, dim3(grid), dim3(256), 0, s, dst, n, key, lo, scale);
         break;
+    case MI355_DTYPE_F8E4M3:
+        hipLaunchKernelGGL(fill_uniform_kernel<MI355_DTYPE_F8E4M3>, dim3(grid), dim3(256), 0, s, dst, n, key, lo, scale);
+        break;
+    case MI355_DTYPE_F8E5M2:
+        hipLaunchKernelGGL(fill_uniform_kernel<MI355_DTYPE_F8E5M2>, dim3(grid), dim3(256), 0, s, dst, n, key, lo, scale);
+        break;
     default:
         return fail(ctx, MI355_E_UNSUPPORTED, "mi355_fill_uniform: unsupported dtype %d", dtype);
     }
@@ -135,6 +148,18 @@ MI355_API int32_t mi355_cast(mi355_ctx *ctx, mi355_stream stream, const void *sr
     CAST_CASE(MI355_DTYPE_F32, MI355_DTYPE_F32)
     CAST_CASE(MI355_DTYPE_BF16, MI355_DTYPE_F16)
     CAST_CASE(MI355_DTYPE_F16, MI355_DTYPE_BF16)
+    CAST_CASE(MI355_DTYPE_F32, MI355_DTYPE_F8E4M3)
+    CAST_CASE(MI355_DTYPE_F32, MI355_DTYPE_F8E5M2)
+    CAST_CASE(MI355_DTYPE_BF16, MI355_DTYPE_F8E4M3)
+    CAST_CASE(MI355_DTYPE_BF16, MI355_DTYPE_F8E5M2)
+    CAST_CASE(MI355_DTYPE_F16, MI355_DTYPE_F8E4M3)
+    CAST_CASE(MI355_DTYPE_F16, MI355_DTYPE_F8E5M2)
+    CAST_CASE(MI355_DTYPE_F8E4M3, MI355_DTYPE_F32)
+    CAST_CASE(MI355_DTYPE_F8E5M2, MI355_DTYPE_F32)
+    CAST_CASE(MI355_DTYPE_F8E4M3, MI355_DTYPE_BF16)
+    CAST_CASE(MI355_DTYPE_F8E5M2, MI355_DTYPE_BF16)
+    CAST_CASE(MI355_DTYPE_F8E4M3, MI355_DTYPE_F16)
+    CAST_CASE(MI355_DTYPE_F8E5M2, MI355_DTYPE_F16)
     if (!launched) return fail(ctx, MI355_E_UNSUPPORTED, "mi355_cast: unsupported %d -> %d", src_dtype, dst_dtype);
     check_launch(ctx, "mi355_cast");
     return MI355_OK;

@@ -10,9 +10,13 @@ int32_t validate(mi355_ctx *ctx, const mi355_gemm_desc *d, const void *a, const 
     if (!d) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_gemm: descriptor is NULL");
     if (d->m < 0 || d->n < 0 || d->k < 0 || d->batch < 0)
         return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_gemm: negative dimension");
-    if (d->dtype_ab != MI355_DTYPE_F32 && d->dtype_ab != MI355_DTYPE_BF16 && d->dtype_ab != MI355_DTYPE_F16)
+    const bool f8 = is_fp8(d->dtype_ab);
+    if (d->dtype_ab != MI355_DTYPE_F32 && d->dtype_ab != MI355_DTYPE_BF16 && d->dtype_ab != MI355_DTYPE_F16 && !f8)
         return fail(ctx, MI355_E_UNSUPPORTED, "mi355_gemm: unsupported input dtype %d", d->dtype_ab);
-    if (d->dtype_c != MI355_DTYPE_F32 && d->dtype_c != d->dtype_ab)
+    if (f8) {
+        if (d->dtype_c != MI355_DTYPE_F32 && d->dtype_c != MI355_DTYPE_BF16 && d->dtype_c != MI355_DTYPE_F16)
+            return fail(ctx, MI355_E_UNSUPPORTED, "mi355_gemm: fp8 inputs write f32, bf16 or f16 (got %d)", d->dtype_c);
+    } else if (d->dtype_c != MI355_DTYPE_F32 && d->dtype_c != d->dtype_ab)
         return fail(ctx, MI355_E_UNSUPPORTED, "mi355_gemm: output dtype %d must be f32 or the input dtype", d->dtype_c);
     if (d->m == 0 || d->n == 0 || d->batch == 0) return MI355_OK;
     if (!c || (d->k > 0 && (!a || !b))) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_gemm: NULL operand");
@@ -30,6 +34,8 @@ int32_t validate(mi355_ctx *ctx, const mi355_gemm_desc *d, const void *a, const 
 int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
 {
     if (d.k == 0) return MI355_GEMM_ALGO_GENERIC;  // writes zeros
+    if (is_fp8(d.dtype_ab))   // one MFMA kernel (256x256 tiles); m*n*k below 2^21 is launch-bound either way
+        return (gemm_lp256w4_supports(d, a, b, c) && d.m * d.n * d.k >= ((int64_t)1 << 21)) ? MI355_GEMM_ALGO_LP_256W4 : MI355_GEMM_ALGO_GENERIC;
     if (d.dtype_ab == MI355_DTYPE_F32) {
         // 256x256 tiles (one wave per SIMD) when they give (nearly) every CU a tile; else 128x128
         if (gemm_lp256w4_supports(d, a, b, c) && ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch >= 192) return MI355_GEMM_ALGO_LP_256W4;
@@ -66,7 +72,7 @@ struct relayout_plan {
 bool plan_relayout(const mi355_gemm_desc &d, const void *a, const void *b, const void *c, relayout_plan &p)
 {
     if (d.k == 0 || d.m * d.n * d.k < (int64_t)1 << 21) return false;           // tiny: not worth extra launches
-    const int64_t esz = d.dtype_ab == MI355_DTYPE_F32 ? 4 : 2;
+    const int64_t esz = (int64_t)dtype_size(d.dtype_ab);
     const int64_t ktile = 128 / esz, ve = 16 / esz;
     p.kpad = (d.k + ktile - 1) / ktile * ktile;
     const bool ragged_k = p.kpad != d.k;
@@ -89,7 +95,7 @@ int32_t relayout_for_mfma(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
 {
     relayout_plan p;
     if (!plan_relayout(d, a, b, c, p)) return MI355_E_UNSUPPORTED;
-    const int esz = d.dtype_ab == MI355_DTYPE_F32 ? 4 : 2;
+    const int esz = (int)dtype_size(d.dtype_ab);
     nd = p.nd; na = a; nb = b;
     if (p.a) {
         const int64_t nba = d.stride_a == 0 ? 1 : d.batch;

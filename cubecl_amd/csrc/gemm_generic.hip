@@ -3,6 +3,7 @@
 // Correctness path, not a roofline path: 64x64x16 tile, 4x4 outputs per thread, f32 FMA chain in
 // k order (the order of runtime_tests/cmma.rs:695-722).
 #include "gemm_common.hpp"
+#include "fp8.hpp"
 
 #include <hip/hip_fp16.h>
 
@@ -14,6 +15,8 @@ template <int DT>
 __device__ __forceinline__ float load_as_f32(const void *p, int64_t idx)
 {
     if (DT == MI355_DTYPE_F32) return static_cast<const float *>(p)[idx];
+    if (DT == MI355_DTYPE_F8E4M3) return e4m3_to_f32(static_cast<const uint8_t *>(p)[idx]);
+    if (DT == MI355_DTYPE_F8E5M2) return e5m2_to_f32(static_cast<const uint8_t *>(p)[idx]);
     const uint16_t raw = static_cast<const uint16_t *>(p)[idx];
     if (DT == MI355_DTYPE_BF16) return __uint_as_float((uint32_t)raw << 16);
     return __half2float(__ushort_as_half(raw));
@@ -116,6 +119,12 @@ int32_t launch_gemm_generic(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc
     else if (ab == MI355_DTYPE_BF16 && cd == MI355_DTYPE_BF16) launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16>(s, d, a, b, c);
     else if (ab == MI355_DTYPE_F16 && cd == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(s, d, a, b, c);
     else if (ab == MI355_DTYPE_F16 && cd == MI355_DTYPE_F16) launch<MI355_DTYPE_F16, MI355_DTYPE_F16>(s, d, a, b, c);
+    else if (ab == MI355_DTYPE_F8E4M3 && cd == MI355_DTYPE_F32) launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_F32>(s, d, a, b, c);
+    else if (ab == MI355_DTYPE_F8E4M3 && cd == MI355_DTYPE_BF16) launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_BF16>(s, d, a, b, c);
+    else if (ab == MI355_DTYPE_F8E4M3 && cd == MI355_DTYPE_F16) launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_F16>(s, d, a, b, c);
+    else if (ab == MI355_DTYPE_F8E5M2 && cd == MI355_DTYPE_F32) launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_F32>(s, d, a, b, c);
+    else if (ab == MI355_DTYPE_F8E5M2 && cd == MI355_DTYPE_BF16) launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_BF16>(s, d, a, b, c);
+    else if (ab == MI355_DTYPE_F8E5M2 && cd == MI355_DTYPE_F16) launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_F16>(s, d, a, b, c);
     else return fail(ctx, MI355_E_UNSUPPORTED, "generic GEMM: unsupported dtypes ab=%d c=%d", ab, cd);
     check_launch(ctx, "mi355_gemm(generic)");
     return MI355_OK;

@@ -1,8 +1,8 @@
-// gemm_lp256w4.hip -- bf16 / f16 / f32 GEMM, 256x256 workgroup tile x one 128-byte K line (64 16-bit or
-// 32 f32 k-values), FOUR waves, one per SIMD.
+// gemm_lp256w4.hip -- bf16 / f16 / f32 / fp8 GEMM, 256x256 workgroup tile x one 128-byte K line (128 fp8,
+// 64 16-bit or 32 f32 k-values), FOUR waves, one per SIMD.
 //
-// Roofline: MFMA bf16/f16, ~2.5 PFLOP/s dense; MFMA f32 (v_mfma_f32_32x32x2_f32, exact f32), 157.3 TFLOP/s
-// (MI355X_MICROARCH.md).  This is the headline kernel for BASELINE configs C3 (8192^3 bf16), C5 (batched
+// Roofline: MFMA bf16/f16, ~2.5 PFLOP/s dense; MFMA f32 (v_mfma_f32_32x32x2_f32, exact f32), 157.3 TFLOP/s;
+// MFMA fp8 (v_mfma_f32_32x32x64_f8f6f4, OCP e4m3 / e5m2), ~5 PFLOP/s dense (MI355X_MICROARCH.md).  This is the headline kernel for BASELINE configs C3 (8192^3 bf16), C5 (batched
 // 2048^3 bf16) and C2 (4096^3 f32, K-contiguous operands).
 //
 // Why one wave per SIMD.  The 8-wave ping-pong kernel (gemm_lp256.hip) hands the matrix pipe of a
@@ -72,6 +72,22 @@ template <> struct lp<MI355_DTYPE_F16> {
     static constexpr int ESZ = 2;
     static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c)
     { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+// fp8: one v_mfma_f32_32x32x64_f8f6f4 (64 cycles, twice the bf16 rate) eats 32 bytes per lane and operand: lane-half
+// h supplies k = 32h .. 32h+31 of a 64-wide k-step, i.e. two adjacent 16-byte chunks of the row.  A K-tile (128
+// k-values) is two such steps.  The instruction is emitted without block scales (all scale operands zero selects
+// the unscaled encoding; checked in the ISA); cbsz / blgp = 0 reads e4m3, 1 reads e5m2.
+template <> struct lp<MI355_DTYPE_F8E4M3> {
+    typedef i32x8 frag;
+    static constexpr int ESZ = 1;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c)
+    { return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0); }
+};
+template <> struct lp<MI355_DTYPE_F8E5M2> {
+    typedef i32x8 frag;
+    static constexpr int ESZ = 1;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c)
+    { return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 1, 1, 0, 0, 0, 0); }
 };
 template <> struct lp<MI355_DTYPE_F32> {
     typedef f32x4 frag;
@@ -159,7 +175,8 @@ gemm_lp256w4_kernel(gemm_args g)
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
     const int64_t batch = blockIdx.y;
     constexpr int ESZ = lp<DT>::ESZ;
-    constexpr int BK = ROW_BYTES / ESZ;                 // 64 (16-bit) / 32 (f32) k-values per K-tile
+    constexpr bool F8 = ESZ == 1;
+    constexpr int BK = ROW_BYTES / ESZ;                 // 128 (fp8) / 64 (16-bit) / 32 (f32) k-values per K-tile
     const char *__restrict__ A = static_cast<const char *>(g.a) + batch * g.stride_a * ESZ;
     const char *__restrict__ B = static_cast<const char *>(g.b) + batch * g.stride_b * ESZ;
     const int nk = (int)(g.k / BK);
@@ -194,6 +211,7 @@ gemm_lp256w4_kernel(gemm_args g)
 
     // ---- fragment read offsets: row*128 + ((2s+h) ^ f) * 16, f = (row>>1)&7 = (l31>>1)&7 for every tile row
     const int f = (l31 >> 1) & 7;
+    const int hd = (f & 1) ? -16 : 16;                  // fp8: the second 16 bytes of a fragment sit in physical chunk ^ 1
     const int rowoff_a = (wm * 128 + l31) * ROW_BYTES;
     const int rowoff_b = BNN ? (wn * 128 + l31) * 4 : (wn * 128 + l31) * ROW_BYTES;
 
@@ -211,7 +229,14 @@ gemm_lp256w4_kernel(gemm_args g)
     auto read_one = [&](auto buf, auto idx, const char *pa, const char *pb) {
         constexpr int BUF = decltype(buf)::value, R = decltype(idx)::value;
         if (W4_ABL & 2) return;
-        if constexpr (BNN) {
+        if constexpr (F8) {
+            // fp8: 16 reads per k-step of 64; read R fills half R&1 of fragment R>>1 (same fragment order as below)
+            constexpr int FR = R >> 1, HALF = R & 1;
+            const char *p = (FR == 0) ? pb : (FR <= 4) ? pa + (FR - 1) * 32 * ROW_BYTES : pb + (FR - 4) * 32 * ROW_BYTES;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(p + (HALF ? hd : 0));
+            frag &dst = (FR == 0) ? fb[BUF][0] : (FR <= 4) ? fa[BUF][(FR - 1) & 3] : fb[BUF][(FR - 4) & 3];
+            dst[4 * HALF + 0] = (int)v[0]; dst[4 * HALF + 1] = (int)v[1]; dst[4 * HALF + 2] = (int)v[2]; dst[4 * HALF + 3] = (int)v[3];
+        } else if constexpr (BNN) {
             if (R >= 1 && R <= 4) fa[BUF][R - 1] = *reinterpret_cast<const frag *>(pa + (R - 1) * 32 * ROW_BYTES);
             else {
                 constexpr int JB = (R == 0) ? 0 : R - 4;       // element e of B fragment JB: k-row e of this lane-half's four
@@ -237,7 +262,7 @@ gemm_lp256w4_kernel(gemm_args g)
     };
     auto mfma_one = [&](auto buf, auto idx) {
         constexpr int BUF = decltype(buf)::value, I = decltype(idx)::value & 3, J = decltype(idx)::value >> 2;
-        if (W4_ABL & 4) {
+        if constexpr ((W4_ABL & 4) != 0) {    // (constexpr: the host pass must not see a 256-bit "v" operand)
             asm volatile("" ::"v"(fb[BUF][J]), "v"(fa[BUF][I]));
             return;
         }
@@ -298,12 +323,18 @@ gemm_lp256w4_kernel(gemm_args g)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     {
-        const int x = (h ^ f) << 4;
+        const int x = F8 ? ((2 * h) ^ f) << 4 : (h ^ f) << 4;
         const char *rd_a = smem + rowoff_a + x, *rd_b = smem + UNIT_BYTES + rowoff_b + (BNN ? (4 * h) * 1024 : x);
         read_one(IC<0>{}, IC<0>{}, rd_a, rd_b); read_one(IC<0>{}, IC<1>{}, rd_a, rd_b);
         read_one(IC<0>{}, IC<2>{}, rd_a, rd_b); read_one(IC<0>{}, IC<3>{}, rd_a, rd_b);
         read_one(IC<0>{}, IC<4>{}, rd_a, rd_b); read_one(IC<0>{}, IC<5>{}, rd_a, rd_b);
         read_one(IC<0>{}, IC<6>{}, rd_a, rd_b); read_one(IC<0>{}, IC<7>{}, rd_a, rd_b);
+        if constexpr (F8) {
+            read_one(IC<0>{}, IC<8>{}, rd_a, rd_b); read_one(IC<0>{}, IC<9>{}, rd_a, rd_b);
+            read_one(IC<0>{}, IC<10>{}, rd_a, rd_b); read_one(IC<0>{}, IC<11>{}, rd_a, rd_b);
+            read_one(IC<0>{}, IC<12>{}, rd_a, rd_b); read_one(IC<0>{}, IC<13>{}, rd_a, rd_b);
+            read_one(IC<0>{}, IC<14>{}, rd_a, rd_b); read_one(IC<0>{}, IC<15>{}, rd_a, rd_b);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -348,11 +379,64 @@ gemm_lp256w4_kernel(gemm_args g)
         sa = sa1;                                                                                           \
         sb = sb1;                                                                                           \
     }
+    // fp8 K-tile: two k-steps of 64 (d = 0, 1), 16 MFMAs of 64 cycles each; register buffer 0 always holds the
+    // fragments of d = 0, buffer 1 those of d = 1.  Same hand-over point as above (three quarters through):
+    //     d=0, MFMA 0-15 : one read of frags(t, d=1) after each; DMA unit 2t+4 pieces 0-7 after the odd ones
+    //     d=1, MFMA 0-7  : nothing else
+    //          vmcnt(8), lgkmcnt(0), s_barrier (BAR_t)
+    //     d=1, MFMA 8-15 : two reads of frags(t+1, d=0) and one DMA piece of unit 2t+5 after each
+#define W8_G(CUR, NXT, IDX, NR, R0, DM, IS_B, J)                                                            \
+    mfma_one(IC<CUR>{}, IC<IDX>{});                                                                          \
+    if constexpr ((NR) >= 1) read_one(IC<NXT>{}, IC<(R0)>{}, rd_a, rd_b);                                    \
+    if constexpr ((NR) >= 2) read_one(IC<NXT>{}, IC<(R0) + 1>{}, rd_a, rd_b);                                \
+    if constexpr (DM) dma_one(IC<IS_B>{}, IC<J>{}, dma_koff, dma_base);                                      \
+    __builtin_amdgcn_sched_barrier(0);
+#define W8_KTILE(ISSUE)                                                                                     \
+    {                                                                                                       \
+        const int sa1 = adv(sa, 2), sb1 = adv(sb, 2);                                                       \
+        const int s4 = adv(sa, 4);                                                                          \
+        const int s5 = sa;                                                                                  \
+        const int64_t dma_koff = (int64_t)(t + 2) * ROW_BYTES;                                              \
+        const char *rd_a, *rd_b;                                                                            \
+        char *dma_base;                                                                                     \
+        rd_a = smem + sa + rowoff_a + z1; rd_b = smem + sb + rowoff_b + z1; dma_base = smem + s4 + dst_piece; \
+        W8_G(0, 1, 0, 1, 0, 0, 0, 0)            W8_G(0, 1, 1, 1, 1, (ISSUE), 0, 0)                            \
+        W8_G(0, 1, 2, 1, 2, 0, 0, 0)            W8_G(0, 1, 3, 1, 3, (ISSUE), 0, 1)                            \
+        W8_G(0, 1, 4, 1, 4, 0, 0, 0)            W8_G(0, 1, 5, 1, 5, (ISSUE), 0, 2)                            \
+        W8_G(0, 1, 6, 1, 6, 0, 0, 0)            W8_G(0, 1, 7, 1, 7, (ISSUE), 0, 3)                            \
+        W8_G(0, 1, 8, 1, 8, 0, 0, 0)            W8_G(0, 1, 9, 1, 9, (ISSUE), 0, 4)                            \
+        W8_G(0, 1, 10, 1, 10, 0, 0, 0)          W8_G(0, 1, 11, 1, 11, (ISSUE), 0, 5)                          \
+        W8_G(0, 1, 12, 1, 12, 0, 0, 0)          W8_G(0, 1, 13, 1, 13, (ISSUE), 0, 6)                          \
+        W8_G(0, 1, 14, 1, 14, 0, 0, 0)          W8_G(0, 1, 15, 1, 15, (ISSUE), 0, 7)                          \
+        W8_G(1, 0, 0, 0, 0, 0, 0, 0) W8_G(1, 0, 1, 0, 0, 0, 0, 0) W8_G(1, 0, 2, 0, 0, 0, 0, 0) W8_G(1, 0, 3, 0, 0, 0, 0, 0) \
+        W8_G(1, 0, 4, 0, 0, 0, 0, 0) W8_G(1, 0, 5, 0, 0, 0, 0, 0) W8_G(1, 0, 6, 0, 0, 0, 0, 0) W8_G(1, 0, 7, 0, 0, 0, 0, 0) \
+        if (!(W4_ABL & 8)) {                                                                                \
+        if (ISSUE) WAIT_VMCNT(8); else WAIT_VMCNT(0);                                                       \
+        WAIT_LGKM0();                                                                                       \
+        __builtin_amdgcn_s_barrier();                                                                       \
+        }                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        rd_a = smem + sa1 + rowoff_a + z0; rd_b = smem + sb1 + rowoff_b + z0; dma_base = smem + s5 + dst_piece; \
+        W8_G(1, 0, 8, 2, 0, (ISSUE), 1, 0)      W8_G(1, 0, 9, 2, 2, (ISSUE), 1, 1)                            \
+        W8_G(1, 0, 10, 2, 4, (ISSUE), 1, 2)     W8_G(1, 0, 11, 2, 6, (ISSUE), 1, 3)                           \
+        W8_G(1, 0, 12, 2, 8, (ISSUE), 1, 4)     W8_G(1, 0, 13, 2, 10, (ISSUE), 1, 5)                          \
+        W8_G(1, 0, 14, 2, 12, (ISSUE), 1, 6)    W8_G(1, 0, 15, 2, 14, (ISSUE), 1, 7)                          \
+        sa = sa1;                                                                                           \
+        sb = sb1;                                                                                           \
+    }
+    const int z0 = ((2 * h) ^ f) << 4, z1 = ((4 + 2 * h) ^ f) << 4;      // fp8: first chunk of this lane-half, k-steps d = 0, 1
     W4_STAMP(1);
     int t = 0;
-    for (; t + 2 < nk; ++t) W4_KTILE(1)
-    for (; t < nk; ++t) W4_KTILE(0)
+    if constexpr (F8) {
+        for (; t + 2 < nk; ++t) W8_KTILE(1)
+        for (; t < nk; ++t) W8_KTILE(0)
+    } else {
+        for (; t + 2 < nk; ++t) W4_KTILE(1)
+        for (; t < nk; ++t) W4_KTILE(0)
+    }
 #undef W4_KTILE
+#undef W8_KTILE
+#undef W8_G
     W4_STAMP(2);
 #undef W4_STEP_BODY
 #undef W4_GROUP
@@ -463,11 +547,14 @@ namespace mi355 {
 
 bool gemm_lp256w4_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
 {
-    if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16 && d.dtype_ab != MI355_DTYPE_F32) return false;
-    if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != d.dtype_ab) return false;
+    const bool f8 = d.dtype_ab == MI355_DTYPE_F8E4M3 || d.dtype_ab == MI355_DTYPE_F8E5M2;
+    if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16 && d.dtype_ab != MI355_DTYPE_F32 && !f8) return false;
+    if (f8) {
+        if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != MI355_DTYPE_BF16 && d.dtype_c != MI355_DTYPE_F16) return false;
+    } else if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != d.dtype_ab) return false;
     if (d.trans_a) return false;
     if (!d.trans_b && d.dtype_ab != MI355_DTYPE_F32) return false;          // row-major B: f32 only
-    const int64_t esz = d.dtype_ab == MI355_DTYPE_F32 ? 4 : 2;
+    const int64_t esz = f8 ? 1 : d.dtype_ab == MI355_DTYPE_F32 ? 4 : 2;
     const int64_t BK = ROW_BYTES / esz;
     if (d.k < BK || d.k % BK != 0) return false;
     const int64_t csz = d.dtype_c == MI355_DTYPE_F32 ? 4 : 2;      // the epilogue writes C in 16-byte pieces
@@ -498,7 +585,15 @@ int32_t launch_gemm_lp256w4(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc
     g.tiles_n = (uint32_t)((d.n + BN - 1) / BN);
     g.group_m = W4_GROUP_M;
     const uint32_t batch = (uint32_t)d.batch;
-    if (d.dtype_ab == MI355_DTYPE_F32) {
+    if (d.dtype_ab == MI355_DTYPE_F8E4M3) {
+        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_F32>(ctx, s, g, batch, 32);
+        else if (d.dtype_c == MI355_DTYPE_BF16) launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_BF16>(ctx, s, g, batch, 33);
+        else launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_F16>(ctx, s, g, batch, 34);
+    } else if (d.dtype_ab == MI355_DTYPE_F8E5M2) {
+        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_F32>(ctx, s, g, batch, 35);
+        else if (d.dtype_c == MI355_DTYPE_BF16) launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_BF16>(ctx, s, g, batch, 36);
+        else launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_F16>(ctx, s, g, batch, 37);
+    } else if (d.dtype_ab == MI355_DTYPE_F32) {
         if (d.trans_b) launch<MI355_DTYPE_F32, MI355_DTYPE_F32, false>(ctx, s, g, batch, 16);
         else launch<MI355_DTYPE_F32, MI355_DTYPE_F32, true>(ctx, s, g, batch, 17);
     } else if (d.dtype_ab == MI355_DTYPE_BF16) {

@@ -20,7 +20,7 @@ namespace {
 
 // dst[c][r] = src[r][c] for a rows x cols matrix (per batch entry).  64 x 64 tile per workgroup of 256 threads;
 // 16-byte accesses on both sides when the tile is interior and everything is 16-byte aligned, element-wise at
-// the ragged edges.  T = uint16_t (bf16 / f16 bits) or uint32_t (f32 bits).
+// the ragged edges.  T = uint8_t (fp8 bits), uint16_t (bf16 / f16 bits) or uint32_t (f32 bits).
 template <typename T>
 __global__ void __launch_bounds__(256)
 transpose_kernel(const T *__restrict__ src, T *__restrict__ dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst,
@@ -127,7 +127,10 @@ void launch_pad_copy(hipStream_t s, const void *src, void *dst, int64_t rows, in
     const int vec_ok = (reinterpret_cast<uintptr_t>(src) & 15u) == 0 && (ld_src % ve) == 0 && (stride_src % ve) == 0;
     const dim3 grid((uint32_t)std::max<int64_t>(1, std::min<int64_t>((cols_pad / ve + 255) / 256, 16)),
                     (uint32_t)std::min<int64_t>(rows, 4096), (uint32_t)batch);
-    if (esz == 2)
+    if (esz == 1)
+        hipLaunchKernelGGL(pad_copy_kernel<uint8_t>, grid, dim3(256), 0, s, static_cast<const uint8_t *>(src),
+                           static_cast<uint8_t *>(dst), rows, cols, cols_pad, ld_src, ld_dst, stride_src, stride_dst, vec_ok);
+    else if (esz == 2)
         hipLaunchKernelGGL(pad_copy_kernel<uint16_t>, grid, dim3(256), 0, s, static_cast<const uint16_t *>(src),
                            static_cast<uint16_t *>(dst), rows, cols, cols_pad, ld_src, ld_dst, stride_src, stride_dst, vec_ok);
     else
@@ -144,7 +147,10 @@ void launch_transpose(hipStream_t s, const void *src, void *dst, int64_t rows, i
     const int64_t ve = 16 / esz;
     const int vec_ok = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0 && (ld_src % ve) == 0 &&
                        (ld_dst % ve) == 0 && (stride_src % ve) == 0 && (stride_dst % ve) == 0;
-    if (esz == 2)
+    if (esz == 1)
+        hipLaunchKernelGGL(transpose_kernel<uint8_t>, grid, dim3(256), 0, s, static_cast<const uint8_t *>(src),
+                           static_cast<uint8_t *>(dst), rows, cols, ld_src, ld_dst, stride_src, stride_dst, tiles_c, vec_ok);
+    else if (esz == 2)
         hipLaunchKernelGGL(transpose_kernel<uint16_t>, grid, dim3(256), 0, s, static_cast<const uint16_t *>(src),
                            static_cast<uint16_t *>(dst), rows, cols, ld_src, ld_dst, stride_src, stride_dst, tiles_c, vec_ok);
     else

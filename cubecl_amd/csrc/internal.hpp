@@ -69,13 +69,14 @@ inline hipStream_t stream_of(mi355_ctx *ctx, mi355_stream s)
 {
     return s ? reinterpret_cast<hipStream_t>(s) : ctx->compute_stream;
 }
+inline bool is_fp8(int32_t dtype) { return dtype == MI355_DTYPE_F8E4M3 || dtype == MI355_DTYPE_F8E5M2; }
 inline size_t dtype_size(int32_t dtype)
 {
     switch (dtype) {
     case MI355_DTYPE_F32: case MI355_DTYPE_I32: case MI355_DTYPE_U32: return 4;
     case MI355_DTYPE_BF16: case MI355_DTYPE_F16: return 2;
     case MI355_DTYPE_F64: case MI355_DTYPE_I64: case MI355_DTYPE_U64: return 8;
-    case MI355_DTYPE_U8: case MI355_DTYPE_I8: return 1;
+    case MI355_DTYPE_U8: case MI355_DTYPE_I8: case MI355_DTYPE_F8E4M3: case MI355_DTYPE_F8E5M2: return 1;
     default: return 0;
     }
 }

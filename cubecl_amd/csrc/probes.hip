@@ -4,6 +4,7 @@
 // matrix-core ceiling the GEMMs are priced against).  Measured ceilings, reported by bench.py
 // beside the spec peaks.
 #include "gemm_common.hpp"
+#include "fp8.hpp"
 
 #include <algorithm>
 
@@ -63,6 +64,14 @@ probe_mfma_kernel(uint32_t iters, float *__restrict__ sink)
         for (uint32_t i = 0; i < iters; ++i) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, ones, acc[a], 0, 0, 0);
+        }
+    } else if (DT == MI355_DTYPE_F8E4M3) {
+        i32x8 ones;                                           // e4m3 1.0 = 0x38 in every byte
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones[e] = 0x38383838;
+        for (uint32_t i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones, ones, acc[a], 0, 0, 0, 0, 0, 0);
         }
     } else {
         f16x8 ones;
@@ -126,6 +135,53 @@ probe_mfma_data_kernel(uint32_t iters, float *__restrict__ sink)
             const bf16x8 t = a[0];
             a[0] = a[1]; a[1] = a[2]; a[2] = a[3]; a[3] = t;
         }
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+    if (t == 1.2345e38f) sink[0] = t;
+}
+
+// The same loop on the fp8 matrix instruction (v_mfma_f32_32x32x64_f8f6f4, e4m3), operands uniform[-1,1) rounded to
+// e4m3, different per lane / fragment, rotating every iteration.
+__global__ void __launch_bounds__(256)
+probe_mfma_data_f8_kernel(uint32_t iters, float *__restrict__ sink)
+{
+    const uint32_t tid = threadIdx.x;
+    i32x8 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            uint32_t wa = 0, wb = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float va = (probe_mix(tid * 977u + i * 131u + (e * 4 + q) * 7u + blockIdx.x * 7919u) >> 8) * (2.0f / 16777216.0f) - 1.0f;
+                const float vb = (probe_mix(tid * 613u + i * 257u + (e * 4 + q) * 11u + 99991u + blockIdx.x * 104729u) >> 8) * (2.0f / 16777216.0f) - 1.0f;
+                wa |= (uint32_t)f32_to_e4m3(va) << (8 * q);
+                wb |= (uint32_t)f32_to_e4m3(vb) << (8 * q);
+            }
+            a[i][e] = (int)wa;
+            b[i][e] = (int)wb;
+        }
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (uint32_t it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b[j], a[i], acc[i][j], 0, 0, 0, 0, 0, 0);
+        const i32x8 t = a[0];
+        a[0] = a[1]; a[1] = a[2]; a[2] = a[3]; a[3] = t;
     }
     float t = 0.f;
 #pragma unroll
@@ -279,13 +335,14 @@ MI355_API int32_t mi355_probe_mfma_data(mi355_ctx *ctx, mi355_stream stream, int
 {
     MI355_REQUIRE_CTX(ctx);
     if (!sink) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_probe_mfma_data: sink is NULL");
-    if (mode != 0 && mode != 1) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_probe_mfma_data: mode must be 0 or 1");
+    if (mode < 0 || mode > 2) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_probe_mfma_data: mode must be 0, 1 or 2");
     const uint32_t grid = ctx->props.num_streaming_multiprocessors;   // one 4-wave workgroup per CU, one wave per SIMD
     hipStream_t s = stream_of(ctx, stream);
     if (mode == 0) hipLaunchKernelGGL(probe_mfma_data_kernel<0>, dim3(grid), dim3(256), 0, s, iters, static_cast<float *>(sink));
-    else hipLaunchKernelGGL(probe_mfma_data_kernel<1>, dim3(grid), dim3(256), 0, s, iters, static_cast<float *>(sink));
+    else if (mode == 1) hipLaunchKernelGGL(probe_mfma_data_kernel<1>, dim3(grid), dim3(256), 0, s, iters, static_cast<float *>(sink));
+    else hipLaunchKernelGGL(probe_mfma_data_f8_kernel, dim3(grid), dim3(256), 0, s, iters, static_cast<float *>(sink));
     check_launch(ctx, "mi355_probe_mfma_data");
-    if (out_ops) *out_ops = (uint64_t)grid * 4ull * iters * 16ull * (2ull * 32 * 32 * 16);
+    if (out_ops) *out_ops = (uint64_t)grid * 4ull * iters * 16ull * (2ull * 32 * 32 * (mode == 2 ? 64 : 16));
     return MI355_OK;
 }
 
@@ -327,6 +384,10 @@ MI355_API int32_t mi355_probe_mfma(mi355_ctx *ctx, mi355_stream stream, int32_t 
     case MI355_DTYPE_F16:
         flop_per_mfma = 2ull * 32 * 32 * 16;
         hipLaunchKernelGGL(probe_mfma_kernel<MI355_DTYPE_F16>, dim3(grid), dim3(256), 0, s, iters, static_cast<float *>(sink));
+        break;
+    case MI355_DTYPE_F8E4M3:
+        flop_per_mfma = 2ull * 32 * 32 * 64;
+        hipLaunchKernelGGL(probe_mfma_kernel<MI355_DTYPE_F8E4M3>, dim3(grid), dim3(256), 0, s, iters, static_cast<float *>(sink));
         break;
     default:
         return fail(ctx, MI355_E_UNSUPPORTED, "mi355_probe_mfma: unsupported dtype %d", dtype_ab);

@@ -43,6 +43,8 @@ class ElemType(enum.IntEnum):
     U64 = N.DTYPE_U64
     U8 = N.DTYPE_U8
     I8 = N.DTYPE_I8
+    F8E4M3 = N.DTYPE_F8E4M3          # FloatKind::E4M3 (crates/cubecl-ir/src/types/scalar.rs)
+    F8E5M2 = N.DTYPE_F8E5M2          # FloatKind::E5M2
 
     def size(self) -> int:
         return N.DTYPE_SIZE[int(self)]

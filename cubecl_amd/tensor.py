@@ -13,7 +13,9 @@ from .runtime import (ComputeClient, CopyDescriptor, ElemType, Handle, ServerErr
 
 _NP = {ElemType.F32: np.float32, ElemType.F64: np.float64, ElemType.I32: np.int32, ElemType.U32: np.uint32,
        ElemType.I64: np.int64, ElemType.U64: np.uint64, ElemType.U8: np.uint8, ElemType.I8: np.int8,
-       ElemType.BF16: np.uint16, ElemType.F16: np.float16}
+       ElemType.BF16: np.uint16, ElemType.F16: np.float16,
+       ElemType.F8E4M3: np.uint8, ElemType.F8E5M2: np.uint8}     # bit patterns (numpy has no bfloat16 / fp8)
+_BITS_ONLY = (ElemType.BF16, ElemType.F8E4M3, ElemType.F8E5M2)
 
 
 @dataclass
@@ -47,10 +49,10 @@ class TensorHandle:
 
     @staticmethod
     def from_numpy(client: ComputeClient, array: np.ndarray, dtype: Optional[ElemType] = None) -> "TensorHandle":
-        """Upload; `dtype` BF16 expects uint16 bit patterns (numpy has no bfloat16)."""
+        """Upload; `dtype` BF16 expects uint16 bit patterns, F8E4M3 / F8E5M2 uint8 bit patterns."""
         array = np.ascontiguousarray(array)
         if dtype is None:
-            dtype = {np.dtype(v): k for k, v in _NP.items() if k != ElemType.BF16}[array.dtype]
+            dtype = {np.dtype(v): k for k, v in _NP.items() if k not in _BITS_ONLY}[array.dtype]
         handle = client.create_from_slice(array)
         return TensorHandle.new_contiguous(array.shape, handle, dtype)
 

@@ -81,7 +81,9 @@ enum {
     MI355_DTYPE_I64 = 6,
     MI355_DTYPE_U64 = 7,
     MI355_DTYPE_U8 = 8,
-    MI355_DTYPE_I8 = 9
+    MI355_DTYPE_I8 = 9,
+    MI355_DTYPE_F8E4M3 = 10, /* OCP e4m3fn: no infinities, S.1111.111 = NaN, max 448 (fp8_e4m3.rs:12-37) */
+    MI355_DTYPE_F8E5M2 = 11  /* OCP e5m2: IEEE-style inf / NaN, max 57344 (fp8_e5m2.rs:12-38) */
 };
 
 /* ReduceOperation (server/base.rs:623-628) + the two extra ops array-wide argmax needs.
@@ -260,8 +262,9 @@ int32_t mi355_cast(mi355_ctx *ctx, mi355_stream stream, const void *src, int32_t
  *                                                        form of the cmma tests (cmma.rs:23)
  * Batch strides are in elements; 0 broadcasts an operand
  * (crates/cubecl-std/src/tensor/matrix_batch_layout.rs:21-79).
- * dtype_ab: F32 (MFMA f32, exact-f32 products), BF16 or F16 (MFMA, f32 accumulate).
- * dtype_c: F32, or the same 16-bit type as the inputs (RNE on store).
+ * dtype_ab: F32 (MFMA f32, exact-f32 products), BF16 or F16 (MFMA, f32 accumulate), F8E4M3 or F8E5M2
+ *           (OCP FP8 on v_mfma_f32_32x32x64_f8f6f4, unscaled, f32 accumulate; both operands the same format).
+ * dtype_c: F32, or the same 16-bit type as the inputs (RNE on store); fp8 inputs write F32, BF16 or F16.
  * Layouts the MFMA kernels do not stage directly (trans_a == 1; 16-bit row-major B) are re-laid out
  * K-contiguous into library-owned per-stream scratch first, as the reference's launchers do with
  * into_contiguous; shapes no MFMA kernel takes (K not a multiple of the K-tile, unaligned rows) run
@@ -283,7 +286,7 @@ enum {
     MI355_GEMM_ALGO_F32_MFMA = 2, /* 128x128 LDS-tiled v_mfma_f32_32x32x2_f32                 */
     MI355_GEMM_ALGO_LP_128 = 3,   /* bf16/f16 128x128x64 LDS-DMA tile, v_mfma_f32_32x32x16     */
     MI355_GEMM_ALGO_LP_256 = 4,   /* bf16/f16 256x256x64 tile, 8 waves (ragged M/N allowed)    */
-    MI355_GEMM_ALGO_LP_256W4 = 5, /* bf16/f16/f32 256x256 tile, 4 waves x 128x128, M,N % 256 == 0 */
+    MI355_GEMM_ALGO_LP_256W4 = 5, /* fp8/bf16/f16/f32 256x256 tile x 128-byte K line, 4 waves x 128x128 */
     MI355_GEMM_ALGO_LP_256P = 6   /* the same tile as a persistent kernel: one workgroup per CU walks
                                      several output tiles with a continuous K-tile stream          */
 };
@@ -364,7 +367,8 @@ int32_t mi355_probe_compute_direct(mi355_ctx *ctx, mi355_stream stream, uint32_t
 int32_t mi355_probe_launch_overhead(mi355_ctx *ctx, mi355_stream stream, uint32_t launches,
                                     void *sink);
 /* The same issue loop on the GEMM kernels' 4x4 accumulator shape (bf16), register-resident, with
- * mode 0 = all-ones operands, mode 1 = uniform[-1,1) operands rotating every iteration.  Mode 1 is
+ * mode 0 = all-ones operands, mode 1 = uniform[-1,1) operands rotating every iteration, mode 2 = mode 1 on
+ * the fp8 instruction (v_mfma_f32_32x32x64_f8f6f4, e4m3 operands).  Mode 1 is
  * the matrix-pipe ceiling for the benchmark's operand distribution once DVFS has clocked the chip
  * down to its power budget; bench.py reports it beside the spec peak (not a reference probe). */
 int32_t mi355_probe_mfma_data(mi355_ctx *ctx, mi355_stream stream, int32_t mode, uint32_t iters,

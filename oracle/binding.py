@@ -15,6 +15,7 @@ _DIR = Path(__file__).resolve().parent
 LIB_PATH = _DIR / "liboracle.so"
 SEED = 0x5EEDC0BE
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
+DT_F8E4M3, DT_F8E5M2 = 10, 11
 
 _lib = None
 
@@ -61,6 +62,10 @@ def lib() -> C.CDLL:
     L.oracle_plane_inclusive_sum_f32.restype = None
     L.oracle_cpu_sum_argmax_f32.argtypes = [P, u64, i32, C.POINTER(f32), C.POINTER(u64)]
     L.oracle_cpu_sum_argmax_f32.restype = C.c_double
+    L.oracle_convert_f32_to_fp8.argtypes = [P, P, u64, i32]
+    L.oracle_convert_f32_to_fp8.restype = None
+    L.oracle_convert_fp8_to_f32.argtypes = [P, P, u64, i32]
+    L.oracle_convert_fp8_to_f32.restype = None
     L.oracle_cpu_gemm.argtypes = [P, P, P, i32, i32, i64, i64, i64, i64, i64, i64, i32, i32]
     L.oracle_cpu_gemm.restype = C.c_double
     _lib = L
@@ -105,7 +110,24 @@ def from_f16(x: np.ndarray) -> np.ndarray:
     return out
 
 
-_NP_OF = {DT_F32: np.float32, DT_BF16: np.uint16, DT_F16: np.uint16}
+def to_fp8(x: np.ndarray, dtype: int = DT_F8E4M3) -> np.ndarray:
+    """f32 -> OCP FP8 bits (RNE, saturating to +-MAX, NaN kept): e4m3::from_f32 / e5m2::from_f32
+    (crates/cubecl-common/src/float/fp8/fp8_e4m3.rs:77-87, fp8_e5m2.rs:78-88)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty(x.shape, dtype=np.uint8)
+    lib().oracle_convert_f32_to_fp8(_p(x), _p(out), x.size, int(dtype == DT_F8E5M2))
+    return out
+
+
+def from_fp8(x: np.ndarray, dtype: int = DT_F8E4M3) -> np.ndarray:
+    """OCP FP8 bits -> f32, exact (fp8_e4m3.rs:110-115)."""
+    x = np.ascontiguousarray(x, dtype=np.uint8)
+    out = np.empty(x.shape, dtype=np.float32)
+    lib().oracle_convert_fp8_to_f32(_p(x), _p(out), x.size, int(dtype == DT_F8E5M2))
+    return out
+
+
+_NP_OF = {DT_F32: np.float32, DT_BF16: np.uint16, DT_F16: np.uint16, DT_F8E4M3: np.uint8, DT_F8E5M2: np.uint8}
 
 
 def gemm(a: np.ndarray, b: np.ndarray, m: int, n: int, k: int, *, dtype_ab: int = DT_F32, dtype_c: int = DT_F32,

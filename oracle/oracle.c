@@ -130,14 +130,66 @@ ORACLE_API void oracle_convert_bf16_to_f32(const uint16_t *src, float *dst, uint
 ORACLE_API void oracle_convert_f16_to_f32(const uint16_t *src, float *dst, uint64_t n)
 { for (uint64_t i = 0; i < n; ++i) dst[i] = oracle_f16_to_f32(src[i]); }
 
+/* ------------------------------------------------------------------------------------------
+ * 8-bit floats (OCP FP8).  The reference wraps the third-party `float8` crate (Cargo.lock: float8 0.7.0, not
+ * vendored) in crates/cubecl-common/src/float/fp8/{fp8_e4m3,fp8_e5m2}.rs and states the contract there:
+ *   e4m3 (fp8_e4m3.rs:12-37, :77-100): 1-4-3, bias 7, NO infinities, only S.1111.111 is NaN, MAX = 0x7E = 448;
+ *   e5m2 (fp8_e5m2.rs:12-38, :78-100): 1-5-2, bias 15, IEEE-style: S.11111.00 = inf, S.11111.{01,10,11} = NaN,
+ *                                      MAX = 0x7B = 57344;
+ *   from_f32: round to nearest even; values too large, infinities included, SATURATE to +-MAX; NaN stays NaN;
+ *             too-small values become subnormals or +-0.
+ * Pinned by the known answers of those files' own tests (tests/test_oracle_golden.py).
+ * ------------------------------------------------------------------------------------------ */
+static inline uint8_t f32_to_fp8(float f, int mbits, int bias, uint8_t max_code)
+{
+    const uint32_t u = f32_bits(f);
+    const uint8_t sign = (uint8_t)((u >> 24) & 0x80u);
+    const uint32_t a = u & 0x7FFFFFFFu;
+    if (a > 0x7F800000u) return (uint8_t)(sign | 0x7Fu);                    /* NaN */
+    const float af = bits_f32(a);
+    const float min_normal = ldexpf(1.0f, 1 - bias);
+    uint32_t code;
+    if (af < min_normal) {
+        /* subnormal range: multiples of 2^(1-bias-mbits); rintf is round-to-nearest-even; the top value
+         * 2^mbits is the encoding of the smallest normal, as it should be */
+        code = (uint32_t)rintf(af * ldexpf(1.0f, bias - 1 + mbits));
+    } else {
+        const int shift = 23 - mbits;
+        const uint32_t r = a + ((1u << (shift - 1)) - 1u) + ((a >> shift) & 1u);   /* RNE on the dropped bits */
+        const uint32_t rebias = (uint32_t)(127 - bias) << mbits;
+        code = (r >> shift) - rebias;
+        if (r >= 0x7F800000u || code > max_code) code = max_code;           /* saturate (inf included) */
+    }
+    if (code > max_code) code = max_code;
+    return (uint8_t)(sign | code);
+}
+ORACLE_API uint8_t oracle_f32_to_e4m3(float f) { return f32_to_fp8(f, 3, 7, 0x7E); }
+ORACLE_API uint8_t oracle_f32_to_e5m2(float f) { return f32_to_fp8(f, 2, 15, 0x7B); }
+ORACLE_API float oracle_e4m3_to_f32(uint8_t b)
+{
+    const uint32_t e = (b >> 3) & 15u, m = b & 7u;
+    float v;
+    if (e == 15u && m == 7u) return bits_f32(((uint32_t)(b & 0x80u) << 24) | 0x7FC00000u);
+    if (e == 0u) v = (float)m * (1.0f / 512.0f);                            /* m * 2^-9 */
+    else v = bits_f32(((e + 120u) << 23) | (m << 20));
+    return (b & 0x80u) ? -v : v;
+}
+ORACLE_API float oracle_e5m2_to_f32(uint8_t b) { return oracle_f16_to_f32((uint16_t)((uint16_t)b << 8)); }
+ORACLE_API void oracle_convert_f32_to_fp8(const float *src, uint8_t *dst, uint64_t n, int e5m2)
+{ for (uint64_t i = 0; i < n; ++i) dst[i] = e5m2 ? oracle_f32_to_e5m2(src[i]) : oracle_f32_to_e4m3(src[i]); }
+ORACLE_API void oracle_convert_fp8_to_f32(const uint8_t *src, float *dst, uint64_t n, int e5m2)
+{ for (uint64_t i = 0; i < n; ++i) dst[i] = e5m2 ? oracle_e5m2_to_f32(src[i]) : oracle_e4m3_to_f32(src[i]); }
+
 /* dtype codes shared with include/mi355cube.h (MI355_DTYPE_*) */
-enum { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
+enum { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2, DT_F8E4M3 = 10, DT_F8E5M2 = 11 };
 
 static inline float load_elem(const void *p, int dtype, int64_t idx)
 {
     switch (dtype) {
     case DT_F32:  return ((const float *)p)[idx];
     case DT_BF16: return oracle_bf16_to_f32(((const uint16_t *)p)[idx]);
+    case DT_F8E4M3: return oracle_e4m3_to_f32(((const uint8_t *)p)[idx]);
+    case DT_F8E5M2: return oracle_e5m2_to_f32(((const uint8_t *)p)[idx]);
     default:      return oracle_f16_to_f32(((const uint16_t *)p)[idx]);
     }
 }
@@ -146,6 +198,8 @@ static inline void store_elem(void *p, int dtype, int64_t idx, double v)
     switch (dtype) {
     case DT_F32:  ((float *)p)[idx] = (float)v; break;
     case DT_BF16: ((uint16_t *)p)[idx] = oracle_f32_to_bf16((float)v); break;
+    case DT_F8E4M3: ((uint8_t *)p)[idx] = oracle_f32_to_e4m3((float)v); break;
+    case DT_F8E5M2: ((uint8_t *)p)[idx] = oracle_f32_to_e5m2((float)v); break;
     default:      ((uint16_t *)p)[idx] = oracle_f32_to_f16((float)v); break;
     }
 }

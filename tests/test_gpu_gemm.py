@@ -6,6 +6,7 @@ Tolerances (written here, per BASELINE.json "within 1e-5 relative for f32"):
     (already rounded) inputs -- MFMA products are exact in f32, only the summation order differs;
   * 16-bit outputs: within one unit in the last place of the 16-bit format.
 """
+import ctypes as C
 import json
 from pathlib import Path
 
@@ -25,6 +26,9 @@ ALGOS = {"auto": N.GEMM_ALGO_AUTO, "generic": N.GEMM_ALGO_GENERIC, "f32": N.GEMM
 def _to_dev(client, oracle, x, dtype):
     if dtype == ElemType.F32:
         return TensorHandle.from_numpy(client, x.astype(np.float32)), x.astype(np.float32)
+    if dtype in (ElemType.F8E4M3, ElemType.F8E5M2):
+        bits = oracle.to_fp8(x, int(dtype))
+        return TensorHandle.from_numpy(client, bits, dtype), oracle.from_fp8(bits, int(dtype))
     bits = oracle.to_bf16(x) if dtype == ElemType.BF16 else oracle.to_f16(x)
     back = oracle.from_bf16(bits) if dtype == ElemType.BF16 else oracle.from_f16(bits)
     return TensorHandle.from_numpy(client, bits, dtype), back
@@ -507,3 +511,105 @@ def test_auto_selection_and_errors(client):
     ops.matmul(client, TensorHandle.new_contiguous((8, 0), client.empty(0), ElemType.F32),
                TensorHandle.new_contiguous((0, 8), client.empty(0), ElemType.F32), c)
     assert not c.to_numpy(client).any()
+
+
+# ---- OCP FP8 operands (v_mfma_f32_32x32x64_f8f6f4 inside the 256x256 kernel; generic kernel for the rest) ---------
+F8 = [ElemType.F8E4M3, ElemType.F8E5M2]
+
+
+@pytest.mark.parametrize("dtype", F8)
+def test_fp8_fill_and_casts_match_the_oracle_bit_for_bit(client, oracle, dtype):
+    n = 1 << 16
+    t = TensorHandle.uniform(client, (n,), dtype, 0x5EEDC0BE, 77, -3.0, 3.0)
+    want = oracle.to_fp8(oracle.fill_uniform(n, 77, -3.0, 3.0), int(dtype))
+    assert np.array_equal(t.to_numpy(client), want)
+    # f32 -> fp8: specials, saturation, subnormals, ties; fp8 -> f32: every encoding
+    codes = np.arange(256, dtype=np.uint8)
+    dec = oracle.from_fp8(codes, int(dtype))
+    pos = dec[:128][np.isfinite(dec[:128])]
+    mids = ((pos[:-1].astype(np.float64) + pos[1:].astype(np.float64)) / 2).astype(np.float32)
+    x = np.concatenate([np.float32([0.0, -0.0, np.inf, -np.inf, np.nan, 1e30, -1e30, 448.0, 449.0, 464.0, 465.0, 57344.0, 61440.0,
+                                    1e-10, -1e-10, 2.0 ** -10, 2.0 ** -17]), mids, -mids,
+                        np.nextafter(mids, np.float32(0)), np.nextafter(mids, np.float32(1e9)),
+                        oracle.fill_uniform(4096, 78, -500.0, 500.0)]).astype(np.float32)
+    src = TensorHandle.from_numpy(client, x)
+    dst = client.empty(x.size)
+    client._s.check(client.lib.mi355_cast(client.ctx, None, src.device_ptr(), N.DTYPE_F32, dst.device_ptr(), int(dtype), x.size))
+    got = client.read_one(dst).view(np.uint8)[: x.size]
+    assert np.array_equal(got, oracle.to_fp8(x, int(dtype)))
+    back = client.empty(256 * 4)
+    csrc = TensorHandle.from_numpy(client, codes, dtype)
+    client._s.check(client.lib.mi355_cast(client.ctx, None, csrc.device_ptr(), int(dtype), back.device_ptr(), N.DTYPE_F32, 256))
+    gotf = client.read_one(back).view(np.float32)[:256]
+    assert np.array_equal(np.isnan(gotf), np.isnan(dec)) and np.array_equal(gotf[~np.isnan(dec)], dec[~np.isnan(dec)])
+
+
+@pytest.mark.parametrize("dtype", F8)
+@pytest.mark.parametrize("m,n,k", [(3, 5, 7), (65, 67, 130), (64, 64, 256)])
+def test_fp8_generic_kernel_is_bit_exact_against_the_f32_loop(client, oracle, dtype, m, n, k):
+    # products of fp8 values are exact in f32, so the generic kernel's fma chain equals the reference loop
+    # (test_simple_cube_expected, cmma.rs:695-722) bit for bit, in k order
+    a = oracle.to_fp8(oracle.fill_uniform(m * k, 90, -1.0, 1.0), int(dtype))
+    b = oracle.to_fp8(oracle.fill_uniform(n * k, 91, -1.0, 1.0), int(dtype))
+    ta = TensorHandle.new(client.create_from_slice(a), (m, k), (k, 1), dtype)
+    tb = TensorHandle.new(client.create_from_slice(b), (k, n), (1, k), dtype)
+    c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 4), ElemType.F32)
+    ops.matmul(client, ta, tb, c, algo=N.GEMM_ALGO_GENERIC)
+    want = oracle.gemm(a, b, m, n, k, dtype_ab=int(dtype), trans_b=True)
+    assert np.array_equal(c.to_numpy(client).reshape(-1), want)
+
+
+@pytest.mark.parametrize("dtype", F8)
+@pytest.mark.parametrize("out", [ElemType.F32, ElemType.BF16, ElemType.F16])
+@pytest.mark.parametrize("m,n,k", [(256, 256, 128), (256, 512, 384), (512, 768, 1024), (300, 504, 256), (5, 4096, 512)])
+def test_fp8_mfma_parity(client, oracle, dtype, out, m, n, k):
+    d = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=k, ldc=n, dtype_ab=int(dtype), dtype_c=int(out), trans_b=1)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    run_case(client, oracle, m, n, k, dtype, out, True, N.GEMM_ALGO_AUTO)
+
+
+def test_fp8_identity_returns_operand_values_and_batches(client, oracle):
+    m = n = 256
+    k = 512
+    for dtype, one in ((ElemType.F8E4M3, 0x38), (ElemType.F8E5M2, 0x3C)):
+        eye = np.zeros((m, k), dtype=np.uint8)
+        eye[np.arange(m), np.arange(m) * 2 + 1] = one                           # row i picks k = 2i + 1
+        bbits = oracle.to_fp8(oracle.fill_uniform(3 * n * k, 92, -300.0, 300.0), int(dtype)).reshape(3, n, k)
+        a = TensorHandle.new(client.create_from_slice(eye), (3, m, k), (0, k, 1), dtype)     # broadcast A
+        b = TensorHandle.new(client.create_from_slice(bbits), (3, k, n), (n * k, 1, k), dtype)
+        c = TensorHandle.new_contiguous((3, m, n), client.empty(3 * m * n * 4), ElemType.F32)
+        ops.matmul(client, a, b, c, algo=N.GEMM_ALGO_LP_256W4)
+        got = c.to_numpy(client)
+        want = oracle.from_fp8(bbits, int(dtype))[:, :, 1::2].transpose(0, 2, 1)              # C[b][i][j] = B[b][j][2i+1]
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("dtype", F8)
+def test_fp8_other_layouts_go_through_relayout_or_generic(client, oracle, dtype):
+    # row-major B, ragged K, padded / unaligned rows, transposed A: re-laid out into scratch, then the MFMA kernel
+    d = N.GemmDesc(m=512, n=512, k=512, batch=1, lda=512, ldb=512, ldc=512, dtype_ab=int(dtype), dtype_c=N.DTYPE_F32, trans_b=0)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    run_case(client, oracle, 512, 512, 512, dtype, ElemType.F32, False, N.GEMM_ALGO_AUTO)
+    run_case(client, oracle, 300, 260, 200, dtype, ElemType.F32, True, N.GEMM_ALGO_AUTO)             # ragged K
+    run_case(client, oracle, 256, 256, 256, dtype, ElemType.BF16, True, N.GEMM_ALGO_AUTO, lda=259, ldb=263, ldc=272)
+    run_case(client, oracle, 256, 384, 256, dtype, ElemType.F32, True, N.GEMM_ALGO_AUTO, batch=3, bcast_b=True)
+    run_case(client, oracle, 16, 16, 32, dtype, ElemType.F32, True, N.GEMM_ALGO_AUTO)                # tiny: generic
+    # bitwise repeatability (race screen) of the MFMA path
+    a = TensorHandle.uniform(client, (1024, 2048), dtype, 1, 93, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (1024, 2048), dtype, 1, 94, -1.0, 1.0)
+    bt = TensorHandle.new(b.handle, (2048, 1024), (1, 2048), dtype)
+    c1 = TensorHandle.new_contiguous((1024, 1024), client.empty(4 << 20), ElemType.F32)
+    c2 = TensorHandle.new_contiguous((1024, 1024), client.empty(4 << 20), ElemType.F32)
+    ops.matmul(client, a, bt, c1)
+    first = c1.to_numpy(client).copy()
+    for _ in range(5):
+        ops.matmul(client, a, bt, c2)
+        assert np.array_equal(c2.to_numpy(client), first)
+
+
+def test_fp8_rejects_what_it_does_not_do(client):
+    d = dict(m=256, n=256, k=256, batch=1, lda=256, ldb=256, ldc=256, trans_b=1)
+    a = client.empty(1 << 16)
+    with pytest.raises(ServerError):        # fp8 output is not produced by the GEMM
+        client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(N.GemmDesc(dtype_ab=N.DTYPE_F8E4M3, dtype_c=N.DTYPE_F8E4M3, **d)),
+                                              a.device_ptr(), a.device_ptr(), a.device_ptr()))

@@ -101,6 +101,74 @@ def test_bf16_conversion_matches_torch(oracle):
 
 
 # ---- reductions -----------------------------------------------------------------------------------------
+# ---- OCP FP8 (crates/cubecl-common/src/float/fp8/fp8_e4m3.rs, fp8_e5m2.rs; float8 0.7.0 underneath) --------
+def test_fp8_known_answers_of_the_reference_tests(oracle):
+    E4, E5 = oracle.DT_F8E4M3, oracle.DT_F8E5M2
+    f = lambda *v: np.array(v, dtype=np.float32)
+    # fp8_e4m3.rs:302-316 max_is_the_largest_finite_value / min_is_max_negated; MAX = 0x7E, NAN = S.1111.111 (:36-64)
+    assert oracle.from_fp8(oracle.to_fp8(f(448.0), E4), E4)[0] == 448.0
+    assert oracle.from_fp8(oracle.to_fp8(f(np.finfo(np.float32).max), E4), E4)[0] == 448.0
+    assert oracle.to_fp8(f(448.0), E4)[0] == 0x7E and np.isnan(oracle.from_fp8(np.array([0x7F], np.uint8), E4)[0])
+    assert oracle.from_fp8(np.array([0xFE], np.uint8), E4)[0] == -448.0
+    assert oracle.to_fp8(f(np.inf, -np.inf), E4).tolist() == [0x7E, 0xFE]          # "infinities included, saturate"
+    # fp8_e5m2.rs:307-335: MAX = 0x7B = 57344, the step past MAX is infinity, six NaN encodings (:115)
+    assert oracle.from_fp8(oracle.to_fp8(f(57344.0), E5), E5)[0] == 57344.0
+    assert oracle.from_fp8(oracle.to_fp8(f(np.finfo(np.float32).max), E5), E5)[0] == 57344.0
+    assert oracle.to_fp8(f(57344.0), E5)[0] == 0x7B and np.isinf(oracle.from_fp8(np.array([0x7C], np.uint8), E5)[0])
+    assert oracle.from_fp8(np.array([0xFB], np.uint8), E5)[0] == -57344.0
+    nan5 = np.isnan(oracle.from_fp8(np.arange(256, dtype=np.uint8), E5))
+    assert np.flatnonzero(nan5).tolist() == [0x7D, 0x7E, 0x7F, 0xFD, 0xFE, 0xFF]
+    nan4 = np.isnan(oracle.from_fp8(np.arange(256, dtype=np.uint8), E4))
+    assert np.flatnonzero(nan4).tolist() == [0x7F, 0xFF]
+    # NaN stays NaN, zero keeps its sign, ONE = 0x38 / 0x3C
+    for dt, one in ((E4, 0x38), (E5, 0x3C)):
+        assert np.isnan(oracle.from_fp8(oracle.to_fp8(f(np.nan), dt), dt)[0])
+        assert oracle.to_fp8(f(0.0, -0.0, 1.0, -1.0), dt).tolist() == [0x00, 0x80, one, 0x80 | one]
+
+
+@pytest.mark.parametrize("name", ["e4m3", "e5m2"])
+def test_fp8_conversion_matches_torch_and_round_trips(oracle, name):
+    torch = pytest.importorskip("torch")
+    dt, tdt, mx = {"e4m3": (oracle.DT_F8E4M3, torch.float8_e4m3fn, 448.0),
+                   "e5m2": (oracle.DT_F8E5M2, torch.float8_e5m2, 57344.0)}[name]
+    codes = np.arange(256, dtype=np.uint8)
+    dec = oracle.from_fp8(codes, dt)
+    # decode: every encoding equals torch's independent table (NaNs compared as NaNs)
+    tdec = torch.arange(256, dtype=torch.uint8).view(tdt).float().numpy()
+    assert np.array_equal(np.isnan(dec), np.isnan(tdec)) and np.array_equal(dec[~np.isnan(dec)], tdec[~np.isnan(tdec)])
+    # every finite encoding round-trips; decoded values are strictly increasing over the positive codes
+    fin = np.isfinite(dec)
+    assert np.array_equal(oracle.to_fp8(dec[fin], dt), codes[fin])
+    pos = dec[:128][np.isfinite(dec[:128])]
+    assert np.all(np.diff(pos) > 0)
+    # encode: round-to-nearest-even agrees with torch on random in-range values, on every midpoint between two
+    # neighbouring encodings (the ties) and just beside them; torch does not saturate, so only |x| <= MAX
+    rng = np.random.default_rng(7)
+    mids = ((pos[:-1].astype(np.float64) + pos[1:].astype(np.float64)) / 2).astype(np.float32)
+    x = np.concatenate([rng.uniform(-mx, mx, 100000), rng.normal(0, 1, 100000), rng.uniform(-2.0 ** -5, 2.0 ** -5, 100000),
+                        mids, -mids, np.nextafter(mids, np.float32(0)), np.nextafter(mids, np.float32(1e9))]).astype(np.float32)
+    x = x[np.abs(x) <= mx]
+    ref = torch.from_numpy(x).to(tdt).view(torch.uint8).numpy()
+    assert np.array_equal(oracle.to_fp8(x, dt), ref)
+    # above MAX everything saturates (the reference's contract; torch's e4m3fn would give NaN there)
+    big = np.array([mx * 1.0001, mx * 1.5, 1e30, -1e30], dtype=np.float32)
+    assert oracle.to_fp8(big, dt).tolist() == [oracle.to_fp8(np.float32([mx]), dt)[0]] * 3 + [0x80 | oracle.to_fp8(np.float32([mx]), dt)[0]]
+
+
+def test_fp8_gemm_is_exact_in_f32_for_small_k(oracle):
+    # products of two 4-bit significands are exact in f32 and so are short sums of them: the f32 loop of
+    # test_simple_cube_expected (cmma.rs:695-722) and the f64 oracle agree bit for bit
+    rng = np.random.default_rng(3)
+    m, n, k = 8, 12, 32
+    a = oracle.to_fp8(rng.uniform(-1, 1, m * k).astype(np.float32))
+    b = oracle.to_fp8(rng.uniform(-1, 1, n * k).astype(np.float32))
+    c32 = oracle.gemm(a, b, m, n, k, dtype_ab=oracle.DT_F8E4M3, trans_b=True)
+    c64 = oracle.gemm(a, b, m, n, k, dtype_ab=oracle.DT_F8E4M3, trans_b=True, acc_f64=True)
+    ref = oracle.from_fp8(a).reshape(m, k).astype(np.float64) @ oracle.from_fp8(b).reshape(n, k).astype(np.float64).T
+    assert np.array_equal(c64.reshape(m, n), ref.astype(np.float32))
+    assert np.allclose(c32, c64, rtol=0, atol=1e-5)
+
+
 def test_sum_things_input(oracle):
     # examples/sum_things/src/lib.rs:180: [-1, 10, 1, 5] -> 15
     x = np.array([-1.0, 10.0, 1.0, 5.0], dtype=np.float32)
