@@ -56,6 +56,15 @@ class MmaConfig(C.Structure):
                 ("a_type", C.c_int32), ("b_type", C.c_int32), ("cd_type", C.c_int32)]
 
 
+class MemoryUsage(C.Structure):
+    """mi355_memory_usage (MemoryUsage of memory_management/base.rs:8-28 + driver-call counters)."""
+    _fields_ = [(n, C.c_uint64) for n in ("number_allocs", "bytes_in_use", "bytes_padding", "bytes_reserved",
+                                          "driver_allocs", "driver_frees", "cache_hits", "reserved")]
+
+
+ALLOC_MODE_AUTO, ALLOC_MODE_PERSISTENT = 0, 1
+
+
 class DeviceProps(C.Structure):
     _fields_ = [
         ("abi_version", C.c_uint32), ("device_index", C.c_int32),
@@ -103,6 +112,11 @@ PROTOTYPES = {
     "mi355_alloc": (C.c_int32, [_P, C.c_uint64, _PP]),
     "mi355_free": (C.c_int32, [_P, _P]),
     "mi355_mem_info": (C.c_int32, [_P, _U64P, _U64P]),
+    "mi355_pool_alloc": (C.c_int32, [_P, _P, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "mi355_pool_free": (C.c_int32, [_P, _P, _P]),
+    "mi355_pool_cleanup": (C.c_int32, [_P, C.c_int32]),
+    "mi355_pool_mode": (C.c_int32, [_P, C.c_int32]),
+    "mi355_pool_usage": (C.c_int32, [_P, C.POINTER(MemoryUsage)]),
     "mi355_pitched_row_bytes": (C.c_int32, [_P, C.c_uint64, _U64P]),
     "mi355_pinned_alloc": (C.c_int32, [_P, C.c_uint64, _PP]),
     "mi355_pinned_free": (C.c_int32, [_P, _P]),

@@ -32,6 +32,8 @@ struct mi355_profile_slot {
     bool live;
 };
 
+namespace mi355 { struct memory_pool; }   // pool.cpp
+
 // One per DeviceId; the reference's HipServer + HipContext
 // (crates/cubecl-hip/src/compute/server.rs:151-161).
 struct mi355_ctx {
@@ -52,6 +54,7 @@ struct mi355_ctx {
     bool capturing = false;                // a hipStream capture window is open (graph API)
     // library-owned device scratch per (stream, kind): split-K slabs, re-laid-out GEMM operands
     std::map<std::pair<hipStream_t, int>, std::pair<void *, size_t>> scratch;
+    mi355::memory_pool *pool = nullptr;    // caching allocator behind mi355_pool_* (pool.cpp)
     uint64_t func_attr_mask = 0;  // kernels whose dynamic-LDS attribute is already raised on this device
 };
 
@@ -65,6 +68,11 @@ int32_t map_hip_error(hipError_t e);
 // contract: crates/cubecl-hip/src/compute/server.rs:263-269).
 void check_launch(mi355_ctx *ctx, const char *what);
 bool rccl_available();  // comm.cpp
+// pool.cpp
+int32_t pool_alloc(mi355_ctx *ctx, hipStream_t stream, uint64_t bytes, void **out);
+int32_t pool_free(mi355_ctx *ctx, hipStream_t stream, void *ptr);
+int32_t pool_cleanup(mi355_ctx *ctx, int32_t explicit_);
+void pool_destroy(mi355_ctx *ctx);
 inline hipStream_t stream_of(mi355_ctx *ctx, mi355_stream s)
 {
     return s ? reinterpret_cast<hipStream_t>(s) : ctx->compute_stream;

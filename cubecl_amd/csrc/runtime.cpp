@@ -224,6 +224,7 @@ MI355_API int32_t mi355_ctx_destroy(mi355_ctx *ctx)
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
     for (void *p : ctx->pending_free) hipFree(p);
+    pool_destroy(ctx);
     for (auto &s : ctx->profiles)
         if (s.live) { hipEventDestroy(s.start); hipEventDestroy(s.stop); }
     if (ctx->fence_a) hipEventDestroy(ctx->fence_a);

@@ -108,17 +108,18 @@ class ServerError(RuntimeError):
 # handles
 # ----------------------------------------------------------------------------------------------
 class _Memory:
-    """Server-side storage slot (GpuStorage resource); freed when the last Handle drops."""
+    """A reservation from the server's memory pool (ManagedMemoryHandle); goes back to the pool when the last
+    Handle drops, on the stream the client works on, so the pool may hand it out again stream-ordered."""
 
-    __slots__ = ("server", "ptr", "size", "__weakref__")
+    __slots__ = ("server", "ptr", "size", "stream", "__weakref__")
 
-    def __init__(self, server: "_Server", ptr: int, size: int):
-        self.server, self.ptr, self.size = server, ptr, size
+    def __init__(self, server: "_Server", ptr: int, size: int, stream=None):
+        self.server, self.ptr, self.size, self.stream = server, ptr, size, stream
 
     def __del__(self):
         try:
             if self.ptr and self.server is not None and self.server.ctx:
-                self.server.lib.mi355_free(self.server.ctx, C.c_void_p(self.ptr))
+                self.server.lib.mi355_pool_free(self.server.ctx, self.stream, C.c_void_p(self.ptr))
         except Exception:
             pass
 
@@ -312,9 +313,10 @@ class ComputeClient:
 
     # -- memory ------------------------------------------------------------------------------
     def empty(self, size: int) -> Handle:
+        """client.empty: a reservation from the memory pool (memory_manage.rs:1084), not a driver allocation."""
         ptr = C.c_void_p()
-        self._s.check(self.lib.mi355_alloc(self.ctx, size, C.byref(ptr)))
-        return Handle(_Memory(self._s, ptr.value or 0, size), None, None, size)
+        self._s.check(self.lib.mi355_pool_alloc(self.ctx, self.stream, size, C.byref(ptr)))
+        return Handle(_Memory(self._s, ptr.value or 0, size, self.stream), None, None, size)
 
     def create_from_slice(self, data) -> Handle:
         buf = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
@@ -430,9 +432,22 @@ class ComputeClient:
         self._s.check(self.lib.mi355_sync(self.ctx, self.stream))
 
     def memory_usage(self) -> dict:
+        """client.memory_usage(): MemoryUsage of the pool (memory_management/base.rs:8-28) plus the device totals."""
+        u = N.MemoryUsage()
+        self._s.check(self.lib.mi355_pool_usage(self.ctx, C.byref(u)))
         free, total = C.c_uint64(), C.c_uint64()
         self._s.check(self.lib.mi355_mem_info(self.ctx, C.byref(free), C.byref(total)))
-        return {"bytes_free": free.value, "bytes_total": total.value, "bytes_in_use": total.value - free.value}
+        out = {name: int(getattr(u, name)) for name, _ in N.MemoryUsage._fields_ if name != "reserved"}
+        out.update(device_bytes_free=free.value, device_bytes_total=total.value)
+        return out
+
+    def memory_cleanup(self) -> None:
+        """client.memory_cleanup(): give everything the pool holds and nobody uses back to the driver."""
+        self._s.check(self.lib.mi355_pool_cleanup(self.ctx, 1))
+
+    def allocation_mode(self, mode: int) -> None:
+        """client.allocation_mode(MemoryAllocationMode): N.ALLOC_MODE_AUTO / N.ALLOC_MODE_PERSISTENT."""
+        self._s.check(self.lib.mi355_pool_mode(self.ctx, mode))
 
     def profile(self, fn, name: str = ""):
         """client.profile(closure, name): returns (result, device nanoseconds)."""

@@ -169,6 +169,37 @@ int32_t mi355_alloc(mi355_ctx *ctx, uint64_t bytes, void **out_dptr);
 /* ComputeStorage::dealloc: deferred until mi355_flush. */
 int32_t mi355_free(mi355_ctx *ctx, void *dptr);
 int32_t mi355_mem_info(mi355_ctx *ctx, uint64_t *out_free, uint64_t *out_total);
+
+/* ----- memory pool: what ComputeClient::empty / create reserve from ---------------------------
+ * MemoryManagement of the reference (crates/cubecl-runtime/src/memory_management/memory_manage.rs):
+ * `reserve` (:1084), `cleanup` (:938), `memory_usage` (:1238), `mode` (:900).  A stream-ordered
+ * caching allocator: requests up to 32 MiB are slices of quarter-octave size classes carved out of
+ * slab pages, larger ones exclusive pages (2 MiB granules) cached by size when freed.  A freed block
+ * is reused at once by the stream it was freed on and by other streams once that stream has passed
+ * the free point (an event, never a device synchronisation).  Cached exclusive pages go back to the
+ * driver after 5000 x (1 + size / 1 GiB) reservations without reuse (:242, :641-651) or on an
+ * explicit cleanup; nothing is released and no driver allocation is made inside a graph-capture
+ * window (:948-952) -- a request that would need one fails with MI355_E_UNSUPPORTED.
+ * mi355_alloc / mi355_free above stay the raw ComputeStorage page calls. */
+enum {
+    MI355_ALLOC_MODE_AUTO = 0,       /* MemoryAllocationMode::Auto (memory_manage.rs:155-162) */
+    MI355_ALLOC_MODE_PERSISTENT = 1  /* ::Persistent: exact-size pages that periodic cleanup never releases */
+};
+typedef struct {
+    uint64_t number_allocs;  /* MemoryUsage (memory_management/base.rs:8-28): live reservations     */
+    uint64_t bytes_in_use;   /* bytes requested by them                                              */
+    uint64_t bytes_padding;  /* rounding on top of that                                              */
+    uint64_t bytes_reserved; /* device memory the pool holds (in use + cached)                       */
+    uint64_t driver_allocs;  /* additions: hipMalloc / hipFree calls made and requests served from   */
+    uint64_t driver_frees;   /* the cache since the context was created                              */
+    uint64_t cache_hits;
+    uint64_t reserved;
+} mi355_memory_usage;
+int32_t mi355_pool_alloc(mi355_ctx *ctx, mi355_stream stream, uint64_t bytes, void **out_dptr);
+int32_t mi355_pool_free(mi355_ctx *ctx, mi355_stream stream, void *dptr);
+int32_t mi355_pool_cleanup(mi355_ctx *ctx, int32_t explicit_cleanup);
+int32_t mi355_pool_mode(mi355_ctx *ctx, int32_t mode);
+int32_t mi355_pool_usage(mi355_ctx *ctx, mi355_memory_usage *out);
 /* MemoryLayoutPolicy::apply for a rank>=2 tensor (crates/cubecl-runtime/src/allocator.rs:21-72):
  * returns the row pitch in bytes for rows of `width_bytes`. */
 int32_t mi355_pitched_row_bytes(mi355_ctx *ctx, uint64_t width_bytes, uint64_t *out_pitch);

@@ -65,7 +65,8 @@ def test_zeros_and_memory_usage(client):
     t = TensorHandle.zeros(client, (33, 17), ElemType.F32)
     assert not t.to_numpy(client).any()
     usage = client.memory_usage()
-    assert usage["bytes_total"] > 0 and usage["bytes_in_use"] > 0
+    assert usage["device_bytes_total"] > 0 and usage["bytes_in_use"] >= 33 * 17 * 4 and usage["number_allocs"] >= 1
+    assert usage["bytes_reserved"] >= usage["bytes_in_use"] + usage["bytes_padding"]
     client.flush()
 
 
@@ -366,3 +367,184 @@ def test_graph_capture_and_replay_of_a_launch_bound_sequence(client, oracle):
     client.sync()
     assert np.array_equal(cf.to_numpy(client), eager[0])
     client.graph_destroy(g2)
+
+
+# ---- memory pool (MemoryManagement: reserve / cleanup / memory_usage / mode, memory_manage.rs:900-1260) -----------
+def _usage(client):
+    u = N.MemoryUsage()
+    client._s.check(client.lib.mi355_pool_usage(client.ctx, C.byref(u)))
+    return u
+
+
+def _palloc(client, nbytes, stream=None):
+    p = C.c_void_p()
+    client._s.check(client.lib.mi355_pool_alloc(client.ctx, stream, nbytes, C.byref(p)))
+    return p.value or 0
+
+
+def _pfree(client, ptr, stream=None):
+    client._s.check(client.lib.mi355_pool_free(client.ctx, stream, C.c_void_p(ptr)))
+
+
+def test_pool_reuses_freed_blocks_without_driver_calls_and_accounts_usage(client):
+    lib, ctx = client.lib, client.ctx
+    client.sync()
+    client.memory_cleanup()                                      # start from an empty cache (other tests' pages)
+    base = _usage(client)
+    sizes = [1, 511, 512, 513, 1000, 4096, 5000, 1 << 20, (1 << 20) + 1, 3 << 20, 32 << 20, (32 << 20) + 1, 100 << 20]
+    ptrs = [_palloc(client, n) for n in sizes]
+    assert len(set(ptrs)) == len(ptrs) and all(p and p % 256 == 0 for p in ptrs)
+    u = _usage(client)
+    assert u.number_allocs - base.number_allocs == len(sizes)
+    assert u.bytes_in_use - base.bytes_in_use == sum(sizes)
+    pad = u.bytes_padding - base.bytes_padding
+    # slices: quarter-octave classes (< 25 % + the 512-byte floor); exclusive pages: < 2 MiB each
+    assert pad <= sum(max(n // 4, 512) if n <= (32 << 20) else (2 << 20) for n in sizes)
+    # live blocks do not alias: distinct patterns survive
+    for i, (p, n) in enumerate(zip(ptrs, sizes)):
+        client._s.check(lib.mi355_memset(ctx, None, C.c_void_p(p), 0x10 + i, n))
+    for i, (p, n) in enumerate(zip(ptrs, sizes)):
+        host = np.empty(min(n, 4096), dtype=np.uint8)
+        client._s.check(lib.mi355_read(ctx, None, C.c_void_p(p + n - host.size), host.ctypes.data_as(C.c_void_p), host.size))
+        assert np.all(host == 0x10 + i)
+    for p in ptrs:
+        _pfree(client, p)
+    mid = _usage(client)
+    assert mid.number_allocs == base.number_allocs and mid.bytes_in_use == base.bytes_in_use
+    assert mid.bytes_reserved >= u.bytes_reserved - 0 and mid.driver_frees == u.driver_frees   # nothing went back to the driver
+    # the same requests again: every one is a cache hit on the very same block, no hipMalloc
+    again = [_palloc(client, n) for n in sizes]
+    after = _usage(client)
+    assert sorted(again) == sorted(ptrs)
+    assert after.driver_allocs == mid.driver_allocs and after.cache_hits - mid.cache_hits == len(sizes)
+    for p in again:
+        _pfree(client, p)
+    # edge cases
+    assert _palloc(client, 0) == 0
+    with pytest.raises(ServerError) as e:
+        _pfree(client, 0xDEAD000)
+    assert e.value.code == N.E_NOT_FOUND
+    with pytest.raises(ServerError) as e:
+        _palloc(client, client.properties().max_page_size + 1)
+    assert e.value.code == N.E_BUFFER_TOO_BIG
+
+
+def test_pool_reuse_is_stream_ordered(client):
+    """A block freed on stream A while A still has work that touches it must not be handed to stream B until A has
+    passed the free point; stream A itself may have it back at once."""
+    lib, ctx = client.lib, client.ctx
+    s2 = C.c_void_p()
+    client._s.check(lib.mi355_stream_create(ctx, C.byref(s2)))
+    client.sync()
+    client.memory_cleanup()
+    S = 4096
+    a = TensorHandle.uniform(client, (S, S), ElemType.BF16, 1, 1, -1.0, 1.0)
+    n = S * S * 4
+    x = _palloc(client, n)                                       # 64 MiB: an exclusive page
+    d = N.GemmDesc(m=S, n=S, k=S, batch=1, lda=S, ldb=S, ldc=S, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_F32, trans_b=1)
+    client.sync()
+    for _ in range(40):                                          # ~5 ms of work on the default stream writing into x
+        client._s.check(lib.mi355_gemm(ctx, None, C.byref(d), a.device_ptr(), a.device_ptr(), C.c_void_p(x)))
+    _pfree(client, x)                                            # freed on the default stream, work still in flight
+    y = _palloc(client, n, s2)                                   # another stream: must NOT get x yet
+    z = _palloc(client, n)                                       # the freeing stream: gets x back at once
+    assert y != x and z == x
+    client.sync()
+    _pfree(client, z)
+    client.sync()
+    w = _palloc(client, n, s2)                                   # the event has completed: now stream 2 may reuse x
+    assert w == x
+    _pfree(client, w, s2)
+    _pfree(client, y, s2)
+    client._s.check(lib.mi355_sync(ctx, s2))
+    client._s.check(lib.mi355_stream_destroy(ctx, s2))
+
+
+def test_pool_cleanup_periodic_release_and_persistent_mode(client):
+    lib, ctx = client.lib, client.ctx
+    client.sync()
+    client.memory_cleanup()
+    base = _usage(client)
+    big = 96 << 20
+    p = _palloc(client, big)
+    q = _palloc(client, 3000)
+    _pfree(client, p)
+    held = _usage(client)
+    assert held.bytes_reserved - base.bytes_reserved >= big       # cached, not returned
+    client.memory_cleanup()                                       # explicit: cached page goes back; the live slice's page stays
+    after = _usage(client)
+    assert after.bytes_reserved <= held.bytes_reserved - big and after.driver_frees > held.driver_frees
+    assert after.number_allocs == base.number_allocs + 1
+    # periodic release: an exclusive page unused for 5000 x (1 + size / 1 GiB) reservations is returned (memory_manage.rs:641-651)
+    p = _palloc(client, big)
+    _pfree(client, p)
+    client.sync()
+    before = _usage(client)
+    for _ in range(6200):
+        _pfree(client, _palloc(client, 600))
+    late = _usage(client)
+    assert late.bytes_reserved <= before.bytes_reserved - big and late.driver_frees == before.driver_frees + 1
+    # persistent mode: exact-size pages (256-byte granules) that the periodic release never touches
+    client.allocation_mode(N.ALLOC_MODE_PERSISTENT)
+    w = _palloc(client, (5 << 20) + 300)
+    wu = _usage(client)
+    assert wu.bytes_padding - late.bytes_padding < 256
+    _pfree(client, w)
+    client.allocation_mode(N.ALLOC_MODE_AUTO)
+    client.sync()
+    for _ in range(6200):
+        _pfree(client, _palloc(client, 600))
+    assert _usage(client).bytes_reserved == wu.bytes_reserved     # still cached
+    client.allocation_mode(N.ALLOC_MODE_PERSISTENT)
+    assert _palloc(client, (5 << 20) + 300) == w                  # and handed out again for the same size
+    _pfree(client, w)
+    client.allocation_mode(N.ALLOC_MODE_AUTO)
+    _pfree(client, q)
+    client.memory_cleanup()
+    with pytest.raises(ServerError):
+        client.allocation_mode(7)
+
+
+def test_pool_inside_a_capture_window_serves_from_the_cache_only(client):
+    lib, ctx = client.lib, client.ctx
+    n = 48 << 20
+    p = _palloc(client, n)
+    _pfree(client, p)
+    client.sync()
+    client._s.check(lib.mi355_graph_begin_capture(ctx, None))
+    try:
+        q = _palloc(client, n)                                    # cached page: fine inside the window
+        assert q == p
+        with pytest.raises(ServerError) as e:                     # would need hipMalloc: refused, not a corrupted capture
+            _palloc(client, (777 << 20) + 12345)
+        assert e.value.code == N.E_UNSUPPORTED
+        client._s.check(lib.mi355_memset(ctx, None, C.c_void_p(q), 0x5A, n))
+        _pfree(client, q)
+    finally:
+        g = C.c_void_p()
+        client._s.check(lib.mi355_graph_end_capture(ctx, None, C.byref(g)))
+    client._s.check(lib.mi355_graph_replay(ctx, None, g))
+    client.sync()
+    host = np.empty(4096, dtype=np.uint8)
+    client._s.check(lib.mi355_read(ctx, None, C.c_void_p(p), host.ctypes.data_as(C.c_void_p), host.size))
+    assert np.all(host == 0x5A)
+    client._s.check(lib.mi355_graph_destroy(ctx, g))
+
+
+# ---- measured ceilings (examples/throughput; cubecl-std throughput/base.rs) -------------------------------------------
+def test_memory_curve_and_roofline_bounds(client):
+    from cubecl_amd import throughput as T
+    curve = T.measure_memory_curve(client, T.MemoryAccess.Read, cap=256 << 20)
+    pts = curve.points()
+    assert [p.bytes for p in pts] == [32768 << i for i in range(14)]          # 32 KiB .. 256 MiB
+    rates = [p.bytes_per_s for p in pts]
+    assert rates[0] < 0.2e12 < 2.0e12 < rates[-1] < 9.0e12                    # launch-bound at 32 KiB, HBM-bound at 256 MiB
+    assert all(b > 0.7 * a for a, b in zip(rates, rates[1:]))                 # grows (within noise) with the working set
+    assert curve.ceiling_at(48 << 10) == pytest.approx(rates[0] + (T._log2(48 << 10) - 15) * (rates[1] - rates[0]))
+    copy = T.measure_working_set(client, T.MemoryAccess.Copy, 1 << 30)
+    write = T.measure_working_set(client, T.MemoryAccess.Write, 512 << 20)
+    assert 3.0e12 < copy < 9.0e12 and 2.0e12 < write < 9.0e12
+    S = 8192
+    b = T.roofline_bounds(client, T.Work(2 * S ** 3, 3 * S * S * 2), T.Thresholds.uniform(0.5), curve=curve)
+    assert 1.5e15 < b.compute_ops_per_s < 2.7e15 and 1e-7 < b.launch_overhead_s < 2e-5
+    assert 0.7e-3 < b.time_limit() < 1.6e-3                                   # the 8192^3 bf16 GEMM must beat this to count as good

@@ -82,3 +82,35 @@ def test_value_types():
     assert sorted([DeviceId(0, 3), DeviceId(0, 1)])[0].index_id == 1
     assert ElemType.BF16.size() == 2 and ElemType.F32.size() == 4
     assert int(ReduceOperation.Sum) == 0 and int(ReduceOperation.Mean) == 1
+
+
+# ---- throughput curve host logic (crates/cubecl-runtime/src/throughput/curve.rs tests :186-259, ported) ------------
+def test_working_set_sweep_known_answers():
+    from cubecl_amd.throughput import MIN_WORKING_SET as m, working_set_sweep
+    assert working_set_sweep(8 * m) == [m, 2 * m, 4 * m, 8 * m]
+    assert working_set_sweep(12 * m) == [m, 2 * m, 4 * m, 8 * m]      # stops at the last power of two that fits
+    assert working_set_sweep(m // 4) == [m // 4]                       # below the minimum: the cap alone
+
+
+def test_memory_curve_interpolates_clamps_and_drops_unusable_points():
+    from cubecl_amd.throughput import MemoryAccess, MemoryCurve, MemoryPoint, _log2
+    MB = 1 << 20
+    curve = MemoryCurve(MemoryAccess.Read, [MemoryPoint(4 * MB, 200.0), MemoryPoint(MB, 100.0), MemoryPoint(MB, 999.0)])
+    assert [p.bytes for p in curve.points()] == [MB, 4 * MB] and curve.points()[0].bytes_per_s == 100.0
+    assert abs(curve.ceiling_at(2 * MB) - 150.0) < 1e-6                # geometric midpoint -> half the rate span
+    assert abs(curve.ceiling_at(MB) - 100.0) < 1e-6 and abs(curve.ceiling_at(4 * MB) - 200.0) < 1e-6
+    assert abs(curve.ceiling_at(1) - 100.0) < 1e-6 and abs(curve.ceiling_at(2 ** 64 - 1) - 200.0) < 1e-6
+    empty = MemoryCurve(MemoryAccess.Read, [MemoryPoint(MB, float("nan")), MemoryPoint(0, 5.0), MemoryPoint(MB, 0.0)])
+    assert empty.points() == () and empty.ceiling_at(MB) is None
+    assert _log2(1) == 0.0 and _log2(MB) == 20.0 and _log2(1 << 63) == 63.0 and _log2(0) == 0.0
+    assert _log2(2 * MB) < _log2(3 * MB) < _log2(4 * MB)
+
+
+def test_roofline_time_limit_is_the_slower_bound_plus_a_launch():
+    from cubecl_amd.throughput import Bounds, Thresholds, Work
+    w = Work(compute_ops=2 * 8192 ** 3, bytes=3 * 8192 * 8192 * 2)
+    b = Bounds(2.5e15, 8e12, 2e-6, w, Thresholds.uniform(0.5))
+    assert abs(b.time_limit() - (w.compute_ops / 2.5e15 / 0.5 + 2e-6)) < 1e-12      # compute bound
+    b = Bounds(2.5e15, 8e12, 2e-6, Work(10, 1 << 30), Thresholds(0.5, 0.8))
+    assert abs(b.time_limit() - ((1 << 30) / 8e12 / 0.8 + 2e-6)) < 1e-12             # memory bound
+    assert Bounds(1.0, 1.0, 0.0, w, Thresholds(0.0, float("nan"))).time_limit() is None
