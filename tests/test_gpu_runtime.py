@@ -405,7 +405,7 @@ def test_pool_reuses_freed_blocks_without_driver_calls_and_accounts_usage(client
         client._s.check(lib.mi355_memset(ctx, None, C.c_void_p(p), 0x10 + i, n))
     for i, (p, n) in enumerate(zip(ptrs, sizes)):
         host = np.empty(min(n, 4096), dtype=np.uint8)
-        client._s.check(lib.mi355_read(ctx, None, C.c_void_p(p + n - host.size), host.ctypes.data_as(C.c_void_p), host.size))
+        client._s.check(lib.mi355_read(ctx, None, host.ctypes.data_as(C.c_void_p), C.c_void_p(p + n - host.size), host.size))
         assert np.all(host == 0x10 + i)
     for p in ptrs:
         _pfree(client, p)
@@ -478,6 +478,7 @@ def test_pool_cleanup_periodic_release_and_persistent_mode(client):
     # periodic release: an exclusive page unused for 5000 x (1 + size / 1 GiB) reservations is returned (memory_manage.rs:641-651)
     p = _palloc(client, big)
     _pfree(client, p)
+    _pfree(client, _palloc(client, 600))                          # the slab page of the filler requests below exists from here on
     client.sync()
     before = _usage(client)
     for _ in range(6200):
@@ -526,7 +527,7 @@ def test_pool_inside_a_capture_window_serves_from_the_cache_only(client):
     client._s.check(lib.mi355_graph_replay(ctx, None, g))
     client.sync()
     host = np.empty(4096, dtype=np.uint8)
-    client._s.check(lib.mi355_read(ctx, None, C.c_void_p(p), host.ctypes.data_as(C.c_void_p), host.size))
+    client._s.check(lib.mi355_read(ctx, None, host.ctypes.data_as(C.c_void_p), C.c_void_p(p), host.size))
     assert np.all(host == 0x5A)
     client._s.check(lib.mi355_graph_destroy(ctx, g))
 
