@@ -42,7 +42,8 @@ DTYPE_F32, DTYPE_BF16, DTYPE_F16, DTYPE_F64, DTYPE_I32, DTYPE_U32, DTYPE_I64, DT
 DTYPE_SIZE = {DTYPE_F32: 4, DTYPE_BF16: 2, DTYPE_F16: 2, DTYPE_F64: 8, DTYPE_I32: 4, DTYPE_U32: 4, DTYPE_I64: 8,
               DTYPE_U64: 8, DTYPE_U8: 1, DTYPE_I8: 1}
 DTYPE_F8E4M3, DTYPE_F8E5M2 = 10, 11            # OCP FP8 (fp8_e4m3.rs / fp8_e5m2.rs of the reference)
-DTYPE_SIZE.update({DTYPE_F8E4M3: 1, DTYPE_F8E5M2: 1})
+DTYPE_F4E2M1X2, DTYPE_UE8M0 = 12, 13            # packed e2m1 pairs (one byte per pair), MX block scales
+DTYPE_SIZE.update({DTYPE_F8E4M3: 1, DTYPE_F8E5M2: 1, DTYPE_F4E2M1X2: 1, DTYPE_UE8M0: 1})
 
 REDUCE_SUM, REDUCE_MEAN, REDUCE_MAX, REDUCE_MIN = 0, 1, 2, 3
 PLANE_PROD, PLANE_INCLUSIVE_SUM, PLANE_EXCLUSIVE_SUM = 100, 101, 102
@@ -90,6 +91,13 @@ class GemmDesc(C.Structure):
         ("dtype_ab", C.c_int32), ("dtype_c", C.c_int32), ("trans_a", C.c_int32), ("trans_b", C.c_int32),
         ("algo", C.c_int32), ("reserved", C.c_int32),
     ]
+
+
+class GemmScaledDesc(C.Structure):
+    """mi355_gemm_scaled_desc."""
+    _fields_ = [(n, C.c_int64) for n in ("m", "n", "k", "batch", "lda", "ldb", "ldc", "ld_sa", "ld_sb", "stride_a", "stride_b",
+                                         "stride_c", "stride_sa", "stride_sb")] + \
+               [(n, C.c_int32) for n in ("dtype_a", "dtype_b", "dtype_c", "block", "algo", "reserved")]
 
 
 _P = C.c_void_p
@@ -147,6 +155,8 @@ PROTOTYPES = {
     "mi355_cast": (C.c_int32, [_P, _P, _P, C.c_int32, _P, C.c_int32, C.c_uint64]),
     "mi355_gemm": (C.c_int32, [_P, _P, C.POINTER(GemmDesc), _P, _P, _P]),
     "mi355_gemm_select": (C.c_int32, [_P, C.POINTER(GemmDesc), _I32P]),
+    "mi355_gemm_scaled": (C.c_int32, [_P, _P, C.POINTER(GemmScaledDesc), _P, _P, _P, _P, _P]),
+    "mi355_gemm_scaled_select": (C.c_int32, [_P, C.POINTER(GemmScaledDesc), _I32P]),
     "mi355_reduce_workspace_bytes": (C.c_int32, [_P, C.c_uint64, _U64P]),
     "mi355_reduce_sum_f32": (C.c_int32, [_P, _P, _P, C.c_uint64, _P, _P, C.c_uint64]),
     "mi355_argmax_f32": (C.c_int32, [_P, _P, _P, C.c_uint64, _P, _P, _P, C.c_uint64]),

@@ -51,6 +51,7 @@ __global__ void __launch_bounds__(256) fill_uniform_kernel(void *__restrict__ ds
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float v = rng_value(key, i, lo, scale);
         if (DTYPE == MI355_DTYPE_F32) static_cast<float *>(dst)[i] = v;
+        else if (DTYPE == MI355_DTYPE_U8) static_cast<uint8_t *>(dst)[i] = (uint8_t)(int)floorf(v);   // bytes: floor of the value
         else if (DTYPE == MI355_DTYPE_BF16) static_cast<uint16_t *>(dst)[i] = f32_to_bf16(v);
         else if (DTYPE == MI355_DTYPE_F8E4M3) static_cast<uint8_t *>(dst)[i] = f32_to_e4m3(v);
         else if (DTYPE == MI355_DTYPE_F8E5M2) static_cast<uint8_t *>(dst)[i] = f32_to_e5m2(v);
@@ -112,6 +113,11 @@ MI355_API int32_t mi355_fill_uniform(mi355_ctx *ctx, mi355_stream stream, void *
         break;
     case MI355_DTYPE_F16:
         hipLaunchKernelGGL(fill_uniform_kernel<MI355_DTYPE_F16>, dim3(grid), dim3(256), 0, s, dst, n, key, lo, scale);
+        break;
+    case MI355_DTYPE_U8:            // also what packed fp4 pairs and ue8m0 scales are filled as: n BYTES, floor(uniform[lo, hi))
+    case MI355_DTYPE_F4E2M1X2:
+    case MI355_DTYPE_UE8M0:
+        hipLaunchKernelGGL(fill_uniform_kernel<MI355_DTYPE_U8>, dim3(grid), dim3(256), 0, s, dst, n, key, lo, scale);
         break;
     case MI355_DTYPE_F8E4M3:
         hipLaunchKernelGGL(fill_uniform_kernel<MI355_DTYPE_F8E4M3>, dim3(grid), dim3(256), 0, s, dst, n, key, lo, scale);

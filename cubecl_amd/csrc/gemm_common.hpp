@@ -11,6 +11,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 namespace mi355 {
@@ -27,6 +28,8 @@ struct gemm_args {
     uint32_t batch_count;    // persistent kernel: tiles x batch form one linear tile sequence
     uint32_t split_k;        // > 1: blockIdx.z selects a K slice and an f32 partial slab (lp128 split-K)
     int64_t split_c_stride;  // elements between the partial slabs of consecutive K slices
+    const void *sa = nullptr, *sb = nullptr;   // MX: re-arranged ue8m0 scales ST[K-tile][padded row][blocks per K-tile row]
+    int64_t stride_sa = 0, stride_sb = 0;      // bytes between batch entries of those
 };
 
 // MI355X dispatches workgroup b to XCD b % 8, each XCD with a private 4 MiB L2
@@ -87,8 +90,12 @@ int32_t launch_gemm_lp256w4(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc
 int32_t launch_gemm_lp256p(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 bool gemm_lp256p_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 bool gemm_lp256w4_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
+// block-scaled (MX) form of the same kernel; sa_t / sb_t are the re-arranged scales (gemm_scaled.hip)
+bool gemm_lp256w4_mx_supports(const mi355_gemm_scaled_desc &d, const void *a, const void *b, const void *c);
+int32_t launch_gemm_lp256w4_mx(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_scaled_desc &d, const void *a, const void *sa_t,
+                               int64_t stride_sa_t, const void *b, const void *sb_t, int64_t stride_sb_t, void *c);
 // library-owned per-stream scratch + operand re-layout (gemm_relayout.hip)
-enum { SCRATCH_SPLITK = 0, SCRATCH_RELAYOUT_A = 1, SCRATCH_RELAYOUT_B = 2 };
+enum { SCRATCH_SPLITK = 0, SCRATCH_RELAYOUT_A = 1, SCRATCH_RELAYOUT_B = 2, SCRATCH_SCALE_A = 3, SCRATCH_SCALE_B = 4 };
 int32_t scratch_get(mi355_ctx *ctx, hipStream_t s, int kind, size_t bytes, void **out);
 void launch_transpose(hipStream_t s, const void *src, void *dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst,
                       int64_t batch, int64_t stride_src, int64_t stride_dst, int esz);

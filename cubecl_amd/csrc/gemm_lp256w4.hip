@@ -89,6 +89,25 @@ template <> struct lp<MI355_DTYPE_F8E5M2> {
     static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c)
     { return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 1, 1, 0, 0, 0, 0); }
 };
+// MX fp4 (e2m1, two per byte, first element in the low nibble): a lane's 16 bytes are 32 k-values = one MX block =
+// its whole share of a 32x32x64 step, which then takes 32 cycles (4x the bf16 rate).  The host hands the kernel the
+// BYTE matrix (k, lda, ldb, strides halved), so ESZ = 1 and a K-tile (128 bytes) is 256 k-values = 4 k-steps: the
+// bf16 schedule as is.  fp4 exists only block-scaled (there is no unscaled fp4 matrix instruction).
+template <> struct lp<MI355_DTYPE_F4E2M1X2> {
+    typedef i32x4 frag;
+    static constexpr int ESZ = 1;
+    static __device__ __forceinline__ f32x16 mfma(frag, frag, f32x16 c) { return c; }   // never used unscaled
+};
+// cbsz / blgp operand-format codes of v_mfma_scale_f32_32x32x64_f8f6f4
+template <int DT> struct mx_fmt { static constexpr int value = DT == MI355_DTYPE_F8E4M3 ? 0 : DT == MI355_DTYPE_F8E5M2 ? 1 : 4; };
+__device__ __forceinline__ i32x8 widen(i32x8 v) { return v; }
+__device__ __forceinline__ i32x8 widen(i32x4 v) { i32x8 w = {v[0], v[1], v[2], v[3], 0, 0, 0, 0}; return w; }   // fp4: the upper half is not read
+// D = C + (X .* 2^(sx-127)) (Y .* 2^(sy-127)): lane l scales its own 32 k-values with byte OPSEL of its scale register
+template <int FMT_X, int FMT_Y, int OPSEL, typename FX, typename FY>
+__device__ __forceinline__ f32x16 mfma_mx(FX x, FY y, f32x16 c, uint32_t sx, uint32_t sy)
+{
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(x), widen(y), c, FMT_X, FMT_Y, OPSEL, (int)sx, OPSEL, (int)sy);
+}
 template <> struct lp<MI355_DTYPE_F32> {
     typedef f32x4 frag;
     static constexpr int ESZ = 4;
@@ -155,13 +174,28 @@ __device__ unsigned long long w4_trace_buf[4096 * 8];
 // (1 KiB each = one DMA piece, no swizzle), and a B fragment is four ds_read_b32 (consecutive lanes ->
 // consecutive n: conflict free) instead of one ds_read_b128 -- affordable because an f32 k-step holds 64
 // MFMAs of 64 cycles.
-template <int DT, int DT_C, bool BNN = false>
+// MX (block-scaled, one ue8m0 scale per 32 k-values; DTB = B's element type, fp8 formats may be mixed): the scales come
+// pre-arranged by gemm_scaled.cpp as ST[K-tile][row padded to the tile grid][NB bytes] (NB = 4 fp8 / 8 fp4 blocks per
+// K-tile row), so a lane's share -- the NB/2 blocks of its lane-half, contiguous -- is one coalesced 2- or 4-byte load
+// per 32-row block and K-tile, issued one K-tile ahead into a second register set.  These loads are inline asm like the
+// DMA (the compiler must not insert its own waits into the counted vmcnt stream).
+__device__ __forceinline__ void scale_ld16(uint32_t &dst, const void *ubase, uint32_t voff, int imm)
+{
+    asm volatile("global_load_ushort %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(ubase), "n"(imm) : "memory");
+}
+__device__ __forceinline__ void scale_ld32(uint32_t &dst, const void *ubase, uint32_t voff, int imm)
+{
+    asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(ubase), "n"(imm) : "memory");
+}
+
+template <int DT, int DT_C, bool BNN = false, int DTB = DT, bool MX = false>
 __global__ void __launch_bounds__(256)
 gemm_lp256w4_kernel(gemm_args g)
 {
     static_assert(!BNN || DT == MI355_DTYPE_F32, "row-major B is implemented for f32 only");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     typedef typename lp<DT>::frag frag;
+    static_assert(sizeof(typename lp<DTB>::frag) == sizeof(frag), "A and B fragments must have the same width");
 
     const int tid = threadIdx.x;
     W4_STAMP(0);
@@ -175,7 +209,10 @@ gemm_lp256w4_kernel(gemm_args g)
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
     const int64_t batch = blockIdx.y;
     constexpr int ESZ = lp<DT>::ESZ;
-    constexpr bool F8 = ESZ == 1;
+    constexpr bool F8 = DT == MI355_DTYPE_F8E4M3 || DT == MI355_DTYPE_F8E5M2;
+    constexpr bool F4 = DT == MI355_DTYPE_F4E2M1X2;
+    static_assert(!F4 || MX, "fp4 exists only block-scaled");
+    static_assert(!MX || F8 || F4, "block scaling is an fp8 / fp4 feature");
     constexpr int BK = ROW_BYTES / ESZ;                 // 128 (fp8) / 64 (16-bit) / 32 (f32) k-values per K-tile
     const char *__restrict__ A = static_cast<const char *>(g.a) + batch * g.stride_a * ESZ;
     const char *__restrict__ B = static_cast<const char *>(g.b) + batch * g.stride_b * ESZ;
@@ -223,7 +260,46 @@ gemm_lp256w4_kernel(gemm_args g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    frag fa[2][4], fb[2][4];
+    frag fa[2][4];
+    typename lp<DTB>::frag fb[2][4];
+
+    // ---- MX scales: sc_* = this K-tile's (byte OPSEL = k-step), sn_* = the next K-tile's, in flight --------------
+    constexpr int NB = F4 ? 8 : 4;                                        // MX blocks (scale bytes) per K-tile row
+    uint32_t sc_a[4] = {0, 0, 0, 0}, sc_b[4] = {0, 0, 0, 0}, sn_a[4] = {0, 0, 0, 0}, sn_b[4] = {0, 0, 0, 0};
+    const char *sbase_a = nullptr, *sbase_b = nullptr;                    // uniform: ST[t] + tile row 0 (+ batch)
+    uint32_t svoff_a = 0, svoff_b = 0;
+    int64_t sstep_a = 0, sstep_b = 0;                                     // bytes from ST[t] to ST[t+1]
+    if constexpr (MX) {
+        sstep_a = (int64_t)g.tiles_m * BM * NB;
+        sstep_b = (int64_t)g.tiles_n * BN * NB;
+        sbase_a = static_cast<const char *>(g.sa) + batch * g.stride_sa + m0 * NB;
+        sbase_b = static_cast<const char *>(g.sb) + batch * g.stride_sb + n0 * NB;
+        svoff_a = (uint32_t)((wm * 128 + l31) * NB + h * (NB / 2));
+        svoff_b = (uint32_t)((wn * 128 + l31) * NB + h * (NB / 2));
+    }
+    // scale load number Q of a K-tile: Q = 0..3 -> A row-block Q, 4..7 -> B row-block Q-4 (32 rows = 32*NB bytes apart)
+    auto scale_one = [&](auto qq) {
+        constexpr int Q = decltype(qq)::value;
+        if constexpr (MX) {
+            if constexpr (F4) {
+                if constexpr (Q < 4) scale_ld32(sn_a[Q & 3], sbase_a, svoff_a, (Q & 3) * 32 * NB);
+                else scale_ld32(sn_b[Q & 3], sbase_b, svoff_b, (Q & 3) * 32 * NB);
+            } else {
+                if constexpr (Q < 4) scale_ld16(sn_a[Q & 3], sbase_a, svoff_a, (Q & 3) * 32 * NB);
+                else scale_ld16(sn_b[Q & 3], sbase_b, svoff_b, (Q & 3) * 32 * NB);
+            }
+        }
+    };
+    // the scales of the next K-tile have landed (at most NEWER younger vector-memory operations may still fly): take them
+#define W4_TAKE_SCALES(NEWER)                                                                                  \
+    if constexpr (MX) {                                                                                        \
+        asm volatile("s_waitcnt vmcnt(" W4_STR(NEWER) ")"                                                       \
+                     : "+v"(sn_a[0]), "+v"(sn_a[1]), "+v"(sn_a[2]), "+v"(sn_a[3]), "+v"(sn_b[0]), "+v"(sn_b[1]),   \
+                       "+v"(sn_b[2]), "+v"(sn_b[3])::"memory");                                                 \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) { sc_a[q_] = sn_a[q_]; sc_b[q_] = sn_b[q_]; }          \
+        sbase_a += sstep_a;                                                                                    \
+        sbase_b += sstep_b;                                                                                    \
+    }
 
     // fragment load order == order of first use by the next k-step's MFMAs (j outer, i inner)
     auto read_one = [&](auto buf, auto idx, const char *pa, const char *pb) {
@@ -260,8 +336,14 @@ gemm_lp256w4_kernel(gemm_args g)
                                lds_addr_of(base));
         }
     };
-    auto mfma_one = [&](auto buf, auto idx) {
+    auto mfma_one = [&](auto buf, auto idx, auto step) {
         constexpr int BUF = decltype(buf)::value, I = decltype(idx)::value & 3, J = decltype(idx)::value >> 2;
+        if constexpr (MX) {
+            // first MFMA operand = B fragment (its format in cbsz, its scale first), second = A fragment
+            acc[I][J] = mfma_mx<mx_fmt<DTB>::value, mx_fmt<DT>::value, decltype(step)::value>(fb[BUF][J], fa[BUF][I], acc[I][J],
+                                                                                             sc_b[J], sc_a[I]);
+            return;
+        }
         if constexpr ((W4_ABL & 4) != 0) {    // (constexpr: the host pass must not see a 256-bit "v" operand)
             asm volatile("" ::"v"(fb[BUF][J]), "v"(fa[BUF][I]));
             return;
@@ -286,27 +368,33 @@ gemm_lp256w4_kernel(gemm_args g)
     //   MFMA idx, then at most one fragment read of the NEXT k-step (into the other register
     //   buffer) or one DMA piece.  RMASK / DMASK: bit idx set = a read / a DMA follows MFMA idx.
     //   DMA pieces are J0, J0+1, ... in mask order.
-#define W4_STEP_BODY(CUR, NXT, RMASK, DMASK, IS_B, J0)                                               \
+    //   MX: STEP = k-step within the K-tile (the scale byte the MFMAs select); SMASK / Q0: scale loads of the next
+    //   K-tile, numbered Q0, Q0+1, ... in mask order.
+#define W4_STEP_BODY(CUR, NXT, RMASK, DMASK, IS_B, J0, STEP, SMASK, Q0)                              \
     {                                                                                                \
-        constexpr unsigned rmask_ = (RMASK), dmask_ = (DMASK);                                       \
-        W4_GROUP(CUR, NXT, 0, rmask_, dmask_, IS_B, J0)  W4_GROUP(CUR, NXT, 1, rmask_, dmask_, IS_B, J0)   \
-        W4_GROUP(CUR, NXT, 2, rmask_, dmask_, IS_B, J0)  W4_GROUP(CUR, NXT, 3, rmask_, dmask_, IS_B, J0)   \
-        W4_GROUP(CUR, NXT, 4, rmask_, dmask_, IS_B, J0)  W4_GROUP(CUR, NXT, 5, rmask_, dmask_, IS_B, J0)   \
-        W4_GROUP(CUR, NXT, 6, rmask_, dmask_, IS_B, J0)  W4_GROUP(CUR, NXT, 7, rmask_, dmask_, IS_B, J0)   \
-        W4_GROUP(CUR, NXT, 8, rmask_, dmask_, IS_B, J0)  W4_GROUP(CUR, NXT, 9, rmask_, dmask_, IS_B, J0)   \
-        W4_GROUP(CUR, NXT, 10, rmask_, dmask_, IS_B, J0) W4_GROUP(CUR, NXT, 11, rmask_, dmask_, IS_B, J0)  \
-        W4_GROUP(CUR, NXT, 12, rmask_, dmask_, IS_B, J0) W4_GROUP(CUR, NXT, 13, rmask_, dmask_, IS_B, J0)  \
-        W4_GROUP(CUR, NXT, 14, rmask_, dmask_, IS_B, J0) W4_GROUP(CUR, NXT, 15, rmask_, dmask_, IS_B, J0)  \
+        constexpr unsigned rmask_ = (RMASK), dmask_ = (DMASK), smask_ = (SMASK);                     \
+        W4_GROUP(CUR, NXT, 0, IS_B, J0, STEP, Q0)  W4_GROUP(CUR, NXT, 1, IS_B, J0, STEP, Q0)         \
+        W4_GROUP(CUR, NXT, 2, IS_B, J0, STEP, Q0)  W4_GROUP(CUR, NXT, 3, IS_B, J0, STEP, Q0)         \
+        W4_GROUP(CUR, NXT, 4, IS_B, J0, STEP, Q0)  W4_GROUP(CUR, NXT, 5, IS_B, J0, STEP, Q0)         \
+        W4_GROUP(CUR, NXT, 6, IS_B, J0, STEP, Q0)  W4_GROUP(CUR, NXT, 7, IS_B, J0, STEP, Q0)         \
+        W4_GROUP(CUR, NXT, 8, IS_B, J0, STEP, Q0)  W4_GROUP(CUR, NXT, 9, IS_B, J0, STEP, Q0)         \
+        W4_GROUP(CUR, NXT, 10, IS_B, J0, STEP, Q0) W4_GROUP(CUR, NXT, 11, IS_B, J0, STEP, Q0)        \
+        W4_GROUP(CUR, NXT, 12, IS_B, J0, STEP, Q0) W4_GROUP(CUR, NXT, 13, IS_B, J0, STEP, Q0)        \
+        W4_GROUP(CUR, NXT, 14, IS_B, J0, STEP, Q0) W4_GROUP(CUR, NXT, 15, IS_B, J0, STEP, Q0)        \
     }
-#define W4_GROUP(CUR, NXT, IDX, rmask_, dmask_, IS_B, J0)                                            \
-    mfma_one(IC<CUR>{}, IC<IDX>{});                                                                  \
+#define W4_GROUP(CUR, NXT, IDX, IS_B, J0, STEP, Q0)                                                  \
+    mfma_one(IC<CUR>{}, IC<IDX>{}, IC<STEP>{});                                                      \
     if constexpr ((rmask_ >> IDX) & 1u)                                                              \
         read_one(IC<NXT>{}, IC<__builtin_popcount(rmask_ & ((1u << IDX) - 1u))>{}, rd_a, rd_b);      \
+    if constexpr ((smask_ >> IDX) & 1u)                                                              \
+        scale_one(IC<Q0 + __builtin_popcount(smask_ & ((1u << IDX) - 1u))>{});                       \
     if constexpr ((dmask_ >> IDX) & 1u)                                                              \
         dma_one(IC<IS_B>{}, IC<J0 + __builtin_popcount(dmask_ & ((1u << IDX) - 1u))>{}, dma_koff, dma_base); \
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- prologue: units 0..3 (K-tiles 0 and 1), then the first fragments ---------------------------
+    // ---- prologue: (MX: the scales of K-tile 0,) units 0..3 (K-tiles 0 and 1), then the first fragments ------
+    scale_one(IC<0>{}); scale_one(IC<1>{}); scale_one(IC<2>{}); scale_one(IC<3>{});
+    scale_one(IC<4>{}); scale_one(IC<5>{}); scale_one(IC<6>{}); scale_one(IC<7>{});
     {
         const int64_t k0 = 0, k1 = (int64_t)min(1, nk - 1) * ROW_BYTES;   // nk == 1: K-tile 0 twice, drained at the hand-over
         char *b0 = smem + dst_piece;
@@ -319,11 +407,14 @@ gemm_lp256w4_kernel(gemm_args g)
 #undef W4_PRO
     }
     WAIT_VMCNT(16);                      // units 0, 1 landed (this wave's share)
+    W4_TAKE_SCALES(16)                   // (older than every DMA: landed too)
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     {
-        const int x = F8 ? ((2 * h) ^ f) << 4 : (h ^ f) << 4;
+        // MX: lane-half h owns the contiguous half of the row (chunks 4h .. 4h+3 = MX blocks NB/2*h ..), so that its
+        // scale bytes are contiguous; unscaled: the interleaved mapping the measured kernels were tuned with
+        const int x = MX ? ((4 * h) ^ f) << 4 : F8 ? ((2 * h) ^ f) << 4 : (h ^ f) << 4;
         const char *rd_a = smem + rowoff_a + x, *rd_b = smem + UNIT_BYTES + rowoff_b + (BNN ? (4 * h) * 1024 : x);
         read_one(IC<0>{}, IC<0>{}, rd_a, rd_b); read_one(IC<0>{}, IC<1>{}, rd_a, rd_b);
         read_one(IC<0>{}, IC<2>{}, rd_a, rd_b); read_one(IC<0>{}, IC<3>{}, rd_a, rd_b);
@@ -341,7 +432,8 @@ gemm_lp256w4_kernel(gemm_args g)
     int sa = 0;                          // ring byte offset of unit 2t   (A of K-tile t)
     int sb = UNIT_BYTES;                 // ring byte offset of unit 2t+1 (B of K-tile t)
     auto adv = [](int x, int n) { x += n * UNIT_BYTES; return x >= LDS_BYTES ? x - LDS_BYTES : x; };
-    const int x1 = ((2 + h) ^ f) << 4, x2 = ((4 + h) ^ f) << 4, x3 = ((6 + h) ^ f) << 4, x0 = (h ^ f) << 4;
+    const int x1 = ((MX ? 4 * h + 1 : 2 + h) ^ f) << 4, x2 = ((MX ? 4 * h + 2 : 4 + h) ^ f) << 4,
+              x3 = ((MX ? 4 * h + 3 : 6 + h) ^ f) << 4, x0 = ((MX ? 4 * h : h) ^ f) << 4;
     // B fragment offsets per k-step: same chunks as A for [N][K]; k-rows 8s + 4h (.. +3) for row-major B
     const int y0 = BNN ? (4 * h) * 1024 : x0, y1 = BNN ? (8 + 4 * h) * 1024 : x1, y2 = BNN ? (16 + 4 * h) * 1024 : x2,
               y3 = BNN ? (24 + 4 * h) * 1024 : x3;
@@ -350,7 +442,7 @@ gemm_lp256w4_kernel(gemm_args g)
     // ISSUE = 0: the last two K-tiles of the tile -- there is nothing left to fetch, so no DMA is issued (the first
     // version re-read the last K-tile into dead slots to keep the counts uniform: 2 K-tiles of useless L2 traffic
     // per output tile and a vmcnt(0) stall on them before the epilogue) and the hand-over waits for everything.
-#define W4_KTILE(ISSUE)                                                                                     \
+#define W4_KTILE(ISSUE, SC)                                                                                  \
     {                                                                                                       \
         const int sa1 = adv(sa, 2), sb1 = adv(sb, 2);     /* units 2t+2, 2t+3 (K-tile t+1) */               \
         const int s4 = adv(sa, 4);                        /* unit 2t+4 -> slot of unit 2t-1 */               \
@@ -360,22 +452,25 @@ gemm_lp256w4_kernel(gemm_args g)
         char *dma_base;                                                                                     \
         /* k-step 0: reads of step 1 after MFMA 0-7, unit 2t+4 pieces 0-3 after MFMA 9,11,13,15 */          \
         rd_a = smem + sa + rowoff_a + x1; rd_b = smem + sb + rowoff_b + y1; dma_base = smem + s4 + dst_piece; \
-        W4_STEP_BODY(0, 1, 0x00FFu, (ISSUE) ? 0xAA00u : 0u, 0, 0)                                            \
+        /* (MX: the 8 scale loads of K-tile t+1 after MFMA 8,10,12,14 of k-steps 0 and 1) */                \
+        W4_STEP_BODY(0, 1, 0x00FFu, (ISSUE) ? 0xAA00u : 0u, 0, 0, 0, (MX && (SC)) ? 0x5500u : 0u, 0)         \
         /* k-step 1: reads of step 2, unit 2t+4 pieces 4-7 */                                               \
         rd_a = smem + sa + rowoff_a + x2; rd_b = smem + sb + rowoff_b + y2;                                 \
-        W4_STEP_BODY(1, 0, 0x00FFu, (ISSUE) ? 0xAA00u : 0u, 0, 4)                                            \
+        W4_STEP_BODY(1, 0, 0x00FFu, (ISSUE) ? 0xAA00u : 0u, 0, 4, 1, (MX && (SC)) ? 0x5500u : 0u, 4)         \
         /* k-step 2: reads of step 3, no DMA; then the K-tile hand-over */                                  \
         rd_a = smem + sa + rowoff_a + x3; rd_b = smem + sb + rowoff_b + y3;                                 \
-        W4_STEP_BODY(0, 1, 0x00FFu, 0x0000u, 0, 0)                                                          \
+        W4_STEP_BODY(0, 1, 0x00FFu, 0x0000u, 0, 0, 2, 0u, 0)                                                \
         if (!(W4_ABL & 8)) {                              /* dev ablation 8: no hand-over (timing only, races) */ \
-        if (ISSUE) WAIT_VMCNT(8); else WAIT_VMCNT(0);     /* my share of K-tile t+1 landed (unit 2t+4 may fly) */ \
+        /* my share of K-tile t+1 landed; unit 2t+4 (and, MX, the 8 scale loads issued among it) may fly */ \
+        if (ISSUE) { if constexpr (MX) WAIT_VMCNT(16); else WAIT_VMCNT(8); } else WAIT_VMCNT(0);            \
         WAIT_LGKM0();                                     /* my reads of K-tile t are complete */           \
         __builtin_amdgcn_s_barrier();                     /* BAR_t */                                        \
         }                                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
         /* k-step 3: reads of step 0 of K-tile t+1 after even MFMAs, unit 2t+5 pieces 0-7 after odd ones */ \
         rd_a = smem + sa1 + rowoff_a + x0; rd_b = smem + sb1 + rowoff_b + y0; dma_base = smem + s5 + dst_piece; \
-        W4_STEP_BODY(1, 0, 0x5555u, (ISSUE) ? 0xAAAAu : 0u, 1, 0)                                            \
+        W4_STEP_BODY(1, 0, 0x5555u, (ISSUE) ? 0xAAAAu : 0u, 1, 0, 3, 0u, 0)                                  \
+        if constexpr (MX && (SC)) { if (ISSUE) { W4_TAKE_SCALES(8) } else { W4_TAKE_SCALES(0) } }           \
         sa = sa1;                                                                                           \
         sb = sb1;                                                                                           \
     }
@@ -385,13 +480,16 @@ gemm_lp256w4_kernel(gemm_args g)
     //     d=1, MFMA 0-7  : nothing else
     //          vmcnt(8), lgkmcnt(0), s_barrier (BAR_t)
     //     d=1, MFMA 8-15 : two reads of frags(t+1, d=0) and one DMA piece of unit 2t+5 after each
-#define W8_G(CUR, NXT, IDX, NR, R0, DM, IS_B, J)                                                            \
-    mfma_one(IC<CUR>{}, IC<IDX>{});                                                                          \
+    //   MX: the 8 scale loads of K-tile t+1 follow the even MFMAs of d=0 (SQ = load number, -1 = none).
+#define W8_G(CUR, NXT, IDX, NR, R0, DM, IS_B, J, SQ)                                                        \
+    mfma_one(IC<CUR>{}, IC<IDX>{}, IC<CUR>{});            /* buffer number == k-step d == scale byte */      \
     if constexpr ((NR) >= 1) read_one(IC<NXT>{}, IC<(R0)>{}, rd_a, rd_b);                                    \
     if constexpr ((NR) >= 2) read_one(IC<NXT>{}, IC<(R0) + 1>{}, rd_a, rd_b);                                \
+    if constexpr ((SQ) >= 0) scale_one(IC<((SQ) >= 0 ? (SQ) : 0)>{});                                        \
     if constexpr (DM) dma_one(IC<IS_B>{}, IC<J>{}, dma_koff, dma_base);                                      \
     __builtin_amdgcn_sched_barrier(0);
-#define W8_KTILE(ISSUE)                                                                                     \
+#define W8_SQ(SC, Q) ((MX && (SC)) ? (Q) : -1)
+#define W8_KTILE(ISSUE, SC)                                                                                  \
     {                                                                                                       \
         const int sa1 = adv(sa, 2), sb1 = adv(sb, 2);                                                       \
         const int s4 = adv(sa, 4);                                                                          \
@@ -400,43 +498,56 @@ gemm_lp256w4_kernel(gemm_args g)
         const char *rd_a, *rd_b;                                                                            \
         char *dma_base;                                                                                     \
         rd_a = smem + sa + rowoff_a + z1; rd_b = smem + sb + rowoff_b + z1; dma_base = smem + s4 + dst_piece; \
-        W8_G(0, 1, 0, 1, 0, 0, 0, 0)            W8_G(0, 1, 1, 1, 1, (ISSUE), 0, 0)                            \
-        W8_G(0, 1, 2, 1, 2, 0, 0, 0)            W8_G(0, 1, 3, 1, 3, (ISSUE), 0, 1)                            \
-        W8_G(0, 1, 4, 1, 4, 0, 0, 0)            W8_G(0, 1, 5, 1, 5, (ISSUE), 0, 2)                            \
-        W8_G(0, 1, 6, 1, 6, 0, 0, 0)            W8_G(0, 1, 7, 1, 7, (ISSUE), 0, 3)                            \
-        W8_G(0, 1, 8, 1, 8, 0, 0, 0)            W8_G(0, 1, 9, 1, 9, (ISSUE), 0, 4)                            \
-        W8_G(0, 1, 10, 1, 10, 0, 0, 0)          W8_G(0, 1, 11, 1, 11, (ISSUE), 0, 5)                          \
-        W8_G(0, 1, 12, 1, 12, 0, 0, 0)          W8_G(0, 1, 13, 1, 13, (ISSUE), 0, 6)                          \
-        W8_G(0, 1, 14, 1, 14, 0, 0, 0)          W8_G(0, 1, 15, 1, 15, (ISSUE), 0, 7)                          \
-        W8_G(1, 0, 0, 0, 0, 0, 0, 0) W8_G(1, 0, 1, 0, 0, 0, 0, 0) W8_G(1, 0, 2, 0, 0, 0, 0, 0) W8_G(1, 0, 3, 0, 0, 0, 0, 0) \
-        W8_G(1, 0, 4, 0, 0, 0, 0, 0) W8_G(1, 0, 5, 0, 0, 0, 0, 0) W8_G(1, 0, 6, 0, 0, 0, 0, 0) W8_G(1, 0, 7, 0, 0, 0, 0, 0) \
+        W8_G(0, 1, 0, 1, 0, 0, 0, 0, W8_SQ(SC, 0))     W8_G(0, 1, 1, 1, 1, (ISSUE), 0, 0, -1)                 \
+        W8_G(0, 1, 2, 1, 2, 0, 0, 0, W8_SQ(SC, 1))     W8_G(0, 1, 3, 1, 3, (ISSUE), 0, 1, -1)                 \
+        W8_G(0, 1, 4, 1, 4, 0, 0, 0, W8_SQ(SC, 2))     W8_G(0, 1, 5, 1, 5, (ISSUE), 0, 2, -1)                 \
+        W8_G(0, 1, 6, 1, 6, 0, 0, 0, W8_SQ(SC, 3))     W8_G(0, 1, 7, 1, 7, (ISSUE), 0, 3, -1)                 \
+        W8_G(0, 1, 8, 1, 8, 0, 0, 0, W8_SQ(SC, 4))     W8_G(0, 1, 9, 1, 9, (ISSUE), 0, 4, -1)                 \
+        W8_G(0, 1, 10, 1, 10, 0, 0, 0, W8_SQ(SC, 5))   W8_G(0, 1, 11, 1, 11, (ISSUE), 0, 5, -1)               \
+        W8_G(0, 1, 12, 1, 12, 0, 0, 0, W8_SQ(SC, 6))   W8_G(0, 1, 13, 1, 13, (ISSUE), 0, 6, -1)               \
+        W8_G(0, 1, 14, 1, 14, 0, 0, 0, W8_SQ(SC, 7))   W8_G(0, 1, 15, 1, 15, (ISSUE), 0, 7, -1)               \
+        W8_G(1, 0, 0, 0, 0, 0, 0, 0, -1) W8_G(1, 0, 1, 0, 0, 0, 0, 0, -1) W8_G(1, 0, 2, 0, 0, 0, 0, 0, -1) W8_G(1, 0, 3, 0, 0, 0, 0, 0, -1) \
+        W8_G(1, 0, 4, 0, 0, 0, 0, 0, -1) W8_G(1, 0, 5, 0, 0, 0, 0, 0, -1) W8_G(1, 0, 6, 0, 0, 0, 0, 0, -1) W8_G(1, 0, 7, 0, 0, 0, 0, 0, -1) \
         if (!(W4_ABL & 8)) {                                                                                \
-        if (ISSUE) WAIT_VMCNT(8); else WAIT_VMCNT(0);                                                       \
+        if (ISSUE) { if constexpr (MX) WAIT_VMCNT(16); else WAIT_VMCNT(8); } else WAIT_VMCNT(0);            \
         WAIT_LGKM0();                                                                                       \
         __builtin_amdgcn_s_barrier();                                                                       \
         }                                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
         rd_a = smem + sa1 + rowoff_a + z0; rd_b = smem + sb1 + rowoff_b + z0; dma_base = smem + s5 + dst_piece; \
-        W8_G(1, 0, 8, 2, 0, (ISSUE), 1, 0)      W8_G(1, 0, 9, 2, 2, (ISSUE), 1, 1)                            \
-        W8_G(1, 0, 10, 2, 4, (ISSUE), 1, 2)     W8_G(1, 0, 11, 2, 6, (ISSUE), 1, 3)                           \
-        W8_G(1, 0, 12, 2, 8, (ISSUE), 1, 4)     W8_G(1, 0, 13, 2, 10, (ISSUE), 1, 5)                          \
-        W8_G(1, 0, 14, 2, 12, (ISSUE), 1, 6)    W8_G(1, 0, 15, 2, 14, (ISSUE), 1, 7)                          \
+        W8_G(1, 0, 8, 2, 0, (ISSUE), 1, 0, -1)      W8_G(1, 0, 9, 2, 2, (ISSUE), 1, 1, -1)                    \
+        W8_G(1, 0, 10, 2, 4, (ISSUE), 1, 2, -1)     W8_G(1, 0, 11, 2, 6, (ISSUE), 1, 3, -1)                   \
+        W8_G(1, 0, 12, 2, 8, (ISSUE), 1, 4, -1)     W8_G(1, 0, 13, 2, 10, (ISSUE), 1, 5, -1)                  \
+        W8_G(1, 0, 14, 2, 12, (ISSUE), 1, 6, -1)    W8_G(1, 0, 15, 2, 14, (ISSUE), 1, 7, -1)                  \
+        if constexpr (MX && (SC)) { if (ISSUE) { W4_TAKE_SCALES(8) } else { W4_TAKE_SCALES(0) } }           \
         sa = sa1;                                                                                           \
         sb = sb1;                                                                                           \
     }
-    const int z0 = ((2 * h) ^ f) << 4, z1 = ((4 + 2 * h) ^ f) << 4;      // fp8: first chunk of this lane-half, k-steps d = 0, 1
+    // fp8: first chunk of this lane-half for k-steps d = 0, 1 (MX: the half-row 4h .. 4h+3, see the prologue)
+    const int z0 = ((MX ? 4 * h : 2 * h) ^ f) << 4, z1 = ((MX ? 4 * h + 2 : 4 + 2 * h) ^ f) << 4;
     W4_STAMP(1);
     int t = 0;
-    if constexpr (F8) {
-        for (; t + 2 < nk; ++t) W8_KTILE(1)
-        for (; t < nk; ++t) W8_KTILE(0)
+    // MX: every K-tile but the last also fetches the next one's scales (SC), so the DMA-free tail splits in two
+    if constexpr (F8 && MX) {
+        for (; t + 2 < nk; ++t) W8_KTILE(1, 1)
+        for (; t + 1 < nk; ++t) W8_KTILE(0, 1)
+        for (; t < nk; ++t) W8_KTILE(0, 0)
+    } else if constexpr (F8) {
+        for (; t + 2 < nk; ++t) W8_KTILE(1, 0)
+        for (; t < nk; ++t) W8_KTILE(0, 0)
+    } else if constexpr (MX) {
+        for (; t + 2 < nk; ++t) W4_KTILE(1, 1)
+        for (; t + 1 < nk; ++t) W4_KTILE(0, 1)
+        for (; t < nk; ++t) W4_KTILE(0, 0)
     } else {
-        for (; t + 2 < nk; ++t) W4_KTILE(1)
-        for (; t < nk; ++t) W4_KTILE(0)
+        for (; t + 2 < nk; ++t) W4_KTILE(1, 0)
+        for (; t < nk; ++t) W4_KTILE(0, 0)
     }
 #undef W4_KTILE
 #undef W8_KTILE
 #undef W8_G
+#undef W8_SQ
+#undef W4_TAKE_SCALES
     W4_STAMP(2);
 #undef W4_STEP_BODY
 #undef W4_GROUP
@@ -523,15 +634,15 @@ gemm_lp256w4_kernel(gemm_args g)
 #endif
 }
 
-template <int DT, int DT_C, bool BNN = false>
+template <int DT, int DT_C, bool BNN = false, int DTB = DT, bool MX = false>
 void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch, int slot)
 {
     if (!(ctx->func_attr_mask & (1ull << slot))) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_lp256w4_kernel<DT, DT_C, BNN>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_lp256w4_kernel<DT, DT_C, BNN, DTB, MX>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         ctx->func_attr_mask |= (1ull << slot);
     }
-    hipLaunchKernelGGL((gemm_lp256w4_kernel<DT, DT_C, BNN>), dim3(g.tiles_m * g.tiles_n, batch), dim3(256), LDS_BYTES, s, g);
+    hipLaunchKernelGGL((gemm_lp256w4_kernel<DT, DT_C, BNN, DTB, MX>), dim3(g.tiles_m * g.tiles_n, batch), dim3(256), LDS_BYTES, s, g);
 }
 
 }  // namespace
@@ -604,6 +715,59 @@ int32_t launch_gemm_lp256w4(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc
         else launch<MI355_DTYPE_F16, MI355_DTYPE_F16>(ctx, s, g, batch, 15);
     }
     check_launch(ctx, "mi355_gemm(lp256w4)");
+    return MI355_OK;
+}
+
+// ---- block-scaled (MX) form ---------------------------------------------------------------------------------------------
+bool gemm_lp256w4_mx_supports(const mi355_gemm_scaled_desc &d, const void *a, const void *b, const void *c)
+{
+    const bool f4 = d.dtype_a == MI355_DTYPE_F4E2M1X2;
+    if (f4 ? d.dtype_b != MI355_DTYPE_F4E2M1X2 : !(is_fp8(d.dtype_a) && is_fp8(d.dtype_b))) return false;
+    if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != MI355_DTYPE_BF16) return false;           // (f16 output: generic kernel)
+    if (d.block != 32) return false;
+    const int64_t bk = f4 ? 256 : 128;                                    // k-values per 128-byte K-tile row
+    if (d.k < bk || d.k % bk != 0) return false;
+    const int64_t epb = f4 ? 2 : 1;                                       // elements per byte
+    if ((d.lda % (16 * epb)) || (d.ldb % (16 * epb)) || (d.stride_a % (16 * epb)) || (d.stride_b % (16 * epb))) return false;
+    if ((reinterpret_cast<uintptr_t>(a) & 15u) || (reinterpret_cast<uintptr_t>(b) & 15u)) return false;
+    const int64_t csz = d.dtype_c == MI355_DTYPE_F32 ? 4 : 2;
+    if (((d.ldc * csz) & 15) || ((d.stride_c * csz) & 15) || (reinterpret_cast<uintptr_t>(c) & 15u)) return false;
+    if (d.m < 1 || d.n < 1 || d.batch > 65535) return false;
+    if (((d.m + BM - 1) / BM) * ((d.n + BN - 1) / BN) > 0x7FFFFFFF) return false;
+    if ((int64_t)BM * std::max(d.lda, d.ldb) / epb >= (1ll << 32)) return false;
+    return true;
+}
+
+int32_t launch_gemm_lp256w4_mx(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_scaled_desc &d, const void *a, const void *sa_t,
+                               int64_t stride_sa_t, const void *b, const void *sb_t, int64_t stride_sb_t, void *c)
+{
+    if (!gemm_lp256w4_mx_supports(d, a, b, c))
+        return fail(ctx, MI355_E_UNSUPPORTED, "lp256w4 block-scaled GEMM: shape/layout not supported by this kernel");
+    const int64_t epb = d.dtype_a == MI355_DTYPE_F4E2M1X2 ? 2 : 1;        // fp4: the kernel works on the byte matrix
+    gemm_args g{};
+    g.a = a; g.b = b; g.c = c;
+    g.m = d.m; g.n = d.n; g.k = d.k / epb;
+    g.lda = d.lda / epb; g.ldb = d.ldb / epb; g.ldc = d.ldc;
+    g.stride_a = d.stride_a / epb; g.stride_b = d.stride_b / epb; g.stride_c = d.stride_c;
+    g.tiles_m = (uint32_t)((d.m + BM - 1) / BM);
+    g.tiles_n = (uint32_t)((d.n + BN - 1) / BN);
+    g.group_m = W4_GROUP_M;
+    g.sa = sa_t; g.sb = sb_t; g.stride_sa = stride_sa_t; g.stride_sb = stride_sb_t;
+    const uint32_t batch = (uint32_t)d.batch;
+    const bool f32c = d.dtype_c == MI355_DTYPE_F32;
+    constexpr int E4 = MI355_DTYPE_F8E4M3, E5 = MI355_DTYPE_F8E5M2, F4 = MI355_DTYPE_F4E2M1X2, CF = MI355_DTYPE_F32, CB = MI355_DTYPE_BF16;
+    if (d.dtype_a == F4) {
+        if (f32c) launch<F4, CF, false, F4, true>(ctx, s, g, batch, 46); else launch<F4, CB, false, F4, true>(ctx, s, g, batch, 47);
+    } else if (d.dtype_a == E4 && d.dtype_b == E4) {
+        if (f32c) launch<E4, CF, false, E4, true>(ctx, s, g, batch, 38); else launch<E4, CB, false, E4, true>(ctx, s, g, batch, 39);
+    } else if (d.dtype_a == E5 && d.dtype_b == E5) {
+        if (f32c) launch<E5, CF, false, E5, true>(ctx, s, g, batch, 40); else launch<E5, CB, false, E5, true>(ctx, s, g, batch, 41);
+    } else if (d.dtype_a == E4) {
+        if (f32c) launch<E4, CF, false, E5, true>(ctx, s, g, batch, 42); else launch<E4, CB, false, E5, true>(ctx, s, g, batch, 43);
+    } else {
+        if (f32c) launch<E5, CF, false, E4, true>(ctx, s, g, batch, 44); else launch<E5, CB, false, E4, true>(ctx, s, g, batch, 45);
+    }
+    check_launch(ctx, "mi355_gemm_scaled(lp256w4)");
     return MI355_OK;
 }
 

@@ -85,6 +85,7 @@ inline size_t dtype_size(int32_t dtype)
     case MI355_DTYPE_BF16: case MI355_DTYPE_F16: return 2;
     case MI355_DTYPE_F64: case MI355_DTYPE_I64: case MI355_DTYPE_U64: return 8;
     case MI355_DTYPE_U8: case MI355_DTYPE_I8: case MI355_DTYPE_F8E4M3: case MI355_DTYPE_F8E5M2: return 1;
+    case MI355_DTYPE_F4E2M1X2: case MI355_DTYPE_UE8M0: return 1;   // (a packed fp4 PAIR is one byte)
     default: return 0;
     }
 }

@@ -87,6 +87,53 @@ def matmul(client: ComputeClient, lhs: TensorHandle, rhs: TensorHandle, out: Ten
                                           C.c_void_p(rhs.device_ptr()), C.c_void_p(out.device_ptr())))
 
 
+def matmul_scaled(client: ComputeClient, lhs: TensorHandle, lhs_scales: TensorHandle, rhs: TensorHandle,
+                  rhs_scales: TensorHandle, out: TensorHandle, *, block: int = 32, algo: int = N.GEMM_ALGO_AUTO) -> None:
+    """Block-scaled matmul, out[.., m, n] = sum_k lhs[.., m, k] s_l[.., m, k/block] rhs[.., n, k] s_r[.., n, k/block].
+
+    The layouts are the reference test's (runtime_tests/cmma.rs:1549-1560): `lhs` [.., m, k] row-major, `rhs` stored
+    [.., n, k], scales [.., rows, k / block] (ue8m0).  F4E2M1X2 handles have a BYTE shape: [.., rows, k / 2]."""
+    packed = 2 if lhs.dtype == ElemType.F4E2M1X2 else 1
+    m, k = lhs.shape[-2], lhs.shape[-1] * packed
+    n, k2 = rhs.shape[-2], rhs.shape[-1] * packed
+    if k != k2 or out.shape[-2] != m or out.shape[-1] != n or lhs_scales.shape[-2] != m or rhs_scales.shape[-2] != n:
+        raise ServerError(N.E_INVALID_ARGUMENT, f"matmul_scaled: shape mismatch {lhs.shape} x {rhs.shape} -> {out.shape}")
+    if lhs_scales.shape[-1] * block != k or rhs_scales.shape[-1] * block != k:
+        raise ServerError(N.E_INVALID_ARGUMENT, f"matmul_scaled: {lhs_scales.shape[-1]} scales per row do not cover k = {k} in blocks of {block}")
+    for t, name in ((lhs, "lhs"), (rhs, "rhs"), (out, "out"), (lhs_scales, "lhs_scales"), (rhs_scales, "rhs_scales")):
+        if t.strides[-1] != 1:
+            raise ServerError(N.E_UNSUPPORTED_STRIDES, f"matmul_scaled: {name} must be contiguous along its last axis")
+
+    def bstride(t, name):
+        if t.rank() == 2:
+            return 1, 0
+        if t.rank() != 3:
+            raise ServerError(N.E_UNSUPPORTED_STRIDES, f"matmul_scaled: {name} must have rank 2 or 3")
+        return t.shape[0], t.strides[0]
+    (ba, sa), (bb, sb), (bc, sc) = bstride(lhs, "lhs"), bstride(rhs, "rhs"), bstride(out, "out")
+    (bsa, ssa), (bsb, ssb) = bstride(lhs_scales, "lhs_scales"), bstride(rhs_scales, "rhs_scales")
+    batch = bc
+    for b_, name in ((ba, "lhs"), (bb, "rhs"), (bsa, "lhs_scales"), (bsb, "rhs_scales")):
+        if b_ not in (1, batch):
+            raise ServerError(N.E_INVALID_ARGUMENT, f"matmul_scaled: {name} batch {b_} does not broadcast to {batch}")
+    if (ba == batch) != (bsa == batch) or (bb == batch) != (bsb == batch):
+        raise ServerError(N.E_INVALID_ARGUMENT, "matmul_scaled: an operand and its scales must be batched alike")
+    desc = N.GemmScaledDesc(m=m, n=n, k=k, batch=batch, lda=lhs.strides[-2] * packed, ldb=rhs.strides[-2] * packed,
+                            ldc=out.strides[-2], ld_sa=lhs_scales.strides[-2], ld_sb=rhs_scales.strides[-2],
+                            stride_a=(sa if ba == batch else 0) * packed, stride_b=(sb if bb == batch else 0) * packed,
+                            stride_c=sc, stride_sa=ssa if bsa == batch else 0, stride_sb=ssb if bsb == batch else 0,
+                            dtype_a=int(lhs.dtype), dtype_b=int(rhs.dtype), dtype_c=int(out.dtype), block=block, algo=algo)
+    client._s.check(client.lib.mi355_gemm_scaled(client.ctx, client.stream, C.byref(desc), C.c_void_p(lhs.device_ptr()),
+                                                 C.c_void_p(lhs_scales.device_ptr()), C.c_void_p(rhs.device_ptr()),
+                                                 C.c_void_p(rhs_scales.device_ptr()), C.c_void_p(out.device_ptr())))
+
+
+def gemm_scaled_select(client: ComputeClient, desc: N.GemmScaledDesc) -> int:
+    algo = C.c_int32()
+    client._s.check(client.lib.mi355_gemm_scaled_select(client.ctx, C.byref(desc), C.byref(algo)))
+    return algo.value
+
+
 def gemm_select(client: ComputeClient, desc: N.GemmDesc) -> int:
     algo = C.c_int32()
     client._s.check(client.lib.mi355_gemm_select(client.ctx, C.byref(desc), C.byref(algo)))

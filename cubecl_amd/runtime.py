@@ -45,6 +45,8 @@ class ElemType(enum.IntEnum):
     I8 = N.DTYPE_I8
     F8E4M3 = N.DTYPE_F8E4M3          # FloatKind::E4M3 (crates/cubecl-ir/src/types/scalar.rs)
     F8E5M2 = N.DTYPE_F8E5M2          # FloatKind::E5M2
+    F4E2M1X2 = N.DTYPE_F4E2M1X2      # FloatKind::E2M1 packed in pairs (e2m1x2, fp4.rs:19-28): one byte per two elements
+    UE8M0 = N.DTYPE_UE8M0            # FloatKind::UE8M0, the MX block scale
 
     def size(self) -> int:
         return N.DTYPE_SIZE[int(self)]

@@ -14,8 +14,9 @@ from .runtime import (ComputeClient, CopyDescriptor, ElemType, Handle, ServerErr
 _NP = {ElemType.F32: np.float32, ElemType.F64: np.float64, ElemType.I32: np.int32, ElemType.U32: np.uint32,
        ElemType.I64: np.int64, ElemType.U64: np.uint64, ElemType.U8: np.uint8, ElemType.I8: np.int8,
        ElemType.BF16: np.uint16, ElemType.F16: np.float16,
-       ElemType.F8E4M3: np.uint8, ElemType.F8E5M2: np.uint8}     # bit patterns (numpy has no bfloat16 / fp8)
-_BITS_ONLY = (ElemType.BF16, ElemType.F8E4M3, ElemType.F8E5M2)
+       ElemType.F8E4M3: np.uint8, ElemType.F8E5M2: np.uint8,     # bit patterns (numpy has no bfloat16 / fp8)
+       ElemType.F4E2M1X2: np.uint8, ElemType.UE8M0: np.uint8}    # packed e2m1 pairs (shape counts BYTES), ue8m0 scales
+_BITS_ONLY = (ElemType.BF16, ElemType.F8E4M3, ElemType.F8E5M2, ElemType.F4E2M1X2, ElemType.UE8M0)
 
 
 @dataclass

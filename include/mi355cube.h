@@ -83,7 +83,9 @@ enum {
     MI355_DTYPE_U8 = 8,
     MI355_DTYPE_I8 = 9,
     MI355_DTYPE_F8E4M3 = 10, /* OCP e4m3fn: no infinities, S.1111.111 = NaN, max 448 (fp8_e4m3.rs:12-37) */
-    MI355_DTYPE_F8E5M2 = 11  /* OCP e5m2: IEEE-style inf / NaN, max 57344 (fp8_e5m2.rs:12-38) */
+    MI355_DTYPE_F8E5M2 = 11, /* OCP e5m2: IEEE-style inf / NaN, max 57344 (fp8_e5m2.rs:12-38) */
+    MI355_DTYPE_F4E2M1X2 = 12, /* two e2m1 per byte, the first in the low nibble (fp4.rs:204-224); sizes are in BYTES */
+    MI355_DTYPE_UE8M0 = 13   /* block scale 2^(bits - 127), 0xFF = NaN (fp8/fp8_e8m0.rs) */
 };
 
 /* ReduceOperation (server/base.rs:623-628) + the two extra ops array-wide argmax needs.
@@ -326,6 +328,32 @@ int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_gemm_desc *d
                    const void *a, const void *b, void *c);
 /* which kernel AUTO resolves to for a descriptor (for tests / logs) */
 int32_t mi355_gemm_select(mi355_ctx *ctx, const mi355_gemm_desc *desc, int32_t *out_algo);
+
+/* Block-scaled matmul (MX formats): C[b] = (A[b] .* SA[b]) * (B[b] .* SB[b])^T, f32 accumulate -- the operation
+ * `MmaDefinition::execute_scaled` defines per fragment (crates/cubecl-core/src/frontend/cmma.rs:795-840), semantics
+ * pinned by test_cmma_scaled / test_cmma_scaled_fp4 (runtime_tests/cmma.rs:1476-1704):
+ *     C[i][j] = sum_l A[i][l] * SA[i][l / block] * B[j][l] * SB[j][l / block]
+ *   A is row-major [M][K] (lda >= K), B is stored [N][K] (ldb >= K) -- the tests' layouts (:1549-1551);
+ *   SA [M][K/block], SB [N][K/block] are ue8m0 (ld_sa, ld_sb >= K/block, in scales);
+ *   dtype_a / dtype_b: F8E4M3, F8E5M2 (may be mixed) or F4E2M1X2 (both; K, lda, ldb, strides still count ELEMENTS,
+ *   a row of K elements is K/2 bytes, K and lda / ldb even); dtype_c: F32, BF16 or F16.
+ * block == 32 with K a multiple of 128 (fp8) / 256 (fp4) and 16-byte aligned rows runs on
+ * v_mfma_scale_f32_32x32x64_f8f6f4 inside the 256x256 kernel (the scales are first re-arranged per K-tile into
+ * library-owned scratch); every other block size / shape runs on a bounds-checked scalar kernel that follows the
+ * reference loop literally. */
+typedef struct {
+    int64_t m, n, k, batch;
+    int64_t lda, ldb, ldc;
+    int64_t ld_sa, ld_sb;
+    int64_t stride_a, stride_b, stride_c, stride_sa, stride_sb; /* elements / scales between batch entries */
+    int32_t dtype_a, dtype_b, dtype_c;
+    int32_t block;  /* k-values per scale (scales_factor of the reference = k / block) */
+    int32_t algo;   /* MI355_GEMM_ALGO_AUTO, _GENERIC or _LP_256W4 */
+    int32_t reserved;
+} mi355_gemm_scaled_desc;
+int32_t mi355_gemm_scaled(mi355_ctx *ctx, mi355_stream stream, const mi355_gemm_scaled_desc *desc, const void *a,
+                          const void *a_scales, const void *b, const void *b_scales, void *c);
+int32_t mi355_gemm_scaled_select(mi355_ctx *ctx, const mi355_gemm_scaled_desc *desc, int32_t *out_algo);
 
 /* =================================== Reductions ========================================== */
 

@@ -16,6 +16,7 @@ LIB_PATH = _DIR / "liboracle.so"
 SEED = 0x5EEDC0BE
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 DT_F8E4M3, DT_F8E5M2 = 10, 11
+DT_F4E2M1X2, DT_UE8M0 = 12, 13
 
 _lib = None
 
@@ -66,6 +67,14 @@ def lib() -> C.CDLL:
     L.oracle_convert_f32_to_fp8.restype = None
     L.oracle_convert_fp8_to_f32.argtypes = [P, P, u64, i32]
     L.oracle_convert_fp8_to_f32.restype = None
+    L.oracle_pack_e2m1x2.argtypes = [P, P, u64]
+    L.oracle_pack_e2m1x2.restype = None
+    L.oracle_unpack_e2m1x2.argtypes = [P, P, u64]
+    L.oracle_unpack_e2m1x2.restype = None
+    L.oracle_ue8m0_to_f32.argtypes = [C.c_uint8]
+    L.oracle_ue8m0_to_f32.restype = f32
+    L.oracle_gemm_scaled.argtypes = [P, P, P, P, P, i32, i32] + [i64] * 15 + [i32]
+    L.oracle_gemm_scaled.restype = None
     L.oracle_cpu_gemm.argtypes = [P, P, P, i32, i32, i64, i64, i64, i64, i64, i64, i32, i32]
     L.oracle_cpu_gemm.restype = C.c_double
     _lib = L
@@ -125,6 +134,52 @@ def from_fp8(x: np.ndarray, dtype: int = DT_F8E4M3) -> np.ndarray:
     out = np.empty(x.shape, dtype=np.float32)
     lib().oracle_convert_fp8_to_f32(_p(x), _p(out), x.size, int(dtype == DT_F8E5M2))
     return out
+
+
+def pack_e2m1x2(x: np.ndarray) -> np.ndarray:
+    """f32 -> packed e2m1 pairs, first element in the low nibble (e2m1x2::from_f32_slice, fp4.rs:204-216)."""
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+    out = np.empty((x.size + 1) // 2, dtype=np.uint8)
+    lib().oracle_pack_e2m1x2(_p(x), _p(out), x.size)
+    return out
+
+
+def unpack_e2m1x2(bits: np.ndarray, n: int | None = None) -> np.ndarray:
+    bits = np.ascontiguousarray(bits, dtype=np.uint8).reshape(-1)
+    n = 2 * bits.size if n is None else n
+    out = np.empty(n, dtype=np.float32)
+    lib().oracle_unpack_e2m1x2(_p(bits), _p(out), n)
+    return out
+
+
+def from_ue8m0(bits: np.ndarray) -> np.ndarray:
+    """ue8m0 -> f32: 2^(bits - 127), 0xFF = NaN (fp8/fp8_e8m0.rs)."""
+    bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    return np.array([lib().oracle_ue8m0_to_f32(int(b)) for b in bits.reshape(-1)], dtype=np.float32).reshape(bits.shape)
+
+
+def gemm_scaled(a, sa, b, sb, m: int, n: int, k: int, *, dtype_ab: int, dtype_c: int = DT_F32, block: int = 32,
+                lda=None, ldb=None, ldc=None, ld_sa=None, ld_sb=None, batch: int = 1, stride_a=None, stride_b=None,
+                stride_c=None, stride_sa=None, stride_sb=None, acc_f64: bool = False) -> np.ndarray:
+    """Block-scaled C = (A .* SA) (B .* SB)^T following test_cmma_scaled (runtime_tests/cmma.rs:1572-1591)."""
+    a = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1)
+    b = np.ascontiguousarray(b, dtype=np.uint8).reshape(-1)
+    sa = np.ascontiguousarray(sa, dtype=np.uint8).reshape(-1)
+    sb = np.ascontiguousarray(sb, dtype=np.uint8).reshape(-1)
+    lda = k if lda is None else lda
+    ldb = k if ldb is None else ldb
+    ldc = n if ldc is None else ldc
+    ld_sa = k // block if ld_sa is None else ld_sa
+    ld_sb = k // block if ld_sb is None else ld_sb
+    stride_a = m * lda if stride_a is None else stride_a
+    stride_b = n * ldb if stride_b is None else stride_b
+    stride_c = m * ldc if stride_c is None else stride_c
+    stride_sa = m * ld_sa if stride_sa is None else stride_sa
+    stride_sb = n * ld_sb if stride_sb is None else stride_sb
+    c = np.zeros(max(batch * stride_c, m * ldc), dtype=_NP_OF[dtype_c])
+    lib().oracle_gemm_scaled(_p(a), _p(sa), _p(b), _p(sb), _p(c), dtype_ab, dtype_c, m, n, k, block, lda, ldb, ldc, ld_sa, ld_sb,
+                             batch, stride_a, stride_b, stride_c, stride_sa, stride_sb, int(acc_f64))
+    return c
 
 
 _NP_OF = {DT_F32: np.float32, DT_BF16: np.uint16, DT_F16: np.uint16, DT_F8E4M3: np.uint8, DT_F8E5M2: np.uint8}

@@ -250,6 +250,98 @@ ORACLE_API void oracle_gemm(const void *A, const void *B, void *C, int dtype_ab,
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Block-scaled GEMM (MX formats).  Restates the expectation loops of test_cmma_scaled / test_cmma_scaled_fp4
+ * (crates/cubecl-core/src/runtime_tests/cmma.rs:1572-1591, :1684-1703):
+ *     sum += lhs[i,l] * lhs_scale[i, l / block] * rhs[l,j] * rhs_scale[j, l / block]      (f32, left to right)
+ * with A row-major [M][K], B stored [N][K] ("col-major", :1527-1529), one ue8m0 scale per `block` consecutive k
+ * (block = k / scales_factor there), scales laid out [M][K/block] and [N][K/block] (:1549-1560).
+ * Element types: e4m3 / e5m2 (above) and e2m1x2 = two e2m1 per byte, the FIRST element in the LOW nibble
+ * (crates/cubecl-common/src/float/fp4.rs:204-216, :219-224).  e2m1 (1-2-1, bias 1; third-party `float4` 0.2.0
+ * underneath, not vendored) has no NaN and no infinity; its 16 values are the OCP MX table
+ * {0, 0.5, 1, 1.5, 2, 3, 4, 6} x {+,-}.  ue8m0 (fp8/fp8_e8m0.rs): value 2^(bits - 127), 0xFF = NaN.
+ * ------------------------------------------------------------------------------------------ */
+static const float E2M1_VALUES[8] = { 0.0f, 0.5f, 1.0f, 1.5f, 2.0f, 3.0f, 4.0f, 6.0f };
+ORACLE_API float oracle_e2m1_to_f32(uint8_t nibble)
+{
+    const float v = E2M1_VALUES[nibble & 7u];
+    return (nibble & 8u) ? -v : v;
+}
+/* round to nearest, ties to the even code, saturating at +-6; NaN -> +-6 is NOT pinned by the reference (e2m1 has
+ * no NaN; the float4 crate's choice is unknown here) and nothing on the path produces it */
+ORACLE_API uint8_t oracle_f32_to_e2m1(float f)
+{
+    const uint8_t sign = (f32_bits(f) >> 28) & 8u;
+    const float a = fabsf(f);
+    uint8_t code = 7;
+    if (!(a == a)) return (uint8_t)(sign | 7u);
+    for (int c = 0; c < 7; ++c) {
+        const float mid = 0.5f * (E2M1_VALUES[c] + E2M1_VALUES[c + 1]);
+        if (a < mid || (a == mid && (c & 1) == 0)) { code = (uint8_t)c; break; }
+    }
+    return (uint8_t)(sign | code);
+}
+ORACLE_API float oracle_ue8m0_to_f32(uint8_t b)
+{
+    if (b == 0xFFu) return bits_f32(0x7FC00000u);
+    if (b == 0u) return bits_f32(0x00400000u);               /* 2^-127: a subnormal f32, exactly representable */
+    return bits_f32((uint32_t)b << 23);
+}
+ORACLE_API void oracle_pack_e2m1x2(const float *src, uint8_t *dst, uint64_t n)      /* fp4.rs:204-216 */
+{
+    for (uint64_t i = 0; i < (n + 1) / 2; ++i) {
+        const uint8_t a = oracle_f32_to_e2m1(src[2 * i]);
+        const uint8_t b = (2 * i + 1 < n) ? oracle_f32_to_e2m1(src[2 * i + 1]) : 0;
+        dst[i] = (uint8_t)((a & 0x0F) | ((b << 4) & 0xF0));
+    }
+}
+ORACLE_API void oracle_unpack_e2m1x2(const uint8_t *src, float *dst, uint64_t n)
+{
+    for (uint64_t i = 0; i < n; ++i) dst[i] = oracle_e2m1_to_f32((uint8_t)((src[i / 2] >> ((i & 1) * 4)) & 0xF));
+}
+
+enum { DT_F4E2M1X2 = 12 };
+static inline float load_mx_elem(const void *p, int dtype, int64_t idx)
+{
+    if (dtype == DT_F4E2M1X2) return oracle_e2m1_to_f32((uint8_t)((((const uint8_t *)p)[idx / 2] >> ((idx & 1) * 4)) & 0xF));
+    return load_elem(p, dtype, idx);
+}
+
+/* lda / ldb / strides in ELEMENTS (an e2m1x2 row of K elements is K/2 bytes; lda must be even then);
+ * ld_sa / ld_sb and the scale batch strides in bytes (= ue8m0 elements). */
+ORACLE_API void oracle_gemm_scaled(const void *A, const uint8_t *SA, const void *B, const uint8_t *SB, void *C,
+                                   int dtype_ab, int dtype_c, int64_t M, int64_t N, int64_t K, int64_t block,
+                                   int64_t lda, int64_t ldb, int64_t ldc, int64_t ld_sa, int64_t ld_sb,
+                                   int64_t batch, int64_t stride_a, int64_t stride_b, int64_t stride_c,
+                                   int64_t stride_sa, int64_t stride_sb, int acc_f64)
+{
+    for (int64_t b = 0; b < batch; ++b) {
+        const int64_t oa = b * stride_a, ob = b * stride_b, oc = b * stride_c;
+        const uint8_t *sa = SA + b * stride_sa, *sb = SB + b * stride_sb;
+        for (int64_t m = 0; m < M; ++m) {
+            for (int64_t n = 0; n < N; ++n) {
+                float sum = 0.0f;
+                double sum64 = 0.0;
+                for (int64_t k = 0; k < K; ++k) {
+                    const float l = load_mx_elem(A, dtype_ab, oa + m * lda + k);
+                    const float ls = oracle_ue8m0_to_f32(sa[m * ld_sa + k / block]);
+                    const float r = load_mx_elem(B, dtype_ab, ob + n * ldb + k);
+                    const float rs = oracle_ue8m0_to_f32(sb[n * ld_sb + k / block]);
+                    if (acc_f64) {
+                        sum64 += (double)l * (double)ls * (double)r * (double)rs;
+                    } else {
+                        float p = l * ls;          /* lhs_val * lhs_scale * rhs_val * rhs_scale, left to right */
+                        p = p * r;
+                        p = p * rs;
+                        sum += p;
+                    }
+                }
+                store_elem(C, dtype_c, oc + m * ldc + n, acc_f64 ? sum64 : (double)sum);
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * Reductions.
  * ------------------------------------------------------------------------------------------ */
 

@@ -169,6 +169,77 @@ def test_fp8_gemm_is_exact_in_f32_for_small_k(oracle):
     assert np.allclose(c32, c64, rtol=0, atol=1e-5)
 
 
+# ---- block-scaled MMA (runtime_tests/cmma.rs:1476-1704) -------------------------------------------------------------
+def _scaled_case(oracle, m, n, k, factor, fp4=False):
+    """The reference test's data (cmma.rs:1517-1531 / :1624-1641), generated exactly as written there."""
+    i, j = np.meshgrid(np.arange(m), np.arange(k), indexing="ij")
+    jn, ik = np.meshgrid(np.arange(n), np.arange(k), indexing="ij")
+    if fp4:
+        lhs = oracle.unpack_e2m1x2(np.arange(16, dtype=np.uint8) * 0x11)[::2][((i + j) % 15) + 1]     # e2m1::from_bits(((i+j)%15)+1)
+        rhs = oracle.unpack_e2m1x2(np.arange(16, dtype=np.uint8) * 0x11)[::2][((ik + jn) % 15) + 1]
+    else:
+        lhs = (i * 2 + j).astype(np.float32)
+        rhs = (ik * 3 + jn).astype(np.float32)
+    si, sj = np.meshgrid(np.arange(m), np.arange(factor), indexing="ij")
+    lhs_scales = (si * 2 + sj + 120).astype(np.uint8)
+    sjn, sif = np.meshgrid(np.arange(n), np.arange(factor), indexing="ij")
+    rhs_scales = (sif * 3 + sjn + 120).astype(np.uint8)
+    return lhs.astype(np.float32), lhs_scales, rhs.astype(np.float32), rhs_scales
+
+
+def _scaled_expected(lhs, ls, rhs, rs, m, n, k, factor):
+    """cmma.rs:1572-1591 verbatim in numpy: f32, left to right."""
+    out = np.zeros((m, n), dtype=np.float32)
+    for l in range(k):
+        blk = l // (k // factor)
+        p = (lhs[:, l:l + 1] * ls[:, blk:blk + 1]).astype(np.float32)
+        p = (p * rhs[None, :, l]).astype(np.float32)
+        p = (p * rs[None, :, blk]).astype(np.float32)
+        out = (out + p).astype(np.float32)
+    return out
+
+
+@pytest.mark.parametrize("dt", ["e4m3", "e5m2"])
+def test_scaled_mma_fp8_reference_case(oracle, dt):
+    m, n, k, factor = 16, 8, 32, 1                                        # cmma.rs:1913-1916
+    dtype = {"e4m3": oracle.DT_F8E4M3, "e5m2": oracle.DT_F8E5M2}[dt]
+    lhs, lsc, rhs, rsc = _scaled_case(oracle, m, n, k, factor)
+    a, b = oracle.to_fp8(lhs, dtype), oracle.to_fp8(rhs, dtype)
+    got = oracle.gemm_scaled(a, lsc, b, rsc, m, n, k, dtype_ab=dtype, block=k // factor).reshape(m, n)
+    # bit-exact against the loop evaluated on the values the fp8 buffers really hold ...
+    want = _scaled_expected(oracle.from_fp8(a, dtype), oracle.from_ue8m0(lsc), oracle.from_fp8(b, dtype), oracle.from_ue8m0(rsc),
+                            m, n, k, factor)
+    assert np.array_equal(got, want)
+    # ... and, like the reference (assert_equals_approx 0.03, :1593), close to the loop on the unrounded integers
+    # (the reference's own budget for the A::from(i*2+j) rounding; e5m2 keeps 2 mantissa bits, so only e4m3 fits it)
+    ideal = _scaled_expected(lhs, oracle.from_ue8m0(lsc), rhs, oracle.from_ue8m0(rsc), m, n, k, factor)
+    if dt == "e4m3":
+        assert np.all(np.abs(got - ideal) <= 0.03 * np.abs(ideal) + 1e-6)
+
+
+def test_scaled_mma_fp4_reference_case(oracle):
+    m, n, k, factor = 16, 8, 64, 2                                        # cmma.rs:1936
+    lhs, lsc, rhs, rsc = _scaled_case(oracle, m, n, k, factor, fp4=True)
+    a, b = oracle.pack_e2m1x2(lhs), oracle.pack_e2m1x2(rhs)
+    assert np.array_equal(oracle.unpack_e2m1x2(a), lhs.reshape(-1))        # every value of the test is an e2m1 value
+    got = oracle.gemm_scaled(a, lsc, b, rsc, m, n, k, dtype_ab=oracle.DT_F4E2M1X2, block=k // factor).reshape(m, n)
+    want = _scaled_expected(lhs, oracle.from_ue8m0(lsc), rhs, oracle.from_ue8m0(rsc), m, n, k, factor)
+    assert np.array_equal(got, want)
+
+
+def test_e2m1_and_ue8m0_tables(oracle):
+    # OCP MX value table of e2m1 (e2m1::MAX = 0x7 = 6.0, MIN = 0xf, fp4.rs:31-35); low nibble first (fp4.rs:204-224)
+    vals = oracle.unpack_e2m1x2(np.arange(16, dtype=np.uint8) * 0x11)[::2]
+    assert vals.tolist() == [0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0, -0.0, -0.5, -1.0, -1.5, -2.0, -3.0, -4.0, -6.0]
+    assert oracle.pack_e2m1x2(np.float32([1.0, -6.0, 0.5])).tolist() == [0xF2, 0x01]
+    assert oracle.unpack_e2m1x2(np.uint8([0xF2])).tolist() == [1.0, -6.0]
+    # round to nearest, ties to the even code, saturating
+    x = np.float32([0.24, 0.25, 0.26, 0.75, 1.25, 1.75, 2.5, 3.5, 5.0, 5.1, 7.0, 1e9, -0.75])
+    assert oracle.unpack_e2m1x2(oracle.pack_e2m1x2(x), x.size).tolist() == [0.0, 0.0, 0.5, 1.0, 1.0, 2.0, 2.0, 4.0, 4.0, 6.0, 6.0, 6.0, -1.0]
+    s = oracle.from_ue8m0(np.uint8([0, 1, 126, 127, 128, 254, 255]))
+    assert s[:6].tolist() == [2.0 ** -127, 2.0 ** -126, 0.5, 1.0, 2.0, 2.0 ** 127] and np.isnan(s[6])
+
+
 def test_sum_things_input(oracle):
     # examples/sum_things/src/lib.rs:180: [-1, 10, 1, 5] -> 15
     x = np.array([-1.0, 10.0, 1.0, 5.0], dtype=np.float32)
