@@ -73,9 +73,11 @@ template <> struct lp<MI355_DTYPE_F16> {
     static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c)
     { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
-// fp8: one v_mfma_f32_32x32x64_f8f6f4 (64 cycles, twice the bf16 rate) eats 32 bytes per lane and operand: lane-half
-// h supplies k = 32h .. 32h+31 of a 64-wide k-step, i.e. two adjacent 16-byte chunks of the row.  A K-tile (128
-// k-values) is two such steps.  The instruction is emitted without block scales (all scale operands zero selects
+// fp8: one v_mfma_f32_32x32x64_f8f6f4 (64 cycles, twice the bf16 rate) eats 32 bytes per lane and operand.  Measured
+// with structured scales (tools/dev/mx_diag2.py): registers 0-3 of BOTH lane-halves form the first 32 k-values of the
+// 64-wide step (lanes 0-31: k 0..15, lanes 32-63: k 16..31; scaled, in the MX form, by the scale lanes 0-31 supply),
+// registers 4-7 the second 32 (scale from lanes 32-63).  Unscaled, any consistent k permutation is as good as another,
+// so that kernel simply feeds lane-half h two adjacent 16-byte chunks.  A K-tile (128 k-values) is two such steps.  The instruction is emitted without block scales (all scale operands zero selects
 // the unscaled encoding; checked in the ISA); cbsz / blgp = 0 reads e4m3, 1 reads e5m2.
 template <> struct lp<MI355_DTYPE_F8E4M3> {
     typedef i32x8 frag;
@@ -248,7 +250,9 @@ gemm_lp256w4_kernel(gemm_args g)
 
     // ---- fragment read offsets: row*128 + ((2s+h) ^ f) * 16, f = (row>>1)&7 = (l31>>1)&7 for every tile row
     const int f = (l31 >> 1) & 7;
-    const int hd = (f & 1) ? -16 : 16;                  // fp8: the second 16 bytes of a fragment sit in physical chunk ^ 1
+    // fp8: the second 16 bytes of a fragment sit in physical chunk ^ 1 (unscaled: logical chunks 2c, 2c+1); MX: logical
+    // chunks c and c+2 (registers 0-3 of both lane-halves are one MX block, registers 4-7 the next) = physical ^ 2
+    const int hd = MX ? ((f & 2) ? -32 : 32) : ((f & 1) ? -16 : 16);
     const int rowoff_a = (wm * 128 + l31) * ROW_BYTES;
     const int rowoff_b = BNN ? (wn * 128 + l31) * 4 : (wn * 128 + l31) * ROW_BYTES;
 
@@ -268,26 +272,24 @@ gemm_lp256w4_kernel(gemm_args g)
     uint32_t sc_a[4] = {0, 0, 0, 0}, sc_b[4] = {0, 0, 0, 0}, sn_a[4] = {0, 0, 0, 0}, sn_b[4] = {0, 0, 0, 0};
     const char *sbase_a = nullptr, *sbase_b = nullptr;                    // uniform: ST[t] + tile row 0 (+ batch)
     uint32_t svoff_a = 0, svoff_b = 0;
+    const int sshift = F4 ? 0 : 8 * h;
     int64_t sstep_a = 0, sstep_b = 0;                                     // bytes from ST[t] to ST[t+1]
     if constexpr (MX) {
         sstep_a = (int64_t)g.tiles_m * BM * NB;
         sstep_b = (int64_t)g.tiles_n * BN * NB;
         sbase_a = static_cast<const char *>(g.sa) + batch * g.stride_sa + m0 * NB;
         sbase_b = static_cast<const char *>(g.sb) + batch * g.stride_sb + n0 * NB;
-        svoff_a = (uint32_t)((wm * 128 + l31) * NB + h * (NB / 2));
-        svoff_b = (uint32_t)((wn * 128 + l31) * NB + h * (NB / 2));
+        // fp4: a lane-half owns the 4 blocks (bytes) 4h .. 4h+3 of the K-tile row; fp8: every lane fetches the row's
+        // 4 bytes and shifts its own into place when it takes them (lanes 0-31 scale blocks 0 / 2, lanes 32-63 blocks 1 / 3)
+        svoff_a = (uint32_t)((wm * 128 + l31) * NB + (F4 ? 4 * h : 0));
+        svoff_b = (uint32_t)((wn * 128 + l31) * NB + (F4 ? 4 * h : 0));
     }
     // scale load number Q of a K-tile: Q = 0..3 -> A row-block Q, 4..7 -> B row-block Q-4 (32 rows = 32*NB bytes apart)
     auto scale_one = [&](auto qq) {
         constexpr int Q = decltype(qq)::value;
         if constexpr (MX) {
-            if constexpr (F4) {
-                if constexpr (Q < 4) scale_ld32(sn_a[Q & 3], sbase_a, svoff_a, (Q & 3) * 32 * NB);
-                else scale_ld32(sn_b[Q & 3], sbase_b, svoff_b, (Q & 3) * 32 * NB);
-            } else {
-                if constexpr (Q < 4) scale_ld16(sn_a[Q & 3], sbase_a, svoff_a, (Q & 3) * 32 * NB);
-                else scale_ld16(sn_b[Q & 3], sbase_b, svoff_b, (Q & 3) * 32 * NB);
-            }
+            if constexpr (Q < 4) scale_ld32(sn_a[Q & 3], sbase_a, svoff_a, (Q & 3) * 32 * NB);
+            else scale_ld32(sn_b[Q & 3], sbase_b, svoff_b, (Q & 3) * 32 * NB);
         }
     };
     // the scales of the next K-tile have landed (at most NEWER younger vector-memory operations may still fly): take them
@@ -296,7 +298,8 @@ gemm_lp256w4_kernel(gemm_args g)
         asm volatile("s_waitcnt vmcnt(" W4_STR(NEWER) ")"                                                       \
                      : "+v"(sn_a[0]), "+v"(sn_a[1]), "+v"(sn_a[2]), "+v"(sn_a[3]), "+v"(sn_b[0]), "+v"(sn_b[1]),   \
                        "+v"(sn_b[2]), "+v"(sn_b[3])::"memory");                                                 \
-        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) { sc_a[q_] = sn_a[q_]; sc_b[q_] = sn_b[q_]; }          \
+        /* fp8: byte 0 / 2 of the shifted word = block h / 2+h of the K-tile = this lane-half's scale in k-step 0 / 1 */ \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) { sc_a[q_] = sn_a[q_] >> sshift; sc_b[q_] = sn_b[q_] >> sshift; } \
         sbase_a += sstep_a;                                                                                    \
         sbase_b += sstep_b;                                                                                    \
     }
@@ -412,9 +415,10 @@ gemm_lp256w4_kernel(gemm_args g)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     {
-        // MX: lane-half h owns the contiguous half of the row (chunks 4h .. 4h+3 = MX blocks NB/2*h ..), so that its
-        // scale bytes are contiguous; unscaled: the interleaved mapping the measured kernels were tuned with
-        const int x = MX ? ((4 * h) ^ f) << 4 : F8 ? ((2 * h) ^ f) << 4 : (h ^ f) << 4;
+        // fp4 (MX): lane-half h owns the contiguous half of the row (chunks = MX blocks 4h .. 4h+3), so that its four
+        // scale bytes are one word; fp8 MX: k-step d = chunks 4d+h (registers 0-3) and 4d+2+h (registers 4-7);
+        // unscaled: the mappings the measured kernels were tuned with
+        const int x = F4 ? ((4 * h) ^ f) << 4 : (F8 && !MX) ? ((2 * h) ^ f) << 4 : (h ^ f) << 4;
         const char *rd_a = smem + rowoff_a + x, *rd_b = smem + UNIT_BYTES + rowoff_b + (BNN ? (4 * h) * 1024 : x);
         read_one(IC<0>{}, IC<0>{}, rd_a, rd_b); read_one(IC<0>{}, IC<1>{}, rd_a, rd_b);
         read_one(IC<0>{}, IC<2>{}, rd_a, rd_b); read_one(IC<0>{}, IC<3>{}, rd_a, rd_b);
@@ -432,8 +436,8 @@ gemm_lp256w4_kernel(gemm_args g)
     int sa = 0;                          // ring byte offset of unit 2t   (A of K-tile t)
     int sb = UNIT_BYTES;                 // ring byte offset of unit 2t+1 (B of K-tile t)
     auto adv = [](int x, int n) { x += n * UNIT_BYTES; return x >= LDS_BYTES ? x - LDS_BYTES : x; };
-    const int x1 = ((MX ? 4 * h + 1 : 2 + h) ^ f) << 4, x2 = ((MX ? 4 * h + 2 : 4 + h) ^ f) << 4,
-              x3 = ((MX ? 4 * h + 3 : 6 + h) ^ f) << 4, x0 = ((MX ? 4 * h : h) ^ f) << 4;
+    const int x1 = ((F4 ? 4 * h + 1 : 2 + h) ^ f) << 4, x2 = ((F4 ? 4 * h + 2 : 4 + h) ^ f) << 4,
+              x3 = ((F4 ? 4 * h + 3 : 6 + h) ^ f) << 4, x0 = ((F4 ? 4 * h : h) ^ f) << 4;
     // B fragment offsets per k-step: same chunks as A for [N][K]; k-rows 8s + 4h (.. +3) for row-major B
     const int y0 = BNN ? (4 * h) * 1024 : x0, y1 = BNN ? (8 + 4 * h) * 1024 : x1, y2 = BNN ? (16 + 4 * h) * 1024 : x2,
               y3 = BNN ? (24 + 4 * h) * 1024 : x3;
@@ -482,7 +486,7 @@ gemm_lp256w4_kernel(gemm_args g)
     //     d=1, MFMA 8-15 : two reads of frags(t+1, d=0) and one DMA piece of unit 2t+5 after each
     //   MX: the 8 scale loads of K-tile t+1 follow the even MFMAs of d=0 (SQ = load number, -1 = none).
 #define W8_G(CUR, NXT, IDX, NR, R0, DM, IS_B, J, SQ)                                                        \
-    mfma_one(IC<CUR>{}, IC<IDX>{}, IC<CUR>{});            /* buffer number == k-step d == scale byte */      \
+    mfma_one(IC<CUR>{}, IC<IDX>{}, IC<2 * CUR>{});        /* buffer number == k-step d; MX scale byte 2d */   \
     if constexpr ((NR) >= 1) read_one(IC<NXT>{}, IC<(R0)>{}, rd_a, rd_b);                                    \
     if constexpr ((NR) >= 2) read_one(IC<NXT>{}, IC<(R0) + 1>{}, rd_a, rd_b);                                \
     if constexpr ((SQ) >= 0) scale_one(IC<((SQ) >= 0 ? (SQ) : 0)>{});                                        \
@@ -523,8 +527,8 @@ gemm_lp256w4_kernel(gemm_args g)
         sa = sa1;                                                                                           \
         sb = sb1;                                                                                           \
     }
-    // fp8: first chunk of this lane-half for k-steps d = 0, 1 (MX: the half-row 4h .. 4h+3, see the prologue)
-    const int z0 = ((MX ? 4 * h : 2 * h) ^ f) << 4, z1 = ((MX ? 4 * h + 2 : 4 + 2 * h) ^ f) << 4;
+    // fp8: first chunk of this lane-half for k-steps d = 0, 1 (MX: chunk 4d + h, its partner 4d + 2 + h via hd)
+    const int z0 = ((MX ? h : 2 * h) ^ f) << 4, z1 = ((MX ? 4 + h : 4 + 2 * h) ^ f) << 4;
     W4_STAMP(1);
     int t = 0;
     // MX: every K-tile but the last also fetches the next one's scales (SC), so the DMA-free tail splits in two
