@@ -442,6 +442,32 @@ def main():
             return out
         guarded("gemm_fp8_e4m3", gemm_fp8)
 
+        def gemm_mx():
+            # block-scaled variants: one ue8m0 scale per 32 k-values of each operand row, bf16 out;
+            # the timed call includes the re-arrangement of the scales into the kernel's per-K-tile layout
+            out = {}
+            for name, dt, epb, peak in (("mxfp8_e4m3", ElemType.F8E4M3, 1, 5000.0), ("mxfp4_e2m1", ElemType.F4E2M1X2, 2, 10000.0)):
+                S_ = 8192
+                if epb == 1:
+                    qa = TensorHandle.uniform(client, (S_, S_), dt, SEED, 910, -1.0, 1.0)
+                    qb = TensorHandle.uniform(client, (S_, S_), dt, SEED, 911, -1.0, 1.0)
+                else:                                              # uniformly random nibble pairs
+                    qa = TensorHandle.uniform(client, (S_ * S_ // 2,), dt, SEED, 910, 0.0, 256.0)
+                    qb = TensorHandle.uniform(client, (S_ * S_ // 2,), dt, SEED, 911, 0.0, 256.0)
+                sa = TensorHandle.uniform(client, (S_ * S_ // 32,), ElemType.UE8M0, SEED, 912, 124.0, 131.0)
+                sb = TensorHandle.uniform(client, (S_ * S_ // 32,), ElemType.UE8M0, SEED, 913, 124.0, 131.0)
+                qc = client.empty(S_ * S_ * 2)
+                d = N.GemmScaledDesc(m=S_, n=S_, k=S_, batch=1, lda=S_, ldb=S_, ldc=S_, ld_sa=S_ // 32, ld_sb=S_ // 32, dtype_a=int(dt),
+                                     dtype_b=int(dt), dtype_c=N.DTYPE_BF16, block=32)
+                call = lambda: client._s.check(lib.mi355_gemm_scaled(ctx, None, C.byref(d), qa.device_ptr(), sa.device_ptr(),
+                                                                     qb.device_ptr(), sb.device_ptr(), qc.device_ptr()))
+                time_op(client, ev, call, 40)
+                b2b = time_op(client, ev, call, 30)
+                tf = 2.0 * S_ ** 3 / b2b / 1e9
+                out[name] = {"shape": f"{S_}^3", "back_to_back_ms": round(b2b, 4), "TFLOPs": round(tf, 1), "frac_of_dense_peak": round(tf / peak, 4)}
+            return out
+        guarded("gemm_block_scaled", gemm_mx)
+
         def batched_c5():
             per_gpu = 64                      # 512 matrices / 8 GPUs
             M = 2048
