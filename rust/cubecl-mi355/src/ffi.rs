@@ -33,6 +33,12 @@ pub const MI355_DTYPE_I64: i32 = 6;
 pub const MI355_DTYPE_U64: i32 = 7;
 pub const MI355_DTYPE_U8: i32 = 8;
 pub const MI355_DTYPE_I8: i32 = 9;
+pub const MI355_DTYPE_F8E4M3: i32 = 10;
+pub const MI355_DTYPE_F8E5M2: i32 = 11;
+pub const MI355_DTYPE_F4E2M1X2: i32 = 12;
+pub const MI355_DTYPE_UE8M0: i32 = 13;
+pub const MI355_ALLOC_MODE_AUTO: i32 = 0;
+pub const MI355_ALLOC_MODE_PERSISTENT: i32 = 1;
 
 pub const MI355_REDUCE_SUM: i32 = 0;
 pub const MI355_REDUCE_MEAN: i32 = 1;
@@ -187,4 +193,67 @@ unsafe extern "C" {
     // Profiling
     pub fn mi355_profile_start(ctx: *mut mi355_ctx, stream: mi355_stream, out_token: *mut u64) -> i32;
     pub fn mi355_profile_stop(ctx: *mut mi355_ctx, stream: mi355_stream, token: u64, out_nanos: *mut u64) -> i32;
+}
+
+// ---- entry points added after the first cut of this crate (same header; not yet used by server.rs) -----------------
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct mi355_gemm_scaled_desc {
+    pub m: i64, pub n: i64, pub k: i64, pub batch: i64,
+    pub lda: i64, pub ldb: i64, pub ldc: i64,
+    pub ld_sa: i64, pub ld_sb: i64,
+    pub stride_a: i64, pub stride_b: i64, pub stride_c: i64, pub stride_sa: i64, pub stride_sb: i64,
+    pub dtype_a: i32, pub dtype_b: i32, pub dtype_c: i32,
+    pub block: i32, pub algo: i32, pub reserved: i32,
+}
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct mi355_memory_usage {
+    pub number_allocs: u64, pub bytes_in_use: u64, pub bytes_padding: u64, pub bytes_reserved: u64,
+    pub driver_allocs: u64, pub driver_frees: u64, pub cache_hits: u64, pub reserved: u64,
+}
+#[repr(C)]
+pub struct mi355_graph {
+    _private: [u8; 0],
+}
+unsafe extern "C" {
+    // MmaDefinition::execute_scaled at matmul level (cmma.rs:795-840)
+    pub fn mi355_gemm_scaled(ctx: *mut mi355_ctx, stream: mi355_stream, desc: *const mi355_gemm_scaled_desc, a: *const c_void,
+                             a_scales: *const c_void, b: *const c_void, b_scales: *const c_void, c: *mut c_void) -> i32;
+    pub fn mi355_gemm_scaled_select(ctx: *mut mi355_ctx, desc: *const mi355_gemm_scaled_desc, out_algo: *mut i32) -> i32;
+    pub fn mi355_gemm_select(ctx: *mut mi355_ctx, desc: *const mi355_gemm_desc, out_algo: *mut i32) -> i32;
+    // an alternative to MemoryManagement-over-Mi355Storage for hosts without the reference's pool (memory_manage.rs)
+    pub fn mi355_pool_alloc(ctx: *mut mi355_ctx, stream: mi355_stream, bytes: u64, out_dptr: *mut *mut c_void) -> i32;
+    pub fn mi355_pool_free(ctx: *mut mi355_ctx, stream: mi355_stream, dptr: *mut c_void) -> i32;
+    pub fn mi355_pool_cleanup(ctx: *mut mi355_ctx, explicit_cleanup: i32) -> i32;
+    pub fn mi355_pool_mode(ctx: *mut mi355_ctx, mode: i32) -> i32;
+    pub fn mi355_pool_usage(ctx: *mut mi355_ctx, out: *mut mi355_memory_usage) -> i32;
+    // ComputeServer::{begin_capture, end_capture, replay} (server/base.rs:453-532)
+    pub fn mi355_graph_begin_capture(ctx: *mut mi355_ctx, stream: mi355_stream) -> i32;
+    pub fn mi355_graph_end_capture(ctx: *mut mi355_ctx, stream: mi355_stream, out_graph: *mut *mut mi355_graph) -> i32;
+    pub fn mi355_graph_replay(ctx: *mut mi355_ctx, stream: mi355_stream, graph: *mut mi355_graph) -> i32;
+    pub fn mi355_graph_destroy(ctx: *mut mi355_ctx, graph: *mut mi355_graph) -> i32;
+    // reductions over any axis, plane ops
+    pub fn mi355_reduce_axis_sum_f32(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const f32, out: *mut f32, outer: u64,
+                                     reduce: u64, inner: u64) -> i32;
+    pub fn mi355_reduce_axis_argmax_f32(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const f32, out_idx: *mut u32, outer: u64,
+                                        reduce: u64, inner: u64) -> i32;
+    pub fn mi355_reduce_last_axis_argmax_f32(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const f32, out_idx: *mut u32,
+                                             rows: u64, cols: u64, row_stride: u64) -> i32;
+    pub fn mi355_plane_reduce_f32(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const f32, out: *mut f32, n: u64, active: u32, op: i32) -> i32;
+    // synthetic data, casts, copies
+    pub fn mi355_fill_uniform(ctx: *mut mi355_ctx, stream: mi355_stream, dst: *mut c_void, dtype: i32, n: u64, seed: u64,
+                              tensor: u64, lo: f32, hi: f32) -> i32;
+    pub fn mi355_cast(ctx: *mut mi355_ctx, stream: mi355_stream, src: *const c_void, src_dtype: i32, dst: *mut c_void,
+                      dst_dtype: i32, n: u64) -> i32;
+    pub fn mi355_copy_d2d(ctx: *mut mi355_ctx, stream: mi355_stream, dst: *mut c_void, src: *const c_void, bytes: u64) -> i32;
+    pub fn mi355_read_async(ctx: *mut mi355_ctx, stream: mi355_stream, dst_host: *mut c_void, src_dptr: *const c_void, bytes: u64) -> i32;
+    // throughput probes (cubecl-std throughput runners)
+    pub fn mi355_probe_memory_read(ctx: *mut mi355_ctx, stream: mi355_stream, buf: *const c_void, bytes: u64, iters: u32, sink: *mut c_void) -> i32;
+    pub fn mi355_probe_memory_copy(ctx: *mut mi355_ctx, stream: mi355_stream, src: *const c_void, dst: *mut c_void, bytes: u64) -> i32;
+    pub fn mi355_probe_memory_write(ctx: *mut mi355_ctx, stream: mi355_stream, dst: *mut c_void, bytes: u64) -> i32;
+    pub fn mi355_probe_mfma(ctx: *mut mi355_ctx, stream: mi355_stream, dtype_ab: i32, iters: u32, sink: *mut c_void, out_ops: *mut u64) -> i32;
+    pub fn mi355_probe_mfma_data(ctx: *mut mi355_ctx, stream: mi355_stream, mode: i32, iters: u32, sink: *mut c_void, out_ops: *mut u64) -> i32;
+    pub fn mi355_probe_compute_direct(ctx: *mut mi355_ctx, stream: mi355_stream, iters: u32, sink: *mut c_void, out_ops: *mut u64) -> i32;
+    pub fn mi355_probe_launch_overhead(ctx: *mut mi355_ctx, stream: mi355_stream, launches: u32, sink: *mut c_void) -> i32;
 }
