@@ -206,10 +206,26 @@ gemm_lp256w4_kernel(gemm_args g)
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
 
+    // Workgroups go to XCD (linear id % 8).  The XCD remap runs over the whole (batch-major) tile sequence, so that an
+    // XCD's 32 resident tiles are a compact patch of ONE matrix of the batch (shared A / B panels in its L2) instead of
+    // 8 tiles each of 4 different matrices; for batch == 1 this is the plain per-matrix remap.
     uint32_t tm, tn;
-    tile_coords(xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n), g.tiles_m, g.tiles_n, g.group_m, tm, tn);
+#ifndef W4_BATCH_REMAP
+#define W4_BATCH_REMAP 1
+#endif
+    const uint32_t tiles_per = g.tiles_m * g.tiles_n;
+    uint32_t tile_lin, batch_u;
+    if (W4_BATCH_REMAP) {
+        const uint32_t v = xcd_remap(blockIdx.y * tiles_per + blockIdx.x, tiles_per * gridDim.y);
+        batch_u = v / tiles_per;
+        tile_lin = v - batch_u * tiles_per;
+    } else {
+        batch_u = blockIdx.y;
+        tile_lin = xcd_remap(blockIdx.x, tiles_per);
+    }
+    tile_coords(tile_lin, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
-    const int64_t batch = blockIdx.y;
+    const int64_t batch = batch_u;
     constexpr int ESZ = lp<DT>::ESZ;
     constexpr bool F8 = DT == MI355_DTYPE_F8E4M3 || DT == MI355_DTYPE_F8E5M2;
     constexpr bool F4 = DT == MI355_DTYPE_F4E2M1X2;
@@ -681,7 +697,7 @@ bool gemm_lp256w4_supports(const mi355_gemm_desc &d, const void *a, const void *
     if ((reinterpret_cast<uintptr_t>(a) & 15u) || (reinterpret_cast<uintptr_t>(b) & 15u)) return false;
     if (d.batch > 65535) return false;
     const int64_t tiles = ((d.m + BM - 1) / BM) * ((d.n + BN - 1) / BN);
-    if (tiles > 0x7FFFFFFF) return false;
+    if (tiles * std::max<int64_t>(d.batch, 1) > 0x7FFFFFFF) return false;   // the XCD remap runs over the (batch, tile) sequence in 32 bits
     if ((int64_t)BM * std::max(d.lda, d.ldb) * esz >= (1ll << 32)) return false;   // per-lane DMA offsets are 32-bit
     return true;
 }
@@ -737,7 +753,7 @@ bool gemm_lp256w4_mx_supports(const mi355_gemm_scaled_desc &d, const void *a, co
     const int64_t csz = d.dtype_c == MI355_DTYPE_F32 ? 4 : 2;
     if (((d.ldc * csz) & 15) || ((d.stride_c * csz) & 15) || (reinterpret_cast<uintptr_t>(c) & 15u)) return false;
     if (d.m < 1 || d.n < 1 || d.batch > 65535) return false;
-    if (((d.m + BM - 1) / BM) * ((d.n + BN - 1) / BN) > 0x7FFFFFFF) return false;
+    if (((d.m + BM - 1) / BM) * ((d.n + BN - 1) / BN) * std::max<int64_t>(d.batch, 1) > 0x7FFFFFFF) return false;
     if ((int64_t)BM * std::max(d.lda, d.ldb) / epb >= (1ll << 32)) return false;
     return true;
 }

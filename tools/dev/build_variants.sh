@@ -7,10 +7,10 @@ NAME=$1; FLAGS=$2; shift 2
 FILES=${@:-gemm_lp256.hip}
 mkdir -p variants/obj_$NAME
 OBJS=""
-for f in runtime.cpp comm.cpp gemm.cpp fill.hip reduce.hip probes.hip gemm_generic.hip gemm_f32.hip gemm_lp128.hip gemm_lp256.hip gemm_lp256w4.hip gemm_lp256p.hip gemm_splitk.hip gemm_relayout.hip; do
+for f in $(sed -n 's/^SRCS := //p' Makefile); do
   base=${f%.*}
   if echo " $FILES " | grep -q " $f "; then
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-value --offload-arch=gfx950 $FLAGS -x hip -c $f -o variants/obj_$NAME/$base.o
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-value -Wno-unused-result --offload-arch=gfx950 -I../../include $FLAGS -x hip -c $f -o variants/obj_$NAME/$base.o
     OBJS="$OBJS variants/obj_$NAME/$base.o"
   else
     OBJS="$OBJS build/$base.o"
