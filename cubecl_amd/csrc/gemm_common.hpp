@@ -59,6 +59,20 @@ __device__ __forceinline__ void tile_coords(uint32_t lin, uint32_t tiles_m, uint
     tn = in_group / gsize;
 }
 
+// Batched launches (grid.x = tiles, grid.y = batch; workgroups go to XCD (x + grid.x * y) % 8): the XCD remap runs over
+// the whole batch-major tile sequence, so that the tiles resident on one XCD are a compact patch of ONE matrix of the
+// batch (shared operand panels in that XCD's L2) rather than a few tiles each of several matrices.  Measured on the
+// 256x256 kernel: +3 % at 64 x 2048^3, +8 % at 256 x 1024^3; identical to the per-matrix remap for batch == 1.
+// Requires tiles * batch < 2^32 (checked by the kernels' supports()).
+__device__ __forceinline__ void batched_tile_coords(uint32_t tiles_m, uint32_t tiles_n, uint32_t group_m, uint32_t &tm,
+                                                    uint32_t &tn, uint32_t &batch)
+{
+    const uint32_t tiles_per = tiles_m * tiles_n;
+    const uint32_t v = xcd_remap(blockIdx.y * tiles_per + blockIdx.x, tiles_per * gridDim.y);
+    batch = v / tiles_per;
+    tile_coords(v - batch * tiles_per, tiles_m, tiles_n, group_m, tm, tn);
+}
+
 __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f)
 {
     uint32_t u = __float_as_uint(f);

@@ -44,10 +44,10 @@ gemm_f32_mfma_kernel(gemm_args g)
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
 
-    uint32_t tm, tn;
-    tile_coords(xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n), g.tiles_m, g.tiles_n, g.group_m, tm, tn);
+    uint32_t tm, tn, batch_u;
+    batched_tile_coords(g.tiles_m, g.tiles_n, g.group_m, tm, tn, batch_u);
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
-    const int64_t batch = blockIdx.y;
+    const int64_t batch = batch_u;
     const float *__restrict__ A = static_cast<const float *>(g.a) + batch * g.stride_a;
     const float *__restrict__ B = static_cast<const float *>(g.b) + batch * g.stride_b;
     float *__restrict__ C = static_cast<float *>(g.c) + batch * g.stride_c;
@@ -195,7 +195,7 @@ bool gemm_f32_mfma_supports(const mi355_gemm_desc &d, const void *a, const void 
     if (!d.trans_b && ((d.n & 3) || d.n < 4)) return false;
     if (d.batch > 65535) return false;
     const int64_t tiles = ((d.m + BM - 1) / BM) * ((d.n + BN - 1) / BN);
-    if (tiles > 0x7FFFFFFF) return false;
+    if (tiles * std::max<int64_t>(d.batch, 1) > 0x7FFFFFFF) return false;   // 32-bit (batch, tile) sequence for the XCD remap
     return true;
 }
 

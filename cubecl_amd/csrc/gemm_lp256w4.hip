@@ -206,24 +206,8 @@ gemm_lp256w4_kernel(gemm_args g)
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
 
-    // Workgroups go to XCD (linear id % 8).  The XCD remap runs over the whole (batch-major) tile sequence, so that an
-    // XCD's 32 resident tiles are a compact patch of ONE matrix of the batch (shared A / B panels in its L2) instead of
-    // 8 tiles each of 4 different matrices; for batch == 1 this is the plain per-matrix remap.
-    uint32_t tm, tn;
-#ifndef W4_BATCH_REMAP
-#define W4_BATCH_REMAP 1
-#endif
-    const uint32_t tiles_per = g.tiles_m * g.tiles_n;
-    uint32_t tile_lin, batch_u;
-    if (W4_BATCH_REMAP) {
-        const uint32_t v = xcd_remap(blockIdx.y * tiles_per + blockIdx.x, tiles_per * gridDim.y);
-        batch_u = v / tiles_per;
-        tile_lin = v - batch_u * tiles_per;
-    } else {
-        batch_u = blockIdx.y;
-        tile_lin = xcd_remap(blockIdx.x, tiles_per);
-    }
-    tile_coords(tile_lin, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
+    uint32_t tm, tn, batch_u;
+    batched_tile_coords(g.tiles_m, g.tiles_n, g.group_m, tm, tn, batch_u);      // XCD remap over the (batch, tile) sequence
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
     const int64_t batch = batch_u;
     constexpr int ESZ = lp<DT>::ESZ;
