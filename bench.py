@@ -296,6 +296,10 @@ def main():
             ms = time_op(client, ev, lambda: client._s.check(
                 lib.mi355_probe_mfma_data(ctx, None, 2, 10000, sink.device_ptr(), C.byref(n_ops))), 5)
             out["mfma_fp8_uniform_operands_TFLOPs"] = round(n_ops.value / ms / 1e9, 1)
+            for key, mode in (("mfma_mxfp4_TFLOPs", 3), ("mfma_mxfp4_random_operands_TFLOPs", 4)):
+                ms = time_op(client, ev, lambda: client._s.check(
+                    lib.mi355_probe_mfma_data(ctx, None, mode, 20000, sink.device_ptr(), C.byref(n_ops))), 5)
+                out[key] = round(n_ops.value / ms / 1e9, 1)
             # the reference's remaining throughput probes (examples/throughput: copy, write, compute-direct, launch)
             buf2 = client.empty(1 << 30)
             ms = time_op(client, ev, lambda: client._s.check(

@@ -193,6 +193,56 @@ probe_mfma_data_f8_kernel(uint32_t iters, float *__restrict__ sink)
     if (t == 1.2345e38f) sink[0] = t;
 }
 
+// The block-scaled instruction on fp4 (v_mfma_scale_f32_32x32x64_f8f6f4, cbsz = blgp = 4: 32 cycles per 32x32x64 step).
+// RANDOM = 0: every nibble 1.0, scales 2^0; RANDOM = 1: random nibbles and scales 2^-3 .. 2^3 that differ per lane and
+// rotate every iteration.
+template <int RANDOM>
+__global__ void __launch_bounds__(256)
+probe_mfma_data_f4_kernel(uint32_t iters, float *__restrict__ sink)
+{
+    const uint32_t tid = threadIdx.x;
+    i32x8 a[4], b[4];
+    int sa[4], sb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            a[i][e] = e < 4 ? (RANDOM ? (int)probe_mix(tid * 977u + i * 131u + e * 7u + blockIdx.x * 7919u) : 0x22222222) : 0;
+            b[i][e] = e < 4 ? (RANDOM ? (int)probe_mix(tid * 613u + i * 257u + e * 11u + 99991u + blockIdx.x * 104729u) : 0x22222222) : 0;
+        }
+        sa[i] = RANDOM ? (int)(0x7C7C7C7Cu + (probe_mix(tid * 31u + i) & 0x07070707u)) : 0x7F7F7F7F;
+        sb[i] = RANDOM ? (int)(0x7C7C7C7Cu + (probe_mix(tid * 57u + i + 77u) & 0x07070707u)) : 0x7F7F7F7F;
+    }
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (uint32_t it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b[j], a[i], acc[i][j], 4, 4, 0, sb[j], 0, sa[i]);
+        if (RANDOM) {
+            const i32x8 t = a[0];
+            a[0] = a[1]; a[1] = a[2]; a[2] = a[3]; a[3] = t;
+            const int ts = sa[0];
+            sa[0] = sa[1]; sa[1] = sa[2]; sa[2] = sa[3]; sa[3] = ts;
+        }
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+    if (t == 1.2345e38f) sink[0] = t;
+}
+
 // memory_direct_throughput (runners/memory_direct.rs:55-117): streaming copy, 16 B per lane, read + write counted.
 __global__ void __launch_bounds__(PR_BLOCK)
 probe_copy_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, uint64_t nvec)
@@ -335,14 +385,16 @@ MI355_API int32_t mi355_probe_mfma_data(mi355_ctx *ctx, mi355_stream stream, int
 {
     MI355_REQUIRE_CTX(ctx);
     if (!sink) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_probe_mfma_data: sink is NULL");
-    if (mode < 0 || mode > 2) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_probe_mfma_data: mode must be 0, 1 or 2");
+    if (mode < 0 || mode > 4) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_probe_mfma_data: mode must be 0 .. 4");
     const uint32_t grid = ctx->props.num_streaming_multiprocessors;   // one 4-wave workgroup per CU, one wave per SIMD
     hipStream_t s = stream_of(ctx, stream);
     if (mode == 0) hipLaunchKernelGGL(probe_mfma_data_kernel<0>, dim3(grid), dim3(256), 0, s, iters, static_cast<float *>(sink));
     else if (mode == 1) hipLaunchKernelGGL(probe_mfma_data_kernel<1>, dim3(grid), dim3(256), 0, s, iters, static_cast<float *>(sink));
-    else hipLaunchKernelGGL(probe_mfma_data_f8_kernel, dim3(grid), dim3(256), 0, s, iters, static_cast<float *>(sink));
+    else if (mode == 2) hipLaunchKernelGGL(probe_mfma_data_f8_kernel, dim3(grid), dim3(256), 0, s, iters, static_cast<float *>(sink));
+    else if (mode == 3) hipLaunchKernelGGL(probe_mfma_data_f4_kernel<0>, dim3(grid), dim3(256), 0, s, iters, static_cast<float *>(sink));
+    else hipLaunchKernelGGL(probe_mfma_data_f4_kernel<1>, dim3(grid), dim3(256), 0, s, iters, static_cast<float *>(sink));
     check_launch(ctx, "mi355_probe_mfma_data");
-    if (out_ops) *out_ops = (uint64_t)grid * 4ull * iters * 16ull * (2ull * 32 * 32 * (mode == 2 ? 64 : 16));
+    if (out_ops) *out_ops = (uint64_t)grid * 4ull * iters * 16ull * (2ull * 32 * 32 * (mode >= 2 ? 64 : 16));
     return MI355_OK;
 }
 

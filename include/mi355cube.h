@@ -427,7 +427,8 @@ int32_t mi355_probe_launch_overhead(mi355_ctx *ctx, mi355_stream stream, uint32_
                                     void *sink);
 /* The same issue loop on the GEMM kernels' 4x4 accumulator shape (bf16), register-resident, with
  * mode 0 = all-ones operands, mode 1 = uniform[-1,1) operands rotating every iteration, mode 2 = mode 1 on
- * the fp8 instruction (v_mfma_f32_32x32x64_f8f6f4, e4m3 operands).  Mode 1 is
+ * the fp8 instruction (v_mfma_f32_32x32x64_f8f6f4, e4m3 operands), modes 3 / 4 = the block-scaled fp4 instruction
+ * (v_mfma_scale_f32_32x32x64_f8f6f4) on all-ones / random nibbles and scales.  Mode 1 is
  * the matrix-pipe ceiling for the benchmark's operand distribution once DVFS has clocked the chip
  * down to its power budget; bench.py reports it beside the spec peak (not a reference probe). */
 int32_t mi355_probe_mfma_data(mi355_ctx *ctx, mi355_stream stream, int32_t mode, uint32_t iters,

@@ -12,6 +12,11 @@ client = Mi355Runtime.client()
 lib, ctx = client.lib, client.ctx
 ev = bench.Events(client)
 out = {}
+sink = client.empty(256)
+n_ops = C.c_uint64()
+for name, mode in (("pipe_mxfp4_ones", 3), ("pipe_mxfp4_random", 4), ("pipe_fp8_uniform", 2)):
+    ms = bench.time_op(client, ev, lambda: client._s.check(lib.mi355_probe_mfma_data(ctx, None, mode, 20000, sink.device_ptr(), C.byref(n_ops))), 5)
+    out[name] = round(n_ops.value / ms / 1e9, 1)
 for dt, dn, epb in ((ElemType.F8E4M3, "mxfp8_e4m3", 1), (ElemType.F4E2M1X2, "mxfp4", 2)):
     for S in (8192, 16384, 4096):
         if S == 16384 and epb == 1:
