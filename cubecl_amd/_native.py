@@ -57,6 +57,9 @@ class MmaConfig(C.Structure):
                 ("a_type", C.c_int32), ("b_type", C.c_int32), ("cd_type", C.c_int32)]
 
 
+ABI_VERSION = 2     # MI355_ABI_VERSION of include/mi355cube.h this table was written against
+
+
 class MemoryUsage(C.Structure):
     """mi355_memory_usage (MemoryUsage of memory_management/base.rs:8-28 + driver-call counters)."""
     _fields_ = [(n, C.c_uint64) for n in ("number_allocs", "bytes_in_use", "bytes_padding", "bytes_reserved",
@@ -64,6 +67,11 @@ class MemoryUsage(C.Structure):
 
 
 ALLOC_MODE_AUTO, ALLOC_MODE_PERSISTENT = 0, 1
+
+
+class ScaledMmaConfig(C.Structure):
+    _fields_ = [("m", C.c_uint32), ("n", C.c_uint32), ("k", C.c_uint32), ("a_type", C.c_int32), ("b_type", C.c_int32),
+                ("cd_type", C.c_int32), ("scales_type", C.c_int32), ("scales_factor", C.c_uint32)]
 
 
 class DeviceProps(C.Structure):
@@ -80,6 +88,7 @@ class DeviceProps(C.Structure):
         ("l2_cache_bytes", C.c_uint32), ("plane_ops", C.c_uint32), ("plane_non_uniform", C.c_uint32),
         ("timing_method_device", C.c_uint32), ("server_comm_enabled", C.c_uint32),
         ("num_mma_configs", C.c_uint32), ("mma_configs", MmaConfig * 16),
+        ("num_scaled_mma_configs", C.c_uint32), ("scaled_mma_configs", ScaledMmaConfig * 8),
     ]
 
 
@@ -222,8 +231,8 @@ def load() -> C.CDLL:
         fn.argtypes = argtypes
     if missing:
         raise NativeLibraryError(f"{path} does not export: {', '.join(missing)}")
-    if lib.mi355_abi_version() != 1:
-        raise NativeLibraryError(f"{path}: ABI version {lib.mi355_abi_version()} != 1")
+    if lib.mi355_abi_version() != ABI_VERSION:
+        raise NativeLibraryError(f"{path}: ABI version {lib.mi355_abi_version()} != {ABI_VERSION}")
     _lib = lib
     return lib
 

@@ -213,6 +213,19 @@ MI355_API int32_t mi355_ctx_create(int32_t device_index, mi355_ctx **out_ctx)
     add_mma(p, 32, 32, 2, MI355_DTYPE_F32, MI355_DTYPE_F32);
     add_mma(p, 16, 16, 4, MI355_DTYPE_F32, MI355_DTYPE_F32);
     add_mma(p, 16, 16, 8, MI355_DTYPE_F32, MI355_DTYPE_F32);
+    // OCP FP8 on v_mfma_f32_32x32x64_f8f6f4 (unscaled) and its block-scaled form (ue8m0 per 32 k: 2 scales per step)
+    add_mma(p, 32, 32, 64, MI355_DTYPE_F8E4M3, MI355_DTYPE_F32);
+    add_mma(p, 32, 32, 64, MI355_DTYPE_F8E5M2, MI355_DTYPE_F32);
+    {
+        const int32_t pairs[5][2] = {{MI355_DTYPE_F8E4M3, MI355_DTYPE_F8E4M3}, {MI355_DTYPE_F8E5M2, MI355_DTYPE_F8E5M2},
+                                     {MI355_DTYPE_F8E4M3, MI355_DTYPE_F8E5M2}, {MI355_DTYPE_F8E5M2, MI355_DTYPE_F8E4M3},
+                                     {MI355_DTYPE_F4E2M1X2, MI355_DTYPE_F4E2M1X2}};
+        for (const auto &pr : pairs) {
+            mi355_scaled_mma_config &c = p.scaled_mma_configs[p.num_scaled_mma_configs++];
+            c.m = 32; c.n = 32; c.k = 64; c.a_type = pr[0]; c.b_type = pr[1]; c.cd_type = MI355_DTYPE_F32;
+            c.scales_type = MI355_DTYPE_UE8M0; c.scales_factor = 2;
+        }
+    }
 
     *out_ctx = ctx;
     return MI355_OK;

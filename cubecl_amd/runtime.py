@@ -303,7 +303,10 @@ class ComputeClient:
     def features(self) -> dict:
         p = self._s.props
         cfgs = [(c.a_type, c.b_type, c.cd_type, c.m, c.n, c.k) for c in p.mma_configs[: p.num_mma_configs]]
-        return {"plane": {"Ops", "NonUniformControlFlow"} if p.plane_ops else set(), "cmma": set(cfgs), "mma": set(cfgs)}
+        scaled = [(c.a_type, c.b_type, c.cd_type, c.scales_type, c.m, c.n, c.k, c.scales_factor)
+                  for c in p.scaled_mma_configs[: p.num_scaled_mma_configs]]
+        return {"plane": {"Ops", "NonUniformControlFlow"} if p.plane_ops else set(), "cmma": set(cfgs), "mma": set(cfgs),
+                "scaled_mma": set(scaled)}          # features.matmul.scaled_mma (ScaledMmaConfig, cmma.rs:1493-1505)
 
     def io_optimized_vector_sizes(self, elem_size: int) -> list:
         width = self._s.props.load_width_bits // 8  # client.rs:1339

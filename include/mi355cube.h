@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define MI355_ABI_VERSION 1
+#define MI355_ABI_VERSION 2
 
 /* ---- status codes (map onto LaunchError / IoError / ServerError, server/base.rs:177-332,
  *      :884-1019; the Rust shim performs the conversion) ------------------------------- */
@@ -108,6 +108,12 @@ typedef struct {
 } mi355_mma_config;                  /* cubecl_ir::features::MmaConfig (features.rs:145) */
 
 typedef struct {
+    uint32_t m, n, k;
+    int32_t a_type, b_type, cd_type, scales_type; /* MI355_DTYPE_*; scales_type = MI355_DTYPE_UE8M0 */
+    uint32_t scales_factor;                       /* scales per k of one instruction (k / 32)       */
+} mi355_scaled_mma_config; /* ScaledMmaConfig (what test_cmma_scaled looks up, runtime_tests/cmma.rs:1493-1505) */
+
+typedef struct {
     uint32_t abi_version;
     int32_t device_index;
     char name[64];                /* hipDeviceProp_t.name                                   */
@@ -138,6 +144,9 @@ typedef struct {
     uint32_t server_comm_enabled;     /* ServerCommunication::SERVER_COMM_ENABLED (RCCL found) */
     uint32_t num_mma_configs;
     mi355_mma_config mma_configs[16]; /* features.matmul.cmma / .mma for gfx950 MFMA        */
+    uint32_t num_scaled_mma_configs;  /* features.matmul.scaled_mma (register_scaled_mma_features,
+                                         crates/cubecl-cpp/src/shared/mma.rs:21-46); since ABI 2   */
+    mi355_scaled_mma_config scaled_mma_configs[8];
 } mi355_device_props_t;
 
 /* =================================== Runtime ============================================= */

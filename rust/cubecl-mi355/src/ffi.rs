@@ -101,6 +101,21 @@ pub struct mi355_device_props_t {
     pub server_comm_enabled: u32,
     pub num_mma_configs: u32,
     pub mma_configs: [mi355_mma_config; 16],
+    pub num_scaled_mma_configs: u32,
+    pub scaled_mma_configs: [mi355_scaled_mma_config; 8],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct mi355_scaled_mma_config {
+    pub m: u32,
+    pub n: u32,
+    pub k: u32,
+    pub a_type: i32,
+    pub b_type: i32,
+    pub cd_type: i32,
+    pub scales_type: i32,
+    pub scales_factor: u32,
 }
 
 #[repr(C)]

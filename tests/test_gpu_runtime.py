@@ -27,6 +27,10 @@ def test_device_properties(client):
     assert (N.DTYPE_BF16, N.DTYPE_BF16, N.DTYPE_F32, 32, 32, 16) in feats["cmma"]
     assert (N.DTYPE_F32, N.DTYPE_F32, N.DTYPE_F32, 32, 32, 2) in feats["cmma"]
     assert "Ops" in feats["plane"]
+    assert (N.DTYPE_F8E4M3, N.DTYPE_F8E4M3, N.DTYPE_F32, 32, 32, 64) in feats["mma"]
+    # what test_cmma_scaled asks before it runs (cmma.rs:1493-1505): a/b/cd/scales types, shape, scales per k
+    assert (N.DTYPE_F8E5M2, N.DTYPE_F8E4M3, N.DTYPE_F32, N.DTYPE_UE8M0, 32, 32, 64, 2) in feats["scaled_mma"]
+    assert (N.DTYPE_F4E2M1X2, N.DTYPE_F4E2M1X2, N.DTYPE_F32, N.DTYPE_UE8M0, 32, 32, 64, 2) in feats["scaled_mma"]
     assert client.io_optimized_vector_sizes(4) == [4, 2, 1]
     assert len(Mi355Runtime.enumerate_devices()) >= 1
 
