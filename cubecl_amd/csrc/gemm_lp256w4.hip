@@ -150,7 +150,7 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void *p)
 }
 
 #ifndef W4_ABL
-#define W4_ABL 0          // dev ablations: 1 no DMA, 2 no fragment reads, 4 no MFMA, 8 no hand-over barrier (results: profiles/r01_power_ablation.md)
+#define W4_ABL 0          // dev ablations: 1 no DMA, 2 no fragment reads, 4 no MFMA, 8 no hand-over barrier, 16 no C stores (results: profiles/r01_power_ablation.md)
 #endif
 
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" W4_STR(n) ")" ::: "memory")
@@ -623,6 +623,7 @@ gemm_lp256w4_kernel(gemm_args g)
                         continue;
                     }
                 }
+                if ((W4_ABL & 16) && g.m > 1) continue;       // dev ablation 16: no C stores (timing only)
 #if W4_NT_C
                 __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(cdst + it * cstep));
 #else
