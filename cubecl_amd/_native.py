@@ -129,6 +129,7 @@ PROTOTYPES = {
     "mi355_alloc": (C.c_int32, [_P, C.c_uint64, _PP]),
     "mi355_free": (C.c_int32, [_P, _P]),
     "mi355_mem_info": (C.c_int32, [_P, _U64P, _U64P]),
+    "mi355_copy_to_ctx": (C.c_int32, [_P, _P, _P, _P, _P, _P, C.c_uint64]),
     "mi355_pool_alloc": (C.c_int32, [_P, _P, C.c_uint64, C.POINTER(C.c_void_p)]),
     "mi355_pool_free": (C.c_int32, [_P, _P, _P]),
     "mi355_pool_cleanup": (C.c_int32, [_P, C.c_int32]),

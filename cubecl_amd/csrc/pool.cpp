@@ -357,7 +357,7 @@ MI355_API int32_t mi355_pool_alloc(mi355_ctx *ctx, mi355_stream stream, uint64_t
 
 MI355_API int32_t mi355_pool_free(mi355_ctx *ctx, mi355_stream stream, void *dptr)
 {
-    if (!ctx) return MI355_E_INVALID_ARGUMENT;
+    MI355_REQUIRE_CTX(ctx);               // (events are created / recorded on this context's device)
     return pool_free(ctx, stream_of(ctx, stream), dptr);
 }
 

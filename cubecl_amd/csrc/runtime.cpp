@@ -499,6 +499,37 @@ MI355_API int32_t mi355_copy_d2d(mi355_ctx *ctx, mi355_stream stream, void *dst_
     return MI355_OK;
 }
 
+// ComputeClient::to_client (client.rs:733-751): one process holding several devices moves a buffer from one client's
+// device to another's.  Here that is a peer copy over xGMI (hipMemcpyPeerAsync) instead of the reference's NCCL
+// send / recv pair between two server threads (cuda server.rs:799-926): same process, so no rendezvous is needed.
+// Ordering: the copy runs on the destination's stream AFTER everything already queued on the source stream (event),
+// and the source stream then waits for the copy, so that whatever it does next to the source buffer -- including the
+// memory pool handing it out again -- is ordered behind the read.
+MI355_API int32_t mi355_copy_to_ctx(mi355_ctx *src_ctx, mi355_stream src_stream, const void *src_dptr, mi355_ctx *dst_ctx,
+                                    mi355_stream dst_stream, void *dst_dptr, uint64_t bytes)
+{
+    if (!src_ctx || !dst_ctx) return MI355_E_INVALID_ARGUMENT;
+    if (bytes == 0) return MI355_OK;
+    if (!src_dptr || !dst_dptr) return fail(dst_ctx, MI355_E_INVALID_ARGUMENT, "mi355_copy_to_ctx: NULL pointer");
+    hipStream_t ss = stream_of(src_ctx, src_stream), ds = stream_of(dst_ctx, dst_stream);
+    if (src_ctx->device != dst_ctx->device) {
+        int can = 0;
+        MI355_HIP(dst_ctx, hipDeviceCanAccessPeer(&can, dst_ctx->device, src_ctx->device));
+        if (!can) return fail(dst_ctx, MI355_E_UNSUPPORTED, "mi355_copy_to_ctx: device %d cannot access device %d", dst_ctx->device, src_ctx->device);
+    }
+    MI355_HIP(src_ctx, hipSetDevice(src_ctx->device));
+    if (!src_ctx->fence_a) MI355_HIP(src_ctx, hipEventCreateWithFlags(&src_ctx->fence_a, hipEventDisableTiming));
+    MI355_HIP(src_ctx, hipEventRecord(src_ctx->fence_a, ss));
+    MI355_HIP(dst_ctx, hipSetDevice(dst_ctx->device));
+    MI355_HIP(dst_ctx, hipStreamWaitEvent(ds, src_ctx->fence_a, 0));
+    MI355_HIP(dst_ctx, hipMemcpyPeerAsync(dst_dptr, dst_ctx->device, src_dptr, src_ctx->device, bytes, ds));
+    if (!dst_ctx->fence_b) MI355_HIP(dst_ctx, hipEventCreateWithFlags(&dst_ctx->fence_b, hipEventDisableTiming));
+    MI355_HIP(dst_ctx, hipEventRecord(dst_ctx->fence_b, ds));
+    MI355_HIP(src_ctx, hipSetDevice(src_ctx->device));
+    MI355_HIP(src_ctx, hipStreamWaitEvent(ss, dst_ctx->fence_b, 0));
+    return MI355_OK;
+}
+
 MI355_API int32_t mi355_memset(mi355_ctx *ctx, mi355_stream stream, void *dptr, int32_t byte_value, uint64_t bytes)
 {
     MI355_REQUIRE_CTX(ctx);

@@ -430,6 +430,29 @@ class ComputeClient:
         self._s.check(self.lib.mi355_module_get_function(self.ctx, module, name.encode(), C.byref(fn)))
         return fn
 
+    def to_client(self, src: Handle, dst_client: "ComputeClient", dtype: ElemType = None) -> Handle:
+        """client.to_client(src, &dst_client, dtype) (client.rs:733-751): the bytes `src` has in use, on the other
+        client's device.  A peer copy over xGMI, stream-ordered on both sides (no host round trip, no sync)."""
+        nbytes = src.size_in_used()
+        out = dst_client.empty(nbytes)
+        self._s.check(self.lib.mi355_copy_to_ctx(self.ctx, self.stream, C.c_void_p(src.device_ptr()), dst_client.ctx,
+                                                 dst_client.stream, C.c_void_p(out.device_ptr()), nbytes))
+        return out
+
+    def send(self, src: Handle, dtype: ElemType, device_ids: Sequence[DeviceId], peer: DeviceId) -> None:
+        """ServerCommunication::send (server/base.rs:694-713) to the rank of `peer` in the sorted id list."""
+        key = tuple(sorted(device_ids))
+        n = src.size_in_used() // ElemType(dtype).size()
+        self._s.check(self.lib.mi355_send(self.ctx, self._s.comms[key], self.stream, C.c_void_p(src.device_ptr()), n,
+                                          int(dtype), key.index(peer)))
+
+    def recv(self, dst: Handle, dtype: ElemType, device_ids: Sequence[DeviceId], peer: DeviceId) -> None:
+        """ServerCommunication::recv (server/base.rs:715-736)."""
+        key = tuple(sorted(device_ids))
+        n = dst.size_in_used() // ElemType(dtype).size()
+        self._s.check(self.lib.mi355_recv(self.ctx, self._s.comms[key], self.stream, C.c_void_p(dst.device_ptr()), n,
+                                          int(dtype), key.index(peer)))
+
     def flush(self) -> None:
         self._s.check(self.lib.mi355_flush(self.ctx))
 

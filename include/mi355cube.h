@@ -256,6 +256,11 @@ int32_t mi355_read_2d(mi355_ctx *ctx, mi355_stream stream, void *dst_host, uint6
                       uint64_t rows);
 int32_t mi355_copy_d2d(mi355_ctx *ctx, mi355_stream stream, void *dst_dptr,
                        const void *src_dptr, uint64_t bytes);
+/* ComputeClient::to_client (client.rs:733-751; runtime_tests/to_client.rs): copies `bytes` from a buffer of `src_ctx`
+ * into a buffer of `dst_ctx` (another device of the same process, or the same one) as a peer copy over xGMI, ordered
+ * after the work queued on the source stream; the source stream waits for the copy in turn. */
+int32_t mi355_copy_to_ctx(mi355_ctx *src_ctx, mi355_stream src_stream, const void *src_dptr,
+                          mi355_ctx *dst_ctx, mi355_stream dst_stream, void *dst_dptr, uint64_t bytes);
 int32_t mi355_memset(mi355_ctx *ctx, mi355_stream stream, void *dptr, int32_t byte_value,
                      uint64_t bytes); /* zeros_array, tensor/handle.rs:199-207 */
 /* ComputeServer::sync: waits for the stream, then reports queued errors. */

@@ -243,6 +243,9 @@ unsafe extern "C" {
     pub fn mi355_pool_cleanup(ctx: *mut mi355_ctx, explicit_cleanup: i32) -> i32;
     pub fn mi355_pool_mode(ctx: *mut mi355_ctx, mode: i32) -> i32;
     pub fn mi355_pool_usage(ctx: *mut mi355_ctx, out: *mut mi355_memory_usage) -> i32;
+    // ComputeClient::to_client (client.rs:733-751)
+    pub fn mi355_copy_to_ctx(src_ctx: *mut mi355_ctx, src_stream: mi355_stream, src_dptr: *const c_void, dst_ctx: *mut mi355_ctx,
+                             dst_stream: mi355_stream, dst_dptr: *mut c_void, bytes: u64) -> i32;
     // ComputeServer::{begin_capture, end_capture, replay} (server/base.rs:453-532)
     pub fn mi355_graph_begin_capture(ctx: *mut mi355_ctx, stream: mi355_stream) -> i32;
     pub fn mi355_graph_end_capture(ctx: *mut mi355_ctx, stream: mi355_stream, out_graph: *mut *mut mi355_graph) -> i32;

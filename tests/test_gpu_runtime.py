@@ -553,3 +553,30 @@ def test_memory_curve_and_roofline_bounds(client):
     b = T.roofline_bounds(client, T.Work(2 * S ** 3, 3 * S * S * 2), T.Thresholds.uniform(0.5), curve=curve)
     assert 1.5e15 < b.compute_ops_per_s < 2.7e15 and 1e-7 < b.launch_overhead_s < 2e-5
     assert 0.7e-3 < b.time_limit() < 1.6e-3                                   # the 8192^3 bf16 GEMM must beat this to count as good
+
+
+def test_to_client_moves_data_between_two_clients(client, oracle):
+    """runtime_tests/to_client.rs: the bytes arrive on the other client's device.  The pod has one GPU, so the second
+    client is a second context on the same device -- the same call path (peer copy, both-way stream ordering)."""
+    from cubecl_amd.runtime import ComputeClient, DeviceId, _Server
+    other_server = _Server(DeviceId(0, 0))
+    other = ComputeClient(other_server)
+    try:
+        expected = np.array([0.0, 1.0, 2.0, 3.0, 4.0, 5.0], dtype=np.float32)          # to_client.rs:28-29
+        out = client.to_client(client.create_from_slice(expected), other, ElemType.F32)
+        assert np.array_equal(other.read_one(out).view(np.float32), expected)
+        # ordered behind work still queued on the source stream, without any host synchronisation in between
+        n = 1 << 26
+        src = TensorHandle.uniform(client, (n,), ElemType.F32, 0x5EEDC0BE, 4242, -1.0, 1.0)     # fill kernel in flight
+        moved = client.to_client(src.handle, other, ElemType.F32)
+        del src                                                    # back to the pool at once: the copy must still see the data
+        got = other.read_one(moved).view(np.float32)
+        assert np.array_equal(got, oracle.fill_uniform(n, 4242, -1.0, 1.0))
+        # a window of a handle moves only its in-use bytes
+        h = client.create_from_slice(np.arange(100, dtype=np.float32))
+        part = client.to_client(h.offset_start_by(40).offset_end_by(200), other)
+        assert np.array_equal(other.read_one(part).view(np.float32), np.arange(10, 50, dtype=np.float32))
+        del out, moved, part
+    finally:
+        other.sync()
+        other_server.close()
