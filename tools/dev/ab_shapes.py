@@ -28,4 +28,14 @@ ba = TensorHandle.uniform(client, (64, M, M), ElemType.BF16, 1, 9, -1.0, 1.0); b
 bc = client.empty(64 * M * M * 2)
 db = bench.gemm_desc(N, M, M, M, N.DTYPE_BF16, N.DTYPE_BF16, batch=64)
 run("bf16_2048x64", lambda: client._s.check(lib.mi355_gemm(ctx, None, C.byref(db), ba.device_ptr(), bb.device_ptr(), bc.device_ptr())), 2.0 * M ** 3 * 64)
+M = 1024
+ba = TensorHandle.uniform(client, (256, M, M), ElemType.BF16, 1, 9, -1.0, 1.0); bb = TensorHandle.uniform(client, (256, M, M), ElemType.BF16, 1, 10, -1.0, 1.0)
+bc = client.empty(256 * M * M * 2)
+dc = bench.gemm_desc(N, M, M, M, N.DTYPE_BF16, N.DTYPE_BF16, batch=256)
+run("bf16_1024x256", lambda: client._s.check(lib.mi355_gemm(ctx, None, C.byref(dc), ba.device_ptr(), bb.device_ptr(), bc.device_ptr())), 2.0 * M ** 3 * 256)
+S = 16384
+a = TensorHandle.uniform(client, (S, S), ElemType.BF16, 1, 1, -1.0, 1.0); b = TensorHandle.uniform(client, (S, S), ElemType.BF16, 1, 2, -1.0, 1.0)
+c = client.empty(S * S * 2)
+d16 = bench.gemm_desc(N, S, S, S, N.DTYPE_BF16, N.DTYPE_BF16)
+run("bf16_16384", lambda: client._s.check(lib.mi355_gemm(ctx, None, C.byref(d16), a.device_ptr(), b.device_ptr(), c.device_ptr())), 2.0 * S ** 3)
 print(json.dumps(out))
