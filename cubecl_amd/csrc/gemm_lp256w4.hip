@@ -178,13 +178,9 @@ __device__ unsigned long long w4_trace_buf[4096 * 8];
 // MFMAs of 64 cycles.
 // MX (block-scaled, one ue8m0 scale per 32 k-values; DTB = B's element type, fp8 formats may be mixed): the scales come
 // pre-arranged by gemm_scaled.cpp as ST[K-tile][row padded to the tile grid][NB bytes] (NB = 4 fp8 / 8 fp4 blocks per
-// K-tile row), so a lane's share -- the NB/2 blocks of its lane-half, contiguous -- is one coalesced 2- or 4-byte load
-// per 32-row block and K-tile, issued one K-tile ahead into a second register set.  These loads are inline asm like the
+// K-tile row), so a lane's share is one coalesced 4-byte load per 32-row block and K-tile (fp4: the four blocks of its
+// lane-half; fp8: the row's four blocks, its own two shifted into place), issued one K-tile ahead into a second register set.  These loads are inline asm like the
 // DMA (the compiler must not insert its own waits into the counted vmcnt stream).
-__device__ __forceinline__ void scale_ld16(uint32_t &dst, const void *ubase, uint32_t voff, int imm)
-{
-    asm volatile("global_load_ushort %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(ubase), "n"(imm) : "memory");
-}
 __device__ __forceinline__ void scale_ld32(uint32_t &dst, const void *ubase, uint32_t voff, int imm)
 {
     asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(ubase), "n"(imm) : "memory");
