@@ -46,9 +46,11 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
     const bool big4 = gemm_lp256w4_supports(d, a, b, c);
     const bool mid = gemm_lp128_supports(d, a, b, c);
     if (big) {
-        // 256x256 tiles only when they still give every CU work
+        // 256x256 tiles once the 128x128 kernel would need more than its two co-resident workgroups per CU (512 tiles of
+        // 128^2 = 128 of 256^2).  Measured (tools/dev/mid_shapes.py): 96-128 tiles a tie, 144-160 tiles +45...55 % for the
+        // 256x256 kernel even though it leaves 40 % of the CUs idle, 64-81 tiles +7...30 % for the 128x128 kernel.
         const int64_t tiles256 = ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch;
-        if (tiles256 >= 192 || !mid) return big4 ? MI355_GEMM_ALGO_LP_256W4 : MI355_GEMM_ALGO_LP_256;
+        if (tiles256 > 128 || !mid) return big4 ? MI355_GEMM_ALGO_LP_256W4 : MI355_GEMM_ALGO_LP_256;
     }
     if (mid) return MI355_GEMM_ALGO_LP_128;
     return MI355_GEMM_ALGO_GENERIC;
