@@ -167,3 +167,31 @@ def test_c4_one_gib_argmax_planted_maxima(client, oracle):
     poke(123, np.float32("nan"))
     ops.argmax(client, x, idx, val)
     assert int(idx.to_numpy(client)[0]) == 123
+
+
+def test_reductions_beyond_2_pow_32_elements(client):
+    """Maximum sizes: indices that do not fit 32 bits (the output index is u64) and a ragged tail."""
+    n = (1 << 32) + 4099                                   # 16 GiB + 16 396 B of f32
+    h = client.empty(4 * n)
+    client._s.check(client.lib.mi355_memset(client.ctx, None, h.device_ptr(), 0, 4 * n))
+    x = TensorHandle.new_contiguous((n,), h, ElemType.F32)
+    idx = TensorHandle.new_contiguous((1,), client.empty(8), ElemType.U64)
+    val = TensorHandle.new_contiguous((1,), client.empty(8), ElemType.F32)
+    s = TensorHandle.new_contiguous((1,), client.empty(8), ElemType.F32)
+
+    def poke(i, v):
+        client.write(h.offset_start_by(4 * i).offset_end_by(4 * (n - i - 1)), np.array([v], dtype=np.float32))
+    planted = {5: 0.5, (1 << 31) + 3: 2.0, (1 << 32) + 17: 4.0, n - 1: 4.0, (1 << 32) - 1: -8.0}
+    for i, v in planted.items():
+        poke(i, v)
+    ops.argmax(client, x, idx, val)
+    assert int(idx.to_numpy(client)[0]) == (1 << 32) + 17 and float(val.to_numpy(client)[0]) == 4.0      # first of the two 4.0
+    ops.reduce_sum(client, x, s)
+    assert float(s.to_numpy(client)[0]) == sum(planted.values())                                         # exact: everything else is 0
+    ops.sum_argmax(client, x, s, idx, val)
+    assert int(idx.to_numpy(client)[0]) == (1 << 32) + 17 and float(s.to_numpy(client)[0]) == sum(planted.values())
+    poke((1 << 32) + 17, 0.0)
+    ops.argmax(client, x, idx, val)
+    assert int(idx.to_numpy(client)[0]) == n - 1                                                         # the very last element
+    del x, h
+    client.memory_cleanup()
