@@ -195,3 +195,30 @@ def test_reductions_beyond_2_pow_32_elements(client):
     assert int(idx.to_numpy(client)[0]) == n - 1                                                         # the very last element
     del x, h
     client.memory_cleanup()
+
+
+def test_gemm_operand_larger_than_4_gib(client, oracle):
+    """Row offsets beyond 2^32 bytes: A is 270 000 x 8192 bf16 (4.4 GB), all zero except four planted rows."""
+    m, n, k = 270_000, 512, 8192
+    ha = client.empty(2 * m * k)
+    client._s.check(client.lib.mi355_memset(client.ctx, None, ha.device_ptr(), 0, 2 * m * k))
+    rows = [0, 131_071, 262_144 + 77, m - 1]                                   # the last two start beyond the 4 GiB mark
+    assert rows[2] * k * 2 > 1 << 32
+    a_rows = oracle.to_bf16(oracle.fill_uniform(len(rows) * k, 710, -1.0, 1.0)).reshape(len(rows), k)
+    for r, bits in zip(rows, a_rows):
+        client.write(ha.offset_start_by(2 * r * k).offset_end_by(2 * (m - r - 1) * k), bits)
+    b = TensorHandle.uniform(client, (n, k), ElemType.BF16, SEED, 711, -1.0, 1.0)
+    b_bits = oracle.to_bf16(oracle.fill_uniform(n * k, 711, -1.0, 1.0))
+    a = TensorHandle.new_contiguous((m, k), ha, ElemType.BF16)
+    c = TensorHandle.new_contiguous((m, n), client.empty(4 * m * n), ElemType.F32)
+    d = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=k, ldc=n, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_F32, trans_b=1)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    ops.matmul(client, a, TensorHandle.new(b.handle, (k, n), (1, k), ElemType.BF16), c)
+    for r, bits in zip(rows, a_rows):
+        got = client.read_one(c.handle.offset_start_by(4 * r * n).offset_end_by(4 * (m - r - 1) * n)).view(np.float32)
+        _rows_check(oracle, bits, b_bits, got[None, :], np.array([0]), k, n, ElemType.BF16)
+    for r in (1, 131_072, 262_144, m - 2):                                     # neighbours of the planted rows stay exactly zero
+        got = client.read_one(c.handle.offset_start_by(4 * r * n).offset_end_by(4 * (m - r - 1) * n)).view(np.float32)
+        assert not got.any()
+    del a, c, ha
+    client.memory_cleanup()
