@@ -127,6 +127,92 @@ int32_t relayout_for_mfma(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
     return MI355_OK;
 }
 
+// ---- the last, partly filled round of 256x256 tiles ----------------------------------------------------------------------
+// All tiles of a GEMM take the same time, so T tiles on 256 CUs cost ceil(T / 256) rounds: 576 tiles (6144^3) pay for
+// 768.  When the leftover is at most half a round, the output is cut into a part whose tile count (nearly) fills whole
+// rounds and a strip of at most 96 tiles whose K range is split `s` ways over the CUs that would otherwise idle: the
+// strip runs as ONE batched launch of the same kernel (batch entry z = K slice z: operand "batch strides" of one slice
+// along the rows, f32 partial slabs as the batched output) followed by the split-K fold (gemm_splitk.hip), which adds
+// the slabs in slice order (deterministic) and converts.  Chosen by a cost model in K-tile units; only for batch == 1.
+struct tail_plan {
+    bool along_m;          // the strip is the last rows (true) or the last columns (false) of C
+    int64_t main_extent;   // rows (columns) handled by the plain launch
+    int64_t splits;
+};
+
+bool plan_tail_split(const mi355_gemm_desc &d, tail_plan &best)
+{
+    if (d.batch != 1 || d.trans_a || !d.trans_b || (d.n & 3)) return false;
+    const int64_t esz = (int64_t)dtype_size(d.dtype_ab), ktile = 128 / esz, nk = d.k / ktile;
+    const int64_t tm = (d.m + 255) / 256, tn = (d.n + 255) / 256, T = tm * tn;
+    if (nk < 8) return false;
+    // cycles: a K-tile costs ~2 200, a tile's prologue + epilogue ~10 000, a launch ~5 000, the fold moves
+    // (s + 1) x 256 KiB per strip tile at ~2 500 B per cycle of the whole chip
+    const double CK = 2200.0, CFIX = 10000.0, CLAUNCH = 5000.0;
+    // A partly filled round is cheaper than a full one: the idle CUs' power budget lets the busy ones clock higher
+    // (64 leftover tiles cost ~0.66 of a round, 128 ~0.83: 6144^3 and 4096 x 6144 x 4096).  Calibrated interleaved against
+    // the plain launch (tools/dev/tail_ab.py): with F0 = 0.7 and strips of at most 96 tiles the split is taken at
+    // 1.02-1.13, 2.25, 3.06 and 4.12 rounds (+28, +18, +15, +11, +7, +7, +7 %) and left alone at 1.5-1.56, 2.44, 4.5 rounds.
+    constexpr double F0 = 0.7;
+    auto rounds = [](int64_t t) {
+        const int64_t left = t % 256;
+        return (double)(t / 256) + (left ? F0 + (1.0 - F0) * (double)left / 256.0 : 0.0);
+    };
+    const double now = rounds(T) * ((double)nk * CK + CFIX);
+    double best_cost = now * 0.93;                          // must win by 7 % to be worth two extra launches
+    bool found = false;
+    for (int dir = 0; dir < 2; ++dir) {
+        const int64_t t_along = dir == 0 ? tm : tn, t_other = dir == 0 ? tn : tm;
+        for (int64_t strip = 1; strip <= t_along && strip * t_other <= 96; ++strip) {
+            const int64_t t_strip = strip * t_other, t_main = T - t_strip;
+            for (int64_t sp = 2; sp <= 16 && sp * t_strip <= 256 && nk / sp >= 4; ++sp) {
+                if (nk % sp) continue;
+                const double fold = (double)t_strip * (double)(sp + 1) * 262144.0 / 2500.0;
+                const double cost = rounds(t_main) * ((double)nk * CK + CFIX) + rounds(sp * t_strip) * ((double)(nk / sp) * CK + CFIX) + fold +
+                                    (t_main > 0 ? 2.0 : 1.0) * CLAUNCH;
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best.along_m = dir == 0;
+                    best.main_extent = (t_along - strip) * 256;
+                    best.splits = sp;
+                    found = true;
+                }
+            }
+        }
+    }
+    return found;
+}
+
+int32_t run_tail_split(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c,
+                       const tail_plan &p)
+{
+    const int64_t esz = (int64_t)dtype_size(d.dtype_ab), csz = (int64_t)dtype_size(d.dtype_c);
+    const int64_t ms = p.along_m ? d.m - p.main_extent : d.m, ns = p.along_m ? d.n : d.n - p.main_extent;   // the strip
+    float *slabs = nullptr;
+    if (splitk_scratch(ctx, s, (size_t)(p.splits * ms * ns) * sizeof(float), &slabs) != MI355_OK) return MI355_E_UNSUPPORTED;
+    const char *a0 = static_cast<const char *>(a), *b0 = static_cast<const char *>(b);
+    char *c0 = static_cast<char *>(c);
+    const char *as = p.along_m ? a0 + p.main_extent * d.lda * esz : a0;
+    const char *bs = p.along_m ? b0 : b0 + p.main_extent * d.ldb * esz;
+    char *cs = p.along_m ? c0 + p.main_extent * d.ldc * csz : c0 + p.main_extent * csz;
+    mi355_gemm_desc sd = d;                                 // the strip: batch entry z = K slice z, f32 slab output
+    sd.m = ms; sd.n = ns; sd.k = d.k / p.splits; sd.batch = p.splits;
+    sd.stride_a = sd.k; sd.stride_b = sd.k; sd.stride_c = ms * ns; sd.ldc = ns; sd.dtype_c = MI355_DTYPE_F32;
+    if (!gemm_lp256w4_supports(sd, as, bs, slabs)) return MI355_E_UNSUPPORTED;
+    if (p.main_extent > 0) {
+        mi355_gemm_desc md = d;
+        if (p.along_m) md.m = p.main_extent; else md.n = p.main_extent;
+        if (!gemm_lp256w4_supports(md, a, b, c)) return MI355_E_UNSUPPORTED;
+        const int32_t rc = launch_gemm_lp256w4(ctx, s, md, a, b, c);
+        if (rc != MI355_OK) return rc;
+    }
+    const int32_t rc = launch_gemm_lp256w4(ctx, s, sd, as, bs, slabs);
+    if (rc != MI355_OK) return rc;
+    launch_splitk_fold(s, slabs, (uint32_t)p.splits, ms * ns, 1, ms, ns, cs, d.dtype_c, d.ldc, 0);
+    check_launch(ctx, "mi355_gemm(tail split-K fold)");
+    return MI355_OK;
+}
+
 }  // namespace
 
 MI355_API int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_gemm_desc *desc, const void *a,
@@ -145,6 +231,10 @@ MI355_API int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_ge
             d = nd; a = na; b = nb;
             algo = select(d, a, b, c);
         }
+    }
+    if (d.algo == MI355_GEMM_ALGO_AUTO && algo == MI355_GEMM_ALGO_LP_256W4) {
+        tail_plan tp;
+        if (plan_tail_split(d, tp) && run_tail_split(ctx, s, d, a, b, c, tp) == MI355_OK) return MI355_OK;
     }
     switch (algo) {
     case MI355_GEMM_ALGO_GENERIC: return launch_gemm_generic(ctx, s, d, a, b, c);

@@ -615,3 +615,24 @@ def test_fp8_rejects_what_it_does_not_do(client):
     with pytest.raises(ServerError):        # fp8 output is not produced by the GEMM
         client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(N.GemmDesc(dtype_ab=N.DTYPE_F8E4M3, dtype_c=N.DTYPE_F8E4M3, **d)),
                                               a.device_ptr(), a.device_ptr(), a.device_ptr()))
+
+
+# ---- partly filled last round: main part + split-K strip (gemm.cpp plan_tail_split) ------------------------------------------
+@pytest.mark.parametrize("m,n,k,dtype,out", [
+    (6144, 6144, 1024, ElemType.BF16, ElemType.BF16),      # 576 tiles = 2.25 rounds: strip of rows, K split
+    (5000, 3328, 2048, ElemType.BF16, ElemType.F32),       # 20 x 13 = 260 tiles, ragged M: strip of columns
+    (3328, 5000, 2048, ElemType.F16, ElemType.F16),        # the transposed case, ragged N (n % 4 == 0)
+    (4608, 4608, 2048, ElemType.F8E4M3, ElemType.BF16),    # fp8: 18 x 18 = 324 tiles
+    (4352, 4096, 512, ElemType.F32, ElemType.F32),         # f32: 17 x 16 = 272 tiles
+])
+def test_partly_filled_last_round_is_split_and_still_exact_enough(client, oracle, m, n, k, dtype, out):
+    run_case(client, oracle, m, n, k, dtype, out, True, N.GEMM_ALGO_AUTO)
+    # the same bits from launch to launch (the fold adds the slabs in slice order)
+    a = TensorHandle.uniform(client, (m, k), dtype, 1, 95, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (n, k), dtype, 1, 96, -1.0, 1.0)
+    bt = TensorHandle.new(b.handle, (k, n), (1, k), dtype)
+    c1 = TensorHandle.new_contiguous((m, n), client.empty(m * n * out.size()), out)
+    c2 = TensorHandle.new_contiguous((m, n), client.empty(m * n * out.size()), out)
+    ops.matmul(client, a, bt, c1)
+    ops.matmul(client, a, bt, c2)
+    assert np.array_equal(c1.to_numpy(client), c2.to_numpy(client))
