@@ -103,6 +103,9 @@ int32_t scratch_get(mi355_ctx *ctx, hipStream_t s, int kind, size_t bytes, void 
 {
     auto &slot = ctx->scratch[{s, kind}];
     if (slot.second < bytes) {
+        // growing means hipMalloc (+ a stream sync and hipFree): none of that is legal inside a capture window; the caller
+        // falls back to a path without scratch, or the launch fails -- warm the sequence up once before capturing
+        if (ctx->capturing) return MI355_E_UNSUPPORTED;
         if (slot.first) {
             if (hipStreamSynchronize(s) != hipSuccess) return MI355_E_EXECUTION;
             hipFree(slot.first);

@@ -251,6 +251,8 @@ reduce_kernel(const float *__restrict__ head, uint32_t head_n, const float *__re
 int32_t ticket_for_stream(mi355_ctx *ctx, hipStream_t s, unsigned int **out)
 {
     constexpr uint32_t SLOTS = 1024;
+    if (ctx->capturing && (!ctx->ticket_buf || ctx->tickets_dirty))      // hipMalloc / hipMemset are not capturable
+        return fail(ctx, MI355_E_UNSUPPORTED, "reduction inside a graph capture before its scratch exists: run it once before capturing");
     if (!ctx->ticket_buf) {
         MI355_HIP(ctx, hipMalloc(&ctx->ticket_buf, SLOTS * 64));
         MI355_HIP(ctx, hipMemset(ctx->ticket_buf, 0, SLOTS * 64));
