@@ -407,6 +407,19 @@ def main():
             return out
         guarded("book_reduce_last_axis_f32", book_reduce)
 
+        def sum_things_c1():
+            # config C1: the reference's own CPU-runnable case (examples/sum_things: array-wide sum of 2^20 f32) -- launch-bound on a GPU
+            n = 1 << 20
+            x = TensorHandle.uniform(client, (n,), ElemType.F32, SEED, 810, 0.0, 1.0)
+            ws = client.empty(1 << 17)
+            o = client.empty(64)
+            call = lambda: client._s.check(lib.mi355_reduce_sum_f32(ctx, None, x.device_ptr(), n, o.device_ptr(), ws.device_ptr(), ws.size))
+            med, best = samples_op(client, ev, call)
+            b2b = time_op(client, ev, call, 200)
+            return {"elements": n, "median_us": round(med * 1e3, 2), "min_us": round(best * 1e3, 2), "back_to_back_us": round(b2b * 1e3, 2),
+                    "GBs_back_to_back": round(n * 4 / b2b / 1e6, 1)}
+        guarded("sum_things_1M_f32", sum_things_c1)
+
         def gemm_f32_c2():
             M = 4096
             fa = TensorHandle.uniform(client, (M, M), ElemType.F32, SEED, 400, -1.0, 1.0)
