@@ -27,6 +27,7 @@
 using namespace mi355;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4r __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -34,6 +35,45 @@ constexpr int RED_BLOCK = 256;                              // 4 waves
 constexpr int RED_UNROLL = 8;                               // 16-B loads in flight per lane
 constexpr int RED_TILE = RED_BLOCK * RED_UNROLL * 4;        // 8192 floats = 32 KiB per tile
 constexpr int RED_MAX_GRID = 4096;
+
+// Input element types of the array-wide reductions: f32, or bf16 / f16 widened to f32 on load (exact), always 16 bytes
+// per lane and load, sums and compares in f32.  EPV = elements per 16-byte vector.
+template <int DT> struct red_in;
+template <> struct red_in<MI355_DTYPE_F32> {
+    typedef float elem;
+    static constexpr int EPV = 4;
+    static __device__ __forceinline__ float widen(float v) { return v; }
+    static __device__ __forceinline__ void unpack(const u32x4r &raw, float (&v)[4])
+    {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = __uint_as_float(raw[c]);
+    }
+};
+template <> struct red_in<MI355_DTYPE_BF16> {
+    typedef uint16_t elem;
+    static constexpr int EPV = 8;
+    static __device__ __forceinline__ float widen(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+    static __device__ __forceinline__ void unpack(const u32x4r &raw, float (&v)[8])
+    {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { v[2 * c] = __uint_as_float(raw[c] << 16); v[2 * c + 1] = __uint_as_float(raw[c] & 0xFFFF0000u); }
+    }
+};
+template <> struct red_in<MI355_DTYPE_F16> {
+    typedef uint16_t elem;
+    static constexpr int EPV = 8;
+    static __device__ __forceinline__ float widen(uint16_t v)
+    {
+        _Float16 h;
+        __builtin_memcpy(&h, &v, 2);
+        return (float)h;
+    }
+    static __device__ __forceinline__ void unpack(const u32x4r &raw, float (&v)[8])
+    {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { v[2 * c] = widen((uint16_t)(raw[c] & 0xFFFFu)); v[2 * c + 1] = widen((uint16_t)(raw[c] >> 16)); }
+    }
+};
 
 struct __attribute__((aligned(16))) red_record {
     float sum;
@@ -112,13 +152,16 @@ __device__ __forceinline__ bool arrive_is_last(unsigned int *ticket, uint32_t G)
 //   in      : 16-byte aligned body of the array (host peels a misaligned head into `head`)
 //   head    : up to 3 leading elements (global indices 0..head_n-1), body index i maps to
 //             global index i + head_n
-template <bool SUM, bool ARG>
+template <bool SUM, bool ARG, int DT = MI355_DTYPE_F32>
 __global__ void __launch_bounds__(RED_BLOCK)
-reduce_kernel(const float *__restrict__ head, uint32_t head_n, const float *__restrict__ in, uint64_t n,
+reduce_kernel(const typename red_in<DT>::elem *__restrict__ head, uint32_t head_n, const typename red_in<DT>::elem *__restrict__ in, uint64_t n,
               red_record *__restrict__ records, unsigned int *__restrict__ ticket, uint64_t n_total, float *__restrict__ out_sum, float *__restrict__ out_val, uint64_t *__restrict__ out_idx)
 {
+    typedef red_in<DT> RI;
+    constexpr int EPV = RI::EPV;
+    constexpr uint64_t TILE = (uint64_t)RED_BLOCK * RED_UNROLL * EPV;       // elements per 32 KiB tile
     const uint32_t tid = threadIdx.x;
-    const uint64_t full_tiles = n / RED_TILE;
+    const uint64_t full_tiles = n / TILE;
     const uint32_t G = gridDim.x;
 
     f32x4 acc[RED_UNROLL];
@@ -131,35 +174,44 @@ reduce_kernel(const float *__restrict__ head, uint32_t head_n, const float *__re
 
     // peeled head: lowest global indices, block 0 only
     if (blockIdx.x == 0 && tid < head_n) {
-        const float v = head[tid];
+        const float v = RI::widen(head[tid]);
         if (SUM) tail_acc += v;
         if (ARG) { best_key = argmax_key(v); best_idx = tid; best_val = (best_key == 0xFFFFFFFFu) ? __builtin_inff() : v; }
     }
 
-    const f32x4 *__restrict__ vin = reinterpret_cast<const f32x4 *>(in);
+    const u32x4r *__restrict__ vin = reinterpret_cast<const u32x4r *>(in);
     for (uint64_t tile = blockIdx.x; tile < full_tiles; tile += G) {
-        const uint64_t vbase = tile * (RED_TILE / 4) + tid;
-        f32x4 v[RED_UNROLL];
+        const uint64_t vbase = tile * (uint64_t)(RED_BLOCK * RED_UNROLL) + tid;
+        u32x4r raw[RED_UNROLL];
 #pragma unroll
-        for (int u = 0; u < RED_UNROLL; ++u) v[u] = __builtin_nontemporal_load(vin + vbase + (uint64_t)u * RED_BLOCK);
+        for (int u = 0; u < RED_UNROLL; ++u) raw[u] = __builtin_nontemporal_load(vin + vbase + (uint64_t)u * RED_BLOCK);
 #pragma unroll
         for (int u = 0; u < RED_UNROLL; ++u) {
-            if (SUM) acc[u] += v[u];
+            float w[EPV];
+            RI::unpack(raw[u], w);
+            if (SUM) {
+                acc[u] += (f32x4){w[0], w[1], w[2], w[3]};
+                if constexpr (EPV == 8) acc[u] += (f32x4){w[4], w[5], w[6], w[7]};
+            }
             if (ARG) {
                 // Fast reject: a 16-byte vector can only matter if it holds a NaN or a value above this
                 // lane's running maximum (new maxima get rare quickly: ~ln(n) per lane), so the exact
                 // key/index update below runs on a few percent of the vectors.  v_max ignores NaNs,
                 // hence the separate unordered test; -0 vs +0 never compares greater, which is the
                 // tie rule (equal keys keep the lower index).
-                const float m4 = fmaxf(fmaxf(v[u][0], v[u][1]), fmaxf(v[u][2], v[u][3]));
-                const bool has_nan = __builtin_isunordered(v[u][0], v[u][1]) | __builtin_isunordered(v[u][2], v[u][3]);
+                float m4 = fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3]));
+                bool has_nan = __builtin_isunordered(w[0], w[1]) | __builtin_isunordered(w[2], w[3]);
+                if constexpr (EPV == 8) {
+                    m4 = fmaxf(m4, fmaxf(fmaxf(w[4], w[5]), fmaxf(w[6], w[7])));
+                    has_nan |= __builtin_isunordered(w[4], w[5]) | __builtin_isunordered(w[6], w[7]);
+                }
                 if ((m4 > best_val) | has_nan | (best_key == 0u)) {
-                    const uint64_t e0 = (vbase + (uint64_t)u * RED_BLOCK) * 4 + head_n;
+                    const uint64_t e0 = (vbase + (uint64_t)u * RED_BLOCK) * EPV + head_n;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const uint32_t k = argmax_key(v[u][c]);
+                    for (int c = 0; c < EPV; ++c) {
+                        const uint32_t k = argmax_key(w[c]);
                         // strict > : within one lane indices only grow, so the first maximum is kept
-                        if (k > best_key) { best_key = k; best_idx = e0 + c; best_val = (k == 0xFFFFFFFFu) ? __builtin_inff() : v[u][c]; }
+                        if (k > best_key) { best_key = k; best_idx = e0 + c; best_val = (k == 0xFFFFFFFFu) ? __builtin_inff() : w[c]; }
                     }
                 }
             }
@@ -167,10 +219,10 @@ reduce_kernel(const float *__restrict__ head, uint32_t head_n, const float *__re
     }
 
     // ragged tail (< one tile): the workgroup next in rotation, guarded scalar loads
-    const uint64_t tail_base = full_tiles * RED_TILE;
+    const uint64_t tail_base = full_tiles * TILE;
     if (tail_base < n && blockIdx.x == (uint32_t)(full_tiles % G)) {
         for (uint64_t i = tail_base + tid; i < n; i += RED_BLOCK) {
-            const float v = in[i];
+            const float v = RI::widen(in[i]);
             if (SUM) tail_acc += v;
             if (ARG) {
                 const uint32_t k = argmax_key(v);
@@ -239,7 +291,7 @@ reduce_kernel(const float *__restrict__ head, uint32_t head_n, const float *__re
             } else {
                 if (out_idx) *out_idx = ix;
                 // bit-exact copy of the winning element
-                if (out_val) *out_val = (ix < head_n) ? head[ix] : in[ix - head_n];
+                if (out_val) *out_val = RI::widen((ix < head_n) ? head[ix] : in[ix - head_n]);
             }
         }
     }
@@ -271,22 +323,24 @@ int32_t ticket_for_stream(mi355_ctx *ctx, hipStream_t s, unsigned int **out)
     return MI355_OK;
 }
 
-uint32_t pick_grid(const mi355_ctx *ctx, uint64_t n)
+uint32_t pick_grid(const mi355_ctx *ctx, uint64_t n, uint64_t tile_elems = RED_TILE)
 {
-    const uint64_t tiles = (n + RED_TILE - 1) / RED_TILE;
+    const uint64_t tiles = (n + tile_elems - 1) / tile_elems;
     static const int per_cu = [] { const char *e = getenv("MI355_REDUCE_WG_PER_CU"); int v = e ? atoi(e) : 3; return v > 0 ? v : 3; }();
     const uint64_t cap = std::min<uint64_t>((uint64_t)ctx->props.num_streaming_multiprocessors * per_cu, RED_MAX_GRID);
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(tiles, cap));
 }
 
-template <bool SUM, bool ARG>
-int32_t run_reduce(mi355_ctx *ctx, mi355_stream stream, const float *in, uint64_t n, float *out_sum,
-                   float *out_val, uint64_t *out_idx, void *workspace, uint64_t workspace_bytes, const char *what)
+template <bool SUM, bool ARG, int DT>
+int32_t run_reduce_t(mi355_ctx *ctx, mi355_stream stream, const void *in_v, uint64_t n, float *out_sum,
+                     float *out_val, uint64_t *out_idx, void *workspace, uint64_t workspace_bytes, const char *what)
 {
-    MI355_REQUIRE_CTX(ctx);
+    typedef typename red_in<DT>::elem elem;
+    constexpr uint32_t ESZ = sizeof(elem);
+    const elem *in = static_cast<const elem *>(in_v);
     if (n && !in) return fail(ctx, MI355_E_INVALID_ARGUMENT, "%s: input is NULL", what);
-    if ((reinterpret_cast<uintptr_t>(in) & 3u) != 0)
-        return fail(ctx, MI355_E_INVALID_ARGUMENT, "%s: input must be 4-byte aligned", what);
+    if ((reinterpret_cast<uintptr_t>(in) & (ESZ - 1)) != 0)
+        return fail(ctx, MI355_E_INVALID_ARGUMENT, "%s: input must be aligned to its element size", what);
     uint64_t need = 0;
     mi355_reduce_workspace_bytes(ctx, n, &need);
     if (!workspace || workspace_bytes < need)
@@ -296,20 +350,33 @@ int32_t run_reduce(mi355_ctx *ctx, mi355_stream stream, const float *in, uint64_
         return fail(ctx, MI355_E_INVALID_ARGUMENT, "%s: workspace must be 16-byte aligned", what);
     hipStream_t s = stream_of(ctx, stream);
     // peel a misaligned head so the body is 16-byte aligned
-    uint32_t head_n = (uint32_t)(((16u - (reinterpret_cast<uintptr_t>(in) & 15u)) & 15u) / 4u);
+    uint32_t head_n = (uint32_t)(((16u - (reinterpret_cast<uintptr_t>(in) & 15u)) & 15u) / ESZ);
     if (head_n > n) head_n = (uint32_t)n;
-    const float *body = in + head_n;
+    const elem *body = in + head_n;
     const uint64_t body_n = n - head_n;
-    const uint32_t G = pick_grid(ctx, body_n);
+    const uint32_t G = pick_grid(ctx, body_n, (uint64_t)RED_BLOCK * RED_UNROLL * red_in<DT>::EPV);
     red_record *records = static_cast<red_record *>(workspace);
     unsigned int *ticket = nullptr;
     const int32_t trc = ticket_for_stream(ctx, s, &ticket);
     if (trc != MI355_OK) return trc;
-    hipLaunchKernelGGL((reduce_kernel<SUM, ARG>), dim3(G), dim3(RED_BLOCK), 0, s, in, head_n, body, body_n, records,
+    hipLaunchKernelGGL((reduce_kernel<SUM, ARG, DT>), dim3(G), dim3(RED_BLOCK), 0, s, in, head_n, body, body_n, records,
                        ticket, n, out_sum, out_val, out_idx);
     if (hipPeekAtLastError() != hipSuccess) ctx->tickets_dirty = true;   // a refused launch never resets its ticket
     check_launch(ctx, what);
     return MI355_OK;
+}
+
+template <bool SUM, bool ARG>
+int32_t run_reduce(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, uint64_t n, float *out_sum,
+                   float *out_val, uint64_t *out_idx, void *workspace, uint64_t workspace_bytes, const char *what)
+{
+    MI355_REQUIRE_CTX(ctx);
+    switch (dtype) {
+    case MI355_DTYPE_F32: return run_reduce_t<SUM, ARG, MI355_DTYPE_F32>(ctx, stream, in, n, out_sum, out_val, out_idx, workspace, workspace_bytes, what);
+    case MI355_DTYPE_BF16: return run_reduce_t<SUM, ARG, MI355_DTYPE_BF16>(ctx, stream, in, n, out_sum, out_val, out_idx, workspace, workspace_bytes, what);
+    case MI355_DTYPE_F16: return run_reduce_t<SUM, ARG, MI355_DTYPE_F16>(ctx, stream, in, n, out_sum, out_val, out_idx, workspace, workspace_bytes, what);
+    default: return fail(ctx, MI355_E_UNSUPPORTED, "%s: input dtype %d (f32, bf16 or f16)", what, dtype);
+    }
 }
 
 // ---- last-axis reductions --------------------------------------------------------------------
@@ -532,15 +599,37 @@ MI355_API int32_t mi355_reduce_sum_f32(mi355_ctx *ctx, mi355_stream stream, cons
                                        void *workspace, uint64_t workspace_bytes)
 {
     if (ctx && !out) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_reduce_sum_f32: out is NULL");
-    return run_reduce<true, false>(ctx, stream, in, n, out, nullptr, nullptr, workspace, workspace_bytes,
+    return run_reduce<true, false>(ctx, stream, in, MI355_DTYPE_F32, n, out, nullptr, nullptr, workspace, workspace_bytes,
                                    "mi355_reduce_sum_f32");
+}
+
+// ---- the same reductions for f32 / bf16 / f16 inputs (widened to f32 on load: sums and compares in f32) ----------------
+MI355_API int32_t mi355_reduce_sum(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, uint64_t n, float *out,
+                                   void *workspace, uint64_t workspace_bytes)
+{
+    if (ctx && !out) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_reduce_sum: out is NULL");
+    return run_reduce<true, false>(ctx, stream, in, dtype, n, out, nullptr, nullptr, workspace, workspace_bytes, "mi355_reduce_sum");
+}
+
+MI355_API int32_t mi355_argmax(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, uint64_t n, float *out_val,
+                               uint64_t *out_idx, void *workspace, uint64_t workspace_bytes)
+{
+    if (ctx && !out_idx && !out_val) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_argmax: no output");
+    return run_reduce<false, true>(ctx, stream, in, dtype, n, nullptr, out_val, out_idx, workspace, workspace_bytes, "mi355_argmax");
+}
+
+MI355_API int32_t mi355_sum_argmax(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, uint64_t n, float *out_sum,
+                                   float *out_val, uint64_t *out_idx, void *workspace, uint64_t workspace_bytes)
+{
+    if (ctx && !out_sum && !out_idx && !out_val) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_sum_argmax: no output");
+    return run_reduce<true, true>(ctx, stream, in, dtype, n, out_sum, out_val, out_idx, workspace, workspace_bytes, "mi355_sum_argmax");
 }
 
 MI355_API int32_t mi355_argmax_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, uint64_t n, float *out_val,
                                    uint64_t *out_idx, void *workspace, uint64_t workspace_bytes)
 {
     if (ctx && !out_idx && !out_val) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_argmax_f32: no output");
-    return run_reduce<false, true>(ctx, stream, in, n, nullptr, out_val, out_idx, workspace, workspace_bytes,
+    return run_reduce<false, true>(ctx, stream, in, MI355_DTYPE_F32, n, nullptr, out_val, out_idx, workspace, workspace_bytes,
                                    "mi355_argmax_f32");
 }
 
@@ -550,7 +639,7 @@ MI355_API int32_t mi355_sum_argmax_f32(mi355_ctx *ctx, mi355_stream stream, cons
 {
     if (ctx && !out_sum && !out_idx && !out_val)
         return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_sum_argmax_f32: no output");
-    return run_reduce<true, true>(ctx, stream, in, n, out_sum, out_val, out_idx, workspace, workspace_bytes,
+    return run_reduce<true, true>(ctx, stream, in, MI355_DTYPE_F32, n, out_sum, out_val, out_idx, workspace, workspace_bytes,
                                   "mi355_sum_argmax_f32");
 }
 

@@ -155,8 +155,9 @@ def _workspace(client: ComputeClient, n: int) -> Handle:
 
 
 def _require_flat_f32(t: TensorHandle, what: str) -> int:
-    if t.dtype != ElemType.F32:
-        raise ServerError(N.E_UNSUPPORTED, f"{what}: only f32 input is implemented")
+    """Array-wide reductions take f32, bf16 or f16 input (16-bit elements are widened to f32 on load)."""
+    if t.dtype not in (ElemType.F32, ElemType.BF16, ElemType.F16):
+        raise ServerError(N.E_UNSUPPORTED, f"{what}: input must be f32, bf16 or f16")
     if not t.is_contiguous():
         raise ServerError(N.E_UNSUPPORTED_STRIDES, f"{what}: input must be contiguous")
     return t.num_elems()
@@ -166,8 +167,8 @@ def reduce_sum(client: ComputeClient, input: TensorHandle, output: TensorHandle)
     """Array-wide sum into output[0] (f32)."""
     n = _require_flat_f32(input, "reduce_sum")
     ws = _workspace(client, n)
-    client._s.check(client.lib.mi355_reduce_sum_f32(client.ctx, client.stream, C.c_void_p(input.device_ptr()), n,
-                                                    C.c_void_p(output.device_ptr()), C.c_void_p(ws.device_ptr()), ws.size))
+    client._s.check(client.lib.mi355_reduce_sum(client.ctx, client.stream, C.c_void_p(input.device_ptr()), int(input.dtype), n,
+                                                C.c_void_p(output.device_ptr()), C.c_void_p(ws.device_ptr()), ws.size))
 
 
 def argmax(client: ComputeClient, input: TensorHandle, out_index: TensorHandle,
@@ -175,8 +176,8 @@ def argmax(client: ComputeClient, input: TensorHandle, out_index: TensorHandle,
     """Array-wide argmax: out_index[0] (u64) = lowest index of the maximum; NaN ranks highest."""
     n = _require_flat_f32(input, "argmax")
     ws = _workspace(client, n)
-    client._s.check(client.lib.mi355_argmax_f32(
-        client.ctx, client.stream, C.c_void_p(input.device_ptr()), n,
+    client._s.check(client.lib.mi355_argmax(
+        client.ctx, client.stream, C.c_void_p(input.device_ptr()), int(input.dtype), n,
         C.c_void_p(out_value.device_ptr()) if out_value is not None else None,
         C.c_void_p(out_index.device_ptr()), C.c_void_p(ws.device_ptr()), ws.size))
 
@@ -186,8 +187,8 @@ def sum_argmax(client: ComputeClient, input: TensorHandle, out_sum: TensorHandle
     """Sum and argmax in one pass over the data."""
     n = _require_flat_f32(input, "sum_argmax")
     ws = _workspace(client, n)
-    client._s.check(client.lib.mi355_sum_argmax_f32(
-        client.ctx, client.stream, C.c_void_p(input.device_ptr()), n, C.c_void_p(out_sum.device_ptr()),
+    client._s.check(client.lib.mi355_sum_argmax(
+        client.ctx, client.stream, C.c_void_p(input.device_ptr()), int(input.dtype), n, C.c_void_p(out_sum.device_ptr()),
         C.c_void_p(out_value.device_ptr()) if out_value is not None else None,
         C.c_void_p(out_index.device_ptr()), C.c_void_p(ws.device_ptr()), ws.size))
 

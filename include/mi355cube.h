@@ -391,6 +391,17 @@ int32_t mi355_argmax_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, u
 int32_t mi355_sum_argmax_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, uint64_t n,
                              float *out_sum, float *out_val, uint64_t *out_idx, void *workspace,
                              uint64_t workspace_bytes);
+/* The same three reductions for f32, bf16 or f16 inputs (`dtype`): elements are widened to f32 on load (exact), sums and
+ * comparisons run in f32, the outputs stay {f32 sum, f32 value of the winning element, u64 index}.  Same rules (lowest
+ * index wins ties, NaN ranks highest, -0 == +0), same single-launch deterministic tree; 16-bit inputs move half the
+ * bytes per element.  Input aligned to its element size. */
+int32_t mi355_reduce_sum(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, uint64_t n,
+                         float *out, void *workspace, uint64_t workspace_bytes);
+int32_t mi355_argmax(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, uint64_t n,
+                     float *out_val, uint64_t *out_idx, void *workspace, uint64_t workspace_bytes);
+int32_t mi355_sum_argmax(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, uint64_t n,
+                         float *out_sum, float *out_val, uint64_t *out_idx, void *workspace,
+                         uint64_t workspace_bytes);
 /* Sum over the last axis of a [rows, cols] view with row stride `row_stride` elements: the
  * book's reduce_matrix (cubecl-book/src/getting-started/src/bin/v1-cpu.rs:7-15). */
 int32_t mi355_reduce_last_axis_sum_f32(mi355_ctx *ctx, mi355_stream stream, const float *in,

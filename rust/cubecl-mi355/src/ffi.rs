@@ -251,6 +251,13 @@ unsafe extern "C" {
     pub fn mi355_graph_end_capture(ctx: *mut mi355_ctx, stream: mi355_stream, out_graph: *mut *mut mi355_graph) -> i32;
     pub fn mi355_graph_replay(ctx: *mut mi355_ctx, stream: mi355_stream, graph: *mut mi355_graph) -> i32;
     pub fn mi355_graph_destroy(ctx: *mut mi355_ctx, graph: *mut mi355_graph) -> i32;
+    // array-wide reductions of f32 / bf16 / f16 input (f32 arithmetic)
+    pub fn mi355_reduce_sum(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const c_void, dtype: i32, n: u64, out: *mut f32,
+                            workspace: *mut c_void, workspace_bytes: u64) -> i32;
+    pub fn mi355_argmax(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const c_void, dtype: i32, n: u64, out_val: *mut f32,
+                        out_idx: *mut u64, workspace: *mut c_void, workspace_bytes: u64) -> i32;
+    pub fn mi355_sum_argmax(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const c_void, dtype: i32, n: u64, out_sum: *mut f32,
+                            out_val: *mut f32, out_idx: *mut u64, workspace: *mut c_void, workspace_bytes: u64) -> i32;
     // reductions over any axis, plane ops
     pub fn mi355_reduce_axis_sum_f32(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const f32, out: *mut f32, outer: u64,
                                      reduce: u64, inner: u64) -> i32;

@@ -252,3 +252,52 @@ def test_axis_argmax_ties_and_nan(client, oracle):
     assert np.array_equal(got, want) and np.array_equal(got, oracle.reduce_axis_argmax(x, 1))
     with pytest.raises(ServerError):
         ops.reduce_sum_axis(client, t, a, 3)
+
+
+# ---- bf16 / f16 inputs of the array-wide reductions (widened to f32 on load) -------------------------------------------
+@pytest.mark.parametrize("dtype", [ElemType.BF16, ElemType.F16])
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 4099, 16384, 16385, (1 << 20) + 13, (1 << 24) + 5])
+def test_16bit_sum_argmax_match_the_oracle(client, oracle, dtype, n):
+    conv, back = (oracle.to_bf16, oracle.from_bf16) if dtype == ElemType.BF16 else (oracle.to_f16, oracle.from_f16)
+    bits = conv(oracle.fill_uniform(n, 31, -1.0, 1.0))
+    vals = back(bits)
+    t = TensorHandle.from_numpy(client, bits, dtype) if n else TensorHandle.new_contiguous((0,), client.empty(0), dtype)
+    out, idx, val = _scalar(client, ElemType.F32), _scalar(client, ElemType.U64), _scalar(client, ElemType.F32)
+    ops.reduce_sum(client, t, out)
+    got = float(out.to_numpy(client)[0])
+    assert abs(got - oracle.sum_f64(vals)) <= REL * max(oracle.sum_abs_f64(vals), 1e-30) or (n == 0 and got == 0.0)
+    if n:
+        ops.argmax(client, t, idx, val)
+        ref_i, ref_v = oracle.argmax(vals)
+        assert int(idx.to_numpy(client)[0]) == ref_i
+        assert val.to_numpy(client).view(np.uint32)[0] == np.float32(ref_v).view(np.uint32)
+        s2 = _scalar(client, ElemType.F32)
+        ops.sum_argmax(client, t, s2, idx, val)
+        assert int(idx.to_numpy(client)[0]) == ref_i and s2.to_numpy(client).view(np.uint32)[0] == out.to_numpy(client).view(np.uint32)[0]
+
+
+@pytest.mark.parametrize("dtype", [ElemType.BF16, ElemType.F16])
+def test_16bit_argmax_rules_and_misaligned_views(client, oracle, dtype):
+    conv = oracle.to_bf16 if dtype == ElemType.BF16 else oracle.to_f16
+    n = 100_003
+    x = oracle.fill_uniform(n, 32, -4.0, 4.0)
+    x[[5, 70_001]] = 9.0                                       # a tie: the lower index wins
+    x[12] = -0.0
+    bits = conv(x)
+    idx, val = _scalar(client, ElemType.U64), _scalar(client, ElemType.F32)
+    h = client.create_from_slice(bits)
+    for skip in (0, 1, 3, 7):                                  # views that start off the 16-byte grid
+        view = TensorHandle.new_contiguous((n - skip,), h.offset_start_by(2 * skip), dtype)
+        ops.argmax(client, view, idx, val)
+        want = 5 - skip if skip <= 5 else 70_001 - skip
+        assert int(idx.to_numpy(client)[0]) == want and float(val.to_numpy(client)[0]) == 9.0
+    nan_bits = bits.copy()
+    nan_bits[[40_000, 90_000]] = 0x7FC0 if dtype == ElemType.BF16 else 0x7E00            # NaN ranks highest, first one wins
+    ops.argmax(client, TensorHandle.from_numpy(client, nan_bits, dtype), idx, val)
+    assert int(idx.to_numpy(client)[0]) == 40_000 and np.isnan(val.to_numpy(client)[0])
+
+
+def test_16bit_reduction_rejects_other_dtypes(client):
+    t = TensorHandle.new_contiguous((16,), client.empty(64), ElemType.I32)
+    with pytest.raises(ServerError):
+        ops.reduce_sum(client, t, _scalar(client, ElemType.F32))
