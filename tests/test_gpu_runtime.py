@@ -580,3 +580,48 @@ def test_to_client_moves_data_between_two_clients(client, oracle):
     finally:
         other.sync()
         other_server.close()
+
+
+def test_pool_randomised_alloc_free_keeps_every_live_block_intact(client):
+    """2 000 random reservations / releases on two streams with a distinct byte pattern per block: no live block is ever
+    handed out twice, nothing is corrupted, the usage counters return to where they started."""
+    lib, ctx = client.lib, client.ctx
+    s2 = C.c_void_p()
+    client._s.check(lib.mi355_stream_create(ctx, C.byref(s2)))
+    client.sync()
+    base = _usage(client)
+    rng = np.random.default_rng(1234)
+    live = {}                                              # ptr -> (size, pattern, stream)
+    sizes = [1, 100, 4096, 70_000, 1 << 20, 3 << 20, 40 << 20]
+    host = np.empty(256, dtype=np.uint8)
+    for step in range(2000):
+        if live and (len(live) > 40 or rng.random() < 0.45):
+            ptr = list(live)[int(rng.integers(len(live)))]
+            size, pat, st = live.pop(ptr)
+            k = min(size, 256)
+            client._s.check(lib.mi355_read(ctx, st, host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr + size - k), k))
+            assert np.all(host[:k] == pat), (step, size)
+            _pfree(client, ptr, st)
+        else:
+            size = int(sizes[int(rng.integers(len(sizes)))] * (0.5 + rng.random()))
+            size = max(size, 1)
+            st = s2 if rng.random() < 0.5 else None
+            ptr = _palloc(client, size, st)
+            assert ptr not in live
+            for q, (qs, _, _) in live.items():             # no overlap with any live block
+                assert ptr + size <= q or q + qs <= ptr
+            pat = int(rng.integers(1, 255))
+            client._s.check(lib.mi355_memset(ctx, st, C.c_void_p(ptr), pat, size))
+            live[ptr] = (size, pat, st)
+    for ptr, (size, pat, st) in live.items():
+        k = min(size, 256)
+        client._s.check(lib.mi355_read(ctx, st, host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), k))
+        assert np.all(host[:k] == pat)
+        _pfree(client, ptr, st)
+    client.sync()
+    client._s.check(lib.mi355_sync(ctx, s2))
+    end = _usage(client)
+    assert end.number_allocs == base.number_allocs and end.bytes_in_use == base.bytes_in_use and end.bytes_padding == base.bytes_padding
+    assert end.cache_hits > base.cache_hits
+    client._s.check(lib.mi355_stream_destroy(ctx, s2))
+    client.memory_cleanup()
