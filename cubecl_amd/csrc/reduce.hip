@@ -382,11 +382,13 @@ int32_t run_reduce(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t 
 // ---- last-axis reductions --------------------------------------------------------------------
 // One wave per row (THREADS=64) or one workgroup per row (THREADS=256/1024).  Rows are
 // independent; the row is streamed with 16-B loads when its base and stride allow it.
-template <int THREADS, bool ARG>
+template <int THREADS, bool ARG, int DT = MI355_DTYPE_F32>
 __global__ void __launch_bounds__(THREADS)
-reduce_rows(const float *__restrict__ in, float *__restrict__ out_sum, uint32_t *__restrict__ out_idx, uint64_t rows,
+reduce_rows(const typename red_in<DT>::elem *__restrict__ in, float *__restrict__ out_sum, uint32_t *__restrict__ out_idx, uint64_t rows,
             uint64_t cols, uint64_t row_stride, int vec_ok)
 {
+    typedef red_in<DT> RI;
+    constexpr int EPV = RI::EPV;
     constexpr int WAVES = THREADS / 64;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
@@ -394,28 +396,31 @@ reduce_rows(const float *__restrict__ in, float *__restrict__ out_sum, uint32_t 
     __shared__ uint32_t s_key[WAVES];
     __shared__ uint64_t s_idx[WAVES];
     for (uint64_t row = blockIdx.x; row < rows; row += gridDim.x) {
-        const float *__restrict__ p = in + row * row_stride;
+        const typename RI::elem *__restrict__ p = in + row * row_stride;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         uint32_t key = 0u; uint64_t idx = ~0ull;
         uint64_t done = 0;
         if (vec_ok) {
-            const f32x4 *__restrict__ vp = reinterpret_cast<const f32x4 *>(p);
-            const uint64_t nv = cols / 4;
+            const u32x4r *__restrict__ vp = reinterpret_cast<const u32x4r *>(p);
+            const uint64_t nv = cols / EPV;
             for (uint64_t i = tid; i < nv; i += THREADS) {
-                const f32x4 v = vp[i];
-                if (!ARG) { a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3]; }
-                else {
+                float v[EPV];
+                RI::unpack(vp[i], v);
+                if (!ARG) {
+                    a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+                    if constexpr (EPV == 8) { a0 += v[4]; a1 += v[5]; a2 += v[6]; a3 += v[7]; }
+                } else {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
+                    for (int c = 0; c < EPV; ++c) {
                         const uint32_t k = argmax_key(v[c]);
-                        if (k > key) { key = k; idx = i * 4 + c; }
+                        if (k > key) { key = k; idx = i * EPV + c; }
                     }
                 }
             }
-            done = nv * 4;
+            done = nv * EPV;
         }
         for (uint64_t i = done + tid; i < cols; i += THREADS) {
-            const float v = p[i];
+            const float v = RI::widen(p[i]);
             if (!ARG) a0 += v;
             else { const uint32_t k = argmax_key(v); if (k > key) { key = k; idx = i; } }
         }
@@ -518,8 +523,8 @@ int32_t run_mid(mi355_ctx *ctx, mi355_stream stream, const float *in, float *out
     return MI355_OK;
 }
 
-template <bool ARG>
-int32_t run_rows(mi355_ctx *ctx, mi355_stream stream, const float *in, float *out_sum, uint32_t *out_idx,
+template <bool ARG, int DT = MI355_DTYPE_F32>
+int32_t run_rows(mi355_ctx *ctx, mi355_stream stream, const typename red_in<DT>::elem *in, float *out_sum, uint32_t *out_idx,
                  uint64_t rows, uint64_t cols, uint64_t row_stride, const char *what)
 {
     MI355_REQUIRE_CTX(ctx);
@@ -532,19 +537,20 @@ int32_t run_rows(mi355_ctx *ctx, mi355_stream stream, const float *in, float *ou
     if (ARG && cols > 0xFFFFFFFFull)
         return fail(ctx, MI355_E_UNSUPPORTED, "%s: cols exceed u32 index range", what);
     hipStream_t s = stream_of(ctx, stream);
-    const int vec_ok = ((reinterpret_cast<uintptr_t>(in) & 15u) == 0 && (row_stride % 4) == 0) ? 1 : 0;
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(in) & 15u) == 0 && (row_stride % red_in<DT>::EPV) == 0) ? 1 : 0;
     const uint64_t cus = ctx->props.num_streaming_multiprocessors;
-    if (cols <= 2048) {
+    const uint64_t cols32 = cols * sizeof(typename red_in<DT>::elem) / 4;        // row length in f32-equivalents (bytes / 4)
+    if (cols32 <= 2048) {
         const uint32_t grid = (uint32_t)std::min<uint64_t>(rows, cus * 32);
-        hipLaunchKernelGGL((reduce_rows<64, ARG>), dim3(grid), dim3(64), 0, s, in, out_sum, out_idx, rows, cols,
+        hipLaunchKernelGGL((reduce_rows<64, ARG, DT>), dim3(grid), dim3(64), 0, s, in, out_sum, out_idx, rows, cols,
                            row_stride, vec_ok);
-    } else if (cols <= 65536) {
+    } else if (cols32 <= 65536) {
         const uint32_t grid = (uint32_t)std::min<uint64_t>(rows, cus * 8);
-        hipLaunchKernelGGL((reduce_rows<256, ARG>), dim3(grid), dim3(256), 0, s, in, out_sum, out_idx, rows, cols,
+        hipLaunchKernelGGL((reduce_rows<256, ARG, DT>), dim3(grid), dim3(256), 0, s, in, out_sum, out_idx, rows, cols,
                            row_stride, vec_ok);
     } else {
         const uint32_t grid = (uint32_t)std::min<uint64_t>(rows, cus * 2);
-        hipLaunchKernelGGL((reduce_rows<1024, ARG>), dim3(grid), dim3(1024), 0, s, in, out_sum, out_idx, rows, cols,
+        hipLaunchKernelGGL((reduce_rows<1024, ARG, DT>), dim3(grid), dim3(1024), 0, s, in, out_sum, out_idx, rows, cols,
                            row_stride, vec_ok);
     }
     check_launch(ctx, what);
@@ -655,6 +661,31 @@ MI355_API int32_t mi355_reduce_last_axis_argmax_f32(mi355_ctx *ctx, mi355_stream
 {
     return run_rows<true>(ctx, stream, in, nullptr, out_idx, rows, cols, row_stride,
                           "mi355_reduce_last_axis_argmax_f32");
+}
+
+// last-axis reductions of f32 / bf16 / f16 rows (f32 arithmetic, f32 sums / u32 indices out)
+MI355_API int32_t mi355_reduce_last_axis_sum(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, float *out,
+                                             uint64_t rows, uint64_t cols, uint64_t row_stride)
+{
+    if (!ctx) return MI355_E_INVALID_ARGUMENT;
+    switch (dtype) {
+    case MI355_DTYPE_F32: return run_rows<false>(ctx, stream, static_cast<const float *>(in), out, nullptr, rows, cols, row_stride, "mi355_reduce_last_axis_sum");
+    case MI355_DTYPE_BF16: return run_rows<false, MI355_DTYPE_BF16>(ctx, stream, static_cast<const uint16_t *>(in), out, nullptr, rows, cols, row_stride, "mi355_reduce_last_axis_sum");
+    case MI355_DTYPE_F16: return run_rows<false, MI355_DTYPE_F16>(ctx, stream, static_cast<const uint16_t *>(in), out, nullptr, rows, cols, row_stride, "mi355_reduce_last_axis_sum");
+    default: return fail(ctx, MI355_E_UNSUPPORTED, "mi355_reduce_last_axis_sum: input dtype %d (f32, bf16 or f16)", dtype);
+    }
+}
+
+MI355_API int32_t mi355_reduce_last_axis_argmax(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, uint32_t *out_idx,
+                                                uint64_t rows, uint64_t cols, uint64_t row_stride)
+{
+    if (!ctx) return MI355_E_INVALID_ARGUMENT;
+    switch (dtype) {
+    case MI355_DTYPE_F32: return run_rows<true>(ctx, stream, static_cast<const float *>(in), nullptr, out_idx, rows, cols, row_stride, "mi355_reduce_last_axis_argmax");
+    case MI355_DTYPE_BF16: return run_rows<true, MI355_DTYPE_BF16>(ctx, stream, static_cast<const uint16_t *>(in), nullptr, out_idx, rows, cols, row_stride, "mi355_reduce_last_axis_argmax");
+    case MI355_DTYPE_F16: return run_rows<true, MI355_DTYPE_F16>(ctx, stream, static_cast<const uint16_t *>(in), nullptr, out_idx, rows, cols, row_stride, "mi355_reduce_last_axis_argmax");
+    default: return fail(ctx, MI355_E_UNSUPPORTED, "mi355_reduce_last_axis_argmax: input dtype %d (f32, bf16 or f16)", dtype);
+    }
 }
 
 MI355_API int32_t mi355_reduce_axis_sum_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, float *out, uint64_t outer,

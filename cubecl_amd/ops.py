@@ -194,8 +194,8 @@ def sum_argmax(client: ComputeClient, input: TensorHandle, out_sum: TensorHandle
 
 
 def _rows_view(t: TensorHandle, what: str):
-    if t.dtype != ElemType.F32:
-        raise ServerError(N.E_UNSUPPORTED, f"{what}: only f32 input is implemented")
+    if t.dtype not in (ElemType.F32, ElemType.BF16, ElemType.F16):
+        raise ServerError(N.E_UNSUPPORTED, f"{what}: input must be f32, bf16 or f16")
     if t.rank() == 0:
         raise ServerError(N.E_INVALID_ARGUMENT, f"{what}: rank-0 input")
     cols = t.shape[-1]
@@ -216,14 +216,14 @@ def reduce_sum_last_axis(client: ComputeClient, input: TensorHandle, output: Ten
     """The book's reduce_matrix (cubecl-book/src/getting-started/src/bin/v1-cpu.rs:7-15):
     output shape = input shape minus the last axis."""
     rows, cols, stride = _rows_view(input, "reduce_sum_last_axis")
-    client._s.check(client.lib.mi355_reduce_last_axis_sum_f32(
-        client.ctx, client.stream, C.c_void_p(input.device_ptr()), C.c_void_p(output.device_ptr()), rows, cols, stride))
+    client._s.check(client.lib.mi355_reduce_last_axis_sum(
+        client.ctx, client.stream, C.c_void_p(input.device_ptr()), int(input.dtype), C.c_void_p(output.device_ptr()), rows, cols, stride))
 
 
 def argmax_last_axis(client: ComputeClient, input: TensorHandle, output: TensorHandle) -> None:
     rows, cols, stride = _rows_view(input, "argmax_last_axis")
-    client._s.check(client.lib.mi355_reduce_last_axis_argmax_f32(
-        client.ctx, client.stream, C.c_void_p(input.device_ptr()), C.c_void_p(output.device_ptr()), rows, cols, stride))
+    client._s.check(client.lib.mi355_reduce_last_axis_argmax(
+        client.ctx, client.stream, C.c_void_p(input.device_ptr()), int(input.dtype), C.c_void_p(output.device_ptr()), rows, cols, stride))
 
 
 def _axis_view(t: TensorHandle, axis: int, what: str):

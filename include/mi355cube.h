@@ -410,6 +410,12 @@ int32_t mi355_reduce_last_axis_sum_f32(mi355_ctx *ctx, mi355_stream stream, cons
 int32_t mi355_reduce_last_axis_argmax_f32(mi355_ctx *ctx, mi355_stream stream, const float *in,
                                           uint32_t *out_idx, uint64_t rows, uint64_t cols,
                                           uint64_t row_stride);
+/* the last-axis reductions for f32 / bf16 / f16 rows (`dtype`; widened to f32 on load, f32 sums / u32 indices out;
+ * row_stride in elements) */
+int32_t mi355_reduce_last_axis_sum(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype,
+                                   float *out, uint64_t rows, uint64_t cols, uint64_t row_stride);
+int32_t mi355_reduce_last_axis_argmax(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype,
+                                      uint32_t *out_idx, uint64_t rows, uint64_t cols, uint64_t row_stride);
 /* Sum / argmax over ANY one axis of a contiguous tensor viewed as [outer][reduce][inner] (inner == 1 is the
  * last-axis case above): out is [outer][inner].  The book's reduce_dim generalisation
  * (cubecl-book/src/getting-started/src/bin/v7-gpu.rs:59-77 reduces the last axis of a 3-D tensor; cubek's

@@ -301,3 +301,22 @@ def test_16bit_reduction_rejects_other_dtypes(client):
     t = TensorHandle.new_contiguous((16,), client.empty(64), ElemType.I32)
     with pytest.raises(ServerError):
         ops.reduce_sum(client, t, _scalar(client, ElemType.F32))
+
+
+@pytest.mark.parametrize("dtype", [ElemType.BF16, ElemType.F16])
+@pytest.mark.parametrize("shape", [(512, 8192), (64, 64, 4096), (37, 1001), (3, 3), (1, 200_003), (1000, 1), (5, 70_001), (16, 131_072)])
+def test_last_axis_reductions_16bit(client, oracle, dtype, shape):
+    conv, back = (oracle.to_bf16, oracle.from_bf16) if dtype == ElemType.BF16 else (oracle.to_f16, oracle.from_f16)
+    n = int(np.prod(shape))
+    bits = conv(oracle.fill_uniform(n, 33, -1.0, 1.0)).reshape(shape)
+    x = back(bits).reshape(shape)
+    t = TensorHandle.from_numpy(client, bits, dtype)
+    rows = max(n // shape[-1], 1)
+    out = TensorHandle.new_contiguous(shape[:-1], client.empty(rows * 4), ElemType.F32)
+    ops.reduce_sum_last_axis(client, t, out)
+    exact = oracle.reduce_last_axis_sum(x, f64=True)
+    scale = np.abs(x).sum(axis=-1, dtype=np.float64)
+    assert np.all(np.abs(out.to_numpy(client) - exact) <= REL * np.maximum(scale, 1e-30))
+    oi = TensorHandle.new_contiguous(shape[:-1], client.empty(rows * 4), ElemType.U32)
+    ops.argmax_last_axis(client, t, oi)
+    assert np.array_equal(oi.to_numpy(client), oracle.reduce_last_axis_argmax(x))
