@@ -20,6 +20,7 @@
 //  * MFMA operands swapped (first = B fragment, second = A fragment): each lane then owns 4
 //    consecutive N-columns of one C row per register quad -> 16-byte (f32) / 8-byte (16-bit) stores.
 #include <algorithm>
+#include <type_traits>
 
 #include "gemm_common.hpp"
 
@@ -49,13 +50,16 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
                                      (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
 }
 
-template <int DT, int DT_C>
-__global__ void __launch_bounds__(256, 2)
+// NS = LDS stages.  2 (64 KiB, two workgroups per CU): the co-resident workgroup covers the wait for the next K-tile.
+// 4 (128 KiB, one workgroup per CU): taken when the launch has at most one workgroup per CU anyway (mid-size shapes:
+// <= 256 tiles) -- then nothing else hides the DMA latency, and the K-tiles are fetched three ahead instead of one.
+template <int DT, int DT_C, int NS = 2>
+__global__ void __launch_bounds__(256, NS == 2 ? 2 : 1)
 gemm_lp128_kernel(gemm_args g)
 {
     // [stage][operand][16 KiB]; one array only (a second __shared__ object de-pipelines LDS-DMA
     // loops: guide section 5, ".s-level traps" (a))
-    __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * TILE_BYTES];
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
     typedef typename lp<DT>::frag frag;
 
     const int tid = threadIdx.x;
@@ -121,31 +125,83 @@ gemm_lp128_kernel(gemm_args g)
         }
     };
 
-    if (nk > 0) stage(0, 0);
-    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) lgkmcnt(0) expcnt(0)
-    __syncthreads();
+    frag af[2][2], bf[2][2];                     // [register buffer][tile]
+    auto reads = [&](auto buf, const char *la, const char *lb, int kk) {
+        constexpr int B = decltype(buf)::value;
+        const int q = kk * 2 + h;                // logical 16-byte chunk: 8 k-values
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[B][i] = *reinterpret_cast<const frag *>(la + ra[i] + ((q ^ fa[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[B][j] = *reinterpret_cast<const frag *>(lb + rb[j] + ((q ^ fb[j]) << 4));
+    };
+    auto mfmas = [&](auto buf) {
+        constexpr int B = decltype(buf)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][j] = lp<DT>::mfma(bf[B][j], af[B][i], acc[i][j]);
+    };
+    typedef std::integral_constant<int, 0> B0;
+    typedef std::integral_constant<int, 1> B1;
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-        const char *la = smem + cur * 2 * TILE_BYTES;
-        const char *lb = la + TILE_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            frag af[2], bf[2];
-            const int q = kk * 2 + h;  // logical 16-byte chunk: 8 k-values
-#pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const frag *>(la + ra[i] + ((q ^ fa[i]) << 4));
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const frag *>(lb + rb[j] + ((q ^ fb[j]) << 4));
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i][j] = lp<DT>::mfma(bf[j], af[i], acc[i][j]);
-        }
-        // the DMA for tile kt+1 must have landed and every wave must be done reading `cur`
-        __builtin_amdgcn_s_waitcnt(0);
+    if constexpr (NS == 2) {
+        if (nk > 0) stage(0, 0);
+        __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) lgkmcnt(0) expcnt(0)
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+            const char *la = smem + cur * 2 * TILE_BYTES;
+            const char *lb = la + TILE_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                reads(B0{}, la, lb, kk);
+                mfmas(B0{});
+            }
+            // the DMA for tile kt+1 must have landed and every wave must be done reading `cur`
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+        }
+    } else {
+        // Deep ring (NS stages, K-tiles fetched NS-1 ahead) with the fragments double-buffered in registers: the reads
+        // of k-step kk+1 are issued before the MFMAs of k-step kk, and the hand-over to the next K-tile sits before the
+        // LAST k-step, so that the next tile's first fragments are fetched under its four MFMAs (as gemm_lp256w4.hip).
+        // vmcnt is counted: 8 DMA instructions per wave and K-tile, loads complete in order.
+        static_assert(NS == 4, "the counted waits below are written for four stages");
+#pragma unroll
+        for (int p = 0; p < NS - 1; ++p)
+            if (p < nk) stage(p, p);
+        if (nk >= 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // K-tile 0 landed; tiles 1, 2 may fly
+        else if (nk == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (nk > 0) reads(B0{}, smem, smem + TILE_BYTES, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const char *la = smem + (kt % NS) * 2 * TILE_BYTES;
+            const char *lb = la + TILE_BYTES;
+            reads(B1{}, la, lb, 1); mfmas(B0{});
+            __builtin_amdgcn_sched_barrier(0);
+            reads(B0{}, la, lb, 2); mfmas(B1{});
+            __builtin_amdgcn_sched_barrier(0);
+            reads(B1{}, la, lb, 3); mfmas(B0{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) {
+                // K-tile kt+1 landed: only tile kt+2 (issued in the previous iteration or the prologue) may still fly
+                if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();   // raw: __syncthreads() carries a release fence = vmcnt(0), which would drain the ring
+                __builtin_amdgcn_sched_barrier(0);
+                // everybody is past K-tile kt-1: its buffer takes K-tile kt+3
+                if (kt + NS - 1 < nk) stage((kt + NS - 1) % NS, kt + NS - 1);
+                const char *na = smem + ((kt + 1) % NS) * 2 * TILE_BYTES;
+                reads(B0{}, na, na + TILE_BYTES, 0);
+            }
+            mfmas(B1{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
     // ---- epilogue ---------------------------------------------------------------------------
@@ -193,11 +249,26 @@ gemm_lp128_kernel(gemm_args g)
     }
 }
 
-template <int DT, int DT_C>
-void launch(hipStream_t s, const gemm_args &g, uint32_t batch)
+template <int DT, int DT_C, int NS>
+void launch_ns(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch, int slot)
 {
-    hipLaunchKernelGGL((gemm_lp128_kernel<DT, DT_C>), dim3(g.tiles_m * g.tiles_n, batch, g.split_k > 1 ? g.split_k : 1),
-                       dim3(256), 0, s, g);
+    constexpr int LDS = NS * 2 * TILE_BYTES;
+    if (LDS > 65536 && !(ctx->func_attr_mask & (1ull << slot))) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_lp128_kernel<DT, DT_C, NS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        ctx->func_attr_mask |= (1ull << slot);
+    }
+    hipLaunchKernelGGL((gemm_lp128_kernel<DT, DT_C, NS>), dim3(g.tiles_m * g.tiles_n, batch, g.split_k > 1 ? g.split_k : 1),
+                       dim3(256), LDS, s, g);
+}
+
+template <int DT, int DT_C>
+void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch, int slot)
+{
+    // one workgroup per CU at most: the deep (4-stage) pipeline; otherwise two co-resident 2-stage workgroups per CU
+    const uint64_t wgs = (uint64_t)g.tiles_m * g.tiles_n * batch * (g.split_k > 1 ? g.split_k : 1);
+    if (wgs <= (uint64_t)ctx->props.num_streaming_multiprocessors) launch_ns<DT, DT_C, 4>(ctx, s, g, batch, slot);
+    else launch_ns<DT, DT_C, 2>(ctx, s, g, batch, slot);
 }
 
 }  // namespace
@@ -254,8 +325,8 @@ int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
             gemm_args gs = g;
             gs.c = ws; gs.ldc = d.n; gs.stride_c = d.m * d.n;
             gs.split_k = (uint32_t)splits; gs.split_c_stride = slab;
-            if (d.dtype_ab == MI355_DTYPE_BF16) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(s, gs, batch);
-            else launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(s, gs, batch);
+            if (d.dtype_ab == MI355_DTYPE_BF16) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, gs, batch, 48);
+            else launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(ctx, s, gs, batch, 50);
             check_launch(ctx, "mi355_gemm(lp128 split-K)");
             launch_splitk_fold(s, ws, (uint32_t)splits, slab, d.batch, d.m, d.n, c, d.dtype_c, d.ldc, d.stride_c);
             check_launch(ctx, "mi355_gemm(split-K fold)");
@@ -263,11 +334,11 @@ int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
         }
     }
     if (d.dtype_ab == MI355_DTYPE_BF16) {
-        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(s, g, batch);
-        else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16>(s, g, batch);
+        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, g, batch, 48);
+        else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16>(ctx, s, g, batch, 49);
     } else {
-        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(s, g, batch);
-        else launch<MI355_DTYPE_F16, MI355_DTYPE_F16>(s, g, batch);
+        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(ctx, s, g, batch, 50);
+        else launch<MI355_DTYPE_F16, MI355_DTYPE_F16>(ctx, s, g, batch, 51);
     }
     check_launch(ctx, "mi355_gemm(lp128)");
     return MI355_OK;
