@@ -53,6 +53,18 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
 // NS = LDS stages.  2 (64 KiB, two workgroups per CU): the co-resident workgroup covers the wait for the next K-tile.
 // 4 (128 KiB, one workgroup per CU): taken when the launch has at most one workgroup per CU anyway (mid-size shapes:
 // <= 256 tiles) -- then nothing else hides the DMA latency, and the K-tiles are fetched three ahead instead of one.
+// LDS-DMA as `global_load_lds_dwordx4 v_off, s[base:base+1]`: wave-uniform 64-bit base + constant 32-bit lane offset, LDS
+// destination through M0 (set in the same statement); see gemm_lp256w4.hip.  Not counted by the compiler: every wait on
+// these loads in this file is explicit.
+__device__ __forceinline__ void glds16_s(const void *ubase, uint32_t voff, uint32_t lds_byte_addr)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ubase), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void *p)
+{
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)p;
+}
+
 template <int DT, int DT_C, int NS = 2>
 __global__ void __launch_bounds__(256, NS == 2 ? 2 : 1)
 gemm_lp128_kernel(gemm_args g)
@@ -76,16 +88,14 @@ gemm_lp128_kernel(gemm_args g)
     const char *__restrict__ B = static_cast<const char *>(g.b) + batch * g.stride_b * 2;
 
     // ---- DMA map: wave w, instruction j fills rows (j*4+w)*8 .. +7 of the tile ----------------
-    const char *ga[4];
-    const char *gb[4];
+    const char *ubase_a = A + m0 * g.lda * 2, *ubase_b = B + n0 * g.ldb * 2;      // uniform: first row of the tile
+    uint32_t va[4], vb[4];                                  // per-lane byte offsets from those (rows clamped at the edges)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = (j * 4 + wave) * 8 + (lane >> 3);    // tile row this lane fills
         const int q = (lane & 7) ^ ((r >> 1) & 7);          // logical chunk fetched into physical chunk lane&7
-        const int64_t m = min(m0 + r, g.m - 1);
-        const int64_t n = min(n0 + r, g.n - 1);
-        ga[j] = A + (m * g.lda + q * 8) * 2;
-        gb[j] = B + (n * g.ldb + q * 8) * 2;
+        va[j] = (uint32_t)((min((int64_t)r, g.m - 1 - m0) * g.lda + q * 8) * 2);
+        vb[j] = (uint32_t)((min((int64_t)r, g.n - 1 - n0) * g.ldb + q * 8) * 2);
     }
 
     // ---- fragment read offsets (bytes inside one operand tile) --------------------------------
@@ -120,8 +130,8 @@ gemm_lp128_kernel(gemm_args g)
         const int64_t koff = (int64_t)kt * BK * 2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            glds16(ga[j] + koff, la + (j * 4 + wave) * 1024);
-            glds16(gb[j] + koff, lb + (j * 4 + wave) * 1024);
+            glds16_s(ubase_a + koff, va[j], lds_addr_of(la + (j * 4 + wave) * 1024));
+            glds16_s(ubase_b + koff, vb[j], lds_addr_of(lb + (j * 4 + wave) * 1024));
         }
     };
 
@@ -290,6 +300,7 @@ bool gemm_lp128_supports(const mi355_gemm_desc &d, const void *a, const void *b,
     if (d.batch > 65535) return false;
     const int64_t tiles = ((d.m + BM - 1) / BM) * ((d.n + BN - 1) / BN);
     if (tiles * std::max<int64_t>(d.batch, 1) > 0x7FFFFFFF) return false;   // 32-bit (batch, tile) sequence for the XCD remap
+    if ((int64_t)BM * std::max(d.lda, d.ldb) * 2 >= (1ll << 32)) return false;   // per-lane DMA offsets are 32-bit
     return true;
 }
 
