@@ -34,8 +34,13 @@ int32_t validate(mi355_ctx *ctx, const mi355_gemm_desc *d, const void *a, const 
 int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
 {
     if (d.k == 0) return MI355_GEMM_ALGO_GENERIC;  // writes zeros
-    if (is_fp8(d.dtype_ab))   // one MFMA kernel (256x256 tiles); m*n*k below 2^21 is launch-bound either way
-        return (gemm_lp256w4_supports(d, a, b, c) && d.m * d.n * d.k >= ((int64_t)1 << 21)) ? MI355_GEMM_ALGO_LP_256W4 : MI355_GEMM_ALGO_GENERIC;
+    if (is_fp8(d.dtype_ab)) {   // 256x256 tiles from 129 tiles up (as for bf16), the 128x128 kernel below that
+        const bool big4 = gemm_lp256w4_supports(d, a, b, c), mid = gemm_lp128_supports(d, a, b, c);
+        const int64_t tiles256 = ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch;
+        if (big4 && (tiles256 > 128 || !mid) && d.m * d.n * d.k >= ((int64_t)1 << 21)) return MI355_GEMM_ALGO_LP_256W4;
+        if (mid) return MI355_GEMM_ALGO_LP_128;
+        return MI355_GEMM_ALGO_GENERIC;
+    }
     if (d.dtype_ab == MI355_DTYPE_F32) {
         // 256x256 tiles (one wave per SIMD) when they give (nearly) every CU a tile; else 128x128
         if (gemm_lp256w4_supports(d, a, b, c) && ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch >= 192) return MI355_GEMM_ALGO_LP_256W4;

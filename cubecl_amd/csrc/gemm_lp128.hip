@@ -28,8 +28,8 @@ using namespace mi355;
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int ROW_BYTES = BK * 2;              // 128
+constexpr int BM = 128, BN = 128;
+constexpr int ROW_BYTES = 128;                 // one K-tile row = one 128-byte line: 64 x 16-bit or 128 x fp8 k-values
 constexpr int TILE_BYTES = BM * ROW_BYTES;     // 16 KiB per operand per stage
 
 template <int DT> struct lp;
@@ -42,6 +42,19 @@ template <> struct lp<MI355_DTYPE_F16> {
     typedef f16x8 frag;
     static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c)
     { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+// OCP FP8: one v_mfma_f32_32x32x64_f8f6f4 (64 cycles) per 32-byte fragment = two adjacent 16-byte chunks of the row; a
+// K-tile is two such k-steps (see gemm_lp256w4.hip for the instruction; unscaled, any consistent k assignment is valid).
+template <> struct lp<MI355_DTYPE_F8E4M3> {
+    typedef i32x8 frag;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c)
+    { return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0); }
+};
+template <> struct lp<MI355_DTYPE_F8E5M2> {
+    typedef i32x8 frag;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c)
+    { return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 1, 1, 0, 0, 0, 0); }
 };
 
 __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
@@ -84,18 +97,22 @@ gemm_lp128_kernel(gemm_args g)
     batched_tile_coords(g.tiles_m, g.tiles_n, g.group_m, tm, tn, batch_u);
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
     const int64_t batch = batch_u;
-    const char *__restrict__ A = static_cast<const char *>(g.a) + batch * g.stride_a * 2;
-    const char *__restrict__ B = static_cast<const char *>(g.b) + batch * g.stride_b * 2;
+    constexpr bool F8 = DT == MI355_DTYPE_F8E4M3 || DT == MI355_DTYPE_F8E5M2;
+    constexpr int ESZ = F8 ? 1 : 2;
+    constexpr int BK = ROW_BYTES / ESZ;                  // k-values per K-tile: 128 (fp8) / 64 (16-bit)
+    constexpr int NSTEP = F8 ? 2 : 4;                    // k-steps per K-tile (fp8: 64 k-values per MFMA)
+    const char *__restrict__ A = static_cast<const char *>(g.a) + batch * g.stride_a * ESZ;
+    const char *__restrict__ B = static_cast<const char *>(g.b) + batch * g.stride_b * ESZ;
 
     // ---- DMA map: wave w, instruction j fills rows (j*4+w)*8 .. +7 of the tile ----------------
-    const char *ubase_a = A + m0 * g.lda * 2, *ubase_b = B + n0 * g.ldb * 2;      // uniform: first row of the tile
+    const char *ubase_a = A + m0 * g.lda * ESZ, *ubase_b = B + n0 * g.ldb * ESZ;  // uniform: first row of the tile
     uint32_t va[4], vb[4];                                  // per-lane byte offsets from those (rows clamped at the edges)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = (j * 4 + wave) * 8 + (lane >> 3);    // tile row this lane fills
         const int q = (lane & 7) ^ ((r >> 1) & 7);          // logical chunk fetched into physical chunk lane&7
-        va[j] = (uint32_t)((min((int64_t)r, g.m - 1 - m0) * g.lda + q * 8) * 2);
-        vb[j] = (uint32_t)((min((int64_t)r, g.n - 1 - n0) * g.ldb + q * 8) * 2);
+        va[j] = (uint32_t)(min((int64_t)r, g.m - 1 - m0) * g.lda * ESZ + q * 16);
+        vb[j] = (uint32_t)(min((int64_t)r, g.n - 1 - n0) * g.ldb * ESZ + q * 16);
     }
 
     // ---- fragment read offsets (bytes inside one operand tile) --------------------------------
@@ -127,7 +144,7 @@ gemm_lp128_kernel(gemm_args g)
         const int kt = kt0 + kt_rel;
         char *la = smem + buf * 2 * TILE_BYTES;
         char *lb = la + TILE_BYTES;
-        const int64_t koff = (int64_t)kt * BK * 2;
+        const int64_t koff = (int64_t)kt * ROW_BYTES;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             glds16_s(ubase_a + koff, va[j], lds_addr_of(la + (j * 4 + wave) * 1024));
@@ -138,11 +155,29 @@ gemm_lp128_kernel(gemm_args g)
     frag af[2][2], bf[2][2];                     // [register buffer][tile]
     auto reads = [&](auto buf, const char *la, const char *lb, int kk) {
         constexpr int B = decltype(buf)::value;
-        const int q = kk * 2 + h;                // logical 16-byte chunk: 8 k-values
+        if constexpr (F8) {
+            // k-step kk, lane-half h: logical chunks 4kk + 2h and 4kk + 2h + 1 (the second sits in physical chunk ^ 1)
+            const int q = kk * 4 + 2 * h;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[B][i] = *reinterpret_cast<const frag *>(la + ra[i] + ((q ^ fa[i]) << 4));
+            for (int i = 0; i < 2; ++i) {
+                const char *p0 = la + ra[i] + ((q ^ fa[i]) << 4);
+                const u32x4 lo = *reinterpret_cast<const u32x4 *>(p0);
+                const u32x4 hi = *reinterpret_cast<const u32x4 *>(la + ra[i] + (((q ^ fa[i]) ^ 1) << 4));
+                af[B][i] = (frag){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+            }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bf[B][j] = *reinterpret_cast<const frag *>(lb + rb[j] + ((q ^ fb[j]) << 4));
+            for (int j = 0; j < 2; ++j) {
+                const u32x4 lo = *reinterpret_cast<const u32x4 *>(lb + rb[j] + ((q ^ fb[j]) << 4));
+                const u32x4 hi = *reinterpret_cast<const u32x4 *>(lb + rb[j] + (((q ^ fb[j]) ^ 1) << 4));
+                bf[B][j] = (frag){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+            }
+        } else {
+            const int q = kk * 2 + h;            // logical 16-byte chunk: 8 k-values
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[B][i] = *reinterpret_cast<const frag *>(la + ra[i] + ((q ^ fa[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[B][j] = *reinterpret_cast<const frag *>(lb + rb[j] + ((q ^ fb[j]) << 4));
+        }
     };
     auto mfmas = [&](auto buf) {
         constexpr int B = decltype(buf)::value;
@@ -167,8 +202,10 @@ gemm_lp128_kernel(gemm_args g)
             // (+2...5 % even with the co-resident workgroup filling gaps)
             reads(B0{}, la, lb, 0);
             reads(B1{}, la, lb, 1); mfmas(B0{});
-            reads(B0{}, la, lb, 2); mfmas(B1{});
-            reads(B1{}, la, lb, 3); mfmas(B0{});
+            if constexpr (NSTEP == 4) {
+                reads(B0{}, la, lb, 2); mfmas(B1{});
+                reads(B1{}, la, lb, 3); mfmas(B0{});
+            }
             mfmas(B1{});
             // the DMA for tile kt+1 must have landed and every wave must be done reading `cur`
             __builtin_amdgcn_s_waitcnt(0);
@@ -195,10 +232,12 @@ gemm_lp128_kernel(gemm_args g)
             const char *lb = la + TILE_BYTES;
             reads(B1{}, la, lb, 1); mfmas(B0{});
             __builtin_amdgcn_sched_barrier(0);
-            reads(B0{}, la, lb, 2); mfmas(B1{});
-            __builtin_amdgcn_sched_barrier(0);
-            reads(B1{}, la, lb, 3); mfmas(B0{});
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NSTEP == 4) {
+                reads(B0{}, la, lb, 2); mfmas(B1{});
+                __builtin_amdgcn_sched_barrier(0);
+                reads(B1{}, la, lb, 3); mfmas(B0{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (kt + 1 < nk) {
                 // K-tile kt+1 landed: only tile kt+2 (issued in the previous iteration or the prologue) may still fly
                 if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -290,17 +329,21 @@ namespace mi355 {
 bool gemm_lp128_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
 {
     (void)c;
-    if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16) return false;
-    if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != d.dtype_ab) return false;
+    const bool f8 = is_fp8(d.dtype_ab);
+    if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16 && !f8) return false;
+    if (f8) {
+        if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != MI355_DTYPE_BF16) return false;
+    } else if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != d.dtype_ab) return false;
     if (d.trans_a || !d.trans_b) return false;
+    const int64_t esz = f8 ? 1 : 2, BK = ROW_BYTES / esz, amask = 16 / esz - 1;
     if (d.k < BK || d.k % BK != 0) return false;
     if (d.m < 1 || d.n < 1) return false;
-    if ((d.lda & 7) || (d.ldb & 7) || (d.stride_a & 7) || (d.stride_b & 7)) return false;
+    if ((d.lda & amask) || (d.ldb & amask) || (d.stride_a & amask) || (d.stride_b & amask)) return false;
     if ((reinterpret_cast<uintptr_t>(a) & 15u) || (reinterpret_cast<uintptr_t>(b) & 15u)) return false;
     if (d.batch > 65535) return false;
     const int64_t tiles = ((d.m + BM - 1) / BM) * ((d.n + BN - 1) / BN);
     if (tiles * std::max<int64_t>(d.batch, 1) > 0x7FFFFFFF) return false;   // 32-bit (batch, tile) sequence for the XCD remap
-    if ((int64_t)BM * std::max(d.lda, d.ldb) * 2 >= (1ll << 32)) return false;   // per-lane DMA offsets are 32-bit
+    if ((int64_t)BM * std::max(d.lda, d.ldb) * esz >= (1ll << 32)) return false;   // per-lane DMA offsets are 32-bit
     return true;
 }
 
@@ -324,14 +367,16 @@ int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
     // every slice writes an f32 partial slab, a small kernel folds the slabs in slice order (deterministic) and
     // converts.  The slab traffic (2 x splits x M x N x 4 B) must stay small against the operand stream.
     const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * batch;
-    const int64_t nk = d.k / BK;
+    const bool f8 = is_fp8(d.dtype_ab);
+    const int64_t esz = f8 ? 1 : 2;
+    const int64_t nk = d.k / (ROW_BYTES / esz);
     const int64_t want = 2 * (int64_t)ctx->props.num_streaming_multiprocessors;
     if (tiles < want / 2 && nk >= 8 && batch <= 65535) {
         int64_t splits = std::min<int64_t>({(want + tiles - 1) / tiles, nk / 4, 32});
         const int64_t per = (nk + splits - 1) / splits;
         splits = (nk + per - 1) / per;                                      // no empty slices
         const int64_t slab = d.batch * d.m * d.n;
-        const int64_t operand_bytes = (d.m * d.k + d.n * d.k) * 2 * d.batch;
+        const int64_t operand_bytes = (d.m * d.k + d.n * d.k) * esz * d.batch;
         float *ws = nullptr;
         if (splits > 1 && splits * slab * 8 <= 2 * operand_bytes &&
             splitk_scratch(ctx, s, (size_t)(splits * slab) * sizeof(float), &ws) == MI355_OK) {
@@ -339,14 +384,22 @@ int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
             gs.c = ws; gs.ldc = d.n; gs.stride_c = d.m * d.n;
             gs.split_k = (uint32_t)splits; gs.split_c_stride = slab;
             if (d.dtype_ab == MI355_DTYPE_BF16) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, gs, batch, 48);
-            else launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(ctx, s, gs, batch, 50);
+            else if (d.dtype_ab == MI355_DTYPE_F16) launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(ctx, s, gs, batch, 50);
+            else if (d.dtype_ab == MI355_DTYPE_F8E4M3) launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_F32>(ctx, s, gs, batch, 52);
+            else launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_F32>(ctx, s, gs, batch, 54);
             check_launch(ctx, "mi355_gemm(lp128 split-K)");
             launch_splitk_fold(s, ws, (uint32_t)splits, slab, d.batch, d.m, d.n, c, d.dtype_c, d.ldc, d.stride_c);
             check_launch(ctx, "mi355_gemm(split-K fold)");
             return MI355_OK;
         }
     }
-    if (d.dtype_ab == MI355_DTYPE_BF16) {
+    if (d.dtype_ab == MI355_DTYPE_F8E4M3) {
+        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_F32>(ctx, s, g, batch, 52);
+        else launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_BF16>(ctx, s, g, batch, 53);
+    } else if (d.dtype_ab == MI355_DTYPE_F8E5M2) {
+        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_F32>(ctx, s, g, batch, 54);
+        else launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_BF16>(ctx, s, g, batch, 55);
+    } else if (d.dtype_ab == MI355_DTYPE_BF16) {
         if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, g, batch, 48);
         else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16>(ctx, s, g, batch, 49);
     } else {

@@ -566,8 +566,21 @@ def test_fp8_generic_kernel_is_bit_exact_against_the_f32_loop(client, oracle, dt
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (256, 512, 384), (512, 768, 1024), (300, 504, 256), (5, 4096, 512)])
 def test_fp8_mfma_parity(client, oracle, dtype, out, m, n, k):
     d = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=k, ldc=n, dtype_ab=int(dtype), dtype_c=int(out), trans_b=1)
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    # at most 128 tiles of 256^2: the 128x128 kernel (f32 / bf16 output), otherwise the 256x256 kernel
+    assert ops.gemm_select(client, d) == (N.GEMM_ALGO_LP_256W4 if out == ElemType.F16 else N.GEMM_ALGO_LP_128)
     run_case(client, oracle, m, n, k, dtype, out, True, N.GEMM_ALGO_AUTO)
+    run_case(client, oracle, m, n, k, dtype, out, True, N.GEMM_ALGO_LP_256W4)
+
+
+@pytest.mark.parametrize("dtype", F8)
+@pytest.mark.parametrize("m,n,k,batch", [(128, 128, 128, 1), (128, 256, 256, 1), (384, 128, 1152, 1), (200, 333, 640, 1), (64, 8192, 4096, 1),
+                                         (2048, 2048, 1024, 1), (256, 256, 512, 5), (3072, 3072, 512, 1)])
+def test_fp8_128x128_kernel_every_pipeline_form(client, oracle, dtype, m, n, k, batch):
+    """1, 2, 9, 5 ... K-tiles through the 2-stage and the 4-stage ring, ragged edges, the split-K slabs, batches."""
+    out = ElemType.BF16 if (m + n) % 3 else ElemType.F32
+    run_case(client, oracle, m, n, k, dtype, out, True, N.GEMM_ALGO_LP_128, batch=batch)
+    d = N.GemmDesc(m=3072, n=3072, k=512, batch=1, lda=512, ldb=512, ldc=3072, dtype_ab=int(dtype), dtype_c=N.DTYPE_BF16, trans_b=1)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4                  # 144 tiles of 256^2
 
 
 def test_fp8_identity_returns_operand_values_and_batches(client, oracle):
@@ -590,7 +603,7 @@ def test_fp8_identity_returns_operand_values_and_batches(client, oracle):
 def test_fp8_other_layouts_go_through_relayout_or_generic(client, oracle, dtype):
     # row-major B, ragged K, padded / unaligned rows, transposed A: re-laid out into scratch, then the MFMA kernel
     d = N.GemmDesc(m=512, n=512, k=512, batch=1, lda=512, ldb=512, ldc=512, dtype_ab=int(dtype), dtype_c=N.DTYPE_F32, trans_b=0)
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_128                   # an MFMA kernel after the transpose (4 tiles: the 128x128 one)
     run_case(client, oracle, 512, 512, 512, dtype, ElemType.F32, False, N.GEMM_ALGO_AUTO)
     run_case(client, oracle, 300, 260, 200, dtype, ElemType.F32, True, N.GEMM_ALGO_AUTO)             # ragged K
     run_case(client, oracle, 256, 256, 256, dtype, ElemType.BF16, True, N.GEMM_ALGO_AUTO, lda=259, ldb=263, ldc=272)
