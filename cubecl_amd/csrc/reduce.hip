@@ -455,11 +455,12 @@ reduce_rows(const typename red_in<DT>::elem *__restrict__ in, float *__restrict_
 // each thread folds `reduce` values sequentially (the book's per-unit loop, v4-gpu.rs:47-54, along a strided axis),
 // split into RSPLIT interleaved partial chains when `reduce` is long and outer*inner is too small to fill the chip;
 // the chains are folded in order through LDS.  Roofline: HBM, 4 bytes per input element read once.
-template <bool ARG, int RSPLIT>
+template <bool ARG, int RSPLIT, int DT = MI355_DTYPE_F32>
 __global__ void __launch_bounds__(256)
-reduce_mid_axis(const float *__restrict__ in, float *__restrict__ out_sum, uint32_t *__restrict__ out_idx, uint64_t outer,
+reduce_mid_axis(const typename red_in<DT>::elem *__restrict__ in, float *__restrict__ out_sum, uint32_t *__restrict__ out_idx, uint64_t outer,
                 uint64_t red, uint64_t inner)
 {
+    typedef red_in<DT> RI;
     constexpr int IW = 256 / RSPLIT;                       // inner positions per workgroup
     const uint32_t tid = threadIdx.x, il = tid % IW, rs = tid / IW;
     const uint64_t blocks_i = (inner + IW - 1) / IW;
@@ -471,9 +472,9 @@ reduce_mid_axis(const float *__restrict__ in, float *__restrict__ out_sum, uint3
         float acc = 0.f;
         uint32_t key = 0u, idx = 0u;
         if (i < inner) {
-            const float *p = in + (o * red) * inner + i;
+            const typename RI::elem *p = in + (o * red) * inner + i;
             for (uint64_t r = rs; r < red; r += RSPLIT) {
-                const float v = p[r * inner];
+                const float v = RI::widen(p[r * inner]);
                 if (!ARG) acc += v;
                 else { const uint32_t k = argmax_key(v); if (k > key) { key = k; idx = (uint32_t)r; } }
             }
@@ -499,8 +500,8 @@ reduce_mid_axis(const float *__restrict__ in, float *__restrict__ out_sum, uint3
     }
 }
 
-template <bool ARG>
-int32_t run_mid(mi355_ctx *ctx, mi355_stream stream, const float *in, float *out_sum, uint32_t *out_idx, uint64_t outer,
+template <bool ARG, int DT = MI355_DTYPE_F32>
+int32_t run_mid(mi355_ctx *ctx, mi355_stream stream, const typename red_in<DT>::elem *in, float *out_sum, uint32_t *out_idx, uint64_t outer,
                 uint64_t red, uint64_t inner, const char *what)
 {
     MI355_REQUIRE_CTX(ctx);
@@ -515,7 +516,7 @@ int32_t run_mid(mi355_ctx *ctx, mi355_stream stream, const float *in, float *out
     do {                                                                                                                \
         const uint64_t blocks = outer * ((inner + 256 / R - 1) / (256 / R));                                            \
         const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, cus * 16));                    \
-        hipLaunchKernelGGL((reduce_mid_axis<ARG, R>), dim3(grid), dim3(256), 0, s, in, out_sum, out_idx, outer, red, inner); \
+        hipLaunchKernelGGL((reduce_mid_axis<ARG, R, DT>), dim3(grid), dim3(256), 0, s, in, out_sum, out_idx, outer, red, inner); \
     } while (0)
     if (split) MID(8); else MID(1);
 #undef MID
@@ -700,6 +701,40 @@ MI355_API int32_t mi355_reduce_axis_argmax_f32(mi355_ctx *ctx, mi355_stream stre
 {
     if (inner == 1) return run_rows<true>(ctx, stream, in, nullptr, out_idx, outer, reduce, reduce, "mi355_reduce_axis_argmax_f32");
     return run_mid<true>(ctx, stream, in, nullptr, out_idx, outer, reduce, inner, "mi355_reduce_axis_argmax_f32");
+}
+
+// any-axis reductions of f32 / bf16 / f16 input (f32 arithmetic)
+template <bool ARG, int DT>
+static int32_t axis_dispatch(mi355_ctx *ctx, mi355_stream stream, const void *in, float *out, uint32_t *out_idx, uint64_t outer,
+                             uint64_t reduce, uint64_t inner, const char *what)
+{
+    typedef typename red_in<DT>::elem elem;
+    if (inner == 1) return run_rows<ARG, DT>(ctx, stream, static_cast<const elem *>(in), out, out_idx, outer, reduce, reduce, what);
+    return run_mid<ARG, DT>(ctx, stream, static_cast<const elem *>(in), out, out_idx, outer, reduce, inner, what);
+}
+
+MI355_API int32_t mi355_reduce_axis_sum(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, float *out,
+                                        uint64_t outer, uint64_t reduce, uint64_t inner)
+{
+    if (!ctx) return MI355_E_INVALID_ARGUMENT;
+    switch (dtype) {
+    case MI355_DTYPE_F32: return axis_dispatch<false, MI355_DTYPE_F32>(ctx, stream, in, out, nullptr, outer, reduce, inner, "mi355_reduce_axis_sum");
+    case MI355_DTYPE_BF16: return axis_dispatch<false, MI355_DTYPE_BF16>(ctx, stream, in, out, nullptr, outer, reduce, inner, "mi355_reduce_axis_sum");
+    case MI355_DTYPE_F16: return axis_dispatch<false, MI355_DTYPE_F16>(ctx, stream, in, out, nullptr, outer, reduce, inner, "mi355_reduce_axis_sum");
+    default: return fail(ctx, MI355_E_UNSUPPORTED, "mi355_reduce_axis_sum: input dtype %d (f32, bf16 or f16)", dtype);
+    }
+}
+
+MI355_API int32_t mi355_reduce_axis_argmax(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, uint32_t *out_idx,
+                                           uint64_t outer, uint64_t reduce, uint64_t inner)
+{
+    if (!ctx) return MI355_E_INVALID_ARGUMENT;
+    switch (dtype) {
+    case MI355_DTYPE_F32: return axis_dispatch<true, MI355_DTYPE_F32>(ctx, stream, in, nullptr, out_idx, outer, reduce, inner, "mi355_reduce_axis_argmax");
+    case MI355_DTYPE_BF16: return axis_dispatch<true, MI355_DTYPE_BF16>(ctx, stream, in, nullptr, out_idx, outer, reduce, inner, "mi355_reduce_axis_argmax");
+    case MI355_DTYPE_F16: return axis_dispatch<true, MI355_DTYPE_F16>(ctx, stream, in, nullptr, out_idx, outer, reduce, inner, "mi355_reduce_axis_argmax");
+    default: return fail(ctx, MI355_E_UNSUPPORTED, "mi355_reduce_axis_argmax: input dtype %d (f32, bf16 or f16)", dtype);
+    }
 }
 
 MI355_API int32_t mi355_plane_reduce_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, float *out, uint64_t n,

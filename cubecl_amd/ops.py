@@ -227,8 +227,8 @@ def argmax_last_axis(client: ComputeClient, input: TensorHandle, output: TensorH
 
 
 def _axis_view(t: TensorHandle, axis: int, what: str):
-    if t.dtype != ElemType.F32:
-        raise ServerError(N.E_UNSUPPORTED, f"{what}: only f32 input is implemented")
+    if t.dtype not in (ElemType.F32, ElemType.BF16, ElemType.F16):
+        raise ServerError(N.E_UNSUPPORTED, f"{what}: input must be f32, bf16 or f16")
     if not t.is_contiguous():
         raise ServerError(N.E_UNSUPPORTED_STRIDES, f"{what}: input must be contiguous")
     rank = t.rank()
@@ -246,15 +246,15 @@ def _axis_view(t: TensorHandle, axis: int, what: str):
 def reduce_sum_axis(client: ComputeClient, input: TensorHandle, output: TensorHandle, axis: int) -> None:
     """Sum over one axis: output shape = input shape minus that axis (any axis, contiguous input)."""
     outer, red, inner = _axis_view(input, axis, "reduce_sum_axis")
-    client._s.check(client.lib.mi355_reduce_axis_sum_f32(client.ctx, client.stream, C.c_void_p(input.device_ptr()),
-                                                         C.c_void_p(output.device_ptr()), outer, red, inner))
+    client._s.check(client.lib.mi355_reduce_axis_sum(client.ctx, client.stream, C.c_void_p(input.device_ptr()), int(input.dtype),
+                                                     C.c_void_p(output.device_ptr()), outer, red, inner))
 
 
 def argmax_axis(client: ComputeClient, input: TensorHandle, output: TensorHandle, axis: int) -> None:
     """Argmax over one axis (u32 indices along that axis; lowest index wins ties, NaN ranks highest)."""
     outer, red, inner = _axis_view(input, axis, "argmax_axis")
-    client._s.check(client.lib.mi355_reduce_axis_argmax_f32(client.ctx, client.stream, C.c_void_p(input.device_ptr()),
-                                                            C.c_void_p(output.device_ptr()), outer, red, inner))
+    client._s.check(client.lib.mi355_reduce_axis_argmax(client.ctx, client.stream, C.c_void_p(input.device_ptr()), int(input.dtype),
+                                                        C.c_void_p(output.device_ptr()), outer, red, inner))
 
 
 def plane_reduce(client: ComputeClient, input: TensorHandle, output: TensorHandle, op: int, active: int = 64) -> None:

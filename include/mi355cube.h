@@ -425,6 +425,11 @@ int32_t mi355_reduce_axis_sum_f32(mi355_ctx *ctx, mi355_stream stream, const flo
                                   uint64_t outer, uint64_t reduce, uint64_t inner);
 int32_t mi355_reduce_axis_argmax_f32(mi355_ctx *ctx, mi355_stream stream, const float *in,
                                      uint32_t *out_idx, uint64_t outer, uint64_t reduce, uint64_t inner);
+/* ... and for f32 / bf16 / f16 input (`dtype`) */
+int32_t mi355_reduce_axis_sum(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, float *out,
+                              uint64_t outer, uint64_t reduce, uint64_t inner);
+int32_t mi355_reduce_axis_argmax(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype,
+                                 uint32_t *out_idx, uint64_t outer, uint64_t reduce, uint64_t inner);
 /* plane_sum & friends for one 64-lane plane per 64 inputs (frontend/plane.rs:218-240): every
  * lane receives the butterfly result over the first `active` lanes (power of two <= 64),
  * matching plane_dim_checked = min(PLANE_DIM, CUBE_DIM) (shared/plane.rs:55-58).

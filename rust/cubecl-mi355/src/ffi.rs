@@ -262,6 +262,10 @@ unsafe extern "C" {
                                       rows: u64, cols: u64, row_stride: u64) -> i32;
     pub fn mi355_reduce_last_axis_argmax(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const c_void, dtype: i32, out_idx: *mut u32,
                                          rows: u64, cols: u64, row_stride: u64) -> i32;
+    pub fn mi355_reduce_axis_sum(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const c_void, dtype: i32, out: *mut f32,
+                                 outer: u64, reduce: u64, inner: u64) -> i32;
+    pub fn mi355_reduce_axis_argmax(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const c_void, dtype: i32, out_idx: *mut u32,
+                                    outer: u64, reduce: u64, inner: u64) -> i32;
     // reductions over any axis, plane ops
     pub fn mi355_reduce_axis_sum_f32(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const f32, out: *mut f32, outer: u64,
                                      reduce: u64, inner: u64) -> i32;

@@ -320,3 +320,24 @@ def test_last_axis_reductions_16bit(client, oracle, dtype, shape):
     oi = TensorHandle.new_contiguous(shape[:-1], client.empty(rows * 4), ElemType.U32)
     ops.argmax_last_axis(client, t, oi)
     assert np.array_equal(oi.to_numpy(client), oracle.reduce_last_axis_argmax(x))
+
+
+@pytest.mark.parametrize("dtype", [ElemType.BF16, ElemType.F16])
+@pytest.mark.parametrize("shape,axis", [((64, 256, 1024), 1), ((64, 256, 1024), 0), ((512, 8192), 0), ((3, 1000, 7), 1), ((1, 5, 1), 1),
+                                        ((2048, 33), 0), ((4, 100000, 3), 1), ((64, 256, 1024), 2), ((5, 4, 3, 2), 2)])
+def test_reductions_over_any_axis_16bit(client, oracle, dtype, shape, axis):
+    conv, back = (oracle.to_bf16, oracle.from_bf16) if dtype == ElemType.BF16 else (oracle.to_f16, oracle.from_f16)
+    n = int(np.prod(shape))
+    bits = conv(oracle.fill_uniform(n, 52, -1.0, 1.0)).reshape(shape)
+    x = back(bits).reshape(shape)
+    t = TensorHandle.from_numpy(client, bits, dtype)
+    out_shape = tuple(d for i, d in enumerate(shape) if i != axis % len(shape))
+    m = int(np.prod(out_shape)) if out_shape else 1
+    s = TensorHandle.new_contiguous(out_shape or (1,), client.empty(max(m, 1) * 4), ElemType.F32)
+    ops.reduce_sum_axis(client, t, s, axis)
+    ref = oracle.reduce_axis_sum(x, axis)
+    bound = np.abs(x).astype(np.float64).sum(axis=axis)
+    assert np.all(np.abs(s.to_numpy(client).reshape(ref.shape).astype(np.float64) - ref) <= REL * bound + 1e-30)
+    a = TensorHandle.new_contiguous(out_shape or (1,), client.empty(max(m, 1) * 4), ElemType.U32)
+    ops.argmax_axis(client, t, a, axis)
+    assert np.array_equal(a.to_numpy(client).reshape(ref.shape), oracle.reduce_axis_argmax(x, axis))
