@@ -332,7 +332,7 @@ bool gemm_lp128_supports(const mi355_gemm_desc &d, const void *a, const void *b,
     const bool f8 = is_fp8(d.dtype_ab);
     if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16 && !f8) return false;
     if (f8) {
-        if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != MI355_DTYPE_BF16) return false;
+        if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != MI355_DTYPE_BF16 && d.dtype_c != MI355_DTYPE_F16) return false;
     } else if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != d.dtype_ab) return false;
     if (d.trans_a || !d.trans_b) return false;
     const int64_t esz = f8 ? 1 : 2, BK = ROW_BYTES / esz, amask = 16 / esz - 1;
@@ -395,10 +395,12 @@ int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
     }
     if (d.dtype_ab == MI355_DTYPE_F8E4M3) {
         if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_F32>(ctx, s, g, batch, 52);
-        else launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_BF16>(ctx, s, g, batch, 53);
+        else if (d.dtype_c == MI355_DTYPE_BF16) launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_BF16>(ctx, s, g, batch, 53);
+        else launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_F16>(ctx, s, g, batch, 56);
     } else if (d.dtype_ab == MI355_DTYPE_F8E5M2) {
         if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_F32>(ctx, s, g, batch, 54);
-        else launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_BF16>(ctx, s, g, batch, 55);
+        else if (d.dtype_c == MI355_DTYPE_BF16) launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_BF16>(ctx, s, g, batch, 55);
+        else launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_F16>(ctx, s, g, batch, 57);
     } else if (d.dtype_ab == MI355_DTYPE_BF16) {
         if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, g, batch, 48);
         else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16>(ctx, s, g, batch, 49);

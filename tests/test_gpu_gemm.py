@@ -566,8 +566,7 @@ def test_fp8_generic_kernel_is_bit_exact_against_the_f32_loop(client, oracle, dt
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (256, 512, 384), (512, 768, 1024), (300, 504, 256), (5, 4096, 512)])
 def test_fp8_mfma_parity(client, oracle, dtype, out, m, n, k):
     d = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=k, ldc=n, dtype_ab=int(dtype), dtype_c=int(out), trans_b=1)
-    # at most 128 tiles of 256^2: the 128x128 kernel (f32 / bf16 output), otherwise the 256x256 kernel
-    assert ops.gemm_select(client, d) == (N.GEMM_ALGO_LP_256W4 if out == ElemType.F16 else N.GEMM_ALGO_LP_128)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_128                    # at most 128 tiles of 256^2: the 128x128 kernel
     run_case(client, oracle, m, n, k, dtype, out, True, N.GEMM_ALGO_AUTO)
     run_case(client, oracle, m, n, k, dtype, out, True, N.GEMM_ALGO_LP_256W4)
 
