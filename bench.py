@@ -97,6 +97,30 @@ def samples_op(client, ev, fn, samples=15, warmup=5):
     return out[len(out) // 2], out[0]
 
 
+HUNG = []          # names of watchdogged sections that did not return (see run_with_watchdog)
+
+
+def run_with_watchdog(fn, seconds):
+    """Runs fn() in a helper thread; returns None on success, else a short error string.  ctypes and torch release the GIL
+    inside their calls, so a collective that never completes leaves this thread free to give up on it."""
+    import threading
+    box = {}
+
+    def body():
+        try:
+            fn()
+            box["ok"] = True
+        except Exception as exc:  # noqa: BLE001
+            box["err"] = f"{type(exc).__name__}: {exc}"[:300]
+    t = threading.Thread(target=body, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        HUNG.append(getattr(fn, "__name__", "section"))
+        return f"no completion within {seconds:.0f} s"
+    return box.get("err")
+
+
 def pmc_traffic(size, algo):
     """HBM bytes per launch of the headline kernel from the committed rocprofv3 PMC passes
     (profiles/pmc_traffic.json, written by tools/pmc_traffic.sh: separate --pmc passes for FETCH_SIZE
@@ -129,10 +153,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); none visible")
+    # Rehearsal hooks (single-GPU pod only, never set by the driver): BENCH_FORCE_DEVICE puts every rank on one device and
+    # BENCH_DIST_BACKEND=gloo replaces RCCL for torch's own collectives, so that the N > 1 control flow of this file can be
+    # exercised where only one GPU exists (the RCCL exchange of the extras then fails cleanly: two ranks on one device).
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if "BENCH_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     from cubecl_amd import DeviceId, ElemType, Mi355Runtime, TensorHandle, ops
     from cubecl_amd import _native as N
@@ -144,7 +177,10 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if backend == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
 
     # ------------------------------------------------------------------ headline: C3 ------------------
     S = args.size
@@ -343,49 +379,56 @@ def main():
                                "frac": res["sum"]["frac_of_8TBs"], "traffic": tr if world == 1 else None,
                                "algorithmic_bytes_per_launch": n_local * 4}
             if world > 1:
-                # C4 end to end (cubecl_amd/sharded.py): local fused pass over this rank's slice, then the
-                # exchange step -- RCCL all-reduce of the f32 partial sums (ServerCommunication::all_reduce)
-                # and an all-gather of the (max value, index) records; every rank runs the same combine.
-                from cubecl_amd import sharded
-                ids = [DeviceId(0, i) for i in range(world)]
-                box = [client.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                client.comm_init(ids, box[0], rank=rank)
-                from cubecl_amd import ReduceOperation
-                start, count = sharded.shard_aligned_range(n_total, rank, world, 4)
-                assert count == n_local
-                part = outs.offset_end_by(outs.size - 4)                           # f32 partial sum, reduced in place
-                rec = outs.offset_start_by(8).offset_end_by(outs.size - 24)       # {f32 value, pad, u64 local index}
-                gathered = client.empty(16 * world)
+                def exchange():
+                    # C4 end to end (cubecl_amd/sharded.py): local fused pass over this rank's slice, then the
+                    # exchange step -- RCCL all-reduce of the f32 partial sums (ServerCommunication::all_reduce)
+                    # and an all-gather of the (max value, index) records; every rank runs the same combine.
+                    from cubecl_amd import sharded
+                    ids = [DeviceId(0, i) for i in range(world)]
+                    box = [client.comm_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(box, src=0)
+                    client.comm_init(ids, box[0], rank=rank)
+                    from cubecl_amd import ReduceOperation
+                    start, count = sharded.shard_aligned_range(n_total, rank, world, 4)
+                    assert count == n_local
+                    part = outs.offset_end_by(outs.size - 4)                           # f32 partial sum, reduced in place
+                    rec = outs.offset_start_by(8).offset_end_by(outs.size - 24)       # {f32 value, pad, u64 local index}
+                    gathered = client.empty(16 * world)
 
-                def e2e():
-                    client._s.check(lib.mi355_sum_argmax_f32(ctx, None, p_in, n_local, p_sum, p_val, p_idx, p_ws, ws.size))
-                    client.all_reduce(part, part, ElemType.F32, ids, ReduceOperation.Sum)
-                    client.all_gather(rec, gathered, ElemType.U64, ids)
-                    client.sync_collective()
-                for _ in range(3):
-                    e2e()
-                client.sync(); barrier(); torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(20):
-                    e2e()
-                client.sync(); torch.cuda.synchronize(); barrier()
-                dt = (time.perf_counter() - t1) / 20
-                tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                import numpy as np
-                raw = np.frombuffer(client.read_one(gathered), dtype=np.uint8).reshape(world, 16)
-                pairs = []
-                for r in range(world):
-                    v = float(raw[r, 0:4].copy().view(np.float32)[0])
-                    i = int(raw[r, 8:16].copy().view(np.uint64)[0])
-                    pairs.append((v, sharded.shard_aligned_range(n_total, r, world, 4)[0] + i))
-                gval, gidx = sharded.combine_argmax(pairs)
-                gsum = float(np.frombuffer(client.read_one(part), dtype=np.float32)[0])
-                res["sharded_sum_argmax_exchange"] = {"ms": round(float(tt[0]) * 1e3, 4),
-                                                      "GBs_total": round(n_total * 4 / float(tt[0]) / 1e9, 1),
-                                                      "sum": gsum, "argmax_index": gidx, "argmax_value": gval,
-                                                      "exchange": "RCCL all-reduce (1 x f32) + all-gather (16 B per rank)"}
+                    def e2e():
+                        client._s.check(lib.mi355_sum_argmax_f32(ctx, None, p_in, n_local, p_sum, p_val, p_idx, p_ws, ws.size))
+                        client.all_reduce(part, part, ElemType.F32, ids, ReduceOperation.Sum)
+                        client.all_gather(rec, gathered, ElemType.U64, ids)
+                        client.sync_collective()
+                    for _ in range(3):
+                        e2e()
+                    client.sync(); barrier(); torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(20):
+                        e2e()
+                    client.sync(); torch.cuda.synchronize(); barrier()
+                    dt = (time.perf_counter() - t1) / 20
+                    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    import numpy as np
+                    raw = np.frombuffer(client.read_one(gathered), dtype=np.uint8).reshape(world, 16)
+                    pairs = []
+                    for r in range(world):
+                        v = float(raw[r, 0:4].copy().view(np.float32)[0])
+                        i = int(raw[r, 8:16].copy().view(np.uint64)[0])
+                        pairs.append((v, sharded.shard_aligned_range(n_total, r, world, 4)[0] + i))
+                    gval, gidx = sharded.combine_argmax(pairs)
+                    gsum = float(np.frombuffer(client.read_one(part), dtype=np.float32)[0])
+                    res["sharded_sum_argmax_exchange"] = {"ms": round(float(tt[0]) * 1e3, 4),
+                                                          "GBs_total": round(n_total * 4 / float(tt[0]) / 1e9, 1),
+                                                          "sum": gsum, "argmax_index": gidx, "argmax_value": gval,
+                                                          "exchange": "RCCL all-reduce (1 x f32) + all-gather (16 B per rank)"}
+                # The exchange cannot be rehearsed on the single-GPU pod: never let it take the headline line down with
+                # it.  It runs under a watchdog; a rank that does not come back within the limit reports so and the
+                # process leaves through os._exit after printing (a hung collective cannot be cancelled).
+                outcome = run_with_watchdog(exchange, 180.0)
+                if outcome is not None:
+                    res["sharded_sum_argmax_exchange"] = {"error": outcome}
             return res
         guarded("reduce_1GiB_f32", reduce_c4)
 
@@ -522,8 +565,12 @@ def main():
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
-        dist.destroy_process_group()
+        def farewell():
+            barrier()
+            dist.destroy_process_group()
+        if HUNG or run_with_watchdog(farewell, 60.0) is not None or HUNG:
+            sys.stdout.flush()
+            os._exit(0)          # a collective is stuck somewhere: the line is out, leave without waiting for it
 
 
 if __name__ == "__main__":
