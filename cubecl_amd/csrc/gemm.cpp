@@ -252,6 +252,18 @@ MI355_API int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_ge
     }
 }
 
+// Introspection (no device needed): how mi355_gemm would cut a descriptor that AUTO resolves to the 256x256 kernel.
+MI355_API int32_t mi355_gemm_tail_plan(const mi355_gemm_desc *desc, int32_t *out_along_m, int64_t *out_main_extent, int32_t *out_splits)
+{
+    if (!desc || !out_along_m || !out_main_extent || !out_splits) return MI355_E_INVALID_ARGUMENT;
+    tail_plan tp{};
+    const bool split = plan_tail_split(*desc, tp);
+    *out_along_m = split ? (tp.along_m ? 1 : 0) : 0;
+    *out_main_extent = split ? tp.main_extent : 0;
+    *out_splits = split ? (int32_t)tp.splits : 1;
+    return MI355_OK;
+}
+
 MI355_API int32_t mi355_gemm_select(mi355_ctx *ctx, const mi355_gemm_desc *desc, int32_t *out_algo)
 {
     if (!ctx || !desc || !out_algo) return MI355_E_INVALID_ARGUMENT;

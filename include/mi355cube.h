@@ -342,6 +342,12 @@ int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_gemm_desc *d
                    const void *a, const void *b, void *c);
 /* which kernel AUTO resolves to for a descriptor (for tests / logs) */
 int32_t mi355_gemm_select(mi355_ctx *ctx, const mi355_gemm_desc *desc, int32_t *out_algo);
+/* How a descriptor that resolves to the 256x256 kernel is cut when its last round of tiles is only partly filled (pure
+ * function, no device): *out_splits == 1 -> one plain launch; otherwise rows (out_along_m = 1) or columns
+ * [0, *out_main_extent) of C go to a plain launch and the remaining strip is computed with K split *out_splits ways
+ * (one batched launch + the deterministic slab fold). */
+int32_t mi355_gemm_tail_plan(const mi355_gemm_desc *desc, int32_t *out_along_m, int64_t *out_main_extent,
+                             int32_t *out_splits);
 
 /* Block-scaled matmul (MX formats): C[b] = (A[b] .* SA[b]) * (B[b] .* SB[b])^T, f32 accumulate -- the operation
  * `MmaDefinition::execute_scaled` defines per fragment (crates/cubecl-core/src/frontend/cmma.rs:795-840), semantics

@@ -114,3 +114,39 @@ def test_roofline_time_limit_is_the_slower_bound_plus_a_launch():
     b = Bounds(2.5e15, 8e12, 2e-6, Work(10, 1 << 30), Thresholds(0.5, 0.8))
     assert abs(b.time_limit() - ((1 << 30) / 8e12 / 0.8 + 2e-6)) < 1e-12             # memory bound
     assert Bounds(1.0, 1.0, 0.0, w, Thresholds(0.0, float("nan"))).time_limit() is None
+
+
+# ---- the GEMM dispatcher's last-round planner (pure host logic inside libmi355cube.so; no device needed) -----------------
+def _tail_plan(m, n, k, dtype=None, batch=1, **kw):
+    import ctypes as C
+    from cubecl_amd import _native as N
+    lib = N.load()
+    fields = dict(m=m, n=n, k=k, batch=batch, lda=k, ldb=k, ldc=n, dtype_ab=N.DTYPE_BF16 if dtype is None else dtype,
+                  dtype_c=N.DTYPE_BF16, trans_b=1)
+    fields.update(kw)
+    d = N.GemmDesc(**fields)
+    along, extent, splits = C.c_int32(), C.c_int64(), C.c_int32()
+    assert lib.mi355_gemm_tail_plan(C.byref(d), C.byref(along), C.byref(extent), C.byref(splits)) == N.OK
+    return along.value, extent.value, splits.value
+
+
+def test_tail_plan_splits_only_small_leftover_rounds():
+    from cubecl_amd import _native as N
+    # whole rounds, or a leftover of half a round and more: one plain launch
+    for shape in ((8192, 8192, 8192), (4096, 4096, 4096), (4096, 6144, 4096), (5120, 5120, 5120), (9216, 8192, 4096)):
+        assert _tail_plan(*shape)[2] == 1, shape
+    # 576 tiles = 2.25 rounds: a strip of tile rows, K split so that strip tiles x splits <= 256
+    along, extent, splits = _tail_plan(6144, 6144, 6144)
+    strip_tiles = (6144 - extent) // 256 * 24
+    assert splits > 1 and along == 1 and extent % 256 == 0 and 0 < strip_tiles <= 96 and strip_tiles * splits <= 256
+    assert (6144 // 64) % splits == 0                                  # whole K-tiles per slice
+    # 20 x 13 tiles (ragged M, 4 tiles more than one round): the plain launch keeps at most one round, the strip the rest
+    along, extent, splits = _tail_plan(5000, 3328, 2048)
+    tiles_main = (extent // 256) * (13 if along else 20)
+    assert splits > 1 and extent % 256 == 0 and 0 < tiles_main <= 256 and (20 * 13 - tiles_main) * splits <= 256
+    assert (2048 // 64) % splits == 0
+    # fp8 counts K-tiles of 128, f32 of 32; batches and non-K-contiguous operands are never split
+    assert _tail_plan(4608, 4096, 8192, dtype=N.DTYPE_F8E4M3)[2] > 1
+    assert _tail_plan(4608, 4096, 8192, batch=2)[2] == 1
+    assert _tail_plan(6144, 6144, 6144, trans_b=0)[2] == 1
+    assert _tail_plan(6144, 6144, 256)[2] == 1                          # too few K-tiles to split
