@@ -237,6 +237,7 @@ unsafe extern "C" {
                              a_scales: *const c_void, b: *const c_void, b_scales: *const c_void, c: *mut c_void) -> i32;
     pub fn mi355_gemm_scaled_select(ctx: *mut mi355_ctx, desc: *const mi355_gemm_scaled_desc, out_algo: *mut i32) -> i32;
     pub fn mi355_gemm_select(ctx: *mut mi355_ctx, desc: *const mi355_gemm_desc, out_algo: *mut i32) -> i32;
+    pub fn mi355_gemm_tail_plan(desc: *const mi355_gemm_desc, out_along_m: *mut i32, out_main_extent: *mut i64, out_splits: *mut i32) -> i32;
     // an alternative to MemoryManagement-over-Mi355Storage for hosts without the reference's pool (memory_manage.rs)
     pub fn mi355_pool_alloc(ctx: *mut mi355_ctx, stream: mi355_stream, bytes: u64, out_dptr: *mut *mut c_void) -> i32;
     pub fn mi355_pool_free(ctx: *mut mi355_ctx, stream: mi355_stream, dptr: *mut c_void) -> i32;
