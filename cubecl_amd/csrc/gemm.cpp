@@ -188,6 +188,26 @@ bool plan_tail_split(const mi355_gemm_desc &d, tail_plan &best)
     return found;
 }
 
+// Several rounds of short tiles: the persistent form (gemm_lp256p.hip) streams the next tile's operands during the epilogue
+// and lets the C stores drain under the next tile's MFMAs.  Measured against the one-tile-per-workgroup kernel,
+// interleaved (tools/dev/p_vs_w4.py): K = 512 +10 %, 1024 +4 %, 2048 +1...4 %, 4096 +1 %, 8192 a tie; single-round
+// launches -0.5...-2 %.  A leftover round that the strip split handles gains more from that and keeps the plain kernel.
+bool prefers_persistent(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
+{
+    if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16) return false;
+    const int64_t tiles = ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch, nk = d.k / 64;
+    if (tiles < 512 || nk > 64) return false;
+    if (!gemm_lp256p_supports(d, a, b, c)) return false;
+    tail_plan tp;
+    return !plan_tail_split(d, tp);
+}
+
+int32_t select_auto(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
+{
+    const int32_t algo = select(d, a, b, c);
+    return (algo == MI355_GEMM_ALGO_LP_256W4 && prefers_persistent(d, a, b, c)) ? MI355_GEMM_ALGO_LP_256P : algo;
+}
+
 int32_t run_tail_split(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c,
                        const tail_plan &p)
 {
@@ -228,13 +248,13 @@ MI355_API int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_ge
     if (rc != -1) return rc;
     hipStream_t s = stream_of(ctx, stream);
     mi355_gemm_desc d = *desc;
-    int32_t algo = d.algo == MI355_GEMM_ALGO_AUTO ? select(d, a, b, c) : d.algo;
+    int32_t algo = d.algo == MI355_GEMM_ALGO_AUTO ? select_auto(d, a, b, c) : d.algo;
     if (d.algo == MI355_GEMM_ALGO_AUTO && algo == MI355_GEMM_ALGO_GENERIC) {
         mi355_gemm_desc nd;
         const void *na, *nb;
         if (relayout_for_mfma(ctx, s, d, a, b, c, nd, na, nb) == MI355_OK) {
             d = nd; a = na; b = nb;
-            algo = select(d, a, b, c);
+            algo = select_auto(d, a, b, c);
         }
     }
     if (d.algo == MI355_GEMM_ALGO_AUTO && algo == MI355_GEMM_ALGO_LP_256W4) {
@@ -270,11 +290,11 @@ MI355_API int32_t mi355_gemm_select(mi355_ctx *ctx, const mi355_gemm_desc *desc,
     // alignment-dependent choices are evaluated for 16-byte aligned operands
     static const char aligned_dummy __attribute__((aligned(16))) = 0;
     const mi355_gemm_desc &d = *desc;
-    int32_t algo = select(d, &aligned_dummy, &aligned_dummy, &aligned_dummy);
+    int32_t algo = select_auto(d, &aligned_dummy, &aligned_dummy, &aligned_dummy);
     if (algo == MI355_GEMM_ALGO_GENERIC) {
         relayout_plan p;                  // what mi355_gemm does before it settles for the scalar kernel
         if (plan_relayout(d, &aligned_dummy, &aligned_dummy, &aligned_dummy, p))
-            algo = select(p.nd, &aligned_dummy, &aligned_dummy, &aligned_dummy);
+            algo = select_auto(p.nd, &aligned_dummy, &aligned_dummy, &aligned_dummy);
     }
     *out_algo = algo;
     return MI355_OK;

@@ -21,14 +21,15 @@
 //
 // Restrictions: as gemm_lp256w4.hip, plus K >= two K-tiles.
 //
-// STATUS (round 1): correct (bit-identical to gemm_lp256w4.hip per tile, tests/test_gpu_gemm.py) but NOT selected
-// by MI355_GEMM_ALGO_AUTO: measured steady state 8192^3 1 350 vs 1 383 TFLOP/s, 4096^3 1 241 vs 1 313, 8192x8192x1024
-// 979 vs 1 105, C5 shard 1 119 vs 1 124, f32 4096^3 146.6 vs 146.9.  GRBM cycles per launch (8192^3 / K = 1024):
-// 1 372k / 316k here vs 1 314k / 286k for the one-tile-per-workgroup kernel: the hidden fill/drain latency is worth
-// less than what the epilogue costs in this form (f32 staging in two half-lane passes because only 8 KiB of LDS per
-// wave are free at the boundary, accumulator re-zeroing, per-tile address setup), all of which sit in the one
-// instruction stream a SIMD has.  Kept as an explicit algo for the next round (interleaving block i's epilogue with
-// block i-1's first MFMAs of the next tile is the remaining idea).
+// STATUS (round 1): bit-identical to gemm_lp256w4.hip per tile (tests/test_gpu_gemm.py).  The first form was 2-11 % slower
+// than the one-tile-per-workgroup kernel (f32 staging in two half-lane passes, per-lane 64-bit DMA pointers); with the
+// scalar-base DMA addressing and, for 16-bit C, a staging image converted on the way into LDS (32 rows x 256 B = exactly the
+// wave's 8 KiB, chunk index XOR-ed with the row; accumulators read element by element through `v_accvgpr_read` asm, because
+// the compiler's bulk copy of all 256 accumulators spills inside the tile loop) it is now AHEAD whenever a launch has
+// several rounds of short tiles -- interleaved A/B (tools/dev/p_vs_w4.py): K = 512 +10 %, 1024 +4 %, 2048 +1...4 %
+// (config C5's shard 1 234-1 258 vs 1 202-1 211 TFLOP/s), 4096 +1 %, 8192 a tie, single-round launches -0.5...-2 %.
+// MI355_GEMM_ALGO_AUTO therefore takes it for 16-bit operands when there are >= 512 tiles and K <= 4096, unless the
+// strip split of a small leftover round applies (gemm.cpp).
 #include <algorithm>
 #include <type_traits>
 
@@ -82,6 +83,19 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
 {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
                                      (__attribute__((address_space(3))) void *)lds_dst, 16, 0, W4_DMA_AUX);
+}
+
+// LDS-DMA with a wave-uniform 64-bit base in SGPRs + a constant 32-bit per-lane offset (see gemm_lp256w4.hip: hipcc turns
+// per-lane pointers into one 64-bit vector add per piece in the K loop; worth 4 % there).
+template <int IMM>
+__device__ __forceinline__ void glds16_s(const void *ubase, uint32_t voff, uint32_t lds_byte_addr)
+{
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ubase), "s"(lds_byte_addr), "i"(IMM)
+                 : "memory", "scc");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void *p)
+{
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)p;
 }
 
 #ifndef W4_ABL
@@ -142,7 +156,9 @@ gemm_lp256p_kernel(gemm_args g)
     // lane -> (row = piece*8 + lane/8, physical chunk c = lane%8), source chunk = c ^ ((row>>1)&7); two per-lane
     // pointers per operand (j parity), the (j>>1) step is a wave-uniform byte offset.
     const int sub = lane >> 3, c8 = lane & 7;
-    struct tile_src { const char *a[2], *b[2], *bnn; int64_t m0, n0, batch; };
+    // per tile: wave-uniform bases (first row of the tile; scalar registers); per lane, once: the byte offsets of its 16
+    // bytes of every piece (full tiles only, so they do not depend on the tile)
+    struct tile_src { const char *ua, *ub, *ubnn; int64_t m0, n0, batch; };
     auto locate = [&](uint32_t L) {
         tile_src t;
         const uint32_t R = xcd_remap(L, total);
@@ -152,18 +168,20 @@ gemm_lp256p_kernel(gemm_args g)
         t.m0 = (int64_t)tm * BM; t.n0 = (int64_t)tn * BN; t.batch = bi;
         const char *A = static_cast<const char *>(g.a) + (int64_t)bi * g.stride_a * ESZ;
         const char *B = static_cast<const char *>(g.b) + (int64_t)bi * g.stride_b * ESZ;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int r = wave * 64 + p * 8 + sub;
-            const int q = c8 ^ ((r >> 1) & 7);
-            t.a[p] = A + (t.m0 + r) * g.lda * ESZ + q * 16;
-            t.b[p] = B + (t.n0 + r) * g.ldb * ESZ + q * 16;
-        }
-        t.bnn = B + (int64_t)(wave * 8) * g.ldb * ESZ + t.n0 * ESZ + lane * 16;
+        t.ua = A + t.m0 * g.lda * ESZ;
+        t.ub = B + t.n0 * g.ldb * ESZ;
+        t.ubnn = B + (int64_t)(wave * 8) * g.ldb * ESZ + t.n0 * ESZ;
         return t;
     };
-    const int64_t step_a = 16 * g.lda * ESZ, step_b = 16 * g.ldb * ESZ;   // bytes between pieces j and j+2
-    const int64_t step_bnn = g.ldb * ESZ;
+    uint32_t voff_a[8], voff_b[8], voff_bnn[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = wave * 64 + j * 8 + sub;
+        const int q = c8 ^ ((r >> 1) & 7);
+        voff_a[j] = (uint32_t)(r * g.lda * ESZ + q * 16);
+        voff_b[j] = (uint32_t)(r * g.ldb * ESZ + q * 16);
+        voff_bnn[j] = (uint32_t)(j * g.ldb * ESZ + lane * 16);
+    }
     const int dst_piece = wave * 8 * 1024;                            // + j*1024 within the slot
 
     // ---- fragment read offsets: row*128 + ((2s+h) ^ f) * 16, f = (row>>1)&7 = (l31>>1)&7 for every tile row
@@ -204,10 +222,10 @@ gemm_lp256p_kernel(gemm_args g)
     auto dma_one = [&](auto is_b, auto jj, int64_t koff, char *base) {
         constexpr int J = decltype(jj)::value;
         if constexpr (BNN && decltype(is_b)::value) {
-            glds16(iss.bnn + J * step_bnn + koff * g.ldb, base + J * 1024);   // a K-tile is 32 rows of ldb elements here
+            glds16_s<J * 1024>(iss.ubnn + koff * g.ldb, voff_bnn[J], lds_addr_of(base));   // a K-tile is 32 rows of ldb elements here
         } else {
-            const char *s = decltype(is_b)::value ? iss.b[J & 1] + (J >> 1) * step_b : iss.a[J & 1] + (J >> 1) * step_a;
-            glds16(s + koff, base + J * 1024);
+            glds16_s<J * 1024>((decltype(is_b)::value ? iss.ub : iss.ua) + koff, decltype(is_b)::value ? voff_b[J] : voff_a[J],
+                               lds_addr_of(base));
         }
     };
     auto mfma_one = [&](auto buf, auto idx) {
@@ -337,6 +355,49 @@ gemm_lp256p_kernel(gemm_args g)
             char *crow = C + (cbase + (cur.m0 + wm * 128 + lane / LPR) * g.ldc + cur.n0 + wn * 128) * CSZ + (lane % LPR) * 16;
             const int64_t cstep = (int64_t)RPI * g.ldc * CSZ;
             const int srow = l31 & 15, sx = swz(srow);
+#ifndef P_EPI16
+#define P_EPI16 1
+#endif
+            if constexpr (CSZ == 2 && P_EPI16) {
+                // 16-bit C: the block is converted on its way to LDS and staged as 32 rows x 256 B (exactly this wave's
+                // 8 KiB, no padding: the 16-byte chunk index is XOR-ed with the row instead), read back as whole rows:
+                // half the LDS traffic and instructions of the f32 staging below.
+                (void)srow; (void)sx;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            char *d = stage + l31 * 256 + (((j * 4 + q) ^ (l31 & 15)) << 4) + 8 * h;
+                            // explicit per-element accumulator reads: left to itself the compiler copies the whole 256-register
+                            // accumulator into VGPRs in one go at the loop exit, which spills inside this tile loop
+                            float x0, x1, x2, x3;
+                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x0) : "a"(acc[i][j][4 * q + 0]));
+                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x1) : "a"(acc[i][j][4 * q + 1]));
+                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x2) : "a"(acc[i][j][4 * q + 2]));
+                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x3) : "a"(acc[i][j][4 * q + 3]));
+                            if constexpr (DT_C == MI355_DTYPE_BF16) {
+                                bf16x4 v = {(__bf16)x0, (__bf16)x1, (__bf16)x2, (__bf16)x3};
+                                *reinterpret_cast<bf16x4 *>(d) = v;
+                            } else {
+                                f16x4 v = {(_Float16)x0, (_Float16)x1, (_Float16)x2, (_Float16)x3};
+                                *reinterpret_cast<f16x4 *>(d) = v;
+                            }
+                            if ((q & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // keep the accumulator reads from piling up in VGPRs
+                        }
+                    WAIT_LGKM0();                                  // same-wave hand-over: DS ops of one wave execute in order
+                    char *cdst = crow + (int64_t)(i * 32) * g.ldc * CSZ;
+#pragma unroll
+                    for (int it = 0; it < 32 / RPI; ++it) {
+                        const int r = it * RPI + lane / LPR;
+                        const u32x4 v = *reinterpret_cast<const u32x4 *>(stage + r * 256 + (((lane % LPR) ^ (r & 15)) << 4));
+                        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(cdst + it * cstep));
+                    }
+                    WAIT_LGKM0();                                  // staged rows are in registers before the next block overwrites them
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -433,6 +494,7 @@ bool gemm_lp256p_supports(const mi355_gemm_desc &d, const void *a, const void *b
     if ((reinterpret_cast<uintptr_t>(a) & 15u) || (reinterpret_cast<uintptr_t>(b) & 15u)) return false;
     const int64_t tiles = (d.m / BM) * (d.n / BN) * d.batch;
     if (tiles > 0x7FFFFFFF) return false;
+    if ((int64_t)BM * std::max(d.lda, d.ldb) * esz >= (1ll << 32)) return false;   // per-lane DMA offsets are 32-bit
     return true;
 }
 

@@ -494,6 +494,12 @@ def test_auto_selection_and_errors(client):
     d = N.GemmDesc(m=8192, n=8192, k=8192, batch=1, lda=8192, ldb=8192, ldc=8192, dtype_ab=N.DTYPE_BF16,
                    dtype_c=N.DTYPE_BF16, trans_b=1)
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    # several rounds of short tiles: the persistent form (config C5's shard: 64 x 2048^3); long K or a single round: not
+    d = N.GemmDesc(m=2048, n=2048, k=2048, batch=64, lda=2048, ldb=2048, ldc=2048, stride_a=2048 * 2048, stride_b=2048 * 2048,
+                   stride_c=2048 * 2048, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_BF16, trans_b=1)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256P
+    d.batch = 4
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
     d = N.GemmDesc(m=8192 + 8, n=8192, k=8192, batch=1, lda=8192, ldb=8192, ldc=8192, dtype_ab=N.DTYPE_BF16,
                    dtype_c=N.DTYPE_BF16, trans_b=1)
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4          # ragged M / N stay on the fast kernel
