@@ -57,7 +57,7 @@ class MmaConfig(C.Structure):
                 ("a_type", C.c_int32), ("b_type", C.c_int32), ("cd_type", C.c_int32)]
 
 
-ABI_VERSION = 2     # MI355_ABI_VERSION of include/mi355cube.h this table was written against
+ABI_VERSION = 3     # MI355_ABI_VERSION of include/mi355cube.h this table was written against
 
 
 class MemoryUsage(C.Structure):
@@ -107,6 +107,26 @@ class GemmScaledDesc(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("m", "n", "k", "batch", "lda", "ldb", "ldc", "ld_sa", "ld_sb", "stride_a", "stride_b",
                                          "stride_c", "stride_sa", "stride_sb")] + \
                [(n, C.c_int32) for n in ("dtype_a", "dtype_b", "dtype_c", "block", "algo", "reserved")]
+
+
+MAX_RANK = 8
+COPY_PATH_FLAT, COPY_PATH_ROWS, COPY_PATH_TRANSPOSE, COPY_PATH_GENERIC, COPY_PATH_TWO_SIDED = range(5)
+
+
+class TensorLayout(C.Structure):
+    """mi355_tensor_layout: shape / strides in elements, outermost axis first."""
+    _fields_ = [("rank", C.c_int32), ("reserved", C.c_int32), ("shape", C.c_int64 * MAX_RANK), ("strides", C.c_int64 * MAX_RANK)]
+
+    @staticmethod
+    def of(shape, strides) -> "TensorLayout":
+        shape, strides = list(shape) or [1], list(strides) or [1]
+        if len(shape) != len(strides) or len(shape) > MAX_RANK:
+            raise ValueError(f"layout of rank {len(shape)} / {len(strides)} (at most {MAX_RANK} axes)")
+        lay = TensorLayout()
+        lay.rank = len(shape)
+        for i, (a, b) in enumerate(zip(shape, strides)):
+            lay.shape[i], lay.strides[i] = int(a), int(b)
+        return lay
 
 
 _P = C.c_void_p
@@ -168,6 +188,10 @@ PROTOTYPES = {
     "mi355_gemm_tail_plan": (C.c_int32, [C.POINTER(GemmDesc), _I32P, C.POINTER(C.c_int64), _I32P]),
     "mi355_gemm_scaled": (C.c_int32, [_P, _P, C.POINTER(GemmScaledDesc), _P, _P, _P, _P, _P]),
     "mi355_gemm_scaled_select": (C.c_int32, [_P, C.POINTER(GemmScaledDesc), _I32P]),
+    "mi355_copy_strided": (C.c_int32, [_P, _P, _P, C.POINTER(TensorLayout), _P, C.POINTER(TensorLayout), C.c_int32]),
+    "mi355_copy_strided_plan": (C.c_int32, [_P, C.POINTER(TensorLayout), _P, C.POINTER(TensorLayout), C.c_int32, _I32P, _I32P]),
+    "mi355_copy_packed": (C.c_int32, [_P, _P, _P, C.POINTER(TensorLayout), _P, C.POINTER(TensorLayout), C.POINTER(C.c_int64),
+                                      C.c_int32, C.c_int32, C.c_int32]),
     "mi355_reduce_workspace_bytes": (C.c_int32, [_P, C.c_uint64, _U64P]),
     "mi355_reduce_sum_f32": (C.c_int32, [_P, _P, _P, C.c_uint64, _P, _P, C.c_uint64]),
     "mi355_argmax_f32": (C.c_int32, [_P, _P, _P, C.c_uint64, _P, _P, _P, C.c_uint64]),

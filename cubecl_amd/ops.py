@@ -29,7 +29,6 @@ def _matrix_operand(t: TensorHandle, name: str):
         return False, max(t.shape[-1], 1), batch, 0
     layout = matrix_batch_layout(t.strides)
     if layout.kind == "HighlyPermuted":
-        # the reference launcher would call into_contiguous first (next tier)
         raise ServerError(N.E_UNSUPPORTED_STRIDES, f"matmul: {name} is HighlyPermuted; make it contiguous first")
     rows, cols = t.shape[-2], t.shape[-1]
     rs, cs = t.strides[-2], t.strides[-1]
@@ -57,6 +56,19 @@ def _matrix_operand(t: TensorHandle, name: str):
     return transposed, ld, batch, bstride
 
 
+def _kernel_ready(client: ComputeClient, t: TensorHandle, name: str):
+    """What the reference's matmul launchers do in front of the kernel: an operand whose strides the kernel cannot
+    consume (matrix_batch_layout says HighlyPermuted, or the batch axes do not collapse) goes through
+    into_contiguous first (crates/cubecl-std/src/tensor/matrix_batch_layout.rs:9-19, contiguous/launch.rs:5-20)."""
+    try:
+        return t, _matrix_operand(t, name)
+    except ServerError as e:
+        if e.code != N.E_UNSUPPORTED_STRIDES:
+            raise
+    t = into_contiguous(client, t)
+    return t, _matrix_operand(t, name)
+
+
 def matmul(client: ComputeClient, lhs: TensorHandle, rhs: TensorHandle, out: TensorHandle,
            algo: int = N.GEMM_ALGO_AUTO) -> None:
     """out[.., m, n] = sum_k lhs[.., m, k] * rhs[.., k, n]   (f32 accumulate).
@@ -71,8 +83,8 @@ def matmul(client: ComputeClient, lhs: TensorHandle, rhs: TensorHandle, out: Ten
         raise ServerError(N.E_INVALID_ARGUMENT, f"matmul: shape mismatch {lhs.shape} x {rhs.shape} -> {out.shape}")
     if lhs.dtype != rhs.dtype:
         raise ServerError(N.E_INVALID_ARGUMENT, "matmul: lhs/rhs dtypes differ")
-    ta, lda, ba, sa = _matrix_operand(lhs, "lhs")
-    tb, ldb, bb, sb = _matrix_operand(rhs, "rhs")
+    lhs, (ta, lda, ba, sa) = _kernel_ready(client, lhs, "lhs")
+    rhs, (tb, ldb, bb, sb) = _kernel_ready(client, rhs, "rhs")
     tc, ldc, bc, sc = _matrix_operand(out, "out")
     if tc:
         raise ServerError(N.E_UNSUPPORTED_STRIDES, "matmul: out must be row-major")
@@ -262,3 +274,61 @@ def plane_reduce(client: ComputeClient, input: TensorHandle, output: TensorHandl
     n = input.num_elems()
     client._s.check(client.lib.mi355_plane_reduce_f32(client.ctx, client.stream, C.c_void_p(input.device_ptr()),
                                                       C.c_void_p(output.device_ptr()), n, active, op))
+
+
+# ---- strided copies (crates/cubecl-std/src/tensor/contiguous/) -------------------------------------------------------
+def copy_into(client: ComputeClient, input: TensorHandle, output: TensorHandle) -> None:
+    """copy_into (contiguous/launch.rs:40-56): element q of `input`'s linear view goes to element q of `output`'s linear
+    layout.  Both may be strided, and they may differ in rank as long as they hold the same number of elements."""
+    if input.dtype.size() != output.dtype.size():
+        raise ServerError(N.E_INVALID_ARGUMENT, "copy_into: element sizes differ")
+    li, lo = N.TensorLayout.of(input.shape, input.strides), N.TensorLayout.of(output.shape, output.strides)
+    client._s.check(client.lib.mi355_copy_strided(client.ctx, client.stream, C.c_void_p(input.device_ptr()), C.byref(li),
+                                                  C.c_void_p(output.device_ptr()), C.byref(lo), input.dtype.size()))
+
+
+def copy_plan(client: ComputeClient, input: TensorHandle, output: TensorHandle):
+    """-> (path, bytes per access) copy_into takes for these two views (host-side only)."""
+    li, lo = N.TensorLayout.of(input.shape, input.strides), N.TensorLayout.of(output.shape, output.strides)
+    path, access = C.c_int32(), C.c_int32()
+    rc = client.lib.mi355_copy_strided_plan(C.c_void_p(input.device_ptr()), C.byref(li), C.c_void_p(output.device_ptr()), C.byref(lo),
+                                            input.dtype.size(), C.byref(path), C.byref(access))
+    if rc != N.OK:
+        raise ServerError(rc, "copy_plan: the two views cannot be copied into each other")
+    return path.value, access.value
+
+
+def into_contiguous(client: ComputeClient, input: TensorHandle) -> TensorHandle:
+    """into_contiguous (contiguous/launch.rs:5-20): a new contiguous tensor with the view's elements."""
+    handle = client.empty(input.num_elems() * input.dtype.size())
+    output = TensorHandle.new_contiguous(input.shape, handle, input.dtype)
+    copy_into(client, input, output)
+    return output
+
+
+def into_contiguous_pitched(client: ComputeClient, input: TensorHandle) -> TensorHandle:
+    """into_contiguous_pitched (contiguous/launch.rs:22-37): like into_contiguous, rows padded to the pitch that
+    ComputeClient::empty_tensor picks."""
+    if input.rank() <= 1:
+        return into_contiguous(client, input)
+    output = TensorHandle.empty(client, input.shape, input.dtype)
+    copy_into(client, input, output)
+    return output
+
+
+def into_contiguous_packed(client: ComputeClient, input: TensorHandle, packed_dim: int, shape, packing: int) -> TensorHandle:
+    """into_contiguous_packed (contiguous/base.rs:254-293): `input` stores `packing` sub-word values per u32 / u8 word,
+    packed along axis rank - 1 - packed_dim of the logical `shape`; the result stores the same values packed along the
+    innermost axis."""
+    rank = len(shape)
+    if rank <= 1:
+        return into_contiguous(client, input)
+    out_shape = list(shape)
+    out_shape[-1] = -(-out_shape[-1] // packing)
+    output = TensorHandle.empty(client, out_shape, input.dtype)
+    li, lo = N.TensorLayout.of(input.shape, input.strides), N.TensorLayout.of(output.shape, output.strides)
+    logical = (C.c_int64 * rank)(*[int(d) for d in shape])
+    client._s.check(client.lib.mi355_copy_packed(client.ctx, client.stream, C.c_void_p(input.device_ptr()), C.byref(li),
+                                                 C.c_void_p(output.device_ptr()), C.byref(lo), logical, packed_dim, packing,
+                                                 input.dtype.size()))
+    return output

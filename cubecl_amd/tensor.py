@@ -88,6 +88,25 @@ class TensorHandle:
     def is_contiguous(self) -> bool:
         return tuple(self.strides) == contiguous_strides(self.shape)
 
+    def is_contiguous_pitched(self) -> bool:
+        """contiguous/base.rs:475-501: only the second-to-last stride may carry padding."""
+        rank = len(self.shape)
+        if rank == 0:
+            return True
+        if self.strides[-1] != 1:
+            return False
+        if rank <= 1:
+            return True
+        if sorted(self.strides, reverse=True) != list(self.strides):
+            return False
+        return all(self.strides[i] == self.shape[i + 1] * self.strides[i + 1] for i in range(rank - 2))
+
+    def permute(self, axes: Sequence[int]) -> "TensorHandle":
+        """A view with the axes re-ordered (no data movement): what Burn's swap_dims / permute hand to the launchers."""
+        if sorted(axes) != list(range(len(self.shape))):
+            raise ValueError(f"permute: {axes} is not a permutation of {len(self.shape)} axes")
+        return TensorHandle(self.handle, tuple(self.shape[a] for a in axes), tuple(self.strides[a] for a in axes), self.dtype)
+
     def to_numpy(self, client: ComputeClient) -> np.ndarray:
         raw = client.read_tensor(self.into_copy_descriptor())
         return raw.view(_NP[self.dtype]).reshape(self.shape)

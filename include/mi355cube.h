@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define MI355_ABI_VERSION 2
+#define MI355_ABI_VERSION 3
 
 /* ---- status codes (map onto LaunchError / IoError / ServerError, server/base.rs:177-332,
  *      :884-1019; the Rust shim performs the conversion) ------------------------------- */
@@ -442,6 +442,58 @@ int32_t mi355_reduce_axis_argmax(mi355_ctx *ctx, mi355_stream stream, const void
  * op = MI355_REDUCE_SUM / MAX / MIN, or 100 for product, 101 inclusive sum, 102 exclusive sum. */
 int32_t mi355_plane_reduce_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, float *out,
                                uint64_t n, uint32_t active, int32_t op);
+
+/* =================================== Strided copies (into_contiguous) =================================== */
+
+/* A tensor view: shape and strides in ELEMENTS, outermost axis first (TensorBinding's shape / strides,
+ * crates/cubecl-std/src/tensor/handle.rs).  rank 1..MI355_MAX_RANK; a stride of 0 broadcasts (input side only). */
+#define MI355_MAX_RANK 8
+typedef struct mi355_tensor_layout {
+    int32_t rank;
+    int32_t reserved;
+    int64_t shape[MI355_MAX_RANK];
+    int64_t strides[MI355_MAX_RANK];
+} mi355_tensor_layout;
+
+/* copy_into / into_contiguous / into_contiguous_pitched (crates/cubecl-std/src/tensor/contiguous/launch.rs:5-56,
+ * base.rs:295-389): element q of the input view in row-major (linear) order goes to element q of the output view
+ * in linear order.  The two views hold the same number of elements; they may differ in rank and shape (the
+ * reference's rank-mismatch case, tests/tensor/into_contiguous.rs:139-185) and the OUTPUT may be strided too
+ * (a pitched allocation, or a permuted destination).  elem_size 1, 2, 4 or 8 bytes: the copy moves bits.
+ * HBM-bound: 2 x elements x elem_size bytes per call.  Paths (chosen from the layouts):
+ *   FLAT       both views collapse to one contiguous run                       -> 16-byte vector copy
+ *   ROWS       both views are contiguous along the innermost (collapsed) axis  -> vector copy, rows located by
+ *                                                                                 multiply-shift division
+ *   TRANSPOSE  the input is contiguous along one axis, the output along another (both >= 16 long; 1/2/4-byte
+ *              elements) -> 256-byte x 256-byte tiles through bank-swizzled LDS, 16-byte accesses on both sides
+ *   GENERIC    anything else over a common refinement of the two shapes: one element per access
+ *   TWO_SIDED  two strided views whose axis boundaries do not nest (a strided [2,3] into a strided [3,2]; a
+ *              contiguous side refines against anything): each side decomposes the linear index by its own shape */
+enum {
+    MI355_COPY_PATH_FLAT = 0,
+    MI355_COPY_PATH_ROWS = 1,
+    MI355_COPY_PATH_TRANSPOSE = 2,
+    MI355_COPY_PATH_GENERIC = 3,
+    MI355_COPY_PATH_TWO_SIDED = 4
+};
+int32_t mi355_copy_strided(mi355_ctx *ctx, mi355_stream stream, const void *in, const mi355_tensor_layout *in_layout,
+                           void *out, const mi355_tensor_layout *out_layout, int32_t elem_size);
+/* Host-only: which path (and how many bytes per access) mi355_copy_strided takes for these arguments; no device
+ * needed.  Returns MI355_E_INVALID_ARGUMENT for what mi355_copy_strided would reject. */
+int32_t mi355_copy_strided_plan(const void *in, const mi355_tensor_layout *in_layout, const void *out,
+                                const mi355_tensor_layout *out_layout, int32_t elem_size, int32_t *path,
+                                int32_t *access_bytes);
+
+/* into_contiguous_packed (base.rs:254-293, :391-472): re-packs a tensor of sub-word values -- `packing` values of
+ * word_bits / packing bits in each storage word, packed along axis `rank - 1 - packed_dim` of the input (packed_dim
+ * counts from the innermost axis, as the reference's argument does) -- so that the values are packed along the
+ * innermost axis of the output.  `shape` is the logical (unpacked) shape, rank = in_storage->rank;
+ * in_storage / out_storage describe the word tensors (strides in words); the output holds
+ * prod(shape[:-1]) x ceil(shape[-1] / packing) words.  word_size 4 (u32) or 1 (u8).  Output word w takes, in bit
+ * slot n, the logical element with linear index w * packing + n (base.rs:170-207). */
+int32_t mi355_copy_packed(mi355_ctx *ctx, mi355_stream stream, const void *in, const mi355_tensor_layout *in_storage,
+                          void *out, const mi355_tensor_layout *out_storage, const int64_t *shape,
+                          int32_t packed_dim, int32_t packing, int32_t word_size);
 
 /* =================================== Throughput probes =================================== */
 

@@ -150,3 +150,88 @@ def test_tail_plan_splits_only_small_leftover_rounds():
     assert _tail_plan(4608, 4096, 8192, batch=2)[2] == 1
     assert _tail_plan(6144, 6144, 6144, trans_b=0)[2] == 1
     assert _tail_plan(6144, 6144, 256)[2] == 1                          # too few K-tiles to split
+
+
+def _copy_plan(shape, strides, es, out_shape=None, out_strides=None, in_ptr=0x1000, out_ptr=0x2000):
+    import ctypes as C
+    from cubecl_amd import _native as N
+    from oracle.layout import contiguous_strides as cs
+    lib = N.load()
+    out_shape = list(shape if out_shape is None else out_shape)
+    out_strides = cs(out_shape) if out_strides is None else out_strides
+    li, lo = N.TensorLayout.of(shape, strides), N.TensorLayout.of(out_shape, out_strides)
+    path, access = C.c_int32(-1), C.c_int32(-1)
+    rc = lib.mi355_copy_strided_plan(C.c_void_p(in_ptr), C.byref(li), C.c_void_p(out_ptr), C.byref(lo), es, C.byref(path), C.byref(access))
+    return rc, path.value, access.value
+
+
+def test_copy_strided_plan_picks_the_cheapest_mover():
+    """Host half of copy_into (cubecl_amd/csrc/copy_strided.hip): the two views are refined to a joint space, unit axes
+    dropped, adjacent axes merged, and the mover follows from what is left.  No device involved."""
+    from cubecl_amd import _native as N
+    OK = N.OK
+    # contiguous views of any rank collapse to one run; so does a reshape
+    assert _copy_plan([4, 6, 64], [384, 64, 1], 4) == (OK, N.COPY_PATH_FLAT, 16)
+    assert _copy_plan([4, 6, 64], [384, 64, 1], 4, out_shape=[24, 64]) == (OK, N.COPY_PATH_FLAT, 16)
+    assert _copy_plan([1, 2, 4, 1], [8, 4, 1, 1], 4, out_shape=[1, 2, 4]) == (OK, N.COPY_PATH_FLAT, 16)
+    assert _copy_plan([7], [1], 2) == (OK, N.COPY_PATH_FLAT, 2)                       # 14 bytes: 2-byte accesses
+    assert _copy_plan([8], [1], 2, in_ptr=0x1004) == (OK, N.COPY_PATH_FLAT, 4)        # the pointer caps the width
+    # padded rows on either side: rows
+    assert _copy_plan([30, 64], [80, 1], 4) == (OK, N.COPY_PATH_ROWS, 16)
+    assert _copy_plan([30, 64], [64, 1], 4, out_strides=[66, 1]) == (OK, N.COPY_PATH_ROWS, 8)
+    assert _copy_plan([30, 63], [63, 1], 4, out_strides=[64, 1]) == (OK, N.COPY_PATH_ROWS, 4)
+    assert _copy_plan([5, 7, 64], [64, 320, 1], 2) == (OK, N.COPY_PATH_ROWS, 16)     # outer axes swapped
+    # the input contiguous along another axis than the output: tiles, vectorised when every stride allows
+    assert _copy_plan([64, 128], [1, 64], 2) == (OK, N.COPY_PATH_TRANSPOSE, 16)
+    assert _copy_plan([64, 104], [1, 64], 2)[1:] == (N.COPY_PATH_TRANSPOSE, 16)
+    assert _copy_plan([64, 100], [1, 64], 2)[1:] == (N.COPY_PATH_TRANSPOSE, 2)          # output rows of 200 bytes
+    assert _copy_plan([3, 64, 128], [8192, 1, 64], 1)[1:] == (N.COPY_PATH_TRANSPOSE, 16)
+    assert _copy_plan([64, 128], [128, 1], 4, out_strides=[1, 64])[1:] == (N.COPY_PATH_TRANSPOSE, 16)
+    # NCHW -> NHWC: H and W merge into one axis of 40 * 56
+    assert _copy_plan([4, 40, 56, 48], [107520, 56, 1, 2240], 4)[1:] == (N.COPY_PATH_TRANSPOSE, 16)
+    # too short to tile, 8-byte elements, strided gathers: generic; when one side is contiguous along the innermost joint
+    # axis a thread packs as many elements as divide it into one 16-byte access on that side
+    # (8 bytes when a row holds several such groups -- wider scatters the lanes of the element-wise side --, 16 when the
+    # row is one group and the lanes walk the other side's contiguous axis)
+    assert _copy_plan([8, 128], [1, 8], 4)[1:] == (N.COPY_PATH_GENERIC, 8)
+    assert _copy_plan([64, 128], [1, 64], 8)[1:] == (N.COPY_PATH_GENERIC, 8)
+    assert _copy_plan([100], [3], 4)[1:] == (N.COPY_PATH_GENERIC, 8)
+    assert _copy_plan([100], [3], 1)[1:] == (N.COPY_PATH_GENERIC, 4)
+    assert _copy_plan([102], [3], 4)[1:] == (N.COPY_PATH_GENERIC, 8)
+    assert _copy_plan([101], [3], 4)[1:] == (N.COPY_PATH_GENERIC, 4)
+    assert _copy_plan([1000, 8, 8], [64, 1, 8], 2)[1:] == (N.COPY_PATH_GENERIC, 16)           # 8 x 8 transposes: K = the row
+    assert _copy_plan([100], [1], 2, out_strides=[5])[1:] == (N.COPY_PATH_GENERIC, 8)       # scatter: vector loads
+    assert _copy_plan([100], [3], 4, out_strides=[5])[1:] == (N.COPY_PATH_GENERIC, 4)       # neither side contiguous
+    # the reference's rank-mismatch case (tests/tensor/into_contiguous.rs:143-146) refines to [2, 4]: generic
+    assert _copy_plan([1, 2, 4, 1], [8, 1, 2, 2], 4, out_shape=[1, 2, 4])[1:] == (N.COPY_PATH_GENERIC, 16)
+    # a contiguous output refines against anything; two strided views whose axis boundaries do not nest have no common
+    # refinement
+    assert _copy_plan([2, 3], [1, 2], 4, out_shape=[3, 2])[1:] == (N.COPY_PATH_GENERIC, 4)
+    assert _copy_plan([2, 3], [1, 2], 4, out_shape=[3, 2], out_strides=[4, 1])[1:] == (N.COPY_PATH_TWO_SIDED, 4)
+    # contiguous [2, 3] -> [3, 2] needs none: both collapse
+    assert _copy_plan([2, 3], [3, 1], 4, out_shape=[3, 2])[1:] == (N.COPY_PATH_FLAT, 8)
+    # rejected: element counts differ, broadcasting output, bad element size, rank 9, negative stride
+    E = N.E_INVALID_ARGUMENT
+    assert _copy_plan([4, 8], [8, 1], 4, out_shape=[4, 7])[0] == E
+    assert _copy_plan([4, 8], [8, 1], 4, out_strides=[0, 1])[0] == E
+    assert _copy_plan([4, 8], [8, 1], 3)[0] == E
+    assert _copy_plan([4, 8], [8, -1], 4)[0] == E
+    lay = N.TensorLayout.of([4], [1])
+    lay.rank = 9
+    import ctypes as C
+    assert N.load().mi355_copy_strided_plan(None, C.byref(lay), None, C.byref(lay), 4, None, None) == E
+
+
+def test_contiguous_pitched_predicate_and_permute():
+    from cubecl_amd.runtime import Handle, _Memory
+    h = Handle(_Memory(None, 0, 0, None), None, None, 0)
+    t = TensorHandle.new(h, (2, 3, 4), (16, 4, 1), ElemType.F32)            # pitched rows? no: 3 * 4 != 16
+    assert not t.is_contiguous() and not t.is_contiguous_pitched()
+    assert TensorHandle.new(h, (2, 3, 4), (24, 8, 1), ElemType.F32).is_contiguous_pitched()
+    assert TensorHandle.new(h, (2, 3, 4), (12, 4, 1), ElemType.F32).is_contiguous_pitched()
+    assert not TensorHandle.new(h, (2, 3, 4), (4, 8, 1), ElemType.F32).is_contiguous_pitched()
+    assert not TensorHandle.new(h, (3, 4), (1, 3), ElemType.F32).is_contiguous_pitched()
+    p = TensorHandle.new(h, (2, 3, 4), (12, 4, 1), ElemType.F32).permute([2, 0, 1])
+    assert p.shape == (4, 2, 3) and p.strides == (1, 12, 4)
+    with pytest.raises(ValueError):
+        p.permute([0, 0, 1])

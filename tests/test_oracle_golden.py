@@ -317,3 +317,60 @@ def test_sequential_vs_f64_sum_gap(oracle):
     exact = oracle.sum_f64(x)
     assert abs(exact - float(np.sum(x, dtype=np.float64))) < 1e-6 * exact
     assert abs(oracle.sum_sequential(x) - exact) / exact < 1e-3
+
+
+# ---- strided copies: oracle/layout.py against the reference tests' known answers and CPU formulas ----------------------
+def test_copy_into_rank_mismatch_known_answer():
+    # tests/tensor/into_contiguous.rs:139-185: data 1..8, shape [1, 2, 4, 1] strides [8, 1, 2, 2] -> [1, 2, 4] contiguous;
+    # the test's formula gives src(q) = (q / 4) % 2 + 2 * (q % 4)
+    from oracle import layout as L
+    data = np.arange(1, 9, dtype=np.float32)
+    out = L.copy_into(data, [1, 2, 4, 1], [8, 1, 2, 2], np.zeros(8, np.float32), [1, 2, 4], [8, 4, 1])
+    assert out.tolist() == [1, 3, 5, 7, 2, 4, 6, 8]
+
+
+def test_copy_into_permuted_sweep_matches_numpy_transpose():
+    # :257-283: every permutation of the reference's shapes; payload (i % 251) + 1 (:204-206).  numpy's transpose is an
+    # independent statement of "element q of the permuted view".
+    import itertools
+    from oracle import layout as L
+    shapes = [[2, 3], [3, 2], [4, 6], [6, 4], [2, 2, 3], [3, 2, 2], [2, 3, 4], [4, 3, 2], [8, 3, 4], [3, 8, 5], [16, 5], [5, 16],
+              [8, 8], [16, 16], [32, 2, 3], [2, 3, 4, 5]]
+    for shape in shapes:
+        n = int(np.prod(shape))
+        data = ((np.arange(n) % 251) + 1).astype(np.uint8)
+        bstr = L.contiguous_strides(shape)
+        for perm in itertools.permutations(range(len(shape))):
+            got = L.into_contiguous(data, [shape[p] for p in perm], [bstr[p] for p in perm])
+            assert np.array_equal(got, data.reshape(shape).transpose(perm).reshape(-1)), (shape, perm)
+
+
+def test_copy_into_strided_destination_and_broadcast():
+    from oracle import layout as L
+    src = np.arange(12, dtype=np.int32)
+    dst = np.full(20, -1, dtype=np.int32)
+    L.copy_into(src, [3, 4], [4, 1], dst, [3, 4], [6, 1])                 # pitched rows: the padding stays untouched
+    assert dst.tolist() == [0, 1, 2, 3, -1, -1, 4, 5, 6, 7, -1, -1, 8, 9, 10, 11, -1, -1, -1, -1]
+    out = L.into_contiguous(np.array([7, 8, 9], dtype=np.int32), [2, 3], [0, 1])   # stride 0 broadcasts
+    assert out.tolist() == [7, 8, 9, 7, 8, 9]
+
+
+@pytest.mark.parametrize("shape,dim", [([1, 8, 16], 1), ([1, 8, 8], 1), ([4096, 256], 0), ([8192, 32], 0)])
+def test_packed_repack_reference_cases(shape, dim):
+    # :120-142: the four repack cases; expected = the test's own CPU packer applied along the innermost axis
+    from oracle import layout as L
+    n = int(np.prod(shape))
+    unpacked = ((np.arange(n) % 15) + 1).astype(np.uint32)
+    storage = L.pack_along(unpacked, shape, dim, 8, 4).astype(np.uint32)
+    in_shape = list(shape)
+    in_shape[dim] = -(-in_shape[dim] // 8)
+    got = L.into_contiguous_packed(storage, L.contiguous_strides(in_shape), shape, len(shape) - 1 - dim, 8)
+    assert got.any() and np.array_equal(got, L.pack_along(unpacked, shape, len(shape) - 1, 8, 4).astype(np.uint32))
+
+
+def test_pack_along_known_words():
+    # by hand: values 1..8 (4 bits each) along the only axis -> 0x87654321; packed along axis 0 of [8, 2]: column-wise
+    from oracle import layout as L
+    assert L.pack_along(np.arange(1, 9, dtype=np.uint32), [8], 0, 8, 4).tolist() == [0x87654321]
+    v = np.arange(1, 17, dtype=np.uint32) & 15
+    assert L.pack_along(v, [8, 2], 0, 8, 4).tolist() == [0xFDB97531, 0x0ECA8642]
