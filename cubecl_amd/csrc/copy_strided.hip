@@ -193,6 +193,7 @@ struct tr_args {
     uint64_t np, nq;          // extents of P and Q
     int64_t in_q, out_p;      // input stride along Q, output stride along P (elements)
     uint32_t tiles_p, tiles_q;
+    uint32_t group, groups_p, groups_q;   // tile order: squares of group x group tiles
     int32_t nb;               // batch axes, innermost first
     int32_t vec_ok;           // all bases and strides are 16-byte multiples
     uint32_t bshape[MAXD];
@@ -205,6 +206,7 @@ template <int ES> struct lds_elem;
 template <> struct lds_elem<1> { typedef uint8_t type; };
 template <> struct lds_elem<2> { typedef uint16_t type; };
 template <> struct lds_elem<4> { typedef uint32_t type; };
+template <> struct lds_elem<8> { typedef uint64_t type; };
 
 template <int ES>
 __global__ void __launch_bounds__(256)
@@ -212,17 +214,27 @@ transpose_copy_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
 {
     typedef typename lds_elem<ES>::type T;
     constexpr int VE = 16 / ES;        // elements per 16-byte access
-    constexpr int R = 4 / ES;          // q-rows packed into one LDS dword
+    constexpr int R = ES >= 4 ? 1 : 4 / ES;   // q-rows packed into one LDS dword (an 8-byte element takes two dwords)
+    constexpr int NJ = ES == 8 ? 32 : 64;     // row items of a tile: NJ x R rows of Q
     constexpr int TP = 16 * VE;        // tile extent along P: 256 bytes of input row
-    constexpr int TQ = 64 * R;         // tile extent along Q: 256 bytes of output row
+    constexpr int TQ = NJ * R;         // tile extent along Q: 256 bytes of output row
     __shared__ uint32_t lds[TP * 64];  // tileT[p][64 dword columns], column ^= ((p / VE) & 7) << 2
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // Tile order: G x G squares of tiles, walked P-first inside a square and square by square along P (G = 1: plain
+    // rows of tiles).  With G = 16 the ~2000 workgroups in flight read 4 KiB of each of their input rows and write
+    // 4 KiB of each of their output rows; the host picks it when the row strides are multiples of 4 KiB (see there).
     uint32_t b = blockIdx.x;
-    const uint32_t tp = b % a.tiles_p;
-    b /= a.tiles_p;
-    const uint32_t tq = b % a.tiles_q;
-    b /= a.tiles_q;
+    const uint32_t G = a.group, lp = b % G;
+    b /= G;
+    const uint32_t lq = b % G;
+    b /= G;
+    const uint32_t gp = b % a.groups_p;
+    b /= a.groups_p;
+    const uint32_t gq = b % a.groups_q;
+    b /= a.groups_q;
+    const uint32_t tp = gp * G + lp, tq = gq * G + lq;
+    if (tp >= a.tiles_p || tq >= a.tiles_q) return;
     int64_t off_in = 0, off_out = 0;
     for (int i = 0; i < a.nb; ++i) {
         const uint32_t idx = b % a.bshape[i];
@@ -242,9 +254,9 @@ transpose_copy_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
         // bits walk 4 neighbouring columns (bank bits 0-1), the rest walk cv (bank bits 2-4 through the swizzle)
         const int cv = (lane >> 4) * 4 + (lane & 3), jr = (lane >> 2) & 3;
         const bool p_in = whole || p0 + (uint64_t)(cv * VE) < a.np;
-        u32x4 v[4][R];
+        u32x4 v[NJ / 16][R];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NJ / 16; ++k) {
             const int j = (k * 4 + w) * 4 + jr;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -256,10 +268,14 @@ transpose_copy_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
         }
         const int swz = (cv & 7) << 2;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NJ / 16; ++k) {
             const int j = (k * 4 + w) * 4 + jr;
-            uint32_t *col = lds + (cv * VE) * 64 + (j ^ swz);
-            if constexpr (ES == 4) {
+            uint32_t *col = lds + (cv * VE) * 64 + ((ES == 8 ? 2 * j : j) ^ swz);
+            if constexpr (ES == 8) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    *reinterpret_cast<uint64_t *>(col + e * 64) = (uint64_t)v[k][0][2 * e] | ((uint64_t)v[k][0][2 * e + 1] << 32);
+            } else if constexpr (ES == 4) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) col[e * 64] = v[k][0][e];
             } else if constexpr (ES == 2) {
@@ -295,17 +311,22 @@ transpose_copy_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
     } else {
         // ragged or unaligned tile: the same LDS image, one element per access
         T *l = reinterpret_cast<T *>(lds);
+        const auto at = [](int p, int q) {            // index of element (p, q) in the LDS image, in units of T
+            const int swz = ((p / VE) & 7) << 2;
+            if constexpr (ES == 8) return p * 32 + (((2 * q) ^ swz) >> 1);
+            else return (p * 64 + ((q / R) ^ swz)) * R + (q % R);
+        };
         const uint64_t pe = a.np - p0 < TP ? a.np - p0 : TP, qe = a.nq - q0 < TQ ? a.nq - q0 : TQ;
         for (int lin = tid; lin < TP * TQ; lin += 256) {
             const int q = lin / TP, p = lin % TP;
             if ((uint64_t)p < pe && (uint64_t)q < qe)
-                l[(p * 64 + ((q / R) ^ (((p / VE) & 7) << 2))) * R + (q % R)] = src[(int64_t)q * a.in_q + p];
+                l[at(p, q)] = src[(int64_t)q * a.in_q + p];
         }
         __syncthreads();
         for (int lin = tid; lin < TP * TQ; lin += 256) {
             const int p = lin / TQ, q = lin % TQ;
             if ((uint64_t)p < pe && (uint64_t)q < qe)
-                dst[(int64_t)p * a.out_p + q] = l[(p * 64 + ((q / R) ^ (((p / VE) & 7) << 2))) * R + (q % R)];
+                dst[(int64_t)p * a.out_p + q] = l[at(p, q)];
         }
     }
 }
@@ -481,7 +502,7 @@ const char *make_plan(const void *in, const mi355_tensor_layout *li, const void 
     pl.joint = j;
     pl.access = es;
     pl.path = MI355_COPY_PATH_GENERIC;
-    if (es <= 4) {
+    {
         int p = -1, q = -1;
         for (size_t k = 0; k < j.size(); ++k) {
             if (p < 0 && j[k].si == 1 && j[k].shape >= 16) p = (int)k;
@@ -666,13 +687,22 @@ MI355_API int32_t mi355_copy_strided(mi355_ctx *ctx, mi355_stream stream, const 
         tr_args a;
         memset(&a, 0, sizeof(a));
         const axis &P = pl.joint[pl.p_axis], &Q = pl.joint[pl.q_axis];
-        const int tp_ext = 256 / elem_size, tq_ext = 64 * (4 / elem_size);
+        const int tp_ext = 256 / elem_size, tq_ext = elem_size == 8 ? 32 : 64 * (4 / elem_size);
         a.np = P.shape;
         a.nq = Q.shape;
         a.in_q = Q.si;
         a.out_p = P.so;
         const uint64_t tiles_p = (P.shape + tp_ext - 1) / tp_ext, tiles_q = (Q.shape + tq_ext - 1) / tq_ext;
-        uint64_t blocks = tiles_p * tiles_q;
+        // Rows a multiple of 4 KiB apart on either side pile the pieces of one long row of tiles onto a few HBM channels
+        // (measured, 16384^2 2-byte transpose: 4.2 TB/s walked row by row, 4.7 TB/s in 16 x 16 squares); other
+        // strides spread by themselves and prefer the plain row order (16640 x 15872: 5.1 against 4.9 TB/s).
+        uint32_t group = ((uint64_t)P.so * elem_size) % 4096 == 0 || ((uint64_t)Q.si * elem_size) % 4096 == 0 ? 16 : 1;
+        while (group > 1 && (group > tiles_p || group > tiles_q)) group >>= 1;
+        const uint64_t groups_p = (tiles_p + group - 1) / group, groups_q = (tiles_q + group - 1) / group;
+        a.group = group;
+        a.groups_p = (uint32_t)groups_p;
+        a.groups_q = (uint32_t)groups_q;
+        uint64_t blocks = groups_p * groups_q * group * group;
         a.vec_ok = pl.access == 16;
         for (size_t k = 0; k < pl.joint.size(); ++k) {
             if ((int)k == pl.p_axis || (int)k == pl.q_axis) continue;
@@ -689,6 +719,8 @@ MI355_API int32_t mi355_copy_strided(mi355_ctx *ctx, mi355_stream stream, const 
         uint8_t *op = (uint8_t *)out;
         if (elem_size == 4)
             hipLaunchKernelGGL(transpose_copy_kernel<4>, dim3((uint32_t)blocks), dim3(256), 0, s, ip, op, a);
+        else if (elem_size == 8)
+            hipLaunchKernelGGL(transpose_copy_kernel<8>, dim3((uint32_t)blocks), dim3(256), 0, s, ip, op, a);
         else if (elem_size == 2)
             hipLaunchKernelGGL(transpose_copy_kernel<2>, dim3((uint32_t)blocks), dim3(256), 0, s, ip, op, a);
         else

@@ -140,7 +140,7 @@ def test_flat_and_rows(client, es):
     run_copy(client, payload(40 * 50 * 60, es), [30, 20, 44], [3000, 60, 1], es, offset=5 * 3000 + 7 * 60 + 4)
 
 
-@pytest.mark.parametrize("es", [1, 2, 4])
+@pytest.mark.parametrize("es", [1, 2, 4, 8])
 def test_transpose_tiles(client, es):
     # whole tiles, 16-byte accesses on both sides
     run_copy(client, payload(1024 * 768, es), [768, 1024], [1, 768], es, expect_path=(N.COPY_PATH_TRANSPOSE, 16))
@@ -177,9 +177,9 @@ def test_generic_and_two_sided(client, es):
     run_copy(client, payload(3 * 4097, es), [4097], [3], es, out_strides=[2], expect_path=(N.COPY_PATH_GENERIC, es))
     run_copy(client, payload(512, es), [300, 512], [0, 1], es)
     run_copy(client, payload(300, es), [300, 512], [1, 0], es)
-    # 8-byte transposes take the generic mover
-    if es == 8:
-        run_copy(client, payload(256 * 384, es), [384, 256], [1, 384], es, expect_path=(N.COPY_PATH_GENERIC, 8))
+    # an axis too short to tile (8 < 16): generic, packed along the output's contiguous axis
+    run_copy(client, payload(8 * 384, es), [384, 8], [1, 384], es, expect_path=(N.COPY_PATH_GENERIC, min(8 * es, 16)))
+    run_copy(client, payload(8 * 384, es), [8, 384], [1, 8], es, expect_path=(N.COPY_PATH_GENERIC, {1: 4, 2: 8, 4: 8, 8: 8}[es]))
     # shapes with no common refinement: strided [2, 3] viewed into [3, 2], and a bigger one
     run_copy(client, payload(16, es), [2, 3], [1, 2], es, out_shape=[3, 2], expect_path=(N.COPY_PATH_GENERIC, es))
     run_copy(client, payload(16, es), [2, 3], [1, 2], es, out_shape=[3, 2], out_strides=[4, 1], expect_path=(N.COPY_PATH_TWO_SIDED, es))

@@ -194,7 +194,8 @@ def test_copy_strided_plan_picks_the_cheapest_mover():
     # (8 bytes when a row holds several such groups -- wider scatters the lanes of the element-wise side --, 16 when the
     # row is one group and the lanes walk the other side's contiguous axis)
     assert _copy_plan([8, 128], [1, 8], 4)[1:] == (N.COPY_PATH_GENERIC, 8)
-    assert _copy_plan([64, 128], [1, 64], 8)[1:] == (N.COPY_PATH_GENERIC, 8)
+    assert _copy_plan([64, 128], [1, 64], 8)[1:] == (N.COPY_PATH_TRANSPOSE, 16)
+    assert _copy_plan([8, 128], [1, 8], 8)[1:] == (N.COPY_PATH_GENERIC, 8)
     assert _copy_plan([100], [3], 4)[1:] == (N.COPY_PATH_GENERIC, 8)
     assert _copy_plan([100], [3], 1)[1:] == (N.COPY_PATH_GENERIC, 4)
     assert _copy_plan([102], [3], 4)[1:] == (N.COPY_PATH_GENERIC, 8)

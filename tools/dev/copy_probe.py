@@ -9,6 +9,7 @@ ev = bench.Events(client)
 NAMES = ["flat", "rows", "transpose", "generic", "two_sided"]
 DT = {1: ElemType.U8, 2: ElemType.BF16, 4: ElemType.F32, 8: ElemType.U64}
 GEN_ONLY = "--generic" in sys.argv
+TR_ONLY = "--transpose" in sys.argv
 
 
 def run(label, es, shape, strides, out_strides=None, src_elems=None):
@@ -36,6 +37,15 @@ for es in (4, 2, 1):
         run("short rows [*, 24] of 32", es, [e // 32, 24], [32, 1], src_elems=e)
         run("small transposes [*,8,8]", es, [e // 64, 8, 8], [64, 1, 8])
         continue
+    if TR_ONLY:
+        side = {4: (8192, 16384), 2: (16384, 16384), 1: (16384, 32768)}[es]
+        run(f"2-D transpose {side}", es, [side[1], side[0]], [1, side[1]])
+        run(f"2-D transpose [{side[0] + 256},{side[1] - 512}]", es, [side[1] - 512, side[0] + 256], [1, side[1] - 512])
+        b = e // (2048 * 2048)
+        run(f"batched transpose {b} x 2048^2", es, [b, 2048, 2048], [2048 * 2048, 1, 2048])
+        run(f"K^T [*,4096,64]", es, [e // (4096 * 64), 64, 4096], [4096 * 64, 1, 64])
+        run("full axis reversal [64,64,64,*]", es, [e // 64**3, 64, 64, 64], [1, e // 64**3, e // 64**2, e // 64])
+        continue
     run("flat 512 MiB", es, [e], [1])
     r = e // 4096
     run("rows, pitched input (4096+64)", es, [r, 4096], [4160, 1], src_elems=r * 4160)
@@ -54,4 +64,5 @@ for es in (4, 2, 1):
     run("stride-2 gather", es, [e // 2], [2], src_elems=e)
     run("stride-3 scatter", es, [e // 4], [1], out_strides=[3])
     run("full axis reversal [64,64,64,*]", es, [e // 64**3, 64, 64, 64], [1, e // 64**3, e // 64**2, e // 64])
-run("8-byte transpose (generic)", 8, [4096, 8192], [1, 4096])
+run("8-byte transpose 8192 x 4096", 8, [4096, 8192], [1, 4096])
+run("8-byte transpose 8448 x 3968", 8, [3968, 8448], [1, 3968])
