@@ -558,6 +558,39 @@ def main():
             return out
         guarded("gemm_bf16_shapes", skinny)
 
+        def contiguous():
+            # into_contiguous (crates/cubecl-std/src/tensor/contiguous/launch.rs:5-20) of 512 MiB views: HBM-bound,
+            # algorithmic bytes = read + write = 2 x elements x elem_size; roofline = the 8 TB/s HBM peak, and the
+            # measured copy ceiling of this board is reported next to it under measured_ceilings.
+            from cubecl_amd import ops
+            names = ["flat", "rows", "transpose", "generic", "two_sided"]
+            out = {}
+            cases = (("bf16_transpose_16384x16384", ElemType.BF16, [16384, 16384], [1, 16384]),
+                     ("bf16_transpose_16640x15872", ElemType.BF16, [15872, 16640], [1, 15872]),
+                     ("f32_transpose_8192x16384", ElemType.F32, [16384, 8192], [1, 16384]),
+                     ("bf16_batched_transpose_64x2048x2048", ElemType.BF16, [64, 2048, 2048], [2048 * 2048, 1, 2048]),
+                     ("bf16_kT_1024x4096x64", ElemType.BF16, [1024, 64, 4096], [4096 * 64, 1, 64]),
+                     ("f32_nchw_to_nhwc_167x256x56x56", ElemType.F32, [167, 56, 56, 256], [256 * 3136, 56, 1, 3136]),
+                     ("f32_pitched_rows_32768x4096_of_4160", ElemType.F32, [32768, 4096], [4160, 1]),
+                     ("u8_nhwc_to_nchw_3_channels", ElemType.U8, [3566, 3, 224, 224], [3 * 224 * 224, 1, 224 * 3, 3]),
+                     ("f32_contiguous_512MiB", ElemType.F32, [1 << 27], [1]))
+            for name, dt, shape, strides in cases:
+                n = 1
+                for d_ in shape:
+                    n *= d_
+                span = sum((d_ - 1) * s_ for d_, s_ in zip(shape, strides)) + 1
+                src = client.empty(span * dt.size())
+                dst = client.empty(n * dt.size())
+                tin = TensorHandle.new(src, shape, strides, dt)
+                tout = TensorHandle.new_contiguous(shape, dst, dt)
+                path, access = ops.copy_plan(client, tin, tout)
+                med, best = samples_op(client, ev, lambda: ops.copy_into(client, tin, tout), samples=9, warmup=3)
+                moved = 2 * n * dt.size()
+                out[name] = {"mover": names[path], "access_bytes": access, "median_us": round(med * 1e3, 1),
+                             "GBs": round(moved / med / 1e6, 1), "frac_of_8TBs": round(moved / med / 1e6 / PEAK_HBM_GBS, 4)}
+            return out
+        guarded("into_contiguous_512MiB", contiguous)
+
     if extra:
         result["extra"] = extra
     if errors:

@@ -139,7 +139,17 @@ pub struct mi355_gemm_desc {
     pub reserved: i32,
 }
 
-unsafe extern "C" {
+unsafe /// mi355_tensor_layout: TensorBinding's shape / strides (elements, outermost axis first).
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct mi355_tensor_layout {
+    pub rank: i32,
+    pub reserved: i32,
+    pub shape: [i64; 8],
+    pub strides: [i64; 8],
+}
+
+extern "C" {
     // Runtime
     pub fn mi355_abi_version() -> i32;
     pub fn mi355_device_count(out_count: *mut i32) -> i32;
@@ -247,6 +257,14 @@ unsafe extern "C" {
     // ComputeClient::to_client (client.rs:733-751)
     pub fn mi355_copy_to_ctx(src_ctx: *mut mi355_ctx, src_stream: mi355_stream, src_dptr: *const c_void, dst_ctx: *mut mi355_ctx,
                              dst_stream: mi355_stream, dst_dptr: *mut c_void, bytes: u64) -> i32;
+    // copy_into / into_contiguous / into_contiguous_packed (crates/cubecl-std/src/tensor/contiguous/launch.rs:5-56, base.rs:254-293)
+    pub fn mi355_copy_strided(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const c_void, in_layout: *const mi355_tensor_layout,
+                              out: *mut c_void, out_layout: *const mi355_tensor_layout, elem_size: i32) -> i32;
+    pub fn mi355_copy_strided_plan(input: *const c_void, in_layout: *const mi355_tensor_layout, out: *const c_void,
+                                   out_layout: *const mi355_tensor_layout, elem_size: i32, path: *mut i32, access_bytes: *mut i32) -> i32;
+    pub fn mi355_copy_packed(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const c_void, in_storage: *const mi355_tensor_layout,
+                             out: *mut c_void, out_storage: *const mi355_tensor_layout, shape: *const i64, packed_dim: i32,
+                             packing: i32, word_size: i32) -> i32;
     // ComputeServer::{begin_capture, end_capture, replay} (server/base.rs:453-532)
     pub fn mi355_graph_begin_capture(ctx: *mut mi355_ctx, stream: mi355_stream) -> i32;
     pub fn mi355_graph_end_capture(ctx: *mut mi355_ctx, stream: mi355_stream, out_graph: *mut *mut mi355_graph) -> i32;
