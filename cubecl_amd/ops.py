@@ -175,9 +175,21 @@ def _require_flat_f32(t: TensorHandle, what: str) -> int:
     return t.num_elems()
 
 
+def _consumable(client: ComputeClient, t: TensorHandle, view, what: str):
+    """-> (tensor, view(tensor)): a permuted / sliced input the reduction kernels cannot walk goes through into_contiguous
+    first, the same step the matmul launcher takes (contiguous/launch.rs:5-20)."""
+    try:
+        return t, view(t, what)
+    except ServerError as e:
+        if e.code != N.E_UNSUPPORTED_STRIDES:
+            raise
+    t = into_contiguous(client, t)
+    return t, view(t, what)
+
+
 def reduce_sum(client: ComputeClient, input: TensorHandle, output: TensorHandle) -> None:
     """Array-wide sum into output[0] (f32)."""
-    n = _require_flat_f32(input, "reduce_sum")
+    input, n = _consumable(client, input, _require_flat_f32, "reduce_sum")
     ws = _workspace(client, n)
     client._s.check(client.lib.mi355_reduce_sum(client.ctx, client.stream, C.c_void_p(input.device_ptr()), int(input.dtype), n,
                                                 C.c_void_p(output.device_ptr()), C.c_void_p(ws.device_ptr()), ws.size))
@@ -186,7 +198,7 @@ def reduce_sum(client: ComputeClient, input: TensorHandle, output: TensorHandle)
 def argmax(client: ComputeClient, input: TensorHandle, out_index: TensorHandle,
            out_value: Optional[TensorHandle] = None) -> None:
     """Array-wide argmax: out_index[0] (u64) = lowest index of the maximum; NaN ranks highest."""
-    n = _require_flat_f32(input, "argmax")
+    input, n = _consumable(client, input, _require_flat_f32, "argmax")
     ws = _workspace(client, n)
     client._s.check(client.lib.mi355_argmax(
         client.ctx, client.stream, C.c_void_p(input.device_ptr()), int(input.dtype), n,
@@ -197,7 +209,7 @@ def argmax(client: ComputeClient, input: TensorHandle, out_index: TensorHandle,
 def sum_argmax(client: ComputeClient, input: TensorHandle, out_sum: TensorHandle, out_index: TensorHandle,
                out_value: Optional[TensorHandle] = None) -> None:
     """Sum and argmax in one pass over the data."""
-    n = _require_flat_f32(input, "sum_argmax")
+    input, n = _consumable(client, input, _require_flat_f32, "sum_argmax")
     ws = _workspace(client, n)
     client._s.check(client.lib.mi355_sum_argmax(
         client.ctx, client.stream, C.c_void_p(input.device_ptr()), int(input.dtype), n, C.c_void_p(out_sum.device_ptr()),
@@ -227,13 +239,13 @@ def _rows_view(t: TensorHandle, what: str):
 def reduce_sum_last_axis(client: ComputeClient, input: TensorHandle, output: TensorHandle) -> None:
     """The book's reduce_matrix (cubecl-book/src/getting-started/src/bin/v1-cpu.rs:7-15):
     output shape = input shape minus the last axis."""
-    rows, cols, stride = _rows_view(input, "reduce_sum_last_axis")
+    input, (rows, cols, stride) = _consumable(client, input, _rows_view, "reduce_sum_last_axis")
     client._s.check(client.lib.mi355_reduce_last_axis_sum(
         client.ctx, client.stream, C.c_void_p(input.device_ptr()), int(input.dtype), C.c_void_p(output.device_ptr()), rows, cols, stride))
 
 
 def argmax_last_axis(client: ComputeClient, input: TensorHandle, output: TensorHandle) -> None:
-    rows, cols, stride = _rows_view(input, "argmax_last_axis")
+    input, (rows, cols, stride) = _consumable(client, input, _rows_view, "argmax_last_axis")
     client._s.check(client.lib.mi355_reduce_last_axis_argmax(
         client.ctx, client.stream, C.c_void_p(input.device_ptr()), int(input.dtype), C.c_void_p(output.device_ptr()), rows, cols, stride))
 
@@ -256,15 +268,15 @@ def _axis_view(t: TensorHandle, axis: int, what: str):
 
 
 def reduce_sum_axis(client: ComputeClient, input: TensorHandle, output: TensorHandle, axis: int) -> None:
-    """Sum over one axis: output shape = input shape minus that axis (any axis, contiguous input)."""
-    outer, red, inner = _axis_view(input, axis, "reduce_sum_axis")
+    """Sum over one axis: output shape = input shape minus that axis (any axis; a strided view is made contiguous first)."""
+    input, (outer, red, inner) = _consumable(client, input, lambda t, w: _axis_view(t, axis, w), "reduce_sum_axis")
     client._s.check(client.lib.mi355_reduce_axis_sum(client.ctx, client.stream, C.c_void_p(input.device_ptr()), int(input.dtype),
                                                      C.c_void_p(output.device_ptr()), outer, red, inner))
 
 
 def argmax_axis(client: ComputeClient, input: TensorHandle, output: TensorHandle, axis: int) -> None:
     """Argmax over one axis (u32 indices along that axis; lowest index wins ties, NaN ranks highest)."""
-    outer, red, inner = _axis_view(input, axis, "argmax_axis")
+    input, (outer, red, inner) = _consumable(client, input, lambda t, w: _axis_view(t, axis, w), "argmax_axis")
     client._s.check(client.lib.mi355_reduce_axis_argmax(client.ctx, client.stream, C.c_void_p(input.device_ptr()), int(input.dtype),
                                                         C.c_void_p(output.device_ptr()), outer, red, inner))
 

@@ -341,3 +341,35 @@ def test_reductions_over_any_axis_16bit(client, oracle, dtype, shape, axis):
     a = TensorHandle.new_contiguous(out_shape or (1,), client.empty(max(m, 1) * 4), ElemType.U32)
     ops.argmax_axis(client, t, a, axis)
     assert np.array_equal(a.to_numpy(client).reshape(ref.shape), oracle.reduce_axis_argmax(x, axis))
+
+
+def test_reductions_take_permuted_and_sliced_views(client, oracle):
+    # a view the kernels cannot walk (permuted axes, a column slice) is made contiguous first, as the reference's launchers
+    # do with into_contiguous; the answers are those of the logical tensor
+    x = oracle.fill_uniform(48 * 200 * 96, 77, -1.0, 1.0).reshape(48, 200, 96)
+    t = TensorHandle.from_numpy(client, x)
+    v = t.permute([2, 0, 1])                                   # logical [96, 48, 200]
+    xl = np.ascontiguousarray(x.transpose(2, 0, 1))
+    s1 = _scalar(client, ElemType.F32)
+    ops.reduce_sum(client, v, s1)
+    ref = oracle.sum_f64(xl.reshape(-1))
+    assert abs(float(s1.to_numpy(client)[0]) - ref) <= REL * oracle.sum_abs_f64(xl.reshape(-1))
+    idx = TensorHandle.new_contiguous((1,), client.empty(8), ElemType.U64)
+    ops.argmax(client, v, idx)
+    assert int(idx.to_numpy(client)[0]) == oracle.argmax(xl.reshape(-1))[0]
+    rows = TensorHandle.new_contiguous((96, 48), client.empty(96 * 48 * 4), ElemType.F32)
+    ops.reduce_sum_last_axis(client, v, rows)
+    bound = np.abs(xl).astype(np.float64).sum(axis=-1)
+    assert np.all(np.abs(rows.to_numpy(client).astype(np.float64) - oracle.reduce_last_axis_sum(xl.reshape(-1, 200), f64=True).reshape(96, 48))
+                  <= REL * bound + 1e-30)
+    am = TensorHandle.new_contiguous((96, 200), client.empty(96 * 200 * 4), ElemType.U32)
+    ops.argmax_axis(client, v, am, 1)
+    assert np.array_equal(am.to_numpy(client), oracle.reduce_axis_argmax(xl, 1))
+    # a column slice [:, 10:50] of a [300, 64] matrix
+    m = oracle.fill_uniform(300 * 64, 78, -1.0, 1.0).reshape(300, 64)
+    tm = TensorHandle.from_numpy(client, m)
+    sl = TensorHandle.new(tm.handle.offset_start_by(10 * 4), (300, 40), (64, 1), ElemType.F32)
+    cs = TensorHandle.new_contiguous((40,), client.empty(160), ElemType.F32)
+    ops.reduce_sum_axis(client, sl, cs, 0)
+    ref = m[:, 10:50].astype(np.float64).sum(axis=0)
+    assert np.all(np.abs(cs.to_numpy(client).astype(np.float64) - ref) <= REL * np.abs(m[:, 10:50]).astype(np.float64).sum(axis=0))
