@@ -222,3 +222,63 @@ def test_gemm_operand_larger_than_4_gib(client, oracle):
         assert not got.any()
     del a, c, ha
     client.memory_cleanup()
+
+
+def _window(client, handle, start, count):
+    """`count` bytes of a device buffer from byte `start` (a handle window, server/handle.rs:85-121)."""
+    total = handle.size
+    return client.read_one(handle.offset_start_by(start).offset_end_by(total - start - count))
+
+
+def test_strided_copies_beyond_2_pow_32_elements(client):
+    """copy_into at sizes whose linear indices do not fit 32 bits (the kernels' 64-bit index paths): rows, tiles, packed
+    gather.  Data = counter-RNG bytes generated on the device; checked on sampled windows read back from both sides."""
+    # rows: [8200, 2^20] bytes out of rows pitched by 4096 more -> 8.6e9 one-byte elements
+    rows, cols, pitch = 8200, 1 << 20, (1 << 20) + 4096
+    src = client.empty(rows * pitch)
+    client._s.check(client.lib.mi355_fill_uniform(client.ctx, None, src.device_ptr(), N.DTYPE_U8, rows * pitch, SEED, 900, 0.0, 256.0))
+    tin = TensorHandle.new(src, (rows, cols), (pitch, 1), ElemType.U8)
+    out = ops.into_contiguous(client, tin)
+    assert ops.copy_plan(client, tin, out) == (N.COPY_PATH_ROWS, 16)
+    for r in (0, 1, 2047, 4095, 4096, 4097, 8199):          # rows either side of linear index 2^32 = row 4096
+        a = _window(client, src, r * pitch, cols)
+        b = _window(client, out.handle, r * cols, cols)
+        assert a.any() and np.array_equal(a, b), r
+    del out
+    # the same with odd rows (2^20 - 1 bytes, pitch 2^20 + 4095): one-byte accesses, more than 2^32 of them
+    todd = TensorHandle.new(src, (4400, cols - 1), (pitch - 1, 1), ElemType.U8)
+    out = ops.into_contiguous(client, todd)
+    assert ops.copy_plan(client, todd, out) == (N.COPY_PATH_ROWS, 1)
+    for r in (0, 4095, 4096, 4097, 4399):
+        a = _window(client, src, r * (pitch - 1), cols - 1)
+        b = _window(client, out.handle, r * (cols - 1), cols - 1)
+        assert np.array_equal(a, b), r
+    del out, todd
+    # packed gather: every second byte of the first 2 x (2^32 + 8192) bytes of the same buffer
+    n = (1 << 32) + 8192
+    tg = TensorHandle.new(src, (n,), (2,), ElemType.U8)
+    g = ops.into_contiguous(client, tg)
+    assert ops.copy_plan(client, tg, g) == (N.COPY_PATH_GENERIC, 4)
+    for start in (0, (1 << 31) - 4096, (1 << 32) - 4096, (1 << 32) + 4096):
+        a = _window(client, src, 2 * start, 8192)[::2]
+        b = _window(client, g.handle, start, 4096)
+        assert np.array_equal(a, b), start
+    del g, tg, tin, src
+    client.memory_cleanup()
+    # tiles: [65536 + 256, 65536] one-byte transpose (4.3e9 elements), then back: the round trip is the identity
+    p, q = 65536 + 256, 65536
+    x = client.empty(p * q)
+    client._s.check(client.lib.mi355_fill_uniform(client.ctx, None, x.device_ptr(), N.DTYPE_U8, p * q, SEED, 901, 0.0, 256.0))
+    tx = TensorHandle.new_contiguous((q, p), x, ElemType.U8)               # stored [q][p]
+    ty = ops.into_contiguous(client, tx.permute([1, 0]))                    # [p][q]
+    assert ops.copy_plan(client, tx.permute([1, 0]), ty) == (N.COPY_PATH_TRANSPOSE, 16)
+    for q0, p0 in ((0, 0), (65536 - 256, 65536), (40000, 12345), (65000, 65700)):
+        blk = _window(client, x, q0 * p, 256 * p).reshape(256, p)           # input rows q0 .. q0 + 255
+        for pp in (p0, p0 + 1, p0 + 77):
+            got = _window(client, ty.handle, pp * q + q0, 256)              # output row pp, columns q0 .. q0 + 255
+            assert np.array_equal(got, blk[:, pp]), (q0, pp)
+    tz = ops.into_contiguous(client, ty.permute([1, 0]))
+    for start in (0, (1 << 32) - 65536, p * q - 65536, 3 * (1 << 30) + 12345):
+        assert np.array_equal(_window(client, x, start, 65536), _window(client, tz.handle, start, 65536)), start
+    del tx, ty, tz, x
+    client.memory_cleanup()
