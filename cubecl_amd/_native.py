@@ -188,6 +188,7 @@ PROTOTYPES = {
     "mi355_gemm_tail_plan": (C.c_int32, [C.POINTER(GemmDesc), _I32P, C.POINTER(C.c_int64), _I32P]),
     "mi355_gemm_scaled": (C.c_int32, [_P, _P, C.POINTER(GemmScaledDesc), _P, _P, _P, _P, _P]),
     "mi355_gemm_scaled_select": (C.c_int32, [_P, C.POINTER(GemmScaledDesc), _I32P]),
+    "mi355_fill_identity": (C.c_int32, [_P, _P, _P, C.c_int32, C.c_uint64, C.c_uint64]),
     "mi355_copy_strided": (C.c_int32, [_P, _P, _P, C.POINTER(TensorLayout), _P, C.POINTER(TensorLayout), C.c_int32]),
     "mi355_copy_strided_plan": (C.c_int32, [_P, C.POINTER(TensorLayout), _P, C.POINTER(TensorLayout), C.c_int32, _I32P, _I32P]),
     "mi355_copy_packed": (C.c_int32, [_P, _P, _P, C.POINTER(TensorLayout), _P, C.POINTER(TensorLayout), C.POINTER(C.c_int64),

@@ -92,6 +92,18 @@ uint64_t host_splitmix64(uint64_t x)
     return x ^ (x >> 31);
 }
 
+// Identity matrix (crates/cubecl-std/src/tensor/identity.rs:8-34): out[r][c] = (r == c), rows `ld` elements apart.
+// T carries the element's bits; `one` is the dtype's representation of 1.
+template <typename T>
+__global__ void __launch_bounds__(256) identity_kernel(T *__restrict__ out, uint64_t dim, uint64_t ld, T one)
+{
+    const uint64_t total = dim * dim, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const uint64_t r = i / dim, c = i - r * dim;
+        out[r * ld + c] = r == c ? one : (T)0;
+    }
+}
+
 }  // namespace
 
 MI355_API int32_t mi355_fill_uniform(mi355_ctx *ctx, mi355_stream stream, void *dst, int32_t dtype, uint64_t n,
@@ -168,5 +180,35 @@ MI355_API int32_t mi355_cast(mi355_ctx *ctx, mi355_stream stream, const void *sr
     CAST_CASE(MI355_DTYPE_F8E5M2, MI355_DTYPE_F16)
     if (!launched) return fail(ctx, MI355_E_UNSUPPORTED, "mi355_cast: unsupported %d -> %d", src_dtype, dst_dtype);
     check_launch(ctx, "mi355_cast");
+    return MI355_OK;
+}
+
+MI355_API int32_t mi355_fill_identity(mi355_ctx *ctx, mi355_stream stream, void *out, int32_t dtype, uint64_t dim, uint64_t ld)
+{
+    MI355_REQUIRE_CTX(ctx);
+    if (dim == 0) return MI355_OK;
+    if (!out) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_fill_identity: out is NULL");
+    if (ld < dim) return fail(ctx, MI355_E_UNSUPPORTED_STRIDES, "mi355_fill_identity: row stride %llu < dim %llu", (unsigned long long)ld,
+                              (unsigned long long)dim);
+    hipStream_t s = stream_of(ctx, stream);
+    const uint32_t grid = grid_for(ctx, dim * dim);
+    switch (dtype) {
+    case MI355_DTYPE_F32: hipLaunchKernelGGL(identity_kernel<uint32_t>, dim3(grid), dim3(256), 0, s, (uint32_t *)out, dim, ld, 0x3F800000u); break;
+    case MI355_DTYPE_I32: case MI355_DTYPE_U32:
+        hipLaunchKernelGGL(identity_kernel<uint32_t>, dim3(grid), dim3(256), 0, s, (uint32_t *)out, dim, ld, 1u); break;
+    case MI355_DTYPE_BF16: hipLaunchKernelGGL(identity_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, (uint16_t *)out, dim, ld, (uint16_t)0x3F80); break;
+    case MI355_DTYPE_F16: hipLaunchKernelGGL(identity_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, (uint16_t *)out, dim, ld, (uint16_t)0x3C00); break;
+    case MI355_DTYPE_F64:
+        hipLaunchKernelGGL(identity_kernel<uint64_t>, dim3(grid), dim3(256), 0, s, (uint64_t *)out, dim, ld, 0x3FF0000000000000ull); break;
+    case MI355_DTYPE_I64: case MI355_DTYPE_U64:
+        hipLaunchKernelGGL(identity_kernel<uint64_t>, dim3(grid), dim3(256), 0, s, (uint64_t *)out, dim, ld, 1ull); break;
+    case MI355_DTYPE_U8: case MI355_DTYPE_I8:
+        hipLaunchKernelGGL(identity_kernel<uint8_t>, dim3(grid), dim3(256), 0, s, (uint8_t *)out, dim, ld, (uint8_t)1); break;
+    case MI355_DTYPE_F8E4M3: hipLaunchKernelGGL(identity_kernel<uint8_t>, dim3(grid), dim3(256), 0, s, (uint8_t *)out, dim, ld, (uint8_t)0x38); break;
+    case MI355_DTYPE_F8E5M2: hipLaunchKernelGGL(identity_kernel<uint8_t>, dim3(grid), dim3(256), 0, s, (uint8_t *)out, dim, ld, (uint8_t)0x3C); break;
+    default:
+        return fail(ctx, MI355_E_UNSUPPORTED, "mi355_fill_identity: unsupported dtype %d", dtype);
+    }
+    check_launch(ctx, "mi355_fill_identity");
     return MI355_OK;
 }

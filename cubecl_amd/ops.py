@@ -288,6 +288,19 @@ def plane_reduce(client: ComputeClient, input: TensorHandle, output: TensorHandl
                                                       C.c_void_p(output.device_ptr()), n, active, op))
 
 
+def identity(client: ComputeClient, output: TensorHandle) -> None:
+    """tensor::identity::launch (crates/cubecl-std/src/tensor/identity.rs:36-86): `output`, a square matrix (possibly with
+    pitched rows), becomes the identity matrix of its dtype."""
+    if output.rank() != 2:
+        raise ServerError(N.E_INVALID_ARGUMENT, "identity: input should be a matrix")
+    if output.shape[0] != output.shape[1]:
+        raise ServerError(N.E_INVALID_ARGUMENT, "identity: input should be a square matrix")
+    if output.strides[1] != 1 and output.shape[1] > 1:
+        raise ServerError(N.E_UNSUPPORTED_STRIDES, "identity: the matrix must be row-major")
+    client._s.check(client.lib.mi355_fill_identity(client.ctx, client.stream, C.c_void_p(output.device_ptr()), int(output.dtype),
+                                                   output.shape[0], max(output.strides[0], output.shape[1])))
+
+
 # ---- strided copies (crates/cubecl-std/src/tensor/contiguous/) -------------------------------------------------------
 def copy_into(client: ComputeClient, input: TensorHandle, output: TensorHandle) -> None:
     """copy_into (contiguous/launch.rs:40-56): element q of `input`'s linear view goes to element q of `output`'s linear

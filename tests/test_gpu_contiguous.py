@@ -244,3 +244,41 @@ def test_matmul_takes_highly_permuted_operands(client, oracle):
     ops.matmul(client, ta, tb, tc)
     want = np.einsum("bmk,bkn->bmn", a.astype(np.float64), w.astype(np.float64))
     assert np.allclose(tc.to_numpy(client), want, rtol=1e-5, atol=1e-5)
+
+
+# ---- tensor::identity (crates/cubecl-std/src/tests/tensor/identity.rs) ----------------------------------------------------
+ONE = {ElemType.F32: (np.float32, 1.0), ElemType.F64: (np.float64, 1.0), ElemType.F16: (np.float16, 1.0), ElemType.I32: (np.int32, 1),
+       ElemType.U32: (np.uint32, 1), ElemType.I64: (np.int64, 1), ElemType.U8: (np.uint8, 1), ElemType.BF16: (np.uint16, 0x3F80),
+       ElemType.F8E4M3: (np.uint8, 0x38), ElemType.F8E5M2: (np.uint8, 0x3C)}
+
+
+@pytest.mark.parametrize("dim", [4, 16, 256, 1024])            # test_tiny / _small / _normal / _large (test_macros/identity.rs:17-35)
+def test_identity(client, dim):
+    for dt, (npt, one) in ONE.items():
+        t = TensorHandle.empty(client, (dim, dim), dt)          # pitched when the rows ask for it, as in the reference test
+        ops.identity(client, t)
+        want = np.zeros((dim, dim), dtype=npt)
+        want[np.arange(dim), np.arange(dim)] = one              # identity_cpu (test_utils.rs:3-15): every (dim + 1)-th element
+        assert np.array_equal(t.to_numpy(client), want), (dt, dim)
+
+
+def test_identity_pitched_rows_and_matmul(client, oracle):
+    # odd dim -> pitched rows; the padding between rows is left alone, and I x B returns B's bits through the GEMM
+    dim = 100
+    t = TensorHandle.empty(client, (dim, dim), ElemType.F32)
+    assert t.strides[0] > dim
+    raw = TensorHandle.new_contiguous((dim * t.strides[0],), t.handle, ElemType.F32)
+    client.write(t.handle, np.full(t.handle.size // 4, 7.0, dtype=np.float32))
+    ops.identity(client, t)
+    got = raw.to_numpy(client)[: (dim - 1) * t.strides[0] + dim].copy()
+    img = np.full(dim * t.strides[0], 7.0, dtype=np.float32)
+    img2 = img.reshape(dim, t.strides[0])
+    img2[:, :dim] = np.eye(dim, dtype=np.float32)
+    assert np.array_equal(got, img[: got.size])
+    b = oracle.fill_uniform(dim * 40, 5, -1, 1).reshape(dim, 40)
+    tb = TensorHandle.from_numpy(client, b)
+    tc = TensorHandle.zeros(client, (dim, 40), ElemType.F32)
+    ops.matmul(client, t, tb, tc)
+    assert np.array_equal(tc.to_numpy(client), b)
+    with pytest.raises(ServerError):
+        ops.identity(client, TensorHandle.new_contiguous((4, 5), client.empty(80), ElemType.F32))
