@@ -184,6 +184,7 @@ PROTOTYPES = {
     "mi355_fill_uniform": (C.c_int32, [_P, _P, _P, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, C.c_float]),
     "mi355_cast": (C.c_int32, [_P, _P, _P, C.c_int32, _P, C.c_int32, C.c_uint64]),
     "mi355_gemm": (C.c_int32, [_P, _P, C.POINTER(GemmDesc), _P, _P, _P]),
+    "mi355_gemm_add": (C.c_int32, [_P, _P, C.POINTER(GemmDesc), _P, _P, _P, _P]),
     "mi355_gemm_select": (C.c_int32, [_P, C.POINTER(GemmDesc), _I32P]),
     "mi355_gemm_tail_plan": (C.c_int32, [C.POINTER(GemmDesc), _I32P, C.POINTER(C.c_int64), _I32P]),
     "mi355_gemm_scaled": (C.c_int32, [_P, _P, C.POINTER(GemmScaledDesc), _P, _P, _P, _P, _P]),

@@ -272,6 +272,32 @@ MI355_API int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_ge
     }
 }
 
+// cmma::execute(a, b, c, d) at tensor level: D = A * B + C.  The selected kernel writes the f32 product into
+// library-owned per-stream scratch; gemm_add.hip adds C in f32 and rounds once to dtype_c.
+MI355_API int32_t mi355_gemm_add(mi355_ctx *ctx, mi355_stream stream, const mi355_gemm_desc *desc, const void *a, const void *b,
+                                 const void *c, void *d_out)
+{
+    MI355_REQUIRE_CTX(ctx);
+    int32_t rc = validate(ctx, desc, a, b, d_out);
+    if (rc != -1) return rc;
+    if (!c) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_gemm_add: the C operand is NULL");
+    hipStream_t s = stream_of(ctx, stream);
+    const mi355_gemm_desc &d = *desc;
+    void *prod = nullptr;
+    const size_t bytes = (size_t)d.batch * (size_t)d.m * (size_t)d.n * sizeof(float);
+    if (scratch_get(ctx, s, SCRATCH_PRODUCT, bytes, &prod) != MI355_OK)
+        return fail(ctx, MI355_E_UNSUPPORTED, "mi355_gemm_add: no scratch for the %zu-byte f32 product (inside a capture window?)", bytes);
+    mi355_gemm_desc pd = d;
+    pd.dtype_c = MI355_DTYPE_F32;
+    pd.ldc = d.n;
+    pd.stride_c = d.m * d.n;
+    rc = mi355_gemm(ctx, stream, &pd, a, b, prod);
+    if (rc != MI355_OK) return rc;
+    launch_add_c(s, static_cast<const float *>(prod), c, d_out, d.batch, d.m, d.n, d.dtype_c, d.ldc, d.stride_c);
+    check_launch(ctx, "mi355_gemm_add");
+    return MI355_OK;
+}
+
 // Introspection (no device needed): how mi355_gemm would cut a descriptor that AUTO resolves to the 256x256 kernel.
 MI355_API int32_t mi355_gemm_tail_plan(const mi355_gemm_desc *desc, int32_t *out_along_m, int64_t *out_main_extent, int32_t *out_splits)
 {

@@ -109,7 +109,7 @@ bool gemm_lp256w4_mx_supports(const mi355_gemm_scaled_desc &d, const void *a, co
 int32_t launch_gemm_lp256w4_mx(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_scaled_desc &d, const void *a, const void *sa_t,
                                int64_t stride_sa_t, const void *b, const void *sb_t, int64_t stride_sb_t, void *c);
 // library-owned per-stream scratch + operand re-layout (gemm_relayout.hip)
-enum { SCRATCH_SPLITK = 0, SCRATCH_RELAYOUT_A = 1, SCRATCH_RELAYOUT_B = 2, SCRATCH_SCALE_A = 3, SCRATCH_SCALE_B = 4 };
+enum { SCRATCH_SPLITK = 0, SCRATCH_RELAYOUT_A = 1, SCRATCH_RELAYOUT_B = 2, SCRATCH_SCALE_A = 3, SCRATCH_SCALE_B = 4, SCRATCH_PRODUCT = 5 };
 int32_t scratch_get(mi355_ctx *ctx, hipStream_t s, int kind, size_t bytes, void **out);
 void launch_transpose(hipStream_t s, const void *src, void *dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst,
                       int64_t batch, int64_t stride_src, int64_t stride_dst, int esz);
@@ -119,6 +119,9 @@ void launch_pad_copy(hipStream_t s, const void *src, void *dst, int64_t rows, in
 int32_t splitk_scratch(mi355_ctx *ctx, hipStream_t s, size_t bytes, float **out);
 void launch_splitk_fold(hipStream_t s, const float *slabs, uint32_t splits, int64_t slab_stride, int64_t batch, int64_t m,
                         int64_t n, void *c, int32_t dtype_c, int64_t ldc, int64_t stride_c);
+// D = product + C, one rounding (gemm_add.hip)
+void launch_add_c(hipStream_t s, const float *prod, const void *c_in, void *d_out, int64_t batch, int64_t m, int64_t n,
+                  int32_t dtype_c, int64_t ldc, int64_t stride_c);
 bool gemm_f32_mfma_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 bool gemm_lp128_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 bool gemm_lp256_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);

@@ -70,8 +70,11 @@ def _kernel_ready(client: ComputeClient, t: TensorHandle, name: str):
 
 
 def matmul(client: ComputeClient, lhs: TensorHandle, rhs: TensorHandle, out: TensorHandle,
-           algo: int = N.GEMM_ALGO_AUTO) -> None:
-    """out[.., m, n] = sum_k lhs[.., m, k] * rhs[.., k, n]   (f32 accumulate).
+           algo: int = N.GEMM_ALGO_AUTO, acc: Optional[TensorHandle] = None) -> None:
+    """out[.., m, n] = sum_k lhs[.., m, k] * rhs[.., k, n]   (f32 accumulate)   [+ acc[.., m, n]].
+
+    `acc` is the C operand of cmma::execute(a, b, c, d) (frontend/cmma.rs:1066-1110): the product plus acc is formed
+    in f32 and rounded once to out's dtype; acc has out's dtype and may be `out` itself (in-place accumulate).
 
     Layouts come from strides alone: a `rhs` of logical shape [k, n] with strides [1, k] is the
     reference tests' "ColMajor B" / Out = Lhs * Rhs^T form (cmma.rs:23) and takes the fast
@@ -95,8 +98,25 @@ def matmul(client: ComputeClient, lhs: TensorHandle, rhs: TensorHandle, out: Ten
     desc = N.GemmDesc(m=m, n=n, k=k, batch=batch, lda=lda, ldb=ldb, ldc=ldc,
                       stride_a=sa if ba == batch else 0, stride_b=sb if bb == batch else 0, stride_c=sc,
                       dtype_ab=int(lhs.dtype), dtype_c=int(out.dtype), trans_a=int(ta), trans_b=int(tb), algo=algo)
-    client._s.check(client.lib.mi355_gemm(client.ctx, client.stream, C.byref(desc), C.c_void_p(lhs.device_ptr()),
-                                          C.c_void_p(rhs.device_ptr()), C.c_void_p(out.device_ptr())))
+    if acc is None:
+        client._s.check(client.lib.mi355_gemm(client.ctx, client.stream, C.byref(desc), C.c_void_p(lhs.device_ptr()),
+                                              C.c_void_p(rhs.device_ptr()), C.c_void_p(out.device_ptr())))
+        return
+    if acc.dtype != out.dtype or tuple(acc.shape) != tuple(out.shape):
+        raise ServerError(N.E_INVALID_ARGUMENT, "matmul: acc must have out's shape and dtype")
+    if tuple(acc.strides) != tuple(out.strides):
+        acc = _like(client, acc, out)                       # bring C into D's layout (copy_into)
+    client._s.check(client.lib.mi355_gemm_add(client.ctx, client.stream, C.byref(desc), C.c_void_p(lhs.device_ptr()),
+                                              C.c_void_p(rhs.device_ptr()), C.c_void_p(acc.device_ptr()),
+                                              C.c_void_p(out.device_ptr())))
+
+
+def _like(client: ComputeClient, t: TensorHandle, model: TensorHandle) -> TensorHandle:
+    """A copy of `t` laid out with `model`'s strides."""
+    span = sum((d - 1) * s for d, s in zip(model.shape, model.strides)) + 1 if model.num_elems() else 0
+    out = TensorHandle.new(client.empty(span * t.dtype.size()), model.shape, model.strides, t.dtype)
+    copy_into(client, t, out)
+    return out
 
 
 def matmul_scaled(client: ComputeClient, lhs: TensorHandle, lhs_scales: TensorHandle, rhs: TensorHandle,

@@ -340,6 +340,12 @@ enum {
 
 int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_gemm_desc *desc,
                    const void *a, const void *b, void *c);
+/* cmma::execute(a, b, c, d) at tensor level (frontend/cmma.rs:1066-1110): D[b] = A[b] * B[b] + C[b].
+ * C and D share the descriptor's ldc / stride_c / dtype_c; `c` may be the same buffer as `d` (in-place accumulate),
+ * otherwise the two must not overlap.  A * B + C is formed in f32 -- the reference's accumulator fragment -- and rounded
+ * once to dtype_c.  The f32 product goes through library-owned scratch (batch x M x N x 4 bytes per stream). */
+int32_t mi355_gemm_add(mi355_ctx *ctx, mi355_stream stream, const mi355_gemm_desc *desc,
+                       const void *a, const void *b, const void *c, void *d);
 /* which kernel AUTO resolves to for a descriptor (for tests / logs) */
 int32_t mi355_gemm_select(mi355_ctx *ctx, const mi355_gemm_desc *desc, int32_t *out_algo);
 /* How a descriptor that resolves to the 256x256 kernel is cut when its last round of tiles is only partly filled (pure

@@ -204,6 +204,20 @@ def gemm(a: np.ndarray, b: np.ndarray, m: int, n: int, k: int, *, dtype_ab: int 
     return c
 
 
+def gemm_add(a, b, c, m: int, n: int, k: int, *, dtype_ab: int = DT_F32, dtype_c: int = DT_F32, trans_b: bool = False,
+             batch: int = 1) -> np.ndarray:
+    """D = A * B + C, cmma::execute(a, b, c, d) (crates/cubecl-core/src/frontend/cmma.rs:1066-1110): the accumulator
+    fragment is f32, so the product (oracle_gemm's sequential f32 sum, runtime_tests/cmma.rs:695-722) and C meet in f32 and
+    the result is rounded once to dtype_c.  Contiguous operands; c holds dtype_c values (bit patterns for 16-bit)."""
+    prod = gemm(a, b, m, n, k, dtype_ab=dtype_ab, dtype_c=DT_F32, trans_b=trans_b, batch=batch)
+    c = np.asarray(c).reshape(-1)
+    cw = c.astype(np.float32) if dtype_c == DT_F32 else (from_bf16(c) if dtype_c == DT_BF16 else from_f16(c))
+    d = (prod.reshape(-1) + cw).astype(np.float32)
+    if dtype_c == DT_F32:
+        return d
+    return to_bf16(d) if dtype_c == DT_BF16 else to_f16(d)
+
+
 def sum_sequential(x: np.ndarray) -> float:
     x = np.ascontiguousarray(x, dtype=np.float32)
     return float(lib().oracle_sum_f32_sequential(_p(x), x.size))

@@ -195,6 +195,9 @@ extern "C" {
     // Hot-path operations
     pub fn mi355_gemm(ctx: *mut mi355_ctx, stream: mi355_stream, desc: *const mi355_gemm_desc, a: *const c_void,
                       b: *const c_void, c: *mut c_void) -> i32;
+    // cmma::execute(a, b, c, d): D = A * B + C (frontend/cmma.rs:1066-1110)
+    pub fn mi355_gemm_add(ctx: *mut mi355_ctx, stream: mi355_stream, desc: *const mi355_gemm_desc, a: *const c_void, b: *const c_void,
+                          c: *const c_void, d: *mut c_void) -> i32;
     pub fn mi355_reduce_workspace_bytes(ctx: *mut mi355_ctx, n: u64, out_bytes: *mut u64) -> i32;
     pub fn mi355_reduce_sum_f32(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const f32, n: u64, out: *mut f32,
                                 workspace: *mut c_void, workspace_bytes: u64) -> i32;

@@ -654,3 +654,73 @@ def test_partly_filled_last_round_is_split_and_still_exact_enough(client, oracle
     ops.matmul(client, a, bt, c1)
     ops.matmul(client, a, bt, c2)
     assert np.array_equal(c1.to_numpy(client), c2.to_numpy(client))
+
+
+# ---- D = A * B + C: the C operand of cmma::execute(a, b, c, d) (frontend/cmma.rs:1066-1110) --------------------
+@pytest.mark.parametrize("dtype,out_dtype", [(ElemType.F32, ElemType.F32), (ElemType.BF16, ElemType.F32), (ElemType.BF16, ElemType.BF16),
+                                             (ElemType.F16, ElemType.F16), (ElemType.F8E4M3, ElemType.BF16)])
+@pytest.mark.parametrize("m,n,k,batch,ldc", [(16, 16, 16, 1, 16), (256, 512, 128, 1, 512), (300, 257, 96, 2, 264), (1024, 1024, 512, 3, 1024),
+                                             (64, 100, 0, 1, 100)])
+def test_matmul_add(client, oracle, dtype, out_dtype, m, n, k, batch, ldc):
+    a_host = oracle.fill_uniform(batch * m * max(k, 1), 61, -1.0, 1.0).reshape(batch, m, max(k, 1))[:, :, :k]
+    b_host = oracle.fill_uniform(batch * n * max(k, 1), 62, -1.0, 1.0).reshape(batch, n, max(k, 1))[:, :, :k]
+    c_host = oracle.fill_uniform(batch * m * ldc, 63, -4.0, 4.0).reshape(batch, m, ldc)
+    ta, a_val = _to_dev(client, oracle, np.ascontiguousarray(a_host), dtype)
+    tb, b_val = _to_dev(client, oracle, np.ascontiguousarray(b_host), dtype)
+    tc, c_val = _to_dev(client, oracle, c_host, out_dtype)
+    a_t = TensorHandle.new(ta.handle, (batch, m, k), (m * k, k, 1), dtype)
+    b_t = TensorHandle.new(tb.handle, (batch, k, n), (n * k, 1, k), dtype)                 # stored [n][k]
+    c_t = TensorHandle.new(tc.handle, (batch, m, n), (m * ldc, ldc, 1), out_dtype)
+    d_h = client.empty(batch * m * ldc * out_dtype.size())
+    client._s.check(client.lib.mi355_memset(client.ctx, None, d_h.device_ptr(), 0xEE, d_h.size))
+    d_t = TensorHandle.new(d_h, (batch, m, n), (m * ldc, ldc, 1), out_dtype)
+    ops.matmul(client, a_t, b_t, d_t, acc=c_t)
+    np_dt = np.float32 if out_dtype == ElemType.F32 else np.uint16
+    got_all = client.read_one(d_h).view(np_dt).reshape(batch, m, ldc)
+    for b in range(batch):
+        A, Bm = a_val[b].astype(np.float64), b_val[b].astype(np.float64).T
+        Cm = c_val[b][:, :n].astype(np.float64)
+        ref = A @ Bm + Cm
+        bound = np.abs(A) @ np.abs(Bm) + np.abs(Cm)
+        got = _decode(oracle, got_all[b][:, :n], out_dtype)
+        if out_dtype == ElemType.F32:
+            assert np.all(np.abs(got - ref) <= REL * bound + 1e-30)
+        else:
+            ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(ref), 1e-30))) - (7 if out_dtype == ElemType.BF16 else 10))
+            assert np.all(np.abs(got - ref) <= ulp + REL * bound)
+        if ldc > n:
+            assert np.all(got_all[b][:, n:].view(np.uint8) == 0xEE)
+    # in place: D aliases C
+    ops.matmul(client, a_t, b_t, c_t, acc=c_t)
+    assert np.array_equal(client.read_one(tc.handle).view(np_dt).reshape(batch, m, ldc)[:, :, :n], got_all[:, :, :n])
+
+
+def test_matmul_add_exact_small_integers_and_oracle(client, oracle):
+    # integer-valued operands: every product, the sum and the addition are exact in f32 -> bit equality with the oracle's
+    # restatement (oracle.gemm_add), for f32 and for bf16 output (values below 256 are exact in bf16)
+    m, n, k = 64, 48, 32
+    a = (np.arange(m * k) % 5 - 2).astype(np.float32).reshape(m, k)
+    b = (np.arange(n * k) % 3 - 1).astype(np.float32).reshape(n, k)
+    c = (np.arange(m * n) % 7 - 3).astype(np.float32).reshape(m, n)
+    for dt, odt, odt_o in ((ElemType.F32, ElemType.F32, oracle.DT_F32), (ElemType.BF16, ElemType.BF16, oracle.DT_BF16)):
+        ta, _ = _to_dev(client, oracle, a, dt)
+        tb, _ = _to_dev(client, oracle, b, dt)
+        tc, _ = _to_dev(client, oracle, c, odt)
+        b_t = TensorHandle.new(tb.handle, (k, n), (1, k), dt)
+        d = TensorHandle.new_contiguous((m, n), client.empty(m * n * odt.size()), odt)
+        ops.matmul(client, ta, b_t, d, acc=tc)
+        a_bits = a if dt == ElemType.F32 else oracle.to_bf16(a)
+        b_bits = b if dt == ElemType.F32 else oracle.to_bf16(b)
+        c_bits = c if odt == ElemType.F32 else oracle.to_bf16(c)
+        want = oracle.gemm_add(a_bits, b_bits, c_bits, m, n, k, dtype_ab=int(dt), dtype_c=odt_o, trans_b=True)
+        assert np.array_equal(d.to_numpy(client).reshape(-1), want[: m * n])
+    # acc in another layout than out (pitched) is brought into out's layout first; wrong dtype / shape are refused
+    tcp = TensorHandle.new(client.create_from_slice(np.pad(c, ((0, 0), (0, 16)))), (m, n), (n + 16, 1), ElemType.F32)
+    ta, _ = _to_dev(client, oracle, a, ElemType.F32)
+    tb, _ = _to_dev(client, oracle, b, ElemType.F32)
+    d = TensorHandle.new_contiguous((m, n), client.empty(m * n * 4), ElemType.F32)
+    ops.matmul(client, ta, TensorHandle.new(tb.handle, (k, n), (1, k), ElemType.F32), d, acc=tcp)
+    assert np.array_equal(d.to_numpy(client), a @ b.T + c)
+    with pytest.raises(ServerError):
+        ops.matmul(client, ta, TensorHandle.new(tb.handle, (k, n), (1, k), ElemType.F32), d,
+                   acc=TensorHandle.new_contiguous((m, n), client.empty(m * n * 2), ElemType.BF16))
