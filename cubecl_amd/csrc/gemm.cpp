@@ -283,6 +283,12 @@ MI355_API int32_t mi355_gemm_add(mi355_ctx *ctx, mi355_stream stream, const mi35
     if (!c) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_gemm_add: the C operand is NULL");
     hipStream_t s = stream_of(ctx, stream);
     const mi355_gemm_desc &d = *desc;
+    // f32 output on the 256x256 kernel: C is added inside the kernel's epilogue (one extra read of C, nothing else)
+    if (d.dtype_c == MI355_DTYPE_F32 && (d.algo == MI355_GEMM_ALGO_AUTO || d.algo == MI355_GEMM_ALGO_LP_256W4) &&
+        (reinterpret_cast<uintptr_t>(c) & 15u) == 0 && gemm_lp256w4_supports(d, a, b, d_out) &&
+        (d.algo == MI355_GEMM_ALGO_LP_256W4 || select_auto(d, a, b, d_out) == MI355_GEMM_ALGO_LP_256W4 ||
+         select_auto(d, a, b, d_out) == MI355_GEMM_ALGO_LP_256P))
+        return launch_gemm_lp256w4(ctx, s, d, a, b, d_out, c);
     void *prod = nullptr;
     const size_t bytes = (size_t)d.batch * (size_t)d.m * (size_t)d.n * sizeof(float);
     if (scratch_get(ctx, s, SCRATCH_PRODUCT, bytes, &prod) != MI355_OK)

@@ -30,6 +30,7 @@ struct gemm_args {
     int64_t split_c_stride;  // elements between the partial slabs of consecutive K slices
     const void *sa = nullptr, *sb = nullptr;   // MX: re-arranged ue8m0 scales ST[K-tile][padded row][blocks per K-tile row]
     int64_t stride_sa = 0, stride_sb = 0;      // bytes between batch entries of those
+    const void *c_in = nullptr;                // f32 C only: D = A * B + c_in (same layout as c; may alias it), lp256w4
 };
 
 // MI355X dispatches workgroup b to XCD b % 8, each XCD with a private 4 MiB L2
@@ -100,7 +101,8 @@ int32_t launch_gemm_generic(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc
 int32_t launch_gemm_f32_mfma(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 int32_t launch_gemm_lp256(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
-int32_t launch_gemm_lp256w4(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
+int32_t launch_gemm_lp256w4(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c,
+                            const void *c_in = nullptr);
 int32_t launch_gemm_lp256p(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 bool gemm_lp256p_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 bool gemm_lp256w4_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);

@@ -582,8 +582,27 @@ gemm_lp256w4_kernel(gemm_args g)
         const int64_t col0 = n0 + wn * 128 + (lane % LPR) * EPP;
         const int ncols = (int)max((int64_t)0, min((int64_t)EPP, g.n - col0));   // valid elements of my piece
         const bool interior = (m0 + BM <= g.m) && (n0 + BN <= g.n);       // wave-uniform fast path
+        // D = A * B + c_in (f32 C only, the C operand of cmma::execute): the 32 / RPI pieces of c_in that this lane will
+        // add in block i are fetched before the block's accumulators are staged, so one memory latency per block hides
+        // behind the LDS transposition.  c_in has C's layout and may be C itself.
+        const char *cin = nullptr;
+        if constexpr (DT_C == MI355_DTYPE_F32) cin = static_cast<const char *>(g.c_in);
+        const int64_t cin_off = crow - C;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            f32x4 pre[DT_C == MI355_DTYPE_F32 ? 32 / RPI : 1];
+            if constexpr (DT_C == MI355_DTYPE_F32) {
+                if (cin) {
+                    const char *csrc = cin + cin_off + (int64_t)i * 32 * g.ldc * CSZ;
+#pragma unroll
+                    for (int it = 0; it < 32 / RPI; ++it) {
+                        if (interior || (row0 + i * 32 + it * RPI < g.m && ncols == EPP))
+                            pre[it] = *reinterpret_cast<const f32x4 *>(csrc + it * cstep);
+                        else
+                            pre[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -606,17 +625,27 @@ gemm_lp256w4_kernel(gemm_args g)
             char *cdst = crow + (int64_t)i * 32 * g.ldc * CSZ;
 #pragma unroll
             for (int it = 0; it < 32 / RPI; ++it) {
-                const u32x4 v = *reinterpret_cast<const u32x4 *>(rd + it * RPI * RS);
+                u32x4 v = *reinterpret_cast<const u32x4 *>(rd + it * RPI * RS);
                 if (!interior) {
                     if (row0 + i * 32 + it * RPI >= g.m || ncols <= 0) continue;
                     if (ncols < EPP) {
 #pragma unroll
                         for (int e = 0; e < EPP; ++e) {                    // static indices only (guide rule 20)
                             if (e >= ncols) break;
-                            if constexpr (CSZ == 4) reinterpret_cast<uint32_t *>(cdst + it * cstep)[e] = v[e];
-                            else reinterpret_cast<uint16_t *>(cdst + it * cstep)[e] = (uint16_t)(v[e >> 1] >> ((e & 1) * 16));
+                            if constexpr (CSZ == 4) {
+                                float x = __uint_as_float(v[e]);
+                                if (cin) x += reinterpret_cast<const float *>(cin + cin_off + (int64_t)i * 32 * g.ldc * CSZ + it * cstep)[e];
+                                reinterpret_cast<float *>(cdst + it * cstep)[e] = x;
+                            } else
+                                reinterpret_cast<uint16_t *>(cdst + it * cstep)[e] = (uint16_t)(v[e >> 1] >> ((e & 1) * 16));
                         }
                         continue;
+                    }
+                }
+                if constexpr (DT_C == MI355_DTYPE_F32) {
+                    if (cin) {
+                        const f32x4 sum = __builtin_bit_cast(f32x4, v) + pre[it];
+                        v = __builtin_bit_cast(u32x4, sum);
                     }
                 }
                 if ((W4_ABL & 16) && g.m > 1) continue;       // dev ablation 16: no C stores (timing only)
@@ -684,12 +713,15 @@ bool gemm_lp256w4_supports(const mi355_gemm_desc &d, const void *a, const void *
 }
 
 int32_t launch_gemm_lp256w4(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b,
-                            void *c)
+                            void *c, const void *c_in)
 {
     if (!gemm_lp256w4_supports(d, a, b, c))
         return fail(ctx, MI355_E_UNSUPPORTED, "lp256w4 GEMM: shape/layout not supported by this kernel");
+    if (c_in && (d.dtype_c != MI355_DTYPE_F32 || (reinterpret_cast<uintptr_t>(c_in) & 15u)))
+        return fail(ctx, MI355_E_UNSUPPORTED, "lp256w4 GEMM: the in-kernel C operand needs f32 output and 16-byte alignment");
     gemm_args g{};
     g.a = a; g.b = b; g.c = c;
+    g.c_in = c_in;
     g.m = d.m; g.n = d.n; g.k = d.k;
     g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc;
     g.stride_a = d.stride_a; g.stride_b = d.stride_b; g.stride_c = d.stride_c;

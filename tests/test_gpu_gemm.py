@@ -724,3 +724,33 @@ def test_matmul_add_exact_small_integers_and_oracle(client, oracle):
     with pytest.raises(ServerError):
         ops.matmul(client, ta, TensorHandle.new(tb.handle, (k, n), (1, k), ElemType.F32), d,
                    acc=TensorHandle.new_contiguous((m, n), client.empty(m * n * 2), ElemType.BF16))
+
+
+@pytest.mark.parametrize("dtype", [ElemType.BF16, ElemType.F32, ElemType.F8E4M3])
+@pytest.mark.parametrize("m,n,k,batch,algo", [(256, 512, 256, 1, "lp256w4"), (300, 260, 128, 2, "lp256w4"), (4096, 2304, 256, 1, "auto"),
+                                              (4000, 3500, 256, 1, "auto"), (1024, 768, 512, 5, "auto")])
+def test_matmul_add_f32_inside_the_256_kernel(client, oracle, dtype, m, n, k, batch, algo):
+    """f32 output on the 256x256 kernel adds C in its epilogue (no product scratch): whole and ragged tiles, batches, in place."""
+    a_host = oracle.fill_uniform(batch * m * k, 71, -1.0, 1.0).reshape(batch, m, k)
+    b_host = oracle.fill_uniform(batch * n * k, 72, -1.0, 1.0).reshape(batch, n, k)
+    c_host = oracle.fill_uniform(batch * m * n, 73, -8.0, 8.0).reshape(batch, m, n)
+    ta, a_val = _to_dev(client, oracle, a_host, dtype)
+    tb, b_val = _to_dev(client, oracle, b_host, dtype)
+    tc = TensorHandle.from_numpy(client, c_host)
+    a_t = TensorHandle.new(ta.handle, (batch, m, k), (m * k, k, 1), dtype)
+    b_t = TensorHandle.new(tb.handle, (batch, k, n), (n * k, 1, k), dtype)
+    d_t = TensorHandle.new_contiguous((batch, m, n), client.empty(batch * m * n * 4), ElemType.F32)
+    ops.matmul(client, a_t, b_t, d_t, algo=ALGOS[algo], acc=tc)
+    got = d_t.to_numpy(client)
+    rows = np.unique(np.concatenate([np.arange(0, m, 97), [m - 1, min(m - 1, 255), min(m - 1, 256)]]))
+    for b in range(batch):
+        A, Bm = a_val[b][rows].astype(np.float64), b_val[b].astype(np.float64).T
+        ref = A @ Bm + c_host[b][rows].astype(np.float64)
+        bound = np.abs(A) @ np.abs(Bm) + np.abs(c_host[b][rows]).astype(np.float64)
+        assert np.all(np.abs(got[b][rows].astype(np.float64) - ref) <= REL * bound + 1e-30)
+    # the plain product plus C computed on the host in f32 is the same thing up to the last f32 rounding of the addition
+    p_t = TensorHandle.new_contiguous((batch, m, n), client.empty(batch * m * n * 4), ElemType.F32)
+    ops.matmul(client, a_t, b_t, p_t, algo=ALGOS[algo])
+    assert np.array_equal(got, p_t.to_numpy(client) + c_host)           # same kernel, same sum order: bit-equal
+    ops.matmul(client, a_t, b_t, tc, algo=ALGOS[algo], acc=tc)           # in place
+    assert np.array_equal(tc.to_numpy(client), got)
