@@ -6,6 +6,8 @@ Mirrors crates/cubecl-runtime/src/throughput/{base,curve}.rs and crates/cubecl-s
   * `measure_memory_curve`   std/throughput/base.rs:46-64   one probe per working set
   * `measure_peak_throughput` :79-141          copy / read / write / compute-direct / cmma / launch
   * `roofline_bounds` + `time_limit`   :147-170, tune/bounds_generator.rs:112-160
+  * `measure_peak_throughput(client, key)` / `device_throughput`   :30-44, :77-141   one probe, keyed and sampled as
+    `ThroughputBenchmarker` prescribes (cubecl_amd/roofline.py), cached per device
 
 The kernels are the library's probes (`mi355_probe_*`, cubecl_amd/csrc/probes.hip); everything here is the host
 logic around them.  A working set is measured the way the reference's `MemoryProbe` does it
@@ -21,20 +23,12 @@ from dataclasses import dataclass
 from typing import Iterable, List, Optional, Sequence
 
 from . import _native as N
+from .roofline import (KernelConfig, MemoryAccess, ThroughputBenchmarker, ThroughputCache, ThroughputKey, ThroughputMode,
+                       ThroughputValue)
 
 MIN_WORKING_SET = 8 * 1024                    # curve.rs:25
 DEFAULT_BUFFER_BYTES = 512 * 1024 * 1024      # throughput/base.rs:9
 PROBE_TILE_BYTES = 32 * 1024                  # the probes move whole 32 KiB tiles (probes.hip PR_BLOCK * PR_UNROLL * 16)
-
-
-class MemoryAccess(enum.Enum):
-    """throughput/base.rs `MemoryAccess`: how many buffers a pass touches."""
-    Copy = "copy"
-    Read = "read"
-    Write = "write"
-
-    def buffers(self) -> int:
-        return 2 if self is MemoryAccess.Copy else 1
 
 
 def working_set_sweep(cap: int) -> List[int]:
@@ -243,3 +237,83 @@ def roofline_bounds(client, work: Work, thresholds: Thresholds, *, dtype: int = 
     mem = curve.ceiling_at(work.bytes) if curve is not None else measure_working_set(client, MemoryAccess.Copy,
                                                                                      2 * DEFAULT_BUFFER_BYTES)
     return Bounds(measure_compute(client, dtype), float(mem or 0.0), measure_launch_overhead(client), work, thresholds)
+
+
+# ---- keyed peaks through the reference's sampling protocol ------------------------------------------------------------
+_MFMA_PROBE_TILE = {N.DTYPE_BF16: (32, 32, 16), N.DTYPE_F16: (32, 32, 16), N.DTYPE_F32: (32, 32, 2), N.DTYPE_F8E4M3: (32, 32, 64)}
+
+
+def _kernel_config(client, key: ThroughputKey, keep: list) -> Optional[KernelConfig]:
+    """The `build_kernel` of each runner (std/throughput/runners/*.rs): buffers + a closure that enqueues `iterations`
+    passes and returns the device seconds they took.  `ops_count` follows the reference's units: operations for the
+    compute keys, F32 ELEMENTS for the memory keys (`bytes_per_s` multiplies by the key's element size), launches for
+    the launch key.  None when this device has no probe for the key."""
+    lib, ctx, st = client.lib, client.ctx, client.stream
+    mode = key.mode
+    t = _Timer(client)
+    keep.append(t)
+    sink = client.empty(256)
+    sk = C.c_void_p(sink.device_ptr())
+    keep.append(sink)
+    if mode.kind in ("ComputeDirect", "ComputeCmma"):
+        iters, n_ops = 4096, C.c_uint64()
+        if mode.kind == "ComputeDirect":
+            if mode.dtype != N.DTYPE_F32:
+                return None
+            call = lambda _i: client._s.check(lib.mi355_probe_compute_direct(ctx, st, iters, sk, C.byref(n_ops)))
+        else:
+            d = mode.config.cmma_dims
+            if _MFMA_PROBE_TILE.get(mode.dtype) != (d.m, d.n, d.k) or mode.config.accumulator_type != N.DTYPE_F32:
+                return None
+            call = lambda _i: client._s.check(lib.mi355_probe_mfma(ctx, st, mode.dtype, iters, sk, C.byref(n_ops)))
+        call(0)                                               # fills n_ops
+        return KernelConfig(lambda iterations: t.run(call, iterations), int(n_ops.value))
+    if mode.kind == "Launch":
+        call = lambda _i: client._s.check(lib.mi355_probe_launch_overhead(ctx, st, 1, sk))
+        return KernelConfig(lambda iterations: t.run(call, iterations), 1)
+    access, working_set = mode.memory_probe()
+    per_buf = max(working_set // access.buffers(), PROBE_TILE_BYTES) // PROBE_TILE_BYTES * PROBE_TILE_BYTES
+    pool_bytes = max(DEFAULT_BUFFER_BYTES, per_buf)
+    windows = max(pool_bytes // per_buf, 1)
+    src = client.empty(pool_bytes)
+    dst = client.empty(pool_bytes) if access is MemoryAccess.Copy else None
+    keep.extend([src, dst])
+    client._s.check(lib.mi355_memset(ctx, st, C.c_void_p(src.device_ptr()), 0, pool_bytes))
+    sp, dp = src.device_ptr(), (dst.device_ptr() if dst is not None else 0)
+    cursor = [0]
+
+    def one(_i):
+        off = (cursor[0] % windows) * per_buf                 # the window keeps moving across samples: cold every pass
+        cursor[0] += 1
+        if access is MemoryAccess.Read:
+            client._s.check(lib.mi355_probe_memory_read(ctx, st, C.c_void_p(sp + off), per_buf, 1, sk))
+        elif access is MemoryAccess.Write:
+            client._s.check(lib.mi355_probe_memory_write(ctx, st, C.c_void_p(sp + off), per_buf))
+        else:
+            client._s.check(lib.mi355_probe_memory_copy(ctx, st, C.c_void_p(sp + off), C.c_void_p(dp + off), per_buf))
+    return KernelConfig(lambda iterations: t.run(one, iterations), per_buf * access.buffers() // 4)
+
+
+def measure_peak_throughput(client, key: ThroughputKey, *, cache_enabled: bool = True) -> ThroughputValue:
+    """std/throughput/base.rs:77-141: the peak this device attains for `key`, by the reference's protocol (plateau
+    warm-up, best of 20-200 samples), cached per device name; `ThroughputValue.ZERO` where no probe exists (the
+    reference returns it for a cmma key on a device without matrix instructions)."""
+    keep: list = []
+    try:
+        cfg = _kernel_config(client, key, keep)
+        if cfg is None:
+            return ThroughputValue.ZERO
+        props = client.properties()
+        cache = ThroughputCache.get_for_device(f"{props.name.decode()}#{props.device_index}")
+        return ThroughputBenchmarker(cache, cache_enabled).measure(key, cfg)
+    finally:
+        for k in keep:
+            if isinstance(k, _Timer):
+                k.close()
+        keep.clear()
+        client.memory_cleanup()
+
+
+def device_throughput(client, keys: Iterable[ThroughputKey]) -> List[ThroughputValue]:
+    """std/throughput/base.rs:30-44."""
+    return [measure_peak_throughput(client, k) for k in keys]

@@ -555,6 +555,52 @@ def test_memory_curve_and_roofline_bounds(client):
     assert 0.7e-3 < b.time_limit() < 1.6e-3                                   # the 8192^3 bf16 GEMM must beat this to count as good
 
 
+def test_keyed_peaks_by_the_reference_sampling_protocol_and_device_benchmark(client):
+    """`measure_peak_throughput` (std/throughput/base.rs:77-141) for every key kind, sampled as ThroughputBenchmarker
+    prescribes and cached per device; the `Benchmark` protocol with the device clock around the 1 GiB sum (config C4)."""
+    from cubecl_amd import _native as N, ops
+    from cubecl_amd import roofline as R, throughput as T
+    from cubecl_amd.benchmark import BenchmarkComputations, DeviceBenchmark, TimingMethod
+    K, M = R.ThroughputKey, R.ThroughputMode
+    tile = R.select_cmma_tile(client.features()["cmma"], N.DTYPE_BF16, N.DTYPE_BF16, N.DTYPE_F32, (8192, 8192, 8192))
+    assert tile == (32, 32, 16)
+    keys = [K(M.MemoryRead), K(M.MemoryWorkingSet(R.MemoryAccess.Copy, 256 << 20)), K(M.Launch),
+            R.compute_throughput_key(tile, N.DTYPE_BF16, N.DTYPE_F32), R.compute_throughput_key(None, N.DTYPE_BF16, N.DTYPE_F32)]
+    read, copy, launch, cmma, direct = T.device_throughput(client, keys)
+    assert 5.0e12 < read.bytes_per_s(keys[0]) < 8.0e12 and 3.0e12 < copy.bytes_per_s(keys[1]) < 8.0e12
+    assert 1e-7 < launch.duration_per_op() < 2e-5 and launch.format(keys[2]).endswith("s/launch")
+    assert 1.5e15 < cmma.ops_per_s() < 2.6e15 and cmma.format(keys[3]).endswith("POPS/s")
+    assert 0.5e14 < direct.ops_per_s() < 1.6e14
+    assert T.measure_peak_throughput(client, keys[0]) is read                              # cached per device
+    assert T.measure_peak_throughput(client, K(M.ComputeDirect(N.DTYPE_BF16))) == R.ThroughputValue.ZERO   # no such probe
+    # the two resources of the headline GEMM at these measured peaks: the matrix pipe binds
+    S = 8192
+    bounds = [R.ResourceBound(2 * S ** 3, cmma.ops_per_s()), R.ResourceBound(3 * S * S * 2, read.bytes_per_s(keys[0]))]
+    assert R.binding_resource(bounds) is bounds[0]
+
+    n = 1 << 28
+
+    class SumBench(DeviceBenchmark):
+        def prepare(self):
+            x = TensorHandle.uniform(self.client, (n,), ElemType.F32, 0x5EEDC0BE, 7, 0.0, 1.0)
+            return x, TensorHandle.new_contiguous((1,), self.client.empty(4), ElemType.F32)
+
+        def execute(self, args):
+            ops.reduce_sum(self.client, *args)
+
+        def name(self):
+            return "reduce_sum_1GiB_f32"
+
+        def shapes(self):
+            return [[n]]
+
+    raw = SumBench(client).run(TimingMethod.Device)
+    c = BenchmarkComputations.new(raw)
+    assert len(raw.durations) == 15 and c.min <= c.median <= c.max
+    score = R.score_resources(c.median * 1e-9, [R.ResourceBound(4 * n, 8.0e12)])[0]
+    assert 0.6 < score.fraction_of_peak < 1.0 and "Median" in str(raw)                     # HBM-bound: 0.8-0.88 of 8 TB/s
+
+
 def test_to_client_moves_data_between_two_clients(client, oracle):
     """runtime_tests/to_client.rs: the bytes arrive on the other client's device.  The pod has one GPU, so the second
     client is a second context on the same device -- the same call path (peer copy, both-way stream ordering)."""

@@ -236,3 +236,175 @@ def test_contiguous_pitched_predicate_and_permute():
     assert p.shape == (4, 2, 3) and p.strides == (1, 12, 4)
     with pytest.raises(ValueError):
         p.permute([0, 0, 1])
+
+
+# ---- roofline scoring (crates/cubecl-runtime/src/throughput/roofline.rs tests :109-214, ported one for one) -----------
+def test_roofline_time_at_peak_and_binding_resource():
+    from cubecl_amd.roofline import ResourceBound as B, binding_resource
+    assert B(8, 4.0).time_at_peak() == 2.0
+    for bad in (0.0, float("nan"), float("inf"), 5e-324):
+        assert B(8, bad).time_at_peak() is None
+    slower, faster = B(8, 4.0), B(8, 8.0)
+    assert binding_resource([slower, faster]) is slower
+    unusable, usable = B(8, 0.0), B(8, 4.0)
+    assert binding_resource([unusable, usable]) is usable
+    assert binding_resource([unusable]) is None and binding_resource([]) is None
+
+
+def test_roofline_score_resources_and_binding_achieved():
+    from cubecl_amd.roofline import AchievedThroughput as A, ResourceBound as B, binding_achieved, binding_resource, score_resources
+    s = score_resources(1.0, [B(100, 200.0), B(400, 800.0)])
+    assert [(x.achieved_per_s, x.fraction_of_peak) for x in s] == [(100.0, 0.5), (400.0, 0.5)]
+    z = score_resources(0.0, [B(100, 200.0)])
+    assert z[0].achieved_per_s != z[0].achieved_per_s and z[0].fraction_of_peak != z[0].fraction_of_peak
+    # matmul-shaped run: the read needs 0.9 s at its own peak, the write 0.5 s -> the read binds
+    read, write = B(900_000, 1_000_000.0), B(100_000, 200_000.0)
+    assert binding_resource([read, write]) is read
+    s = score_resources(1.0, [read, write])
+    assert [(x.achieved_per_s, x.fraction_of_peak) for x in s] == [(900_000.0, 0.9), (100_000.0, 0.5)]
+    assert binding_achieved(s).fraction_of_peak == 0.9
+    finite, nan = A(10.0, 0.4), A(float("nan"), float("nan"))
+    assert binding_achieved([nan, finite]).fraction_of_peak == 0.4
+    assert binding_achieved([nan]) is None and binding_achieved([]) is None
+    assert score_resources(1.0, [B(1, 0.0)])[0].fraction_of_peak == float("inf")      # IEEE division, not an exception
+    # the headline GEMM and the 1 GiB sum, priced as bench.py prices them (0.440 ms / 134 us at peak)
+    gemm = [B(2 * 8192 ** 3, 2.5e15), B(3 * 8192 * 8192 * 2, 8e12)]
+    assert binding_resource(gemm) is gemm[0] and abs(gemm[0].time_at_peak() - 0.4398e-3) < 1e-7
+    assert abs(B(1 << 30, 8e12).time_at_peak() - 134.2e-6) < 1e-7
+
+
+# ---- Benchmark statistics (crates/cubecl-common/src/benchmark.rs tests :359-428, ported one for one) ------------------
+def test_benchmark_durations_known_answers():
+    from cubecl_amd.benchmark import BenchmarkComputations, BenchmarkDurations, TimingMethod
+    S = 1_000_000_000
+    d = BenchmarkDurations(TimingMethod.System, [10 * S, 20 * S, 30 * S, 40 * S, 50 * S])
+    assert d.min_max_median_durations() == (10 * S, 50 * S, 30 * S)
+    assert d.variance_duration(d.mean_duration()) == 200 * S
+    d = BenchmarkDurations(TimingMethod.System, [18 * S + 5, 20 * S, 30 * S, 40 * S])
+    assert d.min_max_median_durations() == (18 * S + 5, 40 * S, 30 * S)
+    d = BenchmarkDurations(TimingMethod.System, [10 * S, 20 * S, 30 * S, 40 * S])
+    assert d.mean_duration() == 25 * S
+    c = BenchmarkComputations.new(BenchmarkDurations(TimingMethod.Device, [700_000, 720_000, 740_000]))
+    assert (c.mean, c.median, c.min, c.max) == (720_000, 720_000, 700_000, 740_000)
+    # variance of +-20 us around the mean is 2.67e-10 s^2 -> rounds to 0 ns: the score is 0.8 min + 0.2 median
+    assert c.variance == 0 and c.score() == int(700_000 * 0.8 + 720_000 * (1.0 - 0.8))
+    noisy = BenchmarkComputations(mean=2 * S, median=2 * S, variance=4 * S, min=1 * S, max=3 * S)
+    assert noisy.score() == int((0.8 * S + (1.0 - 0.8) * 2 * S) * (1.0 + (4.0 * S) ** 0.5 / (1.0 + 2.0 * S)))
+
+
+def test_duration_conversions_and_display():
+    from cubecl_amd.benchmark import BenchmarkDurations, TimingMethod, duration_from_secs_f64, format_duration
+    assert duration_from_secs_f64(2.7) == 2_700_000_000 and duration_from_secs_f64(0.0) == 0
+    assert duration_from_secs_f64(1e-9) == 1 and duration_from_secs_f64(0.4e-9) == 0 and duration_from_secs_f64(1.5e-9) == 2
+    with pytest.raises(ValueError):
+        duration_from_secs_f64(-1.0)
+    with pytest.raises(ValueError):
+        duration_from_secs_f64(float("nan"))
+    assert format_duration(25_000_000_000) == "25.000s" and format_duration(743_120) == "743.120µs"
+    assert format_duration(1_234_567) == "1.235ms" and format_duration(12) == "12.000ns"
+    assert format_duration(999_999_600) == "1000.000ms" and format_duration(1_500, 0) == "2µs" and format_duration(2_500, 0) == "2µs"
+    text = str(BenchmarkDurations(TimingMethod.Device, [721_000, 743_000, 750_000]))
+    assert "Timing      device" in text and "Samples     3" in text and "Median      743.000µs" in text
+    assert "Mean        738.000µs" in text and "Min         721.000µs" in text and "Max         750.000µs" in text
+
+
+def test_benchmark_run_protocol(monkeypatch):
+    """5 warm-up executions, then num_samples() timed ones, a sync on both sides of each; BENCH_NUM_SAMPLES overrides 15."""
+    from cubecl_amd.benchmark import Benchmark, TimingMethod, run_benchmark
+    log = []
+
+    class Probe(Benchmark):
+        def prepare(self):
+            log.append("prepare")
+            return 7
+
+        def execute(self, x):
+            log.append(("execute", x))
+            return x
+
+        def name(self):
+            return "probe"
+
+        def sync(self):
+            log.append("sync")
+
+        def shapes(self):
+            return [[2, 3]]
+
+    monkeypatch.delenv("BENCH_NUM_SAMPLES", raising=False)
+    r = Probe().run(TimingMethod.System)
+    assert len(r.durations) == 15 and log.count(("execute", 7)) == 20 and log.count("prepare") == 1
+    assert log[1:4] == ["sync", ("execute", 7), "sync"] and log.count("sync") == 40
+    monkeypatch.setenv("BENCH_NUM_SAMPLES", "4")
+    assert len(Probe().run(TimingMethod.Device).durations) == 4        # default profile() is profile_full
+    monkeypatch.setenv("BENCH_NUM_SAMPLES", "many")
+    assert Probe().num_samples() == 15
+    monkeypatch.setenv("BENCH_NUM_SAMPLES", "3")
+    res = run_benchmark(Probe())
+    assert res.name == "probe" and res.shapes == [[2, 3]] and res.options is None and len(res.raw.durations) == 3
+    assert res.computed.min <= res.computed.median <= res.computed.max and "Benchmarking - probe" in str(res)
+
+
+# ---- ThroughputBenchmarker (crates/cubecl-runtime/src/throughput/benchmarker.rs:40-143) on a scripted device -----------
+def test_throughput_benchmarker_warmup_and_peak_sampling():
+    from cubecl_amd.roofline import KernelConfig, ThroughputBenchmarker, ThroughputCache, ThroughputKey, ThroughputMode
+    calls = []
+
+    def device(iterations):                 # 1 ms per iteration, 30 % slower for the first three samples (a clock ramp)
+        calls.append(iterations)
+        slow = 1.3 if len(calls) <= 3 else 1.0
+        return iterations * 1e-3 * slow
+
+    bm = ThroughputBenchmarker(ThroughputCache("scripted"), cache_enabled=True)
+    key = ThroughputKey(ThroughputMode.MemoryRead)
+    v = bm.measure(key, KernelConfig(device, ops_count=1000))
+    # warm-up: 1 iteration takes 1.3 ms < 20 ms -> ceil(18.7 / 1.3) = 15 more = 16 iterations; two samples of 20.8 ms
+    # (best, then one stable); the ramp is over: 16 ms < 20 ms -> +4 = 20 iterations and the plateau search starts again:
+    # one sample sets the best, three more make it stable
+    assert calls[:4] == [1, 16, 16, 16] and set(calls[4:]) == {20}
+    assert abs(v.duration - 1e-3) < 1e-12 and v.ops_count == 1000 and abs(v.ops_per_s() - 1e6) < 1e-3
+    assert len(calls) == 8 + 22             # sampling stops at i = 21: more than MIN_SAMPLES taken and >= 12 stale ones
+    n = len(calls)
+    assert bm.measure(key, KernelConfig(device, ops_count=5)) is v and len(calls) == n      # cached
+    assert ThroughputBenchmarker(ThroughputCache("other"), cache_enabled=False).measure(key, KernelConfig(lambda i: i * 2e-3, 1)).duration == 2e-3
+    assert ThroughputCache.get_for_device("gfx950#0") is ThroughputCache.get_for_device("gfx950#0")
+    # a sample that keeps improving by more than 1 % never goes stale: all 200 samples are taken
+    t = [1.0]
+
+    def improving(iterations):
+        t[0] *= 0.98
+        return t[0] * iterations
+    assert abs(ThroughputBenchmarker(ThroughputCache("x"), False).sample_peak_duration(2, improving) - 0.98 ** 200) < 1e-12
+
+
+def test_throughput_keys_values_and_cmma_tile_selection():
+    from cubecl_amd import _native as N
+    from cubecl_amd import roofline as R
+    K, M = R.ThroughputKey, R.ThroughputMode
+    # base.rs:218-240: the serialised forms existing caches hold
+    assert K(M.Memory).to_json() == '{"mode":"Memory"}' and K(M.MemoryRead).to_json() == '{"mode":"MemoryRead"}'
+    assert K(M.MemoryWrite).to_json() == '{"mode":"MemoryWrite"}' and K.from_json('{"mode":"Memory"}').mode == M.Memory
+    with pytest.raises(ValueError):
+        K.from_json('{"mode":"Memory","extra":1}')
+    ws = K(M.MemoryWorkingSet(R.MemoryAccess.Copy, 1 << 20))
+    cm = R.compute_throughput_key((32, 32, 16), N.DTYPE_BF16, N.DTYPE_F32)
+    for key in (ws, cm, K(M.ComputeDirect(N.DTYPE_F32)), K(M.Launch)):
+        assert K.from_json(key.to_json()) == key and hash(K.from_json(key.to_json())) == hash(key)
+    assert R.compute_throughput_key(None, N.DTYPE_BF16, N.DTYPE_F32) == K(M.ComputeDirect(N.DTYPE_F32))
+    assert cm.dtype() == N.DTYPE_BF16 and ws.dtype() == N.DTYPE_F32 == R._F32 and R._DTYPE_BYTES == N.DTYPE_SIZE
+    assert M.Memory.memory_probe() == (R.MemoryAccess.Copy, 1 << 30) and M.MemoryRead.memory_probe() == (R.MemoryAccess.Read, 1 << 29)
+    assert ws.mode.memory_probe() == (R.MemoryAccess.Copy, 1 << 20) and M.Launch.memory_probe() is None
+    v = R.ThroughputValue(2_000_000_000, 0.5)
+    assert v.ops_per_s() == 4e9 and v.bytes_per_s(ws) == 1.6e10 and v.format(cm) == "4.0000 GOPS/s" and v.format(ws) == "16.0000 Gbytes/s"
+    assert R.ThroughputValue(1000, 2.73e-3).format(K(M.Launch)) == "2.73µs/launch" and R.ThroughputValue.ZERO.format(K(M.Launch)) == "N/A"
+    assert R.ThroughputValue.ZERO.format(ws) == "N/A" and R.ThroughputValue(0, 1.0).duration_per_op() == 0.0
+    assert R.ThroughputValue(3, 1e-8).duration_per_op() == 3e-9            # 3.33 ns -> the Duration holds 3 ns
+    # cmma.rs:31-60 on the configurations mi355_ctx_create advertises (runtime.cpp)
+    bf, f16, f32 = N.DTYPE_BF16, N.DTYPE_F16, N.DTYPE_F32
+    cfgs = [(bf, bf, f32, 32, 32, 16), (bf, bf, f32, 16, 16, 32), (f16, f16, f32, 32, 32, 16), (bf, bf, f32, 16, 16, 16),
+            (f32, f32, f32, 32, 32, 2), (f32, f32, f32, 16, 16, 4)]
+    assert R.select_cmma_tile(cfgs, bf, bf, f32, (8192, 8192, 8192)) == (32, 32, 16)
+    assert R.select_cmma_tile(cfgs, bf, bf, f32, (16, 16, 64)) == (16, 16, 32)         # 32x32x16 does not fit
+    assert R.select_cmma_tile(cfgs, bf, bf, f32, (16, 16, 16)) == (16, 16, 16)
+    assert R.select_cmma_tile(cfgs, f32, f32, f32, (4096, 4096, 4096)) == (32, 32, 2)
+    assert R.select_cmma_tile(cfgs, bf, f16, f32, (64, 64, 64)) is None and R.select_cmma_tile(cfgs, bf, bf, f32, (8, 64, 64)) is None
