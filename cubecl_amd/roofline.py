@@ -261,13 +261,15 @@ def compute_throughput_key(cmma_tile: Optional[Tuple[int, int, int]], input_elem
 def select_cmma_tile(mma_configs: Iterable[Tuple[int, int, int, int, int, int]], lhs: int, rhs: int, acc: int,
                      problem: Tuple[int, int, int]) -> Optional[Tuple[int, int, int]]:
     """cmma.rs:31-60 over `ComputeClient.features()["cmma"] | ["mma"]` entries `(a, b, cd, m, n, k)`: the matrix
-    instruction with exactly these types that fits inside the problem and has the largest volume (the last of equals)."""
+    instruction with exactly these types that fits inside the problem and has the largest volume.  The reference breaks
+    ties by registration order (`max_by_key` keeps the last); `features()` is a set, so equal volumes are decided by the
+    larger (m, n, k) instead -- f32 32x32x2 over 16x16x8."""
     pm, pn, pk = problem
     best = None
     for (a, b, cd, m, n, k) in mma_configs:
         if (a, b, cd) != (lhs, rhs, acc) or pm < m or pn < n or pk < k:
             continue
-        if best is None or m * n * k >= best[0] * best[1] * best[2]:
+        if best is None or (m * n * k, m, n, k) > (best[0] * best[1] * best[2],) + best:
             best = (m, n, k)
     return best
 
