@@ -68,21 +68,47 @@ class DeviceId:
 
 @dataclass(frozen=True)
 class CubeDim:
+    """server/base.rs:1251-1327."""
     x: int = 1
     y: int = 1
     z: int = 1
 
     @staticmethod
+    def new(client, working_units: int) -> "CubeDim":
+        """:1261-1295 -- (plane_size, planes): a power-of-two number of planes, at most 8 and at most what
+        `working_units` fill, capped by max_units_per_cube; at least one plane."""
+        p = client.properties()
+        plane = int(p.plane_size_max)
+        plane_count_max = max(1, int(working_units) // plane)
+        planes = 1 << min(3, plane_count_max.bit_length() - 1)
+        return CubeDim(plane, max(min(int(p.max_units_per_cube) // plane, planes), 1), 1)
+
+    @staticmethod
+    def new_single() -> "CubeDim":
+        return CubeDim(1, 1, 1)
+
+    @staticmethod
     def new_1d(x: int) -> "CubeDim":
         return CubeDim(x, 1, 1)
+
+    @staticmethod
+    def new_2d(x: int, y: int) -> "CubeDim":
+        return CubeDim(x, y, 1)
+
+    @staticmethod
+    def new_3d(x: int, y: int, z: int) -> "CubeDim":
+        return CubeDim(x, y, z)
 
     def num_elems(self) -> int:
         return self.x * self.y * self.z
 
+    def can_contain(self, other: "CubeDim") -> bool:
+        return self.x >= other.x and self.y >= other.y and self.z >= other.z
+
 
 @dataclass(frozen=True)
 class CubeCount:
-    """CubeCount::Static(x, y, z)."""
+    """CubeCount::Static(x, y, z) (server/base.rs:1148-1153; the Dynamic variant needs the IR's indirect dispatch)."""
     x: int = 1
     y: int = 1
     z: int = 1
@@ -90,6 +116,64 @@ class CubeCount:
     @staticmethod
     def Static(x: int, y: int = 1, z: int = 1) -> "CubeCount":
         return CubeCount(x, y, z)
+
+    @staticmethod
+    def new_single() -> "CubeCount":
+        return CubeCount(1, 1, 1)
+
+    @staticmethod
+    def new_1d(x: int) -> "CubeCount":
+        return CubeCount(x, 1, 1)
+
+    @staticmethod
+    def new_2d(x: int, y: int) -> "CubeCount":
+        return CubeCount(x, y, 1)
+
+    @staticmethod
+    def new_3d(x: int, y: int, z: int) -> "CubeCount":
+        return CubeCount(x, y, z)
+
+    def is_empty(self) -> bool:
+        """:1219-1224 -- a launch with an empty count is a no-op (client.rs:880-884)."""
+        return self.x == 0 or self.y == 0 or self.z == 0
+
+    def __str__(self) -> str:
+        return f"({self.x}, {self.y}, {self.z})"
+
+
+def cube_count_spread(max_cube_count: Sequence[int], num_cubes: int) -> tuple:
+    """server/base.rs:1347-1374: a cube count over the limit in x is halved (rounding up) into y, then y into z."""
+    limits = list(max_cube_count)
+    count = [int(num_cubes), 1, 1]
+    for i in range(2):
+        if count[i] <= limits[i]:
+            break
+        while count[i] > limits[i]:
+            count[i] = (count[i] + 1) // 2
+            count[i + 1] *= 2
+    return tuple(count)
+
+
+@dataclass(frozen=True)
+class CubeCountSelection:
+    """server/base.rs:1156-1197: `Exact(count)` when the spread count is the requested one, else `Approx(count, actual)`
+    -- some cubes are idle and the kernel has to check bounds."""
+    count: CubeCount
+    num_cubes_actual: int
+    exact: bool
+
+    @staticmethod
+    def new(client, num_cubes: int) -> "CubeCountSelection":
+        p = client.properties()
+        c = cube_count_spread(tuple(p.max_cube_count), num_cubes)
+        actual = c[0] * c[1] * c[2]
+        return CubeCountSelection(CubeCount(*c), actual, actual == num_cubes)
+
+    def has_idle(self) -> bool:
+        return not self.exact
+
+    def cube_count(self) -> CubeCount:
+        return self.count
 
 
 class ServerError(RuntimeError):

@@ -408,3 +408,41 @@ def test_throughput_keys_values_and_cmma_tile_selection():
     assert R.select_cmma_tile(cfgs, bf, bf, f32, (16, 16, 16)) == (16, 16, 16)
     assert R.select_cmma_tile(cfgs, f32, f32, f32, (4096, 4096, 4096)) == (32, 32, 2)
     assert R.select_cmma_tile(cfgs, bf, f16, f32, (64, 64, 64)) is None and R.select_cmma_tile(cfgs, bf, bf, f32, (8, 64, 64)) is None
+
+
+# ---- cube count / cube dim selection (crates/cubecl-runtime/src/server/base.rs:1156-1197, :1261-1295, tests :1376-1399) --
+class _Props:
+    plane_size_max, max_units_per_cube, max_cube_count = 64, 1024, (2 ** 31 - 1, 65535, 65535)
+
+
+class _PropsClient:
+    def __init__(self, **kw):
+        self._p = _Props()
+        for k, v in kw.items():
+            setattr(self._p, k, v)
+
+    def properties(self):
+        return self._p
+
+
+def test_cube_count_spread_and_selection():
+    from cubecl_amd import CubeCountSelection, cube_count_spread
+    assert cube_count_spread((32, 32, 32), 2048) == (32, 32, 2)          # safe_num_cubes_even
+    assert cube_count_spread((48, 32, 16), 3177) == (25, 32, 4)          # safe_num_cubes_odd
+    assert cube_count_spread((65535, 65535, 65535), 1000) == (1000, 1, 1)
+    sel = CubeCountSelection.new(_PropsClient(max_cube_count=(48, 32, 16)), 3177)
+    assert sel.has_idle() and sel.num_cubes_actual == 3200 and sel.cube_count() == CubeCount(25, 32, 4)
+    sel = CubeCountSelection.new(_PropsClient(), 1 << 22)                # gfx950 takes 2^31-1 cubes in x: never spread
+    assert not sel.has_idle() and sel.cube_count() == CubeCount.new_1d(1 << 22) and str(sel.cube_count()) == "(4194304, 1, 1)"
+    assert CubeCount.new_2d(4, 0).is_empty() and not CubeCount.new_single().is_empty() and CubeCount.new_3d(1, 2, 3) == CubeCount.Static(1, 2, 3)
+
+
+def test_cube_dim_new_picks_a_power_of_two_number_of_planes():
+    gfx950 = _PropsClient()
+    for units, planes in ((1, 1), (63, 1), (64, 1), (128, 2), (200, 2), (256, 4), (511, 4), (512, 8), (1 << 20, 8)):
+        d = CubeDim.new(gfx950, units)
+        assert (d.x, d.y, d.z) == (64, planes, 1) and d.num_elems() == 64 * planes
+    assert CubeDim.new(_PropsClient(max_units_per_cube=256), 1 << 20) == CubeDim.new_2d(64, 4)     # capped by the unit limit
+    assert CubeDim.new(_PropsClient(max_units_per_cube=32), 100) == CubeDim.new_2d(64, 1)          # never below one plane
+    assert CubeDim.new_3d(8, 8, 2).can_contain(CubeDim.new_2d(8, 4)) and not CubeDim.new_1d(64).can_contain(CubeDim.new_2d(1, 2))
+    assert CubeDim.new_single().num_elems() == 1
