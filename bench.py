@@ -134,6 +134,16 @@ def pmc_traffic(size, algo):
         return None
 
 
+def pmc_mfma_util(size):
+    """Matrix-pipe utilisation of the headline kernel from the committed rocprofv3 PMC pass (profiles/pmc_mfma_util.json,
+    written by tools/pmc_mfma_util.sh: SQ_VALU_MFMA_BUSY_CYCLES per SIMD over GRBM_GUI_ACTIVE per XCD).  None without a pass."""
+    try:
+        ent = json.loads((ROOT / "profiles" / "pmc_mfma_util.json").read_text()).get(f"gemm_bf16_{size}")
+        return ent["mfma_util"] if ent else None
+    except Exception:
+        return None
+
+
 def gemm_desc(N, m, n, k, dtype_ab, dtype_c, trans_b=1, batch=1, algo=0):
     return N.GemmDesc(m=m, n=n, k=k, batch=batch, lda=k, ldb=(k if trans_b else n), ldc=n, stride_a=m * k,
                       stride_b=n * k, stride_c=m * n, dtype_ab=dtype_ab, dtype_c=dtype_c, trans_a=0, trans_b=trans_b,
@@ -263,6 +273,7 @@ def main():
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(gemm_score.fraction_of_peak, 4), "traffic": pmc_traffic(S, sel.value),
                      "kernel_ms": round(kernel_ms / args.steps, 4), "flop_per_launch": flop,
+                     "mfma_util_pmc": pmc_mfma_util(S),
                      # the chip clocks down to its power budget on random operands (MI355X_MICROARCH.md "DVFS
                      # give-back"): the 2.5 PFLOP/s peak assumes 2.4 GHz; these two lines price the kernel
                      # against the matrix-pipe rate at the clock it actually ran at
