@@ -98,6 +98,7 @@ def samples_op(client, ev, fn, samples=15, warmup=5):
 
 
 HUNG = []          # names of watchdogged sections that did not return (see run_with_watchdog)
+THREAD_DEVICE = None    # this rank's device index, for the watchdog's helper threads (set in main)
 
 
 def run_with_watchdog(fn, seconds):
@@ -108,6 +109,9 @@ def run_with_watchdog(fn, seconds):
 
     def body():
         try:
+            if THREAD_DEVICE is not None:         # torch's current device is per thread: a new thread starts on device 0
+                import torch
+                torch.cuda.set_device(THREAD_DEVICE)
             fn()
             box["ok"] = True
         except Exception as exc:  # noqa: BLE001
@@ -170,6 +174,8 @@ def main():
     if "BENCH_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
+    global THREAD_DEVICE
+    THREAD_DEVICE = local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
