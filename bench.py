@@ -297,7 +297,7 @@ def main():
             errors[name] = f"{type(exc).__name__}: {exc}"[:300]
 
     # ------------------------------------------------------------------ CPU baseline ---------------------
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:       # N = 1 only: at N > 1 it would load the cores the other ranks launch from
         def cpu_baseline():
             import numpy as np
             import oracle
