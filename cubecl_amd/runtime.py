@@ -400,6 +400,16 @@ class ComputeClient:
             v //= 2
         return out
 
+    def device_key(self) -> str:
+        """client.rs:1353-1356: stable per-device identity that keys the device-level measurement caches."""
+        return f"{Mi355Runtime.name()}_dev{self._s.device.index_id}"
+
+    def measure_throughput(self, key, kernel_config, *, cache_enabled: bool = True):
+        """client.rs:1358-1368: peak of one probe under the reference's sampling protocol (cubecl_amd/roofline.py),
+        cached per device."""
+        from .roofline import ThroughputBenchmarker, ThroughputCache
+        return ThroughputBenchmarker(ThroughputCache.get_for_device(self.device_key()), cache_enabled).measure(key, kernel_config)
+
     # -- memory ------------------------------------------------------------------------------
     def empty(self, size: int) -> Handle:
         """client.empty: a reservation from the memory pool (memory_manage.rs:1084), not a driver allocation."""

@@ -303,9 +303,7 @@ def measure_peak_throughput(client, key: ThroughputKey, *, cache_enabled: bool =
         cfg = _kernel_config(client, key, keep)
         if cfg is None:
             return ThroughputValue.ZERO
-        props = client.properties()
-        cache = ThroughputCache.get_for_device(f"{props.name.decode()}#{props.device_index}")
-        return ThroughputBenchmarker(cache, cache_enabled).measure(key, cfg)
+        return client.measure_throughput(key, cfg, cache_enabled=cache_enabled)
     finally:
         for k in keep:
             if isinstance(k, _Timer):
