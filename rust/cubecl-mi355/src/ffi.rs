@@ -313,4 +313,12 @@ unsafe extern "C" {
     pub fn mi355_probe_mfma_data(ctx: *mut mi355_ctx, stream: mi355_stream, mode: i32, iters: u32, sink: *mut c_void, out_ops: *mut u64) -> i32;
     pub fn mi355_probe_compute_direct(ctx: *mut mi355_ctx, stream: mi355_stream, iters: u32, sink: *mut c_void, out_ops: *mut u64) -> i32;
     pub fn mi355_probe_launch_overhead(ctx: *mut mi355_ctx, stream: mi355_stream, launches: u32, sink: *mut c_void) -> i32;
+    pub fn mi355_probe_clock(ctx: *mut mi355_ctx, stream: mi355_stream, dev_out: *mut u64) -> i32;
+    // streams / events / modules / collectives the server does not need on its main path (kept so that the table is the header's)
+    pub fn mi355_default_stream(ctx: *mut mi355_ctx, out_stream: *mut mi355_stream) -> i32;
+    pub fn mi355_comm_stream(ctx: *mut mi355_ctx, out_stream: *mut mi355_stream) -> i32;
+    pub fn mi355_event_elapsed_ms(ctx: *mut mi355_ctx, start: mi355_event, stop: mi355_event, out_ms: *mut f32) -> i32;
+    pub fn mi355_module_unload(ctx: *mut mi355_ctx, module: mi355_module) -> i32;
+    pub fn mi355_all_gather(ctx: *mut mi355_ctx, comm: *mut mi355_comm, compute_stream: mi355_stream, src: *const c_void,
+                            dst: *mut c_void, count: u64, dtype: i32) -> i32;
 }

@@ -93,3 +93,21 @@ def test_hot_gemm_kernels_do_not_spill():
     assert len(rows) >= 40
     bad = [r for r in rows if r[2] or r[3]]
     assert not bad, bad
+
+
+def test_rust_ffi_declares_every_header_symbol():
+    """rust/cubecl-mi355/src/ffi.rs is the binding a maintainer compiles; it cannot be built in this image,
+    so at least its table is held to the header: every exported function is declared, and nothing else is."""
+    import re
+    from cubecl_amd import _native
+    text = (Path(__file__).resolve().parents[1] / "rust" / "cubecl-mi355" / "src" / "ffi.rs").read_text()
+    declared = set(re.findall(r"\bpub fn (mi355_\w+)\s*\(", text))
+    header = set(_native.header_symbols())
+    assert header - declared == set(), f"missing in ffi.rs: {sorted(header - declared)}"
+    assert declared - header == set(), f"ffi.rs declares what the header does not: {sorted(declared - header)}"
+    # and with the same number of parameters as the C prototype
+    hdr = re.sub(r"/\*.*?\*/", "", (Path(__file__).resolve().parents[1] / "include" / "mi355cube.h").read_text(), flags=re.S)
+    count = lambda args: 0 if args.strip() in ("", "void") else args.count(",") + 1
+    c_side = {m.group(1): count(m.group(2)) for m in re.finditer(r"\b(mi355_\w+)\s*\(([^()]*)\)\s*;", hdr)}
+    rust = {m.group(1): count(m.group(2)) for m in re.finditer(r"pub fn (mi355_\w+)\s*\(([^()]*)\)", re.sub(r"//[^\n]*", "", text))}
+    assert {k: (c_side[k], rust[k]) for k in header if c_side[k] != rust[k]} == {}
