@@ -111,3 +111,22 @@ def test_rust_ffi_declares_every_header_symbol():
     c_side = {m.group(1): count(m.group(2)) for m in re.finditer(r"\b(mi355_\w+)\s*\(([^()]*)\)\s*;", hdr)}
     rust = {m.group(1): count(m.group(2)) for m in re.finditer(r"pub fn (mi355_\w+)\s*\(([^()]*)\)", re.sub(r"//[^\n]*", "", text))}
     assert {k: (c_side[k], rust[k]) for k in header if c_side[k] != rust[k]} == {}
+
+
+def test_rust_ffi_structs_have_the_header_field_order():
+    import re
+    root = Path(__file__).resolve().parents[1]
+    hdr = re.sub(r"/\*.*?\*/", "", (root / "include" / "mi355cube.h").read_text(), flags=re.S)
+    ffi = re.sub(r"//[^\n]*", "", (root / "rust" / "cubecl-mi355" / "src" / "ffi.rs").read_text())
+    c_structs = {}
+    for m in re.finditer(r"typedef struct(?:\s+\w+)?\s*\{(.*?)\}\s*(\w+)\s*;", hdr, flags=re.S):
+        fields = []
+        for decl in filter(None, (d.strip() for d in m.group(1).split(";"))):
+            parts = decl.split(",")
+            for name in [parts[0].split()[-1]] + [p.strip() for p in parts[1:]]:
+                fields.append(re.sub(r"\[.*", "", name).lstrip("*"))
+        c_structs[m.group(2)] = fields
+    rust = {m.group(1): re.findall(r"pub (\w+)\s*:", m.group(2)) for m in re.finditer(r"pub struct (\w+)\s*\{(.*?)\}", ffi, flags=re.S)}
+    assert len(c_structs) >= 7
+    for name, fields in c_structs.items():
+        assert rust.get(name) == fields, name
