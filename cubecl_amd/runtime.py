@@ -20,7 +20,7 @@ from __future__ import annotations
 
 import ctypes as C
 import enum
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Iterable, Optional, Sequence
 
 import numpy as np

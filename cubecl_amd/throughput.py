@@ -18,13 +18,11 @@ moves, not what happens to be resident.
 from __future__ import annotations
 
 import ctypes as C
-import enum
 from dataclasses import dataclass
 from typing import Iterable, List, Optional, Sequence
 
 from . import _native as N
-from .roofline import (KernelConfig, MemoryAccess, ThroughputBenchmarker, ThroughputCache, ThroughputKey, ThroughputMode,
-                       ThroughputValue)
+from .roofline import KernelConfig, MemoryAccess, ThroughputKey, ThroughputValue
 
 MIN_WORKING_SET = 8 * 1024                    # curve.rs:25
 DEFAULT_BUFFER_BYTES = 512 * 1024 * 1024      # throughput/base.rs:9
