@@ -298,6 +298,17 @@ class ThroughputCache:
         return self._cache.get(key)
 
 
+def env_bool(name: str) -> Optional[bool]:
+    """config/base.rs:186-192: true / 1 / on, false / 0 / off, anything else is no opinion."""
+    import os
+    return {"true": True, "1": True, "on": True, "false": False, "0": False, "off": False}.get(os.environ.get(name, ""))
+
+
+def throughput_cache_enabled() -> bool:
+    enabled = env_bool("CUBECL_THROUGHPUT_CACHE")
+    return True if enabled is None else enabled
+
+
 # ---- benchmarker.rs ---------------------------------------------------------------------------------------------------
 @dataclass
 class KernelConfig:
@@ -316,9 +327,11 @@ class ThroughputBenchmarker:
     REL_TOL = 0.01
     SAMPLE_PATIENCE = 12
 
-    def __init__(self, cache: ThroughputCache, cache_enabled: bool = True):
+    def __init__(self, cache: ThroughputCache, cache_enabled: Optional[bool] = None):
+        """`cache_enabled=None` takes the configuration: on, unless CUBECL_THROUGHPUT_CACHE says off / 0 / false
+        (config/base.rs:157-159, :186-192; examples/throughput/README.md "Caching")."""
         self.cache = cache
-        self.cache_enabled = cache_enabled
+        self.cache_enabled = throughput_cache_enabled() if cache_enabled is None else cache_enabled
 
     def measure(self, key: ThroughputKey, kernel_config: KernelConfig) -> ThroughputValue:
         """benchmarker.rs:40-66: the peak attained -- the minimum time per iteration after the device has warmed up."""

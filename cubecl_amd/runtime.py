@@ -404,7 +404,7 @@ class ComputeClient:
         """client.rs:1353-1356: stable per-device identity that keys the device-level measurement caches."""
         return f"{Mi355Runtime.name()}_dev{self._s.device.index_id}"
 
-    def measure_throughput(self, key, kernel_config, *, cache_enabled: bool = True):
+    def measure_throughput(self, key, kernel_config, *, cache_enabled: Optional[bool] = None):
         """client.rs:1358-1368: peak of one probe under the reference's sampling protocol (cubecl_amd/roofline.py),
         cached per device."""
         from .roofline import ThroughputBenchmarker, ThroughputCache

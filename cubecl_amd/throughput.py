@@ -292,7 +292,7 @@ def _kernel_config(client, key: ThroughputKey, keep: list) -> Optional[KernelCon
     return KernelConfig(lambda iterations: t.run(one, iterations), per_buf * access.buffers() // 4)
 
 
-def measure_peak_throughput(client, key: ThroughputKey, *, cache_enabled: bool = True) -> ThroughputValue:
+def measure_peak_throughput(client, key: ThroughputKey, *, cache_enabled: Optional[bool] = None) -> ThroughputValue:
     """std/throughput/base.rs:77-141: the peak this device attains for `key`, by the reference's protocol (plateau
     warm-up, best of 20-200 samples), cached per device name; `ThroughputValue.ZERO` where no probe exists (the
     reference returns it for a cmma key on a device without matrix instructions)."""

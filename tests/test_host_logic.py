@@ -446,3 +446,21 @@ def test_cube_dim_new_picks_a_power_of_two_number_of_planes():
     assert CubeDim.new(_PropsClient(max_units_per_cube=32), 100) == CubeDim.new_2d(64, 1)          # never below one plane
     assert CubeDim.new_3d(8, 8, 2).can_contain(CubeDim.new_2d(8, 4)) and not CubeDim.new_1d(64).can_contain(CubeDim.new_2d(1, 2))
     assert CubeDim.new_single().num_elems() == 1
+
+
+def test_throughput_cache_follows_the_environment_switch(monkeypatch):
+    """CUBECL_THROUGHPUT_CACHE (config/base.rs:157-159): off forces a fresh measurement, anything unrecognised keeps the default."""
+    from cubecl_amd.roofline import KernelConfig, ThroughputBenchmarker, ThroughputCache, ThroughputKey, ThroughputMode, env_bool
+    key, cache, runs = ThroughputKey(ThroughputMode.Launch), ThroughputCache("env"), []
+
+    def device(iterations):
+        runs.append(iterations)
+        return 1e-3 * iterations
+    for value, fresh in (("", False), ("on", False), ("off", True), ("0", True), ("false", True), ("maybe", False), ("1", False)):
+        monkeypatch.setenv("CUBECL_THROUGHPUT_CACHE", value)
+        before = len(runs)
+        ThroughputBenchmarker(cache).measure(key, KernelConfig(device, 1))
+        assert (len(runs) > before) == (fresh or before == 0), value
+    assert env_bool("CUBECL_THROUGHPUT_CACHE") is True
+    monkeypatch.delenv("CUBECL_THROUGHPUT_CACHE")
+    assert env_bool("CUBECL_THROUGHPUT_CACHE") is None and ThroughputBenchmarker(cache).cache_enabled
