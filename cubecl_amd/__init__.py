@@ -6,7 +6,8 @@ from .runtime import (ComputeClient, CopyDescriptor, CubeCount, CubeCountSelecti
                       Mi355Runtime, ReduceOperation, ServerError, contiguous_strides, has_pitched_row_major_strides)
 from .tensor import MatrixBatchLayout, TensorHandle, matrix_batch_layout
 from . import ops
+from .info import AddressType, InfoBuilder, KernelArguments, MetadataBindingInfo
 
 __all__ = ["ComputeClient", "CopyDescriptor", "CubeCount", "CubeCountSelection", "CubeDim", "cube_count_spread", "DeviceId", "ElemType", "Handle",
            "MemoryLayout", "Mi355Runtime", "ReduceOperation", "ServerError", "TensorHandle", "MatrixBatchLayout",
-           "matrix_batch_layout", "contiguous_strides", "has_pitched_row_major_strides", "ops", "_native"]
+           "matrix_batch_layout", "AddressType", "InfoBuilder", "KernelArguments", "MetadataBindingInfo", "contiguous_strides", "has_pitched_row_major_strides", "ops", "_native"]

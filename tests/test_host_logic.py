@@ -464,3 +464,66 @@ def test_throughput_cache_follows_the_environment_switch(monkeypatch):
     assert env_bool("CUBECL_THROUGHPUT_CACHE") is True
     monkeypatch.delenv("CUBECL_THROUGHPUT_CACHE")
     assert env_bool("CUBECL_THROUGHPUT_CACHE") is None and ThroughputBenchmarker(cache).cache_enabled
+
+
+# ---- info buffer of a launch (crates/cubecl-core/src/codegen/{scalars,metadata,info}.rs) ---------
+def test_info_buffer_layout_known_answers():
+    from cubecl_amd.info import AddressType, InfoBuilder, MetadataBindingInfo
+    b = InfoBuilder()
+    # scalars arrive in argument order, leave grouped in the element type's order: f32 < i32 < u32 < u64 (type.rs)
+    b.scalars.push(7, "u32"); b.scalars.push(1.5, "f32"); b.scalars.push(-2, "i32"); b.scalars.push(9, "u32")
+    b.scalars.push(3, "u32"); b.scalars.push(1 << 40, "u64")
+    # bindings in order: an array of 100, a [2, 3, 4] tensor of 24, a [5, 6] tensor whose buffer holds 64 (pitched rows)
+    b.metadata.register_buffer(100, AddressType.U32)
+    b.metadata.register_tensor(24, (2, 3, 4), (12, 4, 1), AddressType.U32)
+    b.metadata.register_tensor(64, (5, 6), (8, 1), AddressType.U32)
+    info = b.finish(AddressType.U32)
+    w32 = np.frombuffer(info.to_bytes(), dtype="<u4")
+    f32_bits = int(np.float32(1.5).view(np.uint32))
+    scalars = [f32_bits, 0, 0xFFFFFFFE, 0, 7, 9, 3, 0, 0, 1 << 8]                 # each group padded to 8 bytes; u64 = lo, hi
+    static = [100, 24, 64, 0, 3, 5 + 0, 5 + 3, 0]                                  # lens | shape offsets | stride offsets | pad
+    dynamic = [2, 3, 4, 5, 6, 12, 4, 1, 8, 1]                                      # all shapes, then all strides
+    assert w32.tolist() == scalars + static + dynamic
+    assert info.dynamic_metadata_offset == (len(scalars) + len(static)) // 2 and info.data.dtype == np.uint64
+    # the same bindings addressed with u64: one word per entry, no padding anywhere
+    b.metadata.register_buffer(100, AddressType.U64)
+    b.metadata.register_tensor(24, (2, 3, 4), (12, 4, 1), AddressType.U64)
+    info64 = b.finish(AddressType.U64)
+    assert info64.data.tolist() == [100, 24, 0, 3, 2, 3, 4, 12, 4, 1] and info64.dynamic_metadata_offset == 4
+    # builders are drained by finish (the reference reuses one per launcher)
+    assert b.finish(AddressType.U32).data.size == 0
+    # an odd count of u32 entries is padded to a whole word; scalars only
+    b.metadata.register_buffer(5, AddressType.U32)
+    one = b.finish()
+    assert one.data.tolist() == [5] and one.dynamic_metadata_offset == 1
+    b.scalars.push(0x1234, "bf16"); b.scalars.push(True, "bool"); b.scalars.push(-1, "i8")
+    assert np.frombuffer(b.finish().to_bytes(), dtype=np.uint8).reshape(3, 8)[:, :2].tolist() == [[0x34, 0x12], [0xFF, 0], [1, 0]]
+    custom = MetadataBindingInfo.custom([3, 7])
+    assert custom.dynamic_metadata_offset == 0 and custom.to_bytes() == (3).to_bytes(8, "little") + (7).to_bytes(8, "little")
+    with pytest.raises(ValueError):
+        b.metadata.register_tensor(4, (2, 2), (1,), AddressType.U32)
+
+
+def test_buffer_len_semantics_of_the_reference_tests():
+    """runtime_tests/metadata.rs:199-269: the length a kernel sees is bytes in use / (vector) element size."""
+    from cubecl_amd.info import KernelArguments, MetadataBindingInfo, buffer_len
+    mem = _Memory.__new__(_Memory)
+    h = Handle(mem, None, None, 64 * 4)
+    assert buffer_len(h, 4) == 64                                                  # discontiguous view, physical length
+    assert buffer_len(Handle(mem, None, None, 32 * 4), 4, vector_size=4) == 8     # vectors of 4
+    cut = Handle(mem, None, None, 256 * 4).offset_start_by(64 * 4).offset_end_by(64 * 4)
+    assert buffer_len(cut, 4, vector_size=2) == 64                                 # only the window in use counts
+    args = KernelArguments().with_buffer(h).with_buffers([cut]).with_info(MetadataBindingInfo.custom([1]))
+    assert args.resources == [h, cut] and args.info.data.tolist() == [1]
+
+
+def test_info_builder_reproduces_the_struct_of_the_external_test_kernels():
+    """tests/kernels/abi_probe.hip declares `struct info_st { uint32_t scalars[2]; uint32_t buffer_len[2]; }`, the layout the
+    reference's generator emits for two u32 scalars and two array bindings (crates/cubecl-cpp/src/shared/kernel.rs:60-93);
+    the GPU tests hand-pack it -- the builder must produce the same bytes."""
+    from cubecl_amd.info import AddressType, InfoBuilder
+    b = InfoBuilder()
+    b.scalars.push(3, "u32"); b.scalars.push(7, "u32")
+    b.metadata.register_buffer(1000, AddressType.U32); b.metadata.register_buffer(1000, AddressType.U32)
+    info = b.finish(AddressType.U32)
+    assert info.to_bytes() == np.array([3, 7, 1000, 1000], dtype=np.uint32).tobytes() and info.dynamic_metadata_offset == 2
