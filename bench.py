@@ -125,6 +125,31 @@ def run_with_watchdog(fn, seconds):
     return box.get("err")
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, cut by a cgroup CPU quota when the container has one
+    (os.cpu_count() alone reports the machine's logical CPUs, whatever the container is allowed)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:                                                        # cgroup v2
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except Exception:
+        try:                                                    # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and period > 0:
+                quota = q / period
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.999)))
+    return n
+
+
 def pmc_traffic(size, algo):
     """HBM bytes per launch of the headline kernel from the committed rocprofv3 PMC passes
     (profiles/pmc_traffic.json, written by tools/pmc_traffic.sh: separate --pmc passes for FETCH_SIZE
@@ -301,7 +326,7 @@ def main():
         def cpu_baseline():
             import numpy as np
             import oracle
-            cores = os.cpu_count() or 1
+            cores = usable_cores()
             size = 1024
             secs = None
             while True:
@@ -315,7 +340,8 @@ def main():
                 size *= 2
             return {"value": round(2.0 * size ** 3 / secs / 1e12, 5), "unit": "TFLOP/s", "cores": cores, "kind": "port",
                     "sample": f"{size}^3 bf16 GEMM (same RNG/layout), {secs:.2f} s, oracle_cpu_gemm: one worker per "
-                              "cube unit as cubecl-cpu schedules (threadpool/mod.rs:80-99)"}
+                              "cube unit as cubecl-cpu schedules (threadpool/mod.rs:80-99); "
+                              f"{os.cpu_count()} logical CPUs on the host, {cores} usable by this process"}
         try:
             result["cpu_baseline"] = cpu_baseline()
         except Exception as exc:
