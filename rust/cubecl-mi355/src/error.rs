@@ -27,13 +27,33 @@ pub(crate) fn convert(code: i32, requested: u64, max: u64, message: String) -> S
             requested: requested as usize, max: max as usize, backtrace: bt() }).into(),
         MI355_E_UNITS => LaunchError::TooManyResources(ResourceLimitError::Units {
             requested: requested as u32, max: max as u32, backtrace: bt() }).into(),
-        MI355_E_CUBE_DIM | MI355_E_MAX_UNITS_PER_CUBE => LaunchError::Unknown { reason: message, backtrace: bt() }.into(),
+        // the queue carries (requested, max) as two integers; the three extents travel in the message the library
+        // formats ("... Requested (x, y, z), max is (a, b, c).", runtime.cpp mi355_launch)
+        MI355_E_CUBE_DIM => match triples(&message) {
+            Some((requested, max)) => LaunchError::TooManyResources(ResourceLimitError::CubeDim { requested, max, backtrace: bt() }).into(),
+            None => LaunchError::Unknown { reason: message, backtrace: bt() }.into(),
+        },
+        MI355_E_MAX_UNITS_PER_CUBE => LaunchError::TooManyResources(ResourceLimitError::MaxUnitPerCube {
+            requested: requested as u32, max: max as u32, backtrace: bt() }).into(),
         MI355_E_COMPILATION => LaunchError::CompilationError(
             cubecl_runtime::compiler::CompilationError::Generic { reason: message, backtrace: bt() }).into(),
         MI355_E_LAUNCH => LaunchError::Unknown { reason: message, backtrace: bt() }.into(),
         MI355_E_UNSUPPORTED => IoError::UnsupportedIoOperation { backtrace: bt() }.into(),
+        MI355_E_PROFILE => cubecl_runtime::server::ProfileError::Unknown { reason: message, backtrace: bt() }.into(),
+        // a failed stream / device synchronisation, a collective, a missing device: no closer variant than Generic
+        MI355_E_EXECUTION | MI355_E_COMM | MI355_E_NO_DEVICE =>
+            ServerError::Generic { reason: format!("mi355cube status {code}: {message}"), backtrace: bt() },
         _ => ServerError::Generic { reason: format!("mi355cube status {code}: {message}"), backtrace: bt() },
     }
+}
+
+/// The two "(x, y, z)" groups of a cube-dim message.
+fn triples(message: &str) -> Option<((u32, u32, u32), (u32, u32, u32))> {
+    let mut groups = message.split('(').skip(1).filter_map(|g| {
+        let mut it = g.split(')').next()?.split(',').map(|v| v.trim().parse::<u32>());
+        Some((it.next()?.ok()?, it.next()?.ok()?, it.next()?.ok()?))
+    });
+    Some((groups.next()?, groups.next()?))
 }
 
 /// `Ok(())` for `MI355_OK`; drains the error queue into `ServerUnhealthy { errors }` for status 14.
