@@ -1,4 +1,5 @@
 """Host-side logic of the reference surface restated in cubecl_amd (no device needed)."""
+import os
 import numpy as np
 import pytest
 
@@ -527,3 +528,26 @@ def test_info_builder_reproduces_the_struct_of_the_external_test_kernels():
     b.metadata.register_buffer(1000, AddressType.U32); b.metadata.register_buffer(1000, AddressType.U32)
     info = b.finish(AddressType.U32)
     assert info.to_bytes() == np.array([3, 7, 1000, 1000], dtype=np.uint32).tobytes() and info.dynamic_metadata_offset == 2
+
+
+# ---- bench.py host-side helpers (no device) ----------------------------------------------------------------------------
+def test_bench_helpers_and_contract_defaults(monkeypatch):
+    import json
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    sys.path.insert(0, str(root))
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse_args()
+    assert (a.gpus, a.steps, a.warmup, a.size) == (1, 30, 5, 8192)                    # no flags: N = 1, finishes within minutes
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "7", "--warmup", "2"])
+    a = bench.parse_args()
+    assert (a.gpus, a.steps, a.warmup) == (8, 7, 2)
+    assert 1 <= bench.usable_cores() <= (os.cpu_count() or 1)
+    traffic = json.loads((root / "profiles" / "pmc_traffic.json").read_text())["gemm_bf16_8192_algo5"]
+    assert bench.pmc_traffic(8192, 5) == traffic["hbm_bytes_per_launch"] == traffic["fetch_bytes"] + traffic["write_bytes"]
+    assert bench.pmc_traffic(4096, 5) is None and bench.pmc_traffic(8192, 3) is None   # no PMC pass for these: null, not a guess
+    util = bench.pmc_mfma_util(8192)
+    assert util is not None and 0.5 < util < 1.0 and bench.pmc_mfma_util(1234) is None
+    assert bench.PEAK_BF16_TFLOPS == 2500.0 and bench.PEAK_HBM_GBS == 8000.0 and bench.PEAK_F32_TFLOPS == 157.3
