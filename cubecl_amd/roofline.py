@@ -9,6 +9,8 @@ Mirrors crates/cubecl-runtime/src/throughput/:
   * base.rs:10-214         `MemoryAccess`, `ThroughputMode`, `ThroughputKey`, `ThroughputValue` (+ `format`),
                            `compute_throughput_key`
   * cmma.rs:4-60           `CmmaDims`, `ComputeCmmaConfig`, `select_cmma_tile`
+and crates/cubecl-runtime/src/tune/bounds_generator.rs:14-151: `AutotuneBound`, `calculate_bounds`, the `time_limit`
+reductions (`bounds_time_limit`, `TuneBounds`).
 
 Pure host logic: no device, no library call.  Element types are this package's `ElemType` integers, so only the keys
 without a type (`{"mode":"Memory"}` ..., the forms the reference pins in base.rs:218-240) serialise identically.  Durations are seconds (float) except where the reference's arithmetic
@@ -86,6 +88,46 @@ def binding_achieved(scores: Sequence[AchievedThroughput]) -> Optional[AchievedT
         if math.isfinite(s.fraction_of_peak) and (best is None or s.fraction_of_peak >= best.fraction_of_peak):
             best = s
     return best
+
+
+# ---- tune/bounds_generator.rs: the roofline as a time limit ------------------------------------------------------------
+@dataclass(frozen=True)
+class AutotuneBound:
+    """bounds_generator.rs:63-137: a resource bound and the fraction of its peak a good kernel is expected to reach."""
+    resource: ResourceBound
+    threshold: float
+
+    def time_limit(self) -> Optional[float]:
+        """time at peak / threshold; None when the threshold (or the peak) is zero, NaN or infinite."""
+        if not _is_normal(self.threshold):
+            return None
+        t = self.resource.time_at_peak()
+        return None if t is None else t / self.threshold
+
+
+def bounds_time_limit(bounds: Sequence[AutotuneBound]) -> Optional[float]:
+    """:139-143 -- resources overlap at best, so the achievable floor is the SLOWER bound: max, not min."""
+    limits = [t for t in (b.time_limit() for b in bounds) if t is not None]
+    return max(limits) if limits else None
+
+
+@dataclass(frozen=True)
+class TuneBounds:
+    """bounds_generator.rs:14-24 `Bounds`: the per-resource bounds of one launch plus the launch overhead."""
+    bounds: Tuple[AutotuneBound, ...]
+    launch_overhead: float = 0.0                 # seconds
+
+    def time_limit(self) -> Optional[float]:
+        """:145-151 -- no usable bound means no limit at all: the launch overhead is not a limit on its own."""
+        limit = bounds_time_limit(self.bounds)
+        return None if limit is None else limit + self.launch_overhead
+
+
+def calculate_bounds(work, thresholds, compute_throughput: "ThroughputValue", memory_throughput: "ThroughputValue",
+                     memory_key: "ThroughputKey") -> List[AutotuneBound]:
+    """:104-127.  `work` has `compute_ops` and `bytes` (cubecl_common::work::Work), `thresholds` has `compute` and `memory`."""
+    return [AutotuneBound(ResourceBound(work.compute_ops, compute_throughput.ops_per_s()), thresholds.compute),
+            AutotuneBound(ResourceBound(work.bytes, memory_throughput.bytes_per_s(memory_key)), thresholds.memory)]
 
 
 # ---- base.rs / cmma.rs: keys and values -------------------------------------------------------------------------------

@@ -551,3 +551,27 @@ def test_bench_helpers_and_contract_defaults(monkeypatch):
     util = bench.pmc_mfma_util(8192)
     assert util is not None and 0.5 < util < 1.0 and bench.pmc_mfma_util(1234) is None
     assert bench.PEAK_BF16_TFLOPS == 2500.0 and bench.PEAK_HBM_GBS == 8000.0 and bench.PEAK_F32_TFLOPS == 157.3
+
+
+# ---- crates/cubecl-runtime/src/tune/bounds_generator.rs tests (:153-260), ported one for one ---------------------------
+def test_autotune_bounds_known_answers():
+    from cubecl_amd import roofline as R
+    from cubecl_amd.throughput import Thresholds, Work
+    bound = lambda ops, peak, thr: R.AutotuneBound(R.ResourceBound(ops, peak), thr)
+    assert bound(8, 4.0, 0.5).time_limit() == 4.0                                      # (8 / 4) / 0.5
+    for b in (bound(8, 0.0, 0.5), bound(8, float("nan"), 0.5), bound(8, float("inf"), 0.5), bound(8, 4.0, 0.0)):
+        assert b.time_limit() is None
+    assert R.bounds_time_limit([bound(8, 4.0, 1.0), bound(8, 8.0, 1.0)]) == 2.0        # the roofline max, not min
+    assert R.bounds_time_limit([bound(8, 0.0, 1.0), bound(8, 4.0, 1.0)]) == 2.0 and R.bounds_time_limit([]) is None
+    assert R.TuneBounds((bound(8, 4.0, 1.0),), 0.5).time_limit() == 2.5
+    assert R.TuneBounds((), 0.5).time_limit() is None                                  # overhead alone is not a limit
+    key = R.ThroughputKey(R.ThroughputMode.Memory)
+    b = R.calculate_bounds(Work(8, 16), Thresholds(0.5, 1.0), R.ThroughputValue.ZERO, R.ThroughputValue.ZERO, key)
+    assert (b[0].resource.amount, b[0].threshold, b[1].resource.amount, b[1].threshold) == (8, 0.5, 16, 1.0)
+    assert R.bounds_time_limit(b) is None                                              # ZERO throughputs are NaN peaks
+    # measured-style values: 1 PFLOP/s-s of work at 2 PFLOP/s and 0.5 TB at 5 TB/s (F32 elements in the memory value)
+    cmma, mem = R.ThroughputValue(2_000_000, 1e-9), R.ThroughputValue(1_250_000_000, 1e-3)
+    b = R.calculate_bounds(Work(10 ** 15, 5 * 10 ** 11), Thresholds.uniform(1.0), cmma, mem, key)
+    assert b[0].time_limit() == pytest.approx(0.5) and b[1].time_limit() == pytest.approx(0.1)
+    assert R.TuneBounds(tuple(b), 3e-6).time_limit() == pytest.approx(0.500003)
+    assert Thresholds.uniform(1.0) == Thresholds(1.0, 1.0)
