@@ -22,8 +22,10 @@ def lib():
     so = FAKE / "libpooltest.so"
     srcs = [ROOT / "cubecl_amd" / "csrc" / "pool.cpp", ROOT / "cubecl_amd" / "csrc" / "internal.hpp", FAKE / "fake_hip.cpp",
             FAKE / "hip" / "hip_runtime.h", ROOT / "include" / "mi355cube.h"]
-    if not so.exists() or so.stat().st_mtime < max(s.stat().st_mtime for s in srcs):
-        subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-shared", "-fPIC", "-I", str(FAKE), "-o", str(so),
+    # -Bsymbolic: the fake hip* / mi355_* definitions inside this library win over the real ones when libmi355cube.so
+    # (and with it libamdhip64) is already loaded in the test process
+    if not so.exists() or so.stat().st_mtime < max(s.stat().st_mtime for s in srcs + [Path(__file__)]):
+        subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-I", str(FAKE), "-o", str(so),
                         str(srcs[0]), str(srcs[2])], check=True)
     lib = C.CDLL(str(so))
     lib.pooltest_ctx_create.restype = C.c_void_p
