@@ -5,6 +5,7 @@
 #include "../../cubecl_amd/csrc/internal.hpp"
 
 #include <set>
+#include <sys/mman.h>
 
 struct fake_hip_stream { uint64_t submitted = 0, completed = 0; };
 struct fake_hip_event { fake_hip_stream *stream = nullptr; uint64_t seq = 0; };
@@ -12,7 +13,6 @@ struct fake_hip_event { fake_hip_stream *stream = nullptr; uint64_t seq = 0; };
 namespace {
 struct fake_state {
     std::map<uintptr_t, size_t> live;         // device allocations
-    uintptr_t next = 0x7f0000000000ull;
     uint64_t capacity = ~0ull, in_use = 0;
     uint64_t mallocs = 0, frees = 0, bad_frees = 0, event_creates = 0, event_destroys = 0, event_queries = 0, device_syncs = 0;
     std::set<fake_hip_stream *> streams;
@@ -29,12 +29,13 @@ const char *hipGetErrorString(hipError_t e) { return e == hipErrorOutOfMemory ? 
 hipError_t hipMalloc(void **ptr, size_t bytes)
 {
     if (g.in_use + bytes > g.capacity) { *ptr = nullptr; return hipErrorOutOfMemory; }
-    const uintptr_t p = g.next;
-    g.next += (bytes + (2u << 20) - 1) / (2u << 20) * (2u << 20) + (2u << 20);    // 2 MiB aligned, with a guard gap
-    g.live[p] = bytes;
+    // address space only (MAP_NORESERVE): pages exist once a copy touches them, so 256 MiB slab pages cost nothing
+    void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (m == MAP_FAILED) { *ptr = nullptr; return hipErrorOutOfMemory; }
+    g.live[reinterpret_cast<uintptr_t>(m)] = bytes;
     g.in_use += bytes;
     ++g.mallocs;
-    *ptr = reinterpret_cast<void *>(p);
+    *ptr = m;
     return hipSuccess;
 }
 
@@ -42,6 +43,7 @@ hipError_t hipFree(void *ptr)
 {
     auto it = g.live.find(reinterpret_cast<uintptr_t>(ptr));
     if (it == g.live.end()) { ++g.bad_frees; return hipErrorInvalidValue; }
+    munmap(ptr, it->second);
     g.in_use -= it->second;
     g.live.erase(it);
     ++g.frees;
@@ -88,6 +90,7 @@ hipError_t hipEventQuery(hipEvent_t event)
 
 }  // extern "C"
 
+#ifndef FAKE_WITH_RUNTIME
 // ---- what pool.cpp needs from runtime.cpp -------------------------------------------------------------------------
 namespace mi355 {
 int32_t fail(mi355_ctx *ctx, int32_t code, const char *fmt, ...)
@@ -112,9 +115,12 @@ void queue_error(mi355_ctx *ctx, int32_t code, uint64_t requested, uint64_t max,
 int32_t map_hip_error(hipError_t e) { return e == hipSuccess ? MI355_OK : e == hipErrorOutOfMemory ? MI355_E_OUT_OF_MEMORY : MI355_E_EXECUTION; }
 }  // namespace mi355
 
+#endif
+
 // ---- test controls --------------------------------------------------------------------------------------------------
 #define TEST_API extern "C" __attribute__((visibility("default")))
 
+#ifndef FAKE_WITH_RUNTIME
 TEST_API mi355_ctx *pooltest_ctx_create(uint64_t max_page_size)
 {
     mi355_ctx *ctx = new mi355_ctx();
@@ -130,6 +136,7 @@ TEST_API void pooltest_ctx_destroy(mi355_ctx *ctx)
     delete ctx->compute_stream;
     delete ctx;
 }
+#endif
 TEST_API void *pooltest_stream_create(void)
 {
     fake_hip_stream *s = new fake_hip_stream();
@@ -164,4 +171,116 @@ TEST_API int32_t pooltest_inside_allocation(void *ptr, uint64_t bytes)
     if (it == g.live.begin()) return 0;
     --it;
     return p >= it->first && p + bytes <= it->first + it->second;
+}
+
+// ---- the rest of the HIP surface runtime.cpp / comm.cpp use: everything executes at once, in order -------------------
+struct fake_hip_module { int tag; };
+struct fake_hip_function { char name[64]; };
+struct fake_hip_graph { int nodes; };
+struct fake_hip_graph_exec { int nodes; };
+
+namespace {
+struct runtime_state {
+    char arch[64] = "gfx950:sramecc+:xnack-";
+    int warp = 64, devices = 1;
+    hipError_t fail_next_sync = hipSuccess, fail_next_launch = hipSuccess;
+    uint64_t launches = 0, graph_launches = 0, captured = 0;
+    unsigned last_launch[8] = {0};          // grid xyz, block xyz, lds bytes, number of parameters seen
+    uintptr_t last_params[8] = {0};
+    bool capturing = false;
+    int max_dynamic_lds = 0;
+} r;
+void work(hipStream_t s) { if (s) { ++s->submitted; s->completed = s->submitted; } }
+}  // namespace
+
+extern "C" {
+hipError_t hipGetDeviceCount(int *count) { *count = r.devices; return r.devices > 0 ? hipSuccess : hipErrorNoDevice; }
+hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int)
+{
+    memset(p, 0, sizeof *p);
+    snprintf(p->name, sizeof p->name, "Fake Instinct");
+    snprintf(p->gcnArchName, sizeof p->gcnArchName, "%s", r.arch);
+    p->totalGlobalMem = 288ull << 30; p->sharedMemPerBlock = 64 << 10; p->maxSharedMemoryPerMultiProcessor = 160 << 10;
+    p->textureAlignment = 256; p->surfaceAlignment = 256; p->warpSize = r.warp; p->maxThreadsPerBlock = 1024;
+    p->maxThreadsDim[0] = p->maxThreadsDim[1] = p->maxThreadsDim[2] = 1024;
+    p->maxGridSize[0] = 2147483647; p->maxGridSize[1] = p->maxGridSize[2] = 65535;
+    p->multiProcessorCount = 256; p->clockRate = 2400000; p->memoryClockRate = 2000000; p->memoryBusWidth = 8192; p->l2CacheSize = 4 << 20;
+    return hipSuccess;
+}
+hipError_t hipMemGetInfo(size_t *f, size_t *t) { *t = 288ull << 30; *f = *t - g.in_use; return hipSuccess; }
+hipError_t hipDeviceCanAccessPeer(int *can, int, int) { *can = 1; return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = new fake_hip_stream(); g.streams.insert(*s); return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t s) { g.streams.erase(s); delete s; return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t s)
+{
+    if (s) s->completed = s->submitted;
+    const hipError_t e = r.fail_next_sync;
+    r.fail_next_sync = hipSuccess;
+    return e;
+}
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t *e) { return hipEventCreateWithFlags(e, 0); }
+hipError_t hipEventSynchronize(hipEvent_t e) { if (e && e->stream) e->stream->completed = e->stream->submitted; return hipSuccess; }
+hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 1.5f; return hipSuccess; }
+hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) { *p = malloc(bytes); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t st) { memcpy(d, s, n); work(st); return hipSuccess; }
+hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t st)
+{
+    for (size_t i = 0; i < h; ++i) memcpy(static_cast<char *>(d) + i * dp, static_cast<const char *>(s) + i * sp, w);
+    work(st);
+    return hipSuccess;
+}
+hipError_t hipMemcpyPeerAsync(void *d, int, const void *s, int, size_t n, hipStream_t st) { memcpy(d, s, n); work(st); return hipSuccess; }
+hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t st) { memset(d, v, n); work(st); return hipSuccess; }
+hipError_t hipModuleLoadData(hipModule_t *m, const void *image)
+{
+    if (memcmp(image, "FAKEHSACO", 9) != 0) return hipErrorInvalidValue;      // what a bad code object gets from the driver
+    *m = new fake_hip_module{1};
+    return hipSuccess;
+}
+hipError_t hipModuleUnload(hipModule_t m) { delete m; return hipSuccess; }
+hipError_t hipModuleGetFunction(hipFunction_t *f, hipModule_t, const char *name)
+{
+    if (strncmp(name, "missing", 7) == 0) return hipErrorNotFound;
+    *f = new fake_hip_function();
+    snprintf((*f)->name, sizeof (*f)->name, "%s", name);
+    return hipSuccess;
+}
+hipError_t hipModuleLaunchKernel(hipFunction_t, unsigned gx, unsigned gy, unsigned gz, unsigned bx, unsigned by, unsigned bz,
+                                 unsigned lds, hipStream_t st, void **params, void **)
+{
+    if (r.fail_next_launch != hipSuccess) { const hipError_t e = r.fail_next_launch; r.fail_next_launch = hipSuccess; return e; }
+    const unsigned v[7] = {gx, gy, gz, bx, by, bz, lds};
+    memcpy(r.last_launch, v, sizeof v);
+    for (int i = 0; i < 8; ++i) r.last_params[i] = 0;
+    if (params) for (int i = 0; i < 8 && i < (int)r.last_launch[7]; ++i) r.last_params[i] = *reinterpret_cast<uintptr_t *>(params[i]);
+    if (r.capturing) ++r.captured; else ++r.launches;
+    work(st);
+    return hipSuccess;
+}
+hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int value) { r.max_dynamic_lds = value; return hipSuccess; }
+hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { r.capturing = true; r.captured = 0; return hipSuccess; }
+hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *graph)
+{
+    r.capturing = false;
+    *graph = new fake_hip_graph{(int)r.captured};
+    return hipSuccess;
+}
+hipError_t hipGraphInstantiate(hipGraphExec_t *x, hipGraph_t graph, void *, char *, size_t) { *x = new fake_hip_graph_exec{graph->nodes}; return hipSuccess; }
+hipError_t hipGraphLaunch(hipGraphExec_t x, hipStream_t st) { r.graph_launches += 1; r.launches += (uint64_t)x->nodes; work(st); return hipSuccess; }
+hipError_t hipGraphExecDestroy(hipGraphExec_t x) { delete x; return hipSuccess; }
+hipError_t hipGraphDestroy(hipGraph_t graph) { delete graph; return hipSuccess; }
+}  // extern "C"
+
+TEST_API void faketest_set_device(const char *arch, int32_t warp, int32_t devices) { snprintf(r.arch, sizeof r.arch, "%s", arch); r.warp = warp; r.devices = devices; }
+TEST_API void faketest_fail_next(int32_t sync_error, int32_t launch_error) { r.fail_next_sync = sync_error; r.fail_next_launch = launch_error; }
+TEST_API void faketest_expect_params(uint32_t n) { r.last_launch[7] = n; }
+// {launches executed, graph replays, nodes in the last capture, grid xyz, block xyz, lds, max dynamic LDS attribute, params...}
+TEST_API void faketest_launch_log(uint64_t out[20])
+{
+    out[0] = r.launches; out[1] = r.graph_launches; out[2] = r.captured;
+    for (int i = 0; i < 7; ++i) out[3 + i] = r.last_launch[i];
+    out[10] = (uint64_t)r.max_dynamic_lds;
+    for (int i = 0; i < 8; ++i) out[11 + i] = r.last_params[i];
 }

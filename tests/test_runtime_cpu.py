@@ -1,0 +1,218 @@
+"""The host runtime behind the C ABI (cubecl_amd/csrc/runtime.cpp + pool.cpp + comm.cpp) on a fake device: the product
+sources compiled with g++ against tests/fake_hip/ (device memory = anonymous mappings, every stream operation executes at
+once, failures injected on request).  What the reference checks on its DummyServer (crates/cubecl-runtime/tests/
+integration_test.rs) and in runtime_tests/launch.rs -- context creation, storage, IO, the fire-and-forget error queue,
+resource limits, profiling tokens, graph capture -- checked here without a GPU; the same cases run on the MI355X in
+tests/test_gpu_runtime.py.  Test infrastructure only."""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from cubecl_amd import _native as N
+
+ROOT = Path(__file__).resolve().parents[1]
+FAKE = ROOT / "tests" / "fake_hip"
+CSRC = ROOT / "cubecl_amd" / "csrc"
+HIP_ERROR_LAUNCH_FAILURE, HIP_ERROR_INVALID_VALUE = 719, 1
+
+
+@pytest.fixture(scope="module")
+def lib():
+    so = FAKE / "libruntimetest.so"
+    srcs = [CSRC / "runtime.cpp", CSRC / "pool.cpp", CSRC / "comm.cpp", FAKE / "fake_hip.cpp"]
+    deps = srcs + [CSRC / "internal.hpp", FAKE / "hip" / "hip_runtime.h", ROOT / "include" / "mi355cube.h", Path(__file__)]
+    if not so.exists() or so.stat().st_mtime < max(d.stat().st_mtime for d in deps):
+        subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-Wno-format-truncation", "-DFAKE_WITH_RUNTIME", "-shared",
+                        "-fPIC", "-Wl,-Bsymbolic", "-I", str(FAKE), "-o", str(so)] + [str(s) for s in srcs] + ["-ldl"], check=True)
+    lib = C.CDLL(str(so))
+    for name, (restype, argtypes) in N.PROTOTYPES.items():          # the product's own prototype table
+        if hasattr(lib, name):
+            getattr(lib, name).restype, getattr(lib, name).argtypes = restype, argtypes
+    lib.faketest_set_device.argtypes = [C.c_char_p, C.c_int32, C.c_int32]
+    lib.faketest_fail_next.argtypes = [C.c_int32, C.c_int32]
+    lib.faketest_expect_params.argtypes = [C.c_uint32]
+    lib.faketest_launch_log.argtypes = [C.POINTER(C.c_uint64)]
+    lib.pooltest_set_capacity.argtypes = [C.c_uint64]
+    lib.pooltest_counters.argtypes = [C.POINTER(C.c_uint64)]
+    return lib
+
+
+@pytest.fixture()
+def ctx(lib):
+    lib.faketest_set_device(b"gfx950:sramecc+:xnack-", 64, 1)
+    lib.pooltest_set_capacity(288 << 30)
+    c = C.c_void_p()
+    assert lib.mi355_ctx_create(0, C.byref(c)) == N.OK
+    yield c
+    assert lib.mi355_ctx_destroy(c) == N.OK
+
+
+def _device(lib):
+    out = (C.c_uint64 * 8)()
+    lib.pooltest_counters(out)
+    return dict(zip(("mallocs", "frees", "bad_frees", "live", "in_use", "events", "event_queries", "device_syncs"), out))
+
+
+def _launches(lib):
+    out = (C.c_uint64 * 20)()
+    lib.faketest_launch_log(out)
+    return list(out)
+
+
+def _pop(lib, ctx):
+    code, req, mx, buf = C.c_int32(), C.c_uint64(), C.c_uint64(), C.create_string_buffer(512)
+    rc = lib.mi355_error_pop(ctx, C.byref(code), C.byref(req), C.byref(mx), buf, 512)
+    return rc, code.value, req.value, mx.value, buf.value.decode()
+
+
+def test_context_refuses_everything_but_wave64_gfx950_and_describes_the_device(lib, ctx):
+    p = N.DeviceProps()
+    assert lib.mi355_device_props(ctx, C.byref(p)) == N.OK
+    assert (p.plane_size_min, p.plane_size_max, p.load_width_bits, p.num_streaming_multiprocessors, p.num_xcd) == (64, 64, 128, 256, 8)
+    assert p.max_shared_memory_size == 160 << 10 and p.max_units_per_cube == 1024 and tuple(p.max_cube_count) == (2147483647, 65535, 65535)
+    assert p.gcn_arch_name.startswith(b"gfx950") and p.fingerprint.startswith(b"mi355-aot_gfx950") and p.mem_alignment == 256
+    assert p.total_memory == 288 << 30 and p.max_page_size == (288 << 30) // 4 and p.plane_ops == 1 and p.abi_version == N.ABI_VERSION
+    cfgs = {(c.a_type, c.cd_type, c.m, c.n, c.k) for c in p.mma_configs[: p.num_mma_configs]}
+    assert {(N.DTYPE_BF16, N.DTYPE_F32, 32, 32, 16), (N.DTYPE_F32, N.DTYPE_F32, 32, 32, 2), (N.DTYPE_F16, N.DTYPE_F32, 16, 16, 16),
+            (N.DTYPE_F8E4M3, N.DTYPE_F32, 32, 32, 64)} <= cfgs and p.num_scaled_mma_configs == 5
+    other = C.c_void_p()
+    for arch, warp, count, index in ((b"gfx942:sramecc+", 64, 1, 0), (b"gfx1100", 32, 1, 0), (b"gfx950", 64, 0, 0), (b"gfx950", 64, 1, 3)):
+        lib.faketest_set_device(arch, warp, count)
+        assert lib.mi355_ctx_create(index, C.byref(other)) == N.E_NO_DEVICE and not other.value
+        assert lib.mi355_last_global_error()                               # says why: a loud error, not a fallback
+    n = C.c_int32(7)
+    assert lib.mi355_device_count(C.byref(n)) == N.OK and n.value == 1
+    assert lib.mi355_ctx_create(0, None) == N.E_INVALID_ARGUMENT and lib.mi355_sync(None, None) == N.E_INVALID_ARGUMENT
+
+
+def test_storage_limits_deferred_frees_and_io_round_trips(lib, ctx):
+    p = C.c_void_p()
+    assert lib.mi355_alloc(ctx, (72 << 30) + 1, C.byref(p)) == N.E_BUFFER_TOO_BIG and b"max_page_size" in lib.mi355_last_error(ctx)
+    assert lib.mi355_alloc(ctx, 0, C.byref(p)) == N.OK and not p.value                      # empty allocation
+    a, b = C.c_void_p(), C.c_void_p()
+    assert lib.mi355_alloc(ctx, 1 << 20, C.byref(a)) == N.OK and lib.mi355_alloc(ctx, 1 << 20, C.byref(b)) == N.OK
+    live = _device(lib)["live"]
+    assert lib.mi355_free(ctx, a) == N.OK and _device(lib)["live"] == live                  # deferred: nothing reaches the driver ...
+    assert lib.mi355_flush(ctx) == N.OK and _device(lib)["live"] == live - 1                # ... before flush, behind a device sync
+    lib.pooltest_set_capacity(_device(lib)["in_use"] + (1 << 20))
+    assert lib.mi355_free(ctx, b) == N.OK
+    assert lib.mi355_alloc(ctx, 2 << 20, C.byref(a)) == N.OK                                # OOM -> pending frees released -> retry fits
+    assert lib.mi355_alloc(ctx, 2 << 20, C.byref(b)) == N.E_OUT_OF_MEMORY                   # a driver OOM is OutOfMemory, not BufferTooBig
+    lib.pooltest_set_capacity(288 << 30)
+    x = np.arange(1000, dtype=np.float32)
+    back = np.zeros_like(x)
+    assert lib.mi355_write(ctx, None, a, x.ctypes.data, x.nbytes) == N.OK
+    assert lib.mi355_read(ctx, None, back.ctypes.data, a, x.nbytes) == N.OK and np.array_equal(back, x)
+    assert lib.mi355_write(ctx, None, None, None, 0) == N.OK and lib.mi355_write(ctx, None, None, x.ctypes.data, 4) == N.E_INVALID_ARGUMENT
+    # pitched rows (PitchedMemoryLayoutPolicy): 5 rows of 100 bytes on a 128-byte pitch, padding left alone
+    pitch = C.c_uint64()
+    for width, want in ((100, 128), (5, 16), (16, 16), (300, 512), (4096, 4096), (4100, 4352), (0, 0)):
+        assert lib.mi355_pitched_row_bytes(ctx, width, C.byref(pitch)) == N.OK and pitch.value == want, width
+    assert lib.mi355_memset(ctx, None, a, 0xEE, 5 * 128) == N.OK
+    rows = np.arange(500, dtype=np.uint8).reshape(5, 100)
+    assert lib.mi355_write_2d(ctx, None, a, 128, rows.ctypes.data, 100, 100, 5) == N.OK
+    raw = np.zeros(5 * 128, dtype=np.uint8)
+    assert lib.mi355_read(ctx, None, raw.ctypes.data, a, raw.nbytes) == N.OK
+    assert np.array_equal(raw.reshape(5, 128)[:, :100], rows) and np.all(raw.reshape(5, 128)[:, 100:] == 0xEE)
+    out = np.zeros((5, 100), dtype=np.uint8)
+    assert lib.mi355_read_2d(ctx, None, out.ctypes.data, 100, a, 128, 100, 5) == N.OK and np.array_equal(out, rows)
+    assert lib.mi355_write_2d(ctx, None, a, 64, rows.ctypes.data, 100, 100, 5) == N.E_UNSUPPORTED_STRIDES
+    c = C.c_void_p()
+    assert lib.mi355_alloc(ctx, 4096, C.byref(c)) == N.OK and lib.mi355_copy_d2d(ctx, None, c, a, 640) == N.OK
+    assert lib.mi355_read(ctx, None, raw.ctypes.data, c, 640) == N.OK and np.array_equal(raw.reshape(5, 128)[:, :100], rows)
+    for ptr in (a, c):
+        lib.mi355_free(ctx, ptr)
+
+
+def test_launch_is_fire_and_forget_and_failures_surface_at_flush(lib, ctx):
+    mod, fn = C.c_void_p(), C.c_void_p()
+    assert lib.mi355_module_load(ctx, b"not a code object", 17, C.byref(mod)) == N.E_COMPILATION
+    assert lib.mi355_module_load(ctx, b"FAKEHSACO....", 13, C.byref(mod)) == N.OK
+    assert lib.mi355_module_get_function(ctx, mod, b"missing_kernel", C.byref(fn)) == N.E_NOT_FOUND
+    assert lib.mi355_module_get_function(ctx, mod, b"abi_axpb", C.byref(fn)) == N.OK
+    grid, block = (C.c_uint32 * 3), (C.c_uint32 * 3)
+    ptrs = (C.c_void_p * 3)(0x1000, 0x2000, 0x3000)
+    n0 = _launches(lib)[0]
+    for zero in ((0, 1, 1), (1, 0, 1), (1, 1, 0)):                                          # client.rs:880-884: a no-op, not an error
+        assert lib.mi355_launch(ctx, None, fn, grid(*zero), block(64, 1, 1), 0, ptrs, 3) == N.OK
+    assert _launches(lib)[0] == n0 and lib.mi355_flush(ctx) == N.OK
+    lib.faketest_expect_params(3)
+    assert lib.mi355_launch(ctx, None, fn, grid(4, 2, 1), block(256, 1, 1), 96 << 10, ptrs, 3) == N.OK
+    log = _launches(lib)
+    assert log[0] == n0 + 1 and log[3:10] == [4, 2, 1, 256, 1, 1, 96 << 10] and log[10] == 96 << 10     # > 64 KiB of LDS: opted in
+    assert log[11:14] == [0x1000, 0x2000, 0x3000]                                           # kernelParams[i] -> the i-th pointer VALUE
+    # resource limits (runtime_tests/launch.rs:226-348): accepted, queued, reported by the next flush with their numbers
+    assert lib.mi355_launch(ctx, None, fn, grid(1, 1, 1), block(64, 1, 1), (160 << 10) + 1, ptrs, 3) == N.OK
+    assert lib.mi355_launch(ctx, None, fn, grid(1, 1, 1), block(2048, 1, 1), 0, ptrs, 3) == N.OK
+    assert lib.mi355_launch(ctx, None, fn, grid(1, 1, 1), block(64, 32, 1), 0, ptrs, 3) == N.OK
+    lib.faketest_fail_next(0, HIP_ERROR_LAUNCH_FAILURE)
+    assert lib.mi355_launch(ctx, None, fn, grid(1, 1, 1), block(64, 1, 1), 0, ptrs, 3) == N.OK
+    count = C.c_int32()
+    assert _launches(lib)[0] == n0 + 1 and lib.mi355_error_count(ctx, C.byref(count)) == N.OK and count.value == 4
+    assert lib.mi355_flush(ctx) == N.E_SERVER_UNHEALTHY and b"4 queued error" in lib.mi355_last_error(ctx)
+    assert _pop(lib, ctx)[:4] == (N.OK, N.E_SHARED_MEMORY, (160 << 10) + 1, 160 << 10)
+    rc, code, req, mx, msg = _pop(lib, ctx)
+    assert (code, req, mx) == (N.E_CUBE_DIM, 2048, 1024) and "(2048, 1, 1), max is (1024, 1024, 1024)" in msg
+    assert _pop(lib, ctx)[1:4] == (N.E_UNITS, 2048, 1024) and _pop(lib, ctx)[1] == N.E_LAUNCH
+    assert _pop(lib, ctx)[0] == N.E_NOT_FOUND and lib.mi355_flush(ctx) == N.OK              # drained: healthy again
+    # an execution failure discovered at a synchronisation point is reported the same way
+    lib.faketest_fail_next(HIP_ERROR_INVALID_VALUE, 0)
+    assert lib.mi355_sync(ctx, None) == N.E_SERVER_UNHEALTHY and _pop(lib, ctx)[1] == N.E_EXECUTION and lib.mi355_sync(ctx, None) == N.OK
+    assert lib.mi355_launch(ctx, None, None, grid(1, 1, 1), block(1, 1, 1), 0, ptrs, 3) == N.E_INVALID_ARGUMENT
+    assert lib.mi355_module_unload(ctx, mod) == N.OK
+
+
+def test_profile_tokens_events_and_graph_capture(lib, ctx):
+    token, nanos = C.c_uint64(), C.c_uint64()
+    assert lib.mi355_profile_start(ctx, None, C.byref(token)) == N.OK and token.value == 1
+    second = C.c_uint64()
+    assert lib.mi355_profile_start(ctx, None, C.byref(second)) == N.OK and second.value == 2              # nested regions
+    assert lib.mi355_profile_stop(ctx, None, token, C.byref(nanos)) == N.OK and nanos.value == 1_500_000
+    assert lib.mi355_profile_stop(ctx, None, token, C.byref(nanos)) == N.E_PROFILE                         # a token ends once
+    assert lib.mi355_profile_stop(ctx, None, second, C.byref(nanos)) == N.OK and lib.mi355_profile_stop(ctx, None, 99, C.byref(nanos)) == N.E_PROFILE
+    assert lib.mi355_profile_start(ctx, None, C.byref(token)) == N.OK and token.value == 1                 # slots are reused
+    assert lib.mi355_profile_stop(ctx, None, token, None) == N.OK
+    ea, eb, ms = C.c_void_p(), C.c_void_p(), C.c_float()
+    assert lib.mi355_event_create(ctx, C.byref(ea)) == N.OK and lib.mi355_event_create(ctx, C.byref(eb)) == N.OK
+    assert lib.mi355_event_record(ctx, ea, None) == N.OK and lib.mi355_event_record(ctx, eb, None) == N.OK and lib.mi355_event_sync(ctx, eb) == N.OK
+    assert lib.mi355_event_elapsed_ms(ctx, ea, eb, C.byref(ms)) == N.OK and ms.value == 1.5 and lib.mi355_event_record(ctx, None, None) == N.E_INVALID_ARGUMENT
+    assert lib.mi355_event_destroy(ctx, ea) == N.OK and lib.mi355_event_destroy(ctx, eb) == N.OK
+    # graph capture (server/base.rs:472-532): three launches captured, none executed, every replay runs the three
+    mod, fn, graph = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert lib.mi355_module_load(ctx, b"FAKEHSACO", 9, C.byref(mod)) == N.OK and lib.mi355_module_get_function(ctx, mod, b"k", C.byref(fn)) == N.OK
+    assert lib.mi355_graph_end_capture(ctx, None, C.byref(graph)) == N.E_INVALID_ARGUMENT                   # no window open
+    assert lib.mi355_graph_begin_capture(ctx, None) == N.OK and lib.mi355_graph_begin_capture(ctx, None) == N.E_INVALID_ARGUMENT
+    one, before = (C.c_uint32 * 3)(1, 1, 1), _launches(lib)[0]
+    p = C.c_void_p()
+    assert lib.mi355_pool_alloc(ctx, None, 1 << 20, C.byref(p)) == N.E_UNSUPPORTED                          # no driver allocation inside the window
+    for _ in range(3):
+        assert lib.mi355_launch(ctx, None, fn, one, one, 0, None, 0) == N.OK
+    assert lib.mi355_graph_end_capture(ctx, None, C.byref(graph)) == N.OK and graph.value and _launches(lib)[0] == before
+    for _ in range(2):
+        assert lib.mi355_graph_replay(ctx, None, graph) == N.OK
+    log = _launches(lib)
+    assert log[0] == before + 6 and log[2] == 3 and lib.mi355_graph_replay(ctx, None, None) == N.E_NOT_FOUND
+    assert lib.mi355_graph_destroy(ctx, graph) == N.OK and lib.mi355_pool_alloc(ctx, None, 1 << 20, C.byref(p)) == N.OK
+    assert lib.mi355_pool_free(ctx, None, p) == N.OK and lib.mi355_module_unload(ctx, mod) == N.OK
+
+
+def test_two_contexts_move_data_and_collectives_need_a_communicator(lib, ctx):
+    other = C.c_void_p()
+    assert lib.mi355_ctx_create(0, C.byref(other)) == N.OK
+    a, b = C.c_void_p(), C.c_void_p()
+    assert lib.mi355_alloc(ctx, 4096, C.byref(a)) == N.OK and lib.mi355_alloc(other, 4096, C.byref(b)) == N.OK
+    x, back = np.arange(1024, dtype=np.int32), np.zeros(1024, dtype=np.int32)
+    assert lib.mi355_write(ctx, None, a, x.ctypes.data, 4096) == N.OK
+    assert lib.mi355_copy_to_ctx(ctx, None, a, other, None, b, 4096) == N.OK                                # ComputeClient::to_client
+    assert lib.mi355_read(other, None, back.ctypes.data, b, 4096) == N.OK and np.array_equal(back, x)
+    assert lib.mi355_copy_to_ctx(ctx, None, a, other, None, b, 0) == N.OK and lib.mi355_copy_to_ctx(ctx, None, None, other, None, b, 8) == N.E_INVALID_ARGUMENT
+    assert lib.mi355_all_reduce(ctx, None, None, a, a, 1, N.DTYPE_F32, N.REDUCE_SUM) == N.E_INVALID_ARGUMENT     # before comm_init
+    assert b"mi355_comm_init" in lib.mi355_last_error(ctx) and lib.mi355_sync_collective(ctx, None) == N.OK
+    s = C.c_void_p()
+    assert lib.mi355_stream_create(ctx, C.byref(s)) == N.OK and lib.mi355_sync(ctx, s) == N.OK and lib.mi355_stream_destroy(ctx, s) == N.OK
+    for c_, p_ in ((ctx, a), (other, b)):
+        lib.mi355_free(c_, p_)
+    assert lib.mi355_ctx_destroy(other) == N.OK
