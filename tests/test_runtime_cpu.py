@@ -216,3 +216,31 @@ def test_two_contexts_move_data_and_collectives_need_a_communicator(lib, ctx):
     for c_, p_ in ((ctx, a), (other, b)):
         lib.mi355_free(c_, p_)
     assert lib.mi355_ctx_destroy(other) == N.OK
+
+
+def test_remaining_runtime_entry_points(lib, ctx):
+    """Pinned staging, asynchronous reads behind an event, stream getters, memory info, the pool behind client.empty."""
+    host, dev = C.c_void_p(), C.c_void_p()
+    assert lib.mi355_pinned_alloc(ctx, 4096, C.byref(host)) == N.OK and host.value and lib.mi355_pinned_alloc(ctx, 0, C.byref(dev)) == N.OK
+    assert lib.mi355_pool_alloc(ctx, None, 4096, C.byref(dev)) == N.OK
+    src = np.arange(1024, dtype=np.uint32)
+    C.memmove(host.value, src.ctypes.data, 4096)
+    s, ev = C.c_void_p(), C.c_void_p()
+    assert lib.mi355_stream_create(ctx, C.byref(s)) == N.OK and lib.mi355_event_create(ctx, C.byref(ev)) == N.OK
+    assert lib.mi355_write(ctx, s, dev, host, 4096) == N.OK and lib.mi355_event_record(ctx, ev, s) == N.OK
+    assert lib.mi355_stream_wait_event(ctx, None, ev) == N.OK                      # the compute stream continues behind the upload
+    back = np.zeros(1024, dtype=np.uint32)
+    assert lib.mi355_read_async(ctx, None, back.ctypes.data, dev, 4096) == N.OK and lib.mi355_event_record(ctx, ev, None) == N.OK
+    assert lib.mi355_event_sync(ctx, ev) == N.OK and np.array_equal(back, src)
+    assert lib.mi355_read_async(ctx, None, None, dev, 0) == N.OK and lib.mi355_read_async(ctx, None, None, dev, 4) == N.E_INVALID_ARGUMENT
+    d, c_ = C.c_void_p(), C.c_void_p()
+    assert lib.mi355_default_stream(ctx, C.byref(d)) == N.OK and lib.mi355_comm_stream(ctx, C.byref(c_)) == N.OK and d.value != c_.value
+    free_b, total_b = C.c_uint64(), C.c_uint64()
+    assert lib.mi355_mem_info(ctx, C.byref(free_b), C.byref(total_b)) == N.OK and 0 < free_b.value < total_b.value == 288 << 30
+    u = N.MemoryUsage()
+    assert lib.mi355_pool_usage(ctx, C.byref(u)) == N.OK and (u.number_allocs, u.bytes_in_use) == (1, 4096)
+    assert lib.mi355_pool_free(ctx, s, dev) == N.OK and lib.mi355_pool_cleanup(ctx, 1) == N.OK
+    assert lib.mi355_pool_usage(ctx, C.byref(u)) == N.OK and (u.number_allocs, u.bytes_reserved) == (0, 0)
+    assert lib.mi355_pool_mode(ctx, N.ALLOC_MODE_PERSISTENT) == N.OK and lib.mi355_pool_mode(ctx, N.ALLOC_MODE_AUTO) == N.OK
+    assert lib.mi355_event_destroy(ctx, ev) == N.OK and lib.mi355_stream_destroy(ctx, s) == N.OK and lib.mi355_pinned_free(ctx, host) == N.OK
+    assert lib.mi355_abi_version() == N.ABI_VERSION
