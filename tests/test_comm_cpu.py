@@ -1,0 +1,107 @@
+"""ServerCommunication over the C ABI (cubecl_amd/csrc/comm.cpp) with two ranks, without GPUs: the product sources on the
+fake HIP runtime (tests/fake_hip/) and a single-process stand-in for librccl.so.1 (tests/fake_hip/rccl/) found through
+LD_LIBRARY_PATH by comm.cpp's own dlopen -- so the child process below runs the real loading code, the dtype / op mapping
+(crates/cubecl-cuda/src/compute/communication.rs:27-108), the two event fences and the argument checks.  Ranks are two
+contexts of one process, as in the reference's own test (crates/cubecl-core/src/runtime_tests/all_reduce.rs:5-62).
+The real multi-GPU run is the driver's (bench.py --gpus N); test infrastructure only."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+FAKE = ROOT / "tests" / "fake_hip"
+
+CHILD = r'''
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from cubecl_amd import _native as N
+lib = C.CDLL(sys.argv[2])
+for name, (restype, argtypes) in N.PROTOTYPES.items():
+    if hasattr(lib, name):
+        getattr(lib, name).restype, getattr(lib, name).argtypes = restype, argtypes
+lib.faketest_set_device.argtypes = [C.c_char_p, C.c_int32, C.c_int32]
+lib.faketest_set_device(b"gfx950:sramecc+:xnack-", 64, 2)
+ctxs = []
+for i in range(2):
+    c = C.c_void_p(); assert lib.mi355_ctx_create(i, C.byref(c)) == N.OK; ctxs.append(c)
+p = N.DeviceProps(); assert lib.mi355_device_props(ctxs[0], C.byref(p)) == N.OK and p.server_comm_enabled == 1
+
+def dev(ctx, arr):
+    d = C.c_void_p(); assert lib.mi355_alloc(ctx, max(arr.nbytes, 16), C.byref(d)) == N.OK
+    assert lib.mi355_write(ctx, None, d, arr.ctypes.data, arr.nbytes) == N.OK
+    return d
+def host(ctx, d, like):
+    out = np.zeros_like(like); assert lib.mi355_read(ctx, None, out.ctypes.data, d, out.nbytes) == N.OK
+    return out
+
+uid = (C.c_uint8 * N.UNIQUE_ID_BYTES)()
+assert lib.mi355_comm_unique_id(uid) == N.OK and bytes(uid).startswith(b"fake-rccl-")
+comms = []
+for r in range(2):
+    cm = C.c_void_p(); assert lib.mi355_comm_init(ctxs[r], uid, r, 2, C.byref(cm)) == N.OK; comms.append(cm)
+bad = C.c_void_p()
+assert lib.mi355_comm_init(ctxs[0], uid, 2, 2, C.byref(bad)) == N.E_INVALID_ARGUMENT        # rank outside the world
+
+# all_reduce, sum (runtime_tests/all_reduce.rs: every device contributes, every device ends with the sum), in place
+x = [np.array([1, 2, 3, 4], dtype=np.float32), np.array([10, 20, 30, 40], dtype=np.float32)]
+d = [dev(ctxs[r], x[r]) for r in range(2)]
+for r in range(2):
+    assert lib.mi355_all_reduce(ctxs[r], comms[r], None, d[r], d[r], 4, N.DTYPE_F32, N.REDUCE_SUM) == N.OK
+    assert lib.mi355_sync_collective(ctxs[r], None) == N.OK
+for r in range(2):
+    assert host(ctxs[r], d[r], x[0]).tolist() == [11, 22, 33, 44]
+# mean / max / min, out of place, 64-bit integers
+for op, want in ((N.REDUCE_MEAN, [5.5, 11, 16.5, 22]), (N.REDUCE_MAX, [10, 20, 30, 40]), (N.REDUCE_MIN, [1, 2, 3, 4])):
+    src = [dev(ctxs[r], x[r].astype(np.float64)) for r in range(2)]
+    dst = [dev(ctxs[r], np.zeros(4)) for r in range(2)]
+    for r in range(2):
+        assert lib.mi355_all_reduce(ctxs[r], comms[r], None, src[r], dst[r], 4, N.DTYPE_F64, op) == N.OK
+    assert all(host(ctxs[r], dst[r], np.zeros(4)).tolist() == want for r in range(2))
+# all_gather of the (value, index) records the sharded argmax exchanges: 2 x u64 per rank, rank order
+rec = [np.array([7 + r, 1000 * (r + 1)], dtype=np.uint64) for r in range(2)]
+src = [dev(ctxs[r], rec[r]) for r in range(2)]
+dst = [dev(ctxs[r], np.zeros(4, dtype=np.uint64)) for r in range(2)]
+for r in range(2):
+    assert lib.mi355_all_gather(ctxs[r], comms[r], None, src[r], dst[r], 2, N.DTYPE_U64) == N.OK
+assert all(host(ctxs[r], dst[r], np.zeros(4, dtype=np.uint64)).tolist() == [7, 1000, 8, 2000] for r in range(2))
+# send / recv in either call order (runtime_tests/to_client.rs moves 0..6 as f32)
+payload = np.arange(6, dtype=np.float32)
+s0, r1 = dev(ctxs[0], payload), dev(ctxs[1], np.zeros(6, dtype=np.float32))
+assert lib.mi355_send(ctxs[0], comms[0], None, s0, 6, N.DTYPE_F32, 1) == N.OK
+assert lib.mi355_recv(ctxs[1], comms[1], None, r1, 6, N.DTYPE_F32, 0) == N.OK
+assert host(ctxs[1], r1, payload).tolist() == payload.tolist()
+back = dev(ctxs[0], np.zeros(6, dtype=np.float32))
+assert lib.mi355_recv(ctxs[0], comms[0], None, back, 6, N.DTYPE_F32, 1) == N.OK
+assert lib.mi355_send(ctxs[1], comms[1], None, r1, 6, N.DTYPE_F32, 0) == N.OK
+assert host(ctxs[0], back, payload).tolist() == payload.tolist()
+# argument checks of the wrappers themselves
+assert lib.mi355_all_reduce(ctxs[0], comms[0], None, d[0], d[0], 4, N.DTYPE_F8E4M3, N.REDUCE_SUM) == N.E_UNSUPPORTED
+assert lib.mi355_all_reduce(ctxs[0], comms[0], None, d[0], d[0], 4, N.DTYPE_F32, 77) == N.E_UNSUPPORTED
+assert lib.mi355_all_reduce(ctxs[0], comms[0], None, d[0], d[0], 0, N.DTYPE_F32, N.REDUCE_SUM) == N.OK       # empty: no-op
+assert lib.mi355_all_reduce(ctxs[0], comms[0], None, None, d[0], 4, N.DTYPE_F32, N.REDUCE_SUM) == N.E_INVALID_ARGUMENT
+assert lib.mi355_send(ctxs[0], comms[0], None, s0, 6, N.DTYPE_F32, 0) == N.E_INVALID_ARGUMENT               # to itself
+assert lib.mi355_recv(ctxs[0], comms[0], None, back, 6, N.DTYPE_F32, 5) == N.E_INVALID_ARGUMENT
+# a collective the library refuses comes back as MI355_E_COMM with RCCL's message (same rank twice before its peer)
+assert lib.mi355_all_reduce(ctxs[0], comms[0], None, d[0], d[0], 4, N.DTYPE_F32, N.REDUCE_SUM) == N.OK
+assert lib.mi355_all_reduce(ctxs[0], comms[0], None, d[0], d[0], 4, N.DTYPE_F32, N.REDUCE_SUM) == N.E_COMM
+assert b"invalid usage" in lib.mi355_last_error(ctxs[0])
+for r in range(2):
+    assert lib.mi355_comm_destroy(ctxs[r], comms[r]) == N.OK and lib.mi355_ctx_destroy(ctxs[r]) == N.OK
+print("comm ok")
+'''
+
+
+def test_collectives_between_two_ranks_on_the_fake_device():
+    rccl = FAKE / "rccl" / "librccl.so.1"
+    src = FAKE / "rccl" / "fake_rccl.cpp"
+    if not rccl.exists() or rccl.stat().st_mtime < src.stat().st_mtime:
+        subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-shared", "-fPIC", "-fvisibility=hidden", "-o", str(rccl), str(src)],
+                       check=True)
+    from test_runtime_cpu import build_runtime_lib           # the product sources on the fake HIP runtime
+    runtime = build_runtime_lib()
+    env = dict(os.environ, LD_LIBRARY_PATH=str(FAKE / "rccl") + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([sys.executable, "-c", CHILD, str(ROOT), str(runtime)], env=env, capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode == 0 and "comm ok" in out.stdout, out.stderr[-2000:]

@@ -19,15 +19,19 @@ CSRC = ROOT / "cubecl_amd" / "csrc"
 HIP_ERROR_LAUNCH_FAILURE, HIP_ERROR_INVALID_VALUE = 719, 1
 
 
-@pytest.fixture(scope="module")
-def lib():
+def build_runtime_lib() -> Path:
     so = FAKE / "libruntimetest.so"
     srcs = [CSRC / "runtime.cpp", CSRC / "pool.cpp", CSRC / "comm.cpp", FAKE / "fake_hip.cpp"]
     deps = srcs + [CSRC / "internal.hpp", FAKE / "hip" / "hip_runtime.h", ROOT / "include" / "mi355cube.h", Path(__file__)]
     if not so.exists() or so.stat().st_mtime < max(d.stat().st_mtime for d in deps):
         subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-Wno-format-truncation", "-DFAKE_WITH_RUNTIME", "-shared",
                         "-fPIC", "-Wl,-Bsymbolic", "-I", str(FAKE), "-o", str(so)] + [str(s) for s in srcs] + ["-ldl"], check=True)
-    lib = C.CDLL(str(so))
+    return so
+
+
+@pytest.fixture(scope="module")
+def lib():
+    lib = C.CDLL(str(build_runtime_lib()))
     for name, (restype, argtypes) in N.PROTOTYPES.items():          # the product's own prototype table
         if hasattr(lib, name):
             getattr(lib, name).restype, getattr(lib, name).argtypes = restype, argtypes
