@@ -1,0 +1,157 @@
+"""The host mirror of the reference surface -- `ComputeClient`, `Handle`, pitched tensors, the error model, `profile`,
+graph capture, `to_client`, `KernelArguments` -- driven end to end on the CPU: the same Python classes the GPU tests use,
+over the product's runtime / pool sources compiled against the fake HIP runtime (tests/fake_hip/).  The fake library is
+injected into a `_Server` built by hand here; `Mi355Runtime.client()` itself never looks for anything but the real
+libmi355cube.so (tests/test_abi_cpu.py::test_missing_library_raises).  Counterpart of the reference's client tests on its
+DummyServer (crates/cubecl-runtime/tests/integration_test.rs)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from cubecl_amd import (AddressType, CubeCount, CubeDim, DeviceId, ElemType, InfoBuilder, KernelArguments, ServerError)
+from cubecl_amd import _native as N
+from cubecl_amd.info import buffer_len
+from cubecl_amd.runtime import ComputeClient, _Server
+from test_runtime_cpu import build_runtime_lib
+
+
+@pytest.fixture(scope="module")
+def fake():
+    lib = C.CDLL(str(build_runtime_lib()))
+    for name, (restype, argtypes) in N.PROTOTYPES.items():
+        if hasattr(lib, name):
+            getattr(lib, name).restype, getattr(lib, name).argtypes = restype, argtypes
+    lib.faketest_set_device.argtypes = [C.c_char_p, C.c_int32, C.c_int32]
+    lib.faketest_expect_params.argtypes = [C.c_uint32]
+    lib.faketest_launch_log.argtypes = [C.POINTER(C.c_uint64)]
+    lib.faketest_set_device(b"gfx950:sramecc+:xnack-", 64, 2)
+    return lib
+
+
+def _client(lib, index=0) -> ComputeClient:
+    s = _Server.__new__(_Server)
+    s.lib, s.device, s.comms = lib, DeviceId(0, index), {}
+    ctx = C.c_void_p()
+    assert lib.mi355_ctx_create(index, C.byref(ctx)) == N.OK
+    s.ctx, s.props = ctx, N.DeviceProps()
+    s.check(lib.mi355_device_props(ctx, C.byref(s.props)))
+    return ComputeClient(s)
+
+
+@pytest.fixture()
+def client(fake):
+    c = _client(fake)
+    yield c
+    c._s.close()
+
+
+def _log(lib):
+    out = (C.c_uint64 * 20)()
+    lib.faketest_launch_log(out)
+    return list(out)
+
+
+def test_buffers_handles_and_pitched_tensors_round_trip(client):
+    x = np.arange(64, dtype=np.float32)
+    h = client.create_from_slice(x)
+    assert np.array_equal(client.read_one(h).view(np.float32), x)
+    window = h.offset_start_by(16).offset_end_by(32)                         # bytes [16, 224): elements 4 .. 55
+    assert window.size_in_used() == 208 and np.array_equal(client.read_one(window).view(np.float32), x[4:56])
+    assert buffer_len(window, 4) == 52 and buffer_len(h, 4, vector_size=4) == 16
+    client.write(window, np.full(52, -1.0, dtype=np.float32))
+    back = client.read_one(h).view(np.float32)
+    assert np.array_equal(back[:4], x[:4]) and np.all(back[4:56] == -1.0) and np.array_equal(back[56:], x[56:])
+    assert client.read_one(client.empty(0)).size == 0                        # empty read (crates/cubecl-hip/tests/empty_read.rs)
+    # empty_tensor applies the pitched layout policy: rows of 25 f32 (100 bytes) sit on a 128-byte pitch
+    layout = client.empty_tensor((3, 5, 25), 4)
+    assert layout.strides == (5 * 32, 32, 1) and layout.memory.size_in_used() == 15 * 128
+    data = np.arange(375, dtype=np.float32).reshape(3, 5, 25)
+    desc = layout.memory.copy_descriptor((3, 5, 25), layout.strides, 4)
+    client.write_tensor(desc, data)
+    assert np.array_equal(client.read_tensor(desc).view(np.float32).reshape(3, 5, 25), data)
+    assert client.empty_tensor((4, 64), 4).strides == (64, 1) and client.empty_tensor((7,), 2).strides == (1,)
+    with pytest.raises(ServerError) as e:
+        client.read_tensor(layout.memory.copy_descriptor((3, 5, 25), (1, 3, 15), 4))
+    assert e.value.kind == "UnsupportedStrides"
+    assert client.io_optimized_vector_sizes(2) == [8, 4, 2, 1] and client.io_optimized_vector_sizes(4) == [4, 2, 1]
+    assert client.features()["plane"] == {"Ops", "NonUniformControlFlow"}
+
+
+def test_pool_is_what_client_empty_allocates_from(client):
+    before = client.memory_usage()
+    a = client.empty(1 << 20)
+    ptr = a.device_ptr()
+    u = client.memory_usage()
+    assert u["number_allocs"] == before["number_allocs"] + 1 and u["bytes_in_use"] == before["bytes_in_use"] + (1 << 20)
+    del a                                                                    # last handle gone: back to the pool, not to the driver
+    assert client.memory_usage()["number_allocs"] == before["number_allocs"]
+    assert client.empty(1 << 20).device_ptr() == ptr                         # and reused by the next request of the class
+    client.memory_cleanup()
+    u = client.memory_usage()
+    assert u["bytes_reserved"] == 0 and u["device_bytes_total"] == 288 << 30
+    client.allocation_mode(N.ALLOC_MODE_PERSISTENT)
+    w = client.empty(1000)
+    assert client.memory_usage()["bytes_padding"] == 24                      # exact size in 256-byte granules
+    client.allocation_mode(N.ALLOC_MODE_AUTO)
+    del w
+    with pytest.raises(ServerError) as e:
+        client.empty(100 << 30)
+    assert e.value.kind == "BufferTooBig"
+
+
+def test_launch_errors_surface_as_server_unhealthy_with_the_reference_taxonomy(client, fake):
+    mod = client.load_module(b"FAKEHSACO")
+    fn = client.get_function(mod, "abi_axpb")
+    with pytest.raises(ServerError) as e:
+        client.load_module(b"garbage!!!")
+    assert e.value.kind == "CompilationError"
+    with pytest.raises(ServerError) as e:
+        client.get_function(mod, "missing")
+    assert e.value.kind == "NotFound"
+    src, dst = client.create_from_slice(np.arange(1000, dtype=np.uint32)), client.empty(4000)
+    # the info buffer the reference's launcher would build for (u32 scale, u32 bias, two arrays), last pointer of the launch
+    b = InfoBuilder()
+    b.scalars.push(3, "u32"); b.scalars.push(7, "u32")
+    b.metadata.register_buffer(buffer_len(src, 4), AddressType.U32); b.metadata.register_buffer(buffer_len(dst, 4), AddressType.U32)
+    args = KernelArguments().with_buffers([src, dst]).with_info(b.finish())
+    n0 = _log(fake)[0]
+    fake.faketest_expect_params(3)
+    args.launch(client, fn, CubeCount.new_1d(4), CubeDim.new(client, 1000))
+    log = _log(fake)
+    assert log[0] == n0 + 1 and log[3:9] == [4, 1, 1, 64, 8, 1]              # CubeDim::new: 8 planes of 64
+    assert log[11:13] == [src.device_ptr(), dst.device_ptr()]
+    info_words = (C.c_uint32 * 4).from_address(log[13])                      # "device" memory is host memory here
+    assert list(info_words) == [3, 7, 1000, 1000]
+    client.launch(fn, CubeCount.Static(0, 1, 1), CubeDim.new_1d(64), [src, dst])     # zero cube count: no-op
+    assert _log(fake)[0] == n0 + 1
+    client.flush()
+    client.launch(fn, CubeCount.new_single(), CubeDim.new_1d(64), [src, dst], shared_mem_bytes=(160 << 10) + 8)
+    client.launch(fn, CubeCount.new_single(), CubeDim.new_2d(64, 32), [src, dst])
+    with pytest.raises(ServerError) as e:
+        client.flush()
+    assert e.value.kind == "ServerUnhealthy" and [x.kind for x in e.value.errors] == ["TooManyResources(SharedMemory)", "TooManyResources(Units)"]
+    assert (e.value.errors[0].requested, e.value.errors[0].max) == ((160 << 10) + 8, 160 << 10) and e.value.errors[1].requested == 2048
+    client.flush()                                                           # drained: healthy again
+    client.sync()
+
+
+def test_profile_capture_replay_and_to_client(client, fake):
+    result, nanos = client.profile(lambda: 42, "answer")
+    assert (result, nanos) == (42, 1_500_000)
+    fn = client.get_function(client.load_module(b"FAKEHSACO"), "k")
+    before = _log(fake)[0]
+    graph = client.capture(lambda: [client.launch(fn, CubeCount.new_single(), CubeDim.new_single(), []) for _ in range(4)])
+    assert _log(fake)[0] == before                                           # captured, not executed
+    client.replay(graph); client.replay(graph)
+    assert _log(fake)[0] == before + 8
+    client.graph_destroy(graph)
+    other = _client(fake, 1)
+    try:
+        data = np.array([0.0, 1.0, 2.0, 3.0, 4.0, 5.0], dtype=np.float32)   # runtime_tests/to_client.rs:28-29
+        moved = client.to_client(client.create_from_slice(data), other, ElemType.F32)
+        assert np.array_equal(other.read_one(moved).view(np.float32), data)
+        assert client.device_key() == "mi355_dev0" and other.device_key() == "mi355_dev1"
+    finally:
+        del moved
+        other._s.close()
