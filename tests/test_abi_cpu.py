@@ -130,3 +130,14 @@ def test_rust_ffi_structs_have_the_header_field_order():
     assert len(c_structs) >= 7
     for name, fields in c_structs.items():
         assert rust.get(name) == fields, name
+
+
+def test_product_never_reaches_for_the_fake_runtime():
+    """tests/fake_hip (fake HIP / RCCL for the CPU tests of the host code) is test infrastructure like oracle/: nothing that
+    ships -- the package, its native sources and Makefile, bench.py, the entry points, the examples -- may mention it."""
+    root = Path(__file__).resolve().parents[1]
+    shipped = [root / "bench.py", root / "__graft_entry__.py", *(root / "cubecl_amd").rglob("*.py"), *(root / "examples").rglob("*.py"),
+               *(root / "cubecl_amd" / "csrc").glob("*.cpp"), *(root / "cubecl_amd" / "csrc").glob("*.hip"),
+               *(root / "cubecl_amd" / "csrc").glob("*.hpp"), root / "cubecl_amd" / "csrc" / "Makefile", root / "include" / "mi355cube.h"]
+    offenders = [str(p.relative_to(root)) for p in shipped if "fake_hip" in p.read_text(errors="ignore") or "FAKE_WITH_RUNTIME" in p.read_text(errors="ignore")]
+    assert offenders == []
