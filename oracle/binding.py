@@ -35,6 +35,8 @@ def lib() -> C.CDLL:
     P, u64, i64, i32, f32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_int, C.c_float
     L.oracle_fill_uniform_f32.argtypes = [P, u64, u64, u64, f32, f32]
     L.oracle_fill_uniform_f32.restype = None
+    L.oracle_fill_uniform_f32_at.argtypes = [P, u64, u64, u64, u64, f32, f32]
+    L.oracle_fill_uniform_f32_at.restype = None
     for name in ("oracle_convert_f32_to_bf16", "oracle_convert_f32_to_f16", "oracle_convert_bf16_to_f32",
                  "oracle_convert_f16_to_f32"):
         getattr(L, name).argtypes = [P, P, u64]
@@ -88,6 +90,13 @@ def _p(a: np.ndarray):
 def fill_uniform(n: int, tensor: int, lo: float, hi: float, seed: int = SEED) -> np.ndarray:
     out = np.empty(n, dtype=np.float32)
     lib().oracle_fill_uniform_f32(_p(out), n, seed, tensor, lo, hi)
+    return out
+
+
+def fill_uniform_at(start: int, n: int, tensor: int, lo: float, hi: float, seed: int = SEED) -> np.ndarray:
+    """Elements [start, start + n) of fill_uniform's stream (counter RNG: no need to generate what lies in front)."""
+    out = np.empty(n, dtype=np.float32)
+    lib().oracle_fill_uniform_f32_at(_p(out), start, n, seed, tensor, lo, hi)
     return out
 
 

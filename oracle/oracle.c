@@ -70,6 +70,15 @@ ORACLE_API void oracle_fill_uniform_f32(float *dst, uint64_t n, uint64_t seed, u
     for (uint64_t i = 0; i < n; ++i) dst[i] = fmaf(scale, rng_unit(seed, tensor, i), lo);
 }
 
+/* Elements [start, start + n) of the same stream: the RNG is counter-based (element i of tensor t = counter (t, i)),
+ * so a window of a large device tensor can be regenerated without the elements in front of it. */
+ORACLE_API void oracle_fill_uniform_f32_at(float *dst, uint64_t start, uint64_t n, uint64_t seed, uint64_t tensor,
+                                           float lo, float hi)
+{
+    const float scale = hi - lo;
+    for (uint64_t i = 0; i < n; ++i) dst[i] = fmaf(scale, rng_unit(seed, tensor, start + i), lo);
+}
+
 /* ------------------------------------------------------------------------------------------
  * 16-bit float conversions (no _Float16 / __bf16 in gcc 11 on x86).
  * ------------------------------------------------------------------------------------------ */

@@ -76,6 +76,124 @@ def test_c3_bf16_8192_identity_returns_operand_bits(client, oracle):
     assert np.array_equal(c.to_numpy(client).reshape(S, S), b.to_numpy(client).reshape(S, S).T)
 
 
+def _bench_desc(m, n, k, dtype_ab, dtype_c, batch=1):
+    """The descriptor bench.py builds (bench.py gemm_desc): contiguous operands, B stored [N][K], batch strides set."""
+    return N.GemmDesc(m=m, n=n, k=k, batch=batch, lda=k, ldb=k, ldc=n, stride_a=m * k, stride_b=n * k, stride_c=m * n,
+                      dtype_ab=dtype_ab, dtype_c=dtype_c, trans_a=0, trans_b=1, algo=N.GEMM_ALGO_AUTO)
+
+
+def _bf16_rows_check(oracle, a_bits, b_bits, got_bits, rows, k, n):
+    """bf16 C against the f64 oracle: |got - ref| <= one bf16 ulp of ref + 1e-5 * sum|a||b| (f32 accumulation bound
+    of BASELINE.json + the single rounding of the store; reference loop runtime_tests/cmma.rs:695-722)."""
+    A = oracle.from_bf16(a_bits).reshape(-1, k)[rows].astype(np.float64)
+    Bm = oracle.from_bf16(b_bits).reshape(n, k).astype(np.float64).T
+    ref = A @ Bm
+    bound = np.abs(A) @ np.abs(Bm)
+    got = oracle.from_bf16(got_bits).astype(np.float64)
+    ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(ref), 2.0 ** -126))) - 7)          # bf16: 8 significant bits
+    err = np.abs(got - ref)
+    assert np.all(err <= ulp + REL * bound), float((err / (ulp + REL * bound)).max())
+    # and the rounding is to nearest: at least ~99 % of the outputs are the correctly rounded f64 result
+    exact = oracle.to_bf16(ref.astype(np.float32))
+    assert np.mean(exact == got_bits) > 0.98
+
+
+def test_c3_bf16_8192_bf16_output_as_benched(client, oracle):
+    """Config C3 in the EXACT form bench.py times it (bench.py:228-238): 8192^3 bf16, f32 accumulate, **bf16 C**, the
+    bench's descriptor through mi355_gemm with AUTO selection -- sampled rows against the f64-accumulating oracle."""
+    import ctypes as C
+    S = 8192
+    a = TensorHandle.uniform(client, (S, S), ElemType.BF16, SEED, 100, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (S, S), ElemType.BF16, SEED, 200, -1.0, 1.0)        # stored [N][K]
+    c = TensorHandle.new_contiguous((S, S), client.empty(S * S * 2), ElemType.BF16)
+    d = _bench_desc(S, S, S, N.DTYPE_BF16, N.DTYPE_BF16)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()),
+                                          C.c_void_p(c.device_ptr())))
+    got = c.to_numpy(client).reshape(S, S)
+    rows = np.array([0, 1, 127, 128, 255, 256, 4095, 4096, 8191, 5003, 6144 + 77])      # every wave row-block position
+    a_bits = oracle.to_bf16(oracle.fill_uniform(S * S, 100, -1.0, 1.0))
+    b_bits = oracle.to_bf16(oracle.fill_uniform(S * S, 200, -1.0, 1.0))
+    assert np.array_equal(b.to_numpy(client).reshape(-1)[-(1 << 16):], b_bits[-(1 << 16):])   # device RNG == oracle RNG
+    _bf16_rows_check(oracle, a_bits, b_bits, got[rows], rows, S, S)
+    # the f32-output form of the same launch rounds to the same bf16 values (one rounding, after the f32 accumulation)
+    c32 = TensorHandle.new_contiguous((S, S), client.empty(S * S * 4), ElemType.F32)
+    ops.matmul(client, a, TensorHandle.new(b.handle, (S, S), (1, S), ElemType.BF16), c32)
+    assert np.array_equal(oracle.to_bf16(c32.to_numpy(client).reshape(S, S)[rows]), got[rows])
+
+
+def test_c5_batch64_2048_bf16_as_benched_takes_the_persistent_kernel(client, oracle):
+    """Config C5's per-GPU shard in the EXACT form bench.py times it (bench.py batched_c5): batch 64 of 2048^3 bf16 -> bf16 C.
+    AUTO must take the persistent 256x256 kernel; sampled rows of five matrices (first, last, three inside) against the
+    f64 oracle, operands regenerated window by window from the counter RNG."""
+    import ctypes as C
+    B, M = 64, 2048
+    a = TensorHandle.uniform(client, (B, M, M), ElemType.BF16, SEED, 500, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (B, M, M), ElemType.BF16, SEED, 600, -1.0, 1.0)
+    c = TensorHandle.new_contiguous((B, M, M), client.empty(B * M * M * 2), ElemType.BF16)
+    d = _bench_desc(M, M, M, N.DTYPE_BF16, N.DTYPE_BF16, batch=B)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256P
+    client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()),
+                                          C.c_void_p(c.device_ptr())))
+    rows = np.array([0, 255, 256, 1023, 1024 + 129, 2047])
+    mm = M * M
+    for bi in (0, 1, 31, 40, 63):
+        a_bits = oracle.to_bf16(oracle.fill_uniform_at(bi * mm, mm, 500, -1.0, 1.0))
+        b_bits = oracle.to_bf16(oracle.fill_uniform_at(bi * mm, mm, 600, -1.0, 1.0))
+        got = client.read_one(c.handle.offset_start_by(2 * bi * mm).offset_end_by(2 * (B - 1 - bi) * mm)).view(np.uint16).reshape(M, M)
+        if bi in (0, 63):                                                              # the device operand IS the oracle's
+            dev = client.read_one(a.handle.offset_start_by(2 * bi * mm).offset_end_by(2 * (B - 1 - bi) * mm)).view(np.uint16)
+            assert np.array_equal(dev, a_bits)
+        _bf16_rows_check(oracle, a_bits, b_bits, got[rows], rows, M, M)
+    # the one-tile-per-workgroup kernel computes the same tiles bit for bit (same per-tile summation order)
+    c2 = TensorHandle.new_contiguous((B, M, M), client.empty(B * M * M * 2), ElemType.BF16)
+    d.algo = N.GEMM_ALGO_LP_256W4
+    client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()),
+                                          C.c_void_p(c2.device_ptr())))
+    for bi in (0, 17, 63):
+        w = lambda t: client.read_one(t.handle.offset_start_by(2 * bi * mm).offset_end_by(2 * (B - 1 - bi) * mm))
+        assert np.array_equal(w(c), w(c2))
+
+
+def test_c4_one_gib_fused_sum_argmax_equals_separate_passes_and_oracle(client, oracle):
+    """The fused pass the multi-GPU path launches (mi355_sum_argmax_f32, bench.py reduce_c4 / sharded.py) on the full
+    1 GiB array: bit-identical to the separate sum and argmax kernels, and equal to the CPU oracle."""
+    n = 1 << 28
+    x = TensorHandle.uniform(client, (n,), ElemType.F32, SEED, 300, 0.0, 1.0)
+    s1 = TensorHandle.new_contiguous((1,), client.empty(8), ElemType.F32)
+    s2 = TensorHandle.new_contiguous((1,), client.empty(8), ElemType.F32)
+    i1 = TensorHandle.new_contiguous((1,), client.empty(8), ElemType.U64)
+    i2 = TensorHandle.new_contiguous((1,), client.empty(8), ElemType.U64)
+    v1 = TensorHandle.new_contiguous((1,), client.empty(8), ElemType.F32)
+    v2 = TensorHandle.new_contiguous((1,), client.empty(8), ElemType.F32)
+    ops.reduce_sum(client, x, s1)
+    ops.argmax(client, x, i1, v1)
+    ops.sum_argmax(client, x, s2, i2, v2)
+    assert np.array_equal(s1.to_numpy(client).view(np.uint32), s2.to_numpy(client).view(np.uint32))   # same tree, same bits
+    assert int(i1.to_numpy(client)[0]) == int(i2.to_numpy(client)[0])
+    assert np.array_equal(v1.to_numpy(client).view(np.uint32), v2.to_numpy(client).view(np.uint32))
+    host = oracle.fill_uniform(n, 300, 0.0, 1.0)
+    exact = oracle.sum_f64(host)
+    assert abs(float(s2.to_numpy(client)[0]) - exact) <= REL * exact
+    o_idx, o_val = oracle.argmax(host)
+    assert int(i2.to_numpy(client)[0]) == o_idx and float(v2.to_numpy(client)[0]) == float(o_val)     # bit-exact index
+    # run-to-run determinism of the fused pass
+    ops.sum_argmax(client, x, s1, i1, v1)
+    assert np.array_equal(s1.to_numpy(client).view(np.uint32), s2.to_numpy(client).view(np.uint32))
+    assert int(i1.to_numpy(client)[0]) == int(i2.to_numpy(client)[0])
+    # every 1/8 slice (what each rank of the 8-GPU job reduces) through the fused pass, combined as sharded.py does
+    parts, pairs = [], []
+    for r in range(8):
+        start, count = sharded.shard_aligned_range(n, r, 8, 4)
+        view = TensorHandle.new_contiguous((count,), x.handle.offset_start_by(4 * start).offset_end_by(4 * (n - start - count)),
+                                           ElemType.F32)
+        ops.sum_argmax(client, view, s1, i1, v1)
+        parts.append(float(s1.to_numpy(client)[0]))
+        pairs.append((float(v1.to_numpy(client)[0]), start + int(i1.to_numpy(client)[0])))
+    assert abs(sum(parts) - exact) <= REL * exact
+    assert sharded.combine_argmax(pairs) == (float(o_val), o_idx)
+
+
 def test_c2_f32_4096_sampled_rows_both_layouts(client, oracle):
     M = 4096
     a = TensorHandle.uniform(client, (M, M), ElemType.F32, SEED, 400, -1.0, 1.0)
