@@ -150,27 +150,67 @@ def usable_cores():
     return n
 
 
-def pmc_traffic(size, algo):
-    """HBM bytes per launch of the headline kernel from the committed rocprofv3 PMC passes
-    (profiles/pmc_traffic.json, written by tools/pmc_traffic.sh: separate --pmc passes for FETCH_SIZE
-    and WRITE_SIZE, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when no
-    pass exists for this size / kernel."""
+# Sources a PMC pass is tied to: the committed counters describe ONE binary, so every profiles/pmc_*.json entry carries the
+# sha256 of the kernel's sources at the time of the pass (tools/pmc_all.sh) and bench.py prints the figure only when the
+# sources it is running from still hash to the same value (and the demangled kernel name is the one expected).
+KERNEL_SOURCES = {
+    "gemm": ("cubecl_amd/csrc/gemm_lp256w4.hip", "cubecl_amd/csrc/gemm_common.hpp", "cubecl_amd/csrc/gemm.cpp", "cubecl_amd/csrc/internal.hpp"),
+    "reduce": ("cubecl_amd/csrc/reduce.hip", "cubecl_amd/csrc/internal.hpp"),
+}
+PROFILES_DIR = ROOT / "profiles"
+HEADLINE_KERNEL = "gemm_lp256w4_kernel<1, 1, false, 1, false>"     # bf16 x bf16 -> bf16 C, [N][K] B, unscaled (what rocprofv3 prints)
+REDUCE_SUM_KERNEL = "reduce_kernel<true, false>"
+
+
+def kernel_source_sha(kind):
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES[kind]:
+        h.update(rel.encode() + b"\0" + (ROOT / rel).read_bytes())
+    return h.hexdigest()[:16]
+
+
+def _pmc_entry(file, key, kind, kernel):
+    """-> (entry, None) when profiles/<file> holds a pass for `key` taken on THIS source tree and kernel, else (None, why)."""
     try:
-        table = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
-        ent = table.get(f"gemm_bf16_{size}_algo{algo}")
-        return ent["hbm_bytes_per_launch"] if ent else None
-    except Exception:
-        return None
+        ent = json.loads((PROFILES_DIR / file).read_text()).get(key)
+    except Exception as exc:
+        return None, f"unreadable: {exc}"[:120]
+    if not ent:
+        return None, "no PMC pass for this size / kernel"
+    if kernel not in ent.get("kernel", ""):
+        return None, f"stale: pass taken on kernel '{ent.get('kernel', '?')[:80]}', current kernel is '{kernel}'"
+    if ent.get("source_sha") != kernel_source_sha(kind):
+        return None, f"stale: kernel sources changed since the pass (pass {ent.get('source_sha')}, now {kernel_source_sha(kind)})"
+    return ent, None
+
+
+def _pmc_source(ent):
+    return {k: ent.get(k) for k in ("kernel", "git_sha", "source_sha", "date", "tool") if ent.get(k) is not None}
+
+
+def pmc_traffic(size, algo):
+    """HBM bytes per launch of the headline kernel from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
+    written by tools/pmc_all.sh: separate --pmc passes for FETCH_SIZE and WRITE_SIZE, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  None when no pass exists for this size / kernel or when the pass was
+    taken on other sources (see pmc_traffic_entry for the reason)."""
+    ent, _ = pmc_traffic_entry(size, algo)
+    return ent["hbm_bytes_per_launch"] if ent else None
+
+
+def pmc_traffic_entry(size, algo):
+    return _pmc_entry("pmc_traffic.json", f"gemm_bf16_{size}_algo{algo}", "gemm", HEADLINE_KERNEL)
 
 
 def pmc_mfma_util(size):
-    """Matrix-pipe utilisation of the headline kernel from the committed rocprofv3 PMC pass (profiles/pmc_mfma_util.json,
-    written by tools/pmc_mfma_util.sh: SQ_VALU_MFMA_BUSY_CYCLES per SIMD over GRBM_GUI_ACTIVE per XCD).  None without a pass."""
-    try:
-        ent = json.loads((ROOT / "profiles" / "pmc_mfma_util.json").read_text()).get(f"gemm_bf16_{size}")
-        return ent["mfma_util"] if ent else None
-    except Exception:
-        return None
+    """Matrix-pipe utilisation of the headline kernel from the committed rocprofv3 PMC pass (profiles/pmc_mfma_util.json:
+    SQ_VALU_MFMA_BUSY_CYCLES per SIMD over GRBM_GUI_ACTIVE per XCD).  None without a pass on these sources."""
+    ent, _ = pmc_mfma_util_entry(size)
+    return ent["mfma_util"] if ent else None
+
+
+def pmc_mfma_util_entry(size):
+    return _pmc_entry("pmc_mfma_util.json", f"gemm_bf16_{size}", "gemm", HEADLINE_KERNEL)
 
 
 def gemm_desc(N, m, n, k, dtype_ab, dtype_c, trans_b=1, batch=1, algo=0):
@@ -290,6 +330,8 @@ def main():
     gemm_score = score_resources(kernel_ms / args.steps * 1e-3, [ResourceBound(int(flop), PEAK_BF16_TFLOPS * 1e12)])[0]
     achieved = gemm_score.achieved_per_s / 1e12
 
+    tr_ent, tr_why = pmc_traffic_entry(S, sel.value) if sel.value == 5 else (None, "no PMC pass for this kernel")
+    mu_ent, mu_why = pmc_mfma_util_entry(S) if sel.value == 5 else (None, "no PMC pass for this kernel")
     result = {
         "metric": "GEMM TFLOP/s (8192^3 bf16) + reduce GB/s vs roofline",
         "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -302,9 +344,12 @@ def main():
                    "parallelism": f"batch-sharded x{world}, no data-path collective",
                    "plateau_warmup_steps": plateau_steps},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(gemm_score.fraction_of_peak, 4), "traffic": pmc_traffic(S, sel.value),
+                     "frac": round(gemm_score.fraction_of_peak, 4), "traffic": (tr_ent or {}).get("hbm_bytes_per_launch"),
+                     "traffic_source": _pmc_source(tr_ent) if tr_ent else tr_why,
+                     "algorithmic_bytes_per_launch": 3 * S * S * 2,
                      "kernel_ms": round(kernel_ms / args.steps, 4), "flop_per_launch": flop,
-                     "mfma_util_pmc": pmc_mfma_util(S),
+                     "mfma_util_pmc": (mu_ent or {}).get("mfma_util"),
+                     "mfma_util_source": _pmc_source(mu_ent) if mu_ent else mu_why,
                      # the chip clocks down to its power budget on random operands (MI355X_MICROARCH.md "DVFS
                      # give-back"): the 2.5 PFLOP/s peak assumes 2.4 GHz; these two lines price the kernel
                      # against the matrix-pipe rate at the clock it actually ran at
@@ -421,13 +466,12 @@ def main():
                              "GBs_total": round(gbs * world, 1), "frac_of_8TBs": round(gbs / PEAK_HBM_GBS, 4),
                              "back_to_back_ms": round(b2b, 4), "back_to_back_GBs": round(n_local * 4 / b2b / 1e6, 1)}
             # the second half of the metric ("reduce GB/s vs roofline"): same object shape as the headline roofline
-            try:
-                tr = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text()).get("reduce_1GiB_sum", {}).get("fetch_bytes")
-            except Exception:
-                tr = None
+            rd_ent, rd_why = _pmc_entry("pmc_traffic.json", "reduce_1GiB_sum", "reduce", REDUCE_SUM_KERNEL)
+            tr = rd_ent["fetch_bytes"] if rd_ent else None
             sum_score = score_resources(b2b_ms["sum"] * 1e-3, [ResourceBound(n_local * 4, PEAK_HBM_GBS * 1e9)])[0]
             res["roofline"] = {"bound": "hbm", "achieved": round(sum_score.achieved_per_s / 1e9, 1), "peak": PEAK_HBM_GBS,
                                "unit": "GB/s", "frac": round(sum_score.fraction_of_peak, 4), "traffic": tr if world == 1 else None,
+                               "traffic_source": (_pmc_source(rd_ent) if rd_ent else rd_why) if world == 1 else "pass is for the 1-GPU size",
                                "algorithmic_bytes_per_launch": n_local * 4, "kernel_ms": round(b2b_ms["sum"], 4),
                                "timing": "average of 20 back-to-back launches between one HIP event pair, like the GEMM "
                                          "roofline (the per-sample medians above include one launch gap each)"}

@@ -531,7 +531,7 @@ def test_info_builder_reproduces_the_struct_of_the_external_test_kernels():
 
 
 # ---- bench.py host-side helpers (no device) ----------------------------------------------------------------------------
-def test_bench_helpers_and_contract_defaults(monkeypatch):
+def test_bench_helpers_and_contract_defaults(monkeypatch, tmp_path):
     import json
     import sys
     from pathlib import Path
@@ -545,11 +545,32 @@ def test_bench_helpers_and_contract_defaults(monkeypatch):
     a = bench.parse_args()
     assert (a.gpus, a.steps, a.warmup) == (8, 7, 2)
     assert 1 <= bench.usable_cores() <= (os.cpu_count() or 1)
-    traffic = json.loads((root / "profiles" / "pmc_traffic.json").read_text())["gemm_bf16_8192_algo5"]
-    assert bench.pmc_traffic(8192, 5) == traffic["hbm_bytes_per_launch"] == traffic["fetch_bytes"] + traffic["write_bytes"]
+    # PMC figures are tied to the binary they were taken on: an entry counts only if its kernel name and the sha256 of the
+    # kernel sources match the tree bench.py runs from; anything else is reported as null with the reason.
+    sha = bench.kernel_source_sha("gemm")
+    assert len(sha) == 16 and sha == bench.kernel_source_sha("gemm") and sha != bench.kernel_source_sha("reduce")
+    good = {"kernel": f"void (anonymous namespace)::{bench.HEADLINE_KERNEL}(mi355::gemm_args)", "source_sha": sha, "git_sha": "abc1234",
+            "date": "2026-01-01T00:00Z", "hbm_bytes_per_launch": 1_800_000_000, "fetch_bytes": 1_660_000_000, "write_bytes": 140_000_000}
+    prof = tmp_path
+    monkeypatch.setattr(bench, "PROFILES_DIR", prof)
+    (prof / "pmc_traffic.json").write_text(json.dumps({"gemm_bf16_8192_algo5": good}))
+    (prof / "pmc_mfma_util.json").write_text(json.dumps({"gemm_bf16_8192": dict(good, mfma_util=0.84)}))
+    assert bench.pmc_traffic(8192, 5) == 1_800_000_000 and bench.pmc_mfma_util(8192) == 0.84
+    assert bench._pmc_source(bench.pmc_traffic_entry(8192, 5)[0])["git_sha"] == "abc1234"
     assert bench.pmc_traffic(4096, 5) is None and bench.pmc_traffic(8192, 3) is None   # no PMC pass for these: null, not a guess
-    util = bench.pmc_mfma_util(8192)
-    assert util is not None and 0.5 < util < 1.0 and bench.pmc_mfma_util(1234) is None
+    assert bench.pmc_mfma_util(1234) is None
+    (prof / "pmc_traffic.json").write_text(json.dumps({"gemm_bf16_8192_algo5": dict(good, source_sha="0" * 16)}))
+    ent, why = bench.pmc_traffic_entry(8192, 5)
+    assert ent is None and "sources changed" in why and bench.pmc_traffic(8192, 5) is None
+    (prof / "pmc_traffic.json").write_text(json.dumps({"gemm_bf16_8192_algo5": dict(good, kernel="gemm_lp256w4_kernel<1, 1, false>")}))
+    ent, why = bench.pmc_traffic_entry(8192, 5)
+    assert ent is None and "stale" in why                                               # round 1's three-argument instantiation
+    # whatever is committed under profiles/ either matches the tree or is refused -- never printed on trust
+    monkeypatch.setattr(bench, "PROFILES_DIR", root / "profiles")
+    ent, why = bench.pmc_traffic_entry(8192, 5)
+    assert (ent is None) != (why is None)
+    if ent is not None:
+        assert ent["hbm_bytes_per_launch"] == ent["fetch_bytes"] + ent["write_bytes"] and ent["source_sha"] == sha
     assert bench.PEAK_BF16_TFLOPS == 2500.0 and bench.PEAK_HBM_GBS == 8000.0 and bench.PEAK_F32_TFLOPS == 157.3
 
 

@@ -18,5 +18,7 @@ export TMPDIR=/tmp
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/${TAG}_prof" -o bench -- python "$OLDPWD/bench.py" --no-extras --no-cpu-baseline > "$OLDPWD/$OUT/${TAG}_prof.log" 2>&1 ); echo "rocprof exit $?"
 # everything (extras included), fewer steps: per-kernel time of the other configs (SKIP_ALL=1 leaves this pass out)
 [ "${SKIP_ALL:-0}" = 1 ] || ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/${TAG}_prof_all" -o bench -- python "$OLDPWD/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OLDPWD/$OUT/${TAG}_prof_all.log" 2>&1 ); echo "rocprof(all) exit $?"
+# the 1 GiB reductions on the same binary (the reduce half of the metric): 20 launches of each kernel
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/${TAG}_prof_reduce" -o reduce -- python "$OLDPWD/tools/reduce_probe.py" > "$OLDPWD/$OUT/${TAG}_prof_reduce.log" 2>&1 ); echo "rocprof(reduce) exit $?"
 find $OUT/${TAG}_prof -name "*kernel_stats*" | head -3
 f=$(find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -n 25 "$f"

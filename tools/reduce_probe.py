@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Dev: time the 1 GiB array-wide reductions (15 samples each, median/min)."""
+"""Times the 1 GiB array-wide reductions (15 samples each, median / min); the command the reduce rocprof / PMC passes
+of tools/gpu_check.sh and tools/pmc_all.sh profile."""
 import ctypes as C, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cubecl_amd import Mi355Runtime, TensorHandle, ElemType
 cl = Mi355Runtime.client(); lib, ctx = cl.lib, cl.ctx
 n = 1 << 28
