@@ -97,31 +97,6 @@ pad_copy_kernel(const T *__restrict__ src, T *__restrict__ dst, int64_t rows, in
 
 namespace mi355 {
 
-// Library-owned device scratch, one buffer per (stream, kind): calls on one stream are stream-ordered, so a
-// buffer is never shared by two operations in flight.  Grows on demand (a synchronising hipMalloc, rare).
-int32_t scratch_get(mi355_ctx *ctx, hipStream_t s, int kind, size_t bytes, void **out)
-{
-    auto &slot = ctx->scratch[{s, kind}];
-    if (slot.second < bytes) {
-        // growing means hipMalloc (+ a stream sync and hipFree): none of that is legal inside a capture window; the caller
-        // falls back to a path without scratch, or the launch fails -- warm the sequence up once before capturing
-        if (ctx->capturing) return MI355_E_UNSUPPORTED;
-        if (slot.first) {
-            if (hipStreamSynchronize(s) != hipSuccess) return MI355_E_EXECUTION;
-            hipFree(slot.first);
-            slot = {nullptr, 0};
-        }
-        void *p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            return MI355_E_OUT_OF_MEMORY;
-        }
-        slot = {p, bytes};
-    }
-    *out = slot.first;
-    return MI355_OK;
-}
-
 void launch_pad_copy(hipStream_t s, const void *src, void *dst, int64_t rows, int64_t cols, int64_t cols_pad, int64_t ld_src,
                      int64_t ld_dst, int64_t batch, int64_t stride_src, int64_t stride_dst, int esz)
 {

@@ -10,6 +10,7 @@
 #include <deque>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -52,10 +53,28 @@ struct mi355_ctx {
     std::unordered_map<hipStream_t, uint32_t> ticket_slots;
     bool tickets_dirty = false;
     bool capturing = false;                // a hipStream capture window is open (graph API)
+    // Memory a graph replays against must outlive the graph (the reference routes the allocations of a capture window into
+    // a persistent pool and pins them for the graph's lifetime: crates/cubecl-hip/src/compute/server.rs:288-521):
+    //   capture_id      id of the open window / of the graph it becomes (0: none)
+    //   live_graphs     ids of graphs not yet destroyed
+    //                   (pool.cpp keeps the blocks freed while pinned -- allocated or freed inside a window -- out of
+    //                   its free lists under that id until mi355_graph_destroy)
+    //   capture_scratch library scratch buffers handed out inside the open window
+    //   scratch_refs    scratch buffer -> number of live graphs whose nodes carry its address; a pinned buffer is never
+    //                   freed or regrown in place (scratch_get retires it and the last graph releases it)
+    uint64_t capture_id = 0, next_capture_id = 1;
+    std::set<uint64_t> live_graphs;
+    std::set<void *> capture_scratch;
+    std::map<void *, int> scratch_refs;
+    std::set<void *> scratch_retired;      // pinned scratch that scratch_get has replaced by a bigger buffer
     // library-owned device scratch per (stream, kind): split-K slabs, re-laid-out GEMM operands
     std::map<std::pair<hipStream_t, int>, std::pair<void *, size_t>> scratch;
     mi355::memory_pool *pool = nullptr;    // caching allocator behind mi355_pool_* (pool.cpp)
     uint64_t func_attr_mask = 0;  // kernels whose dynamic-LDS attribute is already raised on this device
+    // One context = one server: the reference funnels every call through one runner thread per device
+    // (crates/cubecl-common/src/device/handle/channel.rs:75-110).  Bindings without that discipline (Python: a Handle
+    // dropped by the garbage collector on another thread while ctypes has released the GIL) are serialised here.
+    std::recursive_mutex mu;
 };
 
 namespace mi355 {
@@ -71,6 +90,10 @@ bool rccl_available();  // comm.cpp
 // pool.cpp
 int32_t pool_alloc(mi355_ctx *ctx, hipStream_t stream, uint64_t bytes, void **out);
 int32_t pool_free(mi355_ctx *ctx, hipStream_t stream, void *ptr);
+void pool_release_graph(mi355_ctx *ctx, uint64_t graph_id);   // a graph died: its pinned blocks go back to the free lists
+void scratch_release(mi355_ctx *ctx, void *ptr);               // a graph died: drop one pin of a library scratch buffer
+// library-owned per-(stream, kind) device scratch (runtime.cpp): split-K slabs, re-laid-out GEMM operands, MX scales
+int32_t scratch_get(mi355_ctx *ctx, hipStream_t s, int kind, size_t bytes, void **out);
 int32_t pool_cleanup(mi355_ctx *ctx, int32_t explicit_);
 void pool_destroy(mi355_ctx *ctx);
 inline hipStream_t stream_of(mi355_ctx *ctx, mi355_stream s)
@@ -92,14 +115,18 @@ inline size_t dtype_size(int32_t dtype)
 
 }  // namespace mi355
 
+// Entry of every call that touches a context: argument check, the context's lock (held to the end of the calling
+// function; recursive, entry points call each other), and the device selection the reference does once per runner thread.
 #define MI355_REQUIRE_CTX(ctx)                                          \
-    do {                                                                \
-        if (!(ctx)) return MI355_E_INVALID_ARGUMENT;                    \
+    if (!(ctx)) return MI355_E_INVALID_ARGUMENT;                        \
+    std::lock_guard<std::recursive_mutex> _mi355_ctx_guard((ctx)->mu);  \
+    {                                                                   \
         hipError_t _e = hipSetDevice((ctx)->device);                    \
         if (_e != hipSuccess)                                           \
             return mi355::fail((ctx), MI355_E_NO_DEVICE, "hipSetDevice(%d): %s", (ctx)->device, \
                                hipGetErrorString(_e));                  \
-    } while (0)
+    }
+#define MI355_LOCK_CTX(ctx) std::lock_guard<std::recursive_mutex> _mi355_ctx_guard((ctx)->mu)
 
 #define MI355_HIP(ctx, expr)                                                               \
     do {                                                                                   \

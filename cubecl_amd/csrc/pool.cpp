@@ -56,6 +56,8 @@ struct pool_block {
     hipEvent_t event = nullptr;                   // recorded at free time
     uint64_t freed_tick = 0;
     bool persistent = false;
+    uint64_t graph_id = 0;                        // allocated or freed inside this capture window: pinned while that graph lives
+    bool idle = false;                            // released by a destroyed graph (its replays were waited for): any stream may take it
 };
 
 size_t bin_size(int b)
@@ -83,6 +85,7 @@ struct memory_pool {
     int mode = MI355_ALLOC_MODE_AUTO;
     uint64_t n_allocs = 0, bytes_in_use = 0, bytes_padding = 0, bytes_reserved = 0;
     uint64_t driver_allocs = 0, driver_frees = 0, cache_hits = 0;
+    std::map<uint64_t, std::vector<pool_block>> held;   // graph id -> blocks freed while pinned (out of the free lists)
 };
 
 namespace {
@@ -114,7 +117,7 @@ hipEvent_t take_event(memory_pool *p)
 // May `stream` start using a block that was freed on `b.stream`?
 bool reusable(const mi355_ctx *ctx, const pool_block &b, hipStream_t stream)
 {
-    if (b.stream == stream) return true;
+    if (b.idle || b.stream == stream) return true;
     if (!b.event || ctx->capturing) return false;  // (no event queries inside a capture window)
     const hipError_t e = hipEventQuery(b.event);
     if (e == hipSuccess) return true;
@@ -234,6 +237,10 @@ int32_t pool_alloc(mi355_ctx *ctx, hipStream_t stream, uint64_t bytes, void **ou
         }
         blk.requested = bytes;
     }
+    blk.idle = false;
+    // An allocation made inside a capture window is baked into the graph's nodes: it stays pinned (never handed to anyone
+    // else) for as long as that graph lives, whenever its owner drops it.
+    blk.graph_id = ctx->capturing ? ctx->capture_id : 0;
     account_alloc(p, blk);
     p->live[blk.ptr] = blk;
     *out = blk.ptr;
@@ -252,6 +259,13 @@ int32_t pool_free(mi355_ctx *ctx, hipStream_t stream, void *ptr)
     --p->n_allocs;
     p->bytes_in_use -= blk.requested;
     p->bytes_padding -= blk.size - blk.requested;
+    // A collective still in flight on the communication stream may read or write this block (a temporary handed to
+    // all_reduce / send and dropped before sync_collective): order the freeing stream behind the communication stream
+    // first, so that same-stream reuse and the event recorded below both cover it.
+    if (ctx->comm_dirty && !ctx->capturing && ctx->fence_b && ctx->comm_stream) {
+        if (hipEventRecord(ctx->fence_b, ctx->comm_stream) != hipSuccess || hipStreamWaitEvent(stream, ctx->fence_b, 0) != hipSuccess)
+            (void)hipGetLastError();
+    }
     blk.stream = stream;
     blk.freed_tick = p->tick;
     blk.event = nullptr;
@@ -263,6 +277,15 @@ int32_t pool_free(mi355_ctx *ctx, hipStream_t stream, void *ptr)
             blk.event = nullptr;
         }
     }
+    // Freed inside a capture window (the captured kernels before this point use it), or allocated inside the window of a
+    // graph that is still alive: the address is part of a replayable graph, so the block stays out of the free lists
+    // until mi355_graph_destroy.  (A slab slice keeps its page's live count: the page must not be released either.)
+    if (ctx->capturing) blk.graph_id = ctx->capture_id;
+    if (blk.graph_id && (blk.graph_id == ctx->capture_id || ctx->live_graphs.count(blk.graph_id))) {
+        p->held[blk.graph_id].push_back(blk);
+        return MI355_OK;
+    }
+    blk.graph_id = 0;
     if (blk.bin >= 0) {
         --blk.page->live;
         p->bins[blk.bin].push_back(blk);
@@ -270,6 +293,28 @@ int32_t pool_free(mi355_ctx *ctx, hipStream_t stream, void *ptr)
         p->big_free.emplace(blk.size, blk);
     }
     return MI355_OK;
+}
+
+// The graph with this id is gone (destroyed after its replays were waited for, or its capture failed): what it pinned
+// is ordinary free memory again.  Blocks freed at capture time carry no event -- nothing but the graph ever used them
+// after that point -- so they are marked idle.
+void pool_release_graph(mi355_ctx *ctx, uint64_t graph_id)
+{
+    memory_pool *p = ctx->pool;
+    if (!p) return;
+    auto it = p->held.find(graph_id);
+    if (it == p->held.end()) return;
+    for (pool_block &blk : it->second) {
+        blk.graph_id = 0;
+        if (!blk.event) blk.idle = true;
+        if (blk.bin >= 0) {
+            --blk.page->live;
+            p->bins[blk.bin].push_back(blk);
+        } else {
+            p->big_free.emplace(blk.size, blk);
+        }
+    }
+    p->held.erase(it);
 }
 
 // explicit == 0: release exclusive pages that sat unused for their dealloc period; explicit != 0: release everything
@@ -334,6 +379,11 @@ void pool_destroy(mi355_ctx *ctx)
         (void)hipFree(kv.second.ptr);
         if (kv.second.event) (void)hipEventDestroy(kv.second.event);
     }
+    for (auto &kv : p->held)
+        for (auto &b : kv.second) {
+            if (b.bin < 0) (void)hipFree(b.ptr);
+            if (b.event) (void)hipEventDestroy(b.event);
+        }
     for (auto &fl : p->bins)
         for (auto &b : fl)
             if (b.event) (void)hipEventDestroy(b.event);

@@ -234,6 +234,7 @@ MI355_API int32_t mi355_ctx_create(int32_t device_index, mi355_ctx **out_ctx)
 MI355_API int32_t mi355_ctx_destroy(mi355_ctx *ctx)
 {
     if (!ctx) return MI355_OK;
+    { MI355_LOCK_CTX(ctx); }               // let a call still running on another thread finish
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
     for (void *p : ctx->pending_free) hipFree(p);
@@ -244,6 +245,7 @@ MI355_API int32_t mi355_ctx_destroy(mi355_ctx *ctx)
     if (ctx->fence_b) hipEventDestroy(ctx->fence_b);
     if (ctx->ticket_buf) hipFree(ctx->ticket_buf);
     for (auto &kv : ctx->scratch) hipFree(kv.second.first);
+    for (void *p : ctx->scratch_retired) hipFree(p);
     if (ctx->compute_stream) hipStreamDestroy(ctx->compute_stream);
     if (ctx->comm_stream) hipStreamDestroy(ctx->comm_stream);
     delete ctx;
@@ -260,6 +262,7 @@ MI355_API int32_t mi355_device_props(mi355_ctx *ctx, mi355_device_props_t *out_p
 MI355_API int32_t mi355_error_count(mi355_ctx *ctx, int32_t *out_count)
 {
     if (!ctx || !out_count) return MI355_E_INVALID_ARGUMENT;
+    MI355_LOCK_CTX(ctx);
     *out_count = (int32_t)ctx->errors.size();
     return MI355_OK;
 }
@@ -268,6 +271,7 @@ MI355_API int32_t mi355_error_pop(mi355_ctx *ctx, int32_t *out_code, uint64_t *o
                                   uint64_t *out_max, char *msg, size_t msg_capacity)
 {
     if (!ctx) return MI355_E_INVALID_ARGUMENT;
+    MI355_LOCK_CTX(ctx);
     if (ctx->errors.empty()) return MI355_E_NOT_FOUND;
     const mi355_queued_error &err = ctx->errors.front();
     if (out_code) *out_code = err.code;
@@ -310,6 +314,7 @@ MI355_API int32_t mi355_alloc(mi355_ctx *ctx, uint64_t bytes, void **out_dptr)
 MI355_API int32_t mi355_free(mi355_ctx *ctx, void *dptr)
 {
     if (!ctx) return MI355_E_INVALID_ARGUMENT;
+    MI355_LOCK_CTX(ctx);
     if (dptr) ctx->pending_free.push_back(dptr);
     return MI355_OK;
 }
@@ -421,6 +426,7 @@ MI355_API int32_t mi355_event_sync(mi355_ctx *ctx, mi355_event event)
 {
     MI355_REQUIRE_CTX(ctx);
     if (!event) return fail(ctx, MI355_E_INVALID_ARGUMENT, "event is NULL");
+    if (ctx->capturing) return fail(ctx, MI355_E_UNSUPPORTED, "mi355_event_sync: not inside a graph capture window");
     MI355_HIP(ctx, hipEventSynchronize(reinterpret_cast<hipEvent_t>(event)));
     return MI355_OK;
 }
@@ -451,6 +457,7 @@ MI355_API int32_t mi355_read_async(mi355_ctx *ctx, mi355_stream stream, void *ds
     MI355_REQUIRE_CTX(ctx);
     if (bytes == 0) return MI355_OK;
     if (!dst_host || !src_dptr) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_read: NULL pointer");
+    if (ctx->capturing) return fail(ctx, MI355_E_UNSUPPORTED, "mi355_read: a read-back inside a graph capture window would end the capture");
     MI355_HIP(ctx, hipMemcpyAsync(dst_host, src_dptr, bytes, hipMemcpyDeviceToHost, stream_of(ctx, stream)));
     return MI355_OK;
 }
@@ -484,6 +491,7 @@ MI355_API int32_t mi355_read_2d(mi355_ctx *ctx, mi355_stream stream, void *dst_h
     if (!dst_host || !src_dptr) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_read_2d: NULL pointer");
     if (dst_pitch < width_bytes || src_pitch < width_bytes)
         return fail(ctx, MI355_E_UNSUPPORTED_STRIDES, "pitch smaller than row width");
+    if (ctx->capturing) return fail(ctx, MI355_E_UNSUPPORTED, "mi355_read_2d: a read-back inside a graph capture window would end the capture");
     MI355_HIP(ctx, hipMemcpy2DAsync(dst_host, dst_pitch, src_dptr, src_pitch, width_bytes, rows,
                                     hipMemcpyDeviceToHost, stream_of(ctx, stream)));
     return mi355_sync(ctx, stream);
@@ -510,6 +518,9 @@ MI355_API int32_t mi355_copy_to_ctx(mi355_ctx *src_ctx, mi355_stream src_stream,
 {
     if (!src_ctx || !dst_ctx) return MI355_E_INVALID_ARGUMENT;
     if (bytes == 0) return MI355_OK;
+    // both servers take part: lock them in address order (two threads copying in opposite directions must not deadlock)
+    mi355_ctx *lo = src_ctx < dst_ctx ? src_ctx : dst_ctx, *hi = src_ctx < dst_ctx ? dst_ctx : src_ctx;
+    std::lock_guard<std::recursive_mutex> g_lo(lo->mu), g_hi(hi->mu);
     if (!src_dptr || !dst_dptr) return fail(dst_ctx, MI355_E_INVALID_ARGUMENT, "mi355_copy_to_ctx: NULL pointer");
     hipStream_t ss = stream_of(src_ctx, src_stream), ds = stream_of(dst_ctx, dst_stream);
     if (src_ctx->device != dst_ctx->device) {
@@ -542,6 +553,9 @@ MI355_API int32_t mi355_memset(mi355_ctx *ctx, mi355_stream stream, void *dptr, 
 MI355_API int32_t mi355_sync(mi355_ctx *ctx, mi355_stream stream)
 {
     MI355_REQUIRE_CTX(ctx);
+    // a host synchronisation aborts an open capture (the reference defers or refuses them: crates/cubecl-hip/src/compute/
+    // command.rs:404, :508): refuse it and keep the window alive
+    if (ctx->capturing) return fail(ctx, MI355_E_UNSUPPORTED, "mi355_sync: not inside a graph capture window");
     hipError_t e = hipStreamSynchronize(stream_of(ctx, stream));
     if (e != hipSuccess) {
         hipGetLastError();
@@ -553,6 +567,7 @@ MI355_API int32_t mi355_sync(mi355_ctx *ctx, mi355_stream stream)
 MI355_API int32_t mi355_flush(mi355_ctx *ctx)
 {
     MI355_REQUIRE_CTX(ctx);
+    if (ctx->capturing) return MI355_OK;          // fenced frees are deferred to the first flush after the window (command.rs:404)
     if (!ctx->pending_free.empty()) {
         // frees wait behind every in-flight use (fence in the reference; here a device sync)
         hipError_t e = hipDeviceSynchronize();
@@ -662,7 +677,14 @@ MI355_API int32_t mi355_launch(mi355_ctx *ctx, mi355_stream stream, mi355_functi
                                          num_ptrs ? params.data() : nullptr, nullptr);
     if (e != hipSuccess) {
         hipGetLastError();
-        queue_error(ctx, MI355_E_LAUNCH, 0, 0, "hipModuleLaunchKernel: %s", hipGetErrorString(e));
+        if (shared_mem_bytes > 64 * 1024)
+            // HIP has no driver-side attribute call for a hipFunction_t (hipFuncSetAttribute resolves host stubs only): when
+            // the driver refuses the opt-in for a module kernel, the limit that really applies to it is the default one
+            queue_error(ctx, MI355_E_SHARED_MEMORY, shared_mem_bytes, 64 * 1024,
+                        "Too much shared memory requested. Requested %u bytes, maximum %u bytes available to a module kernel "
+                        "(hipModuleLaunchKernel: %s).", shared_mem_bytes, 64 * 1024, hipGetErrorString(e));
+        else
+            queue_error(ctx, MI355_E_LAUNCH, 0, 0, "hipModuleLaunchKernel: %s", hipGetErrorString(e));
     }
     return MI355_OK;
 }
@@ -709,6 +731,53 @@ MI355_API int32_t mi355_profile_stop(mi355_ctx *ctx, mi355_stream stream, uint64
     return report_queue(ctx);
 }
 
+/* =================================== Library scratch ===================================== */
+namespace mi355 {
+
+// Library-owned device scratch, one buffer per (stream, kind): calls on one stream are stream-ordered, so a
+// buffer is never shared by two operations in flight.  Grows on demand (a synchronising hipMalloc, rare).
+int32_t scratch_get(mi355_ctx *ctx, hipStream_t s, int kind, size_t bytes, void **out)
+{
+    auto &slot = ctx->scratch[{s, kind}];
+    if (slot.second < bytes) {
+        // growing means hipMalloc (+ a stream sync and hipFree): none of that is legal inside a capture window; the caller
+        // falls back to a path without scratch, or the launch fails -- warm the sequence up once before capturing
+        if (ctx->capturing) return MI355_E_UNSUPPORTED;
+        if (slot.first) {
+            auto pin = ctx->scratch_refs.find(slot.first);
+            if (pin != ctx->scratch_refs.end() && pin->second > 0) {
+                // a live graph replays kernels that carry this address: the buffer is retired, not freed -- the last
+                // graph that pins it releases it (scratch_release)
+                ctx->scratch_retired.insert(slot.first);
+            } else {
+                if (hipStreamSynchronize(s) != hipSuccess) return MI355_E_EXECUTION;
+                hipFree(slot.first);
+            }
+            slot = {nullptr, 0};
+        }
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return MI355_E_OUT_OF_MEMORY;
+        }
+        slot = {p, bytes};
+    }
+    if (ctx->capturing) ctx->capture_scratch.insert(slot.first);   // becomes a pin when the capture ends
+    *out = slot.first;
+    return MI355_OK;
+}
+
+void scratch_release(mi355_ctx *ctx, void *ptr)
+{
+    auto pin = ctx->scratch_refs.find(ptr);
+    if (pin == ctx->scratch_refs.end()) return;
+    if (--pin->second > 0) return;
+    ctx->scratch_refs.erase(pin);
+    if (ctx->scratch_retired.erase(ptr)) hipFree(ptr);             // nobody replays against it any more
+}
+
+}  // namespace mi355
+
 // =================================== Graph capture ==========================================
 // ComputeServer::{begin_capture, end_capture, replay, graph_destroy}
 // (crates/cubecl-runtime/src/server/base.rs:472-532; the HIP backend's implementation over
@@ -720,6 +789,9 @@ MI355_API int32_t mi355_profile_stop(mi355_ctx *ctx, mi355_stream stream, uint64
 struct mi355_graph {
     hipGraph_t graph;
     hipGraphExec_t exec;
+    uint64_t id;                          // the capture window it came from: pins pool blocks under this id
+    std::set<void *> scratch;             // library scratch its nodes carry
+    std::set<hipStream_t> streams;        // streams it was replayed on (waited for before the executable dies)
 };
 
 MI355_API int32_t mi355_graph_begin_capture(mi355_ctx *ctx, mi355_stream stream)
@@ -728,6 +800,8 @@ MI355_API int32_t mi355_graph_begin_capture(mi355_ctx *ctx, mi355_stream stream)
     if (ctx->capturing) return fail(ctx, MI355_E_INVALID_ARGUMENT, "begin_capture: a capture is already open on this context");
     MI355_HIP(ctx, hipStreamBeginCapture(stream_of(ctx, stream), hipStreamCaptureModeThreadLocal));
     ctx->capturing = true;
+    ctx->capture_id = ctx->next_capture_id++;
+    ctx->capture_scratch.clear();
     return MI355_OK;
 }
 
@@ -738,20 +812,32 @@ MI355_API int32_t mi355_graph_end_capture(mi355_ctx *ctx, mi355_stream stream, m
     *out_graph = nullptr;
     if (!ctx->capturing) return fail(ctx, MI355_E_INVALID_ARGUMENT, "end_capture without begin_capture");
     ctx->capturing = false;
+    const uint64_t id = ctx->capture_id;
+    ctx->capture_id = 0;
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(stream_of(ctx, stream), &g);
+    hipGraphExec_t x = nullptr;
     if (e != hipSuccess || !g) {
         (void)hipGetLastError();
+        pool_release_graph(ctx, id);          // nothing will ever replay: what the window pinned is free memory again
+        ctx->capture_scratch.clear();
         return fail(ctx, MI355_E_EXECUTION, "hipStreamEndCapture: %s (an operation in the window was not capturable: "
                     "run the sequence once before capturing so that library scratch exists)", hipGetErrorString(e));
     }
-    hipGraphExec_t x = nullptr;
     e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
     if (e != hipSuccess) {
         hipGraphDestroy(g);
+        pool_release_graph(ctx, id);
+        ctx->capture_scratch.clear();
         return fail(ctx, MI355_E_EXECUTION, "hipGraphInstantiate: %s", hipGetErrorString(e));
     }
-    *out_graph = new mi355_graph{g, x};
+    // From here on the graph owns a pin on every pool block allocated or freed in its window (pool.cpp keeps them out of
+    // the free lists under `id`) and on the library scratch its kernels were captured with.
+    mi355_graph *out = new mi355_graph{g, x, id, {}, {}};
+    out->scratch.swap(ctx->capture_scratch);
+    for (void *p : out->scratch) ++ctx->scratch_refs[p];
+    ctx->live_graphs.insert(id);
+    *out_graph = out;
     return MI355_OK;
 }
 
@@ -759,6 +845,7 @@ MI355_API int32_t mi355_graph_replay(mi355_ctx *ctx, mi355_stream stream, mi355_
 {
     MI355_REQUIRE_CTX(ctx);
     if (!graph) return fail(ctx, MI355_E_NOT_FOUND, "replay: unknown graph");
+    graph->streams.insert(stream_of(ctx, stream));
     hipError_t e = hipGraphLaunch(graph->exec, stream_of(ctx, stream));
     if (e != hipSuccess) {                       // fire-and-forget like launch: queued, reported by flush / sync
         (void)hipGetLastError();
@@ -771,8 +858,21 @@ MI355_API int32_t mi355_graph_destroy(mi355_ctx *ctx, mi355_graph *graph)
 {
     MI355_REQUIRE_CTX(ctx);
     if (!graph) return MI355_OK;
+    // replay returns at enqueue time: wait for the replays still running against this executable before it goes
+    // (crates/cubecl-hip/src/compute/server.rs:497-521); a failed wait means the stream has faulted -- nothing runs any
+    // more, destroying is safe -- and is surfaced through the error queue
+    for (hipStream_t s : graph->streams) {
+        const hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            queue_error(ctx, MI355_E_EXECUTION, 0, 0, "graph_destroy: hipStreamSynchronize: %s", hipGetErrorString(e));
+        }
+    }
     hipGraphExecDestroy(graph->exec);
     hipGraphDestroy(graph->graph);
+    ctx->live_graphs.erase(graph->id);
+    pool_release_graph(ctx, graph->id);          // its pinned blocks are ordinary free memory again
+    for (void *p : graph->scratch) scratch_release(ctx, p);
     delete graph;
     return MI355_OK;
 }

@@ -189,6 +189,9 @@ struct runtime_state {
     uintptr_t last_params[8] = {0};
     bool capturing = false;
     int max_dynamic_lds = 0;
+    hipError_t fail_next_end_capture = hipSuccess;
+    uint64_t stream_syncs = 0, stream_waits = 0;
+    hipStream_t last_wait_stream = nullptr, last_sync_stream = nullptr;
 } r;
 void work(hipStream_t s) { if (s) { ++s->submitted; s->completed = s->submitted; } }
 }  // namespace
@@ -213,12 +216,14 @@ hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = new fake_hi
 hipError_t hipStreamDestroy(hipStream_t s) { g.streams.erase(s); delete s; return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t s)
 {
+    ++r.stream_syncs;
+    r.last_sync_stream = s;
     if (s) s->completed = s->submitted;
     const hipError_t e = r.fail_next_sync;
     r.fail_next_sync = hipSuccess;
     return e;
 }
-hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t, unsigned) { ++r.stream_waits; r.last_wait_stream = s; return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t *e) { return hipEventCreateWithFlags(e, 0); }
 hipError_t hipEventSynchronize(hipEvent_t e) { if (e && e->stream) e->stream->completed = e->stream->submitted; return hipSuccess; }
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 1.5f; return hipSuccess; }
@@ -264,6 +269,7 @@ hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { r.capturin
 hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *graph)
 {
     r.capturing = false;
+    if (r.fail_next_end_capture != hipSuccess) { const hipError_t e = r.fail_next_end_capture; r.fail_next_end_capture = hipSuccess; *graph = nullptr; return e; }
     *graph = new fake_hip_graph{(int)r.captured};
     return hipSuccess;
 }
@@ -284,3 +290,19 @@ TEST_API void faketest_launch_log(uint64_t out[20])
     out[10] = (uint64_t)r.max_dynamic_lds;
     for (int i = 0; i < 8; ++i) out[11 + i] = r.last_params[i];
 }
+
+// {hipStreamSynchronize calls, hipStreamWaitEvent calls, stream of the last wait, stream of the last synchronize}
+TEST_API void faketest_stream_log(uint64_t out[4])
+{
+    out[0] = r.stream_syncs; out[1] = r.stream_waits;
+    out[2] = reinterpret_cast<uintptr_t>(r.last_wait_stream); out[3] = reinterpret_cast<uintptr_t>(r.last_sync_stream);
+}
+TEST_API void faketest_fail_end_capture(int32_t error) { r.fail_next_end_capture = (hipError_t)error; }
+#ifdef FAKE_WITH_RUNTIME
+// library scratch has no entry point of its own (the GEMM launchers call it): reach it directly
+TEST_API int32_t faketest_scratch_get(mi355_ctx *ctx, void *stream, int32_t kind, uint64_t bytes, void **out)
+{
+    return mi355::scratch_get(ctx, stream ? static_cast<hipStream_t>(stream) : ctx->compute_stream, kind, bytes, out);
+}
+TEST_API void faketest_set_comm_dirty(mi355_ctx *ctx, int32_t on) { ctx->comm_dirty = on != 0; }
+#endif

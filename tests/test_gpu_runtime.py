@@ -150,6 +150,28 @@ def test_large_lds_kernel_runs(client):
     assert got == (words * (words - 1) // 2) % (1 << 32)
 
 
+def test_max_lds_kernel_runs_or_reports_the_limit_that_applies(client):
+    """runtime_tests/launch.rs:202-224 at full size: a module kernel launched with exactly `max_shared_memory_size` bytes of
+    dynamic LDS (160 KiB on gfx950).  HIP offers no attribute call for a hipFunction_t, so either the driver admits the launch
+    (then the answer must be right) or the launch is refused and the queued error is SharedMemory{requested, max = 64 KiB},
+    never a generic launch failure."""
+    mod = client.load_module(HSACO.read_bytes())
+    fn = client.get_function(mod, "abi_lds_fill")
+    out = client.create_from_slice(np.zeros(1, dtype=np.uint32))
+    p = client.properties()
+    for nbytes in (96 * 1024, int(p.max_shared_memory_size)):
+        words = nbytes // 4
+        client.launch(fn, CubeCount.Static(1), CubeDim.new_1d(256), [out], _info(client, (words, 0), (1, 1)), shared_mem_bytes=nbytes)
+        try:
+            got = int(client.read_one(out).view(np.uint32)[0])
+        except ServerError as e:
+            first = e.errors[0]
+            assert first.code == N.E_SHARED_MEMORY and first.requested == nbytes and first.max == 64 * 1024
+            client.flush()
+        else:
+            assert got == (words * (words - 1) // 2) % (1 << 32)
+
+
 def test_profile_reports_device_time(client):
     t = TensorHandle.uniform(client, (1 << 24,), ElemType.F32, 1, 1, 0.0, 1.0)
     out = client.empty(4)
@@ -528,12 +550,24 @@ def test_pool_inside_a_capture_window_serves_from_the_cache_only(client):
     finally:
         g = C.c_void_p()
         client._s.check(lib.mi355_graph_end_capture(ctx, None, C.byref(g)))
+    # the block the graph writes to was freed inside the window: it stays pinned while the graph lives, so nobody else gets it
+    r = _palloc(client, n)
+    assert r != p
+    client._s.check(lib.mi355_memset(ctx, None, C.c_void_p(r), 0x11, n))
     client._s.check(lib.mi355_graph_replay(ctx, None, g))
     client.sync()
     host = np.empty(4096, dtype=np.uint8)
     client._s.check(lib.mi355_read(ctx, None, host.ctypes.data_as(C.c_void_p), C.c_void_p(p), host.size))
     assert np.all(host == 0x5A)
+    client._s.check(lib.mi355_read(ctx, None, host.ctypes.data_as(C.c_void_p), C.c_void_p(r), host.size))
+    assert np.all(host == 0x11)                                   # the live tensor was not overwritten by the replay
+    client._s.check(lib.mi355_graph_replay(ctx, None, g))         # destroy waits for this replay
     client._s.check(lib.mi355_graph_destroy(ctx, g))
+    _pfree(client, r)
+    t = _palloc(client, n)
+    assert t in (p, r)                                            # the pin is gone: both pages are cache again
+    _pfree(client, t)
+    client.memory_cleanup()
 
 
 # ---- measured ceilings (examples/throughput; cubecl-std throughput/base.rs) -------------------------------------------

@@ -41,6 +41,13 @@ def lib():
     lib.faketest_launch_log.argtypes = [C.POINTER(C.c_uint64)]
     lib.pooltest_set_capacity.argtypes = [C.c_uint64]
     lib.pooltest_counters.argtypes = [C.POINTER(C.c_uint64)]
+    lib.faketest_stream_log.argtypes = [C.POINTER(C.c_uint64)]
+    lib.faketest_fail_end_capture.argtypes = [C.c_int32]
+    lib.faketest_scratch_get.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.POINTER(C.c_void_p)]
+    lib.faketest_scratch_get.restype = C.c_int32
+    lib.faketest_set_comm_dirty.argtypes = [C.c_void_p, C.c_int32]
+    lib.pooltest_inside_allocation.argtypes = [C.c_void_p, C.c_uint64]
+    lib.pooltest_inside_allocation.restype = C.c_int32
     return lib
 
 
@@ -64,6 +71,12 @@ def _launches(lib):
     out = (C.c_uint64 * 20)()
     lib.faketest_launch_log(out)
     return list(out)
+
+
+def _streams(lib):
+    out = (C.c_uint64 * 4)()
+    lib.faketest_stream_log(out)
+    return dict(zip(("syncs", "waits", "last_wait_stream", "last_sync_stream"), out))
 
 
 def _pop(lib, ctx):
@@ -248,3 +261,153 @@ def test_remaining_runtime_entry_points(lib, ctx):
     assert lib.mi355_pool_mode(ctx, N.ALLOC_MODE_PERSISTENT) == N.OK and lib.mi355_pool_mode(ctx, N.ALLOC_MODE_AUTO) == N.OK
     assert lib.mi355_event_destroy(ctx, ev) == N.OK and lib.mi355_stream_destroy(ctx, s) == N.OK and lib.mi355_pinned_free(ctx, host) == N.OK
     assert lib.mi355_abi_version() == N.ABI_VERSION
+
+
+# ---- memory a graph replays against stays pinned; destroying a graph waits for its replays ----------------------------------
+def _alloc(lib, ctx, nbytes, stream=None):
+    p = C.c_void_p()
+    assert lib.mi355_pool_alloc(ctx, stream, nbytes, C.byref(p)) == N.OK and p.value
+    return p.value
+
+
+def test_graph_pins_the_memory_it_replays_against(lib, ctx):
+    """The reference pins what a capture window allocates for the graph's lifetime (crates/cubecl-hip/src/compute/server.rs:
+    288-521).  Here: a block allocated or freed inside the window never reaches the free lists while the graph lives, so no
+    later client.empty() can receive an address the next replay writes to; mi355_graph_destroy hands everything back."""
+    size = 1 << 20
+    warm = [_alloc(lib, ctx, size) for _ in range(4)]               # warm-up run: the slices exist before the window opens
+    pre = _alloc(lib, ctx, size)                                     # alive before the window, dropped inside it
+    for w in warm:
+        assert lib.mi355_pool_free(ctx, None, w) == N.OK
+    graph = C.c_void_p()
+    assert lib.mi355_graph_begin_capture(ctx, None) == N.OK
+    tmp = _alloc(lib, ctx, size)                                     # a temporary of the captured sequence (cache hit: no hipMalloc)
+    keep = _alloc(lib, ctx, size)                                    # an output the caller keeps beyond the window
+    assert tmp in warm and keep in warm
+    assert lib.mi355_pool_free(ctx, None, tmp) == N.OK and lib.mi355_pool_free(ctx, None, pre) == N.OK
+    again = _alloc(lib, ctx, size)                                   # inside the window too: the freed temporary is NOT handed out twice
+    assert again not in (tmp, pre)
+    # host synchronisation would abort the capture: refused, the window stays open
+    host = (C.c_uint8 * 16)()
+    assert lib.mi355_sync(ctx, None) == N.E_UNSUPPORTED and lib.mi355_read(ctx, None, host, C.c_void_p(keep), 16) == N.E_UNSUPPORTED
+    assert lib.mi355_flush(ctx) == N.OK
+    assert lib.mi355_graph_end_capture(ctx, None, C.byref(graph)) == N.OK and graph.value
+    assert lib.mi355_pool_free(ctx, None, again) == N.OK
+    taken = [_alloc(lib, ctx, size) for _ in range(8)]               # drain every cached slice of the class and then some
+    assert tmp not in taken and pre not in taken and again not in taken and keep not in taken
+    assert lib.mi355_pool_free(ctx, None, keep) == N.OK              # the caller drops the output while the graph is alive
+    assert _alloc(lib, ctx, size) != keep                            # ... still pinned: a replay would overwrite whoever got it
+    assert lib.mi355_graph_replay(ctx, None, graph) == N.OK
+    assert lib.mi355_graph_destroy(ctx, graph) == N.OK
+    back = {_alloc(lib, ctx, size) for _ in range(4)}                # no driver call needed: the four pinned blocks are free memory again
+    assert back == {tmp, pre, again, keep}
+
+
+def test_failed_capture_releases_what_the_window_pinned(lib, ctx):
+    size = 1 << 20
+    a = _alloc(lib, ctx, size)
+    graph = C.c_void_p()
+    assert lib.mi355_graph_begin_capture(ctx, None) == N.OK
+    assert lib.mi355_pool_free(ctx, None, a) == N.OK
+    lib.faketest_fail_end_capture(HIP_ERROR_INVALID_VALUE)
+    assert lib.mi355_graph_end_capture(ctx, None, C.byref(graph)) == N.E_EXECUTION and not graph.value
+    assert _alloc(lib, ctx, size) == a                               # nothing will ever replay: reusable at once
+
+
+def test_library_scratch_baked_into_a_graph_is_never_freed_or_regrown_under_it(lib, ctx):
+    """Split-K slabs / re-laid-out operands live in library scratch whose address is a kernel argument of the captured
+    launches: a later, larger eager call must not hipFree that buffer while the graph can still be replayed."""
+    p1, p2, p3, graph = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert lib.faketest_scratch_get(ctx, None, 0, 1 << 20, C.byref(p1)) == N.OK                # warm-up
+    assert lib.mi355_graph_begin_capture(ctx, None) == N.OK
+    assert lib.faketest_scratch_get(ctx, None, 0, 1 << 19, C.byref(p2)) == N.OK and p2.value == p1.value
+    assert lib.faketest_scratch_get(ctx, None, 0, 1 << 22, C.byref(p3)) == N.E_UNSUPPORTED     # growing inside the window: refused
+    assert lib.mi355_graph_end_capture(ctx, None, C.byref(graph)) == N.OK
+    frees = _device(lib)["frees"]
+    assert lib.faketest_scratch_get(ctx, None, 0, 1 << 22, C.byref(p3)) == N.OK and p3.value != p1.value
+    assert _device(lib)["frees"] == frees and lib.pooltest_inside_allocation(p1, 1 << 20) == 1  # retired, still mapped
+    assert lib.mi355_graph_replay(ctx, None, graph) == N.OK
+    assert lib.mi355_graph_destroy(ctx, graph) == N.OK
+    assert _device(lib)["frees"] == frees + 1 and lib.pooltest_inside_allocation(p1, 1 << 20) == 0
+    assert lib.pooltest_inside_allocation(p3, 1 << 22) == 1                                      # the current buffer is untouched
+
+
+def test_graph_destroy_waits_for_replays_and_reports_a_failed_wait(lib, ctx):
+    mod, fn, graph, s2 = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert lib.mi355_module_load(ctx, b"FAKEHSACO", 9, C.byref(mod)) == N.OK
+    assert lib.mi355_module_get_function(ctx, mod, b"k", C.byref(fn)) == N.OK
+    assert lib.mi355_stream_create(ctx, C.byref(s2)) == N.OK
+    one = (C.c_uint32 * 3)(1, 1, 1)
+    assert lib.mi355_graph_begin_capture(ctx, None) == N.OK
+    assert lib.mi355_launch(ctx, None, fn, one, one, 0, None, 0) == N.OK
+    assert lib.mi355_graph_end_capture(ctx, None, C.byref(graph)) == N.OK
+    assert lib.mi355_graph_replay(ctx, None, graph) == N.OK and lib.mi355_graph_replay(ctx, s2, graph) == N.OK
+    before = _streams(lib)["syncs"]
+    lib.faketest_fail_next(HIP_ERROR_LAUNCH_FAILURE, 0)              # the first wait finds a faulted stream
+    assert lib.mi355_graph_destroy(ctx, graph) == N.OK
+    assert _streams(lib)["syncs"] == before + 2                      # both streams it was replayed on were waited for
+    assert lib.mi355_flush(ctx) == N.E_SERVER_UNHEALTHY
+    rc, code, _, _, msg = _pop(lib, ctx)
+    assert rc == N.OK and code == N.E_EXECUTION and "graph_destroy" in msg
+    assert lib.mi355_stream_destroy(ctx, s2) == N.OK
+
+
+def test_block_dropped_while_a_collective_is_in_flight_is_ordered_behind_the_comm_stream(lib, ctx):
+    """A temporary handed to all_reduce / send and dropped before sync_collective: the pool orders the freeing stream behind the
+    communication stream before the block can be reused (same stream: at once; other streams: through the block's event)."""
+    comm = C.c_void_p()
+    assert lib.mi355_comm_stream(ctx, C.byref(comm)) == N.OK
+    a = _alloc(lib, ctx, 4096)
+    w0 = _streams(lib)["waits"]
+    assert lib.mi355_pool_free(ctx, None, a) == N.OK and _streams(lib)["waits"] == w0          # nothing in flight: no extra work
+    b = _alloc(lib, ctx, 4096)
+    lib.faketest_set_comm_dirty(ctx, 1)                              # a collective was issued and sync_collective has not run
+    assert lib.mi355_pool_free(ctx, None, b) == N.OK
+    log = _streams(lib)
+    default = C.c_void_p()
+    assert lib.mi355_default_stream(ctx, C.byref(default)) == N.OK
+    assert log["waits"] == w0 + 1 and log["last_wait_stream"] == default.value               # the freeing stream waits on the comm fence
+    lib.faketest_set_comm_dirty(ctx, 0)
+
+
+def test_module_kernel_above_64_kib_of_lds_reports_the_limit_that_applies(lib, ctx):
+    mod, fn = C.c_void_p(), C.c_void_p()
+    assert lib.mi355_module_load(ctx, b"FAKEHSACO", 9, C.byref(mod)) == N.OK
+    assert lib.mi355_module_get_function(ctx, mod, b"k", C.byref(fn)) == N.OK
+    one = (C.c_uint32 * 3)(1, 1, 1)
+    assert lib.mi355_launch(ctx, None, fn, one, one, 96 << 10, None, 0) == N.OK and lib.mi355_flush(ctx) == N.OK   # accepted by the driver
+    lib.faketest_fail_next(0, HIP_ERROR_INVALID_VALUE)               # a driver that refuses the opt-in
+    assert lib.mi355_launch(ctx, None, fn, one, one, 96 << 10, None, 0) == N.OK
+    assert lib.mi355_flush(ctx) == N.E_SERVER_UNHEALTHY
+    rc, code, req, mx, _ = _pop(lib, ctx)
+    assert (rc, code, req, mx) == (N.OK, N.E_SHARED_MEMORY, 96 << 10, 64 << 10)
+
+
+def test_context_calls_from_several_threads_are_serialised(lib, ctx):
+    """Handles dropped by the garbage collector on another thread race client.empty() on the main one (ctypes releases the GIL
+    inside foreign calls): the context's lock makes that safe.  4 threads x 2000 alloc / free pairs, then the books balance."""
+    import threading
+    errors = []
+
+    def worker(seed):
+        rng = np.random.default_rng(seed)
+        mine = []
+        for _ in range(2000):
+            if mine and rng.random() < 0.5:
+                if lib.mi355_pool_free(ctx, None, C.c_void_p(mine.pop(int(rng.integers(len(mine)))))) != N.OK:
+                    errors.append("free")
+            else:
+                p = C.c_void_p()
+                if lib.mi355_pool_alloc(ctx, None, int(rng.integers(1, 1 << 16)), C.byref(p)) != N.OK or not p.value:
+                    errors.append("alloc")
+                mine.append(p.value)
+        for q in mine:
+            lib.mi355_pool_free(ctx, None, C.c_void_p(q))
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    usage = N.MemoryUsage()
+    assert not errors and lib.mi355_pool_usage(ctx, C.byref(usage)) == N.OK
+    assert usage.number_allocs == 0 and usage.bytes_in_use == 0 and _device(lib)["bad_frees"] == 0
