@@ -198,6 +198,7 @@ PROTOTYPES = {
     "mi355_reduce_sum_f32": (C.c_int32, [_P, _P, _P, C.c_uint64, _P, _P, C.c_uint64]),
     "mi355_argmax_f32": (C.c_int32, [_P, _P, _P, C.c_uint64, _P, _P, _P, C.c_uint64]),
     "mi355_sum_argmax_f32": (C.c_int32, [_P, _P, _P, C.c_uint64, _P, _P, _P, _P, C.c_uint64]),
+    "mi355_argmax_combine_f32": (C.c_int32, [_P, _P, _P, C.c_uint32, C.POINTER(C.c_uint64), _P, _P]),
     "mi355_reduce_axis_sum": (C.c_int32, [_P, _P, _P, C.c_int32, _P, C.c_uint64, C.c_uint64, C.c_uint64]),
     "mi355_reduce_axis_argmax": (C.c_int32, [_P, _P, _P, C.c_int32, _P, C.c_uint64, C.c_uint64, C.c_uint64]),
     "mi355_reduce_last_axis_sum": (C.c_int32, [_P, _P, _P, C.c_int32, _P, C.c_uint64, C.c_uint64, C.c_uint64]),

@@ -592,6 +592,40 @@ plane_reduce_kernel(const float *__restrict__ in, float *__restrict__ out, uint6
     if (i < n) out[i] = v;
 }
 
+// ---- multi-GPU argmax: the combine step -------------------------------------------------------------
+// After the all-gather every rank holds one record {f32 value, u32 pad, u64 LOCAL index} per shard (the bytes
+// mi355_sum_argmax_f32 wrote at out_val / out_idx, 16 bytes apart).  One wave folds them with the rule the
+// single-GPU kernel uses inside a device (arg_combine over argmax_key: larger value wins, NaN above everything,
+// -0 == +0, ties keep the LOWEST global index), so the winner lands in device memory on every rank, stream-ordered
+// behind the collective -- no host round trip inside the exchange.  An empty shard passes index 2^64-1 and is skipped.
+struct combine_bases { uint64_t base[64]; };
+
+__global__ void __launch_bounds__(64)
+argmax_combine_kernel(const uint32_t *__restrict__ records, uint32_t count, combine_bases bases, float *__restrict__ out_val,
+                      uint64_t *__restrict__ out_idx)
+{
+    const uint32_t lane = threadIdx.x;
+    uint32_t key = 0, bits = 0xFF800000u;                   // -inf: what mi355_argmax_f32 reports for an empty array
+    uint64_t idx = ~0ull;
+    if (lane < count) {
+        const uint32_t vb = records[lane * 4];
+        const uint64_t li = ((uint64_t)records[lane * 4 + 3] << 32) | records[lane * 4 + 2];
+        if (li != ~0ull) { key = argmax_key(__uint_as_float(vb)); idx = bases.base[lane] + li; bits = vb; }
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t okey = __shfl_xor(key, off, 64), obits = __shfl_xor(bits, off, 64);
+        const uint32_t olo = __shfl_xor((uint32_t)idx, off, 64), ohi = __shfl_xor((uint32_t)(idx >> 32), off, 64);
+        const uint64_t oidx = ((uint64_t)ohi << 32) | olo;
+        const bool take = (okey > key) || (okey == key && oidx < idx);
+        key = take ? okey : key; idx = take ? oidx : idx; bits = take ? obits : bits;
+    }
+    if (lane == 0) {
+        if (out_val) *out_val = __uint_as_float(bits);
+        if (out_idx) *out_idx = (idx == ~0ull) ? 0ull : idx;
+    }
+}
+
 }  // namespace
 
 MI355_API int32_t mi355_reduce_workspace_bytes(mi355_ctx *ctx, uint64_t n, uint64_t *out_bytes)
@@ -648,6 +682,22 @@ MI355_API int32_t mi355_sum_argmax_f32(mi355_ctx *ctx, mi355_stream stream, cons
         return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_sum_argmax_f32: no output");
     return run_reduce<true, true>(ctx, stream, in, MI355_DTYPE_F32, n, out_sum, out_val, out_idx, workspace, workspace_bytes,
                                   "mi355_sum_argmax_f32");
+}
+
+MI355_API int32_t mi355_argmax_combine_f32(mi355_ctx *ctx, mi355_stream stream, const void *records, uint32_t count,
+                                           const uint64_t *index_base, float *out_val, uint64_t *out_idx)
+{
+    MI355_REQUIRE_CTX(ctx);
+    if (!out_val && !out_idx) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_argmax_combine_f32: no output");
+    if (count > 64) return fail(ctx, MI355_E_UNSUPPORTED, "mi355_argmax_combine_f32: %u records (at most 64 shards)", count);
+    if (count && (!records || (reinterpret_cast<uintptr_t>(records) & 7u)))
+        return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_argmax_combine_f32: records must be an 8-byte aligned device pointer");
+    combine_bases b{};
+    for (uint32_t r = 0; r < count; ++r) b.base[r] = index_base ? index_base[r] : 0;
+    hipLaunchKernelGGL(argmax_combine_kernel, dim3(1), dim3(64), 0, stream_of(ctx, stream), static_cast<const uint32_t *>(records), count,
+                       b, out_val, out_idx);
+    check_launch(ctx, "mi355_argmax_combine_f32");
+    return MI355_OK;
 }
 
 MI355_API int32_t mi355_reduce_last_axis_sum_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, float *out,

@@ -237,6 +237,18 @@ def sum_argmax(client: ComputeClient, input: TensorHandle, out_sum: TensorHandle
         C.c_void_p(out_index.device_ptr()), C.c_void_p(ws.device_ptr()), ws.size))
 
 
+def argmax_combine(client: ComputeClient, records: Handle, count: int, index_base, out_value: Optional[Handle],
+                   out_index: Optional[Handle]) -> None:
+    """The combine step of the multi-GPU argmax on the device (mi355_argmax_combine_f32): folds `count` gathered records
+    {f32 value, u32 unused, u64 local index} -- rank order, as all_gather delivers them -- into (value, GLOBAL index) with
+    the single-GPU rule; `index_base[r]` is the first element of shard r.  Queued on the client's stream."""
+    base = (C.c_uint64 * max(count, 1))(*[int(b) for b in (index_base or [0] * count)])
+    client._s.check(client.lib.mi355_argmax_combine_f32(
+        client.ctx, client.stream, C.c_void_p(records.device_ptr()), count, base,
+        C.c_void_p(out_value.device_ptr()) if out_value is not None else None,
+        C.c_void_p(out_index.device_ptr()) if out_index is not None else None))
+
+
 def _rows_view(t: TensorHandle, what: str):
     if t.dtype not in (ElemType.F32, ElemType.BF16, ElemType.F16):
         raise ServerError(N.E_UNSUPPORTED, f"{what}: input must be f32, bf16 or f16")

@@ -185,6 +185,19 @@ class RcclExchange(Exchange):
     def barrier(self) -> None:
         self._c.sync()
 
+    def exchange_on_device(self, part, rec, index_base, out_value, out_index) -> None:
+        """The whole exchange step without a host round trip (what the timed multi-GPU job runs): `part` (one f32 on the
+        device) is all-reduced in place, `rec` (16 bytes: {f32 max, u32 unused, u64 local index}, where the fused local
+        pass wrote them) is all-gathered, and after the comm -> compute fence a 64-lane kernel folds the records with the
+        single-GPU argmax rule.  Afterwards the global sum, maximum and its global index are in device memory on EVERY
+        rank, ordered on the compute stream like any other kernel output."""
+        from . import ops
+        gathered = self._buf.offset_start_by(64)
+        self._c.all_reduce(part, part, self._ElemType.F32, self._ids, self._Sum)
+        self._c.all_gather(rec, gathered, self._ElemType.U64, self._ids)
+        self._c.sync_collective()
+        ops.argmax_combine(self._c, gathered, self.world, index_base, out_value, out_index)
+
 
 # ---------------------------------------------------------------------------- sharded ops -----
 

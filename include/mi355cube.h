@@ -403,6 +403,16 @@ int32_t mi355_argmax_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, u
 int32_t mi355_sum_argmax_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, uint64_t n,
                              float *out_sum, float *out_val, uint64_t *out_idx, void *workspace,
                              uint64_t workspace_bytes);
+/* The combine step of the multi-GPU argmax (the reference's ReduceOperation has only Sum / Mean,
+ * crates/cubecl-runtime/src/server/base.rs:623-628 -- an API delta like MI355_REDUCE_MAX / MIN).  `records` (device) holds
+ * `count` <= 64 records of 16 bytes, one per shard in rank order, as mi355_all_gather delivers them: {f32 value, u32
+ * unused, u64 LOCAL index} = the bytes mi355_sum_argmax_f32 writes at out_val / out_idx when those are 8 bytes apart.
+ * index_base (HOST array of `count` u64, NULL = zeros) is the first element of each shard; a record whose index is
+ * 2^64-1 is an empty shard and is ignored.  Same rule as inside one device: larger value wins, NaN above every number,
+ * -0.0 == +0.0, equal values keep the LOWEST global index; no record at all gives -inf / 0.  One 64-lane launch on
+ * `stream`: queue it after mi355_sync_collective and the result is in device memory on every rank, stream-ordered. */
+int32_t mi355_argmax_combine_f32(mi355_ctx *ctx, mi355_stream stream, const void *records, uint32_t count,
+                                 const uint64_t *index_base, float *out_val, uint64_t *out_idx);
 /* The same three reductions for f32, bf16 or f16 inputs (`dtype`): elements are widened to f32 on load (exact), sums and
  * comparisons run in f32, the outputs stay {f32 sum, f32 value of the winning element, u64 index}.  Same rules (lowest
  * index wins ties, NaN ranks highest, -0 == +0), same single-launch deterministic tree; 16-bit inputs move half the

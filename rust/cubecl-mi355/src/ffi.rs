@@ -205,6 +205,8 @@ extern "C" {
                             out_idx: *mut u64, workspace: *mut c_void, workspace_bytes: u64) -> i32;
     pub fn mi355_sum_argmax_f32(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const f32, n: u64, out_sum: *mut f32,
                                 out_val: *mut f32, out_idx: *mut u64, workspace: *mut c_void, workspace_bytes: u64) -> i32;
+    pub fn mi355_argmax_combine_f32(ctx: *mut mi355_ctx, stream: mi355_stream, records: *const c_void, count: u32,
+                                    index_base: *const u64, out_val: *mut f32, out_idx: *mut u64) -> i32;
     pub fn mi355_reduce_last_axis_sum_f32(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const f32, out: *mut f32,
                                           rows: u64, cols: u64, row_stride: u64) -> i32;
     // Collectives (RCCL over xGMI)

@@ -2,10 +2,17 @@
 // LD_LIBRARY_PATH of a child process so that comm.cpp's dlopen("librccl.so.1") finds it).  Ranks are contexts of one
 // process, the reference's own model (crates/cubecl-core/src/runtime_tests/all_reduce.rs: one client per device, one
 // thread); a collective executes when its last rank has called, on the host memory the fake HIP runtime hands out.
+// Every entry point takes one lock, so ranks may also be driven from one thread each (the model comm_init assumes:
+// crates/cubecl-cuda/src/compute/server.rs:669-703 runs on each device's own runner thread).  With FAKE_RCCL_BLOCKING_INIT=1
+// ncclCommInitRank behaves like the real one: it returns only when every rank of the communicator has called it.
+#include <chrono>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -18,12 +25,15 @@ namespace {
 struct call { const void *send = nullptr; void *recv = nullptr; size_t count = 0; int dtype = 0, op = 0; bool set = false; };
 struct p2p { const void *send = nullptr; void *recv = nullptr; size_t count = 0; int dtype = 0; };
 struct group {
-    int nranks = 0;
+    int nranks = 0, joined = 0;
     std::vector<call> reduce, gather;
     std::map<std::pair<int, int>, p2p> wires;   // (from, to)
 };
 std::map<std::string, group> groups;
 int next_id = 1;
+std::mutex mu;
+std::condition_variable cv;
+#define LOCKED std::unique_lock<std::mutex> lock(mu)
 size_t size_of(int dt) { const size_t s[] = {1, 1, 4, 4, 8, 8, 2, 4, 8, 2}; return dt >= 0 && dt < 10 ? s[dt] : 0; }
 
 template <typename T> void reduce_typed(group &g, size_t n, int op)
@@ -47,16 +57,24 @@ typedef ncclComm *ncclComm_t;
 extern "C" {
 __attribute__((visibility("default"))) ncclResult_t ncclGetUniqueId(ncclUniqueId *id)
 {
+    LOCKED;
     memset(id, 0, sizeof *id);
     snprintf(id->internal, sizeof id->internal, "fake-rccl-%d", next_id++);
     return 0;
 }
 __attribute__((visibility("default"))) ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int rank)
 {
+    LOCKED;
     group &g = groups[std::string(id.internal, sizeof id.internal)];
     if (g.nranks == 0) { g.nranks = nranks; g.reduce.resize(nranks); g.gather.resize(nranks); }
     if (g.nranks != nranks || rank < 0 || rank >= nranks) return 4;
     *comm = new ncclComm{&g, rank};
+    ++g.joined;
+    cv.notify_all();
+    const char *blocking = getenv("FAKE_RCCL_BLOCKING_INIT");
+    if (blocking && blocking[0] == '1' &&
+        !cv.wait_for(lock, std::chrono::seconds(30), [&g] { return g.joined >= g.nranks; }))
+        return 5;                                                // a rank never showed up
     return 0;
 }
 __attribute__((visibility("default"))) ncclResult_t ncclCommDestroy(ncclComm_t comm) { delete comm; return 0; }
@@ -64,6 +82,7 @@ __attribute__((visibility("default"))) const char *ncclGetErrorString(ncclResult
 
 __attribute__((visibility("default"))) ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, int dtype, int op, ncclComm_t comm, hipStream_t)
 {
+    LOCKED;
     group &g = *comm->g;
     if (g.reduce[comm->rank].set) return 5;                      // the same rank twice before the others arrived
     g.reduce[comm->rank] = {send, recv, count, dtype, op, true};
@@ -83,6 +102,7 @@ __attribute__((visibility("default"))) ncclResult_t ncclAllReduce(const void *se
 }
 __attribute__((visibility("default"))) ncclResult_t ncclAllGather(const void *send, void *recv, size_t count, int dtype, ncclComm_t comm, hipStream_t)
 {
+    LOCKED;
     group &g = *comm->g;
     if (g.gather[comm->rank].set) return 5;
     g.gather[comm->rank] = {send, recv, count, dtype, 0, true};
@@ -107,6 +127,7 @@ static ncclResult_t wire(group &g, int from, int to)
 }
 __attribute__((visibility("default"))) ncclResult_t ncclSend(const void *send, size_t count, int dtype, int peer, ncclComm_t comm, hipStream_t)
 {
+    LOCKED;
     p2p &w = comm->g->wires[{comm->rank, peer}];
     if (w.recv && (w.count != count || w.dtype != dtype)) return 4;
     w.send = send; w.count = count; w.dtype = dtype;
@@ -114,6 +135,7 @@ __attribute__((visibility("default"))) ncclResult_t ncclSend(const void *send, s
 }
 __attribute__((visibility("default"))) ncclResult_t ncclRecv(void *recv, size_t count, int dtype, int peer, ncclComm_t comm, hipStream_t)
 {
+    LOCKED;
     p2p &w = comm->g->wires[{peer, comm->rank}];
     if (w.send && (w.count != count || w.dtype != dtype)) return 4;
     w.recv = recv; w.count = count; w.dtype = dtype;

@@ -93,15 +93,99 @@ print("comm ok")
 '''
 
 
-def test_collectives_between_two_ranks_on_the_fake_device():
+def _run_child(code, extra_env=None):
     rccl = FAKE / "rccl" / "librccl.so.1"
     src = FAKE / "rccl" / "fake_rccl.cpp"
     if not rccl.exists() or rccl.stat().st_mtime < src.stat().st_mtime:
-        subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-shared", "-fPIC", "-fvisibility=hidden", "-o", str(rccl), str(src)],
-                       check=True)
+        subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-shared", "-fPIC", "-fvisibility=hidden", "-pthread", "-o", str(rccl),
+                        str(src)], check=True)
     from test_runtime_cpu import build_runtime_lib           # the product sources on the fake HIP runtime
     runtime = build_runtime_lib()
-    env = dict(os.environ, LD_LIBRARY_PATH=str(FAKE / "rccl") + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
-    out = subprocess.run([sys.executable, "-c", CHILD, str(ROOT), str(runtime)], env=env, capture_output=True,
-                         text=True, timeout=120)
+    env = dict(os.environ, LD_LIBRARY_PATH=str(FAKE / "rccl") + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""), **(extra_env or {}))
+    return subprocess.run([sys.executable, "-c", code, str(ROOT), str(runtime)], env=env, capture_output=True, text=True, timeout=120)
+
+
+def test_collectives_between_two_ranks_on_the_fake_device():
+    out = _run_child(CHILD)
     assert out.returncode == 0 and "comm ok" in out.stdout, out.stderr[-2000:]
+
+
+# One process, one context per device, one THREAD per device -- the model the reference's comm_init assumes (it runs on each
+# device's own runner thread and blocks until every rank has joined: crates/cubecl-cuda/src/compute/server.rs:669-703) -- with
+# the reference's test body and closed form (crates/cubecl-core/src/runtime_tests/all_reduce.rs:5-62): device i contributes
+# i + j to handle j, every device must end with sum(i) + j * device_count.  The stand-in RCCL blocks in ncclCommInitRank like
+# the real one here; tests/test_gpu_runtime.py runs the same body over real RCCL when the box has two GPUs or more.
+THREADED = r'''
+import ctypes as C, sys, threading
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from cubecl_amd import _native as N
+lib = C.CDLL(sys.argv[2])
+for name, (restype, argtypes) in N.PROTOTYPES.items():
+    if hasattr(lib, name):
+        getattr(lib, name).restype, getattr(lib, name).argtypes = restype, argtypes
+lib.faketest_set_device.argtypes = [C.c_char_p, C.c_int32, C.c_int32]
+NDEV, SIZE, NUM_HANDLES = 4, 100, 8
+lib.faketest_set_device(b"gfx950:sramecc+:xnack-", 64, NDEV)
+uid = (C.c_uint8 * N.UNIQUE_ID_BYTES)()
+assert lib.mi355_comm_unique_id(uid) == N.OK
+step = threading.Barrier(NDEV)            # the stand-in executes a collective inside its LAST caller: line the ranks up per call
+results, errors = {}, []
+
+def device_thread(i):
+    try:
+        ctx, comm = C.c_void_p(), C.c_void_p()
+        assert lib.mi355_ctx_create(i, C.byref(ctx)) == N.OK
+        assert lib.mi355_comm_init(ctx, uid, i, NDEV, C.byref(comm)) == N.OK            # returns once all four have joined
+        handles = []
+        for j in range(NUM_HANDLES):
+            d = C.c_void_p()
+            src = np.full(SIZE, i + j, dtype=np.float32)
+            assert lib.mi355_pool_alloc(ctx, None, src.nbytes, C.byref(d)) == N.OK
+            assert lib.mi355_write(ctx, None, d, src.ctypes.data, src.nbytes) == N.OK
+            handles.append(d)
+        for d in handles:
+            assert lib.mi355_all_reduce(ctx, comm, None, d, d, SIZE, N.DTYPE_F32, N.REDUCE_SUM) == N.OK
+            step.wait()
+        assert lib.mi355_sync_collective(ctx, None) == N.OK                             # AFTER all the all_reduce calls, as the reference
+        got = []
+        for d in handles:
+            out = np.zeros(SIZE, dtype=np.float32)
+            assert lib.mi355_read(ctx, None, out.ctypes.data, d, out.nbytes) == N.OK
+            got.append(out)
+            assert lib.mi355_pool_free(ctx, None, d) == N.OK
+        # the argmax exchange on the same communicator: all-gather of {value, local index} records + the device-side rule's
+        # host twin is checked in tests/test_sharded_gloo.py; here the gather itself, every rank, rank order
+        rec, allrec = C.c_void_p(), C.c_void_p()
+        mine = np.array([100 + i, 7 * i], dtype=np.uint64)
+        assert lib.mi355_pool_alloc(ctx, None, 16, C.byref(rec)) == N.OK and lib.mi355_pool_alloc(ctx, None, 16 * NDEV, C.byref(allrec)) == N.OK
+        assert lib.mi355_write(ctx, None, rec, mine.ctypes.data, 16) == N.OK
+        assert lib.mi355_all_gather(ctx, comm, None, rec, allrec, 2, N.DTYPE_U64) == N.OK
+        step.wait()
+        assert lib.mi355_sync_collective(ctx, None) == N.OK
+        gathered = np.zeros(2 * NDEV, dtype=np.uint64)
+        assert lib.mi355_read(ctx, None, gathered.ctypes.data, allrec, gathered.nbytes) == N.OK
+        results[i] = (got, gathered.tolist())
+        step.wait()
+        assert lib.mi355_comm_destroy(ctx, comm) == N.OK and lib.mi355_ctx_destroy(ctx) == N.OK
+    except BaseException as exc:          # a failed rank must not leave the others waiting forever
+        errors.append(f"device {i}: {type(exc).__name__}: {exc}")
+        step.abort()
+
+threads = [threading.Thread(target=device_thread, args=(i,)) for i in range(NDEV)]
+for t in threads: t.start()
+for t in threads: t.join(60)
+assert not errors and not any(t.is_alive() for t in threads), errors
+value_base = float(sum(range(NDEV)))
+for i in range(NDEV):
+    got, gathered = results[i]
+    for j, out in enumerate(got):
+        assert np.array_equal(out, np.full(SIZE, value_base + j * NDEV, dtype=np.float32)), (i, j, out[:4])
+    assert gathered == [v for r in range(NDEV) for v in (100 + r, 7 * r)]
+print("threaded comm ok")
+'''
+
+
+def test_all_reduce_from_one_thread_per_device_matches_the_references_closed_form():
+    out = _run_child(THREADED, {"FAKE_RCCL_BLOCKING_INIT": "1"})
+    assert out.returncode == 0 and "threaded comm ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])

@@ -121,6 +121,63 @@ def test_argmax_tie_nan_and_zero_rules(client, oracle):
     assert int(idx.to_numpy(client)[0]) == 0 and val.to_numpy(client)[0] == -np.inf
 
 
+def test_argmax_combine_on_the_device_follows_the_single_gpu_rule(client, oracle):
+    """The combine step of the multi-GPU argmax as a kernel (mi355_argmax_combine_f32): gathered {value, local index}
+    records -> (value, GLOBAL index), against (a) the host rule every rank used to run (sharded.combine_argmax) and (b)
+    the oracle's argmax over the concatenated array the shards stand for."""
+    from cubecl_amd import sharded
+    idx, val = _scalar(client, ElemType.U64), _scalar(client, ElemType.F32)
+
+    def run(pairs, bases):
+        rec = np.zeros((len(pairs), 2), dtype=np.uint64)
+        for r, (v, i) in enumerate(pairs):
+            rec[r, 0] = np.float32(v).view(np.uint32)
+            rec[r, 1] = np.uint64(i & 0xFFFFFFFFFFFFFFFF)
+        h = client.create_from_slice(rec.reshape(-1)) if len(pairs) else client.empty(16)
+        ops.argmax_combine(client, h, len(pairs), bases, val.handle, idx.handle)
+        return float(val.to_numpy(client)[0]), int(idx.to_numpy(client)[0])
+
+    nan, inf = float("nan"), float("inf")
+    cases = [
+        ([(1.0, 10), (1.0, 3), (0.5, 0)], [0, 100, 200]),                  # tie across shards: the lower GLOBAL index wins
+        ([(1.0, 10), (1.0, 3)], [1000, 0]),                                # ... global, not local: shard 1 starts first here
+        ([(-0.0, 4), (0.0, 9)], [0, 50]),                                  # -0 == +0
+        ([(inf, 1), (nan, 8), (nan, 5)], [0, 10, 20]),                     # NaN above everything, first NaN (global) wins
+        ([(2.0, -1), (1.0, 7)], [0, 64]),                                  # empty shard ignored
+        ([(2.0, -1), (1.0, -1)], [0, 64]),                                 # all empty: -inf / 0
+        ([(-3.4e38, 0)] * 7 + [(-3.4e37, 5)], [i << 33 for i in range(8)]),   # indices beyond 2^32
+        ([(float(r % 5), r) for r in range(64)], [1000 * r for r in range(64)]),   # a full wave of records
+        ([], []),
+    ]
+    for pairs, bases in cases:
+        gv, gi = run(pairs, bases)
+        hv, hi = sharded.combine_argmax([(v, (b + i) if i >= 0 else -1) for (v, i), b in zip(pairs, bases)])
+        assert gi == hi and (gv == hv or (np.isnan(gv) and np.isnan(hv))), (pairs, bases, gv, gi, hv, hi)
+        if np.signbit(hv) != np.signbit(gv) and not np.isnan(hv):
+            raise AssertionError("sign of zero lost")
+    # end to end on real shards: 8 slices of one array, each reduced by the fused pass, records laid out as the all-gather
+    # delivers them, combined on the device == the oracle's argmax of the whole array
+    n = 3_000_017
+    x = oracle.fill_uniform(n, 29, -1.0, 1.0)
+    x[123_456] = 5.0; x[2_999_999] = 5.0                                   # the maximum twice, in different shards
+    t = TensorHandle.from_numpy(client, x)
+    rec = client.empty(16 * 8)
+    s = _scalar(client, ElemType.F32)
+    starts = []
+    for r in range(8):
+        start, count = sharded.shard_aligned_range(n, r, 8, 4)
+        starts.append(start)
+        view = TensorHandle.new_contiguous((count,), t.handle.offset_start_by(4 * start).offset_end_by(4 * (n - start - count)), ElemType.F32)
+        ov = TensorHandle.new_contiguous((1,), rec.offset_start_by(16 * r).offset_end_by(16 * (7 - r) + 12), ElemType.F32)
+        oi = TensorHandle.new_contiguous((1,), rec.offset_start_by(16 * r + 8).offset_end_by(16 * (7 - r)), ElemType.U64)
+        ops.sum_argmax(client, view, s, oi, ov)
+    ops.argmax_combine(client, rec, 8, starts, val.handle, idx.handle)
+    o_idx, o_val = oracle.argmax(x)
+    assert int(idx.to_numpy(client)[0]) == o_idx == 123_456 and float(val.to_numpy(client)[0]) == float(o_val)
+    with pytest.raises(ServerError):
+        ops.argmax_combine(client, rec, 65, [0] * 65, val.handle, idx.handle)
+
+
 def test_fused_sum_argmax_equals_separate(client, oracle):
     x = oracle.fill_uniform(5_000_011, 23, -1.0, 1.0)
     t = TensorHandle.from_numpy(client, x)

@@ -662,6 +662,75 @@ def test_to_client_moves_data_between_two_clients(client, oracle):
         other_server.close()
 
 
+def test_all_reduce_and_to_client_across_devices_when_the_box_has_several(client, oracle):
+    """The reference's own multi-device tests in its own form -- ONE process, one client per device
+    (runtime_tests/all_reduce.rs:5-62, to_client.rs:9-41) -- over real RCCL / xGMI.  Each device's calls come from its own
+    thread, the model the reference's comm_init assumes (its server thread per device blocks in ncclCommInitRank until every
+    rank has joined: crates/cubecl-cuda/src/compute/server.rs:669-703).  Like the reference test it returns early on a
+    one-GPU box (this pod); the CPU twin over a blocking stand-in RCCL is tests/test_comm_cpu.py."""
+    import threading
+    from cubecl_amd import DeviceId, Mi355Runtime, ReduceOperation, sharded
+    ids = Mi355Runtime.enumerate_devices()
+    if len(ids) < 2:
+        pytest.skip(f"{len(ids)} device(s) visible: the multi-device body needs two (all_reduce.rs:11-13 returns here too)")
+    ndev, SIZE, NUM_HANDLES = len(ids), 100, 8
+    uid = client.comm_unique_id()
+    results, errors = {}, []
+
+    def device_thread(i):
+        try:
+            c = Mi355Runtime.client(ids[i])
+            c.comm_init(ids, uid, rank=i)
+            handles = [c.create_from_slice(np.full(SIZE, i + j, dtype=np.float32)) for j in range(NUM_HANDLES)]
+            for h in handles:
+                c.all_reduce(h, h, ElemType.F32, ids, ReduceOperation.Sum)
+            c.sync_collective()                                   # AFTER all the all_reduce calls (all_reduce.rs:47-48)
+            got = [c.read_one(h).view(np.float32).copy() for h in handles]
+            # C4's exchange on every device: partial sums all-reduced, argmax records gathered and combined ON the device
+            n_total = 1 << 24
+            start, count = sharded.shard_aligned_range(n_total, i, ndev, 4)
+            x = oracle.fill_uniform_at(start, count, 31, 0.0, 1.0)
+            if i == ndev - 1:
+                x[count - 5] = 7.0                                # the global maximum sits in the last shard
+            if i == 0:
+                x[11] = 7.0                                       # ... and, tied, in the first: the lower global index wins
+            t = TensorHandle.from_numpy(c, x)
+            outs = c.empty(64)
+            part = TensorHandle.new_contiguous((1,), outs.offset_end_by(60), ElemType.F32)
+            val = TensorHandle.new_contiguous((1,), outs.offset_start_by(8).offset_end_by(52), ElemType.F32)
+            idx = TensorHandle.new_contiguous((1,), outs.offset_start_by(16).offset_end_by(40), ElemType.U64)
+            from cubecl_amd import ops
+            ops.sum_argmax(c, t, part, idx, val)
+            ex = sharded.RcclExchange(c, ids, i)
+            starts = [sharded.shard_aligned_range(n_total, r, ndev, 4)[0] for r in range(ndev)]
+            g_val, g_idx = outs.offset_start_by(32).offset_end_by(28), outs.offset_start_by(40).offset_end_by(16)
+            ex.exchange_on_device(part.handle, outs.offset_start_by(8).offset_end_by(40), starts, g_val, g_idx)
+            results[i] = (got, float(c.read_one(part.handle).view(np.float32)[0]), float(c.read_one(g_val).view(np.float32)[0]),
+                          int(c.read_one(g_idx).view(np.uint64)[0]), float(x.astype(np.float64).sum()))
+        except BaseException as exc:  # noqa: BLE001
+            errors.append(f"device {i}: {type(exc).__name__}: {exc}")
+    threads = [threading.Thread(target=device_thread, args=(i,)) for i in range(ndev)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(240)
+    assert not errors and not any(t.is_alive() for t in threads), errors
+    value_base = float(sum(d.index_id for d in ids))
+    exact = sum(results[i][4] for i in range(ndev))
+    for i in range(ndev):
+        got, total, gv, gi, _ = results[i]
+        for j, out in enumerate(got):
+            assert np.array_equal(out, np.full(SIZE, value_base + j * ndev, dtype=np.float32)), (i, j)   # all_reduce.rs:52-59
+        assert abs(total - exact) <= 1e-5 * exact and gv == 7.0 and gi == 11
+    # to_client.rs: every ordered pair of devices
+    for a in range(ndev):
+        for b in range(a + 1, ndev):
+            ca, cb = Mi355Runtime.client(ids[a]), Mi355Runtime.client(ids[b])
+            expected = np.array([0.0, 1.0, 2.0, 3.0, 4.0, 5.0], dtype=np.float32)
+            out = ca.to_client(ca.create_from_slice(expected), cb, ElemType.F32)
+            assert np.array_equal(cb.read_one(out).view(np.float32), expected)
+
+
 def test_pool_randomised_alloc_free_keeps_every_live_block_intact(client):
     """2 000 random reservations / releases on two streams with a distinct byte pattern per block: no live block is ever
     handed out twice, nothing is corrupted, the usage counters return to where they started."""
