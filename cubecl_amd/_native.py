@@ -44,6 +44,13 @@ DTYPE_SIZE = {DTYPE_F32: 4, DTYPE_BF16: 2, DTYPE_F16: 2, DTYPE_F64: 8, DTYPE_I32
 DTYPE_F8E4M3, DTYPE_F8E5M2 = 10, 11            # OCP FP8 (fp8_e4m3.rs / fp8_e5m2.rs of the reference)
 DTYPE_F4E2M1X2, DTYPE_UE8M0 = 12, 13            # packed e2m1 pairs (one byte per pair), MX block scales
 DTYPE_SIZE.update({DTYPE_F8E4M3: 1, DTYPE_F8E5M2: 1, DTYPE_F4E2M1X2: 1, DTYPE_UE8M0: 1})
+# advertised for generated kernels only (register_supported_types, crates/cubecl-cpp/src/shared/base.rs:322-375)
+DTYPE_I16, DTYPE_U16, DTYPE_BOOL, DTYPE_FLEX32, DTYPE_INDEX = 14, 15, 16, 17, 18
+DTYPE_SIZE.update({DTYPE_I16: 2, DTYPE_U16: 2, DTYPE_BOOL: 1, DTYPE_FLEX32: 4})
+TYPE_USAGE = {"Conversion": 1, "Arithmetic": 2, "DotProduct": 4, "Buffer": 8}                     # features.rs:79-88
+ATOMIC_USAGE = {"LoadStore": 1, "Exchange": 2, "Add": 4, "MinMax": 8, "Bitwise": 16, "CompareExchange": 32}   # :110-123
+ADDRESS_TYPE_U32, ADDRESS_TYPE_U64 = 1, 2
+LAYOUT_ROW_MAJOR, LAYOUT_COL_MAJOR = 0, 1
 
 REDUCE_SUM, REDUCE_MEAN, REDUCE_MAX, REDUCE_MIN = 0, 1, 2, 3
 PLANE_PROD, PLANE_INCLUSIVE_SUM, PLANE_EXCLUSIVE_SUM = 100, 101, 102
@@ -57,7 +64,7 @@ class MmaConfig(C.Structure):
                 ("a_type", C.c_int32), ("b_type", C.c_int32), ("cd_type", C.c_int32)]
 
 
-ABI_VERSION = 3     # MI355_ABI_VERSION of include/mi355cube.h this table was written against
+ABI_VERSION = 4     # MI355_ABI_VERSION of include/mi355cube.h this table was written against
 
 
 class MemoryUsage(C.Structure):
@@ -72,6 +79,18 @@ ALLOC_MODE_AUTO, ALLOC_MODE_PERSISTENT = 0, 1
 class ScaledMmaConfig(C.Structure):
     _fields_ = [("m", C.c_uint32), ("n", C.c_uint32), ("k", C.c_uint32), ("a_type", C.c_int32), ("b_type", C.c_int32),
                 ("cd_type", C.c_int32), ("scales_type", C.c_int32), ("scales_factor", C.c_uint32)]
+
+
+class TypeUsageEntry(C.Structure):
+    """mi355_type_usage: one ElemType with its TypeUsage (or AtomicUsage) bit set."""
+    _fields_ = [("dtype", C.c_int32), ("usage", C.c_uint32)]
+
+
+class MmaProperties(C.Structure):
+    """mi355_mma_properties: TargetProperties.mma for MFMA (crates/cubecl-ir/src/runtime_properties.rs:19-39)."""
+    _fields_ = [(n, C.c_uint32) for n in ("register_size_bits", "const_plane_size", "register_layout_a", "register_layout_b",
+                                          "register_layout_acc", "register_duplication_a", "register_duplication_b",
+                                          "register_duplication_acc", "contiguous_elements_ab_bits", "contiguous_elements_acc")]
 
 
 class DeviceProps(C.Structure):
@@ -89,6 +108,8 @@ class DeviceProps(C.Structure):
         ("timing_method_device", C.c_uint32), ("server_comm_enabled", C.c_uint32),
         ("num_mma_configs", C.c_uint32), ("mma_configs", MmaConfig * 16),
         ("num_scaled_mma_configs", C.c_uint32), ("scaled_mma_configs", ScaledMmaConfig * 8),
+        ("address_types", C.c_uint32), ("num_type_usage", C.c_uint32), ("type_usage", TypeUsageEntry * 24),
+        ("num_atomic_usage", C.c_uint32), ("atomic_usage", TypeUsageEntry * 8), ("mma_properties", MmaProperties),
     ]
 
 

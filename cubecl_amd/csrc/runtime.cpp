@@ -227,6 +227,24 @@ MI355_API int32_t mi355_ctx_create(int32_t device_index, mi355_ctx **out_ctx)
         }
     }
 
+    // register_supported_types (crates/cubecl-cpp/src/shared/base.rs:322-375), same table, same usages: what generated
+    // kernels may use on this device.  (The matrix types of features.matmul are the MMA lists above.)
+    p.address_types = MI355_ADDRESS_TYPE_U32 | MI355_ADDRESS_TYPE_U64;
+    const int32_t full[] = {MI355_DTYPE_INDEX, MI355_DTYPE_U8, MI355_DTYPE_U16, MI355_DTYPE_U32, MI355_DTYPE_U64, MI355_DTYPE_I8,
+                            MI355_DTYPE_I16, MI355_DTYPE_I32, MI355_DTYPE_I64, MI355_DTYPE_BF16, MI355_DTYPE_F16, MI355_DTYPE_F32,
+                            MI355_DTYPE_FLEX32, MI355_DTYPE_F64, MI355_DTYPE_BOOL};
+    for (int32_t t : full) p.type_usage[p.num_type_usage++] = {t, MI355_TYPE_USAGE_ALL};
+    for (int32_t t : {MI355_DTYPE_F8E4M3, MI355_DTYPE_F8E5M2})
+        p.type_usage[p.num_type_usage++] = {t, MI355_TYPE_USAGE_CONVERSION | MI355_TYPE_USAGE_BUFFER};
+    // atomics: every operation on 32-bit integers; add / load-store / exchange on i64, u64 and f32 (base.rs:364-372)
+    for (int32_t t : {MI355_DTYPE_I32, MI355_DTYPE_I64, MI355_DTYPE_U32, MI355_DTYPE_U64, MI355_DTYPE_F32}) {
+        const bool full32 = t == MI355_DTYPE_I32 || t == MI355_DTYPE_U32;
+        p.atomic_usage[p.num_atomic_usage++] = {t, full32 ? (uint32_t)MI355_ATOMIC_ALL
+                                                          : (uint32_t)(MI355_ATOMIC_ADD | MI355_ATOMIC_LOAD_STORE | MI355_ATOMIC_EXCHANGE)};
+    }
+    // TargetProperties.mma for MFMA (the reference's HIP values are RDNA WMMA with const_plane_size 32, runtime.rs:282-304)
+    p.mma_properties = {32, 64, MI355_LAYOUT_ROW_MAJOR, MI355_LAYOUT_COL_MAJOR, MI355_LAYOUT_COL_MAJOR, 1, 1, 1, 128, 4};
+
     *out_ctx = ctx;
     return MI355_OK;
 }

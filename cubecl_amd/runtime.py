@@ -47,6 +47,12 @@ class ElemType(enum.IntEnum):
     F8E5M2 = N.DTYPE_F8E5M2          # FloatKind::E5M2
     F4E2M1X2 = N.DTYPE_F4E2M1X2      # FloatKind::E2M1 packed in pairs (e2m1x2, fp4.rs:19-28): one byte per two elements
     UE8M0 = N.DTYPE_UE8M0            # FloatKind::UE8M0, the MX block scale
+    # advertised for generated kernels (features().type_usage); this library's own entry points do not take them
+    I16 = N.DTYPE_I16
+    U16 = N.DTYPE_U16
+    BOOL = N.DTYPE_BOOL
+    FLEX32 = N.DTYPE_FLEX32
+    INDEX = N.DTYPE_INDEX
 
     def size(self) -> int:
         return N.DTYPE_SIZE[int(self)]
@@ -389,8 +395,33 @@ class ComputeClient:
         cfgs = [(c.a_type, c.b_type, c.cd_type, c.m, c.n, c.k) for c in p.mma_configs[: p.num_mma_configs]]
         scaled = [(c.a_type, c.b_type, c.cd_type, c.scales_type, c.m, c.n, c.k, c.scales_factor)
                   for c in p.scaled_mma_configs[: p.num_scaled_mma_configs]]
+        def names(bits, table):
+            return frozenset(n for n, b in table.items() if bits & b)
+        # register_supported_types (crates/cubecl-cpp/src/shared/base.rs:322-375): every ElemType a kernel may use with its
+        # TypeUsage set, atomics with their AtomicUsage set, the two address types
+        type_usage = {ElemType(e.dtype): names(e.usage, N.TYPE_USAGE) for e in p.type_usage[: p.num_type_usage]}
+        atomic_usage = {ElemType(e.dtype): names(e.usage, N.ATOMIC_USAGE) for e in p.atomic_usage[: p.num_atomic_usage]}
+        address = {n for n, b in (("U32", N.ADDRESS_TYPE_U32), ("U64", N.ADDRESS_TYPE_U64)) if p.address_types & b}
         return {"plane": {"Ops", "NonUniformControlFlow"} if p.plane_ops else set(), "cmma": set(cfgs), "mma": set(cfgs),
-                "scaled_mma": set(scaled)}          # features.matmul.scaled_mma (ScaledMmaConfig, cmma.rs:1493-1505)
+                "scaled_mma": set(scaled),          # features.matmul.scaled_mma (ScaledMmaConfig, cmma.rs:1493-1505)
+                "type_usage": type_usage, "atomic_type_usage": atomic_usage, "address_types": address}
+
+    def target_properties(self) -> dict:
+        """Runtime::target_properties().mma for this device's matrix cores (runtime.rs:14-52; MmaProperties,
+        crates/cubecl-ir/src/runtime_properties.rs:19-39).  `contiguous_elements(ident, elem_bits)` plays the role of the
+        reference's ContiguousElements closure."""
+        m = self._s.props.mma_properties
+        lay = {N.LAYOUT_ROW_MAJOR: "RowMajor", N.LAYOUT_COL_MAJOR: "ColMajor"}
+
+        def contiguous_elements(ident: str, elem_bits: int) -> int:
+            if ident == "Accumulator":
+                return m.contiguous_elements_acc
+            return max(m.contiguous_elements_ab_bits // elem_bits, 1) if elem_bits < 32 else 1
+        return {"mma": {"register_size_bits": m.register_size_bits, "const_plane_size": m.const_plane_size,
+                        "register_layout_a": lay[m.register_layout_a], "register_layout_b": lay[m.register_layout_b],
+                        "register_layout_acc": lay[m.register_layout_acc], "register_duplication_a": m.register_duplication_a,
+                        "register_duplication_b": m.register_duplication_b, "register_duplication_acc": m.register_duplication_acc,
+                        "contiguous_elements": contiguous_elements}}
 
     def io_optimized_vector_sizes(self, elem_size: int) -> list:
         width = self._s.props.load_width_bits // 8  # client.rs:1339

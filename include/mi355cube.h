@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define MI355_ABI_VERSION 3
+#define MI355_ABI_VERSION 4
 
 /* ---- status codes (map onto LaunchError / IoError / ServerError, server/base.rs:177-332,
  *      :884-1019; the Rust shim performs the conversion) ------------------------------- */
@@ -85,8 +85,23 @@ enum {
     MI355_DTYPE_F8E4M3 = 10, /* OCP e4m3fn: no infinities, S.1111.111 = NaN, max 448 (fp8_e4m3.rs:12-37) */
     MI355_DTYPE_F8E5M2 = 11, /* OCP e5m2: IEEE-style inf / NaN, max 57344 (fp8_e5m2.rs:12-38) */
     MI355_DTYPE_F4E2M1X2 = 12, /* two e2m1 per byte, the first in the low nibble (fp4.rs:204-224); sizes are in BYTES */
-    MI355_DTYPE_UE8M0 = 13   /* block scale 2^(bits - 127), 0xFF = NaN (fp8/fp8_e8m0.rs) */
+    MI355_DTYPE_UE8M0 = 13,  /* block scale 2^(bits - 127), 0xFF = NaN (fp8/fp8_e8m0.rs) */
+    /* types a backend ADVERTISES for generated kernels (register_supported_types, crates/cubecl-cpp/src/shared/base.rs:
+     * 322-375); this library's own entry points do not take them, kernels launched through mi355_launch may */
+    MI355_DTYPE_I16 = 14,
+    MI355_DTYPE_U16 = 15,
+    MI355_DTYPE_BOOL = 16,
+    MI355_DTYPE_FLEX32 = 17, /* FloatKind::Flex32: f32 storage, relaxed compute precision */
+    MI355_DTYPE_INDEX = 18   /* ElemType::Index: the kernel's address type (u32 or u64) */
 };
+
+/* TypeUsage / AtomicUsage bit sets (crates/cubecl-ir/src/features.rs:79-88, :110-123), bit = 1 << variant order */
+enum { MI355_TYPE_USAGE_CONVERSION = 1, MI355_TYPE_USAGE_ARITHMETIC = 2, MI355_TYPE_USAGE_DOT_PRODUCT = 4, MI355_TYPE_USAGE_BUFFER = 8,
+       MI355_TYPE_USAGE_ALL = 15 };
+enum { MI355_ATOMIC_LOAD_STORE = 1, MI355_ATOMIC_EXCHANGE = 2, MI355_ATOMIC_ADD = 4, MI355_ATOMIC_MIN_MAX = 8, MI355_ATOMIC_BITWISE = 16,
+       MI355_ATOMIC_COMPARE_EXCHANGE = 32, MI355_ATOMIC_ALL = 63 };
+enum { MI355_ADDRESS_TYPE_U32 = 1, MI355_ADDRESS_TYPE_U64 = 2 };   /* register_address_type (base.rs:323-324) */
+enum { MI355_LAYOUT_ROW_MAJOR = 0, MI355_LAYOUT_COL_MAJOR = 1 };   /* cmma::MatrixLayout */
 
 /* ReduceOperation (server/base.rs:623-628) + the two extra ops array-wide argmax needs.
  * Sum and Mean are the reference's; Max/Min are an API delta. */
@@ -112,6 +127,27 @@ typedef struct {
     int32_t a_type, b_type, cd_type, scales_type; /* MI355_DTYPE_*; scales_type = MI355_DTYPE_UE8M0 */
     uint32_t scales_factor;                       /* scales per k of one instruction (k / 32)       */
 } mi355_scaled_mma_config; /* ScaledMmaConfig (what test_cmma_scaled looks up, runtime_tests/cmma.rs:1493-1505) */
+
+typedef struct {
+    int32_t dtype;       /* MI355_DTYPE_* */
+    uint32_t usage;      /* MI355_TYPE_USAGE_* bits, or MI355_ATOMIC_* bits in the atomic table */
+} mi355_type_usage;      /* one entry of DeviceProperties' type_usage / atomic_type_usage maps */
+
+/* TargetProperties.mma for the matrix cores of this device (cubecl_ir::MmaProperties, crates/cubecl-ir/src/
+ * runtime_properties.rs:19-39; the reference's HIP values describe RDNA WMMA only, crates/cubecl-hip/src/runtime.rs:282-304).
+ * MFMA on gfx950 (cdna_hip_programming.md section 3): a lane holds k-CONTIGUOUS elements of one A row and of one B
+ * column (8 x 16-bit, 1 x f32, 16 x 8-bit per 128-bit register group) and, of the accumulator, 4 consecutive ROWS of one
+ * column per register quad (32x32: row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), col = lane & 31) -- nothing is held twice. */
+typedef struct {
+    uint32_t register_size_bits;        /* 32 */
+    uint32_t const_plane_size;          /* 64 */
+    uint32_t register_layout_a;         /* MI355_LAYOUT_ROW_MAJOR: k runs along a register group */
+    uint32_t register_layout_b;         /* MI355_LAYOUT_COL_MAJOR */
+    uint32_t register_layout_acc;       /* MI355_LAYOUT_COL_MAJOR: consecutive registers walk down a column */
+    uint32_t register_duplication_a, register_duplication_b, register_duplication_acc;   /* 1, 1, 1 */
+    uint32_t contiguous_elements_ab_bits;   /* contiguous operand elements per lane = this / element bits: 128 (f32: one element) */
+    uint32_t contiguous_elements_acc;       /* 4 */
+} mi355_mma_properties;
 
 typedef struct {
     uint32_t abi_version;
@@ -147,6 +183,13 @@ typedef struct {
     uint32_t num_scaled_mma_configs;  /* features.matmul.scaled_mma (register_scaled_mma_features,
                                          crates/cubecl-cpp/src/shared/mma.rs:21-46); since ABI 2   */
     mi355_scaled_mma_config scaled_mma_configs[8];
+    /* since ABI 4: what register_supported_types advertises (crates/cubecl-cpp/src/shared/base.rs:322-375) */
+    uint32_t address_types;           /* MI355_ADDRESS_TYPE_* bits                              */
+    uint32_t num_type_usage;
+    mi355_type_usage type_usage[24];  /* every supported ElemType with its TypeUsage set        */
+    uint32_t num_atomic_usage;
+    mi355_type_usage atomic_usage[8]; /* atomic element types with their AtomicUsage set        */
+    mi355_mma_properties mma_properties;   /* TargetProperties.mma for MFMA                     */
 } mi355_device_props_t;
 
 /* =================================== Runtime ============================================= */

@@ -37,6 +37,25 @@ pub const MI355_DTYPE_F8E4M3: i32 = 10;
 pub const MI355_DTYPE_F8E5M2: i32 = 11;
 pub const MI355_DTYPE_F4E2M1X2: i32 = 12;
 pub const MI355_DTYPE_UE8M0: i32 = 13;
+pub const MI355_DTYPE_I16: i32 = 14;
+pub const MI355_DTYPE_U16: i32 = 15;
+pub const MI355_DTYPE_BOOL: i32 = 16;
+pub const MI355_DTYPE_FLEX32: i32 = 17;
+pub const MI355_DTYPE_INDEX: i32 = 18;
+pub const MI355_TYPE_USAGE_CONVERSION: u32 = 1;
+pub const MI355_TYPE_USAGE_ARITHMETIC: u32 = 2;
+pub const MI355_TYPE_USAGE_DOT_PRODUCT: u32 = 4;
+pub const MI355_TYPE_USAGE_BUFFER: u32 = 8;
+pub const MI355_ATOMIC_LOAD_STORE: u32 = 1;
+pub const MI355_ATOMIC_EXCHANGE: u32 = 2;
+pub const MI355_ATOMIC_ADD: u32 = 4;
+pub const MI355_ATOMIC_MIN_MAX: u32 = 8;
+pub const MI355_ATOMIC_BITWISE: u32 = 16;
+pub const MI355_ATOMIC_COMPARE_EXCHANGE: u32 = 32;
+pub const MI355_ADDRESS_TYPE_U32: u32 = 1;
+pub const MI355_ADDRESS_TYPE_U64: u32 = 2;
+pub const MI355_LAYOUT_ROW_MAJOR: u32 = 0;
+pub const MI355_LAYOUT_COL_MAJOR: u32 = 1;
 pub const MI355_ALLOC_MODE_AUTO: i32 = 0;
 pub const MI355_ALLOC_MODE_PERSISTENT: i32 = 1;
 
@@ -103,6 +122,34 @@ pub struct mi355_device_props_t {
     pub mma_configs: [mi355_mma_config; 16],
     pub num_scaled_mma_configs: u32,
     pub scaled_mma_configs: [mi355_scaled_mma_config; 8],
+    pub address_types: u32,
+    pub num_type_usage: u32,
+    pub type_usage: [mi355_type_usage; 24],
+    pub num_atomic_usage: u32,
+    pub atomic_usage: [mi355_type_usage; 8],
+    pub mma_properties: mi355_mma_properties,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct mi355_type_usage {
+    pub dtype: i32,
+    pub usage: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct mi355_mma_properties {
+    pub register_size_bits: u32,
+    pub const_plane_size: u32,
+    pub register_layout_a: u32,
+    pub register_layout_b: u32,
+    pub register_layout_acc: u32,
+    pub register_duplication_a: u32,
+    pub register_duplication_b: u32,
+    pub register_duplication_acc: u32,
+    pub contiguous_elements_ab_bits: u32,
+    pub contiguous_elements_acc: u32,
 }
 
 #[repr(C)]

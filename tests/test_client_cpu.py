@@ -155,3 +155,54 @@ def test_profile_capture_replay_and_to_client(client, fake):
     finally:
         del moved
         other._s.close()
+
+
+def test_advertised_types_atomics_and_mma_properties_follow_the_reference_registration(client):
+    """Row a18: what a backend must advertise so that the type-gated tests and launchers run instead of skipping --
+    register_supported_types (crates/cubecl-cpp/src/shared/base.rs:322-375), parsed from the reference source when it is
+    present (this container), and pinned literally so that the GPU box, which has no /root/reference, checks the same table."""
+    import re
+    from pathlib import Path
+    from cubecl_amd import ElemType
+    f = client.features()
+    ALL = frozenset({"Conversion", "Arithmetic", "DotProduct", "Buffer"})
+    full = {"INDEX", "U8", "U16", "U32", "U64", "I8", "I16", "I32", "I64", "BF16", "F16", "F32", "FLEX32", "F64", "BOOL"}
+    want = {ElemType[n]: ALL for n in full}
+    want.update({ElemType.F8E4M3: frozenset({"Conversion", "Buffer"}), ElemType.F8E5M2: frozenset({"Conversion", "Buffer"})})
+    assert f["type_usage"] == want
+    restricted = frozenset({"Add", "LoadStore", "Exchange"})
+    every = frozenset({"LoadStore", "Exchange", "Add", "MinMax", "Bitwise", "CompareExchange"})
+    assert f["atomic_type_usage"] == {ElemType.I32: every, ElemType.U32: every, ElemType.I64: restricted, ElemType.U64: restricted,
+                                      ElemType.F32: restricted}
+    assert f["address_types"] == {"U32", "U64"}
+    src = Path("/root/reference/crates/cubecl-cpp/src/shared/base.rs")
+    if src.exists():                                          # hold the literal table above to the reference's own text
+        body = src.read_text()
+        body = body[body.index("pub fn register_supported_types"):]
+        body = body[: body.index("\n}\n")]
+        sup = body[body.index("let supported_types"): body.index("let supported_atomic_types")]
+        names = set(re.findall(r"(?:UIntKind|IntKind|FloatKind)::(\w+)", sup)) | set(re.findall(r"ElemType::(Index|Bool)", sup))
+        assert {n.upper() for n in names} == full
+        atom = body[body.index("let supported_atomic_types"): body.index("for ty in supported_types")]
+        assert {n.upper() for n in re.findall(r"(?:UIntKind|IntKind|FloatKind)::(\w+)", atom)} == {"I32", "I64", "U32", "U64", "F32"}
+        assert "for ty in [FloatKind::E4M3, FloatKind::E5M2]" in body and "TypeUsage::Conversion | TypeUsage::Buffer" in body
+        assert "AtomicUsage::Add | AtomicUsage::LoadStore | AtomicUsage::Exchange" in body
+        feats = Path("/root/reference/crates/cubecl-ir/src/features.rs").read_text()
+        usage = feats[feats.index("pub enum TypeUsage"):]
+        assert re.findall(r"^    (\w+),", usage[: usage.index("}")], re.M) == ["Conversion", "Arithmetic", "DotProduct", "Buffer"]
+        atomic = feats[feats.index("pub enum AtomicUsage"):]
+        assert re.findall(r"^    (\w+),", atomic[: atomic.index("}")], re.M) == ["LoadStore", "Exchange", "Add", "MinMax", "Bitwise",
+                                                                                 "CompareExchange"]
+    # TargetProperties.mma for MFMA (fields of cubecl_ir::MmaProperties, runtime_properties.rs:19-39): wave64, k-contiguous
+    # operand registers (8 x 16-bit, 16 x 8-bit, one f32), accumulators 4 rows down a column, nothing duplicated
+    m = client.target_properties()["mma"]
+    assert (m["register_size_bits"], m["const_plane_size"]) == (32, 64)
+    assert (m["register_layout_a"], m["register_layout_b"], m["register_layout_acc"]) == ("RowMajor", "ColMajor", "ColMajor")
+    assert (m["register_duplication_a"], m["register_duplication_b"], m["register_duplication_acc"]) == (1, 1, 1)
+    ce = m["contiguous_elements"]
+    assert (ce("A", 16), ce("B", 16), ce("A", 8), ce("A", 32), ce("Accumulator", 32)) == (8, 8, 16, 1, 4)
+    if src.exists():
+        rp = Path("/root/reference/crates/cubecl-ir/src/runtime_properties.rs").read_text()
+        st = rp[rp.index("pub struct MmaProperties"):]
+        fields = re.findall(r"pub (\w+):", st[: st.index("\n}")])
+        assert set(fields) - {"contiguous_elements"} == set(m) - {"contiguous_elements"} and "contiguous_elements" in fields

@@ -152,9 +152,8 @@ def test_argmax_combine_on_the_device_follows_the_single_gpu_rule(client, oracle
     for pairs, bases in cases:
         gv, gi = run(pairs, bases)
         hv, hi = sharded.combine_argmax([(v, (b + i) if i >= 0 else -1) for (v, i), b in zip(pairs, bases)])
-        assert gi == hi and (gv == hv or (np.isnan(gv) and np.isnan(hv))), (pairs, bases, gv, gi, hv, hi)
-        if np.signbit(hv) != np.signbit(gv) and not np.isnan(hv):
-            raise AssertionError("sign of zero lost")
+        same = np.float32(gv).view(np.uint32) == np.float32(hv).view(np.uint32) or (np.isnan(gv) and np.isnan(hv))   # bits: -0 stays -0
+        assert gi == hi and same, (pairs, bases, gv, gi, hv, hi)
     # end to end on real shards: 8 slices of one array, each reduced by the fused pass, records laid out as the all-gather
     # delivers them, combined on the device == the oracle's argmax of the whole array
     n = 3_000_017
