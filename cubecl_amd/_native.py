@@ -56,6 +56,7 @@ REDUCE_SUM, REDUCE_MEAN, REDUCE_MAX, REDUCE_MIN = 0, 1, 2, 3
 PLANE_PROD, PLANE_INCLUSIVE_SUM, PLANE_EXCLUSIVE_SUM = 100, 101, 102
 
 GEMM_ALGO_AUTO, GEMM_ALGO_GENERIC, GEMM_ALGO_F32_MFMA, GEMM_ALGO_LP_128, GEMM_ALGO_LP_256, GEMM_ALGO_LP_256W4, GEMM_ALGO_LP_256P = 0, 1, 2, 3, 4, 5, 6
+GEMM_ALGO_LP_256Q = 7
 UNIQUE_ID_BYTES = 128
 
 

@@ -202,10 +202,21 @@ bool prefers_persistent(const mi355_gemm_desc &d, const void *a, const void *b, 
     return !plan_tail_split(d, tp);
 }
 
+// 16-bit C: the persistent kernel that keeps the finished tile in registers and drips its stores into the next tile's K loop
+// (gemm_lp256q.hip).  Measured against gemm_lp256p.hip, interleaved, 64 x 2048 x 2048 x K (tools/dev/q_ab.py): K = 384 / 448 /
+// 512 (8 stores per K-tile) +1.5 / +2.5 / +4 %, K = 576 ... 960 (4 or 2 stores per K-tile) -5 ... -11 %, K = 1024 / 1536 / 2048 /
+// 4096 +3.6 / +1.5 / +3.6 ... 4.9 / +1.2 %, 8192 a tie.
+bool prefers_dripped_stores(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
+{
+    const int64_t nk = d.k / 64;
+    return gemm_lp256q_supports(d, a, b, c) && (nk >= 16 || (nk >= 6 && nk <= 8));
+}
+
 int32_t select_auto(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
 {
     const int32_t algo = select(d, a, b, c);
-    return (algo == MI355_GEMM_ALGO_LP_256W4 && prefers_persistent(d, a, b, c)) ? MI355_GEMM_ALGO_LP_256P : algo;
+    if (algo != MI355_GEMM_ALGO_LP_256W4 || !prefers_persistent(d, a, b, c)) return algo;
+    return prefers_dripped_stores(d, a, b, c) ? MI355_GEMM_ALGO_LP_256Q : MI355_GEMM_ALGO_LP_256P;
 }
 
 int32_t run_tail_split(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c,
@@ -268,6 +279,7 @@ MI355_API int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_ge
     case MI355_GEMM_ALGO_LP_256: return launch_gemm_lp256(ctx, s, d, a, b, c);
     case MI355_GEMM_ALGO_LP_256W4: return launch_gemm_lp256w4(ctx, s, d, a, b, c);
     case MI355_GEMM_ALGO_LP_256P: return launch_gemm_lp256p(ctx, s, d, a, b, c);
+    case MI355_GEMM_ALGO_LP_256Q: return launch_gemm_lp256q(ctx, s, d, a, b, c);
     default: return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_gemm: unknown algo %d", algo);
     }
 }

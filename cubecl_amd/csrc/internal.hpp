@@ -71,6 +71,7 @@ struct mi355_ctx {
     std::map<std::pair<hipStream_t, int>, std::pair<void *, size_t>> scratch;
     mi355::memory_pool *pool = nullptr;    // caching allocator behind mi355_pool_* (pool.cpp)
     uint64_t func_attr_mask = 0;  // kernels whose dynamic-LDS attribute is already raised on this device
+    uint64_t func_attr_mask2 = 0; // ... second word (gemm_lp256q.hip)
     // One context = one server: the reference funnels every call through one runner thread per device
     // (crates/cubecl-common/src/device/handle/channel.rs:75-110).  Bindings without that discipline (Python: a Handle
     // dropped by the garbage collector on another thread while ctypes has released the GIL) are serialised here.

@@ -196,7 +196,7 @@ ThroughputMode.MemoryWrite = ThroughputMode("MemoryWrite")
 ThroughputMode.Launch = ThroughputMode("Launch")
 
 _F32 = 0            # _native.DTYPE_F32; spelled out so that this module needs no library (checked in tests/test_host_logic.py)
-_DTYPE_BYTES = {0: 4, 1: 2, 2: 2, 3: 8, 4: 4, 5: 4, 6: 8, 7: 8, 8: 1, 9: 1, 10: 1, 11: 1, 12: 1, 13: 1}
+_DTYPE_BYTES = {0: 4, 1: 2, 2: 2, 3: 8, 4: 4, 5: 4, 6: 8, 7: 8, 8: 1, 9: 1, 10: 1, 11: 1, 12: 1, 13: 1, 14: 2, 15: 2, 16: 1, 17: 4}
 
 
 @dataclass(frozen=True)

@@ -377,8 +377,10 @@ enum {
     MI355_GEMM_ALGO_LP_128 = 3,   /* bf16/f16 128x128x64 LDS-DMA tile, v_mfma_f32_32x32x16     */
     MI355_GEMM_ALGO_LP_256 = 4,   /* bf16/f16 256x256x64 tile, 8 waves (ragged M/N allowed)    */
     MI355_GEMM_ALGO_LP_256W4 = 5, /* fp8/bf16/f16/f32 256x256 tile x 128-byte K line, 4 waves x 128x128 */
-    MI355_GEMM_ALGO_LP_256P = 6   /* the same tile as a persistent kernel: one workgroup per CU walks
+    MI355_GEMM_ALGO_LP_256P = 6,  /* the same tile as a persistent kernel: one workgroup per CU walks
                                      several output tiles with a continuous K-tile stream          */
+    MI355_GEMM_ALGO_LP_256Q = 7   /* the persistent kernel with the finished tile held in registers (16-bit C) and its
+                                     stores dripped into the next tile's K loop                      */
 };
 
 int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_gemm_desc *desc,

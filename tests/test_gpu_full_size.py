@@ -122,7 +122,7 @@ def test_c3_bf16_8192_bf16_output_as_benched(client, oracle):
     assert np.array_equal(oracle.to_bf16(c32.to_numpy(client).reshape(S, S)[rows]), got[rows])
 
 
-def test_c5_batch64_2048_bf16_as_benched_takes_the_persistent_kernel(client, oracle):
+def test_c5_batch64_2048_bf16_as_benched_takes_the_dripped_store_kernel(client, oracle):
     """Config C5's per-GPU shard in the EXACT form bench.py times it (bench.py batched_c5): batch 64 of 2048^3 bf16 -> bf16 C.
     AUTO must take the persistent 256x256 kernel; sampled rows of five matrices (first, last, three inside) against the
     f64 oracle, operands regenerated window by window from the counter RNG."""
@@ -132,10 +132,10 @@ def test_c5_batch64_2048_bf16_as_benched_takes_the_persistent_kernel(client, ora
     b = TensorHandle.uniform(client, (B, M, M), ElemType.BF16, SEED, 600, -1.0, 1.0)
     c = TensorHandle.new_contiguous((B, M, M), client.empty(B * M * M * 2), ElemType.BF16)
     d = _bench_desc(M, M, M, N.DTYPE_BF16, N.DTYPE_BF16, batch=B)
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256P
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256Q       # the persistent kernel with dripped stores (gemm_lp256q.hip)
     client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()),
                                           C.c_void_p(c.device_ptr())))
-    rows = np.array([0, 255, 256, 1023, 1024 + 129, 2047])
+    rows = np.array([0, 95, 96, 127, 128, 255, 256, 1023, 1024 + 129, 2047])   # held row blocks and the boundary block of a wave
     mm = M * M
     for bi in (0, 1, 31, 40, 63):
         a_bits = oracle.to_bf16(oracle.fill_uniform_at(bi * mm, mm, 500, -1.0, 1.0))

@@ -20,7 +20,8 @@ pytestmark = pytest.mark.gpu
 GOLD = json.loads((Path(__file__).parent / "golden" / "reference_goldens.json").read_text())
 REL = 1e-5
 ALGOS = {"auto": N.GEMM_ALGO_AUTO, "generic": N.GEMM_ALGO_GENERIC, "f32": N.GEMM_ALGO_F32_MFMA,
-         "lp128": N.GEMM_ALGO_LP_128, "lp256": N.GEMM_ALGO_LP_256, "lp256w4": N.GEMM_ALGO_LP_256W4, "lp256p": N.GEMM_ALGO_LP_256P}
+         "lp128": N.GEMM_ALGO_LP_128, "lp256": N.GEMM_ALGO_LP_256, "lp256w4": N.GEMM_ALGO_LP_256W4, "lp256p": N.GEMM_ALGO_LP_256P,
+         "lp256q": N.GEMM_ALGO_LP_256Q}
 
 
 def _to_dev(client, oracle, x, dtype):
@@ -386,7 +387,48 @@ def test_lp256p_race_screen_across_tile_boundaries(client, oracle):
         assert np.array_equal(c.to_numpy(client), want)
 
 
-@pytest.mark.parametrize("algo", ["lp128", "lp256", "lp256w4", "lp256p", "f32"])
+# ---- the persistent form with dripped stores (16-bit C held in registers) -----------------------------------------------
+# Same tiles, same per-tile summation order as the one-tile-per-workgroup kernel: every comparison is bit for bit.  The K values
+# walk the four drip rates (8 / 4 / 2 / 1 stores per K-tile: 6-8 / 9-14 / 15-26 / 27+ K-tiles) and their edges; the shapes put
+# 1, 2 and "some 1, some 2" tiles on a workgroup (the held tile of a workgroup's LAST tile leaves through the flush path).
+@pytest.mark.parametrize("k", [384, 448, 512, 576, 640, 896, 960, 1024, 1664, 1728, 2048, 4160])
+@pytest.mark.parametrize("m,n,batch", [(512, 512, 1), (4352, 4352, 1), (1024, 512, 72)])
+def test_lp256q_is_bit_identical_to_the_plain_kernel(client, oracle, m, n, batch, k):
+    if (m, k) == (4352, 4160):
+        pytest.skip("covered by the smaller shapes")
+    a = TensorHandle.uniform(client, (batch, m, k), ElemType.BF16, 0x5EEDC0BE, 81, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (batch, n, k), ElemType.BF16, 0x5EEDC0BE, 82, -1.0, 1.0)
+    bt = TensorHandle.new(b.handle, (batch, k, n), (n * k, 1, k), ElemType.BF16)
+    ref = TensorHandle.new_contiguous((batch, m, n), client.empty(batch * m * n * 2), ElemType.BF16)
+    ops.matmul(client, a, bt, ref, algo=ALGOS["lp256w4"])
+    want = ref.to_numpy(client).copy()
+    c = TensorHandle.new_contiguous((batch, m, n), client.empty(batch * m * n * 2), ElemType.BF16)
+    for _ in range(4):                                                     # the counted waits must hold on every launch
+        client._s.check(client.lib.mi355_memset(client.ctx, None, c.device_ptr(), 0xEE, batch * m * n * 2))
+        ops.matmul(client, a, bt, c, algo=ALGOS["lp256q"])
+        assert np.array_equal(c.to_numpy(client), want)
+
+
+def test_lp256q_oracle_f16_identity_pitched_c_and_refusals(client, oracle):
+    run_case(client, oracle, 512, 768, 512, ElemType.F16, ElemType.F16, True, ALGOS["lp256q"])            # against the oracle itself
+    run_case(client, oracle, 768, 512, 1024, ElemType.BF16, ElemType.BF16, True, ALGOS["lp256q"], batch=3, ldc=520)   # pitched C rows
+    m = n = k = 4352                                                        # I x B^T: every tile of both rounds returns the operand's bits
+    eye = np.zeros((m, k), dtype=np.uint16)
+    eye[np.arange(m), np.arange(m)] = 0x3F80
+    bmat = oracle.to_bf16(oracle.fill_uniform(n * k, 92, -1.0, 1.0)).reshape(n, k)
+    ta, tb = TensorHandle.from_numpy(client, eye, ElemType.BF16), TensorHandle.from_numpy(client, bmat, ElemType.BF16)
+    c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 2), ElemType.BF16)
+    ops.matmul(client, TensorHandle.new(ta.handle, (m, k), (k, 1), ElemType.BF16), TensorHandle.new(tb.handle, (k, n), (1, k), ElemType.BF16),
+               c, algo=ALGOS["lp256q"])
+    assert np.array_equal(c.to_numpy(client).reshape(m, n), bmat.T)
+    for kw in (dict(k=320), dict(out=ElemType.F32), dict(lda=1032)):        # fewer than 6 K-tiles / f32 C / lda != ldb: refused, not mis-run
+        with pytest.raises(ServerError) as e:
+            run_case(client, oracle, 512, 512, kw.get("k", 1024), ElemType.BF16, kw.get("out", ElemType.BF16), True, ALGOS["lp256q"],
+                     **({"lda": kw["lda"]} if "lda" in kw else {}))
+        assert e.value.code == N.E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("algo", ["lp128", "lp256", "lp256w4", "lp256p", "f32"])     # (lp256q: its own bit-identity test above)
 def test_race_screen_bitwise_repeatability(client, oracle, algo):
     # the counted-vmcnt / barrier pipeline must give the same bits on every launch (guide: "place reads by
     # the vmcnt/barrier count, never by clean runs") -- 25 launches at a multi-wave-per-CU size
@@ -497,7 +539,13 @@ def test_auto_selection_and_errors(client):
     # several rounds of short tiles: the persistent form (config C5's shard: 64 x 2048^3); long K or a single round: not
     d = N.GemmDesc(m=2048, n=2048, k=2048, batch=64, lda=2048, ldb=2048, ldc=2048, stride_a=2048 * 2048, stride_b=2048 * 2048,
                    stride_c=2048 * 2048, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_BF16, trans_b=1)
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256P
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256Q            # 16-bit C, K = 32 K-tiles: the dripped-store form of it
+    d.dtype_c = N.DTYPE_F32
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256P            # f32 C cannot be held in registers: the plain persistent form
+    d.dtype_c = N.DTYPE_BF16
+    d.k = d.lda = d.ldb = 640
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256P            # 10 K-tiles: measured slower with dripped stores
+    d.k = d.lda = d.ldb = 2048
     d.batch = 4
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
     d = N.GemmDesc(m=8192 + 8, n=8192, k=8192, batch=1, lda=8192, ldb=8192, ldc=8192, dtype_ab=N.DTYPE_BF16,
