@@ -429,7 +429,8 @@ int32_t mi355_gemm_scaled_select(mi355_ctx *ctx, const mi355_gemm_scaled_desc *d
 /* =================================== Reductions ========================================== */
 
 /* Bytes of device workspace the array-wide reductions need for `n` elements (one partial
- * record per workgroup + a ticket word); caller allocates, library never does. */
+ * record per workgroup + a ticket word); caller allocates, library never does.  `ctx` may be NULL:
+ * the size is a property of the kernels (a client can plan the allocation before it reaches a server). */
 int32_t mi355_reduce_workspace_bytes(mi355_ctx *ctx, uint64_t n, uint64_t *out_bytes);
 
 /* Array-wide f32 sum: out[0] = sum_i in[i].  Semantics: examples/sum_things/src/lib.rs:6-19

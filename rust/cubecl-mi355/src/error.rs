@@ -1,9 +1,10 @@
 //! Status-code conversion.  The C ABI never unwinds; each call returns an `int32` and queued
 //! (asynchronous) launch failures are drained with `mi355_error_pop` when
 //! `MI355_E_SERVER_UNHEALTHY` comes back from flush / sync / read -- the reference's contract in
-//! crates/cubecl-hip/src/compute/server.rs:263-269, :706-714.
+//! crates/cubecl-hip/src/compute/server.rs (`launch` pushes onto the stream's `errors`, `command()` drains them into
+//! `ServerError::ServerUnhealthy`).
 use crate::ffi::*;
-use cubecl_common::backtrace::BackTrace;
+use cubecl_environment::backtrace::BackTrace;
 use cubecl_runtime::server::{IoError, LaunchError, ResourceLimitError, ServerError};
 use std::ffi::CStr;
 
@@ -19,10 +20,10 @@ pub(crate) fn convert(code: i32, requested: u64, max: u64, message: String) -> S
     let bt = BackTrace::capture;
     match code {
         MI355_E_INVALID_ARGUMENT => ServerError::Validation { message, backtrace: bt() },
-        MI355_E_OUT_OF_MEMORY => IoError::OutOfMemory { context: message, backtrace: bt() }.into(),
+        MI355_E_OUT_OF_MEMORY => IoError::OutOfMemory { size: requested, backtrace: bt() }.into(),
         MI355_E_BUFFER_TOO_BIG => IoError::BufferTooBig { size: requested, backtrace: bt() }.into(),
         MI355_E_UNSUPPORTED_STRIDES => IoError::UnsupportedStrides { backtrace: bt() }.into(),
-        MI355_E_NOT_FOUND => IoError::NotFound { backtrace: bt(), reason: message }.into(),
+        MI355_E_NOT_FOUND => IoError::NotFound { backtrace: bt(), reason: message.into() }.into(),
         MI355_E_SHARED_MEMORY => LaunchError::TooManyResources(ResourceLimitError::SharedMemory {
             requested: requested as usize, max: max as usize, backtrace: bt() }).into(),
         MI355_E_UNITS => LaunchError::TooManyResources(ResourceLimitError::Units {
@@ -76,4 +77,12 @@ pub(crate) fn check(ctx: *mut mi355_ctx, rc: i32) -> Result<(), ServerError> {
         errors.push(convert(code, req, max, msg));
     }
     Err(ServerError::ServerUnhealthy { errors, backtrace: BackTrace::capture() })
+}
+
+/// The `IoError` a memory call failed with (anything that is not an IO failure is wrapped, server/base.rs `IoError::Execution`).
+pub(crate) fn io(ctx: *mut mi355_ctx, rc: i32, size: u64) -> IoError {
+    match convert(rc, size, 0, last_message(ctx)) {
+        ServerError::Io(err) => err,
+        other => IoError::Execution(Box::new(other)),
+    }
 }

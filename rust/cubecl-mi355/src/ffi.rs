@@ -186,7 +186,7 @@ pub struct mi355_gemm_desc {
     pub reserved: i32,
 }
 
-unsafe /// mi355_tensor_layout: TensorBinding's shape / strides (elements, outermost axis first).
+/// mi355_tensor_layout: TensorBinding's shape / strides (elements, outermost axis first).
 #[repr(C)]
 #[derive(Clone, Copy, Default)]
 pub struct mi355_tensor_layout {
@@ -196,7 +196,7 @@ pub struct mi355_tensor_layout {
     pub strides: [i64; 8],
 }
 
-extern "C" {
+unsafe extern "C" {
     // Runtime
     pub fn mi355_abi_version() -> i32;
     pub fn mi355_device_count(out_count: *mut i32) -> i32;

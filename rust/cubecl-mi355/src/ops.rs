@@ -1,184 +1,145 @@
-//! The hot-path launchers: what a matmul / reduce front-end (cubek) calls on this backend instead of
-//! expanding `#[cube]` kernels.  Operands are `TensorHandle`s (crates/cubecl-std/src/tensor/handle.rs:13-23):
-//! layout comes from strides alone, classified the way `matrix_batch_layout` does
-//! (crates/cubecl-std/src/tensor/matrix_batch_layout.rs:21-79).
-use crate::{error::check, ffi::*, Mi355Runtime};
-use cubecl_runtime::{client::ComputeClient, server::ServerError};
-use cubecl_std::tensor::{matrix_batch_layout, MatrixBatchLayout, TensorHandle};
+//! The hot-path launchers: what a matmul / reduce front-end calls on this backend instead of expanding `#[cube]`
+//! kernels.  Operands are `TensorHandle`s (cubecl-std/src/tensor/handle.rs); a launch is a `NativeTask` handed to
+//! `ComputeClient::launch` with the operands as buffer bindings, so it is stream-ordered, fire-and-forget and
+//! graph-capturable exactly like any other kernel of the reference (errors surface on the next `flush` / `sync`).
+use crate::{
+    Mi355Runtime,
+    compiler::{GemmKey, NativeOp, ReduceKind},
+    ffi::*,
+    task::NativeTask,
+};
+use cubecl_environment::backtrace::BackTrace;
+use cubecl_ir::{ElemType, FloatKind, IntKind, UIntKind};
+use cubecl_runtime::{
+    client::ComputeClient,
+    server::{CubeCount, Handle, KernelArguments, ServerError},
+};
+use cubecl_std::tensor::{MatrixBatchLayout, TensorHandle, matrix_batch_layout};
 
-fn dtype(t: &TensorHandle<Mi355Runtime>) -> i32 {
-    use cubecl_ir::{ElemType::Float, FloatKind::*};
-    match t.dtype.elem_type() { Float(BF16) => MI355_DTYPE_BF16, Float(F16) => MI355_DTYPE_F16, _ => MI355_DTYPE_F32 }
+type Tensor = TensorHandle<Mi355Runtime>;
+
+fn refuse(message: impl Into<String>) -> ServerError {
+    ServerError::Validation { message: message.into(), backtrace: BackTrace::capture() }
 }
 
-/// (transposed, leading dimension, batch stride) of a [.., rows, cols] operand.
-fn operand(t: &TensorHandle<Mi355Runtime>) -> Result<(bool, i64, i64), ServerError> {
-    let r = t.shape().len();
-    let (rs, cs) = (t.strides()[r - 2] as i64, t.strides()[r - 1] as i64);
-    match matrix_batch_layout(t.strides(), None) {
-        MatrixBatchLayout::HighlyPermuted => Err(ServerError::Validation {
-            message: "operand is HighlyPermuted: call into_contiguous first".into(),
-            backtrace: cubecl_common::backtrace::BackTrace::capture() }),
-        _ => {
-            let bstride = if r > 2 { t.strides()[r - 3] as i64 } else { 0 };
-            Ok(if cs == 1 { (false, rs, bstride) } else { (true, cs, bstride) })
-        }
+fn wire(dtype: ElemType) -> Result<i32, ServerError> {
+    Ok(match dtype {
+        ElemType::Float(FloatKind::F32) => MI355_DTYPE_F32,
+        ElemType::Float(FloatKind::BF16) => MI355_DTYPE_BF16,
+        ElemType::Float(FloatKind::F16) => MI355_DTYPE_F16,
+        ElemType::Float(FloatKind::E4M3) => MI355_DTYPE_F8E4M3,
+        ElemType::Float(FloatKind::E5M2) => MI355_DTYPE_F8E5M2,
+        ElemType::Int(IntKind::I32) => MI355_DTYPE_I32,
+        ElemType::UInt(UIntKind::U32) => MI355_DTYPE_U32,
+        other => return Err(refuse(format!("{other:?} is not an operand type of the native kernels"))),
+    })
+}
+
+/// `(transposed, leading dimension, batch stride)` of a `[.., rows, cols]` operand, read from its strides alone.
+fn operand(t: &Tensor) -> Result<(bool, i64, i64), ServerError> {
+    let rank = t.shape().len();
+    if rank < 2 {
+        return Err(refuse("a matmul operand needs at least two axes"));
     }
-}
-
-/// out[.., m, n] = sum_k lhs[.., m, k] * rhs[.., k, n], f32 accumulate (cmma::execute semantics,
-/// crates/cubecl-core/src/frontend/cmma.rs:1066-1110).  Stream-ordered, fire-and-forget like `launch`.
-pub fn matmul(client: &ComputeClient<Mi355Runtime>, lhs: &TensorHandle<Mi355Runtime>, rhs: &TensorHandle<Mi355Runtime>,
-              out: &TensorHandle<Mi355Runtime>) -> Result<(), ServerError> {
-    let r = out.shape().len();
-    let (m, n, k) = (out.shape()[r - 2] as i64, out.shape()[r - 1] as i64, lhs.shape()[lhs.shape().len() - 1] as i64);
-    let batch: i64 = out.shape()[..r - 2].iter().map(|d| *d as i64).product();
-    let (ta, lda, sa) = operand(lhs)?;
-    let (tb, ldb, sb) = operand(rhs)?;
-    let (_, ldc, sc) = operand(out)?;
-    let desc = mi355_gemm_desc { m, n, k, batch, lda, ldb, ldc, stride_a: sa, stride_b: sb, stride_c: sc,
-                                 dtype_ab: dtype(lhs), dtype_c: dtype(out), trans_a: ta as i32, trans_b: tb as i32,
-                                 algo: 0, reserved: 0 };
-    let (a, b, c) = (lhs.handle.clone().binding(), rhs.handle.clone().binding(), out.handle.clone().binding());
-    client.with_server(move |server, stream| {     // runs on the device's runner thread
-        let (pa, pb, pc) = (server.get_resource(a, stream)?, server.get_resource(b, stream)?, server.get_resource(c, stream)?);
-        check(server.ctx, unsafe { mi355_gemm(server.ctx, core::ptr::null_mut(), &desc, pa.resource().ptr, pb.resource().ptr,
-                                              pc.resource().ptr) })
-    })
-}
-
-/// Array-wide f32 sum into out[0]; deterministic tree, one launch.
-pub fn reduce_sum(client: &ComputeClient<Mi355Runtime>, input: &TensorHandle<Mi355Runtime>,
-                  out: &TensorHandle<Mi355Runtime>) -> Result<(), ServerError> {
-    let n: u64 = input.shape().iter().map(|d| *d as u64).product();
-    let ws = client.empty(workspace_bytes(client, n)? as usize);
-    let (i, o, w) = (input.handle.clone().binding(), out.handle.clone().binding(), ws.clone().binding());
-    client.with_server(move |server, stream| {
-        let (pi, po, pw) = (server.get_resource(i, stream)?, server.get_resource(o, stream)?, server.get_resource(w, stream)?);
-        check(server.ctx, unsafe { mi355_reduce_sum_f32(server.ctx, core::ptr::null_mut(), pi.resource().ptr as _, n,
-                                                        po.resource().ptr as _, pw.resource().ptr, pw.resource().size) })
-    })
-}
-
-/// Array-wide argmax: out_index[0] (u64) = lowest index of the maximum; NaN ranks highest, -0 == +0.
-pub fn argmax(client: &ComputeClient<Mi355Runtime>, input: &TensorHandle<Mi355Runtime>,
-              out_index: &TensorHandle<Mi355Runtime>) -> Result<(), ServerError> {
-    let n: u64 = input.shape().iter().map(|d| *d as u64).product();
-    let ws = client.empty(workspace_bytes(client, n)? as usize);
-    let (i, o, w) = (input.handle.clone().binding(), out_index.handle.clone().binding(), ws.clone().binding());
-    client.with_server(move |server, stream| {
-        let (pi, po, pw) = (server.get_resource(i, stream)?, server.get_resource(o, stream)?, server.get_resource(w, stream)?);
-        check(server.ctx, unsafe { mi355_argmax_f32(server.ctx, core::ptr::null_mut(), pi.resource().ptr as _, n,
-                                                    core::ptr::null_mut(), po.resource().ptr as _, pw.resource().ptr,
-                                                    pw.resource().size) })
-    })
-}
-
-/// out = lhs * rhs + acc, formed in f32 and rounded once (the C operand of `cmma::execute`,
-/// crates/cubecl-core/src/frontend/cmma.rs:1066-1110).  `acc` has out's shape, strides and dtype and may be `out`.
-pub fn matmul_add(client: &ComputeClient<Mi355Runtime>, lhs: &TensorHandle<Mi355Runtime>, rhs: &TensorHandle<Mi355Runtime>,
-                  acc: &TensorHandle<Mi355Runtime>, out: &TensorHandle<Mi355Runtime>) -> Result<(), ServerError> {
-    let r = out.shape().len();
-    let (m, n, k) = (out.shape()[r - 2] as i64, out.shape()[r - 1] as i64, lhs.shape()[lhs.shape().len() - 1] as i64);
-    let batch: i64 = out.shape()[..r - 2].iter().map(|d| *d as i64).product();
-    let (ta, lda, sa) = operand(lhs)?;
-    let (tb, ldb, sb) = operand(rhs)?;
-    let (_, ldc, sc) = operand(out)?;
-    if acc.shape() != out.shape() || acc.strides() != out.strides() || dtype(acc) != dtype(out) {
-        return Err(ServerError::Validation { message: "accumulator must have the output's shape, strides and dtype".into(),
-                                             backtrace: cubecl_common::backtrace::BackTrace::capture() });
+    if matches!(matrix_batch_layout(t.strides(), None), MatrixBatchLayout::HighlyPermuted) {
+        return Err(refuse("operand is HighlyPermuted: make it contiguous first"));
     }
-    let desc = mi355_gemm_desc { m, n, k, batch, lda, ldb, ldc, stride_a: sa, stride_b: sb, stride_c: sc,
-                                 dtype_ab: dtype(lhs), dtype_c: dtype(out), trans_a: ta as i32, trans_b: tb as i32,
-                                 algo: 0, reserved: 0 };
-    let (a, b, c, d) = (lhs.handle.clone().binding(), rhs.handle.clone().binding(), acc.handle.clone().binding(),
-                        out.handle.clone().binding());
-    client.with_server(move |server, stream| {
-        let (pa, pb) = (server.get_resource(a, stream)?, server.get_resource(b, stream)?);
-        let (pc, pd) = (server.get_resource(c, stream)?, server.get_resource(d, stream)?);
-        check(server.ctx, unsafe { mi355_gemm_add(server.ctx, core::ptr::null_mut(), &desc, pa.resource().ptr, pb.resource().ptr,
-                                                  pc.resource().ptr, pd.resource().ptr) })
-    })
+    let (row, col) = (t.strides()[rank - 2] as i64, t.strides()[rank - 1] as i64);
+    let batch = if rank > 2 { t.strides()[rank - 3] as i64 } else { 0 };
+    Ok(if col == 1 { (false, row, batch) } else { (true, col, batch) })
 }
 
-/// Array-wide sum AND argmax in one pass over the data (config C4's local step): out_sum[0] f32, out_index[0] u64.
-pub fn sum_argmax(client: &ComputeClient<Mi355Runtime>, input: &TensorHandle<Mi355Runtime>, out_sum: &TensorHandle<Mi355Runtime>,
-                  out_index: &TensorHandle<Mi355Runtime>) -> Result<(), ServerError> {
-    let n: u64 = input.shape().iter().map(|d| *d as u64).product();
-    let dt = dtype(input);
-    let ws = client.empty(workspace_bytes(client, n)? as usize);
-    let (i, s, o, w) = (input.handle.clone().binding(), out_sum.handle.clone().binding(), out_index.handle.clone().binding(),
-                        ws.clone().binding());
-    client.with_server(move |server, stream| {
-        let (pi, ps) = (server.get_resource(i, stream)?, server.get_resource(s, stream)?);
-        let (po, pw) = (server.get_resource(o, stream)?, server.get_resource(w, stream)?);
-        check(server.ctx, unsafe { mi355_sum_argmax(server.ctx, core::ptr::null_mut(), pi.resource().ptr, dt, n, ps.resource().ptr as _,
-                                                    core::ptr::null_mut(), po.resource().ptr as _, pw.resource().ptr,
-                                                    pw.resource().size) })
-    })
+fn buffers(handles: &[&Handle]) -> KernelArguments {
+    KernelArguments::new().with_buffers(handles.iter().map(|h| (*h).clone().binding()).collect())
 }
 
-/// Sum over one axis of a contiguous tensor (the book's `reduce_matrix` generalised, cubecl-book getting-started
-/// v4-gpu.rs:47-70): out has the input's shape without `axis`, f32.
-pub fn reduce_sum_axis(client: &ComputeClient<Mi355Runtime>, input: &TensorHandle<Mi355Runtime>, out: &TensorHandle<Mi355Runtime>,
-                       axis: usize) -> Result<(), ServerError> {
-    let shape = input.shape();
-    let outer: u64 = shape[..axis].iter().map(|d| *d as u64).product();
-    let (reduce, inner): (u64, u64) = (shape[axis] as u64, shape[axis + 1..].iter().map(|d| *d as u64).product());
-    let dt = dtype(input);
-    let (i, o) = (input.handle.clone().binding(), out.handle.clone().binding());
-    client.with_server(move |server, stream| {
-        let (pi, po) = (server.get_resource(i, stream)?, server.get_resource(o, stream)?);
-        check(server.ctx, unsafe { mi355_reduce_axis_sum(server.ctx, core::ptr::null_mut(), pi.resource().ptr, dt,
-                                                         po.resource().ptr as _, outer, reduce, inner) })
-    })
-}
-
-fn layout(t: &TensorHandle<Mi355Runtime>) -> mi355_tensor_layout {
-    let mut l = mi355_tensor_layout { rank: t.shape().len() as i32, reserved: 0, shape: [0; 8], strides: [0; 8] };
-    for (d, (n, s)) in t.shape().iter().zip(t.strides().iter()).enumerate() {
-        l.shape[d] = *n as i64;
-        l.strides[d] = *s as i64;
+/// `out[.., m, n] = sum_k lhs[.., m, k] * rhs[.., k, n]`, f32 accumulation (`mi355_gemm`).
+pub fn matmul(client: &ComputeClient<Mi355Runtime>, lhs: &Tensor, rhs: &Tensor, out: &Tensor) -> Result<(), ServerError> {
+    let rank = out.shape().len();
+    let (trans_a, lda, stride_a) = operand(lhs)?;
+    let (trans_b, ldb, stride_b) = operand(rhs)?;
+    let (trans_c, ldc, stride_c) = operand(out)?;
+    if trans_c {
+        return Err(refuse("the output of a matmul must be row-major"));
     }
-    l
+    let key = GemmKey {
+        m: out.shape()[rank - 2] as i64,
+        n: out.shape()[rank - 1] as i64,
+        k: lhs.shape()[lhs.shape().len() - 1] as i64,
+        batch: out.shape()[..rank - 2].iter().map(|d| *d as i64).product(),
+        lda,
+        ldb,
+        ldc,
+        stride_a,
+        stride_b,
+        stride_c,
+        dtype_ab: wire(lhs.dtype)?,
+        dtype_c: wire(out.dtype)?,
+        trans_a,
+        trans_b,
+    };
+    client.launch(Box::new(NativeTask::gemm(key)), CubeCount::new_single(), buffers(&[&lhs.handle, &rhs.handle, &out.handle]));
+    Ok(())
 }
 
-/// `copy_into` (crates/cubecl-std/src/tensor/contiguous/base.rs): output[idx] = input[idx] for two views of one shape;
-/// the library picks the mover (flat, rows, LDS-transposed tiles, packed gather / scatter) from the two layouts.
-pub fn copy_into(client: &ComputeClient<Mi355Runtime>, input: &TensorHandle<Mi355Runtime>,
-                 output: &TensorHandle<Mi355Runtime>) -> Result<(), ServerError> {
-    let (li, lo, esz) = (layout(input), layout(output), input.dtype.size() as i32);
-    let (i, o) = (input.handle.clone().binding(), output.handle.clone().binding());
-    client.with_server(move |server, stream| {
-        let (pi, po) = (server.get_resource(i, stream)?, server.get_resource(o, stream)?);
-        check(server.ctx, unsafe { mi355_copy_strided(server.ctx, core::ptr::null_mut(), pi.resource().ptr, &li, po.resource().ptr,
-                                                      &lo, esz) })
-    })
+fn whole(kind: ReduceKind, input: &Tensor) -> Result<(NativeTask, u64), ServerError> {
+    let n: u64 = input.shape().iter().map(|d| *d as u64).product();
+    let op = NativeOp::Reduce { kind, dtype: wire(input.dtype)?, rows: 1, cols: n, row_stride: n };
+    Ok((NativeTask { op }, n))
 }
 
-/// `into_contiguous`: a fresh row-major tensor with the input's values (what a matmul front-end calls on a
-/// `MatrixBatchLayout::HighlyPermuted` operand before `matmul`).
-pub fn into_contiguous(client: &ComputeClient<Mi355Runtime>, input: &TensorHandle<Mi355Runtime>)
-                       -> Result<TensorHandle<Mi355Runtime>, ServerError> {
-    let n: usize = input.shape().iter().product();
-    let out = TensorHandle::new_contiguous(input.shape().clone(), client.empty(n * input.dtype.size()), input.dtype);
-    copy_into(client, input, &out)?;
-    Ok(out)
+/// Scratch the whole-buffer reductions need (`mi355_reduce_workspace_bytes`: a function of `n` only).
+fn workspace(client: &ComputeClient<Mi355Runtime>, n: u64) -> Result<Handle, ServerError> {
+    let mut bytes = 0u64;
+    // no context needed for the size query: the layout of the partials is fixed by the kernel, not by the device
+    crate::error::check(core::ptr::null_mut(), unsafe { mi355_reduce_workspace_bytes(core::ptr::null_mut(), n, &mut bytes) })?;
+    Ok(client.empty(bytes as usize))
 }
 
-/// `tensor::identity::launch` (crates/cubecl-std/src/tensor/identity.rs:36-86) on a [dim, dim] tensor with unit column stride.
-pub fn identity(client: &ComputeClient<Mi355Runtime>, output: &TensorHandle<Mi355Runtime>) -> Result<(), ServerError> {
-    let (dim, ld, dt) = (output.shape()[0] as u64, output.strides()[0] as u64, dtype(output));
-    let o = output.handle.clone().binding();
-    client.with_server(move |server, stream| {
-        let po = server.get_resource(o, stream)?;
-        check(server.ctx, unsafe { mi355_fill_identity(server.ctx, core::ptr::null_mut(), po.resource().ptr, dt, dim, ld) })
-    })
+/// Sum of every element into `out[0]` (f32), one deterministic tree (`mi355_reduce_sum`).
+pub fn reduce_sum(client: &ComputeClient<Mi355Runtime>, input: &Tensor, out: &Tensor) -> Result<(), ServerError> {
+    let (task, n) = whole(ReduceKind::Sum, input)?;
+    let scratch = workspace(client, n)?;
+    client.launch(Box::new(task), CubeCount::new_single(), buffers(&[&input.handle, &out.handle, &scratch]));
+    Ok(())
 }
 
-fn workspace_bytes(client: &ComputeClient<Mi355Runtime>, n: u64) -> Result<u64, ServerError> {
-    client.with_server(move |server, _| {
-        let mut bytes = 0u64;
-        check(server.ctx, unsafe { mi355_reduce_workspace_bytes(server.ctx, n, &mut bytes) }).map(|_| bytes)
-    })
+/// Value (f32) and index (u64) of the first maximum (`mi355_argmax`; ties go to the lowest index, NaN never wins).
+pub fn argmax(client: &ComputeClient<Mi355Runtime>, input: &Tensor, out_value: &Tensor, out_index: &Tensor) -> Result<(), ServerError> {
+    let (task, n) = whole(ReduceKind::Argmax, input)?;
+    let scratch = workspace(client, n)?;
+    client.launch(Box::new(task), CubeCount::new_single(), buffers(&[&input.handle, &out_value.handle, &out_index.handle, &scratch]));
+    Ok(())
+}
+
+/// Both of the above in one pass over the input (`mi355_sum_argmax`).
+pub fn sum_argmax(client: &ComputeClient<Mi355Runtime>, input: &Tensor, out_sum: &Tensor, out_value: &Tensor, out_index: &Tensor) -> Result<(), ServerError> {
+    let (task, n) = whole(ReduceKind::SumArgmax, input)?;
+    let scratch = workspace(client, n)?;
+    client.launch(Box::new(task), CubeCount::new_single(),
+                  buffers(&[&input.handle, &out_sum.handle, &out_value.handle, &out_index.handle, &scratch]));
+    Ok(())
+}
+
+/// Per-row sum of a `[rows, cols]` tensor with unit column stride (`mi355_reduce_last_axis_sum`).
+pub fn reduce_sum_rows(client: &ComputeClient<Mi355Runtime>, input: &Tensor, out: &Tensor) -> Result<(), ServerError> {
+    rows(client, ReduceKind::RowSum, input, out)
+}
+
+/// Per-row arg-max (u32 indices) (`mi355_reduce_last_axis_argmax`).
+pub fn argmax_rows(client: &ComputeClient<Mi355Runtime>, input: &Tensor, out: &Tensor) -> Result<(), ServerError> {
+    rows(client, ReduceKind::RowArgmax, input, out)
+}
+
+fn rows(client: &ComputeClient<Mi355Runtime>, kind: ReduceKind, input: &Tensor, out: &Tensor) -> Result<(), ServerError> {
+    let rank = input.shape().len();
+    if rank < 1 || input.strides()[rank - 1] != 1 {
+        return Err(refuse("row reductions need a unit stride on the reduced axis"));
+    }
+    let cols = input.shape()[rank - 1] as u64;
+    let rows: u64 = input.shape()[..rank - 1].iter().map(|d| *d as u64).product();
+    let row_stride = if rank > 1 { input.strides()[rank - 2] as u64 } else { cols };
+    let op = NativeOp::Reduce { kind, dtype: wire(input.dtype)?, rows, cols, row_stride };
+    client.launch(Box::new(NativeTask { op }), CubeCount::new_single(), buffers(&[&input.handle, &out.handle]));
+    Ok(())
 }

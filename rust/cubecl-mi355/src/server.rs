@@ -1,99 +1,487 @@
-//! `Mi355Server`: the `ComputeServer` + `ServerCommunication` implementation.  One instance per
-//! `DeviceId`, created on that device's runner thread by `DeviceService::init`
-//! (crates/cubecl-common/src/device/handle/channel.rs:55-66) and only ever touched from it -- the
-//! single-thread-per-context contract of the C ABI.
+//! `Mi355Server`: `ComputeServer` (cubecl-runtime/src/server/base.rs `pub trait ComputeServer`) over the C ABI.
 //!
-//! Memory management (pools, handles, pending drops) is the reference's own
-//! `MemoryManagement<Mi355Storage>`; only the storage and the device operations are replaced.
-use crate::error::check;
-use crate::ffi::*;
-use crate::storage::{Mi355Resource, Mi355Storage};
-use cubecl_common::{bytes::Bytes, device::DeviceId, future::DynFut, profile::ProfileDuration, stream_id::StreamId};
-use cubecl_ir::ElemType;
-use cubecl_runtime::memory_management::{MemoryAllocationMode, MemoryManagement, MemoryUsage, ManagedMemoryHandle};
-use cubecl_runtime::server::*;
-use cubecl_runtime::storage::ManagedResource;
-use std::collections::HashMap;
-use std::sync::Arc;
+//! Memory is the reference's: every lane owns a `MemoryManagement` pool (`reserve` -> `bind` -> `get_resource`) on top
+//! of the storages in [`crate::storage`].  Ordering is the reference's too: every call starts with
+//! `MultiStream::resolve(stream_id, bindings, ..)`, which inserts the cross-lane waits, and then works on the resolved
+//! lane's `mi355_stream`.  What is this crate's own is the last step of each operation: a call into `libmi355cube.so`.
+use crate::{
+    comm,
+    compiler::{Mi355Compiler, Mi355Kernel, NativeOp, ReduceKind},
+    error,
+    ffi::*,
+    lane::LaneBackend,
+    program::{self, Program},
+    storage::{DeviceSlice, DeviceStorage, PinnedBytes},
+};
+use cubecl_common::{bytes::Bytes, device::DeviceId, profile::ProfileDuration};
+use cubecl_cpp::shared::CompilationOptions;
+use cubecl_environment::{backtrace::BackTrace, future::DynFut, stream::StreamId};
+use cubecl_ir::MemoryDeviceProperties;
+use cubecl_runtime::{
+    allocator::PitchedMemoryLayoutPolicy,
+    compiler::CubeTask,
+    config::{CubeClRuntimeConfig, RuntimeConfig},
+    dry_run::LaunchMode,
+    id::{GraphId, KernelId},
+    kernel::KernelMetadata,
+    logging::ServerLogger,
+    memory_management::{
+        InstallMemoryPoolsError, ManagedMemoryHandle, MemoryAllocationMode, MemoryConfiguration, MemoryHandle, MemoryReport,
+        MemoryUsage,
+    },
+    server::{
+        BufferBinding, CommunicationId, ComputeServer, CopyDescriptor, CubeCount, Handle, IoError, KernelArguments,
+        KernelResource, LaunchError, ProfileError, ProfilingToken, ServerError, ServerUtilities,
+    },
+    storage::{ComputeStorage, ManagedResource},
+    stream::{MultiStream, ResolvedStreams},
+    timestamp_profiler::TimestampProfiler,
+    validation::{validate_cube_dim, validate_units},
+};
+use cubecl_zspace::{Shape, Strides, striding::has_pitched_row_major_strides};
+use std::{collections::HashMap, sync::Arc};
 
-/// A kernel this server can launch: either a code object the caller brought (hand-written or
-/// produced elsewhere) addressed by symbol name, launched through the reference's pointer-array
-/// ABI (crates/cubecl-cpp/src/hip/signature.rs:28-62), or nothing at all for the library ops in
-/// `ops.rs`, which do not go through `launch`.
-pub struct ExternalKernel {
-    pub image: Arc<Vec<u8>>,
-    pub entry: std::ffi::CString,
-    pub cube_dim: CubeDim,
-    pub shared_mem_bytes: u32,
+/// Uploads above this size skip the pinned bounce buffer when the caller's bytes are not already pinned.
+const STAGE_LIMIT: usize = 100 << 20;
+/// Uploads above this size release their staging buffer at once instead of waiting for the queue to fill.
+const EAGER_RELEASE: usize = 10 << 20;
+
+/// What a `KernelId` resolved to the first time it was launched.
+#[derive(Debug, Clone, Copy)]
+enum Loaded {
+    Native(NativeOp),
+    Jit(Program),
 }
 
+/// A captured `mi355_graph` and the pool slices it pins for as long as it can be replayed.
+#[derive(Debug)]
+struct CapturedGraph {
+    raw: *mut mi355_graph,
+    _pinned: Vec<ManagedMemoryHandle>,
+}
+
+#[derive(Debug)]
 pub struct Mi355Server {
     pub(crate) ctx: *mut mi355_ctx,
-    pub(crate) props: mi355_device_props_t,
-    device: DeviceId,
-    memory: MemoryManagement<Mi355Storage>,
-    comms: HashMap<CommunicationId, (*mut mi355_comm, Vec<DeviceId>)>,
-    modules: HashMap<usize, (mi355_module, HashMap<std::ffi::CString, mi355_function>)>,
-    utilities: Arc<ServerUtilities<Self>>,
+    pub(crate) device_id: DeviceId,
+    pub(crate) lanes: MultiStream<LaneBackend>,
+    compiler: Mi355Compiler,
+    options: CompilationOptions,
+    kernels: HashMap<KernelId, Loaded>,
+    timestamps: TimestampProfiler,
+    graphs: HashMap<GraphId, CapturedGraph>,
+    pub(crate) communicators: HashMap<CommunicationId, *mut mi355_comm>,
+    pub(crate) utilities: Arc<ServerUtilities<Self>>,
+    /// Declared last on purpose: fields drop in order, and the lanes above still need the context to destroy their streams.
+    _context: ContextGuard,
 }
-unsafe impl Send for Mi355Server {} // moved once onto the runner thread, never shared (server.rs:163-167)
+unsafe impl Send for Mi355Server {}
+
+/// Destroys the `mi355_ctx` (its modules, its cached pages, its streams) when the server goes away.
+#[derive(Debug)]
+struct ContextGuard(*mut mi355_ctx);
+
+impl Drop for ContextGuard {
+    fn drop(&mut self) {
+        unsafe { mi355_ctx_destroy(self.0) };
+    }
+}
+
+/// How a call treats errors earlier asynchronous launches left on the lane.
+#[derive(Clone, Copy, PartialEq, Eq)]
+pub(crate) enum Pending {
+    /// Report them now (`ServerUnhealthy`) and refuse to go on: reads, syncs, flushes.
+    Surface,
+    /// Leave them queued: launches and writes are fire-and-forget and must not lose an error to a later call.
+    Keep,
+}
+
+/// One resolved call: the lanes `MultiStream` aligned for it.  Dropping it hands cross-lane pins to the GC thread.
+pub(crate) struct Pass<'a> {
+    ctx: *mut mi355_ctx,
+    pub(crate) lanes: ResolvedStreams<'a, LaneBackend>,
+}
+
+impl<'a> Pass<'a> {
+    pub(crate) fn sys(&mut self) -> mi355_stream {
+        self.lanes.current().sys
+    }
+
+    /// Device pointer + length behind a binding, looked up in the pool of the lane that created it.
+    pub(crate) fn slice(&mut self, binding: BufferBinding) -> Result<DeviceSlice, IoError> {
+        self.lanes.get(&binding.stream).memory_management_gpu.get_resource(binding.memory, binding.offset_start, binding.offset_end)
+    }
+
+    fn reserve(&mut self, size: u64) -> Result<ManagedMemoryHandle, IoError> {
+        match self.lanes.current().memory_management_gpu.reserve(size) {
+            Err(IoError::OutOfMemory { .. }) | Err(IoError::PoolCapacityExceeded { .. }) => {
+                // give cached pages back to the driver once, then ask again
+                self.cleanup();
+                self.lanes.current().memory_management_gpu.reserve(size)
+            }
+            other => other,
+        }
+    }
+
+    /// Ties the freshly reserved slice to the handle the client already holds, stamped with this call's cursor so that
+    /// another lane can tell whether it has waited for it.
+    fn bind(&mut self, reserved: ManagedMemoryHandle, handle: ManagedMemoryHandle) -> Result<(), IoError> {
+        let cursor = self.lanes.cursor;
+        self.lanes.current().memory_management_gpu.bind(reserved, handle, cursor)
+    }
+
+    fn empty(&mut self, size: u64) -> Result<Handle, IoError> {
+        let handle = Handle::new(self.lanes.current, size);
+        let reserved = self.reserve(size)?;
+        self.bind(reserved, handle.memory.clone())?;
+        Ok(handle)
+    }
+
+    /// Page-locked bytes from the pinned pool of `origin` (or of the current lane); `None` when that pool is exhausted.
+    fn pinned(&mut self, size: usize, origin: Option<StreamId>) -> Option<Bytes> {
+        let lane = match origin {
+            Some(id) => self.lanes.get(&id),
+            None => self.lanes.current(),
+        };
+        let reserved = lane.memory_management_cpu.reserve(size as u64).ok()?;
+        let binding = MemoryHandle::binding(reserved);
+        let slice = lane.memory_management_cpu.get_resource(binding.clone(), None, None).ok()?;
+        Some(unsafe { Bytes::from_controller(Box::new(PinnedBytes::new(binding, slice)), size) })
+    }
+
+    fn host_bytes(&mut self, size: usize, want_pinned: bool) -> Bytes {
+        if !want_pinned && size > STAGE_LIMIT {
+            return Bytes::from_bytes_vec(vec![0; size]);
+        }
+        self.pinned(size, None).unwrap_or_else(|| Bytes::from_bytes_vec(vec![0; size]))
+    }
+
+    fn cleanup(&mut self) {
+        let lane = self.lanes.current();
+        lane.release_staging();
+        lane.release_staging();
+        if !lane.capturing.is_recording() {
+            lane.info_cache.clear_unpinned();
+        }
+        lane.memory_management_gpu.cleanup(true);
+        lane.memory_management_cpu.cleanup(true);
+    }
+
+    /// Host -> device, contiguous or row-pitched (`mi355_write` / `mi355_write_2d`), asynchronous on the lane's stream.
+    fn upload(&mut self, descriptor: CopyDescriptor, data: Bytes) -> Result<(), IoError> {
+        let CopyDescriptor { handle, shape, strides, elem_size } = descriptor;
+        if !has_pitched_row_major_strides(&shape, &strides) {
+            return Err(IoError::UnsupportedStrides { backtrace: BackTrace::capture() });
+        }
+        let target = self.slice(handle)?;
+        let size = data.len();
+        if size == 0 {
+            return Ok(());
+        }
+        let already_pinned = matches!(data.property(), cubecl_common::bytes::AllocationProperty::Pinned);
+        let data = if !already_pinned && size < STAGE_LIMIT {
+            match self.pinned(size, None) {
+                Some(mut bounce) => {
+                    data.copy_into(&mut bounce);
+                    bounce
+                }
+                None => data,
+            }
+        } else {
+            data
+        };
+        let lane = self.lanes.current();
+        let rc = match pitch_of(&shape, &strides, elem_size) {
+            None => unsafe { mi355_write(self.ctx, lane.sys, target.ptr, data.as_ptr() as *const core::ffi::c_void, size as u64) },
+            Some((width, rows, pitch)) => unsafe {
+                mi355_write_2d(self.ctx, lane.sys, target.ptr, pitch, data.as_ptr() as *const core::ffi::c_void, width, width, rows)
+            },
+        };
+        if rc != MI355_OK {
+            return Err(error::io(self.ctx, rc, size as u64));
+        }
+        // the copy reads `data` after this call returns: park it until a fence behind the copy has been seen
+        lane.drop_queue.push(data);
+        if size > EAGER_RELEASE || lane.drop_queue.should_flush() {
+            lane.release_staging();
+        }
+        Ok(())
+    }
+
+    /// Device -> host into fresh (pinned when possible) bytes; the copy is only enqueued, see `read`.
+    fn download(&mut self, descriptor: CopyDescriptor) -> Result<Bytes, IoError> {
+        let CopyDescriptor { handle, shape, strides, elem_size } = descriptor;
+        if !has_pitched_row_major_strides(&shape, &strides) {
+            return Err(IoError::UnsupportedStrides { backtrace: BackTrace::capture() });
+        }
+        let size = shape.iter().product::<usize>() * elem_size;
+        let mut bytes = self.host_bytes(size, true);
+        if size == 0 {
+            return Ok(bytes);
+        }
+        let source = self.slice(handle)?;
+        let sys = self.sys();
+        let rc = match pitch_of(&shape, &strides, elem_size) {
+            None => unsafe { mi355_read_async(self.ctx, sys, bytes.as_mut_ptr() as *mut core::ffi::c_void, source.ptr, size as u64) },
+            Some((width, rows, pitch)) => unsafe {
+                mi355_read_2d(self.ctx, sys, bytes.as_mut_ptr() as *mut core::ffi::c_void, width, source.ptr, pitch, width, rows)
+            },
+        };
+        match rc {
+            MI355_OK => Ok(bytes),
+            rc => Err(error::io(self.ctx, rc, size as u64)),
+        }
+    }
+
+    /// The metadata words of a launch as a device buffer: staged through the pinned pool, copied on the lane's stream,
+    /// and remembered per lane so that a steady-state loop (and a captured graph) re-uses one buffer per distinct payload.
+    fn info_buffer(&mut self, words: Vec<u64>) -> Result<Handle, ServerError> {
+        let size = core::mem::size_of_val(words.as_slice());
+        let lane = self.lanes.current();
+        let mode = lane.capturing.cache_mode();
+        lane.info_cache.mode(mode);
+        let cacheable = lane.info_cache.should_cache(size);
+        if cacheable && let Some(hit) = lane.info_cache.get(&words) {
+            return Ok(hit);
+        }
+        let raw: &[u8] = bytemuck::cast_slice(&words);
+        let mut staging = self.pinned(raw.len(), None).ok_or_else(|| IoError::Unknown {
+            description: "the pinned pool could not stage the launch metadata".into(),
+            backtrace: BackTrace::capture(),
+        })?;
+        staging.copy_from_slice(raw);
+        let handle = self.empty(raw.len() as u64)?;
+        self.upload(CopyDescriptor::new(handle.clone().binding(), [raw.len()].into(), [1].into(), 1), staging)?;
+        if cacheable {
+            self.lanes.current().info_cache.insert(words, handle.clone());
+        }
+        Ok(handle)
+    }
+}
+
+/// `(row bytes, rows, pitch bytes)` when the innermost rows are padded, `None` for a contiguous buffer.
+fn pitch_of(shape: &Shape, strides: &Strides, elem_size: usize) -> Option<(u64, u64, u64)> {
+    let rank = shape.len();
+    if rank < 2 || strides[rank - 2] == shape[rank - 1] {
+        return None;
+    }
+    let rows: usize = shape.iter().rev().skip(1).product();
+    Some(((shape[rank - 1] * elem_size) as u64, rows as u64, (strides[rank - 2] * elem_size) as u64))
+}
 
 impl Mi355Server {
-    fn resource(&mut self, binding: BufferBinding, stream_id: StreamId) -> Result<Mi355Resource, ServerError> {
-        Ok(*self.get_resource(binding, stream_id)?.resource())
+    pub(crate) fn new(ctx: *mut mi355_ctx, device_id: DeviceId, mem_props: MemoryDeviceProperties, mem_config: MemoryConfiguration,
+                      options: CompilationOptions, utilities: ServerUtilities<Self>) -> Self {
+        let max_streams = CubeClRuntimeConfig::get().streaming.max_streams;
+        let logger = utilities.logger.clone();
+        Self {
+            ctx,
+            device_id,
+            lanes: MultiStream::new(logger.clone(), LaneBackend::new(ctx, mem_props, mem_config, logger), max_streams),
+            compiler: Mi355Compiler::default(),
+            options,
+            kernels: HashMap::new(),
+            timestamps: TimestampProfiler::default(),
+            graphs: HashMap::new(),
+            communicators: HashMap::new(),
+            utilities: Arc::new(utilities),
+            _context: ContextGuard(ctx),
+        }
     }
 
-    fn dtype_code(dtype: ElemType) -> Result<i32, ServerError> {
-        use cubecl_ir::{FloatKind::*, IntKind::*, UIntKind::*};
-        Ok(match dtype {
-            ElemType::Float(F32) => MI355_DTYPE_F32,
-            ElemType::Float(BF16) => MI355_DTYPE_BF16,
-            ElemType::Float(F16) => MI355_DTYPE_F16,
-            ElemType::Float(F64) => MI355_DTYPE_F64,
-            ElemType::Int(I32) => MI355_DTYPE_I32,
-            ElemType::UInt(U32) => MI355_DTYPE_U32,
-            ElemType::Int(I64) => MI355_DTYPE_I64,
-            ElemType::UInt(U64) => MI355_DTYPE_U64,
-            ElemType::UInt(U8) => MI355_DTYPE_U8,
-            ElemType::Int(I8) => MI355_DTYPE_I8,
-            other => return Err(ServerError::Generic {
-                reason: format!("collective on unsupported element type {other:?}"),
-                backtrace: cubecl_common::backtrace::BackTrace::capture() }),
-        })
+    pub(crate) fn pass<'a>(&mut self, stream_id: StreamId, bindings: impl Iterator<Item = &'a BufferBinding>, pending: Pending) -> Result<Pass<'_>, ServerError> {
+        if pending == Pending::Surface {
+            let errors = self.take_errors(stream_id);
+            if !errors.is_empty() {
+                return Err(ServerError::ServerUnhealthy { errors, backtrace: BackTrace::capture() });
+            }
+        }
+        let lanes = self.lanes.resolve(stream_id, bindings, pending == Pending::Surface)?;
+        Ok(Pass { ctx: self.ctx, lanes })
+    }
+
+    pub(crate) fn pass_alone(&mut self, stream_id: StreamId, pending: Pending) -> Result<Pass<'_>, ServerError> {
+        self.pass(stream_id, [].into_iter(), pending)
+    }
+
+    /// Errors queued on the lane by earlier launches, plus whatever the library queued itself (`mi355_error_pop`).
+    fn take_errors(&mut self, stream_id: StreamId) -> Vec<ServerError> {
+        let Ok(mut lanes) = self.lanes.resolve(stream_id, [].into_iter(), false) else {
+            return Vec::new();
+        };
+        let lane = lanes.current();
+        let mut errors = core::mem::take(&mut lane.errors);
+        let mut queued = 0i32;
+        if unsafe { mi355_error_count(self.ctx, &mut queued) } == MI355_OK && queued > 0 {
+            if let Err(ServerError::ServerUnhealthy { errors: native, .. }) = error::check(self.ctx, MI355_E_SERVER_UNHEALTHY) {
+                errors.extend(native);
+            }
+        }
+        if !errors.is_empty() {
+            self.timestamps.error(ProfileError::Unknown { reason: format!("{errors:?}"), backtrace: BackTrace::capture() });
+            lane.memory_management_gpu.cleanup(false);
+        }
+        errors
+    }
+
+    fn record(&mut self, stream_id: StreamId, err: ServerError) {
+        match self.lanes.resolve(stream_id, [].into_iter(), false) {
+            Ok(mut lanes) => lanes.current().errors.push(err),
+            Err(err) => unreachable!("{err}"),
+        }
+    }
+
+    /// First launch of a kernel id: native descriptor, or HIP C++ -> hiprtc -> module.
+    fn load(&mut self, id: &KernelId, kernel: Box<dyn CubeTask<Mi355Compiler>>) -> Result<Loaded, LaunchError> {
+        if let Some(hit) = self.kernels.get(id) {
+            return Ok(*hit);
+        }
+        let compiled = kernel.compile(kernel.define(), &mut self.compiler, &self.options)?;
+        self.utilities.logger.log_compilation(&compiled);
+        let loaded = match compiled.repr {
+            Some(Mi355Kernel::Native(op)) => Loaded::Native(op),
+            Some(Mi355Kernel::Hip(cpp)) => {
+                validate_cube_dim(&self.utilities.properties, id)?;
+                validate_units(&self.utilities.properties, id)?;
+                let limit = self.utilities.properties.hardware.max_shared_memory_size;
+                if cpp.shared_memory_size > limit {
+                    return Err(cubecl_runtime::server::ResourceLimitError::SharedMemory {
+                        requested: cpp.shared_memory_size,
+                        max: limit,
+                        backtrace: BackTrace::capture(),
+                    }
+                    .into());
+                }
+                let image = program::compile_hip(&compiled.source)?;
+                Loaded::Jit(program::load(self.ctx, &image, &compiled.entrypoint_name, compiled.cube_dim, cpp.shared_memory_size)?)
+            }
+            None => {
+                return Err(LaunchError::Unknown {
+                    reason: format!("{} compiled to nothing", kernel.name()),
+                    backtrace: BackTrace::capture(),
+                });
+            }
+        };
+        self.kernels.insert(id.clone(), loaded);
+        Ok(loaded)
+    }
+
+    fn launch_checked(&mut self, kernel: Box<dyn CubeTask<Mi355Compiler>>, count: CubeCount, bindings: KernelArguments,
+                      stream_id: StreamId, launch_mode: LaunchMode) -> Result<(), ServerError> {
+        let id = kernel.id();
+        let loaded = self.load(&id, kernel)?;
+        if launch_mode.is_skipped() {
+            return Ok(());
+        }
+        let ctx = self.ctx;
+        let KernelArguments { resources, info } = bindings;
+        let buffers: Vec<BufferBinding> = resources
+            .into_iter()
+            .map(|resource| match resource {
+                KernelResource::Buffer(binding) => binding,
+                KernelResource::TensorMap(map) => map.binding, // no TMA on CDNA4: the plain buffer is all there is
+            })
+            .collect();
+        let mut pass = self.pass(stream_id, buffers.iter(), Pending::Keep)?;
+
+        let grid = match count {
+            CubeCount::Static(x, y, z) => [x, y, z],
+            CubeCount::Dynamic(binding) => {
+                // three u32 on the device: read them back (a host sync -- the reference does the same)
+                let bytes = pass.download(CopyDescriptor::new(binding, [3].into(), [1].into(), 4))?;
+                pass.lanes.current().fence().wait()?;
+                let dims: &[u32] = bytemuck::cast_slice(&bytes);
+                [dims[0], dims[1], dims[2]]
+            }
+        };
+        if grid.contains(&0) {
+            return Ok(());
+        }
+
+        let mut slices = buffers.into_iter().map(|b| pass.slice(b)).collect::<Result<Vec<_>, _>>()?;
+        let sys = pass.sys();
+        let rc = match loaded {
+            Loaded::Native(op) => run_native(ctx, sys, op, &slices),
+            Loaded::Jit(program) => {
+                let info = pass.info_buffer(info.data)?;
+                slices.push(pass.slice(info.binding())?);
+                let pointers: Vec<*mut core::ffi::c_void> = slices.iter().map(|s| s.ptr).collect();
+                let block = [program.cube_dim.x, program.cube_dim.y, program.cube_dim.z];
+                unsafe {
+                    mi355_launch(ctx, sys, program.function, grid.as_ptr(), block.as_ptr(), program.shared_mem_bytes as u32,
+                                 pointers.as_ptr(), pointers.len() as u32)
+                }
+            }
+        };
+        let lane = pass.lanes.current();
+        if lane.drop_queue.should_flush() {
+            lane.release_staging();
+        }
+        error::check(ctx, rc)
+    }
+
+    fn replay_checked(&mut self, graph: GraphId, stream_id: StreamId) -> Result<(), ServerError> {
+        let raw = self.graphs.get(&graph).map(|g| g.raw).ok_or_else(|| ServerError::graph_state("replay of an unknown or destroyed graph"))?;
+        let ctx = self.ctx;
+        let mut pass = self.pass_alone(stream_id, Pending::Keep)?;
+        let rc = unsafe { mi355_graph_replay(ctx, pass.sys(), raw) };
+        error::check(ctx, rc)
     }
 }
 
-impl cubecl_common::device::DeviceService for Mi355Server {
-    fn init(device_id: DeviceId) -> Self {
-        let mut ctx = core::ptr::null_mut();
-        let rc = unsafe { mi355_ctx_create(device_id.index_id as i32, &mut ctx) };
-        // mi355_ctx_create refuses anything that is not wave64 gfx950; unlike the reference's
-        // `AMDArchitecture::parse` assert (crates/cubecl-hip/src/runtime.rs:118-124) it knows gfx950.
-        assert_eq!(rc, MI355_OK, "mi355_ctx_create: {}", crate::error::last_message(core::ptr::null_mut()));
-        let mut props = unsafe { core::mem::zeroed::<mi355_device_props_t>() };
-        unsafe { mi355_device_props(ctx, &mut props) };
-        let storage = Mi355Storage::new(ctx, props.mem_alignment as usize);
-        let (memory, utilities) = crate::runtime::build_memory_and_utilities(&props, storage, device_id);
-        Self { ctx, props, device: device_id, memory, comms: HashMap::new(), modules: HashMap::new(), utilities }
-    }
-
-    fn utilities(&self) -> cubecl_common::device::ServerUtilitiesHandle {
-        self.utilities.clone() as _
+/// The one place a native descriptor meets its buffers.  Buffer order is the one documented on [`NativeOp`].
+fn run_native(ctx: *mut mi355_ctx, sys: mi355_stream, op: NativeOp, b: &[DeviceSlice]) -> i32 {
+    let need = |n: usize| if b.len() < n { MI355_E_INVALID_ARGUMENT } else { MI355_OK };
+    unsafe {
+        match op {
+            NativeOp::Gemm(key) => match need(3) {
+                MI355_OK => mi355_gemm(ctx, sys, &key.desc(), b[0].ptr, b[1].ptr, b[2].ptr),
+                rc => rc,
+            },
+            NativeOp::GemmAdd(key) => match need(4) {
+                MI355_OK => mi355_gemm_add(ctx, sys, &key.desc(), b[0].ptr, b[1].ptr, b[2].ptr, b[3].ptr),
+                rc => rc,
+            },
+            NativeOp::Reduce { kind, dtype, rows, cols, row_stride } => match kind {
+                ReduceKind::Sum if b.len() >= 3 => mi355_reduce_sum(ctx, sys, b[0].ptr, dtype, cols, b[1].ptr as *mut f32, b[2].ptr, b[2].size),
+                ReduceKind::Argmax if b.len() >= 4 => {
+                    mi355_argmax(ctx, sys, b[0].ptr, dtype, cols, b[1].ptr as *mut f32, b[2].ptr as *mut u64, b[3].ptr, b[3].size)
+                }
+                ReduceKind::SumArgmax if b.len() >= 5 => mi355_sum_argmax(ctx, sys, b[0].ptr, dtype, cols, b[1].ptr as *mut f32,
+                                                                          b[2].ptr as *mut f32, b[3].ptr as *mut u64, b[4].ptr, b[4].size),
+                ReduceKind::RowSum if b.len() >= 2 => mi355_reduce_last_axis_sum(ctx, sys, b[0].ptr, dtype, b[1].ptr as *mut f32, rows, cols, row_stride),
+                ReduceKind::RowArgmax if b.len() >= 2 => {
+                    mi355_reduce_last_axis_argmax(ctx, sys, b[0].ptr, dtype, b[1].ptr as *mut u32, rows, cols, row_stride)
+                }
+                _ => MI355_E_INVALID_ARGUMENT,
+            },
+        }
     }
 }
 
 impl ComputeServer for Mi355Server {
-    type Kernel = Box<dyn cubecl_runtime::compiler::CubeTask<crate::runtime::AotCompiler>>;
+    type Kernel = Box<dyn CubeTask<Mi355Compiler>>;
     type Info = ();
-    type MemoryLayoutPolicy = cubecl_runtime::allocator::PitchedMemoryLayoutPolicy;
-    type Storage = Mi355Storage;
+    type MemoryLayoutPolicy = PitchedMemoryLayoutPolicy;
+    type Storage = DeviceStorage;
 
-    fn initialize_memory(&mut self, memory: ManagedMemoryHandle, size: u64, _stream_id: StreamId) {
-        self.memory.reserve_into(memory, size); // MemoryManagement -> Mi355Storage::alloc -> mi355_alloc
+    fn initialize_memory(&mut self, memory: ManagedMemoryHandle, size: u64, stream_id: StreamId) {
+        let mut pass = match self.pass_alone(stream_id, Pending::Keep) {
+            Ok(pass) => pass,
+            Err(err) => unreachable!("{err}"),
+        };
+        // the client already handed `memory` out, so a failure here has no caller to return to
+        let reserved = pass.reserve(size).unwrap_or_else(|err| panic!("cannot reserve {size} bytes of HBM: {err}"));
+        pass.bind(reserved, memory).unwrap_or_else(|err| panic!("cannot bind {size} bytes of HBM: {err}"));
     }
 
-    fn logger(&self) -> Arc<cubecl_runtime::logging::ServerLogger> {
-        self.utilities.logger.clone()
+    fn staging(&mut self, sizes: &[usize], stream_id: StreamId) -> Result<Vec<Bytes>, ServerError> {
+        let mut pass = self.pass_alone(stream_id, Pending::Keep)?;
+        Ok(sizes.iter().map(|size| pass.host_bytes(*size, true)).collect())
+    }
+
+    fn logger(&self) -> Arc<ServerLogger> {
+        self.lanes.logger.clone()
     }
 
     fn utilities(&self) -> Arc<ServerUtilities<Self>> {
@@ -101,187 +489,214 @@ impl ComputeServer for Mi355Server {
     }
 
     fn read(&mut self, descriptors: Vec<CopyDescriptor>, stream_id: StreamId) -> DynFut<Result<Vec<Bytes>, ServerError>> {
-        // mi355_read enqueues the D2H copy, waits for it and reports queued launch errors
-        // (crates/cubecl-hip/src/compute/command.rs:244-265, :538-614)
-        let mut out = Vec::with_capacity(descriptors.len());
-        let mut status = Ok(());
-        for d in descriptors {
-            let elem = d.elem_size as u64;
-            let rows: u64 = d.shape.iter().rev().skip(1).map(|x| *x as u64).product::<u64>().max(1);
-            let width = d.shape.last().copied().unwrap_or(1) as u64 * elem;
-            let pitch = if d.shape.len() >= 2 { d.strides[d.shape.len() - 2] as u64 * elem } else { width };
-            let res = match self.resource(d.handle, stream_id) { Ok(r) => r, Err(e) => { status = Err(e); break } };
-            let mut bytes = Bytes::from_bytes_vec(vec![0u8; (rows * width) as usize]);
-            let rc = unsafe {
-                if pitch == width {
-                    mi355_read(self.ctx, core::ptr::null_mut(), bytes.as_mut_ptr() as _, res.ptr, rows * width)
-                } else {
-                    mi355_read_2d(self.ctx, core::ptr::null_mut(), bytes.as_mut_ptr() as _, width, res.ptr, pitch, width, rows)
-                }
-            };
-            if let Err(e) = check(self.ctx, rc) { status = Err(e); break }
-            out.push(bytes);
+        let mut pass = match self.pass(stream_id, descriptors.iter().map(|d| &d.handle), Pending::Surface) {
+            Ok(pass) => pass,
+            Err(err) => return Box::pin(async move { Err(err) }),
+        };
+        if pass.lanes.current().capturing.is_recording() {
+            return Box::pin(async { Err(ServerError::graph_state("a read synchronises the stream and cannot be captured")) });
         }
-        Box::pin(async move { status.map(|_| out) })
+        // the bindings stay alive until the copies have run
+        let keep: Vec<BufferBinding> = descriptors.iter().map(|d| d.handle.clone()).collect();
+        let copies: Result<Vec<Bytes>, IoError> = descriptors.into_iter().map(|d| pass.download(d)).collect();
+        let done = pass.lanes.current().fence();
+        Box::pin(async move {
+            let waited = done.wait();
+            drop(keep);
+            waited?;
+            Ok(copies?)
+        })
     }
 
     fn write(&mut self, descriptors: Vec<(CopyDescriptor, Bytes)>, stream_id: StreamId) {
-        for (d, data) in descriptors {
-            if data.is_empty() { continue }              // empty tensors skip the copy (command.rs:363-369)
-            if let Ok(res) = self.resource(d.handle, stream_id) {
-                // stream-ordered; failures are queued inside the library and surface at the next flush/sync/read
-                unsafe { mi355_write(self.ctx, core::ptr::null_mut(), res.ptr, data.as_ptr() as _, data.len() as u64) };
-                self.memory.keep_alive_until_flush(data); // host bytes must outlive the copy (command.rs:402)
-            }
-        }
-    }
-
-    fn sync(&mut self, _stream_id: StreamId) -> DynFut<Result<(), ServerError>> {
-        let r = check(self.ctx, unsafe { mi355_sync(self.ctx, core::ptr::null_mut()) });
-        Box::pin(async move { r })
-    }
-
-    fn get_resource(&mut self, binding: BufferBinding, _stream_id: StreamId)
-        -> Result<ManagedResource<Mi355Resource>, ServerError> {
-        self.memory.get_resource(binding).map_err(Into::into)
-    }
-
-    unsafe fn launch(&mut self, kernel: Self::Kernel, count: CubeCount, bindings: KernelArguments,
-                     stream_id: StreamId, _mode: LaunchMode) {
-        // CubeTask::compile() of an external kernel returns a CompiledKernel naming a PRE-BUILT gfx950 entry
-        // point (README.md:222-224 "external kernels"); nothing is generated or JIT-compiled here.
-        let compiled = kernel.compile(&mut crate::runtime::AotCompiler, &Default::default(), Default::default(), kernel.address_type());
-        let Ok(compiled) = compiled else { return };
-        let ext: &ExternalKernel = compiled.repr.as_ref().expect("AOT kernels carry their code object");
-        let grid = match count {
-            CubeCount::Static(x, y, z) => [x, y, z],
-            CubeCount::Dynamic(b) => {   // blocking 12-byte read-back, as the reference does (server.rs:779-793)
-                let r = self.resource(b, stream_id).expect("dynamic cube count binding");
-                let mut g = [0u32; 3];
-                unsafe { mi355_read(self.ctx, core::ptr::null_mut(), g.as_mut_ptr() as _, r.ptr, 12) };
-                g
-            }
+        let mut pass = match self.pass(stream_id, descriptors.iter().map(|d| &d.0.handle), Pending::Keep) {
+            Ok(pass) => pass,
+            Err(err) => unreachable!("{err}"),
         };
-        if grid.iter().any(|d| *d == 0) { return }        // zero-sized grid = no-op (client.rs:880-884)
-        let key = Arc::as_ptr(&ext.image) as usize;
-        let ctx = self.ctx;
-        let (module, funcs) = self.modules.entry(key).or_insert_with(|| {
-            let mut m = core::ptr::null_mut();
-            unsafe { mi355_module_load(ctx, ext.image.as_ptr() as _, ext.image.len(), &mut m) };
-            (m, HashMap::new())
-        });
-        let func = *funcs.entry(ext.entry.clone()).or_insert_with(|| {
-            let mut f = core::ptr::null_mut();
-            unsafe { mi355_module_get_function(ctx, *module, ext.entry.as_ptr(), &mut f) };
-            f
-        });
-        // one pointer per buffer binding, the info buffer last (crates/cubecl-hip/src/compute/server.rs:816)
-        let mut ptrs: Vec<*mut core::ffi::c_void> = Vec::with_capacity(bindings.resources.len() + 1);
-        for r in bindings.resources {
-            if let KernelResource::Buffer(b) = r { if let Ok(res) = self.resource(b, stream_id) { ptrs.push(res.ptr) } }
+        for (descriptor, data) in descriptors {
+            if let Err(err) = pass.upload(descriptor, data) {
+                pass.lanes.current().errors.push(err.into());
+                return;
+            }
         }
-        let info = self.memory.upload_info(&bindings.info.data);   // pinned staging + content cache (server.rs:128-148)
-        ptrs.push(info.ptr);
-        let block = [ext.cube_dim.x, ext.cube_dim.y, ext.cube_dim.z];
-        // resource-limit violations are QUEUED by the library and surface from flush() as
-        // ServerUnhealthy{errors:[Launch(TooManyResources(..))]} (runtime_tests/launch.rs:226-348)
-        unsafe { mi355_launch(self.ctx, core::ptr::null_mut(), func, grid.as_ptr(), block.as_ptr(), ext.shared_mem_bytes,
-                              ptrs.as_ptr(), ptrs.len() as u32) };
     }
 
-    fn flush(&mut self, _stream_id: StreamId) -> Result<(), ServerError> {
-        check(self.ctx, unsafe { mi355_flush(self.ctx) })
+    fn sync(&mut self, stream_id: StreamId) -> DynFut<Result<(), ServerError>> {
+        let mut pass = match self.pass_alone(stream_id, Pending::Surface) {
+            Ok(pass) => pass,
+            Err(err) => return Box::pin(async move { Err(err) }),
+        };
+        let lane = pass.lanes.current();
+        if lane.capturing.is_recording() {
+            return Box::pin(async { Err(ServerError::graph_state("a sync cannot be captured")) });
+        }
+        let done = lane.fence();
+        Box::pin(async move { done.wait() })
     }
 
-    fn memory_usage(&mut self, _stream_id: StreamId) -> Result<MemoryUsage, ServerError> {
-        Ok(self.memory.memory_usage())
+    fn get_resource(&mut self, binding: BufferBinding, stream_id: StreamId) -> Result<ManagedResource<DeviceSlice>, ServerError> {
+        let mut pass = self.pass(stream_id, [&binding].into_iter(), Pending::Keep)?;
+        let keep = binding.memory.clone();
+        Ok(ManagedResource::new(keep, pass.slice(binding)?))
     }
 
-    fn memory_report(&mut self, _stream_id: StreamId) -> Result<cubecl_runtime::memory_management::MemoryReport, ServerError> {
-        Ok(self.memory.memory_report())
+    unsafe fn launch(&mut self, kernel: Self::Kernel, count: CubeCount, bindings: KernelArguments, stream_id: StreamId, launch_mode: LaunchMode) {
+        if let Err(err) = self.launch_checked(kernel, count, bindings, stream_id, launch_mode) {
+            // fire-and-forget: the failure waits on the lane for the next flush / sync / read
+            match self.timestamps.is_empty() {
+                true => self.record(stream_id, err),
+                false => self.timestamps.error(ProfileError::Server(Box::new(err))),
+            }
+        }
     }
 
-    fn memory_cleanup(&mut self, _stream_id: StreamId) {
-        self.memory.cleanup(true);
-    }
-
-    fn start_profile(&mut self, _stream_id: StreamId) -> Result<ProfilingToken, ServerError> {
-        let mut token = 0u64;
-        check(self.ctx, unsafe { mi355_profile_start(self.ctx, core::ptr::null_mut(), &mut token) })?;
-        Ok(ProfilingToken { id: token })
-    }
-
-    fn end_profile(&mut self, _stream_id: StreamId, token: ProfilingToken) -> Result<ProfileDuration, ProfileError> {
-        let mut nanos = 0u64;
-        let rc = unsafe { mi355_profile_stop(self.ctx, core::ptr::null_mut(), token.id, &mut nanos) };
-        if rc != MI355_OK { return Err(ProfileError::NotRegistered { backtrace: cubecl_common::backtrace::BackTrace::capture() }) }
-        // TimingMethod::Device: GPU time from hipEvents (the reference HIP backend reports System time, runtime.rs:198)
-        Ok(ProfileDuration::new_device_time(core::time::Duration::from_nanos(nanos)))
-    }
-
-    fn allocation_mode(&mut self, mode: MemoryAllocationMode, _stream_id: StreamId) {
-        self.memory.mode(mode);
-    }
-}
-
-impl ServerCommunication for Mi355Server {
-    /// RCCL is present on every ROCm install; the library reports it in the property block.
-    const SERVER_COMM_ENABLED: bool = true;
-
-    fn comm_init(&mut self, device_ids: Vec<DeviceId>) -> Result<(), ServerError> {
-        let id = CommunicationId::from(device_ids.clone());
-        if self.comms.contains_key(&id) { return Ok(()) }
-        let mut sorted = device_ids; sorted.sort();
-        let rank = sorted.iter().position(|d| *d == self.device).expect("own device in the set") as i32;
-        // one ncclUniqueId per device set, created by whoever asks first (communication.rs:14-25)
-        let uid = crate::runtime::unique_id_for(&id);
-        let mut comm = core::ptr::null_mut();
-        check(self.ctx, unsafe { mi355_comm_init(self.ctx, uid.as_ptr(), rank, sorted.len() as i32, &mut comm) })?;
-        self.comms.insert(id, (comm, sorted));
+    fn flush(&mut self, stream_id: StreamId) -> Result<(), ServerError> {
+        let mut pass = self.pass_alone(stream_id, Pending::Surface)?;
+        let lane = pass.lanes.current();
+        lane.release_staging();
+        lane.memory_management_gpu.storage().flush();
         Ok(())
     }
 
-    fn all_reduce(&mut self, src: BufferBinding, dst: BufferBinding, dtype: ElemType, stream_id: StreamId,
-                  op: ReduceOperation, device_ids: Vec<DeviceId>) -> Result<(), ServerError> {
-        let (comm, _) = *self.comms.get(&CommunicationId::from(device_ids)).expect("comm_init first");
-        let (s, d) = (self.resource(src, stream_id)?, self.resource(dst, stream_id)?);
-        let code = Self::dtype_code(dtype)?;
-        let count = s.size / dtype.size() as u64;                       // get_nccl_dtype_count (communication.rs:34-108)
-        let op = match op { ReduceOperation::Sum => MI355_REDUCE_SUM, ReduceOperation::Mean => MI355_REDUCE_MEAN };
-        // the library fences compute -> comm stream and issues ncclAllReduce on the comm stream (server.rs:705-780)
-        check(self.ctx, unsafe { mi355_all_reduce(self.ctx, comm, core::ptr::null_mut(), s.ptr, d.ptr, count, code, op) })
+    fn graph_prepare(&mut self, stream_id: StreamId) -> Result<(), ServerError> {
+        let mut pass = self.pass_alone(stream_id, Pending::Surface)?;
+        let lane = pass.lanes.current();
+        lane.capturing.prepare()?;
+        // from here until end_capture the pools hand out slices that are never recycled: a replay finds every buffer
+        // where the capture saw it
+        lane.memory_management_gpu.capture_begin();
+        lane.memory_management_cpu.capture_begin();
+        Ok(())
     }
 
-    fn sync_collective(&mut self, _stream_id: StreamId) -> Result<(), ServerError> {
-        check(self.ctx, unsafe { mi355_sync_collective(self.ctx, core::ptr::null_mut()) })
+    fn begin_capture(&mut self, stream_id: StreamId) -> Result<(), ServerError> {
+        let ctx = self.ctx;
+        let mut pass = self.pass_alone(stream_id, Pending::Surface)?;
+        let lane = pass.lanes.current();
+        lane.capturing.begin()?;
+        lane.release_staging();
+        lane.release_staging();
+        lane.memory_management_gpu.capture_priming_end();
+        lane.memory_management_cpu.capture_priming_end();
+        let rc = unsafe { mi355_graph_begin_capture(ctx, lane.sys) };
+        if let Err(err) = error::check(ctx, rc) {
+            lane.memory_management_gpu.capture_end();
+            lane.memory_management_cpu.capture_end();
+            lane.info_cache.capture_discard();
+            lane.capturing.abort();
+            return Err(err);
+        }
+        Ok(())
     }
 
-    fn send(&mut self, desc: CopyDescriptor, dtype: ElemType, stream_id: StreamId, dst: DeviceId) -> Result<(), ServerError> {
-        let r = self.resource(desc.handle, stream_id)?;
-        let (comm, ids) = self.comms.values().find(|(_, ids)| ids.contains(&dst)).expect("comm_init first").clone();
-        let peer = ids.iter().position(|d| *d == dst).unwrap() as i32;
-        check(self.ctx, unsafe { mi355_send(self.ctx, comm, core::ptr::null_mut(), r.ptr, r.size / dtype.size() as u64,
-                                            Self::dtype_code(dtype)?, peer) })
+    fn end_capture(&mut self, stream_id: StreamId) -> Result<GraphId, ServerError> {
+        let ctx = self.ctx;
+        let id = GraphId::new();
+        let captured = {
+            let mut pass = self.pass_alone(stream_id, Pending::Keep)?;
+            let lane = pass.lanes.current();
+            lane.capturing.end()?;
+            let mut raw: *mut mi355_graph = core::ptr::null_mut();
+            // the library instantiates the graph, refuses one that recorded a memory node, and releases its own pins
+            // when this fails (cubecl_amd/csrc/runtime.cpp mi355_graph_end_capture)
+            let ended = error::check(ctx, unsafe { mi355_graph_end_capture(ctx, lane.sys, &mut raw) });
+            let mut pinned = lane.memory_management_gpu.capture_end();
+            pinned.extend(lane.memory_management_cpu.capture_end());
+            lane.release_staging();
+            lane.release_staging();
+            match ended {
+                Ok(()) => {
+                    lane.info_cache.capture_commit(id);
+                    CapturedGraph { raw, _pinned: pinned }
+                }
+                Err(err) => {
+                    lane.info_cache.capture_discard();
+                    return Err(err);
+                }
+            }
+        };
+        self.graphs.insert(id, captured);
+        Ok(id)
     }
 
-    fn recv(&mut self, handle: Handle, dtype: ElemType, stream_id: StreamId, src: DeviceId) -> Result<(), ServerError> {
-        let r = self.resource(handle.binding(), stream_id)?;
-        let (comm, ids) = self.comms.values().find(|(_, ids)| ids.contains(&src)).expect("comm_init first").clone();
-        let peer = ids.iter().position(|d| *d == src).unwrap() as i32;
-        check(self.ctx, unsafe { mi355_recv(self.ctx, comm, core::ptr::null_mut(), r.ptr, r.size / dtype.size() as u64,
-                                            Self::dtype_code(dtype)?, peer) })
+    fn replay(&mut self, graph: GraphId, stream_id: StreamId) {
+        if let Err(err) = self.replay_checked(graph, stream_id) {
+            self.record(stream_id, err);
+        }
+    }
+
+    fn graph_destroy(&mut self, graph: GraphId, stream_id: StreamId) {
+        let Some(captured) = self.graphs.remove(&graph) else {
+            return;
+        };
+        // mi355_graph_destroy waits for the streams the graph was replayed on before anything it pins is released
+        // (ADVICE round 1); only after that may `_pinned` return its slices to the pools
+        let destroyed = error::check(self.ctx, unsafe { mi355_graph_destroy(self.ctx, captured.raw) });
+        drop(captured);
+        if let Ok(mut lanes) = self.lanes.resolve(stream_id, [].into_iter(), false) {
+            let lane = lanes.current();
+            lane.info_cache.graph_release(graph);
+            if let Err(err) = destroyed {
+                lane.errors.push(err);
+            }
+        }
+    }
+
+    fn memory_usage(&mut self, stream_id: StreamId) -> Result<MemoryUsage, ServerError> {
+        let mut pass = self.pass_alone(stream_id, Pending::Keep)?;
+        Ok(pass.lanes.current().memory_management_gpu.memory_usage())
+    }
+
+    fn memory_report(&mut self, stream_id: StreamId) -> Result<MemoryReport, ServerError> {
+        let mut pass = self.pass_alone(stream_id, Pending::Keep)?;
+        Ok(pass.lanes.current().memory_management_gpu.memory_report())
+    }
+
+    fn stream_ids(&self) -> Vec<StreamId> {
+        self.lanes.stream_ids().collect()
+    }
+
+    fn memory_cleanup(&mut self, stream_id: StreamId) {
+        if let Ok(mut pass) = self.pass_alone(stream_id, Pending::Keep) {
+            pass.cleanup();
+        }
+    }
+
+    fn install_memory_pools(&mut self, config: MemoryConfiguration, stream_id: StreamId) -> Result<(), InstallMemoryPoolsError> {
+        self.lanes.backend_mut().set_device_pools(config.clone());
+        let (_, props) = self.lanes.backend_mut().device_pools();
+        match self.pass_alone(stream_id, Pending::Keep) {
+            Ok(mut pass) => pass.lanes.current().memory_management_gpu.install_pools(config, &props),
+            Err(_) => Err(InstallMemoryPoolsError::StreamUnavailable),
+        }
+    }
+
+    fn start_profile(&mut self, stream_id: StreamId) -> Result<ProfilingToken, ServerError> {
+        cubecl_environment::future::block_on(self.sync(stream_id))?;
+        Ok(self.timestamps.start())
+    }
+
+    fn end_profile(&mut self, stream_id: StreamId, token: ProfilingToken) -> Result<ProfileDuration, ProfileError> {
+        if let Err(err) = cubecl_environment::future::block_on(self.sync(stream_id)) {
+            self.timestamps.error(ProfileError::Server(Box::new(err)));
+        }
+        self.timestamps.stop(token)
+    }
+
+    fn allocation_mode(&mut self, mode: MemoryAllocationMode, stream_id: StreamId) {
+        match self.pass_alone(stream_id, Pending::Keep) {
+            Ok(mut pass) => pass.lanes.current().memory_management_gpu.mode(mode),
+            Err(err) => unreachable!("{err}"),
+        }
     }
 }
 
 impl Drop for Mi355Server {
     fn drop(&mut self) {
-        for (comm, _) in self.comms.values() { unsafe { mi355_comm_destroy(self.ctx, *comm) }; }
-        unsafe { mi355_ctx_destroy(self.ctx) };
-    }
-}
-
-impl core::fmt::Debug for Mi355Server {
-    fn fmt(&self, f: &mut core::fmt::Formatter<'_>) -> core::fmt::Result {
-        f.debug_struct("Mi355Server").field("device", &self.device).finish()
+        for (_, graph) in self.graphs.drain() {
+            unsafe { mi355_graph_destroy(self.ctx, graph.raw) };
+        }
+        comm::destroy_all(self);
+        // the lanes drop after this body, each syncing and destroying its stream; `_context` goes last
     }
 }
