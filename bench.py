@@ -362,7 +362,7 @@ def main():
         "config": {"workload": f"{S}x{S}x{S} bf16 GEMM, f32 accumulate, bf16 C (BASELINE config C3), one per GPU",
                    "layout": "A[M,K] row-major; B stored [N][K] (Out = Lhs*Rhs^T, the cmma tests' ColMajor-B form)",
                    "operands": "uniform[-1,1) counter RNG seed 0x5EEDC0BE, generated in HBM",
-                   "kernel": {2: "f32_mfma", 3: "lp128", 4: "lp256", 5: "lp256w4", 6: "lp256p", 7: "lp256q", 1: "generic"}.get(sel.value, str(sel.value)),
+                   "kernel": {2: "f32_mfma", 3: "lp128", 4: "lp256", 5: "lp256w4", 6: "lp256p", 7: "lp256q", 8: "skinny", 1: "generic"}.get(sel.value, str(sel.value)),
                    "parallelism": f"batch-sharded x{world}, no data-path collective",
                    "plateau_warmup_steps": plateau_steps},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -673,7 +673,7 @@ def main():
 
         def skinny():
             out = {}
-            for (m, n, k) in ((8192, 8192, 64), (64, 8192, 8192), (8192, 64, 8192), (1, 8192, 8192), (4096, 4096, 4096),
+            for (m, n, k) in ((8192, 8192, 64), (64, 8192, 8192), (8192, 64, 8192), (1, 8192, 8192), (16, 8192, 8192), (4096, 4096, 4096),
                               (6144, 6144, 6144), (4608, 4096, 8192), (2048, 2048, 2048)):
                 sa = TensorHandle.uniform(client, (m, k), ElemType.BF16, SEED, 700, -1.0, 1.0)
                 sb = TensorHandle.uniform(client, (n, k), ElemType.BF16, SEED, 701, -1.0, 1.0)
@@ -683,7 +683,8 @@ def main():
                 lib.mi355_gemm_select(ctx, C.byref(d), C.byref(alg))
                 med, _ = samples_op(client, ev, lambda: client._s.check(
                     lib.mi355_gemm(ctx, None, C.byref(d), sa.device_ptr(), sb.device_ptr(), sc.device_ptr())), samples=7, warmup=2)
-                out[f"{m}x{n}x{k}"] = {"median_ms": round(med, 4), "TFLOPs": round(2.0 * m * n * k / med / 1e9, 1), "algo": alg.value}
+                out[f"{m}x{n}x{k}"] = {"median_ms": round(med, 4), "TFLOPs": round(2.0 * m * n * k / med / 1e9, 1), "algo": alg.value,
+                                       "algorithmic_GBs": round(2.0 * (m * k + n * k + m * n) / med / 1e6, 1)}
             return out
         guarded("gemm_bf16_shapes", skinny)
 

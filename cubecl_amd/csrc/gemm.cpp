@@ -50,6 +50,10 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
     const bool big = gemm_lp256_supports(d, a, b, c);
     const bool big4 = gemm_lp256w4_supports(d, a, b, c);
     const bool mid = gemm_lp128_supports(d, a, b, c);
+    // one or two rows (or columns): HBM-bound on the other operand; stream it once with dot products, no MFMA tile to fill
+    // (gemm_skinny.hip: 20.4 us against 24.7 at 1 x 8192 x 8192).  Up to 16 rows when no MFMA kernel takes the descriptor.
+    if ((d.m <= 16 || d.n <= 16) && gemm_skinny_supports(d, a, b, c) && (std::min(d.m, d.n) <= 2 || !(big || big4 || mid)))
+        return MI355_GEMM_ALGO_SKINNY;
     if (big) {
         // 256x256 tiles once the 128x128 kernel would need more than its two co-resident workgroups per CU (512 tiles of
         // 128^2 = 128 of 256^2).  Measured (tools/dev/mid_shapes.py): 96-128 tiles a tie, 144-160 tiles +45...55 % for the
@@ -280,6 +284,7 @@ MI355_API int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_ge
     case MI355_GEMM_ALGO_LP_256W4: return launch_gemm_lp256w4(ctx, s, d, a, b, c);
     case MI355_GEMM_ALGO_LP_256P: return launch_gemm_lp256p(ctx, s, d, a, b, c);
     case MI355_GEMM_ALGO_LP_256Q: return launch_gemm_lp256q(ctx, s, d, a, b, c);
+    case MI355_GEMM_ALGO_SKINNY: return launch_gemm_skinny(ctx, s, d, a, b, c);
     default: return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_gemm: unknown algo %d", algo);
     }
 }

@@ -379,8 +379,10 @@ enum {
     MI355_GEMM_ALGO_LP_256W4 = 5, /* fp8/bf16/f16/f32 256x256 tile x 128-byte K line, 4 waves x 128x128 */
     MI355_GEMM_ALGO_LP_256P = 6,  /* the same tile as a persistent kernel: one workgroup per CU walks
                                      several output tiles with a continuous K-tile stream          */
-    MI355_GEMM_ALGO_LP_256Q = 7   /* the persistent kernel with the finished tile held in registers (16-bit C) and its
+    MI355_GEMM_ALGO_LP_256Q = 7,  /* the persistent kernel with the finished tile held in registers (16-bit C) and its
                                      stores dripped into the next tile's K loop                      */
+    MI355_GEMM_ALGO_SKINNY = 8    /* bf16/f16, M <= 16 or N <= 16: the large operand streamed once from HBM,
+                                     v_dot2c_f32 accumulation, no matrix core (gemm_skinny.hip)      */
 };
 
 int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_gemm_desc *desc,

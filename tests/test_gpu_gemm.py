@@ -21,7 +21,7 @@ GOLD = json.loads((Path(__file__).parent / "golden" / "reference_goldens.json").
 REL = 1e-5
 ALGOS = {"auto": N.GEMM_ALGO_AUTO, "generic": N.GEMM_ALGO_GENERIC, "f32": N.GEMM_ALGO_F32_MFMA,
          "lp128": N.GEMM_ALGO_LP_128, "lp256": N.GEMM_ALGO_LP_256, "lp256w4": N.GEMM_ALGO_LP_256W4, "lp256p": N.GEMM_ALGO_LP_256P,
-         "lp256q": N.GEMM_ALGO_LP_256Q}
+         "lp256q": N.GEMM_ALGO_LP_256Q, "skinny": N.GEMM_ALGO_SKINNY}
 
 
 def _to_dev(client, oracle, x, dtype):
@@ -802,3 +802,46 @@ def test_matmul_add_f32_inside_the_256_kernel(client, oracle, dtype, m, n, k, ba
     assert np.array_equal(got, p_t.to_numpy(client) + c_host)           # same kernel, same sum order: bit-equal
     ops.matmul(client, a_t, b_t, tc, algo=ALGOS[algo], acc=tc)           # in place
     assert np.array_equal(tc.to_numpy(client), got)
+
+
+# ---- at most 16 rows or columns: the dot2 row-streaming kernel (gemm_skinny.hip) ---------------------------------------------
+@pytest.mark.parametrize("m,n,k,kw", [
+    (1, 8192, 8192, {}),                       # the GEMV the bench quotes
+    (1, 37, 8, {}),                            # one partial chunk, ragged row count
+    (2, 1000, 4104, {}),                       # K = 8 full chunks + 8 elements
+    (3, 777, 520, {"lda": 528, "ldb": 536}),   # padded rows on both operands
+    (4, 64, 1024, {"ldc": 72}),                # pitched C: padding stays untouched
+    (5, 130, 2048, {"batch": 3}),
+    (8, 256, 1544, {"batch": 2, "bcast_b": True}),
+    (16, 4096, 1024, {}),                      # 64 partial sums per lane: the full butterfly
+    (13, 19, 72, {}),
+    (4096, 1, 1024, {}),                       # N <= 16: roles swapped, output walked column-wise
+    (1000, 7, 4104, {"ldc": 8}),
+    (515, 16, 640, {"batch": 2}),
+])
+@pytest.mark.parametrize("dtype,out_dtype", [(ElemType.BF16, ElemType.BF16), (ElemType.F16, ElemType.F32), (ElemType.BF16, ElemType.F32)])
+def test_skinny_dot2_kernel_matches_the_oracle(client, oracle, m, n, k, kw, dtype, out_dtype):
+    d = N.GemmDesc(m=m, n=n, k=k, batch=kw.get("batch", 1), lda=kw.get("lda", k), ldb=kw.get("ldb", k), ldc=kw.get("ldc", n),
+                   stride_a=m * kw.get("lda", k), stride_b=0 if kw.get("bcast_b") else n * kw.get("ldb", k), stride_c=m * kw.get("ldc", n),
+                   dtype_ab=int(dtype), dtype_c=int(out_dtype), trans_a=0, trans_b=1, algo=0)
+    if min(m, n) <= 2:       # AUTO: one or two rows / columns stream through this kernel, wider ones keep the MFMA path when it runs
+        assert ops.gemm_select(client, d) == N.GEMM_ALGO_SKINNY
+    run_case(client, oracle, m, n, k, dtype, out_dtype, True, ALGOS["skinny"], **kw)
+    run_case(client, oracle, m, n, k, dtype, out_dtype, True, ALGOS["auto"], **kw)
+
+
+def test_skinny_kernel_refusals_and_determinism(client, oracle):
+    # both extents above 16, a row-major B, an unaligned K: refused when forced, AUTO goes elsewhere
+    for (m, n, k, tb) in ((17, 17, 64, True), (4, 64, 60, True), (4, 64, 64, False)):
+        with pytest.raises(ServerError):
+            run_case(client, oracle, m, n, k, ElemType.BF16, ElemType.F32, tb, ALGOS["skinny"])
+        run_case(client, oracle, m, n, k, ElemType.BF16, ElemType.F32, tb, ALGOS["auto"])
+    # fixed summation order: repeated launches give the same bits
+    a = TensorHandle.uniform(client, (8, 8192), ElemType.BF16, 3, 1, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (4096, 8192), ElemType.BF16, 3, 2, -1.0, 1.0)
+    outs = []
+    for _ in range(3):
+        c = TensorHandle.new_contiguous((8, 4096), client.empty(8 * 4096 * 4), ElemType.F32)
+        ops.matmul(client, a, TensorHandle.new(b.handle, (8192, 4096), (1, 8192), ElemType.BF16), c, algo=ALGOS["skinny"])
+        outs.append(c.to_numpy(client).copy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
