@@ -54,6 +54,12 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
     // (gemm_skinny.hip: 20.4 us against 24.7 at 1 x 8192 x 8192).  Up to 16 rows when no MFMA kernel takes the descriptor.
     if ((d.m <= 16 || d.n <= 16) && gemm_skinny_supports(d, a, b, c) && (std::min(d.m, d.n) <= 2 || !(big || big4 || mid)))
         return MI355_GEMM_ALGO_SKINNY;
+    // Output-bound (K of at most four K-tiles) over more than one round of 256x256 tiles: the 128x128 kernel in its
+    // single-stage form, four workgroups per CU -- the C stores of three hide the fetch + MFMA phase of the fourth, where a
+    // 256x256 workgroup (alone on its CU) serialises them.  bf16, 8192 x 8192 x K (tools/dev/shortk_probe.py): K = 64 32.3 us
+    // against 41.9, K = 128 37.1 against 38.9 (persistent), K = 192 40.9 / 43.0, K = 256 46.8 / 49.0; 16384 x 8192 x 64
+    // 51.6 / 68.8.  A single round (4096 x 4096: 256 tiles) stays with the large tile (10.6 us against 12.2).
+    if (mid && d.k <= 256 && ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch > 256) return MI355_GEMM_ALGO_LP_128;
     if (big) {
         // 256x256 tiles once the 128x128 kernel would need more than its two co-resident workgroups per CU (512 tiles of
         // 128^2 = 128 of 256^2).  Measured (tools/dev/mid_shapes.py): 96-128 tiles a tie, 144-160 tiles +45...55 % for the

@@ -63,7 +63,9 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
                                      (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
 }
 
-// NS = LDS stages.  2 (64 KiB, two workgroups per CU): the co-resident workgroup covers the wait for the next K-tile.
+// NS = LDS stages.  1 (32-36 KiB, four workgroups per CU): launches whose K is a single K-tile -- output-bound, nothing to
+// pipeline inside a workgroup, so what hides one workgroup's operand fetch and MFMAs is the C stores of the three others.
+// 2 (64 KiB, two workgroups per CU): the co-resident workgroup covers the wait for the next K-tile.
 // 4 (128 KiB, one workgroup per CU): taken when the launch has at most one workgroup per CU anyway (mid-size shapes:
 // <= 256 tiles) -- then nothing else hides the DMA latency, and the K-tiles are fetched three ahead instead of one.
 // LDS-DMA as `global_load_lds_dwordx4 v_off, s[base:base+1]`: wave-uniform 64-bit base + constant 32-bit lane offset, LDS
@@ -79,7 +81,7 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void *p)
 }
 
 template <int DT, int DT_C, int NS = 2>
-__global__ void __launch_bounds__(256, NS == 2 ? 2 : 1)
+__global__ void __launch_bounds__(256, NS == 1 ? 4 : NS == 2 ? 2 : 1)
 gemm_lp128_kernel(gemm_args g)
 {
     // [stage][operand][16 KiB]; one array only (a second __shared__ object de-pipelines LDS-DMA
@@ -189,7 +191,24 @@ gemm_lp128_kernel(gemm_args g)
     typedef std::integral_constant<int, 0> B0;
     typedef std::integral_constant<int, 1> B1;
 
-    if constexpr (NS == 2) {
+    if constexpr (NS == 1) {
+        // one stage: fetch, wait, multiply, hand the buffer back.  Nothing overlaps inside the workgroup; the three
+        // co-resident workgroups do the overlapping (launched for K of at most SK1_MAX_TILES K-tiles).
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt > 0) __syncthreads();                     // every wave is done reading the previous K-tile
+            stage(0, kt);
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            const char *la = smem, *lb = smem + TILE_BYTES;
+            reads(B0{}, la, lb, 0);
+            reads(B1{}, la, lb, 1); mfmas(B0{});
+            if constexpr (NSTEP == 4) {
+                reads(B0{}, la, lb, 2); mfmas(B1{});
+                reads(B1{}, la, lb, 3); mfmas(B0{});
+            }
+            mfmas(B1{});
+        }
+    } else if constexpr (NS == 2) {
         if (nk > 0) stage(0, 0);
         __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) lgkmcnt(0) expcnt(0)
         __syncthreads();
@@ -259,8 +278,69 @@ gemm_lp128_kernel(gemm_args g)
     char *__restrict__ C = static_cast<char *>(g.c);
     constexpr int CSZ = (DT_C == MI355_DTYPE_F32) ? 4 : 2;
     const int64_t cbase = batch * g.stride_c + (int64_t)z * g.split_c_stride;
-    const bool vec_ok = (((g.ldc * CSZ) & (4 * CSZ - 1)) == 0) &&
-                        (((reinterpret_cast<uintptr_t>(C) + (uint64_t)cbase * CSZ) & (4 * CSZ - 1)) == 0);
+    // Whole-line stores.  Straight from the accumulators a store instruction would put 8 (16-bit) or 16 (f32) bytes on
+    // each of 32 different rows, so every 128-byte line of C would be assembled from 8-16 partial writes -- measured on the
+    // 256x256 kernel and again here, partial-line stores cost tens of percent (8192 x 8192 x 64 bf16: 49.6 us before).  Each
+    // wave instead transposes its 64 x 64 block through LDS, 32 rows at a time, and writes rows: 16 bytes per lane,
+    // 128 (16-bit) / 256 (f32) contiguous bytes per row.  Needs 16-byte aligned rows; anything else takes the element path.
+    const bool rows16 = (((g.ldc * CSZ) & 15) == 0) && (((reinterpret_cast<uintptr_t>(C) + (uint64_t)cbase * CSZ) & 15u) == 0);
+    if (rows16) {
+        constexpr int RS = 64 * CSZ + 16;                  // staged row pitch: +16 B keeps b128 aligned, writes <= 2-way conflicted
+        constexpr int STAGE = (32 * RS + 1023) & ~1023;    // per-wave scratch
+        constexpr int LPR = 64 * CSZ / 16;                 // lanes per output row: 8 / 16
+        constexpr int RPI = 64 / LPR;                      // rows per store instruction: 8 / 4
+        constexpr int EPP = 16 / CSZ;                      // elements per 16-byte piece
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();                                   // every wave is done with the operand tiles: LDS is free
+        char *stage = smem + wave * STAGE;
+        char *wr = stage + l31 * RS + 4 * h * CSZ;
+        const char *rd = stage + (lane / LPR) * RS + (lane % LPR) * 16;
+        const int64_t row0 = m0 + wm * 64 + lane / LPR;                   // + i * 32 + it * RPI
+        const int64_t col0 = n0 + wn * 64 + (lane % LPR) * EPP;
+        char *crow = C + (cbase + row0 * g.ldc + col0) * CSZ;
+        const int64_t cstep = (int64_t)RPI * g.ldc * CSZ;
+        const int ncols = (int)max((int64_t)0, min((int64_t)EPP, g.n - col0));   // valid elements of my piece
+        const bool interior = (m0 + BM <= g.m) && (n0 + BN <= g.n);       // workgroup-uniform fast path
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    char *d = wr + (j * 32 + 8 * q) * CSZ;
+                    if constexpr (DT_C == MI355_DTYPE_F32) {
+                        f32x4 v = {acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        *reinterpret_cast<f32x4 *>(d) = v;
+                    } else {
+                        u32x2 v = {(uint32_t)f32_to_lp<DT_C>(acc[i][j][4 * q + 0]) | ((uint32_t)f32_to_lp<DT_C>(acc[i][j][4 * q + 1]) << 16),
+                                   (uint32_t)f32_to_lp<DT_C>(acc[i][j][4 * q + 2]) | ((uint32_t)f32_to_lp<DT_C>(acc[i][j][4 * q + 3]) << 16)};
+                        *reinterpret_cast<u32x2 *>(d) = v;
+                    }
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave hand-over: the DS ops of one wave execute in order
+            char *cdst = crow + (int64_t)i * 32 * g.ldc * CSZ;
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) {
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(rd + it * RPI * RS);
+                if (!interior) {
+                    if (row0 + i * 32 + it * RPI >= g.m || ncols <= 0) continue;
+                    if (ncols < EPP) {
+#pragma unroll
+                        for (int e = 0; e < EPP; ++e) {                    // static indices only
+                            if (e >= ncols) break;
+                            if constexpr (CSZ == 4) reinterpret_cast<uint32_t *>(cdst + it * cstep)[e] = v[e];
+                            else reinterpret_cast<uint16_t *>(cdst + it * cstep)[e] = (uint16_t)(v[e >> 1] >> ((e & 1) * 16));
+                        }
+                        continue;
+                    }
+                }
+                *reinterpret_cast<u32x4 *>(cdst + it * cstep) = v;
+            }
+            __builtin_amdgcn_sched_barrier(0);             // keep the accumulator reads of block i+1 below this point
+        }
+        return;
+    }
+    const bool vec_ok = false;   // rows are not 16-byte aligned here
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int64_t m = m0 + wm * 64 + i * 32 + l31;
@@ -303,7 +383,10 @@ gemm_lp128_kernel(gemm_args g)
 template <int DT, int DT_C, int NS>
 void launch_ns(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch, int slot)
 {
-    constexpr int LDS = NS * 2 * TILE_BYTES;
+    // operand stages, or the four per-wave epilogue scratch areas when those are larger (f32 C with one stage: 36 KiB)
+    constexpr int CSZ_ = DT_C == MI355_DTYPE_F32 ? 4 : 2;
+    constexpr int EPI = 4 * ((32 * (64 * CSZ_ + 16) + 1023) & ~1023);
+    constexpr int LDS = NS * 2 * TILE_BYTES > EPI ? NS * 2 * TILE_BYTES : EPI;
     if (LDS > 65536 && !(ctx->func_attr_mask & (1ull << slot))) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_lp128_kernel<DT, DT_C, NS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -313,12 +396,17 @@ void launch_ns(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch
                        dim3(256), LDS, s, g);
 }
 
+#ifndef SK1_MAX_TILES
+#define SK1_MAX_TILES 4   // K-tiles up to which the single-stage, four-workgroups-per-CU form is launched
+#endif
 template <int DT, int DT_C>
 void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch, int slot)
 {
     // one workgroup per CU at most: the deep (4-stage) pipeline; otherwise two co-resident 2-stage workgroups per CU
     const uint64_t wgs = (uint64_t)g.tiles_m * g.tiles_n * batch * (g.split_k > 1 ? g.split_k : 1);
+    constexpr int BK_ = ROW_BYTES / ((DT == MI355_DTYPE_F8E4M3 || DT == MI355_DTYPE_F8E5M2) ? 1 : 2);
     if (wgs <= (uint64_t)ctx->props.num_streaming_multiprocessors) launch_ns<DT, DT_C, 4>(ctx, s, g, batch, slot);
+    else if (g.k <= SK1_MAX_TILES * BK_ && g.split_k <= 1) launch_ns<DT, DT_C, 1>(ctx, s, g, batch, slot);   // four workgroups per CU
     else launch_ns<DT, DT_C, 2>(ctx, s, g, batch, slot);
 }
 

@@ -1,0 +1,21 @@
+"""dev: output-bound GEMMs (short K) on each candidate kernel (GPU box)."""
+import ctypes as C, sys, os
+sys.path.insert(0, ".")
+import bench
+from cubecl_amd import ElemType, Mi355Runtime, TensorHandle
+from cubecl_amd import _native as N
+client = Mi355Runtime.client(); lib, ctx = client.lib, client.ctx
+ev = bench.Events(client)
+NAMES = {0: "auto", 3: "lp128", 5: "w4", 6: "p"}
+for (m, n, k) in ((8192, 8192, 64), (8192, 8192, 128), (8192, 8192, 192), (8192, 8192, 256), (4096, 4096, 64), (4096, 4096, 128), (16384, 8192, 64), (2048, 2048, 128)):
+    a = TensorHandle.uniform(client, (m, k), ElemType.BF16, 1, 1, -1.0, 1.0); b = TensorHandle.uniform(client, (n, k), ElemType.BF16, 1, 2, -1.0, 1.0)
+    c = client.empty(m * n * 2)
+    line = []
+    for algo in (3, 5, 6, 0):
+        d = bench.gemm_desc(N, m, n, k, N.DTYPE_BF16, N.DTYPE_BF16, trans_b=1, algo=algo)
+        if lib.mi355_gemm(ctx, None, C.byref(d), a.device_ptr(), b.device_ptr(), c.device_ptr()) != 0:
+            line.append(f"{NAMES[algo]} --"); continue
+        best = min(bench.time_op(client, ev, lambda: lib.mi355_gemm(ctx, None, C.byref(d), a.device_ptr(), b.device_ptr(), c.device_ptr()), 20, warmup=3) for _ in range(5))
+        sel = C.c_int32(); lib.mi355_gemm_select(ctx, C.byref(d), C.byref(sel))
+        line.append(f"{NAMES[algo]}{'->' + NAMES.get(sel.value, str(sel.value)) if algo == 0 else ''} {best * 1e3:6.1f} us")
+    print(os.path.basename(os.environ.get("MI355CUBE_LIB", "product")), f"{m}x{n}x{k}: " + "  ".join(line), flush=True)
