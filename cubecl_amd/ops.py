@@ -99,14 +99,14 @@ def matmul(client: ComputeClient, lhs: TensorHandle, rhs: TensorHandle, out: Ten
                       stride_a=sa if ba == batch else 0, stride_b=sb if bb == batch else 0, stride_c=sc,
                       dtype_ab=int(lhs.dtype), dtype_c=int(out.dtype), trans_a=int(ta), trans_b=int(tb), algo=algo)
     if acc is None:
-        client._s.check(client.lib.mi355_gemm(client.ctx, client.stream, C.byref(desc), C.c_void_p(lhs.device_ptr()),
+        client._s.check(client.lib.mi355_gemm(client.ctx, client.on(lhs, rhs, out), C.byref(desc), C.c_void_p(lhs.device_ptr()),
                                               C.c_void_p(rhs.device_ptr()), C.c_void_p(out.device_ptr())))
         return
     if acc.dtype != out.dtype or tuple(acc.shape) != tuple(out.shape):
         raise ServerError(N.E_INVALID_ARGUMENT, "matmul: acc must have out's shape and dtype")
     if tuple(acc.strides) != tuple(out.strides):
         acc = _like(client, acc, out)                       # bring C into D's layout (copy_into)
-    client._s.check(client.lib.mi355_gemm_add(client.ctx, client.stream, C.byref(desc), C.c_void_p(lhs.device_ptr()),
+    client._s.check(client.lib.mi355_gemm_add(client.ctx, client.on(lhs, rhs, acc, out), C.byref(desc), C.c_void_p(lhs.device_ptr()),
                                               C.c_void_p(rhs.device_ptr()), C.c_void_p(acc.device_ptr()),
                                               C.c_void_p(out.device_ptr())))
 
@@ -155,7 +155,7 @@ def matmul_scaled(client: ComputeClient, lhs: TensorHandle, lhs_scales: TensorHa
                             stride_a=(sa if ba == batch else 0) * packed, stride_b=(sb if bb == batch else 0) * packed,
                             stride_c=sc, stride_sa=ssa if bsa == batch else 0, stride_sb=ssb if bsb == batch else 0,
                             dtype_a=int(lhs.dtype), dtype_b=int(rhs.dtype), dtype_c=int(out.dtype), block=block, algo=algo)
-    client._s.check(client.lib.mi355_gemm_scaled(client.ctx, client.stream, C.byref(desc), C.c_void_p(lhs.device_ptr()),
+    client._s.check(client.lib.mi355_gemm_scaled(client.ctx, client.on(lhs, lhs_scales, rhs, rhs_scales, out), C.byref(desc), C.c_void_p(lhs.device_ptr()),
                                                  C.c_void_p(lhs_scales.device_ptr()), C.c_void_p(rhs.device_ptr()),
                                                  C.c_void_p(rhs_scales.device_ptr()), C.c_void_p(out.device_ptr())))
 
@@ -176,7 +176,7 @@ _WORKSPACES: dict = {}
 
 
 def _workspace(client: ComputeClient, n: int) -> Handle:
-    key = id(client._s)
+    key = (id(client._s), client.stream_id())      # one per logical stream: two lanes may reduce at the same time
     need = C.c_uint64()
     client._s.check(client.lib.mi355_reduce_workspace_bytes(client.ctx, n, C.byref(need)))
     ws = _WORKSPACES.get(key)
@@ -211,7 +211,7 @@ def reduce_sum(client: ComputeClient, input: TensorHandle, output: TensorHandle)
     """Array-wide sum into output[0] (f32)."""
     input, n = _consumable(client, input, _require_flat_f32, "reduce_sum")
     ws = _workspace(client, n)
-    client._s.check(client.lib.mi355_reduce_sum(client.ctx, client.stream, C.c_void_p(input.device_ptr()), int(input.dtype), n,
+    client._s.check(client.lib.mi355_reduce_sum(client.ctx, client.on(input, output, ws), C.c_void_p(input.device_ptr()), int(input.dtype), n,
                                                 C.c_void_p(output.device_ptr()), C.c_void_p(ws.device_ptr()), ws.size))
 
 
@@ -221,7 +221,7 @@ def argmax(client: ComputeClient, input: TensorHandle, out_index: TensorHandle,
     input, n = _consumable(client, input, _require_flat_f32, "argmax")
     ws = _workspace(client, n)
     client._s.check(client.lib.mi355_argmax(
-        client.ctx, client.stream, C.c_void_p(input.device_ptr()), int(input.dtype), n,
+        client.ctx, client.on(input, out_value, out_index, ws), C.c_void_p(input.device_ptr()), int(input.dtype), n,
         C.c_void_p(out_value.device_ptr()) if out_value is not None else None,
         C.c_void_p(out_index.device_ptr()), C.c_void_p(ws.device_ptr()), ws.size))
 
@@ -232,7 +232,7 @@ def sum_argmax(client: ComputeClient, input: TensorHandle, out_sum: TensorHandle
     input, n = _consumable(client, input, _require_flat_f32, "sum_argmax")
     ws = _workspace(client, n)
     client._s.check(client.lib.mi355_sum_argmax(
-        client.ctx, client.stream, C.c_void_p(input.device_ptr()), int(input.dtype), n, C.c_void_p(out_sum.device_ptr()),
+        client.ctx, client.on(input, out_sum, out_value, out_index, ws), C.c_void_p(input.device_ptr()), int(input.dtype), n, C.c_void_p(out_sum.device_ptr()),
         C.c_void_p(out_value.device_ptr()) if out_value is not None else None,
         C.c_void_p(out_index.device_ptr()), C.c_void_p(ws.device_ptr()), ws.size))
 
@@ -244,7 +244,7 @@ def argmax_combine(client: ComputeClient, records: Handle, count: int, index_bas
     the single-GPU rule; `index_base[r]` is the first element of shard r.  Queued on the client's stream."""
     base = (C.c_uint64 * max(count, 1))(*[int(b) for b in (index_base or [0] * count)])
     client._s.check(client.lib.mi355_argmax_combine_f32(
-        client.ctx, client.stream, C.c_void_p(records.device_ptr()), count, base,
+        client.ctx, client.on(records, out_value, out_index), C.c_void_p(records.device_ptr()), count, base,
         C.c_void_p(out_value.device_ptr()) if out_value is not None else None,
         C.c_void_p(out_index.device_ptr()) if out_index is not None else None))
 
@@ -273,13 +273,13 @@ def reduce_sum_last_axis(client: ComputeClient, input: TensorHandle, output: Ten
     output shape = input shape minus the last axis."""
     input, (rows, cols, stride) = _consumable(client, input, _rows_view, "reduce_sum_last_axis")
     client._s.check(client.lib.mi355_reduce_last_axis_sum(
-        client.ctx, client.stream, C.c_void_p(input.device_ptr()), int(input.dtype), C.c_void_p(output.device_ptr()), rows, cols, stride))
+        client.ctx, client.on(input, output), C.c_void_p(input.device_ptr()), int(input.dtype), C.c_void_p(output.device_ptr()), rows, cols, stride))
 
 
 def argmax_last_axis(client: ComputeClient, input: TensorHandle, output: TensorHandle) -> None:
     input, (rows, cols, stride) = _consumable(client, input, _rows_view, "argmax_last_axis")
     client._s.check(client.lib.mi355_reduce_last_axis_argmax(
-        client.ctx, client.stream, C.c_void_p(input.device_ptr()), int(input.dtype), C.c_void_p(output.device_ptr()), rows, cols, stride))
+        client.ctx, client.on(input, output), C.c_void_p(input.device_ptr()), int(input.dtype), C.c_void_p(output.device_ptr()), rows, cols, stride))
 
 
 def _axis_view(t: TensorHandle, axis: int, what: str):
@@ -302,21 +302,21 @@ def _axis_view(t: TensorHandle, axis: int, what: str):
 def reduce_sum_axis(client: ComputeClient, input: TensorHandle, output: TensorHandle, axis: int) -> None:
     """Sum over one axis: output shape = input shape minus that axis (any axis; a strided view is made contiguous first)."""
     input, (outer, red, inner) = _consumable(client, input, lambda t, w: _axis_view(t, axis, w), "reduce_sum_axis")
-    client._s.check(client.lib.mi355_reduce_axis_sum(client.ctx, client.stream, C.c_void_p(input.device_ptr()), int(input.dtype),
+    client._s.check(client.lib.mi355_reduce_axis_sum(client.ctx, client.on(input, output), C.c_void_p(input.device_ptr()), int(input.dtype),
                                                      C.c_void_p(output.device_ptr()), outer, red, inner))
 
 
 def argmax_axis(client: ComputeClient, input: TensorHandle, output: TensorHandle, axis: int) -> None:
     """Argmax over one axis (u32 indices along that axis; lowest index wins ties, NaN ranks highest)."""
     input, (outer, red, inner) = _consumable(client, input, lambda t, w: _axis_view(t, axis, w), "argmax_axis")
-    client._s.check(client.lib.mi355_reduce_axis_argmax(client.ctx, client.stream, C.c_void_p(input.device_ptr()), int(input.dtype),
+    client._s.check(client.lib.mi355_reduce_axis_argmax(client.ctx, client.on(input, output), C.c_void_p(input.device_ptr()), int(input.dtype),
                                                         C.c_void_p(output.device_ptr()), outer, red, inner))
 
 
 def plane_reduce(client: ComputeClient, input: TensorHandle, output: TensorHandle, op: int, active: int = 64) -> None:
     """plane_sum / plane_prod / plane_max / plane_min / inclusive / exclusive sum over 64-lane planes."""
     n = input.num_elems()
-    client._s.check(client.lib.mi355_plane_reduce_f32(client.ctx, client.stream, C.c_void_p(input.device_ptr()),
+    client._s.check(client.lib.mi355_plane_reduce_f32(client.ctx, client.on(input, output), C.c_void_p(input.device_ptr()),
                                                       C.c_void_p(output.device_ptr()), n, active, op))
 
 
@@ -329,7 +329,7 @@ def identity(client: ComputeClient, output: TensorHandle) -> None:
         raise ServerError(N.E_INVALID_ARGUMENT, "identity: input should be a square matrix")
     if output.strides[1] != 1 and output.shape[1] > 1:
         raise ServerError(N.E_UNSUPPORTED_STRIDES, "identity: the matrix must be row-major")
-    client._s.check(client.lib.mi355_fill_identity(client.ctx, client.stream, C.c_void_p(output.device_ptr()), int(output.dtype),
+    client._s.check(client.lib.mi355_fill_identity(client.ctx, client.on(output), C.c_void_p(output.device_ptr()), int(output.dtype),
                                                    output.shape[0], max(output.strides[0], output.shape[1])))
 
 
@@ -340,7 +340,7 @@ def copy_into(client: ComputeClient, input: TensorHandle, output: TensorHandle) 
     if input.dtype.size() != output.dtype.size():
         raise ServerError(N.E_INVALID_ARGUMENT, "copy_into: element sizes differ")
     li, lo = N.TensorLayout.of(input.shape, input.strides), N.TensorLayout.of(output.shape, output.strides)
-    client._s.check(client.lib.mi355_copy_strided(client.ctx, client.stream, C.c_void_p(input.device_ptr()), C.byref(li),
+    client._s.check(client.lib.mi355_copy_strided(client.ctx, client.on(input, output), C.c_void_p(input.device_ptr()), C.byref(li),
                                                   C.c_void_p(output.device_ptr()), C.byref(lo), input.dtype.size()))
 
 
@@ -385,7 +385,7 @@ def into_contiguous_packed(client: ComputeClient, input: TensorHandle, packed_di
     output = TensorHandle.empty(client, out_shape, input.dtype)
     li, lo = N.TensorLayout.of(input.shape, input.strides), N.TensorLayout.of(output.shape, output.strides)
     logical = (C.c_int64 * rank)(*[int(d) for d in shape])
-    client._s.check(client.lib.mi355_copy_packed(client.ctx, client.stream, C.c_void_p(input.device_ptr()), C.byref(li),
+    client._s.check(client.lib.mi355_copy_packed(client.ctx, client.on(input, output), C.c_void_p(input.device_ptr()), C.byref(li),
                                                  C.c_void_p(output.device_ptr()), C.byref(lo), logical, packed_dim, packing,
                                                  input.dtype.size()))
     return output

@@ -203,15 +203,28 @@ class _Memory:
     """A reservation from the server's memory pool (ManagedMemoryHandle); goes back to the pool when the last
     Handle drops, on the stream the client works on, so the pool may hand it out again stream-ordered."""
 
-    __slots__ = ("server", "ptr", "size", "stream", "__weakref__")
+    __slots__ = ("server", "ptr", "size", "stream", "lane", "cursor", "users", "__weakref__")
 
-    def __init__(self, server: "_Server", ptr: int, size: int, stream=None):
+    def __init__(self, server: "_Server", ptr: int, size: int, stream=None, lane: int = 0, cursor: int = 0):
         self.server, self.ptr, self.size, self.stream = server, ptr, size, stream
+        # the logical stream that bound the memory and that stream's cursor at its last use there: what another stream
+        # compares with what it has already waited for (MultiStream::resolve, stream/event.rs)
+        self.lane, self.cursor = lane, cursor
+        self.users = None        # other lanes that were handed this memory (they must be done before it is recycled)
 
     def __del__(self):
         try:
             if self.ptr and self.server is not None and self.server.ctx:
-                self.server.lib.mi355_pool_free(self.server.ctx, self.stream, C.c_void_p(self.ptr))
+                srv = self.server
+                for index in self.users or ():
+                    # the reverse hazard of a cross-lane use (the reference pins the binding until a GC fence): the freeing
+                    # lane waits, on the device, for what the borrowing lane has issued
+                    ev = C.c_void_p()
+                    if srv.lib.mi355_event_create(srv.ctx, C.byref(ev)) == N.OK:
+                        srv.lib.mi355_event_record(srv.ctx, ev, srv.lanes[index].sys)
+                        srv.lib.mi355_stream_wait_event(srv.ctx, self.stream, ev)
+                        srv.lib.mi355_event_destroy(srv.ctx, ev)
+                srv.lib.mi355_pool_free(srv.ctx, self.stream, C.c_void_p(self.ptr))
         except Exception:
             pass
 
@@ -295,11 +308,24 @@ def has_pitched_row_major_strides(shape: Sequence[int], strides: Sequence[int]) 
 # ----------------------------------------------------------------------------------------------
 # server + client
 # ----------------------------------------------------------------------------------------------
+MAX_STREAMS = 128   # StreamingConfig::max_streams default (config/streaming.rs:43-45)
+
+
+class _Lane:
+    """One logical stream of a server (StreamWrapper, stream/event.rs): the native stream, a cursor that advances with
+    every operation resolved on it, and for every other lane the cursor of that lane this one has already waited for."""
+
+    __slots__ = ("index", "sys", "cursor", "last_synced", "waits")
+
+    def __init__(self, index: int, sys):
+        self.index, self.sys, self.cursor, self.last_synced, self.waits = index, sys, 0, {}, 0
+
+
 class _Server:
     """One per DeviceId (HipServer analogue); owns the C context."""
 
-    def __init__(self, device: DeviceId):
-        self.lib = N.load()
+    def __init__(self, device: DeviceId, lib=None):
+        self.lib = lib if lib is not None else N.load()     # `lib`: a differently built copy of the same ABI (tests)
         self.device = device
         ctx = C.c_void_p()
         rc = self.lib.mi355_ctx_create(device.index_id, C.byref(ctx))
@@ -310,6 +336,18 @@ class _Server:
         self.check(self.lib.mi355_device_props(self.ctx, C.byref(props)))
         self.props = props
         self.comms: dict = {}
+        self.lanes: dict = {0: _Lane(0, C.c_void_p(None))}     # lane 0 = the context's own compute stream
+
+    def lane(self, stream_id: int) -> "_Lane":
+        """The lane of a logical StreamId: `stream_id % MAX_STREAMS` (stream_index, stream/event.rs), its mi355_stream
+        created on first use (EventStreamBackend::create_stream)."""
+        index = int(stream_id) % MAX_STREAMS
+        lane = self.lanes.get(index)
+        if lane is None:
+            sys = C.c_void_p()
+            self.check(self.lib.mi355_stream_create(self.ctx, C.byref(sys)))
+            lane = self.lanes[index] = _Lane(index, sys)
+        return lane
 
     def check(self, rc: int) -> None:
         if rc == N.OK:
@@ -333,6 +371,10 @@ class _Server:
             for comm in self.comms.values():
                 self.lib.mi355_comm_destroy(self.ctx, comm)
             self.comms.clear()
+            for lane in self.lanes.values():
+                if lane.sys:
+                    self.lib.mi355_stream_destroy(self.ctx, lane.sys)
+            self.lanes = {0: _Lane(0, C.c_void_p(None))}
             self.lib.mi355_ctx_destroy(self.ctx)
             self.ctx = None
 
@@ -384,7 +426,59 @@ class ComputeClient:
         self._s = server
         self.lib = server.lib
         self.ctx = server.ctx
-        self.stream = C.c_void_p(None)  # NULL = the context's compute stream
+        self._lane = server.lanes[0]    # StreamId 0: the context's own compute stream (NULL in the C ABI)
+
+    # -- logical streams -------------------------------------------------------------------------
+    @property
+    def stream(self):
+        """The mi355_stream of the lane this client currently issues on."""
+        return self._lane.sys
+
+    def stream_id(self) -> int:
+        return self._lane.index
+
+    def set_stream(self, stream_id: int) -> "ComputeClient":
+        """ComputeClient::set_stream (client.rs:217): everything this client issues from now on goes to the lane of
+        `stream_id`.  Memory keeps the lane that created it; using it from another lane inserts the device-side wait
+        (see `on`)."""
+        self._lane = self._s.lane(stream_id)
+        return self
+
+    def with_stream(self, stream_id: int) -> "ComputeClient":
+        """A second client of the same server pinned to another logical stream (what a thread with its own
+        StreamId::current() sees in the reference)."""
+        other = ComputeClient(self._s)
+        return other.set_stream(stream_id)
+
+    def on(self, *handles):
+        """MultiStream::resolve (stream/event.rs) for one operation: advance this lane's cursor; for every binding that
+        lives on another lane and whose cursor this lane has not yet waited for, record an event behind the origin lane's
+        work (EventStreamBackend::flush) and make this lane's stream wait for it on the device
+        (EventStreamBackend::wait_event = mi355_stream_wait_event).  Returns the stream to issue on."""
+        lane = self._lane
+        lane.cursor += 1
+        origins = {}
+        for h in handles:
+            mem = getattr(getattr(h, "handle", h), "memory", None)
+            if mem is None or mem.server is not self._s:
+                continue
+            if mem.lane == lane.index:
+                mem.cursor = lane.cursor              # last use on its own lane
+            else:
+                if mem.users is None:
+                    mem.users = set()
+                mem.users.add(lane.index)
+                if lane.last_synced.get(mem.lane, -1) < mem.cursor:
+                    origins[mem.lane] = self._s.lanes[mem.lane]
+        for index, origin in origins.items():
+            ev = C.c_void_p()
+            self._s.check(self.lib.mi355_event_create(self.ctx, C.byref(ev)))
+            self._s.check(self.lib.mi355_event_record(self.ctx, ev, origin.sys))
+            self._s.check(self.lib.mi355_stream_wait_event(self.ctx, lane.sys, ev))
+            self._s.check(self.lib.mi355_event_destroy(self.ctx, ev))
+            lane.last_synced[index] = origin.cursor   # everything the origin lane has issued so far is covered
+            lane.waits += 1
+        return lane.sys
 
     # -- properties --------------------------------------------------------------------------
     def properties(self) -> N.DeviceProps:
@@ -445,8 +539,10 @@ class ComputeClient:
     def empty(self, size: int) -> Handle:
         """client.empty: a reservation from the memory pool (memory_manage.rs:1084), not a driver allocation."""
         ptr = C.c_void_p()
-        self._s.check(self.lib.mi355_pool_alloc(self.ctx, self.stream, size, C.byref(ptr)))
-        return Handle(_Memory(self._s, ptr.value or 0, size, self.stream), None, None, size)
+        lane = self._lane
+        lane.cursor += 1
+        self._s.check(self.lib.mi355_pool_alloc(self.ctx, lane.sys, size, C.byref(ptr)))
+        return Handle(_Memory(self._s, ptr.value or 0, size, lane.sys, lane.index, lane.cursor), None, None, size)
 
     def create_from_slice(self, data) -> Handle:
         buf = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
@@ -460,7 +556,7 @@ class ComputeClient:
         buf = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
         if buf.nbytes > handle.size_in_used():
             raise ServerError(N.E_INVALID_ARGUMENT, "write larger than the handle")
-        self._s.check(self.lib.mi355_write(self.ctx, self.stream, C.c_void_p(handle.device_ptr()),
+        self._s.check(self.lib.mi355_write(self.ctx, self.on(handle), C.c_void_p(handle.device_ptr()),
                                            buf.ctypes.data_as(C.c_void_p), buf.nbytes))
         # the host buffer must outlive the copy (command.rs:402): complete it before returning
         self._s.check(self.lib.mi355_sync(self.ctx, self.stream))
@@ -494,7 +590,7 @@ class ComputeClient:
             return self.write(desc.handle, data)
         width = desc.shape[-1] * desc.elem_size
         rows = int(np.prod(desc.shape[:-1]))
-        self._s.check(self.lib.mi355_write_2d(self.ctx, self.stream, C.c_void_p(desc.handle.device_ptr()),
+        self._s.check(self.lib.mi355_write_2d(self.ctx, self.on(desc.handle), C.c_void_p(desc.handle.device_ptr()),
                                               desc.strides[-2] * desc.elem_size, data.ctypes.data_as(C.c_void_p),
                                               width, width, rows))
         self._s.check(self.lib.mi355_sync(self.ctx, self.stream))
@@ -503,7 +599,7 @@ class ComputeClient:
         """Returns the bytes; raises ServerError (incl. queued launch errors) like read_one."""
         n = handle.size_in_used()
         out = np.empty(n, dtype=np.uint8)
-        self._s.check(self.lib.mi355_read(self.ctx, self.stream, out.ctypes.data_as(C.c_void_p),
+        self._s.check(self.lib.mi355_read(self.ctx, self.on(handle), out.ctypes.data_as(C.c_void_p),
                                           C.c_void_p(handle.device_ptr()), n))
         return out
 
@@ -521,12 +617,12 @@ class ComputeClient:
         if n == 0:
             return out
         if len(desc.shape) < 2 or desc.strides[-2] == desc.shape[-1]:
-            self._s.check(self.lib.mi355_read(self.ctx, self.stream, out.ctypes.data_as(C.c_void_p),
+            self._s.check(self.lib.mi355_read(self.ctx, self.on(desc.handle), out.ctypes.data_as(C.c_void_p),
                                               C.c_void_p(desc.handle.device_ptr()), n))
             return out
         width = desc.shape[-1] * desc.elem_size
         rows = int(np.prod(desc.shape[:-1]))
-        self._s.check(self.lib.mi355_read_2d(self.ctx, self.stream, out.ctypes.data_as(C.c_void_p), width,
+        self._s.check(self.lib.mi355_read_2d(self.ctx, self.on(desc.handle), out.ctypes.data_as(C.c_void_p), width,
                                              C.c_void_p(desc.handle.device_ptr()), desc.strides[-2] * desc.elem_size,
                                              width, rows))
         return out
@@ -543,7 +639,8 @@ class ComputeClient:
         arr = (C.c_void_p * max(len(ptrs), 1))(*ptrs)
         grid = (C.c_uint32 * 3)(cube_count.x, cube_count.y, cube_count.z)
         block = (C.c_uint32 * 3)(cube_dim.x, cube_dim.y, cube_dim.z)
-        self._s.check(self.lib.mi355_launch(self.ctx, self.stream, function, grid, block, shared_mem_bytes, arr, len(ptrs)))
+        stream = self.on(*resources, *([info] if info is not None else []))
+        self._s.check(self.lib.mi355_launch(self.ctx, stream, function, grid, block, shared_mem_bytes, arr, len(ptrs)))
 
     def load_module(self, image: bytes):
         mod = C.c_void_p()
@@ -560,22 +657,22 @@ class ComputeClient:
         client's device.  A peer copy over xGMI, stream-ordered on both sides (no host round trip, no sync)."""
         nbytes = src.size_in_used()
         out = dst_client.empty(nbytes)
-        self._s.check(self.lib.mi355_copy_to_ctx(self.ctx, self.stream, C.c_void_p(src.device_ptr()), dst_client.ctx,
-                                                 dst_client.stream, C.c_void_p(out.device_ptr()), nbytes))
+        self._s.check(self.lib.mi355_copy_to_ctx(self.ctx, self.on(src), C.c_void_p(src.device_ptr()), dst_client.ctx,
+                                                 dst_client.on(out), C.c_void_p(out.device_ptr()), nbytes))
         return out
 
     def send(self, src: Handle, dtype: ElemType, device_ids: Sequence[DeviceId], peer: DeviceId) -> None:
         """ServerCommunication::send (server/base.rs:694-713) to the rank of `peer` in the sorted id list."""
         key = tuple(sorted(device_ids))
         n = src.size_in_used() // ElemType(dtype).size()
-        self._s.check(self.lib.mi355_send(self.ctx, self._s.comms[key], self.stream, C.c_void_p(src.device_ptr()), n,
+        self._s.check(self.lib.mi355_send(self.ctx, self._s.comms[key], self.on(src), C.c_void_p(src.device_ptr()), n,
                                           int(dtype), key.index(peer)))
 
     def recv(self, dst: Handle, dtype: ElemType, device_ids: Sequence[DeviceId], peer: DeviceId) -> None:
         """ServerCommunication::recv (server/base.rs:715-736)."""
         key = tuple(sorted(device_ids))
         n = dst.size_in_used() // ElemType(dtype).size()
-        self._s.check(self.lib.mi355_recv(self.ctx, self._s.comms[key], self.stream, C.c_void_p(dst.device_ptr()), n,
+        self._s.check(self.lib.mi355_recv(self.ctx, self._s.comms[key], self.on(dst), C.c_void_p(dst.device_ptr()), n,
                                           int(dtype), key.index(peer)))
 
     def flush(self) -> None:
@@ -659,7 +756,7 @@ class ComputeClient:
         if comm is None:
             raise ServerError(N.E_COMM, "all_reduce before comm_init for this device set")
         count = src.size_in_used() // ElemType(dtype).size()  # get_nccl_dtype_count
-        self._s.check(self.lib.mi355_all_reduce(self.ctx, comm, self.stream, C.c_void_p(src.device_ptr()),
+        self._s.check(self.lib.mi355_all_reduce(self.ctx, comm, self.on(src, dst), C.c_void_p(src.device_ptr()),
                                                 C.c_void_p(dst.device_ptr()), count, int(dtype), int(op)))
 
     def all_gather(self, src: Handle, dst: Handle, dtype: ElemType, device_ids: Sequence[DeviceId]) -> None:
@@ -668,7 +765,7 @@ class ComputeClient:
         if comm is None:
             raise ServerError(N.E_COMM, "all_gather before comm_init for this device set")
         count = src.size_in_used() // ElemType(dtype).size()
-        self._s.check(self.lib.mi355_all_gather(self.ctx, comm, self.stream, C.c_void_p(src.device_ptr()),
+        self._s.check(self.lib.mi355_all_gather(self.ctx, comm, self.on(src, dst), C.c_void_p(src.device_ptr()),
                                                 C.c_void_p(dst.device_ptr()), count, int(dtype)))
 
     def sync_collective(self) -> None:

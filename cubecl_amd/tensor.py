@@ -44,7 +44,7 @@ class TensorHandle:
     @staticmethod
     def zeros(client: ComputeClient, shape: Sequence[int], dtype: ElemType) -> "TensorHandle":
         t = TensorHandle.empty(client, shape, dtype)
-        client._s.check(client.lib.mi355_memset(client.ctx, client.stream, C.c_void_p(t.handle.device_ptr()), 0,
+        client._s.check(client.lib.mi355_memset(client.ctx, client.on(t.handle), C.c_void_p(t.handle.device_ptr()), 0,
                                                 t.handle.size_in_used()))
         return t
 
@@ -63,7 +63,7 @@ class TensorHandle:
         """On-device counter-based fill, bit-identical to oracle_fill_uniform_f32 (+RNE cast)."""
         n = int(np.prod(shape))
         handle = client.empty(n * ElemType(dtype).size())
-        client._s.check(client.lib.mi355_fill_uniform(client.ctx, client.stream, C.c_void_p(handle.device_ptr()),
+        client._s.check(client.lib.mi355_fill_uniform(client.ctx, client.on(handle), C.c_void_p(handle.device_ptr()),
                                                       int(dtype), n, seed, tensor_id, lo, hi))
         return TensorHandle.new_contiguous(shape, handle, dtype)
 

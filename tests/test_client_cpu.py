@@ -30,13 +30,7 @@ def fake():
 
 
 def _client(lib, index=0) -> ComputeClient:
-    s = _Server.__new__(_Server)
-    s.lib, s.device, s.comms = lib, DeviceId(0, index), {}
-    ctx = C.c_void_p()
-    assert lib.mi355_ctx_create(index, C.byref(ctx)) == N.OK
-    s.ctx, s.props = ctx, N.DeviceProps()
-    s.check(lib.mi355_device_props(ctx, C.byref(s.props)))
-    return ComputeClient(s)
+    return ComputeClient(_Server(DeviceId(0, index), lib=lib))
 
 
 @pytest.fixture()
@@ -206,3 +200,65 @@ def test_advertised_types_atomics_and_mma_properties_follow_the_reference_regist
         st = rp[rp.index("pub struct MmaProperties"):]
         fields = re.findall(r"pub (\w+):", st[: st.index("\n}")])
         assert set(fields) - {"contiguous_elements"} == set(m) - {"contiguous_elements"} and "contiguous_elements" in fields
+
+
+def _stream_log(lib):
+    lib.faketest_stream_log.argtypes = [C.POINTER(C.c_uint64)]
+    out = (C.c_uint64 * 4)()
+    lib.faketest_stream_log(out)
+    return list(out)
+
+
+def test_logical_streams_wait_for_each_other_only_when_a_binding_crosses(client, fake):
+    """ComputeClient::set_stream + MultiStream::resolve (crates/cubecl-runtime/src/stream/event.rs:20-78, :150-330) on the
+    Python mirror: a StreamId maps to a lane (`id % max_streams`) with its own mi355_stream; an operation whose binding was
+    created on another lane records an event there and makes the issuing lane's stream wait for it -- once per new
+    cursor, not per use -- and the freeing lane waits for the borrower before the memory goes back to the pool."""
+    a = client.with_stream(1)
+    b = client.with_stream(2)
+    assert (client.stream_id(), a.stream_id(), b.stream_id()) == (0, 1, 2)
+    assert client.with_stream(1 + 128).stream_id() == 1                      # stream_index = id % max_streams
+    assert a.stream.value and b.stream.value and a.stream.value != b.stream.value and not client.stream.value
+    assert client.with_stream(1).stream.value == a.stream.value             # one native stream per lane
+
+    w0 = _stream_log(fake)[1]
+    x = a.create_from_slice(np.arange(256, dtype=np.float32))               # lane 1 binds and writes
+    assert x.memory.lane == 1 and _stream_log(fake)[1] == w0                 # same lane: no wait
+    assert np.array_equal(a.read_one(x).view(np.float32), np.arange(256, dtype=np.float32))
+    assert _stream_log(fake)[1] == w0
+
+    got = b.read_one(x)                                                      # lane 2 reads lane 1's buffer
+    log = _stream_log(fake)
+    assert np.array_equal(got.view(np.float32), np.arange(256, dtype=np.float32))
+    assert log[1] == w0 + 1 and log[2] == b.stream.value                     # one hipStreamWaitEvent, on lane 2's stream
+    b.read_one(x)                                                            # already waited for that cursor
+    assert _stream_log(fake)[1] == w0 + 1
+    a.write(x, np.ones(256, dtype=np.float32))                               # lane 1 touches it again: its cursor moves
+    assert _stream_log(fake)[1] == w0 + 1
+    assert np.array_equal(b.read_one(x).view(np.float32), np.ones(256, dtype=np.float32))
+    assert _stream_log(fake)[1] == w0 + 2                                    # ... so lane 2 waits again
+    assert b._lane.waits == 2 and a._lane.waits == 0
+
+    # a kernel launch resolves every binding: two foreign lanes -> two waits on the launching lane
+    y = b.create_from_slice(np.zeros(64, dtype=np.float32))
+    c = client.with_stream(3)
+    mod = c.load_module(b"FAKEHSACO")
+    fn = c.get_function(mod, "k")
+    from cubecl_amd.runtime import CubeCount, CubeDim
+    before = _stream_log(fake)[1]
+    fake.faketest_expect_params(2)
+    c.launch(fn, CubeCount(1, 1, 1), CubeDim(64, 1, 1), [x, y])
+    log = _stream_log(fake)
+    assert log[1] == before + 2 and log[2] == c.stream.value
+    c.launch(fn, CubeCount(1, 1, 1), CubeDim(64, 1, 1), [x, y])
+    assert _stream_log(fake)[1] == before + 2
+
+    # recycling: lane 1 frees x, which lanes 2 and 3 borrowed -> lane 1's stream waits for both before mi355_pool_free
+    assert x.memory.users == {2, 3}
+    before = _stream_log(fake)[1]
+    stream_a = a.stream.value
+    del x, got
+    import gc
+    gc.collect()
+    log = _stream_log(fake)
+    assert log[1] == before + 2 and log[2] == stream_a

@@ -774,3 +774,38 @@ def test_pool_randomised_alloc_free_keeps_every_live_block_intact(client):
     assert end.cache_hits > base.cache_hits
     client._s.check(lib.mi355_stream_destroy(ctx, s2))
     client.memory_cleanup()
+
+
+def test_logical_streams_order_work_across_lanes_on_the_device(client, oracle):
+    """The async contract of SURVEY.md 8(b) on hardware: three logical streams (ComputeClient::set_stream), each with its
+    own non-blocking mi355_stream.  Lane 1 fills two large operands and lane 2 multiplies them straight away -- without the
+    event wait `on()` inserts, lane 2's GEMM would start while the fills are still running (the fills take ~100 us, the
+    launch a few) -- then lane 3 reduces lane 2's product.  Results must equal the single-stream run bit for bit, and the
+    waits must have been inserted exactly where a binding crossed lanes."""
+    from cubecl_amd import ops
+    m = 2048
+    base = TensorHandle.uniform(client, (m, m), ElemType.BF16, 5, 1, -1.0, 1.0)
+    base_b = TensorHandle.uniform(client, (m, m), ElemType.BF16, 5, 2, -1.0, 1.0)
+    want = TensorHandle.new_contiguous((m, m), client.empty(m * m * 4), ElemType.F32)
+    ops.matmul(client, base, TensorHandle.new(base_b.handle, (m, m), (1, m), ElemType.BF16), want)
+    want_sum = TensorHandle.new_contiguous((1,), client.empty(4), ElemType.F32)
+    ops.reduce_sum(client, TensorHandle.new_contiguous((m * m,), want.handle, ElemType.F32), want_sum)
+    want_c, want_s = want.to_numpy(client).copy(), want_sum.to_numpy(client).copy()
+
+    l1, l2, l3 = client.with_stream(11), client.with_stream(12), client.with_stream(13)
+    assert len({l1.stream.value, l2.stream.value, l3.stream.value}) == 3
+    for rep in range(5):
+        a = TensorHandle.uniform(l1, (m, m), ElemType.BF16, 5, 1, -1.0, 1.0)        # lane 1: the fills
+        b = TensorHandle.uniform(l1, (m, m), ElemType.BF16, 5, 2, -1.0, 1.0)
+        w2 = l2._lane.waits
+        c = TensorHandle.new_contiguous((m, m), l2.empty(m * m * 4), ElemType.F32)
+        ops.matmul(l2, a, TensorHandle.new(b.handle, (m, m), (1, m), ElemType.BF16), c)    # lane 2 consumes lane 1's buffers
+        assert l2._lane.waits == w2 + 1                                          # one wait covers both (same origin lane)
+        w3 = l3._lane.waits
+        s = TensorHandle.new_contiguous((1,), l3.empty(4), ElemType.F32)
+        ops.reduce_sum(l3, TensorHandle.new_contiguous((m * m,), c.handle, ElemType.F32), s)   # lane 3 consumes lane 2's product
+        assert l3._lane.waits == w3 + 1
+        got_s = s.to_numpy(l3)                                                    # read on lane 3: its own buffer, no new wait
+        assert l3._lane.waits == w3 + 1
+        got_c = c.to_numpy(client)                                                # lane 0 reads lane 2's buffer: waits for it
+        assert np.array_equal(got_c, want_c) and np.array_equal(got_s, want_s), rep
