@@ -159,7 +159,7 @@ KERNEL_SOURCES = {
 }
 PROFILES_DIR = ROOT / "profiles"
 HEADLINE_KERNEL = "gemm_lp256w4_kernel<1, 1, false, 1, false>"     # bf16 x bf16 -> bf16 C, [N][K] B, unscaled (what rocprofv3 prints)
-REDUCE_SUM_KERNEL = "reduce_kernel<true, false>"
+REDUCE_SUM_KERNEL = "reduce_kernel<true, false, 0>"      # <SUM, ARGMAX, DT = f32>
 
 
 def kernel_source_sha(kind):

@@ -67,7 +67,7 @@ for r in rows_of("reduce"):
     if "reduce_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
         agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
 for k, v in agg.items():
-    name = "sum" if "<true, false>" in k else "argmax" if "<false, true>" in k else "sum_argmax"
+    name = "sum" if "<true, false" in k else "argmax" if "<false, true" in k else "sum_argmax"   # <SUM, ARG, DT>
     traffic[f"reduce_1GiB_{name}"] = dict(stamp, kernel=k[:120], source_sha=bench.kernel_source_sha("reduce"),
         fetch_bytes=int(statistics.median(v) * 1024 * 2), algorithmic_bytes=1 << 30, FETCH_SIZE_KiB_raw=statistics.median(v), launches=len(v))
 json.dump(traffic, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
