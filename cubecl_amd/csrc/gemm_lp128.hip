@@ -71,8 +71,15 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
 // LDS-DMA as `global_load_lds_dwordx4 v_off, s[base:base+1]`: wave-uniform 64-bit base + constant 32-bit lane offset, LDS
 // destination through M0 (set in the same statement); see gemm_lp256w4.hip.  Not counted by the compiler: every wait on
 // these loads in this file is explicit.
-__device__ __forceinline__ void glds16_s(const void *ubase, uint32_t voff, uint32_t lds_byte_addr)
+__device__ __forceinline__ void glds16_s(const void *ubase_in, uint32_t voff, uint32_t lds_in)
 {
+    // wave-uniform by construction; said again here because hipcc's divergence analysis loses it behind role branches
+    // (the "s" constraint then gets a VGPR pair and the assembler rejects the instruction).  Free when already scalar.
+    const uint64_t u = reinterpret_cast<uint64_t>(ubase_in);
+    const uint64_t us = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+    const void *ubase = reinterpret_cast<const void *>(us);
+    const uint32_t lds_byte_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_in);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ubase), "s"(lds_byte_addr) : "memory");
 }
 __device__ __forceinline__ uint32_t lds_addr_of(const void *p)
@@ -80,10 +87,16 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void *p)
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)p;
 }
 
-template <int DT, int DT_C, int NS = 2>
-__global__ void __launch_bounds__(256, NS == 1 ? 4 : NS == 2 ? 2 : 1)
+// SPEC (with the 4-stage ring only): eight waves, four that multiply and four that do nothing but issue the LDS-DMA pieces
+// and wait for them.  One `global_load_lds_dwordx4` costs the wave that issues it 60-185 cycles of its instruction stream
+// (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"); at eight pieces per wave and K-tile that is more than the 512 cycles
+// the K-tile's 16 MFMAs take, so a wave that does both starves its matrix pipe.  The loader waves own `vmcnt`; the
+// multiplying waves see the ring only through the one s_barrier per K-tile.
+template <int DT, int DT_C, int NS = 2, bool SPEC = false>
+__global__ void __launch_bounds__(SPEC ? 512 : 256, NS == 1 ? 4 : NS == 2 ? (SPEC ? 4 : 2) : SPEC ? 2 : 1)
 gemm_lp128_kernel(gemm_args g)
 {
+    static_assert(!SPEC || NS == 4 || NS == 2, "loader waves are written for the 2-stage and the 4-stage ring");
     // [stage][operand][16 KiB]; one array only (a second __shared__ object de-pipelines LDS-DMA
     // loops: guide section 5, ".s-level traps" (a))
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -91,7 +104,9 @@ gemm_lp128_kernel(gemm_args g)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = SPEC && wave_all >= 4;                 // waves 4..7: DMA issue only
+    const int wave = SPEC ? (wave_all & 3) : wave_all;                             // position in the DMA map / in the 2 x 2 wave grid
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
 
@@ -208,6 +223,38 @@ gemm_lp128_kernel(gemm_args g)
             }
             mfmas(B1{});
         }
+    } else if constexpr (NS == 2 && SPEC) {
+        // two stages, loader waves: the loaders fetch K-tile kt+1 while the others multiply K-tile kt; one raw barrier per
+        // K-tile hands the buffers over (the loaders wait for their DMA before it, the multiplying waves have consumed their
+        // fragment reads before it)
+        if (loader) {
+            if (nk > 0) stage(0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            for (int kt = 0; kt < nk; ++kt) {
+                if (kt + 1 < nk) stage((kt & 1) ^ 1, kt + 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            }
+            return;
+        }
+        __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < nk; ++kt) {
+            const char *la = smem + (kt & 1) * 2 * TILE_BYTES;
+            const char *lb = la + TILE_BYTES;
+            reads(B0{}, la, lb, 0);
+            reads(B1{}, la, lb, 1); mfmas(B0{});
+            if constexpr (NSTEP == 4) {
+                reads(B0{}, la, lb, 2); mfmas(B1{});
+                reads(B1{}, la, lb, 3); mfmas(B0{});
+            }
+            mfmas(B1{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
     } else if constexpr (NS == 2) {
         if (nk > 0) stage(0, 0);
         __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) lgkmcnt(0) expcnt(0)
@@ -236,41 +283,62 @@ gemm_lp128_kernel(gemm_args g)
         // LAST k-step, so that the next tile's first fragments are fetched under its four MFMAs (as gemm_lp256w4.hip).
         // vmcnt is counted: 8 DMA instructions per wave and K-tile, loads complete in order.
         static_assert(NS == 4, "the counted waits below are written for four stages");
+        const bool issues = !SPEC || loader, multiplies = !SPEC || !loader;
+        if (issues) {
 #pragma unroll
-        for (int p = 0; p < NS - 1; ++p)
-            if (p < nk) stage(p, p);
-        if (nk >= 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // K-tile 0 landed; tiles 1, 2 may fly
-        else if (nk == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int p = 0; p < NS - 1; ++p)
+                if (p < nk) stage(p, p);
+            if (nk >= 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // K-tile 0 landed; tiles 1, 2 may fly
+            else if (nk == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (nk > 0) reads(B0{}, smem, smem + TILE_BYTES, 0);
-        for (int kt = 0; kt < nk; ++kt) {
-            const char *la = smem + (kt % NS) * 2 * TILE_BYTES;
-            const char *lb = la + TILE_BYTES;
-            reads(B1{}, la, lb, 1); mfmas(B0{});
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (NSTEP == 4) {
-                reads(B0{}, la, lb, 2); mfmas(B1{});
-                __builtin_amdgcn_sched_barrier(0);
-                reads(B1{}, la, lb, 3); mfmas(B0{});
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (kt + 1 < nk) {
-                // K-tile kt+1 landed: only tile kt+2 (issued in the previous iteration or the prologue) may still fly
+        if (SPEC && loader) {
+            // the loader's whole K loop: wait for K-tile kt+1, meet the multiplying waves at their barrier inside K-tile kt
+            // (everybody is then past K-tile kt-1), refill that slot with K-tile kt+3
+            for (int kt = 0; kt + 1 < nk; ++kt) {
                 if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();   // raw: __syncthreads() carries a release fence = vmcnt(0), which would drain the ring
+                __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                // everybody is past K-tile kt-1: its buffer takes K-tile kt+3
                 if (kt + NS - 1 < nk) stage((kt + NS - 1) % NS, kt + NS - 1);
-                const char *na = smem + ((kt + 1) % NS) * 2 * TILE_BYTES;
-                reads(B0{}, na, na + TILE_BYTES, 0);
             }
-            mfmas(B1{});
-            __builtin_amdgcn_sched_barrier(0);
+            return;                                         // a finished wave no longer counts at the workgroup's barriers
+        }
+        if (multiplies) {
+            if (nk > 0) reads(B0{}, smem, smem + TILE_BYTES, 0);
+            for (int kt = 0; kt < nk; ++kt) {
+                const char *la = smem + (kt % NS) * 2 * TILE_BYTES;
+                const char *lb = la + TILE_BYTES;
+                reads(B1{}, la, lb, 1); mfmas(B0{});
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (NSTEP == 4) {
+                    reads(B0{}, la, lb, 2); mfmas(B1{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    reads(B1{}, la, lb, 3); mfmas(B0{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (kt + 1 < nk) {
+                    if constexpr (!SPEC) {
+                        // K-tile kt+1 landed: only tile kt+2 (issued in the previous iteration or the prologue) may still fly
+                        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    __builtin_amdgcn_s_barrier();   // raw: __syncthreads() carries a release fence = vmcnt(0), which would drain the ring
+                    __builtin_amdgcn_sched_barrier(0);
+                    // everybody is past K-tile kt-1: its buffer takes K-tile kt+3
+                    if constexpr (!SPEC)
+                        if (kt + NS - 1 < nk) stage((kt + NS - 1) % NS, kt + NS - 1);
+                    const char *na = smem + ((kt + 1) % NS) * 2 * TILE_BYTES;
+                    reads(B0{}, na, na + TILE_BYTES, 0);
+                }
+                mfmas(B1{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 
@@ -380,7 +448,13 @@ gemm_lp128_kernel(gemm_args g)
     }
 }
 
-template <int DT, int DT_C, int NS>
+#ifndef LP128_SPEC2
+#define LP128_SPEC2 1  // dev: 0 = the two-stage form without loader waves
+#endif
+#ifndef LP128_SPEC
+#define LP128_SPEC 1   // dev: 0 = the 4-stage ring without loader waves
+#endif
+template <int DT, int DT_C, int NS, bool SPEC = false>
 void launch_ns(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch, int slot)
 {
     // operand stages, or the four per-wave epilogue scratch areas when those are larger (f32 C with one stage: 36 KiB)
@@ -388,12 +462,12 @@ void launch_ns(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch
     constexpr int EPI = 4 * ((32 * (64 * CSZ_ + 16) + 1023) & ~1023);
     constexpr int LDS = NS * 2 * TILE_BYTES > EPI ? NS * 2 * TILE_BYTES : EPI;
     if (LDS > 65536 && !(ctx->func_attr_mask & (1ull << slot))) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_lp128_kernel<DT, DT_C, NS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_lp128_kernel<DT, DT_C, NS, SPEC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         ctx->func_attr_mask |= (1ull << slot);
     }
-    hipLaunchKernelGGL((gemm_lp128_kernel<DT, DT_C, NS>), dim3(g.tiles_m * g.tiles_n, batch, g.split_k > 1 ? g.split_k : 1),
-                       dim3(256), LDS, s, g);
+    hipLaunchKernelGGL((gemm_lp128_kernel<DT, DT_C, NS, SPEC>), dim3(g.tiles_m * g.tiles_n, batch, g.split_k > 1 ? g.split_k : 1),
+                       dim3(SPEC ? 512 : 256), LDS, s, g);
 }
 
 #ifndef SK1_MAX_TILES
@@ -405,9 +479,9 @@ void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch, i
     // one workgroup per CU at most: the deep (4-stage) pipeline; otherwise two co-resident 2-stage workgroups per CU
     const uint64_t wgs = (uint64_t)g.tiles_m * g.tiles_n * batch * (g.split_k > 1 ? g.split_k : 1);
     constexpr int BK_ = ROW_BYTES / ((DT == MI355_DTYPE_F8E4M3 || DT == MI355_DTYPE_F8E5M2) ? 1 : 2);
-    if (wgs <= (uint64_t)ctx->props.num_streaming_multiprocessors) launch_ns<DT, DT_C, 4>(ctx, s, g, batch, slot);
+    if (wgs <= (uint64_t)ctx->props.num_streaming_multiprocessors) launch_ns<DT, DT_C, 4, LP128_SPEC != 0>(ctx, s, g, batch, slot);
     else if (g.k <= SK1_MAX_TILES * BK_ && g.split_k <= 1) launch_ns<DT, DT_C, 1>(ctx, s, g, batch, slot);   // four workgroups per CU
-    else launch_ns<DT, DT_C, 2>(ctx, s, g, batch, slot);
+    else launch_ns<DT, DT_C, 2, LP128_SPEC2 != 0>(ctx, s, g, batch, slot);
 }
 
 }  // namespace
