@@ -93,7 +93,9 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void *p)
 // the K-tile's 16 MFMAs take, so a wave that does both starves its matrix pipe.  The loader waves own `vmcnt`; the
 // multiplying waves see the ring only through the one s_barrier per K-tile.
 template <int DT, int DT_C, int NS = 2, bool SPEC = false>
-__global__ void __launch_bounds__(SPEC ? 512 : 256, NS == 1 ? 4 : NS == 2 ? (SPEC ? 4 : 2) : SPEC ? 2 : 1)
+__global__ void __launch_bounds__(SPEC ? 512 : 256,
+                                  // waves per SIMD the register budget must allow (fp8 fragments are twice as wide: three, not four)
+                                  NS == 1 ? ((DT == MI355_DTYPE_F8E4M3 || DT == MI355_DTYPE_F8E5M2) ? 3 : 4) : NS == 2 ? (SPEC ? 4 : 2) : SPEC ? 2 : 1)
 gemm_lp128_kernel(gemm_args g)
 {
     static_assert(!SPEC || NS == 4 || NS == 2, "loader waves are written for the 2-stage and the 4-stage ring");
