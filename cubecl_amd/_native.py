@@ -58,6 +58,7 @@ PLANE_PROD, PLANE_INCLUSIVE_SUM, PLANE_EXCLUSIVE_SUM = 100, 101, 102
 GEMM_ALGO_AUTO, GEMM_ALGO_GENERIC, GEMM_ALGO_F32_MFMA, GEMM_ALGO_LP_128, GEMM_ALGO_LP_256, GEMM_ALGO_LP_256W4, GEMM_ALGO_LP_256P = 0, 1, 2, 3, 4, 5, 6
 GEMM_ALGO_LP_256Q = 7
 GEMM_ALGO_SKINNY = 8
+GEMM_ALGO_STREAM64 = 9
 UNIQUE_ID_BYTES = 128
 
 

@@ -50,6 +50,15 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
     const bool big = gemm_lp256_supports(d, a, b, c);
     const bool big4 = gemm_lp256w4_supports(d, a, b, c);
     const bool mid = gemm_lp128_supports(d, a, b, c);
+    // 3 ... 64 rows (or columns): 32 streamed rows x the whole K per workgroup, loader waves, no split-K (gemm_stream64.hip).
+    // Interleaved against the split-K 128x128 path over 60 shapes (tools/dev/stream64_probe.py): faster by 5-50 % whenever its
+    // grid is at most two rounds of workgroups and not a handful of workgroups each walking a very long K
+    // (64 x 8192 x 8192 24.4 us against 29.9, 16 x 8192 x 8192 22.3 / 26.4, 8192 x 64 x 8192 24.4 / 33.7, 32 x 8192 x 2048 7.6 / 14.8;
+    // lost: 64 x 32768 x 4096 59 / 45, 64 x 4096 x 16384 38 / 33, 16 x 65536 x 1024 41 / 24).
+    if (std::min(d.m, d.n) > 2 && std::min(d.m, d.n) <= 64 && gemm_stream64_supports(d, a, b, c)) {
+        const int64_t wgs = ((std::max(d.m, d.n) + 31) / 32) * d.batch, nk64 = d.k / 64;
+        if (wgs <= 512 && (nk64 <= 128 || wgs >= 192)) return MI355_GEMM_ALGO_STREAM64;
+    }
     // one or two rows (or columns): HBM-bound on the other operand; stream it once with dot products, no MFMA tile to fill
     // (gemm_skinny.hip: 20.4 us against 24.7 at 1 x 8192 x 8192).  Up to 16 rows when no MFMA kernel takes the descriptor.
     if ((d.m <= 16 || d.n <= 16) && gemm_skinny_supports(d, a, b, c) && (std::min(d.m, d.n) <= 2 || !(big || big4 || mid)))
@@ -291,6 +300,7 @@ MI355_API int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_ge
     case MI355_GEMM_ALGO_LP_256P: return launch_gemm_lp256p(ctx, s, d, a, b, c);
     case MI355_GEMM_ALGO_LP_256Q: return launch_gemm_lp256q(ctx, s, d, a, b, c);
     case MI355_GEMM_ALGO_SKINNY: return launch_gemm_skinny(ctx, s, d, a, b, c);
+    case MI355_GEMM_ALGO_STREAM64: return launch_gemm_stream64(ctx, s, d, a, b, c);
     default: return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_gemm: unknown algo %d", algo);
     }
 }

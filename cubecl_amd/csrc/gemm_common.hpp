@@ -110,6 +110,8 @@ bool gemm_lp256q_supports(const mi355_gemm_desc &d, const void *a, const void *b
 bool gemm_lp256w4_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 int32_t launch_gemm_skinny(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 bool gemm_skinny_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
+int32_t launch_gemm_stream64(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
+bool gemm_stream64_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 // block-scaled (MX) form of the same kernel; sa_t / sb_t are the re-arranged scales (gemm_scaled.hip)
 bool gemm_lp256w4_mx_supports(const mi355_gemm_scaled_desc &d, const void *a, const void *b, const void *c);
 int32_t launch_gemm_lp256w4_mx(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_scaled_desc &d, const void *a, const void *sa_t,

@@ -1,0 +1,313 @@
+// gemm_stream64.hip -- bf16 / f16 GEMM with 3 ... 64 rows (or columns): C[m][n] = sum_k A[m][k] * B[n][k], no split-K.
+//
+// Roofline: HBM.  The large operand is read once; the small one (<= 64 rows x K, <= 1 MiB at K = 8192) stays in L2 and is
+// re-read by every workgroup.  The 128x128 kernel serves these shapes with split-K: few tiles, so K is cut into slices whose
+// f32 partial slabs a second kernel folds (25 % extra traffic at 64 rows plus a launch).  Here a workgroup owns 32 rows of
+// the large operand over the WHOLE K range instead -- 256 workgroups at N = 8192, one per CU, each streaming one contiguous
+// 512 KiB region -- so nothing is split and nothing is folded.
+//
+//   * ten waves: four MULTIPLYING waves, four loader waves for the small operand and two for the streamed one; loaders only
+//     issue LDS-DMA pieces (`global_load_lds_dwordx4`, 1 KiB each) and wait for them.  Two LDS rings: 6-8 K-tiles of the
+//     small operand (L2-resident: short look-ahead) and 24 K-tiles = 96 KiB of the streamed one (HBM latency x bandwidth).
+//     Same 128-byte-row image and chunk swizzle as gemm_lp128.hip.
+//   * ring slots change hands in GROUPS of 2 (MB = 2) or 4 (MB = 1) K-tiles, one s_barrier per group; a group's fragment reads
+//     are all issued before its first MFMA.
+//   * history: one ring for both operands (12-16 K-tiles) left only 40-48 KiB of the streamed operand in flight: 4.5 TB/s
+//     at 64 x 8192 x 8192 (34-36 us), whatever the hand-over granularity.
+//   * tried and dropped: the small operand straight from global memory into registers (32 rows x 32 bytes per load), the ring
+//     carrying the streamed operand only -- 43 us: 32 partial lines per load instruction cost more than the ring traffic saved.
+//   * the four multiplying waves split the K-tile's four k-steps: wave w multiplies k-step w of every K-tile (MB MFMAs of
+//     32x32x16 per K-tile) into its own accumulators; the four partial sums meet once, at the end, through LDS, added in wave
+//     order (deterministic).  That spreads the fragment reads evenly: MB + 1 `ds_read_b128` per wave and K-tile.
+//
+// Either operand may be the small one: with N <= 64 the roles swap and the output tile is stored transposed (C is at most
+// 1 MiB; its stores do not matter).  Accumulation order differs from the other kernels (k-steps interleaved over four
+// accumulators): within the parity tolerance, not bit-identical to them.
+#include <algorithm>
+
+#include "gemm_common.hpp"
+
+using namespace mi355;
+
+namespace {
+
+#ifndef S64_SHIFT
+#define S64_SHIFT 1   // dev: 0 = every workgroup starts at K-tile 0
+#endif
+#ifndef S64_ABL
+#define S64_ABL 0   // dev, timing only: 1 = the small operand always from K-tile 0 (no L2 traffic for it), 2 = the streamed operand re-reads its first 8 K-tiles (no HBM traffic)
+#endif
+constexpr int ROW_BYTES = 128;            // one K-tile row: 64 x 16-bit
+constexpr int BLK = 32 * ROW_BYTES;       // 32 rows of one operand: 4 KiB
+constexpr int BN = 32;                    // streamed rows per workgroup
+
+template <int DT> struct lp;
+template <> struct lp<MI355_DTYPE_BF16> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct lp<MI355_DTYPE_F16> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+struct stream_args {
+    const void *small_;      // [small_rows][K]
+    const void *big;         // [big_rows][K]
+    void *out;
+    int64_t ld_small, ld_big;                       // elements
+    int64_t out_stride_small, out_stride_big;       // elements between consecutive small / big indices of the output
+    int64_t stride_small, stride_big, stride_out;   // batch strides, elements
+    int32_t small_rows, big_rows, k;
+    int32_t dtype_c;
+};
+
+__device__ __forceinline__ void glds16_s(const void *ubase_in, uint32_t voff, uint32_t lds_in)
+{
+    const uint64_t u = reinterpret_cast<uint64_t>(ubase_in);
+    const uint64_t us = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+    const void *ubase = reinterpret_cast<const void *>(us);
+    const uint32_t lds_byte_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_in);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ubase), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void *p)
+{
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)p;
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// MB: 32-row blocks of the small operand (1: up to 32 rows, 2: up to 64).
+template <int DT, int MB>
+__global__ void __launch_bounds__(640, 2) gemm_stream64_kernel(stream_args g)
+{
+    // Two rings.  The streamed operand needs DEPTH: ~25 GB/s per CU x ~2.5 us of HBM latency under load = ~64 KiB in flight
+    // (with both operands in one 12-16 slot ring only 40-48 KiB of it were, and the kernel sat at 4.5 TB/s).  The small
+    // operand is L2-resident and needs only a few K-tiles of look-ahead.  They cannot share loader waves: `vmcnt` retires in
+    // order, so a wave waiting for a near small-operand piece would also wait for every far streamed piece it issued before.
+    constexpr int G = MB == 2 ? 2 : 4;                    // K-tiles per hand-over (one s_barrier per group)
+    constexpr int SGA = MB == 2 ? 3 : 2;                  // groups in the small operand's ring: 6 x 8 KiB / 8 x 4 KiB
+    constexpr int SGB = MB == 2 ? 12 : 6;                 // groups in the streamed operand's ring: 24 x 4 KiB
+    constexpr int SA = SGA * G, SB = SGB * G;
+    constexpr int A_STAGE = MB * BLK;
+    constexpr int B_RING = SA * A_STAGE;                  // byte offset of the streamed ring
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    typedef typename lp<DT>::frag frag;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0-3 multiply, 4-7 load the small operand, 8-9 the streamed one
+    const int w = wave_all & 3;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int64_t n0 = (int64_t)blockIdx.x * BN;
+    const int nk = g.k / 64;
+    const int ng = (nk + G - 1) / G;
+    // Workgroup j walks K starting at K-tile j mod nk and wraps.  Without it all 256 workgroups ask for the same 128-byte
+    // column of their 32 rows at the same time: 8192 lines whose addresses differ only above bit 14 -- the same few HBM
+    // channels -- and the kernel sat at 4.2 TB/s however deep the ring (with the streamed operand re-read from L2 instead:
+    // 19.6 us, so everything but HBM fits in 60 % of the time).  Each output element still sums its K-tiles in one fixed order.
+    const int shift = S64_SHIFT ? (int)(blockIdx.x % (uint32_t)nk) : 0;
+    auto phys = [&](int t) { const int p = t + shift; return p >= nk ? p - nk : p; };
+
+    const char *small_ = static_cast<const char *>(g.small_) + (int64_t)blockIdx.y * g.stride_small * 2;
+    const char *big = static_cast<const char *>(g.big) + (int64_t)blockIdx.y * g.stride_big * 2 + n0 * g.ld_big * 2;
+
+    // a DMA piece is 1 KiB = 8 rows x 128 B; a lane fills 16 bytes: row 8p + lane / 8, physical chunk lane % 8 <- logical
+    // chunk ^ swizzle (as gemm_lp128.hip)
+    if (wave_all >= 8) {
+        // ---- streamed operand: wave 8 fills rows 0-15, wave 9 rows 16-31 of every K-tile (two pieces each)
+        const int half = wave_all - 8;
+        uint32_t voff[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = (half * 2 + j) * 8 + (lane >> 3);
+            const int q = (lane & 7) ^ ((r >> 1) & 7);
+            voff[j] = (uint32_t)(std::min<int64_t>(r, (int64_t)g.big_rows - n0 - 1) * g.ld_big * 2 + q * 16);   // rows past the edge re-read the last one
+        }
+        auto issue_group = [&](int gi) {
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const int t = gi * G + u;
+                if (t < nk) {
+                    const uint32_t slot = lds_addr_of(smem + B_RING + (t % SB) * BLK + half * 2048);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) glds16_s(big + (int64_t)(S64_ABL == 2 ? (t & 7) : phys(t)) * ROW_BYTES, voff[j], slot + j * 1024);
+                }
+            }
+        };
+        for (int gi = 0; gi < std::min(SGB - 1, ng); ++gi) issue_group(gi);
+        for (int gi = 0; gi < ng; ++gi) {
+            // group gi has landed when at most the pieces of the SGB - 2 groups issued after it are outstanding (full groups
+            // when they all exist); in the tail simply wait for everything
+            if ((gi + SGB - 1) * G <= nk) wait_vmcnt<2 * G * (SGB - 2)>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();          // group gi is ready; everybody is done with group gi - 1
+            __builtin_amdgcn_sched_barrier(0);
+            if (gi + SGB - 1 < ng) issue_group(gi + SGB - 1);   // into the slots group gi - 1 just left
+        }
+        return;
+    }
+    if (wave_all >= 4) {
+        // ---- small operand: wave 4 + w fills pieces w, w + 4 (MB = 2) of every K-tile's MB x 32 rows
+        uint32_t voff[MB];
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            const int r = (w + 4 * j) * 8 + (lane >> 3);
+            const int q = (lane & 7) ^ ((r >> 1) & 7);
+            voff[j] = (uint32_t)(std::min<int64_t>(r, (int64_t)g.small_rows - 1) * g.ld_small * 2 + q * 16);
+        }
+        auto issue_group = [&](int gi) {
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const int t = gi * G + u;
+                if (t < nk) {
+                    const uint32_t slot = lds_addr_of(smem + (t % SA) * A_STAGE);
+#pragma unroll
+                    for (int j = 0; j < MB; ++j) glds16_s(small_ + (int64_t)(S64_ABL == 1 ? 0 : phys(t)) * ROW_BYTES, voff[j], slot + (w + 4 * j) * 1024);
+                }
+            }
+        };
+        for (int gi = 0; gi < std::min(SGA - 1, ng); ++gi) issue_group(gi);
+        for (int gi = 0; gi < ng; ++gi) {
+            if ((gi + SGA - 1) * G <= nk) wait_vmcnt<MB * G * (SGA - 2)>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (gi + SGA - 1 < ng) issue_group(gi + SGA - 1);
+        }
+        return;
+    }
+
+    // ---- multiplying waves: wave w takes k-step w of every K-tile -------------------------------------------------------
+    f32x16 acc[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int q = w * 2 + h;                                   // logical 16-byte chunk of my k-step for my lane half
+    int off_s[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        const int row = i * 32 + l31;
+        off_s[i] = row * ROW_BYTES + ((q ^ ((row >> 1) & 7)) << 4);
+    }
+    const int off_b = B_RING + l31 * ROW_BYTES + ((q ^ ((l31 >> 1) & 7)) << 4);
+    for (int gi = 0; gi < ng; ++gi) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // all fragment reads of the group first, then its MFMAs: one LDS latency per group instead of one per K-tile
+        frag bfq[G], afq[G][MB];
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const int t = gi * G + u;
+            if (t < nk) {
+                bfq[u] = *reinterpret_cast<const frag *>(smem + (t % SB) * BLK + off_b);
+#pragma unroll
+                for (int i = 0; i < MB; ++i) afq[u][i] = *reinterpret_cast<const frag *>(smem + (t % SA) * A_STAGE + off_s[i]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            if (gi * G + u < nk) {
+#pragma unroll
+                for (int i = 0; i < MB; ++i) acc[i] = lp<DT>::mfma(bfq[u], afq[u][i], acc[i]);   // operands swapped: a lane owns 4 consecutive streamed columns per quad
+            }
+        }
+        // (the MFMAs need the fragments, so every ds_read of the group has completed before this wave reaches the next barrier)
+    }
+
+    // ---- the four k-step partials meet in LDS (the ring is dead), added in wave order -----------------------------------
+    __syncthreads();                                            // loaders have left; the four of us are done reading the ring
+    float *part = reinterpret_cast<float *>(smem);              // [wave][MB][row 32][col 32], 4 x MB x 4 KiB
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                part[((w * MB + i) * 32 + l31) * 32 + 8 * qd + 4 * h + r] = acc[i][4 * qd + r];   // lane (l31, h): row l31, cols 8 qd + 4 h + r
+    __syncthreads();
+    char *out = static_cast<char *>(g.out);
+    for (int e = tid; e < MB * 32 * 32; e += 256) {      // tid < 256 here: the loader waves have left
+        const int i = e / 1024, row = (e >> 5) & 31, col = e & 31;
+        const int64_t sm = i * 32 + row, bg = n0 + col;
+        if (sm >= g.small_rows || bg >= g.big_rows) continue;
+        float v = part[((0 * MB + i) * 32 + row) * 32 + col];
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) v += part[((ww * MB + i) * 32 + row) * 32 + col];
+        const int64_t o = (int64_t)blockIdx.y * g.stride_out + sm * g.out_stride_small + bg * g.out_stride_big;
+        if (g.dtype_c == MI355_DTYPE_F32) reinterpret_cast<float *>(out)[o] = v;
+        else if (g.dtype_c == MI355_DTYPE_BF16) reinterpret_cast<uint16_t *>(out)[o] = f32_to_bf16_rne(v);
+        else reinterpret_cast<uint16_t *>(out)[o] = f32_to_f16_rne(v);
+    }
+}
+
+template <int DT, int MB>
+void launch_one(mi355_ctx *ctx, hipStream_t s, const stream_args &g, uint32_t batch, int slot)
+{
+    constexpr int LDS = (MB == 2 ? 6 * 2 * BLK : 8 * BLK) + 24 * BLK;   // small ring 48 / 32 KiB + streamed ring 96 KiB
+    if (!(ctx->func_attr_mask2 & (1ull << slot))) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_stream64_kernel<DT, MB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        ctx->func_attr_mask2 |= (1ull << slot);
+    }
+    hipLaunchKernelGGL((gemm_stream64_kernel<DT, MB>), dim3((uint32_t)((g.big_rows + BN - 1) / BN), batch), dim3(640), LDS, s, g);
+}
+
+}  // namespace
+
+namespace mi355 {
+
+// A [M][K], B [N][K] K-contiguous 16-bit, min(M, N) <= 64, K a multiple of 64, 16-byte aligned rows.
+bool gemm_stream64_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
+{
+    (void)c;
+    if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16) return false;
+    if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != MI355_DTYPE_BF16 && d.dtype_c != MI355_DTYPE_F16) return false;
+    if (d.trans_a || !d.trans_b) return false;
+    if (d.m <= 0 || d.n <= 0 || d.k < 64 || (d.k & 63) || d.k > 0x7FFFFFC0) return false;
+    if (std::min(d.m, d.n) > 64) return false;
+    if (d.m > 0x7FFFFFFF || d.n > 0x7FFFFFFF || d.batch < 1 || d.batch > 65535) return false;
+    if ((d.lda & 7) || (d.ldb & 7) || (d.stride_a & 7) || (d.stride_b & 7)) return false;
+    if ((reinterpret_cast<uintptr_t>(a) & 15u) || (reinterpret_cast<uintptr_t>(b) & 15u)) return false;
+    if ((int64_t)64 * std::max(d.lda, d.ldb) * 2 >= (1ll << 32)) return false;     // per-lane DMA offsets are 32-bit
+    return true;
+}
+
+int32_t launch_gemm_stream64(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c)
+{
+    if (!gemm_stream64_supports(d, a, b, c)) return fail(ctx, MI355_E_UNSUPPORTED, "mi355_gemm: the 64-row streaming kernel does not take this descriptor");
+    stream_args g{};
+    const bool a_small = d.m <= d.n;
+    g.small_ = a_small ? a : b;
+    g.big = a_small ? b : a;
+    g.out = c;
+    g.ld_small = a_small ? d.lda : d.ldb;
+    g.ld_big = a_small ? d.ldb : d.lda;
+    g.out_stride_small = a_small ? d.ldc : 1;
+    g.out_stride_big = a_small ? 1 : d.ldc;
+    g.stride_small = a_small ? d.stride_a : d.stride_b;
+    g.stride_big = a_small ? d.stride_b : d.stride_a;
+    g.stride_out = d.stride_c;
+    g.small_rows = (int32_t)(a_small ? d.m : d.n);
+    g.big_rows = (int32_t)(a_small ? d.n : d.m);
+    g.k = (int32_t)d.k;
+    g.dtype_c = d.dtype_c;
+    const bool two = g.small_rows > 32;
+    const uint32_t batch = (uint32_t)d.batch;
+    if (d.dtype_ab == MI355_DTYPE_BF16) {
+        if (two) launch_one<MI355_DTYPE_BF16, 2>(ctx, s, g, batch, 8);
+        else launch_one<MI355_DTYPE_BF16, 1>(ctx, s, g, batch, 9);
+    } else {
+        if (two) launch_one<MI355_DTYPE_F16, 2>(ctx, s, g, batch, 10);
+        else launch_one<MI355_DTYPE_F16, 1>(ctx, s, g, batch, 11);
+    }
+    check_launch(ctx, "mi355_gemm(stream64)");
+    return MI355_OK;
+}
+
+}  // namespace mi355

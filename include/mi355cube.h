@@ -381,8 +381,10 @@ enum {
                                      several output tiles with a continuous K-tile stream          */
     MI355_GEMM_ALGO_LP_256Q = 7,  /* the persistent kernel with the finished tile held in registers (16-bit C) and its
                                      stores dripped into the next tile's K loop                      */
-    MI355_GEMM_ALGO_SKINNY = 8    /* bf16/f16, M <= 16 or N <= 16: the large operand streamed once from HBM,
+    MI355_GEMM_ALGO_SKINNY = 8,   /* bf16/f16, M <= 16 or N <= 16: the large operand streamed once from HBM,
                                      v_dot2c_f32 accumulation, no matrix core (gemm_skinny.hip)      */
+    MI355_GEMM_ALGO_STREAM64 = 9  /* bf16/f16, M <= 64 or N <= 64: 32 streamed rows x the whole K per workgroup,
+                                     loader waves + MFMA, no split-K (gemm_stream64.hip)             */
 };
 
 int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_gemm_desc *desc,

@@ -402,27 +402,29 @@ def test_strided_copies_beyond_2_pow_32_elements(client):
     client.memory_cleanup()
 
 
-@pytest.mark.parametrize("m,n,k", [(8192, 8192, 64), (8192, 8192, 128), (1, 8192, 8192)])
+@pytest.mark.parametrize("m,n,k", [(8192, 8192, 64), (8192, 8192, 128), (1, 8192, 8192), (16, 8192, 8192), (64, 8192, 8192), (8192, 64, 8192)])
 def test_skinny_and_output_bound_shapes_as_benched(client, oracle, m, n, k):
     """The bench's `gemm_bf16_shapes` entries that have kernels of their own, in the form bench.py times them (bf16 -> bf16,
     AUTO): the output-bound 8192 x 8192 x 64 / 128 take the 128x128 kernel in its single-stage form (four workgroups per CU),
-    the GEMV the dot2 row-streaming kernel.  Sampled rows (all rows of the GEMV) against the f64 oracle; for the short-K
-    shapes every 128-row block position of a wave and the last tile are in the sample."""
+    the GEMV the dot2 row-streaming kernel, the 16- and 64-row (or -column) shapes the no-split-K streaming kernel.  Sampled rows
+    (all rows when there are at most 64) against the f64 oracle; for the short-K shapes every 128-row block position of a wave
+    and the last tile are in the sample."""
     import ctypes as C
     a = TensorHandle.uniform(client, (m, k), ElemType.BF16, SEED, 700, -1.0, 1.0)
     b = TensorHandle.uniform(client, (n, k), ElemType.BF16, SEED, 701, -1.0, 1.0)
     c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 2), ElemType.BF16)
     client._s.check(client.lib.mi355_memset(client.ctx, None, C.c_void_p(c.device_ptr()), 0xEE, m * n * 2))
     d = _bench_desc(m, n, k, N.DTYPE_BF16, N.DTYPE_BF16)
-    assert ops.gemm_select(client, d) == (N.GEMM_ALGO_SKINNY if m == 1 else N.GEMM_ALGO_LP_128)
+    want = N.GEMM_ALGO_SKINNY if m == 1 else N.GEMM_ALGO_STREAM64 if min(m, n) <= 64 else N.GEMM_ALGO_LP_128
+    assert ops.gemm_select(client, d) == want
     client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()),
                                           C.c_void_p(c.device_ptr())))
     got = c.to_numpy(client).reshape(m, n)
-    rows = np.array([0]) if m == 1 else np.array([0, 31, 32, 63, 64, 127, 128, 4095, 4096 + 65, 8064, 8191])
+    rows = np.arange(m) if m <= 64 else np.array([0, 31, 32, 63, 64, 127, 128, 4095, 4096 + 65, 8064, 8191])
     a_bits = oracle.to_bf16(oracle.fill_uniform(m * k, 700, -1.0, 1.0))
     b_bits = oracle.to_bf16(oracle.fill_uniform(n * k, 701, -1.0, 1.0))
     _bf16_rows_check(oracle, a_bits, b_bits, got[rows], rows, k, n)
-    if m > 1:   # the one-tile-per-workgroup 256x256 kernel computes the same bits (same K order within a tile)
+    if want == N.GEMM_ALGO_LP_128:   # the one-tile-per-workgroup 256x256 kernel computes the same bits (same K order within a tile)
         c2 = TensorHandle.new_contiguous((m, n), client.empty(m * n * 2), ElemType.BF16)
         d.algo = N.GEMM_ALGO_LP_256W4
         client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()),

@@ -21,7 +21,7 @@ GOLD = json.loads((Path(__file__).parent / "golden" / "reference_goldens.json").
 REL = 1e-5
 ALGOS = {"auto": N.GEMM_ALGO_AUTO, "generic": N.GEMM_ALGO_GENERIC, "f32": N.GEMM_ALGO_F32_MFMA,
          "lp128": N.GEMM_ALGO_LP_128, "lp256": N.GEMM_ALGO_LP_256, "lp256w4": N.GEMM_ALGO_LP_256W4, "lp256p": N.GEMM_ALGO_LP_256P,
-         "lp256q": N.GEMM_ALGO_LP_256Q, "skinny": N.GEMM_ALGO_SKINNY}
+         "lp256q": N.GEMM_ALGO_LP_256Q, "skinny": N.GEMM_ALGO_SKINNY, "stream64": N.GEMM_ALGO_STREAM64}
 
 
 def _to_dev(client, oracle, x, dtype):
@@ -866,4 +866,38 @@ def test_output_bound_shapes_select_the_small_tile(client):
     assert sel(4096, 4096, 64) == N.GEMM_ALGO_LP_256W4                 # one round of 256 tiles: the large tile
     assert sel(8192, 8192, 320) in (N.GEMM_ALGO_LP_256P, N.GEMM_ALGO_LP_256Q, N.GEMM_ALGO_LP_256W4)
     assert sel(1, 8192, 8192) == sel(8192, 2, 4096) == N.GEMM_ALGO_SKINNY
-    assert sel(4, 8192, 8192) == sel(16, 8192, 8192) == N.GEMM_ALGO_LP_128                  # MFMA split-K wins from 3 rows up
+    assert sel(4, 8192, 8192) == sel(16, 8192, 8192) == sel(64, 8192, 8192) == sel(8192, 64, 8192) == N.GEMM_ALGO_STREAM64   # 3 ... 64 rows: no split-K
+    assert sel(64, 32768, 4096) == sel(64, 4096, 16384) == sel(65, 8192, 8192) == N.GEMM_ALGO_LP_128    # many rounds / few long workgroups / 65 rows
+
+
+# ---- 3 ... 64 rows or columns: the no-split-K streaming kernel with loader waves (gemm_stream64.hip) -------------------------
+@pytest.mark.parametrize("m,n,k,kw", [
+    (64, 8192, 8192, {}),                        # the skinny shape the bench quotes
+    (64, 1000, 2048, {}),                        # ragged streamed extent: the last workgroup has 8 of its 32 rows
+    (33, 257, 1024, {"lda": 1032, "ldb": 1040}), # two row blocks with one valid row in the second; padded operand rows
+    (32, 96, 64, {}),                            # a single K-tile (shorter than the ring)
+    (17, 64, 704, {"ldc": 72}),                  # 11 K-tiles: one short of the 12-slot ring; pitched C
+    (3, 4096, 4096, {}),
+    (48, 512, 1600, {"batch": 3}),               # 25 K-tiles: ring wraps twice
+    (64, 320, 1024, {"batch": 2, "bcast_b": True}),
+    (8192, 64, 4096, {}),                        # N <= 64: roles swapped, output tile stored transposed
+    (1000, 40, 2048, {"ldc": 48}),
+    (513, 7, 640, {"batch": 2}),
+])
+@pytest.mark.parametrize("dtype,out_dtype", [(ElemType.BF16, ElemType.BF16), (ElemType.F16, ElemType.F32), (ElemType.BF16, ElemType.F32)])
+def test_stream64_kernel_matches_the_oracle(client, oracle, m, n, k, kw, dtype, out_dtype):
+    run_case(client, oracle, m, n, k, dtype, out_dtype, True, ALGOS["stream64"], **kw)
+
+
+def test_stream64_refusals_determinism_and_repeated_launches(client, oracle):
+    for (m, n, k, tb) in ((65, 65, 128, True), (8, 64, 96, True), (8, 64, 128, False)):       # both extents > 64; K not a multiple of 64; row-major B
+        with pytest.raises(ServerError):
+            run_case(client, oracle, m, n, k, ElemType.BF16, ElemType.F32, tb, ALGOS["stream64"])
+    a = TensorHandle.uniform(client, (64, 8192), ElemType.BF16, 3, 1, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (4096, 8192), ElemType.BF16, 3, 2, -1.0, 1.0)
+    outs = []
+    for _ in range(4):      # back to back on one stream: the ring, the barriers and the LDS hand-over leave nothing behind
+        c = TensorHandle.new_contiguous((64, 4096), client.empty(64 * 4096 * 4), ElemType.F32)
+        ops.matmul(client, a, TensorHandle.new(b.handle, (8192, 4096), (1, 8192), ElemType.BF16), c, algo=ALGOS["stream64"])
+        outs.append(c.to_numpy(client).copy())
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])

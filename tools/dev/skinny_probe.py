@@ -6,9 +6,9 @@ from cubecl_amd import ElemType, Mi355Runtime, TensorHandle
 from cubecl_amd import _native as N
 client = Mi355Runtime.client(); lib, ctx = client.lib, client.ctx
 ev = bench.Events(client)
-NAMES = {0: "auto", 3: "lp128", 5: "w4", 6: "p", 7: "q", 8: "skinny", 4: "lp256"}
-for (m, n, k, algos) in ((1, 8192, 8192, (8, 3)), (4, 8192, 8192, (8, 3)), (16, 8192, 8192, (8, 3)), (8192, 16, 8192, (8, 3)), (1, 16384, 16384, (8, 3)),
-                         (64, 8192, 8192, (0, 3)), (8192, 64, 8192, (0, 3)), (8192, 8192, 64, (0, 5, 3, 4)), (8192, 8192, 128, (0, 5, 3, 4)),
+NAMES = {0: "auto", 3: "lp128", 5: "w4", 6: "p", 7: "q", 8: "skinny", 4: "lp256", 9: "stream64"}
+for (m, n, k, algos) in ((1, 8192, 8192, (8, 3)), (4, 8192, 8192, (8, 3, 9)), (16, 8192, 8192, (8, 3, 9)), (32, 8192, 8192, (3, 9)), (8192, 16, 8192, (8, 3, 9)), (1, 16384, 16384, (8, 3)),
+                         (64, 8192, 8192, (0, 3, 9)), (8192, 64, 8192, (0, 3, 9)), (64, 16384, 4096, (3, 9)), (48, 4096, 16384, (3, 9)), (64, 2048, 2048, (3, 9)), (8192, 8192, 64, (0, 5, 3, 4)), (8192, 8192, 128, (0, 5, 3, 4)),
                          (2048, 2048, 2048, (0, 3, 5))):
     a = TensorHandle.uniform(client, (m, k), ElemType.BF16, 1, 1, -1.0, 1.0); b = TensorHandle.uniform(client, (n, k), ElemType.BF16, 1, 2, -1.0, 1.0)
     c = client.empty(m * n * 2)
