@@ -90,7 +90,7 @@ def test_hot_gemm_kernels_do_not_spill():
         return [(name, k, int(s), int(v)) for k, s, v in found]
     with ThreadPoolExecutor(max_workers=4) as pool:
         rows = [r for rs in pool.map(spills, ["gemm_lp256w4.hip", "gemm_lp256p.hip", "gemm_lp256q.hip", "gemm_lp128.hip", "reduce.hip",
-                                              "copy_strided.hip"]) for r in rs]
+                                              "copy_strided.hip", "gemm_stream64.hip", "gemm_skinny.hip"]) for r in rs]
     assert len(rows) >= 48
     # gemm_lp256q.hip holds a finished tile in 96 registers beside the K loop: the compiler parks a few SCALAR registers in
     # the lanes of a vector register (v_writelane / v_readlane, outside the K-tile bodies) -- no memory traffic, tolerated;
