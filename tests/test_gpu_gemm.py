@@ -901,3 +901,12 @@ def test_stream64_refusals_determinism_and_repeated_launches(client, oracle):
         ops.matmul(client, a, TensorHandle.new(b.handle, (8192, 4096), (1, 8192), ElemType.BF16), c, algo=ALGOS["stream64"])
         outs.append(c.to_numpy(client).copy())
     assert all(np.array_equal(outs[0], o) for o in outs[1:])
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 256, 64), (512, 384, 128), (2048, 2048, 192), (1000, 900, 256), (2048, 2048, 320), (128, 128, 4096)])
+@pytest.mark.parametrize("dtype,out_dtype", [(ElemType.BF16, ElemType.BF16), (ElemType.F16, ElemType.F32)])
+def test_lp128_loader_wave_form_with_rings_shorter_than_their_depth(client, oracle, m, n, k, dtype, out_dtype):
+    """At most one workgroup per CU: gemm_lp128.hip runs its 4-stage ring with four loader waves.  K of 1 ... 5 K-tiles
+    exercises the prologue (fewer K-tiles than ring slots: the loaders' loop runs 0 ... 4 times) and the tail waits; the last
+    shape is one workgroup walking 64 K-tiles."""
+    run_case(client, oracle, m, n, k, dtype, out_dtype, True, ALGOS["lp128"])
