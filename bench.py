@@ -304,6 +304,8 @@ def main():
     p_clk0, p_clk1 = C.c_void_p(clk.device_ptr()), C.c_void_p(clk.device_ptr() + 8192)
     for _ in range(args.warmup):
         step()
+    # the clock probe's first launch loads its code object (0.5 ms on the host, tools/dev/sync_cost.py): not inside the timed region
+    lib.mi355_probe_clock(ctx, None, p_clk0)
     # Plateau warm-up, as the reference's ThroughputBenchmarker does before sampling
     # (crates/cubecl-runtime/src/throughput/benchmarker.rs:40-143: grow the warm-up until the rate stops
     # moving): from idle the chip needs ~25 ms of this kernel before DVFS settles (first 30 launches
