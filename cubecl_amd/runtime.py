@@ -464,6 +464,12 @@ class ComputeClient:
                 continue
             if mem.lane == lane.index:
                 mem.cursor = lane.cursor              # last use on its own lane
+                if mem.users:
+                    # the owner is about to touch memory other lanes were handed: whatever they have issued on it comes
+                    # first (write-after-read across lanes; the reference leaves this one to the caller)
+                    for index in mem.users:
+                        origins[index] = self._s.lanes[index]
+                    mem.users = None
             else:
                 if mem.users is None:
                     mem.users = set()

@@ -233,11 +233,12 @@ def test_logical_streams_wait_for_each_other_only_when_a_binding_crosses(client,
     assert log[1] == w0 + 1 and log[2] == b.stream.value                     # one hipStreamWaitEvent, on lane 2's stream
     b.read_one(x)                                                            # already waited for that cursor
     assert _stream_log(fake)[1] == w0 + 1
-    a.write(x, np.ones(256, dtype=np.float32))                               # lane 1 touches it again: its cursor moves
-    assert _stream_log(fake)[1] == w0 + 1
+    a.write(x, np.ones(256, dtype=np.float32))                               # lane 1 touches it again: its cursor moves,
+    log = _stream_log(fake)                                                  # and it first waits for the borrower (lane 2)
+    assert log[1] == w0 + 2 and log[2] == a.stream.value
     assert np.array_equal(b.read_one(x).view(np.float32), np.ones(256, dtype=np.float32))
-    assert _stream_log(fake)[1] == w0 + 2                                    # ... so lane 2 waits again
-    assert b._lane.waits == 2 and a._lane.waits == 0
+    assert _stream_log(fake)[1] == w0 + 3                                    # ... so lane 2 waits again
+    assert b._lane.waits == 2 and a._lane.waits == 1
 
     # a kernel launch resolves every binding: two foreign lanes -> two waits on the launching lane
     y = b.create_from_slice(np.zeros(64, dtype=np.float32))
@@ -262,3 +263,18 @@ def test_logical_streams_wait_for_each_other_only_when_a_binding_crosses(client,
     gc.collect()
     log = _stream_log(fake)
     assert log[1] == before + 2 and log[2] == stream_a
+
+
+def test_owner_lane_waits_for_borrowers_before_touching_its_memory_again(client, fake):
+    """Write-after-read across logical streams: lane 2 read lane 1's buffer; when lane 1 writes it again, lane 1's stream first
+    waits (on the device) for what lane 2 has issued -- once, then the buffer counts as lane 1's alone again."""
+    a, b = client.with_stream(1), client.with_stream(2)
+    x = a.create_from_slice(np.zeros(64, dtype=np.float32))
+    b.read_one(x)                                                 # lane 2 borrows
+    assert x.memory.users == {2}
+    before = _stream_log(fake)[1]
+    a.write(x, np.ones(64, dtype=np.float32))                     # the owner overwrites
+    log = _stream_log(fake)
+    assert log[1] == before + 1 and log[2] == a.stream.value and x.memory.users is None
+    a.write(x, np.ones(64, dtype=np.float32))
+    assert _stream_log(fake)[1] == before + 1
