@@ -57,7 +57,8 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
     // lost: 64 x 32768 x 4096 59 / 45, 64 x 4096 x 16384 38 / 33, 16 x 65536 x 1024 41 / 24).
     if (std::min(d.m, d.n) > 2 && std::min(d.m, d.n) <= 64 && gemm_stream64_supports(d, a, b, c)) {
         const int64_t wgs = ((std::max(d.m, d.n) + 31) / 32) * d.batch, nk64 = d.k / 64;
-        if (wgs <= 512 && (nk64 <= 128 || wgs >= 192)) return MI355_GEMM_ALGO_STREAM64;
+        // a workgroup walks its K-tiles alone (~0.15 us each): long K needs enough workgroups for that to be hidden
+        if (wgs <= 512 && (nk64 <= 64 || (nk64 <= 128 && wgs >= 64) || wgs >= 192)) return MI355_GEMM_ALGO_STREAM64;
     }
     // one or two rows (or columns): HBM-bound on the other operand; stream it once with dot products, no MFMA tile to fill
     // (gemm_skinny.hip: 20.4 us against 24.7 at 1 x 8192 x 8192).  Up to 16 rows when no MFMA kernel takes the descriptor.

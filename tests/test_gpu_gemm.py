@@ -867,7 +867,8 @@ def test_output_bound_shapes_select_the_small_tile(client):
     assert sel(8192, 8192, 320) in (N.GEMM_ALGO_LP_256P, N.GEMM_ALGO_LP_256Q, N.GEMM_ALGO_LP_256W4)
     assert sel(1, 8192, 8192) == sel(8192, 2, 4096) == N.GEMM_ALGO_SKINNY
     assert sel(4, 8192, 8192) == sel(16, 8192, 8192) == sel(64, 8192, 8192) == sel(8192, 64, 8192) == N.GEMM_ALGO_STREAM64   # 3 ... 64 rows: no split-K
-    assert sel(64, 32768, 4096) == sel(64, 4096, 16384) == sel(65, 8192, 8192) == N.GEMM_ALGO_LP_128    # many rounds / few long workgroups / 65 rows
+    assert sel(64, 32768, 4096) == sel(64, 4096, 16384) == sel(65, 8192, 8192) == sel(64, 64, 8192) == N.GEMM_ALGO_LP_128   # many rounds / few long workgroups / 65 rows
+    assert sel(64, 64, 4096) == sel(64, 2048, 8192) == sel(48, 8192, 16384) == N.GEMM_ALGO_STREAM64
 
 
 # ---- 3 ... 64 rows or columns: the no-split-K streaming kernel with loader waves (gemm_stream64.hip) -------------------------
