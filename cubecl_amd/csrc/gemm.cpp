@@ -57,8 +57,16 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
     // lost: 64 x 32768 x 4096 59 / 45, 64 x 4096 x 16384 38 / 33, 16 x 65536 x 1024 41 / 24).
     if (std::min(d.m, d.n) > 2 && std::min(d.m, d.n) <= 64 && gemm_stream64_supports(d, a, b, c)) {
         const int64_t wgs = ((std::max(d.m, d.n) + 31) / 32) * d.batch, nk64 = d.k / 64;
-        // a workgroup walks its K-tiles alone (~0.15 us each): long K needs enough workgroups for that to be hidden
-        if (wgs <= 512 && (nk64 <= 64 || (nk64 <= 128 && wgs >= 64) || wgs >= 192)) return MI355_GEMM_ALGO_STREAM64;
+        const int64_t small_bytes = std::min(d.m, d.n) * d.k * 2;
+        // * every workgroup re-reads the small operand from L2: past ~1.5 MiB the streamed operand evicts it
+        //   (64 x 8192 x 28672: 110 us against 93 on the split-K path);
+        // * up to 32 rows the kernel keeps winning on large grids in its two-workgroups-per-CU form (16 x 28672 x 8192 83.5 us
+        //   against 111.5, 16 x 32000 x 4096 42.0 / 53.9); with 33-64 rows only up to two rounds (64 x 14336 x 4096 24.0 / 35.2,
+        //   64 x 28672 x 8192 a tie, 64 x 128256 x 4096 295 / 203);
+        // * a workgroup walks its K-tiles alone (~0.15 us each): long K needs enough workgroups for that to be hidden.
+        const int64_t max_wgs = std::min(d.m, d.n) <= 32 ? 2048 : 512;
+        if (small_bytes <= (3ll << 19) && wgs <= max_wgs && (nk64 <= 64 || (nk64 <= 128 && wgs >= 64) || wgs >= 192))
+            return MI355_GEMM_ALGO_STREAM64;
     }
     // one or two rows (or columns): HBM-bound on the other operand; stream it once with dot products, no MFMA tile to fill
     // (gemm_skinny.hip: 20.4 us against 24.7 at 1 x 8192 x 8192).  Up to 16 rows when no MFMA kernel takes the descriptor.
@@ -70,6 +78,9 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
     // against 41.9, K = 128 37.1 against 38.9 (persistent), K = 192 40.9 / 43.0, K = 256 46.8 / 49.0; 16384 x 8192 x 64
     // 51.6 / 68.8.  A single round (4096 x 4096: 256 tiles) stays with the large tile (10.6 us against 12.2).
     if (mid && d.k <= 256 && ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch > 256) return MI355_GEMM_ALGO_LP_128;
+    // at most 128 rows (or columns) over many tiles: a 256-row tile multiplies at least half zeros and streams no faster --
+    // 64 x 128256 x 4096: 192 us on the 128x128 kernel against 222
+    if (mid && std::min(d.m, d.n) <= 128) return MI355_GEMM_ALGO_LP_128;
     if (big) {
         // 256x256 tiles once the 128x128 kernel would need more than its two co-resident workgroups per CU (512 tiles of
         // 128^2 = 128 of 256^2).  Measured (tools/dev/mid_shapes.py): 96-128 tiles a tie, 144-160 tiles +45...55 % for the

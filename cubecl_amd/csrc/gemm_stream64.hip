@@ -82,16 +82,19 @@ template <int N> __device__ __forceinline__ void wait_vmcnt()
 }
 
 // MB: 32-row blocks of the small operand (1: up to 32 rows, 2: up to 64).
-template <int DT, int MB>
-__global__ void __launch_bounds__(640, 2) gemm_stream64_kernel(stream_args g)
+// TWO: half-depth rings, two workgroups per CU -- for grids of more than one workgroup per CU, where a starting workgroup's
+// empty ring and a finishing one's drain overlap the neighbour's streaming (16 x 28672 x 8192: 107 -> 83.5 us); with one
+// workgroup per CU the deep rings win (64 x 8192 x 8192: 24.7 us against 33.9).
+template <int DT, int MB, bool TWO>
+__global__ void __launch_bounds__(640, TWO ? 5 : 2) gemm_stream64_kernel(stream_args g)
 {
     // Two rings.  The streamed operand needs DEPTH: ~25 GB/s per CU x ~2.5 us of HBM latency under load = ~64 KiB in flight
     // (with both operands in one 12-16 slot ring only 40-48 KiB of it were, and the kernel sat at 4.5 TB/s).  The small
     // operand is L2-resident and needs only a few K-tiles of look-ahead.  They cannot share loader waves: `vmcnt` retires in
     // order, so a wave waiting for a near small-operand piece would also wait for every far streamed piece it issued before.
     constexpr int G = MB == 2 ? 2 : 4;                    // K-tiles per hand-over (one s_barrier per group)
-    constexpr int SGA = MB == 2 ? 3 : 2;                  // groups in the small operand's ring: 6 x 8 KiB / 8 x 4 KiB
-    constexpr int SGB = MB == 2 ? 12 : 6;                 // groups in the streamed operand's ring: 24 x 4 KiB
+    constexpr int SGA = TWO ? 2 : (MB == 2 ? 3 : 2);                    // groups in the small operand's ring
+    constexpr int SGB = TWO ? (MB == 2 ? 5 : 2) : (MB == 2 ? 12 : 6);   // groups in the streamed operand's ring
     constexpr int SA = SGA * G, SB = SGB * G;
     constexpr int A_STAGE = MB * BLK;
     constexpr int B_RING = SA * A_STAGE;                  // byte offset of the streamed ring
@@ -247,15 +250,25 @@ __global__ void __launch_bounds__(640, 2) gemm_stream64_kernel(stream_args g)
     }
 }
 
+template <int DT, int MB, bool TWO>
+void launch_form(mi355_ctx *ctx, hipStream_t s, const stream_args &g, uint32_t batch, int slot)
+{
+    constexpr int G_ = MB == 2 ? 2 : 4;
+    constexpr int SGA_ = TWO ? 2 : (MB == 2 ? 3 : 2), SGB_ = TWO ? (MB == 2 ? 5 : 2) : (MB == 2 ? 12 : 6);
+    constexpr int LDS = SGA_ * G_ * MB * BLK + SGB_ * G_ * BLK;          // small ring + streamed ring: 128-144 KiB, or 64-72 KiB x 2
+    if (!(ctx->func_attr_mask2 & (1ull << slot))) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_stream64_kernel<DT, MB, TWO>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        ctx->func_attr_mask2 |= (1ull << slot);
+    }
+    hipLaunchKernelGGL((gemm_stream64_kernel<DT, MB, TWO>), dim3((uint32_t)((g.big_rows + BN - 1) / BN), batch), dim3(640), LDS, s, g);
+}
+
 template <int DT, int MB>
 void launch_one(mi355_ctx *ctx, hipStream_t s, const stream_args &g, uint32_t batch, int slot)
 {
-    constexpr int LDS = (MB == 2 ? 6 * 2 * BLK : 8 * BLK) + 24 * BLK;   // small ring 48 / 32 KiB + streamed ring 96 KiB
-    if (!(ctx->func_attr_mask2 & (1ull << slot))) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_stream64_kernel<DT, MB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        ctx->func_attr_mask2 |= (1ull << slot);
-    }
-    hipLaunchKernelGGL((gemm_stream64_kernel<DT, MB>), dim3((uint32_t)((g.big_rows + BN - 1) / BN), batch), dim3(640), LDS, s, g);
+    const uint64_t wgs = (uint64_t)((g.big_rows + BN - 1) / BN) * batch;
+    if (wgs > (uint64_t)ctx->props.num_streaming_multiprocessors) launch_form<DT, MB, true>(ctx, s, g, batch, slot + 4);
+    else launch_form<DT, MB, false>(ctx, s, g, batch, slot);
 }
 
 }  // namespace

@@ -868,7 +868,8 @@ def test_output_bound_shapes_select_the_small_tile(client):
     assert sel(1, 8192, 8192) == sel(8192, 2, 4096) == N.GEMM_ALGO_SKINNY
     assert sel(4, 8192, 8192) == sel(16, 8192, 8192) == sel(64, 8192, 8192) == sel(8192, 64, 8192) == N.GEMM_ALGO_STREAM64   # 3 ... 64 rows: no split-K
     assert sel(64, 32768, 4096) == sel(64, 4096, 16384) == sel(65, 8192, 8192) == sel(64, 64, 8192) == N.GEMM_ALGO_LP_128   # many rounds / few long workgroups / 65 rows
-    assert sel(64, 64, 4096) == sel(64, 2048, 8192) == sel(48, 8192, 16384) == N.GEMM_ALGO_STREAM64
+    assert sel(64, 64, 4096) == sel(64, 2048, 8192) == sel(32, 8192, 16384) == sel(16, 28672, 8192) == sel(64, 14336, 4096) == N.GEMM_ALGO_STREAM64
+    assert sel(64, 8192, 28672) == sel(64, 28672, 8192) == N.GEMM_ALGO_LP_128        # small operand past 1.5 MiB / 64 rows over more than 512 workgroups
 
 
 # ---- 3 ... 64 rows or columns: the no-split-K streaming kernel with loader waves (gemm_stream64.hip) -------------------------
@@ -884,6 +885,9 @@ def test_output_bound_shapes_select_the_small_tile(client):
     (8192, 64, 4096, {}),                        # N <= 64: roles swapped, output tile stored transposed
     (1000, 40, 2048, {"ldc": 48}),
     (513, 7, 640, {"batch": 2}),
+    (16, 9000, 1024, {}),                        # 282 workgroups: more than one per CU -> half-depth rings, two per CU
+    (64, 8200, 640, {}),                         # the same form with two row blocks; ragged last workgroup
+    (24, 300, 2048, {"batch": 40}),              # 400 workgroups through the batch
 ])
 @pytest.mark.parametrize("dtype,out_dtype", [(ElemType.BF16, ElemType.BF16), (ElemType.F16, ElemType.F32), (ElemType.BF16, ElemType.F32)])
 def test_stream64_kernel_matches_the_oracle(client, oracle, m, n, k, kw, dtype, out_dtype):
