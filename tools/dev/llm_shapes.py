@@ -7,7 +7,7 @@ from cubecl_amd import _native as N
 client = Mi355Runtime.client(); lib, ctx = client.lib, client.ctx
 ev = bench.Events(client)
 NAMES = {3: "lp128", 9: "stream64", 8: "skinny", 5: "w4", 6: "p", 7: "q"}
-for (m, n, k) in ((16, 28672, 8192), (64, 28672, 8192), (32, 14336, 4096), (64, 14336, 4096), (16, 4096, 14336), (64, 8192, 28672), (8, 6144, 4096), (64, 6144, 4096), (128, 8192, 8192), (16, 32000, 4096), (64, 128256, 4096)):
+for (m, n, k) in ((16, 28672, 8192), (64, 28672, 8192), (32, 14336, 4096), (64, 14336, 4096), (16, 4096, 14336), (64, 8192, 28672), (8, 6144, 4096), (64, 6144, 4096), (128, 8192, 8192), (96, 8192, 8192), (128, 28672, 8192), (128, 14336, 4096), (96, 4096, 4096), (8192, 128, 8192), (128, 2048, 2048), (16, 32000, 4096), (64, 128256, 4096)):
     a = TensorHandle.uniform(client, (m, k), ElemType.BF16, 1, 1, -1.0, 1.0); b = TensorHandle.uniform(client, (n, k), ElemType.BF16, 1, 2, -1.0, 1.0)
     c = client.empty(m * n * 2)
     line = []
