@@ -159,8 +159,18 @@ gemm_lp128_kernel(gemm_args g)
     const int kt0 = z * per;
     const int nk = max(0, min(per, nk_total - kt0));
 
+#ifndef LP128_KSTAG
+#define LP128_KSTAG 0   // dev: K-tile order rotated per workgroup (1: by tm + tn, 2: by (tm + tn) & 3, 3: by workgroup id)
+#endif
+#ifndef LP128_ABL
+#define LP128_ABL 0     // dev, timing only: 1 = no DMA after the prologue, 2 = no fragment reads after the first, 4 = no MFMA
+#endif
+    const int kshift = nk <= 0 ? 0 : LP128_KSTAG == 1 ? (int)((tm + tn) % (uint32_t)nk) : LP128_KSTAG == 2 ? (int)((tm + tn) & 3u) % nk
+                                   : LP128_KSTAG == 3 ? (int)(blockIdx.x % (uint32_t)nk) : 0;
     auto stage = [&](int buf, int kt_rel) {
-        const int kt = kt0 + kt_rel;
+        if ((LP128_ABL & 1) && kt_rel >= NS) return;
+        int kt = kt0 + kt_rel;
+        if (LP128_KSTAG) { kt = kt_rel + kshift; kt = kt0 + (kt >= nk ? kt - nk : kt); }
         char *la = smem + buf * 2 * TILE_BYTES;
         char *lb = la + TILE_BYTES;
         const int64_t koff = (int64_t)kt * ROW_BYTES;
@@ -172,8 +182,10 @@ gemm_lp128_kernel(gemm_args g)
     };
 
     frag af[2][2], bf[2][2];                     // [register buffer][tile]
+    bool first_reads = true;
     auto reads = [&](auto buf, const char *la, const char *lb, int kk) {
         constexpr int B = decltype(buf)::value;
+        if (LP128_ABL & 2) { if (!first_reads) return; if (B == 1) first_reads = false; }
         if constexpr (F8) {
             // k-step kk, lane-half h: logical chunks 4kk + 2h and 4kk + 2h + 1 (the second sits in physical chunk ^ 1)
             const int q = kk * 4 + 2 * h;
@@ -200,6 +212,7 @@ gemm_lp128_kernel(gemm_args g)
     };
     auto mfmas = [&](auto buf) {
         constexpr int B = decltype(buf)::value;
+        if (LP128_ABL & 4) return;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
