@@ -76,10 +76,10 @@ __device__ __forceinline__ void batched_tile_coords(uint32_t tiles_m, uint32_t t
 
 __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f)
 {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x0040u);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+    const __bf16 h = (__bf16)f;      // v_cvt_pk_bf16_f32 (gfx950), round-to-nearest-even
+    uint16_t bits;
+    __builtin_memcpy(&bits, &h, 2);
+    return bits;
 }
 
 __device__ __forceinline__ uint16_t f32_to_f16_rne(float f)
@@ -94,6 +94,23 @@ template <int DT>
 __device__ __forceinline__ uint16_t f32_to_lp(float f)
 {
     return DT == MI355_DTYPE_BF16 ? f32_to_bf16_rne(f) : f32_to_f16_rne(f);
+}
+
+// two values -> one dword of 16-bit results (lo in bits 0-15): one v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 (via v_cvt_pkrtz is NOT used: RNE)
+template <int DT>
+__device__ __forceinline__ uint32_t f32x2_to_lp(float lo, float hi)
+{
+    uint32_t u;
+    if constexpr (DT == MI355_DTYPE_BF16) {
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+        __builtin_memcpy(&u, &v, 4);
+    } else {
+        typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+        const f16x2_t v = {(_Float16)lo, (_Float16)hi};
+        __builtin_memcpy(&u, &v, 4);
+    }
+    return u;
 }
 
 // host-side kernel launchers (one per translation unit)

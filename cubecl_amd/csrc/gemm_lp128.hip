@@ -108,6 +108,11 @@ gemm_lp128_kernel(gemm_args g)
     const int lane = tid & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = SPEC && wave_all >= 4;                 // waves 4..7: DMA issue only
+#ifndef LP128_PRIO
+#define LP128_PRIO 0    // dev: issue priority, 1 = multiplying waves raised, 2 = loader waves raised
+#endif
+    if (SPEC && LP128_PRIO == 1 && !loader) __builtin_amdgcn_s_setprio(3);
+    if (SPEC && LP128_PRIO == 2 && loader) __builtin_amdgcn_s_setprio(3);
     const int wave = SPEC ? (wave_all & 3) : wave_all;                             // position in the DMA map / in the 2 x 2 wave grid
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
@@ -163,7 +168,11 @@ gemm_lp128_kernel(gemm_args g)
 #define LP128_KSTAG 0   // dev: K-tile order rotated per workgroup (1: by tm + tn, 2: by (tm + tn) & 3, 3: by workgroup id)
 #endif
 #ifndef LP128_ABL
-#define LP128_ABL 0     // dev, timing only: 1 = no DMA after the prologue, 2 = no fragment reads after the first, 4 = no MFMA
+#define LP128_ABL 0     // dev, timing only: 1 = no DMA after the prologue, 2 = no fragment reads after the first, 4 = no MFMA,
+                        // 8 = no C stores (staging kept), 16 = no epilogue at all
+#endif
+#ifndef LP128_NT
+#define LP128_NT -1     // non-temporal C stores: -1 = every form but the single-stage one (dev: 0 never, 1 always)
 #endif
     const int kshift = nk <= 0 ? 0 : LP128_KSTAG == 1 ? (int)((tm + tn) % (uint32_t)nk) : LP128_KSTAG == 2 ? (int)((tm + tn) & 3u) % nk
                                    : LP128_KSTAG == 3 ? (int)(blockIdx.x % (uint32_t)nk) : 0;
@@ -181,7 +190,7 @@ gemm_lp128_kernel(gemm_args g)
         }
     };
 
-    frag af[2][2], bf[2][2];                     // [register buffer][tile]
+    frag af[4][2], bf[4][2];                     // [register buffer][tile]
     bool first_reads = true;
     auto reads = [&](auto buf, const char *la, const char *lb, int kk) {
         constexpr int B = decltype(buf)::value;
@@ -220,6 +229,11 @@ gemm_lp128_kernel(gemm_args g)
     };
     typedef std::integral_constant<int, 0> B0;
     typedef std::integral_constant<int, 1> B1;
+    typedef std::integral_constant<int, 2> B2;
+    typedef std::integral_constant<int, 3> B3;
+#ifndef LP128_PF2
+#define LP128_PF2 0   // dev: 1 = fragments fetched two k-steps ahead in the loader-wave 4-stage form
+#endif
 
     if constexpr (NS == 1) {
         // one stage: fetch, wait, multiply, hand the buffer back.  Nothing overlaps inside the workgroup; the three
@@ -323,7 +337,31 @@ gemm_lp128_kernel(gemm_args g)
             }
             return;                                         // a finished wave no longer counts at the workgroup's barriers
         }
-        if (multiplies) {
+        if (multiplies && SPEC && LP128_PF2 && NSTEP == 4) {
+            // four fragment buffers, one per k-step of a K-tile, fetched TWO k-steps ahead: a k-step of this tile is only
+            // four MFMAs (128 cycles), less than a loaded LDS round trip.  The hand-over to the next K-tile therefore sits
+            // after the second k-step.
+            if (nk > 0) { reads(B0{}, smem, smem + TILE_BYTES, 0); reads(B1{}, smem, smem + TILE_BYTES, 1); }
+            for (int kt = 0; kt < nk; ++kt) {
+                const char *la = smem + (kt % NS) * 2 * TILE_BYTES;
+                const char *lb = la + TILE_BYTES;
+                reads(B2{}, la, lb, 2); mfmas(B0{});
+                __builtin_amdgcn_sched_barrier(0);
+                reads(B3{}, la, lb, 3); mfmas(B1{});
+                __builtin_amdgcn_sched_barrier(0);
+                const char *na = smem + ((kt + 1) % NS) * 2 * TILE_BYTES;
+                if (kt + 1 < nk) {
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    reads(B0{}, na, na + TILE_BYTES, 0);
+                }
+                mfmas(B2{});
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt + 1 < nk) reads(B1{}, na, na + TILE_BYTES, 1);
+                mfmas(B3{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if (multiplies) {
             if (nk > 0) reads(B0{}, smem, smem + TILE_BYTES, 0);
             for (int kt = 0; kt < nk; ++kt) {
                 const char *la = smem + (kt % NS) * 2 * TILE_BYTES;
@@ -358,6 +396,13 @@ gemm_lp128_kernel(gemm_args g)
     }
 
     // ---- epilogue ---------------------------------------------------------------------------
+    if (LP128_ABL & 16) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[0][0][r] + acc[0][1][r] + acc[1][0][r] + acc[1][1][r];
+        if (t == 12345.678f) static_cast<float *>(g.c)[0] = t;
+        return;
+    }
     char *__restrict__ C = static_cast<char *>(g.c);
     constexpr int CSZ = (DT_C == MI355_DTYPE_F32) ? 4 : 2;
     const int64_t cbase = batch * g.stride_c + (int64_t)z * g.split_c_stride;
@@ -395,8 +440,8 @@ gemm_lp128_kernel(gemm_args g)
                         f32x4 v = {acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
                         *reinterpret_cast<f32x4 *>(d) = v;
                     } else {
-                        u32x2 v = {(uint32_t)f32_to_lp<DT_C>(acc[i][j][4 * q + 0]) | ((uint32_t)f32_to_lp<DT_C>(acc[i][j][4 * q + 1]) << 16),
-                                   (uint32_t)f32_to_lp<DT_C>(acc[i][j][4 * q + 2]) | ((uint32_t)f32_to_lp<DT_C>(acc[i][j][4 * q + 3]) << 16)};
+                        u32x2 v = {f32x2_to_lp<DT_C>(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1]),
+                                   f32x2_to_lp<DT_C>(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3])};
                         *reinterpret_cast<u32x2 *>(d) = v;
                     }
                 }
@@ -417,7 +462,9 @@ gemm_lp128_kernel(gemm_args g)
                         continue;
                     }
                 }
-                *reinterpret_cast<u32x4 *>(cdst + it * cstep) = v;
+                if ((LP128_ABL & 8) && v[0] != 0x12345678u) continue;
+                if (LP128_NT == 1 || (LP128_NT < 0 && NS != 1)) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(cdst + it * cstep));
+                else *reinterpret_cast<u32x4 *>(cdst + it * cstep) = v;
             }
             __builtin_amdgcn_sched_barrier(0);             // keep the accumulator reads of block i+1 below this point
         }

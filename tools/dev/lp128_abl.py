@@ -10,7 +10,7 @@ client = Mi355Runtime.client(); lib, ctx = client.lib, client.ctx
 ev = bench.Events(client)
 check = os.environ.get("CHECK", "0") == "1"
 out = []
-for (m, n, k) in ((2048, 2048, 2048), (2048, 2048, 8192), (1024, 4096, 4096), (4096, 2048, 2048), (4096, 4096, 1024), (2560, 2560, 2560)):
+for (m, n, k) in ((2048, 2048, 2048), (2048, 2048, 8192), (1024, 4096, 4096), (4096, 2048, 2048), (4096, 4096, 1024), (2560, 2560, 2560), (8192, 8192, 64), (8192, 8192, 256)):
     a = TensorHandle.uniform(client, (m, k), ElemType.BF16, 1, 1, -1.0, 1.0); b = TensorHandle.uniform(client, (n, k), ElemType.BF16, 1, 2, -1.0, 1.0)
     c = client.empty(m * n * 2)
     d = bench.gemm_desc(N, m, n, k, N.DTYPE_BF16, N.DTYPE_BF16, trans_b=1, algo=3)

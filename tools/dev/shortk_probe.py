@@ -7,7 +7,7 @@ from cubecl_amd import _native as N
 client = Mi355Runtime.client(); lib, ctx = client.lib, client.ctx
 ev = bench.Events(client)
 NAMES = {0: "auto", 3: "lp128", 5: "w4", 6: "p"}
-for (m, n, k) in ((8192, 8192, 64), (8192, 8192, 128), (8192, 8192, 192), (8192, 8192, 256), (4096, 4096, 64), (4096, 4096, 128), (16384, 8192, 64), (2048, 2048, 128)):
+for (m, n, k) in ((8192, 8192, 64), (8192, 8192, 128), (8192, 8192, 256), (8192, 8192, 384), (8192, 8192, 512), (8192, 8192, 1024), (4096, 4096, 256), (4096, 4096, 512), (6144, 6144, 256), (6144, 6144, 512), (4096, 8192, 512), (16384, 8192, 64), (16384, 8192, 512)):
     a = TensorHandle.uniform(client, (m, k), ElemType.BF16, 1, 1, -1.0, 1.0); b = TensorHandle.uniform(client, (n, k), ElemType.BF16, 1, 2, -1.0, 1.0)
     c = client.empty(m * n * 2)
     line = []
