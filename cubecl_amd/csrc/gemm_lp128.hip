@@ -108,11 +108,6 @@ gemm_lp128_kernel(gemm_args g)
     const int lane = tid & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = SPEC && wave_all >= 4;                 // waves 4..7: DMA issue only
-#ifndef LP128_PRIO
-#define LP128_PRIO 0    // dev: issue priority, 1 = multiplying waves raised, 2 = loader waves raised
-#endif
-    if (SPEC && LP128_PRIO == 1 && !loader) __builtin_amdgcn_s_setprio(3);
-    if (SPEC && LP128_PRIO == 2 && loader) __builtin_amdgcn_s_setprio(3);
     const int wave = SPEC ? (wave_all & 3) : wave_all;                             // position in the DMA map / in the 2 x 2 wave grid
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
@@ -190,7 +185,7 @@ gemm_lp128_kernel(gemm_args g)
         }
     };
 
-    frag af[4][2], bf[4][2];                     // [register buffer][tile]
+    frag af[2][2], bf[2][2];                     // [register buffer][tile]
     bool first_reads = true;
     auto reads = [&](auto buf, const char *la, const char *lb, int kk) {
         constexpr int B = decltype(buf)::value;
@@ -229,11 +224,6 @@ gemm_lp128_kernel(gemm_args g)
     };
     typedef std::integral_constant<int, 0> B0;
     typedef std::integral_constant<int, 1> B1;
-    typedef std::integral_constant<int, 2> B2;
-    typedef std::integral_constant<int, 3> B3;
-#ifndef LP128_PF2
-#define LP128_PF2 0   // dev: 1 = fragments fetched two k-steps ahead in the loader-wave 4-stage form
-#endif
 
     if constexpr (NS == 1) {
         // one stage: fetch, wait, multiply, hand the buffer back.  Nothing overlaps inside the workgroup; the three
@@ -269,6 +259,7 @@ gemm_lp128_kernel(gemm_args g)
             }
             return;
         }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                     // see the 4-stage form: keeps the loop's LDS waits counted
         __builtin_amdgcn_s_barrier();
         for (int kt = 0; kt < nk; ++kt) {
             const char *la = smem + (kt & 1) * 2 * TILE_BYTES;
@@ -337,31 +328,12 @@ gemm_lp128_kernel(gemm_args g)
             }
             return;                                         // a finished wave no longer counts at the workgroup's barriers
         }
-        if (multiplies && SPEC && LP128_PF2 && NSTEP == 4) {
-            // four fragment buffers, one per k-step of a K-tile, fetched TWO k-steps ahead: a k-step of this tile is only
-            // four MFMAs (128 cycles), less than a loaded LDS round trip.  The hand-over to the next K-tile therefore sits
-            // after the second k-step.
-            if (nk > 0) { reads(B0{}, smem, smem + TILE_BYTES, 0); reads(B1{}, smem, smem + TILE_BYTES, 1); }
-            for (int kt = 0; kt < nk; ++kt) {
-                const char *la = smem + (kt % NS) * 2 * TILE_BYTES;
-                const char *lb = la + TILE_BYTES;
-                reads(B2{}, la, lb, 2); mfmas(B0{});
-                __builtin_amdgcn_sched_barrier(0);
-                reads(B3{}, la, lb, 3); mfmas(B1{});
-                __builtin_amdgcn_sched_barrier(0);
-                const char *na = smem + ((kt + 1) % NS) * 2 * TILE_BYTES;
-                if (kt + 1 < nk) {
-                    __builtin_amdgcn_s_barrier();
-                    __builtin_amdgcn_sched_barrier(0);
-                    reads(B0{}, na, na + TILE_BYTES, 0);
-                }
-                mfmas(B2{});
-                __builtin_amdgcn_sched_barrier(0);
-                if (kt + 1 < nk) reads(B1{}, na, na + TILE_BYTES, 1);
-                mfmas(B3{});
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else if (multiplies) {
+        if (multiplies) {
+            // Scalar loads share lgkmcnt with the LDS and return out of order.  With one of them in flight at the loop header
+            // -- as far as the compiler's wait-count bookkeeping knows: hence the builtin, which it reads, not inline asm --
+            // every LDS wait of the loop degrades to lgkmcnt(0), fresh reads included.
+            __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0), vmcnt / expcnt untouched
+            __builtin_amdgcn_sched_barrier(0);
             if (nk > 0) reads(B0{}, smem, smem + TILE_BYTES, 0);
             for (int kt = 0; kt < nk; ++kt) {
                 const char *la = smem + (kt % NS) * 2 * TILE_BYTES;
