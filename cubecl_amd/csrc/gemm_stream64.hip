@@ -200,29 +200,41 @@ __global__ void __launch_bounds__(640, TWO ? 5 : 2) gemm_stream64_kernel(stream_
         off_s[i] = row * ROW_BYTES + ((q ^ ((row >> 1) & 7)) << 4);
     }
     const int off_b = B_RING + l31 * ROW_BYTES + ((q ^ ((l31 >> 1) & 7)) << 4);
-    for (int gi = 0; gi < ng; ++gi) {
+    // no scalar load in flight at the loop header as far as the compiler's wait-count bookkeeping knows (they share lgkmcnt
+    // with the LDS and return out of order: one of them pending turns the loop's counted LDS waits into drains)
+    __builtin_amdgcn_s_waitcnt(0xC07F);                        // lgkmcnt(0)
+    __builtin_amdgcn_sched_barrier(0);
+    // one group: all its fragment reads first, then its MFMAs -- one LDS latency per group instead of one per K-tile.  Whole
+    // groups run without a branch (a branch around a read makes the compiler drain the LDS queue before every later read);
+    // only the last, partial group tests its K-tiles.
+    auto group = [&](int gi, auto whole_c) {
+        constexpr bool WHOLE = decltype(whole_c)::value;
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        // all fragment reads of the group first, then its MFMAs: one LDS latency per group instead of one per K-tile
         frag bfq[G], afq[G][MB];
 #pragma unroll
         for (int u = 0; u < G; ++u) {
             const int t = gi * G + u;
-            if (t < nk) {
+            if (WHOLE || t < nk) {
                 bfq[u] = *reinterpret_cast<const frag *>(smem + (t % SB) * BLK + off_b);
 #pragma unroll
                 for (int i = 0; i < MB; ++i) afq[u][i] = *reinterpret_cast<const frag *>(smem + (t % SA) * A_STAGE + off_s[i]);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < G; ++u) {
-            if (gi * G + u < nk) {
+            if (WHOLE || gi * G + u < nk) {
 #pragma unroll
                 for (int i = 0; i < MB; ++i) acc[i] = lp<DT>::mfma(bfq[u], afq[u][i], acc[i]);   // operands swapped: a lane owns 4 consecutive streamed columns per quad
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
         // (the MFMAs need the fragments, so every ds_read of the group has completed before this wave reaches the next barrier)
-    }
+    };
+    const int ng_whole = nk / G;
+    for (int gi = 0; gi < ng_whole; ++gi) group(gi, std::true_type{});
+    if (ng_whole < ng) group(ng_whole, std::false_type{});
 
     // ---- the four k-step partials meet in LDS (the ring is dead), added in wave order -----------------------------------
     __syncthreads();                                            // loaders have left; the four of us are done reading the ring
