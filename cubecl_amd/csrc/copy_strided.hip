@@ -173,6 +173,100 @@ pack_copy_kernel(const T *__restrict__ in, T *__restrict__ out, uint64_t groups,
     }
 }
 
+// GENERIC, a SHORT axis P of NP = 2..4 elements that is innermost on one side ("interleaved": [.., q, p] packed) and a plane
+// index on the other ("planar": q contiguous, p strided by `sp`): NHWC <-> NCHW images with few channels, complex <-> split
+// re / im, RGB planes.  A thread moves K = 16 / sizeof(T) consecutive q for all NP planes: NP consecutive 16-byte vectors on
+// the interleaved side, one 16-byte vector per plane on the planar side, and the NP x K elements change places in registers
+// (byte permutes; no LDS).  `d` counts q in groups of K (axis 0) and carries the remaining axes; GATHER = the input is the
+// interleaved side.  Every byte is moved once with whole-line accesses on both sides.
+template <typename T, int NP, bool GATHER, bool WIDE>
+__global__ void __launch_bounds__(256)
+plane_copy_kernel(const T *__restrict__ in, T *__restrict__ out, uint64_t groups, dims d, int64_t sp)
+{
+    constexpr int K = 16 / (int)sizeof(T);
+    typedef T vec __attribute__((ext_vector_type(K)));
+    constexpr int U = 2;
+    __shared__ vec stage[4 * NP * 64];                          // one wave's NP x 64 vectors at a time
+    const uint64_t tiles = (groups + 256 * U - 1) / (256 * U);
+    for (uint64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const uint64_t base = t * (256 * U) + threadIdx.x;
+        vec a[U][NP];
+        int64_t oo[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const uint64_t lin = base + k * 256;
+            if (lin < groups) {
+                int64_t oi;
+                if (d.n == 1) {
+                    oi = (int64_t)lin * d.s_in[0];
+                    oo[k] = (int64_t)lin * d.s_out[0];
+                } else {
+                    locate<WIDE>(lin, d, oi, oo[k]);
+                }
+                if constexpr (GATHER) {
+                    // the mirror image of the stores below: when the wave's 64 groups are one contiguous run of the input, every
+                    // load instruction fetches 1 KiB whole and the vectors find their lanes through LDS
+                    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                    const int64_t first = ((int64_t)__builtin_amdgcn_readfirstlane((int)(oi >> 32)) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)oi);
+                    if (__ballot(oi == first + (int64_t)lane * NP * K) == ~0ull) {
+                        vec *st = stage + wave * (NP * 64);
+#pragma unroll
+                        for (int i = 0; i < NP; ++i)
+                            st[i * 64 + lane] = __builtin_nontemporal_load(reinterpret_cast<const vec *>(in + first + ((int64_t)i * 64 + lane) * K));
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int i = 0; i < NP; ++i) a[k][i] = st[lane * NP + i];
+                        __builtin_amdgcn_wave_barrier();
+                        continue;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NP; ++i)
+                    a[k][i] = __builtin_nontemporal_load(reinterpret_cast<const vec *>(in + oi + (GATHER ? (int64_t)i * K : (int64_t)i * sp)));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k)
+            if (base + k * 256 < groups) {
+                vec r[NP];
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                    for (int e = 0; e < K; ++e) {
+                        const int il = e * NP + pl;              // position in the interleaved run of NP x K elements
+                        if constexpr (GATHER) r[pl][e] = a[k][il / K][il % K];
+                        else r[il / K][il % K] = a[k][pl][e];
+                    }
+                if constexpr (!GATHER) {
+                    // A lane's NP vectors are consecutive in the output, so store instruction i would put 16 bytes on every
+                    // NP-th vector: each 128-byte line assembled from NP partial writes (measured: 2.2-3.9 TB/s against 4.9-5.4
+                    // the other way).  When the wave's 64 groups are one contiguous run of the output -- always, except across
+                    // the end of a row -- the vectors change lanes through LDS and every instruction stores 1 KiB whole.
+                    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                    const int64_t first = ((int64_t)__builtin_amdgcn_readfirstlane((int)(oo[k] >> 32)) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)oo[k]);
+                    if (__ballot(oo[k] == first + (int64_t)lane * NP * K) == ~0ull) {
+                        vec *st = stage + wave * (NP * 64);
+#pragma unroll
+                        for (int i = 0; i < NP; ++i) st[lane * NP + i] = r[i];
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int i = 0; i < NP; ++i) r[i] = st[i * 64 + lane];
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int i = 0; i < NP; ++i)
+                            __builtin_nontemporal_store(r[i], reinterpret_cast<vec *>(out + first + ((int64_t)i * 64 + lane) * K));
+                        continue;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NP; ++i)
+                    __builtin_nontemporal_store(r[i], reinterpret_cast<vec *>(out + oo[k] + (GATHER ? (int64_t)i * sp : (int64_t)i * K)));
+            }
+    }
+}
+
 // TWO_SIDED: `di` decomposes the linear index by the input's (collapsed) shape, `dq` by the output's.
 template <typename T, bool WIDE>
 __global__ void __launch_bounds__(256)
@@ -396,6 +490,8 @@ struct plan {
     int p_axis = -1, q_axis = -1;   // TRANSPOSE
     int pack_k = 1;                 // GENERIC: elements per vector access on the contiguous side (1: element-wise)
     bool gather = true;             // GENERIC with pack_k > 1: the OUTPUT is the contiguous side
+    int planes = 0;                 // GENERIC: 2..4 = the short-axis mover (plane_copy_kernel); `gather` = the input is interleaved
+    int q_axis_of_planes = 0;       //          joint axis that runs along the planes (0 or 1); the other of the two is the short one
 };
 
 const char *validate(const mi355_tensor_layout *l, const char *what, uint64_t &count)
@@ -530,6 +626,29 @@ const char *make_plan(const void *in, const mi355_tensor_layout *li, const void 
             return nullptr;
         }
     }
+    // a short axis (2..4 elements) innermost on one side, a plane index on the other: plane_copy_kernel
+    if (es <= 4 && j.size() >= 2) {
+        const int64_t K = 16 / es;
+        // which of the two innermost joint axes is the short one depends on whose axis order the logical shape follows
+        for (int combo = 0; combo < 4; ++combo) {
+            const bool gather = (combo & 1) == 0;               // the input is the interleaved side
+            const int qa = combo >> 1;                          // joint axis that runs along a plane
+            const axis &Q = j[qa], &P = j[1 - qa];
+            const int64_t q_planar = gather ? Q.so : Q.si, q_inter = gather ? Q.si : Q.so;
+            const int64_t p_planar = gather ? P.so : P.si, p_inter = gather ? P.si : P.so;
+            if (P.shape < 2 || P.shape > 4 || p_inter != 1 || q_planar != 1 || q_inter != (int64_t)P.shape) continue;
+            if (Q.shape % (uint64_t)K != 0 || ain % 16 != 0 || aout % 16 != 0 || ((uint64_t)p_planar * (uint64_t)es) % 16 != 0) continue;
+            bool ok = true;
+            for (size_t k = 2; k < j.size(); ++k)
+                ok = ok && ((uint64_t)j[k].si * (uint64_t)es) % 16 == 0 && ((uint64_t)j[k].so * (uint64_t)es) % 16 == 0;
+            if (!ok) continue;
+            pl.planes = (int)P.shape;
+            pl.gather = gather;
+            pl.q_axis_of_planes = qa;
+            pl.access = 16;
+            return nullptr;
+        }
+    }
     // one side contiguous along the innermost joint axis: K elements of it per thread
     if (es < 16 && (j[0].so == 1) != (j[0].si == 1)) {
         const bool gather = j[0].so == 1;
@@ -609,6 +728,26 @@ void launch_pack(hipStream_t s, uint32_t grid, bool wide, bool gather, int k, co
     launch_pack_k<T, 2>(s, grid, wide, gather, in, out, groups, d, s0);
 }
 
+template <typename T, int NP>
+void launch_planes_np(hipStream_t s, uint32_t grid, bool wide, bool gather, const void *in, void *out, uint64_t groups, const dims &d, int64_t sp)
+{
+    if (wide) {
+        if (gather) hipLaunchKernelGGL((plane_copy_kernel<T, NP, true, true>), dim3(grid), dim3(256), 0, s, (const T *)in, (T *)out, groups, d, sp);
+        else hipLaunchKernelGGL((plane_copy_kernel<T, NP, false, true>), dim3(grid), dim3(256), 0, s, (const T *)in, (T *)out, groups, d, sp);
+    } else {
+        if (gather) hipLaunchKernelGGL((plane_copy_kernel<T, NP, true, false>), dim3(grid), dim3(256), 0, s, (const T *)in, (T *)out, groups, d, sp);
+        else hipLaunchKernelGGL((plane_copy_kernel<T, NP, false, false>), dim3(grid), dim3(256), 0, s, (const T *)in, (T *)out, groups, d, sp);
+    }
+}
+
+template <typename T>
+void launch_planes(hipStream_t s, uint32_t grid, bool wide, bool gather, int np, const void *in, void *out, uint64_t groups, const dims &d, int64_t sp)
+{
+    if (np == 2) launch_planes_np<T, 2>(s, grid, wide, gather, in, out, groups, d, sp);
+    else if (np == 3) launch_planes_np<T, 3>(s, grid, wide, gather, in, out, groups, d, sp);
+    else launch_planes_np<T, 4>(s, grid, wide, gather, in, out, groups, d, sp);
+}
+
 template <typename T>
 void launch_two_sided(hipStream_t s, uint32_t grid, bool wide, const void *in, void *out, uint64_t total, const dims &di,
                       const dims &dq)
@@ -648,6 +787,26 @@ MI355_API int32_t mi355_copy_strided(mi355_ctx *ctx, mi355_stream stream, const 
     case MI355_COPY_PATH_ROWS:
     case MI355_COPY_PATH_GENERIC: {
         dims d;
+        if (pl.path == MI355_COPY_PATH_GENERIC && pl.planes > 0) {
+            // axis 0 of the launch = q in groups of K (K elements on the planar side, K x planes on the interleaved one);
+            // the short axis is walked inside the thread; every other joint axis as it is
+            const int64_t K = 16 / elem_size;
+            const axis &Q = pl.joint[pl.q_axis_of_planes], &P = pl.joint[1 - pl.q_axis_of_planes];
+            std::vector<axis> g;
+            g.push_back(axis{Q.shape / (uint64_t)K, Q.si * K, Q.so * K});
+            for (size_t k = 2; k < pl.joint.size(); ++k) g.push_back(pl.joint[k]);
+            fill_dims(d, g);
+            const uint64_t groups = pl.total / (uint64_t)(K * pl.planes);
+            const uint32_t grid = stream_grid(ctx, groups, 2);
+            const int64_t sp = pl.gather ? P.so : P.si;
+            const bool wide_g = groups >= (1ull << 32);
+            switch (elem_size) {
+            case 4: launch_planes<uint32_t>(s, grid, wide_g, pl.gather, pl.planes, in, out, groups, d, sp); break;
+            case 2: launch_planes<uint16_t>(s, grid, wide_g, pl.gather, pl.planes, in, out, groups, d, sp); break;
+            default: launch_planes<uint8_t>(s, grid, wide_g, pl.gather, pl.planes, in, out, groups, d, sp); break;
+            }
+            break;
+        }
         if (pl.path == MI355_COPY_PATH_GENERIC && pl.pack_k > 1) {
             // axis 0 in groups of K elements: the contiguous side advances K per group, the other K x its stride
             std::vector<axis> g = pl.joint;

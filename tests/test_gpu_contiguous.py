@@ -282,3 +282,54 @@ def test_identity_pitched_rows_and_matmul(client, oracle):
     assert np.array_equal(tc.to_numpy(client), b)
     with pytest.raises(ServerError):
         ops.identity(client, TensorHandle.new_contiguous((4, 5), client.empty(80), ElemType.F32))
+
+
+# ---- the short-axis mover (plane_copy_kernel): 2..4 interleaved elements <-> planes --------------------------------------
+@pytest.mark.parametrize("es", [1, 2, 4])
+@pytest.mark.parametrize("planes", [2, 3, 4])
+def test_few_channels_interleaved_to_planar_and_back(client, es, planes):
+    # NHWC <-> NCHW with 2..4 channels, both as into_contiguous of a permuted view (logical order = the output's) and as
+    # copy_into of a contiguous input into a permuted output view (logical order = the input's): the four ways the two
+    # innermost joint axes can be arranged.  H x W = 24 x 40 = 960 positions (a multiple of 16 / es), 5 images.
+    n, h, w, c = 5, 24, 40, planes
+    base = payload(n * h * w * c, es, seed=planes * 10 + es)
+    nhwc, nchw = [h * w * c, w * c, c, 1], [c * h * w, h * w, w, 1]
+    want = (N.COPY_PATH_GENERIC, 16)
+    # NHWC buffer viewed as [N, C, H, W] -> contiguous NCHW (gather, q innermost)
+    run_copy(client, base, [n, c, h, w], [nhwc[0], nhwc[3], nhwc[1], nhwc[2]], es, expect_path=want)
+    # NCHW buffer viewed as [N, H, W, C] -> contiguous NHWC (scatter, p innermost)
+    run_copy(client, base, [n, h, w, c], [nchw[0], nchw[2], nchw[3], nchw[1]], es, expect_path=want)
+    # contiguous NHWC input [N, H, W, C] -> NCHW buffer through a permuted OUTPUT view (gather, p innermost)
+    run_copy(client, base, [n, h, w, c], nhwc, es, out_strides=[nchw[0], nchw[2], nchw[3], nchw[1]], expect_path=want)
+    # contiguous NCHW input [N, C, H, W] -> NHWC buffer through a permuted output view (scatter, q innermost)
+    run_copy(client, base, [n, c, h, w], nchw, es, out_strides=[nhwc[0], nhwc[3], nhwc[1], nhwc[2]], expect_path=want)
+
+
+def test_few_channels_with_padded_planes_and_batches(client):
+    # planes and images further apart than they need to be (pitched destination), two batch axes
+    es, c, hw = 2, 3, 256
+    base = payload(2 * 3 * hw * c, es, seed=5)
+    run_copy(client, base, [2, 3, c, hw], [3 * hw * c, hw * c, 1, c], es, out_strides=[3 * c * 320 + 64, c * 320, 320, 1],
+             expect_path=(N.COPY_PATH_GENERIC, 16))
+
+
+def test_few_channels_fall_back_when_the_vectors_do_not_fit(client):
+    # 250 positions (not a multiple of 16): the element-wise generic mover; still exact
+    for es in (1, 4):
+        base = payload(4 * 250 * 3, es, seed=7)
+        run_copy(client, base, [4, 3, 250], [750, 1, 3], es)
+        run_copy(client, base, [4, 250, 3], [750, 1, 250], es)
+    # a plane stride that is not a multiple of 16 bytes
+    base = payload(2 * 3 * 64 + 64, 1, seed=8)
+    run_copy(client, base, [2, 64, 3], [200, 1, 66], 1)
+
+
+def test_few_channels_at_size(client):
+    # 64 MiB of u8 RGB pixels, NHWC -> NCHW and back: the bench's case at an eighth of its size, bit for bit
+    n, h, w, c = 446, 224, 224, 3
+    base = payload(n * h * w * c, 1, seed=11)
+    src = TensorHandle.new(client.create_from_slice(base), [n, c, h, w], [h * w * c, 1, w * c, c], ElemType.U8)
+    planar = ops.into_contiguous(client, src)
+    assert np.array_equal(planar.to_numpy(client).reshape(n, c, h, w), base.reshape(n, h, w, c).transpose(0, 3, 1, 2))
+    back = ops.into_contiguous(client, TensorHandle.new(planar.handle, [n, h, w, c], [c * h * w, w, 1, h * w], ElemType.U8))
+    assert np.array_equal(back.to_numpy(client).reshape(-1), base)

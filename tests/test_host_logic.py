@@ -204,6 +204,12 @@ def test_copy_strided_plan_picks_the_cheapest_mover():
     assert _copy_plan([1000, 8, 8], [64, 1, 8], 2)[1:] == (N.COPY_PATH_GENERIC, 16)           # 8 x 8 transposes: K = the row
     assert _copy_plan([100], [1], 2, out_strides=[5])[1:] == (N.COPY_PATH_GENERIC, 8)       # scatter: vector loads
     assert _copy_plan([100], [3], 4, out_strides=[5])[1:] == (N.COPY_PATH_GENERIC, 4)       # neither side contiguous
+    # 2..4 interleaved elements <-> planes (NHWC <-> NCHW with few channels): a thread moves 16 bytes of every plane
+    assert _copy_plan([8, 3, 32, 32], [3072, 1, 96, 3], 1)[1:] == (N.COPY_PATH_GENERIC, 16)             # u8 NHWC -> NCHW
+    assert _copy_plan([8, 32, 32, 3], [3072, 32, 1, 1024], 1)[1:] == (N.COPY_PATH_GENERIC, 16)          # u8 NCHW -> NHWC
+    assert _copy_plan([1000, 2], [2, 1], 4, out_strides=[1, 1000])[1:] == (N.COPY_PATH_GENERIC, 16)    # complex -> split
+    assert _copy_plan([8, 3, 1000], [3000, 1, 3], 1)[1:] == (N.COPY_PATH_GENERIC, 4)                    # 1000 % 16 != 0: gathers of 4
+    assert _copy_plan([8, 5, 1024], [5120, 1, 5], 1)[1:] == (N.COPY_PATH_GENERIC, 4)                    # five planes: not this mover
     # the reference's rank-mismatch case (tests/tensor/into_contiguous.rs:143-146) refines to [2, 4]: generic
     assert _copy_plan([1, 2, 4, 1], [8, 1, 2, 2], 4, out_shape=[1, 2, 4])[1:] == (N.COPY_PATH_GENERIC, 16)
     # a contiguous output refines against anything; two strided views whose axis boundaries do not nest have no common
