@@ -658,18 +658,18 @@ def main():
             bc = client.empty(per_gpu * M * M * 2)
             d = gemm_desc(N, M, M, M, N.DTYPE_BF16, N.DTYPE_BF16, trans_b=1, batch=per_gpu)
             call = lambda: client._s.check(lib.mi355_gemm(ctx, None, C.byref(d), ba.device_ptr(), bb.device_ptr(), bc.device_ptr()))
-            med, best = samples_op(client, ev, call, samples=7, warmup=2)
+            med, best = samples_op(client, ev, call, samples=9, warmup=5)      # ~0.85 ms a pass; the first passes after another config ride the DVFS ramp
             tf = 2.0 * M ** 3 * per_gpu / med / 1e9
             alg = C.c_int32()
             lib.mi355_gemm_select(ctx, C.byref(d), C.byref(alg))
             # whole-job figure (the >= 6x at 8 GPUs target is quoted on it): barrier -> every rank launches its shard
-            # 10 x back to back -> sync -> the slowest rank's wall time, exactly the headline's protocol
-            job = job_seconds(call, iters=10, warmup=2)
+            # 20 x back to back (after 5 untimed passes: the DVFS ramp) -> sync -> the slowest rank's wall time, exactly the headline's protocol
+            job = job_seconds(call, iters=20, warmup=5)
             tf_job = 2.0 * M ** 3 * per_gpu * world / job / 1e12
             return {"batch_per_gpu": per_gpu, "batch_total": per_gpu * world, "algo": alg.value, "median_ms": round(med, 3),
                     "TFLOPs_per_gpu": round(tf, 1), "frac_of_2.5PF": round(tf / PEAK_BF16_TFLOPS, 4),
                     "job_ms_per_pass": round(job * 1e3, 3), "TFLOPs_total": round(tf_job, 1),
-                    "TFLOPs_total_timing": "all ranks' FLOP / slowest rank's wall time over 10 back-to-back passes (host clock, barrier before)",
+                    "TFLOPs_total_timing": "all ranks' FLOP / slowest rank's wall time over 20 back-to-back passes after 5 warm-up passes (host clock, barrier before)",
                     "frac_of_2.5PF_per_gpu_job": round(tf_job / world / PEAK_BF16_TFLOPS, 4)}
         guarded("batched_gemm_2048_bf16", batched_c5)
 
@@ -687,7 +687,7 @@ def main():
                 med, _ = samples_op(client, ev, call, samples=7, warmup=2)
                 # these launches are tens of microseconds: a per-sample event pair adds one launch gap (~2.5 us) to each, so the
                 # rate is priced on 20 back-to-back launches (like the roofline objects) and the per-sample median is kept beside it
-                b2b = min(time_op(client, ev, call, 20, warmup=2) for _ in range(3))
+                b2b = min(time_op(client, ev, call, 20, warmup=3) for _ in range(5))
                 out[f"{m}x{n}x{k}"] = {"median_ms": round(med, 4), "back_to_back_ms": round(b2b, 4), "TFLOPs": round(2.0 * m * n * k / b2b / 1e9, 1),
                                        "algo": alg.value, "algorithmic_GBs": round(2.0 * (m * k + n * k + m * n) / b2b / 1e6, 1)}
             return out
