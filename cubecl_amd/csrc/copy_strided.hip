@@ -287,7 +287,7 @@ struct tr_args {
     uint64_t np, nq;          // extents of P and Q
     int64_t in_q, out_p;      // input stride along Q, output stride along P (elements)
     uint32_t tiles_p, tiles_q;
-    uint32_t group, groups_p, groups_q;   // tile order: squares of group x group tiles
+    uint32_t group, group_q, groups_p, groups_q;   // tile order: blocks of group (along P) x group_q (along Q) tiles
     int32_t nb;               // batch axes, innermost first
     int32_t vec_ok;           // all bases and strides are 16-byte multiples
     uint32_t bshape[MAXD];
@@ -318,14 +318,14 @@ transpose_copy_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
     __shared__ uint32_t lds[TP * 64];  // tileT[p][64 dword columns], column ^= ((p / VE) & 7) << 2
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    // Tile order: G x G squares of tiles, walked P-first inside a square and square by square along P (G = 1: plain
-    // rows of tiles).  With G = 16 the ~2000 workgroups in flight read 4 KiB of each of their input rows and write
-    // 4 KiB of each of their output rows; the host picks it when the row strides are multiples of 4 KiB (see there).
+    // Tile order: G x GQ blocks of tiles, walked P-first inside a block and block by block along P (G = 1: plain
+    // rows of tiles).  With 8 x 8 the ~2000 workgroups in flight read 2 KiB of each of their input rows and write
+    // 2 KiB of each of their output rows; the host picks it when the row strides are multiples of 4 KiB (see there).
     uint32_t b = blockIdx.x;
-    const uint32_t G = a.group, lp = b % G;
+    const uint32_t G = a.group, GQ = a.group_q, lp = b % G;
     b /= G;
-    const uint32_t lq = b % G;
-    b /= G;
+    const uint32_t lq = b % GQ;
+    b /= GQ;
     const uint32_t gp = b % a.groups_p;
     b /= a.groups_p;
     uint32_t gq = b % a.groups_q;
@@ -335,7 +335,7 @@ transpose_copy_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
     // by gp walks the squares diagonally: reads and writes both spread over the column offsets.  A bijection per gp.
     // 16384^2 bf16 4.59 -> 4.81 TB/s, 8192 x 4096 8-byte 4.6 -> 5.1 (tools/dev/copy_probe.py --transpose, interleaved).
     if (TR_SKEW && G > 1) gq = (gq + gp) % a.groups_q;   // G > 1 = pitches that are multiples of 4 KiB (host); plain rows of tiles lose 3-8 % to the skew
-    const uint32_t tp = gp * G + lp, tq = gq * G + lq;
+    const uint32_t tp = gp * G + lp, tq = gq * GQ + lq;
     if (tp >= a.tiles_p || tq >= a.tiles_q) return;
     int64_t off_in = 0, off_out = 0;
     for (int i = 0; i < a.nb; ++i) {
@@ -861,15 +861,25 @@ MI355_API int32_t mi355_copy_strided(mi355_ctx *ctx, mi355_stream stream, const 
         a.out_p = P.so;
         const uint64_t tiles_p = (P.shape + tp_ext - 1) / tp_ext, tiles_q = (Q.shape + tq_ext - 1) / tq_ext;
         // Rows a multiple of 4 KiB apart on either side pile the pieces of one long row of tiles onto a few HBM channels
-        // (measured, 16384^2 2-byte transpose: 4.2 TB/s walked row by row, 4.7 TB/s in 16 x 16 squares); other
+        // (measured, 16384^2 2-byte transpose: 4.2 TB/s walked row by row, 4.7 TB/s in 16 x 16 squares, 4.9-5.0 in 8 x 8); other
         // strides spread by themselves and prefer the plain row order (16640 x 15872: 5.1 against 4.9 TB/s).
-        uint32_t group = ((uint64_t)P.so * elem_size) % 4096 == 0 || ((uint64_t)Q.si * elem_size) % 4096 == 0 ? 16 : 1;
-        while (group > 1 && (group > tiles_p || group > tiles_q)) group >>= 1;
-        const uint64_t groups_p = (tiles_p + group - 1) / group, groups_q = (tiles_q + group - 1) / group;
+#ifndef TR_GP
+#define TR_GP 8    // blocks of 8 x 8 tiles: +2-4 % over 16 x 16 on 1-, 2- and 4-byte elements, level on 8-byte (32 x 32, 8 x 32, 64 x 4 ...: slower)
+#endif
+#ifndef TR_GQ
+#define TR_GQ 8
+#endif
+        const bool camping = ((uint64_t)P.so * elem_size) % 4096 == 0 || ((uint64_t)Q.si * elem_size) % 4096 == 0;
+        uint32_t group = camping ? TR_GP : 1, group_q = camping ? TR_GQ : 1;
+        while (group > 1 && group > tiles_p) group >>= 1;
+        while (group_q > 1 && group_q > tiles_q) group_q >>= 1;
+        if (group == 1 || group_q == 1) group = group_q = 1;
+        const uint64_t groups_p = (tiles_p + group - 1) / group, groups_q = (tiles_q + group_q - 1) / group_q;
         a.group = group;
+        a.group_q = group_q;
         a.groups_p = (uint32_t)groups_p;
         a.groups_q = (uint32_t)groups_q;
-        uint64_t blocks = groups_p * groups_q * group * group;
+        uint64_t blocks = groups_p * groups_q * group * group_q;
         a.vec_ok = pl.access == 16;
         for (size_t k = 0; k < pl.joint.size(); ++k) {
             if ((int)k == pl.p_axis || (int)k == pl.q_axis) continue;
