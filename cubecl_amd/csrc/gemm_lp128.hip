@@ -80,7 +80,11 @@ __device__ __forceinline__ void glds16_s(const void *ubase_in, uint32_t voff, ui
                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
     const void *ubase = reinterpret_cast<const void *>(us);
     const uint32_t lds_byte_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_in);
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ubase), "s"(lds_byte_addr) : "memory");
+    // s_nop 4: the base may have just been written by v_readfirstlane, and on gfx9 a VMEM instruction must not read an SGPR
+    // within 5 wait states of a VALU write to it.  The compiler pads its own code for that hazard but cannot see into
+    // inline asm (tools/hazard_scan.py, run by tests/test_abi_cpu.py: 2-3 wait states here before the padding; a prefetch
+    // experiment with none faulted at once).
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ubase), "s"(lds_byte_addr) : "memory");
 }
 __device__ __forceinline__ uint32_t lds_addr_of(const void *p)
 {

@@ -69,7 +69,9 @@ __device__ __forceinline__ void glds16_s(const void *ubase_in, uint32_t voff, ui
                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
     const void *ubase = reinterpret_cast<const void *>(us);
     const uint32_t lds_byte_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_in);
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ubase), "s"(lds_byte_addr) : "memory");
+    // s_nop 4: gfx9 wants 5 wait states between a VALU write of an SGPR (the readfirstlanes above) and a VMEM read of it;
+    // the compiler cannot pad inside inline asm (tools/hazard_scan.py, tests/test_abi_cpu.py)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ubase), "s"(lds_byte_addr) : "memory");
 }
 __device__ __forceinline__ uint32_t lds_addr_of(const void *p)
 {
