@@ -571,7 +571,18 @@ int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
     const int64_t esz = f8 ? 1 : 2;
     const int64_t nk = d.k / (ROW_BYTES / esz);
     const int64_t want = 2 * (int64_t)ctx->props.num_streaming_multiprocessors;
-    if (tiles < want / 2 && nk >= 8 && batch <= 65535) {
+#ifndef LP128_SPLIT_RULE
+#define LP128_SPLIT_RULE 1   // dev: 0 = round 1's rule (any launch of fewer than one tile per CU with 8+ K-tiles)
+#endif
+    // Splitting pays for its slabs (f32 partials written and read back, one more launch: 10-20 us on these shapes) only when
+    // K is long against the number of tiles -- with T tiles, T CUs already stream 16 KiB per K-tile each -- and long in
+    // absolute terms.  Measured pairs, bf16, no split / split (tools/dev/split_ab.py): 32 tiles x 32 K-tiles 14.1 / 17.8 us;
+    // 48 x 48 21.4 / 20.6; 64 x 32 14.8 / 20.7, 64 x 64 26.3 / 25.3, 64 x 128 46.7 / 34.5; 96 x 64 25.9 / 34.8, 96 x 256
+    // 161 / 131; 112 x 16 9.3 / 18.3, 112 x 64 26.3 / 38.9; 128 x 16 9.9 / 20.6, 128 x 128 50.5 / 46.5; 160 x 32 16.6 /
+    // 34.5; 192 x 64 28 / 49; 224 x 128 (128 x 28672 x 8192) 104 / 142.  Rule: at least as many K-tiles as tiles, and 48 of
+    // them unless the tiles are a handful.
+    const bool long_k = LP128_SPLIT_RULE == 0 || (nk >= tiles && (nk >= 48 || tiles <= 16));
+    if (tiles < want / 2 && nk >= 8 && long_k && batch <= 65535) {
         int64_t splits = std::min<int64_t>({(want + tiles - 1) / tiles, nk / 4, 32});
         const int64_t per = (nk + splits - 1) / splits;
         splits = (nk + per - 1) / per;                                      // no empty slices

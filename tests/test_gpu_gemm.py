@@ -234,6 +234,13 @@ def test_split_k_skinny_shapes(client, oracle, m, n, k, out):
     run_case(client, oracle, m, n, k, ElemType.BF16, ElemType.F32 if out == "f32" else ElemType.BF16, True, ALGOS["lp128"])
 
 
+@pytest.mark.parametrize("m,n,k", [(128, 14336, 1024), (96, 6144, 2048), (128, 4096, 2048), (256, 4096, 4096), (128, 3072, 1024)])
+def test_lp128_on_both_sides_of_the_split_rule(client, oracle, m, n, k):
+    # the launcher splits K only when there are at least as many K-tiles as tiles (and 48 of them unless the tiles are a
+    # handful): 112 x 16, 48 x 32, 32 x 32, 24 x 16 stay whole, 64 x 64 is split.  Same answers either way.
+    run_case(client, oracle, m, n, k, ElemType.BF16, ElemType.BF16, True, ALGOS["lp128"])
+
+
 def test_split_k_batched_padded_and_repeatable(client, oracle):
     run_case(client, oracle, 64, 256, 2048, ElemType.F16, ElemType.F16, True, ALGOS["lp128"], batch=2, lda=2056, ldb=2048, ldc=264)
     m, n, k = 64, 1024, 4096

@@ -1,0 +1,19 @@
+"""dev: lp128 (algo 3) on skinny shapes with 96-255 tiles of 128^2, for the library named by MI355CUBE_LIB (GPU box)."""
+import ctypes as C, os, sys
+sys.path.insert(0, ".")
+import bench
+from cubecl_amd import ElemType, Mi355Runtime, TensorHandle
+from cubecl_amd import _native as N
+client = Mi355Runtime.client(); lib, ctx = client.lib, client.ctx
+ev = bench.Events(client)
+out = []
+for (m, n, k) in ((128, 4096, 2048), (128, 4096, 4096), (256, 2048, 4096), (128, 2048, 2048), (128, 1024, 8192), (128, 6144, 3072), (128, 6144, 8192), (256, 2048, 2048), (128, 3072, 1024), (384, 1024, 4096), (128, 8192, 4096), (128, 8192, 8192), (128, 5120, 5120), (128, 28672, 8192), (128, 14336, 4096), (128, 16384, 1024), (256, 8192, 8192)):
+    a = TensorHandle.uniform(client, (m, k), ElemType.BF16, 1, 1, -1.0, 1.0); b = TensorHandle.uniform(client, (n, k), ElemType.BF16, 1, 2, -1.0, 1.0)
+    c = client.empty(m * n * 2)
+    d = bench.gemm_desc(N, m, n, k, N.DTYPE_BF16, N.DTYPE_BF16, trans_b=1, algo=3)
+    run = lambda: lib.mi355_gemm(ctx, None, C.byref(d), a.device_ptr(), b.device_ptr(), c.device_ptr())
+    assert run() == 0
+    best = min(bench.time_op(client, ev, run, 20, warmup=3) for _ in range(5))
+    t = ((m + 127) // 128) * ((n + 127) // 128)
+    out.append(f"{m}x{n}x{k}[{t}] {best * 1e3:5.1f}")
+print(os.path.basename(os.environ.get("MI355CUBE_LIB", "product")), " | ".join(out), flush=True)
