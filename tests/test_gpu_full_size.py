@@ -430,3 +430,27 @@ def test_skinny_and_output_bound_shapes_as_benched(client, oracle, m, n, k):
         client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()),
                                               C.c_void_p(c2.device_ptr())))
         assert np.array_equal(c2.to_numpy(client), c.to_numpy(client))
+
+
+@pytest.mark.parametrize("m,n,k,want", [(16, 28672, 8192, "STREAM64"), (64, 28672, 8192, "LP_128"), (128, 14336, 4096, "LP_128")])
+def test_decode_like_products_at_size(client, oracle, m, n, k, want):
+    """tokens x out_features x in_features as a decoder serves them (bf16 -> bf16, AUTO): 16 tokens take the streaming kernel
+    in its two-workgroups-per-CU form (896 workgroups), 64 and 128 tokens the 128x128 kernel WITHOUT split-K since round 2
+    (224 / 112 tiles for 128 / 64 K-tiles: the launcher's rule, gemm_lp128.hip).  All rows, three blocks of 256 columns (first,
+    one across a tile boundary in the middle, last) against the f64 oracle."""
+    import ctypes as C
+    a = TensorHandle.uniform(client, (m, k), ElemType.BF16, SEED, 710, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (n, k), ElemType.BF16, SEED, 711, -1.0, 1.0)
+    c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 2), ElemType.BF16)
+    client._s.check(client.lib.mi355_memset(client.ctx, None, C.c_void_p(c.device_ptr()), 0xEE, m * n * 2))
+    d = _bench_desc(m, n, k, N.DTYPE_BF16, N.DTYPE_BF16)
+    assert ops.gemm_select(client, d) == getattr(N, "GEMM_ALGO_" + want)
+    client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()),
+                                          C.c_void_p(c.device_ptr())))
+    got = c.to_numpy(client).reshape(m, n)
+    a_bits = oracle.to_bf16(oracle.fill_uniform(m * k, 710, -1.0, 1.0))
+    b_bits = oracle.to_bf16(oracle.fill_uniform(n * k, 711, -1.0, 1.0)).reshape(n, k)
+    rows = np.arange(m)
+    for c0 in (0, n // 2 - 128 - 64, n - 256):
+        _bf16_rows_check(oracle, a_bits, b_bits[c0:c0 + 256].reshape(-1), got[:, c0:c0 + 256], rows, k, 256)
+    assert not np.any(got == 0xEEEE)      # every element was written (0xEEEE is the fill pattern, -3.7e28 as a bf16)
