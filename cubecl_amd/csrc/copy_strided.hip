@@ -177,8 +177,10 @@ pack_copy_kernel(const T *__restrict__ in, T *__restrict__ out, uint64_t groups,
 // index on the other ("planar": q contiguous, p strided by `sp`): NHWC <-> NCHW images with few channels, complex <-> split
 // re / im, RGB planes.  A thread moves K = 16 / sizeof(T) consecutive q for all NP planes: NP consecutive 16-byte vectors on
 // the interleaved side, one 16-byte vector per plane on the planar side, and the NP x K elements change places in registers
-// (byte permutes; no LDS).  `d` counts q in groups of K (axis 0) and carries the remaining axes; GATHER = the input is the
-// interleaved side.  Every byte is moved once with whole-line accesses on both sides.
+// (byte permutes).  On the interleaved side a lane's NP vectors are consecutive, so the vectors additionally change LANES
+// through 4 KiB of LDS per wave whenever the wave's 64 groups are one contiguous run there: every load / store instruction
+// then moves 1 KiB whole instead of touching every NP-th vector.  `d` counts q in groups of K (axis 0) and carries the
+// remaining axes; GATHER = the input is the interleaved side.  Every byte is moved once, in whole lines on both sides.
 template <typename T, int NP, bool GATHER, bool WIDE>
 __global__ void __launch_bounds__(256)
 plane_copy_kernel(const T *__restrict__ in, T *__restrict__ out, uint64_t groups, dims d, int64_t sp)
