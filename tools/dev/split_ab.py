@@ -7,7 +7,7 @@ from cubecl_amd import _native as N
 client = Mi355Runtime.client(); lib, ctx = client.lib, client.ctx
 ev = bench.Events(client)
 out = []
-for (m, n, k) in ((128, 4096, 2048), (128, 4096, 4096), (256, 2048, 4096), (128, 2048, 2048), (128, 1024, 8192), (128, 6144, 3072), (128, 6144, 8192), (256, 2048, 2048), (128, 3072, 1024), (384, 1024, 4096), (128, 8192, 4096), (128, 8192, 8192), (128, 5120, 5120), (128, 28672, 8192), (128, 14336, 4096), (128, 16384, 1024), (256, 8192, 8192)):
+for (m, n, k) in ((64, 28672, 8192), (96, 24576, 4096), (64, 14336, 4096), (200, 12288, 4096), (128, 28672, 8192), (64, 8192, 8192), (1000, 1000, 4096), (72, 16384, 2048), (2048, 2048, 2048), (32, 20480, 8192)):
     a = TensorHandle.uniform(client, (m, k), ElemType.BF16, 1, 1, -1.0, 1.0); b = TensorHandle.uniform(client, (n, k), ElemType.BF16, 1, 2, -1.0, 1.0)
     c = client.empty(m * n * 2)
     d = bench.gemm_desc(N, m, n, k, N.DTYPE_BF16, N.DTYPE_BF16, trans_b=1, algo=3)
