@@ -675,7 +675,7 @@ def main():
 
         def skinny():
             out = {}
-            for (m, n, k) in ((8192, 8192, 64), (64, 8192, 8192), (8192, 64, 8192), (1, 8192, 8192), (16, 8192, 8192), (16, 28672, 8192), (4096, 4096, 4096),
+            for (m, n, k) in ((8192, 8192, 64), (64, 8192, 8192), (8192, 64, 8192), (1, 8192, 8192), (16, 8192, 8192), (16, 28672, 8192), (64, 28672, 8192), (128, 28672, 8192), (4096, 4096, 4096),
                               (6144, 6144, 6144), (4608, 4096, 8192), (2048, 2048, 2048)):
                 sa = TensorHandle.uniform(client, (m, k), ElemType.BF16, SEED, 700, -1.0, 1.0)
                 sb = TensorHandle.uniform(client, (n, k), ElemType.BF16, SEED, 701, -1.0, 1.0)
