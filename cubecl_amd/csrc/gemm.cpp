@@ -55,17 +55,24 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
     // grid is at most two rounds of workgroups and not a handful of workgroups each walking a very long K
     // (64 x 8192 x 8192 24.4 us against 29.9, 16 x 8192 x 8192 22.3 / 26.4, 8192 x 64 x 8192 24.4 / 33.7, 32 x 8192 x 2048 7.6 / 14.8;
     // lost: 64 x 32768 x 4096 59 / 45, 64 x 4096 x 16384 38 / 33, 16 x 65536 x 1024 41 / 24).
+    // three or four rows (or columns) against a small matrix: the dot-product kernel, whose workgroups are many and short,
+    // beats both MFMA paths until the streamed operand reaches a few tens of MB (tools/dev/select_audit.py: 4 x 2048 x 4096
+    // 8.8 us against 10.5 streaming, 2048 x 4 x 2048 5.7 / 7.1, 384 x 4 x 8192 11.7 / 16.1 on the 128x128 kernel, 4 x 512 x
+    // 14336 18.7 / 21.8; 4 x 8192 x 8192 the other way, 24.8 / 22.0)
+    if (std::min(d.m, d.n) > 2 && std::min(d.m, d.n) <= 4 && std::max(d.m, d.n) * d.k * 2 <= (32ll << 20) && d.batch == 1 &&
+        gemm_skinny_supports(d, a, b, c))
+        return MI355_GEMM_ALGO_SKINNY;
     if (std::min(d.m, d.n) > 2 && std::min(d.m, d.n) <= 64 && gemm_stream64_supports(d, a, b, c)) {
         const int64_t wgs = ((std::max(d.m, d.n) + 31) / 32) * d.batch, nk64 = d.k / 64;
         const int64_t small_bytes = std::min(d.m, d.n) * d.k * 2;
-        // * every workgroup re-reads the small operand from L2: past ~1.5 MiB the streamed operand evicts it
-        //   (64 x 8192 x 28672: 110 us against 93 on the split-K path);
+        // * every workgroup re-reads the small operand from L2: past ~2 MiB the streamed operand evicts it
+        //   (64 x 8192 x 28672, 3.5 MiB: 110 us against 93 on the 128x128 path; 8192 x 64 x 14336, 1.75 MiB: 41.4 against 49.0);
         // * up to 32 rows the kernel keeps winning on large grids in its two-workgroups-per-CU form (16 x 28672 x 8192 83.5 us
         //   against 111.5, 16 x 32000 x 4096 42.0 / 53.9); with 33-64 rows only up to two rounds (64 x 14336 x 4096 24.0 / 35.2,
         //   64 x 28672 x 8192 a tie, 64 x 128256 x 4096 295 / 203);
         // * a workgroup walks its K-tiles alone (~0.15 us each): long K needs enough workgroups for that to be hidden.
         const int64_t max_wgs = std::min(d.m, d.n) <= 32 ? 2048 : 512;
-        if (small_bytes <= (3ll << 19) && wgs <= max_wgs && (nk64 <= 64 || (nk64 <= 128 && wgs >= 64) || wgs >= 192))
+        if (small_bytes <= (1ll << 21) && wgs <= max_wgs && (nk64 <= 64 || (nk64 <= 128 && wgs >= 64) || wgs >= 192))
             return MI355_GEMM_ALGO_STREAM64;
     }
     // one or two rows (or columns): HBM-bound on the other operand; stream it once with dot products, no MFMA tile to fill
@@ -227,7 +234,11 @@ bool prefers_persistent(const mi355_gemm_desc &d, const void *a, const void *b, 
 {
     if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16) return false;
     const int64_t tiles = ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch, nk = d.k / 64;
-    if (tiles < 512 || nk > 64) return false;
+    // more than one round of tiles (round 2: was two full rounds).  With 257-511 tiles the second round is partly empty either
+    // way, and the tile hand-over of the persistent forms still hides the epilogues: 8192 x 3072 x 512 (384 tiles) 32.5 ->
+    // 28.1 us, x 1024 50.0 -> 45.8, 7168 x 4096 x 1024 (448) 52.1 -> 49.9, 8192 x 2560 x 512 (320) 30.2 -> 27.2, level from
+    // K = 2048 up (tools/dev/shortk_probe.py)
+    if (tiles <= 256 || nk > 64) return false;
     if (!gemm_lp256p_supports(d, a, b, c)) return false;
     tail_plan tp;
     return !plan_tail_split(d, tp);
