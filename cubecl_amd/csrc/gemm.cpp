@@ -56,10 +56,10 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
     // (64 x 8192 x 8192 24.4 us against 29.9, 16 x 8192 x 8192 22.3 / 26.4, 8192 x 64 x 8192 24.4 / 33.7, 32 x 8192 x 2048 7.6 / 14.8;
     // lost: 64 x 32768 x 4096 59 / 45, 64 x 4096 x 16384 38 / 33, 16 x 65536 x 1024 41 / 24).
     // three or four rows (or columns) against a small matrix: the dot-product kernel, whose workgroups are many and short,
-    // beats both MFMA paths until the streamed operand reaches a few tens of MB (tools/dev/select_audit.py: 4 x 2048 x 4096
+    // beats both MFMA paths while the streamed operand is at most 16 MiB (tools/dev/select_audit.py: 4 x 2048 x 4096
     // 8.8 us against 10.5 streaming, 2048 x 4 x 2048 5.7 / 7.1, 384 x 4 x 8192 11.7 / 16.1 on the 128x128 kernel, 4 x 512 x
-    // 14336 18.7 / 21.8; 4 x 8192 x 8192 the other way, 24.8 / 22.0)
-    if (std::min(d.m, d.n) > 2 && std::min(d.m, d.n) <= 4 && std::max(d.m, d.n) * d.k * 2 <= (32ll << 20) && d.batch == 1 &&
+    // 14336 18.7 / 21.8; the other way from 32 MiB: 8192 x 4 x 2048 8.2-9.7 / 7.0, 4 x 8192 x 8192 24.8 / 22.0)
+    if (std::min(d.m, d.n) > 2 && std::min(d.m, d.n) <= 4 && std::max(d.m, d.n) * d.k * 2 <= (16ll << 20) && d.batch == 1 &&
         gemm_skinny_supports(d, a, b, c))
         return MI355_GEMM_ALGO_SKINNY;
     if (std::min(d.m, d.n) > 2 && std::min(d.m, d.n) <= 64 && gemm_stream64_supports(d, a, b, c)) {
