@@ -83,6 +83,19 @@ template <int N> __device__ __forceinline__ void wait_vmcnt()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+#ifndef S64_T1_G
+#define S64_T1_G 4      // dev: ring geometry of the two-workgroups-per-CU form with up to 32 small rows (G, SGA, SGB)
+#define S64_T1_SGA 2
+#define S64_T1_SGB 2
+#endif
+// Ring geometry per form: G = K-tiles per hand-over (one s_barrier per group), SGA / SGB = groups in the small / streamed ring.
+template <int MB, bool TWO> struct ring_geom {
+    static constexpr int G = (TWO && MB == 1) ? S64_T1_G : MB == 2 ? 2 : 4;
+    static constexpr int SGA = (TWO && MB == 1) ? S64_T1_SGA : TWO ? 2 : (MB == 2 ? 3 : 2);
+    static constexpr int SGB = (TWO && MB == 1) ? S64_T1_SGB : TWO ? 5 : (MB == 2 ? 12 : 6);
+    static constexpr int LDS = SGA * G * MB * BLK + SGB * G * BLK;      // small ring + streamed ring: 128-144 KiB, or 64-72 KiB x 2
+};
+
 // MB: 32-row blocks of the small operand (1: up to 32 rows, 2: up to 64).
 // TWO: half-depth rings, two workgroups per CU -- for grids of more than one workgroup per CU, where a starting workgroup's
 // empty ring and a finishing one's drain overlap the neighbour's streaming (16 x 28672 x 8192: 107 -> 83.5 us); with one
@@ -94,9 +107,8 @@ __global__ void __launch_bounds__(640, TWO ? 5 : 2) gemm_stream64_kernel(stream_
     // (with both operands in one 12-16 slot ring only 40-48 KiB of it were, and the kernel sat at 4.5 TB/s).  The small
     // operand is L2-resident and needs only a few K-tiles of look-ahead.  They cannot share loader waves: `vmcnt` retires in
     // order, so a wave waiting for a near small-operand piece would also wait for every far streamed piece it issued before.
-    constexpr int G = MB == 2 ? 2 : 4;                    // K-tiles per hand-over (one s_barrier per group)
-    constexpr int SGA = TWO ? 2 : (MB == 2 ? 3 : 2);                    // groups in the small operand's ring
-    constexpr int SGB = TWO ? (MB == 2 ? 5 : 2) : (MB == 2 ? 12 : 6);   // groups in the streamed operand's ring
+    typedef ring_geom<MB, TWO> RG;
+    constexpr int G = RG::G, SGA = RG::SGA, SGB = RG::SGB;
     constexpr int SA = SGA * G, SB = SGB * G;
     constexpr int A_STAGE = MB * BLK;
     constexpr int B_RING = SA * A_STAGE;                  // byte offset of the streamed ring
@@ -267,9 +279,7 @@ __global__ void __launch_bounds__(640, TWO ? 5 : 2) gemm_stream64_kernel(stream_
 template <int DT, int MB, bool TWO>
 void launch_form(mi355_ctx *ctx, hipStream_t s, const stream_args &g, uint32_t batch, int slot)
 {
-    constexpr int G_ = MB == 2 ? 2 : 4;
-    constexpr int SGA_ = TWO ? 2 : (MB == 2 ? 3 : 2), SGB_ = TWO ? (MB == 2 ? 5 : 2) : (MB == 2 ? 12 : 6);
-    constexpr int LDS = SGA_ * G_ * MB * BLK + SGB_ * G_ * BLK;          // small ring + streamed ring: 128-144 KiB, or 64-72 KiB x 2
+    constexpr int LDS = ring_geom<MB, TWO>::LDS;
     if (!(ctx->func_attr_mask2 & (1ull << slot))) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_stream64_kernel<DT, MB, TWO>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         ctx->func_attr_mask2 |= (1ull << slot);

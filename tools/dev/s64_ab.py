@@ -7,7 +7,7 @@ from cubecl_amd import _native as N
 client = Mi355Runtime.client(); lib, ctx = client.lib, client.ctx
 ev = bench.Events(client)
 out = []
-for (m, n, k) in ((64, 8192, 8192), (16, 8192, 8192), (8192, 64, 8192), (4, 8192, 8192), (32, 8192, 2048), (16, 28672, 8192), (32, 14336, 4096), (64, 14336, 4096), (64, 6144, 4096), (64, 4096, 4096)):
+for (m, n, k) in ((16, 28672, 8192), (32, 14336, 4096), (16, 32000, 4096), (8, 16384, 4096), (32, 24576, 2048), (16, 8192, 8192), (64, 8192, 8192), (64, 14336, 4096)):
     a = TensorHandle.uniform(client, (m, k), ElemType.BF16, 1, 1, -1.0, 1.0); b = TensorHandle.uniform(client, (n, k), ElemType.BF16, 1, 2, -1.0, 1.0)
     c = client.empty(m * n * 2)
     d = bench.gemm_desc(N, m, n, k, N.DTYPE_BF16, N.DTYPE_BF16, trans_b=1, algo=9)
