@@ -314,6 +314,71 @@ def test_trait_impls_match_the_reference_traits():
     assert not problems, "\n".join(problems)
 
 
+def _norm_type(ty):
+    ty = re.sub(r"'\w+\s*", "", ty)                    # lifetimes
+    ty = re.sub(r"\s+", "", ty)
+    ty = ty.replace("crate::", "").replace("self::", "")
+    return re.sub(r"(\w+::)+(\w+)", r"\2", ty)          # module paths: the last segment names the type
+
+
+def _signature(text, args, end):
+    params = []
+    for a in split_top(args):
+        a = a.strip()
+        if not a:
+            continue
+        if re.match(r"^(&\s*('\w+\s*)?)?(mut\s+)?self\b", a):
+            params.append(re.sub(r"\s+", "", re.sub(r"'\w+\s*", "", a)))
+        else:
+            params.append(_norm_type(a.partition(":")[2]))
+    m = re.match(r"\s*->\s*([^{;]+?)\s*(where\b[^{;]*)?[{;]", text[end:], flags=re.S)
+    return params, (_norm_type(m.group(1)) if m else "")
+
+
+# the only places where an impl may spell a type differently from the trait: an associated or generic type written out
+SIGNATURE_SUBSTITUTIONS = {
+    ("ComputeServer", "get_resource"): ("<StorageasComputeStorage>::Resource", "DeviceSlice"),        # type Storage = DeviceStorage
+    ("CubeTask", "compile"): None,                                                                      # C = Mi355Compiler, see below
+}
+
+
+def test_trait_impl_signatures_are_the_reference_signatures_type_for_type():
+    """Parameter types and return types of every method the crate implements for a reference trait, compared as text with
+    the trait's own declaration (whitespace, lifetimes and module paths aside).  What a first `cargo check` would say about
+    the method headers, as far as text can."""
+    problems, compared = [], 0
+    for name, text in shim_sources().items():
+        for m in re.finditer(r"\bimpl(?:<[^>]*>)?\s+(?:[\w:]+::)?(\w+)(?:<[^>{]*>)?\s+for\s+([\w<>:, ]+?)\s*\{", text):
+            trait = m.group(1)
+            if trait not in TRAITS:
+                continue
+            body = balanced(text, m.end() - 1)
+            ttext = strip_comments(Path(TRAITS[trait]).read_text())
+            tm = re.search(rf"pub trait {trait}\b[^{{]*\{{", ttext)
+            tbody = balanced(ttext, tm.end() - 1)
+            want = {f: _signature(tbody, a, e) for f, st, a, e in find_fns(tbody) if tbody[:st].count("{") == tbody[:st].count("}")}
+            for fname, start, args, end in find_fns(body):
+                if body[:start].count("{") != body[:start].count("}") or fname not in want:
+                    continue
+                have, ref = _signature(body, args, end), want[fname]
+                compared += 1
+                if have == ref:
+                    continue
+                sub = SIGNATURE_SUBSTITUTIONS.get((trait, fname), ())
+                if sub is None:      # CubeTask<C>::compile with C = Mi355Compiler: `&mut C`, `&C::CompilationOptions`, `CompiledKernel<C>`
+                    ok = have == (["&self", "KernelDefinition", "&mutMi355Compiler", "&<Mi355CompilerasCompiler>::CompilationOptions"],
+                                  "Result<CompiledKernel<Mi355Compiler>,CompilationError>") and \
+                         ref == (["&self", "KernelDefinition", "&mutC", "&CompilationOptions"], "Result<CompiledKernel<C>,CompilationError>")
+                elif sub:
+                    ok = ([p.replace(sub[0], sub[1]) for p in ref[0]], ref[1].replace(sub[0], sub[1])) == have
+                else:
+                    ok = False
+                if not ok:
+                    problems.append(f"{name}: {trait}::{fname}\n    reference: ({', '.join(ref[0])}) -> {ref[1]}\n    crate    : ({', '.join(have[0])}) -> {have[1]}")
+    assert compared >= 60, compared
+    assert not problems, "\n".join(problems)
+
+
 # struct / enum-variant literals of reference types the crate builds: name -> (file, kind)
 LITERALS = {
     "CompiledKernel": RT / "kernel.rs",
