@@ -129,6 +129,54 @@ def test_rust_ffi_declares_every_header_symbol():
     assert {k: (c_side[k], rust[k]) for k in header if c_side[k] != rust[k]} == {}
 
 
+def test_rust_ffi_parameter_types_are_the_c_prototypes():
+    """Every `pub fn mi355_*` of ffi.rs against its C prototype, parameter by parameter and the return type: the C type is
+    translated (int32_t -> i32, `const T *` -> `*const T`, `T **` -> `*mut *mut T`, `void *const *` -> `*const *mut c_void`,
+    arrays decay) and must read like the Rust one."""
+    import re
+    root = Path(__file__).resolve().parents[1]
+    hdr = re.sub(r"/\*.*?\*/", "", (root / "include" / "mi355cube.h").read_text(), flags=re.S)
+    hdr = re.sub(r"//[^\n]*", "", hdr)
+    hdr = re.sub(r"^\s*#[^\n]*$", "", hdr, flags=re.M)
+    rs = re.sub(r"//[^\n]*", "", (root / "rust" / "cubecl-mi355" / "src" / "ffi.rs").read_text())
+    base = {"int32_t": "i32", "uint32_t": "u32", "int64_t": "i64", "uint64_t": "u64", "uint8_t": "u8", "uint16_t": "u16", "size_t": "usize",
+            "float": "f32", "double": "f64", "char": "c_char", "void": "c_void", "int": "c_int", "unsigned": "c_uint", "unsigned int": "c_uint"}
+
+    def c_to_rust(ctype):
+        toks = re.findall(r"\*|\w+", ctype)
+        lead = [t for t in toks[: toks.index("*")] ] if "*" in toks else toks
+        pointee_const = "const" in lead
+        name = " ".join(t for t in lead if t not in ("const", "struct"))
+        out = base.get(name, name)
+        rest = toks[len(lead):]
+        i = 0
+        while i < len(rest):                      # each `*`, optionally followed by `const` (which qualifies THIS pointer)
+            assert rest[i] == "*", ctype
+            out = ("*const " if pointee_const else "*mut ") + out
+            pointee_const = i + 1 < len(rest) and rest[i + 1] == "const"
+            i += 2 if pointee_const else 1
+        return out
+
+    def c_param(p):
+        m = re.match(r"^(.*?)(\b\w+)\s*(\[\s*\w*\s*\])?$", p.strip(), flags=re.S)
+        ty, name, arr = m.group(1), m.group(2), m.group(3)
+        if not ty.strip():
+            ty = name                                  # an unnamed parameter: the identifier was the type
+        return c_to_rust(ty + ("*" if arr else ""))
+
+    split = lambda args: [] if args.strip() in ("", "void") else [a.strip() for a in args.split(",")]
+    c_side = {}
+    for m in re.finditer(r"(?:MI355_API\s+)?([\w\s\*]+?)\b(mi355_\w+)\s*\(([^()]*)\)\s*;", hdr):
+        if "typedef" not in m.group(1):
+            c_side[m.group(2)] = ([c_param(p) for p in split(m.group(3))], c_to_rust(m.group(1).strip()))
+    rust = {}
+    for m in re.finditer(r"pub fn (mi355_\w+)\s*\(([^()]*)\)\s*(?:->\s*([^;]+))?;", rs):
+        rust[m.group(1)] = ([re.sub(r"\s+", " ", a.partition(":")[2].strip()) for a in split(m.group(2))],
+                            re.sub(r"\s+", " ", (m.group(3) or "c_void").strip()))
+    assert len(c_side) >= 90 and set(c_side) == set(rust)
+    assert {k: (c_side[k], rust[k]) for k in c_side if c_side[k] != rust[k]} == {}
+
+
 def test_rust_ffi_structs_have_the_header_field_order():
     import re
     root = Path(__file__).resolve().parents[1]
