@@ -177,6 +177,51 @@ def test_rust_ffi_parameter_types_are_the_c_prototypes():
     assert {k: (c_side[k], rust[k]) for k in c_side if c_side[k] != rust[k]} == {}
 
 
+def test_python_ctypes_prototypes_are_the_c_prototypes():
+    """cubecl_amd/_native.py PROTOTYPES (what every ctypes call of the Python mirror is checked against) versus the header:
+    same parameter count, and per parameter the same class -- any pointer (or handle) on both sides, else the same width,
+    signedness and float-ness."""
+    import ctypes as C
+    import re
+    from cubecl_amd import _native
+    root = Path(__file__).resolve().parents[1]
+    hdr = re.sub(r"/\*.*?\*/", "", (root / "include" / "mi355cube.h").read_text(), flags=re.S)
+    hdr = re.sub(r"//[^\n]*", "", hdr)
+    hdr = re.sub(r"^\s*#[^\n]*$", "", hdr, flags=re.M)
+    scalar = {"int32_t": C.c_int32, "uint32_t": C.c_uint32, "int64_t": C.c_int64, "uint64_t": C.c_uint64, "size_t": C.c_size_t,
+              "float": C.c_float, "double": C.c_double, "int": C.c_int}
+    handles = {"mi355_stream", "mi355_event", "mi355_module", "mi355_function"}
+
+    def c_class(p, is_param=True):
+        p = p.strip()
+        if "*" in p or "[" in p:
+            return "ptr"
+        toks = [t for t in re.findall(r"\w+", p) if t not in ("const", "struct")]
+        ty = toks[0] if (len(toks) == 1 or not is_param) else " ".join(toks[:-1])
+        return "ptr" if ty in handles else scalar[ty]
+
+    def py_class(t):
+        if t is None:
+            return "void"
+        if t in (C.c_void_p, C.c_char_p) or isinstance(t, type(C.POINTER(C.c_int))) and hasattr(t, "contents"):
+            return "ptr"
+        return t
+
+    split = lambda args: [] if args.strip() in ("", "void") else [a.strip() for a in args.split(",")]
+    checked = 0
+    for m in re.finditer(r"(?:MI355_API\s+)?([\w\s\*]+?)\b(mi355_\w+)\s*\(([^()]*)\)\s*;", hdr):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3)
+        if "typedef" in ret:
+            continue
+        restype, argtypes = _native.PROTOTYPES[name]
+        want = [c_class(p) for p in split(args)]
+        have = [py_class(t) for t in argtypes]
+        assert want == have, (name, want, have)
+        assert ("void" if ret == "void" else c_class(ret, is_param=False)) == py_class(restype), (name, ret, restype)
+        checked += 1
+    assert checked >= 90 and checked == len(_native.PROTOTYPES)
+
+
 def test_rust_ffi_structs_have_the_header_field_order():
     import re
     root = Path(__file__).resolve().parents[1]
