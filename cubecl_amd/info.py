@@ -3,10 +3,10 @@
 Mirrors
   * crates/cubecl-core/src/codegen/scalars.rs:10-64     `ScalarBuilder`: scalar arguments grouped by element type in the
                                                         type's sort order, each group zero-padded to 8 bytes
-  * crates/cubecl-core/src/codegen/metadata.rs:36-163   `MetadataBuilder`: buffer lengths of every binding, then a shape
+  * crates/cubecl-core/src/codegen/metadata.rs:36-157   `MetadataBuilder`: buffer lengths of every binding, then a shape
                                                         offset and a stride offset per tensor (static part); all shapes,
                                                         then all strides (dynamic part); in u32 or u64 per the address type
-  * crates/cubecl-core/src/codegen/info.rs:8-36         `InfoBuilder.finish`: [scalars | static | dynamic] as u64 words,
+  * crates/cubecl-core/src/codegen/info.rs:8-34         `InfoBuilder.finish`: [scalars | static | dynamic] as u64 words,
                                                         `dynamic_metadata_offset` = words before the dynamic part
   * crates/cubecl-runtime/src/server/base.rs:1027-1098  `KernelArguments`, `MetadataBindingInfo` (+ `custom` for kernels
                                                         compiled outside the reference's code generator)

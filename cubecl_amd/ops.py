@@ -321,7 +321,7 @@ def plane_reduce(client: ComputeClient, input: TensorHandle, output: TensorHandl
 
 
 def identity(client: ComputeClient, output: TensorHandle) -> None:
-    """tensor::identity::launch (crates/cubecl-std/src/tensor/identity.rs:36-86): `output`, a square matrix (possibly with
+    """tensor::identity::launch (crates/cubecl-std/src/tensor/identity.rs:36-84): `output`, a square matrix (possibly with
     pitched rows), becomes the identity matrix of its dtype."""
     if output.rank() != 2:
         raise ServerError(N.E_INVALID_ARGUMENT, "identity: input should be a matrix")

@@ -509,7 +509,7 @@ int32_t mi355_reduce_axis_argmax(mi355_ctx *ctx, mi355_stream stream, const void
 int32_t mi355_plane_reduce_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, float *out,
                                uint64_t n, uint32_t active, int32_t op);
 
-/* tensor::identity::launch (crates/cubecl-std/src/tensor/identity.rs:36-86): writes the dim x dim identity matrix
+/* tensor::identity::launch (crates/cubecl-std/src/tensor/identity.rs:36-84): writes the dim x dim identity matrix
  * (1 on the diagonal in `dtype`, 0 elsewhere) into rows `ld` elements apart (ld >= dim; the padding of a pitched
  * allocation is left alone).  dtype: any float, integer or fp8 type of this header. */
 int32_t mi355_fill_identity(mi355_ctx *ctx, mi355_stream stream, void *out, int32_t dtype, uint64_t dim, uint64_t ld);

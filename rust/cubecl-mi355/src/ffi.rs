@@ -309,7 +309,7 @@ unsafe extern "C" {
     // ComputeClient::to_client (client.rs:733-751)
     pub fn mi355_copy_to_ctx(src_ctx: *mut mi355_ctx, src_stream: mi355_stream, src_dptr: *const c_void, dst_ctx: *mut mi355_ctx,
                              dst_stream: mi355_stream, dst_dptr: *mut c_void, bytes: u64) -> i32;
-    // tensor::identity::launch (crates/cubecl-std/src/tensor/identity.rs:36-86)
+    // tensor::identity::launch (crates/cubecl-std/src/tensor/identity.rs:36-84)
     pub fn mi355_fill_identity(ctx: *mut mi355_ctx, stream: mi355_stream, out: *mut c_void, dtype: i32, dim: u64, ld: u64) -> i32;
     // copy_into / into_contiguous / into_contiguous_packed (crates/cubecl-std/src/tensor/contiguous/launch.rs:5-56, base.rs:254-293)
     pub fn mi355_copy_strided(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const c_void, in_layout: *const mi355_tensor_layout,
