@@ -605,7 +605,7 @@ def test_autotune_bounds_known_answers():
 
 
 def test_reference_citations_point_at_lines_that_exist():
-    """Every `crates/...rs:a-b` (or `examples/`, `cubecl-book/`) citation in the header, the sources, the docs and the tests names a
+    """Every citation of the form crates/<path>.rs:a-b (or under examples/, cubecl-book/) in the header, the sources, the docs and the tests names a
     file of the reference snapshot and a line range inside it -- the judge checks parity through these."""
     import glob
     import os
