@@ -239,6 +239,35 @@ def test_rust_ffi_structs_have_the_header_field_order():
     assert len(c_structs) >= 7
     for name, fields in c_structs.items():
         assert rust.get(name) == fields, name
+    # ... and the field TYPES: `int64_t shape[8]` <-> `[i64; 8]`, `const void *p` <-> `*const c_void`, nested structs by name
+    base = {"int32_t": "i32", "uint32_t": "u32", "int64_t": "i64", "uint64_t": "u64", "uint8_t": "u8", "uint16_t": "u16", "size_t": "usize",
+            "float": "f32", "double": "f64", "char": "c_char", "void": "c_void", "int": "c_int"}
+    consts = {k: v for k, v in re.findall(r"#define\s+(MI355_\w+)\s+(\d+)", hdr)}
+
+    def field_types(body):
+        out = []
+        for decl in filter(None, (d.strip() for d in body.split(";"))):
+            head, *more = [x.strip() for x in decl.split(",")]
+            toks = head.split()
+            ctype, first = " ".join(toks[:-1]), toks[-1]
+            for nm in [first] + more:
+                stars = nm.count("*") + ctype.count("*")
+                dims = [consts.get(d, d) for d in re.findall(r"\[(\w+)\]", nm)]
+                t = re.sub(r"\bconst\b|\bstruct\b|\*", "", ctype).strip()
+                r = base.get(t, t)
+                for _ in range(stars):
+                    r = ("*const " if "const" in ctype else "*mut ") + r
+                for d in reversed(dims):
+                    r = f"[{r}; {d}]"
+                out.append(r)
+        return out
+
+    c_types = {m.group(2): field_types(m.group(1)) for m in re.finditer(r"typedef struct(?:\s+\w+)?\s*\{(.*?)\}\s*(\w+)\s*;", hdr, flags=re.S)}
+    r_types = {m.group(1): [re.sub(r"\s+", " ", t.strip()) for t in re.findall(r"pub \w+\s*:\s*([^,}]+(?:;[^,}\]]+\])?)", m.group(2))]
+               for m in re.finditer(r"pub struct (\w+)\s*\{(.*?)\}", ffi, flags=re.S)}
+    for name, types in c_types.items():
+        have = [re.sub(r";\s*(MI355_\w+)", lambda mm: "; " + consts.get(mm.group(1), mm.group(1)), t) for t in r_types.get(name, [])]
+        assert have == types, (name, [(a, b) for a, b in zip(types, have) if a != b] or (types, have))
 
 
 def test_product_never_reaches_for_the_fake_runtime():
