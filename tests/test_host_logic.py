@@ -635,3 +635,32 @@ def test_reference_citations_point_at_lines_that_exist():
                     bad.append((os.path.relpath(f, root), m.group(0), f"the file has {n} lines"))
     assert total >= 200, total
     assert not bad, bad
+
+
+def test_hazard_scanner_on_synthetic_assembly():
+    """tools/hazard_scan.py (run over the real kernels by tests/test_abi_cpu.py) on four hand-written snippets: a VMEM
+    instruction reading an SGPR two wait states after v_readfirstlane wrote it is reported with its wait-state count, s_nop N
+    counts N + 1, five wait states are enough, and a scalar rewrite of the register clears the hazard."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("hazard_scan", Path(__file__).resolve().parents[1] / "tools" / "hazard_scan.py")
+    hs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hs)
+    bad = hs.scan_text("""
+        v_readfirstlane_b32 s19, v5
+        v_readfirstlane_b32 s18, v4
+        s_mov_b32 m0, s5
+        s_nop 0
+        global_load_lds_dwordx4 v110, s[18:19]
+    """)
+    assert bad == {("global_load_lds_dwordx4", 2): 1, ("global_load_lds_dwordx4", 3): 1}
+    ok = hs.scan_text("""
+        v_readfirstlane_b32 s18, v4
+        s_mov_b32 m0, s5
+        s_nop 4
+        global_load_lds_dwordx4 v110, s[18:19]
+    """)
+    assert ok == {}
+    assert hs.scan_text("v_readfirstlane_b32 s10, v16\nglobal_load_dword v11, v1, s[10:11]\n") == {("global_load_dword", 0): 1}
+    assert hs.scan_text("v_readfirstlane_b32 s10, v16\ns_add_u32 s10, s4, 64\nglobal_load_dword v11, v1, s[10:11]\n") == {}
+    assert hs.scan_text("v_cmp_lt_i32_e64 s[4:5], v1, v2\nbuffer_load_dword v3, v0, s[4:7], 0 offen\n") != {}
