@@ -55,11 +55,12 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
     // grid is at most two rounds of workgroups and not a handful of workgroups each walking a very long K
     // (64 x 8192 x 8192 24.4 us against 29.9, 16 x 8192 x 8192 22.3 / 26.4, 8192 x 64 x 8192 24.4 / 33.7, 32 x 8192 x 2048 7.6 / 14.8;
     // lost: 64 x 32768 x 4096 59 / 45, 64 x 4096 x 16384 38 / 33, 16 x 65536 x 1024 41 / 24).
-    // three or four rows (or columns) against a small matrix: the dot-product kernel, whose workgroups are many and short,
-    // beats both MFMA paths while the streamed operand is at most 16 MiB (tools/dev/select_audit.py: 4 x 2048 x 4096
-    // 8.8 us against 10.5 streaming, 2048 x 4 x 2048 5.7 / 7.1, 384 x 4 x 8192 11.7 / 16.1 on the 128x128 kernel, 4 x 512 x
-    // 14336 18.7 / 21.8; the other way from 32 MiB: 8192 x 4 x 2048 8.2-9.7 / 7.0, 4 x 8192 x 8192 24.8 / 22.0)
-    if (std::min(d.m, d.n) > 2 && std::min(d.m, d.n) <= 4 && std::max(d.m, d.n) * d.k * 2 <= (16ll << 20) && d.batch == 1 &&
+    // three or four rows (or columns) when the streaming kernel below would not fill the chip (it runs one workgroup per 32
+    // streamed rows): the dot-product kernel's many short workgroups beat both MFMA paths (tools/dev/select_audit.py:
+    // 4 x 2048 x 4096 8.8 us against 10.5, 2048 x 4 x 2048 5.7 / 7.1, 384 x 4 x 8192 11.7 / 16.1, 3072 x 4 x 8192 14.6 / 21.4,
+    // 2048 x 4 x 14336 21.3 / 27.8, 4096 x 4 x 14336 25.7 / 29.8); from 192 workgroups up the streaming kernel wins
+    // (8192 x 4 x 2048 7.0 against 8.2-9.7, 4 x 8192 x 8192 22.0 / 24.8)
+    if (std::min(d.m, d.n) > 2 && std::min(d.m, d.n) <= 4 && ((std::max(d.m, d.n) + 31) / 32) * d.batch < 192 && d.batch == 1 &&
         gemm_skinny_supports(d, a, b, c))
         return MI355_GEMM_ALGO_SKINNY;
     if (std::min(d.m, d.n) > 2 && std::min(d.m, d.n) <= 64 && gemm_stream64_supports(d, a, b, c)) {
@@ -70,9 +71,11 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
         // * up to 32 rows the kernel keeps winning on large grids in its two-workgroups-per-CU form (16 x 28672 x 8192 83.5 us
         //   against 111.5, 16 x 32000 x 4096 42.0 / 53.9); with 33-64 rows only up to two rounds (64 x 14336 x 4096 24.0 / 35.2,
         //   64 x 28672 x 8192 a tie, 64 x 128256 x 4096 295 / 203);
-        // * a workgroup walks its K-tiles alone (~0.15 us each): long K needs enough workgroups for that to be hidden.
+        // * a workgroup walks its K-tiles alone (~0.15 us each): K beyond 8192 needs enough workgroups for that to be hidden
+        //   (64 x 4096 x 16384 38 us against 33, 16 x 4096 x 14336 34.5 / 26.7; up to 8192 and 32 rows it wins with any grid: 32 x 512 x 8192
+        //   17.8 / 22.2, 512 x 16 x 8192 17.2 / 21.8, 128 x 16 x 8192 17.1 / 18.9).
         const int64_t max_wgs = std::min(d.m, d.n) <= 32 ? 2048 : 512;
-        if (small_bytes <= (1ll << 21) && wgs <= max_wgs && (nk64 <= 64 || (nk64 <= 128 && wgs >= 64) || wgs >= 192))
+        if (small_bytes <= (1ll << 21) && wgs <= max_wgs && (nk64 <= 64 || (nk64 <= 128 && (wgs >= 64 || std::min(d.m, d.n) <= 32)) || wgs >= 192))
             return MI355_GEMM_ALGO_STREAM64;
     }
     // one or two rows (or columns): HBM-bound on the other operand; stream it once with dot products, no MFMA tile to fill

@@ -878,8 +878,9 @@ def test_output_bound_shapes_select_the_small_tile(client):
     assert sel(64, 64, 4096) == sel(64, 2048, 8192) == sel(32, 8192, 16384) == sel(16, 28672, 8192) == sel(64, 14336, 4096) == N.GEMM_ALGO_STREAM64
     assert sel(64, 8192, 28672) == sel(64, 28672, 8192) == N.GEMM_ALGO_LP_128        # small operand past 2 MiB / 64 rows over more than 512 workgroups
     assert sel(8192, 64, 14336) == N.GEMM_ALGO_STREAM64                               # 1.75 MiB of small operand still streams
-    assert sel(4, 2048, 4096) == sel(384, 4, 8192) == sel(3, 512, 14336) == N.GEMM_ALGO_SKINNY   # 3-4 rows against at most 16 MiB
-    assert sel(8192, 4, 2048) == sel(4, 8192, 8192) == N.GEMM_ALGO_STREAM64           # ... and not beyond
+    assert sel(4, 2048, 4096) == sel(384, 4, 8192) == sel(3, 512, 14336) == sel(4096, 4, 14336) == N.GEMM_ALGO_SKINNY   # 3-4 rows, fewer than 192 streaming workgroups
+    assert sel(8192, 4, 2048) == sel(4, 8192, 8192) == N.GEMM_ALGO_STREAM64           # ... from 192 up the streaming kernel
+    assert sel(32, 512, 8192) == sel(512, 16, 8192) == N.GEMM_ALGO_STREAM64           # few workgroups are fine up to K = 8192
     assert sel(8192, 3072, 512) == N.GEMM_ALGO_LP_256Q and sel(8192, 3072, 640) == N.GEMM_ALGO_LP_256P   # 384 tiles: persistent from one round up
     assert sel(4096, 4096, 512) == N.GEMM_ALGO_LP_256W4                               # exactly one round: the plain kernel
 
