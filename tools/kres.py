@@ -5,12 +5,21 @@ import re, subprocess, sys, os
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 def demangle(n):
     try:
-        return subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", n], capture_output=True, text=True).stdout.strip()
+        for tool in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "c++filt"):
+            try:
+                out = subprocess.run([tool, n], capture_output=True, text=True).stdout.strip()
+                if out and out != n:
+                    return out
+            except Exception:
+                pass
+        return n
     except Exception:
         return n
 for src in sys.argv[1:]:
-    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Rpass-analysis=kernel-resource-usage",
-                          "-c", src, "-o", "/dev/null"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(src))).stderr
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-fvisibility=hidden",
+                          "-I" + os.path.join(root, "include"), "-Rpass-analysis=kernel-resource-usage", "-x", "hip",
+                          "-c", os.path.abspath(src), "-o", "/dev/null"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(src))).stderr
     cur = None
     rows = []
     for line in out.splitlines():
