@@ -219,13 +219,33 @@ def gemm_desc(N, m, n, k, dtype_ab, dtype_c, trans_b=1, batch=1, algo=0):
                       algo=algo)
 
 
+def self_spawn(gpus):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: become the launcher.  Re-runs this very command line
+    as N ranks under torch.distributed.run (one process per GPU, 127.0.0.1 rendezvous on a free port), passes rank 0's JSON
+    line through and leaves with the job's exit code -- so the plain form is a real N-rank job, never a silent 1-rank one."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ, BENCH_SELF_SPAWNED="1")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != max(args.gpus, 1) and world > 1:
-        args.gpus = world
+    if args.gpus > 1 and world != args.gpus:
+        # the launcher decides how many ranks exist; a line claiming another count would be a lie
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    args.gpus = world
 
     import torch
     import torch.distributed as dist
@@ -238,6 +258,8 @@ def main():
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     if "BENCH_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks asked for, {torch.cuda.device_count()} GPUs visible")
     torch.cuda.set_device(local_rank)
     global THREAD_DEVICE
     THREAD_DEVICE = local_rank
@@ -467,6 +489,37 @@ def main():
             return out
         guarded("measured_ceilings", probes)
 
+        def operand_sensitivity():
+            # Separates issue efficiency from power (review of round 2, weak #5): the SAME headline kernel, same descriptor, on
+            # all-zero and all-ones operands -- no toggling in the multipliers, so the chip holds its clock -- next to the
+            # benchmark's uniform[-1,1) operands.  If zeros/ones reach ~2 000+ TFLOP/s the K loop's issue schedule is fine and
+            # the gap on random data is the power limit; if they stall near the random-data figure, issue slack is hiding there.
+            import numpy as _np2
+            out = {}
+            za = TensorHandle.new_contiguous((S, S), client.empty(S * S * 2), ElemType.BF16)
+            zb = TensorHandle.new_contiguous((S, S), client.empty(S * S * 2), ElemType.BF16)
+            zc = client.empty(S * S * 2)
+            d = gemm_desc(N, S, S, S, N.DTYPE_BF16, N.DTYPE_BF16, trans_b=1, algo=args.algo)
+            call = lambda: client._s.check(lib.mi355_gemm(ctx, None, C.byref(d), za.device_ptr(), zb.device_ptr(), zc.device_ptr()))
+            for name, setup in (("zeros", lambda h: lib.mi355_memset(ctx, None, C.c_void_p(h.device_ptr()), 0, S * S * 2)),
+                                ("ones", lambda h: lib.mi355_fill_uniform(ctx, None, C.c_void_p(h.device_ptr()), int(ElemType.BF16), S * S, SEED, 1, 1.0, 1.0)),
+                                ("uniform", lambda h: lib.mi355_fill_uniform(ctx, None, C.c_void_p(h.device_ptr()), int(ElemType.BF16), S * S, SEED, 100 + (h is zb), -1.0, 1.0))):
+                client._s.check(setup(za))
+                client._s.check(setup(zb))
+                time_op(client, ev, call, 60, warmup=0)                    # past the DVFS ramp
+                lib.mi355_probe_clock(ctx, None, p_clk0)
+                ms = time_op(client, ev, call, 40, warmup=0)
+                lib.mi355_probe_clock(ctx, None, p_clk1)
+                tk = _np2.frombuffer(client.read_one(clk), dtype=_np2.uint64).reshape(2, 512, 2).astype(_np2.float64)
+                good = (tk[0, :, 1] > 0) & (tk[1, :, 1] > tk[0, :, 1]) & (tk[1, :, 0] > tk[0, :, 0])
+                ghz = float(_np2.median((tk[1, good, 0] - tk[0, good, 0]) / (tk[1, good, 1] - tk[0, good, 1]) * 0.1)) if good.any() else float("nan")
+                tf = flop / ms / 1e9
+                out[name] = {"TFLOPs": round(tf, 1), "frac_of_2.5PF": round(tf / PEAK_BF16_TFLOPS, 4), "shader_clock_GHz": round(ghz, 3),
+                             "frac_of_peak_at_clock": round(tf / (PEAK_BF16_TFLOPS * ghz / 2.4), 4)}
+            out["gemm_bf16_8192_zero_operands_TFLOPs"] = out["zeros"]["TFLOPs"]
+            return out
+        guarded("headline_kernel_operand_sensitivity", operand_sensitivity)
+
         def reduce_c4():
             n_total = 1 << 28                      # 1 GiB of f32 (config C4)
             n_local = n_total // world
@@ -502,6 +555,31 @@ def main():
                                "algorithmic_bytes_per_launch": n_local * 4, "kernel_ms": round(b2b_ms["sum"], 4),
                                "timing": "average of 20 back-to-back launches between one HIP event pair, like the GEMM "
                                          "roofline (the per-sample medians above include one launch gap each)"}
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                # the reduce half's CPU baseline (north_star: "alongside cubecl-cpu timed on the box's own host cores"): the
+                # oracle's threaded fused sum + argmax -- one contiguous slice per worker, one worker per usable core, the way
+                # cubecl-cpu hands cube units to its pool (threadpool/mod.rs:80-99) -- over the same 1 GiB of the same RNG stream
+                try:
+                    import numpy as np
+                    import oracle
+                    cores = usable_cores()
+                    hx = oracle.fill_uniform(n_total, 300, 0.0, 1.0)
+                    times, spent = [], 0.0
+                    while len(times) < 3 or (spent < 6.0 and len(times) < 12):
+                        secs, hsum, hidx = oracle.cpu_sum_argmax(hx, cores)
+                        times.append(secs)
+                        spent += secs
+                    times.sort()
+                    med_s = times[len(times) // 2]
+                    dev = np.frombuffer(client.read_one(outs), dtype=np.uint8)
+                    res["cpu_baseline"] = {"value": round(n_total * 4 / med_s / 1e9, 2), "unit": "GB/s", "cores": cores, "kind": "port",
+                                           "sample": f"the whole 1 GiB f32 array (same counter RNG stream), fused sum + argmax, median of {len(times)} passes "
+                                                     f"({med_s * 1e3:.1f} ms), oracle_cpu_sum_argmax_f32: one contiguous slice per worker thread",
+                                           "argmax_index_equals_device": bool(hidx == int(dev[16:24].view(np.uint64)[0])),
+                                           "sum_rel_diff_vs_device": float(abs(hsum - float(dev[0:4].view(np.float32)[0])) / abs(hsum))}
+                    del hx
+                except Exception as exc:  # noqa: BLE001
+                    res["cpu_baseline"] = {"value": None, "unit": "GB/s", "kind": "port", "sample": f"failed: {exc}"[:200]}
             if world > 1:
                 def exchange():
                     # C4 end to end (cubecl_amd/sharded.py): local fused pass over this rank's slice, then the
@@ -651,32 +729,50 @@ def main():
         guarded("gemm_block_scaled", gemm_mx)
 
         def batched_c5():
-            per_gpu = 64                      # 512 matrices / 8 GPUs
+            # config C5: batch 512 x 2048^3 bf16, the batch cut into contiguous runs by sharded.shard_range -- the SAME
+            # 512-matrix job at every N (N = 1: all 512 on this GPU, 12 GiB of operands + results; N = 8: 64 each), so
+            # "8 GPUs vs 1" compares one job with itself.  No data-path collective.
+            from cubecl_amd import sharded
+            total = 512
             M = 2048
-            ba = TensorHandle.uniform(client, (per_gpu, M, M), ElemType.BF16, SEED, 500 + rank, -1.0, 1.0)
-            bb = TensorHandle.uniform(client, (per_gpu, M, M), ElemType.BF16, SEED, 600 + rank, -1.0, 1.0)
-            bc = client.empty(per_gpu * M * M * 2)
-            d = gemm_desc(N, M, M, M, N.DTYPE_BF16, N.DTYPE_BF16, trans_b=1, batch=per_gpu)
-            call = lambda: client._s.check(lib.mi355_gemm(ctx, None, C.byref(d), ba.device_ptr(), bb.device_ptr(), bc.device_ptr()))
-            med, best = samples_op(client, ev, call, samples=9, warmup=5)      # ~0.85 ms a pass; the first passes after another config ride the DVFS ramp
-            # priced like the other extras on back-to-back passes (HIP events around 10 passes, best of 3): a per-sample event pair
-            # with a sync on both sides lets the clock sag between samples (this 0.85 ms pass at the chip's power limit reads
-            # 1 110-1 300 TFLOP/s that way on the same box); the per-sample median is kept beside it
-            b2b = min(time_op(client, ev, call, 10, warmup=3) for _ in range(3))
-            tf = 2.0 * M ** 3 * per_gpu / b2b / 1e9
-            tf_med = 2.0 * M ** 3 * per_gpu / med / 1e9
-            alg = C.c_int32()
-            lib.mi355_gemm_select(ctx, C.byref(d), C.byref(alg))
-            # whole-job figure (the >= 6x at 8 GPUs target is quoted on it): barrier -> every rank launches its shard
-            # 20 x back to back (after 5 untimed passes: the DVFS ramp) -> sync -> the slowest rank's wall time, exactly the headline's protocol
-            job = job_seconds(call, iters=20, warmup=5)
-            tf_job = 2.0 * M ** 3 * per_gpu * world / job / 1e12
-            return {"batch_per_gpu": per_gpu, "batch_total": per_gpu * world, "algo": alg.value, "median_ms": round(med, 3),
-                    "back_to_back_ms": round(b2b, 3), "TFLOPs_per_gpu": round(tf, 1), "TFLOPs_per_gpu_per_sample_median": round(tf_med, 1),
-                    "frac_of_2.5PF": round(tf / PEAK_BF16_TFLOPS, 4),
-                    "job_ms_per_pass": round(job * 1e3, 3), "TFLOPs_total": round(tf_job, 1),
-                    "TFLOPs_total_timing": "all ranks' FLOP / slowest rank's wall time over 20 back-to-back passes after 5 warm-up passes (host clock, barrier before)",
-                    "frac_of_2.5PF_per_gpu_job": round(tf_job / world / PEAK_BF16_TFLOPS, 4)}
+            _, mine = sharded.shard_range(total, rank, world)
+            ba = TensorHandle.uniform(client, (mine, M, M), ElemType.BF16, SEED, 500 + rank, -1.0, 1.0)
+            bb = TensorHandle.uniform(client, (mine, M, M), ElemType.BF16, SEED, 600 + rank, -1.0, 1.0)
+            bc = client.empty(mine * M * M * 2)
+
+            def measure(count, tb, pb_handle):
+                d = gemm_desc(N, M, M, M, N.DTYPE_BF16, N.DTYPE_BF16, trans_b=tb, batch=count)
+                call = lambda: client._s.check(lib.mi355_gemm(ctx, None, C.byref(d), ba.device_ptr(), pb_handle.device_ptr(), bc.device_ptr()))
+                med, best = samples_op(client, ev, call, samples=9, warmup=5)      # the first passes after another config ride the DVFS ramp
+                # priced like the other extras on back-to-back passes (HIP events around 10 passes, best of 3): a per-sample event
+                # pair with a sync on both sides lets the clock sag between samples; the per-sample median is kept beside it
+                b2b = min(time_op(client, ev, call, 10, warmup=3) for _ in range(3))
+                alg = C.c_int32()
+                lib.mi355_gemm_select(ctx, C.byref(d), C.byref(alg))
+                # whole-job figure (the >= 6x at 8 GPUs target is quoted on it): barrier -> every rank launches its run of
+                # the batch 20 x back to back (after 5 untimed passes) -> sync -> the slowest rank's wall time
+                job = job_seconds(call, iters=20, warmup=5)
+                flop_rank = 2.0 * M ** 3 * count
+                tf = flop_rank / b2b / 1e9
+                return {"batch_this_rank": count, "algo": alg.value, "median_ms": round(med, 3), "back_to_back_ms": round(b2b, 3),
+                        "TFLOPs_per_gpu": round(tf, 1), "TFLOPs_per_gpu_per_sample_median": round(flop_rank / med / 1e9, 1),
+                        "frac_of_2.5PF": round(tf / PEAK_BF16_TFLOPS, 4), "job_ms_per_pass": round(job * 1e3, 3)}, job
+
+            res, job = measure(mine, 1, bb)
+            tf_job = 2.0 * M ** 3 * total / job / 1e12            # shard_range covers [0, 512) exactly once: all ranks' FLOP
+            res.update({"batch_total": total, "sharding": f"sharded.shard_range({total}, rank, {world})",
+                        "TFLOPs_total": round(tf_job, 1),
+                        "TFLOPs_total_timing": "FLOP of all 512 matrices / slowest rank's wall time over 20 back-to-back passes after 5 warm-up passes (host clock, barrier before)",
+                        "frac_of_2.5PF_per_gpu_job": round(tf_job / world / PEAK_BF16_TFLOPS, 4)})
+            # the reference's default operand layout (TensorHandle::new_contiguous: rhs [K][N] row-major), same job
+            nn, job_nn = measure(mine, 0, bb)
+            nn["TFLOPs_total"] = round(2.0 * M ** 3 * total / job_nn / 1e12, 1)
+            res["row_major_rhs_NN"] = nn
+            if mine != 64:
+                # the 64-matrix run one GPU of an 8-GPU job holds, on this GPU alone (the figure rounds 1-2 quoted)
+                s64, _ = measure(64, 1, bb)
+                res["shard_of_64"] = s64
+            return res
         guarded("batched_gemm_2048_bf16", batched_c5)
 
         def skinny():

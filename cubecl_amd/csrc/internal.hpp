@@ -53,6 +53,8 @@ struct mi355_ctx {
     std::unordered_map<hipStream_t, uint32_t> ticket_slots;
     bool tickets_dirty = false;
     bool capturing = false;                // a hipStream capture window is open (graph API)
+    hipStream_t capture_stream = nullptr;  // ... on this stream (ThreadLocal mode): the other lanes keep running real work
+    std::set<void *> captured_events;      // events recorded on capture_stream inside the open window (graph nodes)
     // Memory a graph replays against must outlive the graph (the reference routes the allocations of a capture window into
     // a persistent pool and pins them for the graph's lifetime: crates/cubecl-hip/src/compute/server.rs:288-521):
     //   capture_id      id of the open window / of the graph it becomes (0: none)

@@ -56,7 +56,8 @@ struct pool_block {
     hipEvent_t event = nullptr;                   // recorded at free time
     uint64_t freed_tick = 0;
     bool persistent = false;
-    uint64_t graph_id = 0;                        // allocated or freed inside this capture window: pinned while that graph lives
+    uint64_t graph_id = 0;                        // allocated inside this capture window: pinned while that graph lives
+    uint64_t free_graph_id = 0;                   // freed inside this capture window: a second, independent pin
     bool idle = false;                            // released by a destroyed graph (its replays were waited for): any stream may take it
 };
 
@@ -85,7 +86,7 @@ struct memory_pool {
     int mode = MI355_ALLOC_MODE_AUTO;
     uint64_t n_allocs = 0, bytes_in_use = 0, bytes_padding = 0, bytes_reserved = 0;
     uint64_t driver_allocs = 0, driver_frees = 0, cache_hits = 0;
-    std::map<uint64_t, std::vector<pool_block>> held;   // graph id -> blocks freed while pinned (out of the free lists)
+    std::vector<pool_block> held;                  // blocks freed while pinned by one or two graphs (out of the free lists)
 };
 
 namespace {
@@ -118,11 +119,17 @@ hipEvent_t take_event(memory_pool *p)
 bool reusable(const mi355_ctx *ctx, const pool_block &b, hipStream_t stream)
 {
     if (b.idle || b.stream == stream) return true;
-    if (!b.event || ctx->capturing) return false;  // (no event queries inside a capture window)
+    if (!b.event || ctx->capturing) return false;  // (no event queries while this thread has a capture open)
     const hipError_t e = hipEventQuery(b.event);
     if (e == hipSuccess) return true;
     (void)hipGetLastError();                       // hipErrorNotReady is not an error here
     return false;
+}
+
+// Is the graph (or open window) with this id still able to replay?
+bool pin_alive(const mi355_ctx *ctx, uint64_t id)
+{
+    return id != 0 && (id == ctx->capture_id || ctx->live_graphs.count(id) != 0);
 }
 
 void retire_event(memory_pool *p, pool_block &b)
@@ -240,7 +247,8 @@ int32_t pool_alloc(mi355_ctx *ctx, hipStream_t stream, uint64_t bytes, void **ou
     blk.idle = false;
     // An allocation made inside a capture window is baked into the graph's nodes: it stays pinned (never handed to anyone
     // else) for as long as that graph lives, whenever its owner drops it.
-    blk.graph_id = ctx->capturing ? ctx->capture_id : 0;
+    blk.graph_id = (ctx->capturing && stream == ctx->capture_stream) ? ctx->capture_id : 0;
+    blk.free_graph_id = 0;
     account_alloc(p, blk);
     p->live[blk.ptr] = blk;
     *out = blk.ptr;
@@ -262,14 +270,17 @@ int32_t pool_free(mi355_ctx *ctx, hipStream_t stream, void *ptr)
     // A collective still in flight on the communication stream may read or write this block (a temporary handed to
     // all_reduce / send and dropped before sync_collective): order the freeing stream behind the communication stream
     // first, so that same-stream reuse and the event recorded below both cover it.
-    if (ctx->comm_dirty && !ctx->capturing && ctx->fence_b && ctx->comm_stream) {
+    // "Inside the window" means: on the stream that is being captured.  Another lane keeps running real work while the
+    // window is open, and a block it frees is ordered by an event like any other.
+    const bool in_window = ctx->capturing && stream == ctx->capture_stream;
+    if (ctx->comm_dirty && !in_window && ctx->fence_b && ctx->comm_stream) {
         if (hipEventRecord(ctx->fence_b, ctx->comm_stream) != hipSuccess || hipStreamWaitEvent(stream, ctx->fence_b, 0) != hipSuccess)
             (void)hipGetLastError();
     }
     blk.stream = stream;
     blk.freed_tick = p->tick;
     blk.event = nullptr;
-    if (!ctx->capturing) {                                        // (an event recorded inside a capture is a graph node)
+    if (!in_window) {                                             // (an event recorded inside a capture is a graph node)
         blk.event = take_event(p);
         if (blk.event && hipEventRecord(blk.event, stream) != hipSuccess) {
             (void)hipGetLastError();
@@ -277,15 +288,17 @@ int32_t pool_free(mi355_ctx *ctx, hipStream_t stream, void *ptr)
             blk.event = nullptr;
         }
     }
-    // Freed inside a capture window (the captured kernels before this point use it), or allocated inside the window of a
-    // graph that is still alive: the address is part of a replayable graph, so the block stays out of the free lists
-    // until mi355_graph_destroy.  (A slab slice keeps its page's live count: the page must not be released either.)
-    if (ctx->capturing) blk.graph_id = ctx->capture_id;
-    if (blk.graph_id && (blk.graph_id == ctx->capture_id || ctx->live_graphs.count(blk.graph_id))) {
-        p->held[blk.graph_id].push_back(blk);
+    // Freed inside a capture window (the captured kernels before this point use it), and / or allocated inside the window
+    // of a graph that is still alive: the address is part of one or two replayable graphs, so the block stays out of the
+    // free lists until the LAST of them is gone (mi355_graph_destroy).  Both pins are kept: a block allocated in window A
+    // and freed in a later window B must outlive A as well as B.  (A slab slice keeps its page's live count: the page must
+    // not be released either.)
+    blk.free_graph_id = in_window ? ctx->capture_id : 0;
+    if (pin_alive(ctx, blk.graph_id) || pin_alive(ctx, blk.free_graph_id)) {
+        p->held.push_back(blk);
         return MI355_OK;
     }
-    blk.graph_id = 0;
+    blk.graph_id = blk.free_graph_id = 0;
     if (blk.bin >= 0) {
         --blk.page->live;
         p->bins[blk.bin].push_back(blk);
@@ -295,17 +308,22 @@ int32_t pool_free(mi355_ctx *ctx, hipStream_t stream, void *ptr)
     return MI355_OK;
 }
 
-// The graph with this id is gone (destroyed after its replays were waited for, or its capture failed): what it pinned
-// is ordinary free memory again.  Blocks freed at capture time carry no event -- nothing but the graph ever used them
-// after that point -- so they are marked idle.
+// The graph with this id is gone (destroyed after its replays were waited for, or its capture failed): what ONLY it
+// pinned is ordinary free memory again; a block another live graph (or the open window) still pins stays held.  Blocks
+// freed at capture time carry no event -- nothing but the graphs ever used them after that point -- so they are marked idle.
 void pool_release_graph(mi355_ctx *ctx, uint64_t graph_id)
 {
     memory_pool *p = ctx->pool;
     if (!p) return;
-    auto it = p->held.find(graph_id);
-    if (it == p->held.end()) return;
-    for (pool_block &blk : it->second) {
-        blk.graph_id = 0;
+    std::vector<pool_block> keep;
+    for (pool_block &blk : p->held) {
+        if (blk.graph_id == graph_id) blk.graph_id = 0;
+        if (blk.free_graph_id == graph_id) blk.free_graph_id = 0;
+        if (pin_alive(ctx, blk.graph_id) || pin_alive(ctx, blk.free_graph_id)) {
+            keep.push_back(blk);
+            continue;
+        }
+        blk.graph_id = blk.free_graph_id = 0;
         if (!blk.event) blk.idle = true;
         if (blk.bin >= 0) {
             --blk.page->live;
@@ -314,7 +332,7 @@ void pool_release_graph(mi355_ctx *ctx, uint64_t graph_id)
             p->big_free.emplace(blk.size, blk);
         }
     }
-    p->held.erase(it);
+    p->held.swap(keep);
 }
 
 // explicit == 0: release exclusive pages that sat unused for their dealloc period; explicit != 0: release everything
@@ -326,7 +344,7 @@ int32_t pool_cleanup(mi355_ctx *ctx, int32_t explicit_)
     if (!p || ctx->capturing) return MI355_OK;                    // nothing may be freed during a capture (:948-952)
     if (explicit_) (void)hipDeviceSynchronize();                  // "release the memory now": everything freed is idle after this
     auto done = [explicit_](const pool_block &b) {
-        if (!b.event) return explicit_ != 0;
+        if (!b.event) return explicit_ != 0 || b.idle;        // idle: released by a dead graph whose replays were waited for
         if (hipEventQuery(b.event) == hipSuccess) return true;
         (void)hipGetLastError();
         return false;
@@ -379,11 +397,10 @@ void pool_destroy(mi355_ctx *ctx)
         (void)hipFree(kv.second.ptr);
         if (kv.second.event) (void)hipEventDestroy(kv.second.event);
     }
-    for (auto &kv : p->held)
-        for (auto &b : kv.second) {
-            if (b.bin < 0) (void)hipFree(b.ptr);
-            if (b.event) (void)hipEventDestroy(b.event);
-        }
+    for (auto &b : p->held) {
+        if (b.bin < 0) (void)hipFree(b.ptr);
+        if (b.event) (void)hipEventDestroy(b.event);
+    }
     for (auto &fl : p->bins)
         for (auto &b : fl)
             if (b.event) (void)hipEventDestroy(b.event);

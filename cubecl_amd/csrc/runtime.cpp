@@ -420,6 +420,7 @@ MI355_API int32_t mi355_event_create(mi355_ctx *ctx, mi355_event *out_event)
 MI355_API int32_t mi355_event_destroy(mi355_ctx *ctx, mi355_event event)
 {
     MI355_REQUIRE_CTX(ctx);
+    ctx->captured_events.erase(event);
     if (event) MI355_HIP(ctx, hipEventDestroy(reinterpret_cast<hipEvent_t>(event)));
     return MI355_OK;
 }
@@ -429,6 +430,9 @@ MI355_API int32_t mi355_event_record(mi355_ctx *ctx, mi355_event event, mi355_st
     MI355_REQUIRE_CTX(ctx);
     if (!event) return fail(ctx, MI355_E_INVALID_ARGUMENT, "event is NULL");
     MI355_HIP(ctx, hipEventRecord(reinterpret_cast<hipEvent_t>(event), stream_of(ctx, stream)));
+    // recorded on the stream under capture: the event is a graph node now, not something the host can wait for
+    if (ctx->capturing && stream_of(ctx, stream) == ctx->capture_stream) ctx->captured_events.insert(event);
+    else ctx->captured_events.erase(event);
     return MI355_OK;
 }
 
@@ -444,7 +448,9 @@ MI355_API int32_t mi355_event_sync(mi355_ctx *ctx, mi355_event event)
 {
     MI355_REQUIRE_CTX(ctx);
     if (!event) return fail(ctx, MI355_E_INVALID_ARGUMENT, "event is NULL");
-    if (ctx->capturing) return fail(ctx, MI355_E_UNSUPPORTED, "mi355_event_sync: not inside a graph capture window");
+    // only an event recorded INSIDE the open window cannot be waited for by the host; the other lanes run real work
+    if (ctx->capturing && ctx->captured_events.count(event))
+        return fail(ctx, MI355_E_UNSUPPORTED, "mi355_event_sync: not inside a graph capture window");
     MI355_HIP(ctx, hipEventSynchronize(reinterpret_cast<hipEvent_t>(event)));
     return MI355_OK;
 }
@@ -475,7 +481,8 @@ MI355_API int32_t mi355_read_async(mi355_ctx *ctx, mi355_stream stream, void *ds
     MI355_REQUIRE_CTX(ctx);
     if (bytes == 0) return MI355_OK;
     if (!dst_host || !src_dptr) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_read: NULL pointer");
-    if (ctx->capturing) return fail(ctx, MI355_E_UNSUPPORTED, "mi355_read: a read-back inside a graph capture window would end the capture");
+    if (ctx->capturing && stream_of(ctx, stream) == ctx->capture_stream)
+        return fail(ctx, MI355_E_UNSUPPORTED, "mi355_read: a read-back inside a graph capture window would end the capture");
     MI355_HIP(ctx, hipMemcpyAsync(dst_host, src_dptr, bytes, hipMemcpyDeviceToHost, stream_of(ctx, stream)));
     return MI355_OK;
 }
@@ -509,7 +516,8 @@ MI355_API int32_t mi355_read_2d(mi355_ctx *ctx, mi355_stream stream, void *dst_h
     if (!dst_host || !src_dptr) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_read_2d: NULL pointer");
     if (dst_pitch < width_bytes || src_pitch < width_bytes)
         return fail(ctx, MI355_E_UNSUPPORTED_STRIDES, "pitch smaller than row width");
-    if (ctx->capturing) return fail(ctx, MI355_E_UNSUPPORTED, "mi355_read_2d: a read-back inside a graph capture window would end the capture");
+    if (ctx->capturing && stream_of(ctx, stream) == ctx->capture_stream)
+        return fail(ctx, MI355_E_UNSUPPORTED, "mi355_read_2d: a read-back inside a graph capture window would end the capture");
     MI355_HIP(ctx, hipMemcpy2DAsync(dst_host, dst_pitch, src_dptr, src_pitch, width_bytes, rows,
                                     hipMemcpyDeviceToHost, stream_of(ctx, stream)));
     return mi355_sync(ctx, stream);
@@ -573,7 +581,9 @@ MI355_API int32_t mi355_sync(mi355_ctx *ctx, mi355_stream stream)
     MI355_REQUIRE_CTX(ctx);
     // a host synchronisation aborts an open capture (the reference defers or refuses them: crates/cubecl-hip/src/compute/
     // command.rs:404, :508): refuse it and keep the window alive
-    if (ctx->capturing) return fail(ctx, MI355_E_UNSUPPORTED, "mi355_sync: not inside a graph capture window");
+    // -- on the stream under capture; another lane is an ordinary stream (ThreadLocal capture mode)
+    if (ctx->capturing && stream_of(ctx, stream) == ctx->capture_stream)
+        return fail(ctx, MI355_E_UNSUPPORTED, "mi355_sync: not inside a graph capture window");
     hipError_t e = hipStreamSynchronize(stream_of(ctx, stream));
     if (e != hipSuccess) {
         hipGetLastError();
@@ -695,7 +705,8 @@ MI355_API int32_t mi355_launch(mi355_ctx *ctx, mi355_stream stream, mi355_functi
                                          num_ptrs ? params.data() : nullptr, nullptr);
     if (e != hipSuccess) {
         hipGetLastError();
-        if (shared_mem_bytes > 64 * 1024)
+        if (shared_mem_bytes > 64 * 1024 && (e == hipErrorInvalidValue || e == hipErrorLaunchOutOfResources || e == hipErrorOutOfMemory))
+            // (only the codes a refused LDS request produces: a bad grid or a stale function stays a launch failure)
             // HIP has no driver-side attribute call for a hipFunction_t (hipFuncSetAttribute resolves host stubs only): when
             // the driver refuses the opt-in for a module kernel, the limit that really applies to it is the default one
             queue_error(ctx, MI355_E_SHARED_MEMORY, shared_mem_bytes, 64 * 1024,
@@ -818,6 +829,7 @@ MI355_API int32_t mi355_graph_begin_capture(mi355_ctx *ctx, mi355_stream stream)
     if (ctx->capturing) return fail(ctx, MI355_E_INVALID_ARGUMENT, "begin_capture: a capture is already open on this context");
     MI355_HIP(ctx, hipStreamBeginCapture(stream_of(ctx, stream), hipStreamCaptureModeThreadLocal));
     ctx->capturing = true;
+    ctx->capture_stream = stream_of(ctx, stream);
     ctx->capture_id = ctx->next_capture_id++;
     ctx->capture_scratch.clear();
     return MI355_OK;
@@ -830,6 +842,8 @@ MI355_API int32_t mi355_graph_end_capture(mi355_ctx *ctx, mi355_stream stream, m
     *out_graph = nullptr;
     if (!ctx->capturing) return fail(ctx, MI355_E_INVALID_ARGUMENT, "end_capture without begin_capture");
     ctx->capturing = false;
+    ctx->capture_stream = nullptr;
+    ctx->captured_events.clear();
     const uint64_t id = ctx->capture_id;
     ctx->capture_id = 0;
     hipGraph_t g = nullptr;

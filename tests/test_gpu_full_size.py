@@ -20,7 +20,32 @@ SEED = 0x5EEDC0BE
 REL = 1e-5
 
 
-def _rows_check(oracle, a_bits, b_bits, got_rows, rows, k, n, dtype, trans_b=True):
+def _record(case, err, ref, bound, extra=None):
+    """Makes the margin visible (review of round 2, weak #2): the tolerance is 1e-5 x sum|a||b| -- north_star's "1e-5 relative"
+    read against the magnitude of the summands, because a dot product of 8192 mixed-sign terms cancels -- so every full-size
+    check records BOTH ratios it achieved: max |err| / sum|a||b| (the asserted one) and max |err| / |ref| (the literal reading,
+    over the outputs that are not themselves cancellation residue: |ref| >= 1e-3 x sum|a||b|).  One JSON line per case in
+    gpurun_out/parity_margins.jsonl and on stdout (pytest -s / the captured log)."""
+    import json
+    import os
+    from pathlib import Path
+    err, ref, bound = (np.asarray(x, dtype=np.float64) for x in (err, ref, bound))
+    solid = np.abs(ref) >= 1e-3 * bound
+    line = {"case": case, "outputs_checked": int(err.size), "max_err_over_sum_abs_products": float((err / (bound + 1e-300)).max()),
+            "max_err_over_abs_ref": float((err[solid] / np.abs(ref[solid])).max()) if solid.any() else None,
+            "outputs_in_literal_reading": int(solid.sum()), "tolerance": REL}
+    line.update(extra or {})
+    print("PARITY_MARGIN " + json.dumps(line))
+    out = Path(os.environ.get("GRAFT_REPO_ROOT", Path(__file__).resolve().parents[1])) / "gpurun_out"
+    try:
+        out.mkdir(exist_ok=True)
+        with open(out / "parity_margins.jsonl", "a") as f:
+            f.write(json.dumps(line) + "\n")
+    except OSError:
+        pass
+
+
+def _rows_check(oracle, a_bits, b_bits, got_rows, rows, k, n, dtype, trans_b=True, case=None):
     """got_rows[i] == A[rows[i], :] . B^T (or B) within REL * sum|a||b| (f32) / one ulp (16-bit out is not used here)."""
     if dtype == ElemType.F32:
         a_val, b_val = a_bits, b_bits
@@ -32,6 +57,8 @@ def _rows_check(oracle, a_bits, b_bits, got_rows, rows, k, n, dtype, trans_b=Tru
     ref = A @ Bm
     bound = np.abs(A) @ np.abs(Bm)
     err = np.abs(got_rows.astype(np.float64) - ref)
+    if case:
+        _record(case, err, ref, bound)
     assert np.all(err <= REL * bound + 1e-30), float((err / (bound + 1e-30)).max())
 
 
@@ -49,7 +76,7 @@ def test_c3_bf16_8192_sampled_rows_linearity_and_kernel_agreement(client, oracle
     a_bits = oracle.to_bf16(oracle.fill_uniform(S * S, 100, -1.0, 1.0))
     b_bits = oracle.to_bf16(oracle.fill_uniform(S * S, 200, -1.0, 1.0))
     assert np.array_equal(a.to_numpy(client).reshape(-1)[: 1 << 16], a_bits[: 1 << 16])   # device RNG == oracle RNG
-    _rows_check(oracle, a_bits, b_bits, got[rows], rows, S, S, ElemType.BF16)
+    _rows_check(oracle, a_bits, b_bits, got[rows], rows, S, S, ElemType.BF16, case="C3 8192^3 bf16 -> f32 C, 8 sampled rows vs f64 oracle")
     # exact linearity under a power of two: scaling A by 2 is exact in bf16, so C doubles bit for bit
     a2 = TensorHandle.from_numpy(client, oracle.to_bf16(2.0 * oracle.from_bf16(a_bits)), ElemType.BF16)
     c2 = TensorHandle.new_contiguous((S, S), client.empty(S * S * 4), ElemType.F32)
@@ -82,7 +109,7 @@ def _bench_desc(m, n, k, dtype_ab, dtype_c, batch=1):
                       dtype_ab=dtype_ab, dtype_c=dtype_c, trans_a=0, trans_b=1, algo=N.GEMM_ALGO_AUTO)
 
 
-def _bf16_rows_check(oracle, a_bits, b_bits, got_bits, rows, k, n):
+def _bf16_rows_check(oracle, a_bits, b_bits, got_bits, rows, k, n, case=None):
     """bf16 C against the f64 oracle: |got - ref| <= one bf16 ulp of ref + 1e-5 * sum|a||b| (f32 accumulation bound
     of BASELINE.json + the single rounding of the store; reference loop runtime_tests/cmma.rs:695-722)."""
     A = oracle.from_bf16(a_bits).reshape(-1, k)[rows].astype(np.float64)
@@ -92,6 +119,9 @@ def _bf16_rows_check(oracle, a_bits, b_bits, got_bits, rows, k, n):
     got = oracle.from_bf16(got_bits).astype(np.float64)
     ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(ref), 2.0 ** -126))) - 7)          # bf16: 8 significant bits
     err = np.abs(got - ref)
+    if case:
+        _record(case, err, ref, bound, {"note": "bf16 C: the error includes the one rounding of the store (<= 2^-8 relative), allowed as one ulp",
+                                        "max_err_over_allowed": float((err / (ulp + REL * bound)).max())})
     assert np.all(err <= ulp + REL * bound), float((err / (ulp + REL * bound)).max())
     # and the rounding is to nearest: at least ~99 % of the outputs are the correctly rounded f64 result
     exact = oracle.to_bf16(ref.astype(np.float32))
@@ -115,11 +145,14 @@ def test_c3_bf16_8192_bf16_output_as_benched(client, oracle):
     a_bits = oracle.to_bf16(oracle.fill_uniform(S * S, 100, -1.0, 1.0))
     b_bits = oracle.to_bf16(oracle.fill_uniform(S * S, 200, -1.0, 1.0))
     assert np.array_equal(b.to_numpy(client).reshape(-1)[-(1 << 16):], b_bits[-(1 << 16):])   # device RNG == oracle RNG
-    _bf16_rows_check(oracle, a_bits, b_bits, got[rows], rows, S, S)
-    # the f32-output form of the same launch rounds to the same bf16 values (one rounding, after the f32 accumulation)
+    _bf16_rows_check(oracle, a_bits, b_bits, got[rows], rows, S, S, case="C3 8192^3 bf16 -> bf16 C as benched, 11 sampled rows vs f64 oracle")
+    # the f32-output form of the same launch rounds to the same bf16 values (one rounding, after the f32 accumulation) -- over
+    # ALL 8192 rows, i.e. every one of the 1024 tiles of the benched <bf16 C> instantiation, the XCD-remapped ones included;
+    # the f32-C instantiation itself is held to the f64 oracle and to an independent kernel over the full output above
     c32 = TensorHandle.new_contiguous((S, S), client.empty(S * S * 4), ElemType.F32)
     ops.matmul(client, a, TensorHandle.new(b.handle, (S, S), (1, S), ElemType.BF16), c32)
-    assert np.array_equal(oracle.to_bf16(c32.to_numpy(client).reshape(S, S)[rows]), got[rows])
+    full32 = c32.to_numpy(client).reshape(S, S)
+    assert np.array_equal(oracle.to_bf16(full32).reshape(S, S), got)
 
 
 def test_c5_batch64_2048_bf16_as_benched_takes_the_dripped_store_kernel(client, oracle):
@@ -144,7 +177,7 @@ def test_c5_batch64_2048_bf16_as_benched_takes_the_dripped_store_kernel(client, 
         if bi in (0, 63):                                                              # the device operand IS the oracle's
             dev = client.read_one(a.handle.offset_start_by(2 * bi * mm).offset_end_by(2 * (B - 1 - bi) * mm)).view(np.uint16)
             assert np.array_equal(dev, a_bits)
-        _bf16_rows_check(oracle, a_bits, b_bits, got[rows], rows, M, M)
+        _bf16_rows_check(oracle, a_bits, b_bits, got[rows], rows, M, M, case=f"C5 shard 64 x 2048^3 bf16 -> bf16 C, matrix {bi}, 10 sampled rows")
     # the one-tile-per-workgroup kernel computes the same tiles bit for bit (same per-tile summation order)
     c2 = TensorHandle.new_contiguous((B, M, M), client.empty(B * M * M * 2), ElemType.BF16)
     d.algo = N.GEMM_ALGO_LP_256W4
@@ -206,7 +239,8 @@ def test_c2_f32_4096_sampled_rows_both_layouts(client, oracle):
         bt = TensorHandle.new(b.handle, (M, M), (1, M) if trans_b else (M, 1), ElemType.F32)
         ops.matmul(client, a, bt, c)
         got = c.to_numpy(client)
-        _rows_check(oracle, a_host, b_host, got[rows], rows, M, M, ElemType.F32, trans_b=trans_b)
+        _rows_check(oracle, a_host, b_host, got[rows], rows, M, M, ElemType.F32, trans_b=trans_b,
+                    case=f"C2 4096^3 f32, {'B stored [N][K]' if trans_b else 'row-major B'}, 6 sampled rows vs f64 oracle")
         ref = TensorHandle.new_contiguous((M, M), client.empty(M * M * 4), ElemType.F32)
         ops.matmul(client, a, bt, ref, algo=N.GEMM_ALGO_F32_MFMA)                        # the 128x128 kernel
         assert np.max(np.abs(ref.to_numpy(client) - got)) <= REL * M

@@ -303,6 +303,69 @@ def test_graph_pins_the_memory_it_replays_against(lib, ctx):
     assert back == {tmp, pre, again, keep}
 
 
+def test_block_allocated_in_one_window_and_freed_in_another_stays_pinned_by_both(lib, ctx):
+    """Review finding (round 2): a block allocated inside graph A's window and dropped inside a later window B used to be held
+    under B only -- destroying B handed it out again while A could still replay into it.  Both pins count."""
+    size = 1 << 20
+    warm = [_alloc(lib, ctx, size) for _ in range(3)]
+    for w in warm:
+        assert lib.mi355_pool_free(ctx, None, w) == N.OK
+    ga, gb = C.c_void_p(), C.c_void_p()
+    assert lib.mi355_graph_begin_capture(ctx, None) == N.OK
+    x = _alloc(lib, ctx, size)                                       # baked into A's nodes
+    assert lib.mi355_graph_end_capture(ctx, None, C.byref(ga)) == N.OK
+    assert lib.mi355_graph_begin_capture(ctx, None) == N.OK
+    assert lib.mi355_pool_free(ctx, None, x) == N.OK                 # dropped inside B's window
+    assert lib.mi355_graph_end_capture(ctx, None, C.byref(gb)) == N.OK
+    assert lib.mi355_graph_destroy(ctx, gb) == N.OK                  # B is gone, A is not
+    taken = [_alloc(lib, ctx, size) for _ in range(6)]
+    assert x not in taken                                            # A's replays still write there
+    assert lib.mi355_graph_replay(ctx, None, ga) == N.OK
+    assert lib.mi355_graph_destroy(ctx, ga) == N.OK
+    assert _alloc(lib, ctx, size) == x                               # the last pin is gone: free memory again
+    # an exclusive page released by a dead graph carries no event: the periodic cleanup must still see it as idle
+    big = _alloc(lib, ctx, 64 << 20)
+    gc_ = C.c_void_p()
+    assert lib.mi355_graph_begin_capture(ctx, None) == N.OK
+    assert lib.mi355_pool_free(ctx, None, big) == N.OK
+    assert lib.mi355_graph_end_capture(ctx, None, C.byref(gc_)) == N.OK
+    assert lib.mi355_graph_destroy(ctx, gc_) == N.OK
+    before = _device(lib)["frees"]
+    for _ in range(12 * 1024):                                       # > 5000 x (1 + 64 MiB / 1 GiB) reservations without reuse
+        q = _alloc(lib, ctx, 1024)
+        assert lib.mi355_pool_free(ctx, None, q) == N.OK
+    assert _device(lib)["frees"] == before + 1                       # the idle page went back to the driver
+
+
+def test_capture_window_is_scoped_to_the_stream_under_capture(lib, ctx):
+    """Review finding (round 2): the window used to be context-wide -- host syncs and reads on OTHER lanes were refused, and a
+    block freed from another lane inside the window got no event and a graph pin.  ThreadLocal capture only concerns the
+    captured stream: the other lanes are ordinary streams."""
+    size = 1 << 20
+    lane_a, lane_b, ev, graph = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert lib.mi355_stream_create(ctx, C.byref(lane_a)) == N.OK and lib.mi355_stream_create(ctx, C.byref(lane_b)) == N.OK
+    assert lib.mi355_event_create(ctx, C.byref(ev)) == N.OK
+    blk = _alloc(lib, ctx, size, lane_b)
+    host = (C.c_uint8 * 16)()
+    assert lib.mi355_graph_begin_capture(ctx, lane_a) == N.OK
+    # lane B is not captured: syncs, reads and events work
+    assert lib.mi355_sync(ctx, lane_b) == N.OK
+    assert lib.mi355_read(ctx, lane_b, host, C.c_void_p(blk), 16) == N.OK
+    assert lib.mi355_event_record(ctx, ev, lane_b) == N.OK and lib.mi355_event_sync(ctx, ev) == N.OK
+    # lane A is: refused, the window survives
+    assert lib.mi355_sync(ctx, lane_a) == N.E_UNSUPPORTED
+    assert lib.mi355_read(ctx, lane_a, host, C.c_void_p(blk), 16) == N.E_UNSUPPORTED
+    assert lib.mi355_event_record(ctx, ev, lane_a) == N.OK and lib.mi355_event_sync(ctx, ev) == N.E_UNSUPPORTED
+    events_before = _device(lib)["events"]
+    assert lib.mi355_pool_free(ctx, lane_b, blk) == N.OK             # freed from lane B: ordered by an event, not pinned by the graph
+    assert lib.mi355_graph_end_capture(ctx, lane_a, C.byref(graph)) == N.OK
+    assert _alloc(lib, ctx, size, lane_b) == blk                     # lane B gets it back at once although the graph is alive
+    assert _device(lib)["events"] >= events_before
+    assert lib.mi355_graph_destroy(ctx, graph) == N.OK
+    assert lib.mi355_event_destroy(ctx, ev) == N.OK
+    assert lib.mi355_stream_destroy(ctx, lane_a) == N.OK and lib.mi355_stream_destroy(ctx, lane_b) == N.OK
+
+
 def test_failed_capture_releases_what_the_window_pinned(lib, ctx):
     size = 1 << 20
     a = _alloc(lib, ctx, size)

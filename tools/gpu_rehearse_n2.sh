@@ -4,8 +4,8 @@
 # cannot work with two ranks on one device and must fail cleanly; the job-level C4 / C5 figures must be there.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out; mkdir -p $OUT
-BENCH_FORCE_DEVICE=0 BENCH_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
-  --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 10 --warmup 3 > $OUT/rehearse_n2.json 2> $OUT/rehearse_n2.err
+# The plain form: bench.py finds no launcher around it (WORLD_SIZE unset) and becomes one (self_spawn -> torch.distributed.run).
+BENCH_FORCE_DEVICE=0 BENCH_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 10 --warmup 3 > $OUT/rehearse_n2.json 2> $OUT/rehearse_n2.err
 echo "rehearsal exit $?"
 python - <<'PY'
 import json
