@@ -426,7 +426,7 @@ def main():
                 s, _ = oracle.cpu_gemm(oracle.to_bf16(x), oracle.to_bf16(y), size, size, size, dtype_ab=oracle.DT_BF16,
                                        dtype_c=oracle.DT_BF16, trans_b=True, units=cores)
                 secs = s
-                if s > 4.0 or size >= 4096:
+                if s > 4.0 or size >= S:          # up to the benched problem itself when the cores finish it within the budget
                     break
                 size *= 2
             return {"value": round(2.0 * size ** 3 / secs / 1e12, 5), "unit": "TFLOP/s", "cores": cores, "kind": "port",

@@ -50,6 +50,16 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
     const bool big = gemm_lp256_supports(d, a, b, c);
     const bool big4 = gemm_lp256w4_supports(d, a, b, c);
     const bool mid = gemm_lp128_supports(d, a, b, c);
+    // Row-major B (the layout TensorHandle::new_contiguous gives a rhs): staged natively by the tile kernels that build the
+    // transposing-read image (gemm_lp256w4.hip "BNN"); the streaming / dot-product kernels for few rows only exist for
+    // K-contiguous operands, so a launch they would win goes through the re-layout pass (GENERIC here = "re-lay out, then
+    // select again" in mi355_gemm) -- a 16 x 8192 x 8192 product costs 22 us there + 50 us of transposition against ~140 us
+    // on 32 tiles of 256x256.
+    if (!d.trans_b) {
+        const int64_t tiles256 = ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch;
+        const bool native = std::min(d.m, d.n) > 128 && ((big4 && tiles256 > 128) || mid);
+        if (!native) return MI355_GEMM_ALGO_GENERIC;
+    }
     // 3 ... 64 rows (or columns): 32 streamed rows x the whole K per workgroup, loader waves, no split-K (gemm_stream64.hip).
     // Interleaved against the split-K 128x128 path over 60 shapes (tools/dev/stream64_probe.py): faster by 5-50 % whenever its
     // grid is at most two rounds of workgroups and not a handful of workgroups each walking a very long K
@@ -91,7 +101,7 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
     // at most 128 rows (or columns) over many tiles: a 256-row tile multiplies at least half zeros and streams no faster --
     // 64 x 128256 x 4096: 192 us on the 128x128 kernel against 222
     if (mid && std::min(d.m, d.n) <= 128) return MI355_GEMM_ALGO_LP_128;
-    if (big) {
+    if (big || big4) {
         // 256x256 tiles once the 128x128 kernel would need more than its two co-resident workgroups per CU (512 tiles of
         // 128^2 = 128 of 256^2).  Measured (tools/dev/mid_shapes.py): 96-128 tiles a tie, 144-160 tiles +45...55 % for the
         // 256x256 kernel even though it leaves 40 % of the CUs idle, 64-81 tiles +7...30 % for the 128x128 kernel.
@@ -188,8 +198,9 @@ struct tail_plan {
 
 bool plan_tail_split(const mi355_gemm_desc &d, tail_plan &best)
 {
-    if (d.batch != 1 || d.trans_a || !d.trans_b || (d.n & 3)) return false;
+    if (d.batch != 1 || d.trans_a || (d.n & 3)) return false;
     const int64_t esz = (int64_t)dtype_size(d.dtype_ab), ktile = 128 / esz, nk = d.k / ktile;
+    if (!d.trans_b && (d.n & (16 / esz - 1))) return false;
     const int64_t tm = (d.m + 255) / 256, tn = (d.n + 255) / 256, T = tm * tn;
     if (nk < 8) return false;
     // cycles: a K-tile costs ~2 200, a tile's prologue + epilogue ~10 000, a launch ~5 000, the fold moves
@@ -274,11 +285,12 @@ int32_t run_tail_split(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, 
     const char *a0 = static_cast<const char *>(a), *b0 = static_cast<const char *>(b);
     char *c0 = static_cast<char *>(c);
     const char *as = p.along_m ? a0 + p.main_extent * d.lda * esz : a0;
-    const char *bs = p.along_m ? b0 : b0 + p.main_extent * d.ldb * esz;
+    // the strip's first column of B: a row of [N][K] storage, a column of row-major [K][N]
+    const char *bs = p.along_m ? b0 : b0 + (d.trans_b ? p.main_extent * d.ldb * esz : p.main_extent * esz);
     char *cs = p.along_m ? c0 + p.main_extent * d.ldc * csz : c0 + p.main_extent * csz;
     mi355_gemm_desc sd = d;                                 // the strip: batch entry z = K slice z, f32 slab output
     sd.m = ms; sd.n = ns; sd.k = d.k / p.splits; sd.batch = p.splits;
-    sd.stride_a = sd.k; sd.stride_b = sd.k; sd.stride_c = ms * ns; sd.ldc = ns; sd.dtype_c = MI355_DTYPE_F32;
+    sd.stride_a = sd.k; sd.stride_b = d.trans_b ? sd.k : sd.k * d.ldb; sd.stride_c = ms * ns; sd.ldc = ns; sd.dtype_c = MI355_DTYPE_F32;
     if (!gemm_lp256w4_supports(sd, as, bs, slabs)) return MI355_E_UNSUPPORTED;
     if (p.main_extent > 0) {
         mi355_gemm_desc md = d;
@@ -372,6 +384,21 @@ MI355_API int32_t mi355_gemm_tail_plan(const mi355_gemm_desc *desc, int32_t *out
     *out_along_m = split ? (tp.along_m ? 1 : 0) : 0;
     *out_main_extent = split ? tp.main_extent : 0;
     *out_splits = split ? (int32_t)tp.splits : 1;
+    return MI355_OK;
+}
+
+MI355_API int32_t mi355_gemm_relayout_plan(const mi355_gemm_desc *desc, int32_t *out_relayout_a, int32_t *out_relayout_b)
+{
+    if (!desc || !out_relayout_a || !out_relayout_b) return MI355_E_INVALID_ARGUMENT;
+    static const char aligned_dummy __attribute__((aligned(16))) = 0;
+    *out_relayout_a = *out_relayout_b = 0;
+    if (desc->m <= 0 || desc->n <= 0 || desc->batch <= 0) return MI355_OK;
+    if (select_auto(*desc, &aligned_dummy, &aligned_dummy, &aligned_dummy) != MI355_GEMM_ALGO_GENERIC) return MI355_OK;
+    relayout_plan p;                  // exactly what mi355_gemm does before it settles for the scalar kernel
+    if (plan_relayout(*desc, &aligned_dummy, &aligned_dummy, &aligned_dummy, p)) {
+        *out_relayout_a = p.a ? 1 : 0;
+        *out_relayout_b = p.b ? 1 : 0;
+    }
     return MI355_OK;
 }
 

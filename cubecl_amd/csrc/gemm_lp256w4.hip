@@ -172,10 +172,20 @@ __device__ unsigned long long w4_trace_buf[4096 * 8];
 #define W4_STAMP(k)
 #endif
 
-// BNN (f32 only): B is row-major [K][N] instead of [N][K].  Its K-tile is then 32 k-rows of 256 n-values
-// (1 KiB each = one DMA piece, no swizzle), and a B fragment is four ds_read_b32 (consecutive lanes ->
-// consecutive n: conflict free) instead of one ds_read_b128 -- affordable because an f32 k-step holds 64
-// MFMAs of 64 cycles.
+// BNN: B is row-major [K][N] instead of [N][K] -- the layout TensorHandle::new_contiguous gives a rhs
+// (crates/cubecl-std/src/tensor/handle.rs:89; the reference's row-major cmma test, runtime_tests/cmma.rs:1160-1177).
+//   f32: the K-tile is 32 k-rows of 256 n-values (1 KiB each = one DMA piece, no swizzle), and a B fragment is four
+//   ds_read_b32 (consecutive lanes -> consecutive n: conflict free) instead of one ds_read_b128 -- affordable because an
+//   f32 k-step holds 64 MFMAs of 64 cycles.
+//   bf16 / f16 (round 3; was: a transposition pass into library scratch): the K-tile is 64 k-rows of 256 n-values = 512 B
+//   each.  The matrix core wants, per lane, 8 consecutive k of ONE column -- strided by the row pitch in this image -- which
+//   is what ds_read_b64_tr_b16 delivers: the 16 lanes of a group hand in the addresses of a [4 k][16 n] block (lane i: row
+//   i/4, columns 4(i%4)..+3) and lane l receives column l, k 0..3.  LDS-DMA writes lane-linear but READS from any per-lane
+//   address, so the image is built for that gather at no cost: 128 blocks of [4 k][32 n] = 256 contiguous bytes (block
+//   (a, b) = k-rows 4a..4a+3 x columns 32b..32b+31 at (a*8 + b)*256, row i of it at +64 i), i.e. a 32-lane read touches one
+//   whole 256-byte bank row: conflict free by construction.  One DMA piece (1 KiB) = four blocks of one a = 4 k-rows x 256
+//   contiguous bytes of global memory (two whole lines per row).  A B fragment is two tr reads (k 0..3 and 4..7 of the lane-
+//   half's eight: blocks a = 4s + 2h and + 1, 2 KiB apart), issued in the slot the ds_read_b128 had.
 // MX (block-scaled, one ue8m0 scale per 32 k-values; DTB = B's element type, fp8 formats may be mixed): the scales come
 // pre-arranged by gemm_scaled.cpp as ST[K-tile][row padded to the tile grid][NB bytes] (NB = 4 fp8 / 8 fp4 blocks per
 // K-tile row), so a lane's share is one coalesced 4-byte load per 32-row block and K-tile (fp4: the four blocks of its
@@ -190,7 +200,8 @@ template <int DT, int DT_C, bool BNN = false, int DTB = DT, bool MX = false>
 __global__ void __launch_bounds__(256)
 gemm_lp256w4_kernel(gemm_args g)
 {
-    static_assert(!BNN || DT == MI355_DTYPE_F32, "row-major B is implemented for f32 only");
+    static_assert(!BNN || DT == MI355_DTYPE_F32 || DT == MI355_DTYPE_BF16 || DT == MI355_DTYPE_F16, "row-major B: f32 and 16-bit operands");
+    constexpr bool BNN16 = BNN && (DT == MI355_DTYPE_BF16 || DT == MI355_DTYPE_F16);
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     typedef typename lp<DT>::frag frag;
     static_assert(sizeof(typename lp<DTB>::frag) == sizeof(frag), "A and B fragments must have the same width");
@@ -236,12 +247,19 @@ gemm_lp256w4_kernel(gemm_args g)
         voff_a[j] = (uint32_t)(min((int64_t)r, g.m - 1 - m0) * g.lda * ESZ + q * 16);
         voff_b[j] = (uint32_t)(min((int64_t)r, g.n - 1 - n0) * g.ldb * ESZ + q * 16);
     }
-    // BNN: piece j of this wave is k-row wave*8 + j of the K-tile, 256 n-values = 64 lanes x 16 B
-    const char *ubase_bnn = B + (int64_t)(wave * 8) * g.ldb * ESZ + n0 * ESZ;
+    // BNN, f32: piece j of this wave is k-row wave*8 + j of the K-tile, 256 n-values = 64 lanes x 16 B
+    // BNN, 16-bit: piece p = wave*8 + j holds blocks (a = p/2, b = 4(p%2) .. +3): lane -> block b = 4(p%2) + lane/16, row
+    //   i = (lane%16)/4 of it, 16-byte chunk lane%4 = columns 32b + 8(lane%4) .. +7 of k-row 4a + i
+    const char *ubase_bnn = B + (int64_t)(BNN16 ? wave * 16 : wave * 8) * g.ldb * ESZ + n0 * ESZ;
     uint32_t voff_bnn[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j)                                           // columns past N re-read the last 4 valid ones
-        voff_bnn[j] = (uint32_t)(j * g.ldb * ESZ + min((int64_t)lane * 4, g.n - 4 - n0) * ESZ);
+    for (int j = 0; j < 8; ++j) {                                         // columns past N re-read the last valid 16 bytes
+        if constexpr (BNN16) {
+            const int64_t col = (j & 1) * 128 + (lane >> 4) * 32 + (lane & 3) * 8;
+            voff_bnn[j] = (uint32_t)(((j >> 1) * 4 + ((lane & 15) >> 2)) * g.ldb * ESZ + min(col, g.n - 8 - n0) * ESZ);
+        } else
+            voff_bnn[j] = (uint32_t)(j * g.ldb * ESZ + min((int64_t)lane * 4, g.n - 4 - n0) * ESZ);
+    }
     const int dst_piece = wave * 8 * 1024;                            // + j*1024 within the slot
 
     // ---- fragment read offsets: row*128 + ((2s+h) ^ f) * 16, f = (row>>1)&7 = (l31>>1)&7 for every tile row
@@ -250,7 +268,9 @@ gemm_lp256w4_kernel(gemm_args g)
     // chunks c and c+2 (registers 0-3 of both lane-halves are one MX block, registers 4-7 the next) = physical ^ 2
     const int hd = MX ? ((f & 2) ? -32 : 32) : ((f & 1) ? -16 : 16);
     const int rowoff_a = (wm * 128 + l31) * ROW_BYTES;
-    const int rowoff_b = BNN ? (wn * 128 + l31) * 4 : (wn * 128 + l31) * ROW_BYTES;
+    // (16-bit row-major B: block b = 4 wn + j of the lane-half's block row, + row (lane%16)/4, + 16-lane group, + 8 B per lane)
+    const int rowoff_b = BNN16 ? wn * 4 * 256 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8
+                         : BNN ? (wn * 128 + l31) * 4 : (wn * 128 + l31) * ROW_BYTES;
 
     f32x16 acc[4][4];
 #pragma unroll
@@ -311,6 +331,18 @@ gemm_lp256w4_kernel(gemm_args g)
             const u32x4 v = *reinterpret_cast<const u32x4 *>(p + (HALF ? hd : 0));
             frag &dst = (FR == 0) ? fb[BUF][0] : (FR <= 4) ? fa[BUF][(FR - 1) & 3] : fb[BUF][(FR - 4) & 3];
             dst[4 * HALF + 0] = (int)v[0]; dst[4 * HALF + 1] = (int)v[1]; dst[4 * HALF + 2] = (int)v[2]; dst[4 * HALF + 3] = (int)v[3];
+        } else if constexpr (BNN16) {
+            if constexpr (R >= 1 && R <= 4) fa[BUF][R - 1] = *reinterpret_cast<const frag *>(pa + (R - 1) * 32 * ROW_BYTES);
+            else {
+                constexpr int JB = (R == 0) ? 0 : R - 4;       // column block JB: k 0..3 from block row a, k 4..7 from a + 1
+                typedef short s16x4 __attribute__((ext_vector_type(4)));
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                const auto q = (const __attribute__((address_space(3))) s16x4 *)(pb + JB * 256);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<__attribute__((address_space(3))) s16x4 *>(q));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<__attribute__((address_space(3))) s16x4 *>(q + 256));
+                const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                fb[BUF][JB] = __builtin_bit_cast(typename lp<DTB>::frag, both);
+            }
         } else if constexpr (BNN) {
             if (R >= 1 && R <= 4) fa[BUF][R - 1] = *reinterpret_cast<const frag *>(pa + (R - 1) * 32 * ROW_BYTES);
             else {
@@ -415,7 +447,7 @@ gemm_lp256w4_kernel(gemm_args g)
         // scale bytes are one word; fp8 MX: k-step d = chunks 4d+h (registers 0-3) and 4d+2+h (registers 4-7);
         // unscaled: the mappings the measured kernels were tuned with
         const int x = F4 ? ((4 * h) ^ f) << 4 : (F8 && !MX) ? ((2 * h) ^ f) << 4 : (h ^ f) << 4;
-        const char *rd_a = smem + rowoff_a + x, *rd_b = smem + UNIT_BYTES + rowoff_b + (BNN ? (4 * h) * 1024 : x);
+        const char *rd_a = smem + rowoff_a + x, *rd_b = smem + UNIT_BYTES + rowoff_b + (BNN16 ? h * 4096 : BNN ? (4 * h) * 1024 : x);
         read_one(IC<0>{}, IC<0>{}, rd_a, rd_b); read_one(IC<0>{}, IC<1>{}, rd_a, rd_b);
         read_one(IC<0>{}, IC<2>{}, rd_a, rd_b); read_one(IC<0>{}, IC<3>{}, rd_a, rd_b);
         read_one(IC<0>{}, IC<4>{}, rd_a, rd_b); read_one(IC<0>{}, IC<5>{}, rd_a, rd_b);
@@ -435,8 +467,9 @@ gemm_lp256w4_kernel(gemm_args g)
     const int x1 = ((F4 ? 4 * h + 1 : 2 + h) ^ f) << 4, x2 = ((F4 ? 4 * h + 2 : 4 + h) ^ f) << 4,
               x3 = ((F4 ? 4 * h + 3 : 6 + h) ^ f) << 4, x0 = ((F4 ? 4 * h : h) ^ f) << 4;
     // B fragment offsets per k-step: same chunks as A for [N][K]; k-rows 8s + 4h (.. +3) for row-major B
-    const int y0 = BNN ? (4 * h) * 1024 : x0, y1 = BNN ? (8 + 4 * h) * 1024 : x1, y2 = BNN ? (16 + 4 * h) * 1024 : x2,
-              y3 = BNN ? (24 + 4 * h) * 1024 : x3;
+    // (16-bit: block rows a = 4s + 2h, + 1: 8 blocks of 256 B per block row)
+    const int y0 = BNN16 ? h * 4096 : BNN ? (4 * h) * 1024 : x0, y1 = BNN16 ? 8192 + h * 4096 : BNN ? (8 + 4 * h) * 1024 : x1,
+              y2 = BNN16 ? 16384 + h * 4096 : BNN ? (16 + 4 * h) * 1024 : x2, y3 = BNN16 ? 24576 + h * 4096 : BNN ? (24 + 4 * h) * 1024 : x3;
 
     // One K-tile.  ISSUE = 1: the steady state (units 2t+4, 2t+5 are issued, vmcnt(8) at the hand-over).
     // ISSUE = 0: the last two K-tiles of the tile -- there is nothing left to fetch, so no DMA is issued (the first
@@ -694,14 +727,15 @@ bool gemm_lp256w4_supports(const mi355_gemm_desc &d, const void *a, const void *
         if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != MI355_DTYPE_BF16 && d.dtype_c != MI355_DTYPE_F16) return false;
     } else if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != d.dtype_ab) return false;
     if (d.trans_a) return false;
-    if (!d.trans_b && d.dtype_ab != MI355_DTYPE_F32) return false;          // row-major B: f32 only
+    if (!d.trans_b && f8) return false;                                     // row-major B: f32 and 16-bit operands
     const int64_t esz = f8 ? 1 : d.dtype_ab == MI355_DTYPE_F32 ? 4 : 2;
     const int64_t BK = ROW_BYTES / esz;
     if (d.k < BK || d.k % BK != 0) return false;
     const int64_t csz = d.dtype_c == MI355_DTYPE_F32 ? 4 : 2;      // the epilogue writes C in 16-byte pieces
     if (((d.ldc * csz) & 15) || ((d.stride_c * csz) & 15) || (reinterpret_cast<uintptr_t>(c) & 15u)) return false;
     if (d.m < 1 || d.n < 1) return false;
-    if (!d.trans_b && (d.n < 4 || (d.n & 3))) return false;              // row-major B is fetched 4 columns at a time
+    // row-major B is fetched 16 bytes of a row at a time: 4 (f32) / 8 (16-bit) columns
+    if (!d.trans_b && (d.n < 16 / esz || (d.n & (16 / esz - 1)))) return false;
     const int64_t amask = 16 / esz - 1;                               // operand rows must be 16-byte aligned
     if ((d.lda & amask) || (d.ldb & amask) || (d.stride_a & amask) || (d.stride_b & amask)) return false;
     if ((reinterpret_cast<uintptr_t>(a) & 15u) || (reinterpret_cast<uintptr_t>(b) & 15u)) return false;
@@ -741,11 +775,21 @@ int32_t launch_gemm_lp256w4(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc
         if (d.trans_b) launch<MI355_DTYPE_F32, MI355_DTYPE_F32, false>(ctx, s, g, batch, 16);
         else launch<MI355_DTYPE_F32, MI355_DTYPE_F32, true>(ctx, s, g, batch, 17);
     } else if (d.dtype_ab == MI355_DTYPE_BF16) {
-        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, g, batch, 12);
-        else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16>(ctx, s, g, batch, 13);
+        if (d.trans_b) {
+            if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, g, batch, 12);
+            else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16>(ctx, s, g, batch, 13);
+        } else {
+            if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32, true>(ctx, s, g, batch, 18);
+            else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16, true>(ctx, s, g, batch, 19);
+        }
     } else {
-        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(ctx, s, g, batch, 14);
-        else launch<MI355_DTYPE_F16, MI355_DTYPE_F16>(ctx, s, g, batch, 15);
+        if (d.trans_b) {
+            if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(ctx, s, g, batch, 14);
+            else launch<MI355_DTYPE_F16, MI355_DTYPE_F16>(ctx, s, g, batch, 15);
+        } else {
+            if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32, true>(ctx, s, g, batch, 20);
+            else launch<MI355_DTYPE_F16, MI355_DTYPE_F16, true>(ctx, s, g, batch, 21);
+        }
     }
     check_launch(ctx, "mi355_gemm(lp256w4)");
     return MI355_OK;

@@ -172,6 +172,13 @@ def gemm_select(client: ComputeClient, desc: N.GemmDesc) -> int:
     return algo.value
 
 
+def gemm_relayout_plan(client: ComputeClient, desc: N.GemmDesc):
+    """(relayout_a, relayout_b): which operands mi355_gemm would copy into library scratch before the MFMA kernel."""
+    ra, rb = C.c_int32(), C.c_int32()
+    client._s.check(client.lib.mi355_gemm_relayout_plan(C.byref(desc), C.byref(ra), C.byref(rb)))
+    return bool(ra.value), bool(rb.value)
+
+
 _WORKSPACES: dict = {}
 
 

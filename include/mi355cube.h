@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define MI355_ABI_VERSION 4
+#define MI355_ABI_VERSION 5
 
 /* ---- status codes (map onto LaunchError / IoError / ServerError, server/base.rs:177-332,
  *      :884-1019; the Rust shim performs the conversion) ------------------------------- */
@@ -403,6 +403,13 @@ int32_t mi355_gemm_select(mi355_ctx *ctx, const mi355_gemm_desc *desc, int32_t *
  * (one batched launch + the deterministic slab fold). */
 int32_t mi355_gemm_tail_plan(const mi355_gemm_desc *desc, int32_t *out_along_m, int64_t *out_main_extent,
                              int32_t *out_splits);
+/* Which operands mi355_gemm (AUTO) would first copy into library scratch, re-laid out K-contiguous -- the role of the
+ * reference launchers' into_contiguous after matrix_batch_layout (crates/cubecl-std/src/tensor/matrix_batch_layout.rs:21-79)
+ * -- before an MFMA kernel runs (pure function, no device; operands taken as 16-byte aligned).  Both 0: the kernels stage
+ * the caller's layout directly and no scratch is touched -- true for row-major A with B either [N][K] or, for f32 and
+ * (since ABI 5) bf16 / f16 tile-kernel shapes, row-major [K][N] as TensorHandle::new_contiguous lays a rhs out
+ * (crates/cubecl-std/src/tensor/handle.rs:89). */
+int32_t mi355_gemm_relayout_plan(const mi355_gemm_desc *desc, int32_t *out_relayout_a, int32_t *out_relayout_b);
 
 /* Block-scaled matmul (MX formats): C[b] = (A[b] .* SA[b]) * (B[b] .* SB[b])^T, f32 accumulate -- the operation
  * `MmaDefinition::execute_scaled` defines per fragment (crates/cubecl-core/src/frontend/cmma.rs:795-840), semantics
