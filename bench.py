@@ -777,21 +777,43 @@ def main():
 
         def skinny():
             out = {}
-            for (m, n, k) in ((8192, 8192, 64), (64, 8192, 8192), (8192, 64, 8192), (1, 8192, 8192), (16, 8192, 8192), (16, 28672, 8192), (64, 28672, 8192), (128, 28672, 8192), (4096, 4096, 4096),
-                              (6144, 6144, 6144), (4608, 4096, 8192), (2048, 2048, 2048)):
-                sa = TensorHandle.uniform(client, (m, k), ElemType.BF16, SEED, 700, -1.0, 1.0)
-                sb = TensorHandle.uniform(client, (n, k), ElemType.BF16, SEED, 701, -1.0, 1.0)
-                sc = client.empty(m * n * 2)
-                d = gemm_desc(N, m, n, k, N.DTYPE_BF16, N.DTYPE_BF16, trans_b=1)
+            shapes = [(8192, 8192, 64, 1), (64, 8192, 8192, 1), (8192, 64, 8192, 1), (1, 8192, 8192, 1), (16, 8192, 8192, 1), (16, 28672, 8192, 1),
+                      (64, 28672, 8192, 1), (128, 28672, 8192, 1), (4096, 4096, 4096, 1), (6144, 6144, 6144, 1), (4608, 4096, 8192, 1),
+                      (2048, 2048, 2048, 1),
+                      # the reference's default rhs layout (row-major [K][N], TensorHandle::new_contiguous): staged natively, no re-layout
+                      (8192, 8192, 8192, 0), (4096, 4096, 4096, 0), (2048, 2048, 2048, 0)]
+            for (m, n, k, tb) in shapes:
+                # Cold operands (advisor, round 2): a 128 MiB operand re-read by 20 back-to-back launches is partly served by the
+                # 256 MiB Infinity Cache, which flatters HBM-bound shapes.  Launches rotate through as many operand sets as it
+                # takes to exceed 768 MiB in total (at most 8), so every launch finds its operands in HBM; and the figure is the
+                # MEDIAN of five back-to-back runs, not their minimum.
+                fp = 2 * (m * k + n * k + m * n)
+                nsets = max(1, min(8, -(-(768 << 20) // fp)))
+                sets = []
+                for i in range(nsets):
+                    sets.append((TensorHandle.uniform(client, (m, k), ElemType.BF16, SEED, 700 + 2 * i, -1.0, 1.0),
+                                 TensorHandle.uniform(client, (n, k), ElemType.BF16, SEED, 701 + 2 * i, -1.0, 1.0),    # ([K][N] when tb == 0: same bytes, other meaning)
+                                 client.empty(m * n * 2)))
+                d = gemm_desc(N, m, n, k, N.DTYPE_BF16, N.DTYPE_BF16, trans_b=tb)
                 alg = C.c_int32()
                 lib.mi355_gemm_select(ctx, C.byref(d), C.byref(alg))
-                call = lambda: client._s.check(lib.mi355_gemm(ctx, None, C.byref(d), sa.device_ptr(), sb.device_ptr(), sc.device_ptr()))
+                turn = [0]
+
+                def call():
+                    sa, sb, sc = sets[turn[0] % nsets]
+                    turn[0] += 1
+                    client._s.check(lib.mi355_gemm(ctx, None, C.byref(d), sa.device_ptr(), sb.device_ptr(), sc.device_ptr()))
                 med, _ = samples_op(client, ev, call, samples=7, warmup=2)
                 # these launches are tens of microseconds: a per-sample event pair adds one launch gap (~2.5 us) to each, so the
                 # rate is priced on 20 back-to-back launches (like the roofline objects) and the per-sample median is kept beside it
-                b2b = min(time_op(client, ev, call, 20, warmup=3) for _ in range(5))
-                out[f"{m}x{n}x{k}"] = {"median_ms": round(med, 4), "back_to_back_ms": round(b2b, 4), "TFLOPs": round(2.0 * m * n * k / b2b / 1e9, 1),
-                                       "algo": alg.value, "algorithmic_GBs": round(2.0 * (m * k + n * k + m * n) / b2b / 1e6, 1)}
+                runs = sorted(time_op(client, ev, call, 20, warmup=3) for _ in range(5))
+                b2b = runs[2]
+                ra, rb = C.c_int32(), C.c_int32()
+                lib.mi355_gemm_relayout_plan(C.byref(d), C.byref(ra), C.byref(rb))
+                out[f"{m}x{n}x{k}" + ("" if tb else "_NN")] = {"median_ms": round(med, 4), "back_to_back_ms": round(b2b, 4), "TFLOPs": round(2.0 * m * n * k / b2b / 1e9, 1),
+                                                                "algo": alg.value, "algorithmic_GBs": round(2.0 * (m * k + n * k + m * n) / b2b / 1e6, 1),
+                                                                "operands_relaid_out": bool(ra.value or rb.value), "operand_sets_rotated": nsets,
+                                                                "back_to_back_min_ms": round(runs[0], 4)}
             return out
         guarded("gemm_bf16_shapes", skinny)
 

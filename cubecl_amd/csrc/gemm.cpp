@@ -200,7 +200,7 @@ bool plan_tail_split(const mi355_gemm_desc &d, tail_plan &best)
 {
     if (d.batch != 1 || d.trans_a || (d.n & 3)) return false;
     const int64_t esz = (int64_t)dtype_size(d.dtype_ab), ktile = 128 / esz, nk = d.k / ktile;
-    if (!d.trans_b && (d.n & (16 / esz - 1))) return false;
+    if (!d.trans_b && ((d.n & (16 / esz - 1)) || is_fp8(d.dtype_ab))) return false;   // row-major B: f32 and 16-bit, whole 16-byte pieces
     const int64_t tm = (d.m + 255) / 256, tn = (d.n + 255) / 256, T = tm * tn;
     if (nk < 8) return false;
     // cycles: a K-tile costs ~2 200, a tile's prologue + epilogue ~10 000, a launch ~5 000, the fold moves

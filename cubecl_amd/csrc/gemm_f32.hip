@@ -215,13 +215,9 @@ int32_t launch_gemm_f32_mfma(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_des
     const dim3 grid(g.tiles_m * g.tiles_n, (uint32_t)d.batch);
     const size_t lds = sizeof(f32_smem);
     // the dynamic-LDS attribute is per device: remember it per context, not in a process-wide static
-    const int slot = d.trans_b ? 31 : 30;
     const void *fn = d.trans_b ? reinterpret_cast<const void *>(gemm_f32_mfma_kernel<true>)
                                : reinterpret_cast<const void *>(gemm_f32_mfma_kernel<false>);
-    if (!(ctx->func_attr_mask & (1ull << slot))) {
-        hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        ctx->func_attr_mask |= (1ull << slot);
-    }
+    lds_opt_in(ctx, fn, (int)lds);
     if (d.trans_b) hipLaunchKernelGGL(gemm_f32_mfma_kernel<true>, grid, dim3(256), lds, s, g);
     else hipLaunchKernelGGL(gemm_f32_mfma_kernel<false>, grid, dim3(256), lds, s, g);
     check_launch(ctx, "mi355_gemm(f32 mfma)");

@@ -493,17 +493,13 @@ gemm_lp128_kernel(gemm_args g)
 #define LP128_SPEC 1   // dev: 0 = the 4-stage ring without loader waves
 #endif
 template <int DT, int DT_C, int NS, bool SPEC = false>
-void launch_ns(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch, int slot)
+void launch_ns(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch)
 {
     // operand stages, or the four per-wave epilogue scratch areas when those are larger (f32 C with one stage: 36 KiB)
     constexpr int CSZ_ = DT_C == MI355_DTYPE_F32 ? 4 : 2;
     constexpr int EPI = 4 * ((32 * (64 * CSZ_ + 16) + 1023) & ~1023);
     constexpr int LDS = NS * 2 * TILE_BYTES > EPI ? NS * 2 * TILE_BYTES : EPI;
-    if (LDS > 65536 && !(ctx->func_attr_mask & (1ull << slot))) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_lp128_kernel<DT, DT_C, NS, SPEC>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        ctx->func_attr_mask |= (1ull << slot);
-    }
+    lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_lp128_kernel<DT, DT_C, NS, SPEC>), LDS);
     hipLaunchKernelGGL((gemm_lp128_kernel<DT, DT_C, NS, SPEC>), dim3(g.tiles_m * g.tiles_n, batch, g.split_k > 1 ? g.split_k : 1),
                        dim3(SPEC ? 512 : 256), LDS, s, g);
 }
@@ -512,14 +508,14 @@ void launch_ns(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch
 #define SK1_MAX_TILES 4   // K-tiles up to which the single-stage, four-workgroups-per-CU form is launched
 #endif
 template <int DT, int DT_C>
-void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch, int slot)
+void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch)
 {
     // one workgroup per CU at most: the deep (4-stage) pipeline; otherwise two co-resident 2-stage workgroups per CU
     const uint64_t wgs = (uint64_t)g.tiles_m * g.tiles_n * batch * (g.split_k > 1 ? g.split_k : 1);
     constexpr int BK_ = ROW_BYTES / ((DT == MI355_DTYPE_F8E4M3 || DT == MI355_DTYPE_F8E5M2) ? 1 : 2);
-    if (wgs <= (uint64_t)ctx->props.num_streaming_multiprocessors) launch_ns<DT, DT_C, 4, LP128_SPEC != 0>(ctx, s, g, batch, slot);
-    else if (g.k <= SK1_MAX_TILES * BK_ && g.split_k <= 1) launch_ns<DT, DT_C, 1>(ctx, s, g, batch, slot);   // four workgroups per CU
-    else launch_ns<DT, DT_C, 2, LP128_SPEC2 != 0>(ctx, s, g, batch, slot);
+    if (wgs <= (uint64_t)ctx->props.num_streaming_multiprocessors) launch_ns<DT, DT_C, 4, LP128_SPEC != 0>(ctx, s, g, batch);
+    else if (g.k <= SK1_MAX_TILES * BK_ && g.split_k <= 1) launch_ns<DT, DT_C, 1>(ctx, s, g, batch);   // four workgroups per CU
+    else launch_ns<DT, DT_C, 2, LP128_SPEC2 != 0>(ctx, s, g, batch);
 }
 
 }  // namespace
@@ -594,10 +590,10 @@ int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
             gemm_args gs = g;
             gs.c = ws; gs.ldc = d.n; gs.stride_c = d.m * d.n;
             gs.split_k = (uint32_t)splits; gs.split_c_stride = slab;
-            if (d.dtype_ab == MI355_DTYPE_BF16) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, gs, batch, 48);
-            else if (d.dtype_ab == MI355_DTYPE_F16) launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(ctx, s, gs, batch, 50);
-            else if (d.dtype_ab == MI355_DTYPE_F8E4M3) launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_F32>(ctx, s, gs, batch, 52);
-            else launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_F32>(ctx, s, gs, batch, 54);
+            if (d.dtype_ab == MI355_DTYPE_BF16) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, gs, batch);
+            else if (d.dtype_ab == MI355_DTYPE_F16) launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(ctx, s, gs, batch);
+            else if (d.dtype_ab == MI355_DTYPE_F8E4M3) launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_F32>(ctx, s, gs, batch);
+            else launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_F32>(ctx, s, gs, batch);
             check_launch(ctx, "mi355_gemm(lp128 split-K)");
             launch_splitk_fold(s, ws, (uint32_t)splits, slab, d.batch, d.m, d.n, c, d.dtype_c, d.ldc, d.stride_c);
             check_launch(ctx, "mi355_gemm(split-K fold)");
@@ -605,19 +601,19 @@ int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
         }
     }
     if (d.dtype_ab == MI355_DTYPE_F8E4M3) {
-        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_F32>(ctx, s, g, batch, 52);
-        else if (d.dtype_c == MI355_DTYPE_BF16) launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_BF16>(ctx, s, g, batch, 53);
-        else launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_F16>(ctx, s, g, batch, 56);
+        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_F32>(ctx, s, g, batch);
+        else if (d.dtype_c == MI355_DTYPE_BF16) launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_BF16>(ctx, s, g, batch);
+        else launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_F16>(ctx, s, g, batch);
     } else if (d.dtype_ab == MI355_DTYPE_F8E5M2) {
-        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_F32>(ctx, s, g, batch, 54);
-        else if (d.dtype_c == MI355_DTYPE_BF16) launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_BF16>(ctx, s, g, batch, 55);
-        else launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_F16>(ctx, s, g, batch, 57);
+        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_F32>(ctx, s, g, batch);
+        else if (d.dtype_c == MI355_DTYPE_BF16) launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_BF16>(ctx, s, g, batch);
+        else launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_F16>(ctx, s, g, batch);
     } else if (d.dtype_ab == MI355_DTYPE_BF16) {
-        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, g, batch, 48);
-        else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16>(ctx, s, g, batch, 49);
+        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, g, batch);
+        else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16>(ctx, s, g, batch);
     } else {
-        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(ctx, s, g, batch, 50);
-        else launch<MI355_DTYPE_F16, MI355_DTYPE_F16>(ctx, s, g, batch, 51);
+        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(ctx, s, g, batch);
+        else launch<MI355_DTYPE_F16, MI355_DTYPE_F16>(ctx, s, g, batch);
     }
     check_launch(ctx, "mi355_gemm(lp128)");
     return MI355_OK;

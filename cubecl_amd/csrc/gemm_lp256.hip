@@ -300,13 +300,9 @@ gemm_lp256_kernel(gemm_args g)
 }
 
 template <int DT, int DT_C>
-void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch, int slot)
+void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch)
 {
-    if (!(ctx->func_attr_mask & (1ull << slot))) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_lp256_kernel<DT, DT_C>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        ctx->func_attr_mask |= (1ull << slot);
-    }
+    lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_lp256_kernel<DT, DT_C>), LDS_BYTES);
     hipLaunchKernelGGL((gemm_lp256_kernel<DT, DT_C>), dim3(g.tiles_m * g.tiles_n, batch), dim3(512), LDS_BYTES, s, g);
 }
 
@@ -352,11 +348,11 @@ int32_t launch_gemm_lp256(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
     g.group_m = 8;
     const uint32_t batch = (uint32_t)d.batch;
     if (d.dtype_ab == MI355_DTYPE_BF16) {
-        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, g, batch, 8);
-        else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16>(ctx, s, g, batch, 9);
+        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, g, batch);
+        else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16>(ctx, s, g, batch);
     } else {
-        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(ctx, s, g, batch, 10);
-        else launch<MI355_DTYPE_F16, MI355_DTYPE_F16>(ctx, s, g, batch, 11);
+        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(ctx, s, g, batch);
+        else launch<MI355_DTYPE_F16, MI355_DTYPE_F16>(ctx, s, g, batch);
     }
     check_launch(ctx, "mi355_gemm(lp256)");
     return MI355_OK;

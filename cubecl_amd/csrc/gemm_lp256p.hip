@@ -453,13 +453,9 @@ gemm_lp256p_kernel(gemm_args g)
 }
 
 template <int DT, int DT_C, bool BNN = false>
-void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch, int slot)
+void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch)
 {
-    if (!(ctx->func_attr_mask & (1ull << slot))) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_lp256p_kernel<DT, DT_C, BNN>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        ctx->func_attr_mask |= (1ull << slot);
-    }
+    lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_lp256p_kernel<DT, DT_C, BNN>), LDS_BYTES);
     // one workgroup per CU (LDS admits no more); fewer when there are fewer tiles than CUs
     const uint32_t total = g.tiles_m * g.tiles_n * batch;
     const uint32_t grid = std::min<uint32_t>(total, ctx->props.num_streaming_multiprocessors);
@@ -514,14 +510,14 @@ int32_t launch_gemm_lp256p(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc 
     g.batch_count = (uint32_t)d.batch;
     const uint32_t batch = (uint32_t)d.batch;
     if (d.dtype_ab == MI355_DTYPE_F32) {
-        if (d.trans_b) launch<MI355_DTYPE_F32, MI355_DTYPE_F32, false>(ctx, s, g, batch, 24);
-        else launch<MI355_DTYPE_F32, MI355_DTYPE_F32, true>(ctx, s, g, batch, 25);
+        if (d.trans_b) launch<MI355_DTYPE_F32, MI355_DTYPE_F32, false>(ctx, s, g, batch);
+        else launch<MI355_DTYPE_F32, MI355_DTYPE_F32, true>(ctx, s, g, batch);
     } else if (d.dtype_ab == MI355_DTYPE_BF16) {
-        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, g, batch, 20);
-        else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16>(ctx, s, g, batch, 21);
+        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, g, batch);
+        else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16>(ctx, s, g, batch);
     } else {
-        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(ctx, s, g, batch, 22);
-        else launch<MI355_DTYPE_F16, MI355_DTYPE_F16>(ctx, s, g, batch, 23);
+        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(ctx, s, g, batch);
+        else launch<MI355_DTYPE_F16, MI355_DTYPE_F16>(ctx, s, g, batch);
     }
     check_launch(ctx, "mi355_gemm(lp256p)");
     return MI355_OK;

@@ -535,12 +535,9 @@ gemm_lp256q_kernel(gemm_args g)
 }
 
 template <int DT, int D>
-void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch, int slot)
+void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch)
 {
-    if (!(ctx->func_attr_mask2 & (1ull << slot))) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_lp256q_kernel<DT, D>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        ctx->func_attr_mask2 |= (1ull << slot);
-    }
+    lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_lp256q_kernel<DT, D>), LDS_BYTES);
     const uint32_t total = g.tiles_m * g.tiles_n * batch;
     const uint32_t grid = std::min<uint32_t>(total, ctx->props.num_streaming_multiprocessors);   // one workgroup per CU (LDS admits no more)
     hipLaunchKernelGGL((gemm_lp256q_kernel<DT, D>), dim3(grid), dim3(256), LDS_BYTES, s, g);
@@ -583,9 +580,9 @@ int32_t launch_gemm_lp256q(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc 
     const uint32_t batch = (uint32_t)d.batch;
     const int drip = drip_for(d.k / 64);
     const bool bf = d.dtype_ab == MI355_DTYPE_BF16;
-#define Q_LAUNCH(DD, SLOT)                                                                              \
-    if (bf) launch<MI355_DTYPE_BF16, DD>(ctx, s, g, batch, SLOT); else launch<MI355_DTYPE_F16, DD>(ctx, s, g, batch, (SLOT) + 1);
-    if (drip == 1) { Q_LAUNCH(1, 0) } else if (drip == 2) { Q_LAUNCH(2, 2) } else if (drip == 4) { Q_LAUNCH(4, 4) } else { Q_LAUNCH(8, 6) }
+#define Q_LAUNCH(DD)                                                                              \
+    if (bf) launch<MI355_DTYPE_BF16, DD>(ctx, s, g, batch); else launch<MI355_DTYPE_F16, DD>(ctx, s, g, batch);
+    if (drip == 1) { Q_LAUNCH(1) } else if (drip == 2) { Q_LAUNCH(2) } else if (drip == 4) { Q_LAUNCH(4) } else { Q_LAUNCH(8) }
 #undef Q_LAUNCH
     check_launch(ctx, "mi355_gemm(lp256q)");
     return MI355_OK;

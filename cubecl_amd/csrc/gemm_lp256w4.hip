@@ -698,13 +698,9 @@ gemm_lp256w4_kernel(gemm_args g)
 }
 
 template <int DT, int DT_C, bool BNN = false, int DTB = DT, bool MX = false>
-void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch, int slot)
+void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch)
 {
-    if (!(ctx->func_attr_mask & (1ull << slot))) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_lp256w4_kernel<DT, DT_C, BNN, DTB, MX>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        ctx->func_attr_mask |= (1ull << slot);
-    }
+    lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_lp256w4_kernel<DT, DT_C, BNN, DTB, MX>), LDS_BYTES);
     hipLaunchKernelGGL((gemm_lp256w4_kernel<DT, DT_C, BNN, DTB, MX>), dim3(g.tiles_m * g.tiles_n, batch), dim3(256), LDS_BYTES, s, g);
 }
 
@@ -764,31 +760,31 @@ int32_t launch_gemm_lp256w4(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc
     g.group_m = W4_GROUP_M;
     const uint32_t batch = (uint32_t)d.batch;
     if (d.dtype_ab == MI355_DTYPE_F8E4M3) {
-        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_F32>(ctx, s, g, batch, 32);
-        else if (d.dtype_c == MI355_DTYPE_BF16) launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_BF16>(ctx, s, g, batch, 33);
-        else launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_F16>(ctx, s, g, batch, 34);
+        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_F32>(ctx, s, g, batch);
+        else if (d.dtype_c == MI355_DTYPE_BF16) launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_BF16>(ctx, s, g, batch);
+        else launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_F16>(ctx, s, g, batch);
     } else if (d.dtype_ab == MI355_DTYPE_F8E5M2) {
-        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_F32>(ctx, s, g, batch, 35);
-        else if (d.dtype_c == MI355_DTYPE_BF16) launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_BF16>(ctx, s, g, batch, 36);
-        else launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_F16>(ctx, s, g, batch, 37);
+        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_F32>(ctx, s, g, batch);
+        else if (d.dtype_c == MI355_DTYPE_BF16) launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_BF16>(ctx, s, g, batch);
+        else launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_F16>(ctx, s, g, batch);
     } else if (d.dtype_ab == MI355_DTYPE_F32) {
-        if (d.trans_b) launch<MI355_DTYPE_F32, MI355_DTYPE_F32, false>(ctx, s, g, batch, 16);
-        else launch<MI355_DTYPE_F32, MI355_DTYPE_F32, true>(ctx, s, g, batch, 17);
+        if (d.trans_b) launch<MI355_DTYPE_F32, MI355_DTYPE_F32, false>(ctx, s, g, batch);
+        else launch<MI355_DTYPE_F32, MI355_DTYPE_F32, true>(ctx, s, g, batch);
     } else if (d.dtype_ab == MI355_DTYPE_BF16) {
         if (d.trans_b) {
-            if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, g, batch, 12);
-            else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16>(ctx, s, g, batch, 13);
+            if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, g, batch);
+            else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16>(ctx, s, g, batch);
         } else {
-            if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32, true>(ctx, s, g, batch, 18);
-            else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16, true>(ctx, s, g, batch, 19);
+            if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32, true>(ctx, s, g, batch);
+            else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16, true>(ctx, s, g, batch);
         }
     } else {
         if (d.trans_b) {
-            if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(ctx, s, g, batch, 14);
-            else launch<MI355_DTYPE_F16, MI355_DTYPE_F16>(ctx, s, g, batch, 15);
+            if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(ctx, s, g, batch);
+            else launch<MI355_DTYPE_F16, MI355_DTYPE_F16>(ctx, s, g, batch);
         } else {
-            if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32, true>(ctx, s, g, batch, 20);
-            else launch<MI355_DTYPE_F16, MI355_DTYPE_F16, true>(ctx, s, g, batch, 21);
+            if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32, true>(ctx, s, g, batch);
+            else launch<MI355_DTYPE_F16, MI355_DTYPE_F16, true>(ctx, s, g, batch);
         }
     }
     check_launch(ctx, "mi355_gemm(lp256w4)");
@@ -834,15 +830,15 @@ int32_t launch_gemm_lp256w4_mx(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_s
     const bool f32c = d.dtype_c == MI355_DTYPE_F32;
     constexpr int E4 = MI355_DTYPE_F8E4M3, E5 = MI355_DTYPE_F8E5M2, F4 = MI355_DTYPE_F4E2M1X2, CF = MI355_DTYPE_F32, CB = MI355_DTYPE_BF16;
     if (d.dtype_a == F4) {
-        if (f32c) launch<F4, CF, false, F4, true>(ctx, s, g, batch, 46); else launch<F4, CB, false, F4, true>(ctx, s, g, batch, 47);
+        if (f32c) launch<F4, CF, false, F4, true>(ctx, s, g, batch); else launch<F4, CB, false, F4, true>(ctx, s, g, batch);
     } else if (d.dtype_a == E4 && d.dtype_b == E4) {
-        if (f32c) launch<E4, CF, false, E4, true>(ctx, s, g, batch, 38); else launch<E4, CB, false, E4, true>(ctx, s, g, batch, 39);
+        if (f32c) launch<E4, CF, false, E4, true>(ctx, s, g, batch); else launch<E4, CB, false, E4, true>(ctx, s, g, batch);
     } else if (d.dtype_a == E5 && d.dtype_b == E5) {
-        if (f32c) launch<E5, CF, false, E5, true>(ctx, s, g, batch, 40); else launch<E5, CB, false, E5, true>(ctx, s, g, batch, 41);
+        if (f32c) launch<E5, CF, false, E5, true>(ctx, s, g, batch); else launch<E5, CB, false, E5, true>(ctx, s, g, batch);
     } else if (d.dtype_a == E4) {
-        if (f32c) launch<E4, CF, false, E5, true>(ctx, s, g, batch, 42); else launch<E4, CB, false, E5, true>(ctx, s, g, batch, 43);
+        if (f32c) launch<E4, CF, false, E5, true>(ctx, s, g, batch); else launch<E4, CB, false, E5, true>(ctx, s, g, batch);
     } else {
-        if (f32c) launch<E5, CF, false, E4, true>(ctx, s, g, batch, 44); else launch<E5, CB, false, E4, true>(ctx, s, g, batch, 45);
+        if (f32c) launch<E5, CF, false, E4, true>(ctx, s, g, batch); else launch<E5, CB, false, E4, true>(ctx, s, g, batch);
     }
     check_launch(ctx, "mi355_gemm_scaled(lp256w4)");
     return MI355_OK;

@@ -277,22 +277,19 @@ __global__ void __launch_bounds__(640, TWO ? 5 : 2) gemm_stream64_kernel(stream_
 }
 
 template <int DT, int MB, bool TWO>
-void launch_form(mi355_ctx *ctx, hipStream_t s, const stream_args &g, uint32_t batch, int slot)
+void launch_form(mi355_ctx *ctx, hipStream_t s, const stream_args &g, uint32_t batch)
 {
     constexpr int LDS = ring_geom<MB, TWO>::LDS;
-    if (!(ctx->func_attr_mask2 & (1ull << slot))) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_stream64_kernel<DT, MB, TWO>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        ctx->func_attr_mask2 |= (1ull << slot);
-    }
+    lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_stream64_kernel<DT, MB, TWO>), LDS);
     hipLaunchKernelGGL((gemm_stream64_kernel<DT, MB, TWO>), dim3((uint32_t)((g.big_rows + BN - 1) / BN), batch), dim3(640), LDS, s, g);
 }
 
 template <int DT, int MB>
-void launch_one(mi355_ctx *ctx, hipStream_t s, const stream_args &g, uint32_t batch, int slot)
+void launch_one(mi355_ctx *ctx, hipStream_t s, const stream_args &g, uint32_t batch)
 {
     const uint64_t wgs = (uint64_t)((g.big_rows + BN - 1) / BN) * batch;
-    if (wgs > (uint64_t)ctx->props.num_streaming_multiprocessors) launch_form<DT, MB, true>(ctx, s, g, batch, slot + 4);
-    else launch_form<DT, MB, false>(ctx, s, g, batch, slot);
+    if (wgs > (uint64_t)ctx->props.num_streaming_multiprocessors) launch_form<DT, MB, true>(ctx, s, g, batch);
+    else launch_form<DT, MB, false>(ctx, s, g, batch);
 }
 
 }  // namespace
@@ -337,11 +334,11 @@ int32_t launch_gemm_stream64(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_des
     const bool two = g.small_rows > 32;
     const uint32_t batch = (uint32_t)d.batch;
     if (d.dtype_ab == MI355_DTYPE_BF16) {
-        if (two) launch_one<MI355_DTYPE_BF16, 2>(ctx, s, g, batch, 8);
-        else launch_one<MI355_DTYPE_BF16, 1>(ctx, s, g, batch, 9);
+        if (two) launch_one<MI355_DTYPE_BF16, 2>(ctx, s, g, batch);
+        else launch_one<MI355_DTYPE_BF16, 1>(ctx, s, g, batch);
     } else {
-        if (two) launch_one<MI355_DTYPE_F16, 2>(ctx, s, g, batch, 10);
-        else launch_one<MI355_DTYPE_F16, 1>(ctx, s, g, batch, 11);
+        if (two) launch_one<MI355_DTYPE_F16, 2>(ctx, s, g, batch);
+        else launch_one<MI355_DTYPE_F16, 1>(ctx, s, g, batch);
     }
     check_launch(ctx, "mi355_gemm(stream64)");
     return MI355_OK;

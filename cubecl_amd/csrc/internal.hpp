@@ -72,8 +72,7 @@ struct mi355_ctx {
     // library-owned device scratch per (stream, kind): split-K slabs, re-laid-out GEMM operands
     std::map<std::pair<hipStream_t, int>, std::pair<void *, size_t>> scratch;
     mi355::memory_pool *pool = nullptr;    // caching allocator behind mi355_pool_* (pool.cpp)
-    uint64_t func_attr_mask = 0;  // kernels whose dynamic-LDS attribute is already raised on this device
-    uint64_t func_attr_mask2 = 0; // ... second word (gemm_lp256q.hip)
+    std::set<const void *> lds_opted;  // kernels whose dynamic-LDS attribute is already raised on this device (lds_opt_in)
     // One context = one server: the reference funnels every call through one runner thread per device
     // (crates/cubecl-common/src/device/handle/channel.rs:75-110).  Bindings without that discipline (Python: a Handle
     // dropped by the garbage collector on another thread while ctypes has released the GIL) are serialised here.
@@ -99,6 +98,13 @@ void scratch_release(mi355_ctx *ctx, void *ptr);               // a graph died: 
 int32_t scratch_get(mi355_ctx *ctx, hipStream_t s, int kind, size_t bytes, void **out);
 int32_t pool_cleanup(mi355_ctx *ctx, int32_t explicit_);
 void pool_destroy(mi355_ctx *ctx);
+// More than 64 KiB of dynamic LDS needs a per-kernel opt-in; once per (context = device, kernel), keyed by the kernel's
+// host stub so that no two instantiations can ever share a bookkeeping slot.
+inline void lds_opt_in(mi355_ctx *ctx, const void *kernel, int lds_bytes)
+{
+    if (ctx->lds_opted.insert(kernel).second)
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+}
 inline hipStream_t stream_of(mi355_ctx *ctx, mi355_stream s)
 {
     return s ? reinterpret_cast<hipStream_t>(s) : ctx->compute_stream;

@@ -155,6 +155,54 @@ def test_c3_bf16_8192_bf16_output_as_benched(client, oracle):
     assert np.array_equal(oracle.to_bf16(full32).reshape(S, S), got)
 
 
+def _nn_bench_desc(m, n, k, dtype_ab, dtype_c, batch=1):
+    """bench.py's descriptor for the reference's default rhs layout: B row-major [K][N] (trans_b = 0)."""
+    return N.GemmDesc(m=m, n=n, k=k, batch=batch, lda=k, ldb=n, ldc=n, stride_a=m * k, stride_b=n * k, stride_c=m * n,
+                      dtype_ab=dtype_ab, dtype_c=dtype_c, trans_a=0, trans_b=0, algo=N.GEMM_ALGO_AUTO)
+
+
+def test_c3_bf16_8192_row_major_rhs_is_native_and_bit_identical_to_the_k_contiguous_form(client, oracle):
+    """Config C3 with the rhs as TensorHandle::new_contiguous lays it out ([K][N], crates/cubecl-std/src/tensor/handle.rs:89):
+    no operand is copied (empty re-layout plan, no library scratch), the 256x256 kernel stages B through its transposing-read
+    image, and all 64 Mi outputs equal those of the K-contiguous launch (held to the f64 oracle above) bit for bit."""
+    import ctypes as C
+    S = 8192
+    a = TensorHandle.uniform(client, (S, S), ElemType.BF16, SEED, 100, -1.0, 1.0)
+    b_nk = TensorHandle.uniform(client, (S, S), ElemType.BF16, SEED, 200, -1.0, 1.0)      # [N][K]
+    b_kn = ops.into_contiguous(client, TensorHandle.new(b_nk.handle, (S, S), (1, S), ElemType.BF16))   # its transpose, [K][N]
+    outs = []
+    for d, b in ((_bench_desc(S, S, S, N.DTYPE_BF16, N.DTYPE_BF16), b_nk), (_nn_bench_desc(S, S, S, N.DTYPE_BF16, N.DTYPE_BF16), b_kn)):
+        assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4 and ops.gemm_relayout_plan(client, d) == (False, False)
+        c = TensorHandle.new_contiguous((S, S), client.empty(S * S * 2), ElemType.BF16)
+        client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()),
+                                              C.c_void_p(c.device_ptr())))
+        outs.append(c.to_numpy(client))
+    assert np.array_equal(outs[0], outs[1])
+    # and directly against the oracle on a few rows (the transposition above is a device kernel too)
+    rows = np.array([3, 255, 4097, 8190])
+    a_bits = oracle.to_bf16(oracle.fill_uniform(S * S, 100, -1.0, 1.0))
+    b_bits = oracle.to_bf16(oracle.fill_uniform(S * S, 200, -1.0, 1.0))
+    _bf16_rows_check(oracle, a_bits, b_bits, outs[1].reshape(S, S)[rows], rows, S, S, case="C3 8192^3 bf16, row-major rhs (NN), 4 sampled rows vs f64 oracle")
+
+
+def test_c5_batch64_2048_bf16_row_major_rhs_is_native(client, oracle):
+    """Config C5's shard with row-major rhs matrices: native (no re-layout), bit-identical to the K-contiguous launch."""
+    import ctypes as C
+    B, M = 64, 2048
+    a = TensorHandle.uniform(client, (B, M, M), ElemType.BF16, SEED, 500, -1.0, 1.0)
+    b_nk = TensorHandle.uniform(client, (B, M, M), ElemType.BF16, SEED, 600, -1.0, 1.0)
+    b_kn = ops.into_contiguous(client, TensorHandle.new(b_nk.handle, (B, M, M), (M * M, 1, M), ElemType.BF16))
+    outs = []
+    for d, b in ((_bench_desc(M, M, M, N.DTYPE_BF16, N.DTYPE_BF16, batch=B), b_nk), (_nn_bench_desc(M, M, M, N.DTYPE_BF16, N.DTYPE_BF16, batch=B), b_kn)):
+        assert ops.gemm_relayout_plan(client, d) == (False, False)
+        assert ops.gemm_select(client, d) in (N.GEMM_ALGO_LP_256W4, N.GEMM_ALGO_LP_256P, N.GEMM_ALGO_LP_256Q)
+        c = TensorHandle.new_contiguous((B, M, M), client.empty(B * M * M * 2), ElemType.BF16)
+        client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()),
+                                              C.c_void_p(c.device_ptr())))
+        outs.append(c.to_numpy(client))
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_c5_batch64_2048_bf16_as_benched_takes_the_dripped_store_kernel(client, oracle):
     """Config C5's per-GPU shard in the EXACT form bench.py times it (bench.py batched_c5): batch 64 of 2048^3 bf16 -> bf16 C.
     AUTO must take the persistent 256x256 kernel; sampled rows of five matrices (first, last, three inside) against the

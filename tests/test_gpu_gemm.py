@@ -458,6 +458,66 @@ def test_race_screen_bitwise_repeatability(client, oracle, algo):
         assert np.array_equal(c.to_numpy(client), first)
 
 
+# ---- row-major B (the reference's default rhs layout), staged natively by the tile kernels (round 3) --------------------
+def _nn_desc(m, n, k, dtype, out, ldb=None, batch=1, algo=N.GEMM_ALGO_AUTO):
+    ldb = ldb or n
+    return N.GemmDesc(m=m, n=n, k=k, batch=batch, lda=k, ldb=ldb, ldc=n, stride_a=m * k, stride_b=k * ldb, stride_c=m * n,
+                      dtype_ab=int(dtype), dtype_c=int(out), trans_a=0, trans_b=0, algo=algo)
+
+
+@pytest.mark.parametrize("m,n,k,ldb", [(3072, 3072, 128, None),      # 144 tiles: one K-tile pair, every wave position
+                                       (3000, 3080, 192, 3088),      # ragged M and N (N % 8 == 0), pitched rows of B
+                                       (2304, 4104, 64, None),       # a single K-tile; the last tile column is 8 wide
+                                       (4096, 2304, 320, 2304)])     # five K-tiles: the ring wraps
+@pytest.mark.parametrize("dtype,out", [(ElemType.BF16, "f32"), (ElemType.BF16, "same"), (ElemType.F16, "f32"), (ElemType.F16, "same")])
+def test_row_major_b_16bit_is_staged_natively_by_the_256_tile_kernel(client, oracle, m, n, k, ldb, dtype, out):
+    """TensorHandle::new_contiguous lays a rhs out [K][N] (crates/cubecl-std/src/tensor/handle.rs:89; the reference's row-major
+    cmma case is runtime_tests/cmma.rs:1160-1177).  From one round of 256x256 tiles up no operand is copied: the descriptor
+    resolves to the 256x256 kernel and the re-layout plan is empty; values against the f64 oracle like every other layout."""
+    odt = ElemType.F32 if out == "f32" else dtype
+    d = _nn_desc(m, n, k, dtype, odt, ldb)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    assert ops.gemm_relayout_plan(client, d) == (False, False)
+    run_case(client, oracle, m, n, k, dtype, odt, False, ALGOS["auto"], ldb=ldb)
+
+
+@pytest.mark.parametrize("dtype", [ElemType.BF16, ElemType.F16])
+def test_row_major_b_gives_the_bits_of_the_k_contiguous_form(client, oracle, dtype):
+    """Same tile, same k order inside every MFMA, same K-tile order: the row-major-B instantiation must reproduce the
+    [N][K] one bit for bit (f32 C), forced on the 256x256 kernel at a size with edge tiles and a batch with a broadcast B."""
+    m, n, k, batch = 520, 776, 448, 3
+    a_host = oracle.fill_uniform(batch * m * k, 61, -1.0, 1.0)
+    b_host = oracle.fill_uniform(k * n, 62, -1.0, 1.0).reshape(k, n)
+    conv = oracle.to_bf16 if dtype == ElemType.BF16 else oracle.to_f16
+    a = TensorHandle.from_numpy(client, conv(a_host), dtype)
+    b_kn = TensorHandle.from_numpy(client, conv(b_host), dtype)
+    b_nk = TensorHandle.from_numpy(client, conv(np.ascontiguousarray(b_host.T)), dtype)
+    a_t = TensorHandle.new(a.handle, (batch, m, k), (m * k, k, 1), dtype)
+    outs = []
+    for handle, strides in ((b_kn, (0, n, 1)), (b_nk, (0, 1, k))):
+        c = TensorHandle.new_contiguous((batch, m, n), client.empty(batch * m * n * 4), ElemType.F32)
+        ops.matmul(client, a_t, TensorHandle.new(handle.handle, (batch, k, n), strides, dtype), c, algo=N.GEMM_ALGO_LP_256W4)
+        outs.append(c.to_numpy(client))
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_row_major_b_refusals_of_the_tile_kernel(client, oracle):
+    """N not a multiple of 8 (a 16-byte DMA piece would straddle the row end) or rows of B not 16-byte aligned: the 256x256
+    kernel refuses when forced, AUTO re-lays B out and still lands on an MFMA kernel."""
+    for (m, n, k, ldb) in ((3072, 3076, 128, 3080), (3072, 3072, 128, 3076)):
+        d = _nn_desc(m, n, k, ElemType.BF16, ElemType.F32, ldb, algo=N.GEMM_ALGO_LP_256W4)
+        a = client.empty(m * k * 2)
+        b = client.empty(k * ldb * 2)
+        c = client.empty(m * n * 4)
+        rc = client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()), C.c_void_p(c.device_ptr()))
+        assert rc == N.E_UNSUPPORTED
+        d.algo = N.GEMM_ALGO_AUTO
+        assert ops.gemm_relayout_plan(client, d) == (False, True) and ops.gemm_select(client, d) != N.GEMM_ALGO_GENERIC
+    # few rows: the streaming kernels only exist for K-contiguous operands, so B is re-laid out for them
+    d = _nn_desc(16, 8192, 8192, ElemType.BF16, ElemType.BF16)
+    assert ops.gemm_relayout_plan(client, d) == (False, True) and ops.gemm_select(client, d) == N.GEMM_ALGO_STREAM64
+
+
 # ---- layouts the MFMA kernels do not stage directly: re-laid out K-contiguous into library scratch first ------------
 @pytest.mark.parametrize("m,n,k", [(512, 512, 512), (300, 260, 128), (256, 1024, 320), (1000, 513, 192)])
 @pytest.mark.parametrize("dtype,out", [(ElemType.BF16, "f32"), (ElemType.BF16, "same"), (ElemType.F16, "f32")])

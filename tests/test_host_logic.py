@@ -146,10 +146,13 @@ def test_tail_plan_splits_only_small_leftover_rounds():
     tiles_main = (extent // 256) * (13 if along else 20)
     assert splits > 1 and extent % 256 == 0 and 0 < tiles_main <= 256 and (20 * 13 - tiles_main) * splits <= 256
     assert (2048 // 64) % splits == 0
-    # fp8 counts K-tiles of 128, f32 of 32; batches and non-K-contiguous operands are never split
+    # fp8 counts K-tiles of 128, f32 of 32; batches and transposed A are never split
     assert _tail_plan(4608, 4096, 8192, dtype=N.DTYPE_F8E4M3)[2] > 1
     assert _tail_plan(4608, 4096, 8192, batch=2)[2] == 1
-    assert _tail_plan(6144, 6144, 6144, trans_b=0)[2] == 1
+    assert _tail_plan(6144, 6144, 6144, trans_a=1, lda=6144)[2] == 1
+    # row-major B (round 3: staged natively by the 256x256 kernel for 16-bit operands too) is cut exactly like [N][K] B; fp8 is not
+    assert _tail_plan(6144, 6144, 6144, trans_b=0, ldb=6144) == _tail_plan(6144, 6144, 6144)
+    assert _tail_plan(4608, 4096, 8192, dtype=N.DTYPE_F8E4M3, trans_b=0, ldb=4096)[2] == 1
     assert _tail_plan(6144, 6144, 256)[2] == 1                          # too few K-tiles to split
 
 
