@@ -57,7 +57,7 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
     // on 32 tiles of 256x256.
     if (!d.trans_b) {
         const int64_t tiles256 = ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch;
-        const bool native = std::min(d.m, d.n) > 128 && ((big4 && tiles256 > 128) || mid);
+        const bool native = (std::min(d.m, d.n) > 128 && big4 && tiles256 > 128) || (std::min(d.m, d.n) > 64 && mid);
         if (!native) return MI355_GEMM_ALGO_GENERIC;
     }
     // 3 ... 64 rows (or columns): 32 streamed rows x the whole K per workgroup, loader waves, no split-K (gemm_stream64.hip).

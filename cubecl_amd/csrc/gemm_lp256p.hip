@@ -130,14 +130,15 @@ __device__ __forceinline__ void p_stamp(int tid, int k) { if (tid == 0 && blockI
 #define P_STAMP(k)
 #endif
 
-// BNN (f32 only): B is row-major [K][N] instead of [N][K] (see gemm_lp256w4.hip).
+// BNN: B is row-major [K][N] instead of [N][K] (f32 and, since round 3, bf16 / f16: see gemm_lp256w4.hip).
 template <int DT, int DT_C, bool BNN = false>
 __global__ void __launch_bounds__(256)
 gemm_lp256p_kernel(gemm_args g)
 {
-    static_assert(!BNN || DT == MI355_DTYPE_F32, "row-major B is implemented for f32 only");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     typedef typename lp<DT>::frag frag;
+    // row-major B with 16-bit operands: the transposing-read image of gemm_lp256w4.hip ("BNN, bf16 / f16")
+    constexpr bool BNN16 = BNN && DT != MI355_DTYPE_F32;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -170,7 +171,7 @@ gemm_lp256p_kernel(gemm_args g)
         const char *B = static_cast<const char *>(g.b) + (int64_t)bi * g.stride_b * ESZ;
         t.ua = A + t.m0 * g.lda * ESZ;
         t.ub = B + t.n0 * g.ldb * ESZ;
-        t.ubnn = B + (int64_t)(wave * 8) * g.ldb * ESZ + t.n0 * ESZ;
+        t.ubnn = B + (int64_t)(BNN16 ? wave * 16 : wave * 8) * g.ldb * ESZ + t.n0 * ESZ;
         return t;
     };
     uint32_t voff_a[8], voff_b[8], voff_bnn[8];
@@ -180,14 +181,18 @@ gemm_lp256p_kernel(gemm_args g)
         const int q = c8 ^ ((r >> 1) & 7);
         voff_a[j] = (uint32_t)(r * g.lda * ESZ + q * 16);
         voff_b[j] = (uint32_t)(r * g.ldb * ESZ + q * 16);
-        voff_bnn[j] = (uint32_t)(j * g.ldb * ESZ + lane * 16);
+        if constexpr (BNN16)    // piece wave*8 + j: block row a = 4 wave + j/2, blocks 4(j%2) + lane/16, row (lane%16)/4, chunk lane%4
+            voff_bnn[j] = (uint32_t)(((j >> 1) * 4 + ((lane & 15) >> 2)) * g.ldb * ESZ + (j & 1) * 256 + (lane >> 4) * 64 + (lane & 3) * 16);
+        else
+            voff_bnn[j] = (uint32_t)(j * g.ldb * ESZ + lane * 16);
     }
     const int dst_piece = wave * 8 * 1024;                            // + j*1024 within the slot
 
     // ---- fragment read offsets: row*128 + ((2s+h) ^ f) * 16, f = (row>>1)&7 = (l31>>1)&7 for every tile row
     const int f = (l31 >> 1) & 7;
     const int rowoff_a = (wm * 128 + l31) * ROW_BYTES;
-    const int rowoff_b = BNN ? (wn * 128 + l31) * 4 : (wn * 128 + l31) * ROW_BYTES;
+    const int rowoff_b = BNN16 ? wn * 4 * 256 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8
+                         : BNN ? (wn * 128 + l31) * 4 : (wn * 128 + l31) * ROW_BYTES;
 
     f32x16 acc[4][4];
     auto zero_acc = [&]() {
@@ -206,7 +211,18 @@ gemm_lp256p_kernel(gemm_args g)
     // fragment load order == order of first use by the next k-step's MFMAs (j outer, i inner)
     auto read_one = [&](auto buf, auto idx, const char *pa, const char *pb) {
         constexpr int BUF = decltype(buf)::value, R = decltype(idx)::value;
-        if constexpr (BNN) {
+        if constexpr (BNN16) {
+            if constexpr (R >= 1 && R <= 4) fa[BUF][R - 1] = *reinterpret_cast<const frag *>(pa + (R - 1) * 32 * ROW_BYTES);
+            else {
+                constexpr int JB = (R == 0) ? 0 : R - 4;       // column block JB: k 0..3 from block row a, k 4..7 from a + 1 (2 KiB on)
+                typedef short s16x4 __attribute__((ext_vector_type(4)));
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                const auto q = (__attribute__((address_space(3))) s16x4 *)(pb + JB * 256);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(q);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(q + 256);
+                fb[BUF][JB] = __builtin_bit_cast(frag, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+        } else if constexpr (BNN) {
             if (R >= 1 && R <= 4) fa[BUF][R - 1] = *reinterpret_cast<const frag *>(pa + (R - 1) * 32 * ROW_BYTES);
             else {
                 constexpr int JB = (R == 0) ? 0 : R - 4;
@@ -283,7 +299,7 @@ gemm_lp256p_kernel(gemm_args g)
     __builtin_amdgcn_sched_barrier(0);
     {
         const int x = (h ^ f) << 4;
-        const char *rd_a = smem + rowoff_a + x, *rd_b = smem + UNIT_BYTES + rowoff_b + (BNN ? (4 * h) * 1024 : x);
+        const char *rd_a = smem + rowoff_a + x, *rd_b = smem + UNIT_BYTES + rowoff_b + (BNN16 ? h * 4096 : BNN ? (4 * h) * 1024 : x);
         read_one(IC<0>{}, IC<0>{}, rd_a, rd_b); read_one(IC<0>{}, IC<1>{}, rd_a, rd_b);
         read_one(IC<0>{}, IC<2>{}, rd_a, rd_b); read_one(IC<0>{}, IC<3>{}, rd_a, rd_b);
         read_one(IC<0>{}, IC<4>{}, rd_a, rd_b); read_one(IC<0>{}, IC<5>{}, rd_a, rd_b);
@@ -295,8 +311,8 @@ gemm_lp256p_kernel(gemm_args g)
     int sb = UNIT_BYTES;                 // ... and of its B unit; the ring runs on across output tiles
     auto adv = [](int x, int n) { x += n * UNIT_BYTES; return x >= LDS_BYTES ? x - LDS_BYTES : x; };
     const int x1 = ((2 + h) ^ f) << 4, x2 = ((4 + h) ^ f) << 4, x3 = ((6 + h) ^ f) << 4, x0 = (h ^ f) << 4;
-    const int y0 = BNN ? (4 * h) * 1024 : x0, y1 = BNN ? (8 + 4 * h) * 1024 : x1, y2 = BNN ? (16 + 4 * h) * 1024 : x2,
-              y3 = BNN ? (24 + 4 * h) * 1024 : x3;
+    const int y0 = BNN16 ? h * 4096 : BNN ? (4 * h) * 1024 : x0, y1 = BNN16 ? 8192 + h * 4096 : BNN ? (8 + 4 * h) * 1024 : x1,
+              y2 = BNN16 ? 16384 + h * 4096 : BNN ? (16 + 4 * h) * 1024 : x2, y3 = BNN16 ? 24576 + h * 4096 : BNN ? (24 + 4 * h) * 1024 : x3;
 
     char *__restrict__ C = static_cast<char *>(g.c);
     constexpr int CSZ = (DT_C == MI355_DTYPE_F32) ? 4 : 2;
@@ -478,7 +494,6 @@ bool gemm_lp256p_supports(const mi355_gemm_desc &d, const void *a, const void *b
     if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16 && d.dtype_ab != MI355_DTYPE_F32) return false;
     if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != d.dtype_ab) return false;
     if (d.trans_a) return false;
-    if (!d.trans_b && d.dtype_ab != MI355_DTYPE_F32) return false;          // row-major B: f32 only
     const int64_t esz = d.dtype_ab == MI355_DTYPE_F32 ? 4 : 2;
     const int64_t BK = ROW_BYTES / esz;
     if (d.k < 2 * BK || d.k % BK != 0) return false;              // the stream is two K-tiles deep
@@ -513,11 +528,21 @@ int32_t launch_gemm_lp256p(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc 
         if (d.trans_b) launch<MI355_DTYPE_F32, MI355_DTYPE_F32, false>(ctx, s, g, batch);
         else launch<MI355_DTYPE_F32, MI355_DTYPE_F32, true>(ctx, s, g, batch);
     } else if (d.dtype_ab == MI355_DTYPE_BF16) {
-        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, g, batch);
-        else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16>(ctx, s, g, batch);
+        if (d.trans_b) {
+            if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, g, batch);
+            else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16>(ctx, s, g, batch);
+        } else {
+            if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32, true>(ctx, s, g, batch);
+            else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16, true>(ctx, s, g, batch);
+        }
     } else {
-        if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(ctx, s, g, batch);
-        else launch<MI355_DTYPE_F16, MI355_DTYPE_F16>(ctx, s, g, batch);
+        if (d.trans_b) {
+            if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(ctx, s, g, batch);
+            else launch<MI355_DTYPE_F16, MI355_DTYPE_F16>(ctx, s, g, batch);
+        } else {
+            if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32, true>(ctx, s, g, batch);
+            else launch<MI355_DTYPE_F16, MI355_DTYPE_F16, true>(ctx, s, g, batch);
+        }
     }
     check_launch(ctx, "mi355_gemm(lp256p)");
     return MI355_OK;

@@ -22,7 +22,12 @@
 // last DMA piece): the next hand-over counts them as allowed-in-flight (vmcnt(8 + D)) and only the hand-over after that
 // (1.75 K-tiles = ~4000 cycles later) needs them gone.  Every K-tile body below is instantiated with its exact count.
 //
-// Restrictions: as gemm_lp256p.hip, plus 16-bit C of the operand type, lda == ldb and K >= (24 / D + 3) K-tiles.
+// Restrictions: as gemm_lp256p.hip, plus 16-bit C of the operand type, lda == ldb (B stored [N][K]) and K >= (24 / D + 3) K-tiles.
+//
+// BNN (round 3): B row-major [K][N], the layout TensorHandle::new_contiguous gives a rhs.  Image, DMA map and the two
+// ds_read_b64_tr_b16 per fragment are those of gemm_lp256w4.hip ("BNN, bf16 / f16"); tiles are full here, so the piece
+// offsets are scalar (wave-uniform base arithmetic) and B's whole per-lane part is ONE register -- the held tile leaves
+// room for no more.
 #include <algorithm>
 #include <type_traits>
 
@@ -114,7 +119,7 @@ template <int V> using IC = std::integral_constant<int, V>;
 __device__ __forceinline__ uint32_t opaque(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
 
 // D = dripped stores per K-tile (1, 2, 4 or 8): the 24 held stores leave during the first 24 / D K-tiles of the next tile
-template <int DT, int D>
+template <int DT, int D, bool BNN = false>
 __global__ void __launch_bounds__(256)
 gemm_lp256q_kernel(gemm_args g)
 {
@@ -143,7 +148,10 @@ gemm_lp256q_kernel(gemm_args g)
         tile_coords(tl, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
         t.m0 = (int64_t)tm * BM; t.n0 = (int64_t)tn * BN; t.batch = bi;
         t.ua = static_cast<const char *>(g.a) + ((int64_t)bi * g.stride_a + t.m0 * g.lda) * ESZ;
-        t.ub = static_cast<const char *>(g.b) + ((int64_t)bi * g.stride_b + t.n0 * g.ldb) * ESZ;
+        if constexpr (BNN)   // column n0 of k-row 16 wave: this wave's pieces are blocks rows a = 4 wave .. 4 wave + 3 (k-rows 16 wave .. +15)
+            t.ub = static_cast<const char *>(g.b) + ((int64_t)bi * g.stride_b + t.n0 + (int64_t)(wave * 16) * g.ldb) * ESZ;
+        else
+            t.ub = static_cast<const char *>(g.b) + ((int64_t)bi * g.stride_b + t.n0 * g.ldb) * ESZ;
         return t;
     };
     // DMA map (gemm_lp256w4.hip): a unit is 32 pieces of 1 KiB (8 rows); this wave fills pieces wave*8 + j;
@@ -157,10 +165,14 @@ gemm_lp256q_kernel(gemm_args g)
         voff[j] = (uint32_t)(r * g.lda * ESZ + q * 16);
     }
     const int dst_piece = wave * 8 * 1024;
+    // BNN: lane -> row (lane%16)/4 of block lane/16 of the piece, 16-byte chunk lane%4 (gemm_lp256w4.hip); piece j adds the
+    // wave-uniform (j/2) * 4 k-rows + (j%2) * 256 bytes
+    const uint32_t voff_nn = BNN ? (uint32_t)(((lane & 15) >> 2) * g.ldb * ESZ + (lane >> 4) * 64 + (lane & 3) * 16) : 0u;
+    const int64_t ldb4 = (int64_t)4 * g.ldb * ESZ;          // bytes between block rows (4 k-rows) of row-major B
 
     const int f = (l31 >> 1) & 7;
     const int rowoff_a = (wm * 128 + l31) * ROW_BYTES;
-    const int rowoff_b = (wn * 128 + l31) * ROW_BYTES;
+    const int rowoff_b = BNN ? wn * 4 * 256 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8 : (wn * 128 + l31) * ROW_BYTES;
 
     f32x16 acc[4][4];            // never zeroed: the first k-step of a tile accumulates into a literal zero operand
     frag fa[2][4], fb[2][4];
@@ -169,13 +181,24 @@ gemm_lp256q_kernel(gemm_args g)
 
     auto read_one = [&](auto buf, auto idx, const char *pa, const char *pb) {
         constexpr int BUF = decltype(buf)::value, R = decltype(idx)::value;
-        if (R == 0) fb[BUF][0] = *reinterpret_cast<const frag *>(pb);
-        else if (R <= 4) fa[BUF][R - 1] = *reinterpret_cast<const frag *>(pa + (R - 1) * 32 * ROW_BYTES);
+        if constexpr (R >= 1 && R <= 4) fa[BUF][R - 1] = *reinterpret_cast<const frag *>(pa + (R - 1) * 32 * ROW_BYTES);
+        else if constexpr (BNN) {
+            constexpr int JB = (R == 0) ? 0 : R - 4;           // column block JB: k 0..3 from block row a, k 4..7 from a + 1 (2 KiB on)
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const auto q = (__attribute__((address_space(3))) s16x4 *)(pb + JB * 256);
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(q);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(q + 256);
+            fb[BUF][JB] = __builtin_bit_cast(frag, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        } else if constexpr (R == 0) fb[BUF][0] = *reinterpret_cast<const frag *>(pb);
         else fb[BUF][R - 4] = *reinterpret_cast<const frag *>(pb + (R - 4) * 32 * ROW_BYTES);
     };
     auto dma_one = [&](auto is_b, auto jj, int64_t koff, char *base) {
         constexpr int J = decltype(jj)::value;
-        glds16_s<J * 1024>((decltype(is_b)::value ? iss.ub : iss.ua) + koff, voff[J], lds_addr_of(base));
+        if constexpr (BNN && decltype(is_b)::value)   // koff = K-tile * 128 bytes along K = K-tile * 64 k-rows of ldb elements here
+            glds16_s<J * 1024>(iss.ub + koff * g.ldb + (J >> 1) * ldb4 + (J & 1) * 256, voff_nn, lds_addr_of(base));
+        else
+            glds16_s<J * 1024>((decltype(is_b)::value ? iss.ub : iss.ua) + koff, voff[J], lds_addr_of(base));
     };
     auto mfma_one = [&](auto buf, auto idx, auto first) {
         constexpr int BUF = decltype(buf)::value, I = decltype(idx)::value & 3, J = decltype(idx)::value >> 2;
@@ -374,7 +397,7 @@ gemm_lp256q_kernel(gemm_args g)
     __builtin_amdgcn_sched_barrier(0);
     {
         const int x = (h ^ f) << 4;
-        const char *rd_a = smem + rowoff_a + x, *rd_b = smem + UNIT_BYTES + rowoff_b + x;
+        const char *rd_a = smem + rowoff_a + x, *rd_b = smem + UNIT_BYTES + rowoff_b + (BNN ? h * 4096 : x);
         read_one(IC<0>{}, IC<0>{}, rd_a, rd_b); read_one(IC<0>{}, IC<1>{}, rd_a, rd_b);
         read_one(IC<0>{}, IC<2>{}, rd_a, rd_b); read_one(IC<0>{}, IC<3>{}, rd_a, rd_b);
         read_one(IC<0>{}, IC<4>{}, rd_a, rd_b); read_one(IC<0>{}, IC<5>{}, rd_a, rd_b);
@@ -386,6 +409,8 @@ gemm_lp256q_kernel(gemm_args g)
     int sb = UNIT_BYTES;                 // ... and of its B unit; the ring runs on across output tiles
     auto adv = [](int x, int n) { x += n * UNIT_BYTES; return x >= LDS_BYTES ? x - LDS_BYTES : x; };
     const int x1 = ((2 + h) ^ f) << 4, x2 = ((4 + h) ^ f) << 4, x3 = ((6 + h) ^ f) << 4, x0 = (h ^ f) << 4;
+    // B fragment offsets per k-step: the same chunks as A for [N][K]; block rows a = 4s + 2h (8 blocks of 256 B each) for row-major B
+    const int y0 = BNN ? h * 4096 : x0, y1 = BNN ? 8192 + h * 4096 : x1, y2 = BNN ? 16384 + h * 4096 : x2, y3 = BNN ? 24576 + h * 4096 : x3;
 
     char *__restrict__ C = static_cast<char *>(g.c);
     uint32_t Lnext = 0;
@@ -413,14 +438,14 @@ gemm_lp256q_kernel(gemm_args g)
         const int64_t dma_koff = (int64_t)min(t + 2 - kbase, nk - 1) * ROW_BYTES;   /* clamp: only without a next tile */ \
         const char *rd_a, *rd_b;                                                                            \
         char *dma_base;                                                                                     \
-        rd_a = smem + sa + rowoff_a + x1; rd_b = smem + sb + rowoff_b + x1; dma_base = smem + s4 + dst_piece; \
+        rd_a = smem + sa + rowoff_a + x1; rd_b = smem + sb + rowoff_b + y1; dma_base = smem + s4 + dst_piece; \
         /* the segment whose first row this K-tile stores is transposed between the MFMAs of k-step 2 */  \
         constexpr int n0_ = ((G) >= 0 ? (G) : 0) * D;                                                       \
         constexpr int tseg_ = (Q_SLICED && (G) >= 0 && n0_ % 4 == 0) ? (D == 8 ? 2 : n0_ / 4) : -1;         \
         Q_STEP_BODY(0, 1, 0x00FFu, 0xAA00u, 0, 0, FIRST, 0, -1)                                              \
-        rd_a = smem + sa + rowoff_a + x2; rd_b = smem + sb + rowoff_b + x2;                                 \
+        rd_a = smem + sa + rowoff_a + x2; rd_b = smem + sb + rowoff_b + y2;                                 \
         Q_STEP_BODY(1, 0, 0x00FFu, 0xAA00u, 0, 4, 0, 0, -1)                                                  \
-        rd_a = smem + sa + rowoff_a + x3; rd_b = smem + sb + rowoff_b + x3;                                 \
+        rd_a = smem + sa + rowoff_a + x3; rd_b = smem + sb + rowoff_b + y3;                                 \
         Q_STEP_BODY(0, 1, 0x00FFu, 0x0000u, 0, 0, 0, 0, tseg_)                                               \
         if constexpr (Q_STORE_AT == 2 && (G) >= 0) { store_group(IC<((G) >= 0 ? (G) : 0)>{}, rb_base); __builtin_amdgcn_sched_barrier(0); } \
         if constexpr (Q_STORE_AT == 2) { if constexpr ((G) >= 0) WAIT_VMCNT(8 + D); else WAIT_VMCNT(((FIRST) && (WAITN) == 16) ? 16 : 8); }   \
@@ -429,7 +454,7 @@ gemm_lp256q_kernel(gemm_args g)
         WAIT_LGKM0();                    /* my reads of this K-tile are complete */                          \
         __builtin_amdgcn_s_barrier();    /* BAR_t */                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
-        rd_a = smem + sa1 + rowoff_a + x0; rd_b = smem + sb1 + rowoff_b + x0; dma_base = smem + s5 + dst_piece; \
+        rd_a = smem + sa1 + rowoff_a + x0; rd_b = smem + sb1 + rowoff_b + y0; dma_base = smem + s5 + dst_piece; \
         if constexpr (LASTK) stage_off = sb + wave * 8192 + (int)opaque((uint32_t)(l31 * 256 + 8 * h));   /* B unit of this K-tile: dead since BAR_t */ \
         Q_STEP_BODY(1, 0, 0x5555u, 0xAAAAu, 1, 0, 0, LASTK, -1)                                              \
         if constexpr (LASTK) { drain_one(IC<14>{}); drain_one(IC<15>{}); __builtin_amdgcn_sched_barrier(0); } \
@@ -534,13 +559,13 @@ gemm_lp256q_kernel(gemm_args g)
     WAIT_VMCNT(0);                       // drain the clamped tail DMA (and the last stores) before the workgroup retires
 }
 
-template <int DT, int D>
+template <int DT, int D, bool BNN>
 void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch)
 {
-    lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_lp256q_kernel<DT, D>), LDS_BYTES);
+    lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_lp256q_kernel<DT, D, BNN>), LDS_BYTES);
     const uint32_t total = g.tiles_m * g.tiles_n * batch;
     const uint32_t grid = std::min<uint32_t>(total, ctx->props.num_streaming_multiprocessors);   // one workgroup per CU (LDS admits no more)
-    hipLaunchKernelGGL((gemm_lp256q_kernel<DT, D>), dim3(grid), dim3(256), LDS_BYTES, s, g);
+    hipLaunchKernelGGL((gemm_lp256q_kernel<DT, D, BNN>), dim3(grid), dim3(256), LDS_BYTES, s, g);
 }
 
 int drip_for(int64_t nk)                 // fewest stores per K-tile whose drip phase (K-tiles 1 .. 24 / D) fits: nk >= 24 / D + 3
@@ -559,7 +584,7 @@ bool gemm_lp256q_supports(const mi355_gemm_desc &d, const void *a, const void *b
     if (d.dtype_c != d.dtype_ab) return false;                     // (f32 C would need 256 held registers: gemm_lp256p.hip)
     if (!gemm_lp256p_supports(d, a, b, c)) return false;           // full tiles, K-contiguous 16-byte aligned operands, ...
     if (drip_for(d.k / 64) == 0) return false;
-    if (d.lda != d.ldb) return false;                              // one set of per-lane DMA offsets for both operands
+    if (d.trans_b && d.lda != d.ldb) return false;                 // [N][K] B: one set of per-lane DMA offsets for both operands
     if ((int64_t)32 * d.ldc * 2 >= (1ll << 32)) return false;      // per-lane store offsets are 32-bit
     return true;
 }
@@ -581,7 +606,8 @@ int32_t launch_gemm_lp256q(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc 
     const int drip = drip_for(d.k / 64);
     const bool bf = d.dtype_ab == MI355_DTYPE_BF16;
 #define Q_LAUNCH(DD)                                                                              \
-    if (bf) launch<MI355_DTYPE_BF16, DD>(ctx, s, g, batch); else launch<MI355_DTYPE_F16, DD>(ctx, s, g, batch);
+    if (d.trans_b) { if (bf) launch<MI355_DTYPE_BF16, DD, false>(ctx, s, g, batch); else launch<MI355_DTYPE_F16, DD, false>(ctx, s, g, batch); } \
+    else { if (bf) launch<MI355_DTYPE_BF16, DD, true>(ctx, s, g, batch); else launch<MI355_DTYPE_F16, DD, true>(ctx, s, g, batch); }
     if (drip == 1) { Q_LAUNCH(1) } else if (drip == 2) { Q_LAUNCH(2) } else if (drip == 4) { Q_LAUNCH(4) } else { Q_LAUNCH(8) }
 #undef Q_LAUNCH
     check_launch(ctx, "mi355_gemm(lp256q)");

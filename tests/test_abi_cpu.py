@@ -106,7 +106,9 @@ def test_hot_gemm_kernels_do_not_spill_and_pad_their_asm_hazards():
     # gemm_lp256q.hip holds a finished tile in 96 registers beside the K loop: the compiler parks a few SCALAR registers in
     # the lanes of a vector register (v_writelane / v_readlane, outside the K-tile bodies) -- no memory traffic, tolerated;
     # a vector-register spill (scratch memory, and an s_waitcnt vmcnt(0) per reload that drains the LDS-DMA stream) never is
-    bad = [r for r in rows if r[3] or (r[2] and "lp256q" not in r[1]) or r[2] > 32]
+    # (round 3: its row-major-B instantiations carry two more 64-bit scalars -- 36-38 parked registers; the K-tile bodies hold
+    # the same four v_readlane as the [N][K] ones)
+    bad = [r for r in rows if r[3] or (r[2] and "lp256q" not in r[1]) or r[2] > 40]
     assert not bad, bad
     assert not any(hazards.values()), {k: v for k, v in hazards.items() if v}
 
