@@ -482,10 +482,23 @@ def test_row_major_b_16bit_is_staged_natively_by_the_256_tile_kernel(client, ora
 
 
 @pytest.mark.parametrize("dtype", [ElemType.BF16, ElemType.F16])
-def test_row_major_b_gives_the_bits_of_the_k_contiguous_form(client, oracle, dtype):
-    """Same tile, same k order inside every MFMA, same K-tile order: the row-major-B instantiation must reproduce the
-    [N][K] one bit for bit (f32 C), forced on the 256x256 kernel at a size with edge tiles and a batch with a broadcast B."""
-    m, n, k, batch = 520, 776, 448, 3
+@pytest.mark.parametrize("algo,m,n,k,batch,out16", [
+    ("lp256w4", 520, 776, 448, 3, False),      # edge tiles, broadcast B
+    ("lp256w4", 512, 768, 64, 2, True),        # a single K-tile, 16-bit C
+    ("lp256p", 512, 768, 448, 3, False),       # persistent form: the K-tile stream runs across tiles
+    ("lp256p", 768, 512, 128, 5, True),
+    ("lp256q", 512, 768, 448, 3, True),        # dripped stores, 8 per K-tile
+    ("lp256q", 768, 768, 1024, 2, True),       # ... 2 per K-tile
+    ("lp256q", 512, 512, 2048, 6, True),       # ... 1 per K-tile (the C5 form)
+    ("lp128", 520, 776, 448, 1, False),        # 4-stage ring + loader waves (one workgroup per CU at most), edge tiles
+    ("lp128", 2048, 2304, 320, 2, True),       # two-stage form + loader waves
+    ("lp128", 4096, 4104, 64, 1, True),        # single-stage form (four workgroups per CU)
+    ("lp128", 136, 264, 8192, 1, False),       # split-K slices
+])
+def test_row_major_b_gives_the_bits_of_the_k_contiguous_form(client, oracle, dtype, algo, m, n, k, batch, out16):
+    """Same tile, same k order inside every MFMA, same K-tile order: every row-major-B instantiation must reproduce its
+    [N][K] twin bit for bit -- forced per kernel, so that each form of each kernel is covered (the [N][K] twins are held
+    to the f64 oracle by the tests above); B is one matrix broadcast over the batch."""
     a_host = oracle.fill_uniform(batch * m * k, 61, -1.0, 1.0)
     b_host = oracle.fill_uniform(k * n, 62, -1.0, 1.0).reshape(k, n)
     conv = oracle.to_bf16 if dtype == ElemType.BF16 else oracle.to_f16
@@ -493,12 +506,27 @@ def test_row_major_b_gives_the_bits_of_the_k_contiguous_form(client, oracle, dty
     b_kn = TensorHandle.from_numpy(client, conv(b_host), dtype)
     b_nk = TensorHandle.from_numpy(client, conv(np.ascontiguousarray(b_host.T)), dtype)
     a_t = TensorHandle.new(a.handle, (batch, m, k), (m * k, k, 1), dtype)
+    odt = dtype if out16 else ElemType.F32
     outs = []
     for handle, strides in ((b_kn, (0, n, 1)), (b_nk, (0, 1, k))):
-        c = TensorHandle.new_contiguous((batch, m, n), client.empty(batch * m * n * 4), ElemType.F32)
-        ops.matmul(client, a_t, TensorHandle.new(handle.handle, (batch, k, n), strides, dtype), c, algo=N.GEMM_ALGO_LP_256W4)
+        c = TensorHandle.new_contiguous((batch, m, n), client.empty(batch * m * n * odt.size()), odt)
+        ops.matmul(client, a_t, TensorHandle.new(handle.handle, (batch, k, n), strides, dtype), c, algo=ALGOS[algo])
         outs.append(c.to_numpy(client))
     assert np.array_equal(outs[0], outs[1])
+    # and one matrix against the oracle directly, so that the pair cannot be wrong together
+    A = (oracle.from_bf16(conv(a_host[: m * k])) if dtype == ElemType.BF16 else oracle.from_f16(conv(a_host[: m * k]))).reshape(m, k)[:64].astype(np.float64)
+    Bv = (oracle.from_bf16(conv(b_host)) if dtype == ElemType.BF16 else oracle.from_f16(conv(b_host))).reshape(k, n).astype(np.float64)
+    got = _decode(oracle, outs[0].reshape(batch, m, n)[0][:64], odt)
+    tol = REL * (np.abs(A) @ np.abs(Bv)) + (0 if not out16 else np.abs(A @ Bv) * 2.0 ** (-7 if dtype == ElemType.BF16 else -10))
+    assert np.all(np.abs(got - A @ Bv) <= tol + 1e-30)
+
+
+@pytest.mark.parametrize("m,n,k", [(1024, 1024, 1024), (2048, 2048, 2048), (200, 4096, 512), (65, 8200, 256)])
+def test_row_major_b_mid_size_shapes_are_native_on_the_128_tile_kernel(client, oracle, m, n, k):
+    """Below one round of 256x256 tiles AUTO lands on the 128x128 kernel, which stages row-major B itself from 65 rows up."""
+    d = _nn_desc(m, n, k, ElemType.BF16, ElemType.BF16)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_128 and ops.gemm_relayout_plan(client, d) == (False, False)
+    run_case(client, oracle, m, n, k, ElemType.BF16, ElemType.BF16, False, ALGOS["auto"])
 
 
 def test_row_major_b_refusals_of_the_tile_kernel(client, oracle):
