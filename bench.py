@@ -386,7 +386,7 @@ def main():
         "config": {"workload": f"{S}x{S}x{S} bf16 GEMM, f32 accumulate, bf16 C (BASELINE config C3), one per GPU",
                    "layout": "A[M,K] row-major; B stored [N][K] (Out = Lhs*Rhs^T, the cmma tests' ColMajor-B form)",
                    "operands": "uniform[-1,1) counter RNG seed 0x5EEDC0BE, generated in HBM",
-                   "kernel": {2: "f32_mfma", 3: "lp128", 4: "lp256", 5: "lp256w4", 6: "lp256p", 7: "lp256q", 8: "skinny", 9: "stream64", 1: "generic"}.get(sel.value, str(sel.value)),
+                   "kernel": {2: "f32_mfma", 3: "lp128", 4: "lp256", 5: "lp256w4", 6: "lp256p", 7: "lp256q", 8: "skinny", 9: "stream64", 10: "lp256x128", 1: "generic"}.get(sel.value, str(sel.value)),
                    "parallelism": f"batch-sharded x{world}, no data-path collective",
                    "plateau_warmup_steps": plateau_steps},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -779,7 +779,7 @@ def main():
             out = {}
             shapes = [(8192, 8192, 64, 1), (64, 8192, 8192, 1), (8192, 64, 8192, 1), (1, 8192, 8192, 1), (16, 8192, 8192, 1), (16, 28672, 8192, 1),
                       (64, 28672, 8192, 1), (128, 28672, 8192, 1), (4096, 4096, 4096, 1), (6144, 6144, 6144, 1), (4608, 4096, 8192, 1),
-                      (2048, 2048, 2048, 1),
+                      (2048, 2048, 2048, 1), (4096, 2048, 4096, 1),
                       # the reference's default rhs layout (row-major [K][N], TensorHandle::new_contiguous): staged natively, no re-layout
                       (8192, 8192, 8192, 0), (4096, 4096, 4096, 0), (2048, 2048, 2048, 0)]
             for (m, n, k, tb) in shapes:

@@ -59,6 +59,7 @@ GEMM_ALGO_AUTO, GEMM_ALGO_GENERIC, GEMM_ALGO_F32_MFMA, GEMM_ALGO_LP_128, GEMM_AL
 GEMM_ALGO_LP_256Q = 7
 GEMM_ALGO_SKINNY = 8
 GEMM_ALGO_STREAM64 = 9
+GEMM_ALGO_LP_256X128 = 10
 UNIQUE_ID_BYTES = 128
 
 

@@ -101,6 +101,15 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
     // at most 128 rows (or columns) over many tiles: a 256-row tile multiplies at least half zeros and streams no faster --
     // 64 x 128256 x 4096: 192 us on the 128x128 kernel against 222
     if (mid && std::min(d.m, d.n) <= 128) return MI355_GEMM_ALGO_LP_128;
+    // More than one 128x128 tile per CU but at most one 256x128 tile per CU, and a long K: the 256 x 128 form of the same
+    // kernel (gemm_lp128.hip, MI = 4) -- 0.75 x the L2 -> LDS bytes per FLOP, which is what the two co-resident 128x128
+    // workgroups per CU are bound by.  Interleaved, cold operands (profiles/r03_tile_256x128_sweep.txt, 50 shapes): K >= 3072
+    // +7 ... +24 % (4096 x 2048 x 4096 72.1 -> 62.2 us, 2560^2 x 4096 67.1 -> 56.4, 4096 x 1536 x 4096 68.5 -> 55.1), K = 2048 a
+    // tie, K = 1024 -3 ... -7 %; with at most one 128x128 tile per CU it loses (2048^3: 27.5 us against 19.0 -- half the CUs).
+    {
+        const int64_t t128 = ((d.m + 127) / 128) * ((d.n + 127) / 128) * d.batch, tall = ((d.m + 255) / 256) * ((d.n + 127) / 128) * d.batch;
+        if (mid && t128 > 256 && tall <= 256 && d.k >= 2560 && gemm_lp256x128_supports(d, a, b, c)) return MI355_GEMM_ALGO_LP_256X128;
+    }
     if (big || big4) {
         // 256x256 tiles once the 128x128 kernel would need more than its two co-resident workgroups per CU (512 tiles of
         // 128^2 = 128 of 256^2).  Measured (tools/dev/mid_shapes.py): 96-128 tiles a tie, 144-160 tiles +45...55 % for the
@@ -339,6 +348,7 @@ MI355_API int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_ge
     case MI355_GEMM_ALGO_LP_256Q: return launch_gemm_lp256q(ctx, s, d, a, b, c);
     case MI355_GEMM_ALGO_SKINNY: return launch_gemm_skinny(ctx, s, d, a, b, c);
     case MI355_GEMM_ALGO_STREAM64: return launch_gemm_stream64(ctx, s, d, a, b, c);
+    case MI355_GEMM_ALGO_LP_256X128: return launch_gemm_lp256x128(ctx, s, d, a, b, c);
     default: return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_gemm: unknown algo %d", algo);
     }
 }

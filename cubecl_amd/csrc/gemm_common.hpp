@@ -117,6 +117,8 @@ __device__ __forceinline__ uint32_t f32x2_to_lp(float lo, float hi)
 int32_t launch_gemm_generic(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 int32_t launch_gemm_f32_mfma(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
+int32_t launch_gemm_lp256x128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
+bool gemm_lp256x128_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 int32_t launch_gemm_lp256(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 int32_t launch_gemm_lp256w4(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c,
                             const void *c_in = nullptr);

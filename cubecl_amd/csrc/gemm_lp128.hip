@@ -33,7 +33,18 @@ namespace {
 
 constexpr int BM = 128, BN = 128;
 constexpr int ROW_BYTES = 128;                 // one K-tile row = one 128-byte line: 64 x 16-bit or 128 x fp8 k-values
-constexpr int TILE_BYTES = BM * ROW_BYTES;     // 16 KiB per operand per stage
+constexpr int TILE_BYTES = BM * ROW_BYTES;     // 16 KiB per operand per stage (the B tile always; the A tile for MI = 2)
+// MI = 32-row blocks per wave along M.  2: the 128 x 128 tile (waves 2 x 2, 64 x 64 each).  4 (round 3): a 256 x 128 tile
+// (waves 2 x 2, 128 x 64 each, 128 accumulators) -- 48 KiB per K-tile for twice the FLOPs of a 128 x 128 tile, i.e. 0.75 x
+// the L2 -> LDS bytes per FLOP, which is what the 128 x 128 kernel is bound by on mid-size shapes
+// (profiles/r02_lp128_mid_size_bound.md: 42-46 B/clk per CU of a 64 B/clk path with and without the matrix pipe running).
+// Three-stage ring (144 KiB) + loader waves, one workgroup per CU; 16-bit operands only (fp8 fragments are twice as wide).
+template <int MI> struct geom {
+    static constexpr int BMK = 64 * MI;                        // tile rows
+    static constexpr int A_BYTES = BMK * ROW_BYTES;            // A tile per stage
+    static constexpr int STAGE = A_BYTES + TILE_BYTES;         // A + B per stage
+};
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int DT> struct lp;
 template <> struct lp<MI355_DTYPE_BF16> {
@@ -99,13 +110,16 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void *p)
 // (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"); at eight pieces per wave and K-tile that is more than the 512 cycles
 // the K-tile's 16 MFMAs take, so a wave that does both starves its matrix pipe.  The loader waves own `vmcnt`; the
 // multiplying waves see the ring only through the one s_barrier per K-tile.
-template <int DT, int DT_C, int NS = 2, bool SPEC = false, bool BNN = false>
+template <int DT, int DT_C, int NS = 2, bool SPEC = false, bool BNN = false, int MI = 2>
 __global__ void __launch_bounds__(SPEC ? 512 : 256,
                                   // waves per SIMD the register budget must allow (fp8 fragments are twice as wide: three, not four)
                                   NS == 1 ? ((DT == MI355_DTYPE_F8E4M3 || DT == MI355_DTYPE_F8E5M2) ? 3 : 4) : NS == 2 ? (SPEC ? 4 : 2) : SPEC ? 2 : 1)
 gemm_lp128_kernel(gemm_args g)
 {
-    static_assert(!SPEC || NS == 4 || NS == 2, "loader waves are written for the 2-stage and the 4-stage ring");
+    static_assert(!SPEC || NS == 4 || NS == 3 || NS == 2, "loader waves are written for the 2-stage ring and the deep rings");
+    static_assert(MI == 2 || (MI == 4 && NS == 3 && DT != MI355_DTYPE_F8E4M3 && DT != MI355_DTYPE_F8E5M2), "256 x 128 tile: three-stage ring, 16-bit operands");
+    constexpr int BMK = geom<MI>::BMK, A_BYTES = geom<MI>::A_BYTES, STG = geom<MI>::STAGE;
+    constexpr int PIECES = 2 * MI + 4;           // LDS-DMA instructions per wave and K-tile (A: BMK / 32, B: 4)
     static_assert(!BNN || DT == MI355_DTYPE_BF16 || DT == MI355_DTYPE_F16, "row-major B: 16-bit operands");
     // [stage][operand][16 KiB]; one array only (a second __shared__ object de-pipelines LDS-DMA
     // loops: guide section 5, ".s-level traps" (a))
@@ -122,7 +136,7 @@ gemm_lp128_kernel(gemm_args g)
 
     uint32_t tm, tn, batch_u;
     batched_tile_coords(g.tiles_m, g.tiles_n, g.group_m, tm, tn, batch_u);
-    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    const int64_t m0 = (int64_t)tm * BMK, n0 = (int64_t)tn * BN;
     const int64_t batch = batch_u;
     constexpr bool F8 = DT == MI355_DTYPE_F8E4M3 || DT == MI355_DTYPE_F8E5M2;
     constexpr int ESZ = F8 ? 1 : 2;
@@ -134,12 +148,17 @@ gemm_lp128_kernel(gemm_args g)
     // ---- DMA map: wave w, instruction j fills rows (j*4+w)*8 .. +7 of the tile ----------------
     const char *ubase_a = A + m0 * g.lda * ESZ;                                   // uniform: first row of the tile
     const char *ubase_b = BNN ? B + n0 * ESZ : B + n0 * g.ldb * ESZ;              // ... first column, for row-major B
-    uint32_t va[4], vb[4];                                  // per-lane byte offsets from those (rows clamped at the edges)
+    uint32_t va[2 * MI], vb[4];                             // per-lane byte offsets from those (rows clamped at the edges)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 2 * MI; ++j) {
         const int r = (j * 4 + wave) * 8 + (lane >> 3);    // tile row this lane fills
         const int q = (lane & 7) ^ ((r >> 1) & 7);          // logical chunk fetched into physical chunk lane&7
         va[j] = (uint32_t)(min((int64_t)r, g.m - 1 - m0) * g.lda * ESZ + q * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (j * 4 + wave) * 8 + (lane >> 3);
+        const int q = (lane & 7) ^ ((r >> 1) & 7);
         if constexpr (BNN) {
             // piece p = j*4 + wave is block row a = p (k-rows 4p .. 4p+3): lane -> block lane/16, row (lane%16)/4 of it,
             // 16-byte chunk lane%4 = columns 32 (lane/16) + 8 (lane%4) .. +7; columns past N re-read the last valid 16 bytes
@@ -152,18 +171,21 @@ gemm_lp128_kernel(gemm_args g)
     const int rbn = BNN ? wn * 2 * 256 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8 : 0;
 
     // ---- fragment read offsets (bytes inside one operand tile) --------------------------------
-    int ra[2], rb[2], fa[2], fb[2];
+    int ra[MI], rb[2], fa[MI], fb[2];
+#pragma unroll
+    for (int t = 0; t < MI; ++t) {
+        const int rowa = wm * 32 * MI + t * 32 + l31;
+        ra[t] = rowa * ROW_BYTES; fa[t] = (rowa >> 1) & 7;
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int rowa = wm * 64 + t * 32 + l31;
         const int rowb = wn * 64 + t * 32 + l31;
-        ra[t] = rowa * ROW_BYTES; fa[t] = (rowa >> 1) & 7;
         rb[t] = rowb * ROW_BYTES; fb[t] = (rowb >> 1) & 7;
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -192,17 +214,17 @@ gemm_lp128_kernel(gemm_args g)
         if ((LP128_ABL & 1) && kt_rel >= NS) return;
         int kt = kt0 + kt_rel;
         if (LP128_KSTAG) { kt = kt_rel + kshift; kt = kt0 + (kt >= nk ? kt - nk : kt); }
-        char *la = smem + buf * 2 * TILE_BYTES;
-        char *lb = la + TILE_BYTES;
+        char *la = smem + buf * STG;
+        char *lb = la + A_BYTES;
         const int64_t koff = (int64_t)kt * ROW_BYTES;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 2 * MI; ++j) {
             glds16_s(ubase_a + koff, va[j], lds_addr_of(la + (j * 4 + wave) * 1024));
-            glds16_s(ubase_b + (BNN ? koff * g.ldb : koff), vb[j], lds_addr_of(lb + (j * 4 + wave) * 1024));   // (row-major B: a K-tile is 64 rows of ldb elements)
+            if (j < 4) glds16_s(ubase_b + (BNN ? koff * g.ldb : koff), vb[j & 3], lds_addr_of(lb + (j * 4 + wave) * 1024));   // (row-major B: a K-tile is 64 rows of ldb elements)
         }
     };
 
-    frag af[2][2], bf[2][2];                     // [register buffer][tile]
+    frag af[2][MI], bf[2][2];                    // [register buffer][tile]
     bool first_reads = true;
     auto reads = [&](auto buf, const char *la, const char *lb, int kk) {
         constexpr int B = decltype(buf)::value;
@@ -211,7 +233,7 @@ gemm_lp128_kernel(gemm_args g)
             // k-step kk, lane-half h: logical chunks 4kk + 2h and 4kk + 2h + 1 (the second sits in physical chunk ^ 1)
             const int q = kk * 4 + 2 * h;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < MI; ++i) {
                 const char *p0 = la + ra[i] + ((q ^ fa[i]) << 4);
                 const u32x4 lo = *reinterpret_cast<const u32x4 *>(p0);
                 const u32x4 hi = *reinterpret_cast<const u32x4 *>(la + ra[i] + (((q ^ fa[i]) ^ 1) << 4));
@@ -226,7 +248,7 @@ gemm_lp128_kernel(gemm_args g)
         } else {
             const int q = kk * 2 + h;            // logical 16-byte chunk: 8 k-values
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[B][i] = *reinterpret_cast<const frag *>(la + ra[i] + ((q ^ fa[i]) << 4));
+            for (int i = 0; i < MI; ++i) af[B][i] = *reinterpret_cast<const frag *>(la + ra[i] + ((q ^ fa[i]) << 4));
             if constexpr (BNN) {
                 // k-step kk, lane-half h: k 0..3 of its eight from block row a = 4kk + 2h, k 4..7 from a + 1 (4 blocks = 1 KiB on)
                 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -250,7 +272,7 @@ gemm_lp128_kernel(gemm_args g)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) acc[i][j] = lp<DT>::mfma(bf[B][j], af[B][i], acc[i][j]);
+            for (int i = 0; i < MI; ++i) acc[i][j] = lp<DT>::mfma(bf[B][j], af[B][i], acc[i][j]);
     };
     typedef std::integral_constant<int, 0> B0;
     typedef std::integral_constant<int, 1> B1;
@@ -263,7 +285,7 @@ gemm_lp128_kernel(gemm_args g)
             stage(0, kt);
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
-            const char *la = smem, *lb = smem + TILE_BYTES;
+            const char *la = smem, *lb = smem + A_BYTES;
             reads(B0{}, la, lb, 0);
             reads(B1{}, la, lb, 1); mfmas(B0{});
             if constexpr (NSTEP == 4) {
@@ -292,8 +314,8 @@ gemm_lp128_kernel(gemm_args g)
         __builtin_amdgcn_s_waitcnt(0xC07F);                     // see the 4-stage form: keeps the loop's LDS waits counted
         __builtin_amdgcn_s_barrier();
         for (int kt = 0; kt < nk; ++kt) {
-            const char *la = smem + (kt & 1) * 2 * TILE_BYTES;
-            const char *lb = la + TILE_BYTES;
+            const char *la = smem + (kt & 1) * STG;
+            const char *lb = la + A_BYTES;
             reads(B0{}, la, lb, 0);
             reads(B1{}, la, lb, 1); mfmas(B0{});
             if constexpr (NSTEP == 4) {
@@ -312,8 +334,8 @@ gemm_lp128_kernel(gemm_args g)
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
             if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-            const char *la = smem + cur * 2 * TILE_BYTES;
-            const char *lb = la + TILE_BYTES;
+            const char *la = smem + cur * STG;
+            const char *lb = la + A_BYTES;
             // fragments double-buffered in registers: the reads of k-step kk+1 go out before the MFMAs of k-step kk
             // (+2...5 % even with the co-resident workgroup filling gaps)
             reads(B0{}, la, lb, 0);
@@ -331,30 +353,40 @@ gemm_lp128_kernel(gemm_args g)
         // Deep ring (NS stages, K-tiles fetched NS-1 ahead) with the fragments double-buffered in registers: the reads
         // of k-step kk+1 are issued before the MFMAs of k-step kk, and the hand-over to the next K-tile sits before the
         // LAST k-step, so that the next tile's first fragments are fetched under its four MFMAs (as gemm_lp256w4.hip).
-        // vmcnt is counted: 8 DMA instructions per wave and K-tile, loads complete in order.
-        static_assert(NS == 4, "the counted waits below are written for four stages");
+        // vmcnt is counted: PIECES DMA instructions per wave and K-tile, loads complete in order.  K-tiles are issued three
+        // ahead in both forms: K-tile kt+2 may still fly when K-tile kt+1 is needed.
+        //   NS = 4: K-tile kt+3 is issued after the hand-over barrier of K-tile kt into the slot of K-tile kt-1 -- the
+        //           multiplying waves may still have fragment reads of K-tile kt in the LDS queue at that barrier.
+        //   NS = 3 (256 x 128 tile; 48 KiB per stage leave room for three): K-tile kt+3 goes into the slot of K-tile kt
+        //           ITSELF, so the multiplying waves wait for their last reads of it (lgkmcnt(0)) before the barrier, as
+        //           gemm_lp256w4.hip does.  (The first form of this kernel refilled the slot of K-tile kt-1 with K-tile kt+2:
+        //           one K-tile in flight, fetch and wait serialised, ~2 000 cycles per K-tile of 1 024 MFMA cycles.)
+        static_assert(NS == 4 || NS == 3, "the counted waits below are written for three or four stages");
+        constexpr bool FULL = NS == 3;               // every slot of the ring is refilled as soon as its K-tile is consumed
+        constexpr int AHEAD = 3;                     // K-tiles issued ahead of the one being multiplied
+        static_assert(AHEAD == (FULL ? NS : NS - 1), "ring depth and issue distance");
         const bool issues = !SPEC || loader, multiplies = !SPEC || !loader;
         if (issues) {
 #pragma unroll
-            for (int p = 0; p < NS - 1; ++p)
-                if (p < nk) stage(p, p);
-            if (nk >= 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // K-tile 0 landed; tiles 1, 2 may fly
-            else if (nk == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int p = 0; p < AHEAD; ++p)
+                if (p < nk) stage(p % NS, p);
+            if (nk >= AHEAD) wait_vm<(AHEAD - 1) * PIECES>();                         // K-tile 0 landed; the other prologue tiles may fly
+            else if (nk == 2) wait_vm<PIECES>();
+            else wait_vm<0>();
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (SPEC && loader) {
             // the loader's whole K loop: wait for K-tile kt+1, meet the multiplying waves at their barrier inside K-tile kt
-            // (everybody is then past K-tile kt-1), refill that slot with K-tile kt+3
+            // (everybody is then past K-tile kt-1 -- FULL: and done reading K-tile kt), refill the freed slot with K-tile kt+3
             for (int kt = 0; kt + 1 < nk; ++kt) {
-                if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (kt + 2 < nk) wait_vm<PIECES>();
+                else wait_vm<0>();
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                if (kt + NS - 1 < nk) stage((kt + NS - 1) % NS, kt + NS - 1);
+                if (kt + AHEAD < nk) stage((kt + AHEAD) % NS, kt + AHEAD);
             }
             return;                                         // a finished wave no longer counts at the workgroup's barriers
         }
@@ -364,10 +396,10 @@ gemm_lp128_kernel(gemm_args g)
             // every LDS wait of the loop degrades to lgkmcnt(0), fresh reads included.
             __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0), vmcnt / expcnt untouched
             __builtin_amdgcn_sched_barrier(0);
-            if (nk > 0) reads(B0{}, smem, smem + TILE_BYTES, 0);
+            if (nk > 0) reads(B0{}, smem, smem + A_BYTES, 0);
             for (int kt = 0; kt < nk; ++kt) {
-                const char *la = smem + (kt % NS) * 2 * TILE_BYTES;
-                const char *lb = la + TILE_BYTES;
+                const char *la = smem + (kt % NS) * STG;
+                const char *lb = la + A_BYTES;
                 reads(B1{}, la, lb, 1); mfmas(B0{});
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (NSTEP == 4) {
@@ -379,17 +411,21 @@ gemm_lp128_kernel(gemm_args g)
                 if (kt + 1 < nk) {
                     if constexpr (!SPEC) {
                         // K-tile kt+1 landed: only tile kt+2 (issued in the previous iteration or the prologue) may still fly
-                        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (kt + 2 < nk) wait_vm<PIECES>();
+                        else wait_vm<0>();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr (FULL) {           // my reads of K-tile kt are complete: its slot is refilled right behind the barrier
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     __builtin_amdgcn_s_barrier();   // raw: __syncthreads() carries a release fence = vmcnt(0), which would drain the ring
                     __builtin_amdgcn_sched_barrier(0);
                     // everybody is past K-tile kt-1: its buffer takes K-tile kt+3
                     if constexpr (!SPEC)
-                        if (kt + NS - 1 < nk) stage((kt + NS - 1) % NS, kt + NS - 1);
-                    const char *na = smem + ((kt + 1) % NS) * 2 * TILE_BYTES;
-                    reads(B0{}, na, na + TILE_BYTES, 0);
+                        if (kt + AHEAD < nk) stage((kt + AHEAD) % NS, kt + AHEAD);
+                    const char *na = smem + ((kt + 1) % NS) * STG;
+                    reads(B0{}, na, na + A_BYTES, 0);
                 }
                 mfmas(B1{});
                 __builtin_amdgcn_sched_barrier(0);
@@ -401,7 +437,9 @@ gemm_lp128_kernel(gemm_args g)
     if (LP128_ABL & 16) {
         float t = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t += acc[0][0][r] + acc[0][1][r] + acc[1][0][r] + acc[1][1][r];
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) t += acc[i][0][r] + acc[i][1][r];
         if (t == 12345.678f) static_cast<float *>(g.c)[0] = t;
         return;
     }
@@ -425,14 +463,14 @@ gemm_lp128_kernel(gemm_args g)
         char *stage = smem + wave * STAGE;
         char *wr = stage + l31 * RS + 4 * h * CSZ;
         const char *rd = stage + (lane / LPR) * RS + (lane % LPR) * 16;
-        const int64_t row0 = m0 + wm * 64 + lane / LPR;                   // + i * 32 + it * RPI
+        const int64_t row0 = m0 + wm * 32 * MI + lane / LPR;              // + i * 32 + it * RPI
         const int64_t col0 = n0 + wn * 64 + (lane % LPR) * EPP;
         char *crow = C + (cbase + row0 * g.ldc + col0) * CSZ;
         const int64_t cstep = (int64_t)RPI * g.ldc * CSZ;
         const int ncols = (int)max((int64_t)0, min((int64_t)EPP, g.n - col0));   // valid elements of my piece
-        const bool interior = (m0 + BM <= g.m) && (n0 + BN <= g.n);       // workgroup-uniform fast path
+        const bool interior = (m0 + BMK <= g.m) && (n0 + BN <= g.n);      // workgroup-uniform fast path
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -474,8 +512,8 @@ gemm_lp128_kernel(gemm_args g)
     }
     const bool vec_ok = false;   // rows are not 16-byte aligned here
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int64_t m = m0 + wm * 64 + i * 32 + l31;
+    for (int i = 0; i < MI; ++i) {
+        const int64_t m = m0 + wm * 32 * MI + i * 32 + l31;
         if (m >= g.m) continue;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -518,15 +556,15 @@ gemm_lp128_kernel(gemm_args g)
 #ifndef LP128_SPEC
 #define LP128_SPEC 1   // dev: 0 = the 4-stage ring without loader waves
 #endif
-template <int DT, int DT_C, int NS, bool SPEC = false, bool BNN = false>
+template <int DT, int DT_C, int NS, bool SPEC = false, bool BNN = false, int MI = 2>
 void launch_ns(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch)
 {
     // operand stages, or the four per-wave epilogue scratch areas when those are larger (f32 C with one stage: 36 KiB)
     constexpr int CSZ_ = DT_C == MI355_DTYPE_F32 ? 4 : 2;
     constexpr int EPI = 4 * ((32 * (64 * CSZ_ + 16) + 1023) & ~1023);
-    constexpr int LDS = NS * 2 * TILE_BYTES > EPI ? NS * 2 * TILE_BYTES : EPI;
-    lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_lp128_kernel<DT, DT_C, NS, SPEC, BNN>), LDS);
-    hipLaunchKernelGGL((gemm_lp128_kernel<DT, DT_C, NS, SPEC, BNN>), dim3(g.tiles_m * g.tiles_n, batch, g.split_k > 1 ? g.split_k : 1),
+    constexpr int LDS = NS * geom<MI>::STAGE > EPI ? NS * geom<MI>::STAGE : EPI;
+    lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_lp128_kernel<DT, DT_C, NS, SPEC, BNN, MI>), LDS);
+    hipLaunchKernelGGL((gemm_lp128_kernel<DT, DT_C, NS, SPEC, BNN, MI>), dim3(g.tiles_m * g.tiles_n, batch, g.split_k > 1 ? g.split_k : 1),
                        dim3(SPEC ? 512 : 256), LDS, s, g);
 }
 
@@ -653,6 +691,39 @@ int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
         }
     }
     check_launch(ctx, "mi355_gemm(lp128)");
+    return MI355_OK;
+}
+
+// ---- the 256 x 128 tile (MI = 4): 16-bit operands, at most one round of tiles (one workgroup per CU: 144 KiB of LDS) --------
+bool gemm_lp256x128_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
+{
+    if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16) return false;
+    return gemm_lp128_supports(d, a, b, c);
+}
+
+int32_t launch_gemm_lp256x128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c)
+{
+    if (!gemm_lp256x128_supports(d, a, b, c))
+        return fail(ctx, MI355_E_UNSUPPORTED, "lp256x128 GEMM: shape/layout not supported by this kernel");
+    gemm_args g{};
+    g.a = a; g.b = b; g.c = c;
+    g.m = d.m; g.n = d.n; g.k = d.k;
+    g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc;
+    g.stride_a = d.stride_a; g.stride_b = d.stride_b; g.stride_c = d.stride_c;
+    g.tiles_m = (uint32_t)((d.m + 255) / 256);
+    g.tiles_n = (uint32_t)((d.n + BN - 1) / BN);
+    g.group_m = 4;                        // 4 x 8 tiles of 256 x 128 = the 1024 x 1024 patch an XCD's 32 workgroups share
+    g.split_k = 1;
+    g.split_c_stride = 0;
+    const uint32_t batch = (uint32_t)d.batch;
+#define TALL(DT_, DC_) { if (d.trans_b) launch_ns<DT_, DC_, 3, true, false, 4>(ctx, s, g, batch); else launch_ns<DT_, DC_, 3, true, true, 4>(ctx, s, g, batch); }
+    if (d.dtype_ab == MI355_DTYPE_BF16) {
+        if (d.dtype_c == MI355_DTYPE_F32) TALL(MI355_DTYPE_BF16, MI355_DTYPE_F32) else TALL(MI355_DTYPE_BF16, MI355_DTYPE_BF16)
+    } else {
+        if (d.dtype_c == MI355_DTYPE_F32) TALL(MI355_DTYPE_F16, MI355_DTYPE_F32) else TALL(MI355_DTYPE_F16, MI355_DTYPE_F16)
+    }
+#undef TALL
+    check_launch(ctx, "mi355_gemm(lp256x128)");
     return MI355_OK;
 }
 

@@ -383,8 +383,10 @@ enum {
                                      stores dripped into the next tile's K loop                      */
     MI355_GEMM_ALGO_SKINNY = 8,   /* bf16/f16, M <= 16 or N <= 16: the large operand streamed once from HBM,
                                      v_dot2c_f32 accumulation, no matrix core (gemm_skinny.hip)      */
-    MI355_GEMM_ALGO_STREAM64 = 9  /* bf16/f16, M <= 64 or N <= 64: 32 streamed rows x the whole K per workgroup,
+    MI355_GEMM_ALGO_STREAM64 = 9, /* bf16/f16, M <= 64 or N <= 64: 32 streamed rows x the whole K per workgroup,
                                      loader waves + MFMA, no split-K (gemm_stream64.hip)             */
+    MI355_GEMM_ALGO_LP_256X128 = 10 /* bf16/f16 256x128x64 tile (gemm_lp128.hip, MI = 4): three-stage LDS ring + loader
+                                     waves, one workgroup per CU; mid-size shapes of at most one round of such tiles */
 };
 
 int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_gemm_desc *desc,

@@ -155,6 +155,29 @@ def test_c3_bf16_8192_bf16_output_as_benched(client, oracle):
     assert np.array_equal(oracle.to_bf16(full32).reshape(S, S), got)
 
 
+def test_mid_size_4096x2048x4096_as_benched_takes_the_256x128_tile(client, oracle):
+    """bench.py's `4096x2048x4096` entry: AUTO takes the 256 x 128 form of the mid-size kernel (256 tiles, one per CU); all
+    outputs equal the 128x128 kernel's bit for bit (same k order per output) and sampled rows meet the f64 oracle."""
+    import ctypes as C
+    m, n, k = 4096, 2048, 4096
+    a = TensorHandle.uniform(client, (m, k), ElemType.BF16, SEED, 700, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (n, k), ElemType.BF16, SEED, 701, -1.0, 1.0)
+    d = _bench_desc(m, n, k, N.DTYPE_BF16, N.DTYPE_BF16)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256X128
+    outs = []
+    for algo in (N.GEMM_ALGO_AUTO, N.GEMM_ALGO_LP_128):
+        d.algo = algo
+        c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 2), ElemType.BF16)
+        client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()),
+                                              C.c_void_p(c.device_ptr())))
+        outs.append(c.to_numpy(client).reshape(m, n))
+    assert np.array_equal(outs[0], outs[1])
+    rows = np.array([0, 127, 128, 255, 256, 2047, 2048 + 129, 4095])
+    a_bits = oracle.to_bf16(oracle.fill_uniform(m * k, 700, -1.0, 1.0))
+    b_bits = oracle.to_bf16(oracle.fill_uniform(n * k, 701, -1.0, 1.0))
+    _bf16_rows_check(oracle, a_bits, b_bits, outs[0][rows], rows, k, n, case="4096x2048x4096 bf16 on the 256x128 tile, 8 sampled rows vs f64 oracle")
+
+
 def _nn_bench_desc(m, n, k, dtype_ab, dtype_c, batch=1):
     """bench.py's descriptor for the reference's default rhs layout: B row-major [K][N] (trans_b = 0)."""
     return N.GemmDesc(m=m, n=n, k=k, batch=batch, lda=k, ldb=n, ldc=n, stride_a=m * k, stride_b=n * k, stride_c=m * n,

@@ -21,7 +21,8 @@ GOLD = json.loads((Path(__file__).parent / "golden" / "reference_goldens.json").
 REL = 1e-5
 ALGOS = {"auto": N.GEMM_ALGO_AUTO, "generic": N.GEMM_ALGO_GENERIC, "f32": N.GEMM_ALGO_F32_MFMA,
          "lp128": N.GEMM_ALGO_LP_128, "lp256": N.GEMM_ALGO_LP_256, "lp256w4": N.GEMM_ALGO_LP_256W4, "lp256p": N.GEMM_ALGO_LP_256P,
-         "lp256q": N.GEMM_ALGO_LP_256Q, "skinny": N.GEMM_ALGO_SKINNY, "stream64": N.GEMM_ALGO_STREAM64}
+         "lp256q": N.GEMM_ALGO_LP_256Q, "skinny": N.GEMM_ALGO_SKINNY, "stream64": N.GEMM_ALGO_STREAM64,
+         "lp256x128": N.GEMM_ALGO_LP_256X128}
 
 
 def _to_dev(client, oracle, x, dtype):
@@ -456,6 +457,38 @@ def test_race_screen_bitwise_repeatability(client, oracle, algo):
     for _ in range(25):
         ops.matmul(client, a, bt, c, algo=ALGOS[algo])
         assert np.array_equal(c.to_numpy(client), first)
+
+
+# ---- the 256 x 128 tile (gemm_lp128.hip with four row blocks per wave, three-stage ring + loader waves; round 3) ----------
+@pytest.mark.parametrize("m,n,k,batch", [(256, 128, 64, 1),        # one tile, one K-tile
+                                          (512, 256, 128, 1),       # two K-tiles: the prologue covers the whole K
+                                          (2048, 2048, 448, 1),     # 128 tiles, seven K-tiles: the ring wraps twice
+                                          (300, 200, 192, 3),       # ragged M and N, batch
+                                          (1000, 1160, 320, 1)])    # ragged, every wave position at an edge
+@pytest.mark.parametrize("dtype,out,trans_b", [(ElemType.BF16, "f32", True), (ElemType.BF16, "same", True), (ElemType.F16, "same", True),
+                                                (ElemType.BF16, "f32", False), (ElemType.F16, "same", False)])
+def test_lp256x128_matches_the_oracle(client, oracle, m, n, k, batch, dtype, out, trans_b):
+    odt = ElemType.F32 if out == "f32" else dtype
+    ldb = None if trans_b else (n + 7) // 8 * 8
+    run_case(client, oracle, m, n, k, dtype, odt, trans_b, ALGOS["lp256x128"], batch=batch, ldb=ldb)
+
+
+def test_lp256x128_gives_the_bits_of_the_128_tile_kernel(client, oracle):
+    """Same MFMA, same k order per output, same K-tile order: the two tile heights of gemm_lp128.hip must agree bit for bit."""
+    m, n, k = 1536, 1280, 1024
+    a = TensorHandle.uniform(client, (m, k), ElemType.BF16, 0x5EEDC0BE, 81, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (n, k), ElemType.BF16, 0x5EEDC0BE, 82, -1.0, 1.0)
+    bt = TensorHandle.new(b.handle, (k, n), (1, k), ElemType.BF16)
+    outs = []
+    for algo in ("lp128", "lp256x128"):
+        c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 4), ElemType.F32)
+        ops.matmul(client, a, bt, c, algo=ALGOS[algo])
+        outs.append(c.to_numpy(client))
+    assert np.array_equal(outs[0], outs[1])
+    for _ in range(10):                                   # the counted-vmcnt ring gives the same bits on every launch
+        c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 4), ElemType.F32)
+        ops.matmul(client, a, bt, c, algo=ALGOS["lp256x128"])
+        assert np.array_equal(c.to_numpy(client), outs[1])
 
 
 # ---- row-major B (the reference's default rhs layout), staged natively by the tile kernels (round 3) --------------------
@@ -968,6 +1001,10 @@ def test_output_bound_shapes_select_the_small_tile(client):
     assert sel(8192, 64, 14336) == N.GEMM_ALGO_STREAM64                               # 1.75 MiB of small operand still streams
     assert sel(4, 2048, 4096) == sel(384, 4, 8192) == sel(3, 512, 14336) == sel(4096, 4, 14336) == N.GEMM_ALGO_SKINNY   # 3-4 rows, fewer than 192 streaming workgroups
     assert sel(8192, 4, 2048) == sel(4, 8192, 8192) == N.GEMM_ALGO_STREAM64           # ... from 192 up the streaming kernel
+    # the 256 x 128 tile: more than one 128x128 tile per CU, at most one 256 x 128 tile per CU, long K (round 3)
+    assert sel(4096, 2048, 4096) == sel(2560, 2560, 3072) == sel(2048, 2048, 8192, batch=2) == sel(4096, 1536, 8192) == N.GEMM_ALGO_LP_256X128
+    assert sel(4096, 2048, 2048) == sel(2048, 2048, 8192) == sel(3072, 2560, 1024) == N.GEMM_ALGO_LP_128   # K <= 2048 / one 128x128 tile per CU
+    assert sel(4096, 2304, 4096) == N.GEMM_ALGO_LP_256W4                              # 288 tiles of 256 x 128: two rounds -- the 256x256 tile
     assert sel(32, 512, 8192) == sel(512, 16, 8192) == N.GEMM_ALGO_STREAM64           # few workgroups are fine up to K = 8192
     assert sel(8192, 3072, 512) == N.GEMM_ALGO_LP_256Q and sel(8192, 3072, 640) == N.GEMM_ALGO_LP_256P   # 384 tiles: persistent from one round up
     assert sel(4096, 4096, 512) == N.GEMM_ALGO_LP_256W4                               # exactly one round: the plain kernel
