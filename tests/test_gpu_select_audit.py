@@ -1,0 +1,61 @@
+"""The GEMM dispatcher's thresholds, made falsifiable (review of round 2, next #7).
+
+`gemm.cpp::select` holds ~25 measured crossovers between ten kernels.  They were measured on the builder's boxes; on a box
+where one of them is wrong, the symptom used to be a slower bench entry and nothing else.  This test times AUTO against EVERY
+kernel that accepts the descriptor over a fixed grid of 40 bf16 shapes -- the bench's skinny / output-bound / mid-size / decode
+shapes among them -- interleaved, three rounds, medians, cold operands (launches rotate through operand sets larger than the
+Infinity Cache), and fails when AUTO is more than 15 % AND more than 2 us behind the best forced kernel on any shape.  The
+full table goes to gpurun_out/select_audit.txt."""
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+GRID = [
+    # the bench's entries
+    (8192, 8192, 64), (64, 8192, 8192), (8192, 64, 8192), (1, 8192, 8192), (16, 8192, 8192), (16, 28672, 8192), (64, 28672, 8192),
+    (128, 28672, 8192), (4096, 4096, 4096), (6144, 6144, 6144), (4608, 4096, 8192), (2048, 2048, 2048), (4096, 2048, 4096),
+    # few rows / columns
+    (2, 8192, 8192), (4, 8192, 8192), (4, 2048, 4096), (32, 14336, 4096), (48, 4096, 4096), (96, 8192, 4096), (8192, 128, 8192),
+    (256, 12288, 4096), (128, 14336, 4096), (3072, 4, 8192),
+    # short K over many tiles
+    (8192, 8192, 256), (16384, 8192, 128), (8192, 3072, 512), (7168, 4096, 1024), (4096, 4096, 64),
+    # mid-size: the 128x128 / 256x128 / 256x256 crossovers
+    (1024, 4096, 4096), (2048, 2048, 8192), (2560, 2560, 4096), (4096, 2048, 2048), (3072, 3072, 3072), (4096, 1536, 8192),
+    (4096, 2304, 4096), (3072, 2560, 1024),
+    # partly filled rounds of the 256x256 tile
+    (5120, 5120, 5120), (4352, 4096, 4096), (8192, 8192, 2048), (6144, 4096, 2048),
+]
+ALGOS = ["auto", "lp128", "lp256x128", "lp256w4", "lp256p", "lp256q", "stream64", "skinny"]
+
+
+def test_auto_is_within_15_percent_of_the_best_forced_kernel_on_every_shape_of_the_grid(client):
+    sys.path.insert(0, str(ROOT / "tools"))
+    sys.path.insert(0, str(ROOT))
+    import ab_algos
+    import bench
+    ev = bench.Events(client)
+    res = ab_algos.measure(client, ev, GRID, ALGOS, rounds=3, iters=10)
+    lines, behind = [], []
+    for (m, n, k), r in res.items():
+        us = {a: t for a, t in r["us"].items() if t == t}
+        best_algo, best = min(((a, t) for a, t in us.items() if a != "auto"), key=lambda x: x[1])
+        auto = us["auto"]
+        ratio = auto / best
+        flag = ratio > 1.15 and auto - best > 2.0
+        lines.append(f"{m}x{n}x{k}: AUTO -> {r['auto']:9s} {auto:8.1f} us   best forced {best_algo:9s} {best:8.1f} us   x{ratio:.3f}"
+                     + ("   <-- BEHIND" if flag else "") + "   | " + "  ".join(f"{a} {t:.1f}" for a, t in us.items() if a != "auto"))
+        if flag:
+            behind.append(lines[-1])
+    out = Path(os.environ.get("GRAFT_REPO_ROOT", ROOT)) / "gpurun_out"
+    try:
+        out.mkdir(exist_ok=True)
+        (out / "select_audit.txt").write_text("\n".join(lines) + "\n")
+    except OSError:
+        pass
+    print("\n".join(lines))
+    assert not behind, "AUTO is more than 15 % (and 2 us) behind a forced kernel:\n" + "\n".join(behind)
