@@ -66,7 +66,7 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
     // (64 x 8192 x 8192 24.4 us against 29.9, 16 x 8192 x 8192 22.3 / 26.4, 8192 x 64 x 8192 24.4 / 33.7, 32 x 8192 x 2048 7.6 / 14.8;
     // lost: 64 x 32768 x 4096 59 / 45, 64 x 4096 x 16384 38 / 33, 16 x 65536 x 1024 41 / 24).
     // three or four rows (or columns) when the streaming kernel below would not fill the chip (it runs one workgroup per 32
-    // streamed rows): the dot-product kernel's many short workgroups beat both MFMA paths (tools/dev/select_audit.py:
+    // streamed rows): the dot-product kernel's many short workgroups beat both MFMA paths (tests/test_gpu_select_audit.py, round 2:
     // 4 x 2048 x 4096 8.8 us against 10.5, 2048 x 4 x 2048 5.7 / 7.1, 384 x 4 x 8192 11.7 / 16.1, 3072 x 4 x 8192 14.6 / 21.4,
     // 2048 x 4 x 14336 21.3 / 27.8, 4096 x 4 x 14336 25.7 / 29.8); from 192 workgroups up the streaming kernel wins
     // (8192 x 4 x 2048 7.0 against 8.2-9.7, 4 x 8192 x 8192 22.0 / 24.8)
@@ -112,7 +112,7 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
     }
     if (big || big4) {
         // 256x256 tiles once the 128x128 kernel would need more than its two co-resident workgroups per CU (512 tiles of
-        // 128^2 = 128 of 256^2).  Measured (tools/dev/mid_shapes.py): 96-128 tiles a tie, 144-160 tiles +45...55 % for the
+        // 128^2 = 128 of 256^2).  Measured (tools/ab_algos.py): 96-128 tiles a tie, 144-160 tiles +45...55 % for the
         // 256x256 kernel even though it leaves 40 % of the CUs idle, 64-81 tiles +7...30 % for the 128x128 kernel.
         const int64_t tiles256 = ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch;
         if (tiles256 > 128 || !mid) return big4 ? MI355_GEMM_ALGO_LP_256W4 : MI355_GEMM_ALGO_LP_256;

@@ -86,6 +86,18 @@ impl ComputeStorage for DeviceStorage {
     }
 }
 
+/// A lane (or the whole server) going away takes its pools with it: `MemoryManagement` does not `dealloc` its pages on
+/// drop, and `mi355_ctx_destroy` only frees what was queued through `mi355_free`.  Runs while the context is still alive
+/// (`Mi355Server` declares its `ContextGuard` last).
+impl Drop for DeviceStorage {
+    fn drop(&mut self) {
+        for ptr in self.retired.drain(..).chain(self.live.drain().map(|(_, p)| p)) {
+            unsafe { mi355_free(self.ctx, ptr) };
+        }
+        unsafe { mi355_flush(self.ctx) };
+    }
+}
+
 #[derive(Debug)]
 pub struct PinnedStorage {
     ctx: *mut mi355_ctx,
@@ -131,6 +143,16 @@ impl ComputeStorage for PinnedStorage {
 
     fn flush(&mut self) {
         for ptr in self.retired.drain(..) {
+            unsafe { mi355_pinned_free(self.ctx, ptr as *mut core::ffi::c_void) };
+        }
+    }
+}
+
+impl Drop for PinnedStorage {
+    fn drop(&mut self) {
+        // (staging buffers still referenced by a `Bytes` hold a binding of the pool, not of this storage: by the time the
+        // storage drops the lane's drop queue has been flushed and no copy is in flight)
+        for ptr in self.retired.drain(..).chain(self.live.drain().map(|(_, (p, _))| p)) {
             unsafe { mi355_pinned_free(self.ctx, ptr as *mut core::ffi::c_void) };
         }
     }

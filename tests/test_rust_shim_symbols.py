@@ -578,3 +578,150 @@ def test_integration_doc_lists_no_invented_symbols():
         assert ghost not in doc, ghost
         for name, text in shim_sources().items():
             assert ghost not in text, (ghost, name)
+
+
+# ---- round 3: the likeliest first compile errors a text check can still reach ---------------------------------------------
+def _generic_arity(decl_generics):
+    """(required, total) type / const parameters of a `<...>` declaration; lifetimes do not count, defaulted ones are optional."""
+    params = [p for p in split_top(decl_generics) if not p.startswith("'")]
+    required = len([p for p in params if "=" not in p.split(":")[0] and not re.search(r"=\s*[\w:<>]+\s*$", p)])
+    return required, len(params)
+
+
+def test_generic_types_are_spelled_with_the_reference_number_of_parameters():
+    """`MemoryManagement<S>`, `MultiStream<B>`, `ComputeClient<R>`, `PendingDropQueue<F>` ...: every reference-defined generic
+    type the crate spells with `<...>` carries as many type arguments as its declaration takes (lifetimes aside)."""
+    all_ref = "\n".join(crate_text(c) for c in REEXPORTS)
+    decls = {}
+    for m in re.finditer(r"\bpub(?:\([a-z]+\))?\s+(?:struct|enum|trait|type)\s+(\w+)\s*<", all_ref):
+        i = m.end() - 1
+        depth, j = 0, i
+        while j < len(all_ref):
+            if all_ref[j] == "<":
+                depth += 1
+            elif all_ref[j] == ">" and all_ref[j - 1] != "-":
+                depth -= 1
+                if depth == 0:
+                    break
+            j += 1
+        decls.setdefault(m.group(1), set()).add(_generic_arity(all_ref[i + 1:j]))
+    checked, problems = 0, []
+    own = set(re.findall(r"\b(?:struct|enum|trait|type)\s+(\w+)", "\n".join(shim_sources().values())))
+    own |= {"Result", "Option", "Vec", "Box", "Arc", "Rc", "HashMap", "HashSet", "BTreeMap", "VecDeque", "PhantomData", "Mutex", "RefCell", "Cell",
+            "Cow", "Pin", "Future", "Iterator", "IntoIterator", "Fn", "FnMut", "FnOnce", "From", "Into", "AsRef", "Deref", "MaybeUninit"}   # std's, not the reference's
+    for name, text in shim_sources().items():
+        for m in re.finditer(r"\b([A-Z]\w+)\s*<", text):
+            ident = m.group(1)
+            if ident not in decls or ident in own or text[max(0, m.start() - 2):m.start()] == "::" and False:
+                continue
+            i = m.end() - 1
+            depth, j = 0, i
+            while j < len(text):
+                if text[j] == "<":
+                    depth += 1
+                elif text[j] == ">" and text[j - 1] not in "-=":
+                    depth -= 1
+                    if depth == 0:
+                        break
+                elif text[j] in ";{" and depth == 1 and j - i > 200:
+                    break
+                j += 1
+            if depth != 0:
+                continue                                   # a comparison, not a generic argument list
+            args = [a for a in split_top(text[i + 1:j]) if not a.startswith("'")]
+            if any(re.match(r"^\w+\s*=", a) for a in args):        # associated-type bindings (`Iterator<Item = T>`)
+                continue
+            checked += 1
+            if not any(req <= len(args) <= tot for req, tot in decls[ident]):
+                problems.append(f"{name}: {ident}<{text[i + 1:j].strip()[:60]}> has {len(args)} type argument(s), the reference declares {sorted(decls[ident])}")
+    assert checked >= 25, checked
+    assert not problems, "\n".join(problems)
+
+
+def test_every_mi355_constant_the_crate_uses_is_defined_in_ffi_rs_with_the_headers_value():
+    """`MI355_ABI_VERSION` was used by runtime.rs and defined nowhere until round 3: a guaranteed first compile error."""
+    ffi = strip_comments((SHIM / "ffi.rs").read_text())
+    defined = dict(re.findall(r"pub const (MI355_\w+)\s*:\s*\w+\s*=\s*([^;]+);", ffi))
+    used = set()
+    for text in shim_sources().values():
+        used |= set(re.findall(r"\b(MI355_[A-Z0-9_]+)\b", text))
+    missing = sorted(u for u in used if u not in defined)
+    assert not missing, f"used in src/*.rs but not defined in ffi.rs: {missing}"
+    header = (ROOT / "include" / "mi355cube.h").read_text()
+    hvals = dict(re.findall(r"#define\s+(MI355_\w+)\s+(-?\d+)\b", header))
+    hvals.update(dict(re.findall(r"\b(MI355_\w+)\s*=\s*(-?\d+)\s*[,}/]", header)))
+    wrong = {k: (v.strip(), hvals[k]) for k, v in defined.items() if k in hvals and re.fullmatch(r"-?\d+", v.strip()) and int(v) != int(hvals[k])}
+    assert not wrong, wrong
+    assert int(defined["MI355_ABI_VERSION"]) == int(hvals["MI355_ABI_VERSION"])
+
+
+def _error_type(ret):
+    m = re.search(r"Result<(.*)>\s*$", ret.strip(), flags=re.S)
+    if not m:
+        return None
+    parts = split_top(m.group(1))
+    return re.sub(r"\s+", "", parts[-1]).split("::")[-1] if len(parts) == 2 else None
+
+
+def test_question_mark_sites_propagate_an_error_type_the_function_can_return():
+    """`foo()?` inside `fn bar() -> Result<_, E>` compiles only when foo's error type is E or converts into it.  The reference
+    gives ServerError `#[from]` conversions out of IoError / LaunchError / ProfileError -- not the other way round -- so the
+    likeliest first compile error of this crate is an `IoError`-returning function using `?` on a ServerError.  Callee error
+    types come from this crate's own signatures and from the reference's `fn` declarations (skipped when a name has
+    several declarations with different error types, or when the `?` follows a closure-typed combinator)."""
+    rt = crate_text("cubecl_runtime") + "\n" + crate_text("cubecl_common")
+    conversions = set()
+    for enum_m in re.finditer(r"pub enum (\w+Error)\b[^{]*\{", rt):
+        body = balanced(rt, enum_m.end() - 1)
+        for boxed, frm in re.findall(r"#\[from\]\s*(Box<)?(\w+)", body):
+            conversions.add((f"Box<{frm}>" if boxed else frm, enum_m.group(1)))      # From<Box<E>> is not From<E>
+    conversions |= set(re.findall(r"impl From<(\w+)> for (\w+)", rt))
+    assert ("IoError", "ServerError") in conversions and ("ServerError", "IoError") not in conversions
+
+    def declared_errors(text):
+        out = {}
+        for fname, start, args, end in find_fns(text):
+            m = re.match(r"\s*->\s*([^{;]+?)\s*(?:where\b[^{;]*)?[{;]", text[end:], flags=re.S)
+            e = _error_type(m.group(1)) if m else None
+            if e:
+                out.setdefault(fname, set()).add(e)
+        return out
+    own, ref = {}, declared_errors(rt)
+    sources = shim_sources()
+    for text in sources.values():
+        for k, v in declared_errors(text).items():
+            own.setdefault(k, set()).update(v)
+    COMBINATORS = {"ok_or_else", "ok_or", "map_err", "map", "and_then", "transpose", "collect", "unwrap_or", "into", "ok", "get", "get_mut", "next"}
+    checked, problems = 0, []
+    for name, text in sources.items():
+        for fname, start, args, end in find_fns(text):
+            m = re.match(r"\s*->\s*([^{;]+?)\s*(?:where\b[^{;]*)?\{", text[end:], flags=re.S)
+            want = _error_type(m.group(1)) if m else None
+            if not want:
+                continue
+            body_open = end + m.end() - 1
+            body = balanced(text, body_open)
+            for q in re.finditer(r"\)\s*\?", body):
+                # the call whose result the `?` applies to: walk back over the balanced argument list to its name
+                j, depth = q.start(), 0
+                while j >= 0:
+                    if body[j] == ")":
+                        depth += 1
+                    elif body[j] == "(":
+                        depth -= 1
+                        if depth == 0:
+                            break
+                    j -= 1
+                cm = re.search(r"(\w+)\s*(?:::<[^>]*>)?\s*$", body[:j])
+                if not cm or cm.group(1) in COMBINATORS:
+                    continue
+                callee = cm.group(1)
+                errs = own.get(callee) or ref.get(callee)
+                if not errs or len(errs) != 1:
+                    continue
+                have = next(iter(errs))
+                checked += 1
+                if have != want and (have, want) not in conversions:
+                    problems.append(f"{name}: fn {fname} -> Result<_, {want}> uses `?` on {callee}(..) which returns Result<_, {have}> (no From<{have}> for {want})")
+    assert checked >= 25, checked
+    assert not problems, "\n".join(problems)
