@@ -54,6 +54,8 @@ LAYOUT_ROW_MAJOR, LAYOUT_COL_MAJOR = 0, 1
 
 REDUCE_SUM, REDUCE_MEAN, REDUCE_MAX, REDUCE_MIN = 0, 1, 2, 3
 PLANE_PROD, PLANE_INCLUSIVE_SUM, PLANE_EXCLUSIVE_SUM = 100, 101, 102
+(PLANE_ALL, PLANE_ANY, PLANE_ELECT, PLANE_BROADCAST, PLANE_SHUFFLE, PLANE_SHUFFLE_XOR, PLANE_SHUFFLE_UP, PLANE_SHUFFLE_DOWN,
+ PLANE_BALLOT) = range(200, 209)
 
 GEMM_ALGO_AUTO, GEMM_ALGO_GENERIC, GEMM_ALGO_F32_MFMA, GEMM_ALGO_LP_128, GEMM_ALGO_LP_256, GEMM_ALGO_LP_256W4, GEMM_ALGO_LP_256P = 0, 1, 2, 3, 4, 5, 6
 GEMM_ALGO_LP_256Q = 7
@@ -237,6 +239,7 @@ PROTOTYPES = {
     "mi355_reduce_axis_sum_f32": (C.c_int32, [_P, _P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint64]),
     "mi355_reduce_axis_argmax_f32": (C.c_int32, [_P, _P, _P, _P, C.c_uint64, C.c_uint64, C.c_uint64]),
     "mi355_plane_reduce_f32": (C.c_int32, [_P, _P, _P, _P, C.c_uint64, C.c_uint32, C.c_int32]),
+    "mi355_plane_op_f32": (C.c_int32, [_P, _P, _P, _P, C.c_uint64, C.c_uint32, C.c_int32, C.c_uint32]),
     "mi355_probe_memory_read": (C.c_int32, [_P, _P, _P, C.c_uint64, C.c_uint32, _P]),
     "mi355_probe_mfma": (C.c_int32, [_P, _P, C.c_int32, C.c_uint32, _P, _U64P]),
     "mi355_probe_mfma_data": (C.c_int32, [_P, _P, C.c_int32, C.c_uint32, _P, _U64P]),

@@ -592,6 +592,42 @@ plane_reduce_kernel(const float *__restrict__ in, float *__restrict__ out, uint6
     if (i < n) out[i] = v;
 }
 
+// ---- the remaining plane intrinsics (frontend/plane.rs:62-216, :388-440), one plane of `plane` lanes per block --------
+// Launched with blockDim = plane (32 or 64), exactly as the reference's tests launch CubeDim::new_1d(plane_size) on a
+// wave64 device: the lanes beyond `plane` do not exist, so __activemask / __shfl see what a CubeCL kernel would see.
+// Lowering follows crates/cubecl-cpp/src/hip/plane.rs (:19-64: __shfl / __shfl_xor / __shfl_up / __shfl_down / __all / __any /
+// __ballot) and shared/plane.rs:170-174 (elect = lowest lane of the active mask).
+__global__ void __launch_bounds__(64)
+plane_op_kernel(const float *__restrict__ in, void *__restrict__ out_raw, uint64_t n, int op, uint32_t arg)
+{
+    const uint32_t lane = threadIdx.x, plane = blockDim.x;
+    const uint64_t i = (uint64_t)blockIdx.x * plane + lane;
+    if (i >= n) return;                                       // a ragged last plane simply has fewer active lanes
+    const float v = in[i];
+    float *out = static_cast<float *>(out_raw);
+    switch (op) {
+    case MI355_PLANE_ALL: out[i] = __all(v != 0.f) ? 1.f : 0.f; break;
+    case MI355_PLANE_ANY: out[i] = __any(v != 0.f) ? 1.f : 0.f; break;
+    case MI355_PLANE_ELECT: out[i] = ((uint32_t)__builtin_ctzll(__ballot(1)) == lane) ? 1.f : 0.f; break;
+    case MI355_PLANE_BROADCAST:
+    // width = the plane: a source lane outside it leaves the lane's own value (with the default width of 64 a 32-lane plane
+    // would read the registers of lanes that do not exist)
+    case MI355_PLANE_SHUFFLE: out[i] = __shfl(v, (int)arg, (int)plane); break;
+    case MI355_PLANE_SHUFFLE_XOR: out[i] = __shfl_xor(v, (int)arg, (int)plane); break;
+    case MI355_PLANE_SHUFFLE_UP: out[i] = __shfl_up(v, arg, (int)plane); break;
+    case MI355_PLANE_SHUFFLE_DOWN: out[i] = __shfl_down(v, arg, (int)plane); break;
+    case MI355_PLANE_BALLOT: {
+        const unsigned long long m = __ballot(v != 0.f);     // 64-bit on this target: words 0 and 1 of the reference's 4 x u32
+        if (lane == 0) {
+            uint32_t *o = static_cast<uint32_t *>(out_raw) + (uint64_t)blockIdx.x * 4;
+            o[0] = (uint32_t)m; o[1] = (uint32_t)(m >> 32); o[2] = 0; o[3] = 0;
+        }
+        break;
+    }
+    default: break;
+    }
+}
+
 // ---- multi-GPU argmax: the combine step -------------------------------------------------------------
 // After the all-gather every rank holds one record {f32 value, u32 pad, u64 LOCAL index} per shard (the bytes
 // mi355_sum_argmax_f32 wrote at out_val / out_idx, 16 bytes apart).  One wave folds them with the rule the
@@ -804,5 +840,22 @@ MI355_API int32_t mi355_plane_reduce_f32(mi355_ctx *ctx, mi355_stream stream, co
     hipLaunchKernelGGL(plane_reduce_kernel, dim3((uint32_t)blocks), dim3(64), 0, stream_of(ctx, stream), in, out, n,
                        active, op);
     check_launch(ctx, "mi355_plane_reduce_f32");
+    return MI355_OK;
+}
+
+MI355_API int32_t mi355_plane_op_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, void *out, uint64_t n, uint32_t plane,
+                                     int32_t op, uint32_t arg)
+{
+    MI355_REQUIRE_CTX(ctx);
+    if (n == 0) return MI355_OK;
+    if (!in || !out) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_plane_op_f32: NULL pointer");
+    if (plane != 32 && plane != 64) return fail(ctx, MI355_E_INVALID_ARGUMENT, "plane must be 32 or 64 lanes (got %u)", plane);
+    if (op < MI355_PLANE_ALL || op > MI355_PLANE_BALLOT) return fail(ctx, MI355_E_UNSUPPORTED, "unknown plane op %d", op);
+    if ((op == MI355_PLANE_BROADCAST || op == MI355_PLANE_SHUFFLE) && arg >= plane)
+        return fail(ctx, MI355_E_INVALID_ARGUMENT, "source lane %u outside the plane of %u", arg, plane);
+    const uint64_t blocks = (n + plane - 1) / plane;
+    if (blocks > 0x7FFFFFFFull) return fail(ctx, MI355_E_UNSUPPORTED, "too many planes");
+    hipLaunchKernelGGL(plane_op_kernel, dim3((uint32_t)blocks), dim3(plane), 0, stream_of(ctx, stream), in, out, n, (int)op, arg);
+    check_launch(ctx, "mi355_plane_op_f32");
     return MI355_OK;
 }

@@ -327,6 +327,15 @@ def plane_reduce(client: ComputeClient, input: TensorHandle, output: TensorHandl
                                                       C.c_void_p(output.device_ptr()), n, active, op))
 
 
+def plane_op(client: ComputeClient, input: TensorHandle, output: TensorHandle, op: int, plane: int = 64, arg: int = 0) -> None:
+    """plane_all / plane_any / plane_elect / plane_broadcast / plane_shuffle / _xor / _up / _down / plane_ballot
+    (crates/cubecl-core/src/frontend/plane.rs:62-216, :388-440) over planes of `plane` lanes (32 or 64).  `output` holds one f32
+    per input, except for PLANE_BALLOT: 4 x u32 per plane."""
+    n = input.num_elems()
+    client._s.check(client.lib.mi355_plane_op_f32(client.ctx, client.on(input, output), C.c_void_p(input.device_ptr()),
+                                                  C.c_void_p(output.device_ptr()), n, plane, op, arg))
+
+
 def identity(client: ComputeClient, output: TensorHandle) -> None:
     """tensor::identity::launch (crates/cubecl-std/src/tensor/identity.rs:36-84): `output`, a square matrix (possibly with
     pitched rows), becomes the identity matrix of its dtype."""

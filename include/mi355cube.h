@@ -517,6 +517,18 @@ int32_t mi355_reduce_axis_argmax(mi355_ctx *ctx, mi355_stream stream, const void
  * op = MI355_REDUCE_SUM / MAX / MIN, or 100 for product, 101 inclusive sum, 102 exclusive sum. */
 int32_t mi355_plane_reduce_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, float *out,
                                uint64_t n, uint32_t active, int32_t op);
+/* The remaining plane intrinsics at tensor level (crates/cubecl-core/src/frontend/plane.rs:62-216, :388-440; HIP lowering
+ * crates/cubecl-cpp/src/hip/plane.rs:19-64, elect shared/plane.rs:170-174; known answers runtime_tests/plane.rs:527-850): one
+ * plane of `plane` lanes (32 or 64: CubeDim::new_1d(plane) on this wave64 device) per `plane` consecutive inputs.
+ *   ALL / ANY        out[i] = 1.0 if every / any lane of the plane holds a non-zero input, else 0.0
+ *   ELECT            out[i] = 1.0 for the lowest active lane of the plane, 0.0 for the others
+ *   BROADCAST / SHUFFLE (arg = source lane), SHUFFLE_XOR (arg = mask), SHUFFLE_UP / _DOWN (arg = delta): out[i] = the value
+ *                    of the source lane; a source outside the plane leaves the lane's own value (HIP's __shfl_* rule)
+ *   BALLOT           out = 4 x u32 per plane (16 bytes each): the mask of lanes with a non-zero input, words 2 and 3 zero */
+enum { MI355_PLANE_ALL = 200, MI355_PLANE_ANY = 201, MI355_PLANE_ELECT = 202, MI355_PLANE_BROADCAST = 203, MI355_PLANE_SHUFFLE = 204,
+       MI355_PLANE_SHUFFLE_XOR = 205, MI355_PLANE_SHUFFLE_UP = 206, MI355_PLANE_SHUFFLE_DOWN = 207, MI355_PLANE_BALLOT = 208 };
+int32_t mi355_plane_op_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, void *out, uint64_t n, uint32_t plane,
+                           int32_t op, uint32_t arg);
 
 /* tensor::identity::launch (crates/cubecl-std/src/tensor/identity.rs:36-84): writes the dim x dim identity matrix
  * (1 on the diagonal in `dtype`, 0 elsewhere) into rows `ld` elements apart (ld >= dim; the padding of a pitched

@@ -293,6 +293,44 @@ def plane_inclusive_sum(vals: np.ndarray) -> np.ndarray:
     return v
 
 
+PLANE_ALL, PLANE_ANY, PLANE_ELECT, PLANE_BROADCAST, PLANE_SHUFFLE, PLANE_SHUFFLE_XOR, PLANE_SHUFFLE_UP, PLANE_SHUFFLE_DOWN, PLANE_BALLOT = range(200, 209)
+
+
+def plane_op(vals: np.ndarray, op: int, plane: int, arg: int = 0) -> np.ndarray:
+    """The remaining plane intrinsics (crates/cubecl-core/src/frontend/plane.rs:62-216, :388-440) over planes of `plane` lanes
+    -- numpy restatement of the semantics the reference's tests pin (runtime_tests/plane.rs:527-850) and its HIP lowering gives
+    (crates/cubecl-cpp/src/hip/plane.rs:19-64: a shuffle whose source lies outside the plane keeps the lane's own value;
+    shared/plane.rs:170-174: elect = the lowest active lane).  ALL / ANY test "non-zero"; BALLOT returns 4 x u32 per plane."""
+    v = np.ascontiguousarray(vals, dtype=np.float32).reshape(-1)
+    out = np.empty((-(-v.size // plane), 4), dtype=np.uint32) if op == PLANE_BALLOT else v.copy()
+    for p0 in range(0, v.size, plane):
+        x = v[p0:p0 + plane]
+        lanes = np.arange(x.size)
+        if op == PLANE_ALL:
+            out[p0:p0 + plane] = 1.0 if np.all(x != 0) else 0.0
+        elif op == PLANE_ANY:
+            out[p0:p0 + plane] = 1.0 if np.any(x != 0) else 0.0
+        elif op == PLANE_ELECT:
+            out[p0:p0 + plane] = (lanes == 0).astype(np.float32)
+        elif op in (PLANE_BROADCAST, PLANE_SHUFFLE):
+            out[p0:p0 + plane] = x[arg] if arg < x.size else x
+        elif op == PLANE_SHUFFLE_XOR:
+            src = lanes ^ arg
+            out[p0:p0 + plane] = np.where(src < x.size, x[np.minimum(src, x.size - 1)], x)
+        elif op == PLANE_SHUFFLE_UP:
+            src = lanes - arg
+            out[p0:p0 + plane] = np.where(src >= 0, x[np.maximum(src, 0)], x)
+        elif op == PLANE_SHUFFLE_DOWN:
+            src = lanes + arg
+            out[p0:p0 + plane] = np.where(src < x.size, x[np.minimum(src, x.size - 1)], x)
+        elif op == PLANE_BALLOT:
+            m = int(sum(1 << int(i) for i in lanes[x != 0]))
+            out[p0 // plane] = [m & 0xFFFFFFFF, (m >> 32) & 0xFFFFFFFF, 0, 0]
+        else:
+            raise ValueError(op)
+    return out
+
+
 def cpu_sum_argmax(x: np.ndarray, units: int):
     x = np.ascontiguousarray(x, dtype=np.float32)
     s, i = C.c_float(), C.c_uint64()

@@ -352,6 +352,7 @@ unsafe extern "C" {
     pub fn mi355_reduce_last_axis_argmax_f32(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const f32, out_idx: *mut u32,
                                              rows: u64, cols: u64, row_stride: u64) -> i32;
     pub fn mi355_plane_reduce_f32(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const f32, out: *mut f32, n: u64, active: u32, op: i32) -> i32;
+    pub fn mi355_plane_op_f32(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const f32, out: *mut c_void, n: u64, plane: u32, op: i32, arg: u32) -> i32;
     // synthetic data, casts, copies
     pub fn mi355_fill_uniform(ctx: *mut mi355_ctx, stream: mi355_stream, dst: *mut c_void, dtype: i32, n: u64, seed: u64,
                               tensor: u64, lo: f32, hi: f32) -> i32;

@@ -429,3 +429,48 @@ def test_reductions_take_permuted_and_sliced_views(client, oracle):
     ops.reduce_sum_axis(client, sl, cs, 0)
     ref = m[:, 10:50].astype(np.float64).sum(axis=0)
     assert np.all(np.abs(cs.to_numpy(client).astype(np.float64) - ref) <= REL * np.abs(m[:, 10:50]).astype(np.float64).sum(axis=0))
+
+
+@pytest.mark.parametrize("plane", [32, 64])
+def test_remaining_plane_intrinsics_match_the_oracle_and_the_reference_vectors(client, oracle, plane):
+    """plane_all / any / elect / broadcast / shuffle / _xor / _up / _down / ballot (frontend/plane.rs:62-216, :388-440) at tensor
+    level: the device against the oracle over many planes of random data (bit-exact: values only move), then the inputs and
+    expectations of runtime_tests/plane.rs:527-850."""
+    rng = np.random.default_rng(5)
+    n = 37 * plane + (plane // 2)                                  # a ragged last plane: fewer active lanes
+    x = rng.standard_normal(n).astype(np.float32)
+    x[rng.random(n) < 0.3] = 0.0
+    t = TensorHandle.from_numpy(client, x)
+    out = TensorHandle.new_contiguous((n,), client.empty(n * 4), ElemType.F32)
+    for op, arg in ((N.PLANE_ALL, 0), (N.PLANE_ANY, 0), (N.PLANE_ELECT, 0), (N.PLANE_BROADCAST, 2), (N.PLANE_SHUFFLE, plane // 2 - 1),
+                    (N.PLANE_SHUFFLE_XOR, 1), (N.PLANE_SHUFFLE_XOR, 5), (N.PLANE_SHUFFLE_UP, 1), (N.PLANE_SHUFFLE_UP, 7),
+                    (N.PLANE_SHUFFLE_DOWN, 1), (N.PLANE_SHUFFLE_DOWN, 3)):
+        ops.plane_op(client, t, out, op, plane=plane, arg=arg)
+        want = oracle.plane_op(x, op, plane, arg)
+        got = out.to_numpy(client)
+        full = (n // plane) * plane                                # (a source lane beyond a RAGGED plane's end is outside the contract)
+        assert np.array_equal(got[:full].view(np.uint32), want[:full].view(np.uint32)), (op, arg)
+    nb = -(-n // plane)
+    ob = TensorHandle.new_contiguous((nb * 4,), client.empty(nb * 16), ElemType.U32)
+    ops.plane_op(client, t, ob, N.PLANE_BALLOT, plane=plane)
+    assert np.array_equal(ob.to_numpy(client).reshape(nb, 4), oracle.plane_op(x, N.PLANE_BALLOT, plane))
+    # the reference's own cases (plane_size 32 there; shuffle / shuffle_down use the hardware plane)
+    y = (np.arange(plane) % 5).astype(np.float32)
+    y[4] = 10.0
+    for pred, op, want in (((y < 5), N.PLANE_ALL, 0.0), ((y > 5), N.PLANE_ANY, 1.0)):
+        tp = TensorHandle.from_numpy(client, pred.astype(np.float32))
+        o = TensorHandle.new_contiguous((plane,), client.empty(plane * 4), ElemType.F32)
+        ops.plane_op(client, tp, o, op, plane=plane)
+        assert np.all(o.to_numpy(client) == want)
+    tb = TensorHandle.from_numpy(client, (np.arange(plane) < 8).astype(np.float32))
+    o4 = TensorHandle.new_contiguous((4,), client.empty(16), ElemType.U32)
+    ops.plane_op(client, tb, o4, N.PLANE_BALLOT, plane=plane)
+    assert o4.to_numpy(client).tolist() == [0b11111111, 0, 0, 0]                       # test_plane_ballot
+    te = TensorHandle.from_numpy(client, np.zeros(plane, np.float32))
+    oe = TensorHandle.new_contiguous((plane,), client.empty(plane * 4), ElemType.F32)
+    ops.plane_op(client, te, oe, N.PLANE_ELECT, plane=plane)
+    assert oe.to_numpy(client).sum() == 1.0 and oe.to_numpy(client)[0] == 1.0          # test_plane_elect: one unit, the lowest
+    with pytest.raises(ServerError):
+        ops.plane_op(client, te, oe, N.PLANE_SHUFFLE, plane=plane, arg=plane)          # source lane outside the plane
+    with pytest.raises(ServerError):
+        ops.plane_op(client, te, oe, N.PLANE_ALL, plane=48)

@@ -374,3 +374,29 @@ def test_pack_along_known_words():
     assert L.pack_along(np.arange(1, 9, dtype=np.uint32), [8], 0, 8, 4).tolist() == [0x87654321]
     v = np.arange(1, 17, dtype=np.uint32) & 15
     assert L.pack_along(v, [8, 2], 0, 8, 4).tolist() == [0xFDB97531, 0x0ECA8642]
+
+
+def test_remaining_plane_intrinsics_reproduce_the_reference_tests_expectations(oracle):
+    """runtime_tests/plane.rs:527-850 restated: the inputs those tests build and the `expected` vectors they compute, against
+    the oracle's plane_op (all / any / elect / broadcast / ballot / shuffle / xor / up / down)."""
+    plane = 32
+    x = (np.arange(plane) % 5).astype(np.float32)
+    x[4] = 10.0                                                      # test_plane_all / _any (:527-605), vectorization 1
+    assert np.array_equal(oracle.plane_op((x < 5).astype(np.float32), oracle.PLANE_ALL, plane), np.zeros(plane, np.float32))
+    assert np.array_equal(oracle.plane_op((x > 5).astype(np.float32), oracle.PLANE_ANY, plane), np.ones(plane, np.float32))
+    y = (np.arange(plane) % 5).astype(np.float32)                    # ... and the untouched odd batches: all true / none true
+    assert np.array_equal(oracle.plane_op((y < 5).astype(np.float32), oracle.PLANE_ALL, plane), np.ones(plane, np.float32))
+    assert np.array_equal(oracle.plane_op((y > 5).astype(np.float32), oracle.PLANE_ANY, plane), np.zeros(plane, np.float32))
+    # test_plane_ballot (:607-629): UNIT_POS < 8 on a 32-unit cube -> [0b1111_1111, 0, 0, 0]
+    assert oracle.plane_op((np.arange(32) < 8).astype(np.float32), oracle.PLANE_BALLOT, 32).tolist() == [[0b11111111, 0, 0, 0]]
+    # test_plane_elect (:631-659): exactly one unit of the plane adds 1 to output[20]
+    assert oracle.plane_op(np.zeros(32, np.float32), oracle.PLANE_ELECT, 32).sum() == 1.0
+    v = np.arange(plane, dtype=np.float32)
+    assert oracle.plane_op(v, oracle.PLANE_BROADCAST, plane, 2)[0] == v[2]                      # :661-694: unit 0 receives lane 2
+    assert oracle.plane_op(np.arange(64, dtype=np.float32), oracle.PLANE_SHUFFLE, 64, 0)[0] == 0.0   # :696-729
+    assert np.array_equal(oracle.plane_op(v, oracle.PLANE_SHUFFLE_XOR, plane, 1), v[np.arange(plane) ^ 1])          # :731-770
+    up = v.copy(); up[1:] = v[:-1]
+    assert np.array_equal(oracle.plane_op(v, oracle.PLANE_SHUFFLE_UP, plane, 1), up)                                  # :772-810: lane 0 keeps its value
+    w = np.arange(64, dtype=np.float32)
+    down = w.copy(); down[:-1] = w[1:]
+    assert np.array_equal(oracle.plane_op(w, oracle.PLANE_SHUFFLE_DOWN, 64, 1), down)                                 # :812-850: the last lane keeps its value
