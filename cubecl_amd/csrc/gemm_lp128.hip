@@ -85,6 +85,20 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
 // LDS-DMA as `global_load_lds_dwordx4 v_off, s[base:base+1]`: wave-uniform 64-bit base + constant 32-bit lane offset, LDS
 // destination through M0 (set in the same statement); see gemm_lp256w4.hip.  Not counted by the compiler: every wait on
 // these loads in this file is explicit.
+#ifndef LDS_DMA_POLICY
+#define LDS_DMA_POLICY 0   // dev: cache-policy modifiers of the LDS-DMA loads: 1 sc0, 2 sc1, 3 sc0 sc1, 4 nt (measured: profiles/r03_lds_dma_cache_policy.md)
+#endif
+#if LDS_DMA_POLICY == 1
+#define LDS_DMA_MOD " sc0"
+#elif LDS_DMA_POLICY == 2
+#define LDS_DMA_MOD " sc1"
+#elif LDS_DMA_POLICY == 3
+#define LDS_DMA_MOD " sc0 sc1"
+#elif LDS_DMA_POLICY == 4
+#define LDS_DMA_MOD " nt"
+#else
+#define LDS_DMA_MOD ""
+#endif
 __device__ __forceinline__ void glds16_s(const void *ubase_in, uint32_t voff, uint32_t lds_in)
 {
     // wave-uniform by construction; said again here because hipcc's divergence analysis loses it behind role branches
@@ -98,7 +112,7 @@ __device__ __forceinline__ void glds16_s(const void *ubase_in, uint32_t voff, ui
     // within 5 wait states of a VALU write to it.  The compiler pads its own code for that hazard but cannot see into
     // inline asm (tools/hazard_scan.py, run by tests/test_abi_cpu.py: 2-3 wait states here before the padding; a prefetch
     // experiment with none faulted at once).
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ubase), "s"(lds_byte_addr) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" LDS_DMA_MOD ::"v"(voff), "s"(ubase), "s"(lds_byte_addr) : "memory");
 }
 __device__ __forceinline__ uint32_t lds_addr_of(const void *p)
 {

@@ -60,8 +60,29 @@ struct stream_args {
     int64_t stride_small, stride_big, stride_out;   // batch strides, elements
     int32_t small_rows, big_rows, k;
     int32_t dtype_c;
+    int32_t stream_nt;       // the streamed operand is larger than the Infinity Cache could keep: non-temporal LDS-DMA pieces
 };
 
+#ifndef LDS_DMA_POLICY
+#define LDS_DMA_POLICY 0   // dev: cache-policy modifiers of the LDS-DMA loads: 1 sc0, 2 sc1, 3 sc0 sc1, 4 nt (measured: profiles/r03_lds_dma_cache_policy.md)
+#endif
+#if LDS_DMA_POLICY == 1
+#define LDS_DMA_MOD " sc0"
+#elif LDS_DMA_POLICY == 2
+#define LDS_DMA_MOD " sc1"
+#elif LDS_DMA_POLICY == 3
+#define LDS_DMA_MOD " sc0 sc1"
+#elif LDS_DMA_POLICY == 4
+#define LDS_DMA_MOD " nt"
+#else
+#define LDS_DMA_MOD ""
+#endif
+// NT: the piece carries the non-temporal hint.  Only ever the STREAMED operand's pieces (read exactly once), and only when that
+// operand cannot stay in the 256 MiB Infinity Cache anyway (stream_args::stream_nt, set by the launcher): interleaved on cold
+// operands 16 x 28672 x 8192 (470 MiB) 83.9 -> 76.6 us, 32 x 14336 x 4096 29.2 -> 27.8, 128 MiB operands a tie -- but a 128 MiB
+// operand re-read by back-to-back launches loses the cache's help with the hint (25.5 -> 31.9 us), and on the small operand (re-read
+// by every workgroup from L2) or on the tile kernels' operands the hint costs 15-25 % (profiles/r03_lds_dma_cache_policy.md).
+template <bool NT = false>
 __device__ __forceinline__ void glds16_s(const void *ubase_in, uint32_t voff, uint32_t lds_in)
 {
     const uint64_t u = reinterpret_cast<uint64_t>(ubase_in);
@@ -71,7 +92,10 @@ __device__ __forceinline__ void glds16_s(const void *ubase_in, uint32_t voff, ui
     const uint32_t lds_byte_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_in);
     // s_nop 4: gfx9 wants 5 wait states between a VALU write of an SGPR (the readfirstlanes above) and a VMEM read of it;
     // the compiler cannot pad inside inline asm (tools/hazard_scan.py, tests/test_abi_cpu.py)
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ubase), "s"(lds_byte_addr) : "memory");
+    if constexpr (NT)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(ubase), "s"(lds_byte_addr) : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" LDS_DMA_MOD ::"v"(voff), "s"(ubase), "s"(lds_byte_addr) : "memory");
 }
 __device__ __forceinline__ uint32_t lds_addr_of(const void *p)
 {
@@ -151,7 +175,11 @@ __global__ void __launch_bounds__(640, TWO ? 5 : 2) gemm_stream64_kernel(stream_
                 if (t < nk) {
                     const uint32_t slot = lds_addr_of(smem + B_RING + (t % SB) * BLK + half * 2048);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) glds16_s(big + (int64_t)(S64_ABL == 2 ? (t & 7) : phys(t)) * ROW_BYTES, voff[j], slot + j * 1024);
+                    for (int j = 0; j < 2; ++j) {
+                        const char *src = big + (int64_t)(S64_ABL == 2 ? (t & 7) : phys(t)) * ROW_BYTES;
+                        if (g.stream_nt) glds16_s<true>(src, voff[j], slot + j * 1024);      // (wave-uniform branch)
+                        else glds16_s<false>(src, voff[j], slot + j * 1024);
+                    }
                 }
             }
         };
@@ -331,6 +359,8 @@ int32_t launch_gemm_stream64(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_des
     g.big_rows = (int32_t)(a_small ? d.n : d.m);
     g.k = (int32_t)d.k;
     g.dtype_c = d.dtype_c;
+    // streamed bytes of the whole launch against what the 256 MiB Infinity Cache could still hold next to everything else
+    g.stream_nt = (int64_t)g.big_rows * d.k * 2 * std::max<int64_t>(d.batch, 1) > (192ll << 20) ? 1 : 0;
     const bool two = g.small_rows > 32;
     const uint32_t batch = (uint32_t)d.batch;
     if (d.dtype_ab == MI355_DTYPE_BF16) {

@@ -562,6 +562,30 @@ def test_row_major_b_mid_size_shapes_are_native_on_the_128_tile_kernel(client, o
     run_case(client, oracle, m, n, k, ElemType.BF16, ElemType.BF16, False, ALGOS["auto"])
 
 
+def test_row_major_b_through_the_strip_split_of_a_partly_filled_round(client, oracle):
+    """17 x 16 = 272 tiles of 256x256: AUTO cuts a strip off and splits its K (gemm.cpp plan_tail_split).  With row-major B the
+    strip's K slices start k rows further down B (not k columns further along its rows) and a strip of columns starts at a column
+    offset: same cut, same slabs, same fold -- the bits of the [N][K] launch."""
+    m, n, k = 4352, 4096, 512
+    along, extent, splits = C.c_int32(), C.c_int64(), C.c_int32()
+    d = _nn_desc(m, n, k, ElemType.BF16, ElemType.BF16)
+    assert client.lib.mi355_gemm_tail_plan(C.byref(d), C.byref(along), C.byref(extent), C.byref(splits)) == N.OK and splits.value > 1
+    a = TensorHandle.uniform(client, (m, k), ElemType.BF16, 0x5EEDC0BE, 91, -1.0, 1.0)
+    b_nk = TensorHandle.uniform(client, (n, k), ElemType.BF16, 0x5EEDC0BE, 92, -1.0, 1.0)
+    b_kn = ops.into_contiguous(client, TensorHandle.new(b_nk.handle, (k, n), (1, k), ElemType.BF16))
+    outs = []
+    for b_t in (TensorHandle.new(b_nk.handle, (k, n), (1, k), ElemType.BF16), b_kn):
+        c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 2), ElemType.BF16)
+        ops.matmul(client, a, b_t, c)
+        outs.append(c.to_numpy(client))
+    assert np.array_equal(outs[0], outs[1])
+    # and the split launch against the plain one (f32 slabs folded in slice order: within the 16-bit rounding of the output)
+    c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 2), ElemType.BF16)
+    ops.matmul(client, a, b_kn, c, algo=N.GEMM_ALGO_LP_256W4)
+    diff = np.abs(oracle.from_bf16(outs[1]).astype(np.float64) - oracle.from_bf16(c.to_numpy(client)).astype(np.float64))
+    assert np.all(diff <= 2.0 ** -7 * np.maximum(np.abs(oracle.from_bf16(outs[1])), 1e-3) + 1e-5 * k)
+
+
 def test_row_major_b_refusals_of_the_tile_kernel(client, oracle):
     """N not a multiple of 8 (a 16-byte DMA piece would straddle the row end) or rows of B not 16-byte aligned: the 256x256
     kernel refuses when forced, AUTO re-lays B out and still lands on an MFMA kernel."""
