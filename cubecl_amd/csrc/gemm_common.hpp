@@ -31,6 +31,7 @@ struct gemm_args {
     const void *sa = nullptr, *sb = nullptr;   // MX: re-arranged ue8m0 scales ST[K-tile][padded row][blocks per K-tile row]
     int64_t stride_sa = 0, stride_sb = 0;      // bytes between batch entries of those
     const void *c_in = nullptr;                // f32 C only: D = A * B + c_in (same layout as c; may alias it), lp256w4
+    uint32_t nt_mask = 0;                      // gemm_lp128.hip: bit 0 / 1 = the LDS-DMA pieces of A / B carry the non-temporal hint
 };
 
 // MI355X dispatches workgroup b to XCD b % 8, each XCD with a private 4 MiB L2

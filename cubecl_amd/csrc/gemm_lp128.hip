@@ -99,6 +99,7 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
 #else
 #define LDS_DMA_MOD ""
 #endif
+template <bool NT = false>
 __device__ __forceinline__ void glds16_s(const void *ubase_in, uint32_t voff, uint32_t lds_in)
 {
     // wave-uniform by construction; said again here because hipcc's divergence analysis loses it behind role branches
@@ -112,7 +113,12 @@ __device__ __forceinline__ void glds16_s(const void *ubase_in, uint32_t voff, ui
     // within 5 wait states of a VALU write to it.  The compiler pads its own code for that hazard but cannot see into
     // inline asm (tools/hazard_scan.py, run by tests/test_abi_cpu.py: 2-3 wait states here before the padding; a prefetch
     // experiment with none faulted at once).
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" LDS_DMA_MOD ::"v"(voff), "s"(ubase), "s"(lds_byte_addr) : "memory");
+    // NT: an operand that no other tile shares (one tile row / column) and that is larger than the Infinity Cache could keep is
+    // streamed non-temporally (gemm_args::nt_mask, set by the launcher; profiles/r03_lds_dma_cache_policy.md)
+    if constexpr (NT)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(ubase), "s"(lds_byte_addr) : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" LDS_DMA_MOD ::"v"(voff), "s"(ubase), "s"(lds_byte_addr) : "memory");
 }
 __device__ __forceinline__ uint32_t lds_addr_of(const void *p)
 {
@@ -233,8 +239,12 @@ gemm_lp128_kernel(gemm_args g)
         const int64_t koff = (int64_t)kt * ROW_BYTES;
 #pragma unroll
         for (int j = 0; j < 2 * MI; ++j) {
-            glds16_s(ubase_a + koff, va[j], lds_addr_of(la + (j * 4 + wave) * 1024));
-            if (j < 4) glds16_s(ubase_b + (BNN ? koff * g.ldb : koff), vb[j & 3], lds_addr_of(lb + (j * 4 + wave) * 1024));   // (row-major B: a K-tile is 64 rows of ldb elements)
+            if (g.nt_mask & 1u) glds16_s<true>(ubase_a + koff, va[j], lds_addr_of(la + (j * 4 + wave) * 1024));    // (uniform branches)
+            else glds16_s<false>(ubase_a + koff, va[j], lds_addr_of(la + (j * 4 + wave) * 1024));
+            if (j < 4) {                                                       // (row-major B: a K-tile is 64 rows of ldb elements)
+                if (g.nt_mask & 2u) glds16_s<true>(ubase_b + (BNN ? koff * g.ldb : koff), vb[j & 3], lds_addr_of(lb + (j * 4 + wave) * 1024));
+                else glds16_s<false>(ubase_b + (BNN ? koff * g.ldb : koff), vb[j & 3], lds_addr_of(lb + (j * 4 + wave) * 1024));
+            }
         }
     };
 
@@ -637,6 +647,14 @@ int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
     g.group_m = 8;
     g.split_k = 1;
     g.split_c_stride = 0;
+    {
+        // an operand whose tiles no other tile row / column shares, larger than the 256 MiB Infinity Cache could keep: read once
+        const int64_t esz_ = is_fp8(d.dtype_ab) ? 1 : 2, nb = std::max<int64_t>(d.batch, 1);
+#ifndef LP128_NO_NT        // dev: the A/B build without the hint
+        if (g.tiles_n == 1 && d.m * d.k * esz_ * nb > (192ll << 20)) g.nt_mask |= 1u;
+        if (g.tiles_m == 1 && d.n * d.k * esz_ * nb > (192ll << 20)) g.nt_mask |= 2u;
+#endif
+    }
     const uint32_t batch = (uint32_t)d.batch;
     // Split-K for shapes whose tile count cannot fill the chip (skinny M or N, GEMV-like): K is cut into slices,
     // every slice writes an f32 partial slab, a small kernel folds the slabs in slice order (deterministic) and
