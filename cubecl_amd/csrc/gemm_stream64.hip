@@ -6,8 +6,11 @@
 // the large operand over the WHOLE K range instead -- 256 workgroups at N = 8192, one per CU, each streaming one contiguous
 // 512 KiB region -- so nothing is split and nothing is folded.
 //
-//   * ten waves: four MULTIPLYING waves, four loader waves for the small operand and two for the streamed one; loaders only
-//     issue LDS-DMA pieces (`global_load_lds_dwordx4`, 1 KiB each) and wait for them.  Two LDS rings: 6-8 K-tiles of the
+//   * twelve waves: four MULTIPLYING waves, four loader waves for the small operand and four for the streamed one (two until
+//     round 3: with a piece costing its issuing wave ~100 cycles, two waves x two pieces per K-tile left little slack against the
+//     ~340 cycles a K-tile may take -- four waves, interleaved against two on cold operands: 16 x 28672 x 8192 85.8 -> 80.5 us,
+//     32 x 14336 x 4096 -5 %, 128 MiB operands a tie; warm +5...10 % everywhere); loaders only issue LDS-DMA pieces
+//     (`global_load_lds_dwordx4`, 1 KiB each) and wait for them.  Two LDS rings: 6-8 K-tiles of the
 //     small operand (L2-resident: short look-ahead) and 24 K-tiles = 96 KiB of the streamed one (HBM latency x bandwidth).
 //     Same 128-byte-row image and chunk swizzle as gemm_lp128.hip.
 //   * ring slots change hands in GROUPS of 2 (MB = 2) or 4 (MB = 1) K-tiles, one s_barrier per group; a group's fragment reads
@@ -37,6 +40,10 @@ namespace {
 #ifndef S64_ABL
 #define S64_ABL 0   // dev, timing only: 1 = the small operand always from K-tile 0 (no L2 traffic for it), 2 = the streamed operand re-reads its first 8 K-tiles (no HBM traffic)
 #endif
+#ifndef S64_NLB
+#define S64_NLB 4   // loader waves of the streamed operand: 4 (8 rows = one piece per K-tile each; round 3) or 2 (16 rows = two pieces each; rounds 1-2)
+#endif
+constexpr int NLB = S64_NLB, PPW = 4 / NLB;   // pieces per streamed-loader wave and K-tile
 constexpr int ROW_BYTES = 128;            // one K-tile row: 64 x 16-bit
 constexpr int BLK = 32 * ROW_BYTES;       // 32 rows of one operand: 4 KiB
 constexpr int BN = 32;                    // streamed rows per workgroup
@@ -125,7 +132,7 @@ template <int MB, bool TWO> struct ring_geom {
 // empty ring and a finishing one's drain overlap the neighbour's streaming (16 x 28672 x 8192: 107 -> 83.5 us); with one
 // workgroup per CU the deep rings win (64 x 8192 x 8192: 24.7 us against 33.9).
 template <int DT, int MB, bool TWO>
-__global__ void __launch_bounds__(640, TWO ? 5 : 2) gemm_stream64_kernel(stream_args g)
+__global__ void __launch_bounds__(512 + 64 * NLB, TWO ? (NLB == 2 ? 5 : 6) : (NLB == 2 ? 2 : 3)) gemm_stream64_kernel(stream_args g)
 {
     // Two rings.  The streamed operand needs DEPTH: ~25 GB/s per CU x ~2.5 us of HBM latency under load = ~64 KiB in flight
     // (with both operands in one 12-16 slot ring only 40-48 KiB of it were, and the kernel sat at 4.5 TB/s).  The small
@@ -140,7 +147,7 @@ __global__ void __launch_bounds__(640, TWO ? 5 : 2) gemm_stream64_kernel(stream_
     typedef typename lp<DT>::frag frag;
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0-3 multiply, 4-7 load the small operand, 8-9 the streamed one
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0-3 multiply, 4-7 load the small operand, 8 .. 8 + NLB - 1 the streamed one
     const int w = wave_all & 3;
     const int h = lane >> 5, l31 = lane & 31;
     const int64_t n0 = (int64_t)blockIdx.x * BN;
@@ -160,11 +167,11 @@ __global__ void __launch_bounds__(640, TWO ? 5 : 2) gemm_stream64_kernel(stream_
     // chunk ^ swizzle (as gemm_lp128.hip)
     if (wave_all >= 8) {
         // ---- streamed operand: wave 8 fills rows 0-15, wave 9 rows 16-31 of every K-tile (two pieces each)
-        const int half = wave_all - 8;
-        uint32_t voff[2];
+        const int half = wave_all - 8;       // (one of NLB loaders: rows half * 8 PPW ...)
+        uint32_t voff[PPW];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = (half * 2 + j) * 8 + (lane >> 3);
+        for (int j = 0; j < PPW; ++j) {
+            const int r = (half * PPW + j) * 8 + (lane >> 3);
             const int q = (lane & 7) ^ ((r >> 1) & 7);
             voff[j] = (uint32_t)(std::min<int64_t>(r, (int64_t)g.big_rows - n0 - 1) * g.ld_big * 2 + q * 16);   // rows past the edge re-read the last one
         }
@@ -173,9 +180,9 @@ __global__ void __launch_bounds__(640, TWO ? 5 : 2) gemm_stream64_kernel(stream_
             for (int u = 0; u < G; ++u) {
                 const int t = gi * G + u;
                 if (t < nk) {
-                    const uint32_t slot = lds_addr_of(smem + B_RING + (t % SB) * BLK + half * 2048);
+                    const uint32_t slot = lds_addr_of(smem + B_RING + (t % SB) * BLK + half * PPW * 1024);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < PPW; ++j) {
                         const char *src = big + (int64_t)(S64_ABL == 2 ? (t & 7) : phys(t)) * ROW_BYTES;
                         if (g.stream_nt) glds16_s<true>(src, voff[j], slot + j * 1024);      // (wave-uniform branch)
                         else glds16_s<false>(src, voff[j], slot + j * 1024);
@@ -187,7 +194,7 @@ __global__ void __launch_bounds__(640, TWO ? 5 : 2) gemm_stream64_kernel(stream_
         for (int gi = 0; gi < ng; ++gi) {
             // group gi has landed when at most the pieces of the SGB - 2 groups issued after it are outstanding (full groups
             // when they all exist); in the tail simply wait for everything
-            if ((gi + SGB - 1) * G <= nk) wait_vmcnt<2 * G * (SGB - 2)>();
+            if ((gi + SGB - 1) * G <= nk) wait_vmcnt<PPW * G * (SGB - 2)>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();          // group gi is ready; everybody is done with group gi - 1
@@ -309,7 +316,7 @@ void launch_form(mi355_ctx *ctx, hipStream_t s, const stream_args &g, uint32_t b
 {
     constexpr int LDS = ring_geom<MB, TWO>::LDS;
     lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_stream64_kernel<DT, MB, TWO>), LDS);
-    hipLaunchKernelGGL((gemm_stream64_kernel<DT, MB, TWO>), dim3((uint32_t)((g.big_rows + BN - 1) / BN), batch), dim3(640), LDS, s, g);
+    hipLaunchKernelGGL((gemm_stream64_kernel<DT, MB, TWO>), dim3((uint32_t)((g.big_rows + BN - 1) / BN), batch), dim3(512 + 64 * NLB), LDS, s, g);
 }
 
 template <int DT, int MB>
