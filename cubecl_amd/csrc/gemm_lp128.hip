@@ -230,7 +230,18 @@ gemm_lp128_kernel(gemm_args g)
 #endif
     const int kshift = nk <= 0 ? 0 : LP128_KSTAG == 1 ? (int)((tm + tn) % (uint32_t)nk) : LP128_KSTAG == 2 ? (int)((tm + tn) & 3u) % nk
                                    : LP128_KSTAG == 3 ? (int)(blockIdx.x % (uint32_t)nk) : 0;
-    auto stage = [&](int buf, int kt_rel) {
+#ifndef LP128_HYB
+#define LP128_HYB 0     // dev, 256 x 128 tile: 1 = the multiplying waves issue the B pieces themselves (measured, slower: below)
+#endif
+    // HYB (dev switch, off): the four loader waves fetch the A tile only (8 pieces each per K-tile) and the four multiplying
+    // waves the B tile (4 pieces each, issued behind the hand-over barrier).  Idea: twelve pieces per loader wave and K-tile
+    // pace the 256 x 128 tile at ~125 cycles per piece, and a third wave per SIMD does not fit beside 196-VGPR multiplying
+    // waves.  Measured, interleaved twice against the product (profiles/r03_tile_256x128.md): 4096 x 2048 x 4096 80.3 us against
+    // 72.4, 2560^2 x 4096 64.8-72.8 / 58.4, 4096 x 2048 x 8192 143 / 129 -- an LDS-DMA piece costs the wave that issues it far
+    // more than its slot between two MFMAs here (no scalar-base addressing behind the role branch), and the matrix pipe waits.
+    constexpr bool HYB = LP128_HYB && MI == 4 && SPEC;
+    constexpr int PIECES_L = HYB ? 2 * MI : PIECES;     // pieces per LOADER wave and K-tile
+    auto stage = [&](int buf, int kt_rel, bool do_a = true, bool do_b = true) {
         if ((LP128_ABL & 1) && kt_rel >= NS) return;
         int kt = kt0 + kt_rel;
         if (LP128_KSTAG) { kt = kt_rel + kshift; kt = kt0 + (kt >= nk ? kt - nk : kt); }
@@ -239,9 +250,11 @@ gemm_lp128_kernel(gemm_args g)
         const int64_t koff = (int64_t)kt * ROW_BYTES;
 #pragma unroll
         for (int j = 0; j < 2 * MI; ++j) {
-            if (g.nt_mask & 1u) glds16_s<true>(ubase_a + koff, va[j], lds_addr_of(la + (j * 4 + wave) * 1024));    // (uniform branches)
-            else glds16_s<false>(ubase_a + koff, va[j], lds_addr_of(la + (j * 4 + wave) * 1024));
-            if (j < 4) {                                                       // (row-major B: a K-tile is 64 rows of ldb elements)
+            if (do_a) {
+                if (g.nt_mask & 1u) glds16_s<true>(ubase_a + koff, va[j], lds_addr_of(la + (j * 4 + wave) * 1024));    // (uniform branches)
+                else glds16_s<false>(ubase_a + koff, va[j], lds_addr_of(la + (j * 4 + wave) * 1024));
+            }
+            if (j < 4 && do_b) {                                               // (row-major B: a K-tile is 64 rows of ldb elements)
                 if (g.nt_mask & 2u) glds16_s<true>(ubase_b + (BNN ? koff * g.ldb : koff), vb[j & 3], lds_addr_of(lb + (j * 4 + wave) * 1024));
                 else glds16_s<false>(ubase_b + (BNN ? koff * g.ldb : koff), vb[j & 3], lds_addr_of(lb + (j * 4 + wave) * 1024));
             }
@@ -393,9 +406,16 @@ gemm_lp128_kernel(gemm_args g)
         if (issues) {
 #pragma unroll
             for (int p = 0; p < AHEAD; ++p)
-                if (p < nk) stage(p % NS, p);
-            if (nk >= AHEAD) wait_vm<(AHEAD - 1) * PIECES>();                         // K-tile 0 landed; the other prologue tiles may fly
-            else if (nk == 2) wait_vm<PIECES>();
+                if (p < nk) stage(p % NS, p, true, !HYB);
+            if (nk >= AHEAD) wait_vm<(AHEAD - 1) * PIECES_L>();                       // K-tile 0 landed; the other prologue tiles may fly
+            else if (nk == 2) wait_vm<PIECES_L>();
+            else wait_vm<0>();
+        } else if constexpr (HYB) {                                                   // the multiplying waves' share: the B tiles
+#pragma unroll
+            for (int p = 0; p < AHEAD; ++p)
+                if (p < nk) stage(p % NS, p, false, true);
+            if (nk >= AHEAD) wait_vm<(AHEAD - 1) * 4>();
+            else if (nk == 2) wait_vm<4>();
             else wait_vm<0>();
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -405,12 +425,12 @@ gemm_lp128_kernel(gemm_args g)
             // the loader's whole K loop: wait for K-tile kt+1, meet the multiplying waves at their barrier inside K-tile kt
             // (everybody is then past K-tile kt-1 -- FULL: and done reading K-tile kt), refill the freed slot with K-tile kt+3
             for (int kt = 0; kt + 1 < nk; ++kt) {
-                if (kt + 2 < nk) wait_vm<PIECES>();
+                if (kt + 2 < nk) wait_vm<PIECES_L>();
                 else wait_vm<0>();
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                if (kt + AHEAD < nk) stage((kt + AHEAD) % NS, kt + AHEAD);
+                if (kt + AHEAD < nk) stage((kt + AHEAD) % NS, kt + AHEAD, true, !HYB);
             }
             return;                                         // a finished wave no longer counts at the workgroup's barriers
         }
@@ -439,6 +459,11 @@ gemm_lp128_kernel(gemm_args g)
                         else wait_vm<0>();
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    if constexpr (HYB) {            // my B pieces of K-tile kt+1 have landed; those of K-tile kt+2 may fly
+                        if (kt + 2 < nk) wait_vm<4>();
+                        else wait_vm<0>();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     if constexpr (FULL) {           // my reads of K-tile kt are complete: its slot is refilled right behind the barrier
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_sched_barrier(0);
@@ -448,6 +473,8 @@ gemm_lp128_kernel(gemm_args g)
                     // everybody is past K-tile kt-1: its buffer takes K-tile kt+3
                     if constexpr (!SPEC)
                         if (kt + AHEAD < nk) stage((kt + AHEAD) % NS, kt + AHEAD);
+                    if constexpr (HYB)
+                        if (kt + AHEAD < nk) stage((kt + AHEAD) % NS, kt + AHEAD, false, true);
                     const char *na = smem + ((kt + 1) % NS) * STG;
                     reads(B0{}, na, na + A_BYTES, 0);
                 }
