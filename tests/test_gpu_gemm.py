@@ -566,7 +566,7 @@ def test_row_major_b_through_the_strip_split_of_a_partly_filled_round(client, or
     """17 x 16 = 272 tiles of 256x256: AUTO cuts a strip off and splits its K (gemm.cpp plan_tail_split).  With row-major B the
     strip's K slices start k rows further down B (not k columns further along its rows) and a strip of columns starts at a column
     offset: same cut, same slabs, same fold -- the bits of the [N][K] launch."""
-    m, n, k = 4352, 4096, 512
+    m, n, k = 4352, 4096, 2048
     along, extent, splits = C.c_int32(), C.c_int64(), C.c_int32()
     d = _nn_desc(m, n, k, ElemType.BF16, ElemType.BF16)
     assert client.lib.mi355_gemm_tail_plan(C.byref(d), C.byref(along), C.byref(extent), C.byref(splits)) == N.OK and splits.value > 1
