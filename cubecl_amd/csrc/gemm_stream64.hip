@@ -115,15 +115,32 @@ template <int N> __device__ __forceinline__ void wait_vmcnt()
 }
 
 #ifndef S64_T1_G
-#define S64_T1_G 4      // dev: ring geometry of the two-workgroups-per-CU form with up to 32 small rows (G, SGA, SGB)
-#define S64_T1_SGA 2
-#define S64_T1_SGB 2
+#define S64_T1_G 3      // ring geometry of the two-workgroups-per-CU form with up to 32 small rows (G, SGA, SGB); round 3: (3, 3, 3) -- six
+#define S64_T1_SGA 3    // K-tiles of look-ahead on both operands in 72 KiB -- for (4, 2, 2): 8 x 57344 x 4096 95 -> 78 us, 16 x 32000 x 4096 54 -> 50,
+#define S64_T1_SGB 3    // 16 x 28672 x 8192 84.9 -> 81.5 on cold operands (profiles/r03_stream64_ring_geometry.md)
 #endif
 // Ring geometry per form: G = K-tiles per hand-over (one s_barrier per group), SGA / SGB = groups in the small / streamed ring.
+// Ring geometry of the one-workgroup-per-CU forms, re-tuned in round 3 on COLD operands (rounds 1-2 tuned on one operand set,
+// i.e. with the small operand always in the cache hierarchy).  What the cold runs want is look-ahead on the SMALL operand: the
+// K stagger makes every workgroup the first of its XCD to touch 1/32 of the small operand's K-tiles, and with (G, SGA, SGB) =
+// (4, 2, 6) its loaders ran four K-tiles ahead -- ~0.8 us against a ~2 us L2 miss.  Swept (profiles/r03_stream64_ring_geometry.md;
+// product of the time = (4, 2, 6) / (2, 3, 12)): up to 32 rows (8, 2, 3) -- eight K-tiles ahead on both operands -- 16 x 8192 x 8192
+// 30.7 -> 25.0 us cold, 22.9 -> 21.5 warm, 32 x 512 x 8192 20.8 -> 16.1; 33-64 rows (4, 3, 4): 64 x 8192 x 8192 34.5 -> 33.5 cold,
+// 25.1 -> 23.5 warm.
+#ifndef S64_O1_G
+#define S64_O1_G 8      // up to 32 small rows: (G, SGA, SGB)
+#define S64_O1_SGA 2
+#define S64_O1_SGB 3
+#endif
+#ifndef S64_O2_G
+#define S64_O2_G 4      // 33-64 small rows
+#define S64_O2_SGA 3
+#define S64_O2_SGB 4
+#endif
 template <int MB, bool TWO> struct ring_geom {
-    static constexpr int G = (TWO && MB == 1) ? S64_T1_G : MB == 2 ? 2 : 4;
-    static constexpr int SGA = (TWO && MB == 1) ? S64_T1_SGA : TWO ? 2 : (MB == 2 ? 3 : 2);
-    static constexpr int SGB = (TWO && MB == 1) ? S64_T1_SGB : TWO ? 5 : (MB == 2 ? 12 : 6);
+    static constexpr int G = (TWO && MB == 1) ? S64_T1_G : TWO ? 2 : MB == 2 ? S64_O2_G : S64_O1_G;
+    static constexpr int SGA = (TWO && MB == 1) ? S64_T1_SGA : TWO ? 2 : (MB == 2 ? S64_O2_SGA : S64_O1_SGA);
+    static constexpr int SGB = (TWO && MB == 1) ? S64_T1_SGB : TWO ? 5 : (MB == 2 ? S64_O2_SGB : S64_O1_SGB);
     static constexpr int LDS = SGA * G * MB * BLK + SGB * G * BLK;      // small ring + streamed ring: 128-144 KiB, or 64-72 KiB x 2
 };
 
