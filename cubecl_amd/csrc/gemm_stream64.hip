@@ -137,10 +137,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt()
 #define S64_O2_SGA 3
 #define S64_O2_SGB 4
 #endif
+#ifndef S64_T2_G
+#define S64_T2_G 2      // two workgroups per CU, 33-64 small rows; round 3: (2, 3, 4) for (2, 2, 5) -- 48 x 28672 x 4096 68.6 -> 61.5 us,
+#define S64_T2_SGA 3    // 40 x 16384 x 8192 56.9 -> 52.7, 64 x 32768 x 4096 78.8 -> 70.6, 64 x 28672 x 8192 and 64 x 14336 x 4096 ties (cold)
+#define S64_T2_SGB 4
+#endif
 template <int MB, bool TWO> struct ring_geom {
-    static constexpr int G = (TWO && MB == 1) ? S64_T1_G : TWO ? 2 : MB == 2 ? S64_O2_G : S64_O1_G;
-    static constexpr int SGA = (TWO && MB == 1) ? S64_T1_SGA : TWO ? 2 : (MB == 2 ? S64_O2_SGA : S64_O1_SGA);
-    static constexpr int SGB = (TWO && MB == 1) ? S64_T1_SGB : TWO ? 5 : (MB == 2 ? S64_O2_SGB : S64_O1_SGB);
+    static constexpr int G = (TWO && MB == 1) ? S64_T1_G : TWO ? S64_T2_G : MB == 2 ? S64_O2_G : S64_O1_G;
+    static constexpr int SGA = (TWO && MB == 1) ? S64_T1_SGA : TWO ? S64_T2_SGA : (MB == 2 ? S64_O2_SGA : S64_O1_SGA);
+    static constexpr int SGB = (TWO && MB == 1) ? S64_T1_SGB : TWO ? S64_T2_SGB : (MB == 2 ? S64_O2_SGB : S64_O1_SGB);
     static constexpr int LDS = SGA * G * MB * BLK + SGB * G * BLK;      // small ring + streamed ring: 128-144 KiB, or 64-72 KiB x 2
 };
 
