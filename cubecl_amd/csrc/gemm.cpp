@@ -84,8 +84,13 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
         // * a workgroup walks its K-tiles alone (~0.15 us each): K beyond 8192 needs enough workgroups for that to be hidden
         //   (64 x 4096 x 16384 38 us against 33, 16 x 4096 x 14336 34.5 / 26.7; up to 8192 and 32 rows it wins with any grid: 32 x 512 x 8192
         //   17.8 / 22.2, 512 x 16 x 8192 17.2 / 21.8, 128 x 16 x 8192 17.1 / 18.9).
-        const int64_t max_wgs = std::min(d.m, d.n) <= 32 ? 2048 : 512;
-        if (small_bytes <= (1ll << 21) && wgs <= max_wgs && (nk64 <= 64 || (nk64 <= 128 && (wgs >= 64 || std::min(d.m, d.n) <= 32)) || wgs >= 192))
+        // Round 3, after the ring geometry was re-tuned on cold operands (profiles/r03_stream64_ring_geometry.md; 94-shape table
+        // profiles/r03_few_rows_audit.txt): any row count walks K up to 8192 alone from 8 workgroups up (48 x 512 x 8192 18.9 us against 23.5, 64 x 512 x 8192
+        // 18.9 / 23.1); with 17-32 rows the large grids go to the 128x128 kernel from 768 workgroups (32 x 28672 x 4096 46.7 us
+        // against 51.2, 32 x 57344 x 4096 83.2 / 88.2; 32 x 16384 x 8192 at 512 workgroups: 45 against 71 the other way).
+        const int64_t rows = std::min(d.m, d.n);
+        const int64_t max_wgs = rows <= 16 ? 2048 : rows <= 32 ? 768 : 512;
+        if (small_bytes <= (1ll << 21) && wgs <= max_wgs && (nk64 <= 64 || (nk64 <= 128 && (wgs >= 8 || rows <= 32)) || wgs >= 192))
             return MI355_GEMM_ALGO_STREAM64;
     }
     // one or two rows (or columns): HBM-bound on the other operand; stream it once with dot products, no MFMA tile to fill

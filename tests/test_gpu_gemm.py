@@ -1022,6 +1022,7 @@ def test_output_bound_shapes_select_the_small_tile(client):
     assert sel(4, 8192, 8192) == sel(16, 8192, 8192) == sel(64, 8192, 8192) == sel(8192, 64, 8192) == N.GEMM_ALGO_STREAM64   # 3 ... 64 rows: no split-K
     assert sel(64, 32768, 4096) == sel(64, 4096, 16384) == sel(65, 8192, 8192) == sel(64, 64, 8192) == N.GEMM_ALGO_LP_128   # many rounds / few long workgroups / 65 rows
     assert sel(64, 64, 4096) == sel(64, 2048, 8192) == sel(32, 8192, 16384) == sel(16, 28672, 8192) == sel(64, 14336, 4096) == N.GEMM_ALGO_STREAM64
+    assert sel(48, 512, 8192) == sel(64, 512, 8192) == N.GEMM_ALGO_STREAM64 and sel(32, 28672, 4096) == sel(32, 57344, 4096) == N.GEMM_ALGO_LP_128   # round 3
     assert sel(64, 8192, 28672) == sel(64, 28672, 8192) == N.GEMM_ALGO_LP_128        # small operand past 2 MiB / 64 rows over more than 512 workgroups
     assert sel(8192, 64, 14336) == N.GEMM_ALGO_STREAM64                               # 1.75 MiB of small operand still streams
     assert sel(4, 2048, 4096) == sel(384, 4, 8192) == sel(3, 512, 14336) == sel(4096, 4, 14336) == N.GEMM_ALGO_SKINNY   # 3-4 rows, fewer than 192 streaming workgroups
