@@ -399,24 +399,28 @@ gemm_lp128_kernel(gemm_args g)
         //           gemm_lp256w4.hip does.  (The first form of this kernel refilled the slot of K-tile kt-1 with K-tile kt+2:
         //           one K-tile in flight, fetch and wait serialised, ~2 000 cycles per K-tile of 1 024 MFMA cycles.)
         static_assert(NS == 4 || NS == 3, "the counted waits below are written for three or four stages");
-        constexpr bool FULL = NS == 3;               // every slot of the ring is refilled as soon as its K-tile is consumed
-        constexpr int AHEAD = 3;                     // K-tiles issued ahead of the one being multiplied
-        static_assert(AHEAD == (FULL ? NS : NS - 1), "ring depth and issue distance");
+#ifndef LP128_FULL4
+#define LP128_FULL4 0   // dev: the four-stage ring refilled in place as well (four K-tiles ahead); interleaved twice over ten skinny / mid-size
+                        // shapes on cold operands: no effect beyond run-to-run noise (+-5 %), as round 2's five-stage ring
+#endif
+        constexpr bool FULL = NS == 3 || LP128_FULL4;  // every slot of the ring is refilled as soon as its K-tile is consumed
+        constexpr int AHEAD = FULL ? NS : NS - 1;      // K-tiles issued ahead of the one being multiplied
+        // at most `n` whole K-tiles of this wave's pieces may still be in flight
+        auto wait_tiles = [](int n, auto pieces) {
+            constexpr int P = decltype(pieces)::value;
+            if (n >= 3) wait_vm<3 * P>(); else if (n == 2) wait_vm<2 * P>(); else if (n == 1) wait_vm<P>(); else wait_vm<0>();
+        };
         const bool issues = !SPEC || loader, multiplies = !SPEC || !loader;
         if (issues) {
 #pragma unroll
             for (int p = 0; p < AHEAD; ++p)
                 if (p < nk) stage(p % NS, p, true, !HYB);
-            if (nk >= AHEAD) wait_vm<(AHEAD - 1) * PIECES_L>();                       // K-tile 0 landed; the other prologue tiles may fly
-            else if (nk == 2) wait_vm<PIECES_L>();
-            else wait_vm<0>();
+            wait_tiles(min(nk, AHEAD) - 1, std::integral_constant<int, PIECES_L>{});     // K-tile 0 landed; the other prologue tiles may fly
         } else if constexpr (HYB) {                                                   // the multiplying waves' share: the B tiles
 #pragma unroll
             for (int p = 0; p < AHEAD; ++p)
                 if (p < nk) stage(p % NS, p, false, true);
-            if (nk >= AHEAD) wait_vm<(AHEAD - 1) * 4>();
-            else if (nk == 2) wait_vm<4>();
-            else wait_vm<0>();
+            wait_tiles(min(nk, AHEAD) - 1, std::integral_constant<int, 4>{});
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -425,8 +429,7 @@ gemm_lp128_kernel(gemm_args g)
             // the loader's whole K loop: wait for K-tile kt+1, meet the multiplying waves at their barrier inside K-tile kt
             // (everybody is then past K-tile kt-1 -- FULL: and done reading K-tile kt), refill the freed slot with K-tile kt+3
             for (int kt = 0; kt + 1 < nk; ++kt) {
-                if (kt + 2 < nk) wait_vm<PIECES_L>();
-                else wait_vm<0>();
+                wait_tiles(min(AHEAD - 2, nk - kt - 2), std::integral_constant<int, PIECES_L>{});   // K-tile kt+1 landed; the younger ones may fly
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
@@ -455,13 +458,11 @@ gemm_lp128_kernel(gemm_args g)
                 if (kt + 1 < nk) {
                     if constexpr (!SPEC) {
                         // K-tile kt+1 landed: only tile kt+2 (issued in the previous iteration or the prologue) may still fly
-                        if (kt + 2 < nk) wait_vm<PIECES>();
-                        else wait_vm<0>();
+                        wait_tiles(min(AHEAD - 2, nk - kt - 2), std::integral_constant<int, PIECES>{});
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if constexpr (HYB) {            // my B pieces of K-tile kt+1 have landed; those of K-tile kt+2 may fly
-                        if (kt + 2 < nk) wait_vm<4>();
-                        else wait_vm<0>();
+                        wait_tiles(min(AHEAD - 2, nk - kt - 2), std::integral_constant<int, 4>{});
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if constexpr (FULL) {           // my reads of K-tile kt are complete: its slot is refilled right behind the barrier
