@@ -691,7 +691,10 @@ int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
     const bool f8 = is_fp8(d.dtype_ab);
     const int64_t esz = f8 ? 1 : 2;
     const int64_t nk = d.k / (ROW_BYTES / esz);
-    const int64_t want = 2 * (int64_t)ctx->props.num_streaming_multiprocessors;
+#ifndef LP128_WANT_MULT
+#define LP128_WANT_MULT 2   // workgroups the split aims at, in units of CUs
+#endif
+    const int64_t want = LP128_WANT_MULT * (int64_t)ctx->props.num_streaming_multiprocessors;
 #ifndef LP128_SPLIT_RULE
 #define LP128_SPLIT_RULE 1   // dev: 0 = round 1's rule (any launch of fewer than one tile per CU with 8+ K-tiles)
 #endif
@@ -704,11 +707,18 @@ int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
     // them unless the tiles are a handful.
     const bool long_k = LP128_SPLIT_RULE == 0 || (nk >= tiles && (nk >= 48 || tiles <= 16));
     if (tiles < want / 2 && nk >= 8 && long_k && batch <= 65535) {
-        int64_t splits = std::min<int64_t>({(want + tiles - 1) / tiles, nk / 4, 32});
-        const int64_t per = (nk + splits - 1) / splits;
-        splits = (nk + per - 1) / per;                                      // no empty slices
         const int64_t slab = d.batch * d.m * d.n;
         const int64_t operand_bytes = (d.m * d.k + d.n * d.k) * esz * d.batch;
+        // The slab traffic (one f32 write + one read per slice and output) must stay below twice the operand stream.  Until
+        // round 3 a split count beyond that bound was REJECTED (no split at all) instead of capped: 512 x 512 x 8192 wanted
+        // 32 slices, was allowed 16 and ran on 16 workgroups -- 68.7 us against 20.7 with 16 slices; 1024^2 x 4096 37.7 -> 21.6,
+        // 1024 x 512 x 8192 69 -> 25.5 (cold operands, interleaved; profiles/r03_split_k_cap.txt).
+        const int64_t by_traffic = slab > 0 ? (2 * operand_bytes) / (slab * 8) : 1;
+        int64_t splits = std::min<int64_t>({(want + tiles - 1) / tiles, nk / 4, 32, by_traffic});
+        if (splits > 1) {
+            const int64_t per = (nk + splits - 1) / splits;
+            splits = (nk + per - 1) / per;                                  // no empty slices
+        }
         float *ws = nullptr;
         if (splits > 1 && splits * slab * 8 <= 2 * operand_bytes &&
             splitk_scratch(ctx, s, (size_t)(splits * slab) * sizeof(float), &ws) == MI355_OK) {
