@@ -705,7 +705,12 @@ int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
     // 161 / 131; 112 x 16 9.3 / 18.3, 112 x 64 26.3 / 38.9; 128 x 16 9.9 / 20.6, 128 x 128 50.5 / 46.5; 160 x 32 16.6 /
     // 34.5; 192 x 64 28 / 49; 224 x 128 (128 x 28672 x 8192) 104 / 142.  Rule: at least as many K-tiles as tiles, and 48 of
     // them unless the tiles are a handful.
-    const bool long_k = LP128_SPLIT_RULE == 0 || (nk >= tiles && (nk >= 48 || tiles <= 16));
+    // Round 3, re-measured on cold operands with the slice count CAPPED by the slab-traffic bound (below) instead of the split
+    // being rejected beyond it (profiles/r03_split_rule_cold.txt, rule against "always split", interleaved twice): with at most
+    // 128 tiles splitting never loses and wins where the bound leaves two or more slices (32 tiles x 32 K-tiles 20.7 -> 15.3 us,
+    // 64 x 32 20.6 -> 17.6, 72 x 64 36.5 -> 30.1, 96 x 64 37.5 -> 30.7, 128 x 64 37.4 -> 33.2); from 160 tiles up it loses unless K is
+    // long against the tile count (192 x 64 38.6 against 50.4 split, 224 x 128 79 / 110).
+    const bool long_k = LP128_SPLIT_RULE == 0 || tiles <= 128 || (nk >= tiles && nk >= 48);
     if (tiles < want / 2 && nk >= 8 && long_k && batch <= 65535) {
         const int64_t slab = d.batch * d.m * d.n;
         const int64_t operand_bytes = (d.m * d.k + d.n * d.k) * esz * d.batch;

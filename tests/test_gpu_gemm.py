@@ -237,8 +237,9 @@ def test_split_k_skinny_shapes(client, oracle, m, n, k, out):
 
 @pytest.mark.parametrize("m,n,k", [(128, 14336, 1024), (96, 6144, 2048), (128, 4096, 2048), (256, 4096, 4096), (128, 3072, 1024)])
 def test_lp128_on_both_sides_of_the_split_rule(client, oracle, m, n, k):
-    # the launcher splits K only when there are at least as many K-tiles as tiles (and 48 of them unless the tiles are a
-    # handful): 112 x 16, 48 x 32, 32 x 32, 24 x 16 stay whole, 64 x 64 is split.  Same answers either way.
+    # the launcher splits K up to 128 tiles (beyond: only when there are at least as many K-tiles as tiles and 48 of them) and
+    # caps the slice count by the slab-traffic bound: 112 x 16 and 24 x 16 stay whole (the bound leaves one slice), 48 x 32,
+    # 32 x 32 and 64 x 64 are split (round 3; rounds 1-2 kept the first two whole).  Same answers either way.
     run_case(client, oracle, m, n, k, ElemType.BF16, ElemType.BF16, True, ALGOS["lp128"])
 
 
