@@ -719,7 +719,10 @@ int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
         // 32 slices, was allowed 16 and ran on 16 workgroups -- 68.7 us against 20.7 with 16 slices; 1024^2 x 4096 37.7 -> 21.6,
         // 1024 x 512 x 8192 69 -> 25.5 (cold operands, interleaved; profiles/r03_split_k_cap.txt).
         const int64_t by_traffic = slab > 0 ? (2 * operand_bytes) / (slab * 8) : 1;
-        int64_t splits = std::min<int64_t>({(want + tiles - 1) / tiles, nk / 4, 32, by_traffic});
+        // slices so that tiles x slices stays WITHIN the two-workgroups-per-CU residency (floor, not ceil: 144 tiles x 4 slices = 576
+        // workgroups ran a partial second round -- 768 x 3072 x 14336 151 -> 118 us, 1536 x 2048 x 16384 205 -> 177 with 3 and 2 slices;
+        // profiles/r03_split_count_floor.txt)
+        int64_t splits = std::min<int64_t>({std::max<int64_t>(want / tiles, 1), nk / 4, 32, by_traffic});
         if (splits > 1) {
             const int64_t per = (nk + splits - 1) / splits;
             splits = (nk + per - 1) / per;                                  // no empty slices
