@@ -226,7 +226,11 @@ gemm_lp128_kernel(gemm_args g)
                         // 8 = no C stores (staging kept), 16 = no epilogue at all
 #endif
 #ifndef LP128_NT
-#define LP128_NT -1     // non-temporal C stores: -1 = every form but the single-stage one (dev: 0 never, 1 always)
+#define LP128_NT 1      // non-temporal C stores: 1 = every form (round 3); -1 = every form but the single-stage one (round 2); 0 never.
+                        // Round 2 kept plain stores in the single-stage form on measurements with ONE output buffer (the 128 MiB of C stayed
+                        // in the Infinity Cache: 27.1 us plain against 28.6 nt at 8192 x 8192 x 64).  With launches rotating through output
+                        // buffers the cache only delays the write-back: 38.0 us plain against 31.8 nt, 8192 x 8192 x 128 47.6 / 39.5,
+                        // 16384 x 4096 x 128 47.4 / 40.0 (interleaved, profiles/r03_output_bound_nt_stores.txt).
 #endif
     const int kshift = nk <= 0 ? 0 : LP128_KSTAG == 1 ? (int)((tm + tn) % (uint32_t)nk) : LP128_KSTAG == 2 ? (int)((tm + tn) & 3u) % nk
                                    : LP128_KSTAG == 3 ? (int)(blockIdx.x % (uint32_t)nk) : 0;
