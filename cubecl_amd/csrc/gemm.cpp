@@ -102,11 +102,16 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
     // 256x256 workgroup (alone on its CU) serialises them.  bf16, 8192 x 8192 x K (tools/dev/shortk_probe.py): K = 64 32.3 us
     // against 41.9, K = 128 37.1 against 38.9 (persistent), K = 192 40.9 / 43.0, K = 256 46.8 / 49.0; 16384 x 8192 x 64
     // 51.6 / 68.8.  A single round (4096 x 4096: 256 tiles) stays with the large tile (10.6 us against 12.2).
-    // Round 3, cold operands (launches rotating through operand sets larger than the Infinity Cache, tools/ab_algos.py): the
-    // window shrinks to K <= 128 -- at K = 192 / 256 the persistent 256x256 kernel is ahead once the C stores have to reach HBM
-    // (8192 x 8192 x 192: 48.4 us against 54.7, x 256: 54.6 / 61.6, 16384 x 8192 x 256: 88.4 / 100.2, 8192 x 6144 x 256: 36.7 / 45.2);
-    // K = 128 is a tie (44.3 / 45.7, 67.5 / 70.5, 52.3 / 51.7), K = 64 has one K-tile only (34.5 us against 46.4 on the large tile).
-    if (mid && d.k <= 128 && ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch > 256) return MI355_GEMM_ALGO_LP_128;
+    // Round 3, cold operands (launches rotating through operand sets larger than the Infinity Cache, tools/ab_algos.py).  With the
+    // single-stage form's C stores non-temporal (gemm_lp128.hip LP128_NT; with plain stores the window had shrunk to K <= 128 on
+    // cold buffers) it wins up to K = 192 everywhere measured and up to K = 256 on grids of at most 1280 tiles of 256x256
+    // (8192 x 8192 x 192: 42.1 us against 48.2 persistent, x 256: 47.5 / 54.7, 8192 x 4096 x 256: 26.1 / 28.7, 12288 x 8192 x 192: 60.6 / 67.0;
+    // 16384 x 8192 x 256: 96.1 / 90.5 the other way, 8192 x 6144 x 256 a tie; K = 320 is past the single-stage form: 68 / 59;
+    // profiles/r03_short_k_cold.txt, r03_short_k_cold_nt_stores.txt).
+    {
+        const int64_t tiles256 = ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch;
+        if (mid && tiles256 > 256 && (d.k <= 192 || (d.k <= 256 && tiles256 <= 1280))) return MI355_GEMM_ALGO_LP_128;
+    }
     // at most 128 rows (or columns) over many tiles: a 256-row tile multiplies at least half zeros and streams no faster --
     // 64 x 128256 x 4096: 192 us on the 128x128 kernel against 222
     if (mid && std::min(d.m, d.n) <= 128) return MI355_GEMM_ALGO_LP_128;

@@ -1015,8 +1015,8 @@ def test_output_bound_shapes_select_the_small_tile(client):
         d = N.GemmDesc(m=m, n=n, k=k, batch=batch, lda=k, ldb=k, ldc=n, stride_a=m * k, stride_b=n * k, stride_c=m * n,
                        dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_BF16, trans_a=0, trans_b=1, algo=0)
         return ops.gemm_select(client, d)
-    assert sel(8192, 8192, 64) == sel(8192, 8192, 128) == sel(16384, 8192, 128) == N.GEMM_ALGO_LP_128   # several rounds, K <= 128
-    assert sel(8192, 8192, 256) == sel(16384, 8192, 192) == N.GEMM_ALGO_LP_256P        # ... beyond: the persistent large tile (cold operands, round 3)
+    assert sel(8192, 8192, 64) == sel(8192, 8192, 256) == sel(16384, 8192, 192) == N.GEMM_ALGO_LP_128   # several rounds, K <= 192 (<= 256 up to 1280 tiles)
+    assert sel(16384, 8192, 256) == sel(8192, 8192, 320) == N.GEMM_ALGO_LP_256P         # ... beyond: the persistent large tile (cold operands, round 3)
     assert sel(4096, 4096, 64) == N.GEMM_ALGO_LP_256W4                 # one round of 256 tiles: the large tile
     assert sel(8192, 8192, 320) in (N.GEMM_ALGO_LP_256P, N.GEMM_ALGO_LP_256Q, N.GEMM_ALGO_LP_256W4)
     assert sel(1, 8192, 8192) == sel(8192, 2, 4096) == N.GEMM_ALGO_SKINNY
