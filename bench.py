@@ -781,7 +781,9 @@ def main():
                       (64, 28672, 8192, 1), (128, 28672, 8192, 1), (4096, 4096, 4096, 1), (6144, 6144, 6144, 1), (4608, 4096, 8192, 1),
                       (2048, 2048, 2048, 1), (4096, 2048, 4096, 1),
                       # the reference's default rhs layout (row-major [K][N], TensorHandle::new_contiguous): staged natively, no re-layout
-                      (8192, 8192, 8192, 0), (4096, 4096, 4096, 0), (2048, 2048, 2048, 0)]
+                      (8192, 8192, 8192, 0), (4096, 4096, 4096, 0), (2048, 2048, 2048, 0),
+                      # ... and the decode case in that layout: few rows of x times a row-major weight [K][N]
+                      (1, 8192, 8192, 0), (16, 8192, 8192, 0), (16, 28672, 8192, 0), (64, 28672, 8192, 0)]
             for (m, n, k, tb) in shapes:
                 # Cold operands (advisor, round 2): a 128 MiB operand re-read by 20 back-to-back launches is partly served by the
                 # 256 MiB Infinity Cache, which flatters HBM-bound shapes.  Launches rotate through as many operand sets as it

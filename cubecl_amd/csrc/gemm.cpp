@@ -55,10 +55,16 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
     // K-contiguous operands, so a launch they would win goes through the re-layout pass (GENERIC here = "re-lay out, then
     // select again" in mi355_gemm) -- a 16 x 8192 x 8192 product costs 22 us there + 50 us of transposition against ~140 us
     // on 32 tiles of 256x256.
+    // Round 3, late: that held while B was the SMALL operand.  With few ROWS of A (the decode case: x [M][K] times a row-major
+    // weight [K][N]) B is the streamed operand and the transposition pass reads and writes all of it before the product reads it
+    // again -- cold operands, interleaved (profiles/r03_nn_few_rows.txt), re-layout + streaming kernel against the 128x128 kernel's
+    // native NN form (split-K): 1 x 8192 x 8192 69.6 -> 35.0 us, 16 x 8192 x 8192 64.7 -> 35.9, 64 x 8192 x 8192 67.0 -> 41.7,
+    // 16 x 28672 x 8192 270 -> 78.7 (the [N][K] form on its streaming kernel: 76.1), 64 x 28672 x 8192 290 -> 85.2 ([N][K]: 93.1),
+    // 8 x 57344 x 4096 276 -> 81.3, 32 x 4096 x 4096 24.4 -> 16.7.  Few COLUMNS (B small: at most 64 x K) keep the re-layout.
     if (!d.trans_b) {
         const int64_t tiles256 = ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch;
         const bool native = (std::min(d.m, d.n) > 128 && big4 && tiles256 > 128) || (std::min(d.m, d.n) > 64 && mid);
-        if (!native) return MI355_GEMM_ALGO_GENERIC;
+        if (!native) return (mid && d.m <= d.n) ? MI355_GEMM_ALGO_LP_128 : MI355_GEMM_ALGO_GENERIC;
     }
     // 3 ... 64 rows (or columns): 32 streamed rows x the whole K per workgroup, loader waves, no split-K (gemm_stream64.hip).
     // Interleaved against the split-K 128x128 path over 60 shapes (tools/dev/stream64_probe.py): faster by 5-50 % whenever its

@@ -620,9 +620,14 @@ def test_row_major_b_refusals_of_the_tile_kernel(client, oracle):
         assert rc == N.E_UNSUPPORTED
         d.algo = N.GEMM_ALGO_AUTO
         assert ops.gemm_relayout_plan(client, d) == (False, True) and ops.gemm_select(client, d) != N.GEMM_ALGO_GENERIC
-    # few rows: the streaming kernels only exist for K-contiguous operands, so B is re-laid out for them
-    d = _nn_desc(16, 8192, 8192, ElemType.BF16, ElemType.BF16)
+    # few COLUMNS: B is the small operand, re-laid out for the streaming kernel (which only exists for K-contiguous operands);
+    # few ROWS (x [M][K] times a row-major weight [K][N], the decode case): B is the streamed operand and is never transposed --
+    # the 128x128 kernel stages it natively
+    d = _nn_desc(8192, 16, 8192, ElemType.BF16, ElemType.BF16)
     assert ops.gemm_relayout_plan(client, d) == (False, True) and ops.gemm_select(client, d) == N.GEMM_ALGO_STREAM64
+    for m in (1, 16, 64):
+        d = _nn_desc(m, 8192, 8192, ElemType.BF16, ElemType.BF16)
+        assert ops.gemm_relayout_plan(client, d) == (False, False) and ops.gemm_select(client, d) == N.GEMM_ALGO_LP_128
 
 
 # ---- layouts the MFMA kernels do not stage directly: re-laid out K-contiguous into library scratch first ------------

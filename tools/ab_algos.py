@@ -17,6 +17,7 @@ import bench  # noqa: E402
 from cubecl_amd import ElemType, Mi355Runtime, TensorHandle  # noqa: E402
 from cubecl_amd import _native as N  # noqa: E402
 
+VERBOSE = False
 NAMES = {"auto": 0, "generic": 1, "f32": 2, "lp128": 3, "lp256": 4, "lp256w4": 5, "lp256p": 6, "lp256q": 7, "skinny": 8, "stream64": 9,
          "lp256x128": 10}
 BY_ID = {v: k for k, v in NAMES.items()}
@@ -46,6 +47,8 @@ def measure(client, ev, shapes, algos, rounds=5, nn=False, iters=20, cold=True):
                     rc = lib.mi355_gemm(ctx, None, C.byref(d), sa.device_ptr(), sb.device_ptr(), sc.device_ptr())
                     if rc != N.OK:
                         raise RuntimeError(rc)
+                if VERBOSE:
+                    print(f"[ab] {m}x{n}x{k} {a} nn={nn} sets={nsets}", file=sys.stderr, flush=True)
                 try:
                     times[a].append(bench.time_op(client, ev, call, iters, warmup=3) * 1e3)
                 except RuntimeError:
@@ -61,10 +64,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--nn", action="store_true")
+    ap.add_argument("--verbose", action="store_true", help="name every measurement on stderr before it starts")
     ap.add_argument("--warm", action="store_true", help="one operand set (Infinity-Cache-warm operands)")
     ap.add_argument("--algos", default="auto,lp128,lp256x128,lp256w4")
     ap.add_argument("shapes", nargs="+")
     args = ap.parse_args()
+    global VERBOSE
+    VERBOSE = args.verbose
     client = Mi355Runtime.client()
     ev = bench.Events(client)
     shapes = [tuple(int(x) for x in s.split("x")) for s in args.shapes]
