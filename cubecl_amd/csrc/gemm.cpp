@@ -47,6 +47,17 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
         if (gemm_f32_mfma_supports(d, a, b, c)) return MI355_GEMM_ALGO_F32_MFMA;
         return MI355_GEMM_ALGO_GENERIC;
     }
+    // A stored [K][M] with a row-major B (lhs^T . grad_out, the weight-gradient product of a training step): the 128x128 kernel
+    // stages both natively (gemm_lp128.hip ATN) -- taken exactly when that kernel would be chosen for the same shape with a
+    // K-contiguous A; where a 256-tile or a streaming kernel would win, A is transposed into scratch first (GENERIC = "re-lay
+    // out, then select again": 8192^3 797 us that way against ~1 250 on 4096 tiles of 128^2) and B stays as it is.
+    if (d.trans_a) {
+        if (d.trans_b || !gemm_lp128_supports(d, a, b, c)) return MI355_GEMM_ALGO_GENERIC;
+        static const char aligned_dummy __attribute__((aligned(16))) = 0;
+        mi355_gemm_desc e = d;
+        e.trans_a = 0; e.lda = d.k; e.stride_a = d.stride_a == 0 ? 0 : d.m * d.k;
+        return select(e, &aligned_dummy, b, c) == MI355_GEMM_ALGO_LP_128 ? MI355_GEMM_ALGO_LP_128 : MI355_GEMM_ALGO_GENERIC;
+    }
     const bool big = gemm_lp256_supports(d, a, b, c);
     const bool big4 = gemm_lp256w4_supports(d, a, b, c);
     const bool mid = gemm_lp128_supports(d, a, b, c);
@@ -169,12 +180,19 @@ bool plan_relayout(const mi355_gemm_desc &d, const void *a, const void *b, const
     p.b = (!d.trans_b && (d.dtype_ab != MI355_DTYPE_F32 || ragged_k || b_misaligned || (d.n & 3))) ||
           (d.trans_b && (ragged_k || b_misaligned));
     if (!p.a && !p.b) return false;
-    p.nd = d;
-    p.nd.k = p.kpad;
-    if (p.a) { p.nd.trans_a = 0; p.nd.lda = p.kpad; p.nd.stride_a = d.stride_a == 0 ? 0 : d.m * p.kpad; }
-    if (p.b) { p.nd.trans_b = 1; p.nd.ldb = p.kpad; p.nd.stride_b = d.stride_b == 0 ? 0 : d.n * p.kpad; }
     static const char aligned_dummy __attribute__((aligned(16))) = 0;
-    return select(p.nd, p.a ? &aligned_dummy : a, p.b ? &aligned_dummy : b, c) != MI355_GEMM_ALGO_GENERIC;
+    auto planned = [&](bool pa, bool pb) {
+        p.a = pa; p.b = pb;
+        p.nd = d;
+        p.nd.k = p.kpad;
+        if (p.a) { p.nd.trans_a = 0; p.nd.lda = p.kpad; p.nd.stride_a = d.stride_a == 0 ? 0 : d.m * p.kpad; }
+        if (p.b) { p.nd.trans_b = 1; p.nd.ldb = p.kpad; p.nd.stride_b = d.stride_b == 0 ? 0 : d.n * p.kpad; }
+        return select(p.nd, p.a ? &aligned_dummy : a, p.b ? &aligned_dummy : b, c) != MI355_GEMM_ALGO_GENERIC;
+    };
+    // A 16-bit row-major B that is only here because A needs a new layout stays where it is when a tile kernel stages it natively
+    // (until late round 3 both operands were transposed: 2048 x 2048 x 8192 with A stored [K][M] 110.6 us against 95.5 with B left alone)
+    if (p.a && p.b && !d.trans_b && !ragged_k && !b_misaligned && d.dtype_ab != MI355_DTYPE_F32 && planned(true, false)) return true;
+    return planned(p.a, p.b);
 }
 
 int32_t relayout_for_mfma(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c,

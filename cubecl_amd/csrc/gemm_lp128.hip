@@ -130,7 +130,7 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void *p)
 // (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"); at eight pieces per wave and K-tile that is more than the 512 cycles
 // the K-tile's 16 MFMAs take, so a wave that does both starves its matrix pipe.  The loader waves own `vmcnt`; the
 // multiplying waves see the ring only through the one s_barrier per K-tile.
-template <int DT, int DT_C, int NS = 2, bool SPEC = false, bool BNN = false, int MI = 2>
+template <int DT, int DT_C, int NS = 2, bool SPEC = false, bool BNN = false, int MI = 2, bool ATN = false>
 __global__ void __launch_bounds__(SPEC ? 512 : 256,
                                   // waves per SIMD the register budget must allow (fp8 fragments are twice as wide: three, not four)
                                   NS == 1 ? ((DT == MI355_DTYPE_F8E4M3 || DT == MI355_DTYPE_F8E5M2) ? 3 : 4) : NS == 2 ? (SPEC ? 4 : 2) : SPEC ? 2 : 1)
@@ -141,6 +141,7 @@ gemm_lp128_kernel(gemm_args g)
     constexpr int BMK = geom<MI>::BMK, A_BYTES = geom<MI>::A_BYTES, STG = geom<MI>::STAGE;
     constexpr int PIECES = 2 * MI + 4;           // LDS-DMA instructions per wave and K-tile (A: BMK / 32, B: 4)
     static_assert(!BNN || DT == MI355_DTYPE_BF16 || DT == MI355_DTYPE_F16, "row-major B: 16-bit operands");
+    static_assert(!ATN || (BNN && MI == 2), "A stored [K][M]: together with a row-major B, 128 x 128 tile");
     // [stage][operand][16 KiB]; one array only (a second __shared__ object de-pipelines LDS-DMA
     // loops: guide section 5, ".s-level traps" (a))
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -166,14 +167,20 @@ gemm_lp128_kernel(gemm_args g)
     const char *__restrict__ B = static_cast<const char *>(g.b) + batch * g.stride_b * ESZ;
 
     // ---- DMA map: wave w, instruction j fills rows (j*4+w)*8 .. +7 of the tile ----------------
-    const char *ubase_a = A + m0 * g.lda * ESZ;                                   // uniform: first row of the tile
+    const char *ubase_a = ATN ? A + m0 * ESZ : A + m0 * g.lda * ESZ;              // uniform: first row of the tile (first column, A stored [K][M])
     const char *ubase_b = BNN ? B + n0 * ESZ : B + n0 * g.ldb * ESZ;              // ... first column, for row-major B
     uint32_t va[2 * MI], vb[4];                             // per-lane byte offsets from those (rows clamped at the edges)
 #pragma unroll
     for (int j = 0; j < 2 * MI; ++j) {
         const int r = (j * 4 + wave) * 8 + (lane >> 3);    // tile row this lane fills
         const int q = (lane & 7) ^ ((r >> 1) & 7);          // logical chunk fetched into physical chunk lane&7
-        va[j] = (uint32_t)(min((int64_t)r, g.m - 1 - m0) * g.lda * ESZ + q * 16);
+        if constexpr (ATN) {
+            // A stored [K][M] (the lhs of a weight-gradient product, lhs^T . grad): the A tile is 64 k-rows x 128 m, the mirror
+            // image of the row-major B tile -- same blocks of [4 k][32 m], same pieces (see vb below)
+            const int64_t col = (lane >> 4) * 32 + (lane & 3) * 8;
+            va[j] = (uint32_t)(((j * 4 + wave) * 4 + ((lane & 15) >> 2)) * g.lda * ESZ + min(col, g.m - 8 - m0) * ESZ);
+        } else
+            va[j] = (uint32_t)(min((int64_t)r, g.m - 1 - m0) * g.lda * ESZ + q * 16);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -189,6 +196,7 @@ gemm_lp128_kernel(gemm_args g)
     }
     // row-major B: this lane's part of a transposing read -- block wn*2 + j of a block row, row (lane%16)/4, 16-lane group, 8 B per lane
     const int rbn = BNN ? wn * 2 * 256 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8 : 0;
+    const int ran = ATN ? wm * 2 * 256 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8 : 0;
 
     // ---- fragment read offsets (bytes inside one operand tile) --------------------------------
     int ra[MI], rb[2], fa[MI], fb[2];
@@ -255,8 +263,8 @@ gemm_lp128_kernel(gemm_args g)
 #pragma unroll
         for (int j = 0; j < 2 * MI; ++j) {
             if (do_a) {
-                if (g.nt_mask & 1u) glds16_s<true>(ubase_a + koff, va[j], lds_addr_of(la + (j * 4 + wave) * 1024));    // (uniform branches)
-                else glds16_s<false>(ubase_a + koff, va[j], lds_addr_of(la + (j * 4 + wave) * 1024));
+                if (g.nt_mask & 1u) glds16_s<true>(ubase_a + (ATN ? koff * g.lda : koff), va[j], lds_addr_of(la + (j * 4 + wave) * 1024));    // (uniform branches)
+                else glds16_s<false>(ubase_a + (ATN ? koff * g.lda : koff), va[j], lds_addr_of(la + (j * 4 + wave) * 1024));
             }
             if (j < 4 && do_b) {                                               // (row-major B: a K-tile is 64 rows of ldb elements)
                 if (g.nt_mask & 2u) glds16_s<true>(ubase_b + (BNN ? koff * g.ldb : koff), vb[j & 3], lds_addr_of(lb + (j * 4 + wave) * 1024));
@@ -288,12 +296,22 @@ gemm_lp128_kernel(gemm_args g)
             }
         } else {
             const int q = kk * 2 + h;            // logical 16-byte chunk: 8 k-values
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            if constexpr (ATN) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[B][i] = *reinterpret_cast<const frag *>(la + ra[i] + ((q ^ fa[i]) << 4));
+                for (int i = 0; i < MI; ++i) {
+                    const auto p = (__attribute__((address_space(3))) s16x4 *)(la + ran + (kk * 4 + 2 * h) * 1024 + i * 256);
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p);
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p + 128);
+                    af[B][i] = __builtin_bit_cast(frag, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[B][i] = *reinterpret_cast<const frag *>(la + ra[i] + ((q ^ fa[i]) << 4));
+            }
             if constexpr (BNN) {
                 // k-step kk, lane-half h: k 0..3 of its eight from block row a = 4kk + 2h, k 4..7 from a + 1 (4 blocks = 1 KiB on)
-                typedef short s16x4 __attribute__((ext_vector_type(4)));
-                typedef short s16x8 __attribute__((ext_vector_type(8)));
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const auto p = (__attribute__((address_space(3))) s16x4 *)(lb + rbn + (kk * 4 + 2 * h) * 1024 + j * 256);
@@ -612,30 +630,30 @@ gemm_lp128_kernel(gemm_args g)
 #ifndef LP128_SPEC
 #define LP128_SPEC 1   // dev: 0 = the 4-stage ring without loader waves
 #endif
-template <int DT, int DT_C, int NS, bool SPEC = false, bool BNN = false, int MI = 2>
+template <int DT, int DT_C, int NS, bool SPEC = false, bool BNN = false, int MI = 2, bool ATN = false>
 void launch_ns(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch)
 {
     // operand stages, or the four per-wave epilogue scratch areas when those are larger (f32 C with one stage: 36 KiB)
     constexpr int CSZ_ = DT_C == MI355_DTYPE_F32 ? 4 : 2;
     constexpr int EPI = 4 * ((32 * (64 * CSZ_ + 16) + 1023) & ~1023);
     constexpr int LDS = NS * geom<MI>::STAGE > EPI ? NS * geom<MI>::STAGE : EPI;
-    lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_lp128_kernel<DT, DT_C, NS, SPEC, BNN, MI>), LDS);
-    hipLaunchKernelGGL((gemm_lp128_kernel<DT, DT_C, NS, SPEC, BNN, MI>), dim3(g.tiles_m * g.tiles_n, batch, g.split_k > 1 ? g.split_k : 1),
+    lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_lp128_kernel<DT, DT_C, NS, SPEC, BNN, MI, ATN>), LDS);
+    hipLaunchKernelGGL((gemm_lp128_kernel<DT, DT_C, NS, SPEC, BNN, MI, ATN>), dim3(g.tiles_m * g.tiles_n, batch, g.split_k > 1 ? g.split_k : 1),
                        dim3(SPEC ? 512 : 256), LDS, s, g);
 }
 
 #ifndef SK1_MAX_TILES
 #define SK1_MAX_TILES 4   // K-tiles up to which the single-stage, four-workgroups-per-CU form is launched
 #endif
-template <int DT, int DT_C, bool BNN = false>
+template <int DT, int DT_C, bool BNN = false, bool ATN = false>
 void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch)
 {
     // one workgroup per CU at most: the deep (4-stage) pipeline; otherwise two co-resident 2-stage workgroups per CU
     const uint64_t wgs = (uint64_t)g.tiles_m * g.tiles_n * batch * (g.split_k > 1 ? g.split_k : 1);
     constexpr int BK_ = ROW_BYTES / ((DT == MI355_DTYPE_F8E4M3 || DT == MI355_DTYPE_F8E5M2) ? 1 : 2);
-    if (wgs <= (uint64_t)ctx->props.num_streaming_multiprocessors) launch_ns<DT, DT_C, 4, LP128_SPEC != 0, BNN>(ctx, s, g, batch);
-    else if (g.k <= SK1_MAX_TILES * BK_ && g.split_k <= 1) launch_ns<DT, DT_C, 1, false, BNN>(ctx, s, g, batch);   // four workgroups per CU
-    else launch_ns<DT, DT_C, 2, LP128_SPEC2 != 0, BNN>(ctx, s, g, batch);
+    if (wgs <= (uint64_t)ctx->props.num_streaming_multiprocessors) launch_ns<DT, DT_C, 4, LP128_SPEC != 0, BNN, 2, ATN>(ctx, s, g, batch);
+    else if (g.k <= SK1_MAX_TILES * BK_ && g.split_k <= 1) launch_ns<DT, DT_C, 1, false, BNN, 2, ATN>(ctx, s, g, batch);   // four workgroups per CU
+    else launch_ns<DT, DT_C, 2, LP128_SPEC2 != 0, BNN, 2, ATN>(ctx, s, g, batch);
 }
 
 }  // namespace
@@ -650,7 +668,7 @@ bool gemm_lp128_supports(const mi355_gemm_desc &d, const void *a, const void *b,
     if (f8) {
         if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != MI355_DTYPE_BF16 && d.dtype_c != MI355_DTYPE_F16) return false;
     } else if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != d.dtype_ab) return false;
-    if (d.trans_a) return false;
+    if (d.trans_a && (f8 || d.trans_b || d.m < 8 || (d.m & 7))) return false; // A stored [K][M]: 16-bit, with a row-major B, fetched 8 rows of C at a time
     if (!d.trans_b && (f8 || d.n < 8 || (d.n & 7))) return false;            // row-major B: 16-bit operands, fetched 8 columns (16 bytes) at a time
     const int64_t esz = f8 ? 1 : 2, BK = ROW_BYTES / esz, amask = 16 / esz - 1;
     if (d.k < BK || d.k % BK != 0) return false;
@@ -737,8 +755,8 @@ int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
             gemm_args gs = g;
             gs.c = ws; gs.ldc = d.n; gs.stride_c = d.m * d.n;
             gs.split_k = (uint32_t)splits; gs.split_c_stride = slab;
-            if (d.dtype_ab == MI355_DTYPE_BF16) { if (d.trans_b) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, gs, batch); else launch<MI355_DTYPE_BF16, MI355_DTYPE_F32, true>(ctx, s, gs, batch); }
-            else if (d.dtype_ab == MI355_DTYPE_F16) { if (d.trans_b) launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(ctx, s, gs, batch); else launch<MI355_DTYPE_F16, MI355_DTYPE_F32, true>(ctx, s, gs, batch); }
+            if (d.dtype_ab == MI355_DTYPE_BF16) { if (d.trans_a) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32, true, true>(ctx, s, gs, batch); else if (d.trans_b) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, gs, batch); else launch<MI355_DTYPE_BF16, MI355_DTYPE_F32, true>(ctx, s, gs, batch); }
+            else if (d.dtype_ab == MI355_DTYPE_F16) { if (d.trans_a) launch<MI355_DTYPE_F16, MI355_DTYPE_F32, true, true>(ctx, s, gs, batch); else if (d.trans_b) launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(ctx, s, gs, batch); else launch<MI355_DTYPE_F16, MI355_DTYPE_F32, true>(ctx, s, gs, batch); }
             else if (d.dtype_ab == MI355_DTYPE_F8E4M3) launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_F32>(ctx, s, gs, batch);
             else launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_F32>(ctx, s, gs, batch);
             check_launch(ctx, "mi355_gemm(lp128 split-K)");
@@ -756,7 +774,10 @@ int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
         else if (d.dtype_c == MI355_DTYPE_BF16) launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_BF16>(ctx, s, g, batch);
         else launch<MI355_DTYPE_F8E5M2, MI355_DTYPE_F16>(ctx, s, g, batch);
     } else if (d.dtype_ab == MI355_DTYPE_BF16) {
-        if (d.trans_b) {
+        if (d.trans_a) {
+            if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32, true, true>(ctx, s, g, batch);
+            else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16, true, true>(ctx, s, g, batch);
+        } else if (d.trans_b) {
             if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, g, batch);
             else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16>(ctx, s, g, batch);
         } else {
@@ -764,7 +785,10 @@ int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
             else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16, true>(ctx, s, g, batch);
         }
     } else {
-        if (d.trans_b) {
+        if (d.trans_a) {
+            if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32, true, true>(ctx, s, g, batch);
+            else launch<MI355_DTYPE_F16, MI355_DTYPE_F16, true, true>(ctx, s, g, batch);
+        } else if (d.trans_b) {
             if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(ctx, s, g, batch);
             else launch<MI355_DTYPE_F16, MI355_DTYPE_F16>(ctx, s, g, batch);
         } else {
@@ -780,6 +804,7 @@ int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
 bool gemm_lp256x128_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
 {
     if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16) return false;
+    if (d.trans_a) return false;
     return gemm_lp128_supports(d, a, b, c);
 }
 

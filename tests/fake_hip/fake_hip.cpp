@@ -4,6 +4,7 @@
 // a deterministic question.
 #include "../../cubecl_amd/csrc/internal.hpp"
 
+#include <mutex>
 #include <set>
 #include <sys/mman.h>
 
@@ -18,6 +19,10 @@ struct fake_state {
     std::set<fake_hip_stream *> streams;
     std::set<fake_hip_event *> events;
 } g;
+// One lock around the whole fake: the real runtime is thread-safe and the library is driven from one thread per device
+// (tests/test_comm_cpu.py THREADED: four contexts created, used and destroyed concurrently).
+std::recursive_mutex g_mu;
+#define LOCKED std::lock_guard<std::recursive_mutex> lock_(g_mu)
 }  // namespace
 
 extern "C" {
@@ -28,6 +33,7 @@ const char *hipGetErrorString(hipError_t e) { return e == hipErrorOutOfMemory ? 
 
 hipError_t hipMalloc(void **ptr, size_t bytes)
 {
+    LOCKED;
     if (g.in_use + bytes > g.capacity) { *ptr = nullptr; return hipErrorOutOfMemory; }
     // address space only (MAP_NORESERVE): pages exist once a copy touches them, so 256 MiB slab pages cost nothing
     void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
@@ -41,6 +47,7 @@ hipError_t hipMalloc(void **ptr, size_t bytes)
 
 hipError_t hipFree(void *ptr)
 {
+    LOCKED;
     auto it = g.live.find(reinterpret_cast<uintptr_t>(ptr));
     if (it == g.live.end()) { ++g.bad_frees; return hipErrorInvalidValue; }
     munmap(ptr, it->second);
@@ -52,6 +59,7 @@ hipError_t hipFree(void *ptr)
 
 hipError_t hipDeviceSynchronize(void)
 {
+    LOCKED;
     for (fake_hip_stream *s : g.streams) s->completed = s->submitted;
     ++g.device_syncs;
     return hipSuccess;
@@ -59,6 +67,7 @@ hipError_t hipDeviceSynchronize(void)
 
 hipError_t hipEventCreateWithFlags(hipEvent_t *event, unsigned)
 {
+    LOCKED;
     *event = new fake_hip_event();
     g.events.insert(*event);
     ++g.event_creates;
@@ -67,6 +76,7 @@ hipError_t hipEventCreateWithFlags(hipEvent_t *event, unsigned)
 
 hipError_t hipEventDestroy(hipEvent_t event)
 {
+    LOCKED;
     if (!g.events.erase(event)) return hipErrorInvalidValue;
     delete event;
     ++g.event_destroys;
@@ -75,6 +85,7 @@ hipError_t hipEventDestroy(hipEvent_t event)
 
 hipError_t hipEventRecord(hipEvent_t event, hipStream_t stream)
 {
+    LOCKED;
     if (!event || !stream) return hipErrorInvalidValue;
     event->stream = stream;
     event->seq = ++stream->submitted;          // the record itself is a piece of work on the stream
@@ -83,6 +94,7 @@ hipError_t hipEventRecord(hipEvent_t event, hipStream_t stream)
 
 hipError_t hipEventQuery(hipEvent_t event)
 {
+    LOCKED;
     ++g.event_queries;
     if (!event || !event->stream) return hipErrorInvalidValue;
     return event->stream->completed >= event->seq ? hipSuccess : hipErrorNotReady;
@@ -123,6 +135,7 @@ int32_t map_hip_error(hipError_t e) { return e == hipSuccess ? MI355_OK : e == h
 #ifndef FAKE_WITH_RUNTIME
 TEST_API mi355_ctx *pooltest_ctx_create(uint64_t max_page_size)
 {
+    LOCKED;
     mi355_ctx *ctx = new mi355_ctx();
     ctx->props.max_page_size = max_page_size;
     ctx->compute_stream = new fake_hip_stream();
@@ -131,6 +144,7 @@ TEST_API mi355_ctx *pooltest_ctx_create(uint64_t max_page_size)
 }
 TEST_API void pooltest_ctx_destroy(mi355_ctx *ctx)
 {
+    LOCKED;
     mi355::pool_destroy(ctx);
     g.streams.erase(ctx->compute_stream);
     delete ctx->compute_stream;
@@ -139,33 +153,38 @@ TEST_API void pooltest_ctx_destroy(mi355_ctx *ctx)
 #endif
 TEST_API void *pooltest_stream_create(void)
 {
+    LOCKED;
     fake_hip_stream *s = new fake_hip_stream();
     g.streams.insert(s);
     return s;
 }
 TEST_API void pooltest_stream_destroy(void *s)
 {
+    LOCKED;
     g.streams.erase(static_cast<fake_hip_stream *>(s));
     delete static_cast<fake_hip_stream *>(s);
 }
 // everything submitted to the stream so far (NULL: the context's compute stream) has now run
 TEST_API void pooltest_stream_complete(mi355_ctx *ctx, void *s)
 {
+    LOCKED;
     fake_hip_stream *st = s ? static_cast<fake_hip_stream *>(s) : ctx->compute_stream;
     st->completed = st->submitted;
 }
 TEST_API void pooltest_set_capturing(mi355_ctx *ctx, int32_t on) { ctx->capturing = on != 0; }
-TEST_API void pooltest_set_capacity(uint64_t bytes) { g.capacity = bytes; }
+TEST_API void pooltest_set_capacity(uint64_t bytes) { LOCKED; g.capacity = bytes; }
 TEST_API const char *pooltest_last_error(mi355_ctx *ctx) { return ctx->last_error.c_str(); }
 // {mallocs, frees, bad frees, live device allocations, bytes in use on the device, events alive, event queries, device syncs}
 TEST_API void pooltest_counters(uint64_t out[8])
 {
+    LOCKED;
     out[0] = g.mallocs; out[1] = g.frees; out[2] = g.bad_frees; out[3] = g.live.size(); out[4] = g.in_use;
     out[5] = g.events.size(); out[6] = g.event_queries; out[7] = g.device_syncs;
 }
 // is [ptr, ptr + bytes) inside one live device allocation?
 TEST_API int32_t pooltest_inside_allocation(void *ptr, uint64_t bytes)
 {
+    LOCKED;
     const uintptr_t p = reinterpret_cast<uintptr_t>(ptr);
     auto it = g.live.upper_bound(p);
     if (it == g.live.begin()) return 0;
@@ -193,7 +212,7 @@ struct runtime_state {
     uint64_t stream_syncs = 0, stream_waits = 0;
     hipStream_t last_wait_stream = nullptr, last_sync_stream = nullptr;
 } r;
-void work(hipStream_t s) { if (s) { ++s->submitted; s->completed = s->submitted; } }
+void work(hipStream_t s) { LOCKED; if (s) { ++s->submitted; s->completed = s->submitted; } }
 }  // namespace
 
 extern "C" {
@@ -210,12 +229,13 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int)
     p->multiProcessorCount = 256; p->clockRate = 2400000; p->memoryClockRate = 2000000; p->memoryBusWidth = 8192; p->l2CacheSize = 4 << 20;
     return hipSuccess;
 }
-hipError_t hipMemGetInfo(size_t *f, size_t *t) { *t = 288ull << 30; *f = *t - g.in_use; return hipSuccess; }
+hipError_t hipMemGetInfo(size_t *f, size_t *t) { LOCKED; *t = 288ull << 30; *f = *t - g.in_use; return hipSuccess; }
 hipError_t hipDeviceCanAccessPeer(int *can, int, int) { *can = 1; return hipSuccess; }
-hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = new fake_hip_stream(); g.streams.insert(*s); return hipSuccess; }
-hipError_t hipStreamDestroy(hipStream_t s) { g.streams.erase(s); delete s; return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { LOCKED; *s = new fake_hip_stream(); g.streams.insert(*s); return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t s) { LOCKED; g.streams.erase(s); delete s; return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t s)
 {
+    LOCKED;
     ++r.stream_syncs;
     r.last_sync_stream = s;
     if (s) s->completed = s->submitted;
@@ -225,7 +245,7 @@ hipError_t hipStreamSynchronize(hipStream_t s)
 }
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t, unsigned) { ++r.stream_waits; r.last_wait_stream = s; return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t *e) { return hipEventCreateWithFlags(e, 0); }
-hipError_t hipEventSynchronize(hipEvent_t e) { if (e && e->stream) e->stream->completed = e->stream->submitted; return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t e) { LOCKED; if (e && e->stream) e->stream->completed = e->stream->submitted; return hipSuccess; }
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 1.5f; return hipSuccess; }
 hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) { *p = malloc(bytes); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }

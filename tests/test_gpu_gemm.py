@@ -1106,3 +1106,79 @@ def test_lp128_loader_wave_form_with_rings_shorter_than_their_depth(client, orac
     exercises the prologue (fewer K-tiles than ring slots: the loaders' loop runs 0 ... 4 times) and the tail waits; the last
     shape is one workgroup walking 64 K-tiles."""
     run_case(client, oracle, m, n, k, dtype, out_dtype, True, ALGOS["lp128"])
+
+
+# ---- A stored [K][M] with a row-major B: lhs^T . grad_out, the weight-gradient product (gemm_lp128.hip ATN) ---------------------
+def _tn_desc(m, n, k, dtype, out, lda=None, ldb=None, batch=1, algo=N.GEMM_ALGO_AUTO, trans_b=0):
+    lda, ldb = lda or m, ldb or (k if trans_b else n)
+    return N.GemmDesc(m=m, n=n, k=k, batch=batch, lda=lda, ldb=ldb, ldc=n, stride_a=k * lda, stride_b=(n if trans_b else k) * ldb, stride_c=m * n,
+                      dtype_ab=int(dtype), dtype_c=int(out), trans_a=1, trans_b=trans_b, algo=algo)
+
+
+@pytest.mark.parametrize("dtype", [ElemType.BF16, ElemType.F16])
+@pytest.mark.parametrize("m,n,k,batch,lda,out16,algo", [
+    (128, 128, 64, 1, None, False, "lp128"),          # one tile, one K-tile
+    (520, 776, 448, 1, 528, False, "lp128"),          # 4-stage ring + loader waves, edge tiles in both directions, padded rows of A
+    (2048, 2304, 320, 2, None, True, "lp128"),        # two-stage form + loader waves, batches
+    (4096, 4104, 64, 1, None, True, "lp128"),         # single-stage form
+    (136, 264, 8192, 1, None, False, "lp128"),        # split-K slices
+    (512, 512, 8192, 1, None, True, "auto"),          # what a weight gradient looks like: small output, long K
+    (1024, 4096, 2048, 1, 1032, True, "auto"),
+])
+def test_transposed_a_with_row_major_b_is_staged_natively_and_gives_the_bits_of_the_k_contiguous_form(client, oracle, dtype, m, n, k, batch, lda,
+                                                                                                     out16, algo):
+    """A [K][M] and B [K][N] are both walked along their ROWS by K: the A tile is built as the mirror image of the row-major B tile
+    (blocks of [4 k][32 m], fragments through ds_read_b64_tr_b16).  Same k order inside every MFMA, same K-tile order: the bits of
+    the launch with both operands K-contiguous on the same kernel; and one batch entry against the f64 oracle directly."""
+    lda = lda or m
+    conv, back = (oracle.to_bf16, oracle.from_bf16) if dtype == ElemType.BF16 else (oracle.to_f16, oracle.from_f16)
+    a_km = conv(oracle.fill_uniform(batch * k * lda, 71, -1.0, 1.0)).reshape(batch, k, lda)
+    b_kn = conv(oracle.fill_uniform(batch * k * n, 72, -1.0, 1.0)).reshape(batch, k, n)
+    odt = dtype if out16 else ElemType.F32
+    d = _tn_desc(m, n, k, dtype, odt, lda=lda, batch=batch)
+    if algo == "auto":
+        assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_128 and ops.gemm_relayout_plan(client, d) == (False, False)
+    ta, tb = TensorHandle.from_numpy(client, a_km, dtype), TensorHandle.from_numpy(client, b_kn, dtype)
+    c1 = TensorHandle.new_contiguous((batch, m, n), client.empty(batch * m * n * odt.size()), odt)
+    ops.matmul(client, TensorHandle.new(ta.handle, (batch, m, k), (k * lda, 1, lda), dtype), TensorHandle.new(tb.handle, (batch, k, n), (k * n, n, 1), dtype),
+               c1, algo=ALGOS[algo])
+    # the twin: A as [M][K], B as [N][K]
+    a_mk = np.ascontiguousarray(a_km[:, :, :m].transpose(0, 2, 1))
+    b_nk = np.ascontiguousarray(b_kn.transpose(0, 2, 1))
+    ua, ub = TensorHandle.from_numpy(client, a_mk, dtype), TensorHandle.from_numpy(client, b_nk, dtype)
+    c2 = TensorHandle.new_contiguous((batch, m, n), client.empty(batch * m * n * odt.size()), odt)
+    ops.matmul(client, TensorHandle.new(ua.handle, (batch, m, k), (m * k, k, 1), dtype), TensorHandle.new(ub.handle, (batch, k, n), (k * n, 1, k), dtype),
+               c2, algo=N.GEMM_ALGO_LP_128)
+    got = c1.to_numpy(client)
+    assert np.array_equal(got, c2.to_numpy(client))
+    bi = batch - 1
+    A = back(a_mk[bi].reshape(-1)).reshape(m, k)[-96:].astype(np.float64)
+    Bv = back(b_kn[bi].reshape(-1)).reshape(k, n).astype(np.float64)
+    out = _decode(oracle, got.reshape(batch, m, n)[bi][-96:], odt)
+    tol = REL * (np.abs(A) @ np.abs(Bv)) + (0 if not out16 else np.abs(A @ Bv) * 2.0 ** (-7 if dtype == ElemType.BF16 else -10))
+    assert np.all(np.abs(out - A @ Bv) <= tol + 1e-30)
+
+
+def test_transposed_a_selection_and_refusals(client, oracle):
+    bf = ElemType.BF16
+    # a 256-tile shape: A is transposed into scratch, the row-major B stays where it is
+    d = _tn_desc(8192, 8192, 8192, bf, bf)
+    assert ops.gemm_relayout_plan(client, d) == (True, False) and ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    # rows of C not a multiple of 8 / A and B both transposed: no native form
+    assert ops.gemm_relayout_plan(client, _tn_desc(516, 512, 1024, bf, bf)) == (True, False)
+    assert ops.gemm_relayout_plan(client, _tn_desc(512, 512, 1024, bf, bf, trans_b=1)) == (True, False)
+    for d in (_tn_desc(516, 512, 1024, bf, bf, algo=N.GEMM_ALGO_LP_128), _tn_desc(512, 512, 1024, bf, bf, algo=N.GEMM_ALGO_LP_128, trans_b=1),
+              _tn_desc(512, 512, 1024, bf, bf, algo=N.GEMM_ALGO_LP_256X128), _tn_desc(512, 512, 1024, bf, bf, algo=N.GEMM_ALGO_LP_256W4)):
+        a, b, c = client.empty(2 << 20), client.empty(2 << 20), client.empty(2 << 20)
+        rc = client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()), C.c_void_p(c.device_ptr()))
+        assert rc == N.E_UNSUPPORTED
+    # through AUTO those still come out right (re-layout)
+    m, n, k = 516, 512, 1024
+    a_km = oracle.fill_uniform(k * m, 73, -1.0, 1.0).reshape(k, m)
+    b_kn = oracle.fill_uniform(k * n, 74, -1.0, 1.0).reshape(k, n)
+    ta, a_val = _to_dev(client, oracle, a_km, bf)
+    tb, b_val = _to_dev(client, oracle, b_kn, bf)
+    c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 4), ElemType.F32)
+    ops.matmul(client, TensorHandle.new(ta.handle, (m, k), (1, m), bf), TensorHandle.new(tb.handle, (k, n), (n, 1), bf), c)
+    A, Bv = a_val.reshape(k, m).T.astype(np.float64), b_val.reshape(k, n).astype(np.float64)
+    assert np.all(np.abs(c.to_numpy(client).reshape(m, n) - A @ Bv) <= REL * (np.abs(A) @ np.abs(Bv)) + 1e-30)
