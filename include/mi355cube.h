@@ -355,11 +355,15 @@ int32_t mi355_cast(mi355_ctx *ctx, mi355_stream stream, const void *src, int32_t
  * dtype_ab: F32 (MFMA f32, exact-f32 products), BF16 or F16 (MFMA, f32 accumulate), F8E4M3 or F8E5M2
  *           (OCP FP8 on v_mfma_f32_32x32x64_f8f6f4, unscaled, f32 accumulate; both operands the same format).
  * dtype_c: F32, or the same 16-bit type as the inputs (RNE on store); fp8 inputs write F32, BF16 or F16.
- * Layouts the MFMA kernels do not stage directly (trans_a == 1; 16-bit row-major B) are re-laid out
- * K-contiguous into library-owned per-stream scratch first, as the reference's launchers do with
- * into_contiguous; shapes no MFMA kernel takes (K not a multiple of the K-tile, unaligned rows) run
- * on the bounds-checked generic kernel.  The library owns: that scratch, the split-K slabs of skinny
- * shapes, and the reductions' arrival tickets -- never caller memory. */
+ * Row-major B (what TensorHandle::new_contiguous gives a rhs) is staged natively by the tile kernels for F32, BF16 and F16
+ * (N a multiple of 16 bytes' worth of columns), and so is A stored [K][M] together with a row-major B for BF16 / F16 on the
+ * 128x128 kernel (lhs^T . grad_out).  What the MFMA kernels do not stage directly -- trans_a otherwise, fp8 row-major B, a
+ * row-major B of at most 64 columns, K not a multiple of the K-tile, rows or bases not 16-byte aligned -- is first re-laid
+ * out K-contiguous (zero-padded) into library-owned per-stream scratch, as the reference's launchers do with into_contiguous
+ * (mi355_gemm_relayout_plan says which operands); tiny shapes run on the bounds-checked generic kernel.  The library owns:
+ * that scratch, the split-K slabs of skinny shapes, and the reductions' arrival tickets -- never caller memory.
+ * fp8: v_mfma_f32_32x32x64_f8f6f4 adds its products in groups of 8, each cut 13 bits below the group's largest product
+ * (measured) -- MI355_GEMM_ALGO_GENERIC gives the exact-product f32 chain. */
 typedef struct {
     int64_t m, n, k, batch;
     int64_t lda, ldb, ldc;
