@@ -60,17 +60,18 @@ def fp8_mfma_truncation_bound(A, Bt):
 
 
 def run_case(client, oracle, m, n, k, dtype, out_dtype, trans_b, algo, *, lda=None, ldb=None, ldc=None, batch=1,
-             bcast_b=False, seed_t=50):
-    """Random [-1,1) operands; returns nothing, asserts parity."""
-    lda = lda or k
+             bcast_b=False, seed_t=50, trans_a=False):
+    """Random [-1,1) operands; returns nothing, asserts parity.  trans_a: A stored [K][M] (lda >= M)."""
+    lda = lda or (m if trans_a else k)
     ldb = ldb or (k if trans_b else n)
     ldc = ldc or n
     rows_b = n if trans_b else k
-    a_host = oracle.fill_uniform(batch * m * lda, seed_t, -1.0, 1.0).reshape(batch, m, lda)
+    rows_a = k if trans_a else m
+    a_host = oracle.fill_uniform(batch * rows_a * lda, seed_t, -1.0, 1.0).reshape(batch, rows_a, lda)
     b_host = oracle.fill_uniform((1 if bcast_b else batch) * rows_b * ldb, seed_t + 1, -1.0, 1.0).reshape(-1, rows_b, ldb)
     ta, a_val = _to_dev(client, oracle, a_host, dtype)
     tb, b_val = _to_dev(client, oracle, b_host, dtype)
-    a_t = TensorHandle.new(ta.handle, (batch, m, k), (m * lda, lda, 1), dtype)
+    a_t = TensorHandle.new(ta.handle, (batch, m, k), (k * lda, 1, lda) if trans_a else (m * lda, lda, 1), dtype)
     if trans_b:   # logical [k, n] stored [n][k]
         b_t = TensorHandle.new(tb.handle, (batch, k, n), (0 if bcast_b else n * ldb, 1, ldb), dtype)
     else:
@@ -84,7 +85,7 @@ def run_case(client, oracle, m, n, k, dtype, out_dtype, trans_b, algo, *, lda=No
     got_all = raw.view(np_dt).reshape(batch, m, ldc)
     fp8_mfma = dtype in (ElemType.F8E4M3, ElemType.F8E5M2) and algo != N.GEMM_ALGO_GENERIC
     for b in range(batch):
-        A = a_val[b][:, :k].astype(np.float64)
+        A = (a_val[b][:, :m].T if trans_a else a_val[b][:, :k]).astype(np.float64)
         Bm = b_val[0 if bcast_b else b]
         Bm = (Bm[:, :k].T if trans_b else Bm[:, :n]).astype(np.float64)
         ref = A @ Bm

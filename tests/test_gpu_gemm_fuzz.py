@@ -52,6 +52,21 @@ def draw(seed):
     return m, n, k, dtype, out, trans_b, kw
 
 
+def draw_transposed_a(seed):
+    """A stored [K][M] (MatrixBatchLayout::MildlyPermuted { transposed: true } on the lhs, matrix_batch_layout.rs:21-79): the same
+    draw, with lda re-drawn around M; together with a row-major B most 16-bit cases land on the 128x128 kernel's native form
+    (gemm_lp128.hip ATN), the rest on the re-layout pass."""
+    m, n, k, dtype, out, trans_b, kw = draw(5000 + seed)
+    rng = np.random.default_rng(0x7A + seed)
+    if rng.integers(0, 3):
+        trans_b = False                                     # lhs^T . grad_out: both operands walked along their rows by K
+        kw["ldb"] = n + int(rng.choice([0, 0, 8, 16]))
+    if rng.integers(0, 2) and m > 8:
+        m = m // 8 * 8                                      # the native form wants whole 16-byte pieces of A's rows
+    kw["lda"] = m + int(rng.choice([0, 0, 0, 8, 16, 24, 1]))
+    return m, n, k, dtype, out, trans_b, kw
+
+
 def draw_big(seed):
     """More than 128 tiles of 256^2 (or many of 128^2), so that the persistent and the 256-tile kernels answer: 12 cases, a few
     seconds of f64 product each on the host."""
@@ -74,6 +89,12 @@ def draw_big(seed):
 def test_auto_dispatch_on_random_descriptors(client, oracle, seed):
     m, n, k, dtype, out, trans_b, kw = draw(seed)
     run_case(client, oracle, m, n, k, dtype, out, trans_b, N.GEMM_ALGO_AUTO, seed_t=1000 + seed, **kw)
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_auto_dispatch_on_random_descriptors_with_a_transposed_lhs(client, oracle, seed):
+    m, n, k, dtype, out, trans_b, kw = draw_transposed_a(seed)
+    run_case(client, oracle, m, n, k, dtype, out, trans_b, N.GEMM_ALGO_AUTO, seed_t=3000 + seed, trans_a=True, **kw)
 
 
 @pytest.mark.parametrize("seed", range(12))
