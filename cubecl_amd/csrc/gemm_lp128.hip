@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(SPEC ? 512 : 256,
 gemm_lp128_kernel(gemm_args g)
 {
     static_assert(!SPEC || NS == 4 || NS == 3 || NS == 2, "loader waves are written for the 2-stage ring and the deep rings");
-    static_assert(MI == 2 || (MI == 4 && NS == 3 && DT != MI355_DTYPE_F8E4M3 && DT != MI355_DTYPE_F8E5M2), "256 x 128 tile: three-stage ring, 16-bit operands");
+    static_assert(MI == 1 || MI == 2 || (MI == 4 && NS == 3 && DT != MI355_DTYPE_F8E4M3 && DT != MI355_DTYPE_F8E5M2), "256 x 128 tile: three-stage ring, 16-bit operands");
     constexpr int BMK = geom<MI>::BMK, A_BYTES = geom<MI>::A_BYTES, STG = geom<MI>::STAGE;
     constexpr int PIECES = 2 * MI + 4;           // LDS-DMA instructions per wave and K-tile (A: BMK / 32, B: 4)
     static_assert(!BNN || DT == MI355_DTYPE_BF16 || DT == MI355_DTYPE_F16, "row-major B: 16-bit operands");
@@ -261,8 +261,8 @@ gemm_lp128_kernel(gemm_args g)
         char *lb = la + A_BYTES;
         const int64_t koff = (int64_t)kt * ROW_BYTES;
 #pragma unroll
-        for (int j = 0; j < 2 * MI; ++j) {
-            if (do_a) {
+        for (int j = 0; j < (2 * MI > 4 ? 2 * MI : 4); ++j) {
+            if (j < 2 * MI && do_a) {
                 if (g.nt_mask & 1u) glds16_s<true>(ubase_a + (ATN ? koff * g.lda : koff), va[j], lds_addr_of(la + (j * 4 + wave) * 1024));    // (uniform branches)
                 else glds16_s<false>(ubase_a + (ATN ? koff * g.lda : koff), va[j], lds_addr_of(la + (j * 4 + wave) * 1024));
             }
@@ -645,9 +645,25 @@ void launch_ns(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch
 #ifndef SK1_MAX_TILES
 #define SK1_MAX_TILES 4   // K-tiles up to which the single-stage, four-workgroups-per-CU form is launched
 #endif
+// At most 64 rows of A (16-bit operands): a 64 x 128 tile (MI = 1: waves 2 x 2, 32 x 64 each) -- the 128-row tile fetched its
+// upper 64 rows as clamped duplicates from L2, 16 KiB of LDS-DMA intake per K-tile that multiply nothing.  24 KiB per K-tile
+// instead of 32: interleaved twice on cold operands (profiles/r03_small_m_tile.txt), row-major weights 1 x 8192 x 8192 35.2 ->
+// 32.3 us, 16 x 28672 x 8192 85.3 -> 76.3, 64 x 28672 x 8192 88.8 -> 82.6, 8 x 57344 x 4096 84.3 -> 75.6, 48 x 14336 x 4096 35.3 -> 31.0;
+// [N][K] weights 64 x 28672 x 8192 93.5 -> 82.4-92.0, 64 x 14336 x 4096 36.8 -> 33.5-34.4 (every shape -5 ... -12 %).
+#ifndef LP128_SMALL_M
+#define LP128_SMALL_M 1   // dev: 0 = the 128 x 128 tile for every M
+#endif
 template <int DT, int DT_C, bool BNN = false, bool ATN = false>
 void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch)
 {
+    if constexpr (LP128_SMALL_M && !ATN && (DT == MI355_DTYPE_BF16 || DT == MI355_DTYPE_F16)) {
+        if (g.m <= 64) {
+            const uint64_t wgs1 = (uint64_t)g.tiles_m * g.tiles_n * batch * (g.split_k > 1 ? g.split_k : 1);
+            if (wgs1 <= (uint64_t)ctx->props.num_streaming_multiprocessors) launch_ns<DT, DT_C, 4, LP128_SPEC != 0, BNN, 1, false>(ctx, s, g, batch);
+            else launch_ns<DT, DT_C, 2, LP128_SPEC2 != 0, BNN, 1, false>(ctx, s, g, batch);
+            return;
+        }
+    }
     // one workgroup per CU at most: the deep (4-stage) pipeline; otherwise two co-resident 2-stage workgroups per CU
     const uint64_t wgs = (uint64_t)g.tiles_m * g.tiles_n * batch * (g.split_k > 1 ? g.split_k : 1);
     constexpr int BK_ = ROW_BYTES / ((DT == MI355_DTYPE_F8E4M3 || DT == MI355_DTYPE_F8E5M2) ? 1 : 2);
