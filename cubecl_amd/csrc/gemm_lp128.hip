@@ -732,7 +732,20 @@ int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
 #ifndef LP128_WANT_MULT
 #define LP128_WANT_MULT 2   // workgroups the split aims at, in units of CUs
 #endif
-    const int64_t want = LP128_WANT_MULT * (int64_t)ctx->props.num_streaming_multiprocessors;
+    // Slices so that tiles x slices fills the chip ONCE (one workgroup per CU, the deep ring) up to 96 tiles, twice (two co-resident
+    // workgroups per CU) from there to 128 -- until late round 3 always twice.  What a split buys is idle CUs put to work; past one
+    // workgroup per CU it only shortens the slices (pipeline fill per slice, more slab traffic) while the CU's LDS-DMA intake stays
+    // what it is.  Interleaved twice on cold operands, both rhs layouts (profiles/r03_want_mult_nt_nn.txt, r03_want_mult_few_rows.txt):
+    // 256 x 2048 x 8192 31-35 -> 23-24 us, 1024 x 512 x 8192 26.0 -> 22.3, 1024 x 1536 x 4096 31.5 -> 28.5, 128 x 8192 x 8192 47 -> 40-45,
+    // row-major weights 64 x 8192 x 8192 40.0 -> 33.4, 48 x 14336 x 4096 31.5 -> 28.3, 1 x 8192 x 8192 33 -> 30; ties at 512^2 x 8192,
+    // 1024^2 x 4096, 128 x 256 x 8192; 128 tiles keep the pair (2048 x 1024 x 4096 33 us against 39).
+#ifndef LP128_ONCE_UPTO
+#define LP128_ONCE_UPTO 96      // dev: 0 = round 3's earlier rule (always two workgroups per CU)
+#endif
+#ifndef LP128_NOSPLIT_FROM
+#define LP128_NOSPLIT_FROM 160  // dev: 1 << 30 = the earlier rule (any tile count splits when K is long against it)
+#endif
+    const int64_t want = (tiles <= LP128_ONCE_UPTO ? 1 : LP128_WANT_MULT) * (int64_t)ctx->props.num_streaming_multiprocessors;
 #ifndef LP128_SPLIT_RULE
 #define LP128_SPLIT_RULE 1   // dev: 0 = round 1's rule (any launch of fewer than one tile per CU with 8+ K-tiles)
 #endif
@@ -748,8 +761,10 @@ int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
     // 128 tiles splitting never loses and wins where the bound leaves two or more slices (32 tiles x 32 K-tiles 20.7 -> 15.3 us,
     // 64 x 32 20.6 -> 17.6, 72 x 64 36.5 -> 30.1, 96 x 64 37.5 -> 30.7, 128 x 64 37.4 -> 33.2); from 160 tiles up it loses unless K is
     // long against the tile count (192 x 64 38.6 against 50.4 split, 224 x 128 79 / 110).
-    const bool long_k = LP128_SPLIT_RULE == 0 || tiles <= 128 || (nk >= tiles && nk >= 48);
-    if (tiles < want / 2 && nk >= 8 && long_k && batch <= 65535) {
+    // (late round 3: from 160 tiles up never -- 1536 x 2048 x 16384, 192 tiles x 256 K-tiles, 176-183 us in two slices against
+    //  150-155 unsplit; 768 x 3072 x 14336, 144 x 224, still wins split three ways: 122 against 136)
+    const bool long_k = LP128_SPLIT_RULE == 0 || tiles <= 128 || (tiles < LP128_NOSPLIT_FROM && nk >= tiles && nk >= 48);
+    if (tiles < std::max<int64_t>(want, 2 * (int64_t)ctx->props.num_streaming_multiprocessors) / 2 && nk >= 8 && long_k && batch <= 65535) {
         const int64_t slab = d.batch * d.m * d.n;
         const int64_t operand_bytes = (d.m * d.k + d.n * d.k) * esz * d.batch;
         // The slab traffic (one f32 write + one read per slice and output) must stay below twice the operand stream.  Until
