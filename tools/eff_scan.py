@@ -2,7 +2,7 @@
 """Efficiency scan of AUTO over a random grid of bf16 shapes (GPU box, cold operands): time against a crude ideal
 = max(FLOP / 1.5 PFLOP/s, bytes / 5 TB/s) + 2.5 us of launch; prints the shapes furthest from it.  A tool for finding
 dispatcher / launcher decisions that are plainly wrong (a forced-kernel A/B cannot see a bad decision INSIDE a kernel's launcher).
-usage: tools/eff_scan.py [seed] [count]"""
+usage: tools/eff_scan.py [seed] [count] [nn]      (nn: rhs row-major [K][N])"""
 import random
 import sys
 from pathlib import Path
@@ -25,7 +25,7 @@ while len(shapes) < count:
     shapes.add((m, n, k))
 client = Mi355Runtime.client()
 ev = bench.Events(client)
-res = ab_algos.measure(client, ev, sorted(shapes), ["auto"], rounds=3, iters=10)
+res = ab_algos.measure(client, ev, sorted(shapes), ["auto"], rounds=3, iters=10, nn=len(sys.argv) > 3 and sys.argv[3] == "nn")
 rows = []
 for (m, n, k), r in res.items():
     us = r["us"]["auto"]
