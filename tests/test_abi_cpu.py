@@ -281,3 +281,25 @@ def test_product_never_reaches_for_the_fake_runtime():
                *(root / "cubecl_amd" / "csrc").glob("*.hpp"), root / "cubecl_amd" / "csrc" / "Makefile", root / "include" / "mi355cube.h"]
     offenders = [str(p.relative_to(root)) for p in shipped if "fake_hip" in p.read_text(errors="ignore") or "FAKE_WITH_RUNTIME" in p.read_text(errors="ignore")]
     assert offenders == []
+
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _build_c_user(tmp_path):
+    """tests/c_abi/abi_user.c: a plain C99 program against include/mi355cube.h and the product library."""
+    import subprocess
+    exe = tmp_path / "abi_user"
+    libdir = ROOT / "cubecl_amd" / "csrc"
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(ROOT / "tests" / "c_abi" / "abi_user.c"), "-o", str(exe),
+                    f"-L{libdir}", "-lmi355cube", f"-Wl,-rpath,{libdir}"], check=True)
+    return exe
+
+
+def test_the_header_is_plain_c_and_a_c_program_can_drive_the_boundary(tmp_path):
+    """The drop-in boundary is a C ABI: the header must compile as pedantic C99 (not only as the C++ the library is written in), and a C
+    caller -- what a cgo / JNI / Rust extern "C" binding is underneath -- must be able to fill the descriptors and call in.  Without a
+    device the program exercises the ABI version, the host-side planning entry points and the NULL-context refusals."""
+    import subprocess
+    out = subprocess.run([str(_build_c_user(tmp_path))], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "C ABI user ok" in out.stdout, (out.stdout[-800:], out.stderr[-400:])

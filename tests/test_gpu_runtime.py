@@ -805,3 +805,12 @@ def test_logical_streams_order_work_across_lanes_on_the_device(client, oracle):
         assert l3._lane.waits == w3 + 1
         got_c = c.to_numpy(client)                                                # lane 0 reads lane 2's buffer: waits for it
         assert np.array_equal(got_c, want_c) and np.array_equal(got_s, want_s), rep
+
+
+def test_a_plain_c_program_runs_the_hot_path_through_the_c_abi(tmp_path):
+    """tests/c_abi/abi_user.c with a device present: three GEMMs (both rhs layouts, a transposed lhs) and the C1-sized sum, driven from C
+    alone -- no Python, no ctypes -- and checked exactly (operands of ones: every output is K; 2^20 halves sum to 2^19)."""
+    import subprocess
+    from test_abi_cpu import _build_c_user
+    out = subprocess.run([str(_build_c_user(tmp_path))], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "C ABI user ok" in out.stdout and "layout 2: 0 of" in out.stdout and "524288.0" in out.stdout, (out.stdout[-1200:], out.stderr[-400:])
