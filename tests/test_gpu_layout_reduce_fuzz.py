@@ -11,12 +11,14 @@ from oracle import layout as L
 from test_gpu_contiguous import payload, run_copy
 
 pytestmark = pytest.mark.gpu
+import os
+OFFSET = int(os.environ.get("MI355_FUZZ_OFFSET", "0"))     # soak runs: the same tests over another stretch of seeds
 REL = 1e-5
 DIMS = [1, 2, 3, 4, 5, 7, 8, 13, 16, 17, 24, 31, 32, 33, 48, 64, 65, 100, 128, 200, 256, 500, 1024]
 
 
 def draw_layout(seed):
-    rng = np.random.default_rng(0xC0B1 + seed)
+    rng = np.random.default_rng(0xC0B1 + seed + OFFSET)
     while True:
         rank = int(rng.integers(1, 6))
         base = [int(rng.choice(DIMS)) for _ in range(rank)]
@@ -62,7 +64,7 @@ def test_copy_into_on_random_layouts(client, seed):
 
 
 def draw_reduce(seed):
-    rng = np.random.default_rng(0xA715 + seed)
+    rng = np.random.default_rng(0xA715 + seed + OFFSET)
     while True:
         rank = int(rng.integers(1, 5))
         shape = tuple(int(rng.choice(DIMS + [4096, 10007, 70001])) for _ in range(rank))
