@@ -401,7 +401,8 @@ int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_gemm_desc *d
  * once to dtype_c.  The f32 product goes through library-owned scratch (batch x M x N x 4 bytes per stream). */
 int32_t mi355_gemm_add(mi355_ctx *ctx, mi355_stream stream, const mi355_gemm_desc *desc,
                        const void *a, const void *b, const void *c, void *d);
-/* which kernel AUTO resolves to for a descriptor (for tests / logs) */
+/* which kernel AUTO resolves to for a descriptor (for tests / logs).  Host-side only: the answer depends on the descriptor alone
+ * (operands taken as 16-byte aligned), so `ctx` may be NULL -- the dispatcher's decisions are testable without a device. */
 int32_t mi355_gemm_select(mi355_ctx *ctx, const mi355_gemm_desc *desc, int32_t *out_algo);
 /* How a descriptor that resolves to the 256x256 kernel is cut when its last round of tiles is only partly filled (pure
  * function, no device): *out_splits == 1 -> one plain launch; otherwise rows (out_along_m = 1) or columns

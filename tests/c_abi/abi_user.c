@@ -84,8 +84,10 @@ int main(void)
     /* no context: every entry point refuses, none crashes */
     if (mi355_gemm(NULL, NULL, &d, NULL, NULL, NULL) == MI355_OK) ++failures;
     if (mi355_sync(NULL, NULL) == MI355_OK) ++failures;
+    /* ... except the host-side planning ones, which need none: the transposed-lhs 8192^3 ends on the 256x256 kernel (after A's re-layout) */
     int32_t algo = -1;
-    if (mi355_gemm_select(NULL, &d, &algo) == MI355_OK) ++failures;
+    if (mi355_gemm_select(NULL, &d, &algo) != MI355_OK || algo != MI355_GEMM_ALGO_LP_256W4) ++failures;
+    if (mi355_gemm_select(NULL, NULL, &algo) == MI355_OK) ++failures;
 
     /* function pointers: the prototypes are usable as C types */
     int32_t (*gemm)(mi355_ctx *, mi355_stream, const mi355_gemm_desc *, const void *, const void *, void *) = mi355_gemm;

@@ -1,0 +1,78 @@
+"""The GEMM dispatcher's decisions, held on a box without a GPU: `mi355_gemm_select` and `mi355_gemm_relayout_plan` are host-side
+functions of the descriptor alone (ctx may be NULL), so the choices the GPU tests assert next to their parity checks -- and that the
+benchmark's figures are quoted on -- are pinned in the CPU tier as well.  Every row was measured as the fastest kernel for its shape
+on an MI355X (tests/test_gpu_select_audit.py re-measures a 40-shape grid on every GPU run; DESIGN.md section 4 has the tables);
+a change to gemm.cpp::select that moves one of them has to change this table on purpose.
+
+Layouts (include/mi355cube.h): trans_b = 1 is B stored [N][K] (the cmma tests' ColMajor B, runtime_tests/cmma.rs:23); trans_b = 0 is
+the row-major [K][N] rhs `TensorHandle::new_contiguous` gives (crates/cubecl-std/src/tensor/handle.rs:89); trans_a = 1 is a lhs stored
+[K][M] (`MatrixBatchLayout::MildlyPermuted { transposed: true }`, matrix_batch_layout.rs:21-79)."""
+import ctypes as C
+
+import pytest
+
+from cubecl_amd import _native as N
+
+BF, F16, F32, E4 = N.DTYPE_BF16, N.DTYPE_F16, N.DTYPE_F32, N.DTYPE_F8E4M3
+A = {name[len("GEMM_ALGO_"):]: value for name, value in vars(N).items() if name.startswith("GEMM_ALGO_")}
+
+# (what, (m, n, k, dtype_ab, dtype_c or None = same, trans_a, trans_b, batch), kernel, (A re-laid out, B re-laid out))
+TABLE = [
+    ("C3: 8192^3 bf16, the benchmark's headline", (8192, 8192, 8192, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
+    ("C3 with the reference's default rhs layout", (8192, 8192, 8192, BF, None, 0, 0, 1), "LP_256W4", (0, 0)),
+    ("C2: 4096^3 f32", (4096, 4096, 4096, F32, F32, 0, 1, 1), "LP_256W4", (0, 0)),
+    ("C2, row-major rhs", (4096, 4096, 4096, F32, F32, 0, 0, 1), "LP_256W4", (0, 0)),
+    ("C5: 512 x 2048^3 bf16 on one GPU: dripped stores", (2048, 2048, 2048, BF, None, 0, 1, 512), "LP_256Q", (0, 0)),
+    ("C5 with an f32 C: the persistent kernel without them", (2048, 2048, 2048, BF, F32, 0, 1, 512), "LP_256P", (0, 0)),
+    ("C5, row-major rhs", (2048, 2048, 2048, BF, None, 0, 0, 512), "LP_256Q", (0, 0)),
+    ("the 64-matrix shard of an 8-GPU C5", (2048, 2048, 2048, BF, None, 0, 1, 64), "LP_256Q", (0, 0)),
+    ("GEMV", (1, 8192, 8192, BF, None, 0, 1, 1), "SKINNY", (0, 0)),
+    ("GEMV against a row-major weight: native, never transposed", (1, 8192, 8192, BF, None, 0, 0, 1), "LP_128", (0, 0)),
+    ("16 rows", (16, 8192, 8192, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
+    ("16 rows against a row-major weight", (16, 8192, 8192, BF, None, 0, 0, 1), "LP_128", (0, 0)),
+    ("64 rows", (64, 8192, 8192, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
+    ("64 columns", (8192, 64, 8192, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
+    ("64 columns of a row-major rhs: the small operand is re-laid out", (8192, 64, 8192, BF, None, 0, 0, 1), "STREAM64", (0, 1)),
+    ("decode, 16 tokens", (16, 28672, 8192, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
+    ("decode, 64 tokens", (64, 28672, 8192, BF, None, 0, 1, 1), "LP_128", (0, 0)),
+    ("decode, 128 tokens", (128, 28672, 8192, BF, None, 0, 1, 1), "LP_128", (0, 0)),
+    ("decode, 64 tokens, row-major weight", (64, 28672, 8192, BF, None, 0, 0, 1), "LP_128", (0, 0)),
+    ("output-bound: one K-tile", (8192, 8192, 64, BF, None, 0, 1, 1), "LP_128", (0, 0)),
+    ("one 128^2 tile per CU", (2048, 2048, 2048, BF, None, 0, 1, 1), "LP_128", (0, 0)),
+    ("the 256 x 128 tile's band", (4096, 2048, 4096, BF, None, 0, 1, 1), "LP_256X128", (0, 0)),
+    ("one round of 256^2 tiles", (4096, 4096, 4096, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
+    ("a partly filled last round (split inside the launch)", (6144, 6144, 6144, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
+    ("weight gradient lhs^T . grad: native", (512, 512, 8192, BF, None, 1, 0, 1), "LP_128", (0, 0)),
+    ("weight gradient, mid size: native", (2048, 2048, 8192, BF, None, 1, 0, 1), "LP_128", (0, 0)),
+    ("transposed lhs on a 256-tile shape: A through scratch, B stays", (8192, 8192, 8192, BF, None, 1, 0, 1), "LP_256W4", (1, 0)),
+    ("both transposed", (512, 512, 1024, BF, None, 1, 1, 1), "LP_128", (1, 0)),
+    ("transposed lhs, rows of C not a multiple of 8", (516, 512, 1024, BF, None, 1, 0, 1), "LP_128", (1, 0)),
+    ("fp8", (8192, 8192, 8192, E4, BF, 0, 1, 1), "LP_256W4", (0, 0)),
+    ("fp8, mid size", (2048, 2048, 2048, E4, BF, 0, 1, 1), "LP_128", (0, 0)),
+    ("fp8 with a row-major rhs", (4096, 4096, 4096, E4, BF, 0, 0, 1), "LP_256W4", (0, 1)),
+    ("K not a multiple of the K-tile: zero-padded copies", (512, 512, 1000, F16, F32, 0, 1, 1), "LP_128", (1, 1)),
+    ("four rows on a small grid", (4, 2048, 4096, BF, None, 0, 1, 1), "SKINNY", (0, 0)),
+    ("small output, long K: split along K", (512, 512, 8192, BF, None, 0, 1, 1), "LP_128", (0, 0)),
+]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return N.load()
+
+
+@pytest.mark.parametrize("what,shape,kernel,relaid", TABLE, ids=[t[0] for t in TABLE])
+def test_dispatcher_decisions_without_a_device(lib, what, shape, kernel, relaid):
+    m, n, k, ab, c, ta, tb, batch = shape
+    d = N.GemmDesc(m=m, n=n, k=k, batch=batch, lda=m if ta else k, ldb=k if tb else n, ldc=n, stride_a=m * k, stride_b=n * k, stride_c=m * n,
+                   dtype_ab=ab, dtype_c=ab if c is None else c, trans_a=ta, trans_b=tb, algo=N.GEMM_ALGO_AUTO)
+    algo, ra, rb = C.c_int32(-1), C.c_int32(-1), C.c_int32(-1)
+    assert lib.mi355_gemm_select(None, C.byref(d), C.byref(algo)) == N.OK
+    assert lib.mi355_gemm_relayout_plan(C.byref(d), C.byref(ra), C.byref(rb)) == N.OK
+    assert (algo.value, (ra.value, rb.value)) == (A[kernel], relaid), what
+
+
+def test_select_refuses_missing_arguments(lib):
+    d = N.GemmDesc(m=64, n=64, k=64, batch=1, lda=64, ldb=64, ldc=64, dtype_ab=BF, dtype_c=BF, trans_b=1)
+    assert lib.mi355_gemm_select(None, None, C.byref(C.c_int32())) == N.E_INVALID_ARGUMENT
+    assert lib.mi355_gemm_select(None, C.byref(d), None) == N.E_INVALID_ARGUMENT
