@@ -70,7 +70,7 @@ class MmaConfig(C.Structure):
                 ("a_type", C.c_int32), ("b_type", C.c_int32), ("cd_type", C.c_int32)]
 
 
-ABI_VERSION = 5     # MI355_ABI_VERSION of include/mi355cube.h this table was written against
+ABI_VERSION = 6     # MI355_ABI_VERSION of include/mi355cube.h this table was written against
 
 
 class MemoryUsage(C.Structure):
@@ -214,6 +214,7 @@ PROTOTYPES = {
     "mi355_gemm_add": (C.c_int32, [_P, _P, C.POINTER(GemmDesc), _P, _P, _P, _P]),
     "mi355_gemm_select": (C.c_int32, [_P, C.POINTER(GemmDesc), _I32P]),
     "mi355_gemm_tail_plan": (C.c_int32, [C.POINTER(GemmDesc), _I32P, C.POINTER(C.c_int64), _I32P]),
+    "mi355_gemm_split_plan": (C.c_int32, [C.POINTER(GemmDesc), C.c_int32, _I32P]),
     "mi355_gemm_relayout_plan": (C.c_int32, [C.POINTER(GemmDesc), _I32P, _I32P]),
     "mi355_gemm_scaled": (C.c_int32, [_P, _P, C.POINTER(GemmScaledDesc), _P, _P, _P, _P, _P]),
     "mi355_gemm_scaled_select": (C.c_int32, [_P, C.POINTER(GemmScaledDesc), _I32P]),

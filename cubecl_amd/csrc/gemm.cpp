@@ -424,6 +424,17 @@ MI355_API int32_t mi355_gemm_add(mi355_ctx *ctx, mi355_stream stream, const mi35
 }
 
 // Introspection (no device needed): how mi355_gemm would cut a descriptor that AUTO resolves to the 256x256 kernel.
+MI355_API int32_t mi355_gemm_split_plan(const mi355_gemm_desc *desc, int32_t compute_units, int32_t *out_slices)
+{
+    if (!desc || !out_slices || compute_units < 0) return MI355_E_INVALID_ARGUMENT;
+    static const char aligned_dummy __attribute__((aligned(16))) = 0;
+    *out_slices = 1;
+    if (desc->m <= 0 || desc->n <= 0 || desc->k <= 0 || desc->batch <= 0) return MI355_OK;
+    if (!gemm_lp128_supports(*desc, &aligned_dummy, &aligned_dummy, &aligned_dummy)) return MI355_OK;   // the launcher would never see it
+    *out_slices = (int32_t)lp128_split_count(*desc, compute_units ? compute_units : 256);
+    return MI355_OK;
+}
+
 MI355_API int32_t mi355_gemm_tail_plan(const mi355_gemm_desc *desc, int32_t *out_along_m, int64_t *out_main_extent, int32_t *out_splits)
 {
     if (!desc || !out_along_m || !out_main_extent || !out_splits) return MI355_E_INVALID_ARGUMENT;

@@ -119,6 +119,7 @@ int32_t launch_gemm_generic(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc
 int32_t launch_gemm_f32_mfma(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 int32_t launch_gemm_lp256x128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
+int64_t lp128_split_count(const mi355_gemm_desc &d, int64_t cus);   // K slices of the 128x128 kernel's launcher (gemm_lp128.hip), 1 = none
 bool gemm_lp256x128_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 int32_t launch_gemm_lp256(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 int32_t launch_gemm_lp256w4(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c,

@@ -698,6 +698,74 @@ bool gemm_lp128_supports(const mi355_gemm_desc &d, const void *a, const void *b,
     return true;
 }
 
+// ---- how many K slices the launcher cuts a descriptor into (1 = none): a pure function of the descriptor and the number of CUs, so that the
+// decisions below -- five of them were wrong at some point of round 3 -- are testable without a device (mi355_gemm_split_plan) ----------
+int64_t lp128_split_count(const mi355_gemm_desc &d, int64_t cus)
+{
+    // Split-K for shapes whose tile count cannot fill the chip (skinny M or N, GEMV-like): K is cut into slices,
+    // every slice writes an f32 partial slab, a small kernel folds the slabs in slice order (deterministic) and
+    // converts.  The slab traffic (2 x splits x M x N x 4 B) must stay small against the operand stream.
+    const int64_t batch = d.batch;
+    const int64_t tiles = ((d.m + BM - 1) / BM) * ((d.n + BN - 1) / BN) * batch;
+    const bool f8 = is_fp8(d.dtype_ab);
+    const int64_t esz = f8 ? 1 : 2;
+    const int64_t nk = d.k / (ROW_BYTES / esz);
+#ifndef LP128_WANT_MULT
+#define LP128_WANT_MULT 2   // workgroups the split aims at, in units of CUs
+#endif
+    // Slices so that tiles x slices fills the chip ONCE (one workgroup per CU, the deep ring) up to 96 tiles, twice (two co-resident
+    // workgroups per CU) from there to 128 -- until late round 3 always twice.  What a split buys is idle CUs put to work; past one
+    // workgroup per CU it only shortens the slices (pipeline fill per slice, more slab traffic) while the CU's LDS-DMA intake stays
+    // what it is.  Interleaved twice on cold operands, both rhs layouts (profiles/r03_want_mult_nt_nn.txt, r03_want_mult_few_rows.txt):
+    // 256 x 2048 x 8192 31-35 -> 23-24 us, 1024 x 512 x 8192 26.0 -> 22.3, 1024 x 1536 x 4096 31.5 -> 28.5, 128 x 8192 x 8192 47 -> 40-45,
+    // row-major weights 64 x 8192 x 8192 40.0 -> 33.4, 48 x 14336 x 4096 31.5 -> 28.3, 1 x 8192 x 8192 33 -> 30; ties at 512^2 x 8192,
+    // 1024^2 x 4096, 128 x 256 x 8192; 128 tiles keep the pair (2048 x 1024 x 4096 33 us against 39).
+#ifndef LP128_ONCE_UPTO
+#define LP128_ONCE_UPTO 96      // dev: 0 = round 3's earlier rule (always two workgroups per CU)
+#endif
+#ifndef LP128_NOSPLIT_FROM
+#define LP128_NOSPLIT_FROM 160  // dev: 1 << 30 = the earlier rule (any tile count splits when K is long against it)
+#endif
+    const int64_t want = (tiles <= LP128_ONCE_UPTO ? 1 : LP128_WANT_MULT) * cus;
+#ifndef LP128_SPLIT_RULE
+#define LP128_SPLIT_RULE 1   // dev: 0 = round 1's rule (any launch of fewer than one tile per CU with 8+ K-tiles)
+#endif
+    // Splitting pays for its slabs (f32 partials written and read back, one more launch: 10-20 us on these shapes) only when
+    // K is long against the number of tiles -- with T tiles, T CUs already stream 16 KiB per K-tile each -- and long in
+    // absolute terms.  Measured pairs, bf16, no split / split (tools/dev/split_ab.py): 32 tiles x 32 K-tiles 14.1 / 17.8 us;
+    // 48 x 48 21.4 / 20.6; 64 x 32 14.8 / 20.7, 64 x 64 26.3 / 25.3, 64 x 128 46.7 / 34.5; 96 x 64 25.9 / 34.8, 96 x 256
+    // 161 / 131; 112 x 16 9.3 / 18.3, 112 x 64 26.3 / 38.9; 128 x 16 9.9 / 20.6, 128 x 128 50.5 / 46.5; 160 x 32 16.6 /
+    // 34.5; 192 x 64 28 / 49; 224 x 128 (128 x 28672 x 8192) 104 / 142.  Rule: at least as many K-tiles as tiles, and 48 of
+    // them unless the tiles are a handful.
+    // Round 3, re-measured on cold operands with the slice count CAPPED by the slab-traffic bound (below) instead of the split
+    // being rejected beyond it (profiles/r03_split_rule_cold.txt, rule against "always split", interleaved twice): with at most
+    // 128 tiles splitting never loses and wins where the bound leaves two or more slices (32 tiles x 32 K-tiles 20.7 -> 15.3 us,
+    // 64 x 32 20.6 -> 17.6, 72 x 64 36.5 -> 30.1, 96 x 64 37.5 -> 30.7, 128 x 64 37.4 -> 33.2); from 160 tiles up it loses unless K is
+    // long against the tile count (192 x 64 38.6 against 50.4 split, 224 x 128 79 / 110).
+    // (late round 3: from 160 tiles up never -- 1536 x 2048 x 16384, 192 tiles x 256 K-tiles, 176-183 us in two slices against
+    //  150-155 unsplit; 768 x 3072 x 14336, 144 x 224, still wins split three ways: 122 against 136)
+    const bool long_k = LP128_SPLIT_RULE == 0 || tiles <= 128 || (tiles < LP128_NOSPLIT_FROM && nk >= tiles && nk >= 48);
+    if (!(tiles < std::max<int64_t>(want, 2 * cus) / 2 && nk >= 8 && long_k && batch <= 65535)) return 1;
+    {
+        const int64_t slab = d.batch * d.m * d.n;
+        const int64_t operand_bytes = (d.m * d.k + d.n * d.k) * esz * d.batch;
+        // The slab traffic (one f32 write + one read per slice and output) must stay below twice the operand stream.  Until
+        // round 3 a split count beyond that bound was REJECTED (no split at all) instead of capped: 512 x 512 x 8192 wanted
+        // 32 slices, was allowed 16 and ran on 16 workgroups -- 68.7 us against 20.7 with 16 slices; 1024^2 x 4096 37.7 -> 21.6,
+        // 1024 x 512 x 8192 69 -> 25.5 (cold operands, interleaved; profiles/r03_split_k_cap.txt).
+        const int64_t by_traffic = slab > 0 ? (2 * operand_bytes) / (slab * 8) : 1;
+        // slices so that tiles x slices stays WITHIN the two-workgroups-per-CU residency (floor, not ceil: 144 tiles x 4 slices = 576
+        // workgroups ran a partial second round -- 768 x 3072 x 14336 151 -> 118 us, 1536 x 2048 x 16384 205 -> 177 with 3 and 2 slices;
+        // profiles/r03_split_count_floor.txt)
+        int64_t splits = std::min<int64_t>({std::max<int64_t>(want / tiles, 1), nk / 4, 32, by_traffic});
+        if (splits > 1) {
+            const int64_t per = (nk + splits - 1) / splits;
+            splits = (nk + per - 1) / per;                                  // no empty slices
+        }
+        return (splits > 1 && splits * slab * 8 <= 2 * operand_bytes) ? splits : 1;
+    }
+}
+
 int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b,
                           void *c)
 {
@@ -722,67 +790,12 @@ int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
 #endif
     }
     const uint32_t batch = (uint32_t)d.batch;
-    // Split-K for shapes whose tile count cannot fill the chip (skinny M or N, GEMV-like): K is cut into slices,
-    // every slice writes an f32 partial slab, a small kernel folds the slabs in slice order (deterministic) and
-    // converts.  The slab traffic (2 x splits x M x N x 4 B) must stay small against the operand stream.
-    const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * batch;
-    const bool f8 = is_fp8(d.dtype_ab);
-    const int64_t esz = f8 ? 1 : 2;
-    const int64_t nk = d.k / (ROW_BYTES / esz);
-#ifndef LP128_WANT_MULT
-#define LP128_WANT_MULT 2   // workgroups the split aims at, in units of CUs
-#endif
-    // Slices so that tiles x slices fills the chip ONCE (one workgroup per CU, the deep ring) up to 96 tiles, twice (two co-resident
-    // workgroups per CU) from there to 128 -- until late round 3 always twice.  What a split buys is idle CUs put to work; past one
-    // workgroup per CU it only shortens the slices (pipeline fill per slice, more slab traffic) while the CU's LDS-DMA intake stays
-    // what it is.  Interleaved twice on cold operands, both rhs layouts (profiles/r03_want_mult_nt_nn.txt, r03_want_mult_few_rows.txt):
-    // 256 x 2048 x 8192 31-35 -> 23-24 us, 1024 x 512 x 8192 26.0 -> 22.3, 1024 x 1536 x 4096 31.5 -> 28.5, 128 x 8192 x 8192 47 -> 40-45,
-    // row-major weights 64 x 8192 x 8192 40.0 -> 33.4, 48 x 14336 x 4096 31.5 -> 28.3, 1 x 8192 x 8192 33 -> 30; ties at 512^2 x 8192,
-    // 1024^2 x 4096, 128 x 256 x 8192; 128 tiles keep the pair (2048 x 1024 x 4096 33 us against 39).
-#ifndef LP128_ONCE_UPTO
-#define LP128_ONCE_UPTO 96      // dev: 0 = round 3's earlier rule (always two workgroups per CU)
-#endif
-#ifndef LP128_NOSPLIT_FROM
-#define LP128_NOSPLIT_FROM 160  // dev: 1 << 30 = the earlier rule (any tile count splits when K is long against it)
-#endif
-    const int64_t want = (tiles <= LP128_ONCE_UPTO ? 1 : LP128_WANT_MULT) * (int64_t)ctx->props.num_streaming_multiprocessors;
-#ifndef LP128_SPLIT_RULE
-#define LP128_SPLIT_RULE 1   // dev: 0 = round 1's rule (any launch of fewer than one tile per CU with 8+ K-tiles)
-#endif
-    // Splitting pays for its slabs (f32 partials written and read back, one more launch: 10-20 us on these shapes) only when
-    // K is long against the number of tiles -- with T tiles, T CUs already stream 16 KiB per K-tile each -- and long in
-    // absolute terms.  Measured pairs, bf16, no split / split (tools/dev/split_ab.py): 32 tiles x 32 K-tiles 14.1 / 17.8 us;
-    // 48 x 48 21.4 / 20.6; 64 x 32 14.8 / 20.7, 64 x 64 26.3 / 25.3, 64 x 128 46.7 / 34.5; 96 x 64 25.9 / 34.8, 96 x 256
-    // 161 / 131; 112 x 16 9.3 / 18.3, 112 x 64 26.3 / 38.9; 128 x 16 9.9 / 20.6, 128 x 128 50.5 / 46.5; 160 x 32 16.6 /
-    // 34.5; 192 x 64 28 / 49; 224 x 128 (128 x 28672 x 8192) 104 / 142.  Rule: at least as many K-tiles as tiles, and 48 of
-    // them unless the tiles are a handful.
-    // Round 3, re-measured on cold operands with the slice count CAPPED by the slab-traffic bound (below) instead of the split
-    // being rejected beyond it (profiles/r03_split_rule_cold.txt, rule against "always split", interleaved twice): with at most
-    // 128 tiles splitting never loses and wins where the bound leaves two or more slices (32 tiles x 32 K-tiles 20.7 -> 15.3 us,
-    // 64 x 32 20.6 -> 17.6, 72 x 64 36.5 -> 30.1, 96 x 64 37.5 -> 30.7, 128 x 64 37.4 -> 33.2); from 160 tiles up it loses unless K is
-    // long against the tile count (192 x 64 38.6 against 50.4 split, 224 x 128 79 / 110).
-    // (late round 3: from 160 tiles up never -- 1536 x 2048 x 16384, 192 tiles x 256 K-tiles, 176-183 us in two slices against
-    //  150-155 unsplit; 768 x 3072 x 14336, 144 x 224, still wins split three ways: 122 against 136)
-    const bool long_k = LP128_SPLIT_RULE == 0 || tiles <= 128 || (tiles < LP128_NOSPLIT_FROM && nk >= tiles && nk >= 48);
-    if (tiles < std::max<int64_t>(want, 2 * (int64_t)ctx->props.num_streaming_multiprocessors) / 2 && nk >= 8 && long_k && batch <= 65535) {
+    // Split-K for shapes whose tile count cannot fill the chip: see lp128_split_count above
+    const int64_t splits = lp128_split_count(d, (int64_t)ctx->props.num_streaming_multiprocessors);
+    if (splits > 1) {
         const int64_t slab = d.batch * d.m * d.n;
-        const int64_t operand_bytes = (d.m * d.k + d.n * d.k) * esz * d.batch;
-        // The slab traffic (one f32 write + one read per slice and output) must stay below twice the operand stream.  Until
-        // round 3 a split count beyond that bound was REJECTED (no split at all) instead of capped: 512 x 512 x 8192 wanted
-        // 32 slices, was allowed 16 and ran on 16 workgroups -- 68.7 us against 20.7 with 16 slices; 1024^2 x 4096 37.7 -> 21.6,
-        // 1024 x 512 x 8192 69 -> 25.5 (cold operands, interleaved; profiles/r03_split_k_cap.txt).
-        const int64_t by_traffic = slab > 0 ? (2 * operand_bytes) / (slab * 8) : 1;
-        // slices so that tiles x slices stays WITHIN the two-workgroups-per-CU residency (floor, not ceil: 144 tiles x 4 slices = 576
-        // workgroups ran a partial second round -- 768 x 3072 x 14336 151 -> 118 us, 1536 x 2048 x 16384 205 -> 177 with 3 and 2 slices;
-        // profiles/r03_split_count_floor.txt)
-        int64_t splits = std::min<int64_t>({std::max<int64_t>(want / tiles, 1), nk / 4, 32, by_traffic});
-        if (splits > 1) {
-            const int64_t per = (nk + splits - 1) / splits;
-            splits = (nk + per - 1) / per;                                  // no empty slices
-        }
         float *ws = nullptr;
-        if (splits > 1 && splits * slab * 8 <= 2 * operand_bytes &&
-            splitk_scratch(ctx, s, (size_t)(splits * slab) * sizeof(float), &ws) == MI355_OK) {
+        if (splitk_scratch(ctx, s, (size_t)(splits * slab) * sizeof(float), &ws) == MI355_OK) {
             gemm_args gs = g;
             gs.c = ws; gs.ldc = d.n; gs.stride_c = d.m * d.n;
             gs.split_k = (uint32_t)splits; gs.split_c_stride = slab;

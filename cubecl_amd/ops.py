@@ -179,6 +179,13 @@ def gemm_relayout_plan(client: ComputeClient, desc: N.GemmDesc):
     return bool(ra.value), bool(rb.value)
 
 
+def gemm_split_plan(client: ComputeClient, desc: N.GemmDesc) -> int:
+    """K slices the 128x128 kernel's launcher cuts `desc` into on this device (1 = one plain launch)."""
+    out = C.c_int32()
+    client._s.check(client.lib.mi355_gemm_split_plan(C.byref(desc), int(client.properties().num_streaming_multiprocessors or 0), C.byref(out)))
+    return out.value
+
+
 _WORKSPACES: dict = {}
 
 

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define MI355_ABI_VERSION 5
+#define MI355_ABI_VERSION 6
 
 /* ---- status codes (map onto LaunchError / IoError / ServerError, server/base.rs:177-332,
  *      :884-1019; the Rust shim performs the conversion) ------------------------------- */
@@ -410,6 +410,10 @@ int32_t mi355_gemm_select(mi355_ctx *ctx, const mi355_gemm_desc *desc, int32_t *
  * (one batched launch + the deterministic slab fold). */
 int32_t mi355_gemm_tail_plan(const mi355_gemm_desc *desc, int32_t *out_along_m, int64_t *out_main_extent,
                              int32_t *out_splits);
+/* (since ABI 6) How many K slices the 128x128 kernel's launcher cuts a descriptor into on a device with `compute_units` CUs
+ * (0 = 256, the MI355X): 1 = one plain launch, otherwise that many f32 partial slabs + the deterministic fold.  A pure
+ * function like the one above -- what it answers is only acted on when mi355_gemm_select says the 128x128 kernel runs. */
+int32_t mi355_gemm_split_plan(const mi355_gemm_desc *desc, int32_t compute_units, int32_t *out_slices);
 /* Which operands mi355_gemm (AUTO) would first copy into library scratch, re-laid out K-contiguous -- the role of the
  * reference launchers' into_contiguous after matrix_batch_layout (crates/cubecl-std/src/tensor/matrix_batch_layout.rs:21-79)
  * -- before an MFMA kernel runs (pure function, no device; operands taken as 16-byte aligned).  Both 0: the kernels stage

@@ -6,7 +6,7 @@ use core::ffi::{c_char, c_void};
 
 /// `MI355_ABI_VERSION` of the header these declarations were written against; `Mi355Runtime` compares it with what the
 /// loaded library reports (`mi355_device_props_t::abi_version`).
-pub const MI355_ABI_VERSION: u32 = 5;
+pub const MI355_ABI_VERSION: u32 = 6;
 
 pub const MI355_OK: i32 = 0;
 pub const MI355_E_INVALID_ARGUMENT: i32 = 1;
@@ -304,6 +304,7 @@ unsafe extern "C" {
     pub fn mi355_gemm_scaled_select(ctx: *mut mi355_ctx, desc: *const mi355_gemm_scaled_desc, out_algo: *mut i32) -> i32;
     pub fn mi355_gemm_select(ctx: *mut mi355_ctx, desc: *const mi355_gemm_desc, out_algo: *mut i32) -> i32;
     pub fn mi355_gemm_tail_plan(desc: *const mi355_gemm_desc, out_along_m: *mut i32, out_main_extent: *mut i64, out_splits: *mut i32) -> i32;
+    pub fn mi355_gemm_split_plan(desc: *const mi355_gemm_desc, compute_units: i32, out_slices: *mut i32) -> i32;
     pub fn mi355_gemm_relayout_plan(desc: *const mi355_gemm_desc, out_relayout_a: *mut i32, out_relayout_b: *mut i32) -> i32;
     // an alternative to MemoryManagement-over-Mi355Storage for hosts without the reference's pool (memory_manage.rs)
     pub fn mi355_pool_alloc(ctx: *mut mi355_ctx, stream: mi355_stream, bytes: u64, out_dptr: *mut *mut c_void) -> i32;

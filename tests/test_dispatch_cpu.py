@@ -76,3 +76,56 @@ def test_select_refuses_missing_arguments(lib):
     d = N.GemmDesc(m=64, n=64, k=64, batch=1, lda=64, ldb=64, ldc=64, dtype_ab=BF, dtype_c=BF, trans_b=1)
     assert lib.mi355_gemm_select(None, None, C.byref(C.c_int32())) == N.E_INVALID_ARGUMENT
     assert lib.mi355_gemm_select(None, C.byref(d), None) == N.E_INVALID_ARGUMENT
+
+
+# ---- the 128x128 kernel's split-K launcher (gemm_lp128.hip lp128_split_count), through mi355_gemm_split_plan -------------------------------
+# Five decisions in here were wrong at some point of round 3 and only showed as time: a slice count beyond the
+# slab-traffic bound was rejected instead of capped; the count was rounded up past the chip's residency; the target was two workgroups
+# per CU whatever the tile count; from 160 tiles up a long K still split.  (m, n, k, trans_a, trans_b) -> slices on 256 CUs.
+SPLITS = [
+    ((512, 512, 8192, 0, 1), 16),      # 16 tiles: fill the chip once (256 / 16); was 32 wanted -> rejected -> 1 (68.7 us against 16.5)
+    ((1024, 512, 8192, 0, 1), 8),      # 32 tiles: once (26.0 -> 22.3 us against 16 slices)
+    ((256, 2048, 8192, 0, 1), 8),      # 32 tiles (36.4 -> 24-27 us)
+    ((1024, 1024, 4096, 0, 1), 4),     # 64 tiles
+    ((128, 8192, 8192, 0, 1), 4),      # 64 tiles
+    ((1024, 1536, 4096, 0, 1), 2),     # 96 tiles: still once (floor(256 / 96))
+    ((2048, 1024, 4096, 0, 1), 3),     # 128 tiles: the pair per CU (512 / 128 = 4), capped at 3 by the slab-traffic bound
+    ((768, 3072, 14336, 0, 1), 3),     # 144 tiles x 224 K-tiles: floor(512 / 144), not 4 (151 -> 118 us)
+    ((1536, 2048, 16384, 0, 1), 1),    # 192 tiles: never split from 160 up (177 -> 150-168 us unsplit)
+    ((64, 28672, 8192, 0, 1), 1),      # 224 tiles
+    ((128, 28672, 8192, 0, 1), 1),
+    ((2048, 2048, 2048, 0, 1), 1),     # one tile per CU
+    ((8192, 8192, 64, 0, 1), 1),       # one K-tile
+    ((512, 512, 512, 0, 1), 1),        # 8 K-tiles of 16 tiles: nk / 4 = 2 slices would be allowed, the traffic bound says no
+    ((128, 256, 8192, 0, 1), 32),      # 2 tiles: the cap of 32 slices
+    ((96, 96, 16384, 0, 1), 32),
+    ((16, 8192, 8192, 0, 0), 4),       # row-major weight, few rows: 64 tiles of 64 x 128
+    ((1, 8192, 8192, 0, 0), 4),
+    ((64, 8192, 8192, 0, 0), 4),
+    ((512, 512, 8192, 1, 0), 16),      # the weight-gradient layout splits like its K-contiguous twin
+]
+
+
+@pytest.mark.parametrize("shape,slices", SPLITS, ids=["x".join(map(str, s[:3])) + ("_T" if s[3] else "") + ("" if s[4] else "_NN") for s, _ in SPLITS])
+def test_split_k_launcher_decisions_without_a_device(lib, shape, slices):
+    m, n, k, ta, tb = shape
+    d = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=m if ta else k, ldb=k if tb else n, ldc=n, stride_a=m * k, stride_b=n * k, stride_c=m * n,
+                   dtype_ab=BF, dtype_c=BF, trans_a=ta, trans_b=tb, algo=N.GEMM_ALGO_AUTO)
+    got = C.c_int32(-1)
+    assert lib.mi355_gemm_split_plan(C.byref(d), 0, C.byref(got)) == N.OK
+    assert got.value == slices
+    # every slice gets at least four K-tiles and none is empty
+    nk = k // 64
+    if got.value > 1:
+        per = -(-nk // got.value)
+        assert per >= 4 and (got.value - 1) * per < nk
+
+
+def test_split_plan_edges(lib):
+    d = N.GemmDesc(m=512, n=512, k=8192, batch=1, lda=8192, ldb=8192, ldc=512, dtype_ab=BF, dtype_c=BF, trans_b=1)
+    got = C.c_int32(-1)
+    assert lib.mi355_gemm_split_plan(C.byref(d), 128, C.byref(got)) == N.OK and got.value == 8       # half the CUs: half the slices
+    assert lib.mi355_gemm_split_plan(None, 0, C.byref(got)) == N.E_INVALID_ARGUMENT
+    assert lib.mi355_gemm_split_plan(C.byref(d), -1, C.byref(got)) == N.E_INVALID_ARGUMENT
+    d.k = 8200                                                                                     # not a K-tile multiple: the kernel never sees it
+    assert lib.mi355_gemm_split_plan(C.byref(d), 0, C.byref(got)) == N.OK and got.value == 1

@@ -1183,3 +1183,11 @@ def test_transposed_a_selection_and_refusals(client, oracle):
     ops.matmul(client, TensorHandle.new(ta.handle, (m, k), (1, m), bf), TensorHandle.new(tb.handle, (k, n), (n, 1), bf), c)
     A, Bv = a_val.reshape(k, m).T.astype(np.float64), b_val.reshape(k, n).astype(np.float64)
     assert np.all(np.abs(c.to_numpy(client).reshape(m, n) - A @ Bv) <= REL * (np.abs(A) @ np.abs(Bv)) + 1e-30)
+
+
+def test_split_plan_on_the_device_is_what_the_launcher_does(client):
+    """mi355_gemm_split_plan with this device's CU count (ops.gemm_split_plan): 512 x 512 x 8192 runs as 16 slices on 256 CUs -- and rocprofv3
+    shows 16 x 16 = 256 workgroups of the split kernel plus one fold (profiles/r03_rocprof_kernel_stats_all_configs_final_tree.csv)."""
+    d = N.GemmDesc(m=512, n=512, k=8192, batch=1, lda=8192, ldb=8192, ldc=512, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_BF16, trans_b=1)
+    assert client.properties().num_streaming_multiprocessors == 256 and ops.gemm_split_plan(client, d) == 16
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_128
