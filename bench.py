@@ -158,7 +158,7 @@ KERNEL_SOURCES = {
     "reduce": ("cubecl_amd/csrc/reduce.hip", "cubecl_amd/csrc/internal.hpp"),
 }
 PROFILES_DIR = ROOT / "profiles"
-HEADLINE_KERNEL = "gemm_lp256w4_kernel<1, 1, false, 1, false>"     # bf16 x bf16 -> bf16 C, [N][K] B, unscaled (what rocprofv3 prints)
+HEADLINE_KERNEL = "gemm_lp256w4_kernel<1, 1, false, 1, false, false>"     # bf16 x bf16 -> bf16 C, [N][K] B, unscaled (what rocprofv3 prints)
 REDUCE_SUM_KERNEL = "reduce_kernel<true, false, 0>"      # <SUM, ARGMAX, DT = f32>
 
 

@@ -49,14 +49,20 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
     }
     // A stored [K][M] with a row-major B (lhs^T . grad_out, the weight-gradient product of a training step): the 128x128 kernel
     // stages both natively (gemm_lp128.hip ATN) -- taken exactly when that kernel would be chosen for the same shape with a
-    // K-contiguous A; where a 256-tile or a streaming kernel would win, A is transposed into scratch first (GENERIC = "re-lay
-    // out, then select again": 8192^3 797 us that way against ~1 250 on 4096 tiles of 128^2) and B stays as it is.
+    // K-contiguous A, and so does the 256x256 kernel; where another kernel would win (the streaming ones, the 256 x 128 tile, the
+    // persistent forms' ground is taken by the one-tile kernel), A is transposed into scratch first (GENERIC = "re-lay out, then
+    // select again") and B stays as it is.
     if (d.trans_a) {
-        if (d.trans_b || !gemm_lp128_supports(d, a, b, c)) return MI355_GEMM_ALGO_GENERIC;
+        if (d.trans_b) return MI355_GEMM_ALGO_GENERIC;
         static const char aligned_dummy __attribute__((aligned(16))) = 0;
         mi355_gemm_desc e = d;
         e.trans_a = 0; e.lda = d.k; e.stride_a = d.stride_a == 0 ? 0 : d.m * d.k;
-        return select(e, &aligned_dummy, b, c) == MI355_GEMM_ALGO_LP_128 ? MI355_GEMM_ALGO_LP_128 : MI355_GEMM_ALGO_GENERIC;
+        const int32_t twin = select(e, &aligned_dummy, b, c);             // what the same shape takes with a K-contiguous A
+        if (twin == MI355_GEMM_ALGO_LP_128 && gemm_lp128_supports(d, a, b, c)) return MI355_GEMM_ALGO_LP_128;
+        // ... and the 256x256 kernel stages it the same way (gemm_lp256w4.hip ATN; its persistent forms do not: select_auto leaves
+        // a transposed lhs on the one-tile-per-workgroup kernel)
+        if (twin == MI355_GEMM_ALGO_LP_256W4 && gemm_lp256w4_supports(d, a, b, c)) return MI355_GEMM_ALGO_LP_256W4;
+        return MI355_GEMM_ALGO_GENERIC;
     }
     const bool big = gemm_lp256_supports(d, a, b, c);
     const bool big4 = gemm_lp256w4_supports(d, a, b, c);

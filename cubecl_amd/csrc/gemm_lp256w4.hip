@@ -196,12 +196,15 @@ __device__ __forceinline__ void scale_ld32(uint32_t &dst, const void *ubase, uin
     asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(ubase), "n"(imm) : "memory");
 }
 
-template <int DT, int DT_C, bool BNN = false, int DTB = DT, bool MX = false>
+template <int DT, int DT_C, bool BNN = false, int DTB = DT, bool MX = false, bool ATN = false>
 __global__ void __launch_bounds__(256)
 gemm_lp256w4_kernel(gemm_args g)
 {
     static_assert(!BNN || DT == MI355_DTYPE_F32 || DT == MI355_DTYPE_BF16 || DT == MI355_DTYPE_F16, "row-major B: f32 and 16-bit operands");
     constexpr bool BNN16 = BNN && (DT == MI355_DTYPE_BF16 || DT == MI355_DTYPE_F16);
+    // ATN (late round 3): A stored [K][M] together with a row-major B (lhs^T . grad_out) -- the A tile of a K-tile is 64 k-rows x 256 m,
+    // the mirror image of the row-major B tile: same blocks, same pieces, same transposing reads (gemm_lp128.hip ATN)
+    static_assert(!ATN || BNN16, "A stored [K][M]: 16-bit operands, together with a row-major B");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     typedef typename lp<DT>::frag frag;
     static_assert(sizeof(typename lp<DTB>::frag) == sizeof(frag), "A and B fragments must have the same width");
@@ -260,6 +263,15 @@ gemm_lp256w4_kernel(gemm_args g)
         } else
             voff_bnn[j] = (uint32_t)(j * g.ldb * ESZ + min((int64_t)lane * 4, g.n - 4 - n0) * ESZ);
     }
+    const char *ubase_atn = A + (int64_t)(wave * 16) * g.lda * ESZ + m0 * ESZ;
+    uint32_t voff_atn[ATN ? 8 : 1];
+    if constexpr (ATN) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                                     // rows of C past M re-read the last valid 16 bytes
+            const int64_t col = (j & 1) * 128 + (lane >> 4) * 32 + (lane & 3) * 8;
+            voff_atn[j] = (uint32_t)(((j >> 1) * 4 + ((lane & 15) >> 2)) * g.lda * ESZ + min(col, g.m - 8 - m0) * ESZ);
+        }
+    }
     const int dst_piece = wave * 8 * 1024;                            // + j*1024 within the slot
 
     // ---- fragment read offsets: row*128 + ((2s+h) ^ f) * 16, f = (row>>1)&7 = (l31>>1)&7 for every tile row
@@ -267,7 +279,7 @@ gemm_lp256w4_kernel(gemm_args g)
     // fp8: the second 16 bytes of a fragment sit in physical chunk ^ 1 (unscaled: logical chunks 2c, 2c+1); MX: logical
     // chunks c and c+2 (registers 0-3 of both lane-halves are one MX block, registers 4-7 the next) = physical ^ 2
     const int hd = MX ? ((f & 2) ? -32 : 32) : ((f & 1) ? -16 : 16);
-    const int rowoff_a = (wm * 128 + l31) * ROW_BYTES;
+    const int rowoff_a = ATN ? wm * 4 * 256 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8 : (wm * 128 + l31) * ROW_BYTES;
     // (16-bit row-major B: block b = 4 wn + j of the lane-half's block row, + row (lane%16)/4, + 16-lane group, + 8 B per lane)
     const int rowoff_b = BNN16 ? wn * 4 * 256 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8
                          : BNN ? (wn * 128 + l31) * 4 : (wn * 128 + l31) * ROW_BYTES;
@@ -332,8 +344,18 @@ gemm_lp256w4_kernel(gemm_args g)
             frag &dst = (FR == 0) ? fb[BUF][0] : (FR <= 4) ? fa[BUF][(FR - 1) & 3] : fb[BUF][(FR - 4) & 3];
             dst[4 * HALF + 0] = (int)v[0]; dst[4 * HALF + 1] = (int)v[1]; dst[4 * HALF + 2] = (int)v[2]; dst[4 * HALF + 3] = (int)v[3];
         } else if constexpr (BNN16) {
-            if constexpr (R >= 1 && R <= 4) fa[BUF][R - 1] = *reinterpret_cast<const frag *>(pa + (R - 1) * 32 * ROW_BYTES);
-            else {
+            if constexpr (R >= 1 && R <= 4) {
+                if constexpr (ATN) {                             // row block R - 1: k 0..3 from block row a, k 4..7 from a + 1
+                    typedef short s16x4 __attribute__((ext_vector_type(4)));
+                    typedef short s16x8 __attribute__((ext_vector_type(8)));
+                    const auto q = (const __attribute__((address_space(3))) s16x4 *)(pa + (R - 1) * 256);
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<__attribute__((address_space(3))) s16x4 *>(q));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<__attribute__((address_space(3))) s16x4 *>(q + 256));
+                    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    fa[BUF][R - 1] = __builtin_bit_cast(frag, both);
+                } else
+                    fa[BUF][R - 1] = *reinterpret_cast<const frag *>(pa + (R - 1) * 32 * ROW_BYTES);
+            } else {
                 constexpr int JB = (R == 0) ? 0 : R - 4;       // column block JB: k 0..3 from block row a, k 4..7 from a + 1
                 typedef short s16x4 __attribute__((ext_vector_type(4)));
                 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -362,6 +384,8 @@ gemm_lp256w4_kernel(gemm_args g)
         if constexpr (BNN && decltype(is_b)::value) {
             // koff = tile * 128 bytes along K for the K-contiguous layout; here a K-tile is 32 rows of ldb elements
             glds16_s<J * 1024>(ubase_bnn + koff * g.ldb, voff_bnn[J], lds_addr_of(base));
+        } else if constexpr (ATN && !decltype(is_b)::value) {
+            glds16_s<J * 1024>(ubase_atn + koff * g.lda, voff_atn[J], lds_addr_of(base));
         } else {
             glds16_s<J * 1024>((decltype(is_b)::value ? ubase_b : ubase_a) + koff, decltype(is_b)::value ? voff_b[J] : voff_a[J],
                                lds_addr_of(base));
@@ -447,7 +471,7 @@ gemm_lp256w4_kernel(gemm_args g)
         // scale bytes are one word; fp8 MX: k-step d = chunks 4d+h (registers 0-3) and 4d+2+h (registers 4-7);
         // unscaled: the mappings the measured kernels were tuned with
         const int x = F4 ? ((4 * h) ^ f) << 4 : (F8 && !MX) ? ((2 * h) ^ f) << 4 : (h ^ f) << 4;
-        const char *rd_a = smem + rowoff_a + x, *rd_b = smem + UNIT_BYTES + rowoff_b + (BNN16 ? h * 4096 : BNN ? (4 * h) * 1024 : x);
+        const char *rd_a = smem + rowoff_a + (ATN ? h * 4096 : x), *rd_b = smem + UNIT_BYTES + rowoff_b + (BNN16 ? h * 4096 : BNN ? (4 * h) * 1024 : x);
         read_one(IC<0>{}, IC<0>{}, rd_a, rd_b); read_one(IC<0>{}, IC<1>{}, rd_a, rd_b);
         read_one(IC<0>{}, IC<2>{}, rd_a, rd_b); read_one(IC<0>{}, IC<3>{}, rd_a, rd_b);
         read_one(IC<0>{}, IC<4>{}, rd_a, rd_b); read_one(IC<0>{}, IC<5>{}, rd_a, rd_b);
@@ -471,6 +495,8 @@ gemm_lp256w4_kernel(gemm_args g)
     const int y0 = BNN16 ? h * 4096 : BNN ? (4 * h) * 1024 : x0, y1 = BNN16 ? 8192 + h * 4096 : BNN ? (8 + 4 * h) * 1024 : x1,
               y2 = BNN16 ? 16384 + h * 4096 : BNN ? (16 + 4 * h) * 1024 : x2, y3 = BNN16 ? 24576 + h * 4096 : BNN ? (24 + 4 * h) * 1024 : x3;
 
+    const int xa0 = ATN ? y0 : x0, xa1 = ATN ? y1 : x1, xa2 = ATN ? y2 : x2, xa3 = ATN ? y3 : x3;   // A stored [K][M]: block rows, as row-major B
+
     // One K-tile.  ISSUE = 1: the steady state (units 2t+4, 2t+5 are issued, vmcnt(8) at the hand-over).
     // ISSUE = 0: the last two K-tiles of the tile -- there is nothing left to fetch, so no DMA is issued (the first
     // version re-read the last K-tile into dead slots to keep the counts uniform: 2 K-tiles of useless L2 traffic
@@ -484,14 +510,14 @@ gemm_lp256w4_kernel(gemm_args g)
         const char *rd_a, *rd_b;                                                                            \
         char *dma_base;                                                                                     \
         /* k-step 0: reads of step 1 after MFMA 0-7, unit 2t+4 pieces 0-3 after MFMA 9,11,13,15 */          \
-        rd_a = smem + sa + rowoff_a + x1; rd_b = smem + sb + rowoff_b + y1; dma_base = smem + s4 + dst_piece; \
+        rd_a = smem + sa + rowoff_a + xa1; rd_b = smem + sb + rowoff_b + y1; dma_base = smem + s4 + dst_piece; \
         /* (MX: the 8 scale loads of K-tile t+1 after MFMA 8,10,12,14 of k-steps 0 and 1) */                \
         W4_STEP_BODY(0, 1, 0x00FFu, (ISSUE) ? 0xAA00u : 0u, 0, 0, 0, (MX && (SC)) ? 0x5500u : 0u, 0)         \
         /* k-step 1: reads of step 2, unit 2t+4 pieces 4-7 */                                               \
-        rd_a = smem + sa + rowoff_a + x2; rd_b = smem + sb + rowoff_b + y2;                                 \
+        rd_a = smem + sa + rowoff_a + xa2; rd_b = smem + sb + rowoff_b + y2;                                 \
         W4_STEP_BODY(1, 0, 0x00FFu, (ISSUE) ? 0xAA00u : 0u, 0, 4, 1, (MX && (SC)) ? 0x5500u : 0u, 4)         \
         /* k-step 2: reads of step 3, no DMA; then the K-tile hand-over */                                  \
-        rd_a = smem + sa + rowoff_a + x3; rd_b = smem + sb + rowoff_b + y3;                                 \
+        rd_a = smem + sa + rowoff_a + xa3; rd_b = smem + sb + rowoff_b + y3;                                 \
         W4_STEP_BODY(0, 1, 0x00FFu, 0x0000u, 0, 0, 2, 0u, 0)                                                \
         if (!(W4_ABL & 8)) {                              /* dev ablation 8: no hand-over (timing only, races) */ \
         /* my share of K-tile t+1 landed; unit 2t+4 (and, MX, the 8 scale loads issued among it) may fly */ \
@@ -501,7 +527,7 @@ gemm_lp256w4_kernel(gemm_args g)
         }                                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
         /* k-step 3: reads of step 0 of K-tile t+1 after even MFMAs, unit 2t+5 pieces 0-7 after odd ones */ \
-        rd_a = smem + sa1 + rowoff_a + x0; rd_b = smem + sb1 + rowoff_b + y0; dma_base = smem + s5 + dst_piece; \
+        rd_a = smem + sa1 + rowoff_a + xa0; rd_b = smem + sb1 + rowoff_b + y0; dma_base = smem + s5 + dst_piece; \
         W4_STEP_BODY(1, 0, 0x5555u, (ISSUE) ? 0xAAAAu : 0u, 1, 0, 3, 0u, 0)                                  \
         if constexpr (MX && (SC)) { if (ISSUE) { W4_TAKE_SCALES(8) } else { W4_TAKE_SCALES(0) } }           \
         sa = sa1;                                                                                           \
@@ -697,11 +723,11 @@ gemm_lp256w4_kernel(gemm_args g)
 #endif
 }
 
-template <int DT, int DT_C, bool BNN = false, int DTB = DT, bool MX = false>
+template <int DT, int DT_C, bool BNN = false, int DTB = DT, bool MX = false, bool ATN = false>
 void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch)
 {
-    lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_lp256w4_kernel<DT, DT_C, BNN, DTB, MX>), LDS_BYTES);
-    hipLaunchKernelGGL((gemm_lp256w4_kernel<DT, DT_C, BNN, DTB, MX>), dim3(g.tiles_m * g.tiles_n, batch), dim3(256), LDS_BYTES, s, g);
+    lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_lp256w4_kernel<DT, DT_C, BNN, DTB, MX, ATN>), LDS_BYTES);
+    hipLaunchKernelGGL((gemm_lp256w4_kernel<DT, DT_C, BNN, DTB, MX, ATN>), dim3(g.tiles_m * g.tiles_n, batch), dim3(256), LDS_BYTES, s, g);
 }
 
 }  // namespace
@@ -722,7 +748,8 @@ bool gemm_lp256w4_supports(const mi355_gemm_desc &d, const void *a, const void *
     if (f8) {
         if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != MI355_DTYPE_BF16 && d.dtype_c != MI355_DTYPE_F16) return false;
     } else if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != d.dtype_ab) return false;
-    if (d.trans_a) return false;
+    // A stored [K][M]: 16-bit operands, together with a row-major B, fetched 8 rows of C (16 bytes of a k-row) at a time
+    if (d.trans_a && ((d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16) || d.trans_b || d.m < 8 || (d.m & 7))) return false;
     if (!d.trans_b && f8) return false;                                     // row-major B: f32 and 16-bit operands
     const int64_t esz = f8 ? 1 : d.dtype_ab == MI355_DTYPE_F32 ? 4 : 2;
     const int64_t BK = ROW_BYTES / esz;
@@ -771,7 +798,10 @@ int32_t launch_gemm_lp256w4(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc
         if (d.trans_b) launch<MI355_DTYPE_F32, MI355_DTYPE_F32, false>(ctx, s, g, batch);
         else launch<MI355_DTYPE_F32, MI355_DTYPE_F32, true>(ctx, s, g, batch);
     } else if (d.dtype_ab == MI355_DTYPE_BF16) {
-        if (d.trans_b) {
+        if (d.trans_a) {
+            if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32, true, MI355_DTYPE_BF16, false, true>(ctx, s, g, batch);
+            else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16, true, MI355_DTYPE_BF16, false, true>(ctx, s, g, batch);
+        } else if (d.trans_b) {
             if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, g, batch);
             else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16>(ctx, s, g, batch);
         } else {
@@ -779,7 +809,10 @@ int32_t launch_gemm_lp256w4(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc
             else launch<MI355_DTYPE_BF16, MI355_DTYPE_BF16, true>(ctx, s, g, batch);
         }
     } else {
-        if (d.trans_b) {
+        if (d.trans_a) {
+            if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32, true, MI355_DTYPE_F16, false, true>(ctx, s, g, batch);
+            else launch<MI355_DTYPE_F16, MI355_DTYPE_F16, true, MI355_DTYPE_F16, false, true>(ctx, s, g, batch);
+        } else if (d.trans_b) {
             if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F16, MI355_DTYPE_F32>(ctx, s, g, batch);
             else launch<MI355_DTYPE_F16, MI355_DTYPE_F16>(ctx, s, g, batch);
         } else {

@@ -76,15 +76,15 @@ int main(void)
     if (mi355_gemm_relayout_plan(&d, &ra, &rb) != MI355_OK || ra != 0 || rb != 0) ++failures;
     d.trans_b = 0;
     if (mi355_gemm_relayout_plan(&d, &ra, &rb) != MI355_OK || ra != 0 || rb != 0) ++failures;
-    /* lhs stored [K][M] on a 256-tile shape: A goes through scratch, the row-major B does not */
+    /* lhs stored [K][M] (lhs^T . grad_out): staged natively as well */
     d.trans_a = 1;
-    if (mi355_gemm_relayout_plan(&d, &ra, &rb) != MI355_OK || ra != 1 || rb != 0) ++failures;
+    if (mi355_gemm_relayout_plan(&d, &ra, &rb) != MI355_OK || ra != 0 || rb != 0) ++failures;
     printf("relayout plan of the transposed-lhs 8192^3: a %d b %d\n", (int)ra, (int)rb);
 
     /* no context: every entry point refuses, none crashes */
     if (mi355_gemm(NULL, NULL, &d, NULL, NULL, NULL) == MI355_OK) ++failures;
     if (mi355_sync(NULL, NULL) == MI355_OK) ++failures;
-    /* ... except the host-side planning ones, which need none: the transposed-lhs 8192^3 ends on the 256x256 kernel (after A's re-layout) */
+    /* ... except the host-side planning ones, which need none: the transposed-lhs 8192^3 runs on the 256x256 kernel */
     int32_t algo = -1;
     if (mi355_gemm_select(NULL, &d, &algo) != MI355_OK || algo != MI355_GEMM_ALGO_LP_256W4) ++failures;
     if (mi355_gemm_select(NULL, NULL, &algo) == MI355_OK) ++failures;

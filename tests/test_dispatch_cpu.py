@@ -44,7 +44,9 @@ TABLE = [
     ("a partly filled last round (split inside the launch)", (6144, 6144, 6144, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
     ("weight gradient lhs^T . grad: native", (512, 512, 8192, BF, None, 1, 0, 1), "LP_128", (0, 0)),
     ("weight gradient, mid size: native", (2048, 2048, 8192, BF, None, 1, 0, 1), "LP_128", (0, 0)),
-    ("transposed lhs on a 256-tile shape: A through scratch, B stays", (8192, 8192, 8192, BF, None, 1, 0, 1), "LP_256W4", (1, 0)),
+    ("transposed lhs on a 256-tile shape: native on the 256^2 kernel as well", (8192, 8192, 8192, BF, None, 1, 0, 1), "LP_256W4", (0, 0)),
+    ("transposed lhs where the 256 x 128 tile would run: A through scratch, B stays", (4096, 2048, 4096, BF, None, 1, 0, 1), "LP_256X128", (1, 0)),
+    ("transposed lhs, many short tiles: the one-tile kernel, not the persistent forms", (2048, 2048, 2048, BF, None, 1, 0, 64), "LP_256W4", (0, 0)),
     ("both transposed", (512, 512, 1024, BF, None, 1, 1, 1), "LP_128", (1, 0)),
     ("transposed lhs, rows of C not a multiple of 8", (516, 512, 1024, BF, None, 1, 0, 1), "LP_128", (1, 0)),
     ("fp8", (8192, 8192, 8192, E4, BF, 0, 1, 1), "LP_256W4", (0, 0)),

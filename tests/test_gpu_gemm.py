@@ -1125,6 +1125,10 @@ def _tn_desc(m, n, k, dtype, out, lda=None, ldb=None, batch=1, algo=N.GEMM_ALGO_
     (136, 264, 8192, 1, None, False, "lp128"),        # split-K slices
     (512, 512, 8192, 1, None, True, "auto"),          # what a weight gradient looks like: small output, long K
     (1024, 4096, 2048, 1, 1032, True, "auto"),
+    (3072, 3072, 128, 1, None, True, "lp256w4"),      # the 256 x 256 kernel: one K-tile pair, every wave position
+    (4104, 3080, 448, 1, 4112, False, "lp256w4"),     # ... edge tiles in both directions, padded rows of A, f32 C
+    (2304, 2560, 1024, 2, None, True, "lp256w4"),     # ... batches
+    (4096, 4096, 4096, 1, None, True, "auto256"),     # a weight gradient of a large layer: AUTO takes the 256 x 256 kernel natively
 ])
 def test_transposed_a_with_row_major_b_is_staged_natively_and_gives_the_bits_of_the_k_contiguous_form(client, oracle, dtype, m, n, k, batch, lda,
                                                                                                      out16, algo):
@@ -1137,8 +1141,10 @@ def test_transposed_a_with_row_major_b_is_staged_natively_and_gives_the_bits_of_
     b_kn = conv(oracle.fill_uniform(batch * k * n, 72, -1.0, 1.0)).reshape(batch, k, n)
     odt = dtype if out16 else ElemType.F32
     d = _tn_desc(m, n, k, dtype, odt, lda=lda, batch=batch)
-    if algo == "auto":
-        assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_128 and ops.gemm_relayout_plan(client, d) == (False, False)
+    twin_algo = N.GEMM_ALGO_LP_256W4 if algo in ("lp256w4", "auto256") else N.GEMM_ALGO_LP_128
+    if algo in ("auto", "auto256"):
+        assert ops.gemm_select(client, d) == twin_algo and ops.gemm_relayout_plan(client, d) == (False, False)
+        algo = "auto"
     ta, tb = TensorHandle.from_numpy(client, a_km, dtype), TensorHandle.from_numpy(client, b_kn, dtype)
     c1 = TensorHandle.new_contiguous((batch, m, n), client.empty(batch * m * n * odt.size()), odt)
     ops.matmul(client, TensorHandle.new(ta.handle, (batch, m, k), (k * lda, 1, lda), dtype), TensorHandle.new(tb.handle, (batch, k, n), (k * n, n, 1), dtype),
@@ -1149,7 +1155,7 @@ def test_transposed_a_with_row_major_b_is_staged_natively_and_gives_the_bits_of_
     ua, ub = TensorHandle.from_numpy(client, a_mk, dtype), TensorHandle.from_numpy(client, b_nk, dtype)
     c2 = TensorHandle.new_contiguous((batch, m, n), client.empty(batch * m * n * odt.size()), odt)
     ops.matmul(client, TensorHandle.new(ua.handle, (batch, m, k), (m * k, k, 1), dtype), TensorHandle.new(ub.handle, (batch, k, n), (k * n, 1, k), dtype),
-               c2, algo=N.GEMM_ALGO_LP_128)
+               c2, algo=twin_algo)
     got = c1.to_numpy(client)
     assert np.array_equal(got, c2.to_numpy(client))
     bi = batch - 1
@@ -1162,14 +1168,18 @@ def test_transposed_a_with_row_major_b_is_staged_natively_and_gives_the_bits_of_
 
 def test_transposed_a_selection_and_refusals(client, oracle):
     bf = ElemType.BF16
-    # a 256-tile shape: A is transposed into scratch, the row-major B stays where it is
+    # a 256-tile shape is native on the 256 x 256 kernel; where the 256 x 128 tile would run, A is transposed into scratch and the
+    # row-major B stays where it is
     d = _tn_desc(8192, 8192, 8192, bf, bf)
-    assert ops.gemm_relayout_plan(client, d) == (True, False) and ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    assert ops.gemm_relayout_plan(client, d) == (False, False) and ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    d = _tn_desc(4096, 2048, 4096, bf, bf)
+    assert ops.gemm_relayout_plan(client, d) == (True, False) and ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256X128
     # rows of C not a multiple of 8 / A and B both transposed: no native form
     assert ops.gemm_relayout_plan(client, _tn_desc(516, 512, 1024, bf, bf)) == (True, False)
     assert ops.gemm_relayout_plan(client, _tn_desc(512, 512, 1024, bf, bf, trans_b=1)) == (True, False)
     for d in (_tn_desc(516, 512, 1024, bf, bf, algo=N.GEMM_ALGO_LP_128), _tn_desc(512, 512, 1024, bf, bf, algo=N.GEMM_ALGO_LP_128, trans_b=1),
-              _tn_desc(512, 512, 1024, bf, bf, algo=N.GEMM_ALGO_LP_256X128), _tn_desc(512, 512, 1024, bf, bf, algo=N.GEMM_ALGO_LP_256W4)):
+              _tn_desc(512, 512, 1024, bf, bf, algo=N.GEMM_ALGO_LP_256X128), _tn_desc(512, 512, 1024, bf, bf, algo=N.GEMM_ALGO_LP_256W4, trans_b=1),
+              _tn_desc(512, 512, 1024, bf, bf, algo=N.GEMM_ALGO_LP_256P), _tn_desc(516, 512, 1024, bf, bf, algo=N.GEMM_ALGO_LP_256W4)):
         a, b, c = client.empty(2 << 20), client.empty(2 << 20), client.empty(2 << 20)
         rc = client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()), C.c_void_p(c.device_ptr()))
         assert rc == N.E_UNSUPPORTED
