@@ -357,7 +357,7 @@ int32_t mi355_cast(mi355_ctx *ctx, mi355_stream stream, const void *src, int32_t
  * dtype_c: F32, or the same 16-bit type as the inputs (RNE on store); fp8 inputs write F32, BF16 or F16.
  * Row-major B (what TensorHandle::new_contiguous gives a rhs) is staged natively by the tile kernels for F32, BF16 and F16
  * (N a multiple of 16 bytes' worth of columns), and so is A stored [K][M] together with a row-major B for BF16 / F16 on the
- * 128x128 kernel (lhs^T . grad_out).  What the MFMA kernels do not stage directly -- trans_a otherwise, fp8 row-major B, a
+ * 128x128 and the 256x256 kernel (lhs^T . grad_out; M a multiple of 8).  What the MFMA kernels do not stage directly -- trans_a otherwise, fp8 row-major B, a
  * row-major B of at most 64 columns, K not a multiple of the K-tile, rows or bases not 16-byte aligned -- is first re-laid
  * out K-contiguous (zero-padded) into library-owned per-stream scratch, as the reference's launchers do with into_contiguous
  * (mi355_gemm_relayout_plan says which operands); tiny shapes run on the bounds-checked generic kernel.  The library owns:
