@@ -48,3 +48,16 @@ def test_committed_two_rank_rehearsal_line_is_a_two_rank_job_over_the_whole_batc
     c5 = r["extra"]["batched_gemm_2048_bf16"]
     assert c5["batch_total"] == 512 and c5["batch_this_rank"] == 256 and c5["TFLOPs_total"] > 0
     assert r["extra"]["reduce_1GiB_f32"]["sum"]["GBs_total"] > 0
+
+
+def test_guard_check_case_list_builds_without_a_device():
+    """tools/guard_check.py --list: the descriptors the guard-page run walks (the random draws of the fuzz tests, the few-row / decode shapes
+    in both rhs layouts, the benchmark's shapes) can be enumerated on any box -- the tool must not rot between GPU runs."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    out = subprocess.run([sys.executable, str(root / "tools" / "guard_check.py"), "--list"], capture_output=True, text=True, timeout=120)
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert out.returncode == 0 and len(lines) >= 219, (out.stdout[-300:], out.stderr[-500:])
+    assert any("8192, 8192, 8192" in l for l in lines) and any("28672" in l for l in lines)
