@@ -46,6 +46,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plateau-warmup", action="store_true", help="only the W warm-up steps (measures the DVFS ramp too)")
     ap.add_argument("--algo", type=int, default=0, help="MI355_GEMM_ALGO_* override for the headline GEMM")
+    ap.add_argument("--dist", choices=("native", "torch"), default="native",
+                    help="N > 1: barrier / max-over-ranks through the library's own RCCL communicator (native: one RCCL, one HIP "
+                         "runtime in the process; the unique id travels through the launcher's TCP store) or through torch.distributed")
+    ap.add_argument("--extras", default="all", help="comma list of extra sections to run (default: all)")
     return ap.parse_args()
 
 
@@ -95,6 +99,61 @@ def samples_op(client, ev, fn, samples=15, warmup=5):
         out.append(ev.stop_ms())
     out.sort()
     return out[len(out) // 2], out[0]
+
+
+def mapped_libraries():
+    """Which copies of the HIP runtime and of RCCL this process has mapped (/proc/self/maps): torch bundles its own
+    libamdhip64 / librccl next to /opt/rocm's, and by soname whichever is mapped first serves everybody (review of round 3, weak #10)."""
+    out = {}
+    try:
+        for line in open("/proc/self/maps"):
+            path = line.rsplit(" ", 1)[-1].strip()
+            base = path.rsplit("/", 1)[-1]
+            for key in ("libamdhip64", "librccl", "libmi355cube"):
+                if base.startswith(key) and path not in out.setdefault(key, []):
+                    out[key].append(path)
+    except OSError:
+        pass
+    return {k: (v[0] if len(v) == 1 else v) for k, v in out.items()}
+
+
+class Job:
+    """barrier + reductions of a few host numbers over the ranks of this launch.  world == 1: nothing.  `native`: the library's
+    own communicator (cubecl_amd.sharded.RcclJob); `torch`: torch.distributed (nccl = RCCL, or gloo in rehearsals)."""
+
+    def __init__(self, world):
+        self.world, self.kind, self.native, self.dist, self.device, self.why = world, "single", None, None, None, None
+
+    def barrier(self):
+        if self.native is not None:
+            self.native.barrier()
+        elif self.dist is not None:
+            if self.device is not None:
+                self.dist.barrier(device_ids=[self.device])
+            else:
+                self.dist.barrier()
+
+    def max_over_ranks(self, values):
+        if self.native is not None:
+            return self.native.max_over_ranks(values)
+        if self.dist is not None:
+            import torch
+            t = torch.tensor(list(values), dtype=torch.float64, device="cuda" if self.device is not None else "cpu")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            return [float(v) for v in t]
+        return list(values)
+
+
+def launcher_store(rank, world):
+    """The launcher's rendezvous store as a plain key-value store (no process group): torch.distributed.run hosts a TCPStore on
+    MASTER_ADDR:MASTER_PORT (TORCHELASTIC_USE_AGENT_STORE=True) and workers connect as clients; without an agent rank 0 hosts it."""
+    import datetime
+    import torch.distributed as dist
+    addr, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"])
+    agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
+    store = dist.TCPStore(addr, port, world, is_master=(rank == 0 and not agent), timeout=datetime.timedelta(seconds=300),
+                          wait_for_workers=False)
+    return dist.PrefixStore(f"mi355bench/{os.environ.get('TORCHELASTIC_RUN_ID', 'job')}/{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}", store)
 
 
 HUNG = []          # names of watchdogged sections that did not return (see run_with_watchdog)
@@ -154,12 +213,14 @@ def usable_cores():
 # sha256 of the kernel's sources at the time of the pass (tools/pmc_all.sh) and bench.py prints the figure only when the
 # sources it is running from still hash to the same value (and the demangled kernel name is the one expected).
 KERNEL_SOURCES = {
-    "gemm": ("cubecl_amd/csrc/gemm_lp256w4.hip", "cubecl_amd/csrc/gemm_common.hpp", "cubecl_amd/csrc/gemm.cpp", "cubecl_amd/csrc/internal.hpp"),
+    "gemm": ("cubecl_amd/csrc/gemm_lp256w4.hip", "cubecl_amd/csrc/gemm_common.hpp", "cubecl_amd/csrc/internal.hpp"),
+    "gemm_q": ("cubecl_amd/csrc/gemm_lp256q.hip", "cubecl_amd/csrc/gemm_common.hpp", "cubecl_amd/csrc/internal.hpp"),
     "reduce": ("cubecl_amd/csrc/reduce.hip", "cubecl_amd/csrc/internal.hpp"),
 }
 PROFILES_DIR = ROOT / "profiles"
 HEADLINE_KERNEL = "gemm_lp256w4_kernel<1, 1, false, 1, false, false>"     # bf16 x bf16 -> bf16 C, [N][K] B, unscaled (what rocprofv3 prints)
 REDUCE_SUM_KERNEL = "reduce_kernel<true, false, 0>"      # <SUM, ARGMAX, DT = f32>
+C5_KERNEL = "gemm_lp256q_kernel<1, 1, false>"             # <bf16, one dripped store per K-tile, [N][K] B>: batch 512 x 2048^3
 
 
 def kernel_source_sha(kind):
@@ -250,40 +311,75 @@ def main():
     import torch
     import torch.distributed as dist
 
-    if not torch.cuda.is_available():
+    # BENCH_NO_TORCH_CUDA=1 (CPU test tier only, tests/test_bench_cpu.py): MI355CUBE_LIB then points at a test build of the host
+    # runtime with stand-in kernels, so that the N > 1 control flow of this file -- rendezvous, native barrier / max-over-ranks,
+    # the C4 exchange -- runs to completion on a box without a device.  Never set by the driver; such a run's figures mean nothing.
+    fake = os.environ.get("BENCH_NO_TORCH_CUDA") == "1"
+    if not fake and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); none visible")
     # Rehearsal hooks (single-GPU pod only, never set by the driver): BENCH_FORCE_DEVICE puts every rank on one device and
     # BENCH_DIST_BACKEND=gloo replaces RCCL for torch's own collectives, so that the N > 1 control flow of this file can be
     # exercised where only one GPU exists (the RCCL exchange of the extras then fails cleanly: two ranks on one device).
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    dev_index = local_rank                      # the library's device (DeviceId.index_id)
     if "BENCH_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
-    elif torch.cuda.device_count() < world:
+        dev_index = local_rank
+    elif not fake and torch.cuda.device_count() < world:
         raise SystemExit(f"bench.py: {world} ranks asked for, {torch.cuda.device_count()} GPUs visible")
-    torch.cuda.set_device(local_rank)
+    if not fake:
+        torch.cuda.set_device(local_rank)
     global THREAD_DEVICE
-    THREAD_DEVICE = local_rank
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=backend)
+    THREAD_DEVICE = None if fake else local_rank
+
+    def device_sync():
+        if not fake:
+            torch.cuda.synchronize()
 
     from cubecl_amd import DeviceId, ElemType, Mi355Runtime, TensorHandle, ops
     from cubecl_amd import _native as N
 
-    client = Mi355Runtime.client(DeviceId(0, local_rank))
+    client = Mi355Runtime.client(DeviceId(0, dev_index))
     lib, ctx = client.lib, client.ctx
     props = client.properties()
     ev = Events(client)
 
-    def barrier():
-        if world > 1:
+    job = Job(world)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        store = launcher_store(rank, world)
+        native_ok, why = False, None
+        if args.dist == "native":
+            # The library's own communicator carries the job-level barrier and the max over ranks: no torch process group, so one
+            # RCCL communicator and one librccl in the process.  comm_init is collective; every rank then says through the store
+            # whether it came up, and ALL ranks fall back to torch.distributed together if any did not.
+            from cubecl_amd import sharded
+
+            def native_init():
+                job.native = sharded.RcclJob(client, [DeviceId(0, i) for i in range(world)] if "BENCH_FORCE_DEVICE" not in os.environ
+                                             else [DeviceId(0, dev_index)] * world, rank, store)
+                job.native.barrier()
+            why = run_with_watchdog(native_init, 240.0)
+            if HUNG:                    # stuck inside ncclCommInitRank with the context locked: nothing on this context can run any more
+                sys.stderr.write(f"bench.py rank {rank}: native RCCL rendezvous did not complete ({why}); use --dist torch\n")
+                sys.stderr.flush()
+                os._exit(3)
+            store.set(f"native_ok/{rank}", b"1" if why is None else b"0")
+            native_ok = all(bytes(store.get(f"native_ok/{r}")) == b"1" for r in range(world))
+            if not native_ok:
+                job.native = None
+        if native_ok:
+            job.kind = "native"
+        else:
+            job.why = why or ("--dist torch" if args.dist == "torch" else "another rank's native rendezvous failed")
             if backend == "nccl":
-                dist.barrier(device_ids=[local_rank])
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+                job.device = local_rank
             else:
-                dist.barrier()
+                dist.init_process_group(backend=backend)
+            job.dist, job.kind = dist, f"torch:{backend}"
+
+    barrier = job.barrier
 
     def job_seconds(fn, iters, warmup=2):
         """Job-level time of one `fn` (the protocol of the headline, applied to an extra): every rank warms up, barrier,
@@ -293,19 +389,15 @@ def main():
             fn()
         client.sync()
         barrier()
-        torch.cuda.synchronize()
+        device_sync()
         t1 = time.perf_counter()
         for _ in range(iters):
             fn()
         client.sync()
-        torch.cuda.synchronize()
+        device_sync()
         dt = (time.perf_counter() - t1) / iters
         barrier()
-        if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt[0])
-        return dt
+        return job.max_over_ranks([dt])[0]
 
     # ------------------------------------------------------------------ headline: C3 ------------------
     S = args.size
@@ -346,7 +438,7 @@ def main():
             last = cur
     client.sync()
     barrier()
-    torch.cuda.synchronize()
+    device_sync()                        # torch.cuda.synchronize()
     t0 = time.perf_counter()
     lib.mi355_probe_clock(ctx, None, p_clk0)
     ev.start()
@@ -354,10 +446,11 @@ def main():
         step()
     kernel_ms = ev.stop_ms()
     lib.mi355_probe_clock(ctx, None, p_clk1)
-    torch.cuda.synchronize()
+    device_sync()                        # torch.cuda.synchronize()
     client.sync()
+    elapsed_own = time.perf_counter() - t0     # this rank's K steps, launched and drained
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = time.perf_counter() - t0         # ... and every other rank's (the closing barrier is inside the bracket)
     import numpy as _np
     ticks = _np.frombuffer(client.read_one(clk), dtype=_np.uint64).reshape(2, 512, 2).astype(_np.float64)
     # s_memtime is local to a CU: pair the two samples slot by slot (same CU), median over the CUs seen twice
@@ -365,9 +458,7 @@ def main():
     per_cu = (ticks[1, ok, 0] - ticks[0, ok, 0]) / (ticks[1, ok, 1] - ticks[0, ok, 1]) * 0.1      # 100 MHz reference
     eff_clock_ghz = float(_np.median(per_cu)) if per_cu.size else float("nan")
     if world > 1:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(t[0]), float(t[1])
+        elapsed, kernel_ms, elapsed_own = job.max_over_ranks([elapsed, kernel_ms, elapsed_own])
     flop = 2.0 * S * S * S
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * flop * args.steps / elapsed / 1e12
@@ -388,7 +479,9 @@ def main():
                    "operands": "uniform[-1,1) counter RNG seed 0x5EEDC0BE, generated in HBM",
                    "kernel": {2: "f32_mfma", 3: "lp128", 4: "lp256", 5: "lp256w4", 6: "lp256p", 7: "lp256q", 8: "skinny", 9: "stream64", 10: "lp256x128", 1: "generic"}.get(sel.value, str(sel.value)),
                    "parallelism": f"batch-sharded x{world}, no data-path collective",
-                   "plateau_warmup_steps": plateau_steps},
+                   "plateau_warmup_steps": plateau_steps,
+                   "job_collectives": job.kind + (f" (native refused: {job.why})"[:160] if job.why and args.dist == "native" else ""),
+                   "ms_per_step_before_closing_barrier": round(elapsed_own * 1e3 / args.steps, 4)},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(gemm_score.fraction_of_peak, 4), "traffic": (tr_ent or {}).get("hbm_bytes_per_launch"),
                      "traffic_source": _pmc_source(tr_ent) if tr_ent else tr_why,
@@ -404,9 +497,19 @@ def main():
         "device": props.name.decode() + " " + props.gcn_arch_name.decode(),
     }
 
+    # the same launch under the reference's Benchmark protocol (crates/cubecl-common/src/benchmark.rs:160-300: sync around every
+    # sample), outside the timed region: the fixed name every config's second figure carries
+    med_ms, _ = samples_op(client, ev, step)
+    result["roofline"]["frac_per_sample_median"] = round(flop / med_ms / 1e9 / PEAK_BF16_TFLOPS, 4)
+    libs = mapped_libraries()
+    for key in ("libamdhip64", "librccl"):          # which copies serve this process (flat strings: the driver's record keeps scalars)
+        result["config"][key] = str(libs.get(key, "not mapped"))
     extra, errors = {}, {}
+    wanted = None if args.extras == "all" else set(args.extras.split(","))
 
     def guarded(name, fn):
+        if wanted is not None and name not in wanted:
+            return
         try:
             extra[name] = fn()
         except Exception as exc:  # keep the headline line even if an extra fails
@@ -487,7 +590,6 @@ def main():
             ms = time_op(client, ev, lambda: client._s.check(lib.mi355_probe_launch_overhead(ctx, None, 1000, sink.device_ptr())), 3, warmup=1)
             out["launch_overhead_us"] = round(ms, 3)          # ms per 1000 launches = us per launch
             return out
-        guarded("measured_ceilings", probes)
 
         def operand_sensitivity():
             # Separates issue efficiency from power (review of round 2, weak #5): the SAME headline kernel, same descriptor, on
@@ -518,7 +620,6 @@ def main():
                              "frac_of_peak_at_clock": round(tf / (PEAK_BF16_TFLOPS * ghz / 2.4), 4)}
             out["gemm_bf16_8192_zero_operands_TFLOPs"] = out["zeros"]["TFLOPs"]
             return out
-        guarded("headline_kernel_operand_sensitivity", operand_sensitivity)
 
         def reduce_c4():
             n_total = 1 << 28                      # 1 GiB of f32 (config C4)
@@ -529,7 +630,7 @@ def main():
             p_in, p_ws = C.c_void_p(x.device_ptr()), C.c_void_p(ws.device_ptr())
             p_sum, p_val, p_idx = (C.c_void_p(outs.device_ptr() + o) for o in (0, 8, 16))
             res = {"elements_per_gpu": n_local, "bytes_per_gpu": n_local * 4}
-            b2b_ms = {}
+            b2b_ms, med_frac = {}, {}
             for name, fn in (
                 ("sum", lambda: lib.mi355_reduce_sum_f32(ctx, None, p_in, n_local, p_sum, p_ws, ws.size)),
                 ("argmax", lambda: lib.mi355_argmax_f32(ctx, None, p_in, n_local, p_val, p_idx, p_ws, ws.size)),
@@ -543,8 +644,8 @@ def main():
                 res[name] = {"median_ms": round(med, 4), "min_ms": round(best, 4), "GBs_per_gpu": round(gbs, 1),
                              "frac_of_8TBs": round(gbs / PEAK_HBM_GBS, 4),
                              "back_to_back_ms": round(b2b, 4), "back_to_back_GBs": round(n_local * 4 / b2b / 1e6, 1),
-                             "job_ms": round(job * 1e3, 4), "GBs_total": round(n_local * 4 * world / job / 1e9, 1),
-                             "GBs_total_timing": "all ranks' bytes / slowest rank's wall time over 20 back-to-back launches (host clock, barrier before)"}
+                             "job_ms": round(job * 1e3, 4), "GBs_total": round(n_local * 4 * world / job / 1e9, 1)}
+                med_frac[name] = gbs / PEAK_HBM_GBS
             # the second half of the metric ("reduce GB/s vs roofline"): same object shape as the headline roofline
             rd_ent, rd_why = _pmc_entry("pmc_traffic.json", "reduce_1GiB_sum", "reduce", REDUCE_SUM_KERNEL)
             tr = rd_ent["fetch_bytes"] if rd_ent else None
@@ -553,8 +654,20 @@ def main():
                                "unit": "GB/s", "frac": round(sum_score.fraction_of_peak, 4), "traffic": tr if world == 1 else None,
                                "traffic_source": (_pmc_source(rd_ent) if rd_ent else rd_why) if world == 1 else "pass is for the 1-GPU size",
                                "algorithmic_bytes_per_launch": n_local * 4, "kernel_ms": round(b2b_ms["sum"], 4),
-                               "timing": "average of 20 back-to-back launches between one HIP event pair, like the GEMM "
-                                         "roofline (the per-sample medians above include one launch gap each)"}
+                               "frac_per_sample_median": round(med_frac["sum"], 4)}
+            # ... and where the driver's record keeps it: flat scalars beside the GEMM's in the top-level roofline object.  `frac` is
+            # the claim (average of 20 back-to-back launches between one HIP event pair, the protocol of the GEMM roofline and of the
+            # contract's timed region); `frac_per_sample_median` is the reference's Benchmark protocol (a sync around every sample,
+            # crates/cubecl-common/src/benchmark.rs:160-300), kept beside it.
+            rl = res["roofline"]
+            result["roofline"].update({
+                "reduce_sum_bound": "hbm", "reduce_sum_bytes_per_gpu": n_local * 4, "reduce_sum_achieved_GBs": rl["achieved"],
+                "reduce_sum_peak_GBs": PEAK_HBM_GBS, "reduce_sum_frac": rl["frac"], "reduce_sum_frac_per_sample_median": rl["frac_per_sample_median"],
+                "reduce_sum_kernel_ms": rl["kernel_ms"], "reduce_sum_traffic": rl["traffic"],
+                "reduce_argmax_frac": round(n_local * 4 / b2b_ms["argmax"] / 1e6 / PEAK_HBM_GBS, 4),
+                "reduce_sum_argmax_fused_frac": round(n_local * 4 / b2b_ms["sum_argmax_fused"] / 1e6 / PEAK_HBM_GBS, 4),
+                "reduce_sum_GBs_whole_job": res["sum"]["GBs_total"]})
+            result["roofline"]["reduce_1GiB_sum"] = {k: rl[k] for k in ("achieved", "peak", "frac", "traffic", "kernel_ms", "frac_per_sample_median")}
             if rank == 0 and world == 1 and not args.no_cpu_baseline:
                 # the reduce half's CPU baseline (north_star: "alongside cubecl-cpu timed on the box's own host cores"): the
                 # oracle's threaded fused sum + argmax -- one contiguous slice per worker, one worker per usable core, the way
@@ -572,6 +685,10 @@ def main():
                     times.sort()
                     med_s = times[len(times) // 2]
                     dev = np.frombuffer(client.read_one(outs), dtype=np.uint8)
+                    if isinstance(result.get("cpu_baseline"), dict):
+                        result["cpu_baseline"].update({"reduce_value": round(n_total * 4 / med_s / 1e9, 2), "reduce_unit": "GB/s", "reduce_cores": cores,
+                                                       "reduce_sample": f"the whole 1 GiB f32 array, fused sum + argmax, median of {len(times)} passes"})
+                        result["cpu_baseline"]["reduce"] = {"value": round(n_total * 4 / med_s / 1e9, 2), "unit": "GB/s", "cores": cores}
                     res["cpu_baseline"] = {"value": round(n_total * 4 / med_s / 1e9, 2), "unit": "GB/s", "cores": cores, "kind": "port",
                                            "sample": f"the whole 1 GiB f32 array (same counter RNG stream), fused sum + argmax, median of {len(times)} passes "
                                                      f"({med_s * 1e3:.1f} ms), oracle_cpu_sum_argmax_f32: one contiguous slice per worker thread",
@@ -587,9 +704,10 @@ def main():
                     # and an all-gather of the (max value, index) records; every rank runs the same combine.
                     from cubecl_amd import sharded
                     ids = [DeviceId(0, i) for i in range(world)]
-                    box = [client.comm_unique_id() if rank == 0 else None]
-                    dist.broadcast_object_list(box, src=0)
-                    client.comm_init(ids, box[0], rank=rank)
+                    if job.native is None:      # (native: the job's communicator IS the one for this device set -- comm_init returns at once)
+                        if rank == 0:
+                            store.set("c4/unique_id", bytes(client.comm_unique_id()))
+                        client.comm_init(ids, bytes(store.get("c4/unique_id")), rank=rank)
                     from cubecl_amd import ReduceOperation
                     start, count = sharded.shard_aligned_range(n_total, rank, world, 4)
                     assert count == n_local
@@ -620,9 +738,9 @@ def main():
                                                           "GBs_total": round(n_total * 4 / dt / 1e9, 1),
                                                           "sum": gsum, "argmax_index": gidx, "argmax_value": gval,
                                                           "device_combine_equals_host_rule": bool(gidx == hidx and (gval == hval or (gval != gval and hval != hval))),
-                                                          "exchange": "RCCL all-reduce (1 x f32) + all-gather (16 B per rank) + 64-lane combine "
-                                                                      "kernel behind the comm fence; results resident on every device",
-                                                          "timing": "barrier, 20 x (local pass + exchange + combine) on every rank, sync, max over ranks"}
+                                                          "exchange": "RCCL all-reduce (1 x f32) + all-gather (16 B per rank) + combine kernel"}
+                    result["roofline"].update({"reduce_sum_argmax_exchange_ms": round(dt * 1e3, 4),
+                                               "reduce_sum_argmax_exchange_GBs_whole_job": round(n_total * 4 / dt / 1e9, 1)})
                 # The exchange cannot be rehearsed on the single-GPU pod: never let it take the headline line down with
                 # it.  It runs under a watchdog; a rank that does not come back within the limit reports so and the
                 # process leaves through os._exit after printing (a hung collective cannot be cancelled).
@@ -630,7 +748,6 @@ def main():
                 if outcome is not None:
                     res["sharded_sum_argmax_exchange"] = {"error": outcome}
             return res
-        guarded("reduce_1GiB_f32", reduce_c4)
 
         def book_reduce():
             # the reference's only published reduce cases (cubecl-book getting-started: sum over the last axis;
@@ -648,7 +765,6 @@ def main():
                 out["x".join(map(str, shape))] = {"median_us": round(med * 1e3, 2), "GBs": round(n * 4 / med / 1e6, 1),
                                                    "book_wgpu_ms": ref_ms}
             return out
-        guarded("book_reduce_last_axis_f32", book_reduce)
 
         def sum_things_c1():
             # config C1: the reference's own CPU-runnable case (examples/sum_things: array-wide sum of 2^20 f32) -- launch-bound on a GPU
@@ -661,7 +777,6 @@ def main():
             b2b = time_op(client, ev, call, 200)
             return {"elements": n, "median_us": round(med * 1e3, 2), "min_us": round(best * 1e3, 2), "back_to_back_us": round(b2b * 1e3, 2),
                     "GBs_back_to_back": round(n * 4 / b2b / 1e6, 1)}
-        guarded("sum_things_1M_f32", sum_things_c1)
 
         def gemm_f32_c2():
             M = 4096
@@ -683,8 +798,11 @@ def main():
                 out[name] = {"median_ms": round(med, 4), "TFLOPs": round(tf, 1), "frac_of_157TF": round(tf / PEAK_F32_TFLOPS, 4),
                              "back_to_back_ms": round(b2b, 4), "back_to_back_TFLOPs": round(2.0 * M ** 3 / b2b / 1e9, 1),
                              "algo": alg.value}
+                result["roofline"].update({f"c2_f32_4096_{name}_achieved_TFLOPs": round(2.0 * M ** 3 / b2b / 1e9, 1),
+                                           f"c2_f32_4096_{name}_frac": round(2.0 * M ** 3 / b2b / 1e9 / PEAK_F32_TFLOPS, 4),
+                                           f"c2_f32_4096_{name}_frac_per_sample_median": round(tf / PEAK_F32_TFLOPS, 4)})
+            result["roofline"]["c2_f32_peak_TFLOPs"] = PEAK_F32_TFLOPS
             return out
-        guarded("gemm_f32_4096", gemm_f32_c2)
 
         def gemm_fp8():
             # not a BASELINE config: the fp8 variant of the headline shape, e4m3 in, bf16 out
@@ -700,7 +818,6 @@ def main():
                 tf = 2.0 * S_ ** 3 / b2b / 1e9
                 out[f"{S_}^3"] = {"back_to_back_ms": round(b2b, 4), "TFLOPs": round(tf, 1), "frac_of_5PF": round(tf / 5000.0, 4)}
             return out
-        guarded("gemm_fp8_e4m3", gemm_fp8)
 
         def gemm_mx():
             # block-scaled variants: one ue8m0 scale per 32 k-values of each operand row, bf16 out;
@@ -726,7 +843,6 @@ def main():
                 tf = 2.0 * S_ ** 3 / b2b / 1e9
                 out[name] = {"shape": f"{S_}^3", "back_to_back_ms": round(b2b, 4), "TFLOPs": round(tf, 1), "frac_of_dense_peak": round(tf / peak, 4)}
             return out
-        guarded("gemm_block_scaled", gemm_mx)
 
         def batched_c5():
             # config C5: batch 512 x 2048^3 bf16, the batch cut into contiguous runs by sharded.shard_range -- the SAME
@@ -762,18 +878,27 @@ def main():
             tf_job = 2.0 * M ** 3 * total / job / 1e12            # shard_range covers [0, 512) exactly once: all ranks' FLOP
             res.update({"batch_total": total, "sharding": f"sharded.shard_range({total}, rank, {world})",
                         "TFLOPs_total": round(tf_job, 1),
-                        "TFLOPs_total_timing": "FLOP of all 512 matrices / slowest rank's wall time over 20 back-to-back passes after 5 warm-up passes (host clock, barrier before)",
                         "frac_of_2.5PF_per_gpu_job": round(tf_job / world / PEAK_BF16_TFLOPS, 4)})
+            c5_ent, c5_why = _pmc_entry("pmc_traffic.json", "gemm_bf16_c5_batch512", "gemm_q", C5_KERNEL) if (world == 1 and res["algo"] == 7) else (None, "pass is for the 1-GPU job on lp256q")
+            result["roofline"].update({
+                "c5_batched_512x2048_achieved_TFLOPs_whole_job": round(tf_job, 1), "c5_batched_512x2048_frac": round(tf_job / world / PEAK_BF16_TFLOPS, 4),
+                "c5_batched_512x2048_kernel_ms": res["back_to_back_ms"], "c5_batched_512x2048_frac_per_sample_median": round(res["TFLOPs_per_gpu_per_sample_median"] / PEAK_BF16_TFLOPS, 4),
+                "c5_batched_512x2048_algorithmic_bytes": 3 * mine * M * M * 2,
+                "c5_batched_512x2048_traffic": (c5_ent or {}).get("hbm_bytes_per_launch"), "c5_batched_512x2048_l2_hit_rate": (c5_ent or {}).get("l2_hit_rate"),
+                "c5_batched_512x2048_mfma_util_pmc": (c5_ent or {}).get("mfma_util")})
+            result["roofline"]["batched_512x2048"] = {"achieved": round(tf_job, 1), "frac": round(tf_job / world / PEAK_BF16_TFLOPS, 4),
+                                                      "traffic": (c5_ent or {}).get("hbm_bytes_per_launch")}
+            res["pmc"] = ({k: c5_ent.get(k) for k in ("hbm_bytes_per_launch", "fetch_bytes", "write_bytes", "l2_hit_rate", "mfma_util", "git_sha", "source_sha", "date")}
+                          if c5_ent else c5_why)
             # the reference's default operand layout (TensorHandle::new_contiguous: rhs [K][N] row-major), same job
             nn, job_nn = measure(mine, 0, bb)
             nn["TFLOPs_total"] = round(2.0 * M ** 3 * total / job_nn / 1e12, 1)
             res["row_major_rhs_NN"] = nn
-            if mine != 64:
+            if mine > 64:
                 # the 64-matrix run one GPU of an 8-GPU job holds, on this GPU alone (the figure rounds 1-2 quoted)
                 s64, _ = measure(64, 1, bb)
                 res["shard_of_64"] = s64
             return res
-        guarded("batched_gemm_2048_bf16", batched_c5)
 
         def skinny():
             out = {}
@@ -823,7 +948,6 @@ def main():
                                                                 "back_to_back_min_ms": round(runs[0], 4),
                                                                 "warm_one_operand_set_ms": round(warm, 4) if warm else None}
             return out
-        guarded("gemm_bf16_shapes", skinny)
 
         def contiguous():
             # into_contiguous (crates/cubecl-std/src/tensor/contiguous/launch.rs:5-20) of 512 MiB views: HBM-bound,
@@ -856,7 +980,21 @@ def main():
                 out[name] = {"mover": names[path], "access_bytes": access, "median_us": round(med * 1e3, 1),
                              "GBs": round(moved / med / 1e6, 1), "frac_of_8TBs": round(moved / med / 1e6 / PEAK_HBM_GBS, 4)}
             return out
+
+
+        # Order of the line: the sections outside BASELINE.json first, its configs C1, C2, C5, C4 last -- the driver keeps the
+        # LAST 8 KB of stdout (review of round 3, weak #7) -- and the compact per-config summary at the very end.
         guarded("into_contiguous_512MiB", contiguous)
+        guarded("gemm_bf16_shapes", skinny)
+        guarded("gemm_fp8_e4m3", gemm_fp8)
+        guarded("gemm_block_scaled", gemm_mx)
+        guarded("book_reduce_last_axis_f32", book_reduce)
+        guarded("measured_ceilings", probes)
+        guarded("headline_kernel_operand_sensitivity", operand_sensitivity)
+        guarded("sum_things_1M_f32", sum_things_c1)
+        guarded("gemm_f32_4096", gemm_f32_c2)
+        guarded("batched_gemm_2048_bf16", batched_c5)
+        guarded("reduce_1GiB_f32", reduce_c4)
 
     if extra:
         result["extra"] = extra
@@ -867,7 +1005,8 @@ def main():
     if world > 1:
         def farewell():
             barrier()
-            dist.destroy_process_group()
+            if job.dist is not None:
+                dist.destroy_process_group()
         if HUNG or run_with_watchdog(farewell, 60.0) is not None or HUNG:
             sys.stdout.flush()
             os._exit(0)          # a collective is stuck somewhere: the line is out, leave without waiting for it

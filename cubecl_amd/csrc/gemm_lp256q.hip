@@ -112,6 +112,15 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void *p)
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")   /* (n may depend on a template parameter) */
 #define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 template <int V> using IC = std::integral_constant<int, V>;
+// Dev timing trace (-DQ_TRACE, never in the product library): shader-clock stamps of wave 0 of every workgroup for its first
+// 8 tiles -- {K loop entered, K loop left (boundary begins), boundary left} -- read back with mi355_dev_q_trace
+// (tools/dev/q_trace.py: K-loop cycles per K-tile against the 2 048-cycle matrix-pipe floor, boundary cycles per tile).
+#ifdef Q_TRACE
+__device__ unsigned long long q_trace_buf[256 * 32];
+#define Q_STAMP(slot) do { if (tid == 0 && blockIdx.x < 256 && qt_tile < 8) q_trace_buf[blockIdx.x * 32 + qt_tile * 3 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define Q_STAMP(slot)
+#endif
 // A lane-constant value the compiler must re-derive where it is used: without this, hipcc hoists the 16 + 8 per-lane LDS
 // addresses of the boundary staging image to kernel entry, runs out of registers beside the held tile, spills them, and
 // every reload in the tile's last K-tile carries an s_waitcnt vmcnt(0) that drains the LDS-DMA stream (guide: "a
@@ -467,6 +476,9 @@ gemm_lp256q_kernel(gemm_args g)
     }
 
     bool held = false;                   // P holds a finished tile whose stores are still to be issued
+#ifdef Q_TRACE
+    int qt_tile = 0;
+#endif
     constexpr int GPR = 8 / D;           // K-tiles (store groups) per held row block
     for (;;) {
         Lnext = L + gridDim.x;
@@ -477,6 +489,7 @@ gemm_lp256q_kernel(gemm_args g)
         t = 0;
         bool w0 = false;
         char *rb_base = hbase;
+        Q_STAMP(0);
         if (!held) {
             Q_KTILE(1, 0, 8, 8, -1)
 #pragma nounroll                          /* (hipcc once unrolled this loop 8 x and spilled every fragment read) */
@@ -505,6 +518,7 @@ gemm_lp256q_kernel(gemm_args g)
             while (t < nk - 1) Q_KTILE(0, 0, 8, 8, -1)
         }
         Q_KTILE(0, 1, 8, 8, -1)                                   // t == nk - 1: row blocks 0..2 are packed into P
+        Q_STAMP(1);
 
         // ---- tile boundary: row block 3 through this wave's 8 KiB of the dead B slot (as gemm_lp256p.hip) ----------
         {
@@ -540,6 +554,10 @@ gemm_lp256q_kernel(gemm_args g)
             hbase = wbase;
             held = true;
         }
+        Q_STAMP(2);
+#ifdef Q_TRACE
+        ++qt_tile;
+#endif
         if (!has_next) break;
         cur = nxt;
         L = Lnext;
@@ -575,6 +593,13 @@ int drip_for(int64_t nk)                 // fewest stores per K-tile whose drip 
 }
 
 }  // namespace
+
+#ifdef Q_TRACE
+extern "C" __attribute__((visibility("default"))) int mi355_dev_q_trace(unsigned long long *host_out)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(q_trace_buf), sizeof(unsigned long long) * 256 * 32);
+}
+#endif
 
 namespace mi355 {
 

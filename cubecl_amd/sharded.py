@@ -199,6 +199,54 @@ class RcclExchange(Exchange):
         ops.argmax_combine(self._c, gathered, self.world, index_base, out_value, out_index)
 
 
+class RcclJob:
+    """The job-level collectives of a one-process-per-GPU launch over the library's OWN communicator -- barrier and MAX /
+    SUM of a few host numbers -- so that a multi-GPU run needs no second collective library in the process (bench.py until
+    round 3 initialised torch's NCCL process group next to `mi355_comm_init`: two communicators, possibly two librccl copies).
+
+    Rendezvous: rank 0 draws the unique id (`mi355_comm_unique_id`) and publishes it in the launcher's key-value store
+    (`store.set / store.get`: torch.distributed.TCPStore, or anything with those two methods); every rank then joins
+    `client.comm_init(ids, uid, rank)` -- the reference's comm_init (crates/cubecl-cuda/src/compute/server.rs:669-703: rank =
+    position of the own device in the sorted id list).  `device_ids[rank]` must be this client's device."""
+
+    KEY = "mi355cube/unique_id"
+
+    def __init__(self, client, device_ids, rank: int, store, key: str = KEY):
+        from .runtime import ElemType, ReduceOperation
+        self._c, self._ids = client, list(device_ids)
+        self._E, self._R = ElemType, ReduceOperation
+        self.rank, self.world = rank, len(self._ids)
+        if rank == 0:
+            store.set(key, bytes(client.comm_unique_id()))
+        uid = bytes(store.get(key))
+        client.comm_init(self._ids, uid, rank=rank)
+        self._buf = client.empty(256)
+
+    def barrier(self) -> None:
+        """Every rank's compute stream has drained and every rank has arrived: an all-reduce of one f32 behind client.sync()."""
+        self._c.sync()
+        h = self._buf.offset_end_by(self._buf.size - 4)
+        self._c.all_reduce(h, h, self._E.F32, self._ids, self._R.Sum)
+        self._c.sync_collective()
+        self._c.sync()
+
+    def _reduce_f64(self, values: Sequence[float], op) -> List[float]:
+        n = len(values)
+        if not 0 < n <= 16:
+            raise ValueError("RcclJob: 1..16 values per call")
+        h = self._buf.offset_start_by(64).offset_end_by(self._buf.size - 64 - 8 * n)
+        self._c.write(h, np.asarray(values, dtype=np.float64))
+        self._c.all_reduce(h, h, self._E.F64, self._ids, op)
+        self._c.sync_collective()
+        return [float(v) for v in np.frombuffer(self._c.read_one(h), dtype=np.float64)[:n]]
+
+    def max_over_ranks(self, values: Sequence[float]) -> List[float]:
+        return self._reduce_f64(values, self._R.Max)
+
+    def sum_over_ranks(self, values: Sequence[float]) -> List[float]:
+        return self._reduce_f64(values, self._R.Sum)
+
+
 # ---------------------------------------------------------------------------- sharded ops -----
 
 @dataclass

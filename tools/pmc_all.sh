@@ -9,6 +9,7 @@
 #     3. --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE   headline GEMM     mfma_util = (busy / 1024 SIMDs) / (active / 8 XCDs)
 #     4. --pmc FETCH_SIZE          1 GiB reductions (tools/reduce_probe.py)
 #     5. --pmc TCC_HIT_sum TCC_MISS_sum                   headline GEMM     L2 hit rate
+#     6-9. the same four on config C5 as benched at N = 1 (tools/c5_probe.py: batch 512 x 2048^3 bf16, gemm_lp256q.hip), round 4
 # Only --kernel-trace accompanies --pmc (gpurun refuses --pmc with the sys / hip / hsa trace domains).
 # Writes gpurun_out/pmc_traffic.json and gpurun_out/pmc_mfma_util.json (copy both to profiles/).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -25,6 +26,12 @@ run_pass write WRITE_SIZE -- "${BENCH[@]}"
 run_pass mfma SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- "${BENCH[@]}"
 run_pass l2 TCC_HIT_sum TCC_MISS_sum -- "${BENCH[@]}"
 run_pass reduce FETCH_SIZE -- python $R/tools/reduce_probe.py
+C5=(python $R/tools/c5_probe.py 4)
+run_pass c5_fetch FETCH_SIZE -- "${C5[@]}"
+run_pass c5_write WRITE_SIZE -- "${C5[@]}"
+run_pass c5_mfma SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- "${C5[@]}"
+run_pass c5_l2 TCC_HIT_sum TCC_MISS_sum -- "${C5[@]}"
+grep -h "^C5 " $O/pmc_c5_*.log | head -4
 python - "$SIZE" "$GIT_SHA" <<'PY'
 import collections, csv, datetime, glob, json, statistics, sys
 sys.path.insert(0, ".")
@@ -70,6 +77,27 @@ for k, v in agg.items():
     name = "sum" if "<true, false" in k else "argmax" if "<false, true" in k else "sum_argmax"   # <SUM, ARG, DT>
     traffic[f"reduce_1GiB_{name}"] = dict(stamp, kernel=k[:120], source_sha=bench.kernel_source_sha("reduce"),
         fetch_bytes=int(statistics.median(v) * 1024 * 2), algorithmic_bytes=1 << 30, FETCH_SIZE_KiB_raw=statistics.median(v), launches=len(v))
+# config C5 as benched (batch 512 x 2048^3 bf16 on the persistent dripped-store kernel)
+KQ = bench.C5_KERNEL
+f5, n5 = med(rows_of("c5_fetch"), "FETCH_SIZE", KQ)
+w5, _ = med(rows_of("c5_write"), "WRITE_SIZE", KQ)
+if f5 is not None and w5 is not None:
+    fb, wb = int(f5 * 1024 * 2), int(w5 * 1024)
+    ent = dict(stamp, kernel=kname(rows_of("c5_fetch"), KQ), source_sha=bench.kernel_source_sha("gemm_q"), hbm_bytes_per_launch=fb + wb,
+               fetch_bytes=fb, write_bytes=wb, algorithmic_bytes=3 * 512 * 2048 * 2048 * 2, FETCH_SIZE_KiB_raw=f5, WRITE_SIZE_KiB_raw=w5, launches=n5,
+               note="tools/c5_probe.py under rocprofv3 --pmc, one counter per pass, medians over its launches; FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE as reported")
+    h5, _ = med(rows_of("c5_l2"), "TCC_HIT_sum", KQ)
+    m5, _ = med(rows_of("c5_l2"), "TCC_MISS_sum", KQ)
+    if h5 is not None and m5 is not None:
+        ent.update(TCC_HIT_sum=h5, TCC_MISS_sum=m5, l2_hit_rate=round(h5 / (h5 + m5), 4))
+    b5, _ = med(rows_of("c5_mfma"), "SQ_VALU_MFMA_BUSY_CYCLES", KQ)
+    a5, _ = med(rows_of("c5_mfma"), "GRBM_GUI_ACTIVE", KQ)
+    if b5 and a5:
+        ent.update(SQ_VALU_MFMA_BUSY_CYCLES=b5, GRBM_GUI_ACTIVE=a5, mfma_util=round((b5 / 1024) / (a5 / 8), 4),
+                   expected_busy_cycles_32_per_mfma=32 * 512 * 2048 ** 3 / (32 * 32 * 16))
+    traffic["gemm_bf16_c5_batch512"] = ent
+else:
+    print("!! no C5 rows in the FETCH_SIZE / WRITE_SIZE passes")
 json.dump(traffic, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
 busy, nb = med(rows_of("mfma"), "SQ_VALU_MFMA_BUSY_CYCLES", K)
 active, _ = med(rows_of("mfma"), "GRBM_GUI_ACTIVE", K)
