@@ -640,11 +640,11 @@ def main():
                 gbs = n_local * 4 / med / 1e6
                 b2b = time_op(client, ev, lambda: client._s.check(fn()), iters=20, warmup=2)   # 20 launches, one event pair
                 b2b_ms[name] = b2b
-                job = job_seconds(lambda: client._s.check(fn()), iters=20)      # barrier -> all ranks launch -> sync -> max over ranks
+                job_s = job_seconds(lambda: client._s.check(fn()), iters=20)      # barrier -> all ranks launch -> sync -> max over ranks
                 res[name] = {"median_ms": round(med, 4), "min_ms": round(best, 4), "GBs_per_gpu": round(gbs, 1),
                              "frac_of_8TBs": round(gbs / PEAK_HBM_GBS, 4),
                              "back_to_back_ms": round(b2b, 4), "back_to_back_GBs": round(n_local * 4 / b2b / 1e6, 1),
-                             "job_ms": round(job * 1e3, 4), "GBs_total": round(n_local * 4 * world / job / 1e9, 1)}
+                             "job_ms": round(job_s * 1e3, 4), "GBs_total": round(n_local * 4 * world / job_s / 1e9, 1)}
                 med_frac[name] = gbs / PEAK_HBM_GBS
             # the second half of the metric ("reduce GB/s vs roofline"): same object shape as the headline roofline
             rd_ent, rd_why = _pmc_entry("pmc_traffic.json", "reduce_1GiB_sum", "reduce", REDUCE_SUM_KERNEL)
@@ -867,15 +867,15 @@ def main():
                 lib.mi355_gemm_select(ctx, C.byref(d), C.byref(alg))
                 # whole-job figure (the >= 6x at 8 GPUs target is quoted on it): barrier -> every rank launches its run of
                 # the batch 20 x back to back (after 5 untimed passes) -> sync -> the slowest rank's wall time
-                job = job_seconds(call, iters=20, warmup=5)
+                job_s = job_seconds(call, iters=20, warmup=5)
                 flop_rank = 2.0 * M ** 3 * count
                 tf = flop_rank / b2b / 1e9
                 return {"batch_this_rank": count, "algo": alg.value, "median_ms": round(med, 3), "back_to_back_ms": round(b2b, 3),
                         "TFLOPs_per_gpu": round(tf, 1), "TFLOPs_per_gpu_per_sample_median": round(flop_rank / med / 1e9, 1),
-                        "frac_of_2.5PF": round(tf / PEAK_BF16_TFLOPS, 4), "job_ms_per_pass": round(job * 1e3, 3)}, job
+                        "frac_of_2.5PF": round(tf / PEAK_BF16_TFLOPS, 4), "job_ms_per_pass": round(job_s * 1e3, 3)}, job_s
 
-            res, job = measure(mine, 1, bb)
-            tf_job = 2.0 * M ** 3 * total / job / 1e12            # shard_range covers [0, 512) exactly once: all ranks' FLOP
+            res, job_s = measure(mine, 1, bb)
+            tf_job = 2.0 * M ** 3 * total / job_s / 1e12            # shard_range covers [0, 512) exactly once: all ranks' FLOP
             res.update({"batch_total": total, "sharding": f"sharded.shard_range({total}, rank, {world})",
                         "TFLOPs_total": round(tf_job, 1),
                         "frac_of_2.5PF_per_gpu_job": round(tf_job / world / PEAK_BF16_TFLOPS, 4)})

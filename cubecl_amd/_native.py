@@ -52,8 +52,8 @@ ATOMIC_USAGE = {"LoadStore": 1, "Exchange": 2, "Add": 4, "MinMax": 8, "Bitwise":
 ADDRESS_TYPE_U32, ADDRESS_TYPE_U64 = 1, 2
 LAYOUT_ROW_MAJOR, LAYOUT_COL_MAJOR = 0, 1
 
-REDUCE_SUM, REDUCE_MEAN, REDUCE_MAX, REDUCE_MIN = 0, 1, 2, 3
-PLANE_PROD, PLANE_INCLUSIVE_SUM, PLANE_EXCLUSIVE_SUM = 100, 101, 102
+REDUCE_SUM, REDUCE_MEAN, REDUCE_MAX, REDUCE_MIN, REDUCE_PROD, REDUCE_ARGMAX, REDUCE_ARGMIN = 0, 1, 2, 3, 4, 5, 6
+PLANE_PROD, PLANE_INCLUSIVE_SUM, PLANE_EXCLUSIVE_SUM, PLANE_INCLUSIVE_PROD, PLANE_EXCLUSIVE_PROD = 100, 101, 102, 103, 104
 (PLANE_ALL, PLANE_ANY, PLANE_ELECT, PLANE_BROADCAST, PLANE_SHUFFLE, PLANE_SHUFFLE_XOR, PLANE_SHUFFLE_UP, PLANE_SHUFFLE_DOWN,
  PLANE_BALLOT) = range(200, 209)
 
@@ -70,7 +70,7 @@ class MmaConfig(C.Structure):
                 ("a_type", C.c_int32), ("b_type", C.c_int32), ("cd_type", C.c_int32)]
 
 
-ABI_VERSION = 6     # MI355_ABI_VERSION of include/mi355cube.h this table was written against
+ABI_VERSION = 7     # MI355_ABI_VERSION of include/mi355cube.h this table was written against
 
 
 class MemoryUsage(C.Structure):
@@ -228,6 +228,10 @@ PROTOTYPES = {
     "mi355_argmax_f32": (C.c_int32, [_P, _P, _P, C.c_uint64, _P, _P, _P, C.c_uint64]),
     "mi355_sum_argmax_f32": (C.c_int32, [_P, _P, _P, C.c_uint64, _P, _P, _P, _P, C.c_uint64]),
     "mi355_argmax_combine_f32": (C.c_int32, [_P, _P, _P, C.c_uint32, C.POINTER(C.c_uint64), _P, _P]),
+    "mi355_reduce": (C.c_int32, [_P, _P, _P, C.c_int32, C.c_uint64, C.c_int32, _P, _P, C.c_uint64]),
+    "mi355_argreduce": (C.c_int32, [_P, _P, _P, C.c_int32, C.c_uint64, C.c_int32, _P, _P, _P, C.c_uint64]),
+    "mi355_reduce_axis": (C.c_int32, [_P, _P, _P, C.c_int32, C.c_int32, _P, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "mi355_argreduce_axis": (C.c_int32, [_P, _P, _P, C.c_int32, C.c_int32, _P, C.c_uint64, C.c_uint64, C.c_uint64]),
     "mi355_reduce_axis_sum": (C.c_int32, [_P, _P, _P, C.c_int32, _P, C.c_uint64, C.c_uint64, C.c_uint64]),
     "mi355_reduce_axis_argmax": (C.c_int32, [_P, _P, _P, C.c_int32, _P, C.c_uint64, C.c_uint64, C.c_uint64]),
     "mi355_reduce_last_axis_sum": (C.c_int32, [_P, _P, _P, C.c_int32, _P, C.c_uint64, C.c_uint64, C.c_uint64]),

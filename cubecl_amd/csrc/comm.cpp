@@ -87,7 +87,8 @@ bool to_nccl_dtype(int32_t dtype, ncclDataType_t *out)
     }
 }
 
-// to_nccl_op (communication.rs:27-32) + Max/Min
+// to_nccl_op (communication.rs:27-32) + Max / Min / Prod (ncclSum 0, ncclProd 1, ncclMax 2, ncclMin 3, ncclAvg 4); the index
+// reductions MI355_REDUCE_ARGMAX / ARGMIN have no collective form (the sharded argmax all-gathers records: sharded.py)
 bool to_nccl_op(int32_t op, ncclRedOp_t *out)
 {
     switch (op) {
@@ -95,6 +96,7 @@ bool to_nccl_op(int32_t op, ncclRedOp_t *out)
     case MI355_REDUCE_MEAN: *out = 4; return true;
     case MI355_REDUCE_MAX: *out = 2; return true;
     case MI355_REDUCE_MIN: *out = 3; return true;
+    case MI355_REDUCE_PROD: *out = 1; return true;
     default: return false;
     }
 }

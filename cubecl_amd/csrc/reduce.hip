@@ -106,6 +106,53 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// ---- the reduce operations (round 4: max / min / prod / mean values and argmin beside sum and argmax) -----------------------
+// Value operations VOP (the public MI355_REDUCE_* codes; MEAN is SUM with the final division) and index operations AOP.
+//   MAX / MIN  the maximum / minimum under IEEE comparison with -0 < +0; NaN if ANY element is NaN (numpy's max / min; the
+//              value at the argmax / argmin below, up to the NaN's payload and the sign of a zero tie).  The NaN test travels
+//              beside the running value as a flag (v_max_f32 / v_min_f32 drop NaNs), so the result is order independent.
+//   PROD       f32 product in the summation's tree shape (plane_prod, crates/cubecl-core/src/frontend/plane.rs:285)
+//   ARGMIN     the mirror image of ARGMAX: lowest index of the minimum, -0 == +0, NaN ranks FIRST and the first NaN wins
+//              (numpy's argmin) -- the argmax key mirrored (~key) with the NaN code kept on top, same combine
+enum { VOP_NONE = -1, VOP_SUM = MI355_REDUCE_SUM, VOP_MAX = MI355_REDUCE_MAX, VOP_MIN = MI355_REDUCE_MIN, VOP_PROD = MI355_REDUCE_PROD };
+enum { AOP_NONE = 0, AOP_MAX = 1, AOP_MIN = 2 };
+
+template <int VOP> struct vop {
+    static __device__ __forceinline__ float identity()
+    { return VOP == VOP_PROD ? 1.f : VOP == VOP_MAX ? -__builtin_inff() : VOP == VOP_MIN ? __builtin_inff() : 0.f; }
+    static __device__ __forceinline__ float apply(float a, float b)
+    {
+        if constexpr (VOP == VOP_PROD) return a * b;
+        else if constexpr (VOP == VOP_MAX) return __builtin_fmaxf(a, b);
+        else if constexpr (VOP == VOP_MIN) return __builtin_fminf(a, b);
+        else return a + b;
+    }
+    static __device__ __forceinline__ f32x4 apply(f32x4 a, f32x4 b)
+    {
+        if constexpr (VOP == VOP_PROD) return a * b;
+        else if constexpr (VOP == VOP_MAX) return __builtin_elementwise_max(a, b);
+        else if constexpr (VOP == VOP_MIN) return __builtin_elementwise_min(a, b);
+        else return a + b;
+    }
+    static constexpr bool TRACKS_NAN = VOP == VOP_MAX || VOP == VOP_MIN;
+};
+
+template <int VOP>
+__device__ __forceinline__ float wave_fold(float v)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v = vop<VOP>::apply(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// key of the index operations: larger key wins in arg_combine; ARGMIN mirrors every number's key and keeps NaN on top
+template <int AOP>
+__device__ __forceinline__ uint32_t arg_key(float v)
+{
+    const uint32_t k = argmax_key(v);
+    return (AOP == AOP_MIN && k != 0xFFFFFFFFu) ? ~k : k;
+}
+
 __device__ __forceinline__ void wave_argmax(uint32_t &key, uint64_t &idx)
 {
 #pragma unroll
@@ -152,11 +199,19 @@ __device__ __forceinline__ bool arrive_is_last(unsigned int *ticket, uint32_t G)
 //   in      : 16-byte aligned body of the array (host peels a misaligned head into `head`)
 //   head    : up to 3 leading elements (global indices 0..head_n-1), body index i maps to
 //             global index i + head_n
-template <bool SUM, bool ARG, int DT = MI355_DTYPE_F32>
+//   VOP / AOP : value and index operation (above); both at once only as SUM + ARGMAX, the fused pass of the sharded job.
+//   mean_div  : MEAN = SUM with out = sum / mean_div (0 = no division)
+template <int VOP, int AOP, int DT = MI355_DTYPE_F32>
 __global__ void __launch_bounds__(RED_BLOCK)
 reduce_kernel(const typename red_in<DT>::elem *__restrict__ head, uint32_t head_n, const typename red_in<DT>::elem *__restrict__ in, uint64_t n,
-              red_record *__restrict__ records, unsigned int *__restrict__ ticket, uint64_t n_total, float *__restrict__ out_sum, float *__restrict__ out_val, uint64_t *__restrict__ out_idx)
+              red_record *__restrict__ records, unsigned int *__restrict__ ticket, uint64_t n_total, float *__restrict__ out_sum, float *__restrict__ out_val, uint64_t *__restrict__ out_idx,
+              float mean_div)
 {
+    constexpr bool SUM = VOP != VOP_NONE, ARG = AOP != AOP_NONE;        // (SUM: "a value is folded", whatever the operation)
+    static_assert(!(SUM && ARG) || (VOP == VOP_SUM && AOP == AOP_MAX), "fused pass: sum + argmax only");
+    typedef vop<VOP == VOP_NONE ? VOP_SUM : VOP> V;
+    constexpr bool NANS = SUM && V::TRACKS_NAN;
+    constexpr bool AMIN = AOP == AOP_MIN;
     typedef red_in<DT> RI;
     constexpr int EPV = RI::EPV;
     constexpr uint64_t TILE = (uint64_t)RED_BLOCK * RED_UNROLL * EPV;       // elements per 32 KiB tile
@@ -166,17 +221,21 @@ reduce_kernel(const typename red_in<DT>::elem *__restrict__ head, uint32_t head_
 
     f32x4 acc[RED_UNROLL];
 #pragma unroll
-    for (int u = 0; u < RED_UNROLL; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float tail_acc = 0.f;
-    uint32_t best_key = 0u;          // 0 = "nothing yet": every real key is >= 0x007FFFFF (-inf)
+    for (int u = 0; u < RED_UNROLL; ++u) acc[u] = (f32x4){V::identity(), V::identity(), V::identity(), V::identity()};
+    float tail_acc = V::identity();
+    bool nan_seen = false;           // MAX / MIN: some element of this lane's share was a NaN
+    uint32_t best_key = 0u;          // 0 = "nothing yet": every real key is >= 0x007FFFFF (-inf; ARGMIN: +inf)
     uint64_t best_idx = ~0ull;
-    float best_val = -__builtin_inff();   // value behind best_key (+inf once a NaN leads): the fast-reject threshold
+    // value behind best_key: the fast-reject threshold (once a NaN leads nothing but a NaN can follow it: +inf / ARGMIN -inf)
+    constexpr float NAN_LEADS = AMIN ? -__builtin_inff() : __builtin_inff();
+    float best_val = -NAN_LEADS;
 
     // peeled head: lowest global indices, block 0 only
     if (blockIdx.x == 0 && tid < head_n) {
         const float v = RI::widen(head[tid]);
-        if (SUM) tail_acc += v;
-        if (ARG) { best_key = argmax_key(v); best_idx = tid; best_val = (best_key == 0xFFFFFFFFu) ? __builtin_inff() : v; }
+        if (SUM) tail_acc = V::apply(tail_acc, v);
+        if (NANS) nan_seen |= (v != v);
+        if (ARG) { best_key = arg_key<AOP>(v); best_idx = tid; best_val = (best_key == 0xFFFFFFFFu) ? NAN_LEADS : v; }
     }
 
     const u32x4r *__restrict__ vin = reinterpret_cast<const u32x4r *>(in);
@@ -190,8 +249,12 @@ reduce_kernel(const typename red_in<DT>::elem *__restrict__ head, uint32_t head_
             float w[EPV];
             RI::unpack(raw[u], w);
             if (SUM) {
-                acc[u] += (f32x4){w[0], w[1], w[2], w[3]};
-                if constexpr (EPV == 8) acc[u] += (f32x4){w[4], w[5], w[6], w[7]};
+                acc[u] = V::apply(acc[u], (f32x4){w[0], w[1], w[2], w[3]});
+                if constexpr (EPV == 8) acc[u] = V::apply(acc[u], (f32x4){w[4], w[5], w[6], w[7]});
+            }
+            if constexpr (NANS) {
+                nan_seen |= __builtin_isunordered(w[0], w[1]) | __builtin_isunordered(w[2], w[3]);
+                if constexpr (EPV == 8) nan_seen |= __builtin_isunordered(w[4], w[5]) | __builtin_isunordered(w[6], w[7]);
             }
             if (ARG) {
                 // Fast reject: a 16-byte vector can only matter if it holds a NaN or a value above this
@@ -199,19 +262,21 @@ reduce_kernel(const typename red_in<DT>::elem *__restrict__ head, uint32_t head_
                 // key/index update below runs on a few percent of the vectors.  v_max ignores NaNs,
                 // hence the separate unordered test; -0 vs +0 never compares greater, which is the
                 // tie rule (equal keys keep the lower index).
-                float m4 = fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3]));
+                // (ARGMIN: the same with v_min and "below the running minimum")
+                typedef vop<AMIN ? VOP_MIN : VOP_MAX> X;
+                float m4 = X::apply(X::apply(w[0], w[1]), X::apply(w[2], w[3]));
                 bool has_nan = __builtin_isunordered(w[0], w[1]) | __builtin_isunordered(w[2], w[3]);
                 if constexpr (EPV == 8) {
-                    m4 = fmaxf(m4, fmaxf(fmaxf(w[4], w[5]), fmaxf(w[6], w[7])));
+                    m4 = X::apply(m4, X::apply(X::apply(w[4], w[5]), X::apply(w[6], w[7])));
                     has_nan |= __builtin_isunordered(w[4], w[5]) | __builtin_isunordered(w[6], w[7]);
                 }
-                if ((m4 > best_val) | has_nan | (best_key == 0u)) {
+                if ((AMIN ? (m4 < best_val) : (m4 > best_val)) | has_nan | (best_key == 0u)) {
                     const uint64_t e0 = (vbase + (uint64_t)u * RED_BLOCK) * EPV + head_n;
 #pragma unroll
                     for (int c = 0; c < EPV; ++c) {
-                        const uint32_t k = argmax_key(w[c]);
+                        const uint32_t k = arg_key<AOP>(w[c]);
                         // strict > : within one lane indices only grow, so the first maximum is kept
-                        if (k > best_key) { best_key = k; best_idx = e0 + c; best_val = (k == 0xFFFFFFFFu) ? __builtin_inff() : w[c]; }
+                        if (k > best_key) { best_key = k; best_idx = e0 + c; best_val = (k == 0xFFFFFFFFu) ? NAN_LEADS : w[c]; }
                     }
                 }
             }
@@ -223,9 +288,10 @@ reduce_kernel(const typename red_in<DT>::elem *__restrict__ head, uint32_t head_
     if (tail_base < n && blockIdx.x == (uint32_t)(full_tiles % G)) {
         for (uint64_t i = tail_base + tid; i < n; i += RED_BLOCK) {
             const float v = RI::widen(in[i]);
-            if (SUM) tail_acc += v;
+            if (SUM) tail_acc = V::apply(tail_acc, v);
+            if (NANS) nan_seen |= (v != v);
             if (ARG) {
-                const uint32_t k = argmax_key(v);
+                const uint32_t k = arg_key<AOP>(v);
                 if (k > best_key) { best_key = k; best_idx = i + head_n; }
             }
         }
@@ -237,12 +303,16 @@ reduce_kernel(const typename red_in<DT>::elem *__restrict__ head, uint32_t head_
 
     if (SUM) {
         // fixed tree: slots pairwise, then the 4 vector components, then tail, then lanes
-        f32x4 a = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-        f32x4 b = (acc[4] + acc[5]) + (acc[6] + acc[7]);
-        f32x4 s = a + b;
-        float lane_sum = ((s[0] + s[1]) + (s[2] + s[3])) + tail_acc;
-        lane_sum = wave_sum(lane_sum);
+        f32x4 a = V::apply(V::apply(acc[0], acc[1]), V::apply(acc[2], acc[3]));
+        f32x4 b = V::apply(V::apply(acc[4], acc[5]), V::apply(acc[6], acc[7]));
+        f32x4 s = V::apply(a, b);
+        float lane_sum = V::apply(V::apply(V::apply(s[0], s[1]), V::apply(s[2], s[3])), tail_acc);
+        lane_sum = wave_fold<VOP == VOP_NONE ? VOP_SUM : VOP>(lane_sum);
         if (lane == 0) sh.sum[wave] = lane_sum;
+    }
+    if constexpr (NANS) {            // the NaN flag rides in the record's key word (free: no index operation in this pass)
+        const bool any = __any(nan_seen);
+        if (lane == 0) sh.key[wave] = any ? 1u : 0u;
     }
     if (ARG) {
         wave_argmax(best_key, best_idx);
@@ -251,7 +321,8 @@ reduce_kernel(const typename red_in<DT>::elem *__restrict__ head, uint32_t head_
     __syncthreads();
     if (tid == 0) {
         float rs = 0.f; uint32_t rk = 0u; uint64_t ri = ~0ull;
-        if (SUM) rs = (sh.sum[0] + sh.sum[1]) + (sh.sum[2] + sh.sum[3]);
+        if (SUM) rs = V::apply(V::apply(sh.sum[0], sh.sum[1]), V::apply(sh.sum[2], sh.sum[3]));
+        if (NANS) rk = sh.key[0] | sh.key[1] | sh.key[2] | sh.key[3];
         if (ARG) {
             rk = sh.key[0]; ri = sh.idx[0];
 #pragma unroll
@@ -265,29 +336,36 @@ reduce_kernel(const typename red_in<DT>::elem *__restrict__ head, uint32_t head_
     if (!sh.last) return;
 
     // ---- the last workgroup folds the G records in index order (thread t owns t, t+256, ...) ----
-    float facc = 0.f;
+    float facc = V::identity();
     uint32_t key = 0u;
     uint64_t idx = ~0ull;
     for (uint32_t gi = tid; gi < G; gi += RED_BLOCK) {
         const red_record r = record_load(records + gi);            // sc1 loads: served by L2, never a stale L1 line
-        if (SUM) facc += r.sum;
+        if (SUM) facc = V::apply(facc, r.sum);
+        if (NANS) key |= r.key;
         if (ARG) arg_combine(key, idx, r.key, r.idx);
     }
     __syncthreads();                                                // sh.* is reused below
-    if (SUM) { facc = wave_sum(facc); if (lane == 0) sh.sum[wave] = facc; }
+    if (SUM) { facc = wave_fold<VOP == VOP_NONE ? VOP_SUM : VOP>(facc); if (lane == 0) sh.sum[wave] = facc; }
+    if constexpr (NANS) { const bool any = __any(key != 0u); if (lane == 0) sh.key[wave] = any ? 1u : 0u; }
     if (ARG) { wave_argmax(key, idx); if (lane == 0) { sh.key[wave] = key; sh.idx[wave] = idx; } }
     __syncthreads();
     if (tid == 0) {
         typedef __attribute__((address_space(1))) unsigned int gu32;
         __hip_atomic_store((gu32 *)ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
-        if (SUM && out_sum) *out_sum = (sh.sum[0] + sh.sum[1]) + (sh.sum[2] + sh.sum[3]);
+        if (SUM && out_sum) {
+            float total = V::apply(V::apply(sh.sum[0], sh.sum[1]), V::apply(sh.sum[2], sh.sum[3]));
+            if (NANS && (sh.key[0] | sh.key[1] | sh.key[2] | sh.key[3])) total = __uint_as_float(0x7FC00000u);
+            if (VOP == VOP_SUM && mean_div != 0.f) total = total / mean_div;
+            *out_sum = total;
+        }
         if (ARG) {
             uint32_t k = sh.key[0]; uint64_t ix = sh.idx[0];
 #pragma unroll
             for (int w = 1; w < RED_BLOCK / 64; ++w) arg_combine(k, ix, sh.key[w], sh.idx[w]);
             if (n_total == 0) {
                 if (out_idx) *out_idx = 0;
-                if (out_val) *out_val = -__builtin_inff();
+                if (out_val) *out_val = -NAN_LEADS;          // the identity: -inf (argmax) / +inf (argmin)
             } else {
                 if (out_idx) *out_idx = ix;
                 // bit-exact copy of the winning element
@@ -331,9 +409,9 @@ uint32_t pick_grid(const mi355_ctx *ctx, uint64_t n, uint64_t tile_elems = RED_T
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(tiles, cap));
 }
 
-template <bool SUM, bool ARG, int DT>
+template <int VOP, int AOP, int DT>
 int32_t run_reduce_t(mi355_ctx *ctx, mi355_stream stream, const void *in_v, uint64_t n, float *out_sum,
-                     float *out_val, uint64_t *out_idx, void *workspace, uint64_t workspace_bytes, const char *what)
+                     float *out_val, uint64_t *out_idx, void *workspace, uint64_t workspace_bytes, const char *what, float mean_div)
 {
     typedef typename red_in<DT>::elem elem;
     constexpr uint32_t ESZ = sizeof(elem);
@@ -359,22 +437,22 @@ int32_t run_reduce_t(mi355_ctx *ctx, mi355_stream stream, const void *in_v, uint
     unsigned int *ticket = nullptr;
     const int32_t trc = ticket_for_stream(ctx, s, &ticket);
     if (trc != MI355_OK) return trc;
-    hipLaunchKernelGGL((reduce_kernel<SUM, ARG, DT>), dim3(G), dim3(RED_BLOCK), 0, s, in, head_n, body, body_n, records,
-                       ticket, n, out_sum, out_val, out_idx);
+    hipLaunchKernelGGL((reduce_kernel<VOP, AOP, DT>), dim3(G), dim3(RED_BLOCK), 0, s, in, head_n, body, body_n, records,
+                       ticket, n, out_sum, out_val, out_idx, mean_div);
     if (hipPeekAtLastError() != hipSuccess) ctx->tickets_dirty = true;   // a refused launch never resets its ticket
     check_launch(ctx, what);
     return MI355_OK;
 }
 
-template <bool SUM, bool ARG>
+template <int VOP, int AOP>
 int32_t run_reduce(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, uint64_t n, float *out_sum,
-                   float *out_val, uint64_t *out_idx, void *workspace, uint64_t workspace_bytes, const char *what)
+                   float *out_val, uint64_t *out_idx, void *workspace, uint64_t workspace_bytes, const char *what, float mean_div = 0.f)
 {
     MI355_REQUIRE_CTX(ctx);
     switch (dtype) {
-    case MI355_DTYPE_F32: return run_reduce_t<SUM, ARG, MI355_DTYPE_F32>(ctx, stream, in, n, out_sum, out_val, out_idx, workspace, workspace_bytes, what);
-    case MI355_DTYPE_BF16: return run_reduce_t<SUM, ARG, MI355_DTYPE_BF16>(ctx, stream, in, n, out_sum, out_val, out_idx, workspace, workspace_bytes, what);
-    case MI355_DTYPE_F16: return run_reduce_t<SUM, ARG, MI355_DTYPE_F16>(ctx, stream, in, n, out_sum, out_val, out_idx, workspace, workspace_bytes, what);
+    case MI355_DTYPE_F32: return run_reduce_t<VOP, AOP, MI355_DTYPE_F32>(ctx, stream, in, n, out_sum, out_val, out_idx, workspace, workspace_bytes, what, mean_div);
+    case MI355_DTYPE_BF16: return run_reduce_t<VOP, AOP, MI355_DTYPE_BF16>(ctx, stream, in, n, out_sum, out_val, out_idx, workspace, workspace_bytes, what, mean_div);
+    case MI355_DTYPE_F16: return run_reduce_t<VOP, AOP, MI355_DTYPE_F16>(ctx, stream, in, n, out_sum, out_val, out_idx, workspace, workspace_bytes, what, mean_div);
     default: return fail(ctx, MI355_E_UNSUPPORTED, "%s: input dtype %d (f32, bf16 or f16)", what, dtype);
     }
 }
@@ -382,11 +460,29 @@ int32_t run_reduce(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t 
 // ---- last-axis reductions --------------------------------------------------------------------
 // One wave per row (THREADS=64) or one workgroup per row (THREADS=256/1024).  Rows are
 // independent; the row is streamed with 16-B loads when its base and stride allow it.
-template <int THREADS, bool ARG, int DT = MI355_DTYPE_F32>
+// OP: the public operation code -- MI355_REDUCE_SUM / MEAN / MAX / MIN / PROD write f32 values, ARGMAX / ARGMIN u32 indices.
+template <int OP> struct axis_op {
+    static constexpr bool ARG = OP == MI355_REDUCE_ARGMAX || OP == MI355_REDUCE_ARGMIN;
+    static constexpr int AOP = OP == MI355_REDUCE_ARGMIN ? AOP_MIN : AOP_MAX;
+    static constexpr int VOP = (OP == MI355_REDUCE_MAX || OP == MI355_REDUCE_MIN || OP == MI355_REDUCE_PROD) ? OP : VOP_SUM;
+    typedef vop<VOP> V;
+    // the value written for a reduced axis of `count` elements whose fold is `t` (`nan`: MAX / MIN saw a NaN)
+    static __device__ __forceinline__ float finish(float t, bool nan, uint64_t count)
+    {
+        if (V::TRACKS_NAN && nan) return __uint_as_float(0x7FC00000u);
+        if (OP == MI355_REDUCE_MEAN) return t / (float)count;
+        return t;
+    }
+};
+
+template <int THREADS, int OP, int DT = MI355_DTYPE_F32>
 __global__ void __launch_bounds__(THREADS)
 reduce_rows(const typename red_in<DT>::elem *__restrict__ in, float *__restrict__ out_sum, uint32_t *__restrict__ out_idx, uint64_t rows,
             uint64_t cols, uint64_t row_stride, int vec_ok)
 {
+    typedef axis_op<OP> O;
+    typedef typename O::V V;
+    constexpr bool ARG = O::ARG;
     typedef red_in<DT> RI;
     constexpr int EPV = RI::EPV;
     constexpr int WAVES = THREADS / 64;
@@ -397,7 +493,8 @@ reduce_rows(const typename red_in<DT>::elem *__restrict__ in, float *__restrict_
     __shared__ uint64_t s_idx[WAVES];
     for (uint64_t row = blockIdx.x; row < rows; row += gridDim.x) {
         const typename RI::elem *__restrict__ p = in + row * row_stride;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        float a0 = V::identity(), a1 = V::identity(), a2 = V::identity(), a3 = V::identity();
+        bool nan_seen = false;
         uint32_t key = 0u; uint64_t idx = ~0ull;
         uint64_t done = 0;
         if (vec_ok) {
@@ -407,12 +504,16 @@ reduce_rows(const typename red_in<DT>::elem *__restrict__ in, float *__restrict_
                 float v[EPV];
                 RI::unpack(vp[i], v);
                 if (!ARG) {
-                    a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
-                    if constexpr (EPV == 8) { a0 += v[4]; a1 += v[5]; a2 += v[6]; a3 += v[7]; }
+                    a0 = V::apply(a0, v[0]); a1 = V::apply(a1, v[1]); a2 = V::apply(a2, v[2]); a3 = V::apply(a3, v[3]);
+                    if constexpr (EPV == 8) { a0 = V::apply(a0, v[4]); a1 = V::apply(a1, v[5]); a2 = V::apply(a2, v[6]); a3 = V::apply(a3, v[7]); }
+                    if constexpr (V::TRACKS_NAN) {
+                        nan_seen |= __builtin_isunordered(v[0], v[1]) | __builtin_isunordered(v[2], v[3]);
+                        if constexpr (EPV == 8) nan_seen |= __builtin_isunordered(v[4], v[5]) | __builtin_isunordered(v[6], v[7]);
+                    }
                 } else {
 #pragma unroll
                     for (int c = 0; c < EPV; ++c) {
-                        const uint32_t k = argmax_key(v[c]);
+                        const uint32_t k = arg_key<O::AOP>(v[c]);
                         if (k > key) { key = k; idx = i * EPV + c; }
                     }
                 }
@@ -421,16 +522,21 @@ reduce_rows(const typename red_in<DT>::elem *__restrict__ in, float *__restrict_
         }
         for (uint64_t i = done + tid; i < cols; i += THREADS) {
             const float v = RI::widen(p[i]);
-            if (!ARG) a0 += v;
-            else { const uint32_t k = argmax_key(v); if (k > key) { key = k; idx = i; } }
+            if (!ARG) { a0 = V::apply(a0, v); if (V::TRACKS_NAN) nan_seen |= (v != v); }
+            else { const uint32_t k = arg_key<O::AOP>(v); if (k > key) { key = k; idx = i; } }
         }
         if (!ARG) {
-            float s = wave_sum((a0 + a1) + (a2 + a3));
-            if (WAVES == 1) { if (lane == 0) out_sum[row] = s; }
+            float s = wave_fold<O::VOP>(V::apply(V::apply(a0, a1), V::apply(a2, a3)));
+            const bool wave_nan = V::TRACKS_NAN ? (bool)__any(nan_seen) : false;
+            if (WAVES == 1) { if (lane == 0) out_sum[row] = O::finish(s, wave_nan, cols); }
             else {
-                if (lane == 0) s_sum[wave] = s;
+                if (lane == 0) { s_sum[wave] = s; s_key[wave] = wave_nan ? 1u : 0u; }
                 __syncthreads();
-                if (tid == 0) { float t = 0.f; for (int w = 0; w < WAVES; ++w) t += s_sum[w]; out_sum[row] = t; }
+                if (tid == 0) {
+                    float t = V::identity(); uint32_t nn = 0u;
+                    for (int w = 0; w < WAVES; ++w) { t = V::apply(t, s_sum[w]); nn |= s_key[w]; }
+                    out_sum[row] = O::finish(t, nn != 0u, cols);
+                }
                 __syncthreads();
             }
         } else {
@@ -455,11 +561,14 @@ reduce_rows(const typename red_in<DT>::elem *__restrict__ in, float *__restrict_
 // each thread folds `reduce` values sequentially (the book's per-unit loop, v4-gpu.rs:47-54, along a strided axis),
 // split into RSPLIT interleaved partial chains when `reduce` is long and outer*inner is too small to fill the chip;
 // the chains are folded in order through LDS.  Roofline: HBM, 4 bytes per input element read once.
-template <bool ARG, int RSPLIT, int DT = MI355_DTYPE_F32>
+template <int OP, int RSPLIT, int DT = MI355_DTYPE_F32>
 __global__ void __launch_bounds__(256)
 reduce_mid_axis(const typename red_in<DT>::elem *__restrict__ in, float *__restrict__ out_sum, uint32_t *__restrict__ out_idx, uint64_t outer,
                 uint64_t red, uint64_t inner)
 {
+    typedef axis_op<OP> O;
+    typedef typename O::V V;
+    constexpr bool ARG = O::ARG;
     typedef red_in<DT> RI;
     constexpr int IW = 256 / RSPLIT;                       // inner positions per workgroup
     const uint32_t tid = threadIdx.x, il = tid % IW, rs = tid / IW;
@@ -469,26 +578,27 @@ reduce_mid_axis(const typename red_in<DT>::elem *__restrict__ in, float *__restr
     __shared__ uint32_t s_idx[RSPLIT][IW];
     for (uint64_t blk = blockIdx.x; blk < outer * blocks_i; blk += gridDim.x) {
         const uint64_t o = blk / blocks_i, i = (blk % blocks_i) * IW + il;
-        float acc = 0.f;
+        float acc = V::identity();
+        bool nan_seen = false;
         uint32_t key = 0u, idx = 0u;
         if (i < inner) {
             const typename RI::elem *p = in + (o * red) * inner + i;
             for (uint64_t r = rs; r < red; r += RSPLIT) {
                 const float v = RI::widen(p[r * inner]);
-                if (!ARG) acc += v;
-                else { const uint32_t k = argmax_key(v); if (k > key) { key = k; idx = (uint32_t)r; } }
+                if (!ARG) { acc = V::apply(acc, v); if (V::TRACKS_NAN) nan_seen |= (v != v); }
+                else { const uint32_t k = arg_key<O::AOP>(v); if (k > key) { key = k; idx = (uint32_t)r; } }
             }
         }
         if (RSPLIT == 1) {
-            if (i < inner) { if (!ARG) out_sum[o * inner + i] = acc; else out_idx[o * inner + i] = idx; }
+            if (i < inner) { if (!ARG) out_sum[o * inner + i] = O::finish(acc, nan_seen, red); else out_idx[o * inner + i] = idx; }
         } else {
-            if (!ARG) s_sum[rs][il] = acc; else { s_key[rs][il] = key; s_idx[rs][il] = idx; }
+            if (!ARG) { s_sum[rs][il] = acc; s_key[rs][il] = nan_seen ? 1u : 0u; } else { s_key[rs][il] = key; s_idx[rs][il] = idx; }
             __syncthreads();
             if (rs == 0 && i < inner) {
                 if (!ARG) {
-                    float t = s_sum[0][il];
-                    for (int q = 1; q < RSPLIT; ++q) t += s_sum[q][il];
-                    out_sum[o * inner + i] = t;
+                    float t = s_sum[0][il]; uint32_t nn = s_key[0][il];
+                    for (int q = 1; q < RSPLIT; ++q) { t = V::apply(t, s_sum[q][il]); nn |= s_key[q][il]; }
+                    out_sum[o * inner + i] = O::finish(t, nn != 0u, red);
                 } else {
                     uint32_t k = s_key[0][il]; uint64_t ix = s_idx[0][il];
                     for (int q = 1; q < RSPLIT; ++q) arg_combine(k, ix, s_key[q][il], s_idx[q][il]);
@@ -500,10 +610,11 @@ reduce_mid_axis(const typename red_in<DT>::elem *__restrict__ in, float *__restr
     }
 }
 
-template <bool ARG, int DT = MI355_DTYPE_F32>
+template <int OP, int DT = MI355_DTYPE_F32>
 int32_t run_mid(mi355_ctx *ctx, mi355_stream stream, const typename red_in<DT>::elem *in, float *out_sum, uint32_t *out_idx, uint64_t outer,
                 uint64_t red, uint64_t inner, const char *what)
 {
+    constexpr bool ARG = axis_op<OP>::ARG;
     MI355_REQUIRE_CTX(ctx);
     if (outer == 0 || inner == 0) return MI355_OK;
     if ((red && !in) || (!ARG && !out_sum) || (ARG && !out_idx)) return fail(ctx, MI355_E_INVALID_ARGUMENT, "%s: NULL pointer", what);
@@ -516,7 +627,7 @@ int32_t run_mid(mi355_ctx *ctx, mi355_stream stream, const typename red_in<DT>::
     do {                                                                                                                \
         const uint64_t blocks = outer * ((inner + 256 / R - 1) / (256 / R));                                            \
         const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, cus * 16));                    \
-        hipLaunchKernelGGL((reduce_mid_axis<ARG, R, DT>), dim3(grid), dim3(256), 0, s, in, out_sum, out_idx, outer, red, inner); \
+        hipLaunchKernelGGL((reduce_mid_axis<OP, R, DT>), dim3(grid), dim3(256), 0, s, in, out_sum, out_idx, outer, red, inner); \
     } while (0)
     if (split) MID(8); else MID(1);
 #undef MID
@@ -524,10 +635,11 @@ int32_t run_mid(mi355_ctx *ctx, mi355_stream stream, const typename red_in<DT>::
     return MI355_OK;
 }
 
-template <bool ARG, int DT = MI355_DTYPE_F32>
+template <int OP, int DT = MI355_DTYPE_F32>
 int32_t run_rows(mi355_ctx *ctx, mi355_stream stream, const typename red_in<DT>::elem *in, float *out_sum, uint32_t *out_idx,
                  uint64_t rows, uint64_t cols, uint64_t row_stride, const char *what)
 {
+    constexpr bool ARG = axis_op<OP>::ARG;
     MI355_REQUIRE_CTX(ctx);
     if (rows == 0) return MI355_OK;
     if ((cols && !in) || (!ARG && !out_sum) || (ARG && !out_idx))
@@ -543,15 +655,15 @@ int32_t run_rows(mi355_ctx *ctx, mi355_stream stream, const typename red_in<DT>:
     const uint64_t cols32 = cols * sizeof(typename red_in<DT>::elem) / 4;        // row length in f32-equivalents (bytes / 4)
     if (cols32 <= 2048) {
         const uint32_t grid = (uint32_t)std::min<uint64_t>(rows, cus * 32);
-        hipLaunchKernelGGL((reduce_rows<64, ARG, DT>), dim3(grid), dim3(64), 0, s, in, out_sum, out_idx, rows, cols,
+        hipLaunchKernelGGL((reduce_rows<64, OP, DT>), dim3(grid), dim3(64), 0, s, in, out_sum, out_idx, rows, cols,
                            row_stride, vec_ok);
     } else if (cols32 <= 65536) {
         const uint32_t grid = (uint32_t)std::min<uint64_t>(rows, cus * 8);
-        hipLaunchKernelGGL((reduce_rows<256, ARG, DT>), dim3(grid), dim3(256), 0, s, in, out_sum, out_idx, rows, cols,
+        hipLaunchKernelGGL((reduce_rows<256, OP, DT>), dim3(grid), dim3(256), 0, s, in, out_sum, out_idx, rows, cols,
                            row_stride, vec_ok);
     } else {
         const uint32_t grid = (uint32_t)std::min<uint64_t>(rows, cus * 2);
-        hipLaunchKernelGGL((reduce_rows<1024, ARG, DT>), dim3(grid), dim3(1024), 0, s, in, out_sum, out_idx, rows, cols,
+        hipLaunchKernelGGL((reduce_rows<1024, OP, DT>), dim3(grid), dim3(1024), 0, s, in, out_sum, out_idx, rows, cols,
                            row_stride, vec_ok);
     }
     check_launch(ctx, what);
@@ -565,16 +677,18 @@ plane_reduce_kernel(const float *__restrict__ in, float *__restrict__ out, uint6
     const uint32_t lane = threadIdx.x;
     const uint64_t i = (uint64_t)blockIdx.x * 64 + lane;
     float v = (i < n) ? in[i] : 0.f;
-    if (op == 101 || op == 102) {
-        // plane_reduce_inclusive / exclusive (shared/plane.rs:72-97): Hillis-Steele with shuffle_up
+    if (op >= 101 && op <= 104) {
+        // plane_reduce_inclusive / exclusive (shared/plane.rs:72-97): Hillis-Steele with shuffle_up; sum (101 / 102, default 0)
+        // or product (103 / 104, default 1: lower_unop!(ExclusiveFProdOp, plane_reduce_exclusive, OpMul, 1), shared/plane.rs:133-136)
+        const bool mul = op >= 103, exclusive = (op == 102 || op == 104);
         float acc = v;
         for (uint32_t off = 1; off < active; off <<= 1) {
             const float up = __shfl_up(acc, off, 64);
-            if ((lane & (active - 1)) >= off) acc += up;
+            if ((lane & (active - 1)) >= off) acc = mul ? acc * up : acc + up;
         }
-        if (op == 102) {
+        if (exclusive) {
             const float prev = __shfl_up(acc, 1, 64);
-            acc = ((lane & (active - 1)) == 0) ? 0.f : prev;
+            acc = ((lane & (active - 1)) == 0) ? (mul ? 1.f : 0.f) : prev;
         }
         v = acc;
     } else {
@@ -585,7 +699,7 @@ plane_reduce_kernel(const float *__restrict__ in, float *__restrict__ out, uint6
             case MI355_REDUCE_SUM: v = v + o; break;
             case MI355_REDUCE_MAX: v = v > o ? v : o; break;
             case MI355_REDUCE_MIN: v = v < o ? v : o; break;
-            default: v = v * o; break;  // 100: product
+            default: v = v * o; break;  // MI355_REDUCE_PROD (or its round-1 code 100): product
             }
         }
     }
@@ -613,9 +727,11 @@ plane_op_kernel(const float *__restrict__ in, void *__restrict__ out_raw, uint64
     // width = the plane: a source lane outside it leaves the lane's own value (with the default width of 64 a 32-lane plane
     // would read the registers of lanes that do not exist)
     case MI355_PLANE_SHUFFLE: out[i] = __shfl(v, (int)arg, (int)plane); break;
-    case MI355_PLANE_SHUFFLE_XOR: out[i] = __shfl_xor(v, (int)arg, (int)plane); break;
-    case MI355_PLANE_SHUFFLE_UP: out[i] = __shfl_up(v, arg, (int)plane); break;
-    case MI355_PLANE_SHUFFLE_DOWN: out[i] = __shfl_down(v, arg, (int)plane); break;
+    case MI355_PLANE_SHUFFLE_XOR: out[i] = arg >= plane ? v : __shfl_xor(v, (int)arg, (int)plane); break;   // (lane ^ mask outside the plane: own value)
+    // (a delta of a whole plane or more has no source lane inside the plane: every lane keeps its own value -- decided here,
+    //  because __shfl_up / __shfl_down do their index arithmetic in signed int and a delta >= 2^31 would wrap)
+    case MI355_PLANE_SHUFFLE_UP: out[i] = arg >= plane ? v : __shfl_up(v, arg, (int)plane); break;
+    case MI355_PLANE_SHUFFLE_DOWN: out[i] = arg >= plane ? v : __shfl_down(v, arg, (int)plane); break;
     case MI355_PLANE_BALLOT: {
         const unsigned long long m = __ballot(v != 0.f);     // 64-bit on this target: words 0 and 1 of the reference's 4 x u32
         if (lane == 0) {
@@ -677,7 +793,7 @@ MI355_API int32_t mi355_reduce_sum_f32(mi355_ctx *ctx, mi355_stream stream, cons
                                        void *workspace, uint64_t workspace_bytes)
 {
     if (ctx && !out) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_reduce_sum_f32: out is NULL");
-    return run_reduce<true, false>(ctx, stream, in, MI355_DTYPE_F32, n, out, nullptr, nullptr, workspace, workspace_bytes,
+    return run_reduce<VOP_SUM, AOP_NONE>(ctx, stream, in, MI355_DTYPE_F32, n, out, nullptr, nullptr, workspace, workspace_bytes,
                                    "mi355_reduce_sum_f32");
 }
 
@@ -686,28 +802,28 @@ MI355_API int32_t mi355_reduce_sum(mi355_ctx *ctx, mi355_stream stream, const vo
                                    void *workspace, uint64_t workspace_bytes)
 {
     if (ctx && !out) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_reduce_sum: out is NULL");
-    return run_reduce<true, false>(ctx, stream, in, dtype, n, out, nullptr, nullptr, workspace, workspace_bytes, "mi355_reduce_sum");
+    return run_reduce<VOP_SUM, AOP_NONE>(ctx, stream, in, dtype, n, out, nullptr, nullptr, workspace, workspace_bytes, "mi355_reduce_sum");
 }
 
 MI355_API int32_t mi355_argmax(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, uint64_t n, float *out_val,
                                uint64_t *out_idx, void *workspace, uint64_t workspace_bytes)
 {
     if (ctx && !out_idx && !out_val) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_argmax: no output");
-    return run_reduce<false, true>(ctx, stream, in, dtype, n, nullptr, out_val, out_idx, workspace, workspace_bytes, "mi355_argmax");
+    return run_reduce<VOP_NONE, AOP_MAX>(ctx, stream, in, dtype, n, nullptr, out_val, out_idx, workspace, workspace_bytes, "mi355_argmax");
 }
 
 MI355_API int32_t mi355_sum_argmax(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, uint64_t n, float *out_sum,
                                    float *out_val, uint64_t *out_idx, void *workspace, uint64_t workspace_bytes)
 {
     if (ctx && !out_sum && !out_idx && !out_val) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_sum_argmax: no output");
-    return run_reduce<true, true>(ctx, stream, in, dtype, n, out_sum, out_val, out_idx, workspace, workspace_bytes, "mi355_sum_argmax");
+    return run_reduce<VOP_SUM, AOP_MAX>(ctx, stream, in, dtype, n, out_sum, out_val, out_idx, workspace, workspace_bytes, "mi355_sum_argmax");
 }
 
 MI355_API int32_t mi355_argmax_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, uint64_t n, float *out_val,
                                    uint64_t *out_idx, void *workspace, uint64_t workspace_bytes)
 {
     if (ctx && !out_idx && !out_val) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_argmax_f32: no output");
-    return run_reduce<false, true>(ctx, stream, in, MI355_DTYPE_F32, n, nullptr, out_val, out_idx, workspace, workspace_bytes,
+    return run_reduce<VOP_NONE, AOP_MAX>(ctx, stream, in, MI355_DTYPE_F32, n, nullptr, out_val, out_idx, workspace, workspace_bytes,
                                    "mi355_argmax_f32");
 }
 
@@ -717,7 +833,7 @@ MI355_API int32_t mi355_sum_argmax_f32(mi355_ctx *ctx, mi355_stream stream, cons
 {
     if (ctx && !out_sum && !out_idx && !out_val)
         return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_sum_argmax_f32: no output");
-    return run_reduce<true, true>(ctx, stream, in, MI355_DTYPE_F32, n, out_sum, out_val, out_idx, workspace, workspace_bytes,
+    return run_reduce<VOP_SUM, AOP_MAX>(ctx, stream, in, MI355_DTYPE_F32, n, out_sum, out_val, out_idx, workspace, workspace_bytes,
                                   "mi355_sum_argmax_f32");
 }
 
@@ -740,14 +856,14 @@ MI355_API int32_t mi355_argmax_combine_f32(mi355_ctx *ctx, mi355_stream stream, 
 MI355_API int32_t mi355_reduce_last_axis_sum_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, float *out,
                                                  uint64_t rows, uint64_t cols, uint64_t row_stride)
 {
-    return run_rows<false>(ctx, stream, in, out, nullptr, rows, cols, row_stride, "mi355_reduce_last_axis_sum_f32");
+    return run_rows<MI355_REDUCE_SUM>(ctx, stream, in, out, nullptr, rows, cols, row_stride, "mi355_reduce_last_axis_sum_f32");
 }
 
 MI355_API int32_t mi355_reduce_last_axis_argmax_f32(mi355_ctx *ctx, mi355_stream stream, const float *in,
                                                     uint32_t *out_idx, uint64_t rows, uint64_t cols,
                                                     uint64_t row_stride)
 {
-    return run_rows<true>(ctx, stream, in, nullptr, out_idx, rows, cols, row_stride,
+    return run_rows<MI355_REDUCE_ARGMAX>(ctx, stream, in, nullptr, out_idx, rows, cols, row_stride,
                           "mi355_reduce_last_axis_argmax_f32");
 }
 
@@ -757,9 +873,9 @@ MI355_API int32_t mi355_reduce_last_axis_sum(mi355_ctx *ctx, mi355_stream stream
 {
     if (!ctx) return MI355_E_INVALID_ARGUMENT;
     switch (dtype) {
-    case MI355_DTYPE_F32: return run_rows<false>(ctx, stream, static_cast<const float *>(in), out, nullptr, rows, cols, row_stride, "mi355_reduce_last_axis_sum");
-    case MI355_DTYPE_BF16: return run_rows<false, MI355_DTYPE_BF16>(ctx, stream, static_cast<const uint16_t *>(in), out, nullptr, rows, cols, row_stride, "mi355_reduce_last_axis_sum");
-    case MI355_DTYPE_F16: return run_rows<false, MI355_DTYPE_F16>(ctx, stream, static_cast<const uint16_t *>(in), out, nullptr, rows, cols, row_stride, "mi355_reduce_last_axis_sum");
+    case MI355_DTYPE_F32: return run_rows<MI355_REDUCE_SUM>(ctx, stream, static_cast<const float *>(in), out, nullptr, rows, cols, row_stride, "mi355_reduce_last_axis_sum");
+    case MI355_DTYPE_BF16: return run_rows<MI355_REDUCE_SUM, MI355_DTYPE_BF16>(ctx, stream, static_cast<const uint16_t *>(in), out, nullptr, rows, cols, row_stride, "mi355_reduce_last_axis_sum");
+    case MI355_DTYPE_F16: return run_rows<MI355_REDUCE_SUM, MI355_DTYPE_F16>(ctx, stream, static_cast<const uint16_t *>(in), out, nullptr, rows, cols, row_stride, "mi355_reduce_last_axis_sum");
     default: return fail(ctx, MI355_E_UNSUPPORTED, "mi355_reduce_last_axis_sum: input dtype %d (f32, bf16 or f16)", dtype);
     }
 }
@@ -769,9 +885,9 @@ MI355_API int32_t mi355_reduce_last_axis_argmax(mi355_ctx *ctx, mi355_stream str
 {
     if (!ctx) return MI355_E_INVALID_ARGUMENT;
     switch (dtype) {
-    case MI355_DTYPE_F32: return run_rows<true>(ctx, stream, static_cast<const float *>(in), nullptr, out_idx, rows, cols, row_stride, "mi355_reduce_last_axis_argmax");
-    case MI355_DTYPE_BF16: return run_rows<true, MI355_DTYPE_BF16>(ctx, stream, static_cast<const uint16_t *>(in), nullptr, out_idx, rows, cols, row_stride, "mi355_reduce_last_axis_argmax");
-    case MI355_DTYPE_F16: return run_rows<true, MI355_DTYPE_F16>(ctx, stream, static_cast<const uint16_t *>(in), nullptr, out_idx, rows, cols, row_stride, "mi355_reduce_last_axis_argmax");
+    case MI355_DTYPE_F32: return run_rows<MI355_REDUCE_ARGMAX>(ctx, stream, static_cast<const float *>(in), nullptr, out_idx, rows, cols, row_stride, "mi355_reduce_last_axis_argmax");
+    case MI355_DTYPE_BF16: return run_rows<MI355_REDUCE_ARGMAX, MI355_DTYPE_BF16>(ctx, stream, static_cast<const uint16_t *>(in), nullptr, out_idx, rows, cols, row_stride, "mi355_reduce_last_axis_argmax");
+    case MI355_DTYPE_F16: return run_rows<MI355_REDUCE_ARGMAX, MI355_DTYPE_F16>(ctx, stream, static_cast<const uint16_t *>(in), nullptr, out_idx, rows, cols, row_stride, "mi355_reduce_last_axis_argmax");
     default: return fail(ctx, MI355_E_UNSUPPORTED, "mi355_reduce_last_axis_argmax: input dtype %d (f32, bf16 or f16)", dtype);
     }
 }
@@ -779,25 +895,36 @@ MI355_API int32_t mi355_reduce_last_axis_argmax(mi355_ctx *ctx, mi355_stream str
 MI355_API int32_t mi355_reduce_axis_sum_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, float *out, uint64_t outer,
                                             uint64_t reduce, uint64_t inner)
 {
-    if (inner == 1) return run_rows<false>(ctx, stream, in, out, nullptr, outer, reduce, reduce, "mi355_reduce_axis_sum_f32");
-    return run_mid<false>(ctx, stream, in, out, nullptr, outer, reduce, inner, "mi355_reduce_axis_sum_f32");
+    if (inner == 1) return run_rows<MI355_REDUCE_SUM>(ctx, stream, in, out, nullptr, outer, reduce, reduce, "mi355_reduce_axis_sum_f32");
+    return run_mid<MI355_REDUCE_SUM>(ctx, stream, in, out, nullptr, outer, reduce, inner, "mi355_reduce_axis_sum_f32");
 }
 
 MI355_API int32_t mi355_reduce_axis_argmax_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, uint32_t *out_idx,
                                                uint64_t outer, uint64_t reduce, uint64_t inner)
 {
-    if (inner == 1) return run_rows<true>(ctx, stream, in, nullptr, out_idx, outer, reduce, reduce, "mi355_reduce_axis_argmax_f32");
-    return run_mid<true>(ctx, stream, in, nullptr, out_idx, outer, reduce, inner, "mi355_reduce_axis_argmax_f32");
+    if (inner == 1) return run_rows<MI355_REDUCE_ARGMAX>(ctx, stream, in, nullptr, out_idx, outer, reduce, reduce, "mi355_reduce_axis_argmax_f32");
+    return run_mid<MI355_REDUCE_ARGMAX>(ctx, stream, in, nullptr, out_idx, outer, reduce, inner, "mi355_reduce_axis_argmax_f32");
 }
 
 // any-axis reductions of f32 / bf16 / f16 input (f32 arithmetic)
-template <bool ARG, int DT>
+template <int OP, int DT>
 static int32_t axis_dispatch(mi355_ctx *ctx, mi355_stream stream, const void *in, float *out, uint32_t *out_idx, uint64_t outer,
                              uint64_t reduce, uint64_t inner, const char *what)
 {
     typedef typename red_in<DT>::elem elem;
-    if (inner == 1) return run_rows<ARG, DT>(ctx, stream, static_cast<const elem *>(in), out, out_idx, outer, reduce, reduce, what);
-    return run_mid<ARG, DT>(ctx, stream, static_cast<const elem *>(in), out, out_idx, outer, reduce, inner, what);
+    if (inner == 1) return run_rows<OP, DT>(ctx, stream, static_cast<const elem *>(in), out, out_idx, outer, reduce, reduce, what);
+    return run_mid<OP, DT>(ctx, stream, static_cast<const elem *>(in), out, out_idx, outer, reduce, inner, what);
+}
+template <int OP>
+static int32_t axis_dispatch_dtype(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, float *out, uint32_t *out_idx,
+                                   uint64_t outer, uint64_t reduce, uint64_t inner, const char *what)
+{
+    switch (dtype) {
+    case MI355_DTYPE_F32: return axis_dispatch<OP, MI355_DTYPE_F32>(ctx, stream, in, out, out_idx, outer, reduce, inner, what);
+    case MI355_DTYPE_BF16: return axis_dispatch<OP, MI355_DTYPE_BF16>(ctx, stream, in, out, out_idx, outer, reduce, inner, what);
+    case MI355_DTYPE_F16: return axis_dispatch<OP, MI355_DTYPE_F16>(ctx, stream, in, out, out_idx, outer, reduce, inner, what);
+    default: return fail(ctx, MI355_E_UNSUPPORTED, "%s: input dtype %d (f32, bf16 or f16)", what, dtype);
+    }
 }
 
 MI355_API int32_t mi355_reduce_axis_sum(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, float *out,
@@ -805,9 +932,9 @@ MI355_API int32_t mi355_reduce_axis_sum(mi355_ctx *ctx, mi355_stream stream, con
 {
     if (!ctx) return MI355_E_INVALID_ARGUMENT;
     switch (dtype) {
-    case MI355_DTYPE_F32: return axis_dispatch<false, MI355_DTYPE_F32>(ctx, stream, in, out, nullptr, outer, reduce, inner, "mi355_reduce_axis_sum");
-    case MI355_DTYPE_BF16: return axis_dispatch<false, MI355_DTYPE_BF16>(ctx, stream, in, out, nullptr, outer, reduce, inner, "mi355_reduce_axis_sum");
-    case MI355_DTYPE_F16: return axis_dispatch<false, MI355_DTYPE_F16>(ctx, stream, in, out, nullptr, outer, reduce, inner, "mi355_reduce_axis_sum");
+    case MI355_DTYPE_F32: return axis_dispatch<MI355_REDUCE_SUM, MI355_DTYPE_F32>(ctx, stream, in, out, nullptr, outer, reduce, inner, "mi355_reduce_axis_sum");
+    case MI355_DTYPE_BF16: return axis_dispatch<MI355_REDUCE_SUM, MI355_DTYPE_BF16>(ctx, stream, in, out, nullptr, outer, reduce, inner, "mi355_reduce_axis_sum");
+    case MI355_DTYPE_F16: return axis_dispatch<MI355_REDUCE_SUM, MI355_DTYPE_F16>(ctx, stream, in, out, nullptr, outer, reduce, inner, "mi355_reduce_axis_sum");
     default: return fail(ctx, MI355_E_UNSUPPORTED, "mi355_reduce_axis_sum: input dtype %d (f32, bf16 or f16)", dtype);
     }
 }
@@ -817,10 +944,62 @@ MI355_API int32_t mi355_reduce_axis_argmax(mi355_ctx *ctx, mi355_stream stream, 
 {
     if (!ctx) return MI355_E_INVALID_ARGUMENT;
     switch (dtype) {
-    case MI355_DTYPE_F32: return axis_dispatch<true, MI355_DTYPE_F32>(ctx, stream, in, nullptr, out_idx, outer, reduce, inner, "mi355_reduce_axis_argmax");
-    case MI355_DTYPE_BF16: return axis_dispatch<true, MI355_DTYPE_BF16>(ctx, stream, in, nullptr, out_idx, outer, reduce, inner, "mi355_reduce_axis_argmax");
-    case MI355_DTYPE_F16: return axis_dispatch<true, MI355_DTYPE_F16>(ctx, stream, in, nullptr, out_idx, outer, reduce, inner, "mi355_reduce_axis_argmax");
+    case MI355_DTYPE_F32: return axis_dispatch<MI355_REDUCE_ARGMAX, MI355_DTYPE_F32>(ctx, stream, in, nullptr, out_idx, outer, reduce, inner, "mi355_reduce_axis_argmax");
+    case MI355_DTYPE_BF16: return axis_dispatch<MI355_REDUCE_ARGMAX, MI355_DTYPE_BF16>(ctx, stream, in, nullptr, out_idx, outer, reduce, inner, "mi355_reduce_axis_argmax");
+    case MI355_DTYPE_F16: return axis_dispatch<MI355_REDUCE_ARGMAX, MI355_DTYPE_F16>(ctx, stream, in, nullptr, out_idx, outer, reduce, inner, "mi355_reduce_axis_argmax");
     default: return fail(ctx, MI355_E_UNSUPPORTED, "mi355_reduce_axis_argmax: input dtype %d (f32, bf16 or f16)", dtype);
+    }
+}
+
+// ---- every reduce operation through one pair of entry points per form (round 4) ----------------------------------------------
+MI355_API int32_t mi355_reduce(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, uint64_t n, int32_t op, float *out,
+                               void *workspace, uint64_t workspace_bytes)
+{
+    if (ctx && !out) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_reduce: out is NULL");
+    switch (op) {
+    case MI355_REDUCE_SUM: return run_reduce<VOP_SUM, AOP_NONE>(ctx, stream, in, dtype, n, out, nullptr, nullptr, workspace, workspace_bytes, "mi355_reduce(sum)");
+    case MI355_REDUCE_MEAN: return run_reduce<VOP_SUM, AOP_NONE>(ctx, stream, in, dtype, n, out, nullptr, nullptr, workspace, workspace_bytes, "mi355_reduce(mean)",
+                                                                 n ? (float)n : 1.f);
+    case MI355_REDUCE_MAX: return run_reduce<VOP_MAX, AOP_NONE>(ctx, stream, in, dtype, n, out, nullptr, nullptr, workspace, workspace_bytes, "mi355_reduce(max)");
+    case MI355_REDUCE_MIN: return run_reduce<VOP_MIN, AOP_NONE>(ctx, stream, in, dtype, n, out, nullptr, nullptr, workspace, workspace_bytes, "mi355_reduce(min)");
+    case MI355_REDUCE_PROD: return run_reduce<VOP_PROD, AOP_NONE>(ctx, stream, in, dtype, n, out, nullptr, nullptr, workspace, workspace_bytes, "mi355_reduce(prod)");
+    default: return ctx ? fail(ctx, MI355_E_UNSUPPORTED, "mi355_reduce: op %d is not a value reduction (SUM, MEAN, MAX, MIN, PROD)", op) : MI355_E_INVALID_ARGUMENT;
+    }
+}
+
+MI355_API int32_t mi355_argreduce(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, uint64_t n, int32_t op, float *out_val,
+                                  uint64_t *out_idx, void *workspace, uint64_t workspace_bytes)
+{
+    if (ctx && !out_idx && !out_val) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_argreduce: no output");
+    switch (op) {
+    case MI355_REDUCE_ARGMAX: return run_reduce<VOP_NONE, AOP_MAX>(ctx, stream, in, dtype, n, nullptr, out_val, out_idx, workspace, workspace_bytes, "mi355_argreduce(argmax)");
+    case MI355_REDUCE_ARGMIN: return run_reduce<VOP_NONE, AOP_MIN>(ctx, stream, in, dtype, n, nullptr, out_val, out_idx, workspace, workspace_bytes, "mi355_argreduce(argmin)");
+    default: return ctx ? fail(ctx, MI355_E_UNSUPPORTED, "mi355_argreduce: op %d is not an index reduction (ARGMAX, ARGMIN)", op) : MI355_E_INVALID_ARGUMENT;
+    }
+}
+
+MI355_API int32_t mi355_reduce_axis(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, int32_t op, float *out,
+                                    uint64_t outer, uint64_t reduce, uint64_t inner)
+{
+    if (!ctx) return MI355_E_INVALID_ARGUMENT;
+    switch (op) {
+    case MI355_REDUCE_SUM: return axis_dispatch_dtype<MI355_REDUCE_SUM>(ctx, stream, in, dtype, out, nullptr, outer, reduce, inner, "mi355_reduce_axis(sum)");
+    case MI355_REDUCE_MEAN: return axis_dispatch_dtype<MI355_REDUCE_MEAN>(ctx, stream, in, dtype, out, nullptr, outer, reduce, inner, "mi355_reduce_axis(mean)");
+    case MI355_REDUCE_MAX: return axis_dispatch_dtype<MI355_REDUCE_MAX>(ctx, stream, in, dtype, out, nullptr, outer, reduce, inner, "mi355_reduce_axis(max)");
+    case MI355_REDUCE_MIN: return axis_dispatch_dtype<MI355_REDUCE_MIN>(ctx, stream, in, dtype, out, nullptr, outer, reduce, inner, "mi355_reduce_axis(min)");
+    case MI355_REDUCE_PROD: return axis_dispatch_dtype<MI355_REDUCE_PROD>(ctx, stream, in, dtype, out, nullptr, outer, reduce, inner, "mi355_reduce_axis(prod)");
+    default: return fail(ctx, MI355_E_UNSUPPORTED, "mi355_reduce_axis: op %d is not a value reduction (SUM, MEAN, MAX, MIN, PROD)", op);
+    }
+}
+
+MI355_API int32_t mi355_argreduce_axis(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, int32_t op, uint32_t *out_idx,
+                                       uint64_t outer, uint64_t reduce, uint64_t inner)
+{
+    if (!ctx) return MI355_E_INVALID_ARGUMENT;
+    switch (op) {
+    case MI355_REDUCE_ARGMAX: return axis_dispatch_dtype<MI355_REDUCE_ARGMAX>(ctx, stream, in, dtype, nullptr, out_idx, outer, reduce, inner, "mi355_argreduce_axis(argmax)");
+    case MI355_REDUCE_ARGMIN: return axis_dispatch_dtype<MI355_REDUCE_ARGMIN>(ctx, stream, in, dtype, nullptr, out_idx, outer, reduce, inner, "mi355_argreduce_axis(argmin)");
+    default: return fail(ctx, MI355_E_UNSUPPORTED, "mi355_argreduce_axis: op %d is not an index reduction (ARGMAX, ARGMIN)", op);
     }
 }
 
@@ -832,8 +1011,8 @@ MI355_API int32_t mi355_plane_reduce_f32(mi355_ctx *ctx, mi355_stream stream, co
     if (!in || !out) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_plane_reduce_f32: NULL pointer");
     if (active == 0 || active > 64 || (active & (active - 1)) != 0)
         return fail(ctx, MI355_E_INVALID_ARGUMENT, "active lanes must be a power of two <= 64 (got %u)", active);
-    const bool known = op == MI355_REDUCE_SUM || op == MI355_REDUCE_MAX || op == MI355_REDUCE_MIN || op == 100 ||
-                       op == 101 || op == 102;
+    const bool known = op == MI355_REDUCE_SUM || op == MI355_REDUCE_MAX || op == MI355_REDUCE_MIN || op == MI355_REDUCE_PROD || op == 100 ||
+                       (op >= MI355_PLANE_INCLUSIVE_SUM && op <= MI355_PLANE_EXCLUSIVE_PROD);
     if (!known) return fail(ctx, MI355_E_UNSUPPORTED, "unknown plane op %d", op);
     const uint64_t blocks = (n + 63) / 64;
     if (blocks > 0x7FFFFFFFull) return fail(ctx, MI355_E_UNSUPPORTED, "too many planes");

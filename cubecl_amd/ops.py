@@ -251,6 +251,42 @@ def sum_argmax(client: ComputeClient, input: TensorHandle, out_sum: TensorHandle
         C.c_void_p(out_index.device_ptr()), C.c_void_p(ws.device_ptr()), ws.size))
 
 
+_VALUE_OPS = {"sum": N.REDUCE_SUM, "mean": N.REDUCE_MEAN, "max": N.REDUCE_MAX, "min": N.REDUCE_MIN, "prod": N.REDUCE_PROD}
+_INDEX_OPS = {"argmax": N.REDUCE_ARGMAX, "argmin": N.REDUCE_ARGMIN}
+
+
+def _op_code(op, table, what: str) -> int:
+    if isinstance(op, str):
+        if op not in table:
+            raise ServerError(N.E_UNSUPPORTED, f"{what}: unknown operation '{op}' (one of {sorted(table)})")
+        return table[op]
+    return int(op)
+
+
+def reduce(client: ComputeClient, input: TensorHandle, output: TensorHandle, op="sum") -> None:
+    """Array-wide value reduction into output[0] (f32): op = "sum" | "mean" | "max" | "min" | "prod" (or a MI355_REDUCE_* code).
+    max / min: NaN if any element is NaN, -0 < +0 (mi355_reduce, include/mi355cube.h)."""
+    input, n = _consumable(client, input, _require_flat_f32, "reduce")
+    ws = _workspace(client, n)
+    client._s.check(client.lib.mi355_reduce(client.ctx, client.on(input, output, ws), C.c_void_p(input.device_ptr()), int(input.dtype), n,
+                                            _op_code(op, _VALUE_OPS, "reduce"), C.c_void_p(output.device_ptr()), C.c_void_p(ws.device_ptr()), ws.size))
+
+
+def argreduce(client: ComputeClient, input: TensorHandle, out_index: TensorHandle, out_value: Optional[TensorHandle] = None,
+              op="argmax") -> None:
+    """Array-wide index reduction: op = "argmax" | "argmin"; out_index[0] (u64) = lowest index of the extremum, NaN wins, -0 == +0."""
+    input, n = _consumable(client, input, _require_flat_f32, "argreduce")
+    ws = _workspace(client, n)
+    client._s.check(client.lib.mi355_argreduce(
+        client.ctx, client.on(input, out_value, out_index, ws), C.c_void_p(input.device_ptr()), int(input.dtype), n, _op_code(op, _INDEX_OPS, "argreduce"),
+        C.c_void_p(out_value.device_ptr()) if out_value is not None else None,
+        C.c_void_p(out_index.device_ptr()), C.c_void_p(ws.device_ptr()), ws.size))
+
+
+def argmin(client: ComputeClient, input: TensorHandle, out_index: TensorHandle, out_value: Optional[TensorHandle] = None) -> None:
+    argreduce(client, input, out_index, out_value, "argmin")
+
+
 def argmax_combine(client: ComputeClient, records: Handle, count: int, index_base, out_value: Optional[Handle],
                    out_index: Optional[Handle]) -> None:
     """The combine step of the multi-GPU argmax on the device (mi355_argmax_combine_f32): folds `count` gathered records
@@ -327,8 +363,22 @@ def argmax_axis(client: ComputeClient, input: TensorHandle, output: TensorHandle
                                                         C.c_void_p(output.device_ptr()), outer, red, inner))
 
 
+def reduce_axis(client: ComputeClient, input: TensorHandle, output: TensorHandle, axis: int, op="sum") -> None:
+    """Value reduction over one axis (f32 out): op = "sum" | "mean" | "max" | "min" | "prod"; output shape = input shape minus that axis."""
+    input, (outer, red, inner) = _consumable(client, input, lambda t, w: _axis_view(t, axis, w), "reduce_axis")
+    client._s.check(client.lib.mi355_reduce_axis(client.ctx, client.on(input, output), C.c_void_p(input.device_ptr()), int(input.dtype),
+                                                 _op_code(op, _VALUE_OPS, "reduce_axis"), C.c_void_p(output.device_ptr()), outer, red, inner))
+
+
+def argreduce_axis(client: ComputeClient, input: TensorHandle, output: TensorHandle, axis: int, op="argmax") -> None:
+    """Index reduction over one axis (u32 indices along it): op = "argmax" | "argmin"; lowest index wins ties, NaN wins."""
+    input, (outer, red, inner) = _consumable(client, input, lambda t, w: _axis_view(t, axis, w), "argreduce_axis")
+    client._s.check(client.lib.mi355_argreduce_axis(client.ctx, client.on(input, output), C.c_void_p(input.device_ptr()), int(input.dtype),
+                                                    _op_code(op, _INDEX_OPS, "argreduce_axis"), C.c_void_p(output.device_ptr()), outer, red, inner))
+
+
 def plane_reduce(client: ComputeClient, input: TensorHandle, output: TensorHandle, op: int, active: int = 64) -> None:
-    """plane_sum / plane_prod / plane_max / plane_min / inclusive / exclusive sum over 64-lane planes."""
+    """plane_sum / plane_prod / plane_max / plane_min / inclusive / exclusive sum and product over 64-lane planes."""
     n = input.num_elems()
     client._s.check(client.lib.mi355_plane_reduce_f32(client.ctx, client.on(input, output), C.c_void_p(input.device_ptr()),
                                                       C.c_void_p(output.device_ptr()), n, active, op))

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define MI355_ABI_VERSION 6
+#define MI355_ABI_VERSION 7
 
 /* ---- status codes (map onto LaunchError / IoError / ServerError, server/base.rs:177-332,
  *      :884-1019; the Rust shim performs the conversion) ------------------------------- */
@@ -103,9 +103,15 @@ enum { MI355_ATOMIC_LOAD_STORE = 1, MI355_ATOMIC_EXCHANGE = 2, MI355_ATOMIC_ADD 
 enum { MI355_ADDRESS_TYPE_U32 = 1, MI355_ADDRESS_TYPE_U64 = 2 };   /* register_address_type (base.rs:323-324) */
 enum { MI355_LAYOUT_ROW_MAJOR = 0, MI355_LAYOUT_COL_MAJOR = 1 };   /* cmma::MatrixLayout */
 
-/* ReduceOperation (server/base.rs:623-628) + the two extra ops array-wide argmax needs.
- * Sum and Mean are the reference's; Max/Min are an API delta. */
-enum { MI355_REDUCE_SUM = 0, MI355_REDUCE_MEAN = 1, MI355_REDUCE_MAX = 2, MI355_REDUCE_MIN = 3 };
+/* ReduceOperation (server/base.rs:623-628) + the operations the reductions and the argmax exchange need beside it.
+ * Sum and Mean are the reference's; Max / Min / Prod are an API delta for the collectives (RCCL has all three)
+ * and the value reductions of mi355_reduce / mi355_reduce_axis; ArgMax / ArgMin exist only as local reductions
+ * (mi355_argreduce / mi355_argreduce_axis): mi355_all_reduce refuses them. */
+enum { MI355_REDUCE_SUM = 0, MI355_REDUCE_MEAN = 1, MI355_REDUCE_MAX = 2, MI355_REDUCE_MIN = 3, MI355_REDUCE_PROD = 4,
+       MI355_REDUCE_ARGMAX = 5, MI355_REDUCE_ARGMIN = 6 };
+/* scans of mi355_plane_reduce_f32 (plane_inclusive_sum / _exclusive_sum / _inclusive_prod / _exclusive_prod,
+ * crates/cubecl-core/src/frontend/plane.rs:242-283, :309, :334) */
+enum { MI355_PLANE_INCLUSIVE_SUM = 101, MI355_PLANE_EXCLUSIVE_SUM = 102, MI355_PLANE_INCLUSIVE_PROD = 103, MI355_PLANE_EXCLUSIVE_PROD = 104 };
 
 typedef struct mi355_ctx mi355_ctx;
 typedef void *mi355_stream;   /* hipStream_t; NULL = the context's compute stream */
@@ -520,10 +526,32 @@ int32_t mi355_reduce_axis_sum(mi355_ctx *ctx, mi355_stream stream, const void *i
                               uint64_t outer, uint64_t reduce, uint64_t inner);
 int32_t mi355_reduce_axis_argmax(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype,
                                  uint32_t *out_idx, uint64_t outer, uint64_t reduce, uint64_t inner);
+/* Every reduce operation over f32 / bf16 / f16 input (widened to f32 on load; f32 arithmetic, f32 values / integer indices out),
+ * array-wide and over any one axis of a contiguous [outer][reduce][inner] view -- the surface of cubek-reduce that the book's
+ * reduce_dim stands for (cubecl-book/src/getting-started/src/bin/v7-gpu.rs:59-77; plane-level forms
+ * crates/cubecl-core/src/frontend/plane.rs:218 sum, :285 prod, :352 max, :370 min; ReduceOperation::Mean
+ * crates/cubecl-runtime/src/server/base.rs:623-628).
+ *   SUM   as mi355_reduce_sum (fixed tree, deterministic)       MEAN  that sum / (f32)count  (count 0: 0 array-wide, NaN per axis)
+ *   PROD  f32 product in the same tree shape (identity 1)
+ *   MAX / MIN  IEEE maximum / minimum with -0 < +0; NaN if ANY element is NaN (numpy's max / min); empty: -inf / +inf
+ *   ARGMAX     as mi355_argmax: lowest index of the maximum, -0 == +0, NaN ranks above every number, first NaN wins
+ *   ARGMIN     its mirror image: lowest index of the minimum, -0 == +0, NaN ranks first, first NaN wins (numpy's argmin)
+ * mi355_reduce / mi355_argreduce take the workspace of mi355_reduce_workspace_bytes (one launch, records folded by the last
+ * workgroup); the axis forms need none.  argreduce: out_val = bit copy of the winning element; empty: index 0, -inf / +inf. */
+int32_t mi355_reduce(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, uint64_t n, int32_t op, float *out,
+                     void *workspace, uint64_t workspace_bytes);
+int32_t mi355_argreduce(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, uint64_t n, int32_t op, float *out_val,
+                        uint64_t *out_idx, void *workspace, uint64_t workspace_bytes);
+int32_t mi355_reduce_axis(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, int32_t op, float *out,
+                          uint64_t outer, uint64_t reduce, uint64_t inner);
+int32_t mi355_argreduce_axis(mi355_ctx *ctx, mi355_stream stream, const void *in, int32_t dtype, int32_t op, uint32_t *out_idx,
+                             uint64_t outer, uint64_t reduce, uint64_t inner);
 /* plane_sum & friends for one 64-lane plane per 64 inputs (frontend/plane.rs:218-240): every
  * lane receives the butterfly result over the first `active` lanes (power of two <= 64),
  * matching plane_dim_checked = min(PLANE_DIM, CUBE_DIM) (shared/plane.rs:55-58).
- * op = MI355_REDUCE_SUM / MAX / MIN, or 100 for product, 101 inclusive sum, 102 exclusive sum. */
+ * op = MI355_REDUCE_SUM / MAX / MIN / PROD (100 = PROD's round-1 code), or a scan: MI355_PLANE_INCLUSIVE_SUM / _EXCLUSIVE_SUM /
+ * _INCLUSIVE_PROD / _EXCLUSIVE_PROD (Hillis-Steele over shuffle_up, shared/plane.rs:72-97; lane 0 of an exclusive scan
+ * receives 0 / 1). */
 int32_t mi355_plane_reduce_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, float *out,
                                uint64_t n, uint32_t active, int32_t op);
 /* The remaining plane intrinsics at tensor level (crates/cubecl-core/src/frontend/plane.rs:62-216, :388-440; HIP lowering

@@ -55,6 +55,15 @@ def lib() -> C.CDLL:
     L.oracle_reduce_last_axis_sum_f64.restype = None
     L.oracle_argmax_f32.argtypes = [P, u64, C.POINTER(f32)]
     L.oracle_argmax_f32.restype = u64
+    L.oracle_argmin_f32.argtypes = [P, u64, C.POINTER(f32)]
+    L.oracle_argmin_f32.restype = u64
+    L.oracle_max_f32.argtypes = [P, u64]
+    L.oracle_max_f32.restype = f32
+    L.oracle_min_f32.argtypes = [P, u64]
+    L.oracle_min_f32.restype = f32
+    L.oracle_prod_f32_f64.argtypes = [P, u64]
+    L.oracle_prod_f32_f64.restype = C.c_double
+    L.oracle_plane_scan_f32.argtypes = [P, C.c_uint32, i32, i32]
     L.oracle_argmax_key.argtypes = [f32]
     L.oracle_argmax_key.restype = C.c_uint32
     L.oracle_reduce_last_axis_argmax_f32.argtypes = [P, P, u64, u64, u64]
@@ -247,6 +256,56 @@ def argmax(x: np.ndarray):
     val = C.c_float()
     idx = lib().oracle_argmax_f32(_p(x), x.size, C.byref(val))
     return int(idx), np.float32(val.value)
+
+
+def argmin(x: np.ndarray):
+    """(index, value) of the minimum: lowest index wins ties, -0 == +0, the first NaN wins (oracle_argmin_f32)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    val = C.c_float()
+    idx = lib().oracle_argmin_f32(_p(x), x.size, C.byref(val))
+    return int(idx), np.float32(val.value)
+
+
+def reduce_value(x: np.ndarray, op: str):
+    """Array-wide value reduction of mi355_reduce: "sum" / "mean" / "prod" in f64 (numerical oracle of the f32 tree), "max" /
+    "min" exact (NaN if any NaN, -0 < +0, empty: -inf / +inf)."""
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+    if op == "sum":
+        return float(lib().oracle_sum_f32_f64(_p(x), x.size))
+    if op == "mean":
+        return float(lib().oracle_sum_f32_f64(_p(x), x.size)) / float(np.float32(x.size)) if x.size else 0.0
+    if op == "prod":
+        return float(lib().oracle_prod_f32_f64(_p(x), x.size))
+    if op == "max":
+        return np.float32(lib().oracle_max_f32(_p(x), x.size))
+    if op == "min":
+        return np.float32(lib().oracle_min_f32(_p(x), x.size))
+    raise ValueError(op)
+
+
+def reduce_axis_value(x: np.ndarray, axis: int, op: str) -> np.ndarray:
+    """The same along one axis (rows of the moved axis through reduce_value; f64 for sum / mean / prod)."""
+    x = np.asarray(x, dtype=np.float32)
+    moved = np.ascontiguousarray(np.moveaxis(x, axis, -1))
+    rows = moved.reshape(-1, moved.shape[-1]) if moved.shape[-1] else moved.reshape(-1, 0)
+    out = np.array([reduce_value(r, op) for r in rows], dtype=np.float32 if op in ("max", "min") else np.float64)
+    if op == "mean" and moved.shape[-1] == 0:
+        out[:] = np.nan
+    return out.reshape(moved.shape[:-1])
+
+
+def reduce_axis_argmin(x: np.ndarray, axis: int) -> np.ndarray:
+    x = np.asarray(x, dtype=np.float32)
+    moved = np.ascontiguousarray(np.moveaxis(x, axis, -1))
+    rows = moved.reshape(-1, moved.shape[-1])
+    return np.array([argmin(r)[0] for r in rows], dtype=np.uint32).reshape(moved.shape[:-1])
+
+
+def plane_scan(vals: np.ndarray, mul: bool, exclusive: bool) -> np.ndarray:
+    """plane_inclusive / exclusive sum / prod over ONE plane of len(vals) lanes (oracle_plane_scan_f32)."""
+    v = np.ascontiguousarray(vals, dtype=np.float32).copy()
+    lib().oracle_plane_scan_f32(_p(v), v.size, int(mul), int(exclusive))
+    return v
 
 
 def reduce_last_axis_sum(x: np.ndarray, f64: bool = False) -> np.ndarray:

@@ -426,6 +426,53 @@ ORACLE_API uint64_t oracle_argmax_f32(const float *x, uint64_t n, float *out_val
     return best;
 }
 
+/* Argmin: the mirror image (review of round 3, missing #3) -- the minimum under IEEE comparison, lowest index among equal
+ * minima, -0.0 == +0.0, NaN ranks FIRST with the first NaN winning (numpy's argmin).  The device mirrors the key (~key) and
+ * keeps the NaN code on top (cubecl_amd/csrc/reduce.hip arg_key<AOP_MIN>); restated here without the key trick.
+ * n == 0 -> index 0 and +inf. */
+ORACLE_API uint64_t oracle_argmin_f32(const float *x, uint64_t n, float *out_val)
+{
+    if (n == 0) { if (out_val) *out_val = INFINITY; return 0; }
+    uint64_t best = 0;
+    int best_nan = x[0] != x[0];
+    for (uint64_t i = 1; i < n && !best_nan; ++i) {
+        if (x[i] != x[i]) { best = i; best_nan = 1; }
+        else if (x[i] < x[best]) best = i;               /* strict: equal values (and -0 vs +0) keep the lower index */
+    }
+    if (out_val) *out_val = x[best];
+    return best;
+}
+
+/* Value reductions max / min (mi355_reduce, mi355_reduce_axis): the IEEE maximum / minimum with -0 < +0, NaN if ANY element is
+ * NaN (numpy's max / min); empty input gives the identity -inf / +inf.  Restates plane_max / plane_min
+ * (crates/cubecl-core/src/frontend/plane.rs:352, :370) over a whole array with the NaN rule made explicit (the plane forms
+ * lower to max(a, b) / min(a, b), whose NaN behaviour the reference does not pin). */
+ORACLE_API float oracle_max_f32(const float *x, uint64_t n)
+{
+    float m = -INFINITY;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (x[i] != x[i]) return bits_f32(0x7FC00000u);
+        if (x[i] > m || (x[i] == m && f32_bits(m) == 0x80000000u)) m = x[i];      /* +0 beats -0 */
+    }
+    return m;
+}
+ORACLE_API float oracle_min_f32(const float *x, uint64_t n)
+{
+    float m = INFINITY;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (x[i] != x[i]) return bits_f32(0x7FC00000u);
+        if (x[i] < m || (x[i] == m && f32_bits(x[i]) == 0x80000000u)) m = x[i];   /* -0 beats +0 */
+    }
+    return m;
+}
+/* product in f64 (the numerical oracle of MI355_REDUCE_PROD: the device multiplies in f32 in its summation tree's shape) */
+ORACLE_API double oracle_prod_f32_f64(const float *x, uint64_t n)
+{
+    double p = 1.0;
+    for (uint64_t i = 0; i < n; ++i) p *= (double)x[i];
+    return p;
+}
+
 ORACLE_API void oracle_reduce_last_axis_argmax_f32(const float *in, uint32_t *out_idx,
                                                    uint64_t rows, uint64_t cols,
                                                    uint64_t row_stride)
@@ -464,6 +511,25 @@ ORACLE_API void oracle_plane_inclusive_sum_f32(float *vals, uint32_t width)
         for (uint32_t l = 0; l < width; ++l)
             tmp[l] = (l >= off) ? vals[l] + vals[l - off] : vals[l];
         memcpy(vals, tmp, width * sizeof(float));
+    }
+}
+/* plane_inclusive_sum / _prod and plane_exclusive_sum / _prod (crates/cubecl-core/src/frontend/plane.rs:242-283, :309, :334) as
+ * the HIP backend lowers them: plane_reduce_inclusive with OpAdd / OpMul, and plane_reduce_exclusive = the inclusive scan
+ * shuffled up by one lane with lane 0 taking the default 0 / 1 (crates/cubecl-cpp/src/shared/plane.rs:72-97, :128-136). */
+ORACLE_API void oracle_plane_scan_f32(float *vals, uint32_t width, int mul, int exclusive)
+{
+    float tmp[1024];
+    if (width > 1024 || width == 0) return;
+    for (uint32_t off = 1; off < width; off *= 2) {
+        for (uint32_t l = 0; l < width; ++l) {
+            const float up = (l >= off) ? vals[l - off] : vals[l];
+            tmp[l] = (l >= off) ? (mul ? vals[l] * up : vals[l] + up) : vals[l];
+        }
+        memcpy(vals, tmp, width * sizeof(float));
+    }
+    if (exclusive) {
+        for (uint32_t l = width - 1; l > 0; --l) vals[l] = vals[l - 1];
+        vals[0] = mul ? 1.0f : 0.0f;
     }
 }
 

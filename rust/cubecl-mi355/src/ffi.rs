@@ -6,7 +6,7 @@ use core::ffi::{c_char, c_void};
 
 /// `MI355_ABI_VERSION` of the header these declarations were written against; `Mi355Runtime` compares it with what the
 /// loaded library reports (`mi355_device_props_t::abi_version`).
-pub const MI355_ABI_VERSION: u32 = 6;
+pub const MI355_ABI_VERSION: u32 = 7;
 
 pub const MI355_OK: i32 = 0;
 pub const MI355_E_INVALID_ARGUMENT: i32 = 1;
@@ -65,6 +65,11 @@ pub const MI355_ALLOC_MODE_PERSISTENT: i32 = 1;
 
 pub const MI355_REDUCE_SUM: i32 = 0;
 pub const MI355_REDUCE_MEAN: i32 = 1;
+pub const MI355_REDUCE_MAX: i32 = 2;
+pub const MI355_REDUCE_MIN: i32 = 3;
+pub const MI355_REDUCE_PROD: i32 = 4;
+pub const MI355_REDUCE_ARGMAX: i32 = 5;
+pub const MI355_REDUCE_ARGMIN: i32 = 6;
 pub const MI355_UNIQUE_ID_BYTES: usize = 128;
 
 #[repr(C)]
@@ -345,6 +350,15 @@ unsafe extern "C" {
                                  outer: u64, reduce: u64, inner: u64) -> i32;
     pub fn mi355_reduce_axis_argmax(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const c_void, dtype: i32, out_idx: *mut u32,
                                     outer: u64, reduce: u64, inner: u64) -> i32;
+    // every reduce operation (sum / mean / max / min / prod values, argmax / argmin indices), array-wide and over one axis
+    pub fn mi355_reduce(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const c_void, dtype: i32, n: u64, op: i32, out: *mut f32,
+                        workspace: *mut c_void, workspace_bytes: u64) -> i32;
+    pub fn mi355_argreduce(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const c_void, dtype: i32, n: u64, op: i32, out_val: *mut f32,
+                           out_idx: *mut u64, workspace: *mut c_void, workspace_bytes: u64) -> i32;
+    pub fn mi355_reduce_axis(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const c_void, dtype: i32, op: i32, out: *mut f32,
+                             outer: u64, reduce: u64, inner: u64) -> i32;
+    pub fn mi355_argreduce_axis(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const c_void, dtype: i32, op: i32, out_idx: *mut u32,
+                                outer: u64, reduce: u64, inner: u64) -> i32;
     // reductions over any axis, plane ops
     pub fn mi355_reduce_axis_sum_f32(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const f32, out: *mut f32, outer: u64,
                                      reduce: u64, inner: u64) -> i32;

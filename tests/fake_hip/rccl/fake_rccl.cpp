@@ -43,7 +43,7 @@ template <typename T> void reduce_typed(group &g, size_t n, int op)
         T acc = static_cast<const T *>(g.reduce[0].send)[i];
         for (int r = 1; r < g.nranks; ++r) {
             const T v = static_cast<const T *>(g.reduce[r].send)[i];
-            acc = op == 2 ? (v > acc ? v : acc) : op == 3 ? (v < acc ? v : acc) : (T)(acc + v);     // max, min, sum / avg
+            acc = op == 2 ? (v > acc ? v : acc) : op == 3 ? (v < acc ? v : acc) : op == 1 ? (T)(acc * v) : (T)(acc + v);     // max, min, prod, sum / avg
         }
         out[i] = op == 4 ? (T)(acc / (T)g.nranks) : acc;
     }

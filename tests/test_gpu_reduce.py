@@ -474,3 +474,243 @@ def test_remaining_plane_intrinsics_match_the_oracle_and_the_reference_vectors(c
         ops.plane_op(client, te, oe, N.PLANE_SHUFFLE, plane=plane, arg=plane)          # source lane outside the plane
     with pytest.raises(ServerError):
         ops.plane_op(client, te, oe, N.PLANE_ALL, plane=48)
+
+
+# ---- round 4: every reduce operation (max / min / mean / prod values, argmin) and the product scans ----------------------------------
+VALUE_OPS = ["sum", "mean", "max", "min", "prod"]
+
+
+def _value_check(oracle, got, vals, op):
+    """One f32 result of a value reduction over `vals` against the oracle: max / min bit for bit; sum / mean within 1e-5 of
+    sum|x| (/ n); prod within (n + 16) ulp-ish relative steps of the f64 product (each f32 multiply rounds once)."""
+    want = oracle.reduce_value(vals, op)
+    if op in ("max", "min"):
+        assert np.float32(got).view(np.uint32) == np.float32(want).view(np.uint32), (op, got, want)
+    elif op == "prod":
+        n = vals.size
+        assert abs(float(got) - want) <= (n + 16) * 6e-8 * abs(want) + 1e-38, (op, got, want)
+    else:
+        scale = oracle.sum_abs_f64(vals) / (vals.size if (op == "mean" and vals.size) else 1)
+        assert abs(float(got) - want) <= REL * scale + 1e-38, (op, got, want)
+
+
+@pytest.mark.parametrize("dtype", [ElemType.F32, ElemType.BF16, ElemType.F16])
+@pytest.mark.parametrize("n", [0, 1, 3, 7, 65, 4099, 8192, 100_003, (1 << 20) + 13, 5_000_011])
+def test_array_wide_value_reductions_and_argmin_match_the_oracle(client, oracle, dtype, n):
+    """mi355_reduce (sum / mean / max / min / prod) and mi355_argreduce (argmax / argmin) for every input type at sizes around the
+    kernel's tile (8 192 f32 / 16 384 16-bit elements), a ragged tail and a peeled head; products over values near 1 so that
+    5 M factors stay in range (as the reference's plane_prod tests keep theirs, runtime_tests/plane.rs:326-331)."""
+    raw = oracle.fill_uniform(n, 61, -1.0, 1.0)
+    near_one = (1.0 + oracle.fill_uniform(n, 62, -1.0, 1.0) * np.float32(2.0 ** -9)).astype(np.float32)
+    out, idx, val = _scalar(client, ElemType.F32), _scalar(client, ElemType.U64), _scalar(client, ElemType.F32)
+    for op in VALUE_OPS:
+        host = near_one if op == "prod" else raw
+        if dtype == ElemType.F32:
+            bits, vals = host, host
+        else:
+            conv, back = (oracle.to_bf16, oracle.from_bf16) if dtype == ElemType.BF16 else (oracle.to_f16, oracle.from_f16)
+            bits = conv(host)
+            vals = back(bits)
+        t = TensorHandle.from_numpy(client, bits, dtype) if n else TensorHandle.new_contiguous((0,), client.empty(0), dtype)
+        ops.reduce(client, t, out, op)
+        _value_check(oracle, out.to_numpy(client)[0], vals, op)
+        if op == "sum":                                            # the generic entry point runs the tuned sum kernel: same bits
+            o2 = _scalar(client, ElemType.F32)
+            ops.reduce_sum(client, t, o2)
+            assert o2.to_numpy(client).view(np.uint32)[0] == out.to_numpy(client).view(np.uint32)[0]
+        if op == "min":
+            ops.argmin(client, t, idx, val)
+            ri, rv = oracle.argmin(vals)
+            assert int(idx.to_numpy(client)[0]) == ri and val.to_numpy(client).view(np.uint32)[0] == np.float32(rv).view(np.uint32)
+            if n:
+                assert float(val.to_numpy(client)[0]) == float(out.to_numpy(client)[0])          # min == x[argmin] (no NaN, no zero tie here)
+            ops.argreduce(client, t, idx, val, "argmax")
+            assert int(idx.to_numpy(client)[0]) == oracle.argmax(vals)[0]
+
+
+def test_value_reduction_rules_nan_signed_zero_misaligned_and_bad_ops(client, oracle):
+    import ctypes as C
+    n = 200_003
+    x = oracle.fill_uniform(n, 63, 0.5, 2.0)
+    out, idx, val = _scalar(client, ElemType.F32), _scalar(client, ElemType.U64), _scalar(client, ElemType.F32)
+    # planted extrema, twice each: the lower index wins the index reductions
+    x[150_001] = x[77] = 0.25
+    x[199_999] = x[4097] = 3.0
+    t = TensorHandle.from_numpy(client, x)
+    ops.argmin(client, t, idx, val)
+    assert int(idx.to_numpy(client)[0]) == 77 and float(val.to_numpy(client)[0]) == 0.25
+    ops.reduce(client, t, out, "max")
+    assert float(out.to_numpy(client)[0]) == 3.0
+    ops.reduce(client, t, out, "min")
+    assert float(out.to_numpy(client)[0]) == 0.25
+    # signed zeros: as values -0 < +0; as indices they tie and the lowest index wins
+    z = np.zeros(70_001, dtype=np.float32)
+    z[5::7] = -0.0
+    tz = TensorHandle.from_numpy(client, z)
+    ops.reduce(client, tz, out, "max")
+    assert out.to_numpy(client).view(np.uint32)[0] == 0x00000000
+    ops.reduce(client, tz, out, "min")
+    assert out.to_numpy(client).view(np.uint32)[0] == 0x80000000
+    ops.argmin(client, tz, idx, val)
+    assert int(idx.to_numpy(client)[0]) == 0
+    # NaN: max / min turn NaN wherever it sits (vector body, ragged tail, peeled head); argmin takes the FIRST NaN
+    for pos in (123, 8192 * 3 + 17, n - 1):
+        y = x.copy()
+        y[pos] = np.float32("nan")
+        y[min(pos + 1000, n - 1)] = np.float32("nan") if pos + 1000 < n else y[n - 1]
+        ty = TensorHandle.from_numpy(client, y)
+        for op in ("max", "min"):
+            ops.reduce(client, ty, out, op)
+            assert out.to_numpy(client).view(np.uint32)[0] == 0x7FC00000, (pos, op)
+        ops.argmin(client, ty, idx, val)
+        assert int(idx.to_numpy(client)[0]) == pos and np.isnan(val.to_numpy(client)[0])
+        for op in ("sum", "prod"):                                 # ... and sum / prod carry it like any arithmetic does
+            ops.reduce(client, ty, out, op)
+            assert np.isnan(out.to_numpy(client)[0])
+    # a view that starts 4 bytes into a 16-byte line (peeled head of three elements) and ends ragged
+    base = TensorHandle.from_numpy(client, x)
+    view = TensorHandle.new_contiguous((n - 6,), base.handle.offset_start_by(4).offset_end_by(20), ElemType.F32)
+    for op in VALUE_OPS:
+        if op == "prod":
+            continue
+        ops.reduce(client, view, out, op)
+        _value_check(oracle, out.to_numpy(client)[0], x[1:n - 5], op)
+    ops.argmin(client, view, idx, val)
+    assert int(idx.to_numpy(client)[0]) == oracle.argmin(x[1:n - 5])[0]
+    # determinism: the same tree every launch
+    ops.reduce(client, t, out, "prod")
+    first = out.to_numpy(client).view(np.uint32)[0]
+    for _ in range(3):
+        ops.reduce(client, t, out, "prod")
+        assert out.to_numpy(client).view(np.uint32)[0] == first
+    # operation codes are checked: an index operation is not a value reduction and the other way round
+    ws = ops._workspace(client, n)
+    for fn, bad in ((client.lib.mi355_reduce, N.REDUCE_ARGMIN), (client.lib.mi355_reduce, 99)):
+        rc = fn(client.ctx, None, C.c_void_p(t.device_ptr()), N.DTYPE_F32, n, bad, C.c_void_p(out.device_ptr()), C.c_void_p(ws.device_ptr()), ws.size)
+        assert rc == N.E_UNSUPPORTED
+    rc = client.lib.mi355_argreduce(client.ctx, None, C.c_void_p(t.device_ptr()), N.DTYPE_F32, n, N.REDUCE_MAX, C.c_void_p(val.device_ptr()),
+                                    C.c_void_p(idx.device_ptr()), C.c_void_p(ws.device_ptr()), ws.size)
+    assert rc == N.E_UNSUPPORTED
+    with pytest.raises(ServerError):
+        ops.reduce(client, t, out, "median")
+
+
+@pytest.mark.parametrize("dtype", [ElemType.F32, ElemType.BF16])
+@pytest.mark.parametrize("shape,axis", [((512, 8192), 1), ((128, 32768), 1), ((64, 256, 1024), 2), ((64, 64, 4096), 2),      # the book's shapes
+                                        ((64, 256, 1024), 1), ((64, 256, 1024), 0), ((512, 8192), 0), ((3, 1000, 7), 1), ((1, 5, 1), 1),
+                                        ((2048, 33), 0), ((37, 1001), -1), ((5, 4, 3, 2), 2), ((1, 200_003), 1), ((1000, 1), 1)])
+def test_every_reduce_operation_over_any_axis(client, oracle, dtype, shape, axis):
+    """mi355_reduce_axis / mi355_argreduce_axis over the book's shapes (cubecl-book/src/getting-started/src/bin/v7-gpu.rs:59-77)
+    and the shapes of the sum / argmax axis tests: last axis (one wave / one workgroup per row), middle and first axis."""
+    n = int(np.prod(shape))
+    raw = oracle.fill_uniform(n, 64, -1.0, 1.0).reshape(shape)
+    near_one = (1.0 + oracle.fill_uniform(n, 65, -1.0, 1.0) * np.float32(2.0 ** -9)).astype(np.float32).reshape(shape)
+    ax = axis % len(shape)
+    out_shape = tuple(d for i, d in enumerate(shape) if i != ax)
+    m = int(np.prod(out_shape)) if out_shape else 1
+    o = TensorHandle.new_contiguous(out_shape or (1,), client.empty(max(m, 1) * 4), ElemType.F32)
+    oi = TensorHandle.new_contiguous(out_shape or (1,), client.empty(max(m, 1) * 4), ElemType.U32)
+    for op in VALUE_OPS:
+        host = near_one if op == "prod" else raw
+        if dtype == ElemType.F32:
+            bits, vals = host, host
+        else:
+            bits = oracle.to_bf16(host.reshape(-1)).reshape(shape)
+            vals = oracle.from_bf16(bits.reshape(-1)).reshape(shape)
+        t = TensorHandle.from_numpy(client, bits, dtype)
+        ops.reduce_axis(client, t, o, axis, op)
+        got = o.to_numpy(client).reshape(out_shape or (1,))
+        want = oracle.reduce_axis_value(vals, ax, op).reshape(out_shape or (1,))
+        if op in ("max", "min"):
+            assert np.array_equal(got.view(np.uint32), want.astype(np.float32).view(np.uint32)), op
+        elif op == "prod":
+            assert np.all(np.abs(got.astype(np.float64) - want) <= (shape[ax] + 16) * 6e-8 * np.abs(want) + 1e-38), op
+        else:
+            bound = np.abs(vals).astype(np.float64).sum(axis=ax) / (shape[ax] if op == "mean" else 1)
+            assert np.all(np.abs(got.astype(np.float64) - want) <= REL * bound.reshape(got.shape) + 1e-30), op
+        if op == "sum":                                            # the generic entry point and the sum entry point agree bit for bit
+            o2 = TensorHandle.new_contiguous(out_shape or (1,), client.empty(max(m, 1) * 4), ElemType.F32)
+            ops.reduce_sum_axis(client, t, o2, axis)
+            assert np.array_equal(o2.to_numpy(client).view(np.uint32), o.to_numpy(client).view(np.uint32))
+        if op == "min":
+            ops.argreduce_axis(client, t, oi, axis, "argmin")
+            assert np.array_equal(oi.to_numpy(client).reshape(out_shape or (1,)), oracle.reduce_axis_argmin(vals, ax).reshape(out_shape or (1,)))
+            ops.argreduce_axis(client, t, oi, axis, "argmax")
+            assert np.array_equal(oi.to_numpy(client).reshape(out_shape or (1,)), oracle.reduce_axis_argmax(vals, ax).reshape(out_shape or (1,)))
+
+
+def test_axis_value_rules_nan_ties_and_zero(client, oracle):
+    x = np.ones((4, 6, 5), dtype=np.float32)
+    x[:, 2, :] = -3.0
+    x[:, 4, :] = -3.0                     # tie along axis 1: index 2 wins argmin
+    x[1, 5, 3] = np.float32("nan")
+    x[2, 0, 0] = np.float32("nan")
+    x[2, 3, 0] = np.float32("nan")        # first NaN wins
+    x[3, :, 1] = 0.0
+    x[3, 1, 1] = -0.0
+    t = TensorHandle.from_numpy(client, x)
+    a = TensorHandle.new_contiguous((4, 5), client.empty(80), ElemType.U32)
+    o = TensorHandle.new_contiguous((4, 5), client.empty(80), ElemType.F32)
+    for axis in (1, 0, 2):
+        shp = tuple(d for i, d in enumerate(x.shape) if i != axis)
+        ops.argreduce_axis(client, t, a, axis, "argmin")
+        assert np.array_equal(a.to_numpy(client)[: int(np.prod(shp))].reshape(shp), oracle.reduce_axis_argmin(x, axis))
+        for op in ("max", "min"):
+            ops.reduce_axis(client, t, o, axis, op)
+            got = o.to_numpy(client)[: int(np.prod(shp))].reshape(shp)
+            assert np.array_equal(got.view(np.uint32), oracle.reduce_axis_value(x, axis, op).astype(np.float32).view(np.uint32)), (axis, op)
+    ops.argreduce_axis(client, t, a, 1, "argmin")
+    got = a.to_numpy(client).reshape(4, 5)
+    assert got[0, 0] == 2 and got[1, 3] == 5 and got[2, 0] == 0 and got[3, 1] == 2
+    with pytest.raises(ServerError):
+        ops.reduce_axis(client, t, o, 1, "argmin")                 # not a value operation
+
+
+@pytest.mark.parametrize("vec", [1, 2, 4])
+def test_plane_product_scans_reference_vectors(client, oracle, vec):
+    """test_plane_inclusive_prod / test_plane_exclusive_prod (runtime_tests/plane.rs:317-407): plane_size 32 on this wave64 device,
+    inputs 0.5 / 1.25 / 1.75 by x % 3; the device's Hillis-Steele scan equals the oracle's restatement of
+    plane_reduce_inclusive / _exclusive (shared/plane.rs:72-97) bit for bit and the reference's sequential expectation within its
+    own tolerance.  Then 64 active lanes, and PROD through its new code."""
+    plane = 32
+    x = np.array([(0.5, 1.25, 1.75)[i % 3] for i in range(plane * vec)], dtype=np.float32).reshape(plane, vec)
+    for v in range(vec):
+        col = np.ones(64, dtype=np.float32)
+        col[:32] = x[:, v]
+        t = TensorHandle.from_numpy(client, col)
+        out = TensorHandle.new_contiguous((64,), client.empty(256), ElemType.F32)
+        exp_inc = np.cumprod(x[:, v].astype(np.float64))
+        for op, excl in ((N.PLANE_INCLUSIVE_PROD, False), (N.PLANE_EXCLUSIVE_PROD, True)):
+            ops.plane_reduce(client, t, out, op, active=32)
+            got = out.to_numpy(client)[:32]
+            assert np.array_equal(got.view(np.uint32), oracle.plane_scan(x[:, v], True, excl).view(np.uint32))
+            expected = np.concatenate([[1.0], exp_inc[:-1]]) if excl else exp_inc
+            assert np.all(np.abs(got - expected) <= 1e-5 * np.maximum(np.abs(expected), 1.0))
+    y = (1.0 + oracle.fill_uniform(64 * 9, 66, -1.0, 1.0) * np.float32(0.25)).astype(np.float32)
+    t = TensorHandle.from_numpy(client, y)
+    out = TensorHandle.new_contiguous((y.size,), client.empty(y.size * 4), ElemType.F32)
+    for op, mul, excl in ((N.PLANE_INCLUSIVE_PROD, True, False), (N.PLANE_EXCLUSIVE_PROD, True, True), (N.PLANE_INCLUSIVE_SUM, False, False),
+                          (N.PLANE_EXCLUSIVE_SUM, False, True)):
+        ops.plane_reduce(client, t, out, op, active=64)
+        got = out.to_numpy(client).reshape(9, 64)
+        for p in range(9):
+            assert np.array_equal(got[p].view(np.uint32), oracle.plane_scan(y[p * 64:(p + 1) * 64], mul, excl).view(np.uint32)), (op, p)
+    ops.plane_reduce(client, t, out, N.REDUCE_PROD, active=64)
+    a = out.to_numpy(client).copy()
+    ops.plane_reduce(client, t, out, N.PLANE_PROD, active=64)                    # the round-1 code of the same operation
+    assert np.array_equal(a.view(np.uint32), out.to_numpy(client).view(np.uint32))
+    assert np.array_equal(a[:64].view(np.uint32), oracle.plane_reduce(y[:64], 1).view(np.uint32))
+
+
+def test_plane_shuffles_with_a_delta_of_a_plane_or_more_keep_their_own_value(client, oracle):
+    """advisor, round 3: SHUFFLE_UP / _DOWN hand the delta to __shfl_up / __shfl_down, whose index arithmetic is signed -- a delta of
+    2^31 or more wrapped and read a neighbour.  A delta (XOR: a mask) that leaves the plane has no source lane: own value."""
+    for plane in (32, 64):
+        x = np.arange(3 * plane, dtype=np.float32) + 1.0
+        t = TensorHandle.from_numpy(client, x)
+        out = TensorHandle.new_contiguous((x.size,), client.empty(x.size * 4), ElemType.F32)
+        for op in (N.PLANE_SHUFFLE_UP, N.PLANE_SHUFFLE_DOWN, N.PLANE_SHUFFLE_XOR):
+            for arg in (plane, plane + 1, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFF):
+                ops.plane_op(client, t, out, op, plane=plane, arg=arg)
+                assert np.array_equal(out.to_numpy(client), x), (plane, op, arg)
+                assert np.array_equal(oracle.plane_op(x, op, plane, arg), x)

@@ -276,6 +276,87 @@ def test_plane_ops_butterfly(oracle):
     assert inc.tolist() == np.cumsum(np.arange(32)).astype(np.float32).tolist()  # plane.rs:192-230
 
 
+@pytest.mark.parametrize("vec", [1, 2, 4])
+def test_plane_prod_scans_reproduce_the_reference_tests_expectations(oracle, vec):
+    """test_plane_inclusive_prod / test_plane_exclusive_prod (crates/cubecl-core/src/runtime_tests/plane.rs:317-407) restated:
+    plane_size 32, input x % 3 -> 0.5 / 1.25 / 1.75, expected[k] = product of the inputs of the units to the left (inclusive:
+    and its own; exclusive: unit 0 holds 1), per vector component; the reference compares with 1e-5 x max(|e|, 1) scaled to the
+    dtype's epsilon (:852-880).  And the two doc examples of frontend/plane.rs:304, :329."""
+    plane = 32
+    x = np.array([(0.5, 1.25, 1.75)[i % 3] for i in range(plane * vec)], dtype=np.float32).reshape(plane, vec)
+    for v in range(vec):
+        inc_expected = x[:, v].astype(np.float32).copy()
+        exc_expected = np.ones(plane, dtype=np.float32)
+        for k in range(1, plane):                              # the reference test's own (sequential, f32) loops
+            for k1 in range(k):
+                inc_expected[k] = np.float32(inc_expected[k] * x[k1, v])
+                exc_expected[k] = np.float32(exc_expected[k] * x[k1, v])
+        inc = oracle.plane_scan(x[:, v], mul=True, exclusive=False)
+        exc = oracle.plane_scan(x[:, v], mul=True, exclusive=True)
+        assert np.all(np.abs(inc - inc_expected) <= 1e-5 * np.maximum(np.abs(inc_expected), 1.0))
+        assert np.all(np.abs(exc - exc_expected) <= 1e-5 * np.maximum(np.abs(exc_expected), 1.0))
+        assert exc[0] == 1.0 and np.array_equal(exc[1:], inc[:-1])            # plane_reduce_exclusive = inclusive shuffled up (shared/plane.rs:89-97)
+    assert oracle.plane_scan(np.arange(1, 6), True, False).tolist() == [1, 2, 6, 24, 120]
+    assert oracle.plane_scan(np.arange(1, 6), True, True).tolist() == [1, 1, 2, 6, 24]
+    assert oracle.plane_scan(np.arange(32), False, False).tolist() == oracle.plane_inclusive_sum(np.arange(32, dtype=np.float32)).tolist()
+    assert oracle.plane_scan(np.arange(1, 6), False, True).tolist() == [0, 1, 3, 6, 10]
+
+
+def test_value_and_argmin_rules(oracle):
+    """The rules of mi355_reduce / mi355_argreduce (include/mi355cube.h): max / min propagate NaN and order -0 below +0; argmin
+    mirrors argmax (lowest index, -0 == +0, first NaN wins); test_plane_max / _min's vectors (runtime_tests/plane.rs:409-487:
+    0..32 with element 16 set to 999 / -5)."""
+    x = np.arange(32, dtype=np.float32)
+    x[16] = 999.0
+    assert oracle.reduce_value(x, "max") == 999.0 and oracle.plane_reduce(x, 2)[0] == 999.0
+    x[16] = -5.0
+    assert oracle.reduce_value(x, "min") == -5.0 and oracle.plane_reduce(x, 3)[0] == -5.0
+    y = np.array([3.0, -0.0, 0.0, -7.0, 3.0, -7.0], dtype=np.float32)
+    assert oracle.argmin(y) == (3, np.float32(-7.0)) and oracle.argmax(y)[0] == 0
+    z = np.array([0.0, -0.0, 0.0], dtype=np.float32)
+    assert oracle.argmin(z)[0] == 0 and oracle.argmax(z)[0] == 0                       # -0 == +0: the lowest index
+    assert not np.signbit(oracle.reduce_value(z, "max")) and np.signbit(oracle.reduce_value(z, "min"))   # as values: -0 < +0
+    w = np.array([1.0, np.nan, -5.0, np.nan], dtype=np.float32)
+    assert oracle.argmin(w)[0] == 1 and oracle.argmax(w)[0] == 1                       # the first NaN wins both
+    assert np.isnan(oracle.reduce_value(w, "max")) and np.isnan(oracle.reduce_value(w, "min"))
+    e = np.zeros(0, dtype=np.float32)
+    assert oracle.reduce_value(e, "max") == -np.inf and oracle.reduce_value(e, "min") == np.inf
+    assert oracle.argmin(e) == (0, np.float32(np.inf)) and oracle.reduce_value(e, "prod") == 1.0 and oracle.reduce_value(e, "mean") == 0.0
+    m = np.arange(24, dtype=np.float32).reshape(2, 3, 4)
+    assert oracle.reduce_axis_value(m, 1, "mean").tolist() == m.astype(np.float64).mean(axis=1).tolist()
+    assert oracle.reduce_axis_value(m, 2, "prod")[0].tolist() == [0.0, 840.0, 7920.0]
+    assert oracle.reduce_axis_argmin(m, 0).tolist() == np.zeros((3, 4)).tolist()
+    assert oracle.reduce_axis_value(-m, 1, "max").tolist() == (-m).max(axis=1).tolist()
+
+
+def test_fast_division_by_launch_constants_is_exact():
+    """cubecl_amd/csrc/gemm_common.hpp make_fdiv / fdiv: tile indices are divided by launch constants as
+    q = umulhi(n, ceil(2^(31 + l) / d)) >> (l - 1), l = ceil(log2 d) (d = 1: the value itself) -- exact for every n < 2^31.
+    The formula restated on integers: every divisor up to 4 096 and a spread of larger ones against the n where a rounded-up
+    multiplier could first go wrong (multiples of d and their neighbours, the top of the range)."""
+    def make(d):
+        if d <= 1:
+            return 0, 0
+        l = (d - 1).bit_length()
+        mul = ((1 << (31 + l)) + d - 1) // d
+        assert mul < 1 << 32
+        return mul, l - 1
+
+    def q(n, mul, shift):
+        return ((n * mul) >> 32) >> shift if mul else n
+    rng = np.random.default_rng(7)
+    divisors = list(range(1, 4097)) + [int(v) for v in rng.integers(4097, 1 << 31, 600)] + [(1 << 31) - 1, 1 << 30, (1 << 30) + 1, 65535, 65536, 65537]
+    top = (1 << 31) - 1
+    for d in divisors:
+        mul, shift = make(d)
+        ns = {0, 1, d - 1, d, d + 1, top, top - 1, top - d, (top // d) * d, (top // d) * d - 1}
+        ns |= {int(v) for v in rng.integers(0, top, 24)}
+        ns |= {k * d + e for k in (2, 3, 1000, top // d // 2) for e in (-1, 0, 1)}
+        for n in ns:
+            if 0 <= n <= top:
+                assert q(n, mul, shift) == n // d, (n, d)
+
+
 def test_argmax_rules(oracle):
     x = np.array([1.0, 7.0, 3.0, 7.0, -2.0], dtype=np.float32)
     assert oracle.argmax(x) == (1, np.float32(7.0))            # lowest index among equal maxima
