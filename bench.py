@@ -50,6 +50,7 @@ def parse_args():
                     help="N > 1: barrier / max-over-ranks through the library's own RCCL communicator (native: one RCCL, one HIP "
                          "runtime in the process; the unique id travels through the launcher's TCP store) or through torch.distributed")
     ap.add_argument("--extras", default="all", help="comma list of extra sections to run (default: all)")
+    ap.add_argument("--reduce-elements", type=int, default=1 << 28, help="elements of the array-wide reduction extra (2^28 f32 = 1 GiB = config C4; rehearsals shrink it)")
     return ap.parse_args()
 
 
@@ -622,7 +623,7 @@ def main():
             return out
 
         def reduce_c4():
-            n_total = 1 << 28                      # 1 GiB of f32 (config C4)
+            n_total = args.reduce_elements         # 2^28 f32 = 1 GiB (config C4)
             n_local = n_total // world
             x = TensorHandle.uniform(client, (n_local,), ElemType.F32, SEED, 300 + rank, 0.0, 1.0)
             ws = client.empty(1 << 17)

@@ -12,6 +12,7 @@
 // collectives are latency-bound, not xGMI-bandwidth-bound.
 #include "internal.hpp"
 
+#include <cstdlib>
 #include <dlfcn.h>
 #include <unistd.h>
 
@@ -46,9 +47,12 @@ bool load_rccl()
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.tried) return g_rccl.handle != nullptr;
     g_rccl.tried = true;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // By soname first: a process that already has a librccl mapped (PyTorch bundles its own) gets THAT copy, so one RCCL serves
+    // everybody.  MI355_RCCL_LIBRARY names another file outright (a site build of RCCL; the test suite's stand-in).
+    const char *names[] = {getenv("MI355_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
     for (const char *n : names) {
+        if (!n || !*n) continue;
         h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (h) break;
     }

@@ -32,6 +32,9 @@ inline fdiv_t make_fdiv(uint32_t d)
     return fdiv_t{(uint32_t)((num + d - 1) / d), l - 1};          // < 2^32 because 2^l < 2 d
 }
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, uint32_t mul, uint32_t shift) { return mul ? (__umulhi(n, mul) >> shift) : n; }
+#ifndef TILE_COORDS_DIVIDE
+#define TILE_COORDS_DIVIDE 0   // dev (A/B builds only): 1 = the hardware-less division sequences of rounds 1-3 instead of the multipliers
+#endif
 
 struct gemm_args {
     const void *a;
@@ -89,6 +92,14 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg)
 //     tm = group * group_m + in_group % gsize; tn = in_group / gsize           -- with the launch's multipliers (fdiv above)
 __device__ __forceinline__ void tile_coords(uint32_t lin, const gemm_args &g, uint32_t &tm, uint32_t &tn)
 {
+#if TILE_COORDS_DIVIDE
+    {
+        const uint32_t per_group = g.group_m * g.tiles_n, group = lin / per_group, first_m = group * g.group_m;
+        const uint32_t gsize = min(g.tiles_m - first_m, g.group_m), in_group = lin % per_group;
+        tm = first_m + in_group % gsize; tn = in_group / gsize;
+        return;
+    }
+#endif
     const uint32_t per_group = g.group_m * g.tiles_n;
     const uint32_t group = fdiv(lin, g.fd_mul_group, (g.fd_shifts >> 8) & 0xFFu);
     const uint32_t first_m = group * g.group_m;
@@ -108,7 +119,7 @@ __device__ __forceinline__ void batched_tile_coords(const gemm_args &g, uint32_t
 {
     const uint32_t tiles_per = g.tiles_m * g.tiles_n;
     const uint32_t v = xcd_remap(blockIdx.y * tiles_per + blockIdx.x, tiles_per * gridDim.y);
-    batch = fdiv(v, g.fd_mul_tiles, g.fd_shifts & 0xFFu);
+    batch = TILE_COORDS_DIVIDE ? v / tiles_per : fdiv(v, g.fd_mul_tiles, g.fd_shifts & 0xFFu);
     tile_coords(v - batch * tiles_per, g, tm, tn);
 }
 

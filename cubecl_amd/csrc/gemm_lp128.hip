@@ -850,6 +850,7 @@ bool gemm_lp256x128_supports(const mi355_gemm_desc &d, const void *a, const void
 {
     if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16) return false;
     if (d.trans_a) return false;
+    if ((int64_t)256 * std::max(d.lda, d.ldb) * 2 >= (1ll << 32)) return false;   // 256 tile rows: the per-lane DMA offsets of rows 128-255 are 32-bit too
     return gemm_lp128_supports(d, a, b, c);
 }
 

@@ -152,7 +152,7 @@ gemm_lp256q_kernel(gemm_args g)
     auto locate = [&](uint32_t L) {
         tile_src t;
         const uint32_t R = xcd_remap(L, total);
-        const uint32_t bi = fdiv(R, g.fd_mul_tiles, g.fd_shifts & 0xFFu), tl = R - bi * tiles;
+        const uint32_t bi = TILE_COORDS_DIVIDE ? R / tiles : fdiv(R, g.fd_mul_tiles, g.fd_shifts & 0xFFu), tl = R - bi * tiles;
         uint32_t tm, tn;
         tile_coords(tl, g, tm, tn);
         t.m0 = (int64_t)tm * BM; t.n0 = (int64_t)tn * BN; t.batch = bi;

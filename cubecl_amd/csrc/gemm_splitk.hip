@@ -26,7 +26,7 @@ namespace {
 template <int DT_C>
 __global__ void __launch_bounds__(256)
 splitk_fold_kernel(const float *__restrict__ slabs, uint32_t splits, int64_t slab_stride, int64_t m, int64_t n,
-                   void *__restrict__ c, int64_t ldc, int64_t stride_c)
+                   void *__restrict__ c, int64_t ldc, int64_t stride_c, int aligned)
 {
     __shared__ f32x4 part[4][64];
     const uint32_t lane = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -57,11 +57,25 @@ splitk_fold_kernel(const float *__restrict__ slabs, uint32_t splits, int64_t sla
     acc += part[3][lane];
     const uint32_t row = v / n4, q = v - row * n4;
     const int64_t idx = b * stride_c + (int64_t)row * ldc + (int64_t)q * 4;
+    // `aligned`: every row of C starts on a 16- / 8-byte boundary (launcher) -- one vector store; otherwise the SAME sum leaves
+    // element by element: which summation tree an output gets must depend on (m, n, splits) only, never on where C happens
+    // to sit (advisor, round 3: a misaligned or pitched C used to take the serial form and could differ in the last bit)
     if (DT_C == MI355_DTYPE_F32) {
-        *reinterpret_cast<f32x4 *>(static_cast<float *>(c) + idx) = acc;     // (rows of C start on 16 bytes: see the launcher)
+        float *dst = static_cast<float *>(c) + idx;
+        if (aligned) *reinterpret_cast<f32x4 *>(dst) = acc;
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[r] = acc[r];
+        }
     } else {
-        u32x2 o = {f32x2_to_lp<DT_C>(acc[0], acc[1]), f32x2_to_lp<DT_C>(acc[2], acc[3])};
-        *reinterpret_cast<u32x2 *>(static_cast<uint16_t *>(c) + idx) = o;
+        uint16_t *dst = static_cast<uint16_t *>(c) + idx;
+        if (aligned) {
+            u32x2 o = {f32x2_to_lp<DT_C>(acc[0], acc[1]), f32x2_to_lp<DT_C>(acc[2], acc[3])};
+            *reinterpret_cast<u32x2 *>(dst) = o;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[r] = f32_to_lp<DT_C>(acc[r]);
+        }
     }
 }
 
@@ -128,16 +142,17 @@ void launch_splitk_fold(hipStream_t s, const float *slabs, uint32_t splits, int6
     const bool vec = (n % 4) == 0;
     // small outputs: 64 vec4 x 4 slice groups per workgroup, 16- / 8-byte stores (rows of C must start on that boundary)
     const int64_t csz = dtype_c == MI355_DTYPE_F32 ? 4 : 2;
-    const bool wide = vec && splits <= 32 && m * (n / 4) <= 98304 && (ldc % 4) == 0 && (stride_c % 4) == 0 &&
-                      (reinterpret_cast<uintptr_t>(c) % (4 * csz)) == 0;
+    const bool wide = vec && splits <= 32 && m * (n / 4) <= 98304;          // the form -- and with it the summation tree -- follows (m, n, splits) only
+    const int aligned = ((ldc % 4) == 0 && (stride_c % 4) == 0 && (reinterpret_cast<uintptr_t>(c) % (4 * csz)) == 0) ? 1 : 0;
     const int64_t work = vec ? n / 4 : n;
     dim3 grid((uint32_t)std::max<int64_t>(1, std::min<int64_t>((work + 255) / 256, 64)), (uint32_t)m, (uint32_t)batch);
     if (wide) grid = dim3((uint32_t)((m * (n / 4) + 63) / 64), 1, (uint32_t)batch);
 #define FOLD(K, DT) hipLaunchKernelGGL((K<DT>), grid, dim3(256), 0, s, slabs, splits, slab_stride, m, n, c, ldc, stride_c)
+#define FOLDW(DT) hipLaunchKernelGGL((splitk_fold_kernel<DT>), grid, dim3(256), 0, s, slabs, splits, slab_stride, m, n, c, ldc, stride_c, aligned)
     if (wide) {
-        if (dtype_c == MI355_DTYPE_F32) FOLD(splitk_fold_kernel, MI355_DTYPE_F32);
-        else if (dtype_c == MI355_DTYPE_BF16) FOLD(splitk_fold_kernel, MI355_DTYPE_BF16);
-        else FOLD(splitk_fold_kernel, MI355_DTYPE_F16);
+        if (dtype_c == MI355_DTYPE_F32) FOLDW(MI355_DTYPE_F32);
+        else if (dtype_c == MI355_DTYPE_BF16) FOLDW(MI355_DTYPE_BF16);
+        else FOLDW(MI355_DTYPE_F16);
     } else if (vec) {
         if (dtype_c == MI355_DTYPE_F32) FOLD(splitk_fold_rows_kernel, MI355_DTYPE_F32);
         else if (dtype_c == MI355_DTYPE_BF16) FOLD(splitk_fold_rows_kernel, MI355_DTYPE_BF16);
@@ -148,6 +163,7 @@ void launch_splitk_fold(hipStream_t s, const float *slabs, uint32_t splits, int6
         else FOLD(splitk_fold_scalar_kernel, MI355_DTYPE_F16);
     }
 #undef FOLD
+#undef FOLDW
 }
 
 }  // namespace mi355

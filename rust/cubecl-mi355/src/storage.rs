@@ -150,9 +150,12 @@ impl ComputeStorage for PinnedStorage {
 
 impl Drop for PinnedStorage {
     fn drop(&mut self) {
-        // (staging buffers still referenced by a `Bytes` hold a binding of the pool, not of this storage: by the time the
-        // storage drops the lane's drop queue has been flushed and no copy is in flight)
-        for ptr in self.retired.drain(..).chain(self.live.drain().map(|(_, (p, _))| p)) {
+        // Only pages the pool has already handed back (`dealloc`) are freed here.  LIVE pages are left to the process: a
+        // `Bytes` returned by `read` / `staging` (`PinnedBytes`) holds a binding of the memory pool, not of this storage, and
+        // may outlive the lane or the server that owned the storage -- freeing its page here would leave that `Bytes`
+        // pointing at unmapped host memory (advisor, round 3).  The reference frees a pinned page in `dealloc` and has no `Drop`
+        // for the storage either (crates/cubecl-hip/src/compute/storage/cpu.rs:131-141): live pages end with the process.
+        for ptr in self.retired.drain(..) {
             unsafe { mi355_pinned_free(self.ctx, ptr as *mut core::ffi::c_void) };
         }
     }

@@ -279,6 +279,35 @@ def test_split_k_batched_padded_and_repeatable(client, oracle):
         assert np.array_equal(c.to_numpy(client), first)
 
 
+def test_split_k_bits_do_not_depend_on_where_c_sits(client, oracle):
+    """advisor, round 3: the fold of the split-K slabs had two summation trees and picked one by the ALIGNMENT of C (and by
+    ldc % 4), so the same product written into a pitched or offset C could differ in the last bit.  The form now follows
+    (m, n, splits) only: a C that starts 4 bytes off a 16-byte boundary with an odd pitch receives the bits of the aligned launch."""
+    import ctypes as C
+    m, n, k = 64, 1024, 4096
+    a = TensorHandle.uniform(client, (m, k), ElemType.BF16, 0x5EEDC0BE, 83, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (n, k), ElemType.BF16, 0x5EEDC0BE, 84, -1.0, 1.0)
+    for dt_c, np_t, esz in ((N.DTYPE_F32, np.uint32, 4), (N.DTYPE_BF16, np.uint16, 2)):
+        d = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=k, ldc=n, stride_a=m * k, stride_b=n * k, stride_c=m * n, dtype_ab=N.DTYPE_BF16,
+                       dtype_c=dt_c, trans_a=0, trans_b=1, algo=N.GEMM_ALGO_LP_128)
+        plan = ops.gemm_split_plan(client, d) if hasattr(ops, "gemm_split_plan") else None
+        c0 = client.empty(m * n * esz)
+        client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()), C.c_void_p(c0.device_ptr())))
+        ref = client.read_one(c0).view(np_t).reshape(m, n)
+        ldc = n + 3                                                      # odd pitch: rows start on every residue of 16 bytes
+        c1 = client.empty((m * ldc + 8) * esz)
+        client._s.check(client.lib.mi355_memset(client.ctx, None, C.c_void_p(c1.device_ptr()), 0xEE, c1.size))
+        d.ldc, d.stride_c = ldc, m * ldc
+        client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()),
+                                              C.c_void_p(c1.device_ptr() + esz)))       # ... and C itself one element off the allocation
+        raw = client.read_one(c1).view(np_t)
+        got = raw[1:1 + m * ldc].reshape(m, ldc)
+        assert np.array_equal(got[:, :n], ref)
+        fill = 0xEEEEEEEE if esz == 4 else 0xEEEE
+        assert np.all(got[:-1, n:] == fill) and raw[0] == fill          # the padding and the element in front of C are untouched
+        assert plan is None or plan > 1
+
+
 W4_CASES = [(256, 256, 64), (256, 256, 128), (256, 512, 192), (512, 512, 512), (768, 256, 1024), (512, 1024, 320),
             (256, 256, 2048)]
 
