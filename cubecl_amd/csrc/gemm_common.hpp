@@ -16,26 +16,6 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 namespace mi355 {
 
-// Division of a tile index by a launch constant.  The kernels turn a linear workgroup / tile number into (batch, tile row, tile
-// column) with three or four unsigned divisions by values only the launch knows; as hipcc lowers them (v_rcp_iflag_f32 + two
-// correction steps, ~40 dependent VALU instructions each) they were ~250 instructions in front of the first LDS-DMA of every
-// workgroup, and 2 044 shader cycles of idle matrix pipe between two tiles of the persistent kernels (s_memtime stamps,
-// profiles/r04_c5_counters.md).  The host therefore hands over a multiplier per divisor: q = umulhi(n, mul) >> shift, exact for
-// n < 2^31 (mul = ceil(2^(31 + l) / d), l = ceil(log2 d), shift = l - 1; mul = 0 encodes d = 1).
-struct fdiv_t { uint32_t mul, shift; };
-inline fdiv_t make_fdiv(uint32_t d)
-{
-    if (d <= 1) return fdiv_t{0u, 0u};
-    uint32_t l = 0;
-    while ((1ull << l) < d) ++l;                                  // l = ceil(log2 d) >= 1
-    const uint64_t num = 1ull << (31 + l);
-    return fdiv_t{(uint32_t)((num + d - 1) / d), l - 1};          // < 2^32 because 2^l < 2 d
-}
-__device__ __forceinline__ uint32_t fdiv(uint32_t n, uint32_t mul, uint32_t shift) { return mul ? (__umulhi(n, mul) >> shift) : n; }
-#ifndef TILE_COORDS_DIVIDE
-#define TILE_COORDS_DIVIDE 0   // dev (A/B builds only): 1 = the hardware-less division sequences of rounds 1-3 instead of the multipliers
-#endif
-
 struct gemm_args {
     const void *a;
     const void *b;
@@ -52,26 +32,7 @@ struct gemm_args {
     int64_t stride_sa = 0, stride_sb = 0;      // bytes between batch entries of those
     const void *c_in = nullptr;                // f32 C only: D = A * B + c_in (same layout as c; may alias it), lp256w4
     uint32_t nt_mask = 0;                      // gemm_lp128.hip: bit 0 / 1 = the LDS-DMA pieces of A / B carry the non-temporal hint
-    // multipliers for the tile-coordinate divisions (set_tile_divs; every supports() keeps tiles x batch below 2^31): by
-    // tiles_m * tiles_n, by group_m * tiles_n and by tiles_m % group_m (the last, shorter group of tile rows); group_m itself is a
-    // power of two.  Four dwords (the persistent kernels keep them in scalar registers across their tile loop):
-    uint32_t fd_mul_tiles = 0, fd_mul_group = 0, fd_mul_tail = 0;
-    uint32_t fd_shifts = 0;                    // bytes: shift of tiles | of group | of tail | log2(group_m)
 };
-
-// call once tiles_m, tiles_n, group_m (and the batch count) are final
-inline void set_tile_divs(gemm_args &g, uint64_t batch)
-{
-    const uint64_t tiles = (uint64_t)g.tiles_m * g.tiles_n;
-    (void)batch;
-    uint32_t lg = 0;
-    while ((1u << lg) < g.group_m) ++lg;
-    if ((1u << lg) != g.group_m) { g.group_m = 1u << lg; }         // (every launcher passes 4 or 8)
-    const fdiv_t t = make_fdiv((uint32_t)tiles), pg = make_fdiv(g.group_m * g.tiles_n),
-                 tl = make_fdiv(g.tiles_m % g.group_m ? g.tiles_m % g.group_m : g.group_m);
-    g.fd_mul_tiles = t.mul; g.fd_mul_group = pg.mul; g.fd_mul_tail = tl.mul;
-    g.fd_shifts = t.shift | (pg.shift << 8) | (tl.shift << 16) | (lg << 24);
-}
 
 // MI355X dispatches workgroup b to XCD b % 8, each XCD with a private 4 MiB L2
 // (MI355X_MICROARCH.md "Workgroup dispatch").  Remap the linear id so that every XCD walks one
@@ -88,26 +49,16 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg)
 
 // Grouped rasterisation: `group_m` tile-rows are swept column by column before moving down, so
 // concurrently resident workgroups cover a compact block of the output.
-//     group = lin / (group_m * tiles_n); gsize = min(tiles_m - group * group_m, group_m); in_group = lin % (group_m * tiles_n);
-//     tm = group * group_m + in_group % gsize; tn = in_group / gsize           -- with the launch's multipliers (fdiv above)
-__device__ __forceinline__ void tile_coords(uint32_t lin, const gemm_args &g, uint32_t &tm, uint32_t &tn)
+__device__ __forceinline__ void tile_coords(uint32_t lin, uint32_t tiles_m, uint32_t tiles_n, uint32_t group_m,
+                                            uint32_t &tm, uint32_t &tn)
 {
-#if TILE_COORDS_DIVIDE
-    {
-        const uint32_t per_group = g.group_m * g.tiles_n, group = lin / per_group, first_m = group * g.group_m;
-        const uint32_t gsize = min(g.tiles_m - first_m, g.group_m), in_group = lin % per_group;
-        tm = first_m + in_group % gsize; tn = in_group / gsize;
-        return;
-    }
-#endif
-    const uint32_t per_group = g.group_m * g.tiles_n;
-    const uint32_t group = fdiv(lin, g.fd_mul_group, (g.fd_shifts >> 8) & 0xFFu);
-    const uint32_t first_m = group * g.group_m;
-    const uint32_t in_group = lin - group * per_group;
-    const bool tail = g.tiles_m - first_m < g.group_m;             // the last, shorter group of tile rows
-    const uint32_t gsize = tail ? g.tiles_m - first_m : g.group_m;
-    tn = tail ? fdiv(in_group, g.fd_mul_tail, (g.fd_shifts >> 16) & 0xFFu) : in_group >> (g.fd_shifts >> 24);
-    tm = first_m + in_group - tn * gsize;
+    const uint32_t per_group = group_m * tiles_n;
+    const uint32_t group = lin / per_group;
+    const uint32_t first_m = group * group_m;
+    const uint32_t gsize = min(tiles_m - first_m, group_m);
+    const uint32_t in_group = lin % per_group;
+    tm = first_m + in_group % gsize;
+    tn = in_group / gsize;
 }
 
 // Batched launches (grid.x = tiles, grid.y = batch; workgroups go to XCD (x + grid.x * y) % 8): the XCD remap runs over
@@ -115,12 +66,13 @@ __device__ __forceinline__ void tile_coords(uint32_t lin, const gemm_args &g, ui
 // batch (shared operand panels in that XCD's L2) rather than a few tiles each of several matrices.  Measured on the
 // 256x256 kernel: +3 % at 64 x 2048^3, +8 % at 256 x 1024^3; identical to the per-matrix remap for batch == 1.
 // Requires tiles * batch < 2^32 (checked by the kernels' supports()).
-__device__ __forceinline__ void batched_tile_coords(const gemm_args &g, uint32_t &tm, uint32_t &tn, uint32_t &batch)
+__device__ __forceinline__ void batched_tile_coords(uint32_t tiles_m, uint32_t tiles_n, uint32_t group_m, uint32_t &tm,
+                                                    uint32_t &tn, uint32_t &batch)
 {
-    const uint32_t tiles_per = g.tiles_m * g.tiles_n;
+    const uint32_t tiles_per = tiles_m * tiles_n;
     const uint32_t v = xcd_remap(blockIdx.y * tiles_per + blockIdx.x, tiles_per * gridDim.y);
-    batch = TILE_COORDS_DIVIDE ? v / tiles_per : fdiv(v, g.fd_mul_tiles, g.fd_shifts & 0xFFu);
-    tile_coords(v - batch * tiles_per, g, tm, tn);
+    batch = v / tiles_per;
+    tile_coords(v - batch * tiles_per, tiles_m, tiles_n, group_m, tm, tn);
 }
 
 __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f)

@@ -45,7 +45,7 @@ gemm_f32_mfma_kernel(gemm_args g)
     const int h = lane >> 5, l31 = lane & 31;
 
     uint32_t tm, tn, batch_u;
-    batched_tile_coords(g, tm, tn, batch_u);
+    batched_tile_coords(g.tiles_m, g.tiles_n, g.group_m, tm, tn, batch_u);
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
     const int64_t batch = batch_u;
     const float *__restrict__ A = static_cast<const float *>(g.a) + batch * g.stride_a;
@@ -212,7 +212,6 @@ int32_t launch_gemm_f32_mfma(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_des
     g.tiles_m = (uint32_t)((d.m + BM - 1) / BM);
     g.tiles_n = (uint32_t)((d.n + BN - 1) / BN);
     g.group_m = 8;
-    set_tile_divs(g, (uint64_t)d.batch);
     const dim3 grid(g.tiles_m * g.tiles_n, (uint32_t)d.batch);
     const size_t lds = sizeof(f32_smem);
     // the dynamic-LDS attribute is per device: remember it per context, not in a process-wide static

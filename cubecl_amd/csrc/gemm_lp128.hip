@@ -156,7 +156,7 @@ gemm_lp128_kernel(gemm_args g)
     const int h = lane >> 5, l31 = lane & 31;
 
     uint32_t tm, tn, batch_u;
-    batched_tile_coords(g, tm, tn, batch_u);
+    batched_tile_coords(g.tiles_m, g.tiles_n, g.group_m, tm, tn, batch_u);
     const int64_t m0 = (int64_t)tm * BMK, n0 = (int64_t)tn * BN;
     const int64_t batch = batch_u;
     constexpr bool F8 = DT == MI355_DTYPE_F8E4M3 || DT == MI355_DTYPE_F8E5M2;
@@ -779,7 +779,6 @@ int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
     g.tiles_m = (uint32_t)((d.m + BM - 1) / BM);
     g.tiles_n = (uint32_t)((d.n + BN - 1) / BN);
     g.group_m = 8;
-    set_tile_divs(g, (uint64_t)d.batch);
     g.split_k = 1;
     g.split_c_stride = 0;
     {
@@ -866,7 +865,6 @@ int32_t launch_gemm_lp256x128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_de
     g.tiles_m = (uint32_t)((d.m + 255) / 256);
     g.tiles_n = (uint32_t)((d.n + BN - 1) / BN);
     g.group_m = 4;                        // 4 x 8 tiles of 256 x 128 = the 1024 x 1024 patch an XCD's 32 workgroups share
-    set_tile_divs(g, (uint64_t)d.batch);
     g.split_k = 1;
     g.split_c_stride = 0;
     const uint32_t batch = (uint32_t)d.batch;

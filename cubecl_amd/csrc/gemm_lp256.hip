@@ -107,7 +107,7 @@ gemm_lp256_kernel(gemm_args g)
     const int h = lane >> 5, l31 = lane & 31;
 
     uint32_t tm, tn, batch_u;
-    batched_tile_coords(g, tm, tn, batch_u);
+    batched_tile_coords(g.tiles_m, g.tiles_n, g.group_m, tm, tn, batch_u);
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
     const int64_t batch = batch_u;
     const char *__restrict__ A = static_cast<const char *>(g.a) + batch * g.stride_a * 2;
@@ -346,7 +346,6 @@ int32_t launch_gemm_lp256(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
     g.tiles_m = (uint32_t)((d.m + BM - 1) / BM);
     g.tiles_n = (uint32_t)((d.n + BN - 1) / BN);
     g.group_m = 8;
-    set_tile_divs(g, (uint64_t)d.batch);
     const uint32_t batch = (uint32_t)d.batch;
     if (d.dtype_ab == MI355_DTYPE_BF16) {
         if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_BF16, MI355_DTYPE_F32>(ctx, s, g, batch);

@@ -163,9 +163,9 @@ gemm_lp256p_kernel(gemm_args g)
     auto locate = [&](uint32_t L) {
         tile_src t;
         const uint32_t R = xcd_remap(L, total);
-        const uint32_t bi = TILE_COORDS_DIVIDE ? R / tiles : fdiv(R, g.fd_mul_tiles, g.fd_shifts & 0xFFu), tl = R - bi * tiles;
+        const uint32_t bi = R / tiles, tl = R - bi * tiles;
         uint32_t tm, tn;
-        tile_coords(tl, g, tm, tn);
+        tile_coords(tl, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
         t.m0 = (int64_t)tm * BM; t.n0 = (int64_t)tn * BN; t.batch = bi;
         const char *A = static_cast<const char *>(g.a) + (int64_t)bi * g.stride_a * ESZ;
         const char *B = static_cast<const char *>(g.b) + (int64_t)bi * g.stride_b * ESZ;
@@ -522,7 +522,6 @@ int32_t launch_gemm_lp256p(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc 
     g.tiles_m = (uint32_t)(d.m / BM);
     g.tiles_n = (uint32_t)(d.n / BN);
     g.group_m = W4_GROUP_M;
-    set_tile_divs(g, (uint64_t)d.batch);
     g.batch_count = (uint32_t)d.batch;
     const uint32_t batch = (uint32_t)d.batch;
     if (d.dtype_ab == MI355_DTYPE_F32) {

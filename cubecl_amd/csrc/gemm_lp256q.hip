@@ -152,9 +152,9 @@ gemm_lp256q_kernel(gemm_args g)
     auto locate = [&](uint32_t L) {
         tile_src t;
         const uint32_t R = xcd_remap(L, total);
-        const uint32_t bi = TILE_COORDS_DIVIDE ? R / tiles : fdiv(R, g.fd_mul_tiles, g.fd_shifts & 0xFFu), tl = R - bi * tiles;
+        const uint32_t bi = R / tiles, tl = R - bi * tiles;
         uint32_t tm, tn;
-        tile_coords(tl, g, tm, tn);
+        tile_coords(tl, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
         t.m0 = (int64_t)tm * BM; t.n0 = (int64_t)tn * BN; t.batch = bi;
         t.ua = static_cast<const char *>(g.a) + ((int64_t)bi * g.stride_a + t.m0 * g.lda) * ESZ;
         if constexpr (BNN)   // column n0 of k-row 16 wave: this wave's pieces are blocks rows a = 4 wave .. 4 wave + 3 (k-rows 16 wave .. +15)
@@ -626,7 +626,6 @@ int32_t launch_gemm_lp256q(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc 
     g.tiles_m = (uint32_t)(d.m / BM);
     g.tiles_n = (uint32_t)(d.n / BN);
     g.group_m = 8;
-    set_tile_divs(g, (uint64_t)d.batch);
     g.batch_count = (uint32_t)d.batch;
     const uint32_t batch = (uint32_t)d.batch;
     const int drip = drip_for(d.k / 64);

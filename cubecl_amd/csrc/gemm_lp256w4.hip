@@ -217,7 +217,7 @@ gemm_lp256w4_kernel(gemm_args g)
     const int h = lane >> 5, l31 = lane & 31;
 
     uint32_t tm, tn, batch_u;
-    batched_tile_coords(g, tm, tn, batch_u);      // XCD remap over the (batch, tile) sequence
+    batched_tile_coords(g.tiles_m, g.tiles_n, g.group_m, tm, tn, batch_u);      // XCD remap over the (batch, tile) sequence
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
     const int64_t batch = batch_u;
     constexpr int ESZ = lp<DT>::ESZ;
@@ -785,7 +785,6 @@ int32_t launch_gemm_lp256w4(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc
     g.tiles_m = (uint32_t)((d.m + BM - 1) / BM);
     g.tiles_n = (uint32_t)((d.n + BN - 1) / BN);
     g.group_m = W4_GROUP_M;
-    set_tile_divs(g, (uint64_t)d.batch);
     const uint32_t batch = (uint32_t)d.batch;
     if (d.dtype_ab == MI355_DTYPE_F8E4M3) {
         if (d.dtype_c == MI355_DTYPE_F32) launch<MI355_DTYPE_F8E4M3, MI355_DTYPE_F32>(ctx, s, g, batch);
@@ -859,7 +858,6 @@ int32_t launch_gemm_lp256w4_mx(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_s
     g.tiles_m = (uint32_t)((d.m + BM - 1) / BM);
     g.tiles_n = (uint32_t)((d.n + BN - 1) / BN);
     g.group_m = W4_GROUP_M;
-    set_tile_divs(g, (uint64_t)d.batch);
     g.sa = sa_t; g.sb = sb_t; g.stride_sa = stride_sa_t; g.stride_sb = stride_sb_t;
     const uint32_t batch = (uint32_t)d.batch;
     const bool f32c = d.dtype_c == MI355_DTYPE_F32;

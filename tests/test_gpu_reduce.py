@@ -649,8 +649,8 @@ def test_axis_value_rules_nan_ties_and_zero(client, oracle):
     x[3, :, 1] = 0.0
     x[3, 1, 1] = -0.0
     t = TensorHandle.from_numpy(client, x)
-    a = TensorHandle.new_contiguous((4, 5), client.empty(80), ElemType.U32)
-    o = TensorHandle.new_contiguous((4, 5), client.empty(80), ElemType.F32)
+    a = TensorHandle.new_contiguous((30,), client.empty(120), ElemType.U32)      # room for the largest output: axis 0 leaves (6, 5)
+    o = TensorHandle.new_contiguous((30,), client.empty(120), ElemType.F32)
     for axis in (1, 0, 2):
         shp = tuple(d for i, d in enumerate(x.shape) if i != axis)
         ops.argreduce_axis(client, t, a, axis, "argmin")
@@ -660,7 +660,7 @@ def test_axis_value_rules_nan_ties_and_zero(client, oracle):
             got = o.to_numpy(client)[: int(np.prod(shp))].reshape(shp)
             assert np.array_equal(got.view(np.uint32), oracle.reduce_axis_value(x, axis, op).astype(np.float32).view(np.uint32)), (axis, op)
     ops.argreduce_axis(client, t, a, 1, "argmin")
-    got = a.to_numpy(client).reshape(4, 5)
+    got = a.to_numpy(client)[:20].reshape(4, 5)
     assert got[0, 0] == 2 and got[1, 3] == 5 and got[2, 0] == 0 and got[3, 1] == 2
     with pytest.raises(ServerError):
         ops.reduce_axis(client, t, o, 1, "argmin")                 # not a value operation

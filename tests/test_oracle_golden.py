@@ -329,34 +329,6 @@ def test_value_and_argmin_rules(oracle):
     assert oracle.reduce_axis_value(-m, 1, "max").tolist() == (-m).max(axis=1).tolist()
 
 
-def test_fast_division_by_launch_constants_is_exact():
-    """cubecl_amd/csrc/gemm_common.hpp make_fdiv / fdiv: tile indices are divided by launch constants as
-    q = umulhi(n, ceil(2^(31 + l) / d)) >> (l - 1), l = ceil(log2 d) (d = 1: the value itself) -- exact for every n < 2^31.
-    The formula restated on integers: every divisor up to 4 096 and a spread of larger ones against the n where a rounded-up
-    multiplier could first go wrong (multiples of d and their neighbours, the top of the range)."""
-    def make(d):
-        if d <= 1:
-            return 0, 0
-        l = (d - 1).bit_length()
-        mul = ((1 << (31 + l)) + d - 1) // d
-        assert mul < 1 << 32
-        return mul, l - 1
-
-    def q(n, mul, shift):
-        return ((n * mul) >> 32) >> shift if mul else n
-    rng = np.random.default_rng(7)
-    divisors = list(range(1, 4097)) + [int(v) for v in rng.integers(4097, 1 << 31, 600)] + [(1 << 31) - 1, 1 << 30, (1 << 30) + 1, 65535, 65536, 65537]
-    top = (1 << 31) - 1
-    for d in divisors:
-        mul, shift = make(d)
-        ns = {0, 1, d - 1, d, d + 1, top, top - 1, top - d, (top // d) * d, (top // d) * d - 1}
-        ns |= {int(v) for v in rng.integers(0, top, 24)}
-        ns |= {k * d + e for k in (2, 3, 1000, top // d // 2) for e in (-1, 0, 1)}
-        for n in ns:
-            if 0 <= n <= top:
-                assert q(n, mul, shift) == n // d, (n, d)
-
-
 def test_argmax_rules(oracle):
     x = np.array([1.0, 7.0, 3.0, 7.0, -2.0], dtype=np.float32)
     assert oracle.argmax(x) == (1, np.float32(7.0))            # lowest index among equal maxima

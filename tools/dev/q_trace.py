@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Dev: where a workgroup of the persistent dripped-store kernel (gemm_lp256q.hip) spends its cycles on config C5 -- K loop against
 tile boundary, per tile (needs a -DQ_TRACE variant build: tools/dev/build_variants.sh qtrace "-DQ_TRACE" gemm_lp256q.hip).
+Resolution: a stamp (s_memtime + its wait + a store) costs ~1 000 cycles itself -- the "gap" column is two stamps and little else,
+and every K-loop figure carries one (profiles/r04_c5_counters.md).
 usage (GPU box): MI355CUBE_LIB=$PWD/cubecl_amd/csrc/variants/libmi355cube_qtrace.so python tools/dev/q_trace.py [batch]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
