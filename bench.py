@@ -220,7 +220,7 @@ KERNEL_SOURCES = {
 }
 PROFILES_DIR = ROOT / "profiles"
 HEADLINE_KERNEL = "gemm_lp256w4_kernel<1, 1, false, 1, false, false>"     # bf16 x bf16 -> bf16 C, [N][K] B, unscaled (what rocprofv3 prints)
-REDUCE_SUM_KERNEL = "reduce_kernel<true, false, 0>"      # <SUM, ARGMAX, DT = f32>
+REDUCE_SUM_KERNEL = "reduce_kernel<0, 0, 0>"      # <VOP = MI355_REDUCE_SUM, AOP = none, DT = f32> (until round 3: <true, false, 0>)
 C5_KERNEL = "gemm_lp256q_kernel<1, 1, false>"             # <bf16, one dripped store per K-tile, [N][K] B>: batch 512 x 2048^3
 
 

@@ -273,6 +273,27 @@ gemm_lp128_kernel(gemm_args g)
         }
     };
 
+#ifndef LP128_INSTREAM
+#define LP128_INSTREAM 0   // dev, deep rings without loader waves: 1 = the multiplying waves issue the pieces of K-tile kt+AHEAD in four
+                           // portions between the k-steps of the following K-tile (gemm_lp256w4.hip's in-stream issue) instead of
+                           // back to back behind the hand-over barrier.  Round 4, interleaved three times on cold operands against the
+                           // loader-wave forms (profiles/r04_lp128_in_stream_dma.txt): the 256 x 128 tile LOSES 9-17 % (4096 x 2048 x 4096 80 ->
+                           // 87 us, 2560^2 x 4096 64 -> 75, 4096 x 1536 x 8192 114 -> 132), the 128 x 128 tile ties (2048^3 24.6 / 24.1,
+                           // 1024 x 4096 x 4096 45.9 / 45.2).  Off; the loader waves stay.
+#endif
+    // linear piece p of a K-tile: 0 .. 2 MI - 1 = A piece p, then the four B pieces
+    auto stage_pieces = [&](int buf, int kt_rel, int p0, int p1) {
+        int kt = kt0 + kt_rel;
+        char *la = smem + buf * STG;
+        char *lb = la + A_BYTES;
+        const int64_t koff = (int64_t)kt * ROW_BYTES;
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p) {
+            if (p < p0 || p >= p1) continue;
+            if (p < 2 * MI) glds16_s<false>(ubase_a + (ATN ? koff * g.lda : koff), va[p < 2 * MI ? p : 0], lds_addr_of(la + (p * 4 + wave) * 1024));
+            else glds16_s<false>(ubase_b + (BNN ? koff * g.ldb : koff), vb[(p - 2 * MI) & 3], lds_addr_of(lb + ((p - 2 * MI) * 4 + wave) * 1024));
+        }
+    };
     frag af[2][MI], bf[2][2];                    // [register buffer][tile]
     bool first_reads = true;
     auto reads = [&](auto buf, const char *la, const char *lb, int kk) {
@@ -466,15 +487,21 @@ gemm_lp128_kernel(gemm_args g)
             __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0), vmcnt / expcnt untouched
             __builtin_amdgcn_sched_barrier(0);
             if (nk > 0) reads(B0{}, smem, smem + A_BYTES, 0);
+            constexpr bool INSTREAM = LP128_INSTREAM && !SPEC && NSTEP == 4;
+            constexpr int Q = (PIECES + 3) / 4;          // pieces per portion
+            int pend = -1;                               // K-tile whose pieces 1 .. 3 x Q are still to be issued (in-stream form)
             for (int kt = 0; kt < nk; ++kt) {
                 const char *la = smem + (kt % NS) * STG;
                 const char *lb = la + A_BYTES;
                 reads(B1{}, la, lb, 1); mfmas(B0{});
+                if constexpr (INSTREAM) if (pend >= 0) stage_pieces(pend % NS, pend, Q, 2 * Q);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (NSTEP == 4) {
                     reads(B0{}, la, lb, 2); mfmas(B1{});
+                    if constexpr (INSTREAM) if (pend >= 0) stage_pieces(pend % NS, pend, 2 * Q, 3 * Q);
                     __builtin_amdgcn_sched_barrier(0);
                     reads(B1{}, la, lb, 3); mfmas(B0{});
+                    if constexpr (INSTREAM) if (pend >= 0) { stage_pieces(pend % NS, pend, 3 * Q, PIECES); pend = -1; }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (kt + 1 < nk) {
@@ -494,8 +521,10 @@ gemm_lp128_kernel(gemm_args g)
                     __builtin_amdgcn_s_barrier();   // raw: __syncthreads() carries a release fence = vmcnt(0), which would drain the ring
                     __builtin_amdgcn_sched_barrier(0);
                     // everybody is past K-tile kt-1: its buffer takes K-tile kt+3
-                    if constexpr (!SPEC)
+                    if constexpr (!SPEC && !INSTREAM)
                         if (kt + AHEAD < nk) stage((kt + AHEAD) % NS, kt + AHEAD);
+                    if constexpr (INSTREAM)           // the first portion here, the other three between the next K-tile's k-steps
+                        if (kt + AHEAD < nk) { pend = kt + AHEAD; stage_pieces(pend % NS, pend, 0, Q); }
                     if constexpr (HYB)
                         if (kt + AHEAD < nk) stage((kt + AHEAD) % NS, kt + AHEAD, false, true);
                     const char *na = smem + ((kt + 1) % NS) * STG;
@@ -868,7 +897,7 @@ int32_t launch_gemm_lp256x128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_de
     g.split_k = 1;
     g.split_c_stride = 0;
     const uint32_t batch = (uint32_t)d.batch;
-#define TALL(DT_, DC_) { if (d.trans_b) launch_ns<DT_, DC_, 3, true, false, 4>(ctx, s, g, batch); else launch_ns<DT_, DC_, 3, true, true, 4>(ctx, s, g, batch); }
+#define TALL(DT_, DC_) { if (d.trans_b) launch_ns<DT_, DC_, 3, !LP128_INSTREAM, false, 4>(ctx, s, g, batch); else launch_ns<DT_, DC_, 3, !LP128_INSTREAM, true, 4>(ctx, s, g, batch); }
     if (d.dtype_ab == MI355_DTYPE_BF16) {
         if (d.dtype_c == MI355_DTYPE_F32) TALL(MI355_DTYPE_BF16, MI355_DTYPE_F32) else TALL(MI355_DTYPE_BF16, MI355_DTYPE_BF16)
     } else {

@@ -74,7 +74,10 @@ for r in rows_of("reduce"):
     if "reduce_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
         agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
 for k, v in agg.items():
-    name = "sum" if "<true, false" in k else "argmax" if "<false, true" in k else "sum_argmax"   # <SUM, ARG, DT>
+    if "reduce_kernel<0, 0," in k: name = "sum"                  # <VOP, AOP, DT>: value op SUM = 0, no index op
+    elif "reduce_kernel<-1, 1," in k: name = "argmax"            # no value op, index op ARGMAX = 1
+    elif "reduce_kernel<0, 1," in k: name = "sum_argmax"
+    else: continue
     traffic[f"reduce_1GiB_{name}"] = dict(stamp, kernel=k[:120], source_sha=bench.kernel_source_sha("reduce"),
         fetch_bytes=int(statistics.median(v) * 1024 * 2), algorithmic_bytes=1 << 30, FETCH_SIZE_KiB_raw=statistics.median(v), launches=len(v))
 # config C5 as benched (batch 512 x 2048^3 bf16 on the persistent dripped-store kernel)
