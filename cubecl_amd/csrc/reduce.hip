@@ -99,6 +99,13 @@ __device__ __forceinline__ void arg_combine(uint32_t &key, uint64_t &idx, uint32
     idx = take ? oidx : idx;
 }
 
+__device__ __forceinline__ void arg_combine_u32(uint32_t &key, uint32_t &idx, uint32_t okey, uint32_t oidx)
+{
+    const bool take = (okey > key) || (okey == key && oidx < idx);
+    key = take ? okey : key;
+    idx = take ? oidx : idx;
+}
+
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll
@@ -557,57 +564,158 @@ reduce_rows(const typename red_in<DT>::elem *__restrict__ in, float *__restrict_
 }
 
 // ---- reductions over a NON-last axis: in is [outer][reduce][inner] (contiguous), out is [outer][inner] ------------
-// Consecutive lanes own consecutive `inner` positions, so every load of the r-loop is a coalesced row segment;
-// each thread folds `reduce` values sequentially (the book's per-unit loop, v4-gpu.rs:47-54, along a strided axis),
-// split into RSPLIT interleaved partial chains when `reduce` is long and outer*inner is too small to fill the chip;
-// the chains are folded in order through LDS.  Roofline: HBM, 4 bytes per input element read once.
-template <int OP, int RSPLIT, int DT = MI355_DTYPE_F32>
+// Roofline: HBM, the input read once.  Until round 4 one thread walked the whole axis for one `inner` position with one load
+// in flight: 0.3-3.4 TB/s (8192 x 8192 over axis 0 = 256 MiB: 292 us, 0.9 TB/s; 4 x 65536 x 1024 over axis 1: 3.4 ms, 0.3 TB/s --
+// profiles/r04_axis_probe_before.txt).  Now a workgroup owns a TILE: TX threads along `inner` (16 bytes each when rows allow,
+// so a wave reads whole lines) x TY = 256 / TX threads along the reduced axis, eight rows in flight per thread; the TY partial
+// vectors meet in LDS in thread order.  When outer x inner alone cannot fill the chip the reduced axis is cut into `chunks`
+// row ranges, every workgroup writes its partial to library scratch and a second launch of the SAME kernel reduces the
+// [outer][chunks][inner] partials (value operations: max / min carry NaN as a NaN partial, mean divides at the very end; index
+// operations: (key, row index) pairs, folded with the lowest-index rule).  The tree is a function of the shape only:
+// deterministic.
+constexpr int SCRATCH_REDUCE_AXIS = 6;      // library scratch kind (gemm_common.hpp lists 0-5)
+
+struct axis_args {
+    const void *in;                 // stage 1: elements of DT; stage 2 of a value operation: f32 partials
+    const uint32_t *in_key, *in_idx;   // stage 2 of an index operation: partial (key, row index) pairs
+    float *out_val;                 // final f32 values, or the partial values when `partial`
+    uint32_t *out_key, *out_idx;    // final u32 indices (out_idx), or partial pairs
+    uint64_t outer, red, inner;
+    uint64_t rows_per_chunk;        // rows of the reduced axis per workgroup (multiple of TY)
+    uint32_t chunks, inner_blocks, log2_tx, partial;
+    float mean_div;                 // != 0: the final value is sum / mean_div
+};
+
+template <int OP, int DT, bool VECTOR, bool PAIRS>
 __global__ void __launch_bounds__(256)
-reduce_mid_axis(const typename red_in<DT>::elem *__restrict__ in, float *__restrict__ out_sum, uint32_t *__restrict__ out_idx, uint64_t outer,
-                uint64_t red, uint64_t inner)
+reduce_axis_tiled(axis_args a)
 {
     typedef axis_op<OP> O;
     typedef typename O::V V;
     constexpr bool ARG = O::ARG;
     typedef red_in<DT> RI;
-    constexpr int IW = 256 / RSPLIT;                       // inner positions per workgroup
-    const uint32_t tid = threadIdx.x, il = tid % IW, rs = tid / IW;
-    const uint64_t blocks_i = (inner + IW - 1) / IW;
-    __shared__ float s_sum[RSPLIT][IW];
-    __shared__ uint32_t s_key[RSPLIT][IW];
-    __shared__ uint32_t s_idx[RSPLIT][IW];
-    for (uint64_t blk = blockIdx.x; blk < outer * blocks_i; blk += gridDim.x) {
-        const uint64_t o = blk / blocks_i, i = (blk % blocks_i) * IW + il;
-        float acc = V::identity();
-        bool nan_seen = false;
-        uint32_t key = 0u, idx = 0u;
-        if (i < inner) {
-            const typename RI::elem *p = in + (o * red) * inner + i;
-            for (uint64_t r = rs; r < red; r += RSPLIT) {
-                const float v = RI::widen(p[r * inner]);
-                if (!ARG) { acc = V::apply(acc, v); if (V::TRACKS_NAN) nan_seen |= (v != v); }
-                else { const uint32_t k = arg_key<O::AOP>(v); if (k > key) { key = k; idx = (uint32_t)r; } }
-            }
-        }
-        if (RSPLIT == 1) {
-            if (i < inner) { if (!ARG) out_sum[o * inner + i] = O::finish(acc, nan_seen, red); else out_idx[o * inner + i] = idx; }
-        } else {
-            if (!ARG) { s_sum[rs][il] = acc; s_key[rs][il] = nan_seen ? 1u : 0u; } else { s_key[rs][il] = key; s_idx[rs][il] = idx; }
-            __syncthreads();
-            if (rs == 0 && i < inner) {
-                if (!ARG) {
-                    float t = s_sum[0][il]; uint32_t nn = s_key[0][il];
-                    for (int q = 1; q < RSPLIT; ++q) { t = V::apply(t, s_sum[q][il]); nn |= s_key[q][il]; }
-                    out_sum[o * inner + i] = O::finish(t, nn != 0u, red);
-                } else {
-                    uint32_t k = s_key[0][il]; uint64_t ix = s_idx[0][il];
-                    for (int q = 1; q < RSPLIT; ++q) arg_combine(k, ix, s_key[q][il], s_idx[q][il]);
-                    out_idx[o * inner + i] = (uint32_t)ix;
+    constexpr int W = VECTOR ? RI::EPV : 1;                 // elements per thread along `inner`
+    constexpr int U = 8;                                    // rows in flight per thread
+    static_assert(!PAIRS || (ARG && !VECTOR), "pair input: the second stage of an index operation, one position per thread");
+    __shared__ uint32_t s_a[256 * W], s_b[256 * W];         // per thread: W values (or keys) and W NaN flags (or row indices)
+
+    const uint32_t tid = threadIdx.x, TX = 1u << a.log2_tx, TY = 256u >> a.log2_tx;
+    const uint32_t tx = tid & (TX - 1), ty = tid >> a.log2_tx;
+    // linear workgroup id -> (outer o, chunk c, inner block ib), inner block fastest
+    const uint64_t wg = blockIdx.x;
+    const uint32_t ib = (uint32_t)(wg % a.inner_blocks);
+    const uint64_t rest = wg / a.inner_blocks;
+    const uint32_t c = (uint32_t)(rest % a.chunks);
+    const uint64_t o = rest / a.chunks;
+    const uint64_t i0 = ((uint64_t)ib * TX + tx) * W;
+    const bool live = i0 < a.inner;
+    const uint64_t r0 = (uint64_t)c * a.rows_per_chunk, r1 = min(a.red, r0 + a.rows_per_chunk);
+
+    float acc[W];
+    uint32_t key[W], idx[W];
+    bool nan_seen[W];
+#pragma unroll
+    for (int e = 0; e < W; ++e) { acc[e] = V::identity(); key[e] = 0u; idx[e] = 0u; nan_seen[e] = false; }
+
+    if (live) {
+        const uint64_t base = (o * a.red) * a.inner + i0;
+        for (uint64_t r = r0 + ty; r < r1; r += (uint64_t)TY * U) {
+            float v[U][W];
+            uint32_t pk[U], pi[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint64_t rr = r + (uint64_t)u * TY;
+                if (rr < r1) {
+                    const uint64_t at = base + rr * a.inner;
+                    if constexpr (PAIRS) { pk[u] = a.in_key[at]; pi[u] = a.in_idx[at]; }
+                    else if constexpr (VECTOR) RI::unpack(__builtin_nontemporal_load(reinterpret_cast<const u32x4r *>(static_cast<const typename RI::elem *>(a.in) + at)), v[u]);
+                    else v[u][0] = RI::widen(static_cast<const typename RI::elem *>(a.in)[at]);
                 }
             }
-            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint64_t rr = r + (uint64_t)u * TY;
+                if (rr < r1) {
+                    if constexpr (PAIRS) {
+                        arg_combine_u32(key[0], idx[0], pk[u], pi[u]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < W; ++e) {
+                            if constexpr (ARG) {
+                                const uint32_t k = arg_key<O::AOP>(v[u][e]);
+                                if (k > key[e]) { key[e] = k; idx[e] = (uint32_t)rr; }       // rows ascend per thread: the first extremum stays
+                            } else {
+                                acc[e] = V::apply(acc[e], v[u][e]);
+                                if (V::TRACKS_NAN) nan_seen[e] |= (v[u][e] != v[u][e]);
+                            }
+                        }
+                    }
+                }
+            }
         }
     }
+    // ---- the TY partial vectors of a column meet in LDS, folded by the ty == 0 thread in ty order ----------------------------
+    if (TY > 1) {
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            s_a[tid * W + e] = ARG ? key[e] : __float_as_uint(acc[e]);
+            s_b[tid * W + e] = ARG ? idx[e] : (nan_seen[e] ? 1u : 0u);
+        }
+        __syncthreads();
+        if (ty == 0) {
+            for (uint32_t t = 1; t < TY; ++t) {
+                const uint32_t other = (t << a.log2_tx) + tx;
+#pragma unroll
+                for (int e = 0; e < W; ++e) {
+                    if constexpr (ARG) arg_combine_u32(key[e], idx[e], s_a[other * W + e], s_b[other * W + e]);
+                    else { acc[e] = V::apply(acc[e], __uint_as_float(s_a[other * W + e])); nan_seen[e] |= s_b[other * W + e] != 0u; }
+                }
+            }
+        }
+    }
+    if (ty != 0 || !live) return;
+    const uint64_t out_at = a.partial ? (o * a.chunks + c) * a.inner + i0 : o * a.inner + i0;
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+        if constexpr (ARG) {
+            if (a.partial) { a.out_key[out_at + e] = key[e]; a.out_idx[out_at + e] = idx[e]; }
+            else a.out_idx[out_at + e] = idx[e];
+        } else {
+            float t = acc[e];
+            if (V::TRACKS_NAN && nan_seen[e]) t = __uint_as_float(0x7FC00000u);
+            if (!a.partial && a.mean_div != 0.f) t = t / a.mean_div;
+            a.out_val[out_at + e] = t;
+        }
+    }
+}
+
+// thread / tile geometry of one stage: TX threads along inner (W elements each), chunks of the reduced axis
+struct axis_geom { uint32_t log2_tx, inner_blocks, chunks; uint64_t rows_per_chunk; };
+inline axis_geom axis_plan(uint64_t outer, uint64_t red, uint64_t inner, int w, uint64_t cus, bool allow_chunks)
+{
+    axis_geom g{};
+    const uint64_t vecs = (inner + w - 1) / w;
+    uint32_t l = 0;
+    while (l < 8 && (1ull << l) < vecs) ++l;                 // TX = smallest power of two covering the row, at most 256
+    g.log2_tx = l;
+    const uint64_t tx = 1ull << l, ty = 256 >> l;
+    g.inner_blocks = (uint32_t)((vecs + tx - 1) / tx);
+    const uint64_t base = std::max<uint64_t>(1, outer * g.inner_blocks);
+    uint64_t chunks = 1;
+    // workgroups per CU the cut aims at: ONE measured best (1 / 2 / 3 / 4 / 6 / 8 / 12 per CU, f32 sums, median of 15 samples, two rounds:
+    // 8192 x 8192 over axis 0 50 / 57 / 54 / 66 / 63 / 73 / 74 us, 4 x 65536 x 1024 over axis 1 165 / 169 / 179 / 183 / 200 / 217 / 240,
+    // 16384^2 over axis 0 166 / 176 / 167 / 179 / 175 / 213 / 192 -- more chunks only add partials and a longer second stage;
+    // profiles/r04_axis_wg_per_cu_sweep.txt)
+    static const uint64_t per_cu = [] { const char *e = getenv("MI355_AXIS_WG_PER_CU"); const int v = e ? atoi(e) : 1; return (uint64_t)(v > 0 ? v : 1); }();
+    if (allow_chunks && base < cus * per_cu) {
+        chunks = std::min<uint64_t>((cus * per_cu + base - 1) / base, std::max<uint64_t>(1, red / (ty * 16)));   // >= two unrolled trips per workgroup
+        chunks = std::min<uint64_t>(chunks, 1024);
+    }
+    uint64_t rows = (red + chunks - 1) / std::max<uint64_t>(chunks, 1);
+    rows = std::max<uint64_t>(ty, (rows + ty - 1) / ty * ty);
+    g.rows_per_chunk = rows;
+    g.chunks = (uint32_t)std::max<uint64_t>(1, (red + rows - 1) / rows);
+    return g;
 }
 
 template <int OP, int DT = MI355_DTYPE_F32>
@@ -615,22 +723,55 @@ int32_t run_mid(mi355_ctx *ctx, mi355_stream stream, const typename red_in<DT>::
                 uint64_t red, uint64_t inner, const char *what)
 {
     constexpr bool ARG = axis_op<OP>::ARG;
+    // the kernel folds SUM and divides at the very end for MEAN
+    constexpr int KOP = OP == MI355_REDUCE_MEAN ? MI355_REDUCE_SUM : OP;
     MI355_REQUIRE_CTX(ctx);
     if (outer == 0 || inner == 0) return MI355_OK;
     if ((red && !in) || (!ARG && !out_sum) || (ARG && !out_idx)) return fail(ctx, MI355_E_INVALID_ARGUMENT, "%s: NULL pointer", what);
     if (ARG && red > 0xFFFFFFFFull) return fail(ctx, MI355_E_UNSUPPORTED, "%s: reduced axis exceeds the u32 index range", what);
     hipStream_t s = stream_of(ctx, stream);
     const uint64_t cus = ctx->props.num_streaming_multiprocessors;
-    const uint64_t threads = outer * inner;                 // one per output with RSPLIT = 1
-    const bool split = threads < cus * 256 * 4 && red >= 64;
-#define MID(R)                                                                                                          \
-    do {                                                                                                                \
-        const uint64_t blocks = outer * ((inner + 256 / R - 1) / (256 / R));                                            \
-        const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, cus * 16));                    \
-        hipLaunchKernelGGL((reduce_mid_axis<OP, R, DT>), dim3(grid), dim3(256), 0, s, in, out_sum, out_idx, outer, red, inner); \
-    } while (0)
-    if (split) MID(8); else MID(1);
-#undef MID
+    constexpr int EPV = red_in<DT>::EPV;
+    const bool vec = (inner % EPV) == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
+    const float mean_div = OP == MI355_REDUCE_MEAN ? (red ? (float)red : __builtin_nanf("")) : 0.f;      // (an empty axis has no mean: 0 / 0)
+    axis_geom g = axis_plan(outer, red, inner, vec ? EPV : 1, cus, true);
+    if (outer * (uint64_t)g.inner_blocks * g.chunks > 0x7FFFFFFFull) return fail(ctx, MI355_E_UNSUPPORTED, "%s: too many tiles", what);
+    axis_args a{};
+    a.in = in; a.outer = outer; a.red = red; a.inner = inner;
+    a.log2_tx = g.log2_tx; a.inner_blocks = g.inner_blocks; a.chunks = g.chunks; a.rows_per_chunk = g.rows_per_chunk;
+    void *scratch = nullptr;
+    if (g.chunks > 1) {
+        const size_t per = (size_t)outer * g.chunks * inner * 4;
+        if (scratch_get(ctx, s, SCRATCH_REDUCE_AXIS, ARG ? 2 * per : per, &scratch) != MI355_OK) {     // no scratch: one workgroup per column block
+            g = axis_plan(outer, red, inner, vec ? EPV : 1, cus, false);
+            a.log2_tx = g.log2_tx; a.inner_blocks = g.inner_blocks; a.chunks = g.chunks; a.rows_per_chunk = g.rows_per_chunk;
+        }
+    }
+    const bool two = g.chunks > 1;
+    a.partial = two ? 1u : 0u;
+    a.mean_div = two ? 0.f : mean_div;
+    if (two) {
+        a.out_val = static_cast<float *>(scratch);
+        a.out_key = static_cast<uint32_t *>(scratch);
+        a.out_idx = static_cast<uint32_t *>(scratch) + (size_t)outer * g.chunks * inner;
+    } else { a.out_val = out_sum; a.out_idx = out_idx; }
+    const uint32_t grid1 = (uint32_t)(outer * (uint64_t)g.inner_blocks * g.chunks);
+    if (vec) hipLaunchKernelGGL((reduce_axis_tiled<KOP, DT, true, false>), dim3(grid1), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((reduce_axis_tiled<KOP, DT, false, false>), dim3(grid1), dim3(256), 0, s, a);
+    if (two) {
+        // stage 2: the partials as [outer][chunks][inner], one workgroup per column block (chunks <= 1024 rows)
+        const bool vec2 = !ARG && (inner % 4) == 0;
+        const axis_geom g2 = axis_plan(outer, g.chunks, inner, vec2 ? 4 : 1, cus, false);
+        axis_args b{};
+        b.in = scratch; b.in_key = static_cast<const uint32_t *>(scratch); b.in_idx = static_cast<const uint32_t *>(scratch) + (size_t)outer * g.chunks * inner;
+        b.outer = outer; b.red = g.chunks; b.inner = inner;
+        b.log2_tx = g2.log2_tx; b.inner_blocks = g2.inner_blocks; b.chunks = 1; b.rows_per_chunk = g2.rows_per_chunk;
+        b.partial = 0; b.mean_div = mean_div; b.out_val = out_sum; b.out_idx = out_idx;
+        const uint32_t grid2 = (uint32_t)(outer * (uint64_t)g2.inner_blocks);
+        if constexpr (ARG) hipLaunchKernelGGL((reduce_axis_tiled<KOP, MI355_DTYPE_F32, false, true>), dim3(grid2), dim3(256), 0, s, b);
+        else if (vec2) hipLaunchKernelGGL((reduce_axis_tiled<KOP, MI355_DTYPE_F32, true, false>), dim3(grid2), dim3(256), 0, s, b);
+        else hipLaunchKernelGGL((reduce_axis_tiled<KOP, MI355_DTYPE_F32, false, false>), dim3(grid2), dim3(256), 0, s, b);
+    }
     check_launch(ctx, what);
     return MI355_OK;
 }
