@@ -767,6 +767,38 @@ def main():
                                                    "book_wgpu_ms": ref_ms}
             return out
 
+        def reduce_axes():
+            # reductions over one axis of a contiguous tensor and the operations beside sum / argmax -- HBM-bound, the input
+            # read once; median of 15 samples (reference protocol), GB/s of input
+            from cubecl_amd import ops
+            out = {}
+            for shape, axis in (((8192, 8192), 0), ((8192, 8192), 1), ((4, 65536, 1024), 1), ((16384, 16384), 0), ((64, 256, 1024), 1)):
+                n = 1
+                for d_ in shape:
+                    n *= d_
+                m = n // shape[axis]
+                x = TensorHandle.uniform(client, shape, ElemType.F32, SEED, 820, -1.0, 1.0)
+                o = TensorHandle.new_contiguous((m,), client.empty(m * 4), ElemType.F32)
+                oi = TensorHandle.new_contiguous((m,), client.empty(m * 4), ElemType.U32)
+                ent = {}
+                for op in ("sum", "max", "argmax"):
+                    fn = (lambda: ops.argreduce_axis(client, x, oi, axis, op)) if op == "argmax" else (lambda: ops.reduce_axis(client, x, o, axis, op))
+                    med, _ = samples_op(client, ev, fn)
+                    ent[op] = {"median_us": round(med * 1e3, 1), "GBs": round(n * 4 / med / 1e6, 1)}
+                out["x".join(map(str, shape)) + f"_axis{axis}"] = ent
+                del x, o, oi
+            n = 1 << 28
+            x = TensorHandle.uniform(client, (n,), ElemType.F32, SEED, 300, 0.0, 1.0)
+            o = TensorHandle.new_contiguous((1,), client.empty(8), ElemType.F32)
+            oi = TensorHandle.new_contiguous((1,), client.empty(8), ElemType.U64)
+            ent = {}
+            for op in ("max", "min", "mean", "prod", "argmin"):
+                fn = (lambda: ops.argreduce(client, x, oi, None, op)) if op == "argmin" else (lambda: ops.reduce(client, x, o, op))
+                b2b = time_op(client, ev, fn, 20, warmup=3)
+                ent[op] = {"back_to_back_us": round(b2b * 1e3, 1), "GBs": round(n * 4 / b2b / 1e6, 1), "frac_of_8TBs": round(n * 4 / b2b / 1e6 / PEAK_HBM_GBS, 4)}
+            out["array_wide_1GiB_f32"] = ent
+            return out
+
         def sum_things_c1():
             # config C1: the reference's own CPU-runnable case (examples/sum_things: array-wide sum of 2^20 f32) -- launch-bound on a GPU
             n = 1 << 20
@@ -990,6 +1022,7 @@ def main():
         guarded("gemm_fp8_e4m3", gemm_fp8)
         guarded("gemm_block_scaled", gemm_mx)
         guarded("book_reduce_last_axis_f32", book_reduce)
+        guarded("reduce_axes_and_ops_f32", reduce_axes)
         guarded("measured_ceilings", probes)
         guarded("headline_kernel_operand_sensitivity", operand_sensitivity)
         guarded("sum_things_1M_f32", sum_things_c1)

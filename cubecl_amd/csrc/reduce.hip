@@ -503,25 +503,51 @@ reduce_rows(const typename red_in<DT>::elem *__restrict__ in, float *__restrict_
         float a0 = V::identity(), a1 = V::identity(), a2 = V::identity(), a3 = V::identity();
         bool nan_seen = false;
         uint32_t key = 0u; uint64_t idx = ~0ull;
+        // index operations: the value behind `key` -- a 16-byte vector only matters if it holds a NaN or something beyond it (the
+        // fast reject of reduce_kernel: the exact key update then runs on a few percent of the vectors)
+        constexpr bool AMIN = O::AOP == AOP_MIN;
+        constexpr float NAN_LEADS = AMIN ? -__builtin_inff() : __builtin_inff();
+        typedef vop<AMIN ? VOP_MIN : VOP_MAX> X;
+        float best_val = -NAN_LEADS;
         uint64_t done = 0;
         if (vec_ok) {
             const u32x4r *__restrict__ vp = reinterpret_cast<const u32x4r *>(p);
             const uint64_t nv = cols / EPV;
-            for (uint64_t i = tid; i < nv; i += THREADS) {
-                float v[EPV];
-                RI::unpack(vp[i], v);
-                if (!ARG) {
-                    a0 = V::apply(a0, v[0]); a1 = V::apply(a1, v[1]); a2 = V::apply(a2, v[2]); a3 = V::apply(a3, v[3]);
-                    if constexpr (EPV == 8) { a0 = V::apply(a0, v[4]); a1 = V::apply(a1, v[5]); a2 = V::apply(a2, v[6]); a3 = V::apply(a3, v[7]); }
-                    if constexpr (V::TRACKS_NAN) {
-                        nan_seen |= __builtin_isunordered(v[0], v[1]) | __builtin_isunordered(v[2], v[3]);
-                        if constexpr (EPV == 8) nan_seen |= __builtin_isunordered(v[4], v[5]) | __builtin_isunordered(v[6], v[7]);
-                    }
-                } else {
+            constexpr int UL = 4;                                   // 16-byte loads in flight per lane (the data is read once: non-temporal)
+            for (uint64_t i0 = tid; i0 < nv; i0 += (uint64_t)THREADS * UL) {
+                u32x4r raw[UL];
 #pragma unroll
-                    for (int c = 0; c < EPV; ++c) {
-                        const uint32_t k = arg_key<O::AOP>(v[c]);
-                        if (k > key) { key = k; idx = i * EPV + c; }
+                for (int u = 0; u < UL; ++u) {
+                    const uint64_t i = i0 + (uint64_t)u * THREADS;
+                    if (i < nv) raw[u] = __builtin_nontemporal_load(vp + i);
+                }
+#pragma unroll
+                for (int u = 0; u < UL; ++u) {
+                    const uint64_t i = i0 + (uint64_t)u * THREADS;
+                    if (i >= nv) break;
+                    float v[EPV];
+                    RI::unpack(raw[u], v);
+                    if (!ARG) {
+                        a0 = V::apply(a0, v[0]); a1 = V::apply(a1, v[1]); a2 = V::apply(a2, v[2]); a3 = V::apply(a3, v[3]);
+                        if constexpr (EPV == 8) { a0 = V::apply(a0, v[4]); a1 = V::apply(a1, v[5]); a2 = V::apply(a2, v[6]); a3 = V::apply(a3, v[7]); }
+                        if constexpr (V::TRACKS_NAN) {
+                            nan_seen |= __builtin_isunordered(v[0], v[1]) | __builtin_isunordered(v[2], v[3]);
+                            if constexpr (EPV == 8) nan_seen |= __builtin_isunordered(v[4], v[5]) | __builtin_isunordered(v[6], v[7]);
+                        }
+                    } else {
+                        float m4 = X::apply(X::apply(v[0], v[1]), X::apply(v[2], v[3]));
+                        bool has_nan = __builtin_isunordered(v[0], v[1]) | __builtin_isunordered(v[2], v[3]);
+                        if constexpr (EPV == 8) {
+                            m4 = X::apply(m4, X::apply(X::apply(v[4], v[5]), X::apply(v[6], v[7])));
+                            has_nan |= __builtin_isunordered(v[4], v[5]) | __builtin_isunordered(v[6], v[7]);
+                        }
+                        if ((AMIN ? (m4 < best_val) : (m4 > best_val)) | has_nan | (key == 0u)) {
+#pragma unroll
+                            for (int c = 0; c < EPV; ++c) {
+                                const uint32_t k = arg_key<O::AOP>(v[c]);
+                                if (k > key) { key = k; idx = i * EPV + c; best_val = (k == 0xFFFFFFFFu) ? NAN_LEADS : v[c]; }
+                            }
+                        }
                     }
                 }
             }
@@ -614,44 +640,72 @@ reduce_axis_tiled(axis_args a)
     float acc[W];
     uint32_t key[W], idx[W];
     bool nan_seen[W];
+    // index operations: acc[e] doubles as the value behind key[e] (nothing seen yet: NaN; a NaN in the lead: +inf / argmin -inf) -- a vector is
+    // keyed only if some element is beyond its column's value or a NaN; eight keys per 16 bytes of bf16 would otherwise make the kernel VALU-bound
+    constexpr bool AMIN = O::AOP == AOP_MIN;
+    constexpr float NAN_LEADS = AMIN ? -__builtin_inff() : __builtin_inff();
 #pragma unroll
-    for (int e = 0; e < W; ++e) { acc[e] = V::identity(); key[e] = 0u; idx[e] = 0u; nan_seen[e] = false; }
+    for (int e = 0; e < W; ++e) { acc[e] = ARG ? __builtin_nanf("") : V::identity(); key[e] = 0u; idx[e] = 0u; nan_seen[e] = false; }
 
     if (live) {
         const uint64_t base = (o * a.red) * a.inner + i0;
-        for (uint64_t r = r0 + ty; r < r1; r += (uint64_t)TY * U) {
-            float v[U][W];
-            uint32_t pk[U], pi[U];
+        // one row's W elements (or one partial pair) into the running state
+        auto consume = [&](const float (&x)[W], uint32_t row) {
+            if constexpr (ARG) {
+                // One test per VECTOR (a branch per element cost more than the keys it saved): "not (x <= running extremum)" is true for
+                // an element beyond it, for a NaN, and while the column has seen nothing (acc starts as NaN); once a NaN leads acc is
+                // +inf (argmin: -inf) and only another NaN passes, to lose on the key.
+                bool cand = false;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint64_t rr = r + (uint64_t)u * TY;
-                if (rr < r1) {
-                    const uint64_t at = base + rr * a.inner;
-                    if constexpr (PAIRS) { pk[u] = a.in_key[at]; pi[u] = a.in_idx[at]; }
-                    else if constexpr (VECTOR) RI::unpack(__builtin_nontemporal_load(reinterpret_cast<const u32x4r *>(static_cast<const typename RI::elem *>(a.in) + at)), v[u]);
-                    else v[u][0] = RI::widen(static_cast<const typename RI::elem *>(a.in)[at]);
-                }
-            }
+                for (int e = 0; e < W; ++e) cand |= AMIN ? !(x[e] >= acc[e]) : !(x[e] <= acc[e]);
+                if (cand) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint64_t rr = r + (uint64_t)u * TY;
-                if (rr < r1) {
-                    if constexpr (PAIRS) {
-                        arg_combine_u32(key[0], idx[0], pk[u], pi[u]);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < W; ++e) {
-                            if constexpr (ARG) {
-                                const uint32_t k = arg_key<O::AOP>(v[u][e]);
-                                if (k > key[e]) { key[e] = k; idx[e] = (uint32_t)rr; }       // rows ascend per thread: the first extremum stays
-                            } else {
-                                acc[e] = V::apply(acc[e], v[u][e]);
-                                if (V::TRACKS_NAN) nan_seen[e] |= (v[u][e] != v[u][e]);
-                            }
-                        }
+                    for (int e = 0; e < W; ++e) {
+                        const uint32_t k = arg_key<O::AOP>(x[e]);
+                        const bool take = k > key[e];                    // rows ascend per thread: the first extremum stays
+                        key[e] = take ? k : key[e];
+                        idx[e] = take ? row : idx[e];
+                        acc[e] = take ? ((k == 0xFFFFFFFFu) ? NAN_LEADS : x[e]) : acc[e];
                     }
                 }
+            } else {
+#pragma unroll
+                for (int e = 0; e < W; ++e) {
+                    acc[e] = V::apply(acc[e], x[e]);
+                    if (V::TRACKS_NAN) nan_seen[e] |= (x[e] != x[e]);
+                }
             }
+        };
+        auto load_raw = [&](uint64_t rr, u32x4r &raw, typename RI::elem &one, uint32_t &pk, uint32_t &pi) {
+            const uint64_t at = base + rr * a.inner;
+            if constexpr (PAIRS) { pk = a.in_key[at]; pi = a.in_idx[at]; }
+            else if constexpr (VECTOR) raw = __builtin_nontemporal_load(reinterpret_cast<const u32x4r *>(static_cast<const typename RI::elem *>(a.in) + at));
+            else one = static_cast<const typename RI::elem *>(a.in)[at];
+        };
+        auto take_raw = [&](uint64_t rr, const u32x4r &raw, typename RI::elem one, uint32_t pk, uint32_t pi) {
+            if constexpr (PAIRS) arg_combine_u32(key[0], idx[0], pk, pi);
+            else {
+                float x[W];
+                if constexpr (VECTOR) RI::unpack(raw, x); else x[0] = RI::widen(one);
+                consume(x, (uint32_t)rr);
+            }
+        };
+        uint64_t r = r0 + ty;
+        // full groups of U rows: all U loads first, RAW (a 16-bit vector is unpacked only when it is consumed -- unpacking inside the load
+        // loop made every load wait for the one before it: one load in flight, 2.3 TB/s on bf16 where f32 ran 6.5), no bounds tests
+        for (; r + (uint64_t)(U - 1) * TY < r1; r += (uint64_t)TY * U) {
+            u32x4r raw[U];
+            typename RI::elem one[U];
+            uint32_t pk[U], pi[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) load_raw(r + (uint64_t)u * TY, raw[u], one[u], pk[u], pi[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) take_raw(r + (uint64_t)u * TY, raw[u], one[u], pk[u], pi[u]);
+        }
+        for (; r < r1; r += TY) {                                 // the ragged rest, one row at a time
+            u32x4r raw; typename RI::elem one; uint32_t pk, pi;
+            load_raw(r, raw, one, pk, pi);
+            take_raw(r, raw, one, pk, pi);
         }
     }
     // ---- the TY partial vectors of a column meet in LDS, folded by the ty == 0 thread in ty order ----------------------------
