@@ -639,13 +639,13 @@ reduce_axis_tiled(axis_args a)
 
     float acc[W];
     uint32_t key[W], idx[W];
-    bool nan_seen[W];
+    uint32_t nanbits = 0u;           // max / min: bit e = column e of this thread has seen a NaN (one VGPR; W booleans lived in SGPR pairs and spilled)
     // index operations: acc[e] doubles as the value behind key[e] (nothing seen yet: NaN; a NaN in the lead: +inf / argmin -inf) -- a vector is
     // keyed only if some element is beyond its column's value or a NaN; eight keys per 16 bytes of bf16 would otherwise make the kernel VALU-bound
     constexpr bool AMIN = O::AOP == AOP_MIN;
     constexpr float NAN_LEADS = AMIN ? -__builtin_inff() : __builtin_inff();
 #pragma unroll
-    for (int e = 0; e < W; ++e) { acc[e] = ARG ? __builtin_nanf("") : V::identity(); key[e] = 0u; idx[e] = 0u; nan_seen[e] = false; }
+    for (int e = 0; e < W; ++e) { acc[e] = ARG ? __builtin_nanf("") : V::identity(); key[e] = 0u; idx[e] = 0u; }
 
     if (live) {
         const uint64_t base = (o * a.red) * a.inner + i0;
@@ -672,7 +672,7 @@ reduce_axis_tiled(axis_args a)
 #pragma unroll
                 for (int e = 0; e < W; ++e) {
                     acc[e] = V::apply(acc[e], x[e]);
-                    if (V::TRACKS_NAN) nan_seen[e] |= (x[e] != x[e]);
+                    if (V::TRACKS_NAN) nanbits |= (x[e] != x[e]) ? (1u << e) : 0u;
                 }
             }
         };
@@ -713,7 +713,7 @@ reduce_axis_tiled(axis_args a)
 #pragma unroll
         for (int e = 0; e < W; ++e) {
             s_a[tid * W + e] = ARG ? key[e] : __float_as_uint(acc[e]);
-            s_b[tid * W + e] = ARG ? idx[e] : (nan_seen[e] ? 1u : 0u);
+            s_b[tid * W + e] = ARG ? idx[e] : ((nanbits >> e) & 1u);
         }
         __syncthreads();
         if (ty == 0) {
@@ -722,7 +722,7 @@ reduce_axis_tiled(axis_args a)
 #pragma unroll
                 for (int e = 0; e < W; ++e) {
                     if constexpr (ARG) arg_combine_u32(key[e], idx[e], s_a[other * W + e], s_b[other * W + e]);
-                    else { acc[e] = V::apply(acc[e], __uint_as_float(s_a[other * W + e])); nan_seen[e] |= s_b[other * W + e] != 0u; }
+                    else { acc[e] = V::apply(acc[e], __uint_as_float(s_a[other * W + e])); nanbits |= s_b[other * W + e] << e; }
                 }
             }
         }
@@ -736,7 +736,7 @@ reduce_axis_tiled(axis_args a)
             else a.out_idx[out_at + e] = idx[e];
         } else {
             float t = acc[e];
-            if (V::TRACKS_NAN && nan_seen[e]) t = __uint_as_float(0x7FC00000u);
+            if (V::TRACKS_NAN && ((nanbits >> e) & 1u)) t = __uint_as_float(0x7FC00000u);
             if (!a.partial && a.mean_div != 0.f) t = t / a.mean_div;
             a.out_val[out_at + e] = t;
         }

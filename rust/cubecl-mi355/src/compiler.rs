@@ -29,6 +29,10 @@ pub enum ReduceKind {
     RowSum,
     /// `mi355_reduce_last_axis_argmax`: one u32 per row.
     RowArgmax,
+    /// `mi355_reduce` with a value operation (`MI355_REDUCE_SUM / MEAN / MAX / MIN / PROD`): whole-buffer, f32 result.
+    Value(i32),
+    /// `mi355_argreduce` with an index operation (`MI355_REDUCE_ARGMAX / ARGMIN`): value and index of the first extremum.
+    Index(i32),
 }
 
 /// A launch the library serves with ahead-of-time code.  Shapes are part of the descriptor the way comptime arguments
@@ -41,6 +45,9 @@ pub enum NativeOp {
     GemmAdd(GemmKey),
     /// Buffers: input, then the outputs the kind has (sum / value / index), then the workspace for the whole-buffer kinds.
     Reduce { kind: ReduceKind, dtype: i32, rows: u64, cols: u64, row_stride: u64 },
+    /// `mi355_reduce_axis` / `mi355_argreduce_axis` over one axis of a contiguous `[outer][reduce][inner]` view; buffers: input, output
+    /// (f32 values for a value operation, u32 indices for `MI355_REDUCE_ARGMAX / ARGMIN`).
+    ReduceAxis { op: i32, dtype: i32, outer: u64, reduce: u64, inner: u64 },
 }
 
 /// `mi355_gemm_desc` with `Eq + Hash` (the C struct is all integers).

@@ -121,6 +121,95 @@ pub fn sum_argmax(client: &ComputeClient<Mi355Runtime>, input: &Tensor, out_sum:
     Ok(())
 }
 
+/// The value operations of `mi355_reduce` / `mi355_reduce_axis` (plane-level forms: `crates/cubecl-core/src/frontend/plane.rs:218`
+/// sum, `:285` prod, `:352` max, `:370` min; `ReduceOperation::Mean`: `crates/cubecl-runtime/src/server/base.rs:623-628`).
+#[derive(Debug, Clone, Copy, PartialEq, Eq)]
+pub enum ValueOp {
+    Sum,
+    Mean,
+    Max,
+    Min,
+    Prod,
+}
+
+impl ValueOp {
+    fn code(self) -> i32 {
+        match self {
+            ValueOp::Sum => MI355_REDUCE_SUM,
+            ValueOp::Mean => MI355_REDUCE_MEAN,
+            ValueOp::Max => MI355_REDUCE_MAX,
+            ValueOp::Min => MI355_REDUCE_MIN,
+            ValueOp::Prod => MI355_REDUCE_PROD,
+        }
+    }
+}
+
+/// The index operations of `mi355_argreduce` / `mi355_argreduce_axis`: lowest index of the extremum, `-0 == +0`, the first NaN wins.
+#[derive(Debug, Clone, Copy, PartialEq, Eq)]
+pub enum IndexOp {
+    ArgMax,
+    ArgMin,
+}
+
+impl IndexOp {
+    fn code(self) -> i32 {
+        match self {
+            IndexOp::ArgMax => MI355_REDUCE_ARGMAX,
+            IndexOp::ArgMin => MI355_REDUCE_ARGMIN,
+        }
+    }
+}
+
+/// Any value reduction of every element into `out[0]` (f32) (`mi355_reduce`; max / min: NaN if any element is NaN, `-0 < +0`).
+pub fn reduce(client: &ComputeClient<Mi355Runtime>, input: &Tensor, out: &Tensor, op: ValueOp) -> Result<(), ServerError> {
+    let (task, n) = whole(ReduceKind::Value(op.code()), input)?;
+    let scratch = workspace(client, n)?;
+    client.launch(Box::new(task), CubeCount::new_single(), buffers(&[&input.handle, &out.handle, &scratch]));
+    Ok(())
+}
+
+/// Value (f32) and index (u64) of the first extremum (`mi355_argreduce`).
+pub fn argreduce(client: &ComputeClient<Mi355Runtime>, input: &Tensor, out_value: &Tensor, out_index: &Tensor, op: IndexOp) -> Result<(), ServerError> {
+    let (task, n) = whole(ReduceKind::Index(op.code()), input)?;
+    let scratch = workspace(client, n)?;
+    client.launch(Box::new(task), CubeCount::new_single(), buffers(&[&input.handle, &out_value.handle, &out_index.handle, &scratch]));
+    Ok(())
+}
+
+/// `[outer][reduce][inner]` of a contiguous tensor around `axis`.
+fn around(input: &Tensor, axis: usize) -> Result<(u64, u64, u64), ServerError> {
+    let shape = input.shape();
+    if axis >= shape.len() {
+        return Err(refuse("axis out of range"));
+    }
+    let mut expect = 1usize;
+    for d in (0..shape.len()).rev() {
+        if shape[d] != 1 && input.strides()[d] != expect {
+            return Err(refuse("axis reductions need a contiguous tensor"));
+        }
+        expect *= shape[d];
+    }
+    let outer: u64 = shape[..axis].iter().map(|d| *d as u64).product();
+    let inner: u64 = shape[axis + 1..].iter().map(|d| *d as u64).product();
+    Ok((outer, shape[axis] as u64, inner))
+}
+
+/// A value reduction over one axis: `out` has the input's shape minus that axis, f32 (`mi355_reduce_axis`).
+pub fn reduce_axis(client: &ComputeClient<Mi355Runtime>, input: &Tensor, out: &Tensor, axis: usize, op: ValueOp) -> Result<(), ServerError> {
+    let (outer, reduce, inner) = around(input, axis)?;
+    let op = NativeOp::ReduceAxis { op: op.code(), dtype: wire(input.dtype)?, outer, reduce, inner };
+    client.launch(Box::new(NativeTask { op }), CubeCount::new_single(), buffers(&[&input.handle, &out.handle]));
+    Ok(())
+}
+
+/// An index reduction over one axis: u32 indices along it (`mi355_argreduce_axis`).
+pub fn argreduce_axis(client: &ComputeClient<Mi355Runtime>, input: &Tensor, out: &Tensor, axis: usize, op: IndexOp) -> Result<(), ServerError> {
+    let (outer, reduce, inner) = around(input, axis)?;
+    let op = NativeOp::ReduceAxis { op: op.code(), dtype: wire(input.dtype)?, outer, reduce, inner };
+    client.launch(Box::new(NativeTask { op }), CubeCount::new_single(), buffers(&[&input.handle, &out.handle]));
+    Ok(())
+}
+
 /// Per-row sum of a `[rows, cols]` tensor with unit column stride (`mi355_reduce_last_axis_sum`).
 pub fn reduce_sum_rows(client: &ComputeClient<Mi355Runtime>, input: &Tensor, out: &Tensor) -> Result<(), ServerError> {
     rows(client, ReduceKind::RowSum, input, out)

@@ -453,7 +453,18 @@ fn run_native(ctx: *mut mi355_ctx, sys: mi355_stream, op: NativeOp, b: &[DeviceS
                 ReduceKind::RowArgmax if b.len() >= 2 => {
                     mi355_reduce_last_axis_argmax(ctx, sys, b[0].ptr, dtype, b[1].ptr as *mut u32, rows, cols, row_stride)
                 }
+                ReduceKind::Value(code) if b.len() >= 3 => mi355_reduce(ctx, sys, b[0].ptr, dtype, cols, code, b[1].ptr as *mut f32, b[2].ptr, b[2].size),
+                ReduceKind::Index(code) if b.len() >= 4 => {
+                    mi355_argreduce(ctx, sys, b[0].ptr, dtype, cols, code, b[1].ptr as *mut f32, b[2].ptr as *mut u64, b[3].ptr, b[3].size)
+                }
                 _ => MI355_E_INVALID_ARGUMENT,
+            },
+            NativeOp::ReduceAxis { op: code, dtype, outer, reduce, inner } => match need(2) {
+                MI355_OK if code == MI355_REDUCE_ARGMAX || code == MI355_REDUCE_ARGMIN => {
+                    mi355_argreduce_axis(ctx, sys, b[0].ptr, dtype, code, b[1].ptr as *mut u32, outer, reduce, inner)
+                }
+                MI355_OK => mi355_reduce_axis(ctx, sys, b[0].ptr, dtype, code, b[1].ptr as *mut f32, outer, reduce, inner),
+                rc => rc,
             },
         }
     }

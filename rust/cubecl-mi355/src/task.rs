@@ -38,6 +38,7 @@ impl NativeTask {
             NativeOp::Gemm(_) => "mi355_gemm",
             NativeOp::GemmAdd(_) => "mi355_gemm_add",
             NativeOp::Reduce { .. } => "mi355_reduce",
+            NativeOp::ReduceAxis { .. } => "mi355_reduce_axis",
         }
     }
 }
