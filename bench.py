@@ -500,8 +500,11 @@ def main():
 
     # the same launch under the reference's Benchmark protocol (crates/cubecl-common/src/benchmark.rs:160-300: sync around every
     # sample), outside the timed region: the fixed name every config's second figure carries
-    med_ms, _ = samples_op(client, ev, step)
-    result["roofline"]["frac_per_sample_median"] = round(flop / med_ms / 1e9 / PEAK_BF16_TFLOPS, 4)
+    # (with the extras only: `--no-extras` is the command the rocprofv3 summary profiles, whose per-kernel average should be that of
+    # the warm-up + timed launches and nothing else)
+    if not args.no_extras:
+        med_ms, _ = samples_op(client, ev, step)
+        result["roofline"]["frac_per_sample_median"] = round(flop / med_ms / 1e9 / PEAK_BF16_TFLOPS, 4)
     libs = mapped_libraries()
     for key in ("libamdhip64", "librccl"):          # which copies serve this process (flat strings: the driver's record keeps scalars)
         result["config"][key] = str(libs.get(key, "not mapped"))
