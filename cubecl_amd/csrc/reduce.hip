@@ -609,6 +609,8 @@ struct axis_args {
     uint64_t outer, red, inner;
     uint64_t rows_per_chunk;        // rows of the reduced axis per workgroup (multiple of TY)
     uint32_t chunks, inner_blocks, log2_tx, partial;
+    uint32_t log2_ty;               // TY = threads along the reduced axis; the remaining 256 / (TX x TY) thread groups take one `outer` slice each
+    uint64_t outer_blocks;          // workgroups along `outer` (OY slices each)
     float mean_div;                 // != 0: the final value is sum / mean_div
 };
 
@@ -625,16 +627,19 @@ reduce_axis_tiled(axis_args a)
     static_assert(!PAIRS || (ARG && !VECTOR), "pair input: the second stage of an index operation, one position per thread");
     __shared__ uint32_t s_a[256 * W], s_b[256 * W];         // per thread: W values (or keys) and W NaN flags (or row indices)
 
-    const uint32_t tid = threadIdx.x, TX = 1u << a.log2_tx, TY = 256u >> a.log2_tx;
-    const uint32_t tx = tid & (TX - 1), ty = tid >> a.log2_tx;
-    // linear workgroup id -> (outer o, chunk c, inner block ib), inner block fastest
+    // thread -> (outer slice oy of this workgroup, row lane ty, column lane tx): a short axis under a narrow `inner` leaves most of a
+    // 256-thread tile without rows, so the spare threads take further `outer` slices (1 048 576 x 16 x 4 over axis 1: one workgroup
+    // per 128 slices = 32 KiB contiguous, instead of one workgroup per slice)
+    const uint32_t tid = threadIdx.x, TX = 1u << a.log2_tx, TY = 1u << a.log2_ty, OY = 256u >> (a.log2_tx + a.log2_ty);
+    const uint32_t tx = tid & (TX - 1), ty = (tid >> a.log2_tx) & (TY - 1), oy = tid >> (a.log2_tx + a.log2_ty);
+    // linear workgroup id -> (outer block ob, chunk c, inner block ib), inner block fastest
     const uint64_t wg = blockIdx.x;
     const uint32_t ib = (uint32_t)(wg % a.inner_blocks);
     const uint64_t rest = wg / a.inner_blocks;
     const uint32_t c = (uint32_t)(rest % a.chunks);
-    const uint64_t o = rest / a.chunks;
+    const uint64_t o = (rest / a.chunks) * OY + oy;
     const uint64_t i0 = ((uint64_t)ib * TX + tx) * W;
-    const bool live = i0 < a.inner;
+    const bool live = i0 < a.inner && o < a.outer;
     const uint64_t r0 = (uint64_t)c * a.rows_per_chunk, r1 = min(a.red, r0 + a.rows_per_chunk);
 
     float acc[W];
@@ -718,7 +723,7 @@ reduce_axis_tiled(axis_args a)
         __syncthreads();
         if (ty == 0) {
             for (uint32_t t = 1; t < TY; ++t) {
-                const uint32_t other = (t << a.log2_tx) + tx;
+                const uint32_t other = (oy << (a.log2_tx + a.log2_ty)) + (t << a.log2_tx) + tx;
 #pragma unroll
                 for (int e = 0; e < W; ++e) {
                     if constexpr (ARG) arg_combine_u32(key[e], idx[e], s_a[other * W + e], s_b[other * W + e]);
@@ -744,7 +749,7 @@ reduce_axis_tiled(axis_args a)
 }
 
 // thread / tile geometry of one stage: TX threads along inner (W elements each), chunks of the reduced axis
-struct axis_geom { uint32_t log2_tx, inner_blocks, chunks; uint64_t rows_per_chunk; };
+struct axis_geom { uint32_t log2_tx, log2_ty, inner_blocks, chunks; uint64_t rows_per_chunk, outer_blocks; };
 inline axis_geom axis_plan(uint64_t outer, uint64_t red, uint64_t inner, int w, uint64_t cus, bool allow_chunks)
 {
     axis_geom g{};
@@ -752,9 +757,16 @@ inline axis_geom axis_plan(uint64_t outer, uint64_t red, uint64_t inner, int w, 
     uint32_t l = 0;
     while (l < 8 && (1ull << l) < vecs) ++l;                 // TX = smallest power of two covering the row, at most 256
     g.log2_tx = l;
-    const uint64_t tx = 1ull << l, ty = 256 >> l;
+    const uint64_t tx = 1ull << l;
+    // row lanes: as many as the tile has left, but no more than give every thread about eight rows (one unrolled trip)
+    uint32_t lt = 0;
+    while ((tx << (lt + 1)) <= 256 && (8ull << (lt + 1)) <= std::max<uint64_t>(red, 8)) ++lt;
+    if (outer == 1) lt = 8 - l;                               // nothing else to give the spare threads to
+    g.log2_ty = lt;
+    const uint64_t ty = 1ull << lt, oy = 256 / (tx * ty);
+    g.outer_blocks = (outer + oy - 1) / oy;
     g.inner_blocks = (uint32_t)((vecs + tx - 1) / tx);
-    const uint64_t base = std::max<uint64_t>(1, outer * g.inner_blocks);
+    const uint64_t base = std::max<uint64_t>(1, g.outer_blocks * g.inner_blocks);
     uint64_t chunks = 1;
     // workgroups per CU the cut aims at: ONE measured best (1 / 2 / 3 / 4 / 6 / 8 / 12 per CU, f32 sums, median of 15 samples, two rounds:
     // 8192 x 8192 over axis 0 50 / 57 / 54 / 66 / 63 / 73 / 74 us, 4 x 65536 x 1024 over axis 1 165 / 169 / 179 / 183 / 200 / 217 / 240,
@@ -789,16 +801,20 @@ int32_t run_mid(mi355_ctx *ctx, mi355_stream stream, const typename red_in<DT>::
     const bool vec = (inner % EPV) == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
     const float mean_div = OP == MI355_REDUCE_MEAN ? (red ? (float)red : __builtin_nanf("")) : 0.f;      // (an empty axis has no mean: 0 / 0)
     axis_geom g = axis_plan(outer, red, inner, vec ? EPV : 1, cus, true);
-    if (outer * (uint64_t)g.inner_blocks * g.chunks > 0x7FFFFFFFull) return fail(ctx, MI355_E_UNSUPPORTED, "%s: too many tiles", what);
+    if (g.outer_blocks * (uint64_t)g.inner_blocks * g.chunks > 0x7FFFFFFFull) return fail(ctx, MI355_E_UNSUPPORTED, "%s: too many tiles", what);
     axis_args a{};
     a.in = in; a.outer = outer; a.red = red; a.inner = inner;
-    a.log2_tx = g.log2_tx; a.inner_blocks = g.inner_blocks; a.chunks = g.chunks; a.rows_per_chunk = g.rows_per_chunk;
+    auto set_geom = [](axis_args &x, const axis_geom &q) {
+        x.log2_tx = q.log2_tx; x.log2_ty = q.log2_ty; x.inner_blocks = q.inner_blocks; x.chunks = q.chunks; x.rows_per_chunk = q.rows_per_chunk;
+        x.outer_blocks = q.outer_blocks;
+    };
+    set_geom(a, g);
     void *scratch = nullptr;
     if (g.chunks > 1) {
         const size_t per = (size_t)outer * g.chunks * inner * 4;
         if (scratch_get(ctx, s, SCRATCH_REDUCE_AXIS, ARG ? 2 * per : per, &scratch) != MI355_OK) {     // no scratch: one workgroup per column block
             g = axis_plan(outer, red, inner, vec ? EPV : 1, cus, false);
-            a.log2_tx = g.log2_tx; a.inner_blocks = g.inner_blocks; a.chunks = g.chunks; a.rows_per_chunk = g.rows_per_chunk;
+            set_geom(a, g);
         }
     }
     const bool two = g.chunks > 1;
@@ -809,7 +825,7 @@ int32_t run_mid(mi355_ctx *ctx, mi355_stream stream, const typename red_in<DT>::
         a.out_key = static_cast<uint32_t *>(scratch);
         a.out_idx = static_cast<uint32_t *>(scratch) + (size_t)outer * g.chunks * inner;
     } else { a.out_val = out_sum; a.out_idx = out_idx; }
-    const uint32_t grid1 = (uint32_t)(outer * (uint64_t)g.inner_blocks * g.chunks);
+    const uint32_t grid1 = (uint32_t)(g.outer_blocks * (uint64_t)g.inner_blocks * g.chunks);
     if (vec) hipLaunchKernelGGL((reduce_axis_tiled<KOP, DT, true, false>), dim3(grid1), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((reduce_axis_tiled<KOP, DT, false, false>), dim3(grid1), dim3(256), 0, s, a);
     if (two) {
@@ -819,9 +835,10 @@ int32_t run_mid(mi355_ctx *ctx, mi355_stream stream, const typename red_in<DT>::
         axis_args b{};
         b.in = scratch; b.in_key = static_cast<const uint32_t *>(scratch); b.in_idx = static_cast<const uint32_t *>(scratch) + (size_t)outer * g.chunks * inner;
         b.outer = outer; b.red = g.chunks; b.inner = inner;
-        b.log2_tx = g2.log2_tx; b.inner_blocks = g2.inner_blocks; b.chunks = 1; b.rows_per_chunk = g2.rows_per_chunk;
+        set_geom(b, g2);
+        b.chunks = 1;
         b.partial = 0; b.mean_div = mean_div; b.out_val = out_sum; b.out_idx = out_idx;
-        const uint32_t grid2 = (uint32_t)(outer * (uint64_t)g2.inner_blocks);
+        const uint32_t grid2 = (uint32_t)(g2.outer_blocks * (uint64_t)g2.inner_blocks);
         if constexpr (ARG) hipLaunchKernelGGL((reduce_axis_tiled<KOP, MI355_DTYPE_F32, false, true>), dim3(grid2), dim3(256), 0, s, b);
         else if (vec2) hipLaunchKernelGGL((reduce_axis_tiled<KOP, MI355_DTYPE_F32, true, false>), dim3(grid2), dim3(256), 0, s, b);
         else hipLaunchKernelGGL((reduce_axis_tiled<KOP, MI355_DTYPE_F32, false, false>), dim3(grid2), dim3(256), 0, s, b);

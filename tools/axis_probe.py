@@ -10,7 +10,8 @@ from cubecl_amd import _native as N
 cl = Mi355Runtime.client(); lib, ctx = cl.lib, cl.ctx
 ev = bench.Events(cl)
 CASES = [((64, 256, 1024), 2), ((64, 256, 1024), 1), ((64, 256, 1024), 0), ((64, 64, 4096), 1), ((512, 8192), 0), ((8192, 8192), 1), ((8192, 8192), 0),
-         ((16, 4096, 4096), 1), ((4096, 16, 4096), 1), ((4, 65536, 1024), 1), ((1 << 14, 1 << 14), 0), ((256, 1 << 20), 1)]
+         ((16, 4096, 4096), 1), ((4096, 16, 4096), 1), ((4, 65536, 1024), 1), ((1 << 14, 1 << 14), 0), ((256, 1 << 20), 1),
+         ((1 << 20, 16, 4), 1), ((1 << 16, 8, 64), 1), ((1 << 20, 3, 8), 1), ((1 << 18, 128, 2), 1)]       # short axis under a narrow inner
 for dtype in (ElemType.F32, ElemType.BF16):
     for shape, axis in CASES:
         n = 1
