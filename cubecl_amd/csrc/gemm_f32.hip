@@ -50,7 +50,13 @@ gemm_f32_mfma_kernel(gemm_args g)
     const int64_t batch = batch_u;
     const float *__restrict__ A = static_cast<const float *>(g.a) + batch * g.stride_a;
     const float *__restrict__ B = static_cast<const float *>(g.b) + batch * g.stride_b;
-    float *__restrict__ C = static_cast<float *>(g.c) + batch * g.stride_c;
+    // split-K (round 4): K slice z of g.split_k covers K-tiles [kt0, kt0 + nk) and writes partial slab z (f32, folded in slice order by
+    // gemm_splitk.hip) -- 1024^3 has 64 tiles for 256 CUs: 74.5 us unsplit, the bound of a 128 x 128 x 1024 tile on one CU's f32 matrix pipe
+    const int nk_total = (int)(g.k / BK);
+    const int z = (g.split_k > 1) ? (int)blockIdx.z : 0;
+    const int per = (nk_total + (int)max(g.split_k, 1u) - 1) / (int)max(g.split_k, 1u);
+    const int kt0 = z * per;
+    float *__restrict__ C = static_cast<float *>(g.c) + batch * g.stride_c + (int64_t)z * g.split_c_stride;
 
     // ---- global -> register staging map (4 x float4 per operand per thread) -----------------
     const float *pa[4];
@@ -62,18 +68,18 @@ gemm_f32_mfma_kernel(gemm_args g)
         {
             const int row = lin >> 3, c4 = lin & 7;
             const int64_t m = min(m0 + row, g.m - 1);
-            pa[e] = A + m * g.lda + c4 * 4;
+            pa[e] = A + m * g.lda + c4 * 4 + (int64_t)kt0 * BK;
             wa[e] = row * LDK + c4 * 4;
         }
         if (TRANS_B) {
             const int row = lin >> 3, c4 = lin & 7;
             const int64_t n = min(n0 + row, g.n - 1);
-            pb[e] = B + n * g.ldb + c4 * 4;
+            pb[e] = B + n * g.ldb + c4 * 4 + (int64_t)kt0 * BK;
             wb[e] = row * LDK + c4 * 4;
         } else {
             const int krow = lin >> 5, c4 = lin & 31;
             const int64_t n = min(n0 + c4 * 4, g.n - 4);
-            pb[e] = B + (int64_t)krow * g.ldb + n;
+            pb[e] = B + ((int64_t)krow + (int64_t)kt0 * BK) * g.ldb + n;
             wb[e] = krow * LDN + c4 * 4;
         }
     }
@@ -95,7 +101,7 @@ gemm_f32_mfma_kernel(gemm_args g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (int)(g.k / BK);
+    const int nk = min(per, nk_total - kt0);              // (the launcher leaves no slice empty)
     f32x4 ga[4], gb[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -212,7 +218,25 @@ int32_t launch_gemm_f32_mfma(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_des
     g.tiles_m = (uint32_t)((d.m + BM - 1) / BM);
     g.tiles_n = (uint32_t)((d.n + BN - 1) / BN);
     g.group_m = 8;
-    const dim3 grid(g.tiles_m * g.tiles_n, (uint32_t)d.batch);
+    // Split-K when the tiles cannot fill the chip and K is long enough to cut: the slabs are f32 like the result, so the fold adds
+    // (splits + 1) x M x N x 4 bytes of traffic -- kept below the operand bytes.  1024^3: 64 tiles x 4 slices.
+    const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * std::max<int64_t>(d.batch, 1), cus = ctx->props.num_streaming_multiprocessors;
+    const int64_t nk_all = d.k / BK;
+    int64_t splits = 1;
+    if (tiles * 2 <= cus && nk_all >= 16) {
+        splits = std::min<int64_t>({cus / tiles, nk_all / 8, 16});
+        // worth it while the time the cut saves (a 128 x 128 x K tile on one CU's f32 matrix pipe: 614 GFLOP/s) is at least twice what the
+        // slabs cost (written once, read once, ~3 TB/s) plus the fold's launch
+        const double tile_us = 2.0 * BM * BN * (double)d.k / 614e3, slab_us = (double)(d.batch * d.m * d.n * 4) / 3e6;
+        while (splits > 1 && (splits + 1) * slab_us + 3.0 > 0.5 * tile_us * (1.0 - 1.0 / (double)splits)) --splits;
+        if (splits > 1) { const int64_t per = (nk_all + splits - 1) / splits; splits = (nk_all + per - 1) / per; }   // no empty slices
+    }
+    float *ws = nullptr;
+    if (splits > 1 && splitk_scratch(ctx, s, (size_t)(splits * d.batch * d.m * d.n) * sizeof(float), &ws) == MI355_OK) {
+        g.c = ws; g.ldc = d.n; g.stride_c = d.m * d.n;
+        g.split_k = (uint32_t)splits; g.split_c_stride = d.batch * d.m * d.n;
+    } else splits = 1;
+    const dim3 grid(g.tiles_m * g.tiles_n, (uint32_t)d.batch, (uint32_t)splits);
     const size_t lds = sizeof(f32_smem);
     // the dynamic-LDS attribute is per device: remember it per context, not in a process-wide static
     const void *fn = d.trans_b ? reinterpret_cast<const void *>(gemm_f32_mfma_kernel<true>)
@@ -221,6 +245,10 @@ int32_t launch_gemm_f32_mfma(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_des
     if (d.trans_b) hipLaunchKernelGGL(gemm_f32_mfma_kernel<true>, grid, dim3(256), lds, s, g);
     else hipLaunchKernelGGL(gemm_f32_mfma_kernel<false>, grid, dim3(256), lds, s, g);
     check_launch(ctx, "mi355_gemm(f32 mfma)");
+    if (splits > 1) {
+        launch_splitk_fold(s, ws, (uint32_t)splits, d.batch * d.m * d.n, d.batch, d.m, d.n, c, MI355_DTYPE_F32, d.ldc, d.stride_c);
+        check_launch(ctx, "mi355_gemm(f32 split-K fold)");
+    }
     return MI355_OK;
 }
 

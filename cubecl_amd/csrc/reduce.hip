@@ -883,11 +883,15 @@ int32_t run_rows(mi355_ctx *ctx, mi355_stream stream, const typename red_in<DT>:
 }
 
 // ---- plane ops: one 64-lane plane per 64 inputs ---------------------------------------------
-__global__ void __launch_bounds__(64)
+// (round 4: four planes = four waves per workgroup, grid-striding over the planes -- one 64-thread workgroup per plane ran a
+//  256 MiB input as a million workgroups)
+__global__ void __launch_bounds__(256)
 plane_reduce_kernel(const float *__restrict__ in, float *__restrict__ out, uint64_t n, uint32_t active, int op)
 {
-    const uint32_t lane = threadIdx.x;
-    const uint64_t i = (uint64_t)blockIdx.x * 64 + lane;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t planes = (n + 63) / 64;
+  for (uint64_t pl = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); pl < planes; pl += (uint64_t)gridDim.x * 4) {
+    const uint64_t i = pl * 64 + lane;
     float v = (i < n) ? in[i] : 0.f;
     if (op >= 101 && op <= 104) {
         // plane_reduce_inclusive / exclusive (shared/plane.rs:72-97): Hillis-Steele with shuffle_up; sum (101 / 102, default 0)
@@ -916,6 +920,7 @@ plane_reduce_kernel(const float *__restrict__ in, float *__restrict__ out, uint6
         }
     }
     if (i < n) out[i] = v;
+  }
 }
 
 // ---- the remaining plane intrinsics (frontend/plane.rs:62-216, :388-440), one plane of `plane` lanes per block --------
@@ -1107,15 +1112,13 @@ MI355_API int32_t mi355_reduce_last_axis_argmax(mi355_ctx *ctx, mi355_stream str
 MI355_API int32_t mi355_reduce_axis_sum_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, float *out, uint64_t outer,
                                             uint64_t reduce, uint64_t inner)
 {
-    if (inner == 1) return run_rows<MI355_REDUCE_SUM>(ctx, stream, in, out, nullptr, outer, reduce, reduce, "mi355_reduce_axis_sum_f32");
-    return run_mid<MI355_REDUCE_SUM>(ctx, stream, in, out, nullptr, outer, reduce, inner, "mi355_reduce_axis_sum_f32");
+    return mi355_reduce_axis_sum(ctx, stream, in, MI355_DTYPE_F32, out, outer, reduce, inner);
 }
 
 MI355_API int32_t mi355_reduce_axis_argmax_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, uint32_t *out_idx,
                                                uint64_t outer, uint64_t reduce, uint64_t inner)
 {
-    if (inner == 1) return run_rows<MI355_REDUCE_ARGMAX>(ctx, stream, in, nullptr, out_idx, outer, reduce, reduce, "mi355_reduce_axis_argmax_f32");
-    return run_mid<MI355_REDUCE_ARGMAX>(ctx, stream, in, nullptr, out_idx, outer, reduce, inner, "mi355_reduce_axis_argmax_f32");
+    return mi355_reduce_axis_argmax(ctx, stream, in, MI355_DTYPE_F32, out_idx, outer, reduce, inner);
 }
 
 // any-axis reductions of f32 / bf16 / f16 input (f32 arithmetic)
@@ -1124,7 +1127,9 @@ static int32_t axis_dispatch(mi355_ctx *ctx, mi355_stream stream, const void *in
                              uint64_t reduce, uint64_t inner, const char *what)
 {
     typedef typename red_in<DT>::elem elem;
-    if (inner == 1) return run_rows<OP, DT>(ctx, stream, static_cast<const elem *>(in), out, out_idx, outer, reduce, reduce, what);
+    // last axis: a wave (or a workgroup) per row -- unless the rows are so short that most of its lanes would idle (16 Mi x 4: 140 GB/s,
+    // 4 Mi x 16: 550, 1 Mi x 64: 2 000 -- profiles/r04_misc_probe.txt); the tiled kernel then packs 256 / TY rows into a workgroup
+    if (inner == 1 && reduce >= 128) return run_rows<OP, DT>(ctx, stream, static_cast<const elem *>(in), out, out_idx, outer, reduce, reduce, what);
     return run_mid<OP, DT>(ctx, stream, static_cast<const elem *>(in), out, out_idx, outer, reduce, inner, what);
 }
 template <int OP>
@@ -1226,9 +1231,8 @@ MI355_API int32_t mi355_plane_reduce_f32(mi355_ctx *ctx, mi355_stream stream, co
     const bool known = op == MI355_REDUCE_SUM || op == MI355_REDUCE_MAX || op == MI355_REDUCE_MIN || op == MI355_REDUCE_PROD || op == 100 ||
                        (op >= MI355_PLANE_INCLUSIVE_SUM && op <= MI355_PLANE_EXCLUSIVE_PROD);
     if (!known) return fail(ctx, MI355_E_UNSUPPORTED, "unknown plane op %d", op);
-    const uint64_t blocks = (n + 63) / 64;
-    if (blocks > 0x7FFFFFFFull) return fail(ctx, MI355_E_UNSUPPORTED, "too many planes");
-    hipLaunchKernelGGL(plane_reduce_kernel, dim3((uint32_t)blocks), dim3(64), 0, stream_of(ctx, stream), in, out, n,
+    const uint64_t blocks = std::min<uint64_t>(((n + 63) / 64 + 3) / 4, (uint64_t)ctx->props.num_streaming_multiprocessors * 32);
+    hipLaunchKernelGGL(plane_reduce_kernel, dim3((uint32_t)std::max<uint64_t>(blocks, 1)), dim3(256), 0, stream_of(ctx, stream), in, out, n,
                        active, op);
     check_launch(ctx, "mi355_plane_reduce_f32");
     return MI355_OK;

@@ -279,6 +279,26 @@ def test_split_k_batched_padded_and_repeatable(client, oracle):
         assert np.array_equal(c.to_numpy(client), first)
 
 
+@pytest.mark.parametrize("m,n,k,batch,trans_b", [(1024, 1024, 1024, 1, True), (1024, 1024, 1024, 1, False), (512, 512, 4096, 1, True), (256, 384, 2048, 2, True),
+                                                 (200, 1000, 1536, 1, False), (128, 128, 8192, 1, True), (1024, 512, 544, 1, True)])
+def test_f32_split_k_when_the_tiles_cannot_fill_the_chip(client, oracle, m, n, k, batch, trans_b):
+    """Round 4: the 128 x 128 f32 kernel cuts K when its tiles leave at least half the CUs idle (1024^3: 64 tiles, 74.5 -> ~25 us) --
+    f32 slabs folded in slice order by the same fold kernel as the 16-bit path.  Parity against the f64 oracle through AUTO and
+    the forced kernel; padded C; the same bits from launch to launch."""
+    ldc = n + 4 if (m, n) == (200, 1000) else None
+    run_case(client, oracle, m, n, k, ElemType.F32, ElemType.F32, trans_b, ALGOS["f32"], batch=batch, ldc=ldc)
+    run_case(client, oracle, m, n, k, ElemType.F32, ElemType.F32, trans_b, ALGOS["auto"], batch=batch)
+    a = TensorHandle.uniform(client, (batch, m, k), ElemType.F32, 0x5EEDC0BE, 85, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (batch, n, k) if trans_b else (batch, k, n), ElemType.F32, 0x5EEDC0BE, 86, -1.0, 1.0)
+    bt = TensorHandle.new(b.handle, (batch, k, n), (n * k, 1, k) if trans_b else (k * n, n, 1), ElemType.F32)
+    c = TensorHandle.new_contiguous((batch, m, n), client.empty(batch * m * n * 4), ElemType.F32)
+    ops.matmul(client, a, bt, c, algo=ALGOS["f32"])
+    first = c.to_numpy(client).copy()
+    for _ in range(4):
+        ops.matmul(client, a, bt, c, algo=ALGOS["f32"])
+        assert np.array_equal(c.to_numpy(client), first)
+
+
 def test_split_k_bits_do_not_depend_on_where_c_sits(client, oracle):
     """advisor, round 3: the fold of the split-K slabs had two summation trees and picked one by the ALIGNMENT of C (and by
     ldc % 4), so the same product written into a pitched or offset C could differ in the last bit.  The form now follows
