@@ -640,7 +640,11 @@ gemm_lp256w4_kernel(gemm_args g)
         const int64_t row0 = m0 + wm * 128 + lane / LPR;                  // + i*32 + it*RPI
         const int64_t col0 = n0 + wn * 128 + (lane % LPR) * EPP;
         const int ncols = (int)max((int64_t)0, min((int64_t)EPP, g.n - col0));   // valid elements of my piece
-        const bool interior = (m0 + BM <= g.m) && (n0 + BN <= g.n);       // wave-uniform fast path
+        // C rows that do not start on 16-byte boundaries (N = 50257 bf16 logits, a view at an odd column): every piece goes
+        // the element-wise way of the edge tiles -- eight 2-byte stores per lane instead of one 16-byte store, which the L2
+        // merges into the same lines (8191 x 8191 x 8192: see profiles/r04_ragged_probe.txt).
+        const bool cvec = ((((uint64_t)g.ldc * CSZ) | ((uint64_t)g.stride_c * CSZ) | reinterpret_cast<uintptr_t>(g.c)) & 15u) == 0;
+        const bool interior = cvec && (m0 + BM <= g.m) && (n0 + BN <= g.n);   // wave-uniform fast path
         // D = A * B + c_in (f32 C only, the C operand of cmma::execute): the 32 / RPI pieces of c_in that this lane will
         // add in block i are fetched before the block's accumulators are staged, so one memory latency per block hides
         // behind the LDS transposition.  c_in has C's layout and may be C itself.
@@ -655,7 +659,7 @@ gemm_lp256w4_kernel(gemm_args g)
                     const char *csrc = cin + cin_off + (int64_t)i * 32 * g.ldc * CSZ;
 #pragma unroll
                     for (int it = 0; it < 32 / RPI; ++it) {
-                        if (interior || (row0 + i * 32 + it * RPI < g.m && ncols == EPP))
+                        if (interior || (cvec && row0 + i * 32 + it * RPI < g.m && ncols == EPP))
                             pre[it] = *reinterpret_cast<const f32x4 *>(csrc + it * cstep);
                         else
                             pre[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -687,7 +691,7 @@ gemm_lp256w4_kernel(gemm_args g)
                 u32x4 v = *reinterpret_cast<const u32x4 *>(rd + it * RPI * RS);
                 if (!interior) {
                     if (row0 + i * 32 + it * RPI >= g.m || ncols <= 0) continue;
-                    if (ncols < EPP) {
+                    if (ncols < EPP || !cvec) {
 #pragma unroll
                         for (int e = 0; e < EPP; ++e) {                    // static indices only (guide rule 20)
                             if (e >= ncols) break;
@@ -754,8 +758,9 @@ bool gemm_lp256w4_supports(const mi355_gemm_desc &d, const void *a, const void *
     const int64_t esz = f8 ? 1 : d.dtype_ab == MI355_DTYPE_F32 ? 4 : 2;
     const int64_t BK = ROW_BYTES / esz;
     if (d.k < BK || d.k % BK != 0) return false;
-    const int64_t csz = d.dtype_c == MI355_DTYPE_F32 ? 4 : 2;      // the epilogue writes C in 16-byte pieces
-    if (((d.ldc * csz) & 15) || ((d.stride_c * csz) & 15) || (reinterpret_cast<uintptr_t>(c) & 15u)) return false;
+    // (C rows off the 16-byte grid are taken: the epilogue then stores element-wise; the persistent forms still decline them)
+    const int64_t csz = d.dtype_c == MI355_DTYPE_F32 ? 4 : 2;
+    if (reinterpret_cast<uintptr_t>(c) & (uintptr_t)(csz - 1)) return false;
     if (d.m < 1 || d.n < 1) return false;
     // row-major B is fetched 16 bytes of a row at a time: 4 (f32) / 8 (16-bit) columns
     if (!d.trans_b && (d.n < 16 / esz || (d.n & (16 / esz - 1)))) return false;

@@ -404,6 +404,49 @@ def test_lp256w4_ragged_edges(client, oracle, m, n, k, dtype, out):
              ALGOS["lp256w4"], ldc=ldc)
 
 
+@pytest.mark.parametrize("m,n,k", [(300, 261, 128), (257, 255, 320), (513, 1001, 128), (256, 256, 64), (130, 770, 192)])
+@pytest.mark.parametrize("dtype,out", [(ElemType.BF16, "f32"), (ElemType.BF16, "same"), (ElemType.F16, "same"), (ElemType.F32, "f32")])
+@pytest.mark.parametrize("pad", [0, 1, 3])
+def test_lp256w4_c_rows_off_the_16_byte_grid(client, oracle, m, n, k, dtype, out, pad):
+    """C rows that start anywhere (N = 50257 logits, a view at an odd column): the epilogue stores element-wise; values against
+    the oracle, the 0xEE padding of a pitched C untouched."""
+    ldc = n + pad
+    if (ldc * (4 if out == "f32" else 2)) % 16 == 0:
+        ldc += 1
+    run_case(client, oracle, m, n, k if dtype != ElemType.F32 else k // 2, dtype, ElemType.F32 if out == "f32" else dtype, True,
+             ALGOS["lp256w4"], ldc=ldc, batch=2 if m < 300 else 1)
+
+
+def test_unaligned_c_gives_the_bits_of_the_aligned_form_and_stays_inside_its_rows(client, oracle):
+    """4100 x 4100 x 512 bf16 through AUTO (289 tiles -> the 256x256 kernel): C placed one element into an allocation with a
+    row pitch of 4101 gives the bits of the aligned product, and neither the element before it, the pitch column nor the tail of
+    the allocation is written."""
+    import ctypes as C
+    m = n = 4100; k = 512
+    a_host = oracle.fill_uniform(m * k, 91, -1.0, 1.0).reshape(m, k)
+    b_host = oracle.fill_uniform(n * k, 92, -1.0, 1.0).reshape(n, k)
+    ta, _ = _to_dev(client, oracle, a_host, ElemType.BF16)
+    tb, _ = _to_dev(client, oracle, b_host, ElemType.BF16)
+    ldc0 = 4104
+    c0 = client.empty(m * ldc0 * 2)
+    ldc1 = 4101
+    c1 = client.empty((1 + m * ldc1 + 7) * 2)
+    client._s.check(client.lib.mi355_memset(client.ctx, None, c1.device_ptr(), 0xEE, c1.size))
+    d = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=k, ldc=ldc0, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_BF16, trans_b=1)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(ta.handle.device_ptr()),
+                                          C.c_void_p(tb.handle.device_ptr()), C.c_void_p(c0.device_ptr())))
+    d.ldc = ldc1
+    client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(ta.handle.device_ptr()),
+                                          C.c_void_p(tb.handle.device_ptr()), C.c_void_p(c1.device_ptr() + 2)))
+    want = client.read_one(c0).view(np.uint16).reshape(m, ldc0)[:, :n]
+    raw = client.read_one(c1).view(np.uint16)
+    assert raw[0] == 0xEEEE and np.all(raw[1 + m * ldc1 - 1:] == 0xEEEE)
+    got = raw[1:1 + m * ldc1].reshape(m, ldc1)
+    assert np.array_equal(got[:, :n], want)
+    assert np.all(got[:-1, n:] == 0xEEEE)
+
+
 def test_lp256w4_ragged_row_major_b_and_batch(client, oracle):
     run_case(client, oracle, 300, 260, 64, ElemType.F32, ElemType.F32, False, ALGOS["lp256w4"])
     run_case(client, oracle, 513, 1000, 96, ElemType.F32, ElemType.F32, False, ALGOS["lp256w4"], batch=2, ldb=1004, ldc=1000)
@@ -781,8 +824,8 @@ def test_auto_selection_and_errors(client):
     d = N.GemmDesc(m=8192 + 8, n=8192, k=8192, batch=1, lda=8192, ldb=8192, ldc=8192, dtype_ab=N.DTYPE_BF16,
                    dtype_c=N.DTYPE_BF16, trans_b=1)
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4          # ragged M / N stay on the fast kernel
-    d.ldc = 8192 + 3                                                   # C rows not 16-byte aligned -> 8-wave kernel
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256
+    d.ldc = 8192 + 3                                                   # C rows not 16-byte aligned: the same kernel stores element-wise
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
     d = N.GemmDesc(m=100, n=100, k=7, batch=1, lda=7, ldb=7, ldc=100, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_F32, trans_b=1)
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_GENERIC
     a = TensorHandle.new_contiguous((8, 8), client.empty(256), ElemType.F32)
@@ -1005,7 +1048,8 @@ def test_matmul_add_exact_small_integers_and_oracle(client, oracle):
 
 
 @pytest.mark.parametrize("dtype", [ElemType.BF16, ElemType.F32, ElemType.F8E4M3])
-@pytest.mark.parametrize("m,n,k,batch,algo", [(256, 512, 256, 1, "lp256w4"), (300, 260, 128, 2, "lp256w4"), (4096, 2304, 256, 1, "auto"),
+@pytest.mark.parametrize("m,n,k,batch,algo", [(256, 512, 256, 1, "lp256w4"), (300, 260, 128, 2, "lp256w4"), (300, 261, 128, 2, "lp256w4"),
+                                              (4096, 2304, 256, 1, "auto"),
                                               (4000, 3500, 256, 1, "auto"), (1024, 768, 512, 5, "auto")])
 def test_matmul_add_f32_inside_the_256_kernel(client, oracle, dtype, m, n, k, batch, algo):
     """f32 output on the 256x256 kernel adds C in its epilogue (no product scratch): whole and ragged tiles, batches, in place."""
