@@ -62,6 +62,7 @@ GEMM_ALGO_LP_256Q = 7
 GEMM_ALGO_SKINNY = 8
 GEMM_ALGO_STREAM64 = 9
 GEMM_ALGO_LP_256X128 = 10
+GEMM_ALGO_NNROWS = 11
 UNIQUE_ID_BYTES = 128
 
 

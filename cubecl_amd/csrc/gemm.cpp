@@ -79,6 +79,15 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
     // 16 x 28672 x 8192 270 -> 78.7 (the [N][K] form on its streaming kernel: 76.1), 64 x 28672 x 8192 290 -> 85.2 ([N][K]: 93.1),
     // 8 x 57344 x 4096 276 -> 81.3, 32 x 4096 x 4096 24.4 -> 16.7.  Few COLUMNS (B small: at most 64 x K) keep the re-layout.
     if (!d.trans_b) {
+        // Round 4: gemm_nnrows.hip (wide row strips, transposition in registers, no split-K launch pair) where the 128x128 kernel
+        // below is weakest -- few column tiles, hence many K slices and a fold launch (N <= 16384), or more than two rounds of
+        // tiles (N > 65536) -- and the weight is worth streaming.  Cold operands, us, nnrows against lp128 (profiles/r04_nnrows_ab.txt):
+        // 1 / 4 / 8 x 8192 x 8192 25.6 / 26.5 / 27.8 against 30.9 (16 rows: a tie), 4 x 14336 x 4096 23.2 / 25.7, 4 x 4096 x 14336
+        // 23.9 / 25.9, 1 / 16 x 128256 x 4096 151 / 191 and 176 / 195; not taken: 4 x 32000 x 4096 44.6 / 40.8 (250 tiles, no
+        // split), 4 x 4096 x 4096 13.8 / 11.7, 16 x 28672 x 8192 85 / 76.
+        if (d.batch == 1 && d.n * d.k >= ((int64_t)1 << 25) && ((d.m <= 8 && d.n <= 16384) || (d.m <= 16 && d.n > 65536)) &&
+            gemm_nnrows_supports(d, a, b, c))
+            return MI355_GEMM_ALGO_NNROWS;
         const int64_t tiles256 = ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch;
         const bool native = (std::min(d.m, d.n) > 128 && big4 && tiles256 > 128) || (std::min(d.m, d.n) > 64 && mid);
         if (!native) return (mid && d.m <= d.n) ? MI355_GEMM_ALGO_LP_128 : MI355_GEMM_ALGO_GENERIC;
@@ -393,6 +402,7 @@ MI355_API int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_ge
     case MI355_GEMM_ALGO_SKINNY: return launch_gemm_skinny(ctx, s, d, a, b, c);
     case MI355_GEMM_ALGO_STREAM64: return launch_gemm_stream64(ctx, s, d, a, b, c);
     case MI355_GEMM_ALGO_LP_256X128: return launch_gemm_lp256x128(ctx, s, d, a, b, c);
+    case MI355_GEMM_ALGO_NNROWS: return launch_gemm_nnrows(ctx, s, d, a, b, c);
     default: return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_gemm: unknown algo %d", algo);
     }
 }

@@ -1,0 +1,440 @@
+// gemm_nnrows.hip -- at most 16 rows against a ROW-MAJOR weight: C[m][n] = sum_k A[m][k] * B[k][n], bf16 / f16, M <= 16.
+//
+// This is the layout `TensorHandle::new_contiguous` gives a rhs (crates/cubecl-std/src/tensor/handle.rs:89; a [K][N] weight
+// classified RowMajor by matrix_batch_layout.rs:21-79): the decode-time product x [M][K] * W [K][N].  Roofline: HBM -- the
+// weight (8192 x 8192 bf16 = 128 MiB in the shape the bench quotes) is read exactly once and is all of the traffic.
+//
+// What makes the layout awkward is that every matrix-core operand wants its K values contiguous per lane while a row of W
+// is contiguous along N; the tile kernels transpose through LDS (gemm_lp128.hip BNN) and read W in 256-byte column strips,
+// which HBM delivers at 5.1 TB/s at best (profiles/r03_hbm_colstrip_probe.txt).  This kernel never moves W through LDS:
+//
+//   * a workgroup owns a STRIP of S = 1024 / 512 / 256 bytes of every k-row of a K slice; a lane owns 8 columns (16 bytes of
+//     a row) and loads FOUR consecutive k-rows of them -- one wave instruction reads S-byte pieces of 64 * 16 / S rows, whole
+//     128-byte lines, non-temporal, U x 4 loads in flight per lane.  Wide strips with the slices of one strip on consecutive
+//     workgroups stream at 5.6-5.8 TB/s (profiles/r04_hbm_rowslab_probe.txt).
+//   * the 4 x 8 block a lane holds is transposed IN REGISTERS (16 v_perm_b32) into eight 4-long k-vectors, one per column,
+//     which is exactly the B operand of v_mfma_f32_4x4x4_16b_{bf16,f16}: sixteen independent 4 x 4 x 4 blocks per
+//     instruction, block = 4 adjacent lanes, each lane supplying ITS OWN column and receiving D[0..3][its column].  The A
+//     operand (x[4r + lane % 4][the lane's four k]) comes from an LDS copy of x's K slice: broadcast reads, no conflicts.
+//     8 x ceil(M / 4) MFMAs of 8 cycles per 64 bytes a lane loads: 4 us of matrix pipe for M = 16 on the quoted shape.
+//   * the 4 * 64 * 16 / S copies of the strip's partial sums (waves x row groups) meet in LDS in a fixed order; with more than
+//     one K slice the f32 partials go to library scratch and the LAST workgroup of the strip to arrive (one ticket word per
+//     strip, gemm_nnrows' share of the stream's ticket slot) adds them in slice order and writes C -- one launch,
+//     deterministic bits, no float atomics.
+//
+// Accumulation: f32, order fixed by (S, slices) = by the shape and the device's CU count -- run-to-run bit-identical; not
+// bit-identical to the other kernels (different association), inside the parity tolerance of tests/test_gpu_gemm.py.
+#include "gemm_common.hpp"
+#include <type_traits>
+
+using namespace mi355;
+
+namespace mi355 {
+int32_t strip_tickets_for_stream(mi355_ctx *ctx, hipStream_t s, unsigned int **out);   // reduce.hip
+void strip_tickets_mark_dirty(mi355_ctx *ctx);
+}  // namespace mi355
+
+namespace {
+
+#ifndef NNR_U
+#define NNR_U 6                  // dev: four-row groups in flight per lane (4, 6 or 8)
+#endif
+// the rounds of the streaming loops written out (a `#pragma unroll` loop over the ring slots was not always unrolled, and a
+// slot index that is not a constant turns the ring into register copies)
+#if NNR_U == 4
+#define NNR_EACH_U(X) X(0) X(1) X(2) X(3)
+#elif NNR_U == 6
+#define NNR_EACH_U(X) X(0) X(1) X(2) X(3) X(4) X(5)
+#else
+#define NNR_EACH_U(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#endif
+typedef __attribute__((address_space(1))) const u32x4 *gptr_u32x4;
+constexpr int STRIP_TICKETS = 496;
+constexpr int SCRATCH_NNROWS = 7;
+
+struct nn_args {
+    const uint16_t *a;           // x [M][K]
+    const uint16_t *b;           // W [K][N]
+    void *c;
+    float *partial;              // [batch][slices][M][N] f32 when slices > 1
+    unsigned int *tickets;       // [batch * strips], zero between calls
+    int32_t m, n, k;
+    int64_t lda, ldb, ldc, stride_a, stride_b, stride_c;
+    int32_t strips, slices, ks;  // ks: k-rows per slice, a multiple of 64
+    int32_t dtype_c;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+template <int DT>
+__device__ __forceinline__ f32x4 mfma4(u32x2 a, u32x2 b, f32x4 c)
+{
+    if constexpr (DT == MI355_DTYPE_BF16)
+        return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(h16x4, a), __builtin_bit_cast(h16x4, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void store_c(void *c, int32_t dtype_c, int64_t off, float v)
+{
+    if (dtype_c == MI355_DTYPE_F32) static_cast<float *>(c)[off] = v;
+    else if (dtype_c == MI355_DTYPE_BF16) static_cast<__bf16 *>(c)[off] = (__bf16)v;
+    else static_cast<_Float16 *>(c)[off] = (_Float16)v;
+}
+
+template <int MB> struct nn_geom {
+    static constexpr int MP = 4 * MB;                                      // x rows staged (zero rows past M)
+    static constexpr int KC = MB == 1 ? 8192 : MB == 2 ? 4096 : 2048;      // k values of x per LDS chunk (64 KiB): a chunk boundary drains the ring
+};
+
+template <int DT, int MB, int S>
+__global__ void __launch_bounds__(256) gemm_nnrows_kernel(const nn_args g)
+{
+    constexpr int U = NNR_U;
+    constexpr int MP = nn_geom<MB>::MP, KC = nn_geom<MB>::KC;
+    constexpr int LPR = S / 16, Q = 64 / LPR, COLS = S / 2;                // lanes per row piece, row groups per wave, columns per strip
+    constexpr int RI = 16 * Q;                                             // k-rows one workgroup iteration covers
+    constexpr int XP = KC + RI + 8;                                        // LDS pitch of an x row: the chunk + a zero tail + 16 B
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ unsigned int is_last;
+    uint16_t *xs = reinterpret_cast<uint16_t *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int p = lane % LPR, q = lane / LPR;
+    const uint32_t strip = blockIdx.x / (uint32_t)g.slices, slice = blockIdx.x % (uint32_t)g.slices, batch = blockIdx.y;
+    const int64_t col = (int64_t)strip * COLS + p * 8;                     // my eight columns (N % 8 == 0: all or none exist)
+    const uint16_t *A = g.a + (int64_t)batch * g.stride_a;
+    const uint16_t *Bp = g.b + (int64_t)batch * g.stride_b + (col < g.n ? col : 0);
+    const int kbeg = (int)slice * g.ks, kend = min(g.k, kbeg + g.ks);
+
+    f32x4 acc[MB][8];
+#pragma unroll
+    for (int r = 0; r < MB; ++r)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[r][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // The W stream: a ring of U four-row groups per lane, refilled slot by slot.  What it takes for the compiler's waitcnt pass
+    // to wait with vmcnt(4 (U - 1)) instead of draining the ring every round (each item measured in the ISA):
+    //   * EVERY load is unconditional -- a load inside a branch makes the number in flight unknown, and the pass answers
+    //     with vmcnt(0).  A slot with nothing left to fetch is refilled with 16 always-resident bytes (x itself), its address
+    //     operands SELECTED, not branched over; a group that does not exist in a ragged last iteration is zeroed when consumed.
+    //   * no load result may be dead on any path (x staging below: pieces past the end are stored to a dump slot) -- the
+    //     pass guards every later write to such a register with a wait for the whole ring.
+    //   * the slot index is a constant (rounds written out by macro: a `#pragma unroll` loop was not always unrolled, and an
+    //     index that is not a constant turns the ring into register copies), and the refill is fenced behind the transposition
+    //     that reads the slot (sched_barrier: the scheduler sinks all 4 U refills to the end of the round otherwise).
+    // (Issuing the loads and the waits by hand in inline asm was tried: the register allocator may copy a slot's registers in
+    // front of the hand-written wait -- it did, in the tail rounds -- and the copy reads a load that has not landed.)
+    u32x4 v[U][4];
+    const int64_t ldb2 = g.ldb * 2;                                        // bytes per k-row
+    const uint32_t voff_lane = (uint32_t)(((int64_t)(w * Q + q) * 4 * g.ldb + (col < g.n ? p * 8 : 0)) * 2);
+    const uint32_t voff_step = (uint32_t)((int64_t)RI * ldb2);
+    const uint16_t *dummy = A + (lane & 3) * 8;                           // always-resident 16 bytes (x staging: loads that have nothing to fetch)
+#ifdef NNR_ASM_LOADS      // dev: loads and waits by hand (see the note above: unsafe, kept for the record)
+#define NNR_LOAD(dst, voff, sbase) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory")
+#define NNR_WAIT(n, u) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(v[u][0]), "+v"(v[u][1]), "+v"(v[u][2]), "+v"(v[u][3])::"memory")
+#else
+#define NNR_LOAD(dst, voff, sbase) dst = __builtin_nontemporal_load(reinterpret_cast<gptr_u32x4>((sbase) + (uint64_t)(voff)))
+#define NNR_WAIT(n, u)
+#endif
+    for (int kc0 = kbeg; kc0 < kend; kc0 += KC) {
+        const int kc1 = min(kend, kc0 + KC);
+        const int nit = (kc1 - kc0 + RI - 1) / RI;
+        // group (it, w, q) = k-rows kc0 + ((it * 4 + w) * Q + q) * 4 ... + 3 (K % 8 == 0: a group exists whole or not at all)
+        const char *sb0 = reinterpret_cast<const char *>(g.b + (int64_t)batch * g.stride_b + (int64_t)strip * COLS + (int64_t)kc0 * g.ldb);
+        const uint64_t sb[4] = {reinterpret_cast<uint64_t>(sb0), reinterpret_cast<uint64_t>(sb0 + ldb2), reinterpret_cast<uint64_t>(sb0 + 2 * ldb2),
+                                reinterpret_cast<uint64_t>(sb0 + 3 * ldb2)};
+        const int last_group = (kc1 - kc0) / 4 - 1;                        // lanes whose group of a ragged last iteration does not exist re-read this one
+        // `real` false (wave-uniform): nothing left to fetch -- the slot is refilled all the same, with 16 always-resident bytes
+        // (x itself), so that the number of loads in flight stays what the hand-written waits assume.  Address operands are
+        // SELECTED, never branched over: two asm statements writing one slot in two arms would meet in a register copy.
+        const uint64_t abase = reinterpret_cast<uint64_t>(A);
+        auto issue = [&](bool real, int it, int u) __attribute__((always_inline)) {
+            const int grp = min((it * 4 + w) * Q + q, last_group);
+            const uint32_t voff = real ? voff_lane + (uint32_t)(grp - (w * Q + q)) * (uint32_t)(4 * ldb2) : 0u;
+            NNR_LOAD(v[u][0], voff, real ? sb[0] : abase);
+            NNR_LOAD(v[u][1], voff, real ? sb[1] : abase);
+            NNR_LOAD(v[u][2], voff, real ? sb[2] : abase);
+            NNR_LOAD(v[u][3], voff, real ? sb[3] : abase);
+        };
+        // a slot whose group has landed (the caller's wait) is transposed, refilled with the group U iterations ahead, multiplied
+        auto consume = [&](auto steady, auto refill, int it, int u) __attribute__((always_inline)) {
+            const int kk = ((it * 4 + w) * Q + q) * 4;
+            if constexpr (!decltype(steady)::value) {
+                if (kc0 + kk >= kc1) {                                     // ragged last iteration: my group does not exist
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[u][j] = (u32x4){0u, 0u, 0u, 0u};
+                }
+            }
+            // in-register transposition: column e of my eight -> its four k values
+            u32x2 bv[8];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                bv[2 * d][0] = __builtin_amdgcn_perm(v[u][1][d], v[u][0][d], 0x05040100u);
+                bv[2 * d][1] = __builtin_amdgcn_perm(v[u][3][d], v[u][2][d], 0x05040100u);
+                bv[2 * d + 1][0] = __builtin_amdgcn_perm(v[u][1][d], v[u][0][d], 0x07060302u);
+                bv[2 * d + 1][1] = __builtin_amdgcn_perm(v[u][3][d], v[u][2][d], 0x07060302u);
+            }
+            if constexpr (decltype(refill)::value) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue(decltype(steady)::value || it + U < nit, it + U, u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (decltype(steady)::value || it < nit) {                     // (wave-uniform; a round past the end only keeps the count)
+#pragma unroll
+                for (int r = 0; r < MB; ++r) {
+                    const u32x2 xa = *reinterpret_cast<const u32x2 *>(xs + (4 * r + (lane & 3)) * XP + kk);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[r][e] = mfma4<DT>(xa, bv[e], acc[r][e]);
+                }
+            }
+        };
+        __syncthreads();                                                   // the previous chunk's x has been read
+#define NNR_X(u) issue(u < nit, u, u);
+        NNR_EACH_U(NNR_X)                                                  // W first: x's staging latency hides behind it
+#undef NNR_X
+        {   // x[0 .. MP)[kc0 .. kc0 + nit * RI) -> LDS, zeros past M and past the slice; loads batched four deep, unconditional
+            const int epr = nit * RI / 8, pieces = MP * epr;               // 16-byte pieces per row / in all
+            for (int base = 0; base < pieces; base += 4 * 256) {
+                u32x4 xv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int idx = base + i * 256 + tid, mm = idx / epr, kk = (idx - mm * epr) * 8;
+                    const bool ok = idx < pieces && mm < g.m && kc0 + kk < kc1;
+                    uint64_t addr = ok ? reinterpret_cast<uint64_t>(A + (int64_t)mm * g.lda + kc0 + kk) : reinterpret_cast<uint64_t>(dummy);
+                    asm("" : "+v"(addr));                                  // a select of ADDRESSES (else: a branch with a load in each arm)
+                    xv[i] = *reinterpret_cast<gptr_u32x4>(addr);
+                    if (!ok) xv[i] = (u32x4){0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int idx = base + i * 256 + tid, mm = idx / epr, kk = (idx - mm * epr) * 8;
+                    // stored UNCONDITIONALLY (pieces past the end go to a dump slot): a load whose value one path never uses stays
+                    // "in flight" for the compiler, which then drains vmcnt inside the streaming loop before reusing its registers
+                    *reinterpret_cast<u32x4 *>(xs + (idx < pieces ? mm * XP + kk : MP * XP)) = xv[i];
+                }
+            }
+        }
+        __syncthreads();                                                   // (the compiler's vmcnt(0) for x also lands the first U groups)
+        int it0 = 0;
+        // Every wait is a constant: before slot u is consumed, exactly U - 1 younger groups are in flight (4 loads each) in every
+        // round but the last, which refills nothing (U - 1 - u younger).
+#if NNR_U == 4
+#define NNR_W_STEADY(u) NNR_WAIT(12, u)
+#elif NNR_U == 6
+#define NNR_W_STEADY(u) NNR_WAIT(20, u)
+#else
+#define NNR_W_STEADY(u) NNR_WAIT(28, u)
+#endif
+        // steady rounds: every consumed iteration exists whole and has a successor U ahead
+#define NNR_X(u) NNR_W_STEADY(u); consume(std::true_type{}, std::true_type{}, it0 + u, u);
+        for (; (it0 + 2 * U) * RI <= kc1 - kc0; it0 += U) { NNR_EACH_U(NNR_X) }
+#undef NNR_X
+        // rounds with a successor round: refills past the end fetch the resident bytes
+#define NNR_X(u) NNR_W_STEADY(u); consume(std::false_type{}, std::true_type{}, it0 + u, u);
+        for (; it0 + U < nit; it0 += U) { NNR_EACH_U(NNR_X) }
+#undef NNR_X
+        // the last round drains the ring
+#define NNR_LAST(u, n) NNR_WAIT(n, u); consume(std::false_type{}, std::false_type{}, it0 + u, u);
+#if NNR_U == 4
+        NNR_LAST(0, 12) NNR_LAST(1, 8) NNR_LAST(2, 4) NNR_LAST(3, 0)
+#elif NNR_U == 6
+        NNR_LAST(0, 20) NNR_LAST(1, 16) NNR_LAST(2, 12) NNR_LAST(3, 8) NNR_LAST(4, 4) NNR_LAST(5, 0)
+#else
+        NNR_LAST(0, 28) NNR_LAST(1, 24) NNR_LAST(2, 20) NNR_LAST(3, 16) NNR_LAST(4, 12) NNR_LAST(5, 8) NNR_LAST(6, 4) NNR_LAST(7, 0)
+#endif
+#undef NNR_LAST
+#undef NNR_W_STEADY
+    }
+#undef NNR_LOAD
+#undef NNR_WAIT
+
+    // ---- the 4 * Q copies of the strip meet in LDS (fixed order) --------------------------------------------------------------
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem);                          // [4 * Q][MP][COLS]
+    {
+        const int copy = w * Q + q;
+#pragma unroll
+        for (int r = 0; r < MB; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float *dst = red + ((copy * MP + 4 * r + i) * COLS + p * 8);
+                *reinterpret_cast<f32x4 *>(dst) = (f32x4){acc[r][0][i], acc[r][1][i], acc[r][2][i], acc[r][3][i]};
+                *reinterpret_cast<f32x4 *>(dst + 4) = (f32x4){acc[r][4][i], acc[r][5][i], acc[r][6][i], acc[r][7][i]};
+            }
+    }
+    __syncthreads();
+    const int64_t strip_col = (int64_t)strip * COLS;
+    char *C = static_cast<char *>(g.c);
+    const int64_t cbase = (int64_t)batch * g.stride_c;
+    float *part = g.partial + ((int64_t)batch * g.slices) * g.m * g.n;    // [slices][M][N] of this batch entry
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    typedef __attribute__((address_space(1))) unsigned int gu32;
+    for (int idx = tid; idx < g.m * (COLS / 4); idx += 256) {
+        const int mm = idx / (COLS / 4), c4 = (idx % (COLS / 4)) * 4;
+        if (strip_col + c4 >= g.n) continue;
+        f32x4 s = *reinterpret_cast<const f32x4 *>(red + (mm * COLS + c4));
+#pragma unroll
+        for (int cp = 1; cp < 4 * Q; ++cp) s += *reinterpret_cast<const f32x4 *>(red + ((cp * MP + mm) * COLS + c4));
+        if (g.slices == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) store_c(C, g.dtype_c, cbase + (int64_t)mm * g.ldc + strip_col + c4 + e, s[e]);
+        } else {                                                           // write-through (sc1) 8-byte stores: see the hand-off below
+            gu64 *dst = (gu64 *)reinterpret_cast<unsigned long long *>(part + ((int64_t)slice * g.m + mm) * g.n + strip_col + c4);
+            __hip_atomic_store(dst, ((unsigned long long)__float_as_uint(s[1]) << 32) | __float_as_uint(s[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 1, ((unsigned long long)__float_as_uint(s[3]) << 32) | __float_as_uint(s[2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (g.slices == 1) return;
+
+    // ---- K slices: the last workgroup of the strip to arrive adds the partials in slice order ---------------------------------
+    // Hand-off as in reduce.hip: agent-scope 8-byte atomic stores (write-through) drained per wave, then the ticket; agent-scope
+    // loads in the folding workgroup.  No fences: a release / acquire fence at agent scope is an L2 write-back / invalidate of the
+    // whole XCD (buffer_wbl2 / buffer_inv sc1) -- with one per workgroup the kernel ran 50 us where the stream takes 24.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // my partials have left the wave ...
+    __syncthreads();                                                       // ... every wave's have, before the ticket
+    unsigned int *ticket = g.tickets + batch * g.strips + strip;
+    if (tid == 0) {
+        const unsigned int old = __hip_atomic_fetch_add((gu32 *)ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = old == (unsigned int)g.slices - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    for (int idx = tid; idx < g.m * (COLS / 4); idx += 256) {
+        const int mm = idx / (COLS / 4), c4 = (idx % (COLS / 4)) * 4;
+        if (strip_col + c4 >= g.n) continue;
+        gu64 *src = (gu64 *)reinterpret_cast<unsigned long long *>(part + (int64_t)mm * g.n + strip_col + c4);
+        const int64_t step = (int64_t)g.m * g.n / 2;                       // 8-byte words between slices (N % 8 == 0)
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int sl = 0; sl < g.slices; ++sl) {
+            const unsigned long long lo = __hip_atomic_load(src + sl * step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long hi = __hip_atomic_load(src + sl * step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s += (f32x4){__uint_as_float((uint32_t)lo), __uint_as_float((uint32_t)(lo >> 32)), __uint_as_float((uint32_t)hi),
+                         __uint_as_float((uint32_t)(hi >> 32))};
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) store_c(C, g.dtype_c, cbase + (int64_t)mm * g.ldc + strip_col + c4 + e, s[e]);
+    }
+    if (tid == 0) __hip_atomic_store((gu32 *)ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
+}
+
+template <int MB, int S> constexpr size_t lds_bytes()
+{
+    constexpr size_t x = (size_t)nn_geom<MB>::MP * (nn_geom<MB>::KC + 16 * (64 / (S / 16)) + 8) * 2 + 16;   // + the dump slot
+    constexpr size_t r = (size_t)4 * (64 / (S / 16)) * nn_geom<MB>::MP * (S / 2) * 4;
+    return x > r ? x : r;
+}
+
+template <int DT, int MB, int S>
+void launch_one(mi355_ctx *ctx, hipStream_t s, const nn_args &g, uint32_t batch)
+{
+    constexpr size_t LDS = lds_bytes<MB, S>();
+    lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_nnrows_kernel<DT, MB, S>), LDS);
+    hipLaunchKernelGGL((gemm_nnrows_kernel<DT, MB, S>), dim3((uint32_t)(g.strips * g.slices), batch), dim3(256), LDS, s, g);
+}
+
+template <int DT, int MB>
+void launch_s(mi355_ctx *ctx, hipStream_t s, const nn_args &g, uint32_t batch, int strip_bytes)
+{
+    if (strip_bytes == 1024) launch_one<DT, MB, 1024>(ctx, s, g, batch);
+    else if (strip_bytes == 512) launch_one<DT, MB, 512>(ctx, s, g, batch);
+    else launch_one<DT, MB, 256>(ctx, s, g, batch);
+}
+
+template <int DT>
+void launch_dt(mi355_ctx *ctx, hipStream_t s, const nn_args &g, uint32_t batch, int strip_bytes)
+{
+    if (g.m <= 4) launch_s<DT, 1>(ctx, s, g, batch, strip_bytes);
+    else if (g.m <= 8) launch_s<DT, 2>(ctx, s, g, batch, strip_bytes);
+    else launch_s<DT, 4>(ctx, s, g, batch, strip_bytes);
+}
+
+// Strip width and K slices.  Measured (profiles/r04_nnrows_ab.txt, cold operands): the stream itself likes wide strips
+// (1024 B: 23.8 us for 128 MiB against 25.7 at 256 B), but every K slice costs M x strip f32 partials written, read back and
+// added by ONE workgroup per strip -- at 8192^2: M = 1 26.7 / 25.5 / 26.6 us with 1024 / 512 / 256-byte strips, M = 4
+// 29.7 / 26.4 / 26.6, M = 16 45.0 / 32.9 / 31.0.  So: 512-byte strips up to four rows, 256-byte strips above; K cut so that
+// at most one workgroup per CU exists (280 workgroups on 256 CUs ran 102 us where 224 run 80); a wider strip only where
+// the narrow one would need more ticket words than a stream's slot holds.
+struct nn_plan { int strip_bytes; int32_t strips, slices, ks; };
+
+bool plan_for(const mi355_gemm_desc &d, int cus, nn_plan &out)
+{
+    static const int force_s = [] { const char *e = getenv("MI355_NNROWS_STRIP"); return e ? atoi(e) : 0; }();
+    static const int force_slices = [] { const char *e = getenv("MI355_NNROWS_SLICES"); return e ? atoi(e) : 0; }();
+    static const int per_cu = [] { const char *e = getenv("MI355_NNROWS_WG_PER_CU"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
+    const int order_few[3] = {512, 256, 1024}, order_many[3] = {256, 512, 1024};
+    for (int i = 0; i < 3; ++i) {
+        const int sb = force_s ? force_s : (d.m <= 4 ? order_few[i] : order_many[i]);
+        if (sb != 1024 && sb != 512 && sb != 256) return false;
+        const int64_t strips = (d.n * 2 + sb - 1) / sb;
+        int64_t slices = std::max<int64_t>(1, (int64_t)cus * per_cu / (strips * d.batch));
+        if (force_slices) slices = force_slices;
+        slices = std::min<int64_t>(slices, (d.k + 63) / 64);
+        const int64_t ks = ((d.k + slices - 1) / slices + 63) / 64 * 64;
+        slices = (d.k + ks - 1) / ks;
+        if (slices > 1 && strips * d.batch > STRIP_TICKETS) {
+            if (force_s) return false;
+            continue;
+        }
+        if (strips * slices * 1 > 0x7FFFFFFF) return false;
+        out = {sb, (int32_t)strips, (int32_t)slices, (int32_t)ks};
+        return true;
+    }
+    return false;
+}
+
+}  // namespace
+
+namespace mi355 {
+
+// A [M][K] K-contiguous, B [K][N] row-major, both 16-bit with 16-byte aligned rows; M <= 16; N and K multiples of 8.
+bool gemm_nnrows_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
+{
+    (void)c;
+    if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16) return false;
+    if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != MI355_DTYPE_BF16 && d.dtype_c != MI355_DTYPE_F16) return false;
+    if (d.trans_a || d.trans_b) return false;
+    if (d.m < 1 || d.m > 16 || d.n < 8 || d.k < 8 || (d.n & 7) || (d.k & 7)) return false;
+    if (d.n > 0x3FFFFFF0 || d.k > 0x3FFFFFF0 || d.batch < 1 || d.batch > 65535) return false;
+    if (d.ldb * 2 * 8400 >= (1ll << 32)) return false;               // a lane's byte offset inside an x chunk (<= 8192 + 64 k-rows) is 32-bit
+    if ((d.lda & 7) || (d.ldb & 7) || (d.stride_a & 7) || (d.stride_b & 7)) return false;
+    if ((reinterpret_cast<uintptr_t>(a) & 15u) || (reinterpret_cast<uintptr_t>(b) & 15u)) return false;
+    nn_plan p;
+    return plan_for(d, 256, p);
+}
+
+int32_t launch_gemm_nnrows(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c)
+{
+    if (!gemm_nnrows_supports(d, a, b, c))
+        return fail(ctx, MI355_E_UNSUPPORTED, "mi355_gemm: the few-rows x row-major-weight kernel does not take this descriptor");
+    nn_plan p;
+    const int cus = ctx->props.num_streaming_multiprocessors > 0 ? ctx->props.num_streaming_multiprocessors : 256;
+    if (!plan_for(d, cus, p)) return fail(ctx, MI355_E_UNSUPPORTED, "mi355_gemm(nnrows): no strip plan");
+    nn_args g{};
+    g.a = static_cast<const uint16_t *>(a);
+    g.b = static_cast<const uint16_t *>(b);
+    g.c = c;
+    g.m = (int32_t)d.m; g.n = (int32_t)d.n; g.k = (int32_t)d.k;
+    g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc;
+    g.stride_a = d.stride_a; g.stride_b = d.stride_b; g.stride_c = d.stride_c;
+    g.strips = p.strips; g.slices = p.slices; g.ks = p.ks;
+    g.dtype_c = d.dtype_c;
+    if (p.slices > 1) {
+        void *part = nullptr;
+        const size_t bytes = (size_t)d.batch * p.slices * d.m * d.n * sizeof(float);
+        if (scratch_get(ctx, s, SCRATCH_NNROWS, bytes, &part) != MI355_OK)
+            return fail(ctx, MI355_E_UNSUPPORTED, "mi355_gemm(nnrows): no scratch for %zu bytes of partial sums (inside a capture window?)", bytes);
+        g.partial = static_cast<float *>(part);
+        const int32_t rc = strip_tickets_for_stream(ctx, s, &g.tickets);
+        if (rc != MI355_OK) return rc;
+    }
+    if (d.dtype_ab == MI355_DTYPE_BF16) launch_dt<MI355_DTYPE_BF16>(ctx, s, g, (uint32_t)d.batch, p.strip_bytes);
+    else launch_dt<MI355_DTYPE_F16>(ctx, s, g, (uint32_t)d.batch, p.strip_bytes);
+    if (p.slices > 1 && hipPeekAtLastError() != hipSuccess) strip_tickets_mark_dirty(ctx);   // a refused launch never resets its tickets
+    check_launch(ctx, "mi355_gemm(nnrows)");
+    return MI355_OK;
+}
+
+}  // namespace mi355

@@ -395,8 +395,11 @@ enum {
                                      v_dot2c_f32 accumulation, no matrix core (gemm_skinny.hip)      */
     MI355_GEMM_ALGO_STREAM64 = 9, /* bf16/f16, M <= 64 or N <= 64: 32 streamed rows x the whole K per workgroup,
                                      loader waves + MFMA, no split-K (gemm_stream64.hip)             */
-    MI355_GEMM_ALGO_LP_256X128 = 10 /* bf16/f16 256x128x64 tile (gemm_lp128.hip, MI = 4): three-stage LDS ring + loader
+    MI355_GEMM_ALGO_LP_256X128 = 10, /* bf16/f16 256x128x64 tile (gemm_lp128.hip, MI = 4): three-stage LDS ring + loader
                                      waves, one workgroup per CU; mid-size shapes of at most one round of such tiles */
+    MI355_GEMM_ALGO_NNROWS = 11   /* bf16/f16, M <= 16 against a row-major [K][N] weight (the rhs TensorHandle::new_contiguous
+                                     gives): wide row strips streamed once, transposed in registers into 4x4x4 MFMA
+                                     operands, K slices folded by the last workgroup to arrive (gemm_nnrows.hip) */
 };
 
 int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_gemm_desc *desc,

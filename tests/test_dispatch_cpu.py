@@ -27,9 +27,12 @@ TABLE = [
     ("C5, row-major rhs", (2048, 2048, 2048, BF, None, 0, 0, 512), "LP_256Q", (0, 0)),
     ("the 64-matrix shard of an 8-GPU C5", (2048, 2048, 2048, BF, None, 0, 1, 64), "LP_256Q", (0, 0)),
     ("GEMV", (1, 8192, 8192, BF, None, 0, 1, 1), "SKINNY", (0, 0)),
-    ("GEMV against a row-major weight: native, never transposed", (1, 8192, 8192, BF, None, 0, 0, 1), "LP_128", (0, 0)),
+    ("GEMV against a row-major weight: the strip-streaming kernel, never transposed", (1, 8192, 8192, BF, None, 0, 0, 1), "NNROWS", (0, 0)),
     ("16 rows", (16, 8192, 8192, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
-    ("16 rows against a row-major weight", (16, 8192, 8192, BF, None, 0, 0, 1), "LP_128", (0, 0)),
+    ("8 rows against a row-major weight", (8, 8192, 8192, BF, None, 0, 0, 1), "NNROWS", (0, 0)),
+    ("16 rows against a row-major weight: a tie, stays", (16, 8192, 8192, BF, None, 0, 0, 1), "LP_128", (0, 0)),
+    ("4 rows, 250 column tiles need no K split: the tile kernel", (4, 32000, 4096, BF, None, 0, 0, 1), "LP_128", (0, 0)),
+    ("16 rows against a row-major vocabulary projection: four rounds of tiles, the strip kernel", (16, 128256, 4096, BF, None, 0, 0, 1), "NNROWS", (0, 0)),
     ("64 rows", (64, 8192, 8192, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
     ("64 columns", (8192, 64, 8192, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
     ("64 columns of a row-major rhs: the small operand is re-laid out", (8192, 64, 8192, BF, None, 0, 0, 1), "STREAM64", (0, 1)),

@@ -24,7 +24,7 @@ REL = 1e-5
 ALGOS = {"auto": N.GEMM_ALGO_AUTO, "generic": N.GEMM_ALGO_GENERIC, "f32": N.GEMM_ALGO_F32_MFMA,
          "lp128": N.GEMM_ALGO_LP_128, "lp256": N.GEMM_ALGO_LP_256, "lp256w4": N.GEMM_ALGO_LP_256W4, "lp256p": N.GEMM_ALGO_LP_256P,
          "lp256q": N.GEMM_ALGO_LP_256Q, "skinny": N.GEMM_ALGO_SKINNY, "stream64": N.GEMM_ALGO_STREAM64,
-         "lp256x128": N.GEMM_ALGO_LP_256X128}
+         "lp256x128": N.GEMM_ALGO_LP_256X128, "nnrows": N.GEMM_ALGO_NNROWS}
 
 
 def _to_dev(client, oracle, x, dtype):
@@ -1076,6 +1076,44 @@ def test_matmul_add_f32_inside_the_256_kernel(client, oracle, dtype, m, n, k, ba
     assert np.array_equal(got, p_t.to_numpy(client) + c_host)           # same kernel, same sum order: bit-equal
     ops.matmul(client, a_t, b_t, tc, algo=ALGOS[algo], acc=tc)           # in place
     assert np.array_equal(tc.to_numpy(client), got)
+
+
+# ---- at most 16 rows against a row-major [K][N] weight: wide row strips, register transposition, 4x4x4 MFMA (gemm_nnrows.hip) -------
+# strip width by shape (plan_for): 16 x 8192 x 8192 -> 1024 B x 16 slices, x 4096 -> 512 B x 8, x 2048 -> 256 B x 4; one slice when the
+# strips alone fill the chip (N = 131072); K slices of 64 ... 8192 rows = every relation of the ring depth to the iteration count
+@pytest.mark.parametrize("m,n,k,kw", [
+    (1, 8192, 8192, {}), (16, 8192, 8192, {}), (16, 8192, 4096, {}), (16, 8192, 2048, {}), (4, 4096, 4096, {}), (8, 2048, 8192, {}),
+    (3, 8, 8, {}), (1, 8, 8200, {}), (16, 16, 64, {}), (7, 520, 1032, {}), (16, 1032, 520, {"ldc": 1040}), (2, 131072, 512, {}),
+    (13, 4104, 6152, {"ldb": 4112, "lda": 6160}), (5, 8192, 1096, {"batch": 3}), (16, 3072, 16384, {}), (1, 1024, 65536, {}),
+    (12, 28672, 1024, {}), (9, 2048, 2056, {"batch": 2, "ldc": 2051})])
+@pytest.mark.parametrize("dtype,out_dtype", [(ElemType.BF16, ElemType.BF16), (ElemType.F16, ElemType.F32), (ElemType.BF16, ElemType.F32)])
+def test_few_rows_times_row_major_weight_matches_the_oracle(client, oracle, m, n, k, kw, dtype, out_dtype):
+    run_case(client, oracle, m, n, k, dtype, out_dtype, False, ALGOS["nnrows"], **kw)
+
+
+def test_few_rows_times_row_major_weight_selection_refusals_and_determinism(client, oracle):
+    bf = N.DTYPE_BF16
+    sel = lambda m, n, k, **kw: ops.gemm_select(client, _nn_desc(m, n, k, bf, bf, **kw))
+    assert sel(1, 8192, 8192) == sel(8, 8192, 8192) == sel(4, 4096, 14336) == sel(16, 128256, 4096) == N.GEMM_ALGO_NNROWS
+    # a tie at 16 rows; 250 column tiles need no K split; too little to stream; too many rows
+    assert N.GEMM_ALGO_NNROWS not in (sel(16, 8192, 8192), sel(4, 32000, 4096), sel(4, 4096, 4096), sel(17, 131072, 4096))
+    d = _nn_desc(16, 8192, 8192, bf, bf); d.trans_b = 1; d.ldb = 8192
+    assert ops.gemm_select(client, d) != N.GEMM_ALGO_NNROWS                                               # [N][K] weights: the streaming kernels
+    for m, n, k in [(17, 512, 512), (4, 516, 512), (4, 512, 516)]:                                         # forced: refused
+        with pytest.raises(ServerError) as e:
+            run_case(client, oracle, m, n, k, ElemType.BF16, ElemType.BF16, False, ALGOS["nnrows"])
+        assert e.value.code == N.E_UNSUPPORTED
+    # run to run bit-identical (K slices meet in slice order), and the per-strip tickets are back at zero after every call
+    m, n, k = 16, 8192, 8192
+    a = TensorHandle.uniform(client, (m, k), ElemType.BF16, 1, 5, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (k, n), ElemType.BF16, 1, 6, -1.0, 1.0)
+    outs = []
+    for _ in range(4):
+        c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 4), ElemType.F32)
+        ops.matmul(client, a, b, c, algo=ALGOS["nnrows"])
+        outs.append(c.to_numpy(client).copy())
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])
+    assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 1.0
 
 
 # ---- at most 16 rows or columns: the dot2 row-streaming kernel (gemm_skinny.hip) ---------------------------------------------

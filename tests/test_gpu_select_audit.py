@@ -34,15 +34,27 @@ GRID = [
     (5120, 5120, 5120), (4352, 4096, 4096), (8192, 8192, 2048), (6144, 4096, 2048),
 ]
 ALGOS = ["auto", "lp128", "lp256x128", "lp256w4", "lp256p", "lp256q", "stream64", "skinny"]
+# few rows against a ROW-MAJOR [K][N] weight (review of round 3, next #6): the rhs layout TensorHandle::new_contiguous gives
+GRID_NN = [(1, 8192, 8192), (4, 8192, 8192), (8, 8192, 8192), (16, 8192, 8192), (4, 4096, 4096), (4, 14336, 4096), (4, 4096, 14336),
+           (16, 4096, 14336), (16, 28672, 8192), (4, 32000, 4096), (1, 128256, 4096), (16, 128256, 4096), (32, 8192, 8192)]
+ALGOS_NN = ["auto", "lp128", "nnrows"]
 
 
 def test_auto_is_within_15_percent_of_the_best_forced_kernel_on_every_shape_of_the_grid(client):
+    audit(client, GRID, ALGOS, False, "select_audit.txt")
+
+
+def test_auto_on_few_rows_times_a_row_major_weight(client):
+    audit(client, GRID_NN, ALGOS_NN, True, "select_audit_nn.txt")
+
+
+def audit(client, grid, algos, nn, log_name):
     sys.path.insert(0, str(ROOT / "tools"))
     sys.path.insert(0, str(ROOT))
     import ab_algos
     import bench
     ev = bench.Events(client)
-    res = ab_algos.measure(client, ev, GRID, ALGOS, rounds=3, iters=10)
+    res = ab_algos.measure(client, ev, grid, algos, rounds=3, iters=10, nn=nn)
 
     def is_behind(r):
         us = {a: t for a, t in r["us"].items() if t == t}
@@ -51,7 +63,7 @@ def test_auto_is_within_15_percent_of_the_best_forced_kernel_on_every_shape_of_t
     # a shape that looks behind is measured once more, longer, before it counts (a 20 us launch beside a DVFS step is noisy)
     suspects = [shape for shape, r in res.items() if is_behind(r)]
     if suspects:
-        res.update(ab_algos.measure(client, ev, suspects, ALGOS, rounds=7, iters=20))
+        res.update(ab_algos.measure(client, ev, suspects, algos, rounds=7, iters=20, nn=nn))
     lines, behind = [], []
     for (m, n, k), r in res.items():
         us = {a: t for a, t in r["us"].items() if t == t}
@@ -66,7 +78,7 @@ def test_auto_is_within_15_percent_of_the_best_forced_kernel_on_every_shape_of_t
     out = Path(os.environ.get("GRAFT_REPO_ROOT", ROOT)) / "gpurun_out"
     try:
         out.mkdir(exist_ok=True)
-        (out / "select_audit.txt").write_text("\n".join(lines) + "\n")
+        (out / log_name).write_text("\n".join(lines) + "\n")
     except OSError:
         pass
     print("\n".join(lines))
