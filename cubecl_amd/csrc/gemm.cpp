@@ -31,7 +31,7 @@ int32_t validate(mi355_ctx *ctx, const mi355_gemm_desc *d, const void *a, const 
     return -1;  // proceed
 }
 
-int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
+int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const void *c, bool strip_kernel = true)
 {
     if (d.k == 0) return MI355_GEMM_ALGO_GENERIC;  // writes zeros
     if (is_fp8(d.dtype_ab)) {   // 256x256 tiles from 129 tiles up (as for bf16), the 128x128 kernel below that
@@ -85,7 +85,7 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
         // 1 / 4 / 8 x 8192 x 8192 25.6 / 26.5 / 27.8 against 30.9 (16 rows: a tie), 4 x 14336 x 4096 23.2 / 25.7, 4 x 4096 x 14336
         // 23.9 / 25.9, 1 / 16 x 128256 x 4096 151 / 191 and 176 / 195; not taken: 4 x 32000 x 4096 44.6 / 40.8 (250 tiles, no
         // split), 4 x 4096 x 4096 13.8 / 11.7, 16 x 28672 x 8192 85 / 76.
-        if (d.batch == 1 && d.n * d.k >= ((int64_t)1 << 25) && ((d.m <= 8 && d.n <= 16384) || (d.m <= 16 && d.n > 65536)) &&
+        if (strip_kernel && d.batch == 1 && d.n * d.k >= ((int64_t)1 << 25) && ((d.m <= 8 && d.n <= 16384) || (d.m <= 16 && d.n > 65536)) &&
             gemm_nnrows_supports(d, a, b, c))
             return MI355_GEMM_ALGO_NNROWS;
         const int64_t tiles256 = ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch;
@@ -387,6 +387,9 @@ MI355_API int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_ge
             algo = select_auto(d, a, b, c);
         }
     }
+    // the strip kernel needs scratch + ticket words that cannot be created inside a capture window: AUTO then takes what it took
+    // before that kernel existed (as the split-K paths fall back to their unsplit forms)
+    if (d.algo == MI355_GEMM_ALGO_AUTO && algo == MI355_GEMM_ALGO_NNROWS && !gemm_nnrows_ready(ctx, s, d)) algo = select(d, a, b, c, false);
     if (d.algo == MI355_GEMM_ALGO_AUTO && algo == MI355_GEMM_ALGO_LP_256W4) {
         tail_plan tp;
         if (plan_tail_split(d, tp) && run_tail_split(ctx, s, d, a, b, c, tp) == MI355_OK) return MI355_OK;

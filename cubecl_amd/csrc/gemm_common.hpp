@@ -133,6 +133,7 @@ int32_t launch_gemm_skinny(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc 
 bool gemm_skinny_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 int32_t launch_gemm_nnrows(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 bool gemm_nnrows_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
+bool gemm_nnrows_ready(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d);   // its scratch exists or may be created now
 int32_t launch_gemm_stream64(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 bool gemm_stream64_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 // block-scaled (MX) form of the same kernel; sa_t / sb_t are the re-arranged scales (gemm_scaled.hip)

@@ -29,11 +29,6 @@
 
 using namespace mi355;
 
-namespace mi355 {
-int32_t strip_tickets_for_stream(mi355_ctx *ctx, hipStream_t s, unsigned int **out);   // reduce.hip
-void strip_tickets_mark_dirty(mi355_ctx *ctx);
-}  // namespace mi355
-
 namespace {
 
 #ifndef NNR_U
@@ -403,6 +398,20 @@ bool gemm_nnrows_supports(const mi355_gemm_desc &d, const void *a, const void *b
     if ((reinterpret_cast<uintptr_t>(a) & 15u) || (reinterpret_cast<uintptr_t>(b) & 15u)) return false;
     nn_plan p;
     return plan_for(d, 256, p);
+}
+
+// Outside a capture window everything can be allocated on the spot; inside one, the K-slice partials and the ticket words
+// must already be there (a first call outside the window creates them).
+bool gemm_nnrows_ready(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d)
+{
+    if (!ctx->capturing) return true;
+    nn_plan p;
+    const int cus = ctx->props.num_streaming_multiprocessors > 0 ? ctx->props.num_streaming_multiprocessors : 256;
+    if (!plan_for(d, cus, p)) return false;
+    if (p.slices == 1) return true;
+    if (!ctx->ticket_buf || ctx->tickets_dirty) return false;
+    const auto it = ctx->scratch.find({s, SCRATCH_NNROWS});
+    return it != ctx->scratch.end() && it->second.second >= (size_t)d.batch * p.slices * d.m * d.n * sizeof(float);
 }
 
 int32_t launch_gemm_nnrows(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c)

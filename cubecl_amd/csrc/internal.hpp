@@ -51,6 +51,8 @@ struct mi355_ctx {
     bool comm_dirty = false;
     void *ticket_buf = nullptr;            // library-owned device scratch: arrival tickets of the reductions
     std::unordered_map<hipStream_t, uint32_t> ticket_slots;
+    std::vector<uint32_t> ticket_free;     // slots of destroyed streams (mi355_stream_destroy), reused first
+    uint32_t ticket_next = 0;              // first slot never handed out
     bool tickets_dirty = false;
     bool capturing = false;                // a hipStream capture window is open (graph API)
     hipStream_t capture_stream = nullptr;  // ... on this stream (ThreadLocal mode): the other lanes keep running real work
@@ -96,6 +98,11 @@ void pool_release_graph(mi355_ctx *ctx, uint64_t graph_id);   // a graph died: i
 void scratch_release(mi355_ctx *ctx, void *ptr);               // a graph died: drop one pin of a library scratch buffer
 // library-owned per-(stream, kind) device scratch (runtime.cpp): split-K slabs, re-laid-out GEMM operands, MX scales
 int32_t scratch_get(mi355_ctx *ctx, hipStream_t s, int kind, size_t bytes, void **out);
+// arrival-ticket words in library-owned device memory, one 2 KiB slot per live stream (runtime.cpp): word 0 the reductions',
+// words 16 ... 511 gemm_nnrows.hip's per-strip tickets
+int32_t ticket_for_stream(mi355_ctx *ctx, hipStream_t s, unsigned int **out);
+int32_t strip_tickets_for_stream(mi355_ctx *ctx, hipStream_t s, unsigned int **out);
+void strip_tickets_mark_dirty(mi355_ctx *ctx);
 int32_t pool_cleanup(mi355_ctx *ctx, int32_t explicit_);
 void pool_destroy(mi355_ctx *ctx);
 // More than 64 KiB of dynamic LDS needs a per-kernel opt-in; once per (context = device, kernel), keyed by the kernel's

@@ -382,34 +382,6 @@ reduce_kernel(const typename red_in<DT>::elem *__restrict__ head, uint32_t head_
     }
 }
 
-// One arrival-ticket word per stream in library-owned device scratch (zeroed when created, left zero by
-// every completed call).  Calls on one stream are stream-ordered, so a word is never shared by two
-// launches in flight.  A stream's slot is 2 KiB: word 0 is the reductions' ticket, words 16 ... 511 are the per-strip
-// tickets of gemm_nnrows.hip (mi355::strip_tickets_for_stream).
-constexpr uint32_t TICKET_SLOT_BYTES = 2048;
-int32_t ticket_for_stream(mi355_ctx *ctx, hipStream_t s, unsigned int **out)
-{
-    constexpr uint32_t SLOTS = 1024;
-    if (ctx->capturing && (!ctx->ticket_buf || ctx->tickets_dirty))      // hipMalloc / hipMemset are not capturable
-        return fail(ctx, MI355_E_UNSUPPORTED, "reduction inside a graph capture before its scratch exists: run it once before capturing");
-    if (!ctx->ticket_buf) {
-        MI355_HIP(ctx, hipMalloc(&ctx->ticket_buf, (size_t)SLOTS * TICKET_SLOT_BYTES));
-        MI355_HIP(ctx, hipMemset(ctx->ticket_buf, 0, (size_t)SLOTS * TICKET_SLOT_BYTES));
-    } else if (ctx->tickets_dirty) {
-        MI355_HIP(ctx, hipDeviceSynchronize());
-        MI355_HIP(ctx, hipMemset(ctx->ticket_buf, 0, (size_t)SLOTS * TICKET_SLOT_BYTES));
-    }
-    ctx->tickets_dirty = false;
-    auto it = ctx->ticket_slots.find(s);
-    if (it == ctx->ticket_slots.end()) {
-        if (ctx->ticket_slots.size() >= SLOTS)
-            return fail(ctx, MI355_E_UNSUPPORTED, "reductions were issued on more than %u distinct streams of one context", SLOTS);
-        it = ctx->ticket_slots.emplace(s, (uint32_t)ctx->ticket_slots.size()).first;
-    }
-    *out = reinterpret_cast<unsigned int *>(static_cast<char *>(ctx->ticket_buf) + (size_t)it->second * TICKET_SLOT_BYTES);
-    return MI355_OK;
-}
-
 uint32_t pick_grid(const mi355_ctx *ctx, uint64_t n, uint64_t tile_elems = RED_TILE)
 {
     const uint64_t tiles = (n + tile_elems - 1) / tile_elems;
@@ -998,22 +970,6 @@ argmax_combine_kernel(const uint32_t *__restrict__ records, uint32_t count, comb
 }
 
 }  // namespace
-
-namespace mi355 {
-
-// gemm_nnrows.hip: up to STRIP_TICKETS arrival words of the stream's slot (zero between calls, as the reductions' word)
-int32_t strip_tickets_for_stream(mi355_ctx *ctx, hipStream_t s, unsigned int **out)
-{
-    unsigned int *t = nullptr;
-    const int32_t rc = ticket_for_stream(ctx, s, &t);
-    if (rc != MI355_OK) return rc;
-    *out = t + 16;
-    return MI355_OK;
-}
-
-void strip_tickets_mark_dirty(mi355_ctx *ctx) { ctx->tickets_dirty = true; }
-
-}  // namespace mi355
 
 MI355_API int32_t mi355_reduce_workspace_bytes(mi355_ctx *ctx, uint64_t n, uint64_t *out_bytes)
 {

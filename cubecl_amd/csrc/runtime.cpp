@@ -389,7 +389,32 @@ MI355_API int32_t mi355_stream_create(mi355_ctx *ctx, mi355_stream *out_stream)
 MI355_API int32_t mi355_stream_destroy(mi355_ctx *ctx, mi355_stream stream)
 {
     MI355_REQUIRE_CTX(ctx);
-    if (stream) MI355_HIP(ctx, hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)));
+    if (!stream) return MI355_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (s == ctx->compute_stream || s == ctx->comm_stream)
+        return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_stream_destroy: the context's own streams die with the context");
+    // What the library keeps per stream goes with it: the scratch buffers (split-K slabs, re-laid-out operands, partial sums) and
+    // the ticket slot.  A service that creates a stream per request would otherwise leak both -- and the driver hands a dead
+    // stream's handle to the next hipStreamCreate, which would then inherit them.  The stream's work is finished first; scratch a
+    // live graph replays against is retired (freed when the last such graph dies), not freed.
+    MI355_HIP(ctx, hipStreamSynchronize(s));
+    for (auto it = ctx->scratch.begin(); it != ctx->scratch.end();) {
+        if (it->first.first != s) { ++it; continue; }
+        void *p = it->second.first;
+        if (p) {
+            const auto pin = ctx->scratch_refs.find(p);
+            if (pin != ctx->scratch_refs.end() && pin->second > 0) ctx->scratch_retired.insert(p);
+            else if (ctx->capture_scratch.count(p)) ctx->scratch_retired.insert(p);   // handed out inside the open window
+            else hipFree(p);
+        }
+        it = ctx->scratch.erase(it);
+    }
+    const auto slot = ctx->ticket_slots.find(s);
+    if (slot != ctx->ticket_slots.end()) {
+        ctx->ticket_free.push_back(slot->second);
+        ctx->ticket_slots.erase(slot);
+    }
+    MI355_HIP(ctx, hipStreamDestroy(s));
     return MI355_OK;
 }
 
@@ -795,6 +820,48 @@ int32_t scratch_get(mi355_ctx *ctx, hipStream_t s, int kind, size_t bytes, void 
     *out = slot.first;
     return MI355_OK;
 }
+
+// One arrival-ticket word per stream in library-owned device scratch (zeroed when created, left zero by
+// every completed call).  Calls on one stream are stream-ordered, so a word is never shared by two
+// launches in flight.  A stream's slot is 2 KiB: word 0 is the reductions' ticket, words 16 ... 511 are the per-strip
+// tickets of gemm_nnrows.hip (mi355::strip_tickets_for_stream).
+constexpr uint32_t TICKET_SLOT_BYTES = 2048;
+int32_t ticket_for_stream(mi355_ctx *ctx, hipStream_t s, unsigned int **out)
+{
+    constexpr uint32_t SLOTS = 1024;
+    if (ctx->capturing && (!ctx->ticket_buf || ctx->tickets_dirty))      // hipMalloc / hipMemset are not capturable
+        return fail(ctx, MI355_E_UNSUPPORTED, "reduction inside a graph capture before its scratch exists: run it once before capturing");
+    if (!ctx->ticket_buf) {
+        MI355_HIP(ctx, hipMalloc(&ctx->ticket_buf, (size_t)SLOTS * TICKET_SLOT_BYTES));
+        MI355_HIP(ctx, hipMemset(ctx->ticket_buf, 0, (size_t)SLOTS * TICKET_SLOT_BYTES));
+    } else if (ctx->tickets_dirty) {
+        MI355_HIP(ctx, hipDeviceSynchronize());
+        MI355_HIP(ctx, hipMemset(ctx->ticket_buf, 0, (size_t)SLOTS * TICKET_SLOT_BYTES));
+    }
+    ctx->tickets_dirty = false;
+    auto it = ctx->ticket_slots.find(s);
+    if (it == ctx->ticket_slots.end()) {
+        uint32_t slot;
+        if (!ctx->ticket_free.empty()) { slot = ctx->ticket_free.back(); ctx->ticket_free.pop_back(); }
+        else if (ctx->ticket_next < SLOTS) slot = ctx->ticket_next++;
+        else return fail(ctx, MI355_E_UNSUPPORTED, "reductions were issued on more than %u live streams of one context", SLOTS);
+        it = ctx->ticket_slots.emplace(s, slot).first;
+    }
+    *out = reinterpret_cast<unsigned int *>(static_cast<char *>(ctx->ticket_buf) + (size_t)it->second * TICKET_SLOT_BYTES);
+    return MI355_OK;
+}
+
+// gemm_nnrows.hip: the per-strip arrival words of the stream's slot (zero between calls, as the reductions' word)
+int32_t strip_tickets_for_stream(mi355_ctx *ctx, hipStream_t s, unsigned int **out)
+{
+    unsigned int *t = nullptr;
+    const int32_t rc = ticket_for_stream(ctx, s, &t);
+    if (rc != MI355_OK) return rc;
+    *out = t + 16;
+    return MI355_OK;
+}
+
+void strip_tickets_mark_dirty(mi355_ctx *ctx) { ctx->tickets_dirty = true; }
 
 void scratch_release(mi355_ctx *ctx, void *ptr)
 {

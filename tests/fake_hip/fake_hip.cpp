@@ -264,6 +264,7 @@ hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t
 }
 hipError_t hipMemcpyPeerAsync(void *d, int, const void *s, int, size_t n, hipStream_t st) { memcpy(d, s, n); work(st); return hipSuccess; }
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t st) { memset(d, v, n); work(st); return hipSuccess; }
+hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 hipError_t hipModuleLoadData(hipModule_t *m, const void *image)
 {
     if (memcmp(image, "FAKEHSACO", 9) != 0) return hipErrorInvalidValue;      // what a bad code object gets from the driver
@@ -331,4 +332,12 @@ TEST_API int32_t faketest_scratch_get(mi355_ctx *ctx, void *stream, int32_t kind
     return mi355::scratch_get(ctx, stream ? static_cast<hipStream_t>(stream) : ctx->compute_stream, kind, bytes, out);
 }
 TEST_API void faketest_set_comm_dirty(mi355_ctx *ctx, int32_t on) { ctx->comm_dirty = on != 0; }
+// ... and so do the arrival-ticket slots (the reductions and gemm_nnrows.hip call it): returns the slot index of the stream
+TEST_API int32_t faketest_ticket_slot(mi355_ctx *ctx, void *stream, int64_t *out_slot)
+{
+    unsigned int *t = nullptr;
+    const int32_t rc = mi355::ticket_for_stream(ctx, stream ? static_cast<hipStream_t>(stream) : ctx->compute_stream, &t);
+    if (rc == MI355_OK) *out_slot = (reinterpret_cast<char *>(t) - static_cast<char *>(ctx->ticket_buf)) / 2048;
+    return rc;
+}
 #endif

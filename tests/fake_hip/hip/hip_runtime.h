@@ -57,6 +57,7 @@ hipError_t hipMemcpy2DAsync(void *dst, size_t dpitch, const void *src, size_t sp
                             hipMemcpyKind kind, hipStream_t stream);
 hipError_t hipMemcpyPeerAsync(void *dst, int dst_device, const void *src, int src_device, size_t bytes, hipStream_t stream);
 hipError_t hipMemsetAsync(void *dst, int value, size_t bytes, hipStream_t stream);
+hipError_t hipMemset(void *dst, int value, size_t bytes);
 hipError_t hipModuleLoadData(hipModule_t *module, const void *image);
 hipError_t hipModuleUnload(hipModule_t module);
 hipError_t hipModuleGetFunction(hipFunction_t *function, hipModule_t module, const char *name);

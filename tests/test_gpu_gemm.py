@@ -715,12 +715,13 @@ def test_row_major_b_refusals_of_the_tile_kernel(client, oracle):
         assert ops.gemm_relayout_plan(client, d) == (False, True) and ops.gemm_select(client, d) != N.GEMM_ALGO_GENERIC
     # few COLUMNS: B is the small operand, re-laid out for the streaming kernel (which only exists for K-contiguous operands);
     # few ROWS (x [M][K] times a row-major weight [K][N], the decode case): B is the streamed operand and is never transposed --
-    # the 128x128 kernel stages it natively
+    # the strip kernel (up to 8 rows at this size, round 4) or the 128x128 kernel stage it natively
     d = _nn_desc(8192, 16, 8192, ElemType.BF16, ElemType.BF16)
     assert ops.gemm_relayout_plan(client, d) == (False, True) and ops.gemm_select(client, d) == N.GEMM_ALGO_STREAM64
     for m in (1, 16, 64):
         d = _nn_desc(m, 8192, 8192, ElemType.BF16, ElemType.BF16)
-        assert ops.gemm_relayout_plan(client, d) == (False, False) and ops.gemm_select(client, d) == N.GEMM_ALGO_LP_128
+        assert ops.gemm_relayout_plan(client, d) == (False, False)
+        assert ops.gemm_select(client, d) == (N.GEMM_ALGO_NNROWS if m == 1 else N.GEMM_ALGO_LP_128)
 
 
 # ---- layouts the MFMA kernels do not stage directly: re-laid out K-contiguous into library scratch first ------------
@@ -1091,6 +1092,28 @@ def test_few_rows_times_row_major_weight_matches_the_oracle(client, oracle, m, n
     run_case(client, oracle, m, n, k, dtype, out_dtype, False, ALGOS["nnrows"], **kw)
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_few_rows_times_row_major_weight_random_shapes(client, oracle, seed):
+    """Seeded draws over everything the strip kernel's geometry depends on: rows (row blocks of 4), N (strips, ragged last strip),
+    K (slices, ring rounds, ragged last iteration, x chunks of 2048 / 4096 / 8192), pitches, batch, dtypes."""
+    rng = np.random.default_rng(1000 + seed)
+    m = int(rng.integers(1, 17))
+    n = 8 * int(rng.choice([1, 3, 16, 33, 64, 129, 500, 1024, 2051, 4100]))
+    k = 8 * int(rng.choice([1, 2, 7, 8, 9, 31, 64, 97, 256, 511, 1025, 2048, 3000]))
+    if n * k > (1 << 26):
+        k = max(8, (1 << 26) // n // 8 * 8)
+    kw = {"batch": int(rng.choice([1, 1, 1, 2, 3]))}
+    if rng.random() < 0.4:
+        kw["ldb"] = n + 8 * int(rng.integers(1, 5))
+    if rng.random() < 0.4:
+        kw["lda"] = k + 8 * int(rng.integers(1, 5))
+    if rng.random() < 0.4:
+        kw["ldc"] = n + int(rng.integers(1, 9))
+    dtype = ElemType.BF16 if rng.random() < 0.6 else ElemType.F16
+    out = ElemType.F32 if rng.random() < 0.5 else dtype
+    run_case(client, oracle, m, n, k, dtype, out, False, ALGOS["nnrows"], **kw)
+
+
 def test_few_rows_times_row_major_weight_selection_refusals_and_determinism(client, oracle):
     bf = N.DTYPE_BF16
     sel = lambda m, n, k, **kw: ops.gemm_select(client, _nn_desc(m, n, k, bf, bf, **kw))
@@ -1114,6 +1137,46 @@ def test_few_rows_times_row_major_weight_selection_refusals_and_determinism(clie
         outs.append(c.to_numpy(client).copy())
     assert all(np.array_equal(outs[0], o) for o in outs[1:])
     assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 1.0
+
+
+def test_few_rows_times_row_major_weight_inside_a_capture_window(client, oracle):
+    """The strip kernel's K-slice scratch and ticket words cannot be created inside a capture window: on a stream that has them
+    (a warm-up call) the captured launch replays the eager bits; on a stream that does not, AUTO takes the tile kernel instead of
+    failing (as the split-K paths fall back) -- and the replay is still right."""
+    import ctypes as C
+    lib, ctx, chk = client.lib, client.ctx, client._s.check
+    m, n, k = 4, 8192, 8192
+    a = TensorHandle.uniform(client, (m, k), ElemType.BF16, 1, 7, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (k, n), ElemType.BF16, 1, 8, -1.0, 1.0)
+    d = _nn_desc(m, n, k, N.DTYPE_BF16, N.DTYPE_F32)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_NNROWS
+    client.sync()
+    want = None
+    streams = [C.c_void_p(), C.c_void_p()]                    # both alive at once: a destroyed stream's handle (and scratch) may be reused
+    for st in streams:
+        chk(lib.mi355_stream_create(ctx, C.byref(st)))
+    for warm, st in zip((True, False), streams):
+        c = client.empty(m * n * 4)
+        run = lambda: chk(lib.mi355_gemm(ctx, st, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()), C.c_void_p(c.device_ptr())))
+        if warm:
+            run()
+            chk(lib.mi355_sync(ctx, st))
+            want = client.read_one(c).view(np.float32).copy()
+        chk(lib.mi355_graph_begin_capture(ctx, st))
+        run()
+        g = C.c_void_p()
+        chk(lib.mi355_graph_end_capture(ctx, st, C.byref(g)))
+        chk(lib.mi355_memset(ctx, st, C.c_void_p(c.device_ptr()), 0xEE, m * n * 4))
+        chk(lib.mi355_graph_replay(ctx, st, g))
+        chk(lib.mi355_sync(ctx, st))
+        got = client.read_one(c).view(np.float32)
+        if warm:
+            assert np.array_equal(got, want)                                   # the strip kernel, same bits as eager
+        else:
+            assert np.allclose(got, want, rtol=0, atol=1e-3 * np.abs(want).max()) and not np.array_equal(got, want)   # another kernel's association
+        chk(lib.mi355_graph_destroy(ctx, g))
+    for st in streams:
+        chk(lib.mi355_stream_destroy(ctx, st))
 
 
 # ---- at most 16 rows or columns: the dot2 row-streaming kernel (gemm_skinny.hip) ---------------------------------------------

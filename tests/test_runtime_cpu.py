@@ -395,6 +395,51 @@ def test_library_scratch_baked_into_a_graph_is_never_freed_or_regrown_under_it(l
     assert lib.pooltest_inside_allocation(p3, 1 << 22) == 1                                      # the current buffer is untouched
 
 
+def test_a_destroyed_stream_takes_its_library_scratch_and_its_ticket_slot_with_it(lib, ctx):
+    """The library keeps scratch buffers and one ticket slot per stream.  A service that creates a stream per request must not
+    leak them (1024 ticket slots per context), and the driver may hand a dead stream's handle to the next hipStreamCreate, which
+    must not inherit buffers; scratch a live graph replays against outlives the stream until that graph dies."""
+    lib.faketest_ticket_slot.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    lib.faketest_ticket_slot.restype = C.c_int32
+    slot, seen = C.c_int64(-1), set()
+    assert lib.faketest_ticket_slot(ctx, None, C.byref(slot)) == N.OK and slot.value == 0      # the compute stream came first
+    for cycle in range(1100):                                  # more streams than a context has ticket slots, one at a time
+        s = C.c_void_p()
+        assert lib.mi355_stream_create(ctx, C.byref(s)) == N.OK
+        assert lib.faketest_ticket_slot(ctx, s, C.byref(slot)) == N.OK, (cycle, lib.mi355_last_error(ctx))
+        seen.add(slot.value)
+        assert lib.mi355_stream_destroy(ctx, s) == N.OK
+    assert seen == {1}                                         # the dead stream's slot is the next stream's
+    live = [C.c_void_p() for _ in range(3)]
+    for s in live:
+        assert lib.mi355_stream_create(ctx, C.byref(s)) == N.OK and lib.faketest_ticket_slot(ctx, s, C.byref(slot)) == N.OK
+        seen.add(slot.value)
+    assert seen == {1, 2, 3}                                   # live streams never share one
+    for s in live:
+        assert lib.mi355_stream_destroy(ctx, s) == N.OK
+    s, p, q = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert lib.mi355_stream_create(ctx, C.byref(s)) == N.OK
+    frees = _device(lib)["frees"]
+    assert lib.faketest_scratch_get(ctx, s, 0, 1 << 20, C.byref(p)) == N.OK and lib.faketest_scratch_get(ctx, s, 2, 1 << 16, C.byref(q)) == N.OK
+    assert lib.mi355_stream_destroy(ctx, s) == N.OK
+    assert _device(lib)["frees"] == frees + 2 and lib.pooltest_inside_allocation(p, 1 << 20) == 0
+    # pinned by a graph: retired with the stream, freed with the graph
+    s2, graph = C.c_void_p(), C.c_void_p()
+    assert lib.mi355_stream_create(ctx, C.byref(s2)) == N.OK
+    assert lib.faketest_scratch_get(ctx, s2, 0, 1 << 20, C.byref(p)) == N.OK
+    assert lib.mi355_graph_begin_capture(ctx, s2) == N.OK
+    assert lib.faketest_scratch_get(ctx, s2, 0, 1 << 19, C.byref(q)) == N.OK and q.value == p.value
+    assert lib.mi355_graph_end_capture(ctx, s2, C.byref(graph)) == N.OK
+    frees = _device(lib)["frees"]
+    assert lib.mi355_stream_destroy(ctx, s2) == N.OK
+    assert _device(lib)["frees"] == frees and lib.pooltest_inside_allocation(p, 1 << 20) == 1
+    assert lib.mi355_graph_destroy(ctx, graph) == N.OK
+    assert _device(lib)["frees"] == frees + 1 and lib.pooltest_inside_allocation(p, 1 << 20) == 0
+    # the context's own streams are not the caller's to destroy
+    own = C.c_void_p()
+    assert lib.mi355_default_stream(ctx, C.byref(own)) == N.OK and lib.mi355_stream_destroy(ctx, own) == N.E_INVALID_ARGUMENT
+
+
 def test_graph_destroy_waits_for_replays_and_reports_a_failed_wait(lib, ctx):
     mod, fn, graph, s2 = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
     assert lib.mi355_module_load(ctx, b"FAKEHSACO", 9, C.byref(mod)) == N.OK
