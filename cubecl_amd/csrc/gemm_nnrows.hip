@@ -44,6 +44,14 @@ namespace {
 #define NNR_EACH_U(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 #endif
 typedef __attribute__((address_space(1))) const u32x4 *gptr_u32x4;
+// Dev timing trace (-DNNR_TRACE, never in the product library): shader-clock stamps of thread 0 of every workgroup -- entry, x
+// staged, K loop left, partials stored, ticket taken, exit -- read back with mi355_dev_nnr_trace (tools/dev/nnrows_trace.py).
+#ifdef NNR_TRACE
+__device__ unsigned long long nnr_trace_buf[1024 * 8];
+#define NNR_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 1024) nnr_trace_buf[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NNR_STAMP(slot)
+#endif
 constexpr int STRIP_TICKETS = 496;
 constexpr int SCRATCH_NNROWS = 7;
 
@@ -103,6 +111,7 @@ __global__ void __launch_bounds__(256) gemm_nnrows_kernel(const nn_args g)
     const uint16_t *Bp = g.b + (int64_t)batch * g.stride_b + (col < g.n ? col : 0);
     const int kbeg = (int)slice * g.ks, kend = min(g.k, kbeg + g.ks);
 
+    NNR_STAMP(0);
     f32x4 acc[MB][8];
 #pragma unroll
     for (int r = 0; r < MB; ++r)
@@ -186,15 +195,15 @@ __global__ void __launch_bounds__(256) gemm_nnrows_kernel(const nn_args g)
             }
         };
         __syncthreads();                                                   // the previous chunk's x has been read
-#define NNR_X(u) issue(u < nit, u, u);
-        NNR_EACH_U(NNR_X)                                                  // W first: x's staging latency hides behind it
-#undef NNR_X
-        {   // x[0 .. MP)[kc0 .. kc0 + nit * RI) -> LDS, zeros past M and past the slice; loads batched four deep, unconditional
+        {   // x[0 .. MP)[kc0 .. kc0 + nit * RI) -> LDS, zeros past M and past the slice; XB loads per thread in flight, unconditional.
+            // The first batch of x goes out BEFORE the ring's first fill and is stored after it: queued behind 24 MiB of W
+            // (all workgroups start together) x came back last, 10 000 cycles in, with the ring long landed and nothing in flight.
+            constexpr int XB = 4 * MB;
             const int epr = nit * RI / 8, pieces = MP * epr;               // 16-byte pieces per row / in all
-            for (int base = 0; base < pieces; base += 4 * 256) {
-                u32x4 xv[4];
+            u32x4 xv[XB];
+            auto x_load = [&](int base) __attribute__((always_inline)) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < XB; ++i) {
                     const int idx = base + i * 256 + tid, mm = idx / epr, kk = (idx - mm * epr) * 8;
                     const bool ok = idx < pieces && mm < g.m && kc0 + kk < kc1;
                     uint64_t addr = ok ? reinterpret_cast<uint64_t>(A + (int64_t)mm * g.lda + kc0 + kk) : reinterpret_cast<uint64_t>(dummy);
@@ -202,16 +211,27 @@ __global__ void __launch_bounds__(256) gemm_nnrows_kernel(const nn_args g)
                     xv[i] = *reinterpret_cast<gptr_u32x4>(addr);
                     if (!ok) xv[i] = (u32x4){0u, 0u, 0u, 0u};
                 }
+            };
+            auto x_store = [&](int base) __attribute__((always_inline)) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < XB; ++i) {
                     const int idx = base + i * 256 + tid, mm = idx / epr, kk = (idx - mm * epr) * 8;
                     // stored UNCONDITIONALLY (pieces past the end go to a dump slot): a load whose value one path never uses stays
                     // "in flight" for the compiler, which then drains vmcnt inside the streaming loop before reusing its registers
                     *reinterpret_cast<u32x4 *>(xs + (idx < pieces ? mm * XP + kk : MP * XP)) = xv[i];
                 }
-            }
+            };
+            x_load(0);
+            __builtin_amdgcn_sched_barrier(0);                            // (the scheduler would put the 4 U ring loads first again)
+#define NNR_X(u) issue(u < nit, u, u);
+            NNR_EACH_U(NNR_X)
+#undef NNR_X
+            __builtin_amdgcn_sched_barrier(0);
+            x_store(0);
+            for (int base = XB * 256; base < pieces; base += XB * 256) { x_load(base); x_store(base); }
         }
         __syncthreads();                                                   // (the compiler's vmcnt(0) for x also lands the first U groups)
+        NNR_STAMP(1);
         int it0 = 0;
         // Every wait is a constant: before slot u is consumed, exactly U - 1 younger groups are in flight (4 loads each) in every
         // round but the last, which refills nothing (U - 1 - u younger).
@@ -246,7 +266,9 @@ __global__ void __launch_bounds__(256) gemm_nnrows_kernel(const nn_args g)
 #undef NNR_WAIT
 
     // ---- the 4 * Q copies of the strip meet in LDS (fixed order) --------------------------------------------------------------
+    NNR_STAMP(2);
     __syncthreads();
+    NNR_STAMP(3);
     float *red = reinterpret_cast<float *>(smem);                          // [4 * Q][MP][COLS]
     {
         const int copy = w * Q + q;
@@ -289,30 +311,72 @@ __global__ void __launch_bounds__(256) gemm_nnrows_kernel(const nn_args g)
     // whole XCD (buffer_wbl2 / buffer_inv sc1) -- with one per workgroup the kernel ran 50 us where the stream takes 24.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // my partials have left the wave ...
     __syncthreads();                                                       // ... every wave's have, before the ticket
+    NNR_STAMP(4);
     unsigned int *ticket = g.tickets + batch * g.strips + strip;
     if (tid == 0) {
         const unsigned int old = __hip_atomic_fetch_add((gu32 *)ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         is_last = old == (unsigned int)g.slices - 1u ? 1u : 0u;
     }
     __syncthreads();
+    NNR_STAMP(5);
     if (!is_last) return;
-    for (int idx = tid; idx < g.m * (COLS / 4); idx += 256) {
-        const int mm = idx / (COLS / 4), c4 = (idx % (COLS / 4)) * 4;
-        if (strip_col + c4 >= g.n) continue;
-        gu64 *src = (gu64 *)reinterpret_cast<unsigned long long *>(part + (int64_t)mm * g.n + strip_col + c4);
-        const int64_t step = (int64_t)g.m * g.n / 2;                       // 8-byte words between slices (N % 8 == 0)
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-        for (int sl = 0; sl < g.slices; ++sl) {
-            const unsigned long long lo = __hip_atomic_load(src + sl * step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long hi = __hip_atomic_load(src + sl * step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s += (f32x4){__uint_as_float((uint32_t)lo), __uint_as_float((uint32_t)(lo >> 32)), __uint_as_float((uint32_t)hi),
-                         __uint_as_float((uint32_t)(hi >> 32))};
-        }
+    // Sixteen 8-byte loads in flight per thread (one after the other, the same sum took 8 000 cycles for 16 rows x 4 slices:
+    // every agent-scope load is a trip to memory): QD quads of the strip per thread and pass, J slices at a time -- one quad x
+    // eight slices while the strip's quads fit one pass, two quads x four slices above.  Loads are unconditional (clamped
+    // indices) so that they can all be issued; what does not exist is not added.  Slices are added in slice order.
+    const int quads = g.m * (COLS / 4);
+    const int64_t step = (int64_t)g.m * g.n / 2;                           // 8-byte words between slices (N % 8 == 0)
+    auto fold = [&](auto qd_c, auto j_c) __attribute__((always_inline)) {
+        constexpr int QD = decltype(qd_c)::value, J = decltype(j_c)::value;
+        for (int base = 0; base < quads; base += QD * 256) {
+            int mm[QD], c4[QD];
+            bool live[QD];
+            gu64 *src[QD];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) store_c(C, g.dtype_c, cbase + (int64_t)mm * g.ldc + strip_col + c4 + e, s[e]);
-    }
+            for (int qd = 0; qd < QD; ++qd) {
+                const int idx = base + qd * 256 + tid;
+                const int id = idx < quads ? idx : 0;
+                mm[qd] = id / (COLS / 4); c4[qd] = (id % (COLS / 4)) * 4;
+                live[qd] = idx < quads && strip_col + c4[qd] < g.n;
+                if (!(strip_col + c4[qd] < g.n)) c4[qd] = 0;               // (a strip's first quad always exists)
+                src[qd] = (gu64 *)reinterpret_cast<unsigned long long *>(part + (int64_t)mm[qd] * g.n + strip_col + c4[qd]);
+            }
+            f32x4 sum[QD];
+#pragma unroll
+            for (int qd = 0; qd < QD; ++qd) sum[qd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int sl0 = 0; sl0 < g.slices; sl0 += J) {
+                unsigned long long wv[J][QD][2];
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const int64_t off = (int64_t)min(sl0 + j, g.slices - 1) * step;
+#pragma unroll
+                    for (int qd = 0; qd < QD; ++qd) {
+                        wv[j][qd][0] = __hip_atomic_load(src[qd] + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        wv[j][qd][1] = __hip_atomic_load(src[qd] + off + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+                    if (sl0 + j < g.slices) {
+#pragma unroll
+                        for (int qd = 0; qd < QD; ++qd)
+                            sum[qd] += (f32x4){__uint_as_float((uint32_t)wv[j][qd][0]), __uint_as_float((uint32_t)(wv[j][qd][0] >> 32)),
+                                               __uint_as_float((uint32_t)wv[j][qd][1]), __uint_as_float((uint32_t)(wv[j][qd][1] >> 32))};
+                    }
+            }
+#pragma unroll
+            for (int qd = 0; qd < QD; ++qd)
+                if (live[qd]) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) store_c(C, g.dtype_c, cbase + (int64_t)mm[qd] * g.ldc + strip_col + c4[qd] + e, sum[qd][e]);
+                }
+        }
+    };
+    if (quads <= 256) fold(std::integral_constant<int, 1>{}, std::integral_constant<int, 8>{});
+    else fold(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
     if (tid == 0) __hip_atomic_store((gu32 *)ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NNR_STAMP(6);
 }
 
 template <int MB, int S> constexpr size_t lds_bytes()
@@ -381,6 +445,15 @@ bool plan_for(const mi355_gemm_desc &d, int cus, nn_plan &out)
 }
 
 }  // namespace
+
+#ifdef NNR_TRACE
+extern "C" __attribute__((visibility("default"))) int mi355_dev_nnr_trace(unsigned long long *host_out, int clear)
+{
+    const int rc = (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(nnr_trace_buf), sizeof(unsigned long long) * 1024 * 8);
+    if (clear) { static unsigned long long z[1024 * 8]; (void)hipMemcpyToSymbol(HIP_SYMBOL(nnr_trace_buf), z, sizeof(z)); }
+    return rc;
+}
+#endif
 
 namespace mi355 {
 
