@@ -122,8 +122,18 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
         // against 51.2, 32 x 57344 x 4096 83.2 / 88.2; 32 x 16384 x 8192 at 512 workgroups: 45 against 71 the other way).
         const int64_t rows = std::min(d.m, d.n);
         const int64_t max_wgs = rows <= 16 ? 2048 : rows <= 32 ? 768 : 512;
-        if (small_bytes <= (1ll << 21) && wgs <= max_wgs && (nk64 <= 64 || (nk64 <= 128 && (wgs >= 8 || rows <= 32)) || wgs >= 192))
-            return MI355_GEMM_ALGO_STREAM64;
+        // Round 4, after the 128x128 kernel got its 64 x 128 tile (profiles/r04_rows_33_64_ab.txt, cold, us, stream64 / lp128): with
+        // 33-64 rows this kernel keeps K <= 2048 on any grid (48 x 4096 x 2048 8.0 / 11.3, 48 x 8192 x 2048 10.5 / 12.6) and the
+        // grids of about one workgroup per CU (48 x 8192 x 8192 29.3 / 37.7, 64 x 8192 x 4096 22.1 / 20.5: a tie); fewer
+        // workgroups walking a long K lose to split-K (48 x 2048 x 8192 24.4 / 13.3, 64 x 4096 x 8192 29.2 / 19.9, 48 x 4096 x 4096
+        // 15.5 / 12.7, 48 x 512 x 8192 19.1 / 10.2), and so do more workgroups than CUs (64 x 10240 x 4096 34.2 / 24.2, 64 x 14336 x 4096
+        // 36.2 / 33.2), K = 4096 on a full grid (64 x 8192 x 4096 22.1 / 20.5) and K past 8192 (64 x 8192 x 14336 57.7 / 44.0).
+        // Up to 32 rows the same holds with wider margins (profiles/r04_rows_le32_ab.txt): K = 8192 on fewer than 192 workgroups goes
+        // to split-K (32 x 512 x 8192 16.3 / 9.5, 16 x 2048 x 8192 18.8 / 11.9, 32 x 4096 x 8192 22.4 / 18.4; 32 x 6144 x 8192 24.5 / 26.4 the
+        // other way), K = 4096 is a tie from 96 workgroups up and 7 % behind below.
+        const bool grid_ok = rows <= 32 ? (nk64 <= 32 || (nk64 <= 64 && wgs >= 96) || wgs >= 192)
+                                        : (nk64 <= 32 || (wgs >= 224 && wgs <= 288 && nk64 > 64 && nk64 <= 128));
+        if (small_bytes <= (1ll << 21) && wgs <= max_wgs && grid_ok) return MI355_GEMM_ALGO_STREAM64;
     }
     // one or two rows (or columns): HBM-bound on the other operand; stream it once with dot products, no MFMA tile to fill
     // (gemm_skinny.hip: 20.4 us against 24.7 at 1 x 8192 x 8192).  Up to 16 rows when no MFMA kernel takes the descriptor.

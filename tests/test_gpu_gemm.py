@@ -1243,17 +1243,20 @@ def test_output_bound_shapes_select_the_small_tile(client):
     assert sel(1, 8192, 8192) == sel(8192, 2, 4096) == N.GEMM_ALGO_SKINNY
     assert sel(4, 8192, 8192) == sel(16, 8192, 8192) == sel(64, 8192, 8192) == sel(8192, 64, 8192) == N.GEMM_ALGO_STREAM64   # 3 ... 64 rows: no split-K
     assert sel(64, 32768, 4096) == sel(64, 4096, 16384) == sel(65, 8192, 8192) == sel(64, 64, 8192) == N.GEMM_ALGO_LP_128   # many rounds / few long workgroups / 65 rows
-    assert sel(64, 64, 4096) == sel(64, 2048, 8192) == sel(32, 8192, 16384) == sel(16, 28672, 8192) == sel(64, 14336, 4096) == N.GEMM_ALGO_STREAM64
-    assert sel(48, 512, 8192) == sel(64, 512, 8192) == N.GEMM_ALGO_STREAM64 and sel(32, 28672, 4096) == sel(32, 57344, 4096) == N.GEMM_ALGO_LP_128   # round 3
+    assert sel(64, 1024, 2048) == sel(64, 7168, 8192) == sel(32, 8192, 16384) == sel(16, 28672, 8192) == N.GEMM_ALGO_STREAM64
+    # round 4 (33-64 rows, after the 128x128 kernel's 64 x 128 tile): short grids walking a long K, more workgroups than CUs, K past 8192
+    assert sel(64, 64, 4096) == sel(64, 2048, 8192) == sel(64, 14336, 4096) == sel(64, 8192, 14336) == sel(48, 4096, 4096) == N.GEMM_ALGO_LP_128
+    assert sel(48, 512, 8192) == sel(64, 512, 8192) == sel(32, 28672, 4096) == sel(32, 57344, 4096) == N.GEMM_ALGO_LP_128   # rounds 3 and 4
     assert sel(64, 8192, 28672) == sel(64, 28672, 8192) == N.GEMM_ALGO_LP_128        # small operand past 2 MiB / 64 rows over more than 512 workgroups
-    assert sel(8192, 64, 14336) == N.GEMM_ALGO_STREAM64                               # 1.75 MiB of small operand still streams
+    assert sel(8192, 32, 14336) == N.GEMM_ALGO_STREAM64                               # 0.9 MiB of small operand still streams
     assert sel(4, 2048, 4096) == sel(384, 4, 8192) == sel(3, 512, 14336) == sel(4096, 4, 14336) == N.GEMM_ALGO_SKINNY   # 3-4 rows, fewer than 192 streaming workgroups
     assert sel(8192, 4, 2048) == sel(4, 8192, 8192) == N.GEMM_ALGO_STREAM64           # ... from 192 up the streaming kernel
     # the 256 x 128 tile: more than one 128x128 tile per CU, at most one 256 x 128 tile per CU, long K (round 3)
     assert sel(4096, 2048, 4096) == sel(2560, 2560, 3072) == sel(2048, 2048, 8192, batch=2) == sel(4096, 1536, 8192) == N.GEMM_ALGO_LP_256X128
     assert sel(4096, 2048, 2048) == sel(2048, 2048, 8192) == sel(3072, 2560, 1024) == N.GEMM_ALGO_LP_128   # K <= 2048 / one 128x128 tile per CU
     assert sel(4096, 2304, 4096) == N.GEMM_ALGO_LP_256W4                              # 288 tiles of 256 x 128: two rounds -- the 256x256 tile
-    assert sel(32, 512, 8192) == sel(512, 16, 8192) == N.GEMM_ALGO_STREAM64           # few workgroups are fine up to K = 8192
+    assert sel(32, 512, 2048) == sel(512, 16, 2048) == sel(32, 6144, 8192) == N.GEMM_ALGO_STREAM64   # few workgroups are fine up to K = 2048; 192 at any K
+    assert sel(32, 512, 8192) == sel(512, 16, 8192) == sel(16, 2048, 8192) == sel(32, 1024, 4096) == N.GEMM_ALGO_LP_128   # round 4: split-K instead
     assert sel(8192, 3072, 512) == N.GEMM_ALGO_LP_256Q and sel(8192, 3072, 640) == N.GEMM_ALGO_LP_256P   # 384 tiles: persistent from one round up
     assert sel(4096, 4096, 512) == N.GEMM_ALGO_LP_256W4                               # exactly one round: the plain kernel
 
