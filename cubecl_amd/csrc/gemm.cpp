@@ -85,12 +85,30 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
         // 1 / 4 / 8 x 8192 x 8192 25.6 / 26.5 / 27.8 against 30.9 (16 rows: a tie), 4 x 14336 x 4096 23.2 / 25.7, 4 x 4096 x 14336
         // 23.9 / 25.9, 1 / 16 x 128256 x 4096 151 / 191 and 176 / 195; not taken: 4 x 32000 x 4096 44.6 / 40.8 (250 tiles, no
         // split), 4 x 4096 x 4096 13.8 / 11.7, 16 x 28672 x 8192 85 / 76.
-        if (strip_kernel && d.batch == 1 && d.n * d.k >= ((int64_t)1 << 25) && ((d.m <= 8 && d.n <= 16384) || (d.m <= 16 && d.n > 65536)) &&
+        // ... or a second round of tiles it fills by less than three quarters (1 x 40568 x 3072: 317 tiles, 54.7 against 48.2)
+        const int64_t t128 = (d.n + 127) / 128;
+        if (strip_kernel && d.batch == 1 && d.n * d.k >= ((int64_t)1 << 25) &&
+            ((d.m <= 8 && (d.n <= 16384 || (t128 > 256 && t128 < 448))) || (d.m <= 16 && d.n > 65536)) &&
             gemm_nnrows_supports(d, a, b, c))
             return MI355_GEMM_ALGO_NNROWS;
         const int64_t tiles256 = ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch;
         const bool native = (std::min(d.m, d.n) > 128 && big4 && tiles256 > 128) || (std::min(d.m, d.n) > 64 && mid);
-        if (!native) return (mid && d.m <= d.n) ? MI355_GEMM_ALGO_LP_128 : MI355_GEMM_ALGO_GENERIC;
+        if (!native) {
+            if (mid && d.m <= d.n) return MI355_GEMM_ALGO_LP_128;
+            // Few COLUMNS (B is the small operand): the re-layout pass (one more launch, ~5 us) pays for itself only where the
+            // streaming kernels then win by more than that.  Round 4 (profiles/r04_few_columns_nn_ab.txt, us, re-layout + streaming
+            // kernel / 128x128 kernel on the row-major B as it is): where the K-contiguous twin would take the 128x128 kernel
+            // anyway the pass was pure loss (32768 x 64 x 512 13.1 / 10.2, 4096 x 64 x 8192 28.6 / 25.7); up to 16 columns the
+            // tile kernel wins or ties throughout (16384 x 16 x 128 11.3 / 6.1, 32768 x 16 x 512 18.5 / 9.7, 8192 x 16 x 2048
+            // 17.2 / 13.4; at K = 8192 a tie: 36.1 / 37.8, the pass stays); 64 columns keep it (8192 x 64 x 512 9.5 / 13.7, x 2048 14.2 / 18.1).
+            if (mid) {
+                static const char aligned_dummy __attribute__((aligned(16))) = 0;
+                mi355_gemm_desc e = d;                  // the K-contiguous twin: B re-laid out [N][K]
+                e.trans_b = 1; e.ldb = d.k; e.stride_b = d.stride_b ? d.n * d.k : 0;
+                if ((d.n <= 16 && d.k <= 4096) || select(e, a, &aligned_dummy, c, false) == MI355_GEMM_ALGO_LP_128) return MI355_GEMM_ALGO_LP_128;
+            }
+            return MI355_GEMM_ALGO_GENERIC;
+        }
     }
     // 3 ... 64 rows (or columns): 32 streamed rows x the whole K per workgroup, loader waves, no split-K (gemm_stream64.hip).
     // Interleaved against the split-K 128x128 path over 60 shapes (tools/dev/stream64_probe.py): faster by 5-50 % whenever its
@@ -131,9 +149,21 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
         // Up to 32 rows the same holds with wider margins (profiles/r04_rows_le32_ab.txt): K = 8192 on fewer than 192 workgroups goes
         // to split-K (32 x 512 x 8192 16.3 / 9.5, 16 x 2048 x 8192 18.8 / 11.9, 32 x 4096 x 8192 22.4 / 18.4; 32 x 6144 x 8192 24.5 / 26.4 the
         // other way), K = 4096 is a tie from 96 workgroups up and 7 % behind below.
-        const bool grid_ok = rows <= 32 ? (nk64 <= 32 || (nk64 <= 64 && wgs >= 96) || wgs >= 192)
+        // Few COLUMNS are not the mirror image: the 128x128 kernel has its 64 x 128 tile for few ROWS only, so with the large
+        // operand on the A side the streaming kernel keeps K <= 4096 on short grids (1472 x 25 x 3072 8.4 / 13.3, 8192 x 48 x 4096
+        // 20.9 / 22.4) -- and loses K past 8192 even on a full grid (9312 x 24 x 14336 68.9 / 53.8, 8192 x 64 x 14336 59.3 / 52.1;
+        // 32 x 8192 x 16384 with the rows on the A side: 48.1 / 62.0 the other way).
+        const bool few_rows = d.m <= d.n;
+        const bool grid_ok = rows <= 32 ? (nk64 <= 32 || (nk64 <= 64 && (wgs >= 96 || !few_rows)) || (wgs >= 192 && (few_rows || nk64 <= 128)))
                                         : (nk64 <= 32 || (wgs >= 224 && wgs <= 288 && nk64 > 64 && nk64 <= 128));
-        if (small_bytes <= (1ll << 21) && wgs <= max_wgs && grid_ok) return MI355_GEMM_ALGO_STREAM64;
+        // ... and with K <= 4096 few columns stream on any grid (the workgroup limits above were measured with the rows on the A
+        // side): 37824 x 23 x 3072 44.8 / 69.8, 51016 x 17 x 1536 32.9 / 39.1 (tools/dev/random_audit.py).
+        // (up to 32 columns: with 64 the tile kernels win there -- 51880 x 64 x 1024 42.2 / 26.2, 20880 x 64 x 1024 19.0 / 14.9.)
+        // Few rows whose 128-column tiles would fill a second round by less than three quarters also stay here past the
+        // workgroup limit: 20 x 40096 x 8192 (314 tiles) 100.4 / 151.1.
+        const int64_t t128 = (std::max(d.m, d.n) + 127) / 128 * d.batch;
+        const bool any_grid = (!few_rows && rows <= 32 && nk64 <= 64) || (few_rows && rows <= 32 && t128 > 256 && t128 < 448 && nk64 >= 64);
+        if (small_bytes <= (1ll << 21) && (any_grid || (wgs <= max_wgs && grid_ok))) return MI355_GEMM_ALGO_STREAM64;
     }
     // one or two rows (or columns): HBM-bound on the other operand; stream it once with dot products, no MFMA tile to fill
     // (gemm_skinny.hip: 20.4 us against 24.7 at 1 x 8192 x 8192).  Up to 16 rows when no MFMA kernel takes the descriptor.
@@ -156,7 +186,12 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
     }
     // at most 128 rows (or columns) over many tiles: a 256-row tile multiplies at least half zeros and streams no faster --
     // 64 x 128256 x 4096: 192 us on the 128x128 kernel against 222
-    if (mid && std::min(d.m, d.n) <= 128) return MI355_GEMM_ALGO_LP_128;
+    // (few COLUMNS fill the 256 rows of the tall tile: one round of it, where it exists, is the exception -- see its rule below)
+    if (mid && std::min(d.m, d.n) <= 128) {
+        const int64_t t128 = ((d.m + 127) / 128) * d.batch, tall = ((d.m + 255) / 256) * d.batch;
+        if (d.n <= 128 && d.m > 128 && t128 > 256 && tall <= 256 && gemm_lp256x128_supports(d, a, b, c)) return MI355_GEMM_ALGO_LP_256X128;
+        return MI355_GEMM_ALGO_LP_128;
+    }
     // More than one 128x128 tile per CU but at most one 256x128 tile per CU, and a long K: the 256 x 128 form of the same
     // kernel (gemm_lp128.hip, MI = 4) -- 0.75 x the L2 -> LDS bytes per FLOP, which is what the two co-resident 128x128
     // workgroups per CU are bound by.  Interleaved, cold operands (profiles/r03_tile_256x128_sweep.txt, 50 shapes): K >= 3072
@@ -164,7 +199,11 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
     // tie, K = 1024 -3 ... -7 %; with at most one 128x128 tile per CU it loses (2048^3: 27.5 us against 19.0 -- half the CUs).
     {
         const int64_t t128 = ((d.m + 127) / 128) * ((d.n + 127) / 128) * d.batch, tall = ((d.m + 255) / 256) * ((d.n + 127) / 128) * d.batch;
-        if (mid && t128 > 256 && tall <= 256 && d.k >= 2560 && gemm_lp256x128_supports(d, a, b, c)) return MI355_GEMM_ALGO_LP_256X128;
+        // Round 4 (profiles/r04_tall_skinny_ab.txt): with one side of at most 512 the short-K exclusion does not hold -- the 256-row
+        // tile halves the workgroups that re-read the small operand: 44440 x 88 x 1536 43.3 -> 35.7 us, 51880 x 64 x 1024 28.3 -> 24.1,
+        // 16384 x 512 x 1024 26.2 -> 21.4, 32768 x 256 x 1024 28.0 -> 23.0, 40000 x 96 x 512 16.6 -> 14.9 (65536 x 64 x 512: a tie).
+        if (mid && t128 > 256 && tall <= 256 && (d.k >= 2560 || std::min(d.m, d.n) <= 512) && gemm_lp256x128_supports(d, a, b, c))
+            return MI355_GEMM_ALGO_LP_256X128;
     }
     if (big || big4) {
         // 256x256 tiles once the 128x128 kernel would need more than its two co-resident workgroups per CU (512 tiles of
@@ -292,6 +331,9 @@ bool plan_tail_split(const mi355_gemm_desc &d, tail_plan &best)
     bool found = false;
     for (int dir = 0; dir < 2; ++dir) {
         const int64_t t_along = dir == 0 ? tm : tn, t_other = dir == 0 ? tn : tm;
+        // the strip is whole tiles of the LAST rows (columns): when that extent ends in a partly filled tile the model's tile
+        // count is wrong and the split lost (4160 x 10240 x 8192: 618 us against 531 plain, tools/dev/random_audit.py)
+        if ((dir == 0 ? d.m : d.n) % 256) continue;
         for (int64_t strip = 1; strip <= t_along && strip * t_other <= 96; ++strip) {
             const int64_t t_strip = strip * t_other, t_main = T - t_strip;
             for (int64_t sp = 2; sp <= 16 && sp * t_strip <= 256 && nk / sp >= 4; ++sp) {

@@ -1248,7 +1248,8 @@ def test_output_bound_shapes_select_the_small_tile(client):
     assert sel(64, 64, 4096) == sel(64, 2048, 8192) == sel(64, 14336, 4096) == sel(64, 8192, 14336) == sel(48, 4096, 4096) == N.GEMM_ALGO_LP_128
     assert sel(48, 512, 8192) == sel(64, 512, 8192) == sel(32, 28672, 4096) == sel(32, 57344, 4096) == N.GEMM_ALGO_LP_128   # rounds 3 and 4
     assert sel(64, 8192, 28672) == sel(64, 28672, 8192) == N.GEMM_ALGO_LP_128        # small operand past 2 MiB / 64 rows over more than 512 workgroups
-    assert sel(8192, 32, 14336) == N.GEMM_ALGO_STREAM64                               # 0.9 MiB of small operand still streams
+    assert sel(8192, 32, 8192) == N.GEMM_ALGO_STREAM64 and sel(8192, 32, 14336) == N.GEMM_ALGO_LP_128   # few columns: K past 8192 goes to split-K (round 4)
+    assert sel(44440, 88, 1536) == sel(16384, 512, 1024) == N.GEMM_ALGO_LP_256X128 and sel(32768, 128, 1024) == N.GEMM_ALGO_LP_128   # tall and skinny (round 4)
     assert sel(4, 2048, 4096) == sel(384, 4, 8192) == sel(3, 512, 14336) == sel(4096, 4, 14336) == N.GEMM_ALGO_SKINNY   # 3-4 rows, fewer than 192 streaming workgroups
     assert sel(8192, 4, 2048) == sel(4, 8192, 8192) == N.GEMM_ALGO_STREAM64           # ... from 192 up the streaming kernel
     # the 256 x 128 tile: more than one 128x128 tile per CU, at most one 256 x 128 tile per CU, long K (round 3)
