@@ -88,7 +88,10 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
         // ... or a second round of tiles it fills by less than three quarters (1 x 40568 x 3072: 317 tiles, 54.7 against 48.2)
         const int64_t t128 = (d.n + 127) / 128;
         if (strip_kernel && d.batch == 1 && d.n * d.k >= ((int64_t)1 << 25) &&
-            ((d.m <= 8 && (d.n <= 16384 || (t128 > 256 && t128 < 448))) || (d.m <= 16 && d.n > 65536)) &&
+            ((d.m <= 8 && (d.n <= 16384 || (t128 > 256 && t128 < 448))) || (d.m <= 16 && d.n > 65536) ||
+             // 9-16 rows since they run on v_mfma_f32_16x16x16 (256-byte strips): 16 x 8192 x 8192 28.7 against 31.3, 16 x 14336 x 4096
+             // 25.4 / 26.7, 16 x 16384 x 4096 28.5 / 30.9; not below N = 8192 (16 x 6144 x 6144 21.0 / 19.4, 16 x 4096 x 14336 27.0 / 25.9)
+             (d.m <= 16 && d.n >= 8192 && d.n <= 16384)) &&
             gemm_nnrows_supports(d, a, b, c))
             return MI355_GEMM_ALGO_NNROWS;
         const int64_t tiles256 = ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch;

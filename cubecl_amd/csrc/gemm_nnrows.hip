@@ -80,6 +80,19 @@ __device__ __forceinline__ f32x4 mfma4(u32x2 a, u32x2 b, f32x4 c)
         return __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(h16x4, a), __builtin_bit_cast(h16x4, b), c, 0, 0, 0);
 }
 
+// v_mfma_f32_16x16x16_{bf16_1k,f16}: lane (j = lane % 16, g = lane / 16) supplies column j's (row i's for A) four k values
+// 4 g ... 4 g + 3 and receives D[4 g ... 4 g + 3][j] -- with 256-byte strips (16 lanes per k-row, four row groups per wave) that
+// is the layout the lanes already hold: ONE instruction per column slot covers 16 rows of x and adds the wave's four row
+// groups inside the matrix pipe (the 4x4x4 form: four instructions and four separate partial sums).
+template <int DT>
+__device__ __forceinline__ f32x4 mfma16(u32x2 a, u32x2 b, f32x4 c)
+{
+    if constexpr (DT == MI355_DTYPE_BF16)
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, a), __builtin_bit_cast(h16x4, b), c, 0, 0, 0);
+}
+
 __device__ __forceinline__ void store_c(void *c, int32_t dtype_c, int64_t off, float v)
 {
     if (dtype_c == MI355_DTYPE_F32) static_cast<float *>(c)[off] = v;
@@ -100,6 +113,8 @@ __global__ void __launch_bounds__(256) gemm_nnrows_kernel(const nn_args g)
     constexpr int LPR = S / 16, Q = 64 / LPR, COLS = S / 2;                // lanes per row piece, row groups per wave, columns per strip
     constexpr int RI = 16 * Q;                                             // k-rows one workgroup iteration covers
     constexpr int XP = KC + RI + 8;                                        // LDS pitch of an x row: the chunk + a zero tail + 16 B
+    constexpr bool W16 = MB == 4 && S == 256;                              // 9-16 rows on 256-byte strips: the 16x16x16 form (mfma16)
+    constexpr int NCOPY = W16 ? 4 : 4 * Q;                                 // partial copies of the strip that meet in LDS
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ unsigned int is_last;
     uint16_t *xs = reinterpret_cast<uint16_t *>(smem);
@@ -112,9 +127,10 @@ __global__ void __launch_bounds__(256) gemm_nnrows_kernel(const nn_args g)
     const int kbeg = (int)slice * g.ks, kend = min(g.k, kbeg + g.ks);
 
     NNR_STAMP(0);
-    f32x4 acc[MB][8];
+    constexpr int AR = W16 ? 1 : MB;                                       // accumulator blocks per column slot
+    f32x4 acc[AR][8];
 #pragma unroll
-    for (int r = 0; r < MB; ++r)
+    for (int r = 0; r < AR; ++r)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[r][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -186,11 +202,17 @@ __global__ void __launch_bounds__(256) gemm_nnrows_kernel(const nn_args g)
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (decltype(steady)::value || it < nit) {                     // (wave-uniform; a round past the end only keeps the count)
+                if constexpr (W16) {
+                    const u32x2 xa = *reinterpret_cast<const u32x2 *>(xs + (lane & 15) * XP + kk);
 #pragma unroll
-                for (int r = 0; r < MB; ++r) {
-                    const u32x2 xa = *reinterpret_cast<const u32x2 *>(xs + (4 * r + (lane & 3)) * XP + kk);
+                    for (int e = 0; e < 8; ++e) acc[0][e] = mfma16<DT>(xa, bv[e], acc[0][e]);
+                } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[r][e] = mfma4<DT>(xa, bv[e], acc[r][e]);
+                    for (int r = 0; r < MB; ++r) {
+                        const u32x2 xa = *reinterpret_cast<const u32x2 *>(xs + (4 * r + (lane & 3)) * XP + kk);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[r][e] = mfma4<DT>(xa, bv[e], acc[r][e]);
+                    }
                 }
             }
         };
@@ -269,8 +291,15 @@ __global__ void __launch_bounds__(256) gemm_nnrows_kernel(const nn_args g)
     NNR_STAMP(2);
     __syncthreads();
     NNR_STAMP(3);
-    float *red = reinterpret_cast<float *>(smem);                          // [4 * Q][MP][COLS]
-    {
+    float *red = reinterpret_cast<float *>(smem);                          // [NCOPY][MP][COLS]
+    if constexpr (W16) {                                                   // lane (p, q) holds rows 4 q ... 4 q + 3 of its eight columns
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float *dst = red + ((w * MP + 4 * q + i) * COLS + p * 8);
+            *reinterpret_cast<f32x4 *>(dst) = (f32x4){acc[0][0][i], acc[0][1][i], acc[0][2][i], acc[0][3][i]};
+            *reinterpret_cast<f32x4 *>(dst + 4) = (f32x4){acc[0][4][i], acc[0][5][i], acc[0][6][i], acc[0][7][i]};
+        }
+    } else {
         const int copy = w * Q + q;
 #pragma unroll
         for (int r = 0; r < MB; ++r)
@@ -293,7 +322,7 @@ __global__ void __launch_bounds__(256) gemm_nnrows_kernel(const nn_args g)
         if (strip_col + c4 >= g.n) continue;
         f32x4 s = *reinterpret_cast<const f32x4 *>(red + (mm * COLS + c4));
 #pragma unroll
-        for (int cp = 1; cp < 4 * Q; ++cp) s += *reinterpret_cast<const f32x4 *>(red + ((cp * MP + mm) * COLS + c4));
+        for (int cp = 1; cp < NCOPY; ++cp) s += *reinterpret_cast<const f32x4 *>(red + ((cp * MP + mm) * COLS + c4));
         if (g.slices == 1) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) store_c(C, g.dtype_c, cbase + (int64_t)mm * g.ldc + strip_col + c4 + e, s[e]);
@@ -382,7 +411,7 @@ __global__ void __launch_bounds__(256) gemm_nnrows_kernel(const nn_args g)
 template <int MB, int S> constexpr size_t lds_bytes()
 {
     constexpr size_t x = (size_t)nn_geom<MB>::MP * (nn_geom<MB>::KC + 16 * (64 / (S / 16)) + 8) * 2 + 16;   // + the dump slot
-    constexpr size_t r = (size_t)4 * (64 / (S / 16)) * nn_geom<MB>::MP * (S / 2) * 4;
+    constexpr size_t r = (size_t)(MB == 4 && S == 256 ? 4 : 4 * (64 / (S / 16))) * nn_geom<MB>::MP * (S / 2) * 4;   // NCOPY copies
     return x > r ? x : r;
 }
 

@@ -30,7 +30,8 @@ TABLE = [
     ("GEMV against a row-major weight: the strip-streaming kernel, never transposed", (1, 8192, 8192, BF, None, 0, 0, 1), "NNROWS", (0, 0)),
     ("16 rows", (16, 8192, 8192, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
     ("8 rows against a row-major weight", (8, 8192, 8192, BF, None, 0, 0, 1), "NNROWS", (0, 0)),
-    ("16 rows against a row-major weight: a tie, stays", (16, 8192, 8192, BF, None, 0, 0, 1), "LP_128", (0, 0)),
+    ("16 rows against a row-major weight: the strip kernel's 16x16x16 form", (16, 8192, 8192, BF, None, 0, 0, 1), "NNROWS", (0, 0)),
+    ("16 rows against a narrower row-major weight: the tile kernel", (16, 6144, 6144, BF, None, 0, 0, 1), "LP_128", (0, 0)),
     ("4 rows, 250 column tiles need no K split: the tile kernel", (4, 32000, 4096, BF, None, 0, 0, 1), "LP_128", (0, 0)),
     ("16 rows against a row-major vocabulary projection: four rounds of tiles, the strip kernel", (16, 128256, 4096, BF, None, 0, 0, 1), "NNROWS", (0, 0)),
     ("64 rows", (64, 8192, 8192, BF, None, 0, 1, 1), "STREAM64", (0, 0)),

@@ -721,7 +721,7 @@ def test_row_major_b_refusals_of_the_tile_kernel(client, oracle):
     for m in (1, 16, 64):
         d = _nn_desc(m, 8192, 8192, ElemType.BF16, ElemType.BF16)
         assert ops.gemm_relayout_plan(client, d) == (False, False)
-        assert ops.gemm_select(client, d) == (N.GEMM_ALGO_NNROWS if m == 1 else N.GEMM_ALGO_LP_128)
+        assert ops.gemm_select(client, d) == (N.GEMM_ALGO_NNROWS if m <= 16 else N.GEMM_ALGO_LP_128)
 
 
 # ---- layouts the MFMA kernels do not stage directly: re-laid out K-contiguous into library scratch first ------------
@@ -1117,9 +1117,9 @@ def test_few_rows_times_row_major_weight_random_shapes(client, oracle, seed):
 def test_few_rows_times_row_major_weight_selection_refusals_and_determinism(client, oracle):
     bf = N.DTYPE_BF16
     sel = lambda m, n, k, **kw: ops.gemm_select(client, _nn_desc(m, n, k, bf, bf, **kw))
-    assert sel(1, 8192, 8192) == sel(8, 8192, 8192) == sel(4, 4096, 14336) == sel(16, 128256, 4096) == N.GEMM_ALGO_NNROWS
-    # a tie at 16 rows; 250 column tiles need no K split; too little to stream; too many rows
-    assert N.GEMM_ALGO_NNROWS not in (sel(16, 8192, 8192), sel(4, 32000, 4096), sel(4, 4096, 4096), sel(17, 131072, 4096))
+    assert sel(1, 8192, 8192) == sel(8, 8192, 8192) == sel(16, 8192, 8192) == sel(4, 4096, 14336) == sel(16, 128256, 4096) == N.GEMM_ALGO_NNROWS
+    # 16 rows below N = 8192; 250 column tiles need no K split; too little to stream; too many rows
+    assert N.GEMM_ALGO_NNROWS not in (sel(16, 6144, 6144), sel(4, 32000, 4096), sel(4, 4096, 4096), sel(17, 131072, 4096))
     d = _nn_desc(16, 8192, 8192, bf, bf); d.trans_b = 1; d.ldb = 8192
     assert ops.gemm_select(client, d) != N.GEMM_ALGO_NNROWS                                               # [N][K] weights: the streaming kernels
     for m, n, k in [(17, 512, 512), (4, 516, 512), (4, 512, 516)]:                                         # forced: refused

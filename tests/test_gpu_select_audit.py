@@ -36,7 +36,8 @@ GRID = [
 ALGOS = ["auto", "lp128", "lp256x128", "lp256w4", "lp256p", "lp256q", "stream64", "skinny"]
 # few rows against a ROW-MAJOR [K][N] weight (review of round 3, next #6): the rhs layout TensorHandle::new_contiguous gives
 GRID_NN = [(1, 8192, 8192), (4, 8192, 8192), (8, 8192, 8192), (16, 8192, 8192), (4, 4096, 4096), (4, 14336, 4096), (4, 4096, 14336),
-           (16, 4096, 14336), (16, 28672, 8192), (4, 32000, 4096), (1, 128256, 4096), (16, 128256, 4096), (32, 8192, 8192)]
+           (16, 4096, 14336), (16, 28672, 8192), (4, 32000, 4096), (1, 128256, 4096), (16, 128256, 4096), (32, 8192, 8192), (16, 14336, 4096),
+           (16, 16384, 4096), (12, 8192, 8192), (16, 6144, 6144), (16, 12288, 4096)]
 ALGOS_NN = ["auto", "lp128", "nnrows"]
 
 
