@@ -434,7 +434,9 @@ void launch_s(mi355_ctx *ctx, hipStream_t s, const nn_args &g, uint32_t batch, i
 template <int DT>
 void launch_dt(mi355_ctx *ctx, hipStream_t s, const nn_args &g, uint32_t batch, int strip_bytes)
 {
-    if (g.m <= 4) launch_s<DT, 1>(ctx, s, g, batch, strip_bytes);
+    static const int min_rows_16 = [] { const char *e = getenv("MI355_NNROWS_ROWS16_FROM"); return e ? atoi(e) : 9; }();   // dev: rows from which the 16-row form runs
+    if (g.m >= min_rows_16 && strip_bytes == 256) launch_s<DT, 4>(ctx, s, g, batch, strip_bytes);
+    else if (g.m <= 4) launch_s<DT, 1>(ctx, s, g, batch, strip_bytes);
     else if (g.m <= 8) launch_s<DT, 2>(ctx, s, g, batch, strip_bytes);
     else launch_s<DT, 4>(ctx, s, g, batch, strip_bytes);
 }
