@@ -216,6 +216,7 @@ PROTOTYPES = {
     "mi355_gemm_select": (C.c_int32, [_P, C.POINTER(GemmDesc), _I32P]),
     "mi355_gemm_tail_plan": (C.c_int32, [C.POINTER(GemmDesc), _I32P, C.POINTER(C.c_int64), _I32P]),
     "mi355_gemm_split_plan": (C.c_int32, [C.POINTER(GemmDesc), C.c_int32, _I32P]),
+    "mi355_gemm_strip_plan": (C.c_int32, [C.POINTER(GemmDesc), C.c_int32, _I32P, _I32P, _I32P]),
     "mi355_gemm_relayout_plan": (C.c_int32, [C.POINTER(GemmDesc), _I32P, _I32P]),
     "mi355_gemm_scaled": (C.c_int32, [_P, _P, C.POINTER(GemmScaledDesc), _P, _P, _P, _P, _P]),
     "mi355_gemm_scaled_select": (C.c_int32, [_P, C.POINTER(GemmScaledDesc), _I32P]),

@@ -477,6 +477,19 @@ bool plan_for(const mi355_gemm_desc &d, int cus, nn_plan &out)
 
 }  // namespace
 
+MI355_API int32_t mi355_gemm_strip_plan(const mi355_gemm_desc *desc, int32_t compute_units, int32_t *out_strip_bytes, int32_t *out_strips,
+                                        int32_t *out_slices)
+{
+    if (!desc || !out_strip_bytes || !out_strips || !out_slices || compute_units < 0) return MI355_E_INVALID_ARGUMENT;
+    static const char aligned_dummy __attribute__((aligned(16))) = 0;
+    *out_strip_bytes = *out_strips = *out_slices = 0;
+    nn_plan p;
+    if (!mi355::gemm_nnrows_supports(*desc, &aligned_dummy, &aligned_dummy, &aligned_dummy) || !plan_for(*desc, compute_units ? compute_units : 256, p))
+        return MI355_OK;
+    *out_strip_bytes = p.strip_bytes; *out_strips = p.strips; *out_slices = p.slices;
+    return MI355_OK;
+}
+
 #ifdef NNR_TRACE
 extern "C" __attribute__((visibility("default"))) int mi355_dev_nnr_trace(unsigned long long *host_out, int clear)
 {

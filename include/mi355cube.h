@@ -423,6 +423,12 @@ int32_t mi355_gemm_tail_plan(const mi355_gemm_desc *desc, int32_t *out_along_m, 
  * (0 = 256, the MI355X): 1 = one plain launch, otherwise that many f32 partial slabs + the deterministic fold.  A pure
  * function like the one above -- what it answers is only acted on when mi355_gemm_select says the 128x128 kernel runs. */
 int32_t mi355_gemm_split_plan(const mi355_gemm_desc *desc, int32_t compute_units, int32_t *out_slices);
+/* (round 4) How the few-rows x row-major-weight kernel (MI355_GEMM_ALGO_NNROWS, gemm_nnrows.hip) would cut a descriptor on a
+ * device with `compute_units` CUs (0 = 256): bytes of a k-row per strip (1024 / 512 / 256), strips along N and K slices per
+ * strip.  Its f32 summation order -- and with it the bits of the result -- is a function of these three alone.  All three 0:
+ * the kernel does not take the descriptor.  Pure function, no device. */
+int32_t mi355_gemm_strip_plan(const mi355_gemm_desc *desc, int32_t compute_units, int32_t *out_strip_bytes, int32_t *out_strips,
+                              int32_t *out_slices);
 /* Which operands mi355_gemm (AUTO) would first copy into library scratch, re-laid out K-contiguous -- the role of the
  * reference launchers' into_contiguous after matrix_batch_layout (crates/cubecl-std/src/tensor/matrix_batch_layout.rs:21-79)
  * -- before an MFMA kernel runs (pure function, no device; operands taken as 16-byte aligned).  Both 0: the kernels stage

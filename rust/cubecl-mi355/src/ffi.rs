@@ -310,6 +310,7 @@ unsafe extern "C" {
     pub fn mi355_gemm_select(ctx: *mut mi355_ctx, desc: *const mi355_gemm_desc, out_algo: *mut i32) -> i32;
     pub fn mi355_gemm_tail_plan(desc: *const mi355_gemm_desc, out_along_m: *mut i32, out_main_extent: *mut i64, out_splits: *mut i32) -> i32;
     pub fn mi355_gemm_split_plan(desc: *const mi355_gemm_desc, compute_units: i32, out_slices: *mut i32) -> i32;
+    pub fn mi355_gemm_strip_plan(desc: *const mi355_gemm_desc, compute_units: i32, out_strip_bytes: *mut i32, out_strips: *mut i32, out_slices: *mut i32) -> i32;
     pub fn mi355_gemm_relayout_plan(desc: *const mi355_gemm_desc, out_relayout_a: *mut i32, out_relayout_b: *mut i32) -> i32;
     // an alternative to MemoryManagement-over-Mi355Storage for hosts without the reference's pool (memory_manage.rs)
     pub fn mi355_pool_alloc(ctx: *mut mi355_ctx, stream: mi355_stream, bytes: u64, out_dptr: *mut *mut c_void) -> i32;

@@ -131,6 +131,31 @@ def _tail_plan(m, n, k, dtype=None, batch=1, **kw):
     return along.value, extent.value, splits.value
 
 
+def test_strip_plan_of_the_few_rows_kernel_is_a_function_of_the_descriptor_and_the_cu_count():
+    """gemm_nnrows.hip sums in an order fixed by (strip bytes, strips, K slices): pinned here without a device, so that a change of
+    the plan -- and with it of the bits -- shows up as a diff (results are bit-identical run to run, per plan)."""
+    import ctypes as C
+    from cubecl_amd import _native as N
+    lib = N.load()
+
+    def plan(m, n, k, cus=0, batch=1, trans_b=0):
+        d = N.GemmDesc(m=m, n=n, k=k, batch=batch, lda=k, ldb=k if trans_b else n, ldc=n, stride_a=m * k, stride_b=n * k, stride_c=m * n,
+                       dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_BF16, trans_a=0, trans_b=trans_b, algo=N.GEMM_ALGO_AUTO)
+        sb, st, sl = C.c_int32(-1), C.c_int32(-1), C.c_int32(-1)
+        assert lib.mi355_gemm_strip_plan(C.byref(d), cus, C.byref(sb), C.byref(st), C.byref(sl)) == N.OK
+        return sb.value, st.value, sl.value
+    assert plan(1, 8192, 8192) == plan(4, 8192, 8192) == (512, 32, 8)             # up to four rows: 512-byte strips, 256 workgroups
+    assert plan(8, 8192, 8192) == plan(16, 8192, 8192) == (256, 64, 4)            # above: 256-byte strips
+    assert plan(16, 8192, 8192, cus=128) == (256, 64, 2) and plan(16, 8192, 8192, cus=304) == (256, 64, 4)   # at most one workgroup per CU
+    assert plan(1, 128256, 4096) == (512, 501, 1)                                 # the strips alone fill the chip: no K slices, no tickets
+    assert plan(16, 128256, 4096) == (256, 1002, 1)                               # 1002 strips: more than a ticket slot holds, but one slice needs none
+    assert plan(2, 131072, 512) == (512, 512, 1) and plan(4, 28672, 8192) == (512, 112, 2)
+    assert plan(3, 8, 8) == (512, 1, 1) and plan(16, 16, 64) == (256, 1, 1)       # K is cut in whole 64-row pieces at most
+    # not taken: more than 16 rows, N or K not a multiple of 8, a K-contiguous rhs
+    assert plan(17, 8192, 8192) == plan(4, 8196, 8192) == plan(4, 8192, 8196) == plan(4, 8192, 8192, trans_b=1) == (0, 0, 0)
+    assert lib.mi355_gemm_strip_plan(None, 0, None, None, None) == N.E_INVALID_ARGUMENT
+
+
 def test_tail_plan_splits_only_small_leftover_rounds():
     from cubecl_amd import _native as N
     # whole rounds, or a leftover of half a round and more: one plain launch
