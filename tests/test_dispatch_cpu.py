@@ -59,6 +59,20 @@ TABLE = [
     ("K not a multiple of the K-tile: zero-padded copies", (512, 512, 1000, F16, F32, 0, 1, 1), "LP_128", (1, 1)),
     ("four rows on a small grid", (4, 2048, 4096, BF, None, 0, 1, 1), "SKINNY", (0, 0)),
     ("small output, long K: split along K", (512, 512, 8192, BF, None, 0, 1, 1), "LP_128", (0, 0)),
+    # round 4: what the random-shape audit (tools/dev/random_audit.py) and the row-count sweeps moved
+    ("48 rows on 16 streaming workgroups walking K = 8192: split-K instead", (48, 512, 8192, BF, None, 0, 1, 1), "LP_128", (0, 0)),
+    ("32 rows on 64 streaming workgroups walking K = 8192: split-K instead", (32, 2048, 8192, BF, None, 0, 1, 1), "LP_128", (0, 0)),
+    ("32 rows, one streaming workgroup per CU, K = 16384: streams", (32, 8192, 16384, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
+    ("64 rows, more streaming workgroups than CUs", (64, 10240, 4096, BF, None, 0, 1, 1), "LP_128", (0, 0)),
+    ("23 columns, K = 3072, any grid: streams (few columns are not few rows)", (37824, 23, 3072, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
+    ("24 columns, K past 8192: split-K", (9312, 24, 14336, BF, None, 0, 1, 1), "LP_128", (0, 0)),
+    ("20 rows whose 128-column tiles would fill a second round by a quarter: streams", (20, 40096, 8192, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
+    ("tall and skinny: the 256 x 128 tile", (44440, 88, 1536, BF, None, 0, 1, 1), "LP_256X128", (0, 0)),
+    ("tall, exactly one round of 128^2 tiles", (32768, 128, 1024, BF, None, 0, 1, 1), "LP_128", (0, 0)),
+    ("16 columns of a row-major rhs, short K: no re-layout pass", (32768, 16, 512, BF, None, 0, 0, 1), "LP_128", (0, 0)),
+    ("64 columns of a row-major rhs whose twin takes the tile kernel anyway: no re-layout pass", (4096, 64, 8192, BF, None, 0, 0, 1), "LP_128", (0, 0)),
+    ("one row against a row-major weight of 317 column tiles", (1, 40568, 3072, BF, None, 0, 0, 1), "NNROWS", (0, 0)),
+    ("ragged M next to a full round: no tail split is planned along M", (4160, 10240, 8192, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
 ]
 
 

@@ -12,6 +12,8 @@ import ctypes as C
 import json
 from pathlib import Path
 
+import os
+
 import numpy as np
 import pytest
 
@@ -1092,7 +1094,7 @@ def test_few_rows_times_row_major_weight_matches_the_oracle(client, oracle, m, n
     run_case(client, oracle, m, n, k, dtype, out_dtype, False, ALGOS["nnrows"], **kw)
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NNROWS_FUZZ_SEEDS", "40"))))
 def test_few_rows_times_row_major_weight_random_shapes(client, oracle, seed):
     """Seeded draws over everything the strip kernel's geometry depends on: rows (row blocks of 4), N (strips, ragged last strip),
     K (slices, ring rounds, ragged last iteration, x chunks of 2048 / 4096 / 8192), pitches, batch, dtypes."""
