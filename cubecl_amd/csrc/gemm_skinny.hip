@@ -36,9 +36,8 @@ namespace {
 // Many small workgroups win: a wave's share is short (16-64 KiB), so what counts is how evenly the rows spread over the
 // chip and how early every CU has loads in flight.  RW is chosen per row count of the small operand (launch_dt).
 constexpr int WAVES = 2;         // waves per workgroup
-constexpr int CHUNK = 64 * 8;    // K elements one wave covers per step
 
-__device__ __forceinline__ u32x4 stream_load(const uint16_t *p)
+__device__ __forceinline__ u32x4 stream_load(const void *p)
 {
 #if SK_NT
     return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
@@ -66,6 +65,24 @@ __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float acc)
     }
 }
 
+// element traits: 16-bit operands go through dot2 (two products per instruction), f32 operands through plain FMAs
+template <int DT> struct sk_elem { typedef uint16_t type; static constexpr int EPV = 8; };
+template <> struct sk_elem<MI355_DTYPE_F32> { typedef float type; static constexpr int EPV = 4; };
+
+// acc += the dot product of two 16-byte pieces
+template <int DT>
+__device__ __forceinline__ float dot16(const u32x4 &a, const u32x4 &b, float acc)
+{
+    if constexpr (DT == MI355_DTYPE_F32) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_fmaf(__uint_as_float(a[j]), __uint_as_float(b[j]), acc);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = dot2<DT>(a[j], b[j], acc);
+    }
+    return acc;
+}
+
 struct skinny_args {
     const void *small_;      // [small_rows][K], K contiguous
     const void *big;         // [big_rows][K], K contiguous
@@ -91,14 +108,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(skinny_args g)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t row0 = ((int64_t)blockIdx.x * WAVES + wave) * RW;
     if (row0 >= g.big_rows) return;
-    const uint16_t *small_ = static_cast<const uint16_t *>(g.small_) + (int64_t)blockIdx.y * g.stride_small;
-    const uint16_t *big = static_cast<const uint16_t *>(g.big) + (int64_t)blockIdx.y * g.stride_big;
+    typedef typename sk_elem<DT>::type elem;
+    constexpr int EPV = sk_elem<DT>::EPV, CH = 64 * EPV;                   // elements per 16-byte piece / per wave step
+    const elem *small_ = static_cast<const elem *>(g.small_) + (int64_t)blockIdx.y * g.stride_small;
+    const elem *big = static_cast<const elem *>(g.big) + (int64_t)blockIdx.y * g.stride_big;
 
     // rows past the end are clamped to the last one: loaded (harmlessly) and never stored
-    const uint16_t *brow[RW];
+    const elem *brow[RW];
 #pragma unroll
     for (int r = 0; r < RW; ++r) brow[r] = big + min(row0 + r, (int64_t)g.big_rows - 1) * g.ld_big;
-    const uint16_t *srow[MT];
+    const elem *srow[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) srow[m] = small_ + (int64_t)min(m, g.small_rows - 1) * g.ld_small;
 
@@ -108,31 +127,29 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(skinny_args g)
 #pragma unroll
         for (int r = 0; r < RW; ++r) acc[m][r] = 0.0f;
 
-    const int k_full = g.k / (2 * CHUNK) * (2 * CHUNK);
-    int k0 = lane * 8;
+    const int k_full = g.k / (2 * CH) * (2 * CH);
+    int k0 = lane * EPV;
     // two chunks per trip: 2 x RW streamed loads in flight before the first dot product
-    for (; k0 < k_full; k0 += 2 * CHUNK) {
+    for (; k0 < k_full; k0 += 2 * CH) {
         u32x4 b0[RW], b1[RW];
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             b0[r] = stream_load(brow[r] + k0);
-            b1[r] = stream_load(brow[r] + k0 + CHUNK);
+            b1[r] = stream_load(brow[r] + k0 + CH);
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const u32x4 s0 = *reinterpret_cast<const u32x4 *>(srow[m] + k0);
-            const u32x4 s1 = *reinterpret_cast<const u32x4 *>(srow[m] + k0 + CHUNK);
+            const u32x4 s1 = *reinterpret_cast<const u32x4 *>(srow[m] + k0 + CH);
 #pragma unroll
             for (int r = 0; r < RW; ++r) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[m][r] = dot2<DT>(s0[j], b0[r][j], acc[m][r]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[m][r] = dot2<DT>(s1[j], b1[r][j], acc[m][r]);
+                acc[m][r] = dot16<DT>(s0, b0[r], acc[m][r]);
+                acc[m][r] = dot16<DT>(s1, b1[r], acc[m][r]);
             }
         }
     }
     // remaining chunks, the last one possibly partial (K is a multiple of 8: a lane's 16 bytes are all in or all out)
-    for (; k0 < g.k; k0 += CHUNK) {
+    for (; k0 < g.k; k0 += CH) {
         u32x4 b0[RW];
 #pragma unroll
         for (int r = 0; r < RW; ++r) b0[r] = stream_load(brow[r] + k0);
@@ -140,9 +157,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(skinny_args g)
         for (int m = 0; m < MT; ++m) {
             const u32x4 s0 = *reinterpret_cast<const u32x4 *>(srow[m] + k0);
 #pragma unroll
-            for (int r = 0; r < RW; ++r)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[m][r] = dot2<DT>(s0[j], b0[r][j], acc[m][r]);
+            for (int r = 0; r < RW; ++r) acc[m][r] = dot16<DT>(s0, b0[r], acc[m][r]);
         }
     }
 
@@ -209,17 +224,19 @@ void launch_dt(hipStream_t s, const skinny_args &g, uint32_t batch)
 
 namespace mi355 {
 
-// A [M][K] and B [N][K] both K-contiguous 16-bit, one of M, N at most 16, 16-byte aligned rows, K a multiple of 8.
+// A [M][K] and B [N][K] both K-contiguous, 16-bit or f32, one of M, N at most 16, 16-byte aligned rows, K a multiple of 8 (f32: 4).
 bool gemm_skinny_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
 {
     (void)c;
-    if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16) return false;
-    if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != MI355_DTYPE_BF16 && d.dtype_c != MI355_DTYPE_F16) return false;
+    const bool f32 = d.dtype_ab == MI355_DTYPE_F32;          // f32 operands (round 4): f32 result only, plain FMAs instead of dot2
+    if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16 && !f32) return false;
+    if (f32 ? d.dtype_c != MI355_DTYPE_F32 : (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != MI355_DTYPE_BF16 && d.dtype_c != MI355_DTYPE_F16)) return false;
     if (d.trans_a || !d.trans_b) return false;
-    if (d.m <= 0 || d.n <= 0 || d.k <= 0 || (d.k & 7) || d.k > 0x7FFFFFF0) return false;
+    const int64_t epv = f32 ? 4 : 8;                         // elements of a 16-byte piece
+    if (d.m <= 0 || d.n <= 0 || d.k <= 0 || (d.k & (epv - 1)) || d.k > 0x7FFFFFF0) return false;
     if (d.m > 16 && d.n > 16) return false;
     if (d.m > 0x7FFFFFFF || d.n > 0x7FFFFFFF || d.batch < 1 || d.batch > 65535) return false;
-    if ((d.lda & 7) || (d.ldb & 7) || (d.stride_a & 7) || (d.stride_b & 7)) return false;
+    if ((d.lda & (epv - 1)) || (d.ldb & (epv - 1)) || (d.stride_a & (epv - 1)) || (d.stride_b & (epv - 1))) return false;
     if ((reinterpret_cast<uintptr_t>(a) & 15u) || (reinterpret_cast<uintptr_t>(b) & 15u)) return false;
     return true;
 }
@@ -243,7 +260,8 @@ int32_t launch_gemm_skinny(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc 
     g.big_rows = (int32_t)(a_small ? d.n : d.m);
     g.k = (int32_t)d.k;
     g.dtype_c = d.dtype_c;
-    if (d.dtype_ab == MI355_DTYPE_BF16) launch_dt<MI355_DTYPE_BF16>(s, g, (uint32_t)d.batch);
+    if (d.dtype_ab == MI355_DTYPE_F32) launch_dt<MI355_DTYPE_F32>(s, g, (uint32_t)d.batch);
+    else if (d.dtype_ab == MI355_DTYPE_BF16) launch_dt<MI355_DTYPE_BF16>(s, g, (uint32_t)d.batch);
     else launch_dt<MI355_DTYPE_F16>(s, g, (uint32_t)d.batch);
     check_launch(ctx, "mi355_gemm(skinny)");
     return MI355_OK;

@@ -1196,7 +1196,8 @@ def test_few_rows_times_row_major_weight_inside_a_capture_window(client, oracle)
     (1000, 7, 4104, {"ldc": 8}),
     (515, 16, 640, {"batch": 2}),
 ])
-@pytest.mark.parametrize("dtype,out_dtype", [(ElemType.BF16, ElemType.BF16), (ElemType.F16, ElemType.F32), (ElemType.BF16, ElemType.F32)])
+@pytest.mark.parametrize("dtype,out_dtype", [(ElemType.BF16, ElemType.BF16), (ElemType.F16, ElemType.F32), (ElemType.BF16, ElemType.F32),
+                                             (ElemType.F32, ElemType.F32)])     # f32 operands (round 4): plain FMAs, four elements per 16-byte piece
 def test_skinny_dot2_kernel_matches_the_oracle(client, oracle, m, n, k, kw, dtype, out_dtype):
     d = N.GemmDesc(m=m, n=n, k=k, batch=kw.get("batch", 1), lda=kw.get("lda", k), ldb=kw.get("ldb", k), ldc=kw.get("ldc", n),
                    stride_a=m * kw.get("lda", k), stride_b=0 if kw.get("bcast_b") else n * kw.get("ldb", k), stride_c=m * kw.get("ldc", n),

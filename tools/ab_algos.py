@@ -23,22 +23,23 @@ NAMES = {"auto": 0, "generic": 1, "f32": 2, "lp128": 3, "lp256": 4, "lp256w4": 5
 BY_ID = {v: k for k, v in NAMES.items()}
 
 
-def measure(client, ev, shapes, algos, rounds=5, nn=False, iters=20, cold=True):
+def measure(client, ev, shapes, algos, rounds=5, nn=False, iters=20, cold=True, f32=False):
     lib, ctx = client.lib, client.ctx
+    et, dt, esz = (ElemType.F32, N.DTYPE_F32, 4) if f32 else (ElemType.BF16, N.DTYPE_BF16, 2)
     out = {}
     for (m, n, k) in shapes:
-        fp = 2 * (m * k + n * k + m * n)
+        fp = esz * (m * k + n * k + m * n)
         nsets = max(1, min(8, -(-(768 << 20) // fp))) if cold else 1
-        sets = [(TensorHandle.uniform(client, (m, k), ElemType.BF16, 1, 2 * i + 1, -1.0, 1.0),
-                 TensorHandle.uniform(client, (n, k), ElemType.BF16, 1, 2 * i + 2, -1.0, 1.0), client.empty(m * n * 2)) for i in range(nsets)]
+        sets = [(TensorHandle.uniform(client, (m, k), et, 1, 2 * i + 1, -1.0, 1.0),
+                 TensorHandle.uniform(client, (n, k), et, 1, 2 * i + 2, -1.0, 1.0), client.empty(m * n * esz)) for i in range(nsets)]
         times = {a: [] for a in algos}
         sel = C.c_int32()
-        d0 = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=(n if nn else k), ldc=n, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_BF16, trans_b=0 if nn else 1, algo=0)
+        d0 = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=(n if nn else k), ldc=n, dtype_ab=dt, dtype_c=dt, trans_b=0 if nn else 1, algo=0)
         lib.mi355_gemm_select(ctx, C.byref(d0), C.byref(sel))
         turn = [0]
         for _ in range(rounds):
             for a in algos:
-                d = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=(n if nn else k), ldc=n, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_BF16,
+                d = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=(n if nn else k), ldc=n, dtype_ab=dt, dtype_c=dt,
                                trans_b=0 if nn else 1, algo=NAMES[a])
 
                 def call():
@@ -64,6 +65,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--nn", action="store_true")
+    ap.add_argument("--f32", action="store_true", help="f32 operands and output instead of bf16")
     ap.add_argument("--verbose", action="store_true", help="name every measurement on stderr before it starts")
     ap.add_argument("--warm", action="store_true", help="one operand set (Infinity-Cache-warm operands)")
     ap.add_argument("--algos", default="auto,lp128,lp256x128,lp256w4")
@@ -75,7 +77,7 @@ def main():
     ev = bench.Events(client)
     shapes = [tuple(int(x) for x in s.split("x")) for s in args.shapes]
     algos = args.algos.split(",")
-    res = measure(client, ev, shapes, algos, args.rounds, args.nn, cold=not args.warm)
+    res = measure(client, ev, shapes, algos, args.rounds, args.nn, cold=not args.warm, f32=args.f32)
     print(f"{'shape':>20s} {'AUTO':>10s} " + " ".join(f"{a:>16s}" for a in algos))
     for (m, n, k), r in res.items():
         cells = []
