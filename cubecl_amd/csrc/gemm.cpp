@@ -46,6 +46,11 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
         // the 128x128 tile kernel): 1 / 2 / 4 / 8 x 8192 x 8192 43.2 / 47.6 / 53.6 / 73.9 against 150-161, 1 x 4096 x 4096 12.9 / 42.2,
         // 8 x 2048 x 8192 25.3 / 44.0; with 16 rows its 64 FMAs per 16 bytes lose (156 / 152, 16 x 4096 x 4096 55.8 / 43.4)
         if (std::min(d.m, d.n) <= 8 && gemm_skinny_supports(d, a, b, c)) return MI355_GEMM_ALGO_SKINNY;
+        // ... and against a ROW-MAJOR f32 weight the strip kernel's f32 form (gemm_nnrows.hip on v_mfma_f32_4x4x1: no transposition at
+        // all), up to 16 rows (profiles/r04_f32_audit.txt, us, against the 128x128 tile kernel): 1 / 8 / 16 x 8192 x 8192 45.8 / 49.0 / 57.7
+        // against 151-158, 16 x 4096 x 4096 19.8 / 46.3, 4 x 28672 x 4096 75 / 294, 1 x 2048 x 1024 10.6 / 23.1
+        if (!d.trans_a && !d.trans_b && d.m <= 16 && d.batch == 1 && d.n * d.k >= ((int64_t)1 << 16) && gemm_nnrows_supports(d, a, b, c))
+            return MI355_GEMM_ALGO_NNROWS;
         // 256x256 tiles (one wave per SIMD) when they give (nearly) every CU a tile; else 128x128
         if (gemm_lp256w4_supports(d, a, b, c) && ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch >= 192) return MI355_GEMM_ALGO_LP_256W4;
         if (gemm_f32_mfma_supports(d, a, b, c)) return MI355_GEMM_ALGO_F32_MFMA;

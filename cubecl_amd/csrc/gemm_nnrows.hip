@@ -56,8 +56,8 @@ constexpr int STRIP_TICKETS = 496;
 constexpr int SCRATCH_NNROWS = 7;
 
 struct nn_args {
-    const uint16_t *a;           // x [M][K]
-    const uint16_t *b;           // W [K][N]
+    const void *a;               // x [M][K]
+    const void *b;               // W [K][N]
     void *c;
     float *partial;              // [batch][slices][M][N] f32 when slices > 1
     unsigned int *tickets;       // [batch * strips], zero between calls
@@ -66,6 +66,10 @@ struct nn_args {
     int32_t strips, slices, ks;  // ks: k-rows per slice, a multiple of 64
     int32_t dtype_c;
 };
+
+// element traits: 16-bit operands (eight columns per 16-byte piece) or, since the end of round 4, f32 (four)
+template <int DT> struct nn_elem { typedef uint16_t type; };
+template <> struct nn_elem<MI355_DTYPE_F32> { typedef uint32_t type; };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
@@ -100,39 +104,41 @@ __device__ __forceinline__ void store_c(void *c, int32_t dtype_c, int64_t off, f
     else static_cast<_Float16 *>(c)[off] = (_Float16)v;
 }
 
-template <int MB> struct nn_geom {
+template <int MB, int EB> struct nn_geom {
     static constexpr int MP = 4 * MB;                                      // x rows staged (zero rows past M)
-    static constexpr int KC = MB == 1 ? 8192 : MB == 2 ? 4096 : 2048;      // k values of x per LDS chunk (64 KiB): a chunk boundary drains the ring
+    static constexpr int KC = 16384 / (MB * EB);                           // k values of x per LDS chunk (64 KiB): a chunk boundary drains the ring
 };
 
 template <int DT, int MB, int S>
 __global__ void __launch_bounds__(256) gemm_nnrows_kernel(const nn_args g)
 {
     constexpr int U = NNR_U;
-    constexpr int MP = nn_geom<MB>::MP, KC = nn_geom<MB>::KC;
-    constexpr int LPR = S / 16, Q = 64 / LPR, COLS = S / 2;                // lanes per row piece, row groups per wave, columns per strip
+    typedef typename nn_elem<DT>::type ET;
+    constexpr int EB = sizeof(ET), EPV = 16 / EB;                          // bytes per element, columns per 16-byte piece
+    constexpr bool F32 = DT == MI355_DTYPE_F32;
+    constexpr int MP = nn_geom<MB, EB>::MP, KC = nn_geom<MB, EB>::KC;
+    constexpr int LPR = S / 16, Q = 64 / LPR, COLS = S / EB;               // lanes per row piece, row groups per wave, columns per strip
     constexpr int RI = 16 * Q;                                             // k-rows one workgroup iteration covers
     constexpr int XP = KC + RI + 8;                                        // LDS pitch of an x row: the chunk + a zero tail + 16 B
-    constexpr bool W16 = MB == 4 && S == 256;                              // 9-16 rows on 256-byte strips: the 16x16x16 form (mfma16)
+    constexpr bool W16 = MB == 4 && S == 256 && !F32;                      // 9-16 rows on 256-byte strips: the 16x16x16 form (mfma16)
     constexpr int NCOPY = W16 ? 4 : 4 * Q;                                 // partial copies of the strip that meet in LDS
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ unsigned int is_last;
-    uint16_t *xs = reinterpret_cast<uint16_t *>(smem);
+    ET *xs = reinterpret_cast<ET *>(smem);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int p = lane % LPR, q = lane / LPR;
     const uint32_t strip = blockIdx.x / (uint32_t)g.slices, slice = blockIdx.x % (uint32_t)g.slices, batch = blockIdx.y;
-    const int64_t col = (int64_t)strip * COLS + p * 8;                     // my eight columns (N % 8 == 0: all or none exist)
-    const uint16_t *A = g.a + (int64_t)batch * g.stride_a;
-    const uint16_t *Bp = g.b + (int64_t)batch * g.stride_b + (col < g.n ? col : 0);
+    const int64_t col = (int64_t)strip * COLS + p * EPV;                   // my eight (f32: four) columns: all of them exist or none
+    const ET *A = static_cast<const ET *>(g.a) + (int64_t)batch * g.stride_a;
     const int kbeg = (int)slice * g.ks, kend = min(g.k, kbeg + g.ks);
 
     NNR_STAMP(0);
     constexpr int AR = W16 ? 1 : MB;                                       // accumulator blocks per column slot
-    f32x4 acc[AR][8];
+    f32x4 acc[AR][EPV];
 #pragma unroll
     for (int r = 0; r < AR; ++r)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[r][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < EPV; ++e) acc[r][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // The W stream: a ring of U four-row groups per lane, refilled slot by slot.  What it takes for the compiler's waitcnt pass
     // to wait with vmcnt(4 (U - 1)) instead of draining the ring every round (each item measured in the ISA):
@@ -147,10 +153,10 @@ __global__ void __launch_bounds__(256) gemm_nnrows_kernel(const nn_args g)
     // (Issuing the loads and the waits by hand in inline asm was tried: the register allocator may copy a slot's registers in
     // front of the hand-written wait -- it did, in the tail rounds -- and the copy reads a load that has not landed.)
     u32x4 v[U][4];
-    const int64_t ldb2 = g.ldb * 2;                                        // bytes per k-row
-    const uint32_t voff_lane = (uint32_t)(((int64_t)(w * Q + q) * 4 * g.ldb + (col < g.n ? p * 8 : 0)) * 2);
+    const int64_t ldb2 = g.ldb * EB;                                       // bytes per k-row
+    const uint32_t voff_lane = (uint32_t)(((int64_t)(w * Q + q) * 4 * g.ldb + (col < g.n ? p * EPV : 0)) * EB);
     const uint32_t voff_step = (uint32_t)((int64_t)RI * ldb2);
-    const uint16_t *dummy = A + (lane & 3) * 8;                           // always-resident 16 bytes (x staging: loads that have nothing to fetch)
+    const ET *dummy = A + (lane & 3) * EPV;                           // always-resident 16 bytes (x staging: loads that have nothing to fetch)
 #ifdef NNR_ASM_LOADS      // dev: loads and waits by hand (see the note above: unsafe, kept for the record)
 #define NNR_LOAD(dst, voff, sbase) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory")
 #define NNR_WAIT(n, u) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(v[u][0]), "+v"(v[u][1]), "+v"(v[u][2]), "+v"(v[u][3])::"memory")
@@ -162,7 +168,8 @@ __global__ void __launch_bounds__(256) gemm_nnrows_kernel(const nn_args g)
         const int kc1 = min(kend, kc0 + KC);
         const int nit = (kc1 - kc0 + RI - 1) / RI;
         // group (it, w, q) = k-rows kc0 + ((it * 4 + w) * Q + q) * 4 ... + 3 (K % 8 == 0: a group exists whole or not at all)
-        const char *sb0 = reinterpret_cast<const char *>(g.b + (int64_t)batch * g.stride_b + (int64_t)strip * COLS + (int64_t)kc0 * g.ldb);
+        const char *sb0 = reinterpret_cast<const char *>(static_cast<const ET *>(g.b) + (int64_t)batch * g.stride_b + (int64_t)strip * COLS +
+                                                         (int64_t)kc0 * g.ldb);
         const uint64_t sb[4] = {reinterpret_cast<uint64_t>(sb0), reinterpret_cast<uint64_t>(sb0 + ldb2), reinterpret_cast<uint64_t>(sb0 + 2 * ldb2),
                                 reinterpret_cast<uint64_t>(sb0 + 3 * ldb2)};
         const int last_group = (kc1 - kc0) / 4 - 1;                        // lanes whose group of a ragged last iteration does not exist re-read this one
@@ -187,6 +194,29 @@ __global__ void __launch_bounds__(256) gemm_nnrows_kernel(const nn_args g)
                     for (int j = 0; j < 4; ++j) v[u][j] = (u32x4){0u, 0u, 0u, 0u};
                 }
             }
+            if constexpr (F32) {
+                // f32: nothing to transpose -- v_mfma_f32_4x4x1_16b_f32 takes ONE k per instruction: each lane supplies its own column's
+                // element of k-row j (B) and x[4 r + lane % 4][that row] (A), sixteen independent 4 x 4 blocks as in the 16-bit form
+                const u32x4 w0 = v[u][0], w1 = v[u][1], w2 = v[u][2], w3 = v[u][3];
+                if constexpr (decltype(refill)::value) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue(decltype(steady)::value || it + U < nit, it + U, u);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (decltype(steady)::value || it < nit) {
+#pragma unroll
+                    for (int r = 0; r < MB; ++r) {
+                        const u32x4 xa = *reinterpret_cast<const u32x4 *>(xs + (4 * r + (lane & 3)) * XP + kk);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc[r][e] = __builtin_amdgcn_mfma_f32_4x4x1f32(__uint_as_float(xa[0]), __uint_as_float(w0[e]), acc[r][e], 0, 0, 0);
+                            acc[r][e] = __builtin_amdgcn_mfma_f32_4x4x1f32(__uint_as_float(xa[1]), __uint_as_float(w1[e]), acc[r][e], 0, 0, 0);
+                            acc[r][e] = __builtin_amdgcn_mfma_f32_4x4x1f32(__uint_as_float(xa[2]), __uint_as_float(w2[e]), acc[r][e], 0, 0, 0);
+                            acc[r][e] = __builtin_amdgcn_mfma_f32_4x4x1f32(__uint_as_float(xa[3]), __uint_as_float(w3[e]), acc[r][e], 0, 0, 0);
+                        }
+                    }
+                }
+            } else {
             // in-register transposition: column e of my eight -> its four k values
             u32x2 bv[8];
 #pragma unroll
@@ -215,18 +245,19 @@ __global__ void __launch_bounds__(256) gemm_nnrows_kernel(const nn_args g)
                     }
                 }
             }
+            }
         };
         __syncthreads();                                                   // the previous chunk's x has been read
         {   // x[0 .. MP)[kc0 .. kc0 + nit * RI) -> LDS, zeros past M and past the slice; XB loads per thread in flight, unconditional.
             // The first batch of x goes out BEFORE the ring's first fill and is stored after it: queued behind 24 MiB of W
             // (all workgroups start together) x came back last, 10 000 cycles in, with the ring long landed and nothing in flight.
             constexpr int XB = 4 * MB;
-            const int epr = nit * RI / 8, pieces = MP * epr;               // 16-byte pieces per row / in all
+            const int epr = nit * RI / EPV, pieces = MP * epr;             // 16-byte pieces per row / in all
             u32x4 xv[XB];
             auto x_load = [&](int base) __attribute__((always_inline)) {
 #pragma unroll
                 for (int i = 0; i < XB; ++i) {
-                    const int idx = base + i * 256 + tid, mm = idx / epr, kk = (idx - mm * epr) * 8;
+                    const int idx = base + i * 256 + tid, mm = idx / epr, kk = (idx - mm * epr) * EPV;
                     const bool ok = idx < pieces && mm < g.m && kc0 + kk < kc1;
                     uint64_t addr = ok ? reinterpret_cast<uint64_t>(A + (int64_t)mm * g.lda + kc0 + kk) : reinterpret_cast<uint64_t>(dummy);
                     asm("" : "+v"(addr));                                  // a select of ADDRESSES (else: a branch with a load in each arm)
@@ -237,7 +268,7 @@ __global__ void __launch_bounds__(256) gemm_nnrows_kernel(const nn_args g)
             auto x_store = [&](int base) __attribute__((always_inline)) {
 #pragma unroll
                 for (int i = 0; i < XB; ++i) {
-                    const int idx = base + i * 256 + tid, mm = idx / epr, kk = (idx - mm * epr) * 8;
+                    const int idx = base + i * 256 + tid, mm = idx / epr, kk = (idx - mm * epr) * EPV;
                     // stored UNCONDITIONALLY (pieces past the end go to a dump slot): a load whose value one path never uses stays
                     // "in flight" for the compiler, which then drains vmcnt inside the streaming loop before reusing its registers
                     *reinterpret_cast<u32x4 *>(xs + (idx < pieces ? mm * XP + kk : MP * XP)) = xv[i];
@@ -305,9 +336,9 @@ __global__ void __launch_bounds__(256) gemm_nnrows_kernel(const nn_args g)
         for (int r = 0; r < MB; ++r)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float *dst = red + ((copy * MP + 4 * r + i) * COLS + p * 8);
+                float *dst = red + ((copy * MP + 4 * r + i) * COLS + p * EPV);
                 *reinterpret_cast<f32x4 *>(dst) = (f32x4){acc[r][0][i], acc[r][1][i], acc[r][2][i], acc[r][3][i]};
-                *reinterpret_cast<f32x4 *>(dst + 4) = (f32x4){acc[r][4][i], acc[r][5][i], acc[r][6][i], acc[r][7][i]};
+                if constexpr (!F32) *reinterpret_cast<f32x4 *>(dst + 4) = (f32x4){acc[r][4][i], acc[r][5][i], acc[r][6][i], acc[r][7][i]};
             }
     }
     __syncthreads();
@@ -408,17 +439,19 @@ __global__ void __launch_bounds__(256) gemm_nnrows_kernel(const nn_args g)
     NNR_STAMP(6);
 }
 
-template <int MB, int S> constexpr size_t lds_bytes()
+template <int DT, int MB, int S> constexpr size_t lds_bytes()
 {
-    constexpr size_t x = (size_t)nn_geom<MB>::MP * (nn_geom<MB>::KC + 16 * (64 / (S / 16)) + 8) * 2 + 16;   // + the dump slot
-    constexpr size_t r = (size_t)(MB == 4 && S == 256 ? 4 : 4 * (64 / (S / 16))) * nn_geom<MB>::MP * (S / 2) * 4;   // NCOPY copies
+    constexpr size_t EB = sizeof(typename nn_elem<DT>::type);
+    constexpr size_t x = (size_t)nn_geom<MB, EB>::MP * (nn_geom<MB, EB>::KC + 16 * (64 / (S / 16)) + 8) * EB + 16;   // + the dump slot
+    constexpr size_t ncopy = (MB == 4 && S == 256 && EB == 2) ? 4 : 4 * (64 / (S / 16));
+    constexpr size_t r = ncopy * nn_geom<MB, EB>::MP * (S / EB) * 4;      // the copies of the strip that meet in LDS
     return x > r ? x : r;
 }
 
 template <int DT, int MB, int S>
 void launch_one(mi355_ctx *ctx, hipStream_t s, const nn_args &g, uint32_t batch)
 {
-    constexpr size_t LDS = lds_bytes<MB, S>();
+    constexpr size_t LDS = lds_bytes<DT, MB, S>();
     lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_nnrows_kernel<DT, MB, S>), LDS);
     hipLaunchKernelGGL((gemm_nnrows_kernel<DT, MB, S>), dim3((uint32_t)(g.strips * g.slices), batch), dim3(256), LDS, s, g);
 }
@@ -458,7 +491,7 @@ bool plan_for(const mi355_gemm_desc &d, int cus, nn_plan &out)
     for (int i = 0; i < 3; ++i) {
         const int sb = force_s ? force_s : (d.m <= 4 ? order_few[i] : order_many[i]);
         if (sb != 1024 && sb != 512 && sb != 256) return false;
-        const int64_t strips = (d.n * 2 + sb - 1) / sb;
+        const int64_t strips = (d.n * (d.dtype_ab == MI355_DTYPE_F32 ? 4 : 2) + sb - 1) / sb;
         int64_t slices = std::max<int64_t>(1, (int64_t)cus * per_cu / (strips * d.batch));
         if (force_slices) slices = force_slices;
         slices = std::min<int64_t>(slices, (d.k + 63) / 64);
@@ -505,13 +538,15 @@ namespace mi355 {
 bool gemm_nnrows_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
 {
     (void)c;
-    if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16) return false;
-    if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != MI355_DTYPE_BF16 && d.dtype_c != MI355_DTYPE_F16) return false;
+    const bool f32 = d.dtype_ab == MI355_DTYPE_F32;                  // f32 operands: f32 result, four columns per 16-byte piece
+    if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16 && !f32) return false;
+    if (f32 ? d.dtype_c != MI355_DTYPE_F32 : (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != MI355_DTYPE_BF16 && d.dtype_c != MI355_DTYPE_F16)) return false;
     if (d.trans_a || d.trans_b) return false;
-    if (d.m < 1 || d.m > 16 || d.n < 8 || d.k < 8 || (d.n & 7) || (d.k & 7)) return false;
+    const int64_t epv = f32 ? 4 : 8, eb = f32 ? 4 : 2;
+    if (d.m < 1 || d.m > 16 || d.n < epv || d.k < epv || (d.n & (epv - 1)) || (d.k & (epv - 1))) return false;
     if (d.n > 0x3FFFFFF0 || d.k > 0x3FFFFFF0 || d.batch < 1 || d.batch > 65535) return false;
-    if (d.ldb * 2 * 8400 >= (1ll << 32)) return false;               // a lane's byte offset inside an x chunk (<= 8192 + 64 k-rows) is 32-bit
-    if ((d.lda & 7) || (d.ldb & 7) || (d.stride_a & 7) || (d.stride_b & 7)) return false;
+    if (d.ldb * eb * (16384 / eb + 72) >= (1ll << 32)) return false; // a lane's byte offset inside an x chunk (<= 16384 / eb + 64 k-rows) is 32-bit
+    if ((d.lda & (epv - 1)) || (d.ldb & (epv - 1)) || (d.stride_a & (epv - 1)) || (d.stride_b & (epv - 1))) return false;
     if ((reinterpret_cast<uintptr_t>(a) & 15u) || (reinterpret_cast<uintptr_t>(b) & 15u)) return false;
     nn_plan p;
     return plan_for(d, 256, p);
@@ -539,8 +574,8 @@ int32_t launch_gemm_nnrows(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc 
     const int cus = ctx->props.num_streaming_multiprocessors > 0 ? ctx->props.num_streaming_multiprocessors : 256;
     if (!plan_for(d, cus, p)) return fail(ctx, MI355_E_UNSUPPORTED, "mi355_gemm(nnrows): no strip plan");
     nn_args g{};
-    g.a = static_cast<const uint16_t *>(a);
-    g.b = static_cast<const uint16_t *>(b);
+    g.a = a;
+    g.b = b;
     g.c = c;
     g.m = (int32_t)d.m; g.n = (int32_t)d.n; g.k = (int32_t)d.k;
     g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc;
@@ -556,7 +591,8 @@ int32_t launch_gemm_nnrows(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc 
         const int32_t rc = strip_tickets_for_stream(ctx, s, &g.tickets);
         if (rc != MI355_OK) return rc;
     }
-    if (d.dtype_ab == MI355_DTYPE_BF16) launch_dt<MI355_DTYPE_BF16>(ctx, s, g, (uint32_t)d.batch, p.strip_bytes);
+    if (d.dtype_ab == MI355_DTYPE_F32) launch_dt<MI355_DTYPE_F32>(ctx, s, g, (uint32_t)d.batch, p.strip_bytes);
+    else if (d.dtype_ab == MI355_DTYPE_BF16) launch_dt<MI355_DTYPE_BF16>(ctx, s, g, (uint32_t)d.batch, p.strip_bytes);
     else launch_dt<MI355_DTYPE_F16>(ctx, s, g, (uint32_t)d.batch, p.strip_bytes);
     if (p.slices > 1 && hipPeekAtLastError() != hipSuccess) strip_tickets_mark_dirty(ctx);   // a refused launch never resets its tickets
     check_launch(ctx, "mi355_gemm(nnrows)");

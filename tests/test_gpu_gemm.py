@@ -1089,7 +1089,8 @@ def test_matmul_add_f32_inside_the_256_kernel(client, oracle, dtype, m, n, k, ba
     (3, 8, 8, {}), (1, 8, 8200, {}), (16, 16, 64, {}), (7, 520, 1032, {}), (16, 1032, 520, {"ldc": 1040}), (2, 131072, 512, {}),
     (13, 4104, 6152, {"ldb": 4112, "lda": 6160}), (5, 8192, 1096, {"batch": 3}), (16, 3072, 16384, {}), (1, 1024, 65536, {}),
     (12, 28672, 1024, {}), (9, 2048, 2056, {"batch": 2, "ldc": 2051})])
-@pytest.mark.parametrize("dtype,out_dtype", [(ElemType.BF16, ElemType.BF16), (ElemType.F16, ElemType.F32), (ElemType.BF16, ElemType.F32)])
+@pytest.mark.parametrize("dtype,out_dtype", [(ElemType.BF16, ElemType.BF16), (ElemType.F16, ElemType.F32), (ElemType.BF16, ElemType.F32),
+                                             (ElemType.F32, ElemType.F32)])     # f32 operands: v_mfma_f32_4x4x1, four columns per lane
 def test_few_rows_times_row_major_weight_matches_the_oracle(client, oracle, m, n, k, kw, dtype, out_dtype):
     run_case(client, oracle, m, n, k, dtype, out_dtype, False, ALGOS["nnrows"], **kw)
 
@@ -1111,8 +1112,12 @@ def test_few_rows_times_row_major_weight_random_shapes(client, oracle, seed):
         kw["lda"] = k + 8 * int(rng.integers(1, 5))
     if rng.random() < 0.4:
         kw["ldc"] = n + int(rng.integers(1, 9))
-    dtype = ElemType.BF16 if rng.random() < 0.6 else ElemType.F16
-    out = ElemType.F32 if rng.random() < 0.5 else dtype
+    dtype = [ElemType.BF16, ElemType.F16, ElemType.F32][int(rng.choice([0, 0, 1, 2]))]
+    out = ElemType.F32 if (rng.random() < 0.5 or dtype == ElemType.F32) else dtype
+    if dtype == ElemType.F32:                                  # half the element count per byte: keep the operand bytes
+        k = max(8, k // 2 // 8 * 8)
+        if "lda" in kw:
+            kw["lda"] = k + 8
     run_case(client, oracle, m, n, k, dtype, out, False, ALGOS["nnrows"], **kw)
 
 
