@@ -1,4 +1,4 @@
-// gemm_nnrows.hip -- at most 16 rows against a ROW-MAJOR weight: C[m][n] = sum_k A[m][k] * B[k][n], bf16 / f16, M <= 16.
+// gemm_nnrows.hip -- at most 16 rows against a ROW-MAJOR weight: C[m][n] = sum_k A[m][k] * B[k][n], bf16 / f16 / f32, M <= 16.
 //
 // This is the layout `TensorHandle::new_contiguous` gives a rhs (crates/cubecl-std/src/tensor/handle.rs:89; a [K][N] weight
 // classified RowMajor by matrix_batch_layout.rs:21-79): the decode-time product x [M][K] * W [K][N].  Roofline: HBM -- the
@@ -21,6 +21,11 @@
 //     one K slice the f32 partials go to library scratch and the LAST workgroup of the strip to arrive (one ticket word per
 //     strip, gemm_nnrows' share of the stream's ticket slot) adds them in slice order and writes C -- one launch,
 //     deterministic bits, no float atomics.
+//
+// Two more forms of the same loop (end of round 4): 9-16 rows on 256-byte strips use v_mfma_f32_16x16x16 -- its operand layout
+// (lane % 16 = column, lane / 16 = one of four k groups) is what the lanes hold there, one instruction per column slot covers
+// all 16 rows and the wave's four row groups are added in the matrix pipe; f32 operands use v_mfma_f32_4x4x1_16b_f32 -- one k
+// per instruction, each lane's own column, so a row-major f32 weight needs no transposition at all (four columns per lane).
 //
 // Accumulation: f32, order fixed by (S, slices) = by the shape and the device's CU count -- run-to-run bit-identical; not
 // bit-identical to the other kernels (different association), inside the parity tolerance of tests/test_gpu_gemm.py.
