@@ -146,6 +146,22 @@ static int32_t fence_compute_to_comm(mi355_ctx *ctx, hipStream_t compute)
     return MI355_OK;
 }
 
+// Which stream a collective of `bytes` (the larger of what it reads and writes on this rank) runs on.  The reference's shape
+// -- a communication stream between two event fences -- lets compute run beside a transfer; a collective of a few bytes has
+// no transfer to hide, and the fences are most of its time (one all-gather of a 16-byte record + the combine kernel behind
+// it, 1 rank on real RCCL: 31.8 us through the fences, see profiles/r05_c4_shard.md for the inline figure).  So a message of at
+// most MI355_COMM_INLINE_BYTES (default 4096) is queued IN the compute stream's order: no fence before it, nothing for
+// mi355_sync_collective to do after it.  Only while no earlier collective is still un-fenced on the communication stream
+// (comm_dirty): a communicator then never has operations in flight on two streams at once, and RCCL sees them in call order.
+static hipStream_t collective_stream(mi355_ctx *ctx, hipStream_t compute, uint64_t bytes, int32_t *rc)
+{
+    static const uint64_t inline_bytes = [] { const char *e = getenv("MI355_COMM_INLINE_BYTES"); return e ? (uint64_t)strtoull(e, nullptr, 10) : 4096ull; }();
+    *rc = MI355_OK;
+    if (bytes <= inline_bytes && !ctx->comm_dirty) return compute;
+    *rc = fence_compute_to_comm(ctx, compute);
+    return ctx->comm_stream;
+}
+
 MI355_API int32_t mi355_comm_unique_id(uint8_t id[MI355_UNIQUE_ID_BYTES])
 {
     if (!id) return MI355_E_INVALID_ARGUMENT;
@@ -196,9 +212,10 @@ MI355_API int32_t mi355_all_reduce(mi355_ctx *ctx, mi355_comm *comm, mi355_strea
     ncclRedOp_t rop;
     if (!to_nccl_dtype(dtype, &dt)) return fail(ctx, MI355_E_UNSUPPORTED, "mi355_all_reduce: dtype %d not supported by RCCL", dtype);
     if (!to_nccl_op(op, &rop)) return fail(ctx, MI355_E_UNSUPPORTED, "mi355_all_reduce: unknown op %d", op);
-    int32_t rc = fence_compute_to_comm(ctx, stream_of(ctx, compute_stream));
+    int32_t rc;
+    hipStream_t on = collective_stream(ctx, stream_of(ctx, compute_stream), count * dtype_size(dtype), &rc);
     if (rc != MI355_OK) return rc;
-    MI355_NCCL(ctx, g_rccl.AllReduce(src, dst, count, dt, rop, comm->comm, ctx->comm_stream));
+    MI355_NCCL(ctx, g_rccl.AllReduce(src, dst, count, dt, rop, comm->comm, on));
     return MI355_OK;
 }
 
@@ -211,9 +228,10 @@ MI355_API int32_t mi355_all_gather(mi355_ctx *ctx, mi355_comm *comm, mi355_strea
     if (!src || !dst) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_all_gather: NULL buffer");
     ncclDataType_t dt;
     if (!to_nccl_dtype(dtype, &dt)) return fail(ctx, MI355_E_UNSUPPORTED, "mi355_all_gather: dtype %d not supported by RCCL", dtype);
-    int32_t rc = fence_compute_to_comm(ctx, stream_of(ctx, compute_stream));
+    int32_t rc;
+    hipStream_t on = collective_stream(ctx, stream_of(ctx, compute_stream), count * dtype_size(dtype) * (uint64_t)comm->world, &rc);
     if (rc != MI355_OK) return rc;
-    MI355_NCCL(ctx, g_rccl.AllGather(src, dst, count, dt, comm->comm, ctx->comm_stream));
+    MI355_NCCL(ctx, g_rccl.AllGather(src, dst, count, dt, comm->comm, on));
     return MI355_OK;
 }
 

@@ -98,7 +98,7 @@ void pool_release_graph(mi355_ctx *ctx, uint64_t graph_id);   // a graph died: i
 void scratch_release(mi355_ctx *ctx, void *ptr);               // a graph died: drop one pin of a library scratch buffer
 // library-owned per-(stream, kind) device scratch (runtime.cpp): split-K slabs, re-laid-out GEMM operands, MX scales
 int32_t scratch_get(mi355_ctx *ctx, hipStream_t s, int kind, size_t bytes, void **out);
-// arrival-ticket words in library-owned device memory, one 2 KiB slot per live stream (runtime.cpp): word 0 the reductions',
+// arrival-ticket words in library-owned device memory, one 16 KiB slot per live stream (runtime.cpp): word 0 the reductions' top ticket (their 32 group tickets from byte 2048 on),
 // words 16 ... 511 gemm_nnrows.hip's per-strip tickets
 int32_t ticket_for_stream(mi355_ctx *ctx, hipStream_t s, unsigned int **out);
 int32_t strip_tickets_for_stream(mi355_ctx *ctx, hipStream_t s, unsigned int **out);

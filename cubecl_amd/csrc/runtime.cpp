@@ -823,9 +823,10 @@ int32_t scratch_get(mi355_ctx *ctx, hipStream_t s, int kind, size_t bytes, void 
 
 // One arrival-ticket word per stream in library-owned device scratch (zeroed when created, left zero by
 // every completed call).  Calls on one stream are stream-ordered, so a word is never shared by two
-// launches in flight.  A stream's slot is 2 KiB: word 0 is the reductions' ticket, words 16 ... 511 are the per-strip
-// tickets of gemm_nnrows.hip (mi355::strip_tickets_for_stream).
-constexpr uint32_t TICKET_SLOT_BYTES = 2048;
+// launches in flight.  A stream's slot is 16 KiB: word 0 is the reductions' top ticket, words 16 ... 511 are the per-strip
+// tickets of gemm_nnrows.hip (mi355::strip_tickets_for_stream), and from byte 2048 on 32 group tickets of the array-wide
+// reductions sit 256 bytes apart (reduce.hip arrive_is_last: one L2 serves the adds on one address at 11 ns each).
+constexpr uint32_t TICKET_SLOT_BYTES = 16384;
 int32_t ticket_for_stream(mi355_ctx *ctx, hipStream_t s, unsigned int **out)
 {
     constexpr uint32_t SLOTS = 1024;

@@ -5,12 +5,10 @@
 // (/opt/skills/guides/cdna_hip_programming.md G2/G7/G11/G13, Appendix B "Reduction"):
 //   - 16 B per lane coalesced loads (global_load_dwordx4, non-temporal: the data is read once),
 //     RED_UNROLL independent loads in flight per lane, one independent accumulator per load slot;
-//   - grid = ONE workgroup per CU since round 5 (the loop below keeps 8-16 loads of every lane in flight by hand; with
-//     the compiler's schedule of rounds 1-4 -- one load, a wait, seven loads -- it took 3 per CU).  128 MiB / 1 GiB, us,
-//     at 1 / 2 / 3 per CU: sum 23.2 / 23.7 / 24.5 and 154.8 / 154.6 / 157.0; fused sum + argmax 26.3 / 26.7 / 27.6 and
-//     155.0 / 162.1 / 166.1 (profiles/r05_c4_shard.md); fewer workgroups = fewer partial records and arrival atomics at
-//     the tail.  Grid-stride over 32 KiB tiles (no XCD remap: there is no inter-workgroup reuse, guide T1 "Transfer: 0% on
-//     LayerNorm"), the remainder dealt out in 4 KiB rows so that every workgroup streams the same bytes +- one row;
+//   - grid = 3 workgroups per CU (measured on the 1 GiB sum: 1/2/3/4/8/16 per CU = 176/156/157/162/181/183 us, and 3 is
+//     the best for the VALU-heavier argmax: 169/161/167 us at 2/3/4;
+//     fewer workgroups = fewer partial records and arrival atomics at the tail), grid-stride over
+//     32 KiB tiles (no XCD remap: there is no inter-workgroup reuse, guide T1 "Transfer: 0% on LayerNorm");
 //   - wave64 xor butterfly in the reference's plane_reduce order
 //     (crates/cubecl-cpp/src/shared/plane.rs:60-70), then LDS across the 4 waves, one partial
 //     record per workgroup; the LAST workgroup to arrive (ticket word) folds the records in index
@@ -24,7 +22,6 @@
 #include "internal.hpp"
 
 #include <algorithm>
-#include <type_traits>
 #include <cstdlib>
 
 using namespace mi355;
@@ -77,16 +74,6 @@ template <> struct red_in<MI355_DTYPE_F16> {
         for (int c = 0; c < 4; ++c) { v[2 * c] = widen((uint16_t)(raw[c] & 0xFFFFu)); v[2 * c + 1] = widen((uint16_t)(raw[c] >> 16)); }
     }
 };
-
-// Dev timing trace (-DRED_TRACE, never in the product library): 100 MHz-counter stamps of thread 0 of every workgroup -- entry,
-// whole rounds done, dealt rows done, record stored, ticket taken, exit -- read back with mi355_dev_red_trace
-// (tools/dev/reduce_trace.py).
-#ifdef RED_TRACE
-__device__ unsigned long long red_trace_buf[4096 * 8];
-#define RED_STAMP(slot) do { if (threadIdx.x == 0) red_trace_buf[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define RED_STAMP(slot) do { } while (0)
-#endif
 
 struct __attribute__((aligned(16))) red_record {
     float sum;
@@ -173,27 +160,6 @@ __device__ __forceinline__ uint32_t arg_key(float v)
     return (AOP == AOP_MIN && k != 0xFFFFFFFFu) ? ~k : k;
 }
 
-// (key, idx) combine carrying the winner's value bits along (the array-wide kernel reports the winning element bit-exactly
-// without going back to memory for it: key collapses -0 / +0 and NaN payloads)
-__device__ __forceinline__ void arg_combine3(uint32_t &key, uint64_t &idx, uint32_t &bits, uint32_t okey, uint64_t oidx, uint32_t obits)
-{
-    const bool take = (okey > key) || (okey == key && oidx < idx);
-    key = take ? okey : key;
-    idx = take ? oidx : idx;
-    bits = take ? obits : bits;
-}
-
-__device__ __forceinline__ void wave_argmax3(uint32_t &key, uint64_t &idx, uint32_t &bits)
-{
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t okey = __shfl_xor(key, off, 64), obits = __shfl_xor(bits, off, 64);
-        const uint32_t olo = __shfl_xor((uint32_t)idx, off, 64);
-        const uint32_t ohi = __shfl_xor((uint32_t)(idx >> 32), off, 64);
-        arg_combine3(key, idx, bits, okey, ((uint64_t)ohi << 32) | olo, obits);
-    }
-}
-
 __device__ __forceinline__ void wave_argmax(uint32_t &key, uint64_t &idx)
 {
 #pragma unroll
@@ -226,27 +192,14 @@ __device__ __forceinline__ red_record record_load(const red_record *slot)
     return r;
 }
 
-// Arrival tickets: returning agent-scope fetch_adds (a compare-and-swap loop here costs one L2 round trip per CONTENDER:
-// 2048 workgroups finishing together took 8 ms).  The words live in library-owned device scratch that is zero between
-// calls: whoever completes a count puts the zero back.
-//   Two levels since round 5.  One L2 serves the fetch_adds on ONE address at 11.4 ns each, whatever the number of waves
-//   asking (tools/dev/atomic_rate_probe.hip: 8 addresses 256 bytes apart 1.8 ns, 64 addresses 0.3 ns): with one word, the 768
-//   workgroups of a pass that finish together -- the 128 MiB shard of config C4 streams for 19 us and its workgroups finish
-//   within 3 us of each other -- queued for 768 x 11.4 ns = 8.8 us behind that word, a third of the pass (trace in
-//   profiles/r05_c4_shard.md).  Now workgroup b counts on word b % 32 of 32 group words 256 bytes apart, and the last of
-//   a group counts on the top word: at most 24 + 32 serialised adds on the way of any workgroup.
-constexpr uint32_t RED_TICKET_GROUPS = 32;
-constexpr uint32_t RED_GROUP_WORD0 = 512, RED_GROUP_WORD_STEP = 64;     // words: the groups start 2 KiB into the stream's slot
+// Arrival ticket: one returning agent-scope fetch_add per workgroup (a compare-and-swap loop here costs
+// one L2 round trip per CONTENDER: 2048 workgroups finishing together took 8 ms).  The word lives in
+// library-owned device scratch that is zero between calls: the last arriver puts the zero back.
 __device__ __forceinline__ bool arrive_is_last(unsigned int *ticket, uint32_t G)
 {
     typedef __attribute__((address_space(1))) unsigned int gu32;
-    const uint32_t g = blockIdx.x % RED_TICKET_GROUPS;
-    const uint32_t members = (G - g + RED_TICKET_GROUPS - 1) / RED_TICKET_GROUPS;
-    gu32 *grp = (gu32 *)(ticket + RED_GROUP_WORD0 + g * RED_GROUP_WORD_STEP);
-    if (__hip_atomic_fetch_add(grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != members - 1) return false;
-    __hip_atomic_store(grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                   // ready for the next call
-    const uint32_t groups = G < RED_TICKET_GROUPS ? G : RED_TICKET_GROUPS;
-    return __hip_atomic_fetch_add((gu32 *)ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1;
+    const unsigned int old = __hip_atomic_fetch_add((gu32 *)ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return old == G - 1;
 }
 
 // Every workgroup folds its tiles into one record; the last one to arrive folds the G records.
@@ -256,10 +209,10 @@ __device__ __forceinline__ bool arrive_is_last(unsigned int *ticket, uint32_t G)
 //   VOP / AOP : value and index operation (above); both at once only as SUM + ARGMAX, the fused pass of the sharded job.
 //   mean_div  : MEAN = SUM with out = sum / mean_div (0 = no division)
 template <int VOP, int AOP, int DT = MI355_DTYPE_F32>
-__global__ void __launch_bounds__(RED_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 8)))   // one workgroup per CU is the grid (pick_grid): the whole register file is one wave's
+__global__ void __launch_bounds__(RED_BLOCK)
 reduce_kernel(const typename red_in<DT>::elem *__restrict__ head, uint32_t head_n, const typename red_in<DT>::elem *__restrict__ in, uint64_t n,
               red_record *__restrict__ records, unsigned int *__restrict__ ticket, uint64_t n_total, float *__restrict__ out_sum, float *__restrict__ out_val, uint64_t *__restrict__ out_idx,
-              float mean_div, uint64_t rounds)
+              float mean_div)
 {
     constexpr bool SUM = VOP != VOP_NONE, ARG = AOP != AOP_NONE;        // (SUM: "a value is folded", whatever the operation)
     static_assert(!(SUM && ARG) || (VOP == VOP_SUM && AOP == AOP_MAX), "fused pass: sum + argmax only");
@@ -268,8 +221,9 @@ reduce_kernel(const typename red_in<DT>::elem *__restrict__ head, uint32_t head_
     constexpr bool AMIN = AOP == AOP_MIN;
     typedef red_in<DT> RI;
     constexpr int EPV = RI::EPV;
-    constexpr uint64_t ROW = (uint64_t)RED_BLOCK * EPV;                     // elements per 4 KiB row (one 16-byte load per lane)
+    constexpr uint64_t TILE = (uint64_t)RED_BLOCK * RED_UNROLL * EPV;       // elements per 32 KiB tile
     const uint32_t tid = threadIdx.x;
+    const uint64_t full_tiles = n / TILE;
     const uint32_t G = gridDim.x;
 
     f32x4 acc[RED_UNROLL];
@@ -278,185 +232,80 @@ reduce_kernel(const typename red_in<DT>::elem *__restrict__ head, uint32_t head_
     float tail_acc = V::identity();
     bool nan_seen = false;           // MAX / MIN: some element of this lane's share was a NaN
     uint32_t best_key = 0u;          // 0 = "nothing yet": every real key is >= 0x007FFFFF (-inf; ARGMIN: +inf)
-    uint64_t best_idx = ~0ull;       // (head and ragged tail elements; the streamed vectors join them below)
-    uint32_t best_bits = 0u;         // the element behind (best_key, best_idx), as loaded (widened)
+    uint64_t best_idx = ~0ull;
+    // value behind best_key: the fast-reject threshold (once a NaN leads nothing but a NaN can follow it: +inf / ARGMIN -inf)
     constexpr float NAN_LEADS = AMIN ? -__builtin_inff() : __builtin_inff();
-    // Index operations over the streamed vectors, branch-free per vector since round 5: the running extremum under FLOAT
-    // comparison (-0 == +0, a NaN never enters), the vector that first reached it (kept whole, with its item / slot code),
-    // and the position of the lane's first NaN; resolved to (key, index) once, behind the stream.  (Rounds 1-4 rejected a
-    // vector with one compare and took an exact per-element path otherwise -- but a wave takes that path when ANY of its 64
-    // lanes has a new extremum, which at the 64 vectors a lane sees of a 128 MiB shard is nearly every vector.)
-    float s_best = -NAN_LEADS;
-    uint32_t s_code = ~0u;           // item * 8 + slot; ~0 = nothing streamed yet
-    u32x4r s_raw = (u32x4r){0u, 0u, 0u, 0u};
-    uint32_t s_nan = ~0u;            // (item * 8 + slot) * EPV + position of the first NaN; ~0 = none
-    uint32_t s_nan_bits = 0u;        // that NaN
+    float best_val = -NAN_LEADS;
 
     // peeled head: lowest global indices, block 0 only
     if (blockIdx.x == 0 && tid < head_n) {
         const float v = RI::widen(head[tid]);
         if (SUM) tail_acc = V::apply(tail_acc, v);
         if (NANS) nan_seen |= (v != v);
-        if (ARG) { best_key = arg_key<AOP>(v); best_idx = tid; best_bits = __float_as_uint(v); }
+        if (ARG) { best_key = arg_key<AOP>(v); best_idx = tid; best_val = (best_key == 0xFFFFFFFFu) ? NAN_LEADS : v; }
     }
 
-    // One 16-byte vector of this lane: `code` = item * 8 + slot names it (item_base(item) + slot * 256 = its index among the
-    // body's vectors; global element = that * EPV + head_n).
-    // `live` (wave-uniform; constant true in the steady loop): a spare load of a short last item contributes nothing -- the
-    // registers are READ all the same (a load result that is dead on some path makes the compiler's waitcnt pass drain
-    // every load in flight before the register is written again).
-    auto consume = [&](auto guarded, const bool live, const u32x4r &rawv, f32x4 &accu, const uint32_t code) __attribute__((always_inline)) {
-        constexpr bool GUARD = decltype(guarded)::value;
-        float w[EPV];
-        RI::unpack(rawv, w);
-        if (SUM) {
-            if constexpr (GUARD) {
+    const u32x4r *__restrict__ vin = reinterpret_cast<const u32x4r *>(in);
+    for (uint64_t tile = blockIdx.x; tile < full_tiles; tile += G) {
+        const uint64_t vbase = tile * (uint64_t)(RED_BLOCK * RED_UNROLL) + tid;
+        u32x4r raw[RED_UNROLL];
 #pragma unroll
-                for (int c = 0; c < EPV; ++c) w[c] = live ? w[c] : V::identity();
+        for (int u = 0; u < RED_UNROLL; ++u) raw[u] = __builtin_nontemporal_load(vin + vbase + (uint64_t)u * RED_BLOCK);
+#pragma unroll
+        for (int u = 0; u < RED_UNROLL; ++u) {
+            float w[EPV];
+            RI::unpack(raw[u], w);
+            if (SUM) {
+                acc[u] = V::apply(acc[u], (f32x4){w[0], w[1], w[2], w[3]});
+                if constexpr (EPV == 8) acc[u] = V::apply(acc[u], (f32x4){w[4], w[5], w[6], w[7]});
             }
-            accu = V::apply(accu, (f32x4){w[0], w[1], w[2], w[3]});
-            if constexpr (EPV == 8) accu = V::apply(accu, (f32x4){w[4], w[5], w[6], w[7]});
-        }
-        if constexpr (NANS) {               // (the identity is never a NaN)
-            nan_seen |= __builtin_isunordered(w[0], w[1]) | __builtin_isunordered(w[2], w[3]);
-            if constexpr (EPV == 8) nan_seen |= __builtin_isunordered(w[4], w[5]) | __builtin_isunordered(w[6], w[7]);
-        }
-        if (ARG) {
-            typedef vop<AMIN ? VOP_MIN : VOP_MAX> X;
-            float m4 = X::apply(X::apply(w[0], w[1]), X::apply(w[2], w[3]));                 // (v_max / v_min drop NaNs)
-            bool has_nan = __builtin_isunordered(w[0], w[1]) | __builtin_isunordered(w[2], w[3]);
-            if constexpr (EPV == 8) {
-                m4 = X::apply(m4, X::apply(X::apply(w[4], w[5]), X::apply(w[6], w[7])));
-                has_nan |= __builtin_isunordered(w[4], w[5]) | __builtin_isunordered(w[6], w[7]);
+            if constexpr (NANS) {
+                nan_seen |= __builtin_isunordered(w[0], w[1]) | __builtin_isunordered(w[2], w[3]);
+                if constexpr (EPV == 8) nan_seen |= __builtin_isunordered(w[4], w[5]) | __builtin_isunordered(w[6], w[7]);
             }
-            // strict comparison: within one lane codes only grow, so the first vector to reach the extremum is kept
-            // (SUM + ARG guarded: w[] holds the sum's identity for a spare load, and `live` keeps it out of the race)
-            const bool take = ((AMIN ? (m4 < s_best) : (m4 > s_best)) | (s_code == ~0u)) & (!GUARD || live);
-            s_best = take ? X::apply(s_best, m4) : s_best;
-            s_code = take ? code : s_code;
+            if (ARG) {
+                // Fast reject: a 16-byte vector can only matter if it holds a NaN or a value above this
+                // lane's running maximum (new maxima get rare quickly: ~ln(n) per lane), so the exact
+                // key/index update below runs on a few percent of the vectors.  v_max ignores NaNs,
+                // hence the separate unordered test; -0 vs +0 never compares greater, which is the
+                // tie rule (equal keys keep the lower index).
+                // (ARGMIN: the same with v_min and "below the running minimum")
+                typedef vop<AMIN ? VOP_MIN : VOP_MAX> X;
+                float m4 = X::apply(X::apply(w[0], w[1]), X::apply(w[2], w[3]));
+                bool has_nan = __builtin_isunordered(w[0], w[1]) | __builtin_isunordered(w[2], w[3]);
+                if constexpr (EPV == 8) {
+                    m4 = X::apply(m4, X::apply(X::apply(w[4], w[5]), X::apply(w[6], w[7])));
+                    has_nan |= __builtin_isunordered(w[4], w[5]) | __builtin_isunordered(w[6], w[7]);
+                }
+                if ((AMIN ? (m4 < best_val) : (m4 > best_val)) | has_nan | (best_key == 0u)) {
+                    const uint64_t e0 = (vbase + (uint64_t)u * RED_BLOCK) * EPV + head_n;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) s_raw[c] = take ? rawv[c] : s_raw[c];
-            if (has_nan & (!GUARD || live)) {                    // rare: exec-masked, skipped by a wave without a NaN
-                if (s_nan == ~0u) {
-                    uint32_t pos = 0;
-#pragma unroll
-                    for (int c = EPV - 1; c >= 0; --c)
-                        if (w[c] != w[c]) { pos = (uint32_t)c; s_nan_bits = __float_as_uint(w[c]); }
-                    s_nan = code * EPV + pos;
+                    for (int c = 0; c < EPV; ++c) {
+                        const uint32_t k = arg_key<AOP>(w[c]);
+                        // strict > : within one lane indices only grow, so the first maximum is kept
+                        if (k > best_key) { best_key = k; best_idx = e0 + c; best_val = (k == 0xFFFFFFFFu) ? NAN_LEADS : w[c]; }
+                    }
                 }
             }
         }
-    };
-
-    // The body in 4 KiB rows (256 lanes x 16 bytes), cut into ITEMS of a workgroup: whole rounds of 32 KiB tiles (8 rows)
-    // grid-stride over the array, and the rows that do not fill another round for EVERY workgroup are dealt out evenly as
-    // one last item, a contiguous run of at most 8 rows (round 5: until then the last round was whole tiles for the first
-    // `tiles % G` workgroups -- at the 128 MiB shard of config C4, 4096 tiles on 768 workgroups, a third of the workgroups
-    // streamed a sixth tile while the rest of the chip idled).
-    //
-    // Items are double-buffered BY HAND: item i + 1 is on its way while item i is consumed, 8 to 16 loads in flight per
-    // lane at any time.  (Left to itself the compiler issued one load, waited for it, then issued the other seven: two
-    // exposed memory latencies per tile -- the ISA of rounds 1-4.)  The rules of gemm_nnrows.hip's ring apply: every load
-    // unconditional (a short item re-reads its last row: same cache lines, no HBM traffic), no dead load result, constant
-    // register indices, the order pinned by sched_barrier; the compiler's own waitcnt pass then counts vmcnt(8).
-    const u32x4r *__restrict__ vin = reinterpret_cast<const u32x4r *>(in);
-    const uint64_t rows = n / ROW;
-    // (`rounds` = rows / (8 G) comes from the host, and the deal below is 32-bit: a 64-bit division is ~150 instructions here)
-    const uint64_t row0 = rounds * G * RED_UNROLL;
-    const uint32_t rem = (uint32_t)(rows - row0);                                      // rem < 8 G <= 2^15
-    const uint32_t lo = rem * blockIdx.x / G, hi = rem * (blockIdx.x + 1u) / G;        // at most 8 rows, wave-uniform
-    const uint32_t dealt = hi - lo;
-    const uint64_t items = rounds + (dealt ? 1u : 0u);
-    // item i: first vector of this lane and live rows (0 = no such item: its loads re-read item 0's first row)
-    auto item_base = [&](uint64_t i) -> uint64_t {
-        return (i < rounds ? (i * G + blockIdx.x) * (uint64_t)RED_UNROLL : (i < items ? row0 + lo : (rounds ? (uint64_t)blockIdx.x * RED_UNROLL : row0 + lo))) * RED_BLOCK + tid;
-    };
-    auto item_rows = [&](uint64_t i) -> uint32_t { return i < rounds ? (uint32_t)RED_UNROLL : (i < items ? dealt : 0u); };
-    auto issue_whole = [&](u32x4r (&r)[RED_UNROLL], uint64_t vbase) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < RED_UNROLL; ++u) r[u] = __builtin_nontemporal_load(vin + vbase + (uint64_t)u * RED_BLOCK);
-    };
-    auto issue_any = [&](u32x4r (&r)[RED_UNROLL], uint64_t vbase, uint32_t cnt) __attribute__((always_inline)) {
-        const uint32_t top = cnt ? cnt - 1u : 0u;
-#pragma unroll
-        for (int u = 0; u < RED_UNROLL; ++u) r[u] = __builtin_nontemporal_load(vin + vbase + (uint64_t)((uint32_t)u < top ? (uint32_t)u : top) * RED_BLOCK);
-    };
-    RED_STAMP(0);
-    if (items) {
-        u32x4r ra[RED_UNROLL], rb[RED_UNROLL];
-        uint64_t i = 0;
-        issue_any(ra, item_base(0), item_rows(0));
-        // steady state: items i, i + 1 and i + 2 are whole tiles.  (Not for the fused pass over 16-bit input: two unguarded
-        // copies of its eight-element bodies beside the guarded one took 255 VGPRs and spilled; it runs every item through
-        // the turn-by-turn loop below, which double-buffers too -- with 32 register copies per item.)
-        // (Refilling each slot the moment it has been consumed -- 15-16 loads in flight instead of 8-16 -- measured SLOWER:
-        // sum 24.6 against 23.4 us on the 128 MiB shard, fused 26.9 against 26.0; profiles/r05_c4_shard.md.)
-        constexpr bool STEADY = !(SUM && ARG && EPV == 8);
-        for (; STEADY && i + 2 < rounds; i += 2) {
-            __builtin_amdgcn_sched_barrier(0);
-            issue_whole(rb, item_base(i + 1));
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < RED_UNROLL; ++u) { consume(std::false_type{}, true, ra[u], acc[u], (uint32_t)i * RED_UNROLL + u); if constexpr (EPV == 8) __builtin_amdgcn_sched_barrier(0); }
-            __builtin_amdgcn_sched_barrier(0);
-            issue_whole(ra, item_base(i + 2));
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < RED_UNROLL; ++u) { consume(std::false_type{}, true, rb[u], acc[u], (uint32_t)(i + 1) * RED_UNROLL + u); if constexpr (EPV == 8) __builtin_amdgcn_sched_barrier(0); }
-        }
-        RED_STAMP(1);
-        // the last one to three items (the dealt rows among them), one per turn: `ra` holds item i, item i + 1 is fetched
-        // into `rb` while it is consumed, then takes its place (a register copy: this loop runs at most three times)
-#pragma nounroll
-        for (; i < items; ++i) {
-            const uint32_t ca = item_rows(i);
-            __builtin_amdgcn_sched_barrier(0);
-            issue_any(rb, item_base(i + 1), item_rows(i + 1));
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < RED_UNROLL; ++u) { consume(std::true_type{}, (uint32_t)u < ca, ra[u], acc[u], (uint32_t)i * RED_UNROLL + u); if constexpr (EPV == 8) __builtin_amdgcn_sched_barrier(0); }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < RED_UNROLL; ++u) ra[u] = rb[u];
-        }
     }
-    if (ARG) {
-        // the streamed vectors' winner of this lane as (key, index), then against the head / tail elements
-        if (s_code != ~0u) {
-            uint32_t k, code, pos, vb;
-            if (s_nan != ~0u) { k = 0xFFFFFFFFu; code = s_nan / EPV; pos = s_nan % EPV; vb = s_nan_bits; }
-            else {
-                float w[EPV];
-                RI::unpack(s_raw, w);
-                pos = 0; vb = __float_as_uint(s_best);
-#pragma unroll
-                for (int c = EPV - 1; c >= 0; --c)
-                    if (w[c] == s_best) { pos = (uint32_t)c; vb = __float_as_uint(w[c]); }       // first element at the extremum (-0 == +0)
-                k = arg_key<AOP>(s_best);
-                code = s_code;
-            }
-            const uint64_t vidx = item_base(code / RED_UNROLL) + (uint64_t)(code % RED_UNROLL) * RED_BLOCK;
-            arg_combine3(best_key, best_idx, best_bits, k, vidx * EPV + head_n + pos, vb);
-        }
-    }
-    RED_STAMP(2);
 
-    // ragged tail (< one row): the last workgroup, guarded scalar loads
-    const uint64_t tail_base = rows * ROW;
-    if (tail_base < n && blockIdx.x == G - 1) {
+    // ragged tail (< one tile): the workgroup next in rotation, guarded scalar loads
+    const uint64_t tail_base = full_tiles * TILE;
+    if (tail_base < n && blockIdx.x == (uint32_t)(full_tiles % G)) {
         for (uint64_t i = tail_base + tid; i < n; i += RED_BLOCK) {
             const float v = RI::widen(in[i]);
             if (SUM) tail_acc = V::apply(tail_acc, v);
             if (NANS) nan_seen |= (v != v);
             if (ARG) {
                 const uint32_t k = arg_key<AOP>(v);
-                if (k > best_key) { best_key = k; best_idx = i + head_n; best_bits = __float_as_uint(v); }
+                if (k > best_key) { best_key = k; best_idx = i + head_n; }
             }
         }
     }
 
     // all LDS scratch in one object (hand-off flag included)
-    __shared__ struct { float sum[RED_BLOCK / 64]; uint32_t key[RED_BLOCK / 64]; uint64_t idx[RED_BLOCK / 64]; uint32_t bits[RED_BLOCK / 64]; uint32_t last; } sh;
+    __shared__ struct { float sum[RED_BLOCK / 64]; uint32_t key[RED_BLOCK / 64]; uint64_t idx[RED_BLOCK / 64]; uint32_t last; } sh;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
 
     if (SUM) {
@@ -473,8 +322,8 @@ reduce_kernel(const typename red_in<DT>::elem *__restrict__ head, uint32_t head_
         if (lane == 0) sh.key[wave] = any ? 1u : 0u;
     }
     if (ARG) {
-        wave_argmax3(best_key, best_idx, best_bits);
-        if (lane == 0) { sh.key[wave] = best_key; sh.idx[wave] = best_idx; sh.bits[wave] = best_bits; }
+        wave_argmax(best_key, best_idx);
+        if (lane == 0) { sh.key[wave] = best_key; sh.idx[wave] = best_idx; }
     }
     __syncthreads();
     if (tid == 0) {
@@ -482,37 +331,31 @@ reduce_kernel(const typename red_in<DT>::elem *__restrict__ head, uint32_t head_
         if (SUM) rs = V::apply(V::apply(sh.sum[0], sh.sum[1]), V::apply(sh.sum[2], sh.sum[3]));
         if (NANS) rk = sh.key[0] | sh.key[1] | sh.key[2] | sh.key[3];
         if (ARG) {
-            // the record carries the winner's VALUE BITS in its key word (the fold below re-derives the key): the last
-            // workgroup then reports the element without a dependent load behind the fold (1.7 us of a 26 us pass)
-            uint32_t rb = sh.bits[0];
             rk = sh.key[0]; ri = sh.idx[0];
 #pragma unroll
-            for (int w = 1; w < RED_BLOCK / 64; ++w) arg_combine3(rk, ri, rb, sh.key[w], sh.idx[w], sh.bits[w]);
-            rk = rb;
+            for (int w = 1; w < RED_BLOCK / 64; ++w) arg_combine(rk, ri, sh.key[w], sh.idx[w]);
         }
         record_store(records + blockIdx.x, rs, rk, ri);            // write-through (sc1) 8-byte stores
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // ... drained before the ticket
-        RED_STAMP(3);
         sh.last = arrive_is_last(ticket, G) ? 1u : 0u;
-        RED_STAMP(4);
     }
     __syncthreads();
     if (!sh.last) return;
 
     // ---- the last workgroup folds the G records in index order (thread t owns t, t+256, ...) ----
     float facc = V::identity();
-    uint32_t key = 0u, bits = 0u;
+    uint32_t key = 0u;
     uint64_t idx = ~0ull;
     for (uint32_t gi = tid; gi < G; gi += RED_BLOCK) {
         const red_record r = record_load(records + gi);            // sc1 loads: served by L2, never a stale L1 line
         if (SUM) facc = V::apply(facc, r.sum);
         if (NANS) key |= r.key;
-        if (ARG) arg_combine3(key, idx, bits, r.idx == ~0ull ? 0u : arg_key<AOP>(__uint_as_float(r.key)), r.idx, r.key);
+        if (ARG) arg_combine(key, idx, r.key, r.idx);
     }
     __syncthreads();                                                // sh.* is reused below
     if (SUM) { facc = wave_fold<VOP == VOP_NONE ? VOP_SUM : VOP>(facc); if (lane == 0) sh.sum[wave] = facc; }
     if constexpr (NANS) { const bool any = __any(key != 0u); if (lane == 0) sh.key[wave] = any ? 1u : 0u; }
-    if (ARG) { wave_argmax3(key, idx, bits); if (lane == 0) { sh.key[wave] = key; sh.idx[wave] = idx; sh.bits[wave] = bits; } }
+    if (ARG) { wave_argmax(key, idx); if (lane == 0) { sh.key[wave] = key; sh.idx[wave] = idx; } }
     __syncthreads();
     if (tid == 0) {
         typedef __attribute__((address_space(1))) unsigned int gu32;
@@ -524,34 +367,25 @@ reduce_kernel(const typename red_in<DT>::elem *__restrict__ head, uint32_t head_
             *out_sum = total;
         }
         if (ARG) {
-            uint32_t k = sh.key[0], vb = sh.bits[0]; uint64_t ix = sh.idx[0];
+            uint32_t k = sh.key[0]; uint64_t ix = sh.idx[0];
 #pragma unroll
-            for (int w = 1; w < RED_BLOCK / 64; ++w) arg_combine3(k, ix, vb, sh.key[w], sh.idx[w], sh.bits[w]);
+            for (int w = 1; w < RED_BLOCK / 64; ++w) arg_combine(k, ix, sh.key[w], sh.idx[w]);
             if (n_total == 0) {
                 if (out_idx) *out_idx = 0;
                 if (out_val) *out_val = -NAN_LEADS;          // the identity: -inf (argmax) / +inf (argmin)
             } else {
                 if (out_idx) *out_idx = ix;
-                if (out_val) *out_val = __uint_as_float(vb);  // the winning element, bit for bit (it travelled with its index)
+                // bit-exact copy of the winning element
+                if (out_val) *out_val = RI::widen((ix < head_n) ? head[ix] : in[ix - head_n]);
             }
         }
-        RED_STAMP(5);
     }
 }
-
-#ifdef RED_TRACE
-extern "C" __attribute__((visibility("default"))) int mi355_dev_red_trace(unsigned long long *host_out, int clear)
-{
-    const int rc = (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(red_trace_buf), sizeof(unsigned long long) * 4096 * 8);
-    if (clear) { static unsigned long long z[4096 * 8]; (void)hipMemcpyToSymbol(HIP_SYMBOL(red_trace_buf), z, sizeof(z)); }
-    return rc;
-}
-#endif
 
 uint32_t pick_grid(const mi355_ctx *ctx, uint64_t n, uint64_t tile_elems = RED_TILE)
 {
     const uint64_t tiles = (n + tile_elems - 1) / tile_elems;
-    static const int per_cu = [] { const char *e = getenv("MI355_REDUCE_WG_PER_CU"); int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
+    static const int per_cu = [] { const char *e = getenv("MI355_REDUCE_WG_PER_CU"); int v = e ? atoi(e) : 3; return v > 0 ? v : 3; }();
     const uint64_t cap = std::min<uint64_t>((uint64_t)ctx->props.num_streaming_multiprocessors * per_cu, RED_MAX_GRID);
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(tiles, cap));
 }
@@ -584,9 +418,8 @@ int32_t run_reduce_t(mi355_ctx *ctx, mi355_stream stream, const void *in_v, uint
     unsigned int *ticket = nullptr;
     const int32_t trc = ticket_for_stream(ctx, s, &ticket);
     if (trc != MI355_OK) return trc;
-    const uint64_t rounds = body_n / ((uint64_t)RED_BLOCK * red_in<DT>::EPV) / ((uint64_t)G * RED_UNROLL);
     hipLaunchKernelGGL((reduce_kernel<VOP, AOP, DT>), dim3(G), dim3(RED_BLOCK), 0, s, in, head_n, body, body_n, records,
-                       ticket, n, out_sum, out_val, out_idx, mean_div, rounds);
+                       ticket, n, out_sum, out_val, out_idx, mean_div);
     if (hipPeekAtLastError() != hipSuccess) ctx->tickets_dirty = true;   // a refused launch never resets its ticket
     check_launch(ctx, what);
     return MI355_OK;
@@ -1110,29 +943,17 @@ plane_op_kernel(const float *__restrict__ in, void *__restrict__ out_raw, uint64
 // behind the collective -- no host round trip inside the exchange.  An empty shard passes index 2^64-1 and is skipped.
 struct combine_bases { uint64_t base[64]; };
 
-// SUMS (round 5): the record's second word carries the shard's partial sum (where mi355_sum_argmax_f32 writes out_sum when it
-// is 4 bytes behind out_val), so ONE all-gather moves everything the job exchanges; lane 0 then adds the partial sums
-// in RANK ORDER -- a fixed tree, the same bits on every rank and every run (an all-reduce leaves the order to RCCL's
-// algorithm choice).  An empty shard's sum word must be +0.0.
-template <bool SUMS>
 __global__ void __launch_bounds__(64)
-argmax_combine_kernel(const uint32_t *__restrict__ records, uint32_t count, combine_bases bases, float *__restrict__ out_sum, float *__restrict__ out_val,
+argmax_combine_kernel(const uint32_t *__restrict__ records, uint32_t count, combine_bases bases, float *__restrict__ out_val,
                       uint64_t *__restrict__ out_idx)
 {
     const uint32_t lane = threadIdx.x;
     uint32_t key = 0, bits = 0xFF800000u;                   // -inf: what mi355_argmax_f32 reports for an empty array
     uint64_t idx = ~0ull;
-    float part = 0.f;
     if (lane < count) {
         const uint32_t vb = records[lane * 4];
         const uint64_t li = ((uint64_t)records[lane * 4 + 3] << 32) | records[lane * 4 + 2];
         if (li != ~0ull) { key = argmax_key(__uint_as_float(vb)); idx = bases.base[lane] + li; bits = vb; }
-        if (SUMS) part = __uint_as_float(records[lane * 4 + 1]);
-    }
-    if (SUMS) {
-        float total = 0.f;
-        for (uint32_t r = 0; r < count; ++r) total += __shfl(part, (int)r, 64);      // rank order (count is wave-uniform)
-        if (lane == 0 && out_sum) *out_sum = total;
     }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -1217,25 +1038,9 @@ MI355_API int32_t mi355_argmax_combine_f32(mi355_ctx *ctx, mi355_stream stream, 
         return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_argmax_combine_f32: records must be an 8-byte aligned device pointer");
     combine_bases b{};
     for (uint32_t r = 0; r < count; ++r) b.base[r] = index_base ? index_base[r] : 0;
-    hipLaunchKernelGGL(argmax_combine_kernel<false>, dim3(1), dim3(64), 0, stream_of(ctx, stream), static_cast<const uint32_t *>(records), count,
-                       b, (float *)nullptr, out_val, out_idx);
+    hipLaunchKernelGGL(argmax_combine_kernel, dim3(1), dim3(64), 0, stream_of(ctx, stream), static_cast<const uint32_t *>(records), count,
+                       b, out_val, out_idx);
     check_launch(ctx, "mi355_argmax_combine_f32");
-    return MI355_OK;
-}
-
-MI355_API int32_t mi355_sum_argmax_combine_f32(mi355_ctx *ctx, mi355_stream stream, const void *records, uint32_t count,
-                                               const uint64_t *index_base, float *out_sum, float *out_val, uint64_t *out_idx)
-{
-    MI355_REQUIRE_CTX(ctx);
-    if (!out_sum && !out_val && !out_idx) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_sum_argmax_combine_f32: no output");
-    if (count > 64) return fail(ctx, MI355_E_UNSUPPORTED, "mi355_sum_argmax_combine_f32: %u records (at most 64 shards)", count);
-    if (count && (!records || (reinterpret_cast<uintptr_t>(records) & 7u)))
-        return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_sum_argmax_combine_f32: records must be an 8-byte aligned device pointer");
-    combine_bases b{};
-    for (uint32_t r = 0; r < count; ++r) b.base[r] = index_base ? index_base[r] : 0;
-    hipLaunchKernelGGL(argmax_combine_kernel<true>, dim3(1), dim3(64), 0, stream_of(ctx, stream), static_cast<const uint32_t *>(records), count,
-                       b, out_sum, out_val, out_idx);
-    check_launch(ctx, "mi355_sum_argmax_combine_f32");
     return MI355_OK;
 }
 

@@ -299,6 +299,19 @@ def argmax_combine(client: ComputeClient, records: Handle, count: int, index_bas
         C.c_void_p(out_index.device_ptr()) if out_index is not None else None))
 
 
+def sum_argmax_combine(client: ComputeClient, records: Handle, count: int, index_base, out_sum: Optional[Handle],
+                       out_value: Optional[Handle], out_index: Optional[Handle]) -> None:
+    """The whole combine step of the sharded sum + argmax on the device (mi355_sum_argmax_combine_f32): folds `count` gathered
+    records {f32 value, f32 partial sum, u64 local index} -- rank order, as ONE all_gather delivers them -- into the global
+    sum (partial sums added in rank order: the same bits on every rank) and (value, GLOBAL index) with the single-GPU rule."""
+    base = (C.c_uint64 * max(count, 1))(*[int(b) for b in (index_base or [0] * count)])
+    client._s.check(client.lib.mi355_sum_argmax_combine_f32(
+        client.ctx, client.on(records, out_sum, out_value, out_index), C.c_void_p(records.device_ptr()), count, base,
+        C.c_void_p(out_sum.device_ptr()) if out_sum is not None else None,
+        C.c_void_p(out_value.device_ptr()) if out_value is not None else None,
+        C.c_void_p(out_index.device_ptr()) if out_index is not None else None))
+
+
 def _rows_view(t: TensorHandle, what: str):
     if t.dtype not in (ElemType.F32, ElemType.BF16, ElemType.F16):
         raise ServerError(N.E_UNSUPPORTED, f"{what}: input must be f32, bf16 or f16")

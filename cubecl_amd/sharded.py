@@ -141,6 +141,18 @@ class TorchExchange(Exchange):
         self._dist.barrier()
 
 
+def _checked_ids(device_ids, rank: int):
+    """The device list of a communicator as the library will see it: comm_init defines a rank as the position in the SORTED
+    list (crates/cubecl-cuda/src/compute/server.rs:669-703), so an unsorted list with an explicit rank would silently talk
+    to the wrong peers."""
+    ids = list(device_ids)
+    if ids != sorted(ids):
+        raise ValueError(f"device_ids must be sorted (rank = position in the sorted list): {ids}")
+    if not 0 <= rank < len(ids):
+        raise ValueError(f"rank {rank} outside the {len(ids)} devices of the communicator")
+    return ids
+
+
 class RcclExchange(Exchange):
     """RCCL over xGMI through the C ABI (`mi355_all_reduce` / `mi355_all_gather`), i.e. the
     ServerCommunication operations of the reference on device buffers.  `client.comm_init` must
@@ -148,7 +160,7 @@ class RcclExchange(Exchange):
 
     def __init__(self, client, device_ids, rank: int):
         from .runtime import ElemType, ReduceOperation
-        self._c, self._ids = client, list(device_ids)
+        self._c, self._ids = client, _checked_ids(device_ids, rank)
         self._ElemType, self._Sum = ElemType, ReduceOperation.Sum
         self.rank, self.world = rank, len(self._ids)
         self._buf = client.empty(64 + 16 * self.world)
@@ -185,18 +197,33 @@ class RcclExchange(Exchange):
     def barrier(self) -> None:
         self._c.sync()
 
-    def exchange_on_device(self, part, rec, index_base, out_value, out_index) -> None:
-        """The whole exchange step without a host round trip (what the timed multi-GPU job runs): `part` (one f32 on the
-        device) is all-reduced in place, `rec` (16 bytes: {f32 max, u32 unused, u64 local index}, where the fused local
-        pass wrote them) is all-gathered, and after the comm -> compute fence a 64-lane kernel folds the records with the
-        single-GPU argmax rule.  Afterwards the global sum, maximum and its global index are in device memory on EVERY
-        rank, ordered on the compute stream like any other kernel output."""
+    def exchange_on_device(self, rec, index_base, out_sum, out_value, out_index, mode: str = "gather") -> None:
+        """The whole exchange step without a host round trip (what the timed multi-GPU job runs).  `rec` is the 16-byte
+        record the fused local pass wrote: {f32 max, f32 partial sum, u64 local index} (`mi355_sum_argmax_f32` with
+        out_val = rec, out_sum = rec + 4, out_idx = rec + 8).
+
+        mode "gather" (default since round 5): ONE collective -- `rec` is all-gathered, and behind the comm -> compute fence a
+        64-lane kernel adds the partial sums in rank order and folds the argmax candidates with the single-GPU rule
+        (`mi355_sum_argmax_combine_f32`): the same bits on every rank, and one RCCL launch latency instead of two.
+        mode "all_reduce": the reference's shape (`ServerCommunication::all_reduce`, crates/cubecl-cuda/src/compute/
+        server.rs:705-780) -- the partial sum is all-reduced (Sum) into `out_sum`, the record all-gathered for the argmax.
+
+        Afterwards the global sum, maximum and its global index are in device memory on EVERY rank, ordered on the compute
+        stream like any other kernel output."""
         from . import ops
         gathered = self._buf.offset_start_by(64)
-        self._c.all_reduce(part, part, self._ElemType.F32, self._ids, self._Sum)
-        self._c.all_gather(rec, gathered, self._ElemType.U64, self._ids)
-        self._c.sync_collective()
-        ops.argmax_combine(self._c, gathered, self.world, index_base, out_value, out_index)
+        if mode == "gather":
+            self._c.all_gather(rec, gathered, self._ElemType.U64, self._ids)
+            self._c.sync_collective()
+            ops.sum_argmax_combine(self._c, gathered, self.world, index_base, out_sum, out_value, out_index)
+        elif mode == "all_reduce":
+            part = rec.offset_start_by(4).offset_end_by(rec.size_in_used() - 8)      # the record's second word
+            self._c.all_reduce(part, out_sum, self._ElemType.F32, self._ids, self._Sum)
+            self._c.all_gather(rec, gathered, self._ElemType.U64, self._ids)
+            self._c.sync_collective()
+            ops.argmax_combine(self._c, gathered, self.world, index_base, out_value, out_index)
+        else:
+            raise ValueError(f"exchange_on_device: mode {mode!r} (gather or all_reduce)")
 
 
 class RcclJob:
@@ -213,7 +240,7 @@ class RcclJob:
 
     def __init__(self, client, device_ids, rank: int, store, key: str = KEY):
         from .runtime import ElemType, ReduceOperation
-        self._c, self._ids = client, list(device_ids)
+        self._c, self._ids = client, _checked_ids(device_ids, rank)
         self._E, self._R = ElemType, ReduceOperation
         self.rank, self.world = rank, len(self._ids)
         if rank == 0:
@@ -221,6 +248,7 @@ class RcclJob:
         uid = bytes(store.get(key))
         client.comm_init(self._ids, uid, rank=rank)
         self._buf = client.empty(256)
+        client.write(self._buf, np.zeros(256, dtype=np.uint8))      # the barrier all-reduces its first word: never garbage / NaN
 
     def barrier(self) -> None:
         """Every rank's compute stream has drained and every rank has arrived: an all-reduce of one f32 behind client.sync()."""

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define MI355_ABI_VERSION 7
+#define MI355_ABI_VERSION 8
 
 /* ---- status codes (map onto LaunchError / IoError / ServerError, server/base.rs:177-332,
  *      :884-1019; the Rust shim performs the conversion) ------------------------------- */
@@ -496,6 +496,15 @@ int32_t mi355_sum_argmax_f32(mi355_ctx *ctx, mi355_stream stream, const float *i
  * `stream`: queue it after mi355_sync_collective and the result is in device memory on every rank, stream-ordered. */
 int32_t mi355_argmax_combine_f32(mi355_ctx *ctx, mi355_stream stream, const void *records, uint32_t count,
                                  const uint64_t *index_base, float *out_val, uint64_t *out_idx);
+/* The whole exchange of the sharded sum + argmax (config C4) behind ONE collective (ABI 8): the
+ * record's second word carries the shard's partial sum -- {f32 value, f32 partial sum, u64 LOCAL index} = the bytes
+ * mi355_sum_argmax_f32 writes with out_val = rec, out_sum = rec + 4, out_idx = rec + 8 -- so mi355_all_gather moves sums
+ * and argmax candidates together, and this launch folds both: out_sum = the partial sums added in RANK ORDER starting from
+ * +0.0 (a fixed tree: the same bits on every rank and every run, where the reference's all_reduce(Sum),
+ * crates/cubecl-cuda/src/compute/server.rs:705-780, leaves the order to the collective's algorithm), out_val / out_idx as
+ * mi355_argmax_combine_f32.  An empty shard passes index 2^64-1 and sum +0.0.  Any of the outputs may be NULL. */
+int32_t mi355_sum_argmax_combine_f32(mi355_ctx *ctx, mi355_stream stream, const void *records, uint32_t count,
+                                     const uint64_t *index_base, float *out_sum, float *out_val, uint64_t *out_idx);
 /* The same three reductions for f32, bf16 or f16 inputs (`dtype`): elements are widened to f32 on load (exact), sums and
  * comparisons run in f32, the outputs stay {f32 sum, f32 value of the winning element, u64 index}.  Same rules (lowest
  * index wins ties, NaN ranks highest, -0 == +0), same single-launch deterministic tree; 16-bit inputs move half the

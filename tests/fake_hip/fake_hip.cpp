@@ -337,7 +337,7 @@ TEST_API int32_t faketest_ticket_slot(mi355_ctx *ctx, void *stream, int64_t *out
 {
     unsigned int *t = nullptr;
     const int32_t rc = mi355::ticket_for_stream(ctx, stream ? static_cast<hipStream_t>(stream) : ctx->compute_stream, &t);
-    if (rc == MI355_OK) *out_slot = (reinterpret_cast<char *>(t) - static_cast<char *>(ctx->ticket_buf)) / 2048;
+    if (rc == MI355_OK) *out_slot = (reinterpret_cast<char *>(t) - static_cast<char *>(ctx->ticket_buf)) / 16384;
     return rc;
 }
 #endif

@@ -83,3 +83,20 @@ MI355_API int32_t mi355_argmax_combine_f32(mi355_ctx *ctx, mi355_stream, const v
     if (out_idx) *out_idx = (idx == ~0ull) ? 0 : idx;
     return MI355_OK;
 }
+
+// ... and of its SUMS form: the records' second words added in rank order from +0.0, in f32
+MI355_API int32_t mi355_sum_argmax_combine_f32(mi355_ctx *ctx, mi355_stream s, const void *records, uint32_t count, const uint64_t *index_base,
+                                               float *out_sum, float *out_val, uint64_t *out_idx)
+{
+    MI355_REQUIRE_CTX(ctx);
+    const uint32_t *rec = static_cast<const uint32_t *>(records);
+    float total = 0.f;
+    for (uint32_t r = 0; r < count; ++r) {
+        float p;
+        memcpy(&p, &rec[r * 4 + 1], 4);
+        total += p;
+    }
+    if (out_sum) *out_sum = total;
+    if (out_val || out_idx) return mi355_argmax_combine_f32(ctx, s, records, count, index_base, out_val, out_idx);
+    return MI355_OK;
+}

@@ -26,7 +26,10 @@ def test_plain_multi_gpu_form_spawns_one_rank_per_gpu_and_never_prints_a_one_ran
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-extras", "--no-cpu-baseline"])
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]
+    # two ranks: both said so -- or one did and the launcher's failure report names the other (it SIGTERMs the slower rank
+    # as soon as the first one exits: on a loaded box the second message may never be printed)
+    said = r.stderr.count("bench.py needs a GPU")
+    assert said >= 2 or (said == 1 and "local_rank: 0" in r.stderr and "local_rank: 1" in r.stderr), r.stderr[-2000:]
 
 
 def test_rank_count_of_the_launcher_wins_over_a_contradicting_flag():

@@ -177,6 +177,64 @@ def test_argmax_combine_on_the_device_follows_the_single_gpu_rule(client, oracle
         ops.argmax_combine(client, rec, 65, [0] * 65, val.handle, idx.handle)
 
 
+def test_sum_argmax_combine_folds_sums_in_rank_order_and_candidates_by_the_rule(client, oracle):
+    """The exchange of config C4 behind ONE collective (mi355_sum_argmax_combine_f32): records {f32 max, f32 partial sum,
+    u64 local index} as one all-gather delivers them -> global sum = the partial sums added in RANK order in f32 (bit-exact
+    against that loop on the host: the same bits on every rank, whatever RCCL would have chosen), argmax by the single-GPU
+    rule.  End to end: 8 real shards written by the fused pass straight into the record layout."""
+    from cubecl_amd import sharded
+    idx, val, tot = _scalar(client, ElemType.U64), _scalar(client, ElemType.F32), _scalar(client, ElemType.F32)
+    rng = np.random.default_rng(5)
+    for count in (1, 2, 3, 8, 37, 64):
+        rec = np.zeros((count, 4), dtype=np.uint32)
+        parts = (rng.standard_normal(count) * 10.0 ** rng.integers(-3, 6, count)).astype(np.float32)
+        vals = rng.standard_normal(count).astype(np.float32)
+        loc = rng.integers(0, 1 << 40, count, dtype=np.uint64)
+        if count > 2:
+            loc[1] = np.uint64(0xFFFFFFFFFFFFFFFF); parts[1] = 0.0           # an empty shard
+        rec[:, 0], rec[:, 1] = vals.view(np.uint32), parts.view(np.uint32)
+        rec[:, 2], rec[:, 3] = (loc & np.uint64(0xFFFFFFFF)).astype(np.uint32), (loc >> np.uint64(32)).astype(np.uint32)
+        bases = [int(b) for b in rng.integers(0, 1 << 41, count)]
+        ops.sum_argmax_combine(client, client.create_from_slice(rec.reshape(-1)), count, bases, tot.handle, val.handle, idx.handle)
+        ref = np.float32(0.0)
+        for p in parts:
+            ref = np.float32(ref + p)
+        assert tot.to_numpy(client)[0].view(np.uint32) == ref.view(np.uint32), (count, tot.to_numpy(client)[0], ref)
+        hv, hi = sharded.combine_argmax([(float(v), (b + int(i)) if i != np.uint64(0xFFFFFFFFFFFFFFFF) else -1) for v, i, b in zip(vals, loc, bases)])
+        assert int(idx.to_numpy(client)[0]) == hi and np.float32(val.to_numpy(client)[0]).view(np.uint32) == np.float32(hv).view(np.uint32)
+    # 8 shards of one array through the fused pass, each writing its 16-byte record {max, partial sum, local index}
+    n = 3_000_017
+    x = oracle.fill_uniform(n, 31, -1.0, 1.0)
+    x[77] = 9.0; x[2_000_000] = 9.0
+    t = TensorHandle.from_numpy(client, x)
+    rec = client.empty(16 * 8)
+    starts = []
+    for r in range(8):
+        start, count = sharded.shard_aligned_range(n, r, 8, 4)
+        starts.append(start)
+        view = TensorHandle.new_contiguous((count,), t.handle.offset_start_by(4 * start).offset_end_by(4 * (n - start - count)), ElemType.F32)
+        ov = TensorHandle.new_contiguous((1,), rec.offset_start_by(16 * r).offset_end_by(16 * (7 - r) + 12), ElemType.F32)
+        os_ = TensorHandle.new_contiguous((1,), rec.offset_start_by(16 * r + 4).offset_end_by(16 * (7 - r) + 8), ElemType.F32)
+        oi = TensorHandle.new_contiguous((1,), rec.offset_start_by(16 * r + 8).offset_end_by(16 * (7 - r)), ElemType.U64)
+        ops.sum_argmax(client, view, os_, oi, ov)
+    ops.sum_argmax_combine(client, rec, 8, starts, tot.handle, val.handle, idx.handle)
+    raw = np.frombuffer(client.read_one(rec), dtype=np.float32).reshape(8, 4)
+    ref = np.float32(0.0)
+    for p in raw[:, 1]:
+        ref = np.float32(ref + p)
+    exact = oracle.sum_f64(x)
+    got = tot.to_numpy(client)[0]
+    assert got.view(np.uint32) == ref.view(np.uint32) and abs(float(got) - exact) <= 1e-5 * float(np.abs(x.astype(np.float64)).sum())
+    assert int(idx.to_numpy(client)[0]) == oracle.argmax(x)[0] == 77 and float(val.to_numpy(client)[0]) == 9.0
+    # outputs are optional one by one, none at all is an error, and so are more than 64 shards
+    ops.sum_argmax_combine(client, rec, 8, starts, tot.handle, None, None)
+    ops.sum_argmax_combine(client, rec, 8, starts, None, val.handle, idx.handle)
+    with pytest.raises(ServerError):
+        ops.sum_argmax_combine(client, rec, 8, starts, None, None, None)
+    with pytest.raises(ServerError):
+        ops.sum_argmax_combine(client, rec, 65, [0] * 65, tot.handle, val.handle, idx.handle)
+
+
 def test_fused_sum_argmax_equals_separate(client, oracle):
     x = oracle.fill_uniform(5_000_011, 23, -1.0, 1.0)
     t = TensorHandle.from_numpy(client, x)

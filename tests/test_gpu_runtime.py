@@ -692,17 +692,23 @@ def test_all_reduce_and_to_client_across_devices_when_the_box_has_several(client
                 x[11] = 7.0                                       # ... and, tied, in the first: the lower global index wins
             t = TensorHandle.from_numpy(c, x)
             outs = c.empty(64)
-            part = TensorHandle.new_contiguous((1,), outs.offset_end_by(60), ElemType.F32)
-            val = TensorHandle.new_contiguous((1,), outs.offset_start_by(8).offset_end_by(52), ElemType.F32)
-            idx = TensorHandle.new_contiguous((1,), outs.offset_start_by(16).offset_end_by(40), ElemType.U64)
+            # the 16-byte record of the exchange: {f32 max, f32 partial sum, u64 local index}
+            val = TensorHandle.new_contiguous((1,), outs.offset_end_by(60), ElemType.F32)
+            part = TensorHandle.new_contiguous((1,), outs.offset_start_by(4).offset_end_by(56), ElemType.F32)
+            idx = TensorHandle.new_contiguous((1,), outs.offset_start_by(8).offset_end_by(48), ElemType.U64)
             from cubecl_amd import ops
             ops.sum_argmax(c, t, part, idx, val)
             ex = sharded.RcclExchange(c, ids, i)
             starts = [sharded.shard_aligned_range(n_total, r, ndev, 4)[0] for r in range(ndev)]
-            g_val, g_idx = outs.offset_start_by(32).offset_end_by(28), outs.offset_start_by(40).offset_end_by(16)
-            ex.exchange_on_device(part.handle, outs.offset_start_by(8).offset_end_by(40), starts, g_val, g_idx)
-            results[i] = (got, float(c.read_one(part.handle).view(np.float32)[0]), float(c.read_one(g_val).view(np.float32)[0]),
-                          int(c.read_one(g_idx).view(np.uint64)[0]), float(x.astype(np.float64).sum()))
+            g_sum, g_val, g_idx = outs.offset_start_by(32).offset_end_by(28), outs.offset_start_by(36).offset_end_by(24), outs.offset_start_by(40).offset_end_by(16)
+            g_sum2 = outs.offset_start_by(48).offset_end_by(12)
+            rec = outs.offset_end_by(48)
+            ex.exchange_on_device(rec, starts, g_sum, g_val, g_idx)                       # one all-gather, sums folded in rank order
+            one = (float(c.read_one(g_sum).view(np.float32)[0]), float(c.read_one(g_val).view(np.float32)[0]), int(c.read_one(g_idx).view(np.uint64)[0]))
+            ex.exchange_on_device(rec, starts, g_sum2, g_val, g_idx, mode="all_reduce")   # the reference's shape: all_reduce(Sum) + all-gather
+            two = (float(c.read_one(g_sum2).view(np.float32)[0]), float(c.read_one(g_val).view(np.float32)[0]), int(c.read_one(g_idx).view(np.uint64)[0]))
+            assert one[1:] == two[1:] and abs(one[0] - two[0]) <= 1e-6 * abs(one[0]), (one, two)
+            results[i] = (got, one[0], one[1], one[2], float(x.astype(np.float64).sum()))
         except BaseException as exc:  # noqa: BLE001
             errors.append(f"device {i}: {type(exc).__name__}: {exc}")
     threads = [threading.Thread(target=device_thread, args=(i,)) for i in range(ndev)]
