@@ -63,6 +63,7 @@ GEMM_ALGO_SKINNY = 8
 GEMM_ALGO_STREAM64 = 9
 GEMM_ALGO_LP_256X128 = 10
 GEMM_ALGO_NNROWS = 11
+GEMM_ALGO_LP_256X192 = 12
 UNIQUE_ID_BYTES = 128
 
 

@@ -49,7 +49,9 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
         // ... and against a ROW-MAJOR f32 weight the strip kernel's f32 form (gemm_nnrows.hip on v_mfma_f32_4x4x1: no transposition at
         // all), up to 16 rows (profiles/r04_f32_audit.txt, us, against the 128x128 tile kernel): 1 / 8 / 16 x 8192 x 8192 45.8 / 49.0 / 57.7
         // against 151-158, 16 x 4096 x 4096 19.8 / 46.3, 4 x 28672 x 4096 75 / 294, 1 x 2048 x 1024 10.6 / 23.1
-        if (!d.trans_a && !d.trans_b && d.m <= 16 && d.batch == 1 && d.n * d.k >= ((int64_t)1 << 16) && gemm_nnrows_supports(d, a, b, c))
+        // (`strip_kernel` false: the capture-window fallback of mi355_gemm -- the strip kernel's scratch / tickets cannot be created
+        // while a stream is capturing -- must reach the tile kernels here as it does for 16-bit operands)
+        if (strip_kernel && !d.trans_a && !d.trans_b && d.m <= 16 && d.batch == 1 && d.n * d.k >= ((int64_t)1 << 16) && gemm_nnrows_supports(d, a, b, c))
             return MI355_GEMM_ALGO_NNROWS;
         // 256x256 tiles (one wave per SIMD) when they give (nearly) every CU a tile; else 128x128
         if (gemm_lp256w4_supports(d, a, b, c) && ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch >= 192) return MI355_GEMM_ALGO_LP_256W4;
@@ -222,6 +224,15 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
         // 128^2 = 128 of 256^2).  Measured (tools/ab_algos.py): 96-128 tiles a tie, 144-160 tiles +45...55 % for the
         // 256x256 kernel even though it leaves 40 % of the CUs idle, 64-81 tiles +7...30 % for the 128x128 kernel.
         const int64_t tiles256 = ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch;
+        // Round 5: one round of 256x256 tiles that leaves CUs idle, and a round of 256 x 192 tiles (the same kernel, NJ = 3) that
+        // fills more of them.  A K-tile of the narrower tile costs 0.86-0.90 of the square one's (12 MFMAs per k-step against 16 on
+        // the same A fragments), so it pays exactly when it stays ONE round (profiles/r05_tile_256x192_ab.txt, cold, TFLOP/s,
+        // 256x256 / 256x192): 3072^3 917 / 1072, 3072 x 3072 x 8192 1052 / 1168, 4096 x 3072 x 4096 1194 / 1299, 3328^2 x 4096 1157 / 1246;
+        // two rounds lose: 3584^3 1146 / 788, 3072 x 4096 x 4096 1194 / 812, 4096^3 1313 / 979.
+        if (big4 && tiles256 > 128 && tiles256 < 256 && d.trans_b && gemm_lp256x192_supports(d, a, b, c)) {
+            const int64_t tiles192 = ((d.m + 255) / 256) * ((d.n + 191) / 192) * d.batch;
+            if (tiles192 <= 256 && tiles192 > tiles256) return MI355_GEMM_ALGO_LP_256X192;
+        }
         if (tiles256 > 128 || !mid) return big4 ? MI355_GEMM_ALGO_LP_256W4 : MI355_GEMM_ALGO_LP_256;
     }
     if (mid) return MI355_GEMM_ALGO_LP_128;
@@ -394,9 +405,9 @@ bool prefers_dripped_stores(const mi355_gemm_desc &d, const void *a, const void 
     return gemm_lp256q_supports(d, a, b, c) && (nk >= 16 || (nk >= 6 && nk <= 8));
 }
 
-int32_t select_auto(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
+int32_t select_auto(const mi355_gemm_desc &d, const void *a, const void *b, const void *c, bool strip_kernel = true)
 {
-    const int32_t algo = select(d, a, b, c);
+    const int32_t algo = select(d, a, b, c, strip_kernel);
     if (algo != MI355_GEMM_ALGO_LP_256W4 || !prefers_persistent(d, a, b, c)) return algo;
     return prefers_dripped_stores(d, a, b, c) ? MI355_GEMM_ALGO_LP_256Q : MI355_GEMM_ALGO_LP_256P;
 }
@@ -453,7 +464,19 @@ MI355_API int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_ge
     }
     // the strip kernel needs scratch + ticket words that cannot be created inside a capture window: AUTO then takes what it took
     // before that kernel existed (as the split-K paths fall back to their unsplit forms)
-    if (d.algo == MI355_GEMM_ALGO_AUTO && algo == MI355_GEMM_ALGO_NNROWS && !gemm_nnrows_ready(ctx, s, d)) algo = select(d, a, b, c, false);
+    // -- through the same AUTO pipeline (persistent-kernel promotion; GENERIC = "re-lay out, then select again"), so that a
+    // captured graph replays the kernel AUTO would have taken, not the scalar correctness net
+    if (d.algo == MI355_GEMM_ALGO_AUTO && algo == MI355_GEMM_ALGO_NNROWS && !gemm_nnrows_ready(ctx, s, d)) {
+        algo = select_auto(d, a, b, c, false);
+        if (algo == MI355_GEMM_ALGO_GENERIC) {
+            mi355_gemm_desc nd;
+            const void *na, *nb;
+            if (relayout_for_mfma(ctx, s, d, a, b, c, nd, na, nb) == MI355_OK) {
+                d = nd; a = na; b = nb;
+                algo = select_auto(d, a, b, c, false);
+            }
+        }
+    }
     if (d.algo == MI355_GEMM_ALGO_AUTO && algo == MI355_GEMM_ALGO_LP_256W4) {
         tail_plan tp;
         if (plan_tail_split(d, tp) && run_tail_split(ctx, s, d, a, b, c, tp) == MI355_OK) return MI355_OK;
@@ -470,6 +493,7 @@ MI355_API int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_ge
     case MI355_GEMM_ALGO_STREAM64: return launch_gemm_stream64(ctx, s, d, a, b, c);
     case MI355_GEMM_ALGO_LP_256X128: return launch_gemm_lp256x128(ctx, s, d, a, b, c);
     case MI355_GEMM_ALGO_NNROWS: return launch_gemm_nnrows(ctx, s, d, a, b, c);
+    case MI355_GEMM_ALGO_LP_256X192: return launch_gemm_lp256x192(ctx, s, d, a, b, c);
     default: return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_gemm: unknown algo %d", algo);
     }
 }

@@ -129,6 +129,8 @@ bool gemm_lp256p_supports(const mi355_gemm_desc &d, const void *a, const void *b
 int32_t launch_gemm_lp256q(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 bool gemm_lp256q_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 bool gemm_lp256w4_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
+int32_t launch_gemm_lp256x192(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);   // gemm_lp256w4.hip, NJ = 3
+bool gemm_lp256x192_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 int32_t launch_gemm_skinny(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 bool gemm_skinny_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 int32_t launch_gemm_nnrows(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
@@ -141,7 +143,7 @@ bool gemm_lp256w4_mx_supports(const mi355_gemm_scaled_desc &d, const void *a, co
 int32_t launch_gemm_lp256w4_mx(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_scaled_desc &d, const void *a, const void *sa_t,
                                int64_t stride_sa_t, const void *b, const void *sb_t, int64_t stride_sb_t, void *c);
 // library-owned per-stream scratch + operand re-layout (gemm_relayout.hip)
-enum { SCRATCH_SPLITK = 0, SCRATCH_RELAYOUT_A = 1, SCRATCH_RELAYOUT_B = 2, SCRATCH_SCALE_A = 3, SCRATCH_SCALE_B = 4, SCRATCH_PRODUCT = 5 };   // (6: reduce.hip's axis partials, 7: gemm_nnrows.hip's K-slice partials)
+enum { SCRATCH_SPLITK = 0, SCRATCH_RELAYOUT_A = 1, SCRATCH_RELAYOUT_B = 2, SCRATCH_SCALE_A = 3, SCRATCH_SCALE_B = 4, SCRATCH_PRODUCT = 5 };   // (6: reduce.hip's axis partials, 7: gemm_nnrows.hip's K-slice partials, 8: gemm_stream64.hip's)
 int32_t scratch_get(mi355_ctx *ctx, hipStream_t s, int kind, size_t bytes, void **out);
 void launch_transpose(hipStream_t s, const void *src, void *dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst,
                       int64_t batch, int64_t stride_src, int64_t stride_dst, int esz);

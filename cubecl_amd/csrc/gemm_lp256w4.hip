@@ -196,10 +196,17 @@ __device__ __forceinline__ void scale_ld32(uint32_t &dst, const void *ubase, uin
     asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(ubase), "n"(imm) : "memory");
 }
 
-template <int DT, int DT_C, bool BNN = false, int DTB = DT, bool MX = false, bool ATN = false>
+// NJ (round 5): 32-column fragments per wave -- 4 = the 256 x 256 tile; 3 = a 256 x 192 tile (each wave 128 x 96, 12 MFMAs per
+// k-step, 192 accumulators) for grids that leave CUs idle with the square tile (3072^3: 144 tiles of 256 x 256 on 256 CUs, 192 of
+// 256 x 192).  Same ring, same schedule: a B unit is 24 KiB in its 32 KiB slot (6 DMA pieces per wave instead of 8), the reads,
+// MFMAs and pieces of column fragment 3 are simply not emitted.  Plain [N][K] 16-bit operands only.
+template <int DT, int DT_C, bool BNN = false, int DTB = DT, bool MX = false, bool ATN = false, int NJ = 4>
 __global__ void __launch_bounds__(256)
 gemm_lp256w4_kernel(gemm_args g)
 {
+    static_assert(NJ == 4 || (NJ == 3 && !BNN && !MX && !ATN && (DT == MI355_DTYPE_BF16 || DT == MI355_DTYPE_F16)), "256 x 192 tile: plain [N][K] 16-bit operands");
+    constexpr int BNT = NJ * 64;                        // tile columns: 256 or 192
+    constexpr int NPB = NJ * 2;                         // DMA pieces of a B unit per wave: 8 or 6
     static_assert(!BNN || DT == MI355_DTYPE_F32 || DT == MI355_DTYPE_BF16 || DT == MI355_DTYPE_F16, "row-major B: f32 and 16-bit operands");
     constexpr bool BNN16 = BNN && (DT == MI355_DTYPE_BF16 || DT == MI355_DTYPE_F16);
     // ATN (late round 3): A stored [K][M] together with a row-major B (lhs^T . grad_out) -- the A tile of a K-tile is 64 k-rows x 256 m,
@@ -218,7 +225,7 @@ gemm_lp256w4_kernel(gemm_args g)
 
     uint32_t tm, tn, batch_u;
     batched_tile_coords(g.tiles_m, g.tiles_n, g.group_m, tm, tn, batch_u);      // XCD remap over the (batch, tile) sequence
-    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BNT;
     const int64_t batch = batch_u;
     constexpr int ESZ = lp<DT>::ESZ;
     constexpr bool F8 = DT == MI355_DTYPE_F8E4M3 || DT == MI355_DTYPE_F8E5M2;
@@ -248,7 +255,9 @@ gemm_lp256w4_kernel(gemm_args g)
         const int r = wave * 64 + j * 8 + sub;                            // tile row of this lane's 16 bytes
         const int q = c8 ^ ((r >> 1) & 7);
         voff_a[j] = (uint32_t)(min((int64_t)r, g.m - 1 - m0) * g.lda * ESZ + q * 16);
-        voff_b[j] = (uint32_t)(min((int64_t)r, g.n - 1 - n0) * g.ldb * ESZ + q * 16);
+        const int rb = wave * (BNT / 4) + j * 8 + sub;                    // (the B tile has BNT rows: NPB pieces per wave)
+        const int qb = c8 ^ ((rb >> 1) & 7);
+        voff_b[j] = (uint32_t)(min((int64_t)rb, g.n - 1 - n0) * g.ldb * ESZ + qb * 16);
     }
     // BNN, f32: piece j of this wave is k-row wave*8 + j of the K-tile, 256 n-values = 64 lanes x 16 B
     // BNN, 16-bit: piece p = wave*8 + j holds blocks (a = p/2, b = 4(p%2) .. +3): lane -> block b = 4(p%2) + lane/16, row
@@ -273,6 +282,7 @@ gemm_lp256w4_kernel(gemm_args g)
         }
     }
     const int dst_piece = wave * 8 * 1024;                            // + j*1024 within the slot
+    constexpr int DST_PIECE_B_STEP = (NPB - 8) * 1024;                // B units of the 192-column tile: wave * NPB pieces in
 
     // ---- fragment read offsets: row*128 + ((2s+h) ^ f) * 16, f = (row>>1)&7 = (l31>>1)&7 for every tile row
     const int f = (l31 >> 1) & 7;
@@ -282,13 +292,13 @@ gemm_lp256w4_kernel(gemm_args g)
     const int rowoff_a = ATN ? wm * 4 * 256 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8 : (wm * 128 + l31) * ROW_BYTES;
     // (16-bit row-major B: block b = 4 wn + j of the lane-half's block row, + row (lane%16)/4, + 16-lane group, + 8 B per lane)
     const int rowoff_b = BNN16 ? wn * 4 * 256 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8
-                         : BNN ? (wn * 128 + l31) * 4 : (wn * 128 + l31) * ROW_BYTES;
+                         : BNN ? (wn * 128 + l31) * 4 : (wn * (NJ * 32) + l31) * ROW_BYTES;
 
-    f32x16 acc[4][4];
+    f32x16 acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -375,7 +385,7 @@ gemm_lp256w4_kernel(gemm_args g)
         } else {
             if (R == 0) fb[BUF][0] = *reinterpret_cast<const frag *>(pb);
             else if (R <= 4) fa[BUF][R - 1] = *reinterpret_cast<const frag *>(pa + (R - 1) * 32 * ROW_BYTES);
-            else fb[BUF][R - 4] = *reinterpret_cast<const frag *>(pb + (R - 4) * 32 * ROW_BYTES);
+            else if (R - 4 < NJ) fb[BUF][R - 4] = *reinterpret_cast<const frag *>(pb + (R - 4) * 32 * ROW_BYTES);
         }
     };
     auto dma_one = [&](auto is_b, auto jj, int64_t koff, char *base) {
@@ -387,12 +397,14 @@ gemm_lp256w4_kernel(gemm_args g)
         } else if constexpr (ATN && !decltype(is_b)::value) {
             glds16_s<J * 1024>(ubase_atn + koff * g.lda, voff_atn[J], lds_addr_of(base));
         } else {
+            if constexpr (decltype(is_b)::value && J >= NPB) return;          // the 192-column tile: six pieces of B per wave
             glds16_s<J * 1024>((decltype(is_b)::value ? ubase_b : ubase_a) + koff, decltype(is_b)::value ? voff_b[J] : voff_a[J],
-                               lds_addr_of(base));
+                               lds_addr_of(base) + (decltype(is_b)::value ? (uint32_t)(wave * DST_PIECE_B_STEP) : 0u));
         }
     };
     auto mfma_one = [&](auto buf, auto idx, auto step) {
         constexpr int BUF = decltype(buf)::value, I = decltype(idx)::value & 3, J = decltype(idx)::value >> 2;
+        if constexpr (DT != MI355_DTYPE_F32 && J >= NJ) return;               // (f32 re-indexes idx; it only exists with NJ = 4)
         if constexpr (MX) {
             // first MFMA operand = B fragment (its format in cbsz, its scale first), second = A fragment
             acc[I][J] = mfma_mx<mx_fmt<DTB>::value, mx_fmt<DT>::value, decltype(step)::value>(fb[BUF][J], fa[BUF][I], acc[I][J],
@@ -461,7 +473,7 @@ gemm_lp256w4_kernel(gemm_args g)
         W4_PRO(0, k0, 0) W4_PRO(1, k0, 1) W4_PRO(0, k1, 2) W4_PRO(1, k1, 3)
 #undef W4_PRO
     }
-    WAIT_VMCNT(16);                      // units 0, 1 landed (this wave's share)
+    if constexpr (NJ == 4) WAIT_VMCNT(16); else WAIT_VMCNT(14);   // units 0, 1 landed (this wave's share): units 2, 3 = 8 + NPB pieces may fly
     W4_TAKE_SCALES(16)                   // (older than every DMA: landed too)
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -633,18 +645,20 @@ gemm_lp256w4_kernel(gemm_args g)
         char *stage = smem + wave * ((STAGE + 1023) & ~1023);
         char *wr = stage + l31 * RS + 4 * h * CSZ;
         const char *rd = stage + (lane / LPR) * RS + (lane % LPR) * 16;
-        char *crow = C + (cbase + (m0 + wm * 128 + lane / LPR) * g.ldc + n0 + wn * 128) * CSZ + (lane % LPR) * 16;
+        char *crow = C + (cbase + (m0 + wm * 128 + lane / LPR) * g.ldc + n0 + wn * (NJ * 32)) * CSZ + (lane % LPR) * 16;
         const int64_t cstep = (int64_t)RPI * g.ldc * CSZ;
         // edge tiles: rows >= M and columns >= N are not stored (a 16-byte piece straddling N is written element-wise)
         constexpr int EPP = 16 / CSZ;                                     // elements per 16-byte piece
         const int64_t row0 = m0 + wm * 128 + lane / LPR;                  // + i*32 + it*RPI
-        const int64_t col0 = n0 + wn * 128 + (lane % LPR) * EPP;
-        const int ncols = (int)max((int64_t)0, min((int64_t)EPP, g.n - col0));   // valid elements of my piece
+        const int64_t col0 = n0 + wn * (NJ * 32) + (lane % LPR) * EPP;
+        // (the 192-column tile: a wave's rows are NJ * 32 columns wide -- the lanes of a row beyond that have nothing to store)
+        const bool lane_live = NJ == 4 || (int)(lane % LPR) * EPP < NJ * 32;
+        const int ncols = lane_live ? (int)max((int64_t)0, min((int64_t)EPP, g.n - col0)) : 0;   // valid elements of my piece
         // C rows that do not start on 16-byte boundaries (N = 50257 bf16 logits, a view at an odd column): every piece goes
         // the element-wise way of the edge tiles -- eight 2-byte stores per lane instead of one 16-byte store, which the L2
         // merges into the same lines (8191 x 8191 x 8192: see profiles/r04_ragged_probe.txt).
         const bool cvec = ((((uint64_t)g.ldc * CSZ) | ((uint64_t)g.stride_c * CSZ) | reinterpret_cast<uintptr_t>(g.c)) & 15u) == 0;
-        const bool interior = cvec && (m0 + BM <= g.m) && (n0 + BN <= g.n);   // wave-uniform fast path
+        const bool interior = cvec && (m0 + BM <= g.m) && (n0 + BNT <= g.n);   // wave-uniform fast path
         // D = A * B + c_in (f32 C only, the C operand of cmma::execute): the 32 / RPI pieces of c_in that this lane will
         // add in block i are fetched before the block's accumulators are staged, so one memory latency per block hides
         // behind the LDS transposition.  c_in has C's layout and may be C itself.
@@ -659,7 +673,7 @@ gemm_lp256w4_kernel(gemm_args g)
                     const char *csrc = cin + cin_off + (int64_t)i * 32 * g.ldc * CSZ;
 #pragma unroll
                     for (int it = 0; it < 32 / RPI; ++it) {
-                        if (interior || (cvec && row0 + i * 32 + it * RPI < g.m && ncols == EPP))
+                        if ((interior && lane_live) || (cvec && row0 + i * 32 + it * RPI < g.m && ncols == EPP))
                             pre[it] = *reinterpret_cast<const f32x4 *>(csrc + it * cstep);
                         else
                             pre[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -667,7 +681,7 @@ gemm_lp256w4_kernel(gemm_args g)
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     char *d = wr + (j * 32 + 8 * q) * CSZ;
@@ -689,6 +703,7 @@ gemm_lp256w4_kernel(gemm_args g)
 #pragma unroll
             for (int it = 0; it < 32 / RPI; ++it) {
                 u32x4 v = *reinterpret_cast<const u32x4 *>(rd + it * RPI * RS);
+                if (NJ != 4 && !lane_live) continue;
                 if (!interior) {
                     if (row0 + i * 32 + it * RPI >= g.m || ncols <= 0) continue;
                     if (ncols < EPP || !cvec) {
@@ -727,11 +742,11 @@ gemm_lp256w4_kernel(gemm_args g)
 #endif
 }
 
-template <int DT, int DT_C, bool BNN = false, int DTB = DT, bool MX = false, bool ATN = false>
+template <int DT, int DT_C, bool BNN = false, int DTB = DT, bool MX = false, bool ATN = false, int NJ = 4>
 void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch)
 {
-    lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_lp256w4_kernel<DT, DT_C, BNN, DTB, MX, ATN>), LDS_BYTES);
-    hipLaunchKernelGGL((gemm_lp256w4_kernel<DT, DT_C, BNN, DTB, MX, ATN>), dim3(g.tiles_m * g.tiles_n, batch), dim3(256), LDS_BYTES, s, g);
+    lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_lp256w4_kernel<DT, DT_C, BNN, DTB, MX, ATN, NJ>), LDS_BYTES);
+    hipLaunchKernelGGL((gemm_lp256w4_kernel<DT, DT_C, BNN, DTB, MX, ATN, NJ>), dim3(g.tiles_m * g.tiles_n, batch), dim3(256), LDS_BYTES, s, g);
 }
 
 }  // namespace
@@ -826,6 +841,39 @@ int32_t launch_gemm_lp256w4(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc
         }
     }
     check_launch(ctx, "mi355_gemm(lp256w4)");
+    return MI355_OK;
+}
+
+// ---- the 256 x 192 tile (NJ = 3): [N][K] 16-bit operands ---------------------------------------------------------------------
+bool gemm_lp256x192_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
+{
+    if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16) return false;
+    if (d.trans_a || !d.trans_b) return false;
+    return gemm_lp256w4_supports(d, a, b, c);
+}
+
+int32_t launch_gemm_lp256x192(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c)
+{
+    if (!gemm_lp256x192_supports(d, a, b, c))
+        return fail(ctx, MI355_E_UNSUPPORTED, "lp256x192 GEMM: shape/layout not supported by this kernel");
+    gemm_args g{};
+    g.a = a; g.b = b; g.c = c;
+    g.m = d.m; g.n = d.n; g.k = d.k;
+    g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc;
+    g.stride_a = d.stride_a; g.stride_b = d.stride_b; g.stride_c = d.stride_c;
+    g.tiles_m = (uint32_t)((d.m + BM - 1) / BM);
+    g.tiles_n = (uint32_t)((d.n + 191) / 192);
+    g.group_m = W4_GROUP_M;
+    const uint32_t batch = (uint32_t)d.batch;
+    constexpr int BF = MI355_DTYPE_BF16, HF = MI355_DTYPE_F16, CF = MI355_DTYPE_F32;
+    if (d.dtype_ab == BF) {
+        if (d.dtype_c == CF) launch<BF, CF, false, BF, false, false, 3>(ctx, s, g, batch);
+        else launch<BF, BF, false, BF, false, false, 3>(ctx, s, g, batch);
+    } else {
+        if (d.dtype_c == CF) launch<HF, CF, false, HF, false, false, 3>(ctx, s, g, batch);
+        else launch<HF, HF, false, HF, false, false, 3>(ctx, s, g, batch);
+    }
+    check_launch(ctx, "mi355_gemm(lp256x192)");
     return MI355_OK;
 }
 

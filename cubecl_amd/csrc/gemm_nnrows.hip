@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256) gemm_nnrows_kernel(const nn_args g)
     const int64_t ldb2 = g.ldb * EB;                                       // bytes per k-row
     const uint32_t voff_lane = (uint32_t)(((int64_t)(w * Q + q) * 4 * g.ldb + (col < g.n ? p * EPV : 0)) * EB);
     const uint32_t voff_step = (uint32_t)((int64_t)RI * ldb2);
-    const ET *dummy = A + (lane & 3) * EPV;                           // always-resident 16 bytes (x staging: loads that have nothing to fetch)
+    const ET *dummy = A;                                              // always-resident 16 bytes (K >= EPV; x staging: loads that have nothing to fetch)
 #ifdef NNR_ASM_LOADS      // dev: loads and waits by hand (see the note above: unsafe, kept for the record)
 #define NNR_LOAD(dst, voff, sbase) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory")
 #define NNR_WAIT(n, u) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(v[u][0]), "+v"(v[u][1]), "+v"(v[u][2]), "+v"(v[u][3])::"memory")

@@ -27,6 +27,7 @@
 // 1 MiB; its stores do not matter).  Accumulation order differs from the other kernels (k-steps interleaved over four
 // accumulators): within the parity tolerance, not bit-identical to them.
 #include <algorithm>
+#include <cstdlib>
 
 #include "gemm_common.hpp"
 
@@ -68,6 +69,12 @@ struct stream_args {
     int32_t small_rows, big_rows, k;
     int32_t dtype_c;
     int32_t stream_nt;       // the streamed operand is larger than the Infinity Cache could keep: non-temporal LDS-DMA pieces
+    // K slices (round 5, NB > 1 forms): workgroup blockIdx.x = row block * slices + slice walks K-tiles [slice nk / slices,
+    // (slice + 1) nk / slices); its f32 block goes to `partial` [batch][row block][slice][small 32 MB][streamed 32 NB] and the last
+    // workgroup of a row block to arrive (ticket word per row block) adds the slices in slice order and writes the output
+    int32_t slices;
+    float *partial;
+    unsigned int *tickets;
 };
 
 #ifndef LDS_DMA_POLICY
@@ -142,29 +149,48 @@ template <int N> __device__ __forceinline__ void wait_vmcnt()
 #define S64_T2_SGA 3    // 40 x 16384 x 8192 56.9 -> 52.7, 64 x 32768 x 4096 78.8 -> 70.6, 64 x 28672 x 8192 and 64 x 14336 x 4096 ties (cold)
 #define S64_T2_SGB 4
 #endif
-template <int MB, bool TWO> struct ring_geom {
-    static constexpr int G = (TWO && MB == 1) ? S64_T1_G : TWO ? S64_T2_G : MB == 2 ? S64_O2_G : S64_O1_G;
-    static constexpr int SGA = (TWO && MB == 1) ? S64_T1_SGA : TWO ? S64_T2_SGA : (MB == 2 ? S64_O2_SGA : S64_O1_SGA);
-    static constexpr int SGB = (TWO && MB == 1) ? S64_T1_SGB : TWO ? S64_T2_SGB : (MB == 2 ? S64_O2_SGB : S64_O1_SGB);
-    static constexpr int LDS = SGA * G * MB * BLK + SGB * G * BLK;      // small ring + streamed ring: 128-144 KiB, or 64-72 KiB x 2
+#ifndef S64_W2_G
+#define S64_W2_G 2      // NB = 2 (64 streamed rows per workgroup, K in slices; one workgroup per CU), 33-64 small rows: (G, SGA, SGB):
+#define S64_W2_SGA 3    // per K-tile 8 KiB + 8 KiB -- six K-tiles of the small operand ahead, 96 KiB of the streamed one in the ring
+#define S64_W2_SGB 6
+#endif
+#ifndef S64_W1_G
+#define S64_W1_G 4      // NB = 2, up to 32 small rows: per K-tile 4 KiB + 8 KiB
+#define S64_W1_SGA 2
+#define S64_W1_SGB 3
+#endif
+template <int MB, bool TWO, int NB = 1> struct ring_geom {
+    static constexpr int G = NB == 2 ? (MB == 2 ? S64_W2_G : S64_W1_G) : (TWO && MB == 1) ? S64_T1_G : TWO ? S64_T2_G : MB == 2 ? S64_O2_G : S64_O1_G;
+    static constexpr int SGA = NB == 2 ? (MB == 2 ? S64_W2_SGA : S64_W1_SGA) : (TWO && MB == 1) ? S64_T1_SGA : TWO ? S64_T2_SGA : (MB == 2 ? S64_O2_SGA : S64_O1_SGA);
+    static constexpr int SGB = NB == 2 ? (MB == 2 ? S64_W2_SGB : S64_W1_SGB) : (TWO && MB == 1) ? S64_T1_SGB : TWO ? S64_T2_SGB : (MB == 2 ? S64_O2_SGB : S64_O1_SGB);
+    static constexpr int LDS = SGA * G * MB * BLK + SGB * G * NB * BLK;      // small ring + streamed ring: 128-144 KiB, or 64-72 KiB x 2
 };
 
 // MB: 32-row blocks of the small operand (1: up to 32 rows, 2: up to 64).
 // TWO: half-depth rings, two workgroups per CU -- for grids of more than one workgroup per CU, where a starting workgroup's
 // empty ring and a finishing one's drain overlap the neighbour's streaming (16 x 28672 x 8192: 107 -> 83.5 us); with one
 // workgroup per CU the deep rings win (64 x 8192 x 8192: 24.7 us against 33.9).
-template <int DT, int MB, bool TWO>
+// NB (round 5): 32-row blocks of the STREAMED operand per workgroup.  With NB = 2 a workgroup owns 64 streamed rows over HALF of K
+// (args.slices = 2): the small operand crosses the L2 -> LDS path half as often per streamed byte (at 64 x 8192 x 8192 each of
+// the 256 workgroups pulled the whole 1 MiB of it: 1 MiB + 0.5 MiB streamed per CU), and a K-tile's LDS stage holds as much of the
+// streamed operand as of the small one, so the ring keeps 80 KiB of it in flight where the NB = 1 form had 48 (measured bound of
+// that form: ~4.1 TB/s whatever the HBM side did, profiles/r03_stream64_cold_ablation.txt).  The price is the slices' meeting
+// in memory: f32 blocks + one ticket per row block, folded in slice order by the last workgroup to arrive (as gemm_nnrows.hip).
+template <int DT, int MB, bool TWO, int NB = 1>
 __global__ void __launch_bounds__(512 + 64 * NLB, TWO ? (NLB == 2 ? 5 : 6) : (NLB == 2 ? 2 : 3)) gemm_stream64_kernel(stream_args g)
 {
     // Two rings.  The streamed operand needs DEPTH: ~25 GB/s per CU x ~2.5 us of HBM latency under load = ~64 KiB in flight
     // (with both operands in one 12-16 slot ring only 40-48 KiB of it were, and the kernel sat at 4.5 TB/s).  The small
     // operand is L2-resident and needs only a few K-tiles of look-ahead.  They cannot share loader waves: `vmcnt` retires in
     // order, so a wave waiting for a near small-operand piece would also wait for every far streamed piece it issued before.
-    typedef ring_geom<MB, TWO> RG;
+    typedef ring_geom<MB, TWO, NB> RG;
     constexpr int G = RG::G, SGA = RG::SGA, SGB = RG::SGB;
     constexpr int SA = SGA * G, SB = SGB * G;
     constexpr int A_STAGE = MB * BLK;
+    constexpr int B_STAGE = NB * BLK;
     constexpr int B_RING = SA * A_STAGE;                  // byte offset of the streamed ring
+    constexpr int BNW = BN * NB;                          // streamed rows per workgroup
+    static_assert(NLB == 4 || NB == 1, "the NB > 1 forms are written for four streamed-loader waves");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     typedef typename lp<DT>::frag frag;
 
@@ -172,15 +198,19 @@ __global__ void __launch_bounds__(512 + 64 * NLB, TWO ? (NLB == 2 ? 5 : 6) : (NL
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0-3 multiply, 4-7 load the small operand, 8 .. 8 + NLB - 1 the streamed one
     const int w = wave_all & 3;
     const int h = lane >> 5, l31 = lane & 31;
-    const int64_t n0 = (int64_t)blockIdx.x * BN;
-    const int nk = g.k / 64;
+    const int slices = NB == 1 ? 1 : g.slices;
+    const int rb = NB == 1 ? (int)blockIdx.x : (int)(blockIdx.x / (uint32_t)slices), sl = NB == 1 ? 0 : (int)(blockIdx.x % (uint32_t)slices);
+    const int64_t n0 = (int64_t)rb * BNW;
+    const int nk_all = g.k / 64;
+    const int tile0 = NB == 1 ? 0 : (int)((int64_t)sl * nk_all / slices);                     // this slice's K-tiles: [tile0, tile0 + nk)
+    const int nk = NB == 1 ? nk_all : (int)((int64_t)(sl + 1) * nk_all / slices) - tile0;
     const int ng = (nk + G - 1) / G;
     // Workgroup j walks K starting at K-tile j mod nk and wraps.  Without it all 256 workgroups ask for the same 128-byte
     // column of their 32 rows at the same time: 8192 lines whose addresses differ only above bit 14 -- the same few HBM
     // channels -- and the kernel sat at 4.2 TB/s however deep the ring (with the streamed operand re-read from L2 instead:
     // 19.6 us, so everything but HBM fits in 60 % of the time).  Each output element still sums its K-tiles in one fixed order.
-    const int shift = S64_SHIFT ? (int)(blockIdx.x % (uint32_t)nk) : 0;
-    auto phys = [&](int t) { const int p = t + shift; return p >= nk ? p - nk : p; };
+    const int shift = S64_SHIFT ? (int)((uint32_t)rb % (uint32_t)nk) : 0;
+    auto phys = [&](int t) { const int p = t + shift; return tile0 + (p >= nk ? p - nk : p); };
 
     const char *small_ = static_cast<const char *>(g.small_) + (int64_t)blockIdx.y * g.stride_small * 2;
     const char *big = static_cast<const char *>(g.big) + (int64_t)blockIdx.y * g.stride_big * 2 + n0 * g.ld_big * 2;
@@ -190,10 +220,11 @@ __global__ void __launch_bounds__(512 + 64 * NLB, TWO ? (NLB == 2 ? 5 : 6) : (NL
     if (wave_all >= 8) {
         // ---- streamed operand: wave 8 fills rows 0-15, wave 9 rows 16-31 of every K-tile (two pieces each)
         const int half = wave_all - 8;       // (one of NLB loaders: rows half * 8 PPW ...)
-        uint32_t voff[PPW];
+        constexpr int PW = PPW * NB;         // pieces of a K-tile per loader wave
+        uint32_t voff[PW];
 #pragma unroll
-        for (int j = 0; j < PPW; ++j) {
-            const int r = (half * PPW + j) * 8 + (lane >> 3);
+        for (int j = 0; j < PW; ++j) {
+            const int r = (half * PW + j) * 8 + (lane >> 3);
             const int q = (lane & 7) ^ ((r >> 1) & 7);
             voff[j] = (uint32_t)(std::min<int64_t>(r, (int64_t)g.big_rows - n0 - 1) * g.ld_big * 2 + q * 16);   // rows past the edge re-read the last one
         }
@@ -202,9 +233,9 @@ __global__ void __launch_bounds__(512 + 64 * NLB, TWO ? (NLB == 2 ? 5 : 6) : (NL
             for (int u = 0; u < G; ++u) {
                 const int t = gi * G + u;
                 if (t < nk) {
-                    const uint32_t slot = lds_addr_of(smem + B_RING + (t % SB) * BLK + half * PPW * 1024);
+                    const uint32_t slot = lds_addr_of(smem + B_RING + (t % SB) * B_STAGE + half * PW * 1024);
 #pragma unroll
-                    for (int j = 0; j < PPW; ++j) {
+                    for (int j = 0; j < PW; ++j) {
                         const char *src = big + (int64_t)(S64_ABL == 2 ? (t & 7) : phys(t)) * ROW_BYTES;
                         if (g.stream_nt) glds16_s<true>(src, voff[j], slot + j * 1024);      // (wave-uniform branch)
                         else glds16_s<false>(src, voff[j], slot + j * 1024);
@@ -216,7 +247,7 @@ __global__ void __launch_bounds__(512 + 64 * NLB, TWO ? (NLB == 2 ? 5 : 6) : (NL
         for (int gi = 0; gi < ng; ++gi) {
             // group gi has landed when at most the pieces of the SGB - 2 groups issued after it are outstanding (full groups
             // when they all exist); in the tail simply wait for everything
-            if ((gi + SGB - 1) * G <= nk) wait_vmcnt<PPW * G * (SGB - 2)>();
+            if ((gi + SGB - 1) * G <= nk) wait_vmcnt<PW * G * (SGB - 2)>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();          // group gi is ready; everybody is done with group gi - 1
@@ -258,11 +289,13 @@ __global__ void __launch_bounds__(512 + 64 * NLB, TWO ? (NLB == 2 ? 5 : 6) : (NL
     }
 
     // ---- multiplying waves: wave w takes k-step w of every K-tile -------------------------------------------------------
-    f32x16 acc[MB];
+    f32x16 acc[NB][MB];
 #pragma unroll
-    for (int i = 0; i < MB; ++i)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][i][r] = 0.f;
     const int q = w * 2 + h;                                   // logical 16-byte chunk of my k-step for my lane half
     int off_s[MB];
 #pragma unroll
@@ -282,12 +315,13 @@ __global__ void __launch_bounds__(512 + 64 * NLB, TWO ? (NLB == 2 ? 5 : 6) : (NL
         constexpr bool WHOLE = decltype(whole_c)::value;
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        frag bfq[G], afq[G][MB];
+        frag bfq[G][NB], afq[G][MB];
 #pragma unroll
         for (int u = 0; u < G; ++u) {
             const int t = gi * G + u;
             if (WHOLE || t < nk) {
-                bfq[u] = *reinterpret_cast<const frag *>(smem + (t % SB) * BLK + off_b);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) bfq[u][nb] = *reinterpret_cast<const frag *>(smem + (t % SB) * B_STAGE + nb * BLK + off_b);
 #pragma unroll
                 for (int i = 0; i < MB; ++i) afq[u][i] = *reinterpret_cast<const frag *>(smem + (t % SA) * A_STAGE + off_s[i]);
             }
@@ -297,7 +331,9 @@ __global__ void __launch_bounds__(512 + 64 * NLB, TWO ? (NLB == 2 ? 5 : 6) : (NL
         for (int u = 0; u < G; ++u) {
             if (WHOLE || gi * G + u < nk) {
 #pragma unroll
-                for (int i = 0; i < MB; ++i) acc[i] = lp<DT>::mfma(bfq[u], afq[u][i], acc[i]);   // operands swapped: a lane owns 4 consecutive streamed columns per quad
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int i = 0; i < MB; ++i) acc[nb][i] = lp<DT>::mfma(bfq[u][nb], afq[u][i], acc[nb][i]);   // operands swapped: a lane owns 4 consecutive streamed columns per quad
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -309,27 +345,84 @@ __global__ void __launch_bounds__(512 + 64 * NLB, TWO ? (NLB == 2 ? 5 : 6) : (NL
 
     // ---- the four k-step partials meet in LDS (the ring is dead), added in wave order -----------------------------------
     __syncthreads();                                            // loaders have left; the four of us are done reading the ring
-    float *part = reinterpret_cast<float *>(smem);              // [wave][MB][row 32][col 32], 4 x MB x 4 KiB
+    float *part = reinterpret_cast<float *>(smem);              // [wave][NB][MB][row 32][col 32], 4 x NB x MB x 4 KiB
 #pragma unroll
-    for (int i = 0; i < MB; ++i)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd)
+        for (int i = 0; i < MB; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                part[((w * MB + i) * 32 + l31) * 32 + 8 * qd + 4 * h + r] = acc[i][4 * qd + r];   // lane (l31, h): row l31, cols 8 qd + 4 h + r
+            for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    part[(((w * NB + nb) * MB + i) * 32 + l31) * 32 + 8 * qd + 4 * h + r] = acc[nb][i][4 * qd + r];   // lane (l31, h): row l31, cols 8 qd + 4 h + r
     __syncthreads();
     char *out = static_cast<char *>(g.out);
-    for (int e = tid; e < MB * 32 * 32; e += 256) {      // tid < 256 here: the loader waves have left
-        const int i = e / 1024, row = (e >> 5) & 31, col = e & 31;
-        const int64_t sm = i * 32 + row, bg = n0 + col;
-        if (sm >= g.small_rows || bg >= g.big_rows) continue;
-        float v = part[((0 * MB + i) * 32 + row) * 32 + col];
+    auto wave_sum = [&](int blk, int row, int col) {             // the four k-step partials of one element, in wave order
+        float v = part[((0 * NB * MB + blk) * 32 + row) * 32 + col];
 #pragma unroll
-        for (int ww = 1; ww < 4; ++ww) v += part[((ww * MB + i) * 32 + row) * 32 + col];
+        for (int ww = 1; ww < 4; ++ww) v += part[((ww * NB * MB + blk) * 32 + row) * 32 + col];
+        return v;
+    };
+    auto store_out = [&](int64_t sm, int64_t bg, float v) {
         const int64_t o = (int64_t)blockIdx.y * g.stride_out + sm * g.out_stride_small + bg * g.out_stride_big;
         if (g.dtype_c == MI355_DTYPE_F32) reinterpret_cast<float *>(out)[o] = v;
         else if (g.dtype_c == MI355_DTYPE_BF16) reinterpret_cast<uint16_t *>(out)[o] = f32_to_bf16_rne(v);
         else reinterpret_cast<uint16_t *>(out)[o] = f32_to_f16_rne(v);
+    };
+    if (NB == 1 || slices == 1) {
+        for (int e = tid; e < NB * MB * 32 * 32; e += 256) {      // tid < 256 here: the loader waves have left
+            const int blk = e / 1024, nb = blk / MB, i = blk % MB, row = (e >> 5) & 31, col = e & 31;
+            const int64_t sm = i * 32 + row, bg = n0 + nb * 32 + col;
+            if (sm >= g.small_rows || bg >= g.big_rows) continue;
+            store_out(sm, bg, wave_sum(blk, row, col));
+        }
+        return;
+    }
+    if constexpr (NB > 1) {
+        // ---- K slices meet in memory: [batch][row block][slice][blk = nb * MB + i][row 32][col 32] f32 ---------------------------
+        // Hand-off as in reduce.hip / gemm_nnrows.hip: agent-scope 8-byte atomic stores (write-through), drained per wave, then the
+        // row block's ticket; agent-scope loads in the folding workgroup; no fences (a fence per workgroup = an L2 write-back).
+        typedef __attribute__((address_space(1))) unsigned long long gu64;
+        typedef __attribute__((address_space(1))) unsigned int gu32;
+        constexpr int BLOCK_F = NB * MB * 1024;                  // floats of one workgroup's block
+        const int64_t nblocks = (g.big_rows + BNW - 1) / BNW;
+        float *slab0 = g.partial + (((int64_t)blockIdx.y * nblocks + rb) * slices) * BLOCK_F;
+        gu64 *mine = (gu64 *)reinterpret_cast<unsigned long long *>(slab0 + (int64_t)sl * BLOCK_F);
+        for (int e2 = tid; e2 < BLOCK_F / 2; e2 += 256) {
+            const int e = e2 * 2, blk = e / 1024, row = (e >> 5) & 31, col = e & 31;
+            const float v0 = wave_sum(blk, row, col), v1 = wave_sum(blk, row, col + 1);
+            __hip_atomic_store(mine + e2, ((unsigned long long)__float_as_uint(v1) << 32) | __float_as_uint(v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my partials have left the wave ...
+        __syncthreads();                                          // ... every wave's have, before the ticket
+        __shared__ unsigned int is_last;
+        unsigned int *ticket = g.tickets + (int64_t)blockIdx.y * nblocks + rb;
+        if (tid == 0) is_last = __hip_atomic_fetch_add((gu32 *)ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)slices - 1u ? 1u : 0u;
+        __syncthreads();
+        if (!is_last) return;
+        // the last workgroup: every slice's block in slice order (its own comes back from L2), all loads of a pass in flight
+        gu64 *all = (gu64 *)reinterpret_cast<unsigned long long *>(slab0);
+        constexpr int PER = BLOCK_F / 2 / 256;                   // 8-byte pairs per thread: 8 (NB x MB = 4), 4 (= 2)
+        for (int p0 = 0; p0 < PER; p0 += 4) {
+            unsigned long long wv[4][4];                          // [pair][slice]: up to 4 slices
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+                for (int ss = 0; ss < 4; ++ss)
+                    wv[pp][ss] = __hip_atomic_load(all + (int64_t)(ss < slices ? ss : slices - 1) * (BLOCK_F / 2) + (p0 + pp) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+                for (int ss = 0; ss < 4; ++ss)
+                    if (ss < slices) { v0 += __uint_as_float((uint32_t)wv[pp][ss]); v1 += __uint_as_float((uint32_t)(wv[pp][ss] >> 32)); }
+                const int e = ((p0 + pp) * 256 + tid) * 2, blk = e / 1024, nb = blk / MB, i = blk % MB, row = (e >> 5) & 31, col = e & 31;
+                const int64_t sm = i * 32 + row, bg = n0 + nb * 32 + col;
+                if (sm < g.small_rows && bg < g.big_rows) store_out(sm, bg, v0);
+                if (sm < g.small_rows && bg + 1 < g.big_rows) store_out(sm, bg + 1, v1);
+            }
+        }
+        if (tid == 0) __hip_atomic_store((gu32 *)ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
     }
 }
 
@@ -341,9 +434,20 @@ void launch_form(mi355_ctx *ctx, hipStream_t s, const stream_args &g, uint32_t b
     hipLaunchKernelGGL((gemm_stream64_kernel<DT, MB, TWO>), dim3((uint32_t)((g.big_rows + BN - 1) / BN), batch), dim3(512 + 64 * NLB), LDS, s, g);
 }
 
+// the NB = 2 form: 64 streamed rows per workgroup, K in g.slices slices (one workgroup per CU: the deep rings)
+template <int DT, int MB>
+void launch_wide(mi355_ctx *ctx, hipStream_t s, const stream_args &g, uint32_t batch)
+{
+    constexpr int LDS = ring_geom<MB, false, 2>::LDS;
+    lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_stream64_kernel<DT, MB, false, 2>), LDS);
+    const uint32_t nblocks = (uint32_t)((g.big_rows + 2 * BN - 1) / (2 * BN));
+    hipLaunchKernelGGL((gemm_stream64_kernel<DT, MB, false, 2>), dim3(nblocks * (uint32_t)g.slices, batch), dim3(512 + 64 * NLB), LDS, s, g);
+}
+
 template <int DT, int MB>
 void launch_one(mi355_ctx *ctx, hipStream_t s, const stream_args &g, uint32_t batch)
 {
+    if (g.slices > 1) return launch_wide<DT, MB>(ctx, s, g, batch);
     const uint64_t wgs = (uint64_t)((g.big_rows + BN - 1) / BN) * batch;
     if (wgs > (uint64_t)ctx->props.num_streaming_multiprocessors) launch_form<DT, MB, true>(ctx, s, g, batch);
     else launch_form<DT, MB, false>(ctx, s, g, batch);
@@ -352,6 +456,28 @@ void launch_one(mi355_ctx *ctx, hipStream_t s, const stream_args &g, uint32_t ba
 }  // namespace
 
 namespace mi355 {
+
+constexpr int SCRATCH_STREAM64 = 8;     // library scratch kind: the K-slice blocks of the NB = 2 form (gemm_common.hpp lists the others)
+
+// The cut of a launch: 0 = the NB = 1 form (32 streamed rows per workgroup over the whole K), else the number of K slices of the
+// NB = 2 form (64 streamed rows per workgroup).  A pure function of the descriptor and the CU count.  Taken where the NB = 1 form
+// runs one workgroup per CU or less over a long K -- the grid whose small operand crosses the L2 -> LDS path once per workgroup
+// (profiles/r05_stream64_wide.txt).  MI355_S64_WIDE=0 / 1 (dev) forces the choice where the form is possible at all.
+int stream64_slices(const mi355_gemm_desc &d, int cus)
+{
+    const int64_t small_rows = std::min(d.m, d.n), big_rows = std::max(d.m, d.n), nk = d.k / 64;
+    const int64_t wgs1 = (big_rows + BN - 1) / BN * d.batch, nblocks = (big_rows + 2 * BN - 1) / (2 * BN);
+    const bool possible = big_rows >= 2 * BN && nk >= 4 && nblocks * d.batch <= 448;     // one ticket word per row block: 496 per stream
+    if (!possible) return 0;
+    static const int forced = [] { const char *e = getenv("MI355_S64_WIDE"); return e ? atoi(e) : -1; }();
+    if (forced == 0) return 0;
+    if (forced > 0) return forced >= 2 && forced <= 4 ? forced : 2;
+    // Measured (cold, us, NB = 1 / NB = 2 with two slices): 64 x 8192 x 8192 36.4 / 35.1, 8192 x 64 x 8192 36.2 / 34.9, 64 x 7168 x 8192
+    // 35.4 / 33.7, 64 x 8192 x 16384 58.9 / 50.4; not taken: 48 x 8192 x 8192 32.1 / 33.1, 40 rows 29.7 / 32.5, 64 x 8192 x 4096 23.2 / 23.5,
+    // up to 32 rows +3 us, four slices +6 us everywhere.  (The form was built on the reading that the small operand's trips through
+    // L2 -> LDS bound the 64-row case; halving them bought 4 % at K = 8192 -- that reading is wrong, see the profile note.)
+    return (small_rows >= 56 && wgs1 <= cus && wgs1 > cus / 2 && nk >= 128) ? 2 : 0;
+}
 
 // A [M][K], B [N][K] K-contiguous 16-bit, min(M, N) <= 64, K a multiple of 64, 16-byte aligned rows.
 bool gemm_stream64_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
@@ -392,6 +518,21 @@ int32_t launch_gemm_stream64(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_des
     g.stream_nt = (int64_t)g.big_rows * d.k * 2 * std::max<int64_t>(d.batch, 1) > (192ll << 20) ? 1 : 0;
     const bool two = g.small_rows > 32;
     const uint32_t batch = (uint32_t)d.batch;
+    // K slices (the NB = 2 form): scratch for the slices' f32 blocks + the stream's ticket words; inside a capture window that does
+    // not have them yet the launch falls back to the NB = 1 form, which needs neither
+    const int cus = ctx->props.num_streaming_multiprocessors > 0 ? ctx->props.num_streaming_multiprocessors : 256;
+    g.slices = stream64_slices(d, cus);
+    if (g.slices > 1) {
+        const int64_t nblocks = (g.big_rows + 2 * BN - 1) / (2 * BN);
+        const size_t bytes = (size_t)batch * nblocks * g.slices * 2 * (two ? 2 : 1) * 1024 * sizeof(float);
+        void *part = nullptr;
+        const bool can_create = !ctx->capturing || (ctx->ticket_buf && !ctx->tickets_dirty && ctx->scratch.count({s, SCRATCH_STREAM64}) &&
+                                                    ctx->scratch[{s, SCRATCH_STREAM64}].second >= bytes);
+        if (can_create && scratch_get(ctx, s, SCRATCH_STREAM64, bytes, &part) == MI355_OK && strip_tickets_for_stream(ctx, s, &g.tickets) == MI355_OK)
+            g.partial = static_cast<float *>(part);
+        else g.slices = 0;
+    }
+    if (g.slices <= 1) g.slices = 1;
     if (d.dtype_ab == MI355_DTYPE_BF16) {
         if (two) launch_one<MI355_DTYPE_BF16, 2>(ctx, s, g, batch);
         else launch_one<MI355_DTYPE_BF16, 1>(ctx, s, g, batch);
@@ -399,6 +540,7 @@ int32_t launch_gemm_stream64(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_des
         if (two) launch_one<MI355_DTYPE_F16, 2>(ctx, s, g, batch);
         else launch_one<MI355_DTYPE_F16, 1>(ctx, s, g, batch);
     }
+    if (g.slices > 1 && hipPeekAtLastError() != hipSuccess) strip_tickets_mark_dirty(ctx);   // a refused launch never resets its tickets
     check_launch(ctx, "mi355_gemm(stream64)");
     return MI355_OK;
 }

@@ -71,6 +71,12 @@ struct mi355_ctx {
     std::set<void *> capture_scratch;
     std::map<void *, int> scratch_refs;
     std::set<void *> scratch_retired;      // pinned scratch that scratch_get has replaced by a bigger buffer
+    // ... and so must the arrival-ticket slot a captured reduction / strip kernel counts on: a destroyed stream's slot goes back
+    // to ticket_free only when no live graph carries its address (a replay sharing the words with a new stream's launches would
+    // miscount arrivals): capture_tickets = slots handed out inside the open window, ticket_refs = slot -> live graphs carrying
+    // it, ticket_retired = slots of destroyed streams still pinned
+    std::set<uint32_t> capture_tickets, ticket_retired;
+    std::map<uint32_t, int> ticket_refs;
     // library-owned device scratch per (stream, kind): split-K slabs, re-laid-out GEMM operands
     std::map<std::pair<hipStream_t, int>, std::pair<void *, size_t>> scratch;
     mi355::memory_pool *pool = nullptr;    // caching allocator behind mi355_pool_* (pool.cpp)

@@ -411,7 +411,9 @@ MI355_API int32_t mi355_stream_destroy(mi355_ctx *ctx, mi355_stream stream)
     }
     const auto slot = ctx->ticket_slots.find(s);
     if (slot != ctx->ticket_slots.end()) {
-        ctx->ticket_free.push_back(slot->second);
+        const auto pin = ctx->ticket_refs.find(slot->second);
+        if ((pin != ctx->ticket_refs.end() && pin->second > 0) || ctx->capture_tickets.count(slot->second)) ctx->ticket_retired.insert(slot->second);
+        else ctx->ticket_free.push_back(slot->second);
         ctx->ticket_slots.erase(slot);
     }
     MI355_HIP(ctx, hipStreamDestroy(s));
@@ -848,6 +850,7 @@ int32_t ticket_for_stream(mi355_ctx *ctx, hipStream_t s, unsigned int **out)
         else return fail(ctx, MI355_E_UNSUPPORTED, "reductions were issued on more than %u live streams of one context", SLOTS);
         it = ctx->ticket_slots.emplace(s, slot).first;
     }
+    if (ctx->capturing) ctx->capture_tickets.insert(it->second);      // becomes a pin when the capture ends
     *out = reinterpret_cast<unsigned int *>(static_cast<char *>(ctx->ticket_buf) + (size_t)it->second * TICKET_SLOT_BYTES);
     return MI355_OK;
 }
@@ -888,6 +891,7 @@ struct mi355_graph {
     hipGraphExec_t exec;
     uint64_t id;                          // the capture window it came from: pins pool blocks under this id
     std::set<void *> scratch;             // library scratch its nodes carry
+    std::set<uint32_t> tickets;           // arrival-ticket slots its nodes carry
     std::set<hipStream_t> streams;        // streams it was replayed on (waited for before the executable dies)
 };
 
@@ -900,6 +904,7 @@ MI355_API int32_t mi355_graph_begin_capture(mi355_ctx *ctx, mi355_stream stream)
     ctx->capture_stream = stream_of(ctx, stream);
     ctx->capture_id = ctx->next_capture_id++;
     ctx->capture_scratch.clear();
+    ctx->capture_tickets.clear();
     return MI355_OK;
 }
 
@@ -921,6 +926,7 @@ MI355_API int32_t mi355_graph_end_capture(mi355_ctx *ctx, mi355_stream stream, m
         (void)hipGetLastError();
         pool_release_graph(ctx, id);          // nothing will ever replay: what the window pinned is free memory again
         ctx->capture_scratch.clear();
+        ctx->capture_tickets.clear();
         return fail(ctx, MI355_E_EXECUTION, "hipStreamEndCapture: %s (an operation in the window was not capturable: "
                     "run the sequence once before capturing so that library scratch exists)", hipGetErrorString(e));
     }
@@ -929,13 +935,16 @@ MI355_API int32_t mi355_graph_end_capture(mi355_ctx *ctx, mi355_stream stream, m
         hipGraphDestroy(g);
         pool_release_graph(ctx, id);
         ctx->capture_scratch.clear();
+        ctx->capture_tickets.clear();
         return fail(ctx, MI355_E_EXECUTION, "hipGraphInstantiate: %s", hipGetErrorString(e));
     }
     // From here on the graph owns a pin on every pool block allocated or freed in its window (pool.cpp keeps them out of
     // the free lists under `id`) and on the library scratch its kernels were captured with.
-    mi355_graph *out = new mi355_graph{g, x, id, {}, {}};
+    mi355_graph *out = new mi355_graph{g, x, id, {}, {}, {}};
     out->scratch.swap(ctx->capture_scratch);
     for (void *p : out->scratch) ++ctx->scratch_refs[p];
+    out->tickets.swap(ctx->capture_tickets);
+    for (uint32_t t : out->tickets) ++ctx->ticket_refs[t];
     ctx->live_graphs.insert(id);
     *out_graph = out;
     return MI355_OK;
@@ -973,6 +982,12 @@ MI355_API int32_t mi355_graph_destroy(mi355_ctx *ctx, mi355_graph *graph)
     ctx->live_graphs.erase(graph->id);
     pool_release_graph(ctx, graph->id);          // its pinned blocks are ordinary free memory again
     for (void *p : graph->scratch) scratch_release(ctx, p);
+    for (uint32_t t : graph->tickets) {
+        auto pin = ctx->ticket_refs.find(t);
+        if (pin == ctx->ticket_refs.end() || --pin->second > 0) continue;
+        ctx->ticket_refs.erase(pin);
+        if (ctx->ticket_retired.erase(t)) ctx->ticket_free.push_back(t);   // its stream died meanwhile: the slot is reusable now
+    }
     delete graph;
     return MI355_OK;
 }

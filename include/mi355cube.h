@@ -397,9 +397,11 @@ enum {
                                      loader waves + MFMA, no split-K (gemm_stream64.hip)             */
     MI355_GEMM_ALGO_LP_256X128 = 10, /* bf16/f16 256x128x64 tile (gemm_lp128.hip, MI = 4): three-stage LDS ring + loader
                                      waves, one workgroup per CU; mid-size shapes of at most one round of such tiles */
-    MI355_GEMM_ALGO_NNROWS = 11   /* bf16/f16, M <= 16 against a row-major [K][N] weight (the rhs TensorHandle::new_contiguous
+    MI355_GEMM_ALGO_NNROWS = 11,  /* bf16/f16, M <= 16 against a row-major [K][N] weight (the rhs TensorHandle::new_contiguous
                                      gives): wide row strips streamed once, transposed in registers into 4x4x4 MFMA
                                      operands, K slices folded by the last workgroup to arrive (gemm_nnrows.hip) */
+    MI355_GEMM_ALGO_LP_256X192 = 12 /* bf16/f16, [N][K] rhs: the 4-wave kernel of _LP_256W4 on a 256 x 192 tile (each wave 128 x 96):
+                                     grids on which the square tile leaves CUs idle (ABI 8; gemm_lp256w4.hip NJ = 3) */
 };
 
 int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_gemm_desc *desc,

@@ -104,7 +104,8 @@ pub fn reduce_sum(client: &ComputeClient<Mi355Runtime>, input: &Tensor, out: &Te
     Ok(())
 }
 
-/// Value (f32) and index (u64) of the first maximum (`mi355_argmax`; ties go to the lowest index, NaN never wins).
+/// Value (f32) and index (u64) of the first maximum (`mi355_argmax`; ties go to the lowest index, -0 == +0, a NaN ranks ABOVE every
+/// number and the first NaN wins -- `include/mi355cube.h` "Reductions", numpy's rule).
 pub fn argmax(client: &ComputeClient<Mi355Runtime>, input: &Tensor, out_value: &Tensor, out_index: &Tensor) -> Result<(), ServerError> {
     let (task, n) = whole(ReduceKind::Argmax, input)?;
     let scratch = workspace(client, n)?;

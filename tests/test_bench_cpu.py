@@ -105,7 +105,8 @@ def test_two_rank_job_runs_to_completion_on_the_native_collectives_without_a_dev
     """`python bench.py --gpus 2` end to end on this box: bench.py becomes its own launcher (torch.distributed.run), the two ranks
     find the launcher's TCP store, rank 0's unique id travels through it, both join the LIBRARY's communicator (comm.cpp over the
     multi-process RCCL stand-in), barrier and max-over-ranks run on it (no torch process group: `job_collectives` == "native"), the
-    C4 extra runs local pass -> all-reduce + all-gather -> combine (RcclExchange.exchange_on_device), and rank 0 prints ONE line with
+    C4 extra runs local pass -> ONE all-gather of {max, partial sum, index} records -> combine kernel (RcclExchange.exchange_on_device;
+    the reference's all-reduce + all-gather shape is timed beside it), and rank 0 prints ONE line with
     n_gpus == 2.  The figures of such a run mean nothing; its control flow is what the first real 8-GPU run will execute."""
     so, rccl = _build_bench_libs()
     n = 1 << 20
@@ -125,6 +126,7 @@ def test_two_rank_job_runs_to_completion_on_the_native_collectives_without_a_dev
     ex = red["sharded_sum_argmax_exchange"]
     assert "error" not in ex, ex
     assert ex["device_combine_equals_host_rule"] is True
+    assert ex["exchange"].startswith("ONE RCCL all-gather") and ex["ms_with_all_reduce_and_all_gather"] > 0
     # the stand-in fill is lo + (hi - lo) * ((i * 2654435761 + tensor * 97) % 1000) / 1000 with tensor = 300 + rank over each
     # rank's own slice: the all-reduced sum and the combined argmax are what two hosts computing alone would get
     import numpy as np

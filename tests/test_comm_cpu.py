@@ -66,6 +66,28 @@ dst = [dev(ctxs[r], np.zeros(4, dtype=np.uint64)) for r in range(2)]
 for r in range(2):
     assert lib.mi355_all_gather(ctxs[r], comms[r], None, src[r], dst[r], 2, N.DTYPE_U64) == N.OK
 assert all(host(ctxs[r], dst[r], np.zeros(4, dtype=np.uint64)).tolist() == [7, 1000, 8, 2000] for r in range(2))
+# which stream a collective runs on (comm.cpp collective_stream): a message of at most 4 KiB is queued in the compute stream's
+# order -- no compute -> comm fence before it, nothing for sync_collective to do behind it -- a larger one goes through the
+# communication stream between the two event fences (crates/cubecl-cuda/src/compute/server.rs:749, :764-797), and so does a
+# small one issued while a larger one is still un-fenced (one communicator never has work in flight on two streams)
+log = (C.c_uint64 * 4)()
+def waits():
+    lib.faketest_stream_log(log); return int(log[1])
+w0 = waits()
+for r in range(2):
+    assert lib.mi355_all_gather(ctxs[r], comms[r], None, src[r], dst[r], 2, N.DTYPE_U64) == N.OK
+    assert lib.mi355_sync_collective(ctxs[r], None) == N.OK
+assert waits() == w0, "a 32-byte all-gather must not fence"
+big = [dev(ctxs[r], np.full(2048, r + 1.0, dtype=np.float32)) for r in range(2)]                 # 8 KiB
+for r in range(2):
+    assert lib.mi355_all_reduce(ctxs[r], comms[r], None, big[r], big[r], 2048, N.DTYPE_F32, N.REDUCE_SUM) == N.OK
+assert waits() == w0 + 2, "compute -> comm fence of the 8 KiB all-reduce, once per rank"
+for r in range(2):                                                                               # small, behind the un-fenced large one
+    assert lib.mi355_all_gather(ctxs[r], comms[r], None, src[r], dst[r], 2, N.DTYPE_U64) == N.OK
+assert waits() == w0 + 4, "a small collective behind an un-fenced large one follows it onto the communication stream"
+for r in range(2):
+    assert lib.mi355_sync_collective(ctxs[r], None) == N.OK
+assert waits() == w0 + 6 and host(ctxs[0], big[0], np.zeros(2048, dtype=np.float32)).tolist() == [3.0] * 2048
 # send / recv in either call order (runtime_tests/to_client.rs moves 0..6 as f32)
 payload = np.arange(6, dtype=np.float32)
 s0, r1 = dev(ctxs[0], payload), dev(ctxs[1], np.zeros(6, dtype=np.float32))

@@ -26,7 +26,7 @@ REL = 1e-5
 ALGOS = {"auto": N.GEMM_ALGO_AUTO, "generic": N.GEMM_ALGO_GENERIC, "f32": N.GEMM_ALGO_F32_MFMA,
          "lp128": N.GEMM_ALGO_LP_128, "lp256": N.GEMM_ALGO_LP_256, "lp256w4": N.GEMM_ALGO_LP_256W4, "lp256p": N.GEMM_ALGO_LP_256P,
          "lp256q": N.GEMM_ALGO_LP_256Q, "skinny": N.GEMM_ALGO_SKINNY, "stream64": N.GEMM_ALGO_STREAM64,
-         "lp256x128": N.GEMM_ALGO_LP_256X128, "nnrows": N.GEMM_ALGO_NNROWS}
+         "lp256x128": N.GEMM_ALGO_LP_256X128, "nnrows": N.GEMM_ALGO_NNROWS, "lp256x192": N.GEMM_ALGO_LP_256X192}
 
 
 def _to_dev(client, oracle, x, dtype):
@@ -417,6 +417,41 @@ def test_lp256w4_c_rows_off_the_16_byte_grid(client, oracle, m, n, k, dtype, out
         ldc += 1
     run_case(client, oracle, m, n, k if dtype != ElemType.F32 else k // 2, dtype, ElemType.F32 if out == "f32" else dtype, True,
              ALGOS["lp256w4"], ldc=ldc, batch=2 if m < 300 else 1)
+
+
+# ---- the 256 x 192 tile of the 4-wave kernel (gemm_lp256w4.hip NJ = 3; round 5) ------------------------------------------------
+X192_CASES = [(256, 192, 64), (256, 384, 128), (512, 576, 512), (300, 200, 128), (1, 192, 64), (257, 191, 320), (255, 385, 192),
+              (700, 40, 256), (8, 8, 64), (513, 1000, 128), (768, 960, 1024), (3072, 3072, 256)]
+
+
+@pytest.mark.parametrize("m,n,k", X192_CASES)
+@pytest.mark.parametrize("dtype,out", [(ElemType.BF16, "f32"), (ElemType.BF16, "same"), (ElemType.F16, "same"), (ElemType.F16, "f32")])
+def test_lp256x192_parity_and_the_bits_of_the_square_tile(client, oracle, m, n, k, dtype, out):
+    """The 256 x 192 tile against the oracle on whole and ragged grids (pitched C: the 0xEE padding stays), and against the
+    256 x 256 tile of the same kernel bit for bit -- every output element sums the same K-tiles through the same MFMAs in the
+    same order, only the tile it lives in differs."""
+    out_dtype = ElemType.F32 if out == "f32" else dtype
+    ldc = (n + 7) // 8 * 8 + 8
+    run_case(client, oracle, m, n, k, dtype, out_dtype, True, ALGOS["lp256x192"], ldc=ldc)
+    a = TensorHandle.uniform(client, (m, k), dtype, 5, 1, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (n, k), dtype, 5, 2, -1.0, 1.0)
+    bt = TensorHandle.new(b.handle, (k, n), (1, k), dtype)
+    got = []
+    for algo in ("lp256x192", "lp256w4"):
+        c = TensorHandle.new_contiguous((m, n), client.empty(m * n * out_dtype.size()), out_dtype)
+        ops.matmul(client, a, bt, c, algo=ALGOS[algo])
+        got.append(client.read_one(c.handle).copy())
+    assert np.array_equal(got[0], got[1])
+
+
+@pytest.mark.parametrize("pad", [1, 3])
+def test_lp256x192_c_rows_off_the_16_byte_grid_batches_and_refusals(client, oracle, pad):
+    run_case(client, oracle, 300, 261, 128, ElemType.BF16, ElemType.BF16, True, ALGOS["lp256x192"], ldc=261 + pad, batch=2)
+    run_case(client, oracle, 513, 1001, 128, ElemType.BF16, ElemType.F32, True, ALGOS["lp256x192"], ldc=1001 + pad)
+    run_case(client, oracle, 256, 384, 192, ElemType.F16, ElemType.F16, True, ALGOS["lp256x192"], batch=3, bcast_b=True, lda=200, ldb=208)
+    for kw in ({"dtype": ElemType.F32}, {"trans_b": False}, {"k": 96}):             # f32 operands, row-major B, K off the K-tile grid
+        with pytest.raises(ServerError):
+            run_case(client, oracle, 256, 192, kw.get("k", 128), kw.get("dtype", ElemType.BF16), ElemType.F32, kw.get("trans_b", True), ALGOS["lp256x192"])
 
 
 def test_unaligned_c_gives_the_bits_of_the_aligned_form_and_stays_inside_its_rows(client, oracle):
@@ -1146,16 +1181,18 @@ def test_few_rows_times_row_major_weight_selection_refusals_and_determinism(clie
     assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 1.0
 
 
-def test_few_rows_times_row_major_weight_inside_a_capture_window(client, oracle):
+@pytest.mark.parametrize("elem, dtype", [(ElemType.BF16, N.DTYPE_BF16), (ElemType.F32, N.DTYPE_F32)], ids=["bf16", "f32"])
+def test_few_rows_times_row_major_weight_inside_a_capture_window(client, oracle, elem, dtype):
     """The strip kernel's K-slice scratch and ticket words cannot be created inside a capture window: on a stream that has them
     (a warm-up call) the captured launch replays the eager bits; on a stream that does not, AUTO takes the tile kernel instead of
-    failing (as the split-K paths fall back) -- and the replay is still right."""
+    failing (as the split-K paths fall back) -- and the replay is still right.  (f32: the advisor of round 4 found the fallback
+    never left the strip kernel there -- the f32 rule did not look at the switch -- and the captured call returned E_UNSUPPORTED.)"""
     import ctypes as C
     lib, ctx, chk = client.lib, client.ctx, client._s.check
     m, n, k = 4, 8192, 8192
-    a = TensorHandle.uniform(client, (m, k), ElemType.BF16, 1, 7, -1.0, 1.0)
-    b = TensorHandle.uniform(client, (k, n), ElemType.BF16, 1, 8, -1.0, 1.0)
-    d = _nn_desc(m, n, k, N.DTYPE_BF16, N.DTYPE_F32)
+    a = TensorHandle.uniform(client, (m, k), elem, 1, 7, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (k, n), elem, 1, 8, -1.0, 1.0)
+    d = _nn_desc(m, n, k, dtype, N.DTYPE_F32)
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_NNROWS
     client.sync()
     want = None
@@ -1286,6 +1323,11 @@ def test_output_bound_shapes_select_the_small_tile(client):
     (16, 9000, 1024, {}),                        # 282 workgroups: more than one per CU -> half-depth rings, two per CU
     (64, 8200, 640, {}),                         # the same form with two row blocks; ragged last workgroup
     (24, 300, 2048, {"batch": 40}),              # 400 workgroups through the batch
+    # round 5, the NB = 2 form (64 streamed rows per workgroup, K in two slices folded by the last workgroup of a row block): taken from
+    # 56 rows at K >= 8192 on grids of 129-256 workgroups of the NB = 1 form -- (64, 8192, 8192) above is one
+    (60, 5000, 8192, {"lda": 8200, "ldc": 5008}),   # 157 workgroups -> 79 row blocks, the last with 8 of its 64 rows; padded rows
+    (4200, 57, 8192, {}),                        # roles swapped: the output block stored transposed by the folding workgroup
+    (64, 4160, 16384, {}),                       # 128 K-tiles per slice
 ])
 @pytest.mark.parametrize("dtype,out_dtype", [(ElemType.BF16, ElemType.BF16), (ElemType.F16, ElemType.F32), (ElemType.BF16, ElemType.F32)])
 def test_stream64_kernel_matches_the_oracle(client, oracle, m, n, k, kw, dtype, out_dtype):
@@ -1304,6 +1346,36 @@ def test_stream64_refusals_determinism_and_repeated_launches(client, oracle):
         ops.matmul(client, a, TensorHandle.new(b.handle, (8192, 4096), (1, 8192), ElemType.BF16), c, algo=ALGOS["stream64"])
         outs.append(c.to_numpy(client).copy())
     assert all(np.array_equal(outs[0], o) for o in outs[1:])
+    # the sliced form (two K slices meeting in library scratch, ticket per row block): the same bits on every launch and on another
+    # stream (its own scratch and tickets), and inside a capture window on a stream that has neither -- where it falls back to the
+    # unsliced form: another association, the same product
+    import ctypes as C
+    lib, ctx, chk = client.lib, client.ctx, client._s.check
+    b2 = TensorHandle.uniform(client, (8192, 8192), ElemType.BF16, 3, 4, -1.0, 1.0)
+    d = N.GemmDesc(m=64, n=8192, k=8192, batch=1, lda=8192, ldb=8192, ldc=8192, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_F32, trans_b=1, algo=ALGOS["stream64"])
+    outs = []
+    streams = [None, C.c_void_p(), C.c_void_p()]
+    for st in streams[1:]:
+        chk(lib.mi355_stream_create(ctx, C.byref(st)))
+    for rep, st in enumerate((None, None, streams[1])):
+        c = client.empty(64 * 8192 * 4)
+        chk(lib.mi355_memset(ctx, st, C.c_void_p(c.device_ptr()), 0xEE, c.size))
+        chk(lib.mi355_gemm(ctx, st, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b2.device_ptr()), C.c_void_p(c.device_ptr())))
+        chk(lib.mi355_sync(ctx, st))
+        outs.append(client.read_one(c).view(np.float32).copy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    c = client.empty(64 * 8192 * 4)
+    g = C.c_void_p()
+    chk(lib.mi355_graph_begin_capture(ctx, streams[2]))
+    chk(lib.mi355_gemm(ctx, streams[2], C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b2.device_ptr()), C.c_void_p(c.device_ptr())))
+    chk(lib.mi355_graph_end_capture(ctx, streams[2], C.byref(g)))
+    chk(lib.mi355_graph_replay(ctx, streams[2], g))
+    chk(lib.mi355_sync(ctx, streams[2]))
+    got = client.read_one(c).view(np.float32)
+    assert np.allclose(got, outs[0], rtol=0, atol=1e-3 * np.abs(outs[0]).max()) and not np.array_equal(got, outs[0])
+    chk(lib.mi355_graph_destroy(ctx, g))
+    for st in streams[1:]:
+        chk(lib.mi355_stream_destroy(ctx, st))
 
 
 @pytest.mark.parametrize("m,n,k", [(256, 256, 64), (512, 384, 128), (2048, 2048, 192), (1000, 900, 256), (2048, 2048, 320), (128, 128, 4096)])

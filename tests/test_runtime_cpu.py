@@ -435,6 +435,26 @@ def test_a_destroyed_stream_takes_its_library_scratch_and_its_ticket_slot_with_i
     assert _device(lib)["frees"] == frees and lib.pooltest_inside_allocation(p, 1 << 20) == 1
     assert lib.mi355_graph_destroy(ctx, graph) == N.OK
     assert _device(lib)["frees"] == frees + 1 and lib.pooltest_inside_allocation(p, 1 << 20) == 0
+    # ... and so is the ticket slot a captured kernel counts on (advisor, round 4): a replay must never share its arrival words with
+    # a new stream's launches -- the slot of a destroyed stream is handed out again only when the last graph carrying it is gone
+    s3, s4, g3 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert lib.mi355_stream_create(ctx, C.byref(s3)) == N.OK and lib.faketest_ticket_slot(ctx, s3, C.byref(slot)) == N.OK
+    pinned = slot.value
+    assert lib.mi355_graph_begin_capture(ctx, s3) == N.OK
+    assert lib.faketest_ticket_slot(ctx, s3, C.byref(slot)) == N.OK and slot.value == pinned      # a reduction inside the window
+    assert lib.mi355_graph_end_capture(ctx, s3, C.byref(g3)) == N.OK
+    assert lib.mi355_stream_destroy(ctx, s3) == N.OK
+    assert lib.mi355_stream_create(ctx, C.byref(s4)) == N.OK and lib.faketest_ticket_slot(ctx, s4, C.byref(slot)) == N.OK
+    assert slot.value != pinned                                # the graph is alive: its slot stays out of circulation
+    assert lib.mi355_stream_destroy(ctx, s4) == N.OK and lib.mi355_graph_destroy(ctx, g3) == N.OK
+    got = set()
+    for _ in range(2):                                         # both free slots come back, the once-pinned one among them
+        s5 = C.c_void_p()
+        assert lib.mi355_stream_create(ctx, C.byref(s5)) == N.OK and lib.faketest_ticket_slot(ctx, s5, C.byref(slot)) == N.OK
+        got.add(slot.value); live.append(s5)
+    assert pinned in got
+    for s5 in live[-2:]:
+        assert lib.mi355_stream_destroy(ctx, s5) == N.OK
     # the context's own streams are not the caller's to destroy
     own = C.c_void_p()
     assert lib.mi355_default_stream(ctx, C.byref(own)) == N.OK and lib.mi355_stream_destroy(ctx, own) == N.E_INVALID_ARGUMENT
