@@ -64,6 +64,7 @@ GEMM_ALGO_STREAM64 = 9
 GEMM_ALGO_LP_256X128 = 10
 GEMM_ALGO_NNROWS = 11
 GEMM_ALGO_LP_256X192 = 12
+GEMM_ALGO_LP_192X192 = 13
 UNIQUE_ID_BYTES = 128
 
 

@@ -75,7 +75,8 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
         if (twin == MI355_GEMM_ALGO_LP_256W4 && gemm_lp256w4_supports(d, a, b, c)) return MI355_GEMM_ALGO_LP_256W4;
         return MI355_GEMM_ALGO_GENERIC;
     }
-    const bool big = gemm_lp256_supports(d, a, b, c);
+    // (the 8-wave 256x256 kernel, gemm_lp256.hip, was retired in round 5: since the 4-wave kernel takes unaligned C rows no AUTO path
+    // reached it; MI355_GEMM_ALGO_LP_256 stays as an alias of the 4-wave kernel for callers that name it)
     const bool big4 = gemm_lp256w4_supports(d, a, b, c);
     const bool mid = gemm_lp128_supports(d, a, b, c);
     // Row-major B (the layout TensorHandle::new_contiguous gives a rhs): staged natively by the tile kernels that build the
@@ -181,7 +182,7 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
     }
     // one or two rows (or columns): HBM-bound on the other operand; stream it once with dot products, no MFMA tile to fill
     // (gemm_skinny.hip: 20.4 us against 24.7 at 1 x 8192 x 8192).  Up to 16 rows when no MFMA kernel takes the descriptor.
-    if ((d.m <= 16 || d.n <= 16) && gemm_skinny_supports(d, a, b, c) && (std::min(d.m, d.n) <= 2 || !(big || big4 || mid)))
+    if ((d.m <= 16 || d.n <= 16) && gemm_skinny_supports(d, a, b, c) && (std::min(d.m, d.n) <= 2 || !(big4 || mid)))
         return MI355_GEMM_ALGO_SKINNY;
     // Output-bound (K of at most four K-tiles) over more than one round of 256x256 tiles: the 128x128 kernel in its
     // single-stage form, four workgroups per CU -- the C stores of three hide the fetch + MFMA phase of the fourth, where a
@@ -206,6 +207,19 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
         if (d.n <= 128 && d.m > 128 && t128 > 256 && tall <= 256 && gemm_lp256x128_supports(d, a, b, c)) return MI355_GEMM_ALGO_LP_256X128;
         return MI355_GEMM_ALGO_LP_128;
     }
+    // Round 5: ONE round of 192 x 192 tiles of the 4-wave kernel (gemm_lp256w4.hip NJ = NI = 3) that fills most of the chip -- the
+    // mid-size band where the square 256 tile leaves >= 44 % of the CUs idle and the 128-wide tiles are bound by L2 -> LDS delivery.
+    // A K-tile of it costs ~0.85 of the square tile's for 0.56 of the work, so it pays exactly while it stays one round
+    // (profiles/r05_tile_192x192_ab.txt, cold, TFLOP/s, against the best of 256x256 / 256x192 / 256x128 / 128x128): 3072^3 1185 / 1105,
+    // 3072^2 x 8192 1257 / 1172, 2304^3 859 / 716, 2688^3 989 / 913, 2816^2 x 4096 1085 / 1021, 3072 x 2304 x 4096 994 / 943,
+    // 4096 x 2048 x 4096 1131 / 1068, 2560^2 x 4096 915 / 894; below ~144 tiles the 128x128 kernel's two workgroups per CU win
+    // (2048^3: 121 tiles, 696 / 762; 1920^2 x 4096: 100 tiles, 720 / 777), a long K on few tiles is a tie with the 256 x 128 tile
+    // (3072 x 1536 x 8192: 128 tiles, 727 / 732; 2048 x 3072 x 8192: 176 tiles, 913 / 941 -- kept on that tile).
+    // (K of at least 16 K-tiles: 3072^2 x 512 631 on the square tile against 525)
+    if (big4 && d.trans_b && std::min(d.m, d.n) > 512 && d.k >= 1024 && gemm_lp256x192_supports(d, a, b, c)) {
+        const int64_t tiles192 = ((d.m + 191) / 192) * ((d.n + 191) / 192) * d.batch;
+        if (tiles192 >= 144 && tiles192 <= 256 && !(d.k >= 8192 && tiles192 < 192)) return MI355_GEMM_ALGO_LP_192X192;
+    }
     // More than one 128x128 tile per CU but at most one 256x128 tile per CU, and a long K: the 256 x 128 form of the same
     // kernel (gemm_lp128.hip, MI = 4) -- 0.75 x the L2 -> LDS bytes per FLOP, which is what the two co-resident 128x128
     // workgroups per CU are bound by.  Interleaved, cold operands (profiles/r03_tile_256x128_sweep.txt, 50 shapes): K >= 3072
@@ -219,7 +233,7 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
         if (mid && t128 > 256 && tall <= 256 && (d.k >= 2560 || std::min(d.m, d.n) <= 512) && gemm_lp256x128_supports(d, a, b, c))
             return MI355_GEMM_ALGO_LP_256X128;
     }
-    if (big || big4) {
+    if (big4) {
         // 256x256 tiles once the 128x128 kernel would need more than its two co-resident workgroups per CU (512 tiles of
         // 128^2 = 128 of 256^2).  Measured (tools/ab_algos.py): 96-128 tiles a tie, 144-160 tiles +45...55 % for the
         // 256x256 kernel even though it leaves 40 % of the CUs idle, 64-81 tiles +7...30 % for the 128x128 kernel.
@@ -233,7 +247,7 @@ int32_t select(const mi355_gemm_desc &d, const void *a, const void *b, const voi
             const int64_t tiles192 = ((d.m + 255) / 256) * ((d.n + 191) / 192) * d.batch;
             if (tiles192 <= 256 && tiles192 > tiles256) return MI355_GEMM_ALGO_LP_256X192;
         }
-        if (tiles256 > 128 || !mid) return big4 ? MI355_GEMM_ALGO_LP_256W4 : MI355_GEMM_ALGO_LP_256;
+        if (tiles256 > 128 || !mid) return MI355_GEMM_ALGO_LP_256W4;
     }
     if (mid) return MI355_GEMM_ALGO_LP_128;
     return MI355_GEMM_ALGO_GENERIC;
@@ -485,7 +499,7 @@ MI355_API int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_ge
     case MI355_GEMM_ALGO_GENERIC: return launch_gemm_generic(ctx, s, d, a, b, c);
     case MI355_GEMM_ALGO_F32_MFMA: return launch_gemm_f32_mfma(ctx, s, d, a, b, c);
     case MI355_GEMM_ALGO_LP_128: return launch_gemm_lp128(ctx, s, d, a, b, c);
-    case MI355_GEMM_ALGO_LP_256: return launch_gemm_lp256(ctx, s, d, a, b, c);
+    case MI355_GEMM_ALGO_LP_256: return launch_gemm_lp256w4(ctx, s, d, a, b, c);      // retired 8-wave kernel: an alias since ABI 8
     case MI355_GEMM_ALGO_LP_256W4: return launch_gemm_lp256w4(ctx, s, d, a, b, c);
     case MI355_GEMM_ALGO_LP_256P: return launch_gemm_lp256p(ctx, s, d, a, b, c);
     case MI355_GEMM_ALGO_LP_256Q: return launch_gemm_lp256q(ctx, s, d, a, b, c);
@@ -494,6 +508,7 @@ MI355_API int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_ge
     case MI355_GEMM_ALGO_LP_256X128: return launch_gemm_lp256x128(ctx, s, d, a, b, c);
     case MI355_GEMM_ALGO_NNROWS: return launch_gemm_nnrows(ctx, s, d, a, b, c);
     case MI355_GEMM_ALGO_LP_256X192: return launch_gemm_lp256x192(ctx, s, d, a, b, c);
+    case MI355_GEMM_ALGO_LP_192X192: return launch_gemm_lp256x192(ctx, s, d, a, b, c, 192);
     default: return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_gemm: unknown algo %d", algo);
     }
 }

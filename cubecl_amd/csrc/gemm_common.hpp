@@ -121,7 +121,6 @@ int32_t launch_gemm_lp128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &
 int32_t launch_gemm_lp256x128(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 int64_t lp128_split_count(const mi355_gemm_desc &d, int64_t cus);   // K slices of the 128x128 kernel's launcher (gemm_lp128.hip), 1 = none
 bool gemm_lp256x128_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
-int32_t launch_gemm_lp256(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 int32_t launch_gemm_lp256w4(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c,
                             const void *c_in = nullptr);
 int32_t launch_gemm_lp256p(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
@@ -129,7 +128,7 @@ bool gemm_lp256p_supports(const mi355_gemm_desc &d, const void *a, const void *b
 int32_t launch_gemm_lp256q(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 bool gemm_lp256q_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 bool gemm_lp256w4_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
-int32_t launch_gemm_lp256x192(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);   // gemm_lp256w4.hip, NJ = 3
+int32_t launch_gemm_lp256x192(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c, int tile_rows = 256);   // gemm_lp256w4.hip, NJ = 3 (tile_rows 192: NI = 3 too)
 bool gemm_lp256x192_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 int32_t launch_gemm_skinny(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 bool gemm_skinny_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
@@ -158,6 +157,5 @@ void launch_add_c(hipStream_t s, const float *prod, const void *c_in, void *d_ou
                   int32_t dtype_c, int64_t ldc, int64_t stride_c);
 bool gemm_f32_mfma_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 bool gemm_lp128_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
-bool gemm_lp256_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 
 }  // namespace mi355

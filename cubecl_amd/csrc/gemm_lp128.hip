@@ -3,7 +3,7 @@
 // Roofline: MFMA bf16/f16, ~2.5 PFLOP/s dense.  This is the medium-tile kernel: 4 waves (2x2),
 // each a 64x64 output (2x2 MFMA tiles of 32x32, 64 accumulator registers), 2 workgroups per CU.
 // It serves shapes too small to fill the chip with 256x256 tiles and is the validated base of
-// the staging scheme the 256x256 kernel (gemm_lp256.hip) reuses:
+// the staging scheme the 256x256 kernels (gemm_lp256w4.hip and its persistent forms) reuse:
 //
 //  * HBM -> LDS by LDS-DMA (`global_load_lds_dwordx4`, 16 B per lane, no VGPR round trip;
 //    cdna_hip_programming.md section 5).  One wave instruction fills 1 KiB = 8 tile rows of

@@ -5,7 +5,7 @@
 // MFMA fp8 (v_mfma_f32_32x32x64_f8f6f4, OCP e4m3 / e5m2), ~5 PFLOP/s dense (MI355X_MICROARCH.md).  This is the headline kernel for BASELINE configs C3 (8192^3 bf16), C5 (batched
 // 2048^3 bf16) and C2 (4096^3 f32, K-contiguous operands).
 //
-// Why one wave per SIMD.  The 8-wave ping-pong kernel (gemm_lp256.hip) hands the matrix pipe of a
+// Why one wave per SIMD.  The 8-wave ping-pong kernel (gemm_lp256.hip of rounds 1-4, retired in round 5) handed the matrix pipe of a
 // SIMD back and forth between two waves through s_barrier; its ablations (profiles/) show the
 // hand-over itself costs ~16 % with every load removed, and the load phases barely overlap the
 // MFMA phases.  Here each SIMD hosts ONE wave that owns a 128 x 128 output (4 x 4 MFMA tiles of
@@ -37,7 +37,7 @@
 //   never reaches 0 in the steady state.  The last two K-tiles of a tile have nothing left to fetch: they run a
 //   second copy of the body without DMA and with vmcnt(0) at the hand-over.
 //
-// Restrictions (the dispatcher falls back to gemm_lp256.hip / gemm_lp128.hip otherwise):
+// Restrictions (the dispatcher falls back to gemm_lp128.hip or the re-layout pass otherwise):
 //   K % 64 (16-bit) / 32 (f32) == 0, A row-major [M][K], B stored [N][K] (trans_b = 1; f32 also takes row-major
 //   [K][N] with N % 4 == 0), operand and C rows 16-byte aligned.  M and N are arbitrary: edge tiles clamp their
 //   loads to the last valid row and skip the stores outside the matrix.
@@ -200,13 +200,17 @@ __device__ __forceinline__ void scale_ld32(uint32_t &dst, const void *ubase, uin
 // k-step, 192 accumulators) for grids that leave CUs idle with the square tile (3072^3: 144 tiles of 256 x 256 on 256 CUs, 192 of
 // 256 x 192).  Same ring, same schedule: a B unit is 24 KiB in its 32 KiB slot (6 DMA pieces per wave instead of 8), the reads,
 // MFMAs and pieces of column fragment 3 are simply not emitted.  Plain [N][K] 16-bit operands only.
-template <int DT, int DT_C, bool BNN = false, int DTB = DT, bool MX = false, bool ATN = false, int NJ = 4>
+// NI: the same for the rows -- 3 = 192 tile rows (each wave 96 rows): with NJ = 3 a 192 x 192 tile, 9 MFMAs per k-step, 144 accumulators.
+template <int DT, int DT_C, bool BNN = false, int DTB = DT, bool MX = false, bool ATN = false, int NJ = 4, int NI = 4>
 __global__ void __launch_bounds__(256)
 gemm_lp256w4_kernel(gemm_args g)
 {
-    static_assert(NJ == 4 || (NJ == 3 && !BNN && !MX && !ATN && (DT == MI355_DTYPE_BF16 || DT == MI355_DTYPE_F16)), "256 x 192 tile: plain [N][K] 16-bit operands");
+    static_assert((NJ == 4 && NI == 4) || ((NJ == 3 || NJ == 4) && (NI == 3 || NI == 4) && !BNN && !MX && !ATN && (DT == MI355_DTYPE_BF16 || DT == MI355_DTYPE_F16)),
+                  "narrow tiles: plain [N][K] 16-bit operands");
     constexpr int BNT = NJ * 64;                        // tile columns: 256 or 192
     constexpr int NPB = NJ * 2;                         // DMA pieces of a B unit per wave: 8 or 6
+    constexpr int BMT = NI * 64;                        // tile rows: 256 or 192
+    constexpr int NPA = NI * 2;                         // DMA pieces of an A unit per wave
     static_assert(!BNN || DT == MI355_DTYPE_F32 || DT == MI355_DTYPE_BF16 || DT == MI355_DTYPE_F16, "row-major B: f32 and 16-bit operands");
     constexpr bool BNN16 = BNN && (DT == MI355_DTYPE_BF16 || DT == MI355_DTYPE_F16);
     // ATN (late round 3): A stored [K][M] together with a row-major B (lhs^T . grad_out) -- the A tile of a K-tile is 64 k-rows x 256 m,
@@ -225,7 +229,7 @@ gemm_lp256w4_kernel(gemm_args g)
 
     uint32_t tm, tn, batch_u;
     batched_tile_coords(g.tiles_m, g.tiles_n, g.group_m, tm, tn, batch_u);      // XCD remap over the (batch, tile) sequence
-    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BNT;
+    const int64_t m0 = (int64_t)tm * BMT, n0 = (int64_t)tn * BNT;
     const int64_t batch = batch_u;
     constexpr int ESZ = lp<DT>::ESZ;
     constexpr bool F8 = DT == MI355_DTYPE_F8E4M3 || DT == MI355_DTYPE_F8E5M2;
@@ -252,7 +256,7 @@ gemm_lp256w4_kernel(gemm_args g)
     uint32_t voff_a[8], voff_b[8];                                        // piece j of this wave: rows j*8 + lane/8
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int r = wave * 64 + j * 8 + sub;                            // tile row of this lane's 16 bytes
+        const int r = wave * (BMT / 4) + j * 8 + sub;                     // tile row of this lane's 16 bytes (BMT rows: NPA pieces per wave)
         const int q = c8 ^ ((r >> 1) & 7);
         voff_a[j] = (uint32_t)(min((int64_t)r, g.m - 1 - m0) * g.lda * ESZ + q * 16);
         const int rb = wave * (BNT / 4) + j * 8 + sub;                    // (the B tile has BNT rows: NPB pieces per wave)
@@ -283,20 +287,21 @@ gemm_lp256w4_kernel(gemm_args g)
     }
     const int dst_piece = wave * 8 * 1024;                            // + j*1024 within the slot
     constexpr int DST_PIECE_B_STEP = (NPB - 8) * 1024;                // B units of the 192-column tile: wave * NPB pieces in
+    constexpr int DST_PIECE_A_STEP = (NPA - 8) * 1024;                // ... and A units of the 192-row tile
 
     // ---- fragment read offsets: row*128 + ((2s+h) ^ f) * 16, f = (row>>1)&7 = (l31>>1)&7 for every tile row
     const int f = (l31 >> 1) & 7;
     // fp8: the second 16 bytes of a fragment sit in physical chunk ^ 1 (unscaled: logical chunks 2c, 2c+1); MX: logical
     // chunks c and c+2 (registers 0-3 of both lane-halves are one MX block, registers 4-7 the next) = physical ^ 2
     const int hd = MX ? ((f & 2) ? -32 : 32) : ((f & 1) ? -16 : 16);
-    const int rowoff_a = ATN ? wm * 4 * 256 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8 : (wm * 128 + l31) * ROW_BYTES;
+    const int rowoff_a = ATN ? wm * 4 * 256 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8 : (wm * (NI * 32) + l31) * ROW_BYTES;
     // (16-bit row-major B: block b = 4 wn + j of the lane-half's block row, + row (lane%16)/4, + 16-lane group, + 8 B per lane)
     const int rowoff_b = BNN16 ? wn * 4 * 256 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8
                          : BNN ? (wn * 128 + l31) * 4 : (wn * (NJ * 32) + l31) * ROW_BYTES;
 
-    f32x16 acc[4][NJ];
+    f32x16 acc[NI][NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -384,7 +389,7 @@ gemm_lp256w4_kernel(gemm_args g)
             }
         } else {
             if (R == 0) fb[BUF][0] = *reinterpret_cast<const frag *>(pb);
-            else if (R <= 4) fa[BUF][R - 1] = *reinterpret_cast<const frag *>(pa + (R - 1) * 32 * ROW_BYTES);
+            else if (R <= 4) { if constexpr (R - 1 < NI) fa[BUF][R - 1] = *reinterpret_cast<const frag *>(pa + (R - 1) * 32 * ROW_BYTES); }
             else if (R - 4 < NJ) fb[BUF][R - 4] = *reinterpret_cast<const frag *>(pb + (R - 4) * 32 * ROW_BYTES);
         }
     };
@@ -398,13 +403,14 @@ gemm_lp256w4_kernel(gemm_args g)
             glds16_s<J * 1024>(ubase_atn + koff * g.lda, voff_atn[J], lds_addr_of(base));
         } else {
             if constexpr (decltype(is_b)::value && J >= NPB) return;          // the 192-column tile: six pieces of B per wave
+            if constexpr (!decltype(is_b)::value && J >= NPA) return;         // the 192-row tile: six pieces of A per wave
             glds16_s<J * 1024>((decltype(is_b)::value ? ubase_b : ubase_a) + koff, decltype(is_b)::value ? voff_b[J] : voff_a[J],
-                               lds_addr_of(base) + (decltype(is_b)::value ? (uint32_t)(wave * DST_PIECE_B_STEP) : 0u));
+                               lds_addr_of(base) + (uint32_t)(wave * (decltype(is_b)::value ? DST_PIECE_B_STEP : DST_PIECE_A_STEP)));
         }
     };
     auto mfma_one = [&](auto buf, auto idx, auto step) {
         constexpr int BUF = decltype(buf)::value, I = decltype(idx)::value & 3, J = decltype(idx)::value >> 2;
-        if constexpr (DT != MI355_DTYPE_F32 && J >= NJ) return;               // (f32 re-indexes idx; it only exists with NJ = 4)
+        if constexpr (DT != MI355_DTYPE_F32 && (J >= NJ || I >= NI)) return;   // (f32 re-indexes idx; it only exists with NJ = NI = 4)
         if constexpr (MX) {
             // first MFMA operand = B fragment (its format in cbsz, its scale first), second = A fragment
             acc[I][J] = mfma_mx<mx_fmt<DTB>::value, mx_fmt<DT>::value, decltype(step)::value>(fb[BUF][J], fa[BUF][I], acc[I][J],
@@ -473,7 +479,8 @@ gemm_lp256w4_kernel(gemm_args g)
         W4_PRO(0, k0, 0) W4_PRO(1, k0, 1) W4_PRO(0, k1, 2) W4_PRO(1, k1, 3)
 #undef W4_PRO
     }
-    if constexpr (NJ == 4) WAIT_VMCNT(16); else WAIT_VMCNT(14);   // units 0, 1 landed (this wave's share): units 2, 3 = 8 + NPB pieces may fly
+    // units 0, 1 landed (this wave's share): units 2, 3 = NPA + NPB pieces may fly
+    if constexpr (NPA + NPB == 16) WAIT_VMCNT(16); else if constexpr (NPA + NPB == 14) WAIT_VMCNT(14); else WAIT_VMCNT(12);
     W4_TAKE_SCALES(16)                   // (older than every DMA: landed too)
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -533,7 +540,7 @@ gemm_lp256w4_kernel(gemm_args g)
         W4_STEP_BODY(0, 1, 0x00FFu, 0x0000u, 0, 0, 2, 0u, 0)                                                \
         if (!(W4_ABL & 8)) {                              /* dev ablation 8: no hand-over (timing only, races) */ \
         /* my share of K-tile t+1 landed; unit 2t+4 (and, MX, the 8 scale loads issued among it) may fly */ \
-        if (ISSUE) { if constexpr (MX) WAIT_VMCNT(16); else WAIT_VMCNT(8); } else WAIT_VMCNT(0);            \
+        if (ISSUE) { if constexpr (MX) WAIT_VMCNT(16); else if constexpr (NPA == 8) WAIT_VMCNT(8); else WAIT_VMCNT(6); } else WAIT_VMCNT(0); \
         WAIT_LGKM0();                                     /* my reads of K-tile t are complete */           \
         __builtin_amdgcn_s_barrier();                     /* BAR_t */                                        \
         }                                                                                                   \
@@ -645,11 +652,11 @@ gemm_lp256w4_kernel(gemm_args g)
         char *stage = smem + wave * ((STAGE + 1023) & ~1023);
         char *wr = stage + l31 * RS + 4 * h * CSZ;
         const char *rd = stage + (lane / LPR) * RS + (lane % LPR) * 16;
-        char *crow = C + (cbase + (m0 + wm * 128 + lane / LPR) * g.ldc + n0 + wn * (NJ * 32)) * CSZ + (lane % LPR) * 16;
+        char *crow = C + (cbase + (m0 + wm * (NI * 32) + lane / LPR) * g.ldc + n0 + wn * (NJ * 32)) * CSZ + (lane % LPR) * 16;
         const int64_t cstep = (int64_t)RPI * g.ldc * CSZ;
         // edge tiles: rows >= M and columns >= N are not stored (a 16-byte piece straddling N is written element-wise)
         constexpr int EPP = 16 / CSZ;                                     // elements per 16-byte piece
-        const int64_t row0 = m0 + wm * 128 + lane / LPR;                  // + i*32 + it*RPI
+        const int64_t row0 = m0 + wm * (NI * 32) + lane / LPR;            // + i*32 + it*RPI
         const int64_t col0 = n0 + wn * (NJ * 32) + (lane % LPR) * EPP;
         // (the 192-column tile: a wave's rows are NJ * 32 columns wide -- the lanes of a row beyond that have nothing to store)
         const bool lane_live = NJ == 4 || (int)(lane % LPR) * EPP < NJ * 32;
@@ -658,7 +665,7 @@ gemm_lp256w4_kernel(gemm_args g)
         // the element-wise way of the edge tiles -- eight 2-byte stores per lane instead of one 16-byte store, which the L2
         // merges into the same lines (8191 x 8191 x 8192: see profiles/r04_ragged_probe.txt).
         const bool cvec = ((((uint64_t)g.ldc * CSZ) | ((uint64_t)g.stride_c * CSZ) | reinterpret_cast<uintptr_t>(g.c)) & 15u) == 0;
-        const bool interior = cvec && (m0 + BM <= g.m) && (n0 + BNT <= g.n);   // wave-uniform fast path
+        const bool interior = cvec && (m0 + BMT <= g.m) && (n0 + BNT <= g.n);   // wave-uniform fast path
         // D = A * B + c_in (f32 C only, the C operand of cmma::execute): the 32 / RPI pieces of c_in that this lane will
         // add in block i are fetched before the block's accumulators are staged, so one memory latency per block hides
         // behind the LDS transposition.  c_in has C's layout and may be C itself.
@@ -666,7 +673,7 @@ gemm_lp256w4_kernel(gemm_args g)
         if constexpr (DT_C == MI355_DTYPE_F32) cin = static_cast<const char *>(g.c_in);
         const int64_t cin_off = crow - C;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             f32x4 pre[DT_C == MI355_DTYPE_F32 ? 32 / RPI : 1];
             if constexpr (DT_C == MI355_DTYPE_F32) {
                 if (cin) {
@@ -742,11 +749,11 @@ gemm_lp256w4_kernel(gemm_args g)
 #endif
 }
 
-template <int DT, int DT_C, bool BNN = false, int DTB = DT, bool MX = false, bool ATN = false, int NJ = 4>
+template <int DT, int DT_C, bool BNN = false, int DTB = DT, bool MX = false, bool ATN = false, int NJ = 4, int NI = 4>
 void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch)
 {
-    lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_lp256w4_kernel<DT, DT_C, BNN, DTB, MX, ATN, NJ>), LDS_BYTES);
-    hipLaunchKernelGGL((gemm_lp256w4_kernel<DT, DT_C, BNN, DTB, MX, ATN, NJ>), dim3(g.tiles_m * g.tiles_n, batch), dim3(256), LDS_BYTES, s, g);
+    lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_lp256w4_kernel<DT, DT_C, BNN, DTB, MX, ATN, NJ, NI>), LDS_BYTES);
+    hipLaunchKernelGGL((gemm_lp256w4_kernel<DT, DT_C, BNN, DTB, MX, ATN, NJ, NI>), dim3(g.tiles_m * g.tiles_n, batch), dim3(256), LDS_BYTES, s, g);
 }
 
 }  // namespace
@@ -852,21 +859,29 @@ bool gemm_lp256x192_supports(const mi355_gemm_desc &d, const void *a, const void
     return gemm_lp256w4_supports(d, a, b, c);
 }
 
-int32_t launch_gemm_lp256x192(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c)
+int32_t launch_gemm_lp256x192(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c, int tile_rows)
 {
-    if (!gemm_lp256x192_supports(d, a, b, c))
+    if (!gemm_lp256x192_supports(d, a, b, c) || (tile_rows != 256 && tile_rows != 192))
         return fail(ctx, MI355_E_UNSUPPORTED, "lp256x192 GEMM: shape/layout not supported by this kernel");
     gemm_args g{};
     g.a = a; g.b = b; g.c = c;
     g.m = d.m; g.n = d.n; g.k = d.k;
     g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc;
     g.stride_a = d.stride_a; g.stride_b = d.stride_b; g.stride_c = d.stride_c;
-    g.tiles_m = (uint32_t)((d.m + BM - 1) / BM);
+    g.tiles_m = (uint32_t)((d.m + tile_rows - 1) / tile_rows);
     g.tiles_n = (uint32_t)((d.n + 191) / 192);
     g.group_m = W4_GROUP_M;
     const uint32_t batch = (uint32_t)d.batch;
     constexpr int BF = MI355_DTYPE_BF16, HF = MI355_DTYPE_F16, CF = MI355_DTYPE_F32;
-    if (d.dtype_ab == BF) {
+    if (tile_rows == 192) {
+        if (d.dtype_ab == BF) {
+            if (d.dtype_c == CF) launch<BF, CF, false, BF, false, false, 3, 3>(ctx, s, g, batch);
+            else launch<BF, BF, false, BF, false, false, 3, 3>(ctx, s, g, batch);
+        } else {
+            if (d.dtype_c == CF) launch<HF, CF, false, HF, false, false, 3, 3>(ctx, s, g, batch);
+            else launch<HF, HF, false, HF, false, false, 3, 3>(ctx, s, g, batch);
+        }
+    } else if (d.dtype_ab == BF) {
         if (d.dtype_c == CF) launch<BF, CF, false, BF, false, false, 3>(ctx, s, g, batch);
         else launch<BF, BF, false, BF, false, false, 3>(ctx, s, g, batch);
     } else {

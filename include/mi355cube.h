@@ -385,7 +385,7 @@ enum {
     MI355_GEMM_ALGO_GENERIC = 1,  /* bounds-checked scalar-FMA kernel, any shape / layout     */
     MI355_GEMM_ALGO_F32_MFMA = 2, /* 128x128 LDS-tiled v_mfma_f32_32x32x2_f32                 */
     MI355_GEMM_ALGO_LP_128 = 3,   /* bf16/f16 128x128x64 LDS-DMA tile, v_mfma_f32_32x32x16     */
-    MI355_GEMM_ALGO_LP_256 = 4,   /* bf16/f16 256x256x64 tile, 8 waves (ragged M/N allowed)    */
+    MI355_GEMM_ALGO_LP_256 = 4,   /* retired (ABI 8): was the 8-wave 256x256 kernel; now an alias of _LP_256W4  */
     MI355_GEMM_ALGO_LP_256W4 = 5, /* fp8/bf16/f16/f32 256x256 tile x 128-byte K line, 4 waves x 128x128 */
     MI355_GEMM_ALGO_LP_256P = 6,  /* the same tile as a persistent kernel: one workgroup per CU walks
                                      several output tiles with a continuous K-tile stream          */
@@ -400,8 +400,9 @@ enum {
     MI355_GEMM_ALGO_NNROWS = 11,  /* bf16/f16, M <= 16 against a row-major [K][N] weight (the rhs TensorHandle::new_contiguous
                                      gives): wide row strips streamed once, transposed in registers into 4x4x4 MFMA
                                      operands, K slices folded by the last workgroup to arrive (gemm_nnrows.hip) */
-    MI355_GEMM_ALGO_LP_256X192 = 12 /* bf16/f16, [N][K] rhs: the 4-wave kernel of _LP_256W4 on a 256 x 192 tile (each wave 128 x 96):
+    MI355_GEMM_ALGO_LP_256X192 = 12, /* bf16/f16, [N][K] rhs: the 4-wave kernel of _LP_256W4 on a 256 x 192 tile (each wave 128 x 96):
                                      grids on which the square tile leaves CUs idle (ABI 8; gemm_lp256w4.hip NJ = 3) */
+    MI355_GEMM_ALGO_LP_192X192 = 13  /* ... and on a 192 x 192 tile (each wave 96 x 96; NJ = NI = 3) */
 };
 
 int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_gemm_desc *desc,

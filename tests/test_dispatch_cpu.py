@@ -48,7 +48,14 @@ TABLE = [
     ("decode, 64 tokens, row-major weight", (64, 28672, 8192, BF, None, 0, 0, 1), "LP_128", (0, 0)),
     ("output-bound: one K-tile", (8192, 8192, 64, BF, None, 0, 1, 1), "LP_128", (0, 0)),
     ("one 128^2 tile per CU", (2048, 2048, 2048, BF, None, 0, 1, 1), "LP_128", (0, 0)),
-    ("the 256 x 128 tile's band", (4096, 2048, 4096, BF, None, 0, 1, 1), "LP_256X128", (0, 0)),
+    ("one round of 192^2 tiles on most of the chip (round 5; was the 256 x 128 tile's)", (4096, 2048, 4096, BF, None, 0, 1, 1), "LP_192X192", (0, 0)),
+    ("3072^3: 256 tiles of 192^2 instead of 144 of 256^2", (3072, 3072, 3072, BF, None, 0, 1, 1), "LP_192X192", (0, 0)),
+    ("144 tiles of 192^2", (2304, 2304, 2304, BF, None, 0, 1, 1), "LP_192X192", (0, 0)),
+    ("121 tiles of 192^2: the 128^2 kernel's two workgroups per CU", (2048, 2048, 4096, BF, None, 0, 1, 1), "LP_128", (0, 0)),
+    ("a long K on 176 tiles of 192^2 stays on the 256 x 128 tile", (2048, 3072, 8192, BF, None, 0, 1, 1), "LP_256X128", (0, 0)),
+    ("one round of 256 x 192 tiles where 192^2 would need two", (4096, 3072, 4096, BF, None, 0, 1, 1), "LP_256X192", (0, 0)),
+    ("196 tiles of 256^2: every narrower tile needs a second round", (3584, 3584, 3584, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
+    ("the narrow tiles stage [N][K] operands only: a row-major rhs keeps the square tile", (3072, 3072, 3072, BF, None, 0, 0, 1), "LP_256W4", (0, 0)),
     ("one round of 256^2 tiles", (4096, 4096, 4096, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
     ("a partly filled last round (split inside the launch)", (6144, 6144, 6144, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
     ("weight gradient lhs^T . grad: native", (512, 512, 8192, BF, None, 1, 0, 1), "LP_128", (0, 0)),

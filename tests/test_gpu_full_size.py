@@ -82,8 +82,8 @@ def test_c3_bf16_8192_sampled_rows_linearity_and_kernel_agreement(client, oracle
     c2 = TensorHandle.new_contiguous((S, S), client.empty(S * S * 4), ElemType.F32)
     ops.matmul(client, TensorHandle.new(a2.handle, (S, S), (S, 1), ElemType.BF16), bt, c2)
     assert np.array_equal(c2.to_numpy(client), 2.0 * got)
-    # an independent kernel (8 waves, different summation order) agrees within the f32 bound |a||b| <= 1 per product
-    ops.matmul(client, a, bt, c2, algo=N.GEMM_ALGO_LP_256)
+    # another kernel (the 128x128 tile's loader-wave form) agrees within the f32 bound |a||b| <= 1 per product
+    ops.matmul(client, a, bt, c2, algo=N.GEMM_ALGO_LP_128)
     assert np.max(np.abs(c2.to_numpy(client) - got)) <= REL * S
     # bit-reproducible from launch to launch
     ops.matmul(client, a, bt, c2)
@@ -155,15 +155,16 @@ def test_c3_bf16_8192_bf16_output_as_benched(client, oracle):
     assert np.array_equal(oracle.to_bf16(full32).reshape(S, S), got)
 
 
-def test_mid_size_4096x2048x4096_as_benched_takes_the_256x128_tile(client, oracle):
-    """bench.py's `4096x2048x4096` entry: AUTO takes the 256 x 128 form of the mid-size kernel (256 tiles, one per CU); all
-    outputs equal the 128x128 kernel's bit for bit (same k order per output) and sampled rows meet the f64 oracle."""
+def test_mid_size_4096x2048x4096_as_benched_takes_the_192x192_tile(client, oracle):
+    """bench.py's `4096x2048x4096` entry: AUTO takes the 192 x 192 tile of the 4-wave kernel since round 5 (242 tiles, one round;
+    until then the 256 x 128 form of the mid-size kernel); all outputs equal the 128x128 kernel's bit for bit (same k order per
+    output) and sampled rows meet the f64 oracle."""
     import ctypes as C
     m, n, k = 4096, 2048, 4096
     a = TensorHandle.uniform(client, (m, k), ElemType.BF16, SEED, 700, -1.0, 1.0)
     b = TensorHandle.uniform(client, (n, k), ElemType.BF16, SEED, 701, -1.0, 1.0)
     d = _bench_desc(m, n, k, N.DTYPE_BF16, N.DTYPE_BF16)
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256X128
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_192X192
     outs = []
     for algo in (N.GEMM_ALGO_AUTO, N.GEMM_ALGO_LP_128):
         d.algo = algo
@@ -175,7 +176,7 @@ def test_mid_size_4096x2048x4096_as_benched_takes_the_256x128_tile(client, oracl
     rows = np.array([0, 127, 128, 255, 256, 2047, 2048 + 129, 4095])
     a_bits = oracle.to_bf16(oracle.fill_uniform(m * k, 700, -1.0, 1.0))
     b_bits = oracle.to_bf16(oracle.fill_uniform(n * k, 701, -1.0, 1.0))
-    _bf16_rows_check(oracle, a_bits, b_bits, outs[0][rows], rows, k, n, case="4096x2048x4096 bf16 on the 256x128 tile, 8 sampled rows vs f64 oracle")
+    _bf16_rows_check(oracle, a_bits, b_bits, outs[0][rows], rows, k, n, case="4096x2048x4096 bf16 on the 192x192 tile, 8 sampled rows vs f64 oracle")
 
 
 def _nn_bench_desc(m, n, k, dtype_ab, dtype_c, batch=1):

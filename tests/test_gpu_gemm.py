@@ -26,7 +26,7 @@ REL = 1e-5
 ALGOS = {"auto": N.GEMM_ALGO_AUTO, "generic": N.GEMM_ALGO_GENERIC, "f32": N.GEMM_ALGO_F32_MFMA,
          "lp128": N.GEMM_ALGO_LP_128, "lp256": N.GEMM_ALGO_LP_256, "lp256w4": N.GEMM_ALGO_LP_256W4, "lp256p": N.GEMM_ALGO_LP_256P,
          "lp256q": N.GEMM_ALGO_LP_256Q, "skinny": N.GEMM_ALGO_SKINNY, "stream64": N.GEMM_ALGO_STREAM64,
-         "lp256x128": N.GEMM_ALGO_LP_256X128, "nnrows": N.GEMM_ALGO_NNROWS, "lp256x192": N.GEMM_ALGO_LP_256X192}
+         "lp256x128": N.GEMM_ALGO_LP_256X128, "nnrows": N.GEMM_ALGO_NNROWS, "lp256x192": N.GEMM_ALGO_LP_256X192, "lp192x192": N.GEMM_ALGO_LP_192X192}
 
 
 def _to_dev(client, oracle, x, dtype):
@@ -223,32 +223,6 @@ def test_generic_parity_any_shape(client, oracle, dtype, out, trans_b, m, n, k):
     run_case(client, oracle, m, n, k, dtype, out, trans_b, ALGOS["generic"])
 
 
-LP256_CASES = [(256, 256, 64), (256, 256, 128), (256, 512, 192), (512, 512, 512), (300, 260, 128), (1, 256, 64),
-               (257, 255, 320), (768, 256, 1024)]
-
-
-@pytest.mark.parametrize("m,n,k", LP256_CASES)
-@pytest.mark.parametrize("dtype", [ElemType.BF16, ElemType.F16])
-@pytest.mark.parametrize("out", ["f32", "same"])
-def test_lp256_parity(client, oracle, m, n, k, dtype, out):
-    run_case(client, oracle, m, n, k, dtype, ElemType.F32 if out == "f32" else dtype, True, ALGOS["lp256"])
-
-
-def test_lp256_identity_and_batch(client, oracle):
-    run_case(client, oracle, 256, 256, 128, ElemType.BF16, ElemType.BF16, True, ALGOS["lp256"], batch=3)
-    run_case(client, oracle, 512, 256, 64, ElemType.BF16, ElemType.F32, True, ALGOS["lp256"], batch=2, bcast_b=True,
-             lda=72, ldb=64, ldc=260)
-    m = n = k = 512
-    eye = np.eye(m, dtype=np.float32)
-    bmat = ((np.arange(k)[:, None] * 3 + np.arange(n)[None, :] * 7) % 251).astype(np.float32)
-    ta, _ = _to_dev(client, oracle, eye, ElemType.BF16)
-    tb, _ = _to_dev(client, oracle, np.ascontiguousarray(bmat.T), ElemType.BF16)
-    c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 4), ElemType.F32)
-    ops.matmul(client, TensorHandle.new(ta.handle, (m, k), (k, 1), ElemType.BF16),
-               TensorHandle.new(tb.handle, (k, n), (1, k), ElemType.BF16), c, algo=ALGOS["lp256"])
-    assert np.array_equal(c.to_numpy(client), bmat)
-
-
 SPLITK_CASES = [(64, 1024, 4096), (1, 512, 2048), (128, 128, 8192), (200, 130, 1024), (64, 256, 576)]
 
 
@@ -420,38 +394,40 @@ def test_lp256w4_c_rows_off_the_16_byte_grid(client, oracle, m, n, k, dtype, out
 
 
 # ---- the 256 x 192 tile of the 4-wave kernel (gemm_lp256w4.hip NJ = 3; round 5) ------------------------------------------------
-X192_CASES = [(256, 192, 64), (256, 384, 128), (512, 576, 512), (300, 200, 128), (1, 192, 64), (257, 191, 320), (255, 385, 192),
+X192_CASES = [(256, 192, 64), (192, 192, 64), (384, 384, 128), (256, 384, 128), (512, 576, 512), (300, 200, 128), (1, 192, 64), (257, 191, 320), (255, 385, 192), (193, 100, 128),
               (700, 40, 256), (8, 8, 64), (513, 1000, 128), (768, 960, 1024), (3072, 3072, 256)]
 
 
+@pytest.mark.parametrize("tile", ["lp256x192", "lp192x192"])
 @pytest.mark.parametrize("m,n,k", X192_CASES)
 @pytest.mark.parametrize("dtype,out", [(ElemType.BF16, "f32"), (ElemType.BF16, "same"), (ElemType.F16, "same"), (ElemType.F16, "f32")])
-def test_lp256x192_parity_and_the_bits_of_the_square_tile(client, oracle, m, n, k, dtype, out):
+def test_lp256x192_parity_and_the_bits_of_the_square_tile(client, oracle, m, n, k, dtype, out, tile):
     """The 256 x 192 tile against the oracle on whole and ragged grids (pitched C: the 0xEE padding stays), and against the
     256 x 256 tile of the same kernel bit for bit -- every output element sums the same K-tiles through the same MFMAs in the
     same order, only the tile it lives in differs."""
     out_dtype = ElemType.F32 if out == "f32" else dtype
     ldc = (n + 7) // 8 * 8 + 8
-    run_case(client, oracle, m, n, k, dtype, out_dtype, True, ALGOS["lp256x192"], ldc=ldc)
+    run_case(client, oracle, m, n, k, dtype, out_dtype, True, ALGOS[tile], ldc=ldc)
     a = TensorHandle.uniform(client, (m, k), dtype, 5, 1, -1.0, 1.0)
     b = TensorHandle.uniform(client, (n, k), dtype, 5, 2, -1.0, 1.0)
     bt = TensorHandle.new(b.handle, (k, n), (1, k), dtype)
     got = []
-    for algo in ("lp256x192", "lp256w4"):
+    for algo in (tile, "lp256w4"):
         c = TensorHandle.new_contiguous((m, n), client.empty(m * n * out_dtype.size()), out_dtype)
         ops.matmul(client, a, bt, c, algo=ALGOS[algo])
         got.append(client.read_one(c.handle).copy())
     assert np.array_equal(got[0], got[1])
 
 
+@pytest.mark.parametrize("tile", ["lp256x192", "lp192x192"])
 @pytest.mark.parametrize("pad", [1, 3])
-def test_lp256x192_c_rows_off_the_16_byte_grid_batches_and_refusals(client, oracle, pad):
-    run_case(client, oracle, 300, 261, 128, ElemType.BF16, ElemType.BF16, True, ALGOS["lp256x192"], ldc=261 + pad, batch=2)
-    run_case(client, oracle, 513, 1001, 128, ElemType.BF16, ElemType.F32, True, ALGOS["lp256x192"], ldc=1001 + pad)
-    run_case(client, oracle, 256, 384, 192, ElemType.F16, ElemType.F16, True, ALGOS["lp256x192"], batch=3, bcast_b=True, lda=200, ldb=208)
+def test_lp256x192_c_rows_off_the_16_byte_grid_batches_and_refusals(client, oracle, pad, tile):
+    run_case(client, oracle, 300, 261, 128, ElemType.BF16, ElemType.BF16, True, ALGOS[tile], ldc=261 + pad, batch=2)
+    run_case(client, oracle, 513, 1001, 128, ElemType.BF16, ElemType.F32, True, ALGOS[tile], ldc=1001 + pad)
+    run_case(client, oracle, 256, 384, 192, ElemType.F16, ElemType.F16, True, ALGOS[tile], batch=3, bcast_b=True, lda=200, ldb=208)
     for kw in ({"dtype": ElemType.F32}, {"trans_b": False}, {"k": 96}):             # f32 operands, row-major B, K off the K-tile grid
         with pytest.raises(ServerError):
-            run_case(client, oracle, 256, 192, kw.get("k", 128), kw.get("dtype", ElemType.BF16), ElemType.F32, kw.get("trans_b", True), ALGOS["lp256x192"])
+            run_case(client, oracle, 256, 192, kw.get("k", 128), kw.get("dtype", ElemType.BF16), ElemType.F32, kw.get("trans_b", True), ALGOS[tile])
 
 
 def test_unaligned_c_gives_the_bits_of_the_aligned_form_and_stays_inside_its_rows(client, oracle):
@@ -589,7 +565,7 @@ def test_lp256q_oracle_f16_identity_pitched_c_and_refusals(client, oracle):
         assert e.value.code == N.E_UNSUPPORTED
 
 
-@pytest.mark.parametrize("algo", ["lp128", "lp256", "lp256w4", "lp256p", "f32"])     # (lp256q: its own bit-identity test above)
+@pytest.mark.parametrize("algo", ["lp128", "lp256w4", "lp256p", "f32"])     # (lp256q: its own bit-identity test above)
 def test_race_screen_bitwise_repeatability(client, oracle, algo):
     # the counted-vmcnt / barrier pipeline must give the same bits on every launch (guide: "place reads by
     # the vmcnt/barrier count, never by clean runs") -- 25 launches at a multi-wave-per-CU size
@@ -842,8 +818,8 @@ def test_auto_selection_and_errors(client):
     d = N.GemmDesc(m=2048, n=2048, k=2048, batch=1, lda=2048, ldb=2048, ldc=2048, dtype_ab=N.DTYPE_BF16,
                    dtype_c=N.DTYPE_BF16, trans_b=1)
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_128             # 64 tiles of 256^2: the 128x128 kernel fills the chip better
-    d.m = d.n = d.lda = d.ldb = d.ldc = d.k = 3072                      # 144 tiles of 256^2: measured +55 % on the 256x256 kernel
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    d.m = d.n = d.lda = d.ldb = d.ldc = d.k = 3072                      # 144 tiles of 256^2 (+55 % over the 128x128 kernel) -- and since
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_192X192         # round 5 256 tiles of 192^2 of the same kernel: another +25 %
     d = N.GemmDesc(m=8192, n=8192, k=8192, batch=1, lda=8192, ldb=8192, ldc=8192, dtype_ab=N.DTYPE_BF16,
                    dtype_c=N.DTYPE_BF16, trans_b=1)
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
@@ -1298,7 +1274,11 @@ def test_output_bound_shapes_select_the_small_tile(client):
     assert sel(4, 2048, 4096) == sel(384, 4, 8192) == sel(3, 512, 14336) == sel(4096, 4, 14336) == N.GEMM_ALGO_SKINNY   # 3-4 rows, fewer than 192 streaming workgroups
     assert sel(8192, 4, 2048) == sel(4, 8192, 8192) == N.GEMM_ALGO_STREAM64           # ... from 192 up the streaming kernel
     # the 256 x 128 tile: more than one 128x128 tile per CU, at most one 256 x 128 tile per CU, long K (round 3)
-    assert sel(4096, 2048, 4096) == sel(2560, 2560, 3072) == sel(2048, 2048, 8192, batch=2) == sel(4096, 1536, 8192) == N.GEMM_ALGO_LP_256X128
+    assert sel(2048, 3072, 8192) == sel(4096, 1536, 8192) == N.GEMM_ALGO_LP_256X128
+    # round 5: one round of 192 x 192 tiles (144-256 of them) of the 4-wave kernel takes the rest of that band, 256 x 192 tiles where
+    # those would need a second round
+    assert sel(4096, 2048, 4096) == sel(2560, 2560, 3072) == sel(2048, 2048, 8192, batch=2) == sel(3072, 3072, 3072) == sel(2304, 2304, 2304) == N.GEMM_ALGO_LP_192X192
+    assert sel(4096, 3072, 4096) == sel(3328, 3328, 4096) == N.GEMM_ALGO_LP_256X192 and sel(3584, 3584, 3584) == sel(4096, 4096, 4096) == N.GEMM_ALGO_LP_256W4
     assert sel(4096, 2048, 2048) == sel(2048, 2048, 8192) == sel(3072, 2560, 1024) == N.GEMM_ALGO_LP_128   # K <= 2048 / one 128x128 tile per CU
     assert sel(4096, 2304, 4096) == N.GEMM_ALGO_LP_256W4                              # 288 tiles of 256 x 128: two rounds -- the 256x256 tile
     assert sel(32, 512, 2048) == sel(512, 16, 2048) == sel(32, 6144, 8192) == N.GEMM_ALGO_STREAM64   # few workgroups are fine up to K = 2048; 192 at any K

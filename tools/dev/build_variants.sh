@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../../cubecl_amd/csrc"
 NAME=$1; FLAGS=$2; shift 2
-FILES=${@:-gemm_lp256.hip}
+FILES=${@:-gemm_lp256w4.hip}
 mkdir -p variants/obj_$NAME
 OBJS=""
 for f in $(sed -n 's/^SRCS := //p' Makefile); do
