@@ -214,12 +214,14 @@ def usable_cores():
 # sha256 of the kernel's sources at the time of the pass (tools/pmc_all.sh) and bench.py prints the figure only when the
 # sources it is running from still hash to the same value (and the demangled kernel name is the one expected).
 KERNEL_SOURCES = {
-    "gemm": ("cubecl_amd/csrc/gemm_lp256w4.hip", "cubecl_amd/csrc/gemm_common.hpp", "cubecl_amd/csrc/internal.hpp"),
+    "gemm": ("cubecl_amd/csrc/gemm_lp256m16.hip", "cubecl_amd/csrc/gemm_common.hpp", "cubecl_amd/csrc/internal.hpp"),
     "gemm_q": ("cubecl_amd/csrc/gemm_lp256q.hip", "cubecl_amd/csrc/gemm_common.hpp", "cubecl_amd/csrc/internal.hpp"),
     "reduce": ("cubecl_amd/csrc/reduce.hip", "cubecl_amd/csrc/internal.hpp"),
 }
 PROFILES_DIR = ROOT / "profiles"
-HEADLINE_KERNEL = "gemm_lp256w4_kernel<1, 1, false, 1, false, false>"     # bf16 x bf16 -> bf16 C, [N][K] B, unscaled (what rocprofv3 prints)
+HEADLINE_KERNEL = "gemm_lp256m16_kernel<1, 1>"     # bf16 x bf16 -> bf16 C, [N][K] B, on v_mfma_f32_16x16x32 (what rocprofv3 prints; until round 4:
+                                                   # gemm_lp256w4_kernel<1, 1, false, 1, false, false>)
+HEADLINE_ALGO = 14                                 # MI355_GEMM_ALGO_LP_256M16: what AUTO takes for config C3
 REDUCE_SUM_KERNEL = "reduce_kernel<0, 0, 0>"      # <VOP = MI355_REDUCE_SUM, AOP = none, DT = f32> (until round 3: <true, false, 0>)
 C5_KERNEL = "gemm_lp256q_kernel<1, 1, false>"             # <bf16, one dripped store per K-tile, [N][K] B>: batch 512 x 2048^3
 

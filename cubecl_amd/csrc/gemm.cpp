@@ -422,8 +422,19 @@ bool prefers_dripped_stores(const mi355_gemm_desc &d, const void *a, const void 
 int32_t select_auto(const mi355_gemm_desc &d, const void *a, const void *b, const void *c, bool strip_kernel = true)
 {
     const int32_t algo = select(d, a, b, c, strip_kernel);
-    if (algo != MI355_GEMM_ALGO_LP_256W4 || !prefers_persistent(d, a, b, c)) return algo;
-    return prefers_dripped_stores(d, a, b, c) ? MI355_GEMM_ALGO_LP_256Q : MI355_GEMM_ALGO_LP_256P;
+    if (algo != MI355_GEMM_ALGO_LP_256W4) return algo;
+    if (prefers_persistent(d, a, b, c)) return prefers_dripped_stores(d, a, b, c) ? MI355_GEMM_ALGO_LP_256Q : MI355_GEMM_ALGO_LP_256P;
+    // Round 5: several full rounds of 256x256 tiles of [N][K] 16-bit operands run at the chip's POWER limit on random data; there the
+    // same tile on v_mfma_f32_16x16x32 (gemm_lp256m16.hip: half the accumulator bytes through the register file per FLOP) holds
+    // 1.83-1.87 GHz where the 32x32x16 kernel holds 1.63: 8192^3 1 440 -> 1 533-1 563 TFLOP/s.  Below ~3 rounds the chip is not
+    // power-bound and the wider instruction's slack per issue slot wins (4096^3 a tie, 3584^3 -4 %): profiles/r05_m16_ab.txt.
+    // (Not where the launcher would split a ragged last round off: that planner's model is the 32x32 kernel's.)
+    {
+        const int64_t tiles256 = ((d.m + 255) / 256) * ((d.n + 255) / 256) * d.batch;
+        tail_plan tp;
+        if (tiles256 >= 768 && gemm_lp256m16_supports(d, a, b, c) && !plan_tail_split(d, tp)) return MI355_GEMM_ALGO_LP_256M16;
+    }
+    return algo;
 }
 
 int32_t run_tail_split(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c,
@@ -509,6 +520,7 @@ MI355_API int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_ge
     case MI355_GEMM_ALGO_NNROWS: return launch_gemm_nnrows(ctx, s, d, a, b, c);
     case MI355_GEMM_ALGO_LP_256X192: return launch_gemm_lp256x192(ctx, s, d, a, b, c);
     case MI355_GEMM_ALGO_LP_192X192: return launch_gemm_lp256x192(ctx, s, d, a, b, c, 192);
+    case MI355_GEMM_ALGO_LP_256M16: return launch_gemm_lp256m16(ctx, s, d, a, b, c);
     default: return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_gemm: unknown algo %d", algo);
     }
 }

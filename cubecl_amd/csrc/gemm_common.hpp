@@ -130,6 +130,8 @@ bool gemm_lp256q_supports(const mi355_gemm_desc &d, const void *a, const void *b
 bool gemm_lp256w4_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 int32_t launch_gemm_lp256x192(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c, int tile_rows = 256);   // gemm_lp256w4.hip, NJ = 3 (tile_rows 192: NI = 3 too)
 bool gemm_lp256x192_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
+int32_t launch_gemm_lp256m16(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);   // gemm_lp256m16.hip
+bool gemm_lp256m16_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 int32_t launch_gemm_skinny(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 bool gemm_skinny_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 int32_t launch_gemm_nnrows(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);

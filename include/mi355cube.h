@@ -402,7 +402,9 @@ enum {
                                      operands, K slices folded by the last workgroup to arrive (gemm_nnrows.hip) */
     MI355_GEMM_ALGO_LP_256X192 = 12, /* bf16/f16, [N][K] rhs: the 4-wave kernel of _LP_256W4 on a 256 x 192 tile (each wave 128 x 96):
                                      grids on which the square tile leaves CUs idle (ABI 8; gemm_lp256w4.hip NJ = 3) */
-    MI355_GEMM_ALGO_LP_192X192 = 13  /* ... and on a 192 x 192 tile (each wave 96 x 96; NJ = NI = 3) */
+    MI355_GEMM_ALGO_LP_192X192 = 13, /* ... and on a 192 x 192 tile (each wave 96 x 96; NJ = NI = 3) */
+    MI355_GEMM_ALGO_LP_256M16 = 14   /* bf16/f16, [N][K] rhs: the 256 x 256 tile on v_mfma_f32_16x16x32 (eight MFMAs per A fragment: the
+                                     order that issues at 16 cycles and holds a higher clock on random operands; gemm_lp256m16.hip) */
 };
 
 int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_gemm_desc *desc,

@@ -69,7 +69,7 @@ def test_c3_bf16_8192_sampled_rows_linearity_and_kernel_agreement(client, oracle
     bt = TensorHandle.new(b.handle, (S, S), (1, S), ElemType.BF16)
     c = TensorHandle.new_contiguous((S, S), client.empty(S * S * 4), ElemType.F32)
     d = N.GemmDesc(m=S, n=S, k=S, batch=1, lda=S, ldb=S, ldc=S, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_F32, trans_b=1)
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256M16
     ops.matmul(client, a, bt, c)
     got = c.to_numpy(client)
     rows = np.array([0, 1, 255, 256, 4095, 4096, 8191, 5003])
@@ -137,11 +137,11 @@ def test_c3_bf16_8192_bf16_output_as_benched(client, oracle):
     b = TensorHandle.uniform(client, (S, S), ElemType.BF16, SEED, 200, -1.0, 1.0)        # stored [N][K]
     c = TensorHandle.new_contiguous((S, S), client.empty(S * S * 2), ElemType.BF16)
     d = _bench_desc(S, S, S, N.DTYPE_BF16, N.DTYPE_BF16)
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256M16
     client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()),
                                           C.c_void_p(c.device_ptr())))
     got = c.to_numpy(client).reshape(S, S)
-    rows = np.array([0, 1, 127, 128, 255, 256, 4095, 4096, 8191, 5003, 6144 + 77])      # every wave row-block position
+    rows = np.array([0, 1, 15, 16, 127, 128, 255, 256, 4095, 4096, 8191, 5003, 6144 + 77])      # every wave row-block position
     a_bits = oracle.to_bf16(oracle.fill_uniform(S * S, 100, -1.0, 1.0))
     b_bits = oracle.to_bf16(oracle.fill_uniform(S * S, 200, -1.0, 1.0))
     assert np.array_equal(b.to_numpy(client).reshape(-1)[-(1 << 16):], b_bits[-(1 << 16):])   # device RNG == oracle RNG
@@ -196,7 +196,11 @@ def test_c3_bf16_8192_row_major_rhs_is_native_and_bit_identical_to_the_k_contigu
     b_kn = ops.into_contiguous(client, TensorHandle.new(b_nk.handle, (S, S), (1, S), ElemType.BF16))   # its transpose, [K][N]
     outs = []
     for d, b in ((_bench_desc(S, S, S, N.DTYPE_BF16, N.DTYPE_BF16), b_nk), (_nn_bench_desc(S, S, S, N.DTYPE_BF16, N.DTYPE_BF16), b_kn)):
-        assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4 and ops.gemm_relayout_plan(client, d) == (False, False)
+        # (AUTO takes the 16x16x32 form of the tile for the K-contiguous rhs since round 5 -- another summation order; the
+        # statement here is about the STAGING of the 32x32x16 kernel, so that kernel is named for the K-contiguous launch)
+        assert ops.gemm_select(client, d) == (N.GEMM_ALGO_LP_256M16 if d.trans_b else N.GEMM_ALGO_LP_256W4) and ops.gemm_relayout_plan(client, d) == (False, False)
+        if d.trans_b:
+            d.algo = N.GEMM_ALGO_LP_256W4
         c = TensorHandle.new_contiguous((S, S), client.empty(S * S * 2), ElemType.BF16)
         client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()),
                                               C.c_void_p(c.device_ptr())))
@@ -566,7 +570,7 @@ def test_gemm_operand_larger_than_4_gib(client, oracle):
     a = TensorHandle.new_contiguous((m, k), ha, ElemType.BF16)
     c = TensorHandle.new_contiguous((m, n), client.empty(4 * m * n), ElemType.F32)
     d = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=k, ldc=n, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_F32, trans_b=1)
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256M16                  # 2110 tiles of 256^2: the 16x16x32 form (same addressing)
     ops.matmul(client, a, TensorHandle.new(b.handle, (k, n), (1, k), ElemType.BF16), c)
     for r, bits in zip(rows, a_rows):
         got = client.read_one(c.handle.offset_start_by(4 * r * n).offset_end_by(4 * (m - r - 1) * n)).view(np.float32)

@@ -26,7 +26,7 @@ REL = 1e-5
 ALGOS = {"auto": N.GEMM_ALGO_AUTO, "generic": N.GEMM_ALGO_GENERIC, "f32": N.GEMM_ALGO_F32_MFMA,
          "lp128": N.GEMM_ALGO_LP_128, "lp256": N.GEMM_ALGO_LP_256, "lp256w4": N.GEMM_ALGO_LP_256W4, "lp256p": N.GEMM_ALGO_LP_256P,
          "lp256q": N.GEMM_ALGO_LP_256Q, "skinny": N.GEMM_ALGO_SKINNY, "stream64": N.GEMM_ALGO_STREAM64,
-         "lp256x128": N.GEMM_ALGO_LP_256X128, "nnrows": N.GEMM_ALGO_NNROWS, "lp256x192": N.GEMM_ALGO_LP_256X192, "lp192x192": N.GEMM_ALGO_LP_192X192}
+         "lp256x128": N.GEMM_ALGO_LP_256X128, "nnrows": N.GEMM_ALGO_NNROWS, "lp256x192": N.GEMM_ALGO_LP_256X192, "lp192x192": N.GEMM_ALGO_LP_192X192, "lp256m16": N.GEMM_ALGO_LP_256M16}
 
 
 def _to_dev(client, oracle, x, dtype):
@@ -430,6 +430,38 @@ def test_lp256x192_c_rows_off_the_16_byte_grid_batches_and_refusals(client, orac
             run_case(client, oracle, 256, 192, kw.get("k", 128), kw.get("dtype", ElemType.BF16), ElemType.F32, kw.get("trans_b", True), ALGOS[tile])
 
 
+# ---- the 256 x 256 tile on v_mfma_f32_16x16x32 (gemm_lp256m16.hip; round 5) -----------------------------------------------------
+M16_CASES = [(256, 256, 64), (256, 256, 128), (256, 512, 192), (512, 512, 512), (768, 256, 1024), (512, 1024, 320), (256, 256, 2048),
+             (300, 260, 128), (1, 256, 64), (257, 255, 320), (255, 513, 192), (700, 40, 256), (8, 8, 64), (513, 1000, 128)]
+
+
+@pytest.mark.parametrize("m,n,k", M16_CASES)
+@pytest.mark.parametrize("dtype,out", [(ElemType.BF16, "f32"), (ElemType.BF16, "same"), (ElemType.F16, "same"), (ElemType.F16, "f32")])
+def test_lp256m16_parity(client, oracle, m, n, k, dtype, out):
+    """The 16x16x32 form of the 256 x 256 kernel against the oracle: whole and ragged grids, pitched C (the 0xEE padding stays)."""
+    ldc = (n + 7) // 8 * 8 + 8
+    run_case(client, oracle, m, n, k, dtype, ElemType.F32 if out == "f32" else dtype, True, ALGOS["lp256m16"], ldc=ldc)
+
+
+@pytest.mark.parametrize("pad", [1, 3])
+def test_lp256m16_c_rows_off_the_16_byte_grid_batches_identity_and_refusals(client, oracle, pad):
+    run_case(client, oracle, 300, 261, 128, ElemType.BF16, ElemType.BF16, True, ALGOS["lp256m16"], ldc=261 + pad, batch=2)
+    run_case(client, oracle, 513, 1001, 128, ElemType.BF16, ElemType.F32, True, ALGOS["lp256m16"], ldc=1001 + pad)
+    run_case(client, oracle, 256, 512, 192, ElemType.F16, ElemType.F16, True, ALGOS["lp256m16"], batch=3, bcast_b=True, lda=200, ldb=208)
+    m = n = k = 512                                                      # identity x B returns B's bits: every fragment lands where it belongs
+    eye = np.eye(m, dtype=np.float32)
+    bmat = ((np.arange(k)[:, None] * 3 + np.arange(n)[None, :] * 7) % 251).astype(np.float32)
+    ta, _ = _to_dev(client, oracle, eye, ElemType.BF16)
+    tb, _ = _to_dev(client, oracle, np.ascontiguousarray(bmat.T), ElemType.BF16)
+    c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 4), ElemType.F32)
+    ops.matmul(client, TensorHandle.new(ta.handle, (m, k), (k, 1), ElemType.BF16), TensorHandle.new(tb.handle, (k, n), (1, k), ElemType.BF16), c,
+               algo=ALGOS["lp256m16"])
+    assert np.array_equal(c.to_numpy(client), bmat)
+    for kw in ({"dtype": ElemType.F32}, {"trans_b": False}, {"k": 96}):
+        with pytest.raises(ServerError):
+            run_case(client, oracle, 256, 256, kw.get("k", 128), kw.get("dtype", ElemType.BF16), ElemType.F32, kw.get("trans_b", True), ALGOS["lp256m16"])
+
+
 def test_unaligned_c_gives_the_bits_of_the_aligned_form_and_stays_inside_its_rows(client, oracle):
     """4100 x 4100 x 512 bf16 through AUTO (289 tiles -> the 256x256 kernel): C placed one element into an allocation with a
     row pitch of 4101 gives the bits of the aligned product, and neither the element before it, the pitch column nor the tail of
@@ -822,7 +854,7 @@ def test_auto_selection_and_errors(client):
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_192X192         # round 5 256 tiles of 192^2 of the same kernel: another +25 %
     d = N.GemmDesc(m=8192, n=8192, k=8192, batch=1, lda=8192, ldb=8192, ldc=8192, dtype_ab=N.DTYPE_BF16,
                    dtype_c=N.DTYPE_BF16, trans_b=1)
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256M16          # four rounds at the power limit: the 16x16x32 form (round 5)
     # several rounds of short tiles: the persistent form (config C5's shard: 64 x 2048^3); long K or a single round: not
     d = N.GemmDesc(m=2048, n=2048, k=2048, batch=64, lda=2048, ldb=2048, ldc=2048, stride_a=2048 * 2048, stride_b=2048 * 2048,
                    stride_c=2048 * 2048, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_BF16, trans_b=1)
@@ -837,9 +869,9 @@ def test_auto_selection_and_errors(client):
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
     d = N.GemmDesc(m=8192 + 8, n=8192, k=8192, batch=1, lda=8192, ldb=8192, ldc=8192, dtype_ab=N.DTYPE_BF16,
                    dtype_c=N.DTYPE_BF16, trans_b=1)
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4          # ragged M / N stay on the fast kernel
-    d.ldc = 8192 + 3                                                   # C rows not 16-byte aligned: the same kernel stores element-wise
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4          # ragged M / N stay on the fast kernel (4.1 rounds: the launcher
+    d.ldc = 8192 + 3                                                   # splits the last strip off, the 32x32x16 kernel's ground)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4          # C rows not 16-byte aligned: the same kernel stores element-wise
     d = N.GemmDesc(m=100, n=100, k=7, batch=1, lda=7, ldb=7, ldc=100, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_F32, trans_b=1)
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_GENERIC
     a = TensorHandle.new_contiguous((8, 8), client.empty(256), ElemType.F32)
@@ -1279,7 +1311,8 @@ def test_output_bound_shapes_select_the_small_tile(client):
     # those would need a second round
     assert sel(4096, 2048, 4096) == sel(2560, 2560, 3072) == sel(2048, 2048, 8192, batch=2) == sel(3072, 3072, 3072) == sel(2304, 2304, 2304) == N.GEMM_ALGO_LP_192X192
     assert sel(4096, 3072, 4096) == sel(3328, 3328, 4096) == N.GEMM_ALGO_LP_256X192 and sel(3584, 3584, 3584) == sel(4096, 4096, 4096) == N.GEMM_ALGO_LP_256W4
-    assert sel(4096, 2048, 2048) == sel(2048, 2048, 8192) == sel(3072, 2560, 1024) == N.GEMM_ALGO_LP_128   # K <= 2048 / one 128x128 tile per CU
+    assert sel(2048, 2048, 8192) == N.GEMM_ALGO_LP_128                                  # one 128x128 tile per CU (121 tiles of 192^2: too few)
+    assert sel(4096, 2048, 2048) == sel(3072, 2560, 1024) == N.GEMM_ALGO_LP_192X192       # round 5 (were the 128x128 kernel's: 1059 / 781, 918 / 693 TFLOP/s)
     assert sel(4096, 2304, 4096) == N.GEMM_ALGO_LP_256W4                              # 288 tiles of 256 x 128: two rounds -- the 256x256 tile
     assert sel(32, 512, 2048) == sel(512, 16, 2048) == sel(32, 6144, 8192) == N.GEMM_ALGO_STREAM64   # few workgroups are fine up to K = 2048; 192 at any K
     assert sel(32, 512, 8192) == sel(512, 16, 8192) == sel(16, 2048, 8192) == sel(32, 1024, 4096) == N.GEMM_ALGO_LP_128   # round 4: split-K instead

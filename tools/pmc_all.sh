@@ -58,7 +58,7 @@ fetch, nf = med(rows_of("fetch"), "FETCH_SIZE", K)
 write, nw = med(rows_of("write"), "WRITE_SIZE", K)
 if fetch is not None and write is not None:
     fb, wb = int(fetch * 1024 * 2), int(write * 1024)
-    traffic[f"gemm_bf16_{size}_algo5"] = dict(stamp, kernel=kname(rows_of("fetch"), K), source_sha=bench.kernel_source_sha("gemm"),
+    traffic[f"gemm_bf16_{size}_algo{bench.HEADLINE_ALGO}"] = dict(stamp, kernel=kname(rows_of("fetch"), K), source_sha=bench.kernel_source_sha("gemm"),
         hbm_bytes_per_launch=fb + wb, fetch_bytes=fb, write_bytes=wb, algorithmic_bytes=3 * size * size * 2,
         FETCH_SIZE_KiB_raw=fetch, WRITE_SIZE_KiB_raw=write, launches=nf,
         note="rocprofv3 --pmc, one counter per pass, medians over the launches of one bench.py --no-extras run; FETCH_SIZE x2 "
@@ -67,8 +67,8 @@ else:
     print("!! no headline GEMM rows in the FETCH_SIZE / WRITE_SIZE passes")
 hit, _ = med(rows_of("l2"), "TCC_HIT_sum", K)
 miss, _ = med(rows_of("l2"), "TCC_MISS_sum", K)
-if hit is not None and miss is not None and f"gemm_bf16_{size}_algo5" in traffic:
-    traffic[f"gemm_bf16_{size}_algo5"].update(TCC_HIT_sum=hit, TCC_MISS_sum=miss, l2_hit_rate=round(hit / (hit + miss), 4))
+if hit is not None and miss is not None and f"gemm_bf16_{size}_algo{bench.HEADLINE_ALGO}" in traffic:
+    traffic[f"gemm_bf16_{size}_algo{bench.HEADLINE_ALGO}"].update(TCC_HIT_sum=hit, TCC_MISS_sum=miss, l2_hit_rate=round(hit / (hit + miss), 4))
 agg = collections.defaultdict(list)
 for r in rows_of("reduce"):
     if "reduce_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
@@ -108,7 +108,7 @@ util = {}
 if busy and active:
     util[f"gemm_bf16_{size}"] = dict(stamp, kernel=kname(rows_of("mfma"), K), source_sha=bench.kernel_source_sha("gemm"),
         SQ_VALU_MFMA_BUSY_CYCLES=busy, GRBM_GUI_ACTIVE=active, mfma_busy_cycles_per_simd=busy / 1024, resident_cycles_per_xcd=active / 8,
-        mfma_util=round((busy / 1024) / (active / 8), 4), expected_busy_cycles_32_per_mfma=32 * size ** 3 / (32 * 32 * 16), launches=nb,
+        mfma_util=round((busy / 1024) / (active / 8), 4), expected_busy_cycles_16_per_mfma=16 * size ** 3 / (16 * 16 * 32), launches=nb,
         note="rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace, medians over the launches of one bench.py --no-extras run")
 else:
     print("!! no headline GEMM rows in the MFMA pass")
