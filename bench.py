@@ -51,6 +51,9 @@ def parse_args():
                          "runtime in the process; the unique id travels through the launcher's TCP store) or through torch.distributed")
     ap.add_argument("--extras", default="all", help="comma list of extra sections to run (default: all)")
     ap.add_argument("--reduce-elements", type=int, default=1 << 28, help="elements of the array-wide reduction extra (2^28 f32 = 1 GiB = config C4; rehearsals shrink it)")
+    ap.add_argument("--threads", type=int, default=0,
+                    help="the reference's process model instead of one process per GPU: ONE process, one host thread + one context per device "
+                         "(crates/cubecl-common/src/device/handle/channel.rs:24-37), N devices; headline + the C4 exchange only")
     return ap.parse_args()
 
 
@@ -277,6 +280,10 @@ def pmc_mfma_util_entry(size):
     return _pmc_entry("pmc_mfma_util.json", f"gemm_bf16_{size}", "gemm", HEADLINE_KERNEL)
 
 
+ALGO_NAMES = {1: "generic", 2: "f32_mfma", 3: "lp128", 4: "lp256 (alias of lp256w4)", 5: "lp256w4", 6: "lp256p", 7: "lp256q", 8: "skinny", 9: "stream64",
+              10: "lp256x128", 11: "nnrows", 12: "lp256x192", 13: "lp192x192", 14: "lp256m16"}
+
+
 def gemm_desc(N, m, n, k, dtype_ab, dtype_c, trans_b=1, batch=1, algo=0):
     return N.GemmDesc(m=m, n=n, k=k, batch=batch, lda=k, ldb=(k if trans_b else n), ldc=n, stride_a=m * k,
                       stride_b=n * k, stride_c=m * n, dtype_ab=dtype_ab, dtype_c=dtype_c, trans_a=0, trans_b=trans_b,
@@ -299,8 +306,115 @@ def self_spawn(gpus):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+def main_threads(args):
+    """`bench.py --threads N`: the reference's own multi-device model -- one process, one server per DeviceId, each driven by its
+    own host thread (DeviceHandle: crates/cubecl-common/src/device/handle/channel.rs:24-37), one communicator per sorted id set
+    joined from the device threads (comm_init blocks until every rank has called it: crates/cubecl-cuda/src/compute/
+    server.rs:669-703).  Same step, same timing rule as the one-process-per-GPU form: every thread warms up, all meet at a host
+    barrier behind their own device sync, every thread launches K steps and waits for its stream, the SLOWEST thread's wall
+    time counts, value = N x work / that.  Then config C4 end to end: each device reduces its 1/N slice (fused sum + argmax)
+    and runs the one-collective exchange.  One JSON line, n_gpus = N, config.process_model says which model ran."""
+    import threading
+
+    import numpy as np
+
+    from cubecl_amd import DeviceId, ElemType, Mi355Runtime, TensorHandle, sharded
+    from cubecl_amd import _native as N
+    n, S, K, W = args.threads, args.size, args.steps, args.warmup
+    ids = [DeviceId(0, i) for i in range(n)]
+    uid = bytes(Mi355Runtime.client(ids[0]).comm_unique_id())
+    gate = threading.Barrier(n)
+    out, errors = [None] * n, []
+    flop = 2.0 * S * S * S
+    n_total = args.reduce_elements
+
+    def device_thread(i):
+        try:
+            c = Mi355Runtime.client(ids[i])
+            lib, ctx = c.lib, c.ctx
+            c.comm_init(ids, uid, rank=i)
+            a = TensorHandle.uniform(c, (S, S), ElemType.BF16, SEED, 100 + i, -1.0, 1.0)
+            b = TensorHandle.uniform(c, (S, S), ElemType.BF16, SEED, 200 + i, -1.0, 1.0)
+            cc = c.empty(S * S * 2)
+            d = gemm_desc(N, S, S, S, N.DTYPE_BF16, N.DTYPE_BF16, trans_b=1, algo=args.algo)
+            sel = C.c_int32(args.algo)
+            if args.algo == 0:
+                c._s.check(lib.mi355_gemm_select(ctx, C.byref(d), C.byref(sel)))
+            pa, pb, pc = C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()), C.c_void_p(cc.device_ptr())
+            step = lambda: c._s.check(lib.mi355_gemm(ctx, None, C.byref(d), pa, pb, pc))
+            for _ in range(W):
+                step()
+            c.sync()
+            gate.wait()
+            t0 = time.perf_counter()
+            for _ in range(K):
+                step()
+            c.sync()
+            dt = time.perf_counter() - t0
+            gate.wait()
+            # config C4: this device's slice, then the exchange (one all-gather + the combine kernel), 20 steps
+            start, count = sharded.shard_aligned_range(n_total, i, n, 4)
+            x = TensorHandle.uniform(c, (max(count, 4),), ElemType.F32, SEED, 300 + i, 0.0, 1.0)
+            ws, outs = c.empty(1 << 17), c.empty(64)
+            p_val, p_sum, p_idx = (C.c_void_p(outs.device_ptr() + o) for o in (0, 4, 8))
+            rec = outs.offset_end_by(outs.size - 16)
+            g_sum, g_val, g_idx = (outs.offset_start_by(o).offset_end_by(outs.size - o - w) for o, w in ((32, 4), (36, 4), (40, 8)))
+            ex = sharded.RcclExchange(c, ids, i)
+            starts = [sharded.shard_aligned_range(n_total, r, n, 4)[0] for r in range(n)]
+
+            def c4():
+                c._s.check(lib.mi355_sum_argmax_f32(ctx, None, C.c_void_p(x.device_ptr()), count, p_sum, p_val, p_idx, C.c_void_p(ws.device_ptr()), ws.size))
+                ex.exchange_on_device(rec, starts, g_sum, g_val, g_idx)
+            for _ in range(3):
+                c4()
+            c.sync()
+            gate.wait()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                c4()
+            c.sync()
+            dt4 = (time.perf_counter() - t0) / 20
+            gate.wait()
+            got = np.frombuffer(c.read_one(outs), dtype=np.uint8)
+            out[i] = {"seconds": dt, "algo": sel.value, "c4_seconds": dt4, "c4_sum": float(got[32:36].view(np.float32)[0]),
+                      "c4_max": float(got[36:40].view(np.float32)[0]), "c4_index": int(got[40:48].view(np.uint64)[0]),
+                      "device": c.properties().name.decode()}
+        except BaseException as exc:  # noqa: BLE001
+            errors.append(f"device {i}: {type(exc).__name__}: {exc}"[:300])
+            gate.abort()
+    threads = [threading.Thread(target=device_thread, args=(i,), daemon=True) for i in range(n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    if errors or any(t.is_alive() for t in threads) or any(o is None for o in out):
+        sys.stderr.write("bench.py --threads: " + "; ".join(errors or ["a device thread did not finish"]) + "\n")
+        sys.stderr.flush()
+        os._exit(3)
+    worst = max(o["seconds"] for o in out)
+    worst4 = max(o["c4_seconds"] for o in out)
+    agree = len({(o["c4_sum"], o["c4_max"], o["c4_index"]) for o in out}) == 1
+    value = n * flop * K / worst / 1e12
+    print(json.dumps({
+        "metric": "GEMM TFLOP/s (8192^3 bf16) + reduce GB/s vs roofline", "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": n, "steps": K, "warmup": W,
+        "ms_per_step": round(worst * 1e3 / K, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{S}x{S}x{S} bf16 GEMM, f32 accumulate, bf16 C (BASELINE config C3), one per GPU",
+                   "process_model": "one process, one host thread + one mi355_ctx per device (the reference's DeviceHandle model); one communicator "
+                                    "joined from the device threads",
+                   "kernel": ALGO_NAMES.get(out[0]["algo"], str(out[0]["algo"])), "parallelism": f"batch-sharded x{n}, no data-path collective"},
+        "roofline": {"bound": "mfma", "achieved": round(value / n, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(value / n / PEAK_BF16_TFLOPS, 4),
+                     "traffic": None, "reduce_sum_argmax_exchange_ms": round(worst4 * 1e3, 4),
+                     "reduce_sum_argmax_exchange_GBs_whole_job": round(n_total * 4 / worst4 / 1e9, 1)},
+        "extra": {"reduce_1GiB_f32": {"sharded_sum_argmax_exchange": {"ms": round(worst4 * 1e3, 4), "sum": out[0]["c4_sum"], "argmax_value": out[0]["c4_max"],
+                                                                       "argmax_index": out[0]["c4_index"], "every_device_holds_the_same_result": agree,
+                                                                       "exchange": "ONE RCCL all-gather (16 B per rank: max, partial sum, index) + combine kernel"}}},
+        "device": out[0]["device"]}), flush=True)
+
+
 def main():
     args = parse_args()
+    if args.threads > 0:
+        return main_threads(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_spawn(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
@@ -480,7 +594,7 @@ def main():
         "config": {"workload": f"{S}x{S}x{S} bf16 GEMM, f32 accumulate, bf16 C (BASELINE config C3), one per GPU",
                    "layout": "A[M,K] row-major; B stored [N][K] (Out = Lhs*Rhs^T, the cmma tests' ColMajor-B form)",
                    "operands": "uniform[-1,1) counter RNG seed 0x5EEDC0BE, generated in HBM",
-                   "kernel": {2: "f32_mfma", 3: "lp128", 4: "lp256", 5: "lp256w4", 6: "lp256p", 7: "lp256q", 8: "skinny", 9: "stream64", 10: "lp256x128", 1: "generic"}.get(sel.value, str(sel.value)),
+                   "kernel": ALGO_NAMES.get(sel.value, str(sel.value)),
                    "parallelism": f"batch-sharded x{world}, no data-path collective",
                    "plateau_warmup_steps": plateau_steps,
                    "job_collectives": job.kind + (f" (native refused: {job.why})"[:160] if job.why and args.dist == "native" else ""),

@@ -183,6 +183,36 @@ gemm_lp256m16_kernel(gemm_args g)
     int sb = UNIT_BYTES;                 // ring byte offset of unit 2t+1 (B of K-tile t)
     auto adv = [](int x, int n) { x += n * UNIT_BYTES; return x >= LDS_BYTES ? x - LDS_BYTES : x; };
 
+    // Where a K-tile's 32 fragment reads, 16 DMA pieces and its hand-over sit among its 128 MFMAs (dev switch M16_SCHED; measured on
+    // 8192^3, profiles/r05_m16_schedule.txt):
+    //   0  k-step 0: a read behind every other MFMA of 0-31, two pieces of unit 2t+4 per 16 MFMAs; k-step 1: hand-over behind MFMA 15,
+    //      a read behind every other MFMA of 16-47, unit 2t+5 spread over 16-63
+    //   1  as 0 with the reads of k-step 0 behind every FOURTH MFMA of 0-63
+    //   2  hand-over behind MFMA 31 of k-step 1, its reads behind every other MFMA of 32-63
+    //   3  (the first version) all 16 reads of a k-step behind 16 consecutive MFMAs, hand-over behind MFMA 31
+#ifndef M16_SCHED
+#define M16_SCHED 0
+#endif
+#if M16_SCHED == 1
+#define M16_STEP0(ISSUE) M16_Q(0, 1, 0, 0x1111u, 0, (ISSUE) ? 0x0404u : 0u, 0, 0) M16_Q(0, 1, 16, 0x1111u, 4, (ISSUE) ? 0x0404u : 0u, 0, 2) \
+                         M16_Q(0, 1, 32, 0x1111u, 8, (ISSUE) ? 0x0404u : 0u, 0, 4) M16_Q(0, 1, 48, 0x1111u, 12, (ISSUE) ? 0x0404u : 0u, 0, 6)
+#elif M16_SCHED == 3
+#define M16_STEP0(ISSUE) M16_Q(0, 1, 0, 0xFFFFu, 0, 0u, 0, 0) M16_Q(0, 1, 16, 0u, 0, (ISSUE) ? 0xAAAAu : 0u, 0, 0) M16_Q(0, 1, 32, 0u, 0, 0u, 0, 0) M16_Q(0, 1, 48, 0u, 0, 0u, 0, 0)
+#else
+#define M16_STEP0(ISSUE) M16_Q(0, 1, 0, 0x5555u, 0, (ISSUE) ? 0x0808u : 0u, 0, 0) M16_Q(0, 1, 16, 0x5555u, 8, (ISSUE) ? 0x0808u : 0u, 0, 2) \
+                         M16_Q(0, 1, 32, 0u, 0, (ISSUE) ? 0x0808u : 0u, 0, 4) M16_Q(0, 1, 48, 0u, 0, (ISSUE) ? 0x0808u : 0u, 0, 6)
+#endif
+#if M16_SCHED == 2
+#define M16_STEP1_HEAD M16_Q(1, 0, 0, 0u, 0, 0u, 0, 0) M16_Q(1, 0, 16, 0u, 0, 0u, 0, 0)
+#define M16_STEP1_TAIL(ISSUE) M16_Q(1, 0, 32, 0x5555u, 0, (ISSUE) ? 0x2222u : 0u, 1, 0) M16_Q(1, 0, 48, 0x5555u, 8, (ISSUE) ? 0x2222u : 0u, 1, 4)
+#elif M16_SCHED == 3
+#define M16_STEP1_HEAD M16_Q(1, 0, 0, 0u, 0, 0u, 0, 0) M16_Q(1, 0, 16, 0u, 0, 0u, 0, 0)
+#define M16_STEP1_TAIL(ISSUE) M16_Q(1, 0, 32, 0xFFFFu, 0, 0u, 0, 0) M16_Q(1, 0, 48, 0u, 0, (ISSUE) ? 0x5555u : 0u, 1, 0)
+#else
+#define M16_STEP1_HEAD M16_Q(1, 0, 0, 0u, 0, 0u, 0, 0)
+#define M16_STEP1_TAIL(ISSUE) M16_Q(1, 0, 16, 0x5555u, 0, (ISSUE) ? 0x0808u : 0u, 1, 0) M16_Q(1, 0, 32, 0x5555u, 8, (ISSUE) ? 0x0808u : 0u, 1, 2) \
+                              M16_Q(1, 0, 48, 0u, 0, (ISSUE) ? 0x2222u : 0u, 1, 4)
+#endif
     // One K-tile.  ISSUE = 1: the steady state; ISSUE = 0: the last two K-tiles (nothing left to fetch, the hand-over waits for all).
 #define M16_KTILE(ISSUE)                                                                                           \
     {                                                                                                             \
@@ -196,20 +226,14 @@ gemm_lp256m16_kernel(gemm_args g)
         /* (Reads and pieces are spread thin: a 16-cycle MFMA hides one LDS or DMA issue, not a run of them -- with the 16      */ \
         /* reads behind 16 consecutive MFMAs the loop ran at 0.76 of the MFMA rate at its clock, profiles/r05_m16_schedule.txt) */ \
         rd_a = smem + sa + rowoff_a + x1; rd_b = smem + sb + rowoff_b + x1; dma_base = smem + s4 + dst_piece;       \
-        M16_Q(0, 1, 0, 0x5555u, 0, (ISSUE) ? 0x0808u : 0u, 0, 0)                                                   \
-        M16_Q(0, 1, 16, 0x5555u, 8, (ISSUE) ? 0x0808u : 0u, 0, 2)                                                  \
-        M16_Q(0, 1, 32, 0u, 0, (ISSUE) ? 0x0808u : 0u, 0, 4)                                                       \
-        M16_Q(0, 1, 48, 0u, 0, (ISSUE) ? 0x0808u : 0u, 0, 6)                                                       \
-        /* k-step 1 (buffer 1): 16 MFMAs, the hand-over, then the reads of (t+1, 0) and unit 2t+5 */              \
-        M16_Q(1, 0, 0, 0u, 0, 0u, 0, 0)                                                                            \
+        M16_STEP0(ISSUE)                                                                                          \
+        M16_STEP1_HEAD                                                                                            \
         if (ISSUE) WAIT_VMCNT(8); else WAIT_VMCNT(0);     /* my share of K-tile t+1 landed; unit 2t+4 may fly */    \
         WAIT_LGKM0();                                     /* my reads of K-tile t are complete */                  \
         __builtin_amdgcn_s_barrier();                     /* BAR_t */                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         rd_a = smem + sa1 + rowoff_a + x0; rd_b = smem + sb1 + rowoff_b + x0; dma_base = smem + s5 + dst_piece;     \
-        M16_Q(1, 0, 16, 0x5555u, 0, (ISSUE) ? 0x0808u : 0u, 1, 0)                                                  \
-        M16_Q(1, 0, 32, 0x5555u, 8, (ISSUE) ? 0x0808u : 0u, 1, 2)                                                  \
-        M16_Q(1, 0, 48, 0u, 0, (ISSUE) ? 0x2222u : 0u, 1, 4)                                                       \
+        M16_STEP1_TAIL(ISSUE)                                                                                     \
         sa = sa1;                                                                                                 \
         sb = sb1;                                                                                                 \
     }

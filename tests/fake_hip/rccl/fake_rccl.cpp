@@ -27,6 +27,7 @@ struct p2p { const void *send = nullptr; void *recv = nullptr; size_t count = 0;
 struct group {
     int nranks = 0, joined = 0;
     std::vector<call> reduce, gather;
+    unsigned long long gen_reduce = 0, gen_gather = 0;   // completed collectives (FAKE_RCCL_BLOCKING: a rank waits for its own to complete)
     std::map<std::pair<int, int>, p2p> wires;   // (from, to)
 };
 std::map<std::string, group> groups;
@@ -34,6 +35,10 @@ int next_id = 1;
 std::mutex mu;
 std::condition_variable cv;
 #define LOCKED std::unique_lock<std::mutex> lock(mu)
+// FAKE_RCCL_BLOCKING=1 (one THREAD per rank, each issuing collectives at its own pace -- bench.py --threads): a call returns when the
+// collective it belongs to has executed, and a rank that is a collective ahead of its peers waits for them instead of being refused.
+// Without it a call returns at once ("enqueued") and the last rank to arrive executes -- what a single thread driving every rank needs.
+bool blocking() { static const bool b = [] { const char *e = getenv("FAKE_RCCL_BLOCKING"); return e && e[0] == '1'; }(); return b; }
 size_t size_of(int dt) { const size_t s[] = {1, 1, 4, 4, 8, 8, 2, 4, 8, 2}; return dt >= 0 && dt < 10 ? s[dt] : 0; }
 
 template <typename T> void reduce_typed(group &g, size_t n, int op)
@@ -84,9 +89,16 @@ __attribute__((visibility("default"))) ncclResult_t ncclAllReduce(const void *se
 {
     LOCKED;
     group &g = *comm->g;
-    if (g.reduce[comm->rank].set) return 5;                      // the same rank twice before the others arrived
+    if (g.reduce[comm->rank].set) {                              // the same rank twice before the others arrived
+        if (!blocking() || !cv.wait_for(lock, std::chrono::seconds(60), [&] { return !g.reduce[comm->rank].set; })) return 5;
+    }
     g.reduce[comm->rank] = {send, recv, count, dtype, op, true};
-    for (const call &c : g.reduce) if (!c.set) return 0;         // not everyone is here yet: enqueued
+    const unsigned long long mine = g.gen_reduce;
+    for (const call &c : g.reduce)
+        if (!c.set) {                                            // not everyone is here yet: enqueued
+            if (blocking() && !cv.wait_for(lock, std::chrono::seconds(60), [&] { return g.gen_reduce != mine; })) return 5;
+            return 0;
+        }
     for (const call &c : g.reduce) if (c.count != count || c.dtype != dtype || c.op != op) return 4;
     switch (dtype) {
     case 2: reduce_typed<int32_t>(g, count, op); break;
@@ -98,15 +110,24 @@ __attribute__((visibility("default"))) ncclResult_t ncclAllReduce(const void *se
     default: return 4;
     }
     for (call &c : g.reduce) c.set = false;
+    ++g.gen_reduce;
+    cv.notify_all();
     return 0;
 }
 __attribute__((visibility("default"))) ncclResult_t ncclAllGather(const void *send, void *recv, size_t count, int dtype, ncclComm_t comm, hipStream_t)
 {
     LOCKED;
     group &g = *comm->g;
-    if (g.gather[comm->rank].set) return 5;
+    if (g.gather[comm->rank].set) {
+        if (!blocking() || !cv.wait_for(lock, std::chrono::seconds(60), [&] { return !g.gather[comm->rank].set; })) return 5;
+    }
     g.gather[comm->rank] = {send, recv, count, dtype, 0, true};
-    for (const call &c : g.gather) if (!c.set) return 0;
+    const unsigned long long mine = g.gen_gather;
+    for (const call &c : g.gather)
+        if (!c.set) {
+            if (blocking() && !cv.wait_for(lock, std::chrono::seconds(60), [&] { return g.gen_gather != mine; })) return 5;
+            return 0;
+        }
     const size_t bytes = count * size_of(dtype);
     std::vector<char> all(bytes * g.nranks);
     for (int r = 0; r < g.nranks; ++r) {
@@ -115,6 +136,8 @@ __attribute__((visibility("default"))) ncclResult_t ncclAllGather(const void *se
     }
     for (int r = 0; r < g.nranks; ++r) memcpy(g.gather[r].recv, all.data(), all.size());
     for (call &c : g.gather) c.set = false;
+    ++g.gen_gather;
+    cv.notify_all();
     return 0;
 }
 static ncclResult_t wire(group &g, int from, int to)

@@ -144,6 +144,43 @@ def test_two_rank_job_runs_to_completion_on_the_native_collectives_without_a_dev
     assert line["roofline"]["reduce_sum_argmax_exchange_ms"] > 0
 
 
+def test_threaded_single_process_model_runs_to_completion_without_a_device():
+    """`python bench.py --threads 2`: the reference's own process model (one process, one host thread + one context per device:
+    crates/cubecl-common/src/device/handle/channel.rs:24-37; one communicator joined from the device threads: crates/cubecl-cuda/
+    src/compute/server.rs:669-703) end to end on the fake runtime + the in-process RCCL stand-in: both device threads step the
+    headline, meet at the host barrier, run config C4's local pass + one-collective exchange, and ONE line comes out with n_gpus 2 --
+    so the first multi-GPU box can run either model (review of round 4, next #8)."""
+    so, _ = _build_bench_libs()
+    rccl = FAKE / "rccl" / "librccl.so.1"
+    src = FAKE / "rccl" / "fake_rccl.cpp"
+    if not rccl.exists() or rccl.stat().st_mtime < src.stat().st_mtime:
+        subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-shared", "-fPIC", "-fvisibility=hidden", "-pthread", "-o", str(rccl), str(src)], check=True)
+    n = 1 << 20
+    r = _run(["--threads", "2", "--steps", "2", "--warmup", "1", "--reduce-elements", str(n)],
+             {"BENCH_NO_TORCH_CUDA": "1", "MI355CUBE_LIB": str(so), "MI355_RCCL_LIBRARY": str(rccl), "FAKE_HIP_DEVICES": "2", "OMP_NUM_THREADS": "1",
+              "FAKE_RCCL_BLOCKING": "1", "FAKE_RCCL_BLOCKING_INIT": "1"},
+             timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["process_model"].startswith("one process, one host thread")
+    ex = line["extra"]["reduce_1GiB_f32"]["sharded_sum_argmax_exchange"]
+    assert ex["every_device_holds_the_same_result"] is True and ex["ms"] > 0
+    import numpy as np
+    parts, best = [], None                      # the stand-in fill of tests/fake_hip/fake_kernels.cpp, tensor = 300 + device, as in the two-rank test
+    for rank in range(2):
+        i = np.arange(n // 2, dtype=np.uint64)
+        x = (((i * np.uint64(2654435761) + np.uint64((300 + rank) * 97)) % np.uint64(1000)).astype(np.float32) / np.float32(1000.0)).astype(np.float32)
+        parts.append(np.float32(x.astype(np.float64).sum()))
+        j = int(np.argmax(x))
+        cand = (float(x[j]), rank * (n // 2) + j)
+        if best is None or cand[0] > best[0]:
+            best = cand
+    assert abs(ex["sum"] - float(parts[0] + parts[1])) <= 1e-3 * abs(float(parts[0] + parts[1]))
+    assert ex["argmax_index"] == best[1] and abs(ex["argmax_value"] - best[0]) < 1e-6
+
+
 def test_native_rendezvous_that_fails_on_every_rank_falls_back_to_torch_together():
     """No RCCL at all (MI355_RCCL_LIBRARY points nowhere and the soname is not on this box's path): comm_init fails on both ranks,
     they agree through the store and fall back to torch.distributed (gloo here) TOGETHER -- the line says so, the job completes."""

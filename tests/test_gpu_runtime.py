@@ -820,3 +820,22 @@ def test_a_plain_c_program_runs_the_hot_path_through_the_c_abi(tmp_path):
     from test_abi_cpu import _build_c_user
     out = subprocess.run([str(_build_c_user(tmp_path))], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "C ABI user ok" in out.stdout and "layout 2: 0 of" in out.stdout and "524288.0" in out.stdout, (out.stdout[-1200:], out.stderr[-400:])
+
+
+def test_bench_threaded_model_on_the_real_device_with_one_device_thread():
+    """`bench.py --threads 1` on the real runtime and the real RCCL (a one-rank communicator joined from the device thread): the
+    reference's process model end to end -- headline steps, host barrier, config C4's local pass + one-collective exchange --
+    where only one GPU exists; the N > 1 form of the same code runs on the fake runtime in tests/test_bench_cpu.py."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--threads", "1", "--steps", "3", "--warmup", "1", "--size", "2048",
+                        "--reduce-elements", str(1 << 24)], capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-800:], r.stderr[-2000:])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["process_model"].startswith("one process")
+    ex = line["extra"]["reduce_1GiB_f32"]["sharded_sum_argmax_exchange"]
+    assert ex["every_device_holds_the_same_result"] and abs(ex["sum"] - (1 << 23)) < 5e3 and 0.0 <= ex["argmax_value"] < 1.0
