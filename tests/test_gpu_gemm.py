@@ -1306,14 +1306,15 @@ def test_output_bound_shapes_select_the_small_tile(client):
     assert sel(4, 2048, 4096) == sel(384, 4, 8192) == sel(3, 512, 14336) == sel(4096, 4, 14336) == N.GEMM_ALGO_SKINNY   # 3-4 rows, fewer than 192 streaming workgroups
     assert sel(8192, 4, 2048) == sel(4, 8192, 8192) == N.GEMM_ALGO_STREAM64           # ... from 192 up the streaming kernel
     # the 256 x 128 tile: more than one 128x128 tile per CU, at most one 256 x 128 tile per CU, long K (round 3)
-    assert sel(2048, 3072, 8192) == sel(4096, 1536, 8192) == N.GEMM_ALGO_LP_256X128
-    # round 5: one round of 192 x 192 tiles (144-256 of them) of the 4-wave kernel takes the rest of that band, 256 x 192 tiles where
-    # those would need a second round
-    assert sel(4096, 2048, 4096) == sel(2560, 2560, 3072) == sel(2048, 2048, 8192, batch=2) == sel(3072, 3072, 3072) == sel(2304, 2304, 2304) == N.GEMM_ALGO_LP_192X192
+    assert sel(2048, 2048, 8192, batch=2) == N.GEMM_ALGO_LP_256X128
+    # round 5: the cost table (gemm.cpp TILE_COSTS, fitted by tools/dev/tile_cost_model.py) decides among the tile kernels for [N][K]
+    # operands past 512 x 512 up to one round of the square tile: one round of 192 x 192 tiles takes most of that band, 256 x 192
+    # tiles where those would need a second round
+    assert sel(4096, 2048, 4096) == sel(2560, 2560, 3072) == sel(2048, 3072, 8192) == sel(4096, 1536, 8192) == sel(3072, 3072, 3072) == sel(2304, 2304, 2304) == N.GEMM_ALGO_LP_192X192
     assert sel(4096, 3072, 4096) == sel(3328, 3328, 4096) == N.GEMM_ALGO_LP_256X192 and sel(3584, 3584, 3584) == sel(4096, 4096, 4096) == N.GEMM_ALGO_LP_256W4
     assert sel(2048, 2048, 8192) == N.GEMM_ALGO_LP_128                                  # one 128x128 tile per CU (121 tiles of 192^2: too few)
     assert sel(4096, 2048, 2048) == sel(3072, 2560, 1024) == N.GEMM_ALGO_LP_192X192       # round 5 (were the 128x128 kernel's: 1059 / 781, 918 / 693 TFLOP/s)
-    assert sel(4096, 2304, 4096) == N.GEMM_ALGO_LP_256W4                              # 288 tiles of 256 x 128: two rounds -- the 256x256 tile
+    assert sel(4096, 2304, 4096) == N.GEMM_ALGO_LP_256X192                            # 144 tiles of 256^2, 288 of 256 x 128 (two rounds), 192 of 256 x 192: the table's call
     assert sel(32, 512, 2048) == sel(512, 16, 2048) == sel(32, 6144, 8192) == N.GEMM_ALGO_STREAM64   # few workgroups are fine up to K = 2048; 192 at any K
     assert sel(32, 512, 8192) == sel(512, 16, 8192) == sel(16, 2048, 8192) == sel(32, 1024, 4096) == N.GEMM_ALGO_LP_128   # round 4: split-K instead
     assert sel(8192, 3072, 512) == N.GEMM_ALGO_LP_256Q and sel(8192, 3072, 640) == N.GEMM_ALGO_LP_256P   # 384 tiles: persistent from one round up

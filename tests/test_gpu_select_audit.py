@@ -2,7 +2,7 @@
 
 `gemm.cpp::select` holds ~25 measured crossovers between ten kernels.  They were measured on the builder's boxes; on a box
 where one of them is wrong, the symptom used to be a slower bench entry and nothing else.  This test times AUTO against EVERY
-kernel that accepts the descriptor over a fixed grid of 40 bf16 shapes -- the bench's skinny / output-bound / mid-size / decode
+kernel that accepts the descriptor over a fixed grid of 52 bf16 shapes -- the bench's skinny / output-bound / mid-size / decode
 shapes among them -- interleaved, three rounds, medians, cold operands (launches rotate through operand sets larger than the
 Infinity Cache), and fails when AUTO is more than 15 % AND more than 3 us behind the best forced kernel on any shape (3 us: launches
 of 8-15 us carry about +-1 us of launch-to-launch noise per kernel; the bar was 2 us until the last evidence call of round 3, where the
@@ -32,8 +32,11 @@ GRID = [
     (4096, 2304, 4096), (3072, 2560, 1024),
     # partly filled rounds of the 256x256 tile
     (5120, 5120, 5120), (4352, 4096, 4096), (8192, 8192, 2048), (6144, 4096, 2048),
+    # round 5: the cost table's band (one round of 256 x 256 / 256 x 192 / 192 x 192 / 256 x 128 / 128 x 128 tiles) and the 16x16x32 kernel's ground
+    (2304, 2304, 2304), (2560, 2560, 1024), (4096, 2048, 1024), (3072, 3072, 1024), (2048, 3072, 8192), (4096, 3072, 4096), (3584, 3584, 3584),
+    (1792, 4864, 4096), (2048, 4608, 1024), (2816, 2816, 4096), (1920, 1920, 4096), (8192, 8192, 8192),
 ]
-ALGOS = ["auto", "lp128", "lp256x128", "lp256w4", "lp256p", "lp256q", "stream64", "skinny"]
+ALGOS = ["auto", "lp128", "lp256x128", "lp256w4", "lp256p", "lp256q", "stream64", "skinny", "lp256x192", "lp192x192", "lp256m16"]
 # few rows against a ROW-MAJOR [K][N] weight (review of round 3, next #6): the rhs layout TensorHandle::new_contiguous gives
 GRID_NN = [(1, 8192, 8192), (4, 8192, 8192), (8, 8192, 8192), (16, 8192, 8192), (4, 4096, 4096), (4, 14336, 4096), (4, 4096, 14336),
            (16, 4096, 14336), (16, 28672, 8192), (4, 32000, 4096), (1, 128256, 4096), (16, 128256, 4096), (32, 8192, 8192), (16, 14336, 4096),
