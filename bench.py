@@ -610,7 +610,10 @@ def main():
                      # give-back"): the 2.5 PFLOP/s peak assumes 2.4 GHz; these two lines price the kernel
                      # against the matrix-pipe rate at the clock it actually ran at
                      "shader_clock_GHz": round(eff_clock_ghz, 3),
-                     "frac_of_peak_at_clock": round(achieved / (PEAK_BF16_TFLOPS * eff_clock_ghz / 2.4), 4)},
+                     "frac_of_peak_at_clock": round(achieved / (PEAK_BF16_TFLOPS * eff_clock_ghz / 2.4), 4),
+                     # shader cycles of one launch: what stays put between boxes whose sustained clocks differ (a rocprof summary taken
+                     # on one box reconciles with a bench line of another through this product, review of round 4, next #4)
+                     "kernel_ms_times_shader_clock_GHz": round(kernel_ms / args.steps * eff_clock_ghz, 4)},
         "device": props.name.decode() + " " + props.gcn_arch_name.decode(),
     }
 

@@ -38,6 +38,9 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef M16_GROUP_M
+#define M16_GROUP_M 8   // tile rows per rasterisation group (as gemm_lp256w4.hip: each XCD's 32 resident tiles form an 8 x 4 patch); 4 / 16 measured: see profiles/r05_m16_schedule.txt
+#endif
 constexpr int BM = 256, BN = 256;
 constexpr int ROW_BYTES = 128;
 constexpr int UNIT_BYTES = BM * ROW_BYTES;        // 32 KiB: one ring slot
@@ -334,7 +337,7 @@ int32_t launch_gemm_lp256m16(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_des
     g.stride_a = d.stride_a; g.stride_b = d.stride_b; g.stride_c = d.stride_c;
     g.tiles_m = (uint32_t)((d.m + BM - 1) / BM);
     g.tiles_n = (uint32_t)((d.n + BN - 1) / BN);
-    g.group_m = 8;
+    g.group_m = M16_GROUP_M;
     const uint32_t batch = (uint32_t)d.batch;
     constexpr int BF = MI355_DTYPE_BF16, HF = MI355_DTYPE_F16, CF = MI355_DTYPE_F32;
     if (d.dtype_ab == BF) {

@@ -2,7 +2,7 @@
 """Launches BASELINE config C5 as bench.py times it at N = 1 -- batch 512 x 2048^3 bf16 -> bf16 C, AUTO (gemm_lp256q.hip) -- a few
 times; the command the C5 PMC passes of tools/pmc_all.sh profile.  Prints the rate and the shader clock the launches ran at
 (mi355_probe_clock around them: s_memtime against the 100 MHz reference, per CU).
-usage: python tools/c5_probe.py [launches] [nn] [batch]"""
+usage: python tools/c5_probe.py [launches] [nn] [batch] [algo]     (algo: MI355_GEMM_ALGO_* to force, default AUTO)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -18,8 +18,11 @@ ev = bench.Events(cl)
 a = TensorHandle.uniform(cl, (B, M, M), ElemType.BF16, bench.SEED, 500, -1.0, 1.0)
 b = TensorHandle.uniform(cl, (B, M, M), ElemType.BF16, bench.SEED, 600, -1.0, 1.0)
 c = cl.empty(B * M * M * 2)
-d = bench.gemm_desc(N, M, M, M, N.DTYPE_BF16, N.DTYPE_BF16, trans_b=tb, batch=B)
-alg = C.c_int32(); lib.mi355_gemm_select(ctx, C.byref(d), C.byref(alg))
+FORCE = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+d = bench.gemm_desc(N, M, M, M, N.DTYPE_BF16, N.DTYPE_BF16, trans_b=tb, batch=B, algo=FORCE)
+alg = C.c_int32(FORCE)
+if not FORCE:
+    lib.mi355_gemm_select(ctx, C.byref(d), C.byref(alg))
 call = lambda: cl._s.check(lib.mi355_gemm(ctx, None, C.byref(d), a.device_ptr(), b.device_ptr(), c.device_ptr()))
 clk = cl.empty(2 * 8192)
 lib.mi355_memset(ctx, None, C.c_void_p(clk.device_ptr()), 0, 2 * 8192)

@@ -1,1 +1,1 @@
-python -m pytest tests/test_gpu_select_audit.py -x -q -m gpu -k "every_shape" 2>&1 | tail -12
+python -m pytest tests/test_gpu_guard_pages.py -x -q -m gpu 2>&1 | tail -6

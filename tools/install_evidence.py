@@ -16,17 +16,21 @@ for src, dst in (("rehearse_n2.json", f"{tag}_rehearse_n2.json"), ("select_audit
                  (f"{tag}_kres.txt", f"{tag}_kernel_resources.txt"), ("parity_margins.jsonl", f"{tag}_parity_margins.jsonl"),
                  ("pmc_traffic.json", "pmc_traffic.json"), ("pmc_mfma_util.json", "pmc_mfma_util.json")):
     shutil.copy(G + src, P + dst)
-rows = [r for r in csv.DictReader(open(glob.glob(G + f"{tag}_prof/**/*kernel_trace.csv", recursive=True)[0])) if "gemm_lp256w4_kernel" in r["Kernel_Name"]]
+sys.path.insert(0, ".")
+import bench
+HK = bench.HEADLINE_KERNEL
+rows = [r for r in csv.DictReader(open(glob.glob(G + f"{tag}_prof/**/*kernel_trace.csv", recursive=True)[0])) if HK.split("<")[0] in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
 n, t, w = len(d), d[-30:], d[:-30]
 text = f"""rocprofv3 --kernel-trace --stats -- python bench.py --no-extras --no-cpu-baseline (tools/gpu_check.sh {tag}), tree {sha}
-kernel gemm_lp256w4_kernel<1, 1, false, 1, false, false>: {n} launches in the trace, in start order:
+kernel {HK}: {n} launches in the trace, in start order:
   5 warm-up + {len(w) - 5} plateau warm-up launches     average {sum(w) / len(w):8.1f} us   (the DVFS ramp from idle: first 20 average {sum(d[:20]) / 20:.1f})
   the 30 TIMED launches (back to back)            average {sum(t) / 30:8.1f} us   min {min(t):.1f}  max {max(t):.1f}
   all {n}                                          average {sum(d) / n:8.1f} us   (what {tag}_rocprof_kernel_stats_headline.csv prints)
 bench.py's figure for the timed region of the same process (HIP events around the 30 launches): roofline.kernel_ms = {under["roofline"]["kernel_ms"]} ms
-({tag}_bench_under_rocprof_headline.json).  The per-sample launches behind frac_per_sample_median run with the extras only.
+({tag}_bench_under_rocprof_headline.json); kernel_ms x shader clock there = {under["roofline"].get("kernel_ms_times_shader_clock_GHz")} (GHz x ms: the box-independent figure).
+The per-sample launches behind frac_per_sample_median run with the extras only.
 """
 open(P + f"{tag}_rocprof_headline_timed_region.txt", "w").write(text)
 print(text)
