@@ -1291,7 +1291,7 @@ def test_output_bound_shapes_select_the_small_tile(client):
         return ops.gemm_select(client, d)
     assert sel(8192, 8192, 64) == sel(8192, 8192, 256) == sel(16384, 8192, 192) == N.GEMM_ALGO_LP_128   # several rounds, K <= 192 (<= 256 up to 1280 tiles)
     assert sel(16384, 8192, 256) == sel(8192, 8192, 320) == N.GEMM_ALGO_LP_256P         # ... beyond: the persistent large tile (cold operands, round 3)
-    assert sel(4096, 4096, 64) == N.GEMM_ALGO_LP_256W4                 # one round of 256 tiles: the large tile
+    assert sel(4096, 4096, 64) == N.GEMM_ALGO_LP_128                   # one round of 256 tiles, one K-tile: 9.9 us against 10.7 on the large tile (cold; round 5)
     assert sel(8192, 8192, 320) in (N.GEMM_ALGO_LP_256P, N.GEMM_ALGO_LP_256Q, N.GEMM_ALGO_LP_256W4)
     assert sel(1, 8192, 8192) == sel(8192, 2, 4096) == N.GEMM_ALGO_SKINNY
     assert sel(4, 8192, 8192) == sel(16, 8192, 8192) == sel(64, 8192, 8192) == sel(8192, 64, 8192) == N.GEMM_ALGO_STREAM64   # 3 ... 64 rows: no split-K
