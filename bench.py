@@ -584,8 +584,8 @@ def main():
     gemm_score = score_resources(kernel_ms / args.steps * 1e-3, [ResourceBound(int(flop), PEAK_BF16_TFLOPS * 1e12)])[0]
     achieved = gemm_score.achieved_per_s / 1e12
 
-    tr_ent, tr_why = pmc_traffic_entry(S, sel.value) if sel.value == 5 else (None, "no PMC pass for this kernel")
-    mu_ent, mu_why = pmc_mfma_util_entry(S) if sel.value == 5 else (None, "no PMC pass for this kernel")
+    tr_ent, tr_why = pmc_traffic_entry(S, sel.value) if sel.value == HEADLINE_ALGO else (None, "no PMC pass for this kernel")
+    mu_ent, mu_why = pmc_mfma_util_entry(S) if sel.value == HEADLINE_ALGO else (None, "no PMC pass for this kernel")
     result = {
         "metric": "GEMM TFLOP/s (8192^3 bf16) + reduce GB/s vs roofline",
         "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

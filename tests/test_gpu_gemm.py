@@ -723,18 +723,23 @@ def test_row_major_b_mid_size_shapes_are_native_on_the_128_tile_kernel(client, o
 
 
 def test_row_major_b_through_the_strip_split_of_a_partly_filled_round(client, oracle):
-    """17 x 16 = 272 tiles of 256x256: AUTO cuts a strip off and splits its K (gemm.cpp plan_tail_split).  With row-major B the
-    strip's K slices start k rows further down B (not k columns further along its rows) and a strip of columns starts at a column
-    offset: same cut, same slabs, same fold -- the bits of the [N][K] launch."""
-    m, n, k = 4352, 4096, 2048
+    """24 x 24 = 576 tiles of 256x256 (2.25 rounds): AUTO cuts a strip off and splits its K (gemm.cpp plan_tail_split).  With row-major B
+    the strip's K slices start k rows further down B (not k columns further along its rows) and a strip of columns starts at a column
+    offset: same cut, same slabs, same fold -- the bits of the [N][K] launch.  (Until round 5 this ran on 4352 x 4096 x 2048; the cost
+    table now hands that [N][K] descriptor to a 192 x 192 tile, launched whole -- checked below -- so the twin moved past the table.)"""
     along, extent, splits = C.c_int32(), C.c_int64(), C.c_int32()
-    d = _nn_desc(m, n, k, ElemType.BF16, ElemType.BF16)
-    assert client.lib.mi355_gemm_tail_plan(C.byref(d), C.byref(along), C.byref(extent), C.byref(splits)) == N.OK and splits.value > 1
+    d_nt = N.GemmDesc(m=4352, n=4096, k=2048, batch=1, lda=2048, ldb=2048, ldc=4096, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_BF16, trans_b=1)
+    assert ops.gemm_select(client, d_nt) == N.GEMM_ALGO_LP_192X192
+    assert client.lib.mi355_gemm_tail_plan(C.byref(d_nt), C.byref(along), C.byref(extent), C.byref(splits)) == N.OK and splits.value == 1
+    m = n = k = 6144
     a = TensorHandle.uniform(client, (m, k), ElemType.BF16, 0x5EEDC0BE, 91, -1.0, 1.0)
     b_nk = TensorHandle.uniform(client, (n, k), ElemType.BF16, 0x5EEDC0BE, 92, -1.0, 1.0)
     b_kn = ops.into_contiguous(client, TensorHandle.new(b_nk.handle, (k, n), (1, k), ElemType.BF16))
     outs = []
-    for b_t in (TensorHandle.new(b_nk.handle, (k, n), (1, k), ElemType.BF16), b_kn):
+    for d, b_t in ((N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=k, ldc=n, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_BF16, trans_b=1),
+                    TensorHandle.new(b_nk.handle, (k, n), (1, k), ElemType.BF16)), (_nn_desc(m, n, k, ElemType.BF16, ElemType.BF16), b_kn)):
+        assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+        assert client.lib.mi355_gemm_tail_plan(C.byref(d), C.byref(along), C.byref(extent), C.byref(splits)) == N.OK and splits.value > 1
         c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 2), ElemType.BF16)
         ops.matmul(client, a, b_t, c)
         outs.append(c.to_numpy(client))
