@@ -205,8 +205,8 @@ template <int DT, int DT_C, bool BNN = false, int DTB = DT, bool MX = false, boo
 __global__ void __launch_bounds__(256)
 gemm_lp256w4_kernel(gemm_args g)
 {
-    static_assert((NJ == 4 && NI == 4) || ((NJ == 3 || NJ == 4) && (NI == 3 || NI == 4) && !BNN && !MX && !ATN && (DT == MI355_DTYPE_BF16 || DT == MI355_DTYPE_F16)),
-                  "narrow tiles: plain [N][K] 16-bit operands");
+    static_assert((NJ == 4 && NI == 4) || ((NJ == 3 || NJ == 4) && (NI == 3 || NI == 4) && !MX && !ATN && (DT == MI355_DTYPE_BF16 || DT == MI355_DTYPE_F16)),
+                  "narrow tiles: 16-bit operands, A [M][K], B [N][K] or row-major [K][N]");
     constexpr int BNT = NJ * 64;                        // tile columns: 256 or 192
     constexpr int NPB = NJ * 2;                         // DMA pieces of a B unit per wave: 8 or 6
     constexpr int BMT = NI * 64;                        // tile rows: 256 or 192
@@ -271,8 +271,10 @@ gemm_lp256w4_kernel(gemm_args g)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {                                         // columns past N re-read the last valid 16 bytes
         if constexpr (BNN16) {
-            const int64_t col = (j & 1) * 128 + (lane >> 4) * 32 + (lane & 3) * 8;
-            voff_bnn[j] = (uint32_t)(((j >> 1) * 4 + ((lane & 15) >> 2)) * g.ldb * ESZ + min(col, g.n - 8 - n0) * ESZ);
+            // blocks of a block row: 2 NJ (8, or 6 on the 192-column tile: a piece's four blocks then straddle block rows)
+            const int blk = 4 * j + (lane >> 4), a_local = blk / (2 * NJ), bcol = blk % (2 * NJ);
+            const int64_t col = bcol * 32 + (lane & 3) * 8;
+            voff_bnn[j] = (uint32_t)((a_local * 4 + ((lane & 15) >> 2)) * g.ldb * ESZ + min(col, g.n - 8 - n0) * ESZ);
         } else
             voff_bnn[j] = (uint32_t)(j * g.ldb * ESZ + min((int64_t)lane * 4, g.n - 4 - n0) * ESZ);
     }
@@ -296,7 +298,8 @@ gemm_lp256w4_kernel(gemm_args g)
     const int hd = MX ? ((f & 2) ? -32 : 32) : ((f & 1) ? -16 : 16);
     const int rowoff_a = ATN ? wm * 4 * 256 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8 : (wm * (NI * 32) + l31) * ROW_BYTES;
     // (16-bit row-major B: block b = 4 wn + j of the lane-half's block row, + row (lane%16)/4, + 16-lane group, + 8 B per lane)
-    const int rowoff_b = BNN16 ? wn * 4 * 256 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8
+    constexpr int BROW = 2 * NJ * 256;                                // bytes of one block row of the row-major B image (8 or 6 blocks)
+    const int rowoff_b = BNN16 ? wn * NJ * 256 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8
                          : BNN ? (wn * 128 + l31) * 4 : (wn * (NJ * 32) + l31) * ROW_BYTES;
 
     f32x16 acc[NI][NJ];
@@ -360,7 +363,8 @@ gemm_lp256w4_kernel(gemm_args g)
             dst[4 * HALF + 0] = (int)v[0]; dst[4 * HALF + 1] = (int)v[1]; dst[4 * HALF + 2] = (int)v[2]; dst[4 * HALF + 3] = (int)v[3];
         } else if constexpr (BNN16) {
             if constexpr (R >= 1 && R <= 4) {
-                if constexpr (ATN) {                             // row block R - 1: k 0..3 from block row a, k 4..7 from a + 1
+                if constexpr (R - 1 >= NI) { /* the 192-row tile: three row blocks */ }
+                else if constexpr (ATN) {                             // row block R - 1: k 0..3 from block row a, k 4..7 from a + 1
                     typedef short s16x4 __attribute__((ext_vector_type(4)));
                     typedef short s16x8 __attribute__((ext_vector_type(8)));
                     const auto q = (const __attribute__((address_space(3))) s16x4 *)(pa + (R - 1) * 256);
@@ -372,13 +376,15 @@ gemm_lp256w4_kernel(gemm_args g)
                     fa[BUF][R - 1] = *reinterpret_cast<const frag *>(pa + (R - 1) * 32 * ROW_BYTES);
             } else {
                 constexpr int JB = (R == 0) ? 0 : R - 4;       // column block JB: k 0..3 from block row a, k 4..7 from a + 1
+                if constexpr (JB < NJ) {
                 typedef short s16x4 __attribute__((ext_vector_type(4)));
                 typedef short s16x8 __attribute__((ext_vector_type(8)));
                 const auto q = (const __attribute__((address_space(3))) s16x4 *)(pb + JB * 256);
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<__attribute__((address_space(3))) s16x4 *>(q));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<__attribute__((address_space(3))) s16x4 *>(q + 256));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<__attribute__((address_space(3))) s16x4 *>(q + BROW / 8));
                 const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 fb[BUF][JB] = __builtin_bit_cast(typename lp<DTB>::frag, both);
+                }
             }
         } else if constexpr (BNN) {
             if (R >= 1 && R <= 4) fa[BUF][R - 1] = *reinterpret_cast<const frag *>(pa + (R - 1) * 32 * ROW_BYTES);
@@ -397,8 +403,9 @@ gemm_lp256w4_kernel(gemm_args g)
         constexpr int J = decltype(jj)::value;
         if (W4_ABL & 1) return;
         if constexpr (BNN && decltype(is_b)::value) {
+            if constexpr (J >= NPB) return;                                   // the 192-column tile: six pieces of B per wave
             // koff = tile * 128 bytes along K for the K-contiguous layout; here a K-tile is 32 rows of ldb elements
-            glds16_s<J * 1024>(ubase_bnn + koff * g.ldb, voff_bnn[J], lds_addr_of(base));
+            glds16_s<J * 1024>(ubase_bnn + koff * g.ldb, voff_bnn[J], lds_addr_of(base) + (uint32_t)(wave * DST_PIECE_B_STEP));
         } else if constexpr (ATN && !decltype(is_b)::value) {
             glds16_s<J * 1024>(ubase_atn + koff * g.lda, voff_atn[J], lds_addr_of(base));
         } else {
@@ -490,7 +497,7 @@ gemm_lp256w4_kernel(gemm_args g)
         // scale bytes are one word; fp8 MX: k-step d = chunks 4d+h (registers 0-3) and 4d+2+h (registers 4-7);
         // unscaled: the mappings the measured kernels were tuned with
         const int x = F4 ? ((4 * h) ^ f) << 4 : (F8 && !MX) ? ((2 * h) ^ f) << 4 : (h ^ f) << 4;
-        const char *rd_a = smem + rowoff_a + (ATN ? h * 4096 : x), *rd_b = smem + UNIT_BYTES + rowoff_b + (BNN16 ? h * 4096 : BNN ? (4 * h) * 1024 : x);
+        const char *rd_a = smem + rowoff_a + (ATN ? h * 4096 : x), *rd_b = smem + UNIT_BYTES + rowoff_b + (BNN16 ? h * 2 * BROW : BNN ? (4 * h) * 1024 : x);
         read_one(IC<0>{}, IC<0>{}, rd_a, rd_b); read_one(IC<0>{}, IC<1>{}, rd_a, rd_b);
         read_one(IC<0>{}, IC<2>{}, rd_a, rd_b); read_one(IC<0>{}, IC<3>{}, rd_a, rd_b);
         read_one(IC<0>{}, IC<4>{}, rd_a, rd_b); read_one(IC<0>{}, IC<5>{}, rd_a, rd_b);
@@ -511,8 +518,8 @@ gemm_lp256w4_kernel(gemm_args g)
               x3 = ((F4 ? 4 * h + 3 : 6 + h) ^ f) << 4, x0 = ((F4 ? 4 * h : h) ^ f) << 4;
     // B fragment offsets per k-step: same chunks as A for [N][K]; k-rows 8s + 4h (.. +3) for row-major B
     // (16-bit: block rows a = 4s + 2h, + 1: 8 blocks of 256 B per block row)
-    const int y0 = BNN16 ? h * 4096 : BNN ? (4 * h) * 1024 : x0, y1 = BNN16 ? 8192 + h * 4096 : BNN ? (8 + 4 * h) * 1024 : x1,
-              y2 = BNN16 ? 16384 + h * 4096 : BNN ? (16 + 4 * h) * 1024 : x2, y3 = BNN16 ? 24576 + h * 4096 : BNN ? (24 + 4 * h) * 1024 : x3;
+    const int y0 = BNN16 ? h * 2 * BROW : BNN ? (4 * h) * 1024 : x0, y1 = BNN16 ? (4 + 2 * h) * BROW : BNN ? (8 + 4 * h) * 1024 : x1,
+              y2 = BNN16 ? (8 + 2 * h) * BROW : BNN ? (16 + 4 * h) * 1024 : x2, y3 = BNN16 ? (12 + 2 * h) * BROW : BNN ? (24 + 4 * h) * 1024 : x3;
 
     const int xa0 = ATN ? y0 : x0, xa1 = ATN ? y1 : x1, xa2 = ATN ? y2 : x2, xa3 = ATN ? y3 : x3;   // A stored [K][M]: block rows, as row-major B
 
@@ -855,7 +862,7 @@ int32_t launch_gemm_lp256w4(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc
 bool gemm_lp256x192_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
 {
     if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16) return false;
-    if (d.trans_a || !d.trans_b) return false;
+    if (d.trans_a) return false;                      // (B: [N][K], or row-major [K][N] through the transposing-read image, as the square tile)
     return gemm_lp256w4_supports(d, a, b, c);
 }
 
@@ -873,21 +880,19 @@ int32_t launch_gemm_lp256x192(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_de
     g.group_m = W4_GROUP_M;
     const uint32_t batch = (uint32_t)d.batch;
     constexpr int BF = MI355_DTYPE_BF16, HF = MI355_DTYPE_F16, CF = MI355_DTYPE_F32;
-    if (tile_rows == 192) {
-        if (d.dtype_ab == BF) {
-            if (d.dtype_c == CF) launch<BF, CF, false, BF, false, false, 3, 3>(ctx, s, g, batch);
-            else launch<BF, BF, false, BF, false, false, 3, 3>(ctx, s, g, batch);
-        } else {
-            if (d.dtype_c == CF) launch<HF, CF, false, HF, false, false, 3, 3>(ctx, s, g, batch);
-            else launch<HF, HF, false, HF, false, false, 3, 3>(ctx, s, g, batch);
-        }
-    } else if (d.dtype_ab == BF) {
-        if (d.dtype_c == CF) launch<BF, CF, false, BF, false, false, 3>(ctx, s, g, batch);
-        else launch<BF, BF, false, BF, false, false, 3>(ctx, s, g, batch);
-    } else {
-        if (d.dtype_c == CF) launch<HF, CF, false, HF, false, false, 3>(ctx, s, g, batch);
-        else launch<HF, HF, false, HF, false, false, 3>(ctx, s, g, batch);
-    }
+#define X192_LAUNCH(NN, NI_)                                                                                   \
+    do {                                                                                                       \
+        if (d.dtype_ab == BF) {                                                                                \
+            if (d.dtype_c == CF) launch<BF, CF, NN, BF, false, false, 3, NI_>(ctx, s, g, batch);                \
+            else launch<BF, BF, NN, BF, false, false, 3, NI_>(ctx, s, g, batch);                                \
+        } else {                                                                                               \
+            if (d.dtype_c == CF) launch<HF, CF, NN, HF, false, false, 3, NI_>(ctx, s, g, batch);                \
+            else launch<HF, HF, NN, HF, false, false, 3, NI_>(ctx, s, g, batch);                                \
+        }                                                                                                      \
+    } while (0)
+    if (d.trans_b) { if (tile_rows == 192) X192_LAUNCH(false, 3); else X192_LAUNCH(false, 4); }
+    else { if (tile_rows == 192) X192_LAUNCH(true, 3); else X192_LAUNCH(true, 4); }
+#undef X192_LAUNCH
     check_launch(ctx, "mi355_gemm(lp256x192)");
     return MI355_OK;
 }

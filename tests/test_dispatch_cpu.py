@@ -58,13 +58,17 @@ TABLE = [
     ("short K in the band: 192^2 (17.7 us; 256 x 192 20.0, 128^2 19.1)", (2560, 2560, 1024, BF, None, 0, 1, 1), "LP_192X192", (0, 0)),
     ("one round of 256 x 192 tiles where 192^2 would need two", (4096, 3072, 4096, BF, None, 0, 1, 1), "LP_256X192", (0, 0)),
     ("196 tiles of 256^2: every narrower tile needs a second round", (3584, 3584, 3584, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
-    ("the narrow tiles stage [N][K] operands only: a row-major rhs keeps the square tile", (3072, 3072, 3072, BF, None, 0, 0, 1), "LP_256W4", (0, 0)),
+    ("a row-major rhs through the narrow tiles' transposing-read image (1192 TFLOP/s against 988 on 144 square tiles)", (3072, 3072, 3072, BF, None, 0, 0, 1), "LP_192X192", (0, 0)),
+    ("row-major rhs, one round of 256 x 192 tiles", (4096, 3072, 4096, BF, None, 0, 0, 1), "LP_256X192", (0, 0)),
+    ("row-major rhs, one 128^2 tile per CU (23.2 us against 24.8 on 192^2)", (2048, 2048, 2048, BF, None, 0, 0, 1), "LP_128", (0, 0)),
+    ("row-major rhs, 196 tiles of 256^2", (3584, 3584, 3584, F16, None, 0, 0, 1), "LP_256W4", (0, 0)),
+    ("row-major rhs, tall: 128 tiles of 256 x 192 (65.7 us against 68.4 on the 256 x 128 tile)", (8192, 1024, 4096, BF, None, 0, 0, 1), "LP_256X192", (0, 0)),
     ("one round of 256^2 tiles", (4096, 4096, 4096, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
     ("a partly filled last round (split inside the launch)", (6144, 6144, 6144, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
     ("weight gradient lhs^T . grad: native", (512, 512, 8192, BF, None, 1, 0, 1), "LP_128", (0, 0)),
     ("weight gradient, mid size: native", (2048, 2048, 8192, BF, None, 1, 0, 1), "LP_128", (0, 0)),
     ("transposed lhs on a 256-tile shape: native on the 256^2 kernel as well", (8192, 8192, 8192, BF, None, 1, 0, 1), "LP_256W4", (0, 0)),
-    ("transposed lhs where the 256 x 128 tile would run: A through scratch, B stays", (4096, 2048, 4096, BF, None, 1, 0, 1), "LP_256X128", (1, 0)),
+    ("transposed lhs where a narrow tile would run: A through scratch, B stays", (4096, 2048, 4096, BF, None, 1, 0, 1), "LP_192X192", (1, 0)),
     ("transposed lhs, many short tiles: the one-tile kernel, not the persistent forms", (2048, 2048, 2048, BF, None, 1, 0, 64), "LP_256W4", (0, 0)),
     ("both transposed", (512, 512, 1024, BF, None, 1, 1, 1), "LP_128", (1, 0)),
     ("transposed lhs, rows of C not a multiple of 8", (516, 512, 1024, BF, None, 1, 0, 1), "LP_128", (1, 0)),

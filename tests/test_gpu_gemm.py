@@ -425,9 +425,33 @@ def test_lp256x192_c_rows_off_the_16_byte_grid_batches_and_refusals(client, orac
     run_case(client, oracle, 300, 261, 128, ElemType.BF16, ElemType.BF16, True, ALGOS[tile], ldc=261 + pad, batch=2)
     run_case(client, oracle, 513, 1001, 128, ElemType.BF16, ElemType.F32, True, ALGOS[tile], ldc=1001 + pad)
     run_case(client, oracle, 256, 384, 192, ElemType.F16, ElemType.F16, True, ALGOS[tile], batch=3, bcast_b=True, lda=200, ldb=208)
-    for kw in ({"dtype": ElemType.F32}, {"trans_b": False}, {"k": 96}):             # f32 operands, row-major B, K off the K-tile grid
+    for kw in ({"dtype": ElemType.F32}, {"trans_b": False, "n": 196}, {"k": 96}):   # f32 operands, row-major B whose rows are off the 16-byte grid, K off the K-tile grid
         with pytest.raises(ServerError):
-            run_case(client, oracle, 256, 192, kw.get("k", 128), kw.get("dtype", ElemType.BF16), ElemType.F32, kw.get("trans_b", True), ALGOS[tile])
+            run_case(client, oracle, 256, kw.get("n", 192), kw.get("k", 128), kw.get("dtype", ElemType.BF16), ElemType.F32, kw.get("trans_b", True), ALGOS[tile])
+
+
+X192_NN_CASES = [(256, 192, 64), (192, 192, 128), (384, 384, 128), (512, 576, 512), (300, 200, 128), (1, 192, 64), (257, 184, 320), (255, 392, 192), (193, 104, 128),
+                 (700, 40, 256), (8, 8, 64), (513, 1000, 128), (768, 960, 1024), (3072, 3072, 256)]
+
+
+@pytest.mark.parametrize("tile", ["lp256x192", "lp192x192"])
+@pytest.mark.parametrize("m,n,k", X192_NN_CASES)
+@pytest.mark.parametrize("dtype,out", [(ElemType.BF16, "f32"), (ElemType.F16, "same")])
+def test_lp256x192_row_major_rhs_parity_and_the_bits_of_the_square_tile(client, oracle, m, n, k, dtype, out, tile):
+    """Row-major [K][N] rhs (the reference's default layout) through the narrow tiles: the transposing-read image has six
+    32-column blocks per block row instead of eight.  Against the oracle (pitched C and B), and bit for bit against the
+    256 x 256 tile of the same kernel on the same row-major operand."""
+    out_dtype = ElemType.F32 if out == "f32" else dtype
+    ldc = (n + 7) // 8 * 8 + 8
+    run_case(client, oracle, m, n, k, dtype, out_dtype, False, ALGOS[tile], ldc=ldc, ldb=n + 8)
+    a = TensorHandle.uniform(client, (m, k), dtype, 5, 1, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (k, n), dtype, 5, 2, -1.0, 1.0)
+    got = []
+    for algo in (tile, "lp256w4"):
+        c = TensorHandle.new_contiguous((m, n), client.empty(m * n * out_dtype.size()), out_dtype)
+        ops.matmul(client, a, b, c, algo=ALGOS[algo])
+        got.append(client.read_one(c.handle).copy())
+    assert np.array_equal(got[0], got[1])
 
 
 # ---- the 256 x 256 tile on v_mfma_f32_16x16x32 (gemm_lp256m16.hip; round 5) -----------------------------------------------------
@@ -1465,12 +1489,12 @@ def test_transposed_a_with_row_major_b_is_staged_natively_and_gives_the_bits_of_
 
 def test_transposed_a_selection_and_refusals(client, oracle):
     bf = ElemType.BF16
-    # a 256-tile shape is native on the 256 x 256 kernel; where the 256 x 128 tile would run, A is transposed into scratch and the
-    # row-major B stays where it is
+    # a 256-tile shape is native on the 256 x 256 kernel; where a narrower tile would run (they stage a K-contiguous A only), A is
+    # transposed into scratch and the row-major B stays where it is
     d = _tn_desc(8192, 8192, 8192, bf, bf)
     assert ops.gemm_relayout_plan(client, d) == (False, False) and ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
     d = _tn_desc(4096, 2048, 4096, bf, bf)
-    assert ops.gemm_relayout_plan(client, d) == (True, False) and ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256X128
+    assert ops.gemm_relayout_plan(client, d) == (True, False) and ops.gemm_select(client, d) == N.GEMM_ALGO_LP_192X192
     # rows of C not a multiple of 8 / A and B both transposed: no native form
     assert ops.gemm_relayout_plan(client, _tn_desc(516, 512, 1024, bf, bf)) == (True, False)
     assert ops.gemm_relayout_plan(client, _tn_desc(512, 512, 1024, bf, bf, trans_b=1)) == (True, False)

@@ -166,10 +166,13 @@ def test_tail_plan_splits_only_small_leftover_rounds():
     strip_tiles = (6144 - extent) // 256 * 24
     assert splits > 1 and along == 1 and extent % 256 == 0 and 0 < strip_tiles <= 96 and strip_tiles * splits <= 256
     assert (6144 // 64) % splits == 0                                  # whole K-tiles per slice
-    # 20 x 13 tiles (ragged M, 4 tiles more than one round): the plain launch keeps at most one round, the strip the rest
-    along, extent, splits = _tail_plan(5000, 3328, 2048)
-    tiles_main = (extent // 256) * (13 if along else 20)
-    assert splits > 1 and extent % 256 == 0 and 0 < tiles_main <= 256 and (20 * 13 - tiles_main) * splits <= 256
+    # 32 x 17 tiles (32 more than two rounds): the plain launch keeps whole rounds, the strip the rest
+    along, extent, splits = _tail_plan(8192, 4352, 4096)
+    tiles_main = (extent // 256) * (17 if along else 32)
+    assert splits > 1 and extent % 256 == 0 and tiles_main == 512 and (32 * 17 - tiles_main) * splits <= 256
+    # 20 x 13 tiles of 256^2 with a ragged M: since round 5 the cost table gives the shape to the 192^2 tile, and the plan answers for
+    # the kernel mi355_gemm will run -- no strip
+    assert _tail_plan(5000, 3328, 2048)[2] == 1
     assert (2048 // 64) % splits == 0
     # fp8 counts K-tiles of 128, f32 of 32; batches and transposed A are never split
     assert _tail_plan(4608, 4096, 8192, dtype=N.DTYPE_F8E4M3)[2] > 1

@@ -8,7 +8,10 @@ Model (per kernel k, 16-bit [N][K] operands, cold):
                   padded FLOPs / P_k )            the chip's pace at its power limit on random operands: P_k TFLOP/s
 AUTO takes the kernel with the smallest T_k among those that support the descriptor.
 
-usage: python tools/dev/tile_cost_model.py [--emit]      (--emit prints the C++ table)"""
+The row-major [K][N] rhs has its own rows (--nn: fitted on profiles/r05_tile_nn_ab.txt): the 128-row kernels stage it through a
+different image and run it slower, the 4-wave kernel's transposing reads cost it next to nothing.
+
+usage: python tools/dev/tile_cost_model.py [--nn] [--emit]      (--emit prints the C++ table)"""
 import glob
 import os
 import re
@@ -24,6 +27,8 @@ TILES = {"lp128": (128, 128, 1),        # (two co-resident workgroups share one 
 CUS, F0 = 256, 0.7
 FILES = ["r03_tile_256x128_sweep.txt", "r04_band_129_200_tiles_ab.txt", "r05_tile_256x192_ab.txt", "r05_tile_192x192_ab.txt", "r05_m16_ab.txt",
          "r05_select_audit_cost_table_v1.txt"]
+if "--nn" in sys.argv:
+    FILES = ["r05_tile_nn_ab.txt"]          # (r05_tile_nn_ab2.txt is the held-out check: AUTO column = this table's choice)
 
 
 def parse():
