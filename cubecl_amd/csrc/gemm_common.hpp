@@ -139,6 +139,10 @@ bool gemm_nnrows_supports(const mi355_gemm_desc &d, const void *a, const void *b
 bool gemm_nnrows_ready(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d);   // its scratch exists or may be created now
 int32_t launch_gemm_stream64(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 bool gemm_stream64_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
+// ... its f32 form (gemm_stream64_f32.hip: v_mfma_f32_16x16x4_f32, both operands through per-wave LDS rings); reached through the two above
+int32_t launch_gemm_stream64_f32(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
+bool gemm_stream64_f32_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
+int stream64_f32_blocks(const mi355_gemm_desc &d, int cus);
 // block-scaled (MX) form of the same kernel; sa_t / sb_t are the re-arranged scales (gemm_scaled.hip)
 bool gemm_lp256w4_mx_supports(const mi355_gemm_scaled_desc &d, const void *a, const void *b, const void *c);
 int32_t launch_gemm_lp256w4_mx(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_scaled_desc &d, const void *a, const void *sa_t,

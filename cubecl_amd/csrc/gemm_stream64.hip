@@ -479,10 +479,11 @@ int stream64_slices(const mi355_gemm_desc &d, int cus)
     return (small_rows >= 56 && wgs1 <= cus && wgs1 > cus / 2 && nk >= 128) ? 2 : 0;
 }
 
-// A [M][K], B [N][K] K-contiguous 16-bit, min(M, N) <= 64, K a multiple of 64, 16-byte aligned rows.
+// A [M][K], B [N][K] K-contiguous 16-bit (f32: the form in gemm_stream64_f32.hip), min(M, N) <= 64, K a multiple of 64, 16-byte aligned rows.
 bool gemm_stream64_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
 {
     (void)c;
+    if (d.dtype_ab == MI355_DTYPE_F32) return gemm_stream64_f32_supports(d, a, b, c);      // the f32 form: gemm_stream64_f32.hip
     if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16) return false;
     if (d.dtype_c != MI355_DTYPE_F32 && d.dtype_c != MI355_DTYPE_BF16 && d.dtype_c != MI355_DTYPE_F16) return false;
     if (d.trans_a || !d.trans_b) return false;
@@ -497,6 +498,7 @@ bool gemm_stream64_supports(const mi355_gemm_desc &d, const void *a, const void 
 
 int32_t launch_gemm_stream64(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c)
 {
+    if (d.dtype_ab == MI355_DTYPE_F32) return launch_gemm_stream64_f32(ctx, s, d, a, b, c);
     if (!gemm_stream64_supports(d, a, b, c)) return fail(ctx, MI355_E_UNSUPPORTED, "mi355_gemm: the 64-row streaming kernel does not take this descriptor");
     stream_args g{};
     const bool a_small = d.m <= d.n;

@@ -24,10 +24,16 @@ TABLE = [
     ("C2: 4096^3 f32", (4096, 4096, 4096, F32, F32, 0, 1, 1), "LP_256W4", (0, 0)),
     ("C2, row-major rhs", (4096, 4096, 4096, F32, F32, 0, 0, 1), "LP_256W4", (0, 0)),
     ("f32 GEMV: the row-streaming FMA kernel", (1, 8192, 8192, F32, F32, 0, 1, 1), "SKINNY", (0, 0)),
-    ("f32, 8 columns", (4096, 8, 4096, F32, F32, 0, 1, 1), "SKINNY", (0, 0)),
+    ("f32, 8 columns: the streaming kernel's f32 form from five up (25.6 -> 17.4 us)", (4096, 8, 4096, F32, F32, 0, 1, 1), "STREAM64", (0, 0)),
+    ("f32, 4 rows: a tie, stays on the FMA kernel", (4, 8192, 8192, F32, F32, 0, 1, 1), "SKINNY", (0, 0)),
+    ("f32, 8 rows, K off the 64 grid: the FMA kernel", (8, 4096, 4000, F32, F32, 0, 1, 1), "SKINNY", (0, 0)),
     ("f32 GEMV against a row-major weight: the strip kernel's f32 form", (1, 8192, 8192, F32, F32, 0, 0, 1), "NNROWS", (0, 0)),
     ("f32, 16 rows against a row-major weight", (16, 4096, 4096, F32, F32, 0, 0, 1), "NNROWS", (0, 0)),
-    ("f32, 16 rows: the 128x128 f32 tile (64 FMAs per 16 bytes lose)", (16, 4096, 4096, F32, F32, 0, 1, 1), "F32_MFMA", (0, 0)),
+    ("f32, 16 rows: the streaming kernel's f32 form (round 5; was the 128x128 f32 tile: 45.8 -> 17.4 us)", (16, 4096, 4096, F32, F32, 0, 1, 1), "STREAM64", (0, 0)),
+    ("f32, 16 rows x 8192 x 8192, the shape the round-4 review names (162.6 -> 52.7 us)", (16, 8192, 8192, F32, F32, 0, 1, 1), "STREAM64", (0, 0)),
+    ("f32, 64 columns", (8192, 64, 8192, F32, F32, 0, 1, 1), "STREAM64", (0, 0)),
+    ("f32, 16 rows, K off the 64 grid: the 128x128 f32 tile", (16, 4096, 4000, F32, F32, 0, 1, 1), "F32_MFMA", (0, 0)),
+    ("f32, 65 rows: the 128x128 f32 tile", (65, 4096, 4096, F32, F32, 0, 1, 1), "F32_MFMA", (0, 0)),
     ("C5: 512 x 2048^3 bf16 on one GPU: dripped stores", (2048, 2048, 2048, BF, None, 0, 1, 512), "LP_256Q", (0, 0)),
     ("C5 with an f32 C: the persistent kernel without them", (2048, 2048, 2048, BF, F32, 0, 1, 512), "LP_256P", (0, 0)),
     ("C5, row-major rhs", (2048, 2048, 2048, BF, None, 0, 0, 512), "LP_256Q", (0, 0)),

@@ -1421,6 +1421,62 @@ def test_stream64_refusals_determinism_and_repeated_launches(client, oracle):
         chk(lib.mi355_stream_destroy(ctx, st))
 
 
+# ---- ... its f32 form (gemm_stream64_f32.hip, round 5): v_mfma_f32_16x16x4_f32, both operands through per-wave LDS rings -----------
+@pytest.mark.parametrize("m,n,k,kw", [
+    (16, 8192, 8192, {}),                        # the shape the round-4 review names: 256 workgroups of 32 streamed rows
+    (9, 1000, 2048, {}),                         # one small block with 9 valid rows; ragged streamed extent
+    (16, 33, 64, {}),                            # a single K-block: three of the four waves have nothing to do
+    (12, 48, 128, {"ldc": 56}),                  # two K-blocks; pitched C
+    (16, 64, 192, {}),                           # three K-blocks: fewer than waves
+    (17, 257, 1024, {"lda": 1032, "ldb": 1040}), # two small blocks, one valid row in the second; padded operand rows
+    (32, 4096, 4096, {}),                        # two small blocks, one streamed block per workgroup
+    (32, 9000, 1024, {}),                        # ... two streamed blocks per workgroup (282 workgroups), ragged
+    (33, 640, 1280, {"batch": 3}),               # three small blocks
+    (48, 512, 1600, {"batch": 2, "bcast_b": True}),
+    (64, 2048, 2048, {}),                        # four small blocks: 160 KiB of LDS
+    (64, 8200, 640, {}),
+    (8192, 16, 4096, {}),                        # N <= 64: roles swapped, output block stored transposed
+    (1000, 40, 2048, {"ldc": 48}),
+    (513, 10, 640, {"batch": 2}),
+    (24, 300, 2048, {"batch": 40}),              # many workgroups through the batch
+    (16, 28672, 4096, {}),                       # 448 MiB streamed: non-temporal pieces
+])
+def test_stream64_f32_form_matches_the_oracle(client, oracle, m, n, k, kw):
+    run_case(client, oracle, m, n, k, ElemType.F32, ElemType.F32, True, ALGOS["stream64"], **kw)
+
+
+def test_stream64_f32_form_refusals_determinism_and_capture(client, oracle):
+    for (m, n, k, tb, out) in ((65, 65, 128, True, ElemType.F32), (8, 64, 96, True, ElemType.F32), (8, 64, 128, False, ElemType.F32)):
+        with pytest.raises(ServerError):           # both extents > 64; K not a multiple of 64; row-major B
+            run_case(client, oracle, m, n, k, ElemType.F32, out, tb, ALGOS["stream64"])
+    a = TensorHandle.uniform(client, (16, 4096), ElemType.F32, 3, 1, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (4096, 4096), ElemType.F32, 3, 2, -1.0, 1.0)
+    outs = []
+    for _ in range(4):      # back to back on one stream: rings and the final fold leave nothing behind
+        c = TensorHandle.new_contiguous((16, 4096), client.empty(16 * 4096 * 4), ElemType.F32)
+        ops.matmul(client, a, TensorHandle.new(b.handle, (4096, 4096), (1, 4096), ElemType.F32), c, algo=ALGOS["stream64"])
+        outs.append(c.to_numpy(client).copy())
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])
+    # it needs neither scratch nor tickets: inside a capture window the same kernel runs, the same bits come out
+    import ctypes as C
+    lib, ctx, chk = client.lib, client.ctx, client._s.check
+    d = N.GemmDesc(m=16, n=4096, k=4096, batch=1, lda=4096, ldb=4096, ldc=4096, dtype_ab=N.DTYPE_F32, dtype_c=N.DTYPE_F32, trans_b=1, algo=N.GEMM_ALGO_AUTO)
+    st, g = C.c_void_p(), C.c_void_p()
+    chk(lib.mi355_stream_create(ctx, C.byref(st)))
+    c = client.empty(16 * 4096 * 4)
+    chk(lib.mi355_graph_begin_capture(ctx, st))
+    chk(lib.mi355_gemm(ctx, st, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()), C.c_void_p(c.device_ptr())))
+    chk(lib.mi355_graph_end_capture(ctx, st, C.byref(g)))
+    chk(lib.mi355_graph_replay(ctx, st, g))
+    chk(lib.mi355_sync(ctx, st))
+    sel = C.c_int32()
+    chk(lib.mi355_gemm_select(ctx, C.byref(d), C.byref(sel)))
+    if sel.value == N.GEMM_ALGO_STREAM64:
+        assert np.array_equal(client.read_one(c).view(np.float32).reshape(16, 4096), outs[0])
+    chk(lib.mi355_graph_destroy(ctx, g))
+    chk(lib.mi355_stream_destroy(ctx, st))
+
+
 @pytest.mark.parametrize("m,n,k", [(256, 256, 64), (512, 384, 128), (2048, 2048, 192), (1000, 900, 256), (2048, 2048, 320), (128, 128, 4096)])
 @pytest.mark.parametrize("dtype,out_dtype", [(ElemType.BF16, ElemType.BF16), (ElemType.F16, ElemType.F32)])
 def test_lp128_loader_wave_form_with_rings_shorter_than_their_depth(client, oracle, m, n, k, dtype, out_dtype):
