@@ -117,6 +117,25 @@ def test_dispatcher_decisions_without_a_device(lib, what, shape, kernel, relaid)
     assert (algo.value, (ra.value, rb.value)) == (A[kernel], relaid), what
 
 
+def test_select_compares_against_named_rules_and_the_cost_tables_only():
+    """Round-4 review, item 5: "no numeric literal in select outside the table".  Between the end of `namespace rule` and the end of the
+    dispatcher's namespace (select_fp8 ... select), the only numbers left are tile extents (128, 256), the K-tile (64), element sizes and
+    0 / 1: every measured threshold is a named constant whose measurement is in profiles/dispatch_rules.md under that name."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "cubecl_amd", "csrc", "gemm.cpp")).read()
+    start = src.index("}  // namespace rule")
+    body = re.sub(r"//[^\n]*", "", src[start:src.index("\n}  // namespace\n", start)])
+    assert "int32_t select(" in body and "stream64_wins" in body and "select_f32" in body
+    literals = set(re.findall(r"(?<![A-Za-z_0-9.])(\d+)(?![A-Za-z_0-9.x])", body))
+    assert literals <= {"0", "1", "2", "16", "64", "128", "256"}, sorted(literals)
+    doc = open(os.path.join(root, "profiles", "dispatch_rules.md")).read()
+    rules = src[src.index("namespace rule {"):start]
+    names = re.findall(r"\b([A-Z][A-Z0-9_]{3,}) =", rules)
+    assert len(names) >= 50 and all(n in doc for n in names), [n for n in names if n not in doc]
+
+
 def test_select_refuses_missing_arguments(lib):
     d = N.GemmDesc(m=64, n=64, k=64, batch=1, lda=64, ldb=64, ldc=64, dtype_ab=BF, dtype_c=BF, trans_b=1)
     assert lib.mi355_gemm_select(None, None, C.byref(C.c_int32())) == N.E_INVALID_ARGUMENT

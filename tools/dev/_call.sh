@@ -1,7 +1,10 @@
 set -x
 cd /root/repo
-timeout 900 python -m pytest tests/test_gpu_gemm.py tests/test_gpu_select_audit.py -q -x -m gpu -k "f32 or stream64 or audit or capture" 2>&1 | tail -8
-timeout 900 python tools/ab_algos.py --f32 --rounds 5 --algos auto,skinny,stream64 \
-  1x8192x8192 2x8192x8192 3x8192x8192 4x8192x8192 5x8192x8192 6x8192x8192 8x8192x8192 1x4096x4096 2x4096x4096 4x4096x4096 8x4096x4096 4x28672x4096 8x28672x4096 \
-  8x2048x8192 4x2048x2048 8x1024x1024 8192x4x8192 8192x8x8192 4096x8x4096 2x16384x2048 8x16384x2048 16x6144x6144 16x5120x8192 16x28672x4096 > gpurun_out/r05_stream64_f32_few_rows.txt 2>&1
-cat gpurun_out/r05_stream64_f32_few_rows.txt
+SH=""
+for mn in 3072x3072 2168x7344 3648x8832 3200x2496 13536x536 4096x4096 2048x2048 2560x2560 4096x2048 6144x4096 1792x6112 4352x2624 58376x192 5120x5120 1536x1536 12288x1024 3584x3584 2304x2304; do
+  for k in 128 256 512; do SH="$SH ${mn}x${k}"; done
+done
+for mn in 3072x3072 2168x7344 4096x4096 6144x4096 2560x2560; do SH="$SH ${mn}x384 ${mn}x768"; done
+timeout 900 python tools/ab_algos.py --rounds 5 --algos auto,lp128,lp256x128,lp256w4,lp256x192,lp192x192,lp256m16 $SH > gpurun_out/r05_tile_short_k_ab.txt 2>&1
+timeout 900 python tools/ab_algos.py --nn --rounds 5 --algos auto,lp128,lp256x128,lp256w4,lp256x192,lp192x192 $SH > gpurun_out/r05_tile_short_k_nn_ab.txt 2>&1
+tail -5 gpurun_out/r05_tile_short_k_ab.txt gpurun_out/r05_tile_short_k_nn_ab.txt
