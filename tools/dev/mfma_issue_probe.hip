@@ -122,6 +122,10 @@ int main()
             RUN16(2, 1, 1, false, "16x16x32 diagonal order, rotating A"); RUN16(2, 0, 1, false, "16x16x32 diagonal order, fixed operands");
             RUN16(0, 1, 2, false, "16x16x32 order j/i, rotating A, two waves per SIMD"); RUN16(2, 1, 2, false, "16x16x32 diagonal, rotating A, two waves per SIMD");
             RUN32(0, 1, 2, false, "32x32x16 order j/i, rotating A, two waves per SIMD");
+            // (late in round 5, after the fp8 probe showed the order mattering for the wide shape too)
+            RUN32(1, 1, 1, false, "32x32x16 order i/j (share srcB), rotating A"); RUN32(1, 0, 1, false, "32x32x16 order i/j, fixed operands");
+            RUN32(0, 0, 1, false, "32x32x16 order j/i, fixed operands"); RUN32(2, 1, 1, false, "32x32x16 diagonal order, rotating A");
+            RUN32(0, 1, 1, false, "32x32x16 order j/i, rotating A (again)"); RUN32(1, 1, 1, false, "32x32x16 order i/j, rotating A (again)");
         }
     }
     return 0;
