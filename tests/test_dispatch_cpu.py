@@ -70,6 +70,8 @@ TABLE = [
     ("row-major rhs, 196 tiles of 256^2", (3584, 3584, 3584, F16, None, 0, 0, 1), "LP_256W4", (0, 0)),
     ("row-major rhs, tall: 128 tiles of 256 x 192 (65.7 us against 68.4 on the 256 x 128 tile)", (8192, 1024, 4096, BF, None, 0, 0, 1), "LP_256X192", (0, 0)),
     ("one round of 256^2 tiles", (4096, 4096, 4096, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
+    ("288 tiles of 256^2, long K: the square tile with its leftover strip split along K (240.9 us; 256 x 192 265.0)", (4608, 4096, 8192, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
+    ("272 tiles of 256^2 at K = 4096: the split form loses to two rounds of 192^2 (130.9 / 122.8)", (4352, 4096, 4096, BF, None, 0, 1, 1), "LP_192X192", (0, 0)),
     ("a partly filled last round (split inside the launch)", (6144, 6144, 6144, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
     ("weight gradient lhs^T . grad: native", (512, 512, 8192, BF, None, 1, 0, 1), "LP_128", (0, 0)),
     ("weight gradient, mid size: native", (2048, 2048, 8192, BF, None, 1, 0, 1), "LP_128", (0, 0)),
