@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Fills the placeholders (C3_TF, C4_GBS, ... EVIDENCE_SHA) that README.md and profiles/README.md carry until an evidence call has been
-installed (tools/install_evidence.py TAG SHA) with the figures of profiles/TAG_bench.json and the files next to it.
+"""Writes README.md and profiles/README.md from tools/templates/*.in: the placeholders (C3_TF, C4_GBS, ... EVIDENCE_SHA) become the figures of
+profiles/TAG_bench.json and the files next to it, i.e. of the evidence call tools/install_evidence.py TAG SHA installed.  Edit the templates.
 usage: tools/fill_evidence_numbers.py TAG SHA"""
 import json, re, sys
 tag, sha = sys.argv[1], sys.argv[2]
@@ -31,8 +31,8 @@ sub = {
     "PYTEST_LINE": f"{m.group(1)} passed, {m.group(2) or 0} skipped",
     "C1_US": f"{ex['sum_things_1M_f32']['back_to_back_us']}",
 }
-for path in ("README.md", P + "README.md"):
-    s = open(path).read()
+for src, path in (("tools/templates/README.md.in", "README.md"), ("tools/templates/profiles_README.md.in", P + "README.md")):
+    s = open(src).read()
     for k in sorted(sub, key=len, reverse=True):          # longest first: SHARD_SUM_FRAC before SHARD_SUM
         s = re.sub(rf"\b{k}\b", sub[k], s)
     open(path, "w").write(s)
