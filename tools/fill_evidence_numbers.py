@@ -3,6 +3,7 @@
 profiles/TAG_bench.json and the files next to it, i.e. of the evidence call tools/install_evidence.py TAG SHA installed.  Edit the templates.
 usage: tools/fill_evidence_numbers.py TAG SHA"""
 import json, re, sys
+sys.path.insert(0, ".")
 tag, sha = sys.argv[1], sys.argv[2]
 P = "profiles/"
 r = json.loads([l for l in open(P + f"{tag}_bench.json") if l.startswith("{")][-1])
@@ -16,7 +17,7 @@ sub = {
     "C3_TF": fmt(r["value"], 1), "C3_FRAC": f"{rf['frac']:.4f}", "C3_MS": f"{rf['kernel_ms']}", "C3_GHZ": f"{rf['shader_clock_GHz']}",
     "C3_ATCLK": f"{rf['frac_of_peak_at_clock']:.3f}",
     "C3_TRAFFIC": (f"{rf['traffic'] / rf['algorithmic_bytes_per_launch']:.2f}" if rf.get("traffic") else "n/a"),
-    "C3_L2": str(rf.get("l2_hit_rate", "n/a")), "C3_UTIL": str(rf.get("mfma_util_pmc", "n/a")),
+    "C3_L2": str(json.load(open(P + "pmc_traffic.json")).get(f"gemm_bf16_8192_algo{__import__('bench').HEADLINE_ALGO}", {}).get("l2_hit_rate", "n/a")), "C3_UTIL": str(rf.get("mfma_util_pmc", "n/a")),
     "C4_GBS": fmt(rf["reduce_sum_achieved_GBs"]), "C4_FRAC": f"{rf['reduce_sum_frac']:.3f}", "C4_PS": f"{rf['reduce_sum_frac_per_sample_median']:.3f}",
     "READ_PROBE": fmt(ex["measured_ceilings"]["hbm_read_GBs"]),
     "SHARD_SUM_FRAC": f"{rf['reduce_shard_of_8_sum_frac']:.2f}", "SHARD_FUSED_FRAC": f"{rf['reduce_shard_of_8_fused_frac']:.2f}",

@@ -6,8 +6,12 @@ OUT=gpurun_out; mkdir -p $OUT
 TAG=${1:-run}
 echo "== rocm-smi"; rocm-smi --showproductname 2>/dev/null | head -8
 echo "== pytest -m gpu"
+# (SKIP_PYTEST=1: the suite already ran on this tree in an earlier call of the same evidence round -- e.g. the one that took the PMC passes,
+#  whose json files must sit in profiles/ BEFORE the bench line is taken; its log is kept)
+if [ "${SKIP_PYTEST:-0}" != 1 ]; then
 timeout 1200 python -m pytest tests -m gpu -q --no-header --timeout 300 -p no:cacheprovider --maxfail=60 > $OUT/${TAG}_pytest.log 2>&1
 echo "pytest exit $?"; tail -n 40 $OUT/${TAG}_pytest.log
+fi
 echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/${TAG}_smoke.log 2>&1; echo "smoke exit $?"; tail -n 5 $OUT/${TAG}_smoke.log
 echo "== bench"
