@@ -72,7 +72,15 @@ TABLE = [
     ("one round of 256^2 tiles", (4096, 4096, 4096, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
     ("288 tiles of 256^2, long K: the square tile with its leftover strip split along K (240.9 us; 256 x 192 265.0)", (4608, 4096, 8192, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
     ("272 tiles of 256^2 at K = 4096: the split form loses to two rounds of 192^2 (130.9 / 122.8)", (4352, 4096, 4096, BF, None, 0, 1, 1), "LP_192X192", (0, 0)),
-    ("a partly filled last round (split inside the launch)", (6144, 6144, 6144, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
+    ("576 tiles of 256^2: 2.7 rounds of 256 x 192 tiles (344.5 us) beat the square tile with its leftover strip split (360.0)", (6144, 6144, 6144, BF, None, 0, 1, 1), "LP_256X192", (0, 0)),
+    ("560 tiles, K = 8192: the split square tile (449.5 us; 256 x 192 450.2)", (7168, 5120, 8192, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
+    ("576 tiles, short K: 256 x 192 tiles (71.0 us) instead of the dripped-store persistent form (74.1)", (6144, 6144, 1024, BF, None, 0, 1, 1), "LP_256X192", (0, 0)),
+    ("65-128 rows x 128 tiles, K = 512: one round of 192^2 tiles instead of a split K (10.6 us / 18.9)", (128, 16384, 512, BF, None, 0, 1, 1), "LP_192X192", (0, 0)),
+    ("... not at K = 2048 with few rows (34.6 / 31.6), but with few columns (31.8 / 37.8)", (128, 16384, 2048, BF, None, 0, 1, 1), "LP_128", (0, 0)),
+    ("few columns, K = 2048, 128 tiles", (16384, 104, 2048, BF, None, 0, 1, 1), "LP_192X192", (0, 0)),
+    ("116 rows, a second round of 128-column tiles a quarter full: 192^2 tiles (45.9 us / 52.1)", (116, 40960, 2048, BF, None, 0, 1, 1), "LP_192X192", (0, 0)),
+    ("two K-tiles along 29512 rows: the 128^2 kernel's single-stage form, not the streaming kernel (6.2 us / 15.3)", (29512, 32, 128, BF, None, 0, 1, 1), "LP_128", (0, 0)),
+    ("one K-tile, two rows", (2, 42272, 64, BF, None, 0, 1, 1), "LP_128", (0, 0)),
     ("weight gradient lhs^T . grad: native", (512, 512, 8192, BF, None, 1, 0, 1), "LP_128", (0, 0)),
     ("weight gradient, mid size: native", (2048, 2048, 8192, BF, None, 1, 0, 1), "LP_128", (0, 0)),
     ("transposed lhs on a 256-tile shape: native on the 256^2 kernel as well", (8192, 8192, 8192, BF, None, 1, 0, 1), "LP_256W4", (0, 0)),

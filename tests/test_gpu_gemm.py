@@ -501,8 +501,9 @@ def test_unaligned_c_gives_the_bits_of_the_aligned_form_and_stays_inside_its_row
     ldc1 = 4101
     c1 = client.empty((1 + m * ldc1 + 7) * 2)
     client._s.check(client.lib.mi355_memset(client.ctx, None, c1.device_ptr(), 0xEE, c1.size))
-    d = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=k, ldc=ldc0, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_BF16, trans_b=1)
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    # (forced: since the cost tables cover several rounds down to K = 512, AUTO hands this descriptor to the 256 x 192 tile -- the narrow tiles'
+    #  own unaligned-C cases are test_lp256x192_c_rows_off_the_16_byte_grid_batches_and_refusals)
+    d = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=k, ldc=ldc0, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_BF16, trans_b=1, algo=N.GEMM_ALGO_LP_256W4)
     client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(ta.handle.device_ptr()),
                                           C.c_void_p(tb.handle.device_ptr()), C.c_void_p(c0.device_ptr())))
     d.ldc = ldc1
@@ -693,9 +694,13 @@ def test_row_major_b_16bit_is_staged_natively_by_the_256_tile_kernel(client, ora
     resolves to the 256x256 kernel and the re-layout plan is empty; values against the f64 oracle like every other layout."""
     odt = ElemType.F32 if out == "f32" else dtype
     d = _nn_desc(m, n, k, dtype, odt, ldb)
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    # (one or two K-tiles: since late round 5 the 128 x 128 kernel's single-stage form takes them in this layout too -- 3392 x 2752 x 128 7.9 us
+    #  against 10.5 -- still without a copy; the 256 x 256 kernel's form is then covered forced)
+    assert ops.gemm_select(client, d) == (N.GEMM_ALGO_LP_128 if k <= 128 else N.GEMM_ALGO_LP_256W4)
     assert ops.gemm_relayout_plan(client, d) == (False, False)
     run_case(client, oracle, m, n, k, dtype, odt, False, ALGOS["auto"], ldb=ldb)
+    if k <= 128:
+        run_case(client, oracle, m, n, k, dtype, odt, False, ALGOS["lp256w4"], ldb=ldb)
 
 
 @pytest.mark.parametrize("dtype", [ElemType.BF16, ElemType.F16])
@@ -747,15 +752,18 @@ def test_row_major_b_mid_size_shapes_are_native_on_the_128_tile_kernel(client, o
 
 
 def test_row_major_b_through_the_strip_split_of_a_partly_filled_round(client, oracle):
-    """24 x 24 = 576 tiles of 256x256 (2.25 rounds): AUTO cuts a strip off and splits its K (gemm.cpp plan_tail_split).  With row-major B
+    """18 x 16 = 288 tiles of 256x256 (1.125 rounds) with a long K: AUTO cuts a strip off and splits its K (gemm.cpp plan_tail_split).  With row-major B
     the strip's K slices start k rows further down B (not k columns further along its rows) and a strip of columns starts at a column
     offset: same cut, same slabs, same fold -- the bits of the [N][K] launch.  (Until round 5 this ran on 4352 x 4096 x 2048; the cost
-    table now hands that [N][K] descriptor to a 192 x 192 tile, launched whole -- checked below -- so the twin moved past the table.)"""
+    table now hands that [N][K] descriptor to a 192 x 192 tile, launched whole -- checked below; it prices the square tile WITH the split, which
+    keeps 4608 x 4096 x 8192: 240.9 us against 265.0 on 256 x 192 -- and, its domain widened to three rounds, 6144^3 to the 256 x 192 tile.)"""
     along, extent, splits = C.c_int32(), C.c_int64(), C.c_int32()
     d_nt = N.GemmDesc(m=4352, n=4096, k=2048, batch=1, lda=2048, ldb=2048, ldc=4096, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_BF16, trans_b=1)
     assert ops.gemm_select(client, d_nt) == N.GEMM_ALGO_LP_192X192
     assert client.lib.mi355_gemm_tail_plan(C.byref(d_nt), C.byref(along), C.byref(extent), C.byref(splits)) == N.OK and splits.value == 1
-    m = n = k = 6144
+    m, n, k = 4608, 4096, 8192
+    d6 = N.GemmDesc(m=6144, n=6144, k=6144, batch=1, lda=6144, ldb=6144, ldc=6144, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_BF16, trans_b=1)
+    assert ops.gemm_select(client, d6) == N.GEMM_ALGO_LP_256X192
     a = TensorHandle.uniform(client, (m, k), ElemType.BF16, 0x5EEDC0BE, 91, -1.0, 1.0)
     b_nk = TensorHandle.uniform(client, (n, k), ElemType.BF16, 0x5EEDC0BE, 92, -1.0, 1.0)
     b_kn = ops.into_contiguous(client, TensorHandle.new(b_nk.handle, (k, n), (1, k), ElemType.BF16))
@@ -1033,7 +1041,8 @@ def test_fp8_rejects_what_it_does_not_do(client):
 
 # ---- partly filled last round: main part + split-K strip (gemm.cpp plan_tail_split) ------------------------------------------
 @pytest.mark.parametrize("m,n,k,dtype,out", [
-    (6144, 6144, 1024, ElemType.BF16, ElemType.BF16),      # 576 tiles = 2.25 rounds: strip of rows, K split
+    (4608, 4096, 8192, ElemType.BF16, ElemType.BF16),      # 288 tiles = 1.125 rounds, long K: strip of two tile rows, K split eight ways
+    (6144, 6144, 1024, ElemType.BF16, ElemType.BF16),      # (until round 5 the split's case; now 256 x 192 tiles, launched whole)
     (5000, 3328, 2048, ElemType.BF16, ElemType.F32),       # 20 x 13 = 260 tiles, ragged M: strip of columns
     (3328, 5000, 2048, ElemType.F16, ElemType.F16),        # the transposed case, ragged N (n % 4 == 0)
     (4608, 4608, 2048, ElemType.F8E4M3, ElemType.BF16),    # fp8: 18 x 18 = 324 tiles
@@ -1346,7 +1355,10 @@ def test_output_bound_shapes_select_the_small_tile(client):
     assert sel(4096, 2304, 4096) == N.GEMM_ALGO_LP_256X192                            # 144 tiles of 256^2, 288 of 256 x 128 (two rounds), 192 of 256 x 192: the table's call
     assert sel(32, 512, 2048) == sel(512, 16, 2048) == sel(32, 6144, 8192) == N.GEMM_ALGO_STREAM64   # few workgroups are fine up to K = 2048; 192 at any K
     assert sel(32, 512, 8192) == sel(512, 16, 8192) == sel(16, 2048, 8192) == sel(32, 1024, 4096) == N.GEMM_ALGO_LP_128   # round 4: split-K instead
-    assert sel(8192, 3072, 512) == N.GEMM_ALGO_LP_256Q and sel(8192, 3072, 640) == N.GEMM_ALGO_LP_256P   # 384 tiles: persistent from one round up
+    assert sel(8192, 4096, 512) == N.GEMM_ALGO_LP_256Q and sel(9216, 3072, 640) == N.GEMM_ALGO_LP_256P   # 512 / 432 tiles: persistent from one round up
+    # (384 tiles at K = 512 ... 2048: the cost tables, multi-round down to K = 512 since late round 5, take 256 x 192 tiles -- within 5 % of the
+    #  dripped-store form at K = 512, ahead from K = 1024: profiles/r05_persistent_vs_narrow_ab.txt)
+    assert sel(8192, 3072, 512) == sel(8192, 3072, 2048) == N.GEMM_ALGO_LP_256X192
     assert sel(4096, 4096, 512) == N.GEMM_ALGO_LP_256W4                               # exactly one round: the plain kernel
 
 

@@ -161,25 +161,27 @@ def test_tail_plan_splits_only_small_leftover_rounds():
     # whole rounds, or a leftover of half a round and more: one plain launch
     for shape in ((8192, 8192, 8192), (4096, 4096, 4096), (4096, 6144, 4096), (5120, 5120, 5120), (9216, 8192, 4096)):
         assert _tail_plan(*shape)[2] == 1, shape
-    # 576 tiles = 2.25 rounds: a strip of tile rows, K split so that strip tiles x splits <= 256
-    along, extent, splits = _tail_plan(6144, 6144, 6144)
-    strip_tiles = (6144 - extent) // 256 * 24
+    # 18 x 16 tiles (1.125 rounds) with a long K: a strip of two tile rows, K split so that strip tiles x splits <= 256
+    along, extent, splits = _tail_plan(4608, 4096, 8192)
+    strip_tiles = (4608 - extent) // 256 * 16
     assert splits > 1 and along == 1 and extent % 256 == 0 and 0 < strip_tiles <= 96 and strip_tiles * splits <= 256
-    assert (6144 // 64) % splits == 0                                  # whole K-tiles per slice
-    # 32 x 17 tiles (32 more than two rounds): the plain launch keeps whole rounds, the strip the rest
-    along, extent, splits = _tail_plan(8192, 4352, 4096)
+    assert (8192 // 64) % splits == 0                                  # whole K-tiles per slice
+    # 32 x 17 tiles (32 more than two rounds), long K: the plain launch keeps whole rounds, the strip the rest
+    along, extent, splits = _tail_plan(8192, 4352, 8192)
     tiles_main = (extent // 256) * (17 if along else 32)
     assert splits > 1 and extent % 256 == 0 and tiles_main == 512 and (32 * 17 - tiles_main) * splits <= 256
+    # the same grids with a shorter K, and 6144^3 (576 tiles): the cost tables (three rounds wide since late round 5) give them to the 256 x 192
+    # tile, and the plan answers for the kernel mi355_gemm will run -- no strip
+    assert _tail_plan(8192, 4352, 4096)[2] == 1 and _tail_plan(6144, 6144, 6144)[2] == 1
     # 20 x 13 tiles of 256^2 with a ragged M: since round 5 the cost table gives the shape to the 192^2 tile, and the plan answers for
     # the kernel mi355_gemm will run -- no strip
     assert _tail_plan(5000, 3328, 2048)[2] == 1
-    assert (2048 // 64) % splits == 0
     # fp8 counts K-tiles of 128, f32 of 32; batches and transposed A are never split
     assert _tail_plan(4608, 4096, 8192, dtype=N.DTYPE_F8E4M3)[2] > 1
     assert _tail_plan(4608, 4096, 8192, batch=2)[2] == 1
-    assert _tail_plan(6144, 6144, 6144, trans_a=1, lda=6144)[2] == 1
+    assert _tail_plan(4608, 4096, 8192, trans_a=1, lda=4608)[2] == 1
     # row-major B (round 3: staged natively by the 256x256 kernel for 16-bit operands too) is cut exactly like [N][K] B; fp8 is not
-    assert _tail_plan(6144, 6144, 6144, trans_b=0, ldb=6144) == _tail_plan(6144, 6144, 6144)
+    assert _tail_plan(4608, 4096, 8192, trans_b=0, ldb=4096) == _tail_plan(4608, 4096, 8192)
     assert _tail_plan(4608, 4096, 8192, dtype=N.DTYPE_F8E4M3, trans_b=0, ldb=4096)[2] == 1
     assert _tail_plan(6144, 6144, 256)[2] == 1                          # too few K-tiles to split
 
