@@ -81,6 +81,11 @@ TABLE = [
     ("116 rows, a second round of 128-column tiles a quarter full: 192^2 tiles (45.9 us / 52.1)", (116, 40960, 2048, BF, None, 0, 1, 1), "LP_192X192", (0, 0)),
     ("two K-tiles along 29512 rows: the 128^2 kernel's single-stage form, not the streaming kernel (6.2 us / 15.3)", (29512, 32, 128, BF, None, 0, 1, 1), "LP_128", (0, 0)),
     ("one K-tile, two rows", (2, 42272, 64, BF, None, 0, 1, 1), "LP_128", (0, 0)),
+    ("5 rows, K = 1024 on 1670 streaming workgroups: the 128^2 kernel (23.8 us / 26.9)", (5, 53432, 1024, BF, None, 0, 1, 1), "LP_128", (0, 0)),
+    ("... on 1125: still streams (20.6 / 21.8)", (8, 36000, 1024, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
+    ("16 rows against a row-major weight whose N is not whole 256-column strips: the 128^2 kernel (46.2 us / 57.9)", (16, 14920, 8192, BF, None, 0, 0, 1), "LP_128", (0, 0)),
+    ("... whole strips: the strip kernel", (16, 14336, 8192, BF, None, 0, 0, 1), "NNROWS", (0, 0)),
+    ("one row against a ragged row-major weight: the strip kernel all the same (48.4 / 55.1)", (1, 40568, 3072, BF, None, 0, 0, 1), "NNROWS", (0, 0)),
     ("weight gradient lhs^T . grad: native", (512, 512, 8192, BF, None, 1, 0, 1), "LP_128", (0, 0)),
     ("weight gradient, mid size: native", (2048, 2048, 8192, BF, None, 1, 0, 1), "LP_128", (0, 0)),
     ("transposed lhs on a 256-tile shape: native on the 256^2 kernel as well", (8192, 8192, 8192, BF, None, 1, 0, 1), "LP_256W4", (0, 0)),
