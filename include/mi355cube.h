@@ -394,13 +394,14 @@ enum {
     MI355_GEMM_ALGO_SKINNY = 8,   /* bf16/f16, M <= 16 or N <= 16: the large operand streamed once from HBM,
                                      v_dot2c_f32 accumulation, no matrix core (gemm_skinny.hip)      */
     MI355_GEMM_ALGO_STREAM64 = 9, /* bf16/f16, M <= 64 or N <= 64: 32 streamed rows x the whole K per workgroup,
-                                     loader waves + MFMA, no split-K (gemm_stream64.hip)             */
+                                     loader waves + MFMA, no split-K (gemm_stream64.hip); f32 operands: the same shapes
+                                     on v_mfma_f32_16x16x4_f32 with per-wave LDS rings (gemm_stream64_f32.hip)         */
     MI355_GEMM_ALGO_LP_256X128 = 10, /* bf16/f16 256x128x64 tile (gemm_lp128.hip, MI = 4): three-stage LDS ring + loader
                                      waves, one workgroup per CU; mid-size shapes of at most one round of such tiles */
     MI355_GEMM_ALGO_NNROWS = 11,  /* bf16/f16, M <= 16 against a row-major [K][N] weight (the rhs TensorHandle::new_contiguous
                                      gives): wide row strips streamed once, transposed in registers into 4x4x4 MFMA
                                      operands, K slices folded by the last workgroup to arrive (gemm_nnrows.hip) */
-    MI355_GEMM_ALGO_LP_256X192 = 12, /* bf16/f16, [N][K] rhs: the 4-wave kernel of _LP_256W4 on a 256 x 192 tile (each wave 128 x 96):
+    MI355_GEMM_ALGO_LP_256X192 = 12, /* bf16/f16, [N][K] or row-major rhs: the 4-wave kernel of _LP_256W4 on a 256 x 192 tile (each wave 128 x 96):
                                      grids on which the square tile leaves CUs idle (ABI 8; gemm_lp256w4.hip NJ = 3) */
     MI355_GEMM_ALGO_LP_192X192 = 13, /* ... and on a 192 x 192 tile (each wave 96 x 96; NJ = NI = 3) */
     MI355_GEMM_ALGO_LP_256M16 = 14   /* bf16/f16, [N][K] rhs: the 256 x 256 tile on v_mfma_f32_16x16x32 (eight MFMAs per A fragment: the
