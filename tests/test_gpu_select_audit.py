@@ -2,7 +2,7 @@
 
 `gemm.cpp::select` holds ~25 measured crossovers between ten kernels.  They were measured on the builder's boxes; on a box
 where one of them is wrong, the symptom used to be a slower bench entry and nothing else.  This test times AUTO against EVERY
-kernel that accepts the descriptor over a fixed grid of 52 bf16 shapes -- the bench's skinny / output-bound / mid-size / decode
+kernel that accepts the descriptor over a fixed grid of 60 bf16 shapes -- the bench's skinny / output-bound / mid-size / decode
 shapes among them -- interleaved, three rounds, medians, cold operands (launches rotate through operand sets larger than the
 Infinity Cache), and fails when AUTO is more than 15 % AND more than 3 us behind the best forced kernel on any shape (3 us: launches
 of 8-15 us carry about +-1 us of launch-to-launch noise per kernel; the bar was 2 us until the last evidence call of round 3, where the
@@ -35,6 +35,9 @@ GRID = [
     # round 5: the cost table's band (one round of 256 x 256 / 256 x 192 / 192 x 192 / 256 x 128 / 128 x 128 tiles) and the 16x16x32 kernel's ground
     (2304, 2304, 2304), (2560, 2560, 1024), (4096, 2048, 1024), (3072, 3072, 1024), (2048, 3072, 8192), (4096, 3072, 4096), (3584, 3584, 3584),
     (1792, 4864, 4096), (2048, 4608, 1024), (2816, 2816, 4096), (1920, 1920, 4096), (8192, 8192, 8192),
+    # late round 5: the tables' third round and K = 512 over several rounds, the 65-128-row band, one or two K-tiles along a long side
+    (4672, 7360, 3072), (6144, 6144, 1024), (3520, 10112, 512), (128, 16384, 512), (16384, 104, 1024), (116, 40960, 2048), (29512, 32, 128),
+    (5, 53432, 1024),
 ]
 ALGOS = ["auto", "lp128", "lp256x128", "lp256w4", "lp256p", "lp256q", "stream64", "skinny", "lp256x192", "lp192x192", "lp256m16"]
 # few rows against a ROW-MAJOR [K][N] weight (review of round 3, next #6): the rhs layout TensorHandle::new_contiguous gives
@@ -42,6 +45,10 @@ GRID_NN = [(1, 8192, 8192), (4, 8192, 8192), (8, 8192, 8192), (16, 8192, 8192), 
            (16, 4096, 14336), (16, 28672, 8192), (4, 32000, 4096), (1, 128256, 4096), (16, 128256, 4096), (32, 8192, 8192), (16, 14336, 4096),
            (16, 16384, 4096), (12, 8192, 8192), (16, 6144, 6144), (16, 12288, 4096)]
 ALGOS_NN = ["auto", "lp128", "nnrows"]
+# f32 operands with few rows or columns (round 5: the streaming kernel's f32 form between the FMA kernel and the 128 x 128 f32 tile)
+GRID_F32 = [(1, 8192, 8192), (4, 8192, 8192), (8, 8192, 8192), (16, 8192, 8192), (32, 4096, 4096), (64, 8192, 8192), (16, 28672, 4096),
+            (4096, 32, 4096), (16, 1024, 1024), (8192, 8, 8192), (128, 4096, 4096)]
+ALGOS_F32 = ["auto", "f32", "skinny", "stream64"]
 
 
 def test_auto_is_within_15_percent_of_the_best_forced_kernel_on_every_shape_of_the_grid(client):
@@ -52,13 +59,17 @@ def test_auto_on_few_rows_times_a_row_major_weight(client):
     audit(client, GRID_NN, ALGOS_NN, True, "select_audit_nn.txt")
 
 
-def audit(client, grid, algos, nn, log_name):
+def test_auto_on_f32_few_rows(client):
+    audit(client, GRID_F32, ALGOS_F32, False, "select_audit_f32.txt", f32=True)
+
+
+def audit(client, grid, algos, nn, log_name, f32=False):
     sys.path.insert(0, str(ROOT / "tools"))
     sys.path.insert(0, str(ROOT))
     import ab_algos
     import bench
     ev = bench.Events(client)
-    res = ab_algos.measure(client, ev, grid, algos, rounds=3, iters=10, nn=nn)
+    res = ab_algos.measure(client, ev, grid, algos, rounds=3, iters=10, nn=nn, f32=f32)
 
     def is_behind(r):
         us = {a: t for a, t in r["us"].items() if t == t}
@@ -67,7 +78,7 @@ def audit(client, grid, algos, nn, log_name):
     # a shape that looks behind is measured once more, longer, before it counts (a 20 us launch beside a DVFS step is noisy)
     suspects = [shape for shape, r in res.items() if is_behind(r)]
     if suspects:
-        res.update(ab_algos.measure(client, ev, suspects, algos, rounds=7, iters=20, nn=nn))
+        res.update(ab_algos.measure(client, ev, suspects, algos, rounds=7, iters=20, nn=nn, f32=f32))
     lines, behind = [], []
     for (m, n, k), r in res.items():
         us = {a: t for a, t in r["us"].items() if t == t}
