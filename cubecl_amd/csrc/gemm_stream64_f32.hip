@@ -23,6 +23,7 @@
 // within the parity tolerance of tests/test_gpu_gemm.py, not bit-identical to the tile kernels (different association).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "gemm_common.hpp"
 
@@ -62,6 +63,14 @@ __device__ __forceinline__ void glds16(const void *ubase_in, uint32_t voff, uint
 __device__ __forceinline__ uint32_t lds_addr_of(const void *p)
 {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)p;
+}
+
+template <int N, typename F, int I = 0> __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, F, I + 1>(static_cast<F &&>(f));
+    }
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt()
@@ -124,8 +133,19 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_stream64_f32_kernel(rows_args
 #pragma unroll
         for (int b = 0; b < NBW; ++b) acc[a][b][0] = acc[a][b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // one stage: fragments out of LDS (lane: row j, quad gq of each of the four 16-k chunks), the slot refilled, 16 MB NBW MFMAs
-    auto consume = [&](int stage, int refill_it, bool refill) {
+    // piece T of a stage (the streamed blocks' first), by itself
+    auto issue_one = [&](int stage, int it, auto tt) {
+        constexpr int T = decltype(tt)::value, B = T / 4, Q = T % 4;
+        const int64_t koff = (int64_t)(wave + it * WAVES) * KB;
+        const uint32_t dst = lds_addr_of(ring + stage * STAGE_BYTES) + B * BLOCK_BYTES + Q * 1024;
+        if constexpr (B < NBW) glds16<NT>(big + koff, voff_big[B][Q], dst);
+        else glds16<false>(small_ + koff, voff_small[B - NBW][Q], dst);
+    };
+    // one stage: fragments out of LDS (lane: row j, quad gq of each of the four 16-k chunks), then 16 MB NBW MFMAs with the slot's refill
+    // dealt out among them -- a DMA piece costs its issuing wave ~100 cycles, and in a block of twelve in front of the MFMAs the matrix
+    // pipe sat idle for all of them (profiles/r05_stream64_f32_rows_form.txt)
+    auto consume = [&](int stage, int refill_it, auto refill_c) {
+        constexpr bool refill = decltype(refill_c)::value;
         const char *st = ring + stage * STAGE_BYTES + j * ROW_BYTES;
         f32x4 fw[NBW][4], fs[MB][4];
 #pragma unroll
@@ -137,16 +157,21 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_stream64_f32_kernel(rows_args
             for (int b = 0; b < MB; ++b) fs[b][c] = *reinterpret_cast<const f32x4 *>(st + (NBW + b) * BLOCK_BYTES + phys);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        // the slot is read out: it may be overwritten
-        if (refill) issue(stage, refill_it);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<16>([&](auto gg) {
+            constexpr int G = decltype(gg)::value, C = G / 4, E = G % 4;
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+            for (int a = 0; a < MB; ++a)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int a = 0; a < MB; ++a)
-#pragma unroll
-                    for (int b = 0; b < NBW; ++b)
-                        acc[a][b][e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fs[a][c][e], fw[b][c][e], acc[a][b][e & 1], 0, 0, 0);
+                for (int b = 0; b < NBW; ++b)
+                    acc[a][b][E & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fs[a][C][E], fw[b][C][E], acc[a][b][E & 1], 0, 0, 0);
+            if constexpr (refill) {
+                static_for<(G + 1) * PIECES / 16 - G * PIECES / 16>([&](auto tt) {
+                    issue_one(stage, refill_it, std::integral_constant<int, G * PIECES / 16 + decltype(tt)::value>{});
+                });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
     };
 
     // prologue: S stages in flight (a wave with fewer K-blocks than stages issues what it has)
@@ -155,12 +180,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_stream64_f32_kernel(rows_args
     int it = 0, stage = 0;
     for (; it + S < count; ++it) {                  // steady state: S - 1 younger stages stay in flight
         wait_vmcnt<(S - 1) * PIECES>();
-        consume(stage, it + S, true);
+        consume(stage, it + S, std::true_type{});
         stage = stage + 1 == S ? 0 : stage + 1;
     }
     for (; it < count; ++it) {                                                    // the last S stages: nothing left to issue
         wait_vmcnt<0>();
-        consume(stage, 0, false);
+        consume(stage, 0, std::false_type{});
         stage = stage + 1 == S ? 0 : stage + 1;
     }
 
@@ -185,6 +210,132 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_stream64_f32_kernel(rows_args
             const int m = 16 * a + 4 * gq + r;
             if (m < g.small_rows) out[(int64_t)m * g.out_stride_small] = sum[r];
         }
+    }
+}
+
+// 49 ... 64 small rows (MB = 4 blocks; measured with three too: never ahead): the form above gives every wave its own copy of all MB small blocks, which leaves the ring
+// one stage of look-ahead (16 KiB of the streamed operand in flight per CU: 64 x 8192 x 8192 122 us).  Here the waves split the SMALL
+// rows instead of K: wave w owns small block w and its 16 x 32 piece of the output, all MB waves walk the same K-blocks and SHARE the
+// two streamed blocks of a stage, which they fetch together (wave w issues pieces w, w + MB, ...) -- one s_barrier per K-block ("my
+// pieces of stage i have landed" / "everyone is done reading stage i - 1", whose slot is then refilled), six stages deep: 40 KiB of
+// the streamed operand in flight.  No K split, so no final fold.  The bound is the f32 matrix core: 32 MFMAs x 32 cycles per wave
+// and K-block of 64 -- 131 k cycles = 62 us at 64 x 8192 x 8192 (measured: 97.5, against 106.1 on the K-split form; the refill's DMA pieces are
+// dealt out among the MFMAs in both forms: issued as a block in front of them they cost 64 rows 15 us).
+template <int MB, int S, bool NT>
+__global__ __launch_bounds__(MB * 64) void gemm_stream64_f32_rows_kernel(rows_args g)
+{
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    constexpr int NBW = 2, STAGE_BYTES = (NBW + MB) * BLOCK_BYTES, WSHARE = (NBW * 4 + MB - 1) / MB, PIECES = 4 + WSHARE;
+    static_assert((S - 1) * PIECES <= 63 && S * STAGE_BYTES <= 160 * 1024, "pieces in flight fit vmcnt, the ring fits the CU's LDS");
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, gq = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * (16 * NBW);
+    const float *small_ = static_cast<const float *>(g.small_) + (int64_t)blockIdx.y * g.stride_small;
+    const float *big = static_cast<const float *>(g.big) + (int64_t)blockIdx.y * g.stride_big + row0 * g.ld_big;
+
+    // this wave's pieces of a stage: four of its own small block, WSHARE of the shared streamed blocks (piece p = wave + t MB, modulo 8:
+    // with three waves one piece is fetched twice -- same bytes, same place)
+    uint32_t voff_small[4], voff_big[WSHARE], dst_big[WSHARE];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = 4 * q + gq;
+        voff_small[q] = (uint32_t)(((int64_t)min(16 * wave + r, g.small_rows - 1) * g.ld_small + (j ^ r) * 4) * 4);
+    }
+#pragma unroll
+    for (int t = 0; t < WSHARE; ++t) {
+        const int p = (wave + t * MB) & 7, b = p >> 2, q = p & 3, r = 4 * q + gq;
+        const int64_t row = min((int64_t)(16 * b + r), (int64_t)g.big_rows - 1 - row0);
+        voff_big[t] = (uint32_t)((row * g.ld_big + (j ^ r) * 4) * 4);
+        dst_big[t] = (uint32_t)(b * BLOCK_BYTES + q * 1024);
+    }
+    const int count = g.k / KB;
+    auto issue = [&](int stage, int it) {
+        const int64_t koff = (int64_t)it * KB;
+        const uint32_t dst = lds_addr_of(smem + stage * STAGE_BYTES);
+#pragma unroll
+        for (int t = 0; t < WSHARE; ++t) glds16<NT>(big + koff, voff_big[t], dst + dst_big[t]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16<false>(small_ + koff, voff_small[q], dst + (NBW + wave) * BLOCK_BYTES + q * 1024);
+    };
+    f32x4 acc[NBW][2];
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) acc[b][0] = acc[b][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto issue_one = [&](int stage, int it, auto tt) {               // piece T of this wave's share of a stage
+        constexpr int T = decltype(tt)::value;
+        const int64_t koff = (int64_t)it * KB;
+        const uint32_t dst = lds_addr_of(smem + stage * STAGE_BYTES);
+        if constexpr (T < WSHARE) glds16<NT>(big + koff, voff_big[T], dst + dst_big[T]);
+        else glds16<false>(small_ + koff, voff_small[T - WSHARE], dst + (NBW + wave) * BLOCK_BYTES + (T - WSHARE) * 1024);
+    };
+    // (refill_c: the slot `fill` takes K-block `refill_it`, its pieces dealt out among this stage's MFMAs)
+    auto compute = [&](int stage, int fill, int refill_it, auto refill_c) {
+        constexpr bool refill = decltype(refill_c)::value;
+        const char *st = smem + stage * STAGE_BYTES + j * ROW_BYTES;
+        f32x4 fw[NBW][4], fs[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int phys = ((4 * c + gq) ^ j) * 16;
+#pragma unroll
+            for (int b = 0; b < NBW; ++b) fw[b][c] = *reinterpret_cast<const f32x4 *>(st + b * BLOCK_BYTES + phys);
+            fs[c] = *reinterpret_cast<const f32x4 *>(st + (NBW + wave) * BLOCK_BYTES + phys);
+        }
+        // all twelve reads are in flight before the first MFMA (left alone the compiler re-uses sixteen registers and waits for every chunk's reads
+        // behind the previous chunk's MFMAs: four exposed LDS latencies per K-block); no explicit lgkmcnt wait: every fragment feeds an MFMA below,
+        // so the reads of this stage are complete before the wave can reach the next barrier
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<16>([&](auto gg) {
+            constexpr int G = decltype(gg)::value, C = G / 4, E = G % 4;
+#pragma unroll
+            for (int b = 0; b < NBW; ++b) acc[b][E & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fs[C][E], fw[b][C][E], acc[b][E & 1], 0, 0, 0);
+            if constexpr (refill) {
+                static_for<(G + 1) * PIECES / 16 - G * PIECES / 16>([&](auto tt) {
+                    issue_one(fill, refill_it, std::integral_constant<int, G * PIECES / 16 + decltype(tt)::value>{});
+                });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    const int pre = count < S - 1 ? count : S - 1;
+    for (int s = 0; s < pre; ++s) issue(s, s);
+    int it = 0, stage = 0, fill = S - 1;                            // `fill`: the slot of stage it - 1 (free behind the barrier)
+    for (; it + S - 1 < count; ++it) {
+        wait_vmcnt<(S - 2) * PIECES>();                              // my pieces of stage `it` have landed; S - 2 younger stages may fly
+        __builtin_amdgcn_s_barrier();
+        compute(stage, fill, it + S - 1, std::true_type{});
+        fill = stage;
+        stage = stage + 1 == S ? 0 : stage + 1;
+    }
+    for (; it < count; ++it) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        compute(stage, 0, 0, std::false_type{});
+        stage = stage + 1 == S ? 0 : stage + 1;
+    }
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) {
+        const f32x4 sum = acc[b][0] + acc[b][1];
+        const int64_t n = row0 + 16 * b + j;
+        if (n >= g.big_rows) continue;
+        float *out = g.out + (int64_t)blockIdx.y * g.stride_out + n * g.out_stride_big;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = 16 * wave + 4 * gq + r;
+            if (m < g.small_rows) out[(int64_t)m * g.out_stride_small] = sum[r];
+        }
+    }
+}
+
+template <int MB, int S>
+void launch_rows_form(mi355_ctx *ctx, hipStream_t s, const rows_args &g, uint32_t batch)
+{
+    constexpr int LDS = S * (2 + MB) * BLOCK_BYTES;
+    const uint32_t nblocks = (uint32_t)((g.big_rows + 31) / 32);
+    if ((int64_t)g.big_rows * g.k * 4 * batch > (192ll << 20)) {
+        lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_stream64_f32_rows_kernel<MB, S, true>), LDS);
+        hipLaunchKernelGGL((gemm_stream64_f32_rows_kernel<MB, S, true>), dim3(nblocks, batch), dim3(MB * 64), LDS, s, g);
+    } else {
+        lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_stream64_f32_rows_kernel<MB, S, false>), LDS);
+        hipLaunchKernelGGL((gemm_stream64_f32_rows_kernel<MB, S, false>), dim3(nblocks, batch), dim3(MB * 64), LDS, s, g);
     }
 }
 
@@ -239,6 +390,19 @@ int stream64_f32_blocks(const mi355_gemm_desc &d, int cus)
     return units2 <= units1 ? 2 : 1;
 }
 
+// 49 ... 64 small rows: the rows-split form (gemm_stream64_f32_rows_kernel) where its 32-row workgroups make one to two rounds of the chip.
+// Cold, us, rows-split / K-split (profiles/r05_stream64_f32_rows_form.txt): 64 x 8192 x 8192 97.5 / 106.1, 8192 x 64 x 8192 85.5 / 91.1,
+// 64 x 14336 x 4096 85.5 / 92.9, 56 x 16384 x 2048 46.1 / 56.0; not taken: 64 x 4096 x 4096 (half a round) 41.6 / 27.4, 64 x 28672 x 4096 (3.5 rounds)
+// 167.9 / 163.0, and 33 ... 48 rows anywhere (48 x 8192 x 8192 86.7 / 81.6).  MI355_S64F_ROWS=0 / 1 (dev) forces the choice for 49 ... 64 rows.
+bool stream64_f32_rows_form(const mi355_gemm_desc &d, int cus)
+{
+    const int64_t small_rows = std::min(d.m, d.n), wgs = (std::max(d.m, d.n) + 31) / 32 * d.batch;
+    if (small_rows <= 48) return false;
+    static const int forced = [] { const char *e = getenv("MI355_S64F_ROWS"); return e ? atoi(e) : -1; }();
+    if (forced == 0 || forced == 1) return forced == 1;
+    return wgs >= cus && wgs <= 2 * cus;
+}
+
 int32_t launch_gemm_stream64_f32(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c)
 {
     if (!gemm_stream64_f32_supports(d, a, b, c)) return fail(ctx, MI355_E_UNSUPPORTED, "mi355_gemm: the f32 streaming kernel does not take this descriptor");
@@ -267,6 +431,7 @@ int32_t launch_gemm_stream64_f32(mi355_ctx *ctx, hipStream_t s, const mi355_gemm
         if (nbw == 2) launch_form<2, 2, 2>(ctx, s, g, batch);
         else launch_form<2, 1, 3>(ctx, s, g, batch);
     } else if (g.small_rows <= 48) launch_form<3, 1, 2>(ctx, s, g, batch);
+    else if (stream64_f32_rows_form(d, cus)) launch_rows_form<4, 6>(ctx, s, g, batch);
     else launch_form<4, 1, 2>(ctx, s, g, batch);
     check_launch(ctx, "mi355_gemm(stream64, f32)");
     return MI355_OK;
