@@ -66,6 +66,7 @@ GEMM_ALGO_NNROWS = 11
 GEMM_ALGO_LP_256X192 = 12
 GEMM_ALGO_LP_192X192 = 13
 GEMM_ALGO_LP_256M16 = 14
+GEMM_ALGO_LP_256QM = 15
 UNIQUE_ID_BYTES = 128
 
 

@@ -132,6 +132,8 @@ int32_t launch_gemm_lp256x192(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_de
 bool gemm_lp256x192_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 int32_t launch_gemm_lp256m16(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);   // gemm_lp256m16.hip
 bool gemm_lp256m16_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
+int32_t launch_gemm_lp256qm(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);    // gemm_lp256qm.hip
+bool gemm_lp256qm_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 int32_t launch_gemm_skinny(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);
 bool gemm_skinny_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c);
 int32_t launch_gemm_nnrows(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c);

@@ -1,0 +1,530 @@
+// gemm_lp256qm.hip -- the persistent 256 x 256 kernel with dripped C stores (gemm_lp256q.hip) on v_mfma_f32_16x16x32 with the
+// stationary second source operand (gemm_lp256m16.hip).  Round 6; config C5 (batched 2048^3 bf16, 16-bit C).  Read those two
+// headers first: ring, LDS image, hand-over, vmcnt discipline and rasterisation are theirs.
+//
+// Roofline: MFMA bf16 / f16, 2.5 PFLOP/s dense.  Why: on uniform operands the chip is power-limited; the narrow MFMA shape holds
+// 1.82-1.86 GHz where 32x32x16 holds 1.52-1.54 (C5, same box), but the one-tile-per-workgroup form of the narrow kernel runs C5 at
+// 0.65 of the matrix rate at its clock -- prologue and epilogue of a 32-K-tile tile are not overlapped -- where the persistent
+// 32x32x16 kernel runs at 0.79 of its (lower) clock (profiles/r06_c5_baseline.txt).  This kernel is the persistent form at the
+// narrow shape's clock.
+//
+// What differs from gemm_lp256q.hip:
+//   * K loop: gemm_lp256m16.hip's -- a wave's 128 x 128 block is 8 x 8 accumulators of 16 x 16 (256 AGPRs), a K-tile two k-steps
+//     of 64 MFMAs (A fragment = srcB outer, B fragment = srcA inner), 16 ds_read_b128 per k-step double-buffered in 128 VGPRs.
+//   * The held tile needs no v_permlane swap: the ROWS OF THE B TILE ARE PERMUTED ON THEIR WAY INTO LDS.  With srcA = the B
+//     fragment a lane (l15 = lane % 16, g = lane / 16) holds C[row l15][MFMA columns 4 g .. 4 g + 3] of block (i, j) -- four
+//     consecutive columns of one row.  LDS row r of the B tile is filled from matrix column
+//         pi(r) = 32 (J >> 1) + 8 (n >> 2) + 4 (J & 1) + (n & 3),     J = r >> 4 (column block), n = r & 15
+//     (a wave-uniform row offset per DMA piece + ONE per-lane offset: sub -> 8 (sub >> 2) + (sub & 3) rows), so that the lane's
+//     words of the adjacent column blocks 2 jj, 2 jj + 1 are columns 32 jj + 8 g .. + 7 of its row: one 16-byte chunk, packed
+//     straight out of the accumulators.  The fragment reads, their swizzle and the MFMA order are untouched (the permutation
+//     lives in the DMA's SOURCE addressing), and every output element is the same chain of 16x16x32 MFMAs as in
+//     gemm_lp256m16.hip: bit-identical results.
+//   * Whole-line stores (partial lines are poison, gemm_lp256q.hip): the four lanes g of a row hold 64 bytes of it per chunk
+//     register, so one 2 x 2 exchange between lanes l15 ^ 1 and chunk registers jj ^ 1 (quad-permute DPP + select, 4 VALU per
+//     word, 32 per 16-row block row) makes a chunk register 8 rows x 128 contiguous bytes.  24 held stores per wave and tile
+//     (block rows 0-5 = 96 VGPRs), block rows 6-7 through the dead ring slot at the tile boundary, as in gemm_lp256q.hip.
+//   * Per-lane DMA offsets: four registers (A / B x even / odd piece) + wave-uniform piece offsets in scalar arithmetic (tiles are
+//     full); fragment addresses: x1 = x0 ^ 64.  128 fragment + 96 held registers leave ~30 for everything else.
+//
+// Restrictions: as gemm_lp256q.hip without the row-major-B form (B stored [N][K] only), lda != ldb allowed.
+#include <algorithm>
+#include <type_traits>
+
+#include "gemm_common.hpp"
+
+using namespace mi355;
+
+namespace {
+
+constexpr int BM = 256, BN = 256;
+constexpr int ROW_BYTES = 128;                    // one K-tile row = one 128-byte line: 64 x 16-bit
+constexpr int UNIT_BYTES = BM * ROW_BYTES;        // 32 KiB: one ring slot
+constexpr int NSLOT = 5;
+constexpr int LDS_BYTES = NSLOT * UNIT_BYTES;     // 160 KiB
+constexpr int NHELD = 24;                         // dripped stores per wave and tile: 6 block rows x 2 lines x (even, odd rows)
+
+template <int DT> struct qm;
+template <> struct qm<MI355_DTYPE_BF16> {
+    typedef bf16x8 frag;
+    // The MFMA as inline asm with the accumulator tied to an "a" operand: with the builtin, hipcc's allocator -- 96 held + 96 fragment
+    // registers beside the accumulators -- kept some accumulator blocks in VGPRs, rotated the others through a[4:7] with four
+    // v_accvgpr_write in front of every second MFMA and spilled 384 registers (tools/dev/spill_map.py).  An asm operand of class "a"
+    // at all 128 uses per K-tile leaves it nothing to move.  (Hazards: no MFMA reads an accumulator written less than 64 MFMAs
+    // earlier; the packing reads one QM_LAG >= 2 MFMAs = 64+ cycles after its last write.)
+    static __device__ __forceinline__ void mfma(frag a, frag b, f32x4 &c) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); }
+    static __device__ __forceinline__ void mfma0(frag a, frag b, f32x4 &c) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b)); }
+    static __device__ __forceinline__ uint32_t pack2(float x, float y)
+    {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        const bf16x2 v = {(__bf16)x, (__bf16)y};
+        return __builtin_bit_cast(uint32_t, v);
+    }
+};
+template <> struct qm<MI355_DTYPE_F16> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ void mfma(frag a, frag b, f32x4 &c) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); }
+    static __device__ __forceinline__ void mfma0(frag a, frag b, f32x4 &c) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b)); }
+    static __device__ __forceinline__ uint32_t pack2(float x, float y)
+    {
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        const f16x2 v = {(_Float16)x, (_Float16)y};
+        return __builtin_bit_cast(uint32_t, v);
+    }
+};
+
+// LDS-DMA with a wave-uniform 64-bit base in SGPRs + a constant 32-bit per-lane offset (see gemm_lp256w4.hip)
+template <int IMM>
+__device__ __forceinline__ void glds16_s(const void *ubase, uint32_t voff, uint32_t lds_byte_addr)
+{
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ubase), "s"(lds_byte_addr), "i"(IMM)
+                 : "memory", "scc");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void *p)
+{
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)p;
+}
+
+#ifndef QM_ABL
+#define QM_ABL 0          // dev ablations, timing only: 1 no dripped stores, 2 no boundary stores
+#endif
+#ifndef QM_LAG
+#define QM_LAG 3          // a finished block is packed behind the MFMA this many slots after its own (no wait on the matrix pipe)
+#endif
+#ifndef QM_STORE_FORM
+#define QM_STORE_FORM 1   // 1: inline asm, wave-uniform base in SGPRs + 32-bit lane offset (no address VGPRs); 0: builtin store
+#endif
+#define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+template <int V> using IC = std::integral_constant<int, V>;
+// Dev timing trace (-DQM_TRACE, never in the product library): shader-clock stamps of wave 0 of every workgroup for its first 8
+// tiles -- {K loop entered, K loop left, boundary left} -- read back with mi355_dev_qm_trace
+#ifdef QM_TRACE
+__device__ unsigned long long qm_trace_buf[256 * 32];
+#define QM_STAMP(slot) do { if (tid == 0 && blockIdx.x < 256 && qt_tile < 8) qm_trace_buf[blockIdx.x * 32 + qt_tile * 3 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define QM_STAMP(slot)
+#endif
+// a lane-constant value the compiler must re-derive where it is used (gemm_lp256q.hip: hoisted staging addresses get spilled)
+__device__ __forceinline__ uint32_t opaque(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
+
+// Which fragment read follows MFMA n of k-step ks (read id: 0..7 = B fragment j of the NEXT k-step, 8..15 = A fragment i of it; -1 none).
+//   k-step 0 (the next k-step's operands are this K-tile's, landed long ago): B j behind MFMA 1 + 4 j; A i behind MFMA 8 i + 7, the last
+//     MFMA that multiplies by the fragment it replaces.
+//   k-step 1 (the next k-step's operands are K-tile t + 1's: nothing before the hand-over behind MFMA 15): A 0, A 1 behind MFMAs 16, 18;
+//     B j behind 17 + 4 j; A i (i >= 2) behind 8 i + 7.
+// DMA pieces sit behind MFMAs 3, 11 (mod 16) and, in the last quarter of k-step 1, behind 49, 53, 57, 61: no slot carries two.
+constexpr int qm_read_at(int ks, int n)
+{
+    if (ks == 0) {
+        if ((n & 3) == 1 && n < 32) return n >> 2;
+        if ((n & 7) == 7) return 8 + (n >> 3);
+        return -1;
+    }
+    if (n == 16) return 8;
+    if (n == 18) return 9;
+    if (n >= 17 && n < 49 && ((n - 17) & 3) == 0) return (n - 17) >> 2;
+    if (n >= 23 && (n & 7) == 7) return 8 + (n >> 3);
+    return -1;
+}
+
+// D = dripped stores per K-tile (1, 2, 4 or 8): the 24 held stores leave during K-tiles 1 .. 24 / D of the next tile
+template <int DT, int D>
+__global__ void __launch_bounds__(256)
+gemm_lp256qm_kernel(gemm_args g)
+{
+    static_assert(NHELD % D == 0 && 8 % D == 0, "the held stores must split evenly over K-tiles and row blocks");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    typedef typename qm<DT>::frag frag;
+    constexpr int ESZ = 2, CSZ = 2;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g4 = lane >> 4, l15 = lane & 15;
+    const int nk = (int)(g.k / 64);
+
+    const uint32_t tiles = g.tiles_m * g.tiles_n;
+    const uint32_t total = tiles * g.batch_count;
+    const uint32_t lda_b = (uint32_t)(g.lda * ESZ), ldb_b = (uint32_t)(g.ldb * ESZ);    // bytes per operand row (256 rows < 2^32: supports())
+
+    // ua / ub: this WAVE's first row of the tile's A / B panel (LDS rows 64 wave ..: pieces wave * 8 + j)
+    struct tile_src { const char *ua, *ub; int64_t m0, n0, batch; };
+    auto locate = [&](uint32_t L) {
+        tile_src t;
+        const uint32_t R = xcd_remap(L, total);
+        const uint32_t bi = R / tiles, tl = R - bi * tiles;
+        uint32_t tm, tn;
+        tile_coords(tl, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
+        t.m0 = (int64_t)tm * BM; t.n0 = (int64_t)tn * BN; t.batch = bi;
+        t.ua = static_cast<const char *>(g.a) + ((int64_t)bi * g.stride_a + (t.m0 + wave * 64) * g.lda) * ESZ;
+        t.ub = static_cast<const char *>(g.b) + ((int64_t)bi * g.stride_b + (t.n0 + wave * 64) * g.ldb) * ESZ;
+        return t;
+    };
+    // DMA map: a unit is 32 pieces of 1 KiB (8 LDS rows); this wave fills pieces wave * 8 + j; lane -> (LDS row r = 64 wave + 8 j + sub,
+    // physical chunk c8), source chunk = c8 ^ ((r >> 1) & 7) = c8 ^ (4 (j & 1) + (sub >> 1)).  Source ROW: A r; B pi(r) =
+    // 64 wave + [32 (j >> 2) + 16 (j & 1) + 4 ((j >> 1) & 1)] + [8 (sub >> 2) + (sub & 3)] -- wave-uniform piece part + lane part.
+    const int sub = lane >> 3, c8 = lane & 7;
+    const uint32_t voff_a0 = (uint32_t)sub * lda_b + (uint32_t)((c8 ^ (sub >> 1)) << 4);
+    const uint32_t voff_a1 = (uint32_t)sub * lda_b + (uint32_t)((c8 ^ (4 + (sub >> 1))) << 4);
+    const uint32_t voff_b0 = (uint32_t)(8 * (sub >> 2) + (sub & 3)) * ldb_b + (uint32_t)((c8 ^ (sub >> 1)) << 4);
+    const uint32_t voff_b1 = (uint32_t)(8 * (sub >> 2) + (sub & 3)) * ldb_b + (uint32_t)((c8 ^ (4 + (sub >> 1))) << 4);
+    const int dst_piece = wave * 8 * 1024;
+
+    // fragment reads (gemm_lp256m16.hip): row l15 of a 16-row block, chunk (4 s + g) ^ f, f = (l15 >> 1) & 7; k-step 1 = k-step 0 ^ 64
+    const int f = (l15 >> 1) & 7;
+    const int ro_a = (wm * 128 + l15) * ROW_BYTES + ((g4 ^ f) << 4), ro_b = (wn * 128 + l15) * ROW_BYTES + ((g4 ^ f) << 4);
+
+    f32x4 acc[8][8];             // never zeroed: the first k-step of a tile accumulates into a literal zero operand
+    frag fa[8], fb[2][8];        // A single-buffered IN PLACE (fragment i is re-read behind its eighth MFMA), B double-buffered
+    tile_src iss;                // the tile whose K-tiles are being ISSUED (two ahead of the MFMAs)
+    u32x4 P[3][2][4];            // the finished tile's block rows 0..5 packed: [rb][ii][jj] = block row 2 rb + ii, columns 32 jj + 8 g .. + 7 of row l15
+
+    // Fragment reads.  The A fragment i (srcB) serves MFMAs 8 i .. 8 i + 7 of a k-step and nothing else, so the NEXT k-step's fragment i
+    // is read into the same registers right behind MFMA 8 i + 7 (64 MFMAs before its first use): 32 registers instead of 64, which is
+    // what lets the 96 held registers in.  The B fragments (srcA) are all in use until the k-step's last eight MFMAs: double-buffered.
+    // Read id 0..7 = B fragment j into buffer NXT, 8..15 = A fragment i.
+    auto read_one = [&](auto buf, auto idx, const char *pa, const char *pb) {
+        constexpr int BUF = decltype(buf)::value, R = decltype(idx)::value;
+        if constexpr (R < 8) fb[BUF][R] = *reinterpret_cast<const frag *>(pb + R * 16 * ROW_BYTES);
+        else fa[R - 8] = *reinterpret_cast<const frag *>(pa + (R - 8) * 16 * ROW_BYTES);
+    };
+    auto dma_one = [&](auto is_b, auto jj, int64_t koff, char *base) {
+        constexpr int J = decltype(jj)::value;
+        if constexpr (decltype(is_b)::value) {
+            constexpr uint32_t ROWS = 32 * (J >> 2) + 16 * (J & 1) + 4 * ((J >> 1) & 1);
+            glds16_s<J * 1024>(iss.ub + koff + (uint64_t)(ROWS * ldb_b), (J & 1) ? voff_b1 : voff_b0, lds_addr_of(base));
+        } else {
+            glds16_s<J * 1024>(iss.ua + koff + (uint64_t)((uint32_t)(8 * J) * lda_b), (J & 1) ? voff_a1 : voff_a0, lds_addr_of(base));
+        }
+    };
+    // srcA = the B fragment (changes every MFMA), srcB = the A fragment (stays for eight): the order the matrix pipe issues at 16 cycles
+    auto mfma_one = [&](auto buf, auto idx, auto first) {
+        constexpr int BUF = decltype(buf)::value, I = decltype(idx)::value >> 3, J = decltype(idx)::value & 7;
+        if constexpr (decltype(first)::value) qm<DT>::mfma0(fb[BUF][J], fa[I], acc[I][J]);
+        else qm<DT>::mfma(fb[BUF][J], fa[I], acc[I][J]);
+    };
+    // (no instruction: keeps the 256 accumulators in the AGPR half next to 96 held registers, gemm_lp256q.hip)
+    auto pin_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" : "+a"(acc[i][j]));
+    };
+    // block IDX = (I = IDX >> 3, J = IDX & 7) is final: pack it.  Block rows 0-5 into P, 6-7 into the boundary staging image
+    // (this wave's 8 KiB of the dead B slot: 32 rows x 256 B, 16-byte chunk ^ (row & 15)).
+    int stage_off = 0;
+    const uint32_t lx = (uint32_t)(g4 ^ l15) << 4;       // ((4 jj + g) ^ l15) << 4 = (jj << 6) ^ lx
+    auto drain_one = [&](auto idx) {
+        constexpr int I = decltype(idx)::value >> 3, J = decltype(idx)::value & 7, JJ = J >> 1, E = J & 1;
+        uint32_t w0 = qm<DT>::pack2(acc[I][J][0], acc[I][J][1]), w1 = qm<DT>::pack2(acc[I][J][2], acc[I][J][3]);
+        asm volatile("" : "+v"(w0), "+v"(w1));      // pins the packing HERE, between two MFMAs (left alone, hipcc sinks all 96 conversions of the held
+                                                    // block rows to the tile boundary -- they have no side effect until the stores of the next tile)
+        if constexpr (I >= 6) {
+            const u32x2 w = {w0, w1};
+            *reinterpret_cast<u32x2 *>(smem + stage_off + (I - 6) * 16 * 256 + (((uint32_t)JJ << 6) ^ opaque(lx)) + 8 * E) = w;
+        } else {
+            P[I >> 1][I & 1][JJ][2 * E + 0] = w0;
+            P[I >> 1][I & 1][JJ][2 * E + 1] = w1;
+        }
+    };
+
+    // ---- where the HELD tile goes ---------------------------------------------------------------------------------------------
+    // Chunk register jj of lane (l15, g) = row l15, bytes 64 jj + 16 g of the wave's 256-byte row.  Pair (ii, p) = chunk registers
+    // 2 p, 2 p + 1 of block row ii: after the exchange with lane l15 ^ 1 register 2 p holds the EVEN row of the lane pair, register
+    // 2 p + 1 the odd one, bytes 128 p + 64 (l15 & 1) + 16 g: one store instruction = 8 rows x one whole 128-byte line.
+    char *hbase = nullptr;
+    bool held = false;           // P holds a finished tile whose stores are still to be issued (false only during a workgroup's first tile)
+    const uint32_t pvoff = (uint32_t)((l15 & ~1) * g.ldc * CSZ + 64 * (l15 & 1) + 16 * g4);
+    const int64_t rowbytes = g.ldc * CSZ, rowblock = (int64_t)32 * g.ldc * CSZ;
+    const bool odd1 = (l15 & 1) != 0;
+    // word W of pair TP (= 2 ii + p) of row block RB: 4 VALU
+    auto transpose_word = [&](auto rbb, auto tpp, auto ww) {
+        constexpr int RB = decltype(rbb)::value, II = decltype(tpp)::value >> 1, PP = decltype(tpp)::value & 1, W = decltype(ww)::value;
+        const uint32_t a = P[RB][II][2 * PP][W], b = P[RB][II][2 * PP + 1][W];
+        const uint32_t ax = (uint32_t)__builtin_amdgcn_mov_dpp((int)a, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]: lane ^ 1
+        const uint32_t bx = (uint32_t)__builtin_amdgcn_mov_dpp((int)b, 0xB1, 0xF, 0xF, true);
+        P[RB][II][2 * PP][W] = odd1 ? bx : a;
+        P[RB][II][2 * PP + 1][W] = odd1 ? b : ax;
+    };
+    // store N (0..7) of row block RB: block row ii = N >> 2, line p = (N >> 1) & 1, odd rows = N & 1; rb_base = wave-uniform address of
+    // the row block's first row
+    auto store_one = [&](auto rbb, auto nn, char *rb_base) {
+        constexpr int RB = decltype(rbb)::value, N = decltype(nn)::value, II = N >> 2, PP = (N >> 1) & 1, ODD = N & 1;
+        const u32x4 v = P[RB][II][2 * PP + ODD];
+        if (QM_ABL & 1) { asm volatile("" ::"v"(v)); return; }
+        char *sb_ = rb_base + (II * 16 + ODD) * rowbytes;
+#if QM_STORE_FORM == 1
+        const uint32_t so_ = pvoff;          // (a local copy: a const captured only by an asm operand is not odr-used)
+        asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 1" ::"v"(so_), "v"(v), "s"(sb_), "n"(PP * 128) : "memory");
+#else
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(sb_ + PP * 128 + pvoff));
+#endif
+    };
+    // the slot behind MFMA n (32 <= n < 64, even) of k-step 0 of the K-tile that carries store group G of the row block in P[0]: one
+    // word of a pair whose first store is in the group
+    auto tr_gap = [&](auto gg, auto nn) {
+        constexpr int G = decltype(gg)::value, N = decltype(nn)::value;
+        if constexpr (G >= 0 && N >= 32 && (N & 1) == 0) {
+            constexpr int S = (N - 32) >> 1, K = S >> 2, W = S & 3;                 // K-th pair of this K-tile, word W
+            constexpr int NPAIR = D >= 2 ? D / 2 : ((G & 1) == 0 ? 1 : 0);
+            constexpr int FIRST_PAIR = D >= 2 ? G * (D / 2) : G / 2;
+            if constexpr (K < NPAIR) transpose_word(IC<0>{}, IC<FIRST_PAIR + (K < NPAIR ? K : 0)>{}, IC<W>{});
+        }
+    };
+    // the slot behind MFMA n (odd, < 2 D) of the head of k-step 1: store (n - 1) / 2 of group G
+    auto st_gap = [&](auto gg, auto nn, char *rb_base) {
+        constexpr int G = decltype(gg)::value, N = decltype(nn)::value;
+        if constexpr (G >= 0 && (N & 1) == 1 && N < 2 * D) {
+            if (held) store_one(IC<0>{}, IC<(G >= 0 ? G : 0) * D + (N >> 1)>{}, rb_base);    // (uniform branch: the workgroup's first tile has nothing to store yet)
+        }
+    };
+
+    // 16 MFMAs n = N0 .. N0 + 15 of a k-step.  A read follows MFMA n where qm_read_at(k-step, n) >= 0 (below the kernel); DMASK bit b: a
+    // DMA piece follows MFMA N0 + b.  KS = 0: transposition slots; KS = 1: store slots (head) + packing of finished blocks (DRAIN).
+    // Instruction order pinned by sched_barrier after every group.
+#define QM_G(CUR, NXT, KS, N0, BIT, DMASK, IS_B, J0, FIRST, DRAIN, G)                                                 \
+    mfma_one(IC<CUR>{}, IC<(N0) + (BIT)>{}, IC<FIRST>{});                                                             \
+    if constexpr (qm_read_at(KS, (N0) + (BIT)) >= 0) read_one(IC<NXT>{}, IC<(qm_read_at(KS, (N0) + (BIT)) >= 0 ? qm_read_at(KS, (N0) + (BIT)) : 0)>{}, rd_a, rd_b); \
+    if constexpr (((DMASK) >> (BIT)) & 1u) dma_one(IC<IS_B>{}, IC<(J0) + __builtin_popcount((DMASK) & ((1u << (BIT)) - 1u))>{}, dma_koff, dma_base); \
+    if constexpr ((DRAIN) && (N0) + (BIT) >= QM_LAG) {                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        drain_one(IC<((N0) + (BIT) >= QM_LAG ? (N0) + (BIT) - QM_LAG : 0)>{});                                        \
+    }                                                                                                                 \
+    if constexpr ((KS) == 0 && (G) >= 0) { __builtin_amdgcn_sched_barrier(0); tr_gap(IC<(G)>{}, IC<(N0) + (BIT)>{}); } \
+    if constexpr ((KS) == 1 && (G) >= 0 && (N0) == 0) { __builtin_amdgcn_sched_barrier(0); st_gap(IC<(G)>{}, IC<(N0) + (BIT)>{}, rb_base); } \
+    __builtin_amdgcn_sched_barrier(0);
+#define QM_Q(CUR, NXT, KS, N0, DMASK, IS_B, J0, FIRST, DRAIN, G)                                                      \
+    QM_G(CUR, NXT, KS, N0, 0, DMASK, IS_B, J0, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 1, DMASK, IS_B, J0, FIRST, DRAIN, G)   \
+    QM_G(CUR, NXT, KS, N0, 2, DMASK, IS_B, J0, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 3, DMASK, IS_B, J0, FIRST, DRAIN, G)   \
+    QM_G(CUR, NXT, KS, N0, 4, DMASK, IS_B, J0, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 5, DMASK, IS_B, J0, FIRST, DRAIN, G)   \
+    QM_G(CUR, NXT, KS, N0, 6, DMASK, IS_B, J0, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 7, DMASK, IS_B, J0, FIRST, DRAIN, G)   \
+    QM_G(CUR, NXT, KS, N0, 8, DMASK, IS_B, J0, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 9, DMASK, IS_B, J0, FIRST, DRAIN, G)   \
+    QM_G(CUR, NXT, KS, N0, 10, DMASK, IS_B, J0, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 11, DMASK, IS_B, J0, FIRST, DRAIN, G) \
+    QM_G(CUR, NXT, KS, N0, 12, DMASK, IS_B, J0, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 13, DMASK, IS_B, J0, FIRST, DRAIN, G) \
+    QM_G(CUR, NXT, KS, N0, 14, DMASK, IS_B, J0, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 15, DMASK, IS_B, J0, FIRST, DRAIN, G)
+
+    // ---- first tile of this workgroup: units 0..3 (its K-tiles 0 and 1), then the first fragments --------------------------------
+    uint32_t L = blockIdx.x;
+    tile_src cur = locate(L);
+    iss = cur;
+    {
+        const int64_t k0 = 0, k1 = ROW_BYTES;
+        char *b0 = smem + dst_piece;
+#define QM_PRO(IS_B, KOFF, SLOT)                                                                      \
+        dma_one(IC<IS_B>{}, IC<0>{}, KOFF, b0 + SLOT * UNIT_BYTES); dma_one(IC<IS_B>{}, IC<1>{}, KOFF, b0 + SLOT * UNIT_BYTES); \
+        dma_one(IC<IS_B>{}, IC<2>{}, KOFF, b0 + SLOT * UNIT_BYTES); dma_one(IC<IS_B>{}, IC<3>{}, KOFF, b0 + SLOT * UNIT_BYTES); \
+        dma_one(IC<IS_B>{}, IC<4>{}, KOFF, b0 + SLOT * UNIT_BYTES); dma_one(IC<IS_B>{}, IC<5>{}, KOFF, b0 + SLOT * UNIT_BYTES); \
+        dma_one(IC<IS_B>{}, IC<6>{}, KOFF, b0 + SLOT * UNIT_BYTES); dma_one(IC<IS_B>{}, IC<7>{}, KOFF, b0 + SLOT * UNIT_BYTES);
+        QM_PRO(0, k0, 0) QM_PRO(1, k0, 1) QM_PRO(0, k1, 2) QM_PRO(1, k1, 3)
+#undef QM_PRO
+    }
+    WAIT_VMCNT(16);                      // units 0, 1 landed (this wave's share)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const char *rd_a = smem + ro_a, *rd_b = smem + UNIT_BYTES + ro_b;
+        read_one(IC<0>{}, IC<0>{}, rd_a, rd_b); read_one(IC<0>{}, IC<8>{}, rd_a, rd_b); read_one(IC<0>{}, IC<1>{}, rd_a, rd_b); read_one(IC<0>{}, IC<2>{}, rd_a, rd_b);
+        read_one(IC<0>{}, IC<3>{}, rd_a, rd_b); read_one(IC<0>{}, IC<4>{}, rd_a, rd_b); read_one(IC<0>{}, IC<5>{}, rd_a, rd_b); read_one(IC<0>{}, IC<6>{}, rd_a, rd_b);
+        read_one(IC<0>{}, IC<7>{}, rd_a, rd_b); read_one(IC<0>{}, IC<9>{}, rd_a, rd_b); read_one(IC<0>{}, IC<10>{}, rd_a, rd_b); read_one(IC<0>{}, IC<11>{}, rd_a, rd_b);
+        read_one(IC<0>{}, IC<12>{}, rd_a, rd_b); read_one(IC<0>{}, IC<13>{}, rd_a, rd_b); read_one(IC<0>{}, IC<14>{}, rd_a, rd_b); read_one(IC<0>{}, IC<15>{}, rd_a, rd_b);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    int sa = 0;                          // ring byte offset of the A unit of the K-tile being multiplied
+    int sb = UNIT_BYTES;                 // ... and of its B unit; the ring runs on across output tiles
+    auto adv = [](int x, int n) { x += n * UNIT_BYTES; return x >= LDS_BYTES ? x - LDS_BYTES : x; };
+
+    char *__restrict__ C = static_cast<char *>(g.c);
+    uint32_t Lnext = 0;
+    bool has_next = false;
+    tile_src nxt = cur;
+    int kbase = 0;                       // K-tile index of the issue side = t + 2 - kbase
+    int t = 0;
+
+    // one basic block per K-tile (gemm_lp256q.hip: hipcc schedules per block for register pressure and MFMAs carry no ordering edge)
+#define QM_BLOCK_END() if (__builtin_expect(t > 0x3fffffff, 0)) asm volatile("s_trap 2");
+    // One K-tile.  FIRST: K-tile 0 of an output tile (zero C operand in k-step 0).  LASTK: the tile's last K-tile (blocks are packed
+    // as their last MFMA retires).  WAITN: LDS-DMA pieces + stores that may still fly at the hand-over when no group is stored here
+    // (8: unit 2t+4; 16: + the 8 boundary stores in front of it).  G >= 0: store group G of the row block in P[0] -- its stores sit
+    // in front of the hand-over and may fly too (vmcnt(8 + D)); everything older, the previous group included, has landed.
+#define QM_KTILE(FIRST, LASTK, WAITN, G)                                                                            \
+    {                                                                                                               \
+        const int sa1 = adv(sa, 2), sb1 = adv(sb, 2);     /* units of K-tile t+1 */                                  \
+        const int s4 = adv(sa, 4);                        /* unit 2t+4 -> slot of unit 2t-1 */                       \
+        const int s5 = sa;                                /* unit 2t+5 -> slot of unit 2t   */                       \
+        if (t == nk - 2 && has_next) { iss = nxt; kbase = nk; }   /* from here on the stream feeds the next tile */  \
+        const int64_t dma_koff = (int64_t)min(t + 2 - kbase, nk - 1) * ROW_BYTES;   /* clamp: only without a next tile */ \
+        const char *rd_a, *rd_b;                                                                                    \
+        char *dma_base;                                                                                             \
+        rd_a = smem + sa + (ro_a ^ 64); rd_b = smem + sb + (ro_b ^ 64); dma_base = smem + s4 + dst_piece;           \
+        QM_Q(0, 1, 0, 0, 0x0808u, 0, 0, FIRST, 0, G) QM_Q(0, 1, 0, 16, 0x0808u, 0, 2, FIRST, 0, G)                   \
+        QM_Q(0, 1, 0, 32, 0x0808u, 0, 4, FIRST, 0, G) QM_Q(0, 1, 0, 48, 0x0808u, 0, 6, FIRST, 0, G)                  \
+        QM_Q(1, 0, 1, 0, 0u, 0, 0, 0, LASTK, G)                                                                      \
+        if constexpr ((G) >= 0) { if (held) WAIT_VMCNT(8 + D); else WAIT_VMCNT(8); }   /* my share of the next K-tile landed */ \
+        else if constexpr ((WAITN) == 16) { if (held) WAIT_VMCNT(16); else WAIT_VMCNT(8); }                           \
+        else WAIT_VMCNT(WAITN);                                                                                     \
+        WAIT_LGKM0();                    /* my reads of this K-tile are complete */                                  \
+        __builtin_amdgcn_s_barrier();    /* BAR_t */                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        rd_a = smem + sa1 + ro_a; rd_b = smem + sb1 + ro_b; dma_base = smem + s5 + dst_piece;                        \
+        if constexpr (LASTK) stage_off = sb + wave * 8192 + (int)opaque((uint32_t)(l15 * 256));   /* B unit of this K-tile: dead since BAR_t */ \
+        QM_Q(1, 0, 1, 16, 0x0808u, 1, 0, 0, LASTK, G) QM_Q(1, 0, 1, 32, 0x0808u, 1, 2, 0, LASTK, G)                  \
+        QM_Q(1, 0, 1, 48, 0x2222u, 1, 4, 0, LASTK, G)                                                                \
+        if constexpr (LASTK) {                                                                                      \
+            drain_one(IC<64 - (QM_LAG >= 3 ? 3 : QM_LAG)>{}); drain_one(IC<64 - (QM_LAG >= 2 ? 2 : QM_LAG)>{}); drain_one(IC<63>{}); \
+            __builtin_amdgcn_sched_barrier(0);                                                                      \
+        }                                                                                                           \
+        if constexpr (FIRST) pin_acc();                                                                             \
+        sa = sa1;                                                                                                   \
+        sb = sb1;                                                                                                   \
+        ++t;                                                                                                        \
+        QM_BLOCK_END()                                                                                              \
+    }
+    static_assert(QM_LAG >= 1 && QM_LAG <= 3, "the tail of the packing above covers up to three blocks");
+
+#ifdef QM_TRACE
+    int qt_tile = 0;
+#endif
+    constexpr int GPR = 8 / D;           // K-tiles (store groups) per held row block
+    for (;;) {
+        Lnext = L + gridDim.x;
+        has_next = Lnext < total;
+        nxt = cur;
+        if (has_next) nxt = locate(Lnext);
+        kbase = 0;
+        t = 0;
+        char *rb_base = hbase;
+        QM_STAMP(0);
+        // ONE code path for every tile (the first tile of a workgroup runs the drip phase with its stores branched over: two paths --
+        // held / not held -- met in front of the last K-tile with different register assignments, and hipcc bridged them with five
+        // fragment spills + reloads behind an s_waitcnt vmcnt(0) at the top of every tile).
+        // K-tile 0: the 8 boundary stores of the previous tile sit between unit 3 and unit 4 of this stream
+        QM_KTILE(1, 0, 16, -1)
+        // drip phase, K-tiles 1 .. 24 / D: the row block in P[0] leaves, D stores per K-tile, then the next one moves down
+#pragma nounroll
+        for (int rb = 0; rb < 3; ++rb) {
+            QM_KTILE(0, 0, 8, 0)
+            if constexpr (GPR > 1) QM_KTILE(0, 0, 8, 1)
+            if constexpr (GPR > 2) { QM_KTILE(0, 0, 8, 2) QM_KTILE(0, 0, 8, 3) }
+            if constexpr (GPR > 4) { QM_KTILE(0, 0, 8, 4) QM_KTILE(0, 0, 8, 5) QM_KTILE(0, 0, 8, 6) QM_KTILE(0, 0, 8, 7) }
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) { P[0][ii][jj] = P[1][ii][jj]; P[1][ii][jj] = P[2][ii][jj]; }
+            rb_base += rowblock;
+        }
+#pragma nounroll
+        while (t < nk - 1) QM_KTILE(0, 0, 8, -1)     // (the first of these waits for the last dripped stores: they are older than unit 2t+4)
+        QM_KTILE(0, 1, 8, -1)                                     // t == nk - 1: block rows 0..5 are packed into P, 6..7 into the staging image
+        QM_STAMP(1);
+
+        // ---- tile boundary: block rows 6, 7 through this wave's 8 KiB of the dead B slot ------------------------------------------
+        {
+            char *stage = smem + adv(sb, 3) + wave * 8192;          // slot of the last B unit, my DMA region of it
+            const int64_t cbase = cur.batch * g.stride_c;
+            char *wbase = C + (cbase + (cur.m0 + wm * 128) * g.ldc + cur.n0 + wn * 128) * CSZ;   // my 128x128 block
+            char *crow = wbase + (int64_t)(96 + lane / 16) * g.ldc * CSZ + (lane % 16) * 16;
+            const int64_t cstep = (int64_t)4 * g.ldc * CSZ;
+            WAIT_LGKM0();                                          // same-wave hand-over: DS ops of one wave execute in order
+            // row r = 4 it + lane / 16, chunk (lane % 16) ^ (r & 15)
+            const uint32_t rdx = (uint32_t)((lane >> 4) * 256 + (((lane & 15) ^ (lane >> 4)) << 4));
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(stage + it * 1024 + (opaque(rdx) ^ (uint32_t)((it & 3) << 6)));
+                if (!(QM_ABL & 2)) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(crow + it * cstep));
+                else asm volatile("" ::"v"(v));
+            }
+            WAIT_LGKM0();                                          // staged rows are in registers before this wave's next DMA lands there
+            __builtin_amdgcn_sched_barrier(0);
+            hbase = wbase;
+            held = true;
+        }
+        QM_STAMP(2);
+#ifdef QM_TRACE
+        ++qt_tile;
+#endif
+        if (!has_next) break;
+        cur = nxt;
+        L = Lnext;
+    }
+#undef QM_KTILE
+#undef QM_Q
+#undef QM_G
+    // ---- the last tile of this workgroup has no K loop to hide under: its held stores leave at once ------------------------------
+#define QM_FLUSH(RB)                                                                                                 \
+    transpose_word(IC<RB>{}, IC<0>{}, IC<0>{}); transpose_word(IC<RB>{}, IC<0>{}, IC<1>{}); transpose_word(IC<RB>{}, IC<0>{}, IC<2>{}); transpose_word(IC<RB>{}, IC<0>{}, IC<3>{}); \
+    transpose_word(IC<RB>{}, IC<1>{}, IC<0>{}); transpose_word(IC<RB>{}, IC<1>{}, IC<1>{}); transpose_word(IC<RB>{}, IC<1>{}, IC<2>{}); transpose_word(IC<RB>{}, IC<1>{}, IC<3>{}); \
+    transpose_word(IC<RB>{}, IC<2>{}, IC<0>{}); transpose_word(IC<RB>{}, IC<2>{}, IC<1>{}); transpose_word(IC<RB>{}, IC<2>{}, IC<2>{}); transpose_word(IC<RB>{}, IC<2>{}, IC<3>{}); \
+    transpose_word(IC<RB>{}, IC<3>{}, IC<0>{}); transpose_word(IC<RB>{}, IC<3>{}, IC<1>{}); transpose_word(IC<RB>{}, IC<3>{}, IC<2>{}); transpose_word(IC<RB>{}, IC<3>{}, IC<3>{}); \
+    store_one(IC<RB>{}, IC<0>{}, hbase + (RB) * rowblock); store_one(IC<RB>{}, IC<1>{}, hbase + (RB) * rowblock);   \
+    store_one(IC<RB>{}, IC<2>{}, hbase + (RB) * rowblock); store_one(IC<RB>{}, IC<3>{}, hbase + (RB) * rowblock);   \
+    store_one(IC<RB>{}, IC<4>{}, hbase + (RB) * rowblock); store_one(IC<RB>{}, IC<5>{}, hbase + (RB) * rowblock);   \
+    store_one(IC<RB>{}, IC<6>{}, hbase + (RB) * rowblock); store_one(IC<RB>{}, IC<7>{}, hbase + (RB) * rowblock);
+    QM_FLUSH(0) QM_FLUSH(1) QM_FLUSH(2)
+#undef QM_FLUSH
+    WAIT_VMCNT(0);                       // drain the clamped tail DMA (and the last stores) before the workgroup retires
+}
+
+template <int DT, int D>
+void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch)
+{
+    lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_lp256qm_kernel<DT, D>), LDS_BYTES);
+    const uint32_t total = g.tiles_m * g.tiles_n * batch;
+    const uint32_t grid = std::min<uint32_t>(total, ctx->props.num_streaming_multiprocessors);   // one workgroup per CU (LDS admits no more)
+    hipLaunchKernelGGL((gemm_lp256qm_kernel<DT, D>), dim3(grid), dim3(256), LDS_BYTES, s, g);
+}
+
+int drip_for(int64_t nk)                 // fewest stores per K-tile whose drip phase (K-tiles 1 .. 24 / D) fits: nk >= 24 / D + 3
+{
+    return nk >= 27 ? 1 : nk >= 15 ? 2 : nk >= 9 ? 4 : nk >= 6 ? 8 : 0;
+}
+
+}  // namespace
+
+#ifdef QM_TRACE
+extern "C" __attribute__((visibility("default"))) int mi355_dev_qm_trace(unsigned long long *host_out)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(qm_trace_buf), sizeof(unsigned long long) * 256 * 32);
+}
+#endif
+
+namespace mi355 {
+
+bool gemm_lp256qm_supports(const mi355_gemm_desc &d, const void *a, const void *b, const void *c)
+{
+    if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16) return false;
+    if (d.dtype_c != d.dtype_ab) return false;                     // (f32 C would need 192 held registers)
+    if (d.trans_a || !d.trans_b) return false;                     // A [M][K], B [N][K]
+    if (!gemm_lp256p_supports(d, a, b, c)) return false;           // full tiles, K-contiguous 16-byte aligned operands, 32-bit DMA offsets
+    if (drip_for(d.k / 64) == 0) return false;
+    if ((int64_t)32 * d.ldc * 2 >= (1ll << 32)) return false;      // per-lane store offsets are 32-bit
+    return true;
+}
+
+int32_t launch_gemm_lp256qm(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc &d, const void *a, const void *b, void *c)
+{
+    if (!gemm_lp256qm_supports(d, a, b, c))
+        return fail(ctx, MI355_E_UNSUPPORTED, "lp256qm GEMM: shape/layout not supported by this kernel");
+    gemm_args g{};
+    g.a = a; g.b = b; g.c = c;
+    g.m = d.m; g.n = d.n; g.k = d.k;
+    g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc;
+    g.stride_a = d.stride_a; g.stride_b = d.stride_b; g.stride_c = d.stride_c;
+    g.tiles_m = (uint32_t)(d.m / BM);
+    g.tiles_n = (uint32_t)(d.n / BN);
+    g.group_m = 8;
+    g.batch_count = (uint32_t)d.batch;
+    const uint32_t batch = (uint32_t)d.batch;
+    const int drip = drip_for(d.k / 64);
+    const bool bf = d.dtype_ab == MI355_DTYPE_BF16;
+#define QM_LAUNCH(DD) { if (bf) launch<MI355_DTYPE_BF16, DD>(ctx, s, g, batch); else launch<MI355_DTYPE_F16, DD>(ctx, s, g, batch); }
+    if (drip == 1) QM_LAUNCH(1) else if (drip == 2) QM_LAUNCH(2) else if (drip == 4) QM_LAUNCH(4) else QM_LAUNCH(8)
+#undef QM_LAUNCH
+    check_launch(ctx, "mi355_gemm(lp256qm)");
+    return MI355_OK;
+}
+
+}  // namespace mi355

@@ -404,8 +404,10 @@ enum {
     MI355_GEMM_ALGO_LP_256X192 = 12, /* bf16/f16, [N][K] or row-major rhs: the 4-wave kernel of _LP_256W4 on a 256 x 192 tile (each wave 128 x 96):
                                      grids on which the square tile leaves CUs idle (ABI 8; gemm_lp256w4.hip NJ = 3) */
     MI355_GEMM_ALGO_LP_192X192 = 13, /* ... and on a 192 x 192 tile (each wave 96 x 96; NJ = NI = 3) */
-    MI355_GEMM_ALGO_LP_256M16 = 14   /* bf16/f16, [N][K] rhs: the 256 x 256 tile on v_mfma_f32_16x16x32 (eight MFMAs per A fragment: the
+    MI355_GEMM_ALGO_LP_256M16 = 14,  /* bf16/f16, [N][K] rhs: the 256 x 256 tile on v_mfma_f32_16x16x32 (eight MFMAs per A fragment: the
                                      order that issues at 16 cycles and holds a higher clock on random operands; gemm_lp256m16.hip) */
+    MI355_GEMM_ALGO_LP_256QM = 15    /* bf16/f16, [N][K] rhs, 16-bit C, full tiles: the persistent dripped-store kernel (_LP_256Q) on the 16x16x32
+                                     MFMA order of _LP_256M16; bit-identical to _LP_256M16 (ABI 9; gemm_lp256qm.hip, config C5) */
 };
 
 int32_t mi355_gemm(mi355_ctx *ctx, mi355_stream stream, const mi355_gemm_desc *desc,

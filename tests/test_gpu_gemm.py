@@ -26,7 +26,7 @@ REL = 1e-5
 ALGOS = {"auto": N.GEMM_ALGO_AUTO, "generic": N.GEMM_ALGO_GENERIC, "f32": N.GEMM_ALGO_F32_MFMA,
          "lp128": N.GEMM_ALGO_LP_128, "lp256": N.GEMM_ALGO_LP_256, "lp256w4": N.GEMM_ALGO_LP_256W4, "lp256p": N.GEMM_ALGO_LP_256P,
          "lp256q": N.GEMM_ALGO_LP_256Q, "skinny": N.GEMM_ALGO_SKINNY, "stream64": N.GEMM_ALGO_STREAM64,
-         "lp256x128": N.GEMM_ALGO_LP_256X128, "nnrows": N.GEMM_ALGO_NNROWS, "lp256x192": N.GEMM_ALGO_LP_256X192, "lp192x192": N.GEMM_ALGO_LP_192X192, "lp256m16": N.GEMM_ALGO_LP_256M16}
+         "lp256x128": N.GEMM_ALGO_LP_256X128, "nnrows": N.GEMM_ALGO_NNROWS, "lp256x192": N.GEMM_ALGO_LP_256X192, "lp192x192": N.GEMM_ALGO_LP_192X192, "lp256m16": N.GEMM_ALGO_LP_256M16, "lp256qm": N.GEMM_ALGO_LP_256QM}
 
 
 def _to_dev(client, oracle, x, dtype):
@@ -619,6 +619,54 @@ def test_lp256q_oracle_f16_identity_pitched_c_and_refusals(client, oracle):
         with pytest.raises(ServerError) as e:
             run_case(client, oracle, 512, 512, kw.get("k", 1024), ElemType.BF16, kw.get("out", ElemType.BF16), True, ALGOS["lp256q"],
                      **({"lda": kw["lda"]} if "lda" in kw else {}))
+        assert e.value.code == N.E_UNSUPPORTED
+
+
+# ---- the persistent dripped-store form on v_mfma_f32_16x16x32 (round 6, gemm_lp256qm.hip: config C5) ---------------------------------
+# Every output element is the same chain of 16x16x32 MFMAs as in gemm_lp256m16.hip (the B tile's rows are permuted on their way into
+# LDS, the products are not): bit for bit against that kernel.  K walks the four drip rates and their edges as above; the shapes put
+# 1, 2 and "some 1, some 2" tiles on a workgroup, so the first tile (stores branched over), the steady state and the flush all run.
+@pytest.mark.parametrize("k", [384, 448, 512, 576, 640, 896, 960, 1024, 1664, 1728, 2048, 4160])
+@pytest.mark.parametrize("m,n,batch", [(512, 512, 1), (4352, 4352, 1), (1024, 512, 72)])
+def test_lp256qm_is_bit_identical_to_the_m16_kernel(client, oracle, m, n, batch, k):
+    if (m, k) == (4352, 4160):
+        pytest.skip("covered by the smaller shapes")
+    a = TensorHandle.uniform(client, (batch, m, k), ElemType.BF16, 0x5EEDC0BE, 83, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (batch, n, k), ElemType.BF16, 0x5EEDC0BE, 84, -1.0, 1.0)
+    bt = TensorHandle.new(b.handle, (batch, k, n), (n * k, 1, k), ElemType.BF16)
+    ref = TensorHandle.new_contiguous((batch, m, n), client.empty(batch * m * n * 2), ElemType.BF16)
+    ops.matmul(client, a, bt, ref, algo=ALGOS["lp256m16"])
+    want = ref.to_numpy(client).copy()
+    c = TensorHandle.new_contiguous((batch, m, n), client.empty(batch * m * n * 2), ElemType.BF16)
+    for _ in range(4):                                                     # the counted waits must hold on every launch
+        client._s.check(client.lib.mi355_memset(client.ctx, None, c.device_ptr(), 0xEE, batch * m * n * 2))
+        ops.matmul(client, a, bt, c, algo=ALGOS["lp256qm"])
+        assert np.array_equal(c.to_numpy(client), want)
+
+
+def test_lp256qm_oracle_f16_identity_pitched_operands_and_refusals(client, oracle):
+    run_case(client, oracle, 512, 768, 512, ElemType.F16, ElemType.F16, True, ALGOS["lp256qm"])           # against the oracle itself
+    run_case(client, oracle, 768, 512, 1024, ElemType.BF16, ElemType.BF16, True, ALGOS["lp256qm"], batch=3, ldc=520)   # pitched C rows
+    run_case(client, oracle, 512, 768, 2048, ElemType.BF16, ElemType.BF16, True, ALGOS["lp256qm"], batch=2, lda=2056, ldb=2112)   # lda != ldb (one drip per K-tile)
+    run_case(client, oracle, 512, 512, 640, ElemType.BF16, ElemType.BF16, True, ALGOS["lp256qm"], batch=5, bcast_b=True)          # B broadcast over the batch
+    m = n = k = 4352                                                        # I x B^T: every tile of both rounds returns the operand's bits
+    eye = np.zeros((m, k), dtype=np.uint16)                                 # (a wrong row of the permuted B tile shows as a wrong COLUMN here)
+    eye[np.arange(m), np.arange(m)] = 0x3F80
+    bmat = oracle.to_bf16(oracle.fill_uniform(n * k, 93, -1.0, 1.0)).reshape(n, k)
+    ta, tb = TensorHandle.from_numpy(client, eye, ElemType.BF16), TensorHandle.from_numpy(client, bmat, ElemType.BF16)
+    c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 2), ElemType.BF16)
+    ops.matmul(client, TensorHandle.new(ta.handle, (m, k), (k, 1), ElemType.BF16), TensorHandle.new(tb.handle, (k, n), (1, k), ElemType.BF16),
+               c, algo=ALGOS["lp256qm"])
+    assert np.array_equal(c.to_numpy(client).reshape(m, n), bmat.T)
+    # A x I: the permutation must also hold from the other side (row i of C = row i of A)
+    amat = oracle.to_bf16(oracle.fill_uniform(m * k, 94, -1.0, 1.0)).reshape(m, k)
+    ta, tb = TensorHandle.from_numpy(client, amat, ElemType.BF16), TensorHandle.from_numpy(client, eye, ElemType.BF16)
+    ops.matmul(client, TensorHandle.new(ta.handle, (m, k), (k, 1), ElemType.BF16), TensorHandle.new(tb.handle, (k, n), (1, k), ElemType.BF16),
+               c, algo=ALGOS["lp256qm"])
+    assert np.array_equal(c.to_numpy(client).reshape(m, n), amat)
+    for kw in (dict(k=320), dict(out=ElemType.F32), dict(trans_b=False), dict(m=520)):   # < 6 K-tiles / f32 C / row-major B / ragged tiles: refused, not mis-run
+        with pytest.raises(ServerError) as e:
+            run_case(client, oracle, kw.get("m", 512), 512, kw.get("k", 1024), ElemType.BF16, kw.get("out", ElemType.BF16), kw.get("trans_b", True), ALGOS["lp256qm"])
         assert e.value.code == N.E_UNSUPPORTED
 
 
