@@ -75,7 +75,7 @@ class MmaConfig(C.Structure):
                 ("a_type", C.c_int32), ("b_type", C.c_int32), ("cd_type", C.c_int32)]
 
 
-ABI_VERSION = 8     # MI355_ABI_VERSION of include/mi355cube.h this table was written against
+ABI_VERSION = 9     # MI355_ABI_VERSION of include/mi355cube.h this table was written against
 
 
 class MemoryUsage(C.Structure):
@@ -235,6 +235,7 @@ PROTOTYPES = {
     "mi355_sum_argmax_f32": (C.c_int32, [_P, _P, _P, C.c_uint64, _P, _P, _P, _P, C.c_uint64]),
     "mi355_argmax_combine_f32": (C.c_int32, [_P, _P, _P, C.c_uint32, C.POINTER(C.c_uint64), _P, _P]),
     "mi355_sum_argmax_combine_f32": (C.c_int32, [_P, _P, _P, C.c_uint32, C.POINTER(C.c_uint64), _P, _P, _P]),
+    "mi355_sum_argmax_exchange": (C.c_int32, [_P, _P, _P, _P, _P, C.POINTER(C.c_uint64), _P, _P, _P]),
     "mi355_reduce": (C.c_int32, [_P, _P, _P, C.c_int32, C.c_uint64, C.c_int32, _P, _P, C.c_uint64]),
     "mi355_argreduce": (C.c_int32, [_P, _P, _P, C.c_int32, C.c_uint64, C.c_int32, _P, _P, _P, C.c_uint64]),
     "mi355_reduce_axis": (C.c_int32, [_P, _P, _P, C.c_int32, C.c_int32, _P, C.c_uint64, C.c_uint64, C.c_uint64]),

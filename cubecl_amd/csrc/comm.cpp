@@ -146,19 +146,52 @@ static int32_t fence_compute_to_comm(mi355_ctx *ctx, hipStream_t compute)
     return MI355_OK;
 }
 
+// Orders stream `waiter` behind the last inline collective when that ran on another stream (no-op otherwise).
+static int32_t fence_inline_to(mi355_ctx *ctx, hipStream_t waiter)
+{
+    if (!ctx->inline_dirty || ctx->inline_stream == waiter) return MI355_OK;
+    MI355_HIP(ctx, hipEventRecord(ctx->fence_c, ctx->inline_stream));
+    MI355_HIP(ctx, hipStreamWaitEvent(waiter, ctx->fence_c, 0));
+    return MI355_OK;
+}
+
+// The communication stream takes the next operation: behind everything queued on `compute` (the reference's compute -> comm fence) and
+// behind an inline collective still running on ANOTHER compute stream; one on `compute` itself is covered by the first fence.  From
+// here on the communication stream carries that order (mi355_sync_collective fences it towards whoever asks).
+static int32_t onto_comm_stream(mi355_ctx *ctx, hipStream_t compute)
+{
+    if (ctx->inline_dirty) {
+        if (ctx->inline_stream != compute) {
+            const int32_t rc = fence_inline_to(ctx, ctx->comm_stream);
+            if (rc != MI355_OK) return rc;
+        }
+        ctx->inline_dirty = false;
+    }
+    return fence_compute_to_comm(ctx, compute);
+}
+
 // Which stream a collective of `bytes` (the larger of what it reads and writes on this rank) runs on.  The reference's shape
 // -- a communication stream between two event fences -- lets compute run beside a transfer; a collective of a few bytes has
 // no transfer to hide, and the fences are most of its time (one all-gather of a 16-byte record + the combine kernel behind
 // it, 1 rank on real RCCL: 31.8 us through the fences, see profiles/r05_c4_shard.md for the inline figure).  So a message of at
-// most MI355_COMM_INLINE_BYTES (default 4096) is queued IN the compute stream's order: no fence before it, nothing for
-// mi355_sync_collective to do after it.  Only while no earlier collective is still un-fenced on the communication stream
-// (comm_dirty): a communicator then never has operations in flight on two streams at once, and RCCL sees them in call order.
+// most MI355_COMM_INLINE_BYTES (default 4096) is queued IN the compute stream's order: no fence before it, and for THAT stream
+// nothing for mi355_sync_collective to do after it.  The guarantee of the reference's sync_collective (crates/cubecl-cuda/src/
+// compute/server.rs:782-797) -- any stream named there is ordered behind every collective issued before -- is kept for OTHER
+// streams through `inline_stream` / `fence_c`: the library remembers which stream carries the last inline collective;
+// mi355_sync_collective(another stream), a later collective on another stream (inline or on the communication stream) and
+// mi355_comm_destroy order themselves behind it.  A communicator therefore never has operations in flight on two streams at
+// once, and RCCL sees them in call order.
 static hipStream_t collective_stream(mi355_ctx *ctx, hipStream_t compute, uint64_t bytes, int32_t *rc)
 {
     static const uint64_t inline_bytes = [] { const char *e = getenv("MI355_COMM_INLINE_BYTES"); return e ? (uint64_t)strtoull(e, nullptr, 10) : 4096ull; }();
     *rc = MI355_OK;
-    if (bytes <= inline_bytes && !ctx->comm_dirty) return compute;
-    *rc = fence_compute_to_comm(ctx, compute);
+    if (bytes <= inline_bytes && !ctx->comm_dirty) {
+        if ((*rc = fence_inline_to(ctx, compute)) != MI355_OK) return compute;    // an inline collective still running on ANOTHER compute stream
+        ctx->inline_stream = compute;
+        ctx->inline_dirty = true;
+        return compute;
+    }
+    *rc = onto_comm_stream(ctx, compute);
     return ctx->comm_stream;
 }
 
@@ -196,6 +229,10 @@ MI355_API int32_t mi355_comm_destroy(mi355_ctx *ctx, mi355_comm *comm)
     MI355_REQUIRE_CTX(ctx);
     if (!comm) return MI355_OK;
     hipStreamSynchronize(ctx->comm_stream);
+    if (ctx->inline_dirty && ctx->inline_stream) {          // collectives queued in a compute stream's order (collective_stream)
+        hipStreamSynchronize(ctx->inline_stream);
+        ctx->inline_dirty = false;
+    }
     if (comm->comm) g_rccl.CommDestroy(comm->comm);
     delete comm;
     return MI355_OK;
@@ -246,7 +283,7 @@ MI355_API int32_t mi355_send(mi355_ctx *ctx, mi355_comm *comm, mi355_stream comp
         return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_send: bad peer %d", peer);
     ncclDataType_t dt;
     if (!to_nccl_dtype(dtype, &dt)) return fail(ctx, MI355_E_UNSUPPORTED, "mi355_send: dtype %d not supported by RCCL", dtype);
-    int32_t rc = fence_compute_to_comm(ctx, stream_of(ctx, compute_stream));
+    int32_t rc = onto_comm_stream(ctx, stream_of(ctx, compute_stream));
     if (rc != MI355_OK) return rc;
     MI355_NCCL(ctx, g_rccl.Send(src, count, dt, peer, comm->comm, ctx->comm_stream));
     return MI355_OK;
@@ -263,7 +300,7 @@ MI355_API int32_t mi355_recv(mi355_ctx *ctx, mi355_comm *comm, mi355_stream comp
         return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_recv: bad peer %d", peer);
     ncclDataType_t dt;
     if (!to_nccl_dtype(dtype, &dt)) return fail(ctx, MI355_E_UNSUPPORTED, "mi355_recv: dtype %d not supported by RCCL", dtype);
-    int32_t rc = fence_compute_to_comm(ctx, stream_of(ctx, compute_stream));
+    int32_t rc = onto_comm_stream(ctx, stream_of(ctx, compute_stream));
     if (rc != MI355_OK) return rc;
     MI355_NCCL(ctx, g_rccl.Recv(dst, count, dt, peer, comm->comm, ctx->comm_stream));
     return MI355_OK;
@@ -273,9 +310,18 @@ MI355_API int32_t mi355_recv(mi355_ctx *ctx, mi355_comm *comm, mi355_stream comp
 MI355_API int32_t mi355_sync_collective(mi355_ctx *ctx, mi355_stream compute_stream)
 {
     MI355_REQUIRE_CTX(ctx);
+    hipStream_t s = stream_of(ctx, compute_stream);
+    // a collective that ran inline on ANOTHER compute stream: this stream waits for it as it would for the communication stream
+    // (the flag stays up: a third stream may still ask; the carrying stream itself never needs a fence)
+    int32_t rc = fence_inline_to(ctx, s);
+    if (rc != MI355_OK) return rc;
     if (!ctx->comm_dirty) return MI355_OK;
     MI355_HIP(ctx, hipEventRecord(ctx->fence_b, ctx->comm_stream));
-    MI355_HIP(ctx, hipStreamWaitEvent(stream_of(ctx, compute_stream), ctx->fence_b, 0));
+    MI355_HIP(ctx, hipStreamWaitEvent(s, ctx->fence_b, 0));
     ctx->comm_dirty = false;
     return MI355_OK;
 }
+
+namespace mi355 {
+int comm_world_size(const mi355_comm *comm) { return comm ? comm->world : 0; }
+}  // namespace mi355

@@ -91,6 +91,11 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void *p)
 #ifndef QM_LAG
 #define QM_LAG 3          // a finished block is packed behind the MFMA this many slots after its own (no wait on the matrix pipe)
 #endif
+#ifndef QM_BDRIP
+#define QM_BDRIP 0        // 1: the 8 boundary stores (block rows 6-7) leave one per 8 MFMAs during k-step 0 of the next tile's K-tile 0; 0: in a burst at the
+                          // boundary.  Measured (C5, three interleaved pairs, profiles/r06_qm_ab.txt): 1 = 1 275-1 286, 0 = 1 288-1 303 TFLOP/s -- the stores cost
+                          // the K loop what they cost wherever they sit; the burst keeps K-tile 0 clean
+#endif
 #ifndef QM_STORE_FORM
 #define QM_STORE_FORM 1   // 1: inline asm, wave-uniform base in SGPRs + 32-bit lane offset (no address VGPRs); 0: builtin store
 #endif
@@ -281,6 +286,41 @@ gemm_lp256qm_kernel(gemm_args g)
         }
     };
 
+    // ---- block rows 6, 7 (the staging image) -------------------------------------------------------------------------------------
+    // QM_BDRIP: the image is read back and stored 4 rows x 256 B at a time behind MFMA 8 it + 2 of k-step 0 of the NEXT tile's K-tile 0,
+    // one MFMA in front of DMA piece `it` of that k-step -- the piece of unit 4 that overwrites exactly those 1 024 bytes of this wave's
+    // region.  The read of part it + 1 is issued with the store of part it (two registers quads in rotation), so the store's operand wait
+    // is what orders every read in front of the DMA piece that replaces its source.  vmcnt: the stores sit BETWEEN the pieces of unit 4
+    // instead of in front of them: the same 16 operations may fly at hand-over 0.
+    uint32_t bstage = 0;                 // LDS byte offset of this wave's staging image
+    char *bbase = nullptr;               // wave-uniform address of row 96 of the wave's block
+    const uint32_t bvoff = (uint32_t)((lane >> 4) * g.ldc * CSZ + (lane & 15) * 16);
+    u32x4 bv[2];
+    // row r = 4 it + lane / 16 of the image, chunk (lane % 16) ^ (r & 15)
+    auto bread = [&](auto itt) {
+        constexpr int IT = decltype(itt)::value;
+        const uint32_t rdx = (uint32_t)((lane >> 4) * 256 + (((lane & 15) ^ (lane >> 4)) << 4));
+        bv[IT & 1] = *reinterpret_cast<const u32x4 *>(smem + bstage + IT * 1024 + (opaque(rdx) ^ (uint32_t)((IT & 3) << 6)));
+    };
+    auto bstore = [&](auto itt) {
+        constexpr int IT = decltype(itt)::value;
+        const u32x4 v = bv[IT & 1];
+        if (QM_ABL & 2) { asm volatile("" ::"v"(v)); return; }
+        char *sb_ = bbase + (int64_t)(4 * IT) * rowbytes;
+        const uint32_t so_ = bvoff;
+        asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(so_), "v"(v), "s"(sb_) : "memory");
+    };
+    auto bd_gap = [&](auto nn) {
+        constexpr int N = decltype(nn)::value;
+        if constexpr (QM_BDRIP && (N & 7) == 2) {
+            constexpr int IT = N >> 3;
+            if (held) {
+                bstore(IC<IT>{});
+                if constexpr (IT < 7) bread(IC<(IT < 7 ? IT + 1 : 0)>{});
+            }
+        }
+    };
+
     // 16 MFMAs n = N0 .. N0 + 15 of a k-step.  A read follows MFMA n where qm_read_at(k-step, n) >= 0 (below the kernel); DMASK bit b: a
     // DMA piece follows MFMA N0 + b.  KS = 0: transposition slots; KS = 1: store slots (head) + packing of finished blocks (DRAIN).
     // Instruction order pinned by sched_barrier after every group.
@@ -293,6 +333,7 @@ gemm_lp256qm_kernel(gemm_args g)
         drain_one(IC<((N0) + (BIT) >= QM_LAG ? (N0) + (BIT) - QM_LAG : 0)>{});                                        \
     }                                                                                                                 \
     if constexpr ((KS) == 0 && (G) >= 0) { __builtin_amdgcn_sched_barrier(0); tr_gap(IC<(G)>{}, IC<(N0) + (BIT)>{}); } \
+    if constexpr ((KS) == 0 && (FIRST)) { __builtin_amdgcn_sched_barrier(0); bd_gap(IC<(N0) + (BIT)>{}); }           \
     if constexpr ((KS) == 1 && (G) >= 0 && (N0) == 0) { __builtin_amdgcn_sched_barrier(0); st_gap(IC<(G)>{}, IC<(N0) + (BIT)>{}, rb_base); } \
     __builtin_amdgcn_sched_barrier(0);
 #define QM_Q(CUR, NXT, KS, N0, DMASK, IS_B, J0, FIRST, DRAIN, G)                                                      \
@@ -423,24 +464,19 @@ gemm_lp256qm_kernel(gemm_args g)
 
         // ---- tile boundary: block rows 6, 7 through this wave's 8 KiB of the dead B slot ------------------------------------------
         {
-            char *stage = smem + adv(sb, 3) + wave * 8192;          // slot of the last B unit, my DMA region of it
             const int64_t cbase = cur.batch * g.stride_c;
             char *wbase = C + (cbase + (cur.m0 + wm * 128) * g.ldc + cur.n0 + wn * 128) * CSZ;   // my 128x128 block
-            char *crow = wbase + (int64_t)(96 + lane / 16) * g.ldc * CSZ + (lane % 16) * 16;
-            const int64_t cstep = (int64_t)4 * g.ldc * CSZ;
-            WAIT_LGKM0();                                          // same-wave hand-over: DS ops of one wave execute in order
-            // row r = 4 it + lane / 16, chunk (lane % 16) ^ (r & 15)
-            const uint32_t rdx = (uint32_t)((lane >> 4) * 256 + (((lane & 15) ^ (lane >> 4)) << 4));
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const u32x4 v = *reinterpret_cast<const u32x4 *>(stage + it * 1024 + (opaque(rdx) ^ (uint32_t)((it & 3) << 6)));
-                if (!(QM_ABL & 2)) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(crow + it * cstep));
-                else asm volatile("" ::"v"(v));
-            }
-            WAIT_LGKM0();                                          // staged rows are in registers before this wave's next DMA lands there
-            __builtin_amdgcn_sched_barrier(0);
+            bstage = (uint32_t)(adv(sb, 3) + wave * 8192);          // slot of the last B unit, my DMA region of it
+            bbase = wbase + (int64_t)96 * rowbytes;
             hbase = wbase;
             held = true;
+            bread(IC<0>{});                                         // (same-wave hand-over: the DS ops of one wave execute in order)
+            if constexpr (!QM_BDRIP) {
+                bstore(IC<0>{}); bread(IC<1>{}); bstore(IC<1>{}); bread(IC<2>{}); bstore(IC<2>{}); bread(IC<3>{}); bstore(IC<3>{}); bread(IC<4>{});
+                bstore(IC<4>{}); bread(IC<5>{}); bstore(IC<5>{}); bread(IC<6>{}); bstore(IC<6>{}); bread(IC<7>{}); bstore(IC<7>{});
+                WAIT_LGKM0();                                       // staged rows are in registers before this wave's next DMA lands there
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         QM_STAMP(2);
 #ifdef QM_TRACE
@@ -463,6 +499,10 @@ gemm_lp256qm_kernel(gemm_args g)
     store_one(IC<RB>{}, IC<2>{}, hbase + (RB) * rowblock); store_one(IC<RB>{}, IC<3>{}, hbase + (RB) * rowblock);   \
     store_one(IC<RB>{}, IC<4>{}, hbase + (RB) * rowblock); store_one(IC<RB>{}, IC<5>{}, hbase + (RB) * rowblock);   \
     store_one(IC<RB>{}, IC<6>{}, hbase + (RB) * rowblock); store_one(IC<RB>{}, IC<7>{}, hbase + (RB) * rowblock);
+    if constexpr (QM_BDRIP) {            // ... and neither have its block rows 6, 7 (part 0 is already in bv[0])
+        bstore(IC<0>{}); bread(IC<1>{}); bstore(IC<1>{}); bread(IC<2>{}); bstore(IC<2>{}); bread(IC<3>{}); bstore(IC<3>{}); bread(IC<4>{});
+        bstore(IC<4>{}); bread(IC<5>{}); bstore(IC<5>{}); bread(IC<6>{}); bstore(IC<6>{}); bread(IC<7>{}); bstore(IC<7>{});
+    }
     QM_FLUSH(0) QM_FLUSH(1) QM_FLUSH(2)
 #undef QM_FLUSH
     WAIT_VMCNT(0);                       // drain the clamped tail DMA (and the last stores) before the workgroup retires

@@ -49,6 +49,11 @@ struct mi355_ctx {
     hipEvent_t fence_a = nullptr;  // reusable fences for the comm <-> compute hand-offs
     hipEvent_t fence_b = nullptr;
     bool comm_dirty = false;
+    // collectives of a few bytes run in the CALLER's stream order (comm.cpp collective_stream): the stream that carries the last such
+    // collective not yet fenced towards another stream, and the event mi355_sync_collective(other stream) waits on
+    hipStream_t inline_stream = nullptr;
+    bool inline_dirty = false;
+    hipEvent_t fence_c = nullptr;
     void *ticket_buf = nullptr;            // library-owned device scratch: arrival tickets of the reductions
     std::unordered_map<hipStream_t, uint32_t> ticket_slots;
     std::vector<uint32_t> ticket_free;     // slots of destroyed streams (mi355_stream_destroy), reused first
@@ -97,6 +102,7 @@ int32_t map_hip_error(hipError_t e);
 // contract: crates/cubecl-hip/src/compute/server.rs:263-269).
 void check_launch(mi355_ctx *ctx, const char *what);
 bool rccl_available();  // comm.cpp
+int comm_world_size(const mi355_comm *comm);   // comm.cpp (the struct is private to it)
 // pool.cpp
 int32_t pool_alloc(mi355_ctx *ctx, hipStream_t stream, uint64_t bytes, void **out);
 int32_t pool_free(mi355_ctx *ctx, hipStream_t stream, void *ptr);

@@ -277,6 +277,11 @@ int32_t pool_free(mi355_ctx *ctx, hipStream_t stream, void *ptr)
         if (hipEventRecord(ctx->fence_b, ctx->comm_stream) != hipSuccess || hipStreamWaitEvent(stream, ctx->fence_b, 0) != hipSuccess)
             (void)hipGetLastError();
     }
+    // ... and so may a small collective queued in ANOTHER compute stream's order (comm.cpp collective_stream)
+    if (ctx->inline_dirty && !in_window && ctx->inline_stream && ctx->inline_stream != stream && ctx->fence_c) {
+        if (hipEventRecord(ctx->fence_c, ctx->inline_stream) != hipSuccess || hipStreamWaitEvent(stream, ctx->fence_c, 0) != hipSuccess)
+            (void)hipGetLastError();
+    }
     blk.stream = stream;
     blk.freed_tick = p->tick;
     blk.event = nullptr;

@@ -1239,6 +1239,20 @@ MI355_API int32_t mi355_sum_argmax_combine_f32(mi355_ctx *ctx, mi355_stream stre
     return MI355_OK;
 }
 
+// all-gather + fence + combine of the sharded sum + argmax in one call (header: mi355_sum_argmax_exchange; lives beside the combine
+// kernel so that comm.cpp stays free of kernel symbols -- the host-runtime test library links it without reduce.hip)
+MI355_API int32_t mi355_sum_argmax_exchange(mi355_ctx *ctx, mi355_comm *comm, mi355_stream stream, const void *record, void *gathered,
+                                            const uint64_t *index_base, float *out_sum, float *out_val, uint64_t *out_idx)
+{
+    MI355_REQUIRE_CTX(ctx);
+    if (!comm) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_sum_argmax_exchange: communicator is NULL (call mi355_comm_init)");
+    if (!record || !gathered) return fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_sum_argmax_exchange: NULL record buffer");
+    int32_t rc = mi355_all_gather(ctx, comm, stream, record, gathered, 2, MI355_DTYPE_U64);
+    if (rc == MI355_OK) rc = mi355_sync_collective(ctx, stream);
+    if (rc == MI355_OK) rc = mi355_sum_argmax_combine_f32(ctx, stream, gathered, (uint32_t)comm_world_size(comm), index_base, out_sum, out_val, out_idx);
+    return rc;
+}
+
 MI355_API int32_t mi355_reduce_last_axis_sum_f32(mi355_ctx *ctx, mi355_stream stream, const float *in, float *out,
                                                  uint64_t rows, uint64_t cols, uint64_t row_stride)
 {

@@ -158,7 +158,8 @@ MI355_API int32_t mi355_ctx_create(int32_t device_index, mi355_ctx **out_ctx)
     if ((e = hipStreamCreateWithFlags(&ctx->compute_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->fence_a, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&ctx->fence_b, hipEventDisableTiming)) != hipSuccess) {
+        (e = hipEventCreateWithFlags(&ctx->fence_b, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->fence_c, hipEventDisableTiming)) != hipSuccess) {
         int32_t rc = fail(nullptr, map_hip_error(e), "stream/event creation: %s", hipGetErrorString(e));
         delete ctx;
         return rc;
@@ -261,6 +262,7 @@ MI355_API int32_t mi355_ctx_destroy(mi355_ctx *ctx)
         if (s.live) { hipEventDestroy(s.start); hipEventDestroy(s.stop); }
     if (ctx->fence_a) hipEventDestroy(ctx->fence_a);
     if (ctx->fence_b) hipEventDestroy(ctx->fence_b);
+    if (ctx->fence_c) hipEventDestroy(ctx->fence_c);
     if (ctx->ticket_buf) hipFree(ctx->ticket_buf);
     for (auto &kv : ctx->scratch) hipFree(kv.second.first);
     for (void *p : ctx->scratch_retired) hipFree(p);
@@ -398,6 +400,7 @@ MI355_API int32_t mi355_stream_destroy(mi355_ctx *ctx, mi355_stream stream)
     // stream's handle to the next hipStreamCreate, which would then inherit them.  The stream's work is finished first; scratch a
     // live graph replays against is retired (freed when the last such graph dies), not freed.
     MI355_HIP(ctx, hipStreamSynchronize(s));
+    if (ctx->inline_stream == s) { ctx->inline_stream = nullptr; ctx->inline_dirty = false; }   // its inline collectives have completed
     for (auto it = ctx->scratch.begin(); it != ctx->scratch.end();) {
         if (it->first.first != s) { ++it; continue; }
         void *p = it->second.first;

@@ -776,3 +776,17 @@ class ComputeClient:
 
     def sync_collective(self) -> None:
         self._s.check(self.lib.mi355_sync_collective(self.ctx, self.stream))
+
+    def sum_argmax_exchange(self, record: Handle, gathered: Handle, index_base, out_sum: Optional[Handle], out_value: Optional[Handle],
+                            out_index: Optional[Handle], device_ids: Sequence[DeviceId]) -> None:
+        """The exchange step of the sharded fused sum + argmax as ONE library call (`mi355_sum_argmax_exchange`: all-gather of the
+        16-byte record, comm -> compute fence, combine kernel); the Rust server's `sum_argmax_exchange`
+        (rust/cubecl-mi355/src/comm.rs).  `index_base`: one global start index per rank (host values)."""
+        ids = tuple(sorted(device_ids))
+        comm = self._s.comms.get(ids)
+        if comm is None:
+            raise ServerError(N.E_COMM, "sum_argmax_exchange before comm_init for this device set")
+        base = (C.c_uint64 * max(len(ids), 1))(*[int(b) for b in (index_base or [0] * len(ids))])
+        ptr = lambda h: C.c_void_p(h.device_ptr()) if h is not None else None
+        self._s.check(self.lib.mi355_sum_argmax_exchange(self.ctx, comm, self.on(record, gathered, out_sum, out_value, out_index),
+                                                         ptr(record), ptr(gathered), base, ptr(out_sum), ptr(out_value), ptr(out_index)))

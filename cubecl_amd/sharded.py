@@ -212,7 +212,9 @@ class RcclExchange(Exchange):
         stream like any other kernel output."""
         from . import ops
         gathered = self._buf.offset_start_by(64)
-        if mode == "gather":
+        if mode == "gather":       # one library call (round 6: three calls through the binding were 6-10 us of a 12 us exchange)
+            self._c.sum_argmax_exchange(rec, gathered, index_base, out_sum, out_value, out_index, self._ids)
+        elif mode == "gather3":    # the same exchange as the three calls it is made of (kept for the A/B and the tests)
             self._c.all_gather(rec, gathered, self._ElemType.U64, self._ids)
             self._c.sync_collective()
             ops.sum_argmax_combine(self._c, gathered, self.world, index_base, out_sum, out_value, out_index)
@@ -223,7 +225,7 @@ class RcclExchange(Exchange):
             self._c.sync_collective()
             ops.argmax_combine(self._c, gathered, self.world, index_base, out_value, out_index)
         else:
-            raise ValueError(f"exchange_on_device: mode {mode!r} (gather or all_reduce)")
+            raise ValueError(f"exchange_on_device: mode {mode!r} (gather, gather3 or all_reduce)")
 
 
 class RcclJob:

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define MI355_ABI_VERSION 8
+#define MI355_ABI_VERSION 9
 
 /* ---- status codes (map onto LaunchError / IoError / ServerError, server/base.rs:177-332,
  *      :884-1019; the Rust shim performs the conversion) ------------------------------- */
@@ -716,6 +716,13 @@ int32_t mi355_recv(mi355_ctx *ctx, mi355_comm *comm, mi355_stream compute_stream
 /* ServerCommunication::sync_collective (server.rs:782-797): the compute stream waits for the
  * comm stream. */
 int32_t mi355_sync_collective(mi355_ctx *ctx, mi355_stream compute_stream);
+/* (ABI 9) The exchange of the sharded sum + argmax (mi355_sum_argmax_combine_f32 above) as ONE call -- what the Rust server issues per step (rust/cubecl-mi355/src/comm.rs sum_argmax_exchange) and what
+ * keeps two host round trips through the binding out of a 12 us exchange: mi355_all_gather of this rank's 16-byte `record` (as 2 x u64)
+ * into `gathered` (16 bytes x the communicator's world size, rank order), the comm -> compute fence of mi355_sync_collective, and
+ * mi355_sum_argmax_combine_f32 over `gathered`, all queued on `stream`.  `index_base`: HOST array of world-size u64 (NULL = zeros), read
+ * before the call returns.  record / gathered / outputs are device memory; any output may be NULL.  Errors as the three calls'. */
+int32_t mi355_sum_argmax_exchange(mi355_ctx *ctx, mi355_comm *comm, mi355_stream stream, const void *record, void *gathered,
+                                  const uint64_t *index_base, float *out_sum, float *out_val, uint64_t *out_idx);
 
 /* =================================== Graph capture ======================================= */
 

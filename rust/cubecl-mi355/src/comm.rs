@@ -88,31 +88,30 @@ impl Mi355Server {
     /// The exchange step of a sharded fused sum + arg-max (config C4 of the benchmark) without a host round trip, beyond what
     /// `ServerCommunication` offers (the trait has no all-gather): `record` is the 16-byte `{f32 max, f32 partial sum, u64 local
     /// index}` the local pass wrote (`mi355_sum_argmax_f32` with `out_val = rec`, `out_sum = rec + 4`, `out_idx = rec + 8`),
-    /// `gathered` holds one record per rank.  ONE collective (`mi355_all_gather`), the comm -> compute fence, then a 64-lane kernel
-    /// that adds the partial sums in rank order and folds the candidates with the single-GPU rule (`mi355_sum_argmax_combine_f32`):
-    /// the same bits on every rank.  `index_base[r]` = global index of rank r's first element.  The Python mirror is
-    /// `cubecl_amd/sharded.py::RcclExchange::exchange_on_device(mode = "gather")`; the reference's own shape (all_reduce of the
-    /// sum + a gather of the candidates) is that function's other mode and needs nothing beyond the trait.
+    /// `gathered` holds one record per rank.  ONE library call (`mi355_sum_argmax_exchange`, ABI 9): one collective
+    /// (`mi355_all_gather`), the comm -> compute fence, then a 64-lane kernel that adds the partial sums in rank order and folds the
+    /// candidates with the single-GPU rule: the same bits on every rank.  `index_base[r]` = global index of rank r's first element --
+    /// a HOST slice: the library reads it on the host while it queues the combine kernel (`include/mi355cube.h`, "HOST array"; until
+    /// round 6 this method took a device binding and handed its pointer over, which the first call would have dereferenced on the
+    /// host).  The Python mirror is `cubecl_amd/runtime.py::ComputeClient::sum_argmax_exchange` (`sharded.py`, mode "gather"); the
+    /// reference's own shape (all_reduce of the sum + a gather of the candidates) needs nothing beyond the trait.
     #[allow(clippy::too_many_arguments)]
-    pub fn sum_argmax_exchange(&mut self, record: BufferBinding, gathered: BufferBinding, index_base: BufferBinding, out_sum: BufferBinding,
+    pub fn sum_argmax_exchange(&mut self, record: BufferBinding, gathered: BufferBinding, index_base: &[u64], out_sum: BufferBinding,
                                out_value: BufferBinding, out_index: BufferBinding, stream_id: StreamId, device_ids: Vec<DeviceId>)
                                -> Result<(), ServerError> {
         let ctx = self.ctx;
         let (comm, sorted) = self.communicator(device_ids)?;
-        let ranks = sorted.len() as u32;
-        let mut pass = self.pass(stream_id, [&record, &gathered, &index_base, &out_sum, &out_value, &out_index].into_iter(), Pending::Surface)?;
+        let ranks = sorted.len() as u64;
+        let mut pass = self.pass(stream_id, [&record, &gathered, &out_sum, &out_value, &out_index].into_iter(), Pending::Surface)?;
         let (rec, all) = (pass.slice(record)?, pass.slice(gathered)?);
-        let (base, sum, val, idx) = (pass.slice(index_base)?, pass.slice(out_sum)?, pass.slice(out_value)?, pass.slice(out_index)?);
-        if rec.size < 16 || all.size < 16 * ranks as u64 || base.size < 8 * ranks as u64 {
-            return Err(ServerError::Generic { reason: "sum_argmax_exchange: a 16-byte record per rank and a u64 base per rank".into(),
+        let (sum, val, idx) = (pass.slice(out_sum)?, pass.slice(out_value)?, pass.slice(out_index)?);
+        if rec.size < 16 || all.size < 16 * ranks || index_base.len() as u64 != ranks {
+            return Err(ServerError::Generic { reason: "sum_argmax_exchange: a 16-byte record per rank and one u64 base per rank".into(),
                                               backtrace: BackTrace::capture() });
         }
-        // two u64 per record: the all-gather moves it as 2 x MI355_DTYPE_U64 (the collective only needs a width)
-        error::check(ctx, unsafe { mi355_all_gather(ctx, comm, pass.sys(), rec.ptr, all.ptr, 2, MI355_DTYPE_U64) })?;
-        error::check(ctx, unsafe { mi355_sync_collective(ctx, pass.sys()) })?;
         error::check(ctx, unsafe {
-            mi355_sum_argmax_combine_f32(ctx, pass.sys(), all.ptr, ranks, base.ptr as *const u64, sum.ptr as *mut f32, val.ptr as *mut f32,
-                                         idx.ptr as *mut u64)
+            mi355_sum_argmax_exchange(ctx, comm, pass.sys(), rec.ptr, all.ptr, index_base.as_ptr(), sum.ptr as *mut f32, val.ptr as *mut f32,
+                                      idx.ptr as *mut u64)
         })
     }
 }

@@ -6,7 +6,7 @@ use core::ffi::{c_char, c_void};
 
 /// `MI355_ABI_VERSION` of the header these declarations were written against; `Mi355Runtime` compares it with what the
 /// loaded library reports (`mi355_device_props_t::abi_version`).
-pub const MI355_ABI_VERSION: u32 = 8;
+pub const MI355_ABI_VERSION: u32 = 9;
 
 pub const MI355_OK: i32 = 0;
 pub const MI355_E_INVALID_ARGUMENT: i32 = 1;
@@ -265,6 +265,9 @@ unsafe extern "C" {
                                     index_base: *const u64, out_val: *mut f32, out_idx: *mut u64) -> i32;
     pub fn mi355_sum_argmax_combine_f32(ctx: *mut mi355_ctx, stream: mi355_stream, records: *const c_void, count: u32,
                                         index_base: *const u64, out_sum: *mut f32, out_val: *mut f32, out_idx: *mut u64) -> i32;
+    pub fn mi355_sum_argmax_exchange(ctx: *mut mi355_ctx, comm: *mut mi355_comm, stream: mi355_stream, record: *const c_void,
+                                     gathered: *mut c_void, index_base: *const u64, out_sum: *mut f32, out_val: *mut f32,
+                                     out_idx: *mut u64) -> i32;
     pub fn mi355_reduce_last_axis_sum_f32(ctx: *mut mi355_ctx, stream: mi355_stream, input: *const f32, out: *mut f32,
                                           rows: u64, cols: u64, row_stride: u64) -> i32;
     // Collectives (RCCL over xGMI)

@@ -100,3 +100,16 @@ MI355_API int32_t mi355_sum_argmax_combine_f32(mi355_ctx *ctx, mi355_stream s, c
     if (out_val || out_idx) return mi355_argmax_combine_f32(ctx, s, records, count, index_base, out_val, out_idx);
     return MI355_OK;
 }
+
+// all-gather + fence + combine of the sharded sum + argmax in one call (the product's lives in reduce.hip beside the combine kernel)
+MI355_API int32_t mi355_sum_argmax_exchange(mi355_ctx *ctx, mi355_comm *comm, mi355_stream stream, const void *record, void *gathered,
+                                            const uint64_t *index_base, float *out_sum, float *out_val, uint64_t *out_idx)
+{
+    MI355_REQUIRE_CTX(ctx);
+    if (!comm) return mi355::fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_sum_argmax_exchange: communicator is NULL (call mi355_comm_init)");
+    if (!record || !gathered) return mi355::fail(ctx, MI355_E_INVALID_ARGUMENT, "mi355_sum_argmax_exchange: NULL record buffer");
+    int32_t rc = mi355_all_gather(ctx, comm, stream, record, gathered, 2, MI355_DTYPE_U64);
+    if (rc == MI355_OK) rc = mi355_sync_collective(ctx, stream);
+    if (rc == MI355_OK) rc = mi355_sum_argmax_combine_f32(ctx, stream, gathered, (uint32_t)mi355::comm_world_size(comm), index_base, out_sum, out_val, out_idx);
+    return rc;
+}

@@ -16,7 +16,7 @@ def test_library_loads_and_exports_every_header_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/mi355cube.h but not exported"
     assert set(declared) == set(N.PROTOTYPES), set(declared) ^ set(N.PROTOTYPES)
-    assert lib.mi355_abi_version() == N.ABI_VERSION == 8
+    assert lib.mi355_abi_version() == N.ABI_VERSION == 9
 
 
 def test_struct_layouts_match_header():

@@ -78,6 +78,24 @@ for r in range(2):
     assert lib.mi355_all_gather(ctxs[r], comms[r], None, src[r], dst[r], 2, N.DTYPE_U64) == N.OK
     assert lib.mi355_sync_collective(ctxs[r], None) == N.OK
 assert waits() == w0, "a 32-byte all-gather must not fence"
+# ... but sync_collective keeps the reference's guarantee for ANY stream (crates/cubecl-cuda/src/compute/server.rs:782-797): a second
+# compute stream that asks is ordered behind the inline collective by an event; the stream that carried it needs nothing; a later
+# inline collective issued from the other stream waits for the first (a communicator never has work in flight on two streams)
+s2 = C.c_void_p(); assert lib.mi355_stream_create(ctxs[0], C.byref(s2)) == N.OK
+for r in range(2):
+    assert lib.mi355_all_gather(ctxs[r], comms[r], None, src[r], dst[r], 2, N.DTYPE_U64) == N.OK
+assert lib.mi355_sync_collective(ctxs[0], s2) == N.OK
+lib.faketest_stream_log(log)
+assert int(log[1]) == w0 + 1 and int(log[2]) == s2.value, "another stream is ordered behind an inline collective"
+assert lib.mi355_sync_collective(ctxs[0], None) == N.OK and waits() == w0 + 1, "the carrying stream needs no fence"
+assert lib.mi355_all_gather(ctxs[0], comms[0], s2, src[0], dst[0], 2, N.DTYPE_U64) == N.OK       # rank 0 from its second stream
+assert lib.mi355_all_gather(ctxs[1], comms[1], None, src[1], dst[1], 2, N.DTYPE_U64) == N.OK
+lib.faketest_stream_log(log)
+assert int(log[1]) == w0 + 2 and int(log[2]) == s2.value, "an inline collective on another stream waits for the previous one"
+assert lib.mi355_sync_collective(ctxs[0], s2) == N.OK and waits() == w0 + 2
+assert lib.mi355_stream_destroy(ctxs[0], s2) == N.OK                                            # (synchronizes: nothing left to fence)
+assert lib.mi355_sync_collective(ctxs[0], None) == N.OK and waits() == w0 + 2
+w0 = waits()
 big = [dev(ctxs[r], np.full(2048, r + 1.0, dtype=np.float32)) for r in range(2)]                 # 8 KiB
 for r in range(2):
     assert lib.mi355_all_reduce(ctxs[r], comms[r], None, big[r], big[r], 2048, N.DTYPE_F32, N.REDUCE_SUM) == N.OK

@@ -18,8 +18,11 @@ A = {name[len("GEMM_ALGO_"):]: value for name, value in vars(N).items() if name.
 
 # (what, (m, n, k, dtype_ab, dtype_c or None = same, trans_a, trans_b, batch), kernel, (A re-laid out, B re-laid out))
 TABLE = [
-    ("C3: 8192^3 bf16, the benchmark's headline: the 256^2 tile on 16x16x32 MFMAs (round 5)", (8192, 8192, 8192, BF, None, 0, 1, 1), "LP_256M16", (0, 0)),
-    ("three rounds of 256^2 tiles are not yet power-bound: the 32x32x16 kernel", (6144, 4096, 8192, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
+    ("C3: 8192^3 bf16, the benchmark's headline: the persistent dripped-store loop on 16x16x32 MFMAs (round 6; 1 466 -> 1 481 cold)", (8192, 8192, 8192, BF, None, 0, 1, 1), "LP_256QM", (0, 0)),
+    ("C3 with an f32 C: the one-tile-per-workgroup kernel on 16x16x32 MFMAs (round 5)", (8192, 8192, 8192, BF, F32, 0, 1, 1), "LP_256M16", (0, 0)),
+    ("ragged tiles, four rounds: the one-tile-per-workgroup 16x16x32 kernel", (8200, 8200, 8192, BF, None, 0, 1, 1), "LP_256M16", (0, 0)),
+    ("1.5 rounds of full 256^2 tiles, 16-bit C: the persistent 16x16x32 loop (round 6; until then the 32x32x16 kernel)", (6144, 4096, 8192, BF, None, 0, 1, 1), "LP_256QM", (0, 0)),
+    ("... with an f32 C, not yet power-bound: the 32x32x16 kernel", (6144, 4096, 8192, BF, F32, 0, 1, 1), "LP_256W4", (0, 0)),
     ("C3 with the reference's default rhs layout", (8192, 8192, 8192, BF, None, 0, 0, 1), "LP_256W4", (0, 0)),
     ("C2: 4096^3 f32", (4096, 4096, 4096, F32, F32, 0, 1, 1), "LP_256W4", (0, 0)),
     ("C2, row-major rhs", (4096, 4096, 4096, F32, F32, 0, 0, 1), "LP_256W4", (0, 0)),
@@ -34,10 +37,11 @@ TABLE = [
     ("f32, 64 columns", (8192, 64, 8192, F32, F32, 0, 1, 1), "STREAM64", (0, 0)),
     ("f32, 16 rows, K off the 64 grid: the 128x128 f32 tile", (16, 4096, 4000, F32, F32, 0, 1, 1), "F32_MFMA", (0, 0)),
     ("f32, 65 rows: the 128x128 f32 tile", (65, 4096, 4096, F32, F32, 0, 1, 1), "F32_MFMA", (0, 0)),
-    ("C5: 512 x 2048^3 bf16 on one GPU: dripped stores", (2048, 2048, 2048, BF, None, 0, 1, 512), "LP_256Q", (0, 0)),
+    ("C5: 512 x 2048^3 bf16 on one GPU: dripped stores on 16x16x32 MFMAs (round 6: 1 275 -> 1 340 TFLOP/s)", (2048, 2048, 2048, BF, None, 0, 1, 512), "LP_256QM", (0, 0)),
     ("C5 with an f32 C: the persistent kernel without them", (2048, 2048, 2048, BF, F32, 0, 1, 512), "LP_256P", (0, 0)),
     ("C5, row-major rhs", (2048, 2048, 2048, BF, None, 0, 0, 512), "LP_256Q", (0, 0)),
-    ("the 64-matrix shard of an 8-GPU C5", (2048, 2048, 2048, BF, None, 0, 1, 64), "LP_256Q", (0, 0)),
+    ("the 64-matrix shard of an 8-GPU C5", (2048, 2048, 2048, BF, None, 0, 1, 64), "LP_256QM", (0, 0)),
+    ("two rounds, K = 640: the same loop with four stores per K-tile (1 067 -> 1 083; lp256p 961)", (8192, 8192, 640, BF, None, 0, 1, 1), "LP_256QM", (0, 0)),
     ("GEMV", (1, 8192, 8192, BF, None, 0, 1, 1), "SKINNY", (0, 0)),
     ("GEMV against a row-major weight: the strip-streaming kernel, never transposed", (1, 8192, 8192, BF, None, 0, 0, 1), "NNROWS", (0, 0)),
     ("16 rows", (16, 8192, 8192, BF, None, 0, 1, 1), "STREAM64", (0, 0)),

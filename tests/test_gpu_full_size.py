@@ -137,7 +137,7 @@ def test_c3_bf16_8192_bf16_output_as_benched(client, oracle):
     b = TensorHandle.uniform(client, (S, S), ElemType.BF16, SEED, 200, -1.0, 1.0)        # stored [N][K]
     c = TensorHandle.new_contiguous((S, S), client.empty(S * S * 2), ElemType.BF16)
     d = _bench_desc(S, S, S, N.DTYPE_BF16, N.DTYPE_BF16)
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256M16
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256QM            # round 6: the persistent dripped-store loop on 16x16x32 MFMAs
     client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()),
                                           C.c_void_p(c.device_ptr())))
     got = c.to_numpy(client).reshape(S, S)
@@ -198,7 +198,7 @@ def test_c3_bf16_8192_row_major_rhs_is_native_and_bit_identical_to_the_k_contigu
     for d, b in ((_bench_desc(S, S, S, N.DTYPE_BF16, N.DTYPE_BF16), b_nk), (_nn_bench_desc(S, S, S, N.DTYPE_BF16, N.DTYPE_BF16), b_kn)):
         # (AUTO takes the 16x16x32 form of the tile for the K-contiguous rhs since round 5 -- another summation order; the
         # statement here is about the STAGING of the 32x32x16 kernel, so that kernel is named for the K-contiguous launch)
-        assert ops.gemm_select(client, d) == (N.GEMM_ALGO_LP_256M16 if d.trans_b else N.GEMM_ALGO_LP_256W4) and ops.gemm_relayout_plan(client, d) == (False, False)
+        assert ops.gemm_select(client, d) == (N.GEMM_ALGO_LP_256QM if d.trans_b else N.GEMM_ALGO_LP_256W4) and ops.gemm_relayout_plan(client, d) == (False, False)
         if d.trans_b:
             d.algo = N.GEMM_ALGO_LP_256W4
         c = TensorHandle.new_contiguous((S, S), client.empty(S * S * 2), ElemType.BF16)
@@ -223,7 +223,11 @@ def test_c5_batch64_2048_bf16_row_major_rhs_is_native(client, oracle):
     outs = []
     for d, b in ((_bench_desc(M, M, M, N.DTYPE_BF16, N.DTYPE_BF16, batch=B), b_nk), (_nn_bench_desc(M, M, M, N.DTYPE_BF16, N.DTYPE_BF16, batch=B), b_kn)):
         assert ops.gemm_relayout_plan(client, d) == (False, False)
-        assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256Q           # the dripped-store kernel, both layouts
+        # the dripped-store kernels: 16x16x32 form for the K-contiguous rhs since round 6 (another summation order), 32x32x16 form for the
+        # row-major rhs; the statement here is about the STAGING of the 32x32x16 kernel, so that kernel is named for the K-contiguous launch
+        assert ops.gemm_select(client, d) == (N.GEMM_ALGO_LP_256QM if d.trans_b else N.GEMM_ALGO_LP_256Q)
+        if d.trans_b:
+            d.algo = N.GEMM_ALGO_LP_256Q
         c = TensorHandle.new_contiguous((B, M, M), client.empty(B * M * M * 2), ElemType.BF16)
         client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()),
                                               C.c_void_p(c.device_ptr())))
@@ -242,7 +246,7 @@ def test_c5_batch64_2048_bf16_as_benched_takes_the_dripped_store_kernel(client, 
     b = TensorHandle.uniform(client, (B, M, M), ElemType.BF16, SEED, 600, -1.0, 1.0)
     c = TensorHandle.new_contiguous((B, M, M), client.empty(B * M * M * 2), ElemType.BF16)
     d = _bench_desc(M, M, M, N.DTYPE_BF16, N.DTYPE_BF16, batch=B)
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256Q       # the persistent kernel with dripped stores (gemm_lp256q.hip)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256QM      # the persistent kernel with dripped stores on 16x16x32 MFMAs (gemm_lp256qm.hip)
     client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()),
                                           C.c_void_p(c.device_ptr())))
     rows = np.array([0, 95, 96, 127, 128, 255, 256, 1023, 1024 + 129, 2047])   # held row blocks and the boundary block of a wave
@@ -255,9 +259,9 @@ def test_c5_batch64_2048_bf16_as_benched_takes_the_dripped_store_kernel(client, 
             dev = client.read_one(a.handle.offset_start_by(2 * bi * mm).offset_end_by(2 * (B - 1 - bi) * mm)).view(np.uint16)
             assert np.array_equal(dev, a_bits)
         _bf16_rows_check(oracle, a_bits, b_bits, got[rows], rows, M, M, case=f"C5 shard 64 x 2048^3 bf16 -> bf16 C, matrix {bi}, 10 sampled rows")
-    # the one-tile-per-workgroup kernel computes the same tiles bit for bit (same per-tile summation order)
+    # the one-tile-per-workgroup kernel on the same MFMA shape computes the same tiles bit for bit (same per-tile summation order)
     c2 = TensorHandle.new_contiguous((B, M, M), client.empty(B * M * M * 2), ElemType.BF16)
-    d.algo = N.GEMM_ALGO_LP_256W4
+    d.algo = N.GEMM_ALGO_LP_256M16
     client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()),
                                           C.c_void_p(c2.device_ptr())))
     for bi in (0, 17, 63):
@@ -285,7 +289,7 @@ def test_c5_batch512_2048_bf16_as_benched(client, oracle, layout):
     assert 2 * 256 * mm == 1 << 31 and 2 * B * mm == 1 << 32
     client._s.check(client.lib.mi355_memset(client.ctx, None, C.c_void_p(c.device_ptr()), 0xEE, B * mm * 2))
     d = (_nn_bench_desc if nn else _bench_desc)(M, M, M, N.DTYPE_BF16, N.DTYPE_BF16, batch=B)
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256Q
+    assert ops.gemm_select(client, d) == (N.GEMM_ALGO_LP_256Q if nn else N.GEMM_ALGO_LP_256QM)
     assert ops.gemm_relayout_plan(client, d) == (False, False)
     client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()),
                                           C.c_void_p(c.device_ptr())))
@@ -304,7 +308,7 @@ def test_c5_batch512_2048_bf16_as_benched(client, oracle, layout):
                          case=f"C5 as benched: 512 x 2048^3 bf16 -> bf16 C ({layout}), matrix {bi}, 10 sampled rows vs f64 oracle")
     # the one-tile-per-workgroup kernel on single matrices of the upper half: same per-tile summation order => same bits
     d1 = (_nn_bench_desc if nn else _bench_desc)(M, M, M, N.DTYPE_BF16, N.DTYPE_BF16, batch=1)
-    d1.algo = N.GEMM_ALGO_LP_256W4
+    d1.algo = N.GEMM_ALGO_LP_256W4 if nn else N.GEMM_ALGO_LP_256M16     # (the kernel with the persistent form's MFMA shape)
     c1 = TensorHandle.new_contiguous((M, M), client.empty(mm * 2), ElemType.BF16)
     for bi in (256, 511):
         off = 2 * bi * mm

@@ -939,16 +939,16 @@ def test_auto_selection_and_errors(client):
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_192X192         # round 5 256 tiles of 192^2 of the same kernel: another +25 %
     d = N.GemmDesc(m=8192, n=8192, k=8192, batch=1, lda=8192, ldb=8192, ldc=8192, dtype_ab=N.DTYPE_BF16,
                    dtype_c=N.DTYPE_BF16, trans_b=1)
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256M16          # four rounds at the power limit: the 16x16x32 form (round 5)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256QM           # four rounds at the power limit: the 16x16x32 form (round 5), persistent with dripped stores (round 6)
     # several rounds of short tiles: the persistent form (config C5's shard: 64 x 2048^3); long K or a single round: not
     d = N.GemmDesc(m=2048, n=2048, k=2048, batch=64, lda=2048, ldb=2048, ldc=2048, stride_a=2048 * 2048, stride_b=2048 * 2048,
                    stride_c=2048 * 2048, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_BF16, trans_b=1)
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256Q            # 16-bit C, K = 32 K-tiles: the dripped-store form of it
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256QM           # 16-bit C, K = 32 K-tiles: the dripped-store form of it (on 16x16x32 MFMAs since round 6)
     d.dtype_c = N.DTYPE_F32
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256P            # f32 C cannot be held in registers: the plain persistent form
     d.dtype_c = N.DTYPE_BF16
     d.k = d.lda = d.ldb = 640
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256P            # 10 K-tiles: measured slower with dripped stores
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256QM           # 10 K-tiles: four stores per K-tile (round 6; the 32x32x16 form measured slower than lp256p there)
     d.k = d.lda = d.ldb = 2048
     d.batch = 4
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
@@ -1403,7 +1403,7 @@ def test_output_bound_shapes_select_the_small_tile(client):
     assert sel(4096, 2304, 4096) == N.GEMM_ALGO_LP_256X192                            # 144 tiles of 256^2, 288 of 256 x 128 (two rounds), 192 of 256 x 192: the table's call
     assert sel(32, 512, 2048) == sel(512, 16, 2048) == sel(32, 6144, 8192) == N.GEMM_ALGO_STREAM64   # few workgroups are fine up to K = 2048; 192 at any K
     assert sel(32, 512, 8192) == sel(512, 16, 8192) == sel(16, 2048, 8192) == sel(32, 1024, 4096) == N.GEMM_ALGO_LP_128   # round 4: split-K instead
-    assert sel(8192, 4096, 512) == N.GEMM_ALGO_LP_256Q and sel(9216, 3072, 640) == N.GEMM_ALGO_LP_256P   # 512 / 432 tiles: persistent from one round up
+    assert sel(8192, 4096, 512) == sel(9216, 3072, 640) == N.GEMM_ALGO_LP_256QM      # 512 / 432 tiles: persistent from one round up (round 6: the 16x16x32 form at every drip rate)
     # (384 tiles at K = 512 ... 2048: the cost tables, multi-round down to K = 512 since late round 5, take 256 x 192 tiles -- within 5 % of the
     #  dripped-store form at K = 512, ahead from K = 1024: profiles/r05_persistent_vs_narrow_ab.txt)
     assert sel(8192, 3072, 512) == sel(8192, 3072, 2048) == N.GEMM_ALGO_LP_256X192

@@ -122,4 +122,4 @@ def test_the_draws_reach_the_kernels(client):
     print("kernels chosen over the draws:", sorted(chosen.items()))
     want = {N.GEMM_ALGO_GENERIC, N.GEMM_ALGO_F32_MFMA, N.GEMM_ALGO_LP_128, N.GEMM_ALGO_LP_256W4, N.GEMM_ALGO_SKINNY, N.GEMM_ALGO_STREAM64}
     assert want <= set(chosen), sorted(chosen.items())
-    assert set(chosen) & {N.GEMM_ALGO_LP_256P, N.GEMM_ALGO_LP_256Q, N.GEMM_ALGO_LP_256X128}, sorted(chosen.items())
+    assert set(chosen) & {N.GEMM_ALGO_LP_256P, N.GEMM_ALGO_LP_256Q, N.GEMM_ALGO_LP_256QM, N.GEMM_ALGO_LP_256X128}, sorted(chosen.items())

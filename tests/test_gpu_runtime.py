@@ -708,6 +708,11 @@ def test_all_reduce_and_to_client_across_devices_when_the_box_has_several(client
             ex.exchange_on_device(rec, starts, g_sum2, g_val, g_idx, mode="all_reduce")   # the reference's shape: all_reduce(Sum) + all-gather
             two = (float(c.read_one(g_sum2).view(np.float32)[0]), float(c.read_one(g_val).view(np.float32)[0]), int(c.read_one(g_idx).view(np.uint64)[0]))
             assert one[1:] == two[1:] and abs(one[0] - two[0]) <= 1e-6 * abs(one[0]), (one, two)
+            # the one-call form (mi355_sum_argmax_exchange, default since round 6) against the three calls it is made of: the same bits
+            g_sum3 = outs.offset_start_by(52).offset_end_by(8)
+            ex.exchange_on_device(rec, starts, g_sum3, g_val, g_idx, mode="gather3")
+            three = (float(c.read_one(g_sum3).view(np.float32)[0]), float(c.read_one(g_val).view(np.float32)[0]), int(c.read_one(g_idx).view(np.uint64)[0]))
+            assert one == three, (one, three)
             results[i] = (got, one[0], one[1], one[2], float(x.astype(np.float64).sum()))
         except BaseException as exc:  # noqa: BLE001
             errors.append(f"device {i}: {type(exc).__name__}: {exc}")

@@ -19,7 +19,7 @@ from cubecl_amd import _native as N  # noqa: E402
 
 VERBOSE = False
 NAMES = {"auto": 0, "generic": 1, "f32": 2, "lp128": 3, "lp256": 4, "lp256w4": 5, "lp256p": 6, "lp256q": 7, "skinny": 8, "stream64": 9,
-         "lp256x128": 10, "nnrows": 11, "lp256x192": 12, "lp192x192": 13, "lp256m16": 14}
+         "lp256x128": 10, "nnrows": 11, "lp256x192": 12, "lp192x192": 13, "lp256m16": 14, "lp256qm": 15}
 BY_ID = {v: k for k, v in NAMES.items()}
 
 

@@ -25,7 +25,7 @@ while len(shapes) < count:
     k = 64 * rng.choice([1, 2, 4, 8, 16, 24, 32, 48, 64, 96, 128, 224])
     if 2.0 * m * n * k > 3e12 or 2.0 * (m * k + n * k + m * n) > 1.2e9: continue
     shapes.append((m, n, k))
-ALGOS = ["auto", "lp128", "lp256x128", "lp256w4", "lp256p", "lp256q", "stream64", "skinny", "lp256x192", "lp192x192", "lp256m16"]
+ALGOS = ["auto", "lp128", "lp256x128", "lp256w4", "lp256p", "lp256q", "stream64", "skinny", "lp256x192", "lp192x192", "lp256m16", "lp256qm"]
 for nn in (False, True):
     algos = ALGOS + (["nnrows"] if nn else [])
     res = ab_algos.measure(cl, ev, shapes, algos, rounds=3, iters=10, nn=nn)
