@@ -1,4 +1,5 @@
-// gemm_stream64_f32.hip -- f32 GEMM with 9 ... 64 rows (or columns), both operands K-contiguous: C[m][n] = sum_k A[m][k] * B[n][k].
+// gemm_stream64_f32.hip -- f32 GEMM with 5 ... 64 rows (or columns; rule::F32_STREAM_MIN_ROWS in gemm.cpp -- it runs from one row up, the FMA kernel
+// is faster below five), both operands K-contiguous: C[m][n] = sum_k A[m][k] * B[n][k].
 // The f32 form of MI355_GEMM_ALGO_STREAM64 (round 5; until then these shapes ran on the 128x128 f32 tile: 16 x 8192 x 8192 150 us).
 //
 // Roofline: HBM up to 32 rows (the large operand, 256 MiB at 8192 x 8192, is read once), the f32 matrix core from there

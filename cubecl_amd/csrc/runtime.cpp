@@ -853,7 +853,8 @@ int32_t ticket_for_stream(mi355_ctx *ctx, hipStream_t s, unsigned int **out)
         else return fail(ctx, MI355_E_UNSUPPORTED, "reductions were issued on more than %u live streams of one context", SLOTS);
         it = ctx->ticket_slots.emplace(s, slot).first;
     }
-    if (ctx->capturing) ctx->capture_tickets.insert(it->second);      // becomes a pin when the capture ends
+    if (ctx->capturing && s == ctx->capture_stream) ctx->capture_tickets.insert(it->second);   // becomes a pin when the capture ends (the other
+                                                                                              // lanes run real work: nothing of theirs is a graph node)
     *out = reinterpret_cast<unsigned int *>(static_cast<char *>(ctx->ticket_buf) + (size_t)it->second * TICKET_SLOT_BYTES);
     return MI355_OK;
 }
@@ -898,6 +899,21 @@ struct mi355_graph {
     std::set<hipStream_t> streams;        // streams it was replayed on (waited for before the executable dies)
 };
 
+// A capture that fails pins nothing: slots handed out in its window go back to being ordinary -- and the slot of a stream that was
+// destroyed INSIDE the window (mi355_stream_destroy retired it because the window might have become a graph) returns to the free list
+// unless a live graph still carries it.  (Advisor, round 5: one of the 1 024 slots leaked per failed capture.)
+static void drop_capture_tickets(mi355_ctx *ctx)
+{
+    for (uint32_t t : ctx->capture_tickets) {
+        const auto pin = ctx->ticket_refs.find(t);
+        if (ctx->ticket_retired.count(t) && (pin == ctx->ticket_refs.end() || pin->second <= 0)) {
+            ctx->ticket_retired.erase(t);
+            ctx->ticket_free.push_back(t);
+        }
+    }
+    ctx->capture_tickets.clear();
+}
+
 MI355_API int32_t mi355_graph_begin_capture(mi355_ctx *ctx, mi355_stream stream)
 {
     MI355_REQUIRE_CTX(ctx);
@@ -929,7 +945,7 @@ MI355_API int32_t mi355_graph_end_capture(mi355_ctx *ctx, mi355_stream stream, m
         (void)hipGetLastError();
         pool_release_graph(ctx, id);          // nothing will ever replay: what the window pinned is free memory again
         ctx->capture_scratch.clear();
-        ctx->capture_tickets.clear();
+        drop_capture_tickets(ctx);
         return fail(ctx, MI355_E_EXECUTION, "hipStreamEndCapture: %s (an operation in the window was not capturable: "
                     "run the sequence once before capturing so that library scratch exists)", hipGetErrorString(e));
     }
@@ -938,7 +954,7 @@ MI355_API int32_t mi355_graph_end_capture(mi355_ctx *ctx, mi355_stream stream, m
         hipGraphDestroy(g);
         pool_release_graph(ctx, id);
         ctx->capture_scratch.clear();
-        ctx->capture_tickets.clear();
+        drop_capture_tickets(ctx);
         return fail(ctx, MI355_E_EXECUTION, "hipGraphInstantiate: %s", hipGetErrorString(e));
     }
     // From here on the graph owns a pin on every pool block allocated or freed in its window (pool.cpp keeps them out of

@@ -1210,6 +1210,42 @@ def test_matmul_add_f32_inside_the_256_kernel(client, oracle, dtype, m, n, k, ba
     assert np.array_equal(tc.to_numpy(client), got)
 
 
+def test_matmul_add_f32_stays_fused_where_auto_names_the_16x16x32_kernel(client, oracle):
+    """Advisor, round 5: AUTO's rule for gemm_lp256m16.hip took large [N][K] products with an f32 C off the fused epilogue -- a
+    4-bytes-per-output scratch product + an add pass, and MI355_E_UNSUPPORTED inside a capture window on a stream without that scratch.
+    mi355_gemm_add answers every form of the square tile with the plain kernel's fused epilogue: here inside a capture window on a fresh
+    stream (nothing may be allocated), in place, against the f64 oracle on sampled rows."""
+    import ctypes as C
+    lib, ctx, chk = client.lib, client.ctx, client._s.check
+    m = n = 8192
+    k = 4160                                                   # 1 024 tiles, 65 K-tiles: past the persistent forms, AUTO names the 16x16x32 kernel
+    a = TensorHandle.uniform(client, (m, k), ElemType.BF16, 1, 41, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (n, k), ElemType.BF16, 1, 42, -1.0, 1.0)
+    cacc = TensorHandle.uniform(client, (m, n), ElemType.F32, 1, 43, -8.0, 8.0)
+    c0 = cacc.to_numpy(client).reshape(m, n).copy()
+    d = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=k, ldc=n, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_F32, trans_b=1)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256M16
+    client.sync()
+    st = C.c_void_p()
+    chk(lib.mi355_stream_create(ctx, C.byref(st)))
+    chk(lib.mi355_graph_begin_capture(ctx, st))
+    chk(lib.mi355_gemm_add(ctx, st, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()), C.c_void_p(cacc.device_ptr()),
+                           C.c_void_p(cacc.device_ptr())))    # in place, no scratch: must not be refused
+    g = C.c_void_p()
+    chk(lib.mi355_graph_end_capture(ctx, st, C.byref(g)))
+    chk(lib.mi355_graph_replay(ctx, st, g))
+    chk(lib.mi355_sync(ctx, st))
+    got = cacc.to_numpy(client).reshape(m, n)
+    rows = np.array([0, 1, 127, 128, 255, 256, 4095, 4096, 8191, 5003])
+    A = oracle.from_bf16(a.to_numpy(client).reshape(m, k)[rows]).astype(np.float64)
+    Bm = oracle.from_bf16(b.to_numpy(client).reshape(n, k)).astype(np.float64).T
+    ref = A @ Bm + c0[rows].astype(np.float64)
+    bound = np.abs(A) @ np.abs(Bm) + np.abs(c0[rows]).astype(np.float64)
+    assert np.all(np.abs(got[rows].astype(np.float64) - ref) <= REL * bound + 1e-30)
+    chk(lib.mi355_graph_destroy(ctx, g))
+    chk(lib.mi355_stream_destroy(ctx, st))
+
+
 # ---- at most 16 rows against a row-major [K][N] weight: wide row strips, register transposition, 4x4x4 MFMA (gemm_nnrows.hip) -------
 # strip width by shape (plan_for): 16 x 8192 x 8192 -> 1024 B x 16 slices, x 4096 -> 512 B x 8, x 2048 -> 256 B x 4; one slice when the
 # strips alone fill the chip (N = 131072); K slices of 64 ... 8192 rows = every relation of the ring depth to the iteration count

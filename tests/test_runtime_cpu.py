@@ -455,6 +455,30 @@ def test_a_destroyed_stream_takes_its_library_scratch_and_its_ticket_slot_with_i
     assert pinned in got
     for s5 in live[-2:]:
         assert lib.mi355_stream_destroy(ctx, s5) == N.OK
+    # advisor, round 5: only the CAPTURE stream's slot is pinned by a window (another lane's reductions are real work, not graph nodes) ...
+    cap, other, nxt, g6 = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert lib.mi355_stream_create(ctx, C.byref(cap)) == N.OK and lib.faketest_ticket_slot(ctx, cap, C.byref(slot)) == N.OK
+    cap_slot = slot.value
+    assert lib.mi355_stream_create(ctx, C.byref(other)) == N.OK
+    assert lib.mi355_graph_begin_capture(ctx, cap) == N.OK
+    assert lib.faketest_ticket_slot(ctx, other, C.byref(slot)) == N.OK                 # a reduction on another lane while the window is open
+    other_slot = slot.value
+    assert lib.faketest_ticket_slot(ctx, cap, C.byref(slot)) == N.OK and slot.value == cap_slot
+    assert lib.mi355_stream_destroy(ctx, other) == N.OK
+    assert lib.mi355_stream_create(ctx, C.byref(nxt)) == N.OK and lib.faketest_ticket_slot(ctx, nxt, C.byref(slot)) == N.OK
+    assert slot.value == other_slot                              # not retired: free again at once
+    # ... and a capture that FAILS pins nothing: the window's slot stays an ordinary slot of its stream and goes back with it
+    lib.faketest_fail_end_capture(HIP_ERROR_INVALID_VALUE)
+    assert lib.mi355_graph_end_capture(ctx, cap, C.byref(g6)) == N.E_EXECUTION and not g6.value
+    assert lib.mi355_stream_destroy(ctx, cap) == N.OK and lib.mi355_stream_destroy(ctx, nxt) == N.OK
+    back = set()
+    for _ in range(2):
+        s7 = C.c_void_p()
+        assert lib.mi355_stream_create(ctx, C.byref(s7)) == N.OK and lib.faketest_ticket_slot(ctx, s7, C.byref(slot)) == N.OK
+        back.add(slot.value); live.append(s7)
+    assert back == {cap_slot, other_slot}                        # no slot leaked by the failed capture
+    for s7 in live[-2:]:
+        assert lib.mi355_stream_destroy(ctx, s7) == N.OK
     # the context's own streams are not the caller's to destroy
     own = C.c_void_p()
     assert lib.mi355_default_stream(ctx, C.byref(own)) == N.OK and lib.mi355_stream_destroy(ctx, own) == N.E_INVALID_ARGUMENT
