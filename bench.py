@@ -217,16 +217,17 @@ def usable_cores():
 # sha256 of the kernel's sources at the time of the pass (tools/pmc_all.sh) and bench.py prints the figure only when the
 # sources it is running from still hash to the same value (and the demangled kernel name is the one expected).
 KERNEL_SOURCES = {
-    "gemm": ("cubecl_amd/csrc/gemm_lp256m16.hip", "cubecl_amd/csrc/gemm_common.hpp", "cubecl_amd/csrc/internal.hpp"),
-    "gemm_q": ("cubecl_amd/csrc/gemm_lp256q.hip", "cubecl_amd/csrc/gemm_common.hpp", "cubecl_amd/csrc/internal.hpp"),
+    "gemm": ("cubecl_amd/csrc/gemm_lp256qm.hip", "cubecl_amd/csrc/gemm_common.hpp", "cubecl_amd/csrc/internal.hpp"),
+    "gemm_q": ("cubecl_amd/csrc/gemm_lp256qm.hip", "cubecl_amd/csrc/gemm_common.hpp", "cubecl_amd/csrc/internal.hpp"),
     "reduce": ("cubecl_amd/csrc/reduce.hip", "cubecl_amd/csrc/internal.hpp"),
 }
 PROFILES_DIR = ROOT / "profiles"
-HEADLINE_KERNEL = "gemm_lp256m16_kernel<1, 1>"     # bf16 x bf16 -> bf16 C, [N][K] B, on v_mfma_f32_16x16x32 (what rocprofv3 prints; until round 4:
-                                                   # gemm_lp256w4_kernel<1, 1, false, 1, false, false>)
-HEADLINE_ALGO = 14                                 # MI355_GEMM_ALGO_LP_256M16: what AUTO takes for config C3
+HEADLINE_KERNEL = "gemm_lp256qm_kernel<1, 1>"      # <bf16, one dripped store per K-tile>: bf16 x bf16 -> bf16 C, [N][K] B, persistent, on v_mfma_f32_16x16x32
+                                                   # (what rocprofv3 prints; round 5: gemm_lp256m16_kernel<1, 1>; until round 4: gemm_lp256w4_kernel<...>)
+HEADLINE_ALGO = 15                                 # MI355_GEMM_ALGO_LP_256QM: what AUTO takes for config C3 (round 6)
 REDUCE_SUM_KERNEL = "reduce_kernel<0, 0, 0>"      # <VOP = MI355_REDUCE_SUM, AOP = none, DT = f32> (until round 3: <true, false, 0>)
-C5_KERNEL = "gemm_lp256q_kernel<1, 1, false>"             # <bf16, one dripped store per K-tile, [N][K] B>: batch 512 x 2048^3
+C5_KERNEL = "gemm_lp256qm_kernel<1, 1>"            # the same instantiation on batch 512 x 2048^3 (32 K-tiles per tile; round 5: gemm_lp256q_kernel<1, 1, false>)
+C5_ALGO = 15
 
 
 def kernel_source_sha(kind):
@@ -281,7 +282,7 @@ def pmc_mfma_util_entry(size):
 
 
 ALGO_NAMES = {1: "generic", 2: "f32_mfma", 3: "lp128", 4: "lp256 (alias of lp256w4)", 5: "lp256w4", 6: "lp256p", 7: "lp256q", 8: "skinny", 9: "stream64",
-              10: "lp256x128", 11: "nnrows", 12: "lp256x192", 13: "lp192x192", 14: "lp256m16"}
+              10: "lp256x128", 11: "nnrows", 12: "lp256x192", 13: "lp192x192", 14: "lp256m16", 15: "lp256qm"}
 
 
 def gemm_desc(N, m, n, k, dtype_ab, dtype_c, trans_b=1, batch=1, algo=0):
@@ -425,14 +426,25 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     args.gpus = world
 
-    import torch
-    import torch.distributed as dist
+    # N = 1 never imports torch (review of round 5, weak #4): whichever libamdhip64 is mapped first serves the whole process by
+    # soname, and torch bundles its own (HIP 7.0) next to the /opt/rocm runtime (7.2) the library is built and tested against --
+    # the timings then came from another HIP stack than the parity evidence.  Device presence and the synchronisation of the
+    # contract's bracket come from the library (mi355_device_count; client.sync() = mi355_sync on the stream every kernel of this
+    # file is launched on); torch is loaded for N > 1 only, where the launcher's TCP store and the fallback process group are its.
+    torch = dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
 
     # BENCH_NO_TORCH_CUDA=1 (CPU test tier only, tests/test_bench_cpu.py): MI355CUBE_LIB then points at a test build of the host
     # runtime with stand-in kernels, so that the N > 1 control flow of this file -- rendezvous, native barrier / max-over-ranks,
     # the C4 exchange -- runs to completion on a box without a device.  Never set by the driver; such a run's figures mean nothing.
     fake = os.environ.get("BENCH_NO_TORCH_CUDA") == "1"
-    if not fake and not torch.cuda.is_available():
+    from cubecl_amd import _native as _N0
+    _lib0 = _N0.load()
+    _count = C.c_int32(0)
+    visible = int(_count.value) if _lib0.mi355_device_count(C.byref(_count)) == _N0.OK else 0
+    if not fake and visible < 1:
         raise SystemExit("bench.py needs a GPU (MI355X); none visible")
     # Rehearsal hooks (single-GPU pod only, never set by the driver): BENCH_FORCE_DEVICE puts every rank on one device and
     # BENCH_DIST_BACKEND=gloo replaces RCCL for torch's own collectives, so that the N > 1 control flow of this file can be
@@ -442,16 +454,22 @@ def main():
     if "BENCH_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
         dev_index = local_rank
-    elif not fake and torch.cuda.device_count() < world:
-        raise SystemExit(f"bench.py: {world} ranks asked for, {torch.cuda.device_count()} GPUs visible")
-    if not fake:
+    elif not fake and visible < world:
+        raise SystemExit(f"bench.py: {world} ranks asked for, {visible} GPUs visible")
+    if not fake and torch is not None:
         torch.cuda.set_device(local_rank)
     global THREAD_DEVICE
-    THREAD_DEVICE = None if fake else local_rank
+    THREAD_DEVICE = None if (fake or torch is None) else local_rank
 
     def device_sync():
-        if not fake:
+        # the contract's "torch.cuda.synchronize()".  N > 1: torch's own; N = 1: the library's stream synchronisation (all of this
+        # file's device work is queued on that stream) -- the same guarantee without a second HIP runtime in the process
+        if fake:
+            return
+        if torch is not None:
             torch.cuda.synchronize()
+        else:
+            client.sync()
 
     from cubecl_amd import DeviceId, ElemType, Mi355Runtime, TensorHandle, ops
     from cubecl_amd import _native as N
@@ -555,7 +573,7 @@ def main():
             last = cur
     client.sync()
     barrier()
-    device_sync()                        # torch.cuda.synchronize()
+    device_sync()                        # torch.cuda.synchronize() (N > 1) / client.sync() (N = 1)
     t0 = time.perf_counter()
     lib.mi355_probe_clock(ctx, None, p_clk0)
     ev.start()
@@ -599,18 +617,25 @@ def main():
                    "plateau_warmup_steps": plateau_steps,
                    "job_collectives": job.kind + (f" (native refused: {job.why})"[:160] if job.why and args.dist == "native" else ""),
                    "ms_per_step_before_closing_barrier": round(elapsed_own * 1e3 / args.steps, 4)},
+        # Key ORDER is part of the record: the driver keeps the first ~20 keys of this object, cut at 40 characters (review of round 5,
+        # weak #8) -- so the reduce half of the metric (C4), C5 and C2 sit right behind the GEMM's six, as short flat scalars, filled
+        # in by the extras further down (None = that extra did not run); everything else follows.
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(gemm_score.fraction_of_peak, 4), "traffic": (tr_ent or {}).get("hbm_bytes_per_launch"),
+                     "reduce_sum_achieved_GBs": None, "reduce_sum_frac": None, "reduce_sum_traffic": None, "reduce_sum_kernel_ms": None,
+                     "reduce_shard8_sum_us": None, "reduce_shard8_sum_frac": None, "reduce_shard8_fused_us": None, "reduce_shard8_fused_frac": None,
+                     "c4_8gpu_projected_us": None, "c5_whole_job_TFLOPs": None, "c5_frac": None, "c2_f32_frac": None,
+                     "kernel_ms": round(kernel_ms / args.steps, 4), "shader_clock_GHz": round(eff_clock_ghz, 3),
+                     "frac_of_peak_at_clock": round(achieved / (PEAK_BF16_TFLOPS * eff_clock_ghz / 2.4), 4),
+                     "mfma_util_pmc": (mu_ent or {}).get("mfma_util"),
                      "traffic_source": _pmc_source(tr_ent) if tr_ent else tr_why,
                      "algorithmic_bytes_per_launch": 3 * S * S * 2,
-                     "kernel_ms": round(kernel_ms / args.steps, 4), "flop_per_launch": flop,
-                     "mfma_util_pmc": (mu_ent or {}).get("mfma_util"),
+                     "flop_per_launch": flop,
                      "mfma_util_source": _pmc_source(mu_ent) if mu_ent else mu_why,
                      # the chip clocks down to its power budget on random operands (MI355X_MICROARCH.md "DVFS
                      # give-back"): the 2.5 PFLOP/s peak assumes 2.4 GHz; these two lines price the kernel
                      # against the matrix-pipe rate at the clock it actually ran at
-                     "shader_clock_GHz": round(eff_clock_ghz, 3),
-                     "frac_of_peak_at_clock": round(achieved / (PEAK_BF16_TFLOPS * eff_clock_ghz / 2.4), 4),
+                     # (shader_clock_GHz, frac_of_peak_at_clock: among the first keys above)
                      # shader cycles of one launch: what stays put between boxes whose sustained clocks differ (a rocprof summary taken
                      # on one box reconciles with a bench line of another through this product, review of round 4, next #4)
                      "kernel_ms_times_shader_clock_GHz": round(kernel_ms / args.steps * eff_clock_ghz, 4)},
@@ -627,6 +652,7 @@ def main():
     libs = mapped_libraries()
     for key in ("libamdhip64", "librccl"):          # which copies serve this process (flat strings: the driver's record keeps scalars)
         result["config"][key] = str(libs.get(key, "not mapped"))
+    result["config"]["torch_in_process"] = "torch" in sys.modules     # False at N = 1: one HIP runtime, the one the library is tested against
     extra, errors = {}, {}
     wanted = None if args.extras == "all" else set(args.extras.split(","))
 
@@ -699,10 +725,16 @@ def main():
                     "reference_loop_literal_max_rel": float((e_loop[solid] / np.abs(ref[solid])).max()),
                     "within_tolerance": bool(np.all(e_dev <= 1e-5 * bound))}
         if not fake:
+            # flat scalars: the driver's record of `config` keeps scalars only (review of round 5, weak #1)
             try:
-                result["config"]["parity"] = parity_of_this_run()
+                par = parity_of_this_run()
+                result["config"].update({"parity_reading": par["reading"], "parity_norm_max": par["device_max_err_over_sum_abs_products"],
+                                         "parity_literal_max": par["literal_max_rel"],
+                                         "parity_ref_loop_norm_max": par["reference_loop_max_err_over_sum_abs_products"],
+                                         "parity_ref_loop_literal_max": par["reference_loop_literal_max_rel"],
+                                         "parity_within_tolerance": par["within_tolerance"], "parity_sample": par["sample"]})
             except Exception as exc:  # noqa: BLE001
-                result["config"]["parity"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+                result["config"]["parity_error"] = f"{type(exc).__name__}: {exc}"[:200]
 
     # ------------------------------------------------------------------ extras ---------------------------
     if not args.no_extras:
@@ -889,7 +921,9 @@ def main():
                 result["roofline"].update({"reduce_shard_of_8_bytes": n_sh * 4, "reduce_shard_of_8_sum_us": sh["sum"]["back_to_back_us"],
                                            "reduce_shard_of_8_sum_frac": sh["sum"]["frac_of_8TBs"],
                                            "reduce_shard_of_8_fused_us": fused_us, "reduce_shard_of_8_fused_frac": sh["sum_argmax_fused"]["frac_of_8TBs"],
-                                           "reduce_shard_of_8_fused_per_sample_median_us": sh["sum_argmax_fused"]["per_sample_median_us"]})
+                                           "reduce_shard_of_8_fused_per_sample_median_us": sh["sum_argmax_fused"]["per_sample_median_us"],
+                                           "reduce_shard8_sum_us": sh["sum"]["back_to_back_us"], "reduce_shard8_sum_frac": sh["sum"]["frac_of_8TBs"],
+                                           "reduce_shard8_fused_us": fused_us, "reduce_shard8_fused_frac": sh["sum_argmax_fused"]["frac_of_8TBs"]})
 
                 def exchange_floor():
                     from cubecl_amd import sharded
@@ -922,7 +956,7 @@ def main():
                                                     "(one all-gather on a 1-rank communicator + combine kernel); the xGMI hop of a 16-byte record per peer is not in it")
                     result["roofline"].update({"reduce_exchange_one_rank_gather_us": out["gather_us"], "reduce_exchange_one_rank_two_collectives_us": out["all_reduce_us"],
                                                "reduce_shard_pass_plus_exchange_us": out["shard_pass_plus_exchange_us"],
-                                               "projected_c4_8gpu_us": round(proj, 2),
+                                               "projected_c4_8gpu_us": round(proj, 2), "c4_8gpu_projected_us": round(proj, 2),
                                                "projected_c4_8gpu_GBs_whole_job": round(n_total * 4 / proj / 1e3, 1)})
                 outcome = run_with_watchdog(exchange_floor, 120.0)
                 if outcome is not None:
@@ -1068,6 +1102,7 @@ def main():
                                            f"c2_f32_4096_{name}_frac": round(2.0 * M ** 3 / b2b / 1e9 / PEAK_F32_TFLOPS, 4),
                                            f"c2_f32_4096_{name}_frac_per_sample_median": round(tf / PEAK_F32_TFLOPS, 4)})
             result["roofline"]["c2_f32_peak_TFLOPs"] = PEAK_F32_TFLOPS
+            result["roofline"]["c2_f32_frac"] = result["roofline"]["c2_f32_4096_NT_frac"]
             return out
 
         def gemm_fp8():
@@ -1145,8 +1180,9 @@ def main():
             res.update({"batch_total": total, "sharding": f"sharded.shard_range({total}, rank, {world})",
                         "TFLOPs_total": round(tf_job, 1),
                         "frac_of_2.5PF_per_gpu_job": round(tf_job / world / PEAK_BF16_TFLOPS, 4)})
-            c5_ent, c5_why = _pmc_entry("pmc_traffic.json", "gemm_bf16_c5_batch512", "gemm_q", C5_KERNEL) if (world == 1 and res["algo"] == 7) else (None, "pass is for the 1-GPU job on lp256q")
+            c5_ent, c5_why = _pmc_entry("pmc_traffic.json", "gemm_bf16_c5_batch512", "gemm_q", C5_KERNEL) if (world == 1 and res["algo"] == C5_ALGO) else (None, "pass is for the 1-GPU job on lp256qm")
             result["roofline"].update({
+                "c5_whole_job_TFLOPs": round(tf_job, 1), "c5_frac": round(tf_job / world / PEAK_BF16_TFLOPS, 4),
                 "c5_batched_512x2048_achieved_TFLOPs_whole_job": round(tf_job, 1), "c5_batched_512x2048_frac": round(tf_job / world / PEAK_BF16_TFLOPS, 4),
                 "c5_batched_512x2048_kernel_ms": res["back_to_back_ms"], "c5_batched_512x2048_frac_per_sample_median": round(res["TFLOPs_per_gpu_per_sample_median"] / PEAK_BF16_TFLOPS, 4),
                 "c5_batched_512x2048_algorithmic_bytes": 3 * mine * M * M * 2,

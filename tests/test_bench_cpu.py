@@ -144,6 +144,35 @@ def test_two_rank_job_runs_to_completion_on_the_native_collectives_without_a_dev
     assert line["roofline"]["reduce_sum_argmax_exchange_ms"] > 0
 
 
+def test_one_gpu_line_is_torch_free_and_the_record_keeps_the_whole_metric():
+    """Review of round 5, weak #1 / #4 / #8 and next #4, on the fake runtime: the N = 1 path imports no torch (so the process maps ONE HIP
+    runtime, the /opt/rocm one the library is built and tested against, and `config.libamdhip64` says which); the driver's record of the
+    line keeps scalars of `config` and the first ~20 keys of `roofline` cut at 40 characters -- so the tolerance reading and the reduce
+    half of the metric (C4: 1 GiB sum, the 128 MiB shard, the projected 8-GPU job), C5 and C2 must be flat scalars among the first keys."""
+    so, rccl = _build_bench_libs()
+    n = 1 << 20
+    r = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-plateau-warmup", "--extras", "reduce_1GiB_f32",
+              "--reduce-elements", str(n)],
+             {"BENCH_NO_TORCH_CUDA": "1", "MI355CUBE_LIB": str(so), "MI355_RCCL_LIBRARY": str(rccl), "FAKE_HIP_DEVICES": "1", "OMP_NUM_THREADS": "1"},
+             timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and not line.get("extra_errors"), line.get("extra_errors")
+    assert line["config"]["torch_in_process"] is False
+    assert all(not isinstance(v, (dict, list)) for v in line["config"].values()), [k for k, v in line["config"].items() if isinstance(v, (dict, list))]
+    keys = list(line["roofline"])
+    assert keys[:6] == ["bound", "achieved", "peak", "unit", "frac", "traffic"]
+    want = ["reduce_sum_achieved_GBs", "reduce_sum_frac", "reduce_sum_traffic", "reduce_sum_kernel_ms", "reduce_shard8_sum_us", "reduce_shard8_sum_frac",
+            "reduce_shard8_fused_us", "reduce_shard8_fused_frac", "c4_8gpu_projected_us", "c5_whole_job_TFLOPs", "c5_frac", "c2_f32_frac"]
+    assert all(k in keys[:20] for k in want), keys[:24]
+    assert all(len(k) <= 40 for k in keys[:22]), [k for k in keys[:22] if len(k) > 40]
+    rf = line["roofline"]
+    assert rf["reduce_sum_achieved_GBs"] > 0 and rf["reduce_sum_frac"] > 0 and rf["reduce_shard8_fused_us"] > 0 and rf["reduce_shard8_sum_frac"] > 0
+    assert rf["c4_8gpu_projected_us"] > 0                       # shard pass + the exchange on a one-rank communicator (the RCCL stand-in here)
+    assert rf["c5_frac"] is None and rf["c2_f32_frac"] is None  # those extras were not asked for: present, in place, empty
+
+
 def test_threaded_single_process_model_runs_to_completion_without_a_device():
     """`python bench.py --threads 2`: the reference's own process model (one process, one host thread + one context per device:
     crates/cubecl-common/src/device/handle/channel.rs:24-37; one communicator joined from the device threads: crates/cubecl-cuda/
