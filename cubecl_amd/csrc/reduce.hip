@@ -157,11 +157,40 @@ template <int VOP> struct vop {
     static constexpr bool TRACKS_NAN = VOP == VOP_MAX || VOP == VOP_MIN;
 };
 
+// One step of the wave64 xor butterfly WITHOUT the LDS crossbar (round 6).  __shfl_xor is ds_bpermute_b32: ~130 cycles each, and the
+// folds below are chains of six of them -- two folds of the sum and two of {key, index, bits} stood for ~1.5 us of the 2.7 us between
+// the last byte of a 128 MiB fused pass and its result.  Step s pairs lane i with lane i ^ 2^s; every operation folded here is
+// symmetric (a + b, a * b, max, min bit for bit -- v_max / v_min order -0 below +0 -- and the (key, index) rule), so after step s all
+// lanes of a group of 2^(s+1) hold the same value and ANY lane of the partner group may stand for lane i ^ 2^s:
+//   steps 0, 1: quad-permute DPP (the exact partner); steps 2, 3: row_half_mirror / row_mirror DPP (a lane of the partner group);
+//   steps 4, 5: v_permlane16_swap / v_permlane32_swap of the value with itself: a = {rows 0,0,2,2} / {lower half twice},
+//   b = {rows 1,1,3,3} / {upper half twice} -- own and partner in one order or the other.
+// Returns (a, b) = the two values to combine: the same pairs as the xor butterfly of the reference's plane_reduce lowering
+// (crates/cubecl-cpp/src/shared/plane.rs:60-70), hence the same bits as rounds 1-5.
+template <int STEP>
+__device__ __forceinline__ void butterfly_pair(uint32_t v, uint32_t &a, uint32_t &b)
+{
+    if constexpr (STEP == 0) { a = v; b = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }          // quad_perm [1,0,3,2]
+    else if constexpr (STEP == 1) { a = v; b = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true); }     // quad_perm [2,3,0,1]
+    else if constexpr (STEP == 2) { a = v; b = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true); }    // row_half_mirror
+    else if constexpr (STEP == 3) { a = v; b = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true); }    // row_mirror
+    else if constexpr (STEP == 4) { const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); a = r[0]; b = r[1]; }
+    else { const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); a = r[0]; b = r[1]; }
+}
+
+template <int VOP, int STEP>
+__device__ __forceinline__ float wave_fold_step(float v)
+{
+    uint32_t a, b;
+    butterfly_pair<STEP>(__float_as_uint(v), a, b);
+    return vop<VOP>::apply(__uint_as_float(a), __uint_as_float(b));
+}
+
 template <int VOP>
 __device__ __forceinline__ float wave_fold(float v)
 {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) v = vop<VOP>::apply(v, __shfl_xor(v, off, 64));
+    v = wave_fold_step<VOP, 0>(v); v = wave_fold_step<VOP, 1>(v); v = wave_fold_step<VOP, 2>(v);
+    v = wave_fold_step<VOP, 3>(v); v = wave_fold_step<VOP, 4>(v); v = wave_fold_step<VOP, 5>(v);
     return v;
 }
 
@@ -183,15 +212,22 @@ __device__ __forceinline__ void arg_combine3(uint32_t &key, uint64_t &idx, uint3
     bits = take ? obits : bits;
 }
 
+template <int STEP>
+__device__ __forceinline__ void wave_argmax3_step(uint32_t &key, uint64_t &idx, uint32_t &bits)
+{
+    uint32_t ka, kb, ba, bb, la, lb, ha, hb;
+    butterfly_pair<STEP>(key, ka, kb);
+    butterfly_pair<STEP>(bits, ba, bb);
+    butterfly_pair<STEP>((uint32_t)idx, la, lb);
+    butterfly_pair<STEP>((uint32_t)(idx >> 32), ha, hb);
+    key = ka; bits = ba; idx = ((uint64_t)ha << 32) | la;
+    arg_combine3(key, idx, bits, kb, ((uint64_t)hb << 32) | lb, bb);        // (symmetric: larger key, then lower index; two lanes never tie on both)
+}
+
 __device__ __forceinline__ void wave_argmax3(uint32_t &key, uint64_t &idx, uint32_t &bits)
 {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t okey = __shfl_xor(key, off, 64), obits = __shfl_xor(bits, off, 64);
-        const uint32_t olo = __shfl_xor((uint32_t)idx, off, 64);
-        const uint32_t ohi = __shfl_xor((uint32_t)(idx >> 32), off, 64);
-        arg_combine3(key, idx, bits, okey, ((uint64_t)ohi << 32) | olo, obits);
-    }
+    wave_argmax3_step<0>(key, idx, bits); wave_argmax3_step<1>(key, idx, bits); wave_argmax3_step<2>(key, idx, bits);
+    wave_argmax3_step<3>(key, idx, bits); wave_argmax3_step<4>(key, idx, bits); wave_argmax3_step<5>(key, idx, bits);
 }
 
 __device__ __forceinline__ void wave_argmax(uint32_t &key, uint64_t &idx)
@@ -249,7 +285,43 @@ __device__ __forceinline__ bool arrive_is_last(unsigned int *ticket, uint32_t G)
     return __hip_atomic_fetch_add((gu32 *)ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1;
 }
 
-// Every workgroup folds its tiles into one record; the last one to arrive folds the G records.
+// Round 6: the hand-off WITHOUT tickets for grids of at most RED_POLL_MAX workgroups (the default grid: one per CU).  A ticket costs the
+// tail of a 128 MiB pass three dependent L2 round trips after a workgroup's last byte -- the record store must be acknowledged before
+// the ticket is taken (vmcnt(0)), the group ticket, the top ticket -- and then the folding workgroup loads the records: 2.6 us behind
+// an 18.3 us stream (profiles/r05_c4_shard.md).  Instead every workgroup stores its record as ONE 16-byte write-through store whose
+// last bit says "valid" and leaves; workgroup G - 1 -- dispatched last, so every other workgroup is running or done: it can wait
+// without holding anybody up -- polls the G records (thread t owns t, t + 256, ...: one 16-byte agent-scope load per poll), takes each
+// the moment its valid bit shows, puts the bit back to zero for the next call, and folds in index order as before: same tree, same
+// bits.  One store + one load round trip behind the last byte.  The records live in library-owned device scratch (the stream's
+// ticket slot, zero between calls like the tickets: a caller's workspace could hold anything).  A 16-byte aligned dwordx4 store /
+// load is one L2 transaction each, so a record is seen whole or not at all (stress: tests/test_gpu_reduce.py).
+constexpr uint32_t RED_POLL_WORD0 = 2560, RED_POLL_MAX = 384;           // words: bytes 10240 .. 16383 of the stream's 16 KiB slot
+constexpr uint64_t RED_VALID = 1ull << 63;                              // (indices stay below 2^63; an empty shard's ~0 carries the bit anyway)
+__device__ __forceinline__ void poll_record_store(red_record *slot, float sum, uint32_t key, uint64_t idx)
+{
+    const uint64_t tagged = idx | RED_VALID;
+    const u32x4r v = {__float_as_uint(sum), key, (uint32_t)tagged, (uint32_t)(tagged >> 32)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(slot), "v"(v) : "memory");
+}
+__device__ __forceinline__ red_record poll_record_take(red_record *slot)
+{
+    u32x4r v;
+    for (;;) {
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(slot) : "memory");
+        if (v[3] & 0x80000000u) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    typedef __attribute__((address_space(1))) unsigned long long gu64p;
+    __hip_atomic_store((gu64p *)((unsigned long long *)slot + 1), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // invalid again: ready for the next call
+    red_record r;
+    r.sum = __uint_as_float(v[0]);
+    r.key = v[1];
+    const uint64_t raw = ((uint64_t)v[3] << 32) | v[2];
+    r.idx = raw == ~0ull ? ~0ull : (raw & ~RED_VALID);
+    return r;
+}
+
+// Every workgroup folds its tiles into one record; the last one to arrive (tickets) / workgroup G - 1 (polling) folds the G records.
 //   in      : 16-byte aligned body of the array (host peels a misaligned head into `head`)
 //   head    : up to 3 leading elements (global indices 0..head_n-1), body index i maps to
 //             global index i + head_n
@@ -259,7 +331,7 @@ template <int VOP, int AOP, int DT = MI355_DTYPE_F32>
 __global__ void __launch_bounds__(RED_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 8)))   // one workgroup per CU is the grid (pick_grid): the whole register file is one wave's
 reduce_kernel(const typename red_in<DT>::elem *__restrict__ head, uint32_t head_n, const typename red_in<DT>::elem *__restrict__ in, uint64_t n,
               red_record *__restrict__ records, unsigned int *__restrict__ ticket, uint64_t n_total, float *__restrict__ out_sum, float *__restrict__ out_val, uint64_t *__restrict__ out_idx,
-              float mean_div, uint64_t rounds)
+              float mean_div, uint64_t rounds, uint32_t poll)
 {
     constexpr bool SUM = VOP != VOP_NONE, ARG = AOP != AOP_NONE;        // (SUM: "a value is folded", whatever the operation)
     static_assert(!(SUM && ARG) || (VOP == VOP_SUM && AOP == AOP_MAX), "fused pass: sum + argmax only");
@@ -271,6 +343,17 @@ reduce_kernel(const typename red_in<DT>::elem *__restrict__ head, uint32_t head_
     constexpr uint64_t ROW = (uint64_t)RED_BLOCK * EPV;                     // elements per 4 KiB row (one 16-byte load per lane)
     const uint32_t tid = threadIdx.x;
     const uint32_t G = gridDim.x;
+
+    // The first tile's loads are the first thing the kernel does (round 6): everything below -- accumulator set-up, the head, the deal of
+    // the remainder rows (two 32-bit divisions) -- runs while they are on their way instead of in front of them (first bytes of a cold
+    // 128 MiB pass: 2 us after the first workgroup's entry, of which ~0.8 us is the launch ramp of 256 workgroups).
+    u32x4r ra[RED_UNROLL], rb[RED_UNROLL];
+    if (rounds) {
+        const u32x4r *__restrict__ v0 = reinterpret_cast<const u32x4r *>(in) + (uint64_t)blockIdx.x * (RED_UNROLL * RED_BLOCK) + tid;
+#pragma unroll
+        for (int u = 0; u < RED_UNROLL; ++u) ra[u] = __builtin_nontemporal_load(v0 + (uint64_t)u * RED_BLOCK);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
     f32x4 acc[RED_UNROLL];
 #pragma unroll
@@ -368,6 +451,11 @@ reduce_kernel(const typename red_in<DT>::elem *__restrict__ head, uint32_t head_
     const uint32_t dealt = hi - lo;
     const uint64_t items = rounds + (dealt ? 1u : 0u);
     // item i: first vector of this lane and live rows (0 = no such item: its loads re-read item 0's first row)
+    // (Round 6, measured and dropped -- profiles/r06_shard_tile_rotation.txt, r06_shard_weighted_split.txt: the XCDs of a pass finish up to
+    //  5 us apart -- the odd XCD of every pair streams ~9 % slower, and the XCDs are started 0.1-1.2 us apart -- but neither rotating the
+    //  tile column by round (so that an XCD does not stay on one eighth of the channels) nor contiguous runs weighted 1000 : 915 against
+    //  the odd XCDs moved the pass: the XCDs then finish within 4 % of each other and the pass takes the same 22.7-23.2 us -- the early
+    //  finishers' bandwidth goes to the late ones, the array leaves HBM at ~7.3 TB/s either way -- and contiguous runs cost 1-3 % at 1 GiB.)
     auto item_base = [&](uint64_t i) -> uint64_t {
         return (i < rounds ? (i * G + blockIdx.x) * (uint64_t)RED_UNROLL : (i < items ? row0 + lo : (rounds ? (uint64_t)blockIdx.x * RED_UNROLL : row0 + lo))) * RED_BLOCK + tid;
     };
@@ -383,23 +471,25 @@ reduce_kernel(const typename red_in<DT>::elem *__restrict__ head, uint32_t head_
     };
     RED_STAMP(0);
     if (items) {
-        u32x4r ra[RED_UNROLL], rb[RED_UNROLL];
         uint64_t i = 0;
-        issue_any(ra, item_base(0), item_rows(0));
-        // steady state: items i, i + 1 and i + 2 are whole tiles.  (Not for the fused pass over 16-bit input: two unguarded
+        if (!rounds) issue_any(ra, item_base(0), item_rows(0));      // (with whole rounds item 0 is a whole tile and already on its way)
+        // steady state: items i and i + 1 are whole tiles.  (Not for the fused pass over 16-bit input: two unguarded
         // copies of its eight-element bodies beside the guarded one took 255 VGPRs and spilled; it runs every item through
         // the turn-by-turn loop below, which double-buffers too -- with 32 register copies per item.)
         // (Refilling each slot the moment it has been consumed -- 15-16 loads in flight instead of 8-16 -- measured SLOWER:
         // sum 24.6 against 23.4 us on the 128 MiB shard, fused 26.9 against 26.0; profiles/r05_c4_shard.md.)
         constexpr bool STEADY = !(SUM && ARG && EPV == 8);
-        for (; STEADY && i + 2 < rounds; i += 2) {
+        // (Round 6: the loop runs while items i and i + 1 are whole tiles and fetches item i + 2 with issue_any -- a whole tile, the dealt rows
+        // or nothing.  Until then it stopped while i + 2 was still whole and left the last two whole tiles -- an eighth of a 128 MiB shard -- to
+        // the guarded turn-by-turn loop below: 2.2 us from "whole rounds done" to "dealt rows done" on the fused pass.)
+        for (; STEADY && i + 1 < rounds; i += 2) {
             __builtin_amdgcn_sched_barrier(0);
             issue_whole(rb, item_base(i + 1));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < RED_UNROLL; ++u) { consume(std::false_type{}, true, ra[u], acc[u], (uint32_t)i * RED_UNROLL + u); if constexpr (EPV == 8) __builtin_amdgcn_sched_barrier(0); }
             __builtin_amdgcn_sched_barrier(0);
-            issue_whole(ra, item_base(i + 2));
+            issue_any(ra, item_base(i + 2), item_rows(i + 2));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < RED_UNROLL; ++u) { consume(std::false_type{}, true, rb[u], acc[u], (uint32_t)(i + 1) * RED_UNROLL + u); if constexpr (EPV == 8) __builtin_amdgcn_sched_barrier(0); }
@@ -490,11 +580,18 @@ reduce_kernel(const typename red_in<DT>::elem *__restrict__ head, uint32_t head_
             for (int w = 1; w < RED_BLOCK / 64; ++w) arg_combine3(rk, ri, rb, sh.key[w], sh.idx[w], sh.bits[w]);
             rk = rb;
         }
-        record_store(records + blockIdx.x, rs, rk, ri);            // write-through (sc1) 8-byte stores
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // ... drained before the ticket
-        RED_STAMP(3);
-        sh.last = arrive_is_last(ticket, G) ? 1u : 0u;
-        RED_STAMP(4);
+        if (poll) {                                                 // one 16-byte store with the valid bit, nothing to wait for
+            poll_record_store(reinterpret_cast<red_record *>(ticket + RED_POLL_WORD0) + blockIdx.x, rs, rk, ri);
+            RED_STAMP(3);
+            sh.last = blockIdx.x == G - 1 ? 1u : 0u;
+            RED_STAMP(4);
+        } else {
+            record_store(records + blockIdx.x, rs, rk, ri);        // write-through (sc1) 8-byte stores
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // ... drained before the ticket
+            RED_STAMP(3);
+            sh.last = arrive_is_last(ticket, G) ? 1u : 0u;
+            RED_STAMP(4);
+        }
     }
     __syncthreads();
     if (!sh.last) return;
@@ -504,7 +601,9 @@ reduce_kernel(const typename red_in<DT>::elem *__restrict__ head, uint32_t head_
     uint32_t key = 0u, bits = 0u;
     uint64_t idx = ~0ull;
     for (uint32_t gi = tid; gi < G; gi += RED_BLOCK) {
-        const red_record r = record_load(records + gi);            // sc1 loads: served by L2, never a stale L1 line
+        // polling: waits for the record's valid bit (and clears it); tickets: every record landed before the last ticket was taken
+        const red_record r = poll ? poll_record_take(reinterpret_cast<red_record *>(ticket + RED_POLL_WORD0) + gi)
+                                  : record_load(records + gi);     // sc1 loads: served by L2, never a stale L1 line
         if (SUM) facc = V::apply(facc, r.sum);
         if (NANS) key |= r.key;
         if (ARG) arg_combine3(key, idx, bits, r.idx == ~0ull ? 0u : arg_key<AOP>(__uint_as_float(r.key)), r.idx, r.key);
@@ -516,7 +615,7 @@ reduce_kernel(const typename red_in<DT>::elem *__restrict__ head, uint32_t head_
     __syncthreads();
     if (tid == 0) {
         typedef __attribute__((address_space(1))) unsigned int gu32;
-        __hip_atomic_store((gu32 *)ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
+        if (!poll) __hip_atomic_store((gu32 *)ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
         if (SUM && out_sum) {
             float total = V::apply(V::apply(sh.sum[0], sh.sum[1]), V::apply(sh.sum[2], sh.sum[3]));
             if (NANS && (sh.key[0] | sh.key[1] | sh.key[2] | sh.key[3])) total = __uint_as_float(0x7FC00000u);
@@ -585,8 +684,11 @@ int32_t run_reduce_t(mi355_ctx *ctx, mi355_stream stream, const void *in_v, uint
     const int32_t trc = ticket_for_stream(ctx, s, &ticket);
     if (trc != MI355_OK) return trc;
     const uint64_t rounds = body_n / ((uint64_t)RED_BLOCK * red_in<DT>::EPV) / ((uint64_t)G * RED_UNROLL);
+    // hand-off by polled records (library scratch) on grids that fit the slot, by tickets + the caller's workspace beyond (MI355_REDUCE_POLL=0: dev)
+    static const bool poll_ok = [] { const char *e = getenv("MI355_REDUCE_POLL"); return !e || atoi(e) != 0; }();
+    const uint32_t poll = (poll_ok && G <= RED_POLL_MAX) ? 1u : 0u;
     hipLaunchKernelGGL((reduce_kernel<VOP, AOP, DT>), dim3(G), dim3(RED_BLOCK), 0, s, in, head_n, body, body_n, records,
-                       ticket, n, out_sum, out_val, out_idx, mean_div, rounds);
+                       ticket, n, out_sum, out_val, out_idx, mean_div, rounds, poll);
     if (hipPeekAtLastError() != hipSuccess) ctx->tickets_dirty = true;   // a refused launch never resets its ticket
     check_launch(ctx, what);
     return MI355_OK;

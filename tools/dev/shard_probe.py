@@ -69,6 +69,14 @@ if hasattr(lib, "mi355_dev_red_trace"):
                 print(f"  {nm:28s} n={len(col):4d}  min {rel.min():6.0f}  p10 {np.percentile(rel, 10):6.0f}  median {np.median(rel):6.0f}  p90 {np.percentile(rel, 90):6.0f}  max {rel.max():6.0f}")
         done = t[:, 2] - t0
         print("  streaming done per XCD (workgroup index % 8): " + "  ".join(f"{x}: {np.median(done[x::8]):5.0f}/{done[x::8].max():5.0f}" for x in range(8)) + "   (median/max)")
+        ent = t[:, 0] - t0
+        dur = t[:, 2] - t[:, 0]
+        print("  entry per XCD (median/max):              " + "  ".join(f"{x}: {np.median(ent[x::8]):5.0f}/{ent[x::8].max():5.0f}" for x in range(8)))
+        print("  streaming duration per XCD (done - entry): " + "  ".join(f"{x}: {np.median(dur[x::8]):5.0f}/{dur[x::8].max():5.0f}" for x in range(8)))
+        order = np.arange(len(t)) // 8
+        print("  by dispatch order within the XCD (index / 8), quarters: entry " + "  ".join(f"{np.median(ent[(order >= 8 * i) & (order < 8 * i + 8)]):5.0f}" for i in range(4))
+              + "   duration " + "  ".join(f"{np.median(dur[(order >= 8 * i) & (order < 8 * i + 8)]):5.0f}" for i in range(4))
+              + "   done " + "  ".join(f"{np.median(done[(order >= 8 * i) & (order < 8 * i + 8)]):5.0f}" for i in range(4)))
         q = len(done) // 4
         print("  streaming done by quarter of the grid: " + "  ".join(f"{np.median(done[i * q:(i + 1) * q]):5.0f}" for i in range(4)))
         if prev is not None and len(prev) == len(done):
