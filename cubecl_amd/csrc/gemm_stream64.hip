@@ -345,7 +345,15 @@ __global__ void __launch_bounds__(512 + 64 * NLB, TWO ? (NLB == 2 ? 5 : 6) : (NL
 
     // ---- the four k-step partials meet in LDS (the ring is dead), added in wave order -----------------------------------
     __syncthreads();                                            // loaders have left; the four of us are done reading the ring
-    float *part = reinterpret_cast<float *>(smem);              // [wave][NB][MB][row 32][col 32], 4 x NB x MB x 4 KiB
+    // Row pitch 33 floats (round 6): with 32 the 32 lanes of a half-wave -- rows l31 = 0..31, the same column -- stored to addresses 128
+    // bytes apart = ONE bank, 32-way, 16 x NB x MB times per wave: rocprofv3 counted 3 712 conflict cycles per CU of the 64-row form's
+    // 8 778 LDS-array cycles (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.42; 0.17 on the 32-row form), every one of them here -- the
+    // K loop's fragment reads are conflict free (profiles/r06_stream64_pmc.txt).
+#ifndef S64_PART_PITCH
+#define S64_PART_PITCH 33
+#endif
+    constexpr int PP = S64_PART_PITCH;
+    float *part = reinterpret_cast<float *>(smem);              // [wave][NB][MB][row 32][pitch 33], 4 x NB x MB x 4.1 KiB
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -354,13 +362,13 @@ __global__ void __launch_bounds__(512 + 64 * NLB, TWO ? (NLB == 2 ? 5 : 6) : (NL
             for (int qd = 0; qd < 4; ++qd)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    part[(((w * NB + nb) * MB + i) * 32 + l31) * 32 + 8 * qd + 4 * h + r] = acc[nb][i][4 * qd + r];   // lane (l31, h): row l31, cols 8 qd + 4 h + r
+                    part[(((w * NB + nb) * MB + i) * 32 + l31) * PP + 8 * qd + 4 * h + r] = acc[nb][i][4 * qd + r];   // lane (l31, h): row l31, cols 8 qd + 4 h + r
     __syncthreads();
     char *out = static_cast<char *>(g.out);
     auto wave_sum = [&](int blk, int row, int col) {             // the four k-step partials of one element, in wave order
-        float v = part[((0 * NB * MB + blk) * 32 + row) * 32 + col];
+        float v = part[((0 * NB * MB + blk) * 32 + row) * PP + col];
 #pragma unroll
-        for (int ww = 1; ww < 4; ++ww) v += part[((ww * NB * MB + blk) * 32 + row) * 32 + col];
+        for (int ww = 1; ww < 4; ++ww) v += part[((ww * NB * MB + blk) * 32 + row) * PP + col];
         return v;
     };
     auto store_out = [&](int64_t sm, int64_t bg, float v) {

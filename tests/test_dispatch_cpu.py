@@ -108,6 +108,9 @@ TABLE = [
     ("32 rows on 64 streaming workgroups walking K = 8192: split-K instead", (32, 2048, 8192, BF, None, 0, 1, 1), "LP_128", (0, 0)),
     ("32 rows, one streaming workgroup per CU, K = 16384: streams", (32, 8192, 16384, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
     ("64 rows, more streaming workgroups than CUs", (64, 10240, 4096, BF, None, 0, 1, 1), "LP_128", (0, 0)),
+    ("64 rows, K = 16384 on one streaming workgroup per CU: streams (round 6: 48.9 us / 61.9 on split-K)", (64, 8192, 16384, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
+    ("... K = 14336: split-K (44.3 / 47.9)", (64, 8192, 14336, BF, None, 0, 1, 1), "LP_128", (0, 0)),
+    ("... 288 workgroups at K = 16384: split-K (66.2 / 107.4)", (64, 9216, 16384, BF, None, 0, 1, 1), "LP_128", (0, 0)),
     ("23 columns, K = 3072, any grid: streams (few columns are not few rows)", (37824, 23, 3072, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
     ("24 columns, K past 8192: split-K", (9312, 24, 14336, BF, None, 0, 1, 1), "LP_128", (0, 0)),
     ("20 rows whose 128-column tiles would fill a second round by a quarter: streams", (20, 40096, 8192, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
