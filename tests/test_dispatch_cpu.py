@@ -73,7 +73,8 @@ TABLE = [
     ("row-major rhs, one 128^2 tile per CU (23.2 us against 24.8 on 192^2)", (2048, 2048, 2048, BF, None, 0, 0, 1), "LP_128", (0, 0)),
     ("row-major rhs, 196 tiles of 256^2", (3584, 3584, 3584, F16, None, 0, 0, 1), "LP_256W4", (0, 0)),
     ("row-major rhs, tall: 128 tiles of 256 x 192 (65.7 us against 68.4 on the 256 x 128 tile)", (8192, 1024, 4096, BF, None, 0, 0, 1), "LP_256X192", (0, 0)),
-    ("one round of 256^2 tiles", (4096, 4096, 4096, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
+    ("exactly one full round of 256^2 tiles: every CU busy, the 16x16x32 form (round 6: 103.6 -> 98.1 us)", (4096, 4096, 4096, BF, None, 0, 1, 1), "LP_256M16", (0, 0)),
+    ("... with a row-major rhs: the 32x32x16 kernel", (4096, 4096, 4096, BF, None, 0, 0, 1), "LP_256W4", (0, 0)),
     ("288 tiles of 256^2, long K: the square tile with its leftover strip split along K (240.9 us; 256 x 192 265.0)", (4608, 4096, 8192, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
     ("272 tiles of 256^2 at K = 4096: the split form loses to two rounds of 192^2 (130.9 / 122.8)", (4352, 4096, 4096, BF, None, 0, 1, 1), "LP_192X192", (0, 0)),
     ("576 tiles of 256^2: 2.7 rounds of 256 x 192 tiles (344.5 us) beat the square tile with its leftover strip split (360.0)", (6144, 6144, 6144, BF, None, 0, 1, 1), "LP_256X192", (0, 0)),

@@ -1433,7 +1433,7 @@ def test_output_bound_shapes_select_the_small_tile(client):
     # operands past 512 x 512 up to one round of the square tile: one round of 192 x 192 tiles takes most of that band, 256 x 192
     # tiles where those would need a second round
     assert sel(4096, 2048, 4096) == sel(2560, 2560, 3072) == sel(2048, 3072, 8192) == sel(4096, 1536, 8192) == sel(3072, 3072, 3072) == sel(2304, 2304, 2304) == N.GEMM_ALGO_LP_192X192
-    assert sel(4096, 3072, 4096) == sel(3328, 3328, 4096) == N.GEMM_ALGO_LP_256X192 and sel(3584, 3584, 3584) == sel(4096, 4096, 4096) == N.GEMM_ALGO_LP_256W4
+    assert sel(4096, 3072, 4096) == sel(3328, 3328, 4096) == N.GEMM_ALGO_LP_256X192 and sel(3584, 3584, 3584) == N.GEMM_ALGO_LP_256W4 and sel(4096, 4096, 4096) == N.GEMM_ALGO_LP_256M16   # (one FULL round: the 16x16x32 form, round 6)
     assert sel(2048, 2048, 8192) == N.GEMM_ALGO_LP_128                                  # one 128x128 tile per CU (121 tiles of 192^2: too few)
     assert sel(4096, 2048, 2048) == sel(3072, 2560, 1024) == N.GEMM_ALGO_LP_192X192       # round 5 (were the 128x128 kernel's: 1059 / 781, 918 / 693 TFLOP/s)
     assert sel(4096, 2304, 4096) == N.GEMM_ALGO_LP_256X192                            # 144 tiles of 256^2, 288 of 256 x 128 (two rounds), 192 of 256 x 192: the table's call
@@ -1443,7 +1443,7 @@ def test_output_bound_shapes_select_the_small_tile(client):
     # (384 tiles at K = 512 ... 2048: the cost tables, multi-round down to K = 512 since late round 5, take 256 x 192 tiles -- within 5 % of the
     #  dripped-store form at K = 512, ahead from K = 1024: profiles/r05_persistent_vs_narrow_ab.txt)
     assert sel(8192, 3072, 512) == sel(8192, 3072, 2048) == N.GEMM_ALGO_LP_256X192
-    assert sel(4096, 4096, 512) == N.GEMM_ALGO_LP_256W4                               # exactly one round: the plain kernel
+    assert sel(4096, 4096, 512) == N.GEMM_ALGO_LP_256M16                              # exactly one full round: the plain (one tile per workgroup) kernel on 16x16x32 MFMAs
 
 
 # ---- 3 ... 64 rows or columns: the no-split-K streaming kernel with loader waves (gemm_stream64.hip) -------------------------

@@ -4,11 +4,10 @@
 where one of them is wrong, the symptom used to be a slower bench entry and nothing else.  This test times AUTO against EVERY
 kernel that accepts the descriptor over a fixed grid of 60 bf16 shapes -- the bench's skinny / output-bound / mid-size / decode
 shapes among them -- interleaved, three rounds, medians, cold operands (launches rotate through operand sets larger than the
-Infinity Cache), and fails when AUTO is more than 15 % AND more than 3 us behind the best forced kernel on any shape (3 us: launches
-of 8-15 us carry about +-1 us of launch-to-launch noise per kernel; the bar was 2 us until the last evidence call of round 3, where the
-closest case -- 48 x 4096 x 4096, AUTO 14.3 us on the streaming kernel against 12.7 on the 128x128 kernel since its 64 x 128 tile --
-stood at 1.6 us: a known 12 % that DESIGN.md section 7 lists, not noise to fail a run on).  The full table goes to
-gpurun_out/select_audit.txt."""
+Infinity Cache), and fails when AUTO is more than 10 % AND more than 2 us behind the best forced kernel on any shape (round 6, review of
+round 5 next #8: the bar was 15 % + 3 us, wide enough to hide a wrong kernel on every launch under 20 us; 2 us: launches of 8-15 us carry
+about +-1 us of launch-to-launch noise per kernel, and a suspect is re-measured over seven longer rounds before it counts).  The full
+table goes to gpurun_out/select_audit.txt."""
 import os
 import sys
 from pathlib import Path
@@ -39,7 +38,7 @@ GRID = [
     (4672, 7360, 3072), (6144, 6144, 1024), (3520, 10112, 512), (128, 16384, 512), (16384, 104, 1024), (116, 40960, 2048), (29512, 32, 128),
     (5, 53432, 1024),
 ]
-ALGOS = ["auto", "lp128", "lp256x128", "lp256w4", "lp256p", "lp256q", "stream64", "skinny", "lp256x192", "lp192x192", "lp256m16"]
+ALGOS = ["auto", "lp128", "lp256x128", "lp256w4", "lp256p", "lp256q", "stream64", "skinny", "lp256x192", "lp192x192", "lp256m16", "lp256qm"]
 # few rows against a ROW-MAJOR [K][N] weight (review of round 3, next #6): the rhs layout TensorHandle::new_contiguous gives
 GRID_NN = [(1, 8192, 8192), (4, 8192, 8192), (8, 8192, 8192), (16, 8192, 8192), (4, 4096, 4096), (4, 14336, 4096), (4, 4096, 14336),
            (16, 4096, 14336), (16, 28672, 8192), (4, 32000, 4096), (1, 128256, 4096), (16, 128256, 4096), (32, 8192, 8192), (16, 14336, 4096),
@@ -49,9 +48,10 @@ ALGOS_NN = ["auto", "lp128", "nnrows"]
 GRID_F32 = [(1, 8192, 8192), (4, 8192, 8192), (8, 8192, 8192), (16, 8192, 8192), (32, 4096, 4096), (64, 8192, 8192), (16, 28672, 4096),
             (4096, 32, 4096), (16, 1024, 1024), (8192, 8, 8192), (128, 4096, 4096)]
 ALGOS_F32 = ["auto", "f32", "skinny", "stream64"]
+BAR_RATIO, BAR_US = 1.10, 2.0
 
 
-def test_auto_is_within_15_percent_of_the_best_forced_kernel_on_every_shape_of_the_grid(client):
+def test_auto_is_within_10_percent_of_the_best_forced_kernel_on_every_shape_of_the_grid(client):
     audit(client, GRID, ALGOS, False, "select_audit.txt")
 
 
@@ -74,7 +74,7 @@ def audit(client, grid, algos, nn, log_name, f32=False):
     def is_behind(r):
         us = {a: t for a, t in r["us"].items() if t == t}
         best = min(t for a, t in us.items() if a != "auto")
-        return us["auto"] / best > 1.15 and us["auto"] - best > 3.0
+        return us["auto"] / best > BAR_RATIO and us["auto"] - best > BAR_US
     # a shape that looks behind is measured once more, longer, before it counts (a 20 us launch beside a DVFS step is noisy)
     suspects = [shape for shape, r in res.items() if is_behind(r)]
     if suspects:
@@ -85,7 +85,7 @@ def audit(client, grid, algos, nn, log_name, f32=False):
         best_algo, best = min(((a, t) for a, t in us.items() if a != "auto"), key=lambda x: x[1])
         auto = us["auto"]
         ratio = auto / best
-        flag = ratio > 1.15 and auto - best > 3.0
+        flag = ratio > BAR_RATIO and auto - best > BAR_US
         lines.append(f"{m}x{n}x{k}: AUTO -> {r['auto']:9s} {auto:8.1f} us   best forced {best_algo:9s} {best:8.1f} us   x{ratio:.3f}"
                      + ("   <-- BEHIND" if flag else "") + "   | " + "  ".join(f"{a} {t:.1f}" for a, t in us.items() if a != "auto"))
         if flag:
@@ -97,4 +97,4 @@ def audit(client, grid, algos, nn, log_name, f32=False):
     except OSError:
         pass
     print("\n".join(lines))
-    assert not behind, "AUTO is more than 15 % (and 3 us) behind a forced kernel:\n" + "\n".join(behind)
+    assert not behind, f"AUTO is more than {BAR_RATIO - 1:.0%} (and {BAR_US} us) behind a forced kernel:\n" + "\n".join(behind)
