@@ -100,15 +100,17 @@ def test_hot_gemm_kernels_do_not_spill_and_pad_their_asm_hazards():
         hazards[name] = hazard_scan.scan_text(out)
         return [(name, k, int(s), int(v)) for k, s, v in found]
     with ThreadPoolExecutor(max_workers=4) as pool:
-        rows = [r for rs in pool.map(spills, ["gemm_lp256w4.hip", "gemm_lp256p.hip", "gemm_lp256q.hip", "gemm_lp128.hip", "reduce.hip",
-                                              "copy_strided.hip", "gemm_stream64.hip", "gemm_skinny.hip"]) for r in rs]
-    assert len(rows) >= 48
+        rows = [r for rs in pool.map(spills, ["gemm_lp256w4.hip", "gemm_lp256p.hip", "gemm_lp256q.hip", "gemm_lp256qm.hip", "gemm_lp256m16.hip", "gemm_lp128.hip",
+                                              "reduce.hip", "copy_strided.hip", "gemm_stream64.hip", "gemm_skinny.hip"]) for r in rs]
+    assert len(rows) >= 60
     # gemm_lp256q.hip holds a finished tile in 96 registers beside the K loop: the compiler parks a few SCALAR registers in
     # the lanes of a vector register (v_writelane / v_readlane, outside the K-tile bodies) -- no memory traffic, tolerated;
     # a vector-register spill (scratch memory, and an s_waitcnt vmcnt(0) per reload that drains the LDS-DMA stream) never is
     # (round 3: its row-major-B instantiations carry two more 64-bit scalars -- 36-38 parked registers; the K-tile bodies hold
     # the same four v_readlane as the [N][K] ones)
-    bad = [r for r in rows if r[3] or (r[2] and "lp256q" not in r[1]) or r[2] > 40]
+    # (round 6: gemm_lp256qm.hip, the same structure on 16x16x32 MFMAs, parks 25-43; the index reductions over 16-bit input in reduce.hip
+    # park two scalars since the polled hand-off added a kernel argument -- outside their streaming loops)
+    bad = [r for r in rows if r[3] or (r[2] and "lp256q" not in r[1] and not ("reduce_kernel" in r[1] and r[2] <= 4)) or r[2] > (48 if "lp256qm" in r[1] else 40)]
     assert not bad, bad
     assert not any(hazards.values()), {k: v for k, v in hazards.items() if v}
 

@@ -9,7 +9,7 @@
 #     3. --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE   headline GEMM     mfma_util = (busy / 1024 SIMDs) / (active / 8 XCDs)
 #     4. --pmc FETCH_SIZE          1 GiB reductions (tools/reduce_probe.py)
 #     5. --pmc TCC_HIT_sum TCC_MISS_sum                   headline GEMM     L2 hit rate
-#     6-9. the same four on config C5 as benched at N = 1 (tools/c5_probe.py: batch 512 x 2048^3 bf16, gemm_lp256q.hip), round 4
+#     6-9. the same four on config C5 as benched at N = 1 (tools/c5_probe.py: batch 512 x 2048^3 bf16; gemm_lp256qm.hip since round 6)
 # Only --kernel-trace accompanies --pmc (gpurun refuses --pmc with the sys / hip / hsa trace domains).
 # Writes gpurun_out/pmc_traffic.json and gpurun_out/pmc_mfma_util.json (copy both to profiles/).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -80,7 +80,7 @@ for k, v in agg.items():
     else: continue
     traffic[f"reduce_1GiB_{name}"] = dict(stamp, kernel=k[:120], source_sha=bench.kernel_source_sha("reduce"),
         fetch_bytes=int(statistics.median(v) * 1024 * 2), algorithmic_bytes=1 << 30, FETCH_SIZE_KiB_raw=statistics.median(v), launches=len(v))
-# config C5 as benched (batch 512 x 2048^3 bf16 on the persistent dripped-store kernel)
+# config C5 as benched (batch 512 x 2048^3 bf16 on the persistent dripped-store kernel, 16x16x32 MFMAs)
 KQ = bench.C5_KERNEL
 f5, n5 = med(rows_of("c5_fetch"), "FETCH_SIZE", KQ)
 w5, _ = med(rows_of("c5_write"), "WRITE_SIZE", KQ)
@@ -97,7 +97,7 @@ if f5 is not None and w5 is not None:
     a5, _ = med(rows_of("c5_mfma"), "GRBM_GUI_ACTIVE", KQ)
     if b5 and a5:
         ent.update(SQ_VALU_MFMA_BUSY_CYCLES=b5, GRBM_GUI_ACTIVE=a5, mfma_util=round((b5 / 1024) / (a5 / 8), 4),
-                   expected_busy_cycles_32_per_mfma=32 * 512 * 2048 ** 3 / (32 * 32 * 16))
+                   expected_busy_cycles_16_per_mfma=16 * 512 * 2048 ** 3 / (16 * 16 * 32))
     traffic["gemm_bf16_c5_batch512"] = ent
 else:
     print("!! no C5 rows in the FETCH_SIZE / WRITE_SIZE passes")
