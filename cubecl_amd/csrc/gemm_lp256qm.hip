@@ -119,22 +119,39 @@ __device__ __forceinline__ uint32_t opaque(uint32_t x) { asm volatile("" : "+v"(
 //   k-step 1 (the next k-step's operands are K-tile t + 1's: nothing before the hand-over behind MFMA 15): A 0, A 1 behind MFMAs 16, 18;
 //     B j behind 17 + 4 j; A i (i >= 2) behind 8 i + 7.
 // DMA pieces sit behind MFMAs 3, 11 (mod 16) and, in the last quarter of k-step 1, behind 49, 53, 57, 61: no slot carries two.
-constexpr int qm_read_at(int ks, int n)
+// Row-major B (bnn): a B fragment is TWO transposing reads -- ids 0..7 = its k 0-3 half, 16..23 = its k 4-7 half, one MFMA slot each (two reads
+// behind one MFMA cost the K loop 5 % at the clock: profiles/r06_qm_nn_ab.txt): the second half one slot behind the first, A 1 behind MFMA 20.
+constexpr int qm_read_at(int ks, int n, bool bnn)
 {
     if (ks == 0) {
         if ((n & 3) == 1 && n < 32) return n >> 2;
+        if (bnn && (n & 3) == 2 && n < 32) return 16 + (n >> 2);
         if ((n & 7) == 7) return 8 + (n >> 3);
         return -1;
     }
     if (n == 16) return 8;
-    if (n == 18) return 9;
+    if (n == (bnn ? 20 : 18)) return 9;
     if (n >= 17 && n < 49 && ((n - 17) & 3) == 0) return (n - 17) >> 2;
+    if (bnn && n >= 18 && n < 50 && ((n - 18) & 3) == 0) return 16 + ((n - 18) >> 2);
     if (n >= 23 && (n & 7) == 7) return 8 + (n >> 3);
     return -1;
 }
 
+// BNN (round 6): B row-major [K][N], the layout TensorHandle::new_contiguous gives a rhs (crates/cubecl-std/src/tensor/handle.rs:89).
+//   The matrix core wants, per lane (l15, g), the eight k-values 32 s + 8 g .. + 7 of ONE column 16 j + l15: two ds_read_b64_tr_b16 (k 0-3 and
+//   4-7), each of which transposes, per 16-lane group, a [4 k][16 n] block whose sixteen 8-byte pieces the lanes address themselves (lane i: row
+//   i / 4, columns 4 (i % 4) .. + 3) -- gemm_lp256w4.hip "BNN, bf16 / f16".  Image of a K-tile: 128 blocks of [4 k][32 n] = 256 contiguous bytes,
+//   block (a, b) = k-rows 4 a .. + 3 x columns 32 b .. + 31 at (8 a + b) * 256, row i of it at + 64 i, as there -- EXCEPT that the two 32-byte
+//   halves of a block's rows are swapped where (a >> 1) is odd.  On the 32x32x16 shape the 32 lanes of a half-wave read the two column halves
+//   of one block (one whole 256-byte bank row); here they are the groups g = 0, 1: the SAME column half of two blocks 512 bytes apart -- a
+//   2-way bank conflict on every read -- and with the swap (a >> 1 = 4 s + g) the two groups take opposite halves of the bank row.  The swap
+//   costs nothing: LDS-DMA writes lane-linear but reads any per-lane address (two lane-offset registers, one per swap state).
+//   Output: the MFMA columns keep their natural order (a DMA lane moves 16 contiguous bytes: the column permutation of the [N][K] form is not
+//   available), so the held tile's packed words of column blocks 2 jj, 2 jj + 1 meet through two v_permlane16_swap per pair: lane (l15, g)
+//   then holds columns 16 (2 jj + g % 2) + 8 (g / 2) .. + 7 of its row.  Same MFMA chains as gemm_lp256m16.hip would run on the transposed
+//   operand: bit-identical to the [N][K] form on B^T.
 // D = dripped stores per K-tile (1, 2, 4 or 8): the 24 held stores leave during K-tiles 1 .. 24 / D of the next tile
-template <int DT, int D>
+template <int DT, int D, bool BNN = false>
 __global__ void __launch_bounds__(256)
 gemm_lp256qm_kernel(gemm_args g)
 {
@@ -164,7 +181,10 @@ gemm_lp256qm_kernel(gemm_args g)
         tile_coords(tl, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
         t.m0 = (int64_t)tm * BM; t.n0 = (int64_t)tn * BN; t.batch = bi;
         t.ua = static_cast<const char *>(g.a) + ((int64_t)bi * g.stride_a + (t.m0 + wave * 64) * g.lda) * ESZ;
-        t.ub = static_cast<const char *>(g.b) + ((int64_t)bi * g.stride_b + (t.n0 + wave * 64) * g.ldb) * ESZ;
+        if constexpr (BNN)   // column n0 of k-row 16 wave: this wave's pieces are block rows a = 4 wave .. + 3 of every K-tile
+            t.ub = static_cast<const char *>(g.b) + ((int64_t)bi * g.stride_b + t.n0 + (int64_t)(wave * 16) * g.ldb) * ESZ;
+        else
+            t.ub = static_cast<const char *>(g.b) + ((int64_t)bi * g.stride_b + (t.n0 + wave * 64) * g.ldb) * ESZ;
         return t;
     };
     // DMA map: a unit is 32 pieces of 1 KiB (8 LDS rows); this wave fills pieces wave * 8 + j; lane -> (LDS row r = 64 wave + 8 j + sub,
@@ -173,13 +193,20 @@ gemm_lp256qm_kernel(gemm_args g)
     const int sub = lane >> 3, c8 = lane & 7;
     const uint32_t voff_a0 = (uint32_t)sub * lda_b + (uint32_t)((c8 ^ (sub >> 1)) << 4);
     const uint32_t voff_a1 = (uint32_t)sub * lda_b + (uint32_t)((c8 ^ (4 + (sub >> 1))) << 4);
-    const uint32_t voff_b0 = (uint32_t)(8 * (sub >> 2) + (sub & 3)) * ldb_b + (uint32_t)((c8 ^ (sub >> 1)) << 4);
-    const uint32_t voff_b1 = (uint32_t)(8 * (sub >> 2) + (sub & 3)) * ldb_b + (uint32_t)((c8 ^ (4 + (sub >> 1))) << 4);
+    // BNN: piece J of this wave = block row a = 4 wave + J / 2, blocks b = 4 (J % 2) .. + 3: lane -> block b = 4 (J % 2) + lane / 16, row
+    // (lane % 16) / 4 of it, physical 16-byte chunk lane % 4 <- logical chunk (lane % 4) ^ 2 where (a >> 1) = 2 wave + J / 4 is odd
+    const uint32_t voff_b0 = BNN ? (uint32_t)((lane & 15) >> 2) * ldb_b + (uint32_t)((lane >> 4) * 64 + (lane & 3) * 16)
+                                 : (uint32_t)(8 * (sub >> 2) + (sub & 3)) * ldb_b + (uint32_t)((c8 ^ (sub >> 1)) << 4);
+    const uint32_t voff_b1 = BNN ? (uint32_t)((lane & 15) >> 2) * ldb_b + (uint32_t)((lane >> 4) * 64 + ((lane & 3) ^ 2) * 16)
+                                 : (uint32_t)(8 * (sub >> 2) + (sub & 3)) * ldb_b + (uint32_t)((c8 ^ (4 + (sub >> 1))) << 4);
     const int dst_piece = wave * 8 * 1024;
 
     // fragment reads (gemm_lp256m16.hip): row l15 of a 16-row block, chunk (4 s + g) ^ f, f = (l15 >> 1) & 7; k-step 1 = k-step 0 ^ 64
     const int f = (l15 >> 1) & 7;
-    const int ro_a = (wm * 128 + l15) * ROW_BYTES + ((g4 ^ f) << 4), ro_b = (wn * 128 + l15) * ROW_BYTES + ((g4 ^ f) << 4);
+    // BNN, B: block row 2 g (+ 8 s + u), block 4 wn (+ j / 2), row l15 / 4, half (j % 2) ^ (g % 2), 8 bytes per lane; k-step 1 = + 16 KiB
+    const int ro_a = (wm * 128 + l15) * ROW_BYTES + ((g4 ^ f) << 4);
+    const int ro_b = BNN ? (16 * g4 + 4 * wn) * 256 + (l15 >> 2) * 64 + (g4 & 1) * 32 + (l15 & 3) * 8 : (wn * 128 + l15) * ROW_BYTES + ((g4 ^ f) << 4);
+    constexpr int KS1_B = BNN ? 16384 : 0;         // what k-step 1 adds to ro_b (the [N][K] image: ro_b ^ 64 instead)
 
     f32x4 acc[8][8];             // never zeroed: the first k-step of a tile accumulates into a literal zero operand
     frag fa[8], fb[2][8];        // A single-buffered IN PLACE (fragment i is re-read behind its eighth MFMA), B double-buffered
@@ -192,12 +219,25 @@ gemm_lp256qm_kernel(gemm_args g)
     // Read id 0..7 = B fragment j into buffer NXT, 8..15 = A fragment i.
     auto read_one = [&](auto buf, auto idx, const char *pa, const char *pb) {
         constexpr int BUF = decltype(buf)::value, R = decltype(idx)::value;
-        if constexpr (R < 8) fb[BUF][R] = *reinterpret_cast<const frag *>(pb + R * 16 * ROW_BYTES);
+        if constexpr (BNN && (R < 8 || R >= 16)) {
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            constexpr int JB = R & 7;
+            constexpr bool HI = R >= 16;                                                                               // k 4-7: block row a + 1, 2 KiB on
+            const char *q8 = (JB & 1) ? reinterpret_cast<const char *>(reinterpret_cast<uintptr_t>(pb) ^ 32) : pb;     // odd column block: the other half
+            const auto q = (__attribute__((address_space(3))) s16x4 *)(q8 + (JB >> 1) * 256);
+            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(q + (HI ? 256 : 0));
+            const s16x8 w = __builtin_shufflevector(v, v, 0, 1, 2, 3, 0, 1, 2, 3), cur = __builtin_bit_cast(s16x8, fb[BUF][JB]);
+            if constexpr (HI) fb[BUF][JB] = __builtin_bit_cast(frag, (s16x8)__builtin_shufflevector(cur, w, 0, 1, 2, 3, 8, 9, 10, 11));
+            else fb[BUF][JB] = __builtin_bit_cast(frag, (s16x8)__builtin_shufflevector(w, cur, 0, 1, 2, 3, 12, 13, 14, 15));
+        } else if constexpr (R < 8) fb[BUF][R] = *reinterpret_cast<const frag *>(pb + R * 16 * ROW_BYTES);
         else fa[R - 8] = *reinterpret_cast<const frag *>(pa + (R - 8) * 16 * ROW_BYTES);
     };
     auto dma_one = [&](auto is_b, auto jj, int64_t koff, char *base) {
         constexpr int J = decltype(jj)::value;
-        if constexpr (decltype(is_b)::value) {
+        if constexpr (decltype(is_b)::value && BNN) {    // koff = K-tile * 128 bytes along K = K-tile * 64 k-rows of ldb elements here
+            glds16_s<J * 1024>(iss.ub + koff * g.ldb + (uint64_t)((uint32_t)(4 * (J >> 1)) * ldb_b) + (J & 1) * 256, (J & 4) ? voff_b1 : voff_b0, lds_addr_of(base));
+        } else if constexpr (decltype(is_b)::value) {
             constexpr uint32_t ROWS = 32 * (J >> 2) + 16 * (J & 1) + 4 * ((J >> 1) & 1);
             glds16_s<J * 1024>(iss.ub + koff + (uint64_t)(ROWS * ldb_b), (J & 1) ? voff_b1 : voff_b0, lds_addr_of(base));
         } else {
@@ -220,7 +260,8 @@ gemm_lp256qm_kernel(gemm_args g)
     // block IDX = (I = IDX >> 3, J = IDX & 7) is final: pack it.  Block rows 0-5 into P, 6-7 into the boundary staging image
     // (this wave's 8 KiB of the dead B slot: 32 rows x 256 B, 16-byte chunk ^ (row & 15)).
     int stage_off = 0;
-    const uint32_t lx = (uint32_t)(g4 ^ l15) << 4;       // ((4 jj + g) ^ l15) << 4 = (jj << 6) ^ lx
+    const uint32_t lx = BNN ? (uint32_t)((g4 >> 1) ^ l15) << 4 : (uint32_t)(g4 ^ l15) << 4;       // [N][K]: ((4 jj + g) ^ l15) << 4 = (jj << 6) ^ lx;
+                                                                                                  // BNN: ((4 jj + 2 e + g / 2) ^ l15) << 4 = ((jj << 6) | (e << 5)) ^ lx, + 8 (g % 2)
     auto drain_one = [&](auto idx) {
         constexpr int I = decltype(idx)::value >> 3, J = decltype(idx)::value & 7, JJ = J >> 1, E = J & 1;
         uint32_t w0 = qm<DT>::pack2(acc[I][J][0], acc[I][J][1]), w1 = qm<DT>::pack2(acc[I][J][2], acc[I][J][3]);
@@ -228,10 +269,17 @@ gemm_lp256qm_kernel(gemm_args g)
                                                     // block rows to the tile boundary -- they have no side effect until the stores of the next tile)
         if constexpr (I >= 6) {
             const u32x2 w = {w0, w1};
-            *reinterpret_cast<u32x2 *>(smem + stage_off + (I - 6) * 16 * 256 + (((uint32_t)JJ << 6) ^ opaque(lx)) + 8 * E) = w;
+            if constexpr (BNN) *reinterpret_cast<u32x2 *>(smem + stage_off + (I - 6) * 16 * 256 + ((((uint32_t)JJ << 6) | ((uint32_t)E << 5)) ^ opaque(lx))) = w;   // (stage_off carries 8 (g % 2))
+            else *reinterpret_cast<u32x2 *>(smem + stage_off + (I - 6) * 16 * 256 + (((uint32_t)JJ << 6) ^ opaque(lx)) + 8 * E) = w;
         } else {
             P[I >> 1][I & 1][JJ][2 * E + 0] = w0;
             P[I >> 1][I & 1][JJ][2 * E + 1] = w1;
+            if constexpr (BNN && E == 1) {      // both blocks of the pair are packed: rows 1, 3 of block 2 jj <-> rows 0, 2 of block 2 jj + 1 (see the kernel header)
+                u32x4 &c4 = P[I >> 1][I & 1][JJ];
+                const auto r0 = __builtin_amdgcn_permlane16_swap(c4[0], c4[2], false, false);
+                const auto r1 = __builtin_amdgcn_permlane16_swap(c4[1], c4[3], false, false);
+                c4[0] = r0[0]; c4[2] = r0[1]; c4[1] = r1[0]; c4[3] = r1[1];
+            }
         }
     };
 
@@ -241,7 +289,8 @@ gemm_lp256qm_kernel(gemm_args g)
     // 2 p + 1 the odd one, bytes 128 p + 64 (l15 & 1) + 16 g: one store instruction = 8 rows x one whole 128-byte line.
     char *hbase = nullptr;
     bool held = false;           // P holds a finished tile whose stores are still to be issued (false only during a workgroup's first tile)
-    const uint32_t pvoff = (uint32_t)((l15 & ~1) * g.ldc * CSZ + 64 * (l15 & 1) + 16 * g4);
+    const uint32_t pvoff = BNN ? (uint32_t)((l15 & ~1) * g.ldc * CSZ + 64 * (l15 & 1) + 32 * (g4 & 1) + 16 * (g4 >> 1))
+                               : (uint32_t)((l15 & ~1) * g.ldc * CSZ + 64 * (l15 & 1) + 16 * g4);
     const int64_t rowbytes = g.ldc * CSZ, rowblock = (int64_t)32 * g.ldc * CSZ;
     const bool odd1 = (l15 & 1) != 0;
     // word W of pair TP (= 2 ii + p) of row block RB: 4 VALU
@@ -326,7 +375,7 @@ gemm_lp256qm_kernel(gemm_args g)
     // Instruction order pinned by sched_barrier after every group.
 #define QM_G(CUR, NXT, KS, N0, BIT, DMASK, IS_B, J0, FIRST, DRAIN, G)                                                 \
     mfma_one(IC<CUR>{}, IC<(N0) + (BIT)>{}, IC<FIRST>{});                                                             \
-    if constexpr (qm_read_at(KS, (N0) + (BIT)) >= 0) read_one(IC<NXT>{}, IC<(qm_read_at(KS, (N0) + (BIT)) >= 0 ? qm_read_at(KS, (N0) + (BIT)) : 0)>{}, rd_a, rd_b); \
+    if constexpr (qm_read_at(KS, (N0) + (BIT), BNN) >= 0) read_one(IC<NXT>{}, IC<(qm_read_at(KS, (N0) + (BIT), BNN) >= 0 ? qm_read_at(KS, (N0) + (BIT), BNN) : 0)>{}, rd_a, rd_b); \
     if constexpr (((DMASK) >> (BIT)) & 1u) dma_one(IC<IS_B>{}, IC<(J0) + __builtin_popcount((DMASK) & ((1u << (BIT)) - 1u))>{}, dma_koff, dma_base); \
     if constexpr ((DRAIN) && (N0) + (BIT) >= QM_LAG) {                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
@@ -371,6 +420,10 @@ gemm_lp256qm_kernel(gemm_args g)
         read_one(IC<0>{}, IC<3>{}, rd_a, rd_b); read_one(IC<0>{}, IC<4>{}, rd_a, rd_b); read_one(IC<0>{}, IC<5>{}, rd_a, rd_b); read_one(IC<0>{}, IC<6>{}, rd_a, rd_b);
         read_one(IC<0>{}, IC<7>{}, rd_a, rd_b); read_one(IC<0>{}, IC<9>{}, rd_a, rd_b); read_one(IC<0>{}, IC<10>{}, rd_a, rd_b); read_one(IC<0>{}, IC<11>{}, rd_a, rd_b);
         read_one(IC<0>{}, IC<12>{}, rd_a, rd_b); read_one(IC<0>{}, IC<13>{}, rd_a, rd_b); read_one(IC<0>{}, IC<14>{}, rd_a, rd_b); read_one(IC<0>{}, IC<15>{}, rd_a, rd_b);
+        if constexpr (BNN) {
+            read_one(IC<0>{}, IC<16>{}, rd_a, rd_b); read_one(IC<0>{}, IC<17>{}, rd_a, rd_b); read_one(IC<0>{}, IC<18>{}, rd_a, rd_b); read_one(IC<0>{}, IC<19>{}, rd_a, rd_b);
+            read_one(IC<0>{}, IC<20>{}, rd_a, rd_b); read_one(IC<0>{}, IC<21>{}, rd_a, rd_b); read_one(IC<0>{}, IC<22>{}, rd_a, rd_b); read_one(IC<0>{}, IC<23>{}, rd_a, rd_b);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -400,7 +453,7 @@ gemm_lp256qm_kernel(gemm_args g)
         const int64_t dma_koff = (int64_t)min(t + 2 - kbase, nk - 1) * ROW_BYTES;   /* clamp: only without a next tile */ \
         const char *rd_a, *rd_b;                                                                                    \
         char *dma_base;                                                                                             \
-        rd_a = smem + sa + (ro_a ^ 64); rd_b = smem + sb + (ro_b ^ 64); dma_base = smem + s4 + dst_piece;           \
+        rd_a = smem + sa + (ro_a ^ 64); rd_b = smem + sb + (BNN ? ro_b + KS1_B : (ro_b ^ 64)); dma_base = smem + s4 + dst_piece; \
         QM_Q(0, 1, 0, 0, 0x0808u, 0, 0, FIRST, 0, G) QM_Q(0, 1, 0, 16, 0x0808u, 0, 2, FIRST, 0, G)                   \
         QM_Q(0, 1, 0, 32, 0x0808u, 0, 4, FIRST, 0, G) QM_Q(0, 1, 0, 48, 0x0808u, 0, 6, FIRST, 0, G)                  \
         QM_Q(1, 0, 1, 0, 0u, 0, 0, 0, LASTK, G)                                                                      \
@@ -411,7 +464,7 @@ gemm_lp256qm_kernel(gemm_args g)
         __builtin_amdgcn_s_barrier();    /* BAR_t */                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
         rd_a = smem + sa1 + ro_a; rd_b = smem + sb1 + ro_b; dma_base = smem + s5 + dst_piece;                        \
-        if constexpr (LASTK) stage_off = sb + wave * 8192 + (int)opaque((uint32_t)(l15 * 256));   /* B unit of this K-tile: dead since BAR_t */ \
+        if constexpr (LASTK) stage_off = sb + wave * 8192 + (int)opaque((uint32_t)(l15 * 256 + (BNN ? 8 * (g4 & 1) : 0)));   /* B unit of this K-tile: dead since BAR_t */ \
         QM_Q(1, 0, 1, 16, 0x0808u, 1, 0, 0, LASTK, G) QM_Q(1, 0, 1, 32, 0x0808u, 1, 2, 0, LASTK, G)                  \
         QM_Q(1, 0, 1, 48, 0x2222u, 1, 4, 0, LASTK, G)                                                                \
         if constexpr (LASTK) {                                                                                      \
@@ -508,13 +561,13 @@ gemm_lp256qm_kernel(gemm_args g)
     WAIT_VMCNT(0);                       // drain the clamped tail DMA (and the last stores) before the workgroup retires
 }
 
-template <int DT, int D>
+template <int DT, int D, bool BNN>
 void launch(mi355_ctx *ctx, hipStream_t s, const gemm_args &g, uint32_t batch)
 {
-    lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_lp256qm_kernel<DT, D>), LDS_BYTES);
+    lds_opt_in(ctx, reinterpret_cast<const void *>(gemm_lp256qm_kernel<DT, D, BNN>), LDS_BYTES);
     const uint32_t total = g.tiles_m * g.tiles_n * batch;
     const uint32_t grid = std::min<uint32_t>(total, ctx->props.num_streaming_multiprocessors);   // one workgroup per CU (LDS admits no more)
-    hipLaunchKernelGGL((gemm_lp256qm_kernel<DT, D>), dim3(grid), dim3(256), LDS_BYTES, s, g);
+    hipLaunchKernelGGL((gemm_lp256qm_kernel<DT, D, BNN>), dim3(grid), dim3(256), LDS_BYTES, s, g);
 }
 
 int drip_for(int64_t nk)                 // fewest stores per K-tile whose drip phase (K-tiles 1 .. 24 / D) fits: nk >= 24 / D + 3
@@ -537,7 +590,8 @@ bool gemm_lp256qm_supports(const mi355_gemm_desc &d, const void *a, const void *
 {
     if (d.dtype_ab != MI355_DTYPE_BF16 && d.dtype_ab != MI355_DTYPE_F16) return false;
     if (d.dtype_c != d.dtype_ab) return false;                     // (f32 C would need 192 held registers)
-    if (d.trans_a || !d.trans_b) return false;                     // A [M][K], B [N][K]
+    if (d.trans_a) return false;                                   // A [M][K]; B [N][K] or row-major [K][N]
+    if (!d.trans_b && (int64_t)64 * d.ldb * 2 >= (1ll << 32)) return false;
     if (!gemm_lp256p_supports(d, a, b, c)) return false;           // full tiles, K-contiguous 16-byte aligned operands, 32-bit DMA offsets
     if (drip_for(d.k / 64) == 0) return false;
     if ((int64_t)32 * d.ldc * 2 >= (1ll << 32)) return false;      // per-lane store offsets are 32-bit
@@ -560,7 +614,8 @@ int32_t launch_gemm_lp256qm(mi355_ctx *ctx, hipStream_t s, const mi355_gemm_desc
     const uint32_t batch = (uint32_t)d.batch;
     const int drip = drip_for(d.k / 64);
     const bool bf = d.dtype_ab == MI355_DTYPE_BF16;
-#define QM_LAUNCH(DD) { if (bf) launch<MI355_DTYPE_BF16, DD>(ctx, s, g, batch); else launch<MI355_DTYPE_F16, DD>(ctx, s, g, batch); }
+#define QM_LAUNCH(DD) { if (d.trans_b) { if (bf) launch<MI355_DTYPE_BF16, DD, false>(ctx, s, g, batch); else launch<MI355_DTYPE_F16, DD, false>(ctx, s, g, batch); } \
+                        else { if (bf) launch<MI355_DTYPE_BF16, DD, true>(ctx, s, g, batch); else launch<MI355_DTYPE_F16, DD, true>(ctx, s, g, batch); } }
     if (drip == 1) QM_LAUNCH(1) else if (drip == 2) QM_LAUNCH(2) else if (drip == 4) QM_LAUNCH(4) else QM_LAUNCH(8)
 #undef QM_LAUNCH
     check_launch(ctx, "mi355_gemm(lp256qm)");

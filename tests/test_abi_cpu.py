@@ -108,9 +108,9 @@ def test_hot_gemm_kernels_do_not_spill_and_pad_their_asm_hazards():
     # a vector-register spill (scratch memory, and an s_waitcnt vmcnt(0) per reload that drains the LDS-DMA stream) never is
     # (round 3: its row-major-B instantiations carry two more 64-bit scalars -- 36-38 parked registers; the K-tile bodies hold
     # the same four v_readlane as the [N][K] ones)
-    # (round 6: gemm_lp256qm.hip, the same structure on 16x16x32 MFMAs, parks 25-43; the index reductions over 16-bit input in reduce.hip
+    # (round 6: gemm_lp256qm.hip, the same structure on 16x16x32 MFMAs, parks 25-49; the index reductions over 16-bit input in reduce.hip
     # park two scalars since the polled hand-off added a kernel argument -- outside their streaming loops)
-    bad = [r for r in rows if r[3] or (r[2] and "lp256q" not in r[1] and not ("reduce_kernel" in r[1] and r[2] <= 4)) or r[2] > (48 if "lp256qm" in r[1] else 40)]
+    bad = [r for r in rows if r[3] or (r[2] and "lp256q" not in r[1] and not ("reduce_kernel" in r[1] and r[2] <= 4)) or r[2] > (52 if "lp256qm" in r[1] else 40)]
     assert not bad, bad
     assert not any(hazards.values()), {k: v for k, v in hazards.items() if v}
 

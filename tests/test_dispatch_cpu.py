@@ -23,7 +23,8 @@ TABLE = [
     ("ragged tiles, four rounds: the one-tile-per-workgroup 16x16x32 kernel", (8200, 8200, 8192, BF, None, 0, 1, 1), "LP_256M16", (0, 0)),
     ("1.5 rounds of full 256^2 tiles, 16-bit C: the persistent 16x16x32 loop (round 6; until then the 32x32x16 kernel)", (6144, 4096, 8192, BF, None, 0, 1, 1), "LP_256QM", (0, 0)),
     ("... with an f32 C, not yet power-bound: the 32x32x16 kernel", (6144, 4096, 8192, BF, F32, 0, 1, 1), "LP_256W4", (0, 0)),
-    ("C3 with the reference's default rhs layout", (8192, 8192, 8192, BF, None, 0, 0, 1), "LP_256W4", (0, 0)),
+    ("C3 with the reference's default rhs layout: the 32x32x16 kernel (the 16x16x32 transposing-read form is a tie there, round 6)", (8192, 8192, 8192, BF, None, 0, 0, 1), "LP_256W4", (0, 0)),
+    ("... at K = 4096: the persistent 16x16x32 kernel's row-major form (1 401 -> 1 444 TFLOP/s)", (8192, 8192, 4096, BF, None, 0, 0, 1), "LP_256QM", (0, 0)),
     ("C2: 4096^3 f32", (4096, 4096, 4096, F32, F32, 0, 1, 1), "LP_256W4", (0, 0)),
     ("C2, row-major rhs", (4096, 4096, 4096, F32, F32, 0, 0, 1), "LP_256W4", (0, 0)),
     ("f32 GEMV: the row-streaming FMA kernel", (1, 8192, 8192, F32, F32, 0, 1, 1), "SKINNY", (0, 0)),
@@ -39,7 +40,7 @@ TABLE = [
     ("f32, 65 rows: the 128x128 f32 tile", (65, 4096, 4096, F32, F32, 0, 1, 1), "F32_MFMA", (0, 0)),
     ("C5: 512 x 2048^3 bf16 on one GPU: dripped stores on 16x16x32 MFMAs (round 6: 1 275 -> 1 340 TFLOP/s)", (2048, 2048, 2048, BF, None, 0, 1, 512), "LP_256QM", (0, 0)),
     ("C5 with an f32 C: the persistent kernel without them", (2048, 2048, 2048, BF, F32, 0, 1, 512), "LP_256P", (0, 0)),
-    ("C5, row-major rhs", (2048, 2048, 2048, BF, None, 0, 0, 512), "LP_256Q", (0, 0)),
+    ("C5, row-major rhs: the same kernel's transposing-read form (round 6)", (2048, 2048, 2048, BF, None, 0, 0, 512), "LP_256QM", (0, 0)),
     ("the 64-matrix shard of an 8-GPU C5", (2048, 2048, 2048, BF, None, 0, 1, 64), "LP_256QM", (0, 0)),
     ("two rounds, K = 640: the same loop with four stores per K-tile (1 067 -> 1 083; lp256p 961)", (8192, 8192, 640, BF, None, 0, 1, 1), "LP_256QM", (0, 0)),
     ("GEMV", (1, 8192, 8192, BF, None, 0, 1, 1), "SKINNY", (0, 0)),

@@ -199,8 +199,7 @@ def test_c3_bf16_8192_row_major_rhs_is_native_and_bit_identical_to_the_k_contigu
         # (AUTO takes the 16x16x32 form of the tile for the K-contiguous rhs since round 5 -- another summation order; the
         # statement here is about the STAGING of the 32x32x16 kernel, so that kernel is named for the K-contiguous launch)
         assert ops.gemm_select(client, d) == (N.GEMM_ALGO_LP_256QM if d.trans_b else N.GEMM_ALGO_LP_256W4) and ops.gemm_relayout_plan(client, d) == (False, False)
-        if d.trans_b:
-            d.algo = N.GEMM_ALGO_LP_256W4
+        d.algo = N.GEMM_ALGO_LP_256W4
         c = TensorHandle.new_contiguous((S, S), client.empty(S * S * 2), ElemType.BF16)
         client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()),
                                               C.c_void_p(c.device_ptr())))
@@ -225,9 +224,8 @@ def test_c5_batch64_2048_bf16_row_major_rhs_is_native(client, oracle):
         assert ops.gemm_relayout_plan(client, d) == (False, False)
         # the dripped-store kernels: 16x16x32 form for the K-contiguous rhs since round 6 (another summation order), 32x32x16 form for the
         # row-major rhs; the statement here is about the STAGING of the 32x32x16 kernel, so that kernel is named for the K-contiguous launch
-        assert ops.gemm_select(client, d) == (N.GEMM_ALGO_LP_256QM if d.trans_b else N.GEMM_ALGO_LP_256Q)
-        if d.trans_b:
-            d.algo = N.GEMM_ALGO_LP_256Q
+        assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256QM
+        d.algo = N.GEMM_ALGO_LP_256Q
         c = TensorHandle.new_contiguous((B, M, M), client.empty(B * M * M * 2), ElemType.BF16)
         client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()),
                                               C.c_void_p(c.device_ptr())))
@@ -289,7 +287,7 @@ def test_c5_batch512_2048_bf16_as_benched(client, oracle, layout):
     assert 2 * 256 * mm == 1 << 31 and 2 * B * mm == 1 << 32
     client._s.check(client.lib.mi355_memset(client.ctx, None, C.c_void_p(c.device_ptr()), 0xEE, B * mm * 2))
     d = (_nn_bench_desc if nn else _bench_desc)(M, M, M, N.DTYPE_BF16, N.DTYPE_BF16, batch=B)
-    assert ops.gemm_select(client, d) == (N.GEMM_ALGO_LP_256Q if nn else N.GEMM_ALGO_LP_256QM)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256QM
     assert ops.gemm_relayout_plan(client, d) == (False, False)
     client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()),
                                           C.c_void_p(c.device_ptr())))
@@ -308,7 +306,9 @@ def test_c5_batch512_2048_bf16_as_benched(client, oracle, layout):
                          case=f"C5 as benched: 512 x 2048^3 bf16 -> bf16 C ({layout}), matrix {bi}, 10 sampled rows vs f64 oracle")
     # the one-tile-per-workgroup kernel on single matrices of the upper half: same per-tile summation order => same bits
     d1 = (_nn_bench_desc if nn else _bench_desc)(M, M, M, N.DTYPE_BF16, N.DTYPE_BF16, batch=1)
-    d1.algo = N.GEMM_ALGO_LP_256W4 if nn else N.GEMM_ALGO_LP_256M16     # (the kernel with the persistent form's MFMA shape)
+    # (NT: the one-tile-per-workgroup kernel with the persistent form's MFMA shape; NN: that kernel has no row-major form -- the same kernel on the
+    #  single matrix, another grid and tile walk, reached through 64-bit pointer offsets)
+    d1.algo = N.GEMM_ALGO_LP_256QM if nn else N.GEMM_ALGO_LP_256M16
     c1 = TensorHandle.new_contiguous((M, M), client.empty(mm * 2), ElemType.BF16)
     for bi in (256, 511):
         off = 2 * bi * mm

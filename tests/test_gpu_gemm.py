@@ -644,6 +644,35 @@ def test_lp256qm_is_bit_identical_to_the_m16_kernel(client, oracle, m, n, batch,
         assert np.array_equal(c.to_numpy(client), want)
 
 
+@pytest.mark.parametrize("dtype", [ElemType.BF16, ElemType.F16])
+@pytest.mark.parametrize("m,n,k,batch", [(512, 768, 448, 3), (768, 768, 1024, 2), (512, 512, 2048, 6), (4352, 4352, 640, 1), (1024, 512, 1728, 40)])
+def test_lp256qm_row_major_b_gives_the_bits_of_the_k_contiguous_form(client, oracle, dtype, m, n, k, batch):
+    """Round 6: the row-major [K][N] rhs (TensorHandle::new_contiguous, crates/cubecl-std/src/tensor/handle.rs:89) on the persistent 16x16x32
+    kernel -- transposing reads of a half-swapped block image, natural column order, v_permlane16_swap in the held tile -- runs the same MFMA
+    chains as the [N][K] form on the transposed matrix: bit for bit, at every drip rate, B one matrix broadcast over the batch; and one slab
+    of rows against the oracle directly so that the pair cannot be wrong together."""
+    a_host = oracle.fill_uniform(batch * m * k, 63, -1.0, 1.0)
+    b_host = oracle.fill_uniform(k * n, 64, -1.0, 1.0).reshape(k, n)
+    conv = oracle.to_bf16 if dtype == ElemType.BF16 else oracle.to_f16
+    a = TensorHandle.from_numpy(client, conv(a_host), dtype)
+    b_kn = TensorHandle.from_numpy(client, conv(b_host), dtype)
+    b_nk = TensorHandle.from_numpy(client, conv(np.ascontiguousarray(b_host.T)), dtype)
+    a_t = TensorHandle.new(a.handle, (batch, m, k), (m * k, k, 1), dtype)
+    outs = []
+    for handle, strides in ((b_kn, (0, n, 1)), (b_nk, (0, 1, k))):
+        c = TensorHandle.new_contiguous((batch, m, n), client.empty(batch * m * n * dtype.size()), dtype)
+        client._s.check(client.lib.mi355_memset(client.ctx, None, c.device_ptr(), 0xEE, batch * m * n * dtype.size()))
+        ops.matmul(client, a_t, TensorHandle.new(handle.handle, (batch, k, n), strides, dtype), c, algo=ALGOS["lp256qm"])
+        outs.append(c.to_numpy(client))
+    assert np.array_equal(outs[0], outs[1])
+    dec = oracle.from_bf16 if dtype == ElemType.BF16 else oracle.from_f16
+    A = dec(conv(a_host[: m * k])).reshape(m, k)[:80].astype(np.float64)
+    Bv = dec(conv(b_host)).reshape(k, n).astype(np.float64)
+    got = _decode(oracle, outs[0].reshape(batch, m, n)[0][:80], dtype)
+    tol = REL * (np.abs(A) @ np.abs(Bv)) + np.abs(A @ Bv) * 2.0 ** (-7 if dtype == ElemType.BF16 else -10)
+    assert np.all(np.abs(got - A @ Bv) <= tol + 1e-30)
+
+
 def test_lp256qm_oracle_f16_identity_pitched_operands_and_refusals(client, oracle):
     run_case(client, oracle, 512, 768, 512, ElemType.F16, ElemType.F16, True, ALGOS["lp256qm"])           # against the oracle itself
     run_case(client, oracle, 768, 512, 1024, ElemType.BF16, ElemType.BF16, True, ALGOS["lp256qm"], batch=3, ldc=520)   # pitched C rows
@@ -664,7 +693,8 @@ def test_lp256qm_oracle_f16_identity_pitched_operands_and_refusals(client, oracl
     ops.matmul(client, TensorHandle.new(ta.handle, (m, k), (k, 1), ElemType.BF16), TensorHandle.new(tb.handle, (k, n), (1, k), ElemType.BF16),
                c, algo=ALGOS["lp256qm"])
     assert np.array_equal(c.to_numpy(client).reshape(m, n), amat)
-    for kw in (dict(k=320), dict(out=ElemType.F32), dict(trans_b=False), dict(m=520)):   # < 6 K-tiles / f32 C / row-major B / ragged tiles: refused, not mis-run
+    run_case(client, oracle, 512, 768, 2048, ElemType.BF16, ElemType.BF16, False, ALGOS["lp256qm"], batch=2, lda=2056, ldb=800, ldc=776)   # row-major B, pitched everything
+    for kw in (dict(k=320), dict(out=ElemType.F32), dict(m=520)):   # < 6 K-tiles / f32 C / ragged tiles: refused, not mis-run
         with pytest.raises(ServerError) as e:
             run_case(client, oracle, kw.get("m", 512), 512, kw.get("k", 1024), ElemType.BF16, kw.get("out", ElemType.BF16), kw.get("trans_b", True), ALGOS["lp256qm"])
         assert e.value.code == N.E_UNSUPPORTED
@@ -951,7 +981,9 @@ def test_auto_selection_and_errors(client):
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256QM           # 10 K-tiles: four stores per K-tile (round 6; the 32x32x16 form measured slower than lp256p there)
     d.k = d.lda = d.ldb = 2048
     d.batch = 4
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256M16          # exactly one full round (4 x 64 tiles): the one-tile-per-workgroup 16x16x32 kernel (round 6)
+    d.batch = 3
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4           # 192 tiles: the 32x32x16 kernel
     d = N.GemmDesc(m=8192 + 8, n=8192, k=8192, batch=1, lda=8192, ldb=8192, ldc=8192, dtype_ab=N.DTYPE_BF16,
                    dtype_c=N.DTYPE_BF16, trans_b=1)
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4          # ragged M / N stay on the fast kernel (4.1 rounds: the launcher
@@ -1425,7 +1457,8 @@ def test_output_bound_shapes_select_the_small_tile(client):
     assert sel(64, 8192, 28672) == sel(64, 28672, 8192) == N.GEMM_ALGO_LP_128        # small operand past 2 MiB / 64 rows over more than 512 workgroups
     assert sel(8192, 32, 8192) == N.GEMM_ALGO_STREAM64 and sel(8192, 32, 14336) == N.GEMM_ALGO_LP_128   # few columns: K past 8192 goes to split-K (round 4)
     assert sel(44440, 88, 1536) == sel(16384, 512, 1024) == N.GEMM_ALGO_LP_256X128 and sel(32768, 128, 1024) == N.GEMM_ALGO_LP_128   # tall and skinny (round 4)
-    assert sel(4, 2048, 4096) == sel(384, 4, 8192) == sel(3, 512, 14336) == sel(4096, 4, 14336) == N.GEMM_ALGO_SKINNY   # 3-4 rows, fewer than 192 streaming workgroups
+    assert sel(4, 2048, 4096) == sel(384, 4, 8192) == sel(4096, 4, 14336) == N.GEMM_ALGO_SKINNY   # 3-4 rows, fewer than 192 streaming workgroups
+    assert sel(3, 512, 14336) == sel(3, 896, 14336) == N.GEMM_ALGO_LP_128    # ... but K past 8192 on a handful of tiles: split-K (round 6 audit: 11.8 us against 17.0)
     assert sel(8192, 4, 2048) == sel(4, 8192, 8192) == N.GEMM_ALGO_STREAM64           # ... from 192 up the streaming kernel
     # the 256 x 128 tile: more than one 128x128 tile per CU, at most one 256 x 128 tile per CU, long K (round 3)
     assert sel(2048, 2048, 8192, batch=2) == N.GEMM_ALGO_LP_256X128
