@@ -1,5 +1,6 @@
 """Parity of the HIP reductions with the CPU oracle through the C ABI (bit-exact indices,
 1e-5 relative sums -- BASELINE.json)."""
+from pathlib import Path
 import numpy as np
 import pytest
 
@@ -236,8 +237,11 @@ def test_sum_argmax_combine_folds_sums_in_rank_order_and_candidates_by_the_rule(
 
 
 def test_two_level_arrival_tickets_at_every_grid_size_and_across_back_to_back_launches(client, oracle):
-    """The inter-workgroup hand-off of the array-wide kernel (records written through, drained, then a GROUP ticket and -- for the last of
-    a group -- the TOP ticket; every word put back to zero by whoever completed its count): grids of 1, 2, 31, 32, 33, 63, 64, 65, 255 and
+    """The inter-workgroup hand-off of the array-wide kernel -- since round 6, on these grids, polled records: every workgroup stores ONE 16-byte
+    write-through record whose top bit says "valid", workgroup G - 1 polls them, takes each as its bit shows and puts the bit back to zero (a bit
+    left up by one launch would hand the next launch a stale record: a wrong sum or index here); until round 5, and still beyond 384 workgroups:
+    records written through, drained, then a GROUP ticket and -- for the last of a group -- the TOP ticket, every word put back to zero by
+    whoever completed its count (test_ticket_handoff_still_serves_grids_beyond_the_polled_records).  Grids of 1, 2, 31, 32, 33, 63, 64, 65, 255 and
     256 workgroups -- one member per group, uneven groups, a full house -- launched back to back on two streams in an interleaved order
     (a word left non-zero by one launch breaks the next: wrong last-arriver, a fold over records that have not been written), every result
     against the oracle's f64 sum, the argmax bit-exactly, and every repeat bit-identical to the first (the fold order is fixed).
@@ -280,6 +284,43 @@ def test_two_level_arrival_tickets_at_every_grid_size_and_across_back_to_back_la
                 assert bytes(rec) == first[key], (si, rep, grids[ci])          # same bits on every launch, either stream
     for st in streams:
         chk(lib.mi355_stream_destroy(ctx, st))
+
+
+def test_ticket_handoff_still_serves_grids_beyond_the_polled_records(oracle):
+    """Round 6: on the default grid (one workgroup per CU, at most 384) the hand-off above runs on polled tagged records in library scratch; the
+    two-level tickets + the caller's workspace remain for larger grids -- a device with more CUs, or MI355_REDUCE_WG_PER_CU.  The library reads
+    its dev switches once per process, so this path is driven in a child process: three workgroups per CU (768 records: tickets) and, separately,
+    the default grid with polling switched off, both against the oracle and against each other's argmax; sums within the tolerance (another
+    grid = another tree), the same bits on a repeat."""
+    import os
+    import subprocess
+    import sys
+    child = r'''
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import oracle
+from cubecl_amd import ElemType, Mi355Runtime, TensorHandle, ops
+cl = Mi355Runtime.client()
+for n in (1 << 20, 5_000_011, (1 << 26) + 12345):
+    x = oracle.fill_uniform(n, 41, -1.0, 1.0)
+    x[(n * 7) // 11] = 5.0
+    t = TensorHandle.from_numpy(cl, x)
+    s = TensorHandle.new_contiguous((1,), cl.empty(8), ElemType.F32); v = TensorHandle.new_contiguous((1,), cl.empty(8), ElemType.F32)
+    i = TensorHandle.new_contiguous((1,), cl.empty(8), ElemType.U64)
+    bits = set()
+    for _ in range(3):
+        ops.sum_argmax(cl, t, s, i, v)
+        got = float(s.to_numpy(cl)[0]); bits.add(s.to_numpy(cl).view(np.uint32)[0])
+        assert abs(got - oracle.sum_f64(x)) <= 1e-5 * oracle.sum_abs_f64(x), (n, got)
+        assert int(i.to_numpy(cl)[0]) == (n * 7) // 11 and v.to_numpy(cl)[0] == np.float32(5.0)
+    assert len(bits) == 1
+print("handoff ok")
+'''
+    root = str(Path(__file__).resolve().parents[1])
+    for env in ({"MI355_REDUCE_WG_PER_CU": "3"}, {"MI355_REDUCE_POLL": "0"}):
+        out = subprocess.run([sys.executable, "-c", child, root], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "handoff ok" in out.stdout, (env, out.stdout[-500:], out.stderr[-2000:])
 
 
 def test_fused_sum_argmax_equals_separate(client, oracle):
