@@ -222,11 +222,11 @@ KERNEL_SOURCES = {
     "reduce": ("cubecl_amd/csrc/reduce.hip", "cubecl_amd/csrc/internal.hpp"),
 }
 PROFILES_DIR = ROOT / "profiles"
-HEADLINE_KERNEL = "gemm_lp256qm_kernel<1, 1>"      # <bf16, one dripped store per K-tile>: bf16 x bf16 -> bf16 C, [N][K] B, persistent, on v_mfma_f32_16x16x32
+HEADLINE_KERNEL = "gemm_lp256qm_kernel<1, 1, false>"   # <bf16, one dripped store per K-tile, [N][K] rhs>: bf16 x bf16 -> bf16 C, [N][K] B, persistent, on v_mfma_f32_16x16x32
                                                    # (what rocprofv3 prints; round 5: gemm_lp256m16_kernel<1, 1>; until round 4: gemm_lp256w4_kernel<...>)
 HEADLINE_ALGO = 15                                 # MI355_GEMM_ALGO_LP_256QM: what AUTO takes for config C3 (round 6)
 REDUCE_SUM_KERNEL = "reduce_kernel<0, 0, 0>"      # <VOP = MI355_REDUCE_SUM, AOP = none, DT = f32> (until round 3: <true, false, 0>)
-C5_KERNEL = "gemm_lp256qm_kernel<1, 1>"            # the same instantiation on batch 512 x 2048^3 (32 K-tiles per tile; round 5: gemm_lp256q_kernel<1, 1, false>)
+C5_KERNEL = "gemm_lp256qm_kernel<1, 1, false>"         # the same instantiation on batch 512 x 2048^3 (32 K-tiles per tile; round 5: gemm_lp256q_kernel<1, 1, false>)
 C5_ALGO = 15
 
 
