@@ -10,7 +10,10 @@
 //
 // What differs from gemm_lp256q.hip:
 //   * K loop: gemm_lp256m16.hip's -- a wave's 128 x 128 block is 8 x 8 accumulators of 16 x 16 (256 AGPRs), a K-tile two k-steps
-//     of 64 MFMAs (A fragment = srcB outer, B fragment = srcA inner), 16 ds_read_b128 per k-step double-buffered in 128 VGPRs.
+//     of 64 MFMAs (A fragment = srcB outer, B fragment = srcA inner).  Fragment registers: the 8 A fragments are replaced IN
+//     PLACE (each is dead after its 8 MFMAs of the k-step, its successor's read is issued right there: qm_read_at), the B
+//     fragments double-buffered: 96 registers, not m16's 128.  The MFMAs are inline asm with the accumulator tied ("+a"): the
+//     compiler can neither move an accumulator out of its AGPR nor re-order across the pinned conversions (0 spills).
 //   * The held tile needs no v_permlane swap: the ROWS OF THE B TILE ARE PERMUTED ON THEIR WAY INTO LDS.  With srcA = the B
 //     fragment a lane (l15 = lane % 16, g = lane / 16) holds C[row l15][MFMA columns 4 g .. 4 g + 3] of block (i, j) -- four
 //     consecutive columns of one row.  LDS row r of the B tile is filled from matrix column
@@ -25,9 +28,13 @@
 //     word, 32 per 16-row block row) makes a chunk register 8 rows x 128 contiguous bytes.  24 held stores per wave and tile
 //     (block rows 0-5 = 96 VGPRs), block rows 6-7 through the dead ring slot at the tile boundary, as in gemm_lp256q.hip.
 //   * Per-lane DMA offsets: four registers (A / B x even / odd piece) + wave-uniform piece offsets in scalar arithmetic (tiles are
-//     full); fragment addresses: x1 = x0 ^ 64.  128 fragment + 96 held registers leave ~30 for everything else.
+//     full); fragment addresses: x1 = x0 ^ 64.  96 fragment + 96 held registers leave ~60 for everything else.
 //
-// Restrictions: as gemm_lp256q.hip without the row-major-B form (B stored [N][K] only), lda != ldb allowed.
+//   * Row-major rhs (BNN = true, B stored [K][N]): the B tile's LDS image is K-major, fragments come out of ds_read_b64_tr_b16
+//     (half-swapped block image: no bank conflict), and the drain exchanges with v_permlane16_swap instead of the DMA-side row
+//     permutation.  Same MFMA chain per element: bit-identical to the B-transposed call on B^T (tests/test_gpu_gemm.py).
+//
+// Restrictions: as gemm_lp256q.hip; lda != ldb allowed; the row-major-rhs form needs 64 * ldb * 2 < 2^32 (DMA voffset range).
 #include <algorithm>
 #include <type_traits>
 
@@ -86,8 +93,21 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void *p)
 }
 
 #ifndef QM_ABL
-#define QM_ABL 0          // dev ablations, timing only: 1 no dripped stores, 2 no boundary stores
+#define QM_ABL 0          // dev ablations, timing only: 1 no dripped stores, 2 no boundary stores, 4 every dripped store of a wave into the same 8 KiB (cache-resident: the instruction without its memory traffic)
 #endif
+#ifndef QM_PAD
+#define QM_PAD 0          // dev, timing only -- what an instruction costs by where it sits: 1: 16 scalar adds at the head of every K-tile, 2: one in each of 16 empty MFMA gaps, 4: one more in each of the 16 gaps that carry a DMA piece
+#endif
+#ifndef QM_NT
+#define QM_NT 1           // the held tile's stores carry the streaming hint (0: plain stores, dev A/B)
+#endif
+#define QM_STR_(x) #x
+#define QM_STR(x) QM_STR_(x)
+#define QM_NT_SUFFIX_0 ""
+#define QM_NT_SUFFIX_1 " nt"
+#define QM_NT_CAT_(a, b) a##b
+#define QM_NT_CAT(a, b) QM_NT_CAT_(a, b)
+#define QM_NT_SUFFIX QM_NT_CAT(QM_NT_SUFFIX_, QM_NT)
 #ifndef QM_LAG
 #define QM_LAG 3          // a finished block is packed behind the MFMA this many slots after its own (no wait on the matrix pipe)
 #endif
@@ -105,10 +125,16 @@ template <int V> using IC = std::integral_constant<int, V>;
 // Dev timing trace (-DQM_TRACE, never in the product library): shader-clock stamps of wave 0 of every workgroup for its first 8
 // tiles -- {K loop entered, K loop left, boundary left} -- read back with mi355_dev_qm_trace
 #ifdef QM_TRACE
-__device__ unsigned long long qm_trace_buf[256 * 32];
-#define QM_STAMP(slot) do { if (tid == 0 && blockIdx.x < 256 && qt_tile < 8) qm_trace_buf[blockIdx.x * 32 + qt_tile * 3 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long qm_trace_buf[256 * 64];   // per workgroup: 24 stamps; [32 + 4 k + wave]: cycles in the hand-over, k = 0 vmcnt wait / 1 lgkm + barrier of the first tile, 2 / 3 of the later tiles, 4: K-tiles counted (later tiles)
+#define QM_STAMP(slot) do { if (tid == 0 && blockIdx.x < 256 && qt_tile < 8) qm_trace_buf[blockIdx.x * 64 + qt_tile * 3 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define QM_TW0() const unsigned long long qw0_ = __builtin_amdgcn_s_memtime();
+#define QM_TW1() const unsigned long long qw1_ = __builtin_amdgcn_s_memtime();
+#define QM_TW2() { const unsigned long long qw2_ = __builtin_amdgcn_s_memtime(); if (qt_tile == 0) { qt_w[0] += qw1_ - qw0_; qt_w[1] += qw2_ - qw1_; } else if (qt_tile < 8) { qt_w[2] += qw1_ - qw0_; qt_w[3] += qw2_ - qw1_; qt_w[4] += 1; } }
 #else
 #define QM_STAMP(slot)
+#define QM_TW0()
+#define QM_TW1()
+#define QM_TW2()
 #endif
 // a lane-constant value the compiler must re-derive where it is used (gemm_lp256q.hip: hoisted staging addresses get spilled)
 __device__ __forceinline__ uint32_t opaque(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
@@ -217,21 +243,22 @@ gemm_lp256qm_kernel(gemm_args g)
     // is read into the same registers right behind MFMA 8 i + 7 (64 MFMAs before its first use): 32 registers instead of 64, which is
     // what lets the 96 held registers in.  The B fragments (srcA) are all in use until the k-step's last eight MFMAs: double-buffered.
     // Read id 0..7 = B fragment j into buffer NXT, 8..15 = A fragment i.
-    auto read_one = [&](auto buf, auto idx, const char *pa, const char *pb) {
+    auto read_one = [&](auto buf, auto idx, uint32_t pa, uint32_t pb) {     // pa / pb: LDS byte addresses (32-bit: no base add at the use)
         constexpr int BUF = decltype(buf)::value, R = decltype(idx)::value;
+        typedef const __attribute__((address_space(3))) frag *lfrag;
         if constexpr (BNN && (R < 8 || R >= 16)) {
             typedef short s16x4 __attribute__((ext_vector_type(4)));
             typedef short s16x8 __attribute__((ext_vector_type(8)));
             constexpr int JB = R & 7;
             constexpr bool HI = R >= 16;                                                                               // k 4-7: block row a + 1, 2 KiB on
-            const char *q8 = (JB & 1) ? reinterpret_cast<const char *>(reinterpret_cast<uintptr_t>(pb) ^ 32) : pb;     // odd column block: the other half
-            const auto q = (__attribute__((address_space(3))) s16x4 *)(q8 + (JB >> 1) * 256);
+            const uint32_t q8 = (JB & 1) ? (pb ^ 32u) : pb;                                                            // odd column block: the other half
+            const auto q = (__attribute__((address_space(3))) s16x4 *)(uintptr_t)(q8 + (uint32_t)((JB >> 1) * 256));
             const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(q + (HI ? 256 : 0));
             const s16x8 w = __builtin_shufflevector(v, v, 0, 1, 2, 3, 0, 1, 2, 3), cur = __builtin_bit_cast(s16x8, fb[BUF][JB]);
             if constexpr (HI) fb[BUF][JB] = __builtin_bit_cast(frag, (s16x8)__builtin_shufflevector(cur, w, 0, 1, 2, 3, 8, 9, 10, 11));
             else fb[BUF][JB] = __builtin_bit_cast(frag, (s16x8)__builtin_shufflevector(w, cur, 0, 1, 2, 3, 12, 13, 14, 15));
-        } else if constexpr (R < 8) fb[BUF][R] = *reinterpret_cast<const frag *>(pb + R * 16 * ROW_BYTES);
-        else fa[R - 8] = *reinterpret_cast<const frag *>(pa + (R - 8) * 16 * ROW_BYTES);
+        } else if constexpr (R < 8) fb[BUF][R] = *(lfrag)(uintptr_t)(pb + (uint32_t)(R * 16 * ROW_BYTES));
+        else fa[R - 8] = *(lfrag)(uintptr_t)(pa + (uint32_t)((R - 8) * 16 * ROW_BYTES));
     };
     auto dma_one = [&](auto is_b, auto jj, int64_t koff, char *base) {
         constexpr int J = decltype(jj)::value;
@@ -288,6 +315,7 @@ gemm_lp256qm_kernel(gemm_args g)
     // 2 p, 2 p + 1 of block row ii: after the exchange with lane l15 ^ 1 register 2 p holds the EVEN row of the lane pair, register
     // 2 p + 1 the odd one, bytes 128 p + 64 (l15 & 1) + 16 g: one store instruction = 8 rows x one whole 128-byte line.
     char *hbase = nullptr;
+    [[maybe_unused]] char *abl_base = nullptr;      // (QM_ABL & 4: the workgroup's first tile)
     bool held = false;           // P holds a finished tile whose stores are still to be issued (false only during a workgroup's first tile)
     const uint32_t pvoff = BNN ? (uint32_t)((l15 & ~1) * g.ldc * CSZ + 64 * (l15 & 1) + 32 * (g4 & 1) + 16 * (g4 >> 1))
                                : (uint32_t)((l15 & ~1) * g.ldc * CSZ + 64 * (l15 & 1) + 16 * g4);
@@ -309,9 +337,10 @@ gemm_lp256qm_kernel(gemm_args g)
         const u32x4 v = P[RB][II][2 * PP + ODD];
         if (QM_ABL & 1) { asm volatile("" ::"v"(v)); return; }
         char *sb_ = rb_base + (II * 16 + ODD) * rowbytes;
+        if (QM_ABL & 4) sb_ = abl_base + (II * 16 + ODD) * rowbytes;
 #if QM_STORE_FORM == 1
         const uint32_t so_ = pvoff;          // (a local copy: a const captured only by an asm operand is not odr-used)
-        asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 1" ::"v"(so_), "v"(v), "s"(sb_), "n"(PP * 128) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" QM_NT_SUFFIX "\n\ts_nop 1" ::"v"(so_), "v"(v), "s"(sb_), "n"(PP * 128) : "memory");
 #else
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(sb_ + PP * 128 + pvoff));
 #endif
@@ -373,10 +402,10 @@ gemm_lp256qm_kernel(gemm_args g)
     // 16 MFMAs n = N0 .. N0 + 15 of a k-step.  A read follows MFMA n where qm_read_at(k-step, n) >= 0 (below the kernel); DMASK bit b: a
     // DMA piece follows MFMA N0 + b.  KS = 0: transposition slots; KS = 1: store slots (head) + packing of finished blocks (DRAIN).
     // Instruction order pinned by sched_barrier after every group.
-#define QM_G(CUR, NXT, KS, N0, BIT, DMASK, IS_B, J0, FIRST, DRAIN, G)                                                 \
+#define QM_G(CUR, NXT, KS, N0, BIT, FIRST, DRAIN, G)                                                                  \
     mfma_one(IC<CUR>{}, IC<(N0) + (BIT)>{}, IC<FIRST>{});                                                             \
     if constexpr (qm_read_at(KS, (N0) + (BIT), BNN) >= 0) read_one(IC<NXT>{}, IC<(qm_read_at(KS, (N0) + (BIT), BNN) >= 0 ? qm_read_at(KS, (N0) + (BIT), BNN) : 0)>{}, rd_a, rd_b); \
-    if constexpr (((DMASK) >> (BIT)) & 1u) dma_one(IC<IS_B>{}, IC<(J0) + __builtin_popcount((DMASK) & ((1u << (BIT)) - 1u))>{}, dma_koff, dma_base); \
+    gap_work(IC<KS>{}, IC<(N0) + (BIT)>{});                                                                           \
     if constexpr ((DRAIN) && (N0) + (BIT) >= QM_LAG) {                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
         drain_one(IC<((N0) + (BIT) >= QM_LAG ? (N0) + (BIT) - QM_LAG : 0)>{});                                        \
@@ -385,15 +414,11 @@ gemm_lp256qm_kernel(gemm_args g)
     if constexpr ((KS) == 0 && (FIRST)) { __builtin_amdgcn_sched_barrier(0); bd_gap(IC<(N0) + (BIT)>{}); }           \
     if constexpr ((KS) == 1 && (G) >= 0 && (N0) == 0) { __builtin_amdgcn_sched_barrier(0); st_gap(IC<(G)>{}, IC<(N0) + (BIT)>{}, rb_base); } \
     __builtin_amdgcn_sched_barrier(0);
-#define QM_Q(CUR, NXT, KS, N0, DMASK, IS_B, J0, FIRST, DRAIN, G)                                                      \
-    QM_G(CUR, NXT, KS, N0, 0, DMASK, IS_B, J0, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 1, DMASK, IS_B, J0, FIRST, DRAIN, G)   \
-    QM_G(CUR, NXT, KS, N0, 2, DMASK, IS_B, J0, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 3, DMASK, IS_B, J0, FIRST, DRAIN, G)   \
-    QM_G(CUR, NXT, KS, N0, 4, DMASK, IS_B, J0, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 5, DMASK, IS_B, J0, FIRST, DRAIN, G)   \
-    QM_G(CUR, NXT, KS, N0, 6, DMASK, IS_B, J0, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 7, DMASK, IS_B, J0, FIRST, DRAIN, G)   \
-    QM_G(CUR, NXT, KS, N0, 8, DMASK, IS_B, J0, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 9, DMASK, IS_B, J0, FIRST, DRAIN, G)   \
-    QM_G(CUR, NXT, KS, N0, 10, DMASK, IS_B, J0, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 11, DMASK, IS_B, J0, FIRST, DRAIN, G) \
-    QM_G(CUR, NXT, KS, N0, 12, DMASK, IS_B, J0, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 13, DMASK, IS_B, J0, FIRST, DRAIN, G) \
-    QM_G(CUR, NXT, KS, N0, 14, DMASK, IS_B, J0, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 15, DMASK, IS_B, J0, FIRST, DRAIN, G)
+#define QM_Q(CUR, NXT, KS, N0, FIRST, DRAIN, G)                                                                       \
+    QM_G(CUR, NXT, KS, N0, 0, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 1, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 2, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 3, FIRST, DRAIN, G) \
+    QM_G(CUR, NXT, KS, N0, 4, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 5, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 6, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 7, FIRST, DRAIN, G) \
+    QM_G(CUR, NXT, KS, N0, 8, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 9, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 10, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 11, FIRST, DRAIN, G) \
+    QM_G(CUR, NXT, KS, N0, 12, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 13, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 14, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 15, FIRST, DRAIN, G)
 
     // ---- first tile of this workgroup: units 0..3 (its K-tiles 0 and 1), then the first fragments --------------------------------
     uint32_t L = blockIdx.x;
@@ -415,7 +440,7 @@ gemm_lp256qm_kernel(gemm_args g)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     {
-        const char *rd_a = smem + ro_a, *rd_b = smem + UNIT_BYTES + ro_b;
+        const uint32_t rd_a = lds_addr_of(smem) + (uint32_t)ro_a, rd_b = lds_addr_of(smem) + (uint32_t)(UNIT_BYTES + ro_b);
         read_one(IC<0>{}, IC<0>{}, rd_a, rd_b); read_one(IC<0>{}, IC<8>{}, rd_a, rd_b); read_one(IC<0>{}, IC<1>{}, rd_a, rd_b); read_one(IC<0>{}, IC<2>{}, rd_a, rd_b);
         read_one(IC<0>{}, IC<3>{}, rd_a, rd_b); read_one(IC<0>{}, IC<4>{}, rd_a, rd_b); read_one(IC<0>{}, IC<5>{}, rd_a, rd_b); read_one(IC<0>{}, IC<6>{}, rd_a, rd_b);
         read_one(IC<0>{}, IC<7>{}, rd_a, rd_b); read_one(IC<0>{}, IC<9>{}, rd_a, rd_b); read_one(IC<0>{}, IC<10>{}, rd_a, rd_b); read_one(IC<0>{}, IC<11>{}, rd_a, rd_b);
@@ -427,6 +452,7 @@ gemm_lp256qm_kernel(gemm_args g)
     }
     __builtin_amdgcn_sched_barrier(0);
 
+    [[maybe_unused]] uint32_t qm_pad = 0, qm_padv = 0;
     int sa = 0;                          // ring byte offset of the A unit of the K-tile being multiplied
     int sb = UNIT_BYTES;                 // ... and of its B unit; the ring runs on across output tiles
     auto adv = [](int x, int n) { x += n * UNIT_BYTES; return x >= LDS_BYTES ? x - LDS_BYTES : x; };
@@ -438,49 +464,141 @@ gemm_lp256qm_kernel(gemm_args g)
     int kbase = 0;                       // K-tile index of the issue side = t + 2 - kbase
     int t = 0;
 
+    // ---- the K-tile's bookkeeping, one phase ahead, in MFMA gaps that carry nothing else --------------------------------------------------
+    // Measured on config C3 (profiles/r06_qm_pad_cost.txt): a scalar or vector instruction behind an MFMA whose gap is empty, or holds one
+    // other instruction, costs nothing; sixteen at the head of the K-tile (no MFMA in flight) cost 4 % = 6.4 cycles each, and a fifth
+    // instruction in a gap that already held four as much.  Until this round a K-tile opened with 31 scalar instructions (ring arithmetic,
+    // the issue side's tile switch and K offset, read and DMA addresses) and every DMA piece was five (64-bit base add, M0, the M0 hazard
+    // nop, the load).  Now:
+    //   * everything a K-tile's first half needs (pc_a, pc_m4, pc_ra0, pc_rb0; the tile switch and the K offset behind them) is computed in
+    //     the previous K-tile's gaps behind MFMAs 0 .. 14 of k-step 1, what its second half needs (pc_b, pc_m5, pc_ra1, pc_rb1) in its own
+    //     k-step 0: the registers are dead there (in-place, no copies), and a K-tile opens with its first MFMA;
+    //   * a DMA piece is one v_add (its lane offset: the operand's + the piece's row offset, a gap earlier) and the load: the wave-uniform
+    //     base of the unit stays in one SGPR pair, and M0 is written twice per unit instead of eight times -- the instruction offset of
+    //     global_load_lds moves BOTH addresses (tools/dev/lds_dma_offset_probe.hip), so pieces J and J + 1 .. J + 3 share an M0 with offsets
+    //     0 .. 3072 and the lane offset takes the 1 KiB steps back out (DMA_BIAS keeps it non-negative for every piece and layout).
+#ifndef QM_PINMASK
+#define QM_PINMASK 0xffffffffu
+#endif
+#define QM_PINS(i, x) do { if constexpr ((QM_PINMASK >> (i)) & 1u) asm volatile("" : "+s"(x)); } while (0)
+    constexpr uint32_t DMA_BIAS = 3072;
+    const char *pc_a = nullptr, *pc_b = nullptr;      // wave-uniform source of this K-tile's A pieces (unit 2t+4) / B pieces (unit 2t+5), less DMA_BIAS
+    uint32_t pc_m4 = 0, pc_m5 = 0;                    // LDS byte address of this wave's first piece of those units
+    uint32_t pc_ra0 = 0, pc_rb0 = 0;                  // ring offsets (per lane) of the fragment reads issued during k-step 0 (this K-tile's k-step 1) ...
+    uint32_t pc_ra1 = 0, pc_rb1 = 0;                  // ... and behind the hand-over (K-tile t + 1's k-step 0)
+    uint32_t koff = 0;                                // byte offset along K of the K-tile the issue side is at (K * 2 bytes < 2^32)
+    uint32_t dma_vt = 0;                              // the lane offset of the next piece
+    auto set_m0 = [&](uint32_t v) { asm volatile("s_mov_b32 m0, %0" ::"s"(v) : "memory"); };
+    auto piece_off = [&](auto is_b, auto jj) -> uint32_t {      // (loop-invariant: 8 + 8 SGPRs, as before)
+        constexpr int J = decltype(jj)::value;
+        constexpr uint32_t ADJ = DMA_BIAS - (uint32_t)(J & 3) * 1024u;
+        if constexpr (decltype(is_b)::value && BNN) return (uint32_t)(4 * (J >> 1)) * ldb_b + (uint32_t)((J & 1) * 256) + ADJ;
+        else if constexpr (decltype(is_b)::value) return (uint32_t)(32 * (J >> 2) + 16 * (J & 1) + 4 * ((J >> 1) & 1)) * ldb_b + ADJ;
+        else return (uint32_t)(8 * J) * lda_b + ADJ;
+    };
+    auto dma_prep = [&](auto is_b, auto jj) {
+        constexpr int J = decltype(jj)::value;
+        uint32_t v;
+        if constexpr (decltype(is_b)::value && BNN) v = ((J & 4) ? voff_b1 : voff_b0) + piece_off(is_b, jj);
+        else if constexpr (decltype(is_b)::value) v = ((J & 1) ? voff_b1 : voff_b0) + piece_off(is_b, jj);
+        else v = ((J & 1) ? voff_a1 : voff_a0) + piece_off(is_b, jj);
+        asm volatile("" : "+v"(v));
+        dma_vt = v;
+    };
+    auto dma_go = [&](auto jj, const char *base) {
+        constexpr int J = decltype(jj)::value;
+        const uint32_t vt_ = dma_vt;         // (a local copy: a variable captured only by an asm operand is not odr-used)
+        asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(vt_), "s"(base), "n"((J & 3) * 1024) : "memory");
+    };
+    // second-half state of THIS K-tile (k-step 0 gaps) and first-half state of the NEXT one (k-step 1 gaps in front of the hand-over)
+    const uint32_t lds0 = lds_addr_of(smem);
+    const uint32_t ra_k0 = lds0 + (uint32_t)ro_a, ra_k1 = lds0 + (uint32_t)(ro_a ^ 64);
+    const uint32_t rb_k0 = lds0 + (uint32_t)ro_b, rb_k1 = lds0 + (uint32_t)(BNN ? ro_b + KS1_B : (ro_b ^ 64));
+    const char *iss_a = iss.ua - DMA_BIAS, *iss_b = iss.ub - DMA_BIAS;     // the issue side's panels (iss), biased
+    int pre_sw = 0;
+    auto gap_work = [&](auto kss, auto nn) {
+        constexpr int KS = decltype(kss)::value, N = decltype(nn)::value;
+        if constexpr (KS == 0) {
+            // (pure scalar work floats up to one gap ahead of its pin: odd N -- the gaps behind even MFMAs carry the fragment reads)
+            if constexpr (N == 0) set_m0(pc_m4);
+            if constexpr (N == 32) set_m0(pc_m4 + 4096);
+            if constexpr ((N & 7) == 2) dma_prep(IC<0>{}, IC<(N >> 3)>{});
+            if constexpr ((N & 7) == 3) dma_go(IC<(N >> 3)>{}, pc_a);
+            if constexpr (N == 5) { pc_m5 = lds0 + (uint32_t)(sa + dst_piece); QM_PINS(4, pc_m5); }         // unit 2t+5 takes the slot of unit 2t
+            if constexpr (N == 9) { sa = adv(sa, 2); QM_PINS(1, sa); }                                       // from here on: unit 2t+2
+            if constexpr (N == 17) { pc_ra1 = (uint32_t)sa + ra_k0; asm volatile("" : "+v"(pc_ra1)); }
+            if constexpr (N == 25) {
+                if constexpr (BNN) pc_b = iss_b + (int64_t)koff * g.ldb; else pc_b = iss_b + koff;
+                QM_PINS(3, pc_b);
+            }
+            if constexpr (N == 37) { pc_m4 = lds0 + (uint32_t)(sb + dst_piece); QM_PINS(11, pc_m4); }        // K-tile t + 1: unit 2t+6 takes the slot of unit 2t+1
+            if constexpr (N == 41) { sb = adv(sb, 2); QM_PINS(2, sb); }                                      // from here on: unit 2t+3
+            if constexpr (N == 45) { pc_rb1 = (uint32_t)sb + rb_k0; asm volatile("" : "+v"(pc_rb1)); }
+        } else {
+            // B unit 2t+5 behind the hand-over: pieces 0..3 behind MFMAs 19, 27, 35, 43, pieces 4..7 behind 49, 53, 57, 61
+            if constexpr (N == 13) set_m0(pc_m5);
+            if constexpr (N == 46) set_m0(pc_m5 + 4096);
+            if constexpr (N >= 18 && N < 48 && (N & 7) == 2) dma_prep(IC<1>{}, IC<((N - 18) >> 3)>{});
+            if constexpr (N >= 19 && N < 48 && (N & 7) == 3) dma_go(IC<((N - 19) >> 3)>{}, pc_b);
+            if constexpr (N >= 48 && (N & 3) == 0) dma_prep(IC<1>{}, IC<(4 + ((N - 48) >> 2))>{});
+            if constexpr (N >= 49 && (N & 3) == 1) dma_go(IC<(4 + ((N - 49) >> 2))>{}, pc_b);
+            // K-tile t + 1
+            if constexpr (N == 1) { pre_sw = (t + 1 == nk - 2 && has_next) ? 1 : 0; }
+            if constexpr (N == 3) { iss_a = pre_sw ? nxt.ua - DMA_BIAS : iss_a; QM_PINS(6, iss_a); }
+            if constexpr (N == 5) { iss_b = pre_sw ? nxt.ub - DMA_BIAS : iss_b; QM_PINS(7, iss_b); }
+            if constexpr (N == 7) { kbase = pre_sw ? nk : kbase; QM_PINS(8, kbase); }
+            if constexpr (N == 9) { koff = (uint32_t)min(t + 3 - kbase, nk - 1) * (uint32_t)ROW_BYTES; QM_PINS(9, koff); }   // clamp: only without a next tile
+            if constexpr (N == 11) { pc_a = iss_a + koff; QM_PINS(10, pc_a); }
+            if constexpr (N == 12) { pc_ra0 = (uint32_t)sa + ra_k1; asm volatile("" : "+v"(pc_ra0)); }
+            if constexpr (N == 14) { pc_rb0 = (uint32_t)sb + rb_k1; asm volatile("" : "+v"(pc_rb0)); }
+            if constexpr (N == 62) { ++t; QM_PINS(14, t); }
+        }
+    };
+    // the state K-tile 0 of this workgroup's first tile starts from (iss = cur, kbase = 0)
+    koff = 2u * ROW_BYTES;
+    pc_a = iss_a + koff;
+    pc_m4 = lds0 + (uint32_t)(adv(sa, 4) + dst_piece);
+    pc_ra0 = (uint32_t)sa + ra_k1;
+    pc_rb0 = (uint32_t)sb + rb_k1;
+
     // one basic block per K-tile (gemm_lp256q.hip: hipcc schedules per block for register pressure and MFMAs carry no ordering edge)
 #define QM_BLOCK_END() if (__builtin_expect(t > 0x3fffffff, 0)) asm volatile("s_trap 2");
     // One K-tile.  FIRST: K-tile 0 of an output tile (zero C operand in k-step 0).  LASTK: the tile's last K-tile (blocks are packed
     // as their last MFMA retires).  WAITN: LDS-DMA pieces + stores that may still fly at the hand-over when no group is stored here
     // (8: unit 2t+4; 16: + the 8 boundary stores in front of it).  G >= 0: store group G of the row block in P[0] -- its stores sit
     // in front of the hand-over and may fly too (vmcnt(8 + D)); everything older, the previous group included, has landed.
-#define QM_KTILE(FIRST, LASTK, WAITN, G)                                                                            \
+#define QM_KTILE(FIRST, LASTK, WAITN, G, BE)                                                                        \
     {                                                                                                               \
-        const int sa1 = adv(sa, 2), sb1 = adv(sb, 2);     /* units of K-tile t+1 */                                  \
-        const int s4 = adv(sa, 4);                        /* unit 2t+4 -> slot of unit 2t-1 */                       \
-        const int s5 = sa;                                /* unit 2t+5 -> slot of unit 2t   */                       \
-        if (t == nk - 2 && has_next) { iss = nxt; kbase = nk; }   /* from here on the stream feeds the next tile */  \
-        const int64_t dma_koff = (int64_t)min(t + 2 - kbase, nk - 1) * ROW_BYTES;   /* clamp: only without a next tile */ \
-        const char *rd_a, *rd_b;                                                                                    \
-        char *dma_base;                                                                                             \
-        rd_a = smem + sa + (ro_a ^ 64); rd_b = smem + sb + (BNN ? ro_b + KS1_B : (ro_b ^ 64)); dma_base = smem + s4 + dst_piece; \
-        QM_Q(0, 1, 0, 0, 0x0808u, 0, 0, FIRST, 0, G) QM_Q(0, 1, 0, 16, 0x0808u, 0, 2, FIRST, 0, G)                   \
-        QM_Q(0, 1, 0, 32, 0x0808u, 0, 4, FIRST, 0, G) QM_Q(0, 1, 0, 48, 0x0808u, 0, 6, FIRST, 0, G)                  \
-        QM_Q(1, 0, 1, 0, 0u, 0, 0, 0, LASTK, G)                                                                      \
+        uint32_t rd_a, rd_b;                                                                                        \
+        rd_a = pc_ra0; rd_b = pc_rb0;                                                                 \
+        QM_Q(0, 1, 0, 0, FIRST, 0, G) QM_Q(0, 1, 0, 16, FIRST, 0, G)                                                 \
+        QM_Q(0, 1, 0, 32, FIRST, 0, G) QM_Q(0, 1, 0, 48, FIRST, 0, G)                                                \
+        QM_Q(1, 0, 1, 0, 0, LASTK, G)                                                                                \
+        QM_TW0()                                                                                                    \
         if constexpr ((G) >= 0) { if (held) WAIT_VMCNT(8 + D); else WAIT_VMCNT(8); }   /* my share of the next K-tile landed */ \
         else if constexpr ((WAITN) == 16) { if (held) WAIT_VMCNT(16); else WAIT_VMCNT(8); }                           \
         else WAIT_VMCNT(WAITN);                                                                                     \
+        QM_TW1()                                                                                                    \
         WAIT_LGKM0();                    /* my reads of this K-tile are complete */                                  \
         __builtin_amdgcn_s_barrier();    /* BAR_t */                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
-        rd_a = smem + sa1 + ro_a; rd_b = smem + sb1 + ro_b; dma_base = smem + s5 + dst_piece;                        \
-        if constexpr (LASTK) stage_off = sb + wave * 8192 + (int)opaque((uint32_t)(l15 * 256 + (BNN ? 8 * (g4 & 1) : 0)));   /* B unit of this K-tile: dead since BAR_t */ \
-        QM_Q(1, 0, 1, 16, 0x0808u, 1, 0, 0, LASTK, G) QM_Q(1, 0, 1, 32, 0x0808u, 1, 2, 0, LASTK, G)                  \
-        QM_Q(1, 0, 1, 48, 0x2222u, 1, 4, 0, LASTK, G)                                                                \
+        QM_TW2()                                                                                                    \
+        rd_a = pc_ra1; rd_b = pc_rb1;                                                                 \
+        if constexpr (LASTK) stage_off = adv(sb, 3) + wave * 8192 + (int)opaque((uint32_t)(l15 * 256 + (BNN ? 8 * (g4 & 1) : 0)));   /* B unit of this K-tile (sb is unit 2t+3's by now): dead since BAR_t */ \
+        QM_Q(1, 0, 1, 16, 0, LASTK, G) QM_Q(1, 0, 1, 32, 0, LASTK, G)                                                \
+        QM_Q(1, 0, 1, 48, 0, LASTK, G)                                                                               \
         if constexpr (LASTK) {                                                                                      \
             drain_one(IC<64 - (QM_LAG >= 3 ? 3 : QM_LAG)>{}); drain_one(IC<64 - (QM_LAG >= 2 ? 2 : QM_LAG)>{}); drain_one(IC<63>{}); \
             __builtin_amdgcn_sched_barrier(0);                                                                      \
         }                                                                                                           \
         if constexpr (FIRST) pin_acc();                                                                             \
-        sa = sa1;                                                                                                   \
-        sb = sb1;                                                                                                   \
-        ++t;                                                                                                        \
-        QM_BLOCK_END()                                                                                              \
+        if constexpr (BE) { QM_BLOCK_END() }                                                                        \
     }
     static_assert(QM_LAG >= 1 && QM_LAG <= 3, "the tail of the packing above covers up to three blocks");
 
 #ifdef QM_TRACE
     int qt_tile = 0;
+    unsigned long long qt_w[5] = {0, 0, 0, 0, 0};
 #endif
     constexpr int GPR = 8 / D;           // K-tiles (store groups) per held row block
     for (;;) {
@@ -496,14 +614,14 @@ gemm_lp256qm_kernel(gemm_args g)
         // held / not held -- met in front of the last K-tile with different register assignments, and hipcc bridged them with five
         // fragment spills + reloads behind an s_waitcnt vmcnt(0) at the top of every tile).
         // K-tile 0: the 8 boundary stores of the previous tile sit between unit 3 and unit 4 of this stream
-        QM_KTILE(1, 0, 16, -1)
+        QM_KTILE(1, 0, 16, -1, 1)
         // drip phase, K-tiles 1 .. 24 / D: the row block in P[0] leaves, D stores per K-tile, then the next one moves down
 #pragma nounroll
         for (int rb = 0; rb < 3; ++rb) {
-            QM_KTILE(0, 0, 8, 0)
-            if constexpr (GPR > 1) QM_KTILE(0, 0, 8, 1)
-            if constexpr (GPR > 2) { QM_KTILE(0, 0, 8, 2) QM_KTILE(0, 0, 8, 3) }
-            if constexpr (GPR > 4) { QM_KTILE(0, 0, 8, 4) QM_KTILE(0, 0, 8, 5) QM_KTILE(0, 0, 8, 6) QM_KTILE(0, 0, 8, 7) }
+            QM_KTILE(0, 0, 8, 0, 1)
+            if constexpr (GPR > 1) QM_KTILE(0, 0, 8, 1, 1)
+            if constexpr (GPR > 2) { QM_KTILE(0, 0, 8, 2, 1) QM_KTILE(0, 0, 8, 3, 1) }
+            if constexpr (GPR > 4) { QM_KTILE(0, 0, 8, 4, 1) QM_KTILE(0, 0, 8, 5, 1) QM_KTILE(0, 0, 8, 6, 1) QM_KTILE(0, 0, 8, 7, 1) }
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -511,8 +629,8 @@ gemm_lp256qm_kernel(gemm_args g)
             rb_base += rowblock;
         }
 #pragma nounroll
-        while (t < nk - 1) QM_KTILE(0, 0, 8, -1)     // (the first of these waits for the last dripped stores: they are older than unit 2t+4)
-        QM_KTILE(0, 1, 8, -1)                                     // t == nk - 1: block rows 0..5 are packed into P, 6..7 into the staging image
+        while (t < nk - 1) QM_KTILE(0, 0, 8, -1, 0)     // (the first of these waits for the last dripped stores: they are older than unit 2t+4)
+        QM_KTILE(0, 1, 8, -1, 1)                                     // t == nk - 1: block rows 0..5 are packed into P, 6..7 into the staging image
         QM_STAMP(1);
 
         // ---- tile boundary: block rows 6, 7 through this wave's 8 KiB of the dead B slot ------------------------------------------
@@ -522,6 +640,7 @@ gemm_lp256qm_kernel(gemm_args g)
             bstage = (uint32_t)(adv(sb, 3) + wave * 8192);          // slot of the last B unit, my DMA region of it
             bbase = wbase + (int64_t)96 * rowbytes;
             hbase = wbase;
+            if ((QM_ABL & 4) && !held) abl_base = wbase;
             held = true;
             bread(IC<0>{});                                         // (same-wave hand-over: the DS ops of one wave execute in order)
             if constexpr (!QM_BDRIP) {
@@ -540,8 +659,13 @@ gemm_lp256qm_kernel(gemm_args g)
         L = Lnext;
     }
 #undef QM_KTILE
+    if (QM_PAD && (qm_pad == 0xdeadbeefu || qm_padv == 0xdeadbeefu)) asm volatile("s_trap 2");
 #undef QM_Q
 #undef QM_G
+#ifdef QM_TRACE
+    if (lane == 0 && blockIdx.x < 256)
+        for (int k = 0; k < 5; ++k) qm_trace_buf[blockIdx.x * 64 + 32 + 4 * k + wave] = qt_w[k];
+#endif
     // ---- the last tile of this workgroup has no K loop to hide under: its held stores leave at once ------------------------------
 #define QM_FLUSH(RB)                                                                                                 \
     transpose_word(IC<RB>{}, IC<0>{}, IC<0>{}); transpose_word(IC<RB>{}, IC<0>{}, IC<1>{}); transpose_word(IC<RB>{}, IC<0>{}, IC<2>{}); transpose_word(IC<RB>{}, IC<0>{}, IC<3>{}); \
@@ -580,7 +704,7 @@ int drip_for(int64_t nk)                 // fewest stores per K-tile whose drip 
 #ifdef QM_TRACE
 extern "C" __attribute__((visibility("default"))) int mi355_dev_qm_trace(unsigned long long *host_out)
 {
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(qm_trace_buf), sizeof(unsigned long long) * 256 * 32);
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(qm_trace_buf), sizeof(unsigned long long) * 256 * 64);
 }
 #endif
 

@@ -12,7 +12,7 @@ from cubecl_amd import _native as N
 launches = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 tb = 0 if (len(sys.argv) > 2 and sys.argv[2] == "nn") else 1
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 512
-M = 2048
+M = int(os.environ.get("PROBE_M", 2048))
 cl = Mi355Runtime.client(); lib, ctx = cl.lib, cl.ctx
 ev = bench.Events(cl)
 a = TensorHandle.uniform(cl, (B, M, M), ElemType.BF16, bench.SEED, 500, -1.0, 1.0)
