@@ -327,8 +327,10 @@ gemm_lp256qm_kernel(gemm_args g)
         const uint32_t a = P[RB][II][2 * PP][W], b = P[RB][II][2 * PP + 1][W];
         const uint32_t ax = (uint32_t)__builtin_amdgcn_mov_dpp((int)a, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]: lane ^ 1
         const uint32_t bx = (uint32_t)__builtin_amdgcn_mov_dpp((int)b, 0xB1, 0xF, 0xF, true);
-        P[RB][II][2 * PP][W] = odd1 ? bx : a;
-        P[RB][II][2 * PP + 1][W] = odd1 ? b : ax;
+        uint32_t lo = odd1 ? bx : a, hi = odd1 ? b : ax;
+        asm volatile("" : "+v"(lo), "+v"(hi));          // (left alone, hipcc sinks the selects to the store that reads them: ten instructions in one MFMA gap)
+        P[RB][II][2 * PP][W] = lo;
+        P[RB][II][2 * PP + 1][W] = hi;
     };
     // store N (0..7) of row block RB: block row ii = N >> 2, line p = (N >> 1) & 1, odd rows = N & 1; rb_base = wave-uniform address of
     // the row block's first row
@@ -340,27 +342,48 @@ gemm_lp256qm_kernel(gemm_args g)
         if (QM_ABL & 4) sb_ = abl_base + (II * 16 + ODD) * rowbytes;
 #if QM_STORE_FORM == 1
         const uint32_t so_ = pvoff;          // (a local copy: a const captured only by an asm operand is not odr-used)
+        // (the data registers are read after the issue and are dead behind it as far as hipcc knows -- it hands them to the next VALU result or
+        //  LDS read at once: s_nop 1.  Without it the row-major-rhs form, whose next instruction is a v_xor, stored garbage: round 6)
         asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" QM_NT_SUFFIX "\n\ts_nop 1" ::"v"(so_), "v"(v), "s"(sb_), "n"(PP * 128) : "memory");
 #else
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(sb_ + PP * 128 + pvoff));
 #endif
     };
-    // the slot behind MFMA n (32 <= n < 64, even) of k-step 0 of the K-tile that carries store group G of the row block in P[0]: one
-    // word of a pair whose first store is in the group
+    // the slots behind MFMAs 32 .. 63 of k-step 0 of the K-tile that carries store group G of the row block in P[0]: one word of a pair whose
+    // first store is in the group takes two slots -- the two lane exchanges, then the two selects (four VALU instructions behind one MFMA
+    // cost the K loop, two do not: profiles/r06_qm_pad_cost.txt)
+    uint32_t tr_ax = 0, tr_bx = 0;
     auto tr_gap = [&](auto gg, auto nn) {
         constexpr int G = decltype(gg)::value, N = decltype(nn)::value;
-        if constexpr (G >= 0 && N >= 32 && (N & 1) == 0) {
-            constexpr int S = (N - 32) >> 1, K = S >> 2, W = S & 3;                 // K-th pair of this K-tile, word W
+        if constexpr (G >= 0 && N >= 32) {
+            constexpr int S = N - 32, K = S >> 3, W = (S >> 1) & 3, H = S & 1;      // K-th pair of this K-tile, word W, half H
             constexpr int NPAIR = D >= 2 ? D / 2 : ((G & 1) == 0 ? 1 : 0);
             constexpr int FIRST_PAIR = D >= 2 ? G * (D / 2) : G / 2;
-            if constexpr (K < NPAIR) transpose_word(IC<0>{}, IC<FIRST_PAIR + (K < NPAIR ? K : 0)>{}, IC<W>{});
+            if constexpr (K < NPAIR) {
+                constexpr int TP = FIRST_PAIR + (K < NPAIR ? K : 0), II = TP >> 1, PP = TP & 1;
+                const uint32_t a = P[0][II][2 * PP][W], b = P[0][II][2 * PP + 1][W];
+                if constexpr (H == 0) {
+                    tr_ax = (uint32_t)__builtin_amdgcn_mov_dpp((int)a, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]: lane ^ 1
+                    tr_bx = (uint32_t)__builtin_amdgcn_mov_dpp((int)b, 0xB1, 0xF, 0xF, true);
+                    asm volatile("" : "+v"(tr_ax), "+v"(tr_bx));
+                } else {
+                    uint32_t lo = odd1 ? tr_bx : a, hi = odd1 ? b : tr_ax;
+                    asm volatile("" : "+v"(lo), "+v"(hi));
+                    P[0][II][2 * PP][W] = lo;
+                    P[0][II][2 * PP + 1][W] = hi;
+                }
+            }
         }
     };
-    // the slot behind MFMA n (odd, < 2 D) of the head of k-step 1: store (n - 1) / 2 of group G
+    // the slots behind MFMAs 20, 22, 24, 28, 30, 32, 36, 38 of k-step 1 -- BEHIND the hand-over, between the B pieces: store i < D of group G.
+    // (Until round 6 the stores sat in front of the hand-over and its wait allowed them to fly, vmcnt(8 + D) -- a count that differs between
+    //  a workgroup's first tile and the others: two branches per K-tile.  Behind the hand-over the wait of the NEXT K-tile, vmcnt(8) = its own
+    //  eight A pieces, covers them whether they exist or not.)
     auto st_gap = [&](auto gg, auto nn, char *rb_base) {
         constexpr int G = decltype(gg)::value, N = decltype(nn)::value;
-        if constexpr (G >= 0 && (N & 1) == 1 && N < 2 * D) {
-            if (held) store_one(IC<0>{}, IC<(G >= 0 ? G : 0) * D + (N >> 1)>{}, rb_base);    // (uniform branch: the workgroup's first tile has nothing to store yet)
+        constexpr int I = N == 20 ? 0 : N == 22 ? 1 : N == 24 ? 2 : N == 28 ? 3 : N == 30 ? 4 : N == 32 ? 5 : N == 36 ? 6 : N == 38 ? 7 : -1;
+        if constexpr (G >= 0 && I >= 0 && I < D) {
+            if (held) store_one(IC<0>{}, IC<(G >= 0 ? G : 0) * D + (I >= 0 ? I : 0)>{}, rb_base);    // (uniform branch: the workgroup's first tile has nothing to store yet)
         }
     };
 
@@ -412,7 +435,7 @@ gemm_lp256qm_kernel(gemm_args g)
     }                                                                                                                 \
     if constexpr ((KS) == 0 && (G) >= 0) { __builtin_amdgcn_sched_barrier(0); tr_gap(IC<(G)>{}, IC<(N0) + (BIT)>{}); } \
     if constexpr ((KS) == 0 && (FIRST)) { __builtin_amdgcn_sched_barrier(0); bd_gap(IC<(N0) + (BIT)>{}); }           \
-    if constexpr ((KS) == 1 && (G) >= 0 && (N0) == 0) { __builtin_amdgcn_sched_barrier(0); st_gap(IC<(G)>{}, IC<(N0) + (BIT)>{}, rb_base); } \
+    if constexpr ((KS) == 1 && (G) >= 0 && (N0) >= 16 && (N0) < 48) { __builtin_amdgcn_sched_barrier(0); st_gap(IC<(G)>{}, IC<(N0) + (BIT)>{}, rb_base); } \
     __builtin_amdgcn_sched_barrier(0);
 #define QM_Q(CUR, NXT, KS, N0, FIRST, DRAIN, G)                                                                       \
     QM_G(CUR, NXT, KS, N0, 0, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 1, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 2, FIRST, DRAIN, G) QM_G(CUR, NXT, KS, N0, 3, FIRST, DRAIN, G) \
@@ -575,8 +598,7 @@ gemm_lp256qm_kernel(gemm_args g)
         QM_Q(0, 1, 0, 32, FIRST, 0, G) QM_Q(0, 1, 0, 48, FIRST, 0, G)                                                \
         QM_Q(1, 0, 1, 0, 0, LASTK, G)                                                                                \
         QM_TW0()                                                                                                    \
-        if constexpr ((G) >= 0) { if (held) WAIT_VMCNT(8 + D); else WAIT_VMCNT(8); }   /* my share of the next K-tile landed */ \
-        else if constexpr ((WAITN) == 16) { if (held) WAIT_VMCNT(16); else WAIT_VMCNT(8); }                           \
+        if constexpr ((WAITN) == 16) { if (held) WAIT_VMCNT(16); else WAIT_VMCNT(8); }                           \
         else WAIT_VMCNT(WAITN);                                                                                     \
         QM_TW1()                                                                                                    \
         WAIT_LGKM0();                    /* my reads of this K-tile are complete */                                  \
