@@ -23,7 +23,7 @@ TABLE = [
     ("ragged tiles, four rounds: the one-tile-per-workgroup 16x16x32 kernel", (8200, 8200, 8192, BF, None, 0, 1, 1), "LP_256M16", (0, 0)),
     ("1.5 rounds of full 256^2 tiles, 16-bit C: the persistent 16x16x32 loop (round 6; until then the 32x32x16 kernel)", (6144, 4096, 8192, BF, None, 0, 1, 1), "LP_256QM", (0, 0)),
     ("... with an f32 C, not yet power-bound: the 32x32x16 kernel", (6144, 4096, 8192, BF, F32, 0, 1, 1), "LP_256W4", (0, 0)),
-    ("C3 with the reference's default rhs layout: the 32x32x16 kernel (the 16x16x32 transposing-read form is a tie there, round 6)", (8192, 8192, 8192, BF, None, 0, 0, 1), "LP_256W4", (0, 0)),
+    ("C3 with the reference's default rhs layout: the persistent 16x16x32 kernel's transposing-read form (round 6, second K loop: 1 474 -> 1 617 TFLOP/s)", (8192, 8192, 8192, BF, None, 0, 0, 1), "LP_256QM", (0, 0)),
     ("... at K = 4096: the persistent 16x16x32 kernel's row-major form (1 401 -> 1 444 TFLOP/s)", (8192, 8192, 4096, BF, None, 0, 0, 1), "LP_256QM", (0, 0)),
     ("C2: 4096^3 f32", (4096, 4096, 4096, F32, F32, 0, 1, 1), "LP_256W4", (0, 0)),
     ("C2, row-major rhs", (4096, 4096, 4096, F32, F32, 0, 0, 1), "LP_256W4", (0, 0)),
@@ -68,14 +68,14 @@ TABLE = [
     ("two matrices of 2048^2 x 8192: the table's call", (2048, 2048, 8192, BF, None, 0, 1, 2), "LP_256X128", (0, 0)),
     ("short K in the band: 192^2 (17.7 us; 256 x 192 20.0, 128^2 19.1)", (2560, 2560, 1024, BF, None, 0, 1, 1), "LP_192X192", (0, 0)),
     ("one round of 256 x 192 tiles where 192^2 would need two", (4096, 3072, 4096, BF, None, 0, 1, 1), "LP_256X192", (0, 0)),
-    ("196 tiles of 256^2: every narrower tile needs a second round", (3584, 3584, 3584, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
+    ("196 tiles of 256^2: every narrower tile needs a second round (the 16x16x32 K loop: 80.2 -> 75.2 us, round 6)", (3584, 3584, 3584, BF, None, 0, 1, 1), "LP_256QM", (0, 0)),
     ("a row-major rhs through the narrow tiles' transposing-read image (1192 TFLOP/s against 988 on 144 square tiles)", (3072, 3072, 3072, BF, None, 0, 0, 1), "LP_192X192", (0, 0)),
     ("row-major rhs, one round of 256 x 192 tiles", (4096, 3072, 4096, BF, None, 0, 0, 1), "LP_256X192", (0, 0)),
     ("row-major rhs, one 128^2 tile per CU (23.2 us against 24.8 on 192^2)", (2048, 2048, 2048, BF, None, 0, 0, 1), "LP_128", (0, 0)),
-    ("row-major rhs, 196 tiles of 256^2", (3584, 3584, 3584, F16, None, 0, 0, 1), "LP_256W4", (0, 0)),
+    ("row-major rhs, 196 tiles of 256^2", (3584, 3584, 3584, F16, None, 0, 0, 1), "LP_256QM", (0, 0)),
     ("row-major rhs, tall: 128 tiles of 256 x 192 (65.7 us against 68.4 on the 256 x 128 tile)", (8192, 1024, 4096, BF, None, 0, 0, 1), "LP_256X192", (0, 0)),
-    ("exactly one full round of 256^2 tiles: every CU busy, the 16x16x32 form (round 6: 103.6 -> 98.1 us)", (4096, 4096, 4096, BF, None, 0, 1, 1), "LP_256M16", (0, 0)),
-    ("... with a row-major rhs: the 32x32x16 kernel", (4096, 4096, 4096, BF, None, 0, 0, 1), "LP_256W4", (0, 0)),
+    ("exactly one full round of 256^2 tiles: every CU busy, the 16x16x32 form (round 6: 103.6 -> 98.1 us on lp256m16, 93.9 on the persistent kernel's K loop)", (4096, 4096, 4096, BF, None, 0, 1, 1), "LP_256QM", (0, 0)),
+    ("... with a row-major rhs: the same kernel's transposing-read form (106.2 -> 97.8 us)", (4096, 4096, 4096, BF, None, 0, 0, 1), "LP_256QM", (0, 0)),
     ("288 tiles of 256^2, long K: the square tile with its leftover strip split along K (240.9 us; 256 x 192 265.0)", (4608, 4096, 8192, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
     ("272 tiles of 256^2 at K = 4096: the split form loses to two rounds of 192^2 (130.9 / 122.8)", (4352, 4096, 4096, BF, None, 0, 1, 1), "LP_192X192", (0, 0)),
     ("576 tiles of 256^2: 2.7 rounds of 256 x 192 tiles (344.5 us) beat the square tile with its leftover strip split (360.0)", (6144, 6144, 6144, BF, None, 0, 1, 1), "LP_256X192", (0, 0)),

@@ -188,7 +188,7 @@ def _nn_bench_desc(m, n, k, dtype_ab, dtype_c, batch=1):
 def test_c3_bf16_8192_row_major_rhs_is_native_and_bit_identical_to_the_k_contiguous_form(client, oracle):
     """Config C3 with the rhs as TensorHandle::new_contiguous lays it out ([K][N], crates/cubecl-std/src/tensor/handle.rs:89):
     no operand is copied (empty re-layout plan, no library scratch), the 256x256 kernel stages B through its transposing-read
-    image, and all 64 Mi outputs equal those of the K-contiguous launch (held to the f64 oracle above) bit for bit."""
+    image (ds_read_b64_tr_b16 of a half-swapped block image, gemm_lp256qm.hip), and all 64 Mi outputs equal those of the K-contiguous launch (held to the f64 oracle above) bit for bit."""
     import ctypes as C
     S = 8192
     a = TensorHandle.uniform(client, (S, S), ElemType.BF16, SEED, 100, -1.0, 1.0)
@@ -196,10 +196,9 @@ def test_c3_bf16_8192_row_major_rhs_is_native_and_bit_identical_to_the_k_contigu
     b_kn = ops.into_contiguous(client, TensorHandle.new(b_nk.handle, (S, S), (1, S), ElemType.BF16))   # its transpose, [K][N]
     outs = []
     for d, b in ((_bench_desc(S, S, S, N.DTYPE_BF16, N.DTYPE_BF16), b_nk), (_nn_bench_desc(S, S, S, N.DTYPE_BF16, N.DTYPE_BF16), b_kn)):
-        # (AUTO takes the 16x16x32 form of the tile for the K-contiguous rhs since round 5 -- another summation order; the
-        # statement here is about the STAGING of the 32x32x16 kernel, so that kernel is named for the K-contiguous launch)
-        assert ops.gemm_select(client, d) == (N.GEMM_ALGO_LP_256QM if d.trans_b else N.GEMM_ALGO_LP_256W4) and ops.gemm_relayout_plan(client, d) == (False, False)
-        d.algo = N.GEMM_ALGO_LP_256W4
+        # (AUTO: the persistent 16x16x32 kernel for both layouts since the second K loop of round 6 -- its transposing-read form runs the
+        #  same MFMA chains as its [N][K] form, so the pair is compared as AUTO launches it)
+        assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256QM and ops.gemm_relayout_plan(client, d) == (False, False)
         c = TensorHandle.new_contiguous((S, S), client.empty(S * S * 2), ElemType.BF16)
         client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d), C.c_void_p(a.device_ptr()), C.c_void_p(b.device_ptr()),
                                               C.c_void_p(c.device_ptr())))

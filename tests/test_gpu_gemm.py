@@ -981,9 +981,9 @@ def test_auto_selection_and_errors(client):
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256QM           # 10 K-tiles: four stores per K-tile (round 6; the 32x32x16 form measured slower than lp256p there)
     d.k = d.lda = d.ldb = 2048
     d.batch = 4
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256M16          # exactly one full round (4 x 64 tiles): the one-tile-per-workgroup 16x16x32 kernel (round 6)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256QM           # exactly one full round (4 x 64 tiles): the same kernel, one tile per workgroup (round 6, second K loop)
     d.batch = 3
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4           # 192 tiles: the 32x32x16 kernel
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256QM           # 192 tiles: wherever the square tile is the choice (round 6: 3584^3 80.2 -> 75.2 us)
     d = N.GemmDesc(m=8192 + 8, n=8192, k=8192, batch=1, lda=8192, ldb=8192, ldc=8192, dtype_ab=N.DTYPE_BF16,
                    dtype_c=N.DTYPE_BF16, trans_b=1)
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4          # ragged M / N stay on the fast kernel (4.1 rounds: the launcher
@@ -1466,17 +1466,17 @@ def test_output_bound_shapes_select_the_small_tile(client):
     # operands past 512 x 512 up to one round of the square tile: one round of 192 x 192 tiles takes most of that band, 256 x 192
     # tiles where those would need a second round
     assert sel(4096, 2048, 4096) == sel(2560, 2560, 3072) == sel(2048, 3072, 8192) == sel(4096, 1536, 8192) == sel(3072, 3072, 3072) == sel(2304, 2304, 2304) == N.GEMM_ALGO_LP_192X192
-    assert sel(4096, 3072, 4096) == sel(3328, 3328, 4096) == N.GEMM_ALGO_LP_256X192 and sel(3584, 3584, 3584) == N.GEMM_ALGO_LP_256W4 and sel(4096, 4096, 4096) == N.GEMM_ALGO_LP_256M16   # (one FULL round: the 16x16x32 form, round 6)
+    assert sel(4096, 3072, 4096) == sel(3328, 3328, 4096) == N.GEMM_ALGO_LP_256X192 and sel(3584, 3584, 3584) == N.GEMM_ALGO_LP_256QM and sel(4096, 4096, 4096) == N.GEMM_ALGO_LP_256QM   # (one FULL round: the 16x16x32 form, round 6)
     assert sel(2048, 2048, 8192) == N.GEMM_ALGO_LP_128                                  # one 128x128 tile per CU (121 tiles of 192^2: too few)
     assert sel(4096, 2048, 2048) == sel(3072, 2560, 1024) == N.GEMM_ALGO_LP_192X192       # round 5 (were the 128x128 kernel's: 1059 / 781, 918 / 693 TFLOP/s)
     assert sel(4096, 2304, 4096) == N.GEMM_ALGO_LP_256X192                            # 144 tiles of 256^2, 288 of 256 x 128 (two rounds), 192 of 256 x 192: the table's call
     assert sel(32, 512, 2048) == sel(512, 16, 2048) == sel(32, 6144, 8192) == N.GEMM_ALGO_STREAM64   # few workgroups are fine up to K = 2048; 192 at any K
     assert sel(32, 512, 8192) == sel(512, 16, 8192) == sel(16, 2048, 8192) == sel(32, 1024, 4096) == N.GEMM_ALGO_LP_128   # round 4: split-K instead
     assert sel(8192, 4096, 512) == sel(9216, 3072, 640) == N.GEMM_ALGO_LP_256QM      # 512 / 432 tiles: persistent from one round up (round 6: the 16x16x32 form at every drip rate)
-    # (384 tiles at K = 512 ... 2048: the cost tables, multi-round down to K = 512 since late round 5, take 256 x 192 tiles -- within 5 % of the
-    #  dripped-store form at K = 512, ahead from K = 1024: profiles/r05_persistent_vs_narrow_ab.txt)
-    assert sel(8192, 3072, 512) == sel(8192, 3072, 2048) == N.GEMM_ALGO_LP_256X192
-    assert sel(4096, 4096, 512) == N.GEMM_ALGO_LP_256M16                              # exactly one full round: the plain (one tile per workgroup) kernel on 16x16x32 MFMAs
+    # (384 tiles at K = 1024 ... 2048: the cost tables, multi-round down to K = 512 since late round 5, take 256 x 192 tiles: profiles/
+    #  r05_persistent_vs_narrow_ab.txt; at K = 512 they were within 5 % of the dripped-store form and the 16x16x32 K loop of round 6 takes it)
+    assert sel(8192, 3072, 512) == N.GEMM_ALGO_LP_256QM and sel(8192, 3072, 2048) == N.GEMM_ALGO_LP_256X192
+    assert sel(4096, 4096, 512) == N.GEMM_ALGO_LP_256QM                               # exactly one full round: the 16x16x32 K loop, one tile per workgroup
 
 
 # ---- 3 ... 64 rows or columns: the no-split-K streaming kernel with loader waves (gemm_stream64.hip) -------------------------
