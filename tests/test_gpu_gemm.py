@@ -1563,7 +1563,12 @@ def test_stream64_refusals_determinism_and_repeated_launches(client, oracle):
     (33, 640, 1280, {"batch": 3}),               # three small blocks
     (48, 512, 1600, {"batch": 2, "bcast_b": True}),
     (64, 2048, 2048, {}),                        # four small blocks: 160 KiB of LDS
-    (64, 8200, 640, {}),
+    (64, 8200, 640, {}),                         # 257 workgroups of 32 rows: the rows-split form, ten K-blocks
+    (64, 8192, 1024, {}),                        # ... its steady state (sixteen K-blocks, six stages)
+    (56, 9000, 448, {}),                         # ... seven K-blocks: one steady pair, then the tail; ragged rows on both sides
+    (64, 8192, 192, {}),                         # ... fewer K-blocks than stages
+    (50, 8200, 64, {}),                          # ... a single K-block
+    (8192, 64, 1024, {}),                        # ... few columns: roles swapped
     (8192, 16, 4096, {}),                        # N <= 64: roles swapped, output block stored transposed
     (1000, 40, 2048, {"ldc": 48}),
     (513, 10, 640, {"batch": 2}),
