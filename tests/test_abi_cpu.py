@@ -305,3 +305,52 @@ def test_the_header_is_plain_c_and_a_c_program_can_drive_the_boundary(tmp_path):
     import subprocess
     out = subprocess.run([str(_build_c_user(tmp_path))], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "C ABI user ok" in out.stdout, (out.stdout[-800:], out.stderr[-400:])
+
+
+def test_headline_kernel_keeps_its_k_tile_bookkeeping_in_the_mfma_gaps():
+    """Round 6: on gemm_lp256qm.hip an instruction behind an MFMA whose gap holds at most one or two others is free, one at the head of a
+    K-tile (no MFMA in flight) costs 6.4 cycles and a fifth one in a crowded gap as much (profiles/r06_qm_pad_cost.txt).  The K loop was
+    rebuilt around that -- bookkeeping computed one phase ahead in the empty gaps, DMA pieces of two instructions -- and nothing but the
+    assembly shows whether a later edit (or a compiler update) puts the 31 scalar instructions back at the head: parity tests pass either
+    way.  Compile the file to gfx950 assembly and read the steady-state K-tile (the one block with 128 MFMAs and no store) of the C3 / C5
+    instantiation and of its row-major-rhs form."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        pytest.skip("hipcc not available")
+    root = Path(__file__).resolve().parents[1]
+    out = subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "--offload-arch=gfx950", "--cuda-device-only", "-S",
+                          f"-I{root / 'include'}", str(root / "cubecl_amd" / "csrc" / "gemm_lp256qm.hip"), "-o", "-"],
+                         capture_output=True, text=True, check=True).stdout.split("\n")
+    for inst, max_total, max_gap in (("ILi1ELi1ELb0E", 285, 6), ("ILi1ELi1ELb1E", 320, 7)):       # <bf16, one store per K-tile, [N][K] / row-major rhs>
+        start = next(i for i, l in enumerate(out) if l.startswith("_ZN12_GLOBAL__N_119gemm_lp256qm_kernel" + inst) and ":" in l)
+        end = next(i for i in range(start, len(out)) if "s_endpgm" in out[i])
+        blocks, cur = [], []
+        for l in out[start:end]:
+            if re.match(r"^\.LBB\d+_\d+:", l):
+                blocks.append(cur)
+                cur = []
+            else:
+                t = l.strip()
+                if t and not t.startswith(";") and not t.startswith("."):
+                    cur.append(t.split(";")[0].strip())
+        blocks.append(cur)
+        steady = [b for b in blocks if sum(x.startswith("v_mfma") for x in b) == 128 and not any(x.startswith("global_store") for x in b)
+                  and not any("cvt_pk" in x for x in b)]
+        assert len(steady) == 1, [len(b) for b in steady]
+        gaps, g = [], 0
+        for x in steady[0]:
+            if x.startswith("v_mfma"):
+                gaps.append(g)
+                g = 0
+            else:
+                g += 1
+        gaps.append(g)
+        assert len(steady[0]) <= max_total, (inst, len(steady[0]))
+        assert gaps[0] <= 3 and gaps[-1] <= 4, (inst, gaps[0], gaps[-1])              # the K-tile opens with its first MFMA and closes with a compare and a branch
+        assert max(gaps) <= max_gap, (inst, gaps)
+        loads = [x for x in steady[0] if x.startswith("global_load_lds_dwordx4")]
+        m0 = [x for x in steady[0] if re.match(r"s_(mov_b32|add_u32|add_i32|addk_i32) m0", x) or x.startswith("s_mov_b32 m0")]
+        assert len(loads) == 16 and len(m0) <= 6, (inst, len(loads), len(m0))          # sixteen pieces, M0 written twice per unit
