@@ -27,8 +27,15 @@
 //     register, so one 2 x 2 exchange between lanes l15 ^ 1 and chunk registers jj ^ 1 (quad-permute DPP + select, 4 VALU per
 //     word, 32 per 16-row block row) makes a chunk register 8 rows x 128 contiguous bytes.  24 held stores per wave and tile
 //     (block rows 0-5 = 96 VGPRs), block rows 6-7 through the dead ring slot at the tile boundary, as in gemm_lp256q.hip.
-//   * Per-lane DMA offsets: four registers (A / B x even / odd piece) + wave-uniform piece offsets in scalar arithmetic (tiles are
-//     full); fragment addresses: x1 = x0 ^ 64.  96 fragment + 96 held registers leave ~60 for everything else.
+//   * Per-lane DMA offsets: four registers (A / B x even / odd piece) + wave-uniform piece offsets (tiles are full; the sixteen sums are
+//     loop-invariant registers); fragment addresses: x1 = x0 ^ 64.  96 fragment + 96 held registers leave ~60 for everything else.
+//   * The K-tile's bookkeeping lives in the MFMA gaps (second K loop of round 6; "the K-tile's bookkeeping, one phase ahead" below).  One
+//     wave per SIMD: an instruction behind an MFMA whose gap holds at most one or two others costs nothing, at the head of a K-tile it
+//     costs 6.4 cycles of an idle matrix pipe (profiles/r06_qm_pad_cost.txt).  So ring positions, the issue side's tile switch and K
+//     offset, read and DMA addresses are computed one phase ahead behind odd MFMAs, a DMA piece is a v_mov and the load (M0 twice per
+//     unit: the instruction offset of global_load_lds moves both addresses), the dripped stores sit behind the hand-over (one wait count
+//     for every tile), the next tile's coordinates are worked out behind MFMA 40 of a tile's first K-tile.  Steady K-tile: 269
+//     instructions for 128 MFMAs, head 1, tail 3 (tests/test_abi_cpu.py reads the assembly); mfma_util 0.81 -> 0.87 on config C3.
 //
 //   * Row-major rhs (BNN = true, B stored [K][N]): the B tile's LDS image is K-major, fragments come out of ds_read_b64_tr_b16
 //     (half-swapped block image: no bank conflict), and the drain exchanges with v_permlane16_swap instead of the DMA-side row
@@ -434,7 +441,7 @@ gemm_lp256qm_kernel(gemm_args g)
         drain_one(IC<((N0) + (BIT) >= QM_LAG ? (N0) + (BIT) - QM_LAG : 0)>{});                                        \
     }                                                                                                                 \
     if constexpr ((KS) == 0 && (G) >= 0) { __builtin_amdgcn_sched_barrier(0); tr_gap(IC<(G)>{}, IC<(N0) + (BIT)>{}); } \
-    if constexpr ((KS) == 0 && (FIRST)) { __builtin_amdgcn_sched_barrier(0); bd_gap(IC<(N0) + (BIT)>{}); }           \
+    if constexpr ((KS) == 0 && (FIRST)) { __builtin_amdgcn_sched_barrier(0); bd_gap(IC<(N0) + (BIT)>{}); first_gap(IC<(N0) + (BIT)>{}); } \
     if constexpr ((KS) == 1 && (G) >= 0 && (N0) >= 16 && (N0) < 48) { __builtin_amdgcn_sched_barrier(0); st_gap(IC<(G)>{}, IC<(N0) + (BIT)>{}, rb_base); } \
     __builtin_amdgcn_sched_barrier(0);
 #define QM_Q(CUR, NXT, KS, N0, FIRST, DRAIN, G)                                                                       \
@@ -584,6 +591,14 @@ gemm_lp256qm_kernel(gemm_args g)
     pc_ra0 = (uint32_t)sa + ra_k1;
     pc_rb0 = (uint32_t)sb + rb_k1;
 
+    // the tile after this one (branch-free: without one, the tile itself again -- its K-tiles 0 and 1 are fetched once more and never read)
+    auto first_gap = [&](auto nn) {
+        if constexpr (decltype(nn)::value == 40) {
+            Lnext = L + gridDim.x;
+            has_next = Lnext < total;
+            nxt = locate(has_next ? Lnext : L);
+        }
+    };
     // one basic block per K-tile (gemm_lp256q.hip: hipcc schedules per block for register pressure and MFMAs carry no ordering edge)
 #define QM_BLOCK_END() if (__builtin_expect(t > 0x3fffffff, 0)) asm volatile("s_trap 2");
     // One K-tile.  FIRST: K-tile 0 of an output tile (zero C operand in k-step 0).  LASTK: the tile's last K-tile (blocks are packed
@@ -624,10 +639,8 @@ gemm_lp256qm_kernel(gemm_args g)
 #endif
     constexpr int GPR = 8 / D;           // K-tiles (store groups) per held row block
     for (;;) {
-        Lnext = L + gridDim.x;
-        has_next = Lnext < total;
-        nxt = cur;
-        if (has_next) nxt = locate(Lnext);
+        // (the next tile's coordinates -- two divisions, ~100 scalar instructions -- are worked out behind MFMA 40 of this tile's first K-tile:
+        //  first_gap, below; they are needed from K-tile nk - 3 on)
         kbase = 0;
         t = 0;
         char *rb_base = hbase;
