@@ -77,8 +77,8 @@ TABLE = [
     ("exactly one full round of 256^2 tiles: every CU busy, the 16x16x32 form (round 6: 103.6 -> 98.1 us on lp256m16, 93.9 on the persistent kernel's K loop)", (4096, 4096, 4096, BF, None, 0, 1, 1), "LP_256QM", (0, 0)),
     ("... with a row-major rhs: the same kernel's transposing-read form (106.2 -> 97.8 us)", (4096, 4096, 4096, BF, None, 0, 0, 1), "LP_256QM", (0, 0)),
     ("288 tiles of 256^2, long K: the square tile with its leftover strip split along K (240.9 us; 256 x 192 265.0)", (4608, 4096, 8192, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
-    ("272 tiles of 256^2 at K = 4096: the split form loses to two rounds of 192^2 (130.9 / 122.8)", (4352, 4096, 4096, BF, None, 0, 1, 1), "LP_192X192", (0, 0)),
-    ("576 tiles of 256^2: 2.7 rounds of 256 x 192 tiles (344.5 us) beat the square tile with its leftover strip split (360.0)", (6144, 6144, 6144, BF, None, 0, 1, 1), "LP_256X192", (0, 0)),
+    ("272 tiles of 256^2 at K = 4096: the split form with its main part on the 16x16x32 kernel, a tie with two rounds of 192^2 (125.2 / 122.6 us; until round 6 130.9 with the main part on the 32x32x16 kernel)", (4352, 4096, 4096, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
+    ("576 tiles of 256^2: the square tile with its leftover strip split, main part on the 16x16x32 kernel (326.9 us; 2.7 rounds of 256 x 192 tiles 338.6; until round 6 the split form took 360.0)", (6144, 6144, 6144, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
     ("560 tiles, K = 8192: the split square tile (449.5 us; 256 x 192 450.2)", (7168, 5120, 8192, BF, None, 0, 1, 1), "LP_256W4", (0, 0)),
     ("576 tiles, short K: 256 x 192 tiles (71.0 us) instead of the dripped-store persistent form (74.1)", (6144, 6144, 1024, BF, None, 0, 1, 1), "LP_256X192", (0, 0)),
     ("65-128 rows x 128 tiles, K = 512: one round of 192^2 tiles instead of a split K (10.6 us / 18.9)", (128, 16384, 512, BF, None, 0, 1, 1), "LP_192X192", (0, 0)),

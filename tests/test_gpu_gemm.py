@@ -834,14 +834,16 @@ def test_row_major_b_through_the_strip_split_of_a_partly_filled_round(client, or
     the strip's K slices start k rows further down B (not k columns further along its rows) and a strip of columns starts at a column
     offset: same cut, same slabs, same fold -- the bits of the [N][K] launch.  (Until round 5 this ran on 4352 x 4096 x 2048; the cost
     table now hands that [N][K] descriptor to a 192 x 192 tile, launched whole -- checked below; it prices the square tile WITH the split, which
-    keeps 4608 x 4096 x 8192: 240.9 us against 265.0 on 256 x 192 -- and, its domain widened to three rounds, 6144^3 to the 256 x 192 tile.)"""
+    keeps 4608 x 4096 x 8192: 240.9 us against 265.0 on 256 x 192.  Late round 6: the split's main part -- whole rounds of full tiles -- runs on the
+    persistent 16x16x32 kernel, the table prices that (x 0.95), and 6144^3 comes back from the 256 x 192 tile: 326.9 us against 338.6.)"""
     along, extent, splits = C.c_int32(), C.c_int64(), C.c_int32()
     d_nt = N.GemmDesc(m=4352, n=4096, k=2048, batch=1, lda=2048, ldb=2048, ldc=4096, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_BF16, trans_b=1)
     assert ops.gemm_select(client, d_nt) == N.GEMM_ALGO_LP_192X192
     assert client.lib.mi355_gemm_tail_plan(C.byref(d_nt), C.byref(along), C.byref(extent), C.byref(splits)) == N.OK and splits.value == 1
     m, n, k = 4608, 4096, 8192
     d6 = N.GemmDesc(m=6144, n=6144, k=6144, batch=1, lda=6144, ldb=6144, ldc=6144, dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_BF16, trans_b=1)
-    assert ops.gemm_select(client, d6) == N.GEMM_ALGO_LP_256X192
+    assert ops.gemm_select(client, d6) == N.GEMM_ALGO_LP_256W4
+    assert client.lib.mi355_gemm_tail_plan(C.byref(d6), C.byref(along), C.byref(extent), C.byref(splits)) == N.OK and splits.value > 1
     a = TensorHandle.uniform(client, (m, k), ElemType.BF16, 0x5EEDC0BE, 91, -1.0, 1.0)
     b_nk = TensorHandle.uniform(client, (n, k), ElemType.BF16, 0x5EEDC0BE, 92, -1.0, 1.0)
     b_kn = ops.into_contiguous(client, TensorHandle.new(b_nk.handle, (k, n), (1, k), ElemType.BF16))

@@ -170,9 +170,12 @@ def test_tail_plan_splits_only_small_leftover_rounds():
     along, extent, splits = _tail_plan(8192, 4352, 8192)
     tiles_main = (extent // 256) * (17 if along else 32)
     assert splits > 1 and extent % 256 == 0 and tiles_main == 512 and (32 * 17 - tiles_main) * splits <= 256
-    # the same grids with a shorter K, and 6144^3 (576 tiles): the cost tables (three rounds wide since late round 5) give them to the 256 x 192
-    # tile, and the plan answers for the kernel mi355_gemm will run -- no strip
-    assert _tail_plan(8192, 4352, 4096)[2] == 1 and _tail_plan(6144, 6144, 6144)[2] == 1
+    # the same grid with a shorter K, and 6144^3 (576 tiles): until late round 6 the cost tables gave them to the 256 x 192 tile; with the main
+    # part of the split on the persistent 16x16x32 kernel the split form is ahead (219.8 us against 226.8, 326.9 against 338.6:
+    # profiles/r06_tail_split_rule_ab.txt, r06_tail_split_rule_ab2.txt) and the plan answers for the kernel mi355_gemm will run
+    assert _tail_plan(8192, 4352, 4096)[1:] == (4096, 4) and _tail_plan(6144, 6144, 6144)[2] > 1
+    # ... at K = 2048 the 256 x 192 tile keeps it (121.5 us; no strip)
+    assert _tail_plan(8192, 4352, 2048)[2] == 1
     # 20 x 13 tiles of 256^2 with a ragged M: since round 5 the cost table gives the shape to the 192^2 tile, and the plan answers for
     # the kernel mi355_gemm will run -- no strip
     assert _tail_plan(5000, 3328, 2048)[2] == 1

@@ -28,7 +28,7 @@ CUS, F0 = 256, 0.7
 FILES = ["r03_tile_256x128_sweep.txt", "r04_band_129_200_tiles_ab.txt", "r05_tile_256x192_ab.txt", "r05_tile_192x192_ab.txt", "r05_m16_ab.txt",
          "r05_select_audit_cost_table_v1.txt"]
 if "--nn" in sys.argv:
-    FILES = ["r05_tile_nn_ab.txt"]          # (r05_tile_nn_ab2.txt is the held-out check: AUTO column = this table's choice)
+    FILES = ["r05_tile_nn_ab.txt", "r06_long_k_tiles_nn_ab.txt"]          # (r05_tile_nn_ab2.txt is the held-out check: AUTO column = this table's choice; round 6: nine shapes past K = 8192)
 
 
 def parse():
