@@ -113,6 +113,10 @@ TABLE = [
     ("64 rows, K = 16384 on one streaming workgroup per CU: streams (round 6: 48.9 us / 61.9 on split-K)", (64, 8192, 16384, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
     ("... K = 14336: split-K (44.3 / 47.9)", (64, 8192, 14336, BF, None, 0, 1, 1), "LP_128", (0, 0)),
     ("... 288 workgroups at K = 16384: split-K (66.2 / 107.4)", (64, 9216, 16384, BF, None, 0, 1, 1), "LP_128", (0, 0)),
+    ("47 rows on 298 streaming workgroups -- a second round one sixth full -- at K = 3072: split-K (late round 6: 23.1 us / 19.4)", (47, 9528, 3072, BF, None, 0, 1, 1), "LP_128", (0, 0)),
+    ("... on 352 workgroups: streams (23.3 / 22.4)", (47, 11264, 3072, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
+    ("31 rows on 272 streaming workgroups at K = 4096: split-K (24.4 / 20.4); at K = 3072 it streams (18.7 / 16.8: inside the audit's bar)", (31, 8704, 4096, BF, None, 0, 1, 1), "LP_128", (0, 0)),
+    ("... 31 rows, K = 3072", (31, 8704, 3072, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
     ("23 columns, K = 3072, any grid: streams (few columns are not few rows)", (37824, 23, 3072, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
     ("24 columns, K past 8192: split-K", (9312, 24, 14336, BF, None, 0, 1, 1), "LP_128", (0, 0)),
     ("20 rows whose 128-column tiles would fill a second round by a quarter: streams", (20, 40096, 8192, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
