@@ -117,6 +117,11 @@ TABLE = [
     ("... on 352 workgroups: streams (23.3 / 22.4)", (47, 11264, 3072, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
     ("31 rows on 272 streaming workgroups at K = 4096: split-K (24.4 / 20.4); at K = 3072 it streams (18.7 / 16.8: inside the audit's bar)", (31, 8704, 4096, BF, None, 0, 1, 1), "LP_128", (0, 0)),
     ("... 31 rows, K = 3072", (31, 8704, 3072, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
+    ("6 columns, K = 14336 on 599 streaming workgroups: streams (late round 6: 100.7 us / 120.2 on split-K)", (19152, 6, 14336, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
+    ("... on 291 workgroups (a second round one seventh full): split-K (57.8 / 53.8)", (9312, 4, 14336, BF, None, 0, 1, 1), "LP_128", (0, 0)),
+    ("4 rows against a row-major weight of 160 ragged column tiles -- the 128 x 128 kernel would not split K: the strip kernel (106.0 / 124.4)", (4, 20472, 14336, BF, None, 0, 0, 1), "NNROWS", (0, 0)),
+    ("... 117 column tiles: the 128 x 128 kernel splits K in two (45.4 / 48.0)", (4, 14920, 8192, BF, None, 0, 0, 1), "LP_128", (0, 0)),
+    ("one round of the square tile at most, 8 K-tiles: the narrow tiles are in the table (late round 6: 12.4 us on 192^2, 16.8 on the square tile)", (8840, 960, 512, BF, None, 0, 1, 1), "LP_192X192", (0, 0)),
     ("23 columns, K = 3072, any grid: streams (few columns are not few rows)", (37824, 23, 3072, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
     ("24 columns, K past 8192: split-K", (9312, 24, 14336, BF, None, 0, 1, 1), "LP_128", (0, 0)),
     ("20 rows whose 128-column tiles would fill a second round by a quarter: streams", (20, 40096, 8192, BF, None, 0, 1, 1), "STREAM64", (0, 0)),

@@ -1,0 +1,5 @@
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+for seed in 701 702 703 704 705 706 707 708; do timeout 1500 python tools/dev/random_audit.py $seed 96; done > gpurun_out/r06_random_audit_fresh_seeds.txt 2>&1
+grep -c "AUTO ->" gpurun_out/r06_random_audit_fresh_seeds.txt; grep "BEHIND" gpurun_out/r06_random_audit_fresh_seeds.txt
