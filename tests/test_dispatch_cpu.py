@@ -122,6 +122,9 @@ TABLE = [
     ("4 rows against a row-major weight of 160 ragged column tiles -- the 128 x 128 kernel would not split K: the strip kernel (106.0 / 124.4)", (4, 20472, 14336, BF, None, 0, 0, 1), "NNROWS", (0, 0)),
     ("... 117 column tiles: the 128 x 128 kernel splits K in two (45.4 / 48.0)", (4, 14920, 8192, BF, None, 0, 0, 1), "LP_128", (0, 0)),
     ("one round of the square tile at most, 8 K-tiles: the narrow tiles are in the table (late round 6: 12.4 us on 192^2, 16.8 on the square tile)", (8840, 960, 512, BF, None, 0, 1, 1), "LP_192X192", (0, 0)),
+    ("18 rows whose 128-column tiles leave a second round an eighth full, K = 2048: streams (late round 6: 30.5 us / 41.4 on split-K)", (18, 37312, 2048, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
+    ("... 47 rows, K = 8192 (126.1 / 145.4)", (47, 37312, 8192, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
+    ("... 61 rows: split-K (139.8 / 147.5: inside the audit's bar, and behind at K = 4096)", (61, 37312, 8192, BF, None, 0, 1, 1), "LP_128", (0, 0)),
     ("23 columns, K = 3072, any grid: streams (few columns are not few rows)", (37824, 23, 3072, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
     ("24 columns, K past 8192: split-K", (9312, 24, 14336, BF, None, 0, 1, 1), "LP_128", (0, 0)),
     ("20 rows whose 128-column tiles would fill a second round by a quarter: streams", (20, 40096, 8192, BF, None, 0, 1, 1), "STREAM64", (0, 0)),

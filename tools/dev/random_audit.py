@@ -39,4 +39,5 @@ for nn in (False, True):
         best_a, best = min(forced, key=lambda x: x[1])
         ratio = us["auto"] / best
         flag = "  <-- BEHIND" if ratio > 1.10 and us["auto"] - best > 2.0 else ""
-        print(f"{m:6d}x{n:6d}x{k:6d}: AUTO -> {r['auto']:9s} {us['auto']:8.1f} us   best {best_a:9s} {best:8.1f} us   x{ratio:.3f}{flag}", flush=True)
+        every = "  ".join(f"{a} {t:.1f}" for a, t in forced) if os.environ.get("AUDIT_ALL_TIMES") else ""     # (fit data for tools/dev/tile_cost_model.py)
+        print(f"{m:6d}x{n:6d}x{k:6d}: AUTO -> {r['auto']:9s} {us['auto']:8.1f} us   best {best_a:9s} {best:8.1f} us   x{ratio:.3f}{flag}" + (f"   | {every}" if every else ""), flush=True)
