@@ -863,6 +863,41 @@ def test_row_major_b_through_the_strip_split_of_a_partly_filled_round(client, or
     assert np.all(diff <= 2.0 ** -7 * np.maximum(np.abs(oracle.from_bf16(outs[1])), 1e-3) + 1e-5 * k)
 
 
+@pytest.mark.parametrize("dtype", [ElemType.BF16, ElemType.F16])
+@pytest.mark.parametrize("m,n,k,nn", [(4608, 4096, 8192, False), (4096, 4352, 4096, False), (4608, 4096, 8192, True)])
+def test_leftover_round_split_runs_its_main_part_on_the_persistent_16x16x32_kernel(client, oracle, m, n, k, nn, dtype):
+    """Late round 6 (gemm.cpp run_tail_split): the main part of a split -- whole rounds of full tiles -- is launched on gemm_lp256qm.hip where that
+    kernel takes it.  The rows (columns) of the main part are then, bit for bit, what a forced launch of that kernel writes for the sub-problem on
+    the same operands; the strip -- K slices on gemm_lp256w4.hip, f32 slabs folded in slice order -- agrees with a plain launch within the output's rounding."""
+    along, extent, splits = C.c_int32(), C.c_int64(), C.c_int32()
+    d = _nn_desc(m, n, k, dtype, dtype) if nn else N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=k, ldc=n, dtype_ab=int(dtype), dtype_c=int(dtype), trans_b=1)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    assert client.lib.mi355_gemm_tail_plan(C.byref(d), C.byref(along), C.byref(extent), C.byref(splits)) == N.OK and splits.value > 1 and extent.value > 0
+    a = TensorHandle.uniform(client, (m, k), dtype, 0x5EEDC0BE, 93, -1.0, 1.0)
+    b = TensorHandle.uniform(client, (k, n) if nn else (n, k), dtype, 0x5EEDC0BE, 94, -1.0, 1.0)
+    b_t = b if nn else TensorHandle.new(b.handle, (k, n), (1, k), dtype)
+    c = TensorHandle.new_contiguous((m, n), client.empty(m * n * 2), dtype)
+    ops.matmul(client, a, b_t, c)
+    whole = c.to_numpy(client).view(np.uint16).reshape(m, n)
+    # the sub-problem of the main part, forced on the persistent kernel, written into a fresh C of the full pitch
+    mm, mn = (extent.value, n) if along.value else (m, extent.value)
+    c2 = client.empty(m * n * 2)
+    d2 = N.GemmDesc(m=mm, n=mn, k=k, batch=1, lda=k, ldb=(n if nn else k), ldc=n, dtype_ab=int(dtype), dtype_c=int(dtype), trans_b=0 if nn else 1,
+                    algo=N.GEMM_ALGO_LP_256QM)
+    client._s.check(client.lib.mi355_gemm(client.ctx, None, C.byref(d2), C.c_void_p(a.handle.device_ptr()), C.c_void_p(b.handle.device_ptr()),
+                                          C.c_void_p(c2.device_ptr())))
+    main = TensorHandle.new_contiguous((m, n), c2, dtype).to_numpy(client).view(np.uint16).reshape(m, n)
+    assert np.array_equal(whole[:mm, :mn], main[:mm, :mn])
+    # the strip against a plain launch of the square tile
+    c3 = TensorHandle.new_contiguous((m, n), client.empty(m * n * 2), dtype)
+    ops.matmul(client, a, b_t, c3, algo=N.GEMM_ALGO_LP_256W4)
+    plain = c3.to_numpy(client).view(np.uint16).reshape(m, n)
+    dec = (lambda x: oracle.from_bf16(x)) if dtype == ElemType.BF16 else (lambda x: oracle.from_f16(x))
+    strip = (slice(mm, m), slice(0, n)) if along.value else (slice(0, m), slice(mn, n))
+    got, ref = dec(np.ascontiguousarray(whole[strip])).astype(np.float64), dec(np.ascontiguousarray(plain[strip])).astype(np.float64)
+    assert np.all(np.abs(got - ref) <= 2.0 ** (-7 if dtype == ElemType.BF16 else -10) * np.maximum(np.abs(ref), 1e-3) + 1e-5 * k)
+
+
 def test_row_major_b_refusals_of_the_tile_kernel(client, oracle):
     """N not a multiple of 8 (a 16-byte DMA piece would straddle the row end) or rows of B not 16-byte aligned: the 256x256
     kernel refuses when forced, AUTO re-lays B out and still lands on an MFMA kernel."""
