@@ -1537,6 +1537,10 @@ def test_output_bound_shapes_select_the_small_tile(client):
     (60, 5000, 8192, {"lda": 8200, "ldc": 5008}),   # 157 workgroups -> 79 row blocks, the last with 8 of its 64 rows; padded rows
     (4200, 57, 8192, {}),                        # roles swapped: the output block stored transposed by the folding workgroup
     (64, 4160, 16384, {}),                       # 128 K-tiles per slice
+    # late round 6, the grids AUTO now streams (profiles/dispatch_rules.md STREAM_PART_TILES_*, STREAM_COLS_K_MAX): four and a half rounds of
+    # workgroups with 47 rows, two and a third with 6 columns walking 224 K-tiles
+    (47, 37312, 2048, {}),
+    (19152, 6, 14336, {}),
 ])
 @pytest.mark.parametrize("dtype,out_dtype", [(ElemType.BF16, ElemType.BF16), (ElemType.F16, ElemType.F32), (ElemType.BF16, ElemType.F32)])
 def test_stream64_kernel_matches_the_oracle(client, oracle, m, n, k, kw, dtype, out_dtype):
