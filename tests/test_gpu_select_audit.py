@@ -2,7 +2,7 @@
 
 `gemm.cpp::select` holds ~25 measured crossovers between ten kernels.  They were measured on the builder's boxes; on a box
 where one of them is wrong, the symptom used to be a slower bench entry and nothing else.  This test times AUTO against EVERY
-kernel that accepts the descriptor over a fixed grid of 60 bf16 shapes -- the bench's skinny / output-bound / mid-size / decode
+kernel that accepts the descriptor over a fixed grid of 64 bf16 shapes -- the bench's skinny / output-bound / mid-size / decode
 shapes among them -- interleaved, three rounds, medians, cold operands (launches rotate through operand sets larger than the
 Infinity Cache), and fails when AUTO is more than 10 % AND more than 2 us behind the best forced kernel on any shape (round 6, review of
 round 5 next #8: the bar was 15 % + 3 us, wide enough to hide a wrong kernel on every launch under 20 us; 2 us: launches of 8-15 us carry
@@ -37,6 +37,9 @@ GRID = [
     # late round 5: the tables' third round and K = 512 over several rounds, the 65-128-row band, one or two K-tiles along a long side
     (4672, 7360, 3072), (6144, 6144, 1024), (3520, 10112, 512), (128, 16384, 512), (16384, 104, 1024), (116, 40960, 2048), (29512, 32, 128),
     (5, 53432, 1024),
+    # late round 6: the rules eight fresh audit seeds produced (profiles/dispatch_rules.md STREAM_PART_TILES_*, STREAM_PART_ROUND_*, STREAM_COLS_K_MAX,
+    # NARROW_TILE_MIN_KTILES), each at a shape its A/B sweep decided by 15 % or more
+    (18, 37312, 2048), (47, 8704, 3072), (19152, 6, 14336), (8840, 960, 512),
 ]
 ALGOS = ["auto", "lp128", "lp256x128", "lp256w4", "lp256p", "lp256q", "stream64", "skinny", "lp256x192", "lp192x192", "lp256m16", "lp256qm"]
 # few rows against a ROW-MAJOR [K][N] weight (review of round 3, next #6): the rhs layout TensorHandle::new_contiguous gives
