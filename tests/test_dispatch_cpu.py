@@ -125,6 +125,9 @@ TABLE = [
     ("18 rows whose 128-column tiles leave a second round an eighth full, K = 2048: streams (late round 6: 30.5 us / 41.4 on split-K)", (18, 37312, 2048, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
     ("... 47 rows, K = 8192 (126.1 / 145.4)", (47, 37312, 8192, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
     ("... 61 rows: split-K (139.8 / 147.5: inside the audit's bar, and behind at K = 4096)", (61, 37312, 8192, BF, None, 0, 1, 1), "LP_128", (0, 0)),
+    ("the LM head at 16 tokens, 4 008 streaming workgroups: streams (late round 6: 163.9 us / 197.1 on split-K; the grid limit was 2 048)", (16, 128256, 4096, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
+    ("32 rows on 1 792 streaming workgroups: streams (149.9 / 157.1; the limit was 768)", (32, 57344, 8192, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
+    ("... past the measured grids: split-K", (32, 90000, 4096, BF, None, 0, 1, 1), "LP_128", (0, 0)),
     ("23 columns, K = 3072, any grid: streams (few columns are not few rows)", (37824, 23, 3072, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
     ("24 columns, K past 8192: split-K", (9312, 24, 14336, BF, None, 0, 1, 1), "LP_128", (0, 0)),
     ("20 rows whose 128-column tiles would fill a second round by a quarter: streams", (20, 40096, 8192, BF, None, 0, 1, 1), "STREAM64", (0, 0)),

@@ -1490,7 +1490,11 @@ def test_output_bound_shapes_select_the_small_tile(client):
     assert sel(64, 1024, 2048) == sel(64, 7168, 8192) == sel(32, 8192, 16384) == sel(16, 28672, 8192) == N.GEMM_ALGO_STREAM64
     # round 4 (33-64 rows, after the 128x128 kernel's 64 x 128 tile): short grids walking a long K, more workgroups than CUs, K past 8192
     assert sel(64, 64, 4096) == sel(64, 2048, 8192) == sel(64, 14336, 4096) == sel(64, 8192, 14336) == sel(48, 4096, 4096) == N.GEMM_ALGO_LP_128
-    assert sel(48, 512, 8192) == sel(64, 512, 8192) == sel(32, 28672, 4096) == sel(32, 57344, 4096) == N.GEMM_ALGO_LP_128   # rounds 3 and 4
+    assert sel(48, 512, 8192) == sel(64, 512, 8192) == N.GEMM_ALGO_LP_128   # rounds 3 and 4
+    # (until late round 6 17-32 rows left the streaming kernel from 768 workgroups, up to 16 from 2048: profiles/r06_stream_large_grids_ab.txt -- 32 x 57344
+    #  x 4096 85.8 us against 87.3, 32 x 57344 x 8192 149.9 / 157.1, 16 x 128256 x 4096 163.9 / 197.1, 32 x 28672 x 4096 level)
+    assert sel(32, 28672, 4096) == sel(32, 57344, 4096) == sel(16, 128256, 4096) == sel(4, 152064, 8192) == N.GEMM_ALGO_STREAM64
+    assert sel(32, 90000, 4096) == sel(16, 200000, 4096) == N.GEMM_ALGO_LP_128       # past the measured grids (2560 / 4800 workgroups)
     assert sel(64, 8192, 28672) == sel(64, 28672, 8192) == N.GEMM_ALGO_LP_128        # small operand past 2 MiB / 64 rows over more than 512 workgroups
     assert sel(8192, 32, 8192) == N.GEMM_ALGO_STREAM64 and sel(8192, 32, 14336) == N.GEMM_ALGO_LP_128   # few columns: K past 8192 goes to split-K (round 4)
     assert sel(44440, 88, 1536) == sel(16384, 512, 1024) == N.GEMM_ALGO_LP_256X128 and sel(32768, 128, 1024) == N.GEMM_ALGO_LP_128   # tall and skinny (round 4)
@@ -1541,6 +1545,7 @@ def test_output_bound_shapes_select_the_small_tile(client):
     # workgroups with 47 rows, two and a third with 6 columns walking 224 K-tiles
     (47, 37312, 2048, {}),
     (19152, 6, 14336, {}),
+    (4, 100000, 512, {}),                        # 3 125 workgroups: the LM-head grids AUTO streams up to 4 800 of (STREAM_WGS_16)
 ])
 @pytest.mark.parametrize("dtype,out_dtype", [(ElemType.BF16, ElemType.BF16), (ElemType.F16, ElemType.F32), (ElemType.BF16, ElemType.F32)])
 def test_stream64_kernel_matches_the_oracle(client, oracle, m, n, k, kw, dtype, out_dtype):
