@@ -128,6 +128,10 @@ TABLE = [
     ("the LM head at 16 tokens, 4 008 streaming workgroups: streams (late round 6: 163.9 us / 197.1 on split-K; the grid limit was 2 048)", (16, 128256, 4096, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
     ("32 rows on 1 792 streaming workgroups: streams (149.9 / 157.1; the limit was 768)", (32, 57344, 8192, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
     ("... past the measured grids: split-K", (32, 90000, 4096, BF, None, 0, 1, 1), "LP_128", (0, 0)),
+    ("heads x [seq x 128 x seq], 128 tiles of 128 x 128 over the batch: one round of 192 x 192 tiles instead of a split K (late round 6: 12.6 us / 19.8)", (512, 128, 512, BF, None, 0, 1, 32), "LP_192X192", (0, 0)),
+    ("... with a row-major rhs", (512, 128, 512, BF, None, 0, 0, 32), "LP_192X192", (0, 0)),
+    ("... 128 rows x seq, 16 heads", (128, 1024, 512, BF, None, 0, 1, 16), "LP_192X192", (0, 0)),
+    ("... 256 tiles over the batch: the 128 x 128 kernel fills the chip unsplit (11.5 / 12.3)", (2048, 128, 512, BF, None, 0, 1, 16), "LP_128", (0, 0)),
     ("23 columns, K = 3072, any grid: streams (few columns are not few rows)", (37824, 23, 3072, BF, None, 0, 1, 1), "STREAM64", (0, 0)),
     ("24 columns, K past 8192: split-K", (9312, 24, 14336, BF, None, 0, 1, 1), "LP_128", (0, 0)),
     ("20 rows whose 128-column tiles would fill a second round by a quarter: streams", (20, 40096, 8192, BF, None, 0, 1, 1), "STREAM64", (0, 0)),

@@ -898,6 +898,17 @@ def test_leftover_round_split_runs_its_main_part_on_the_persistent_16x16x32_kern
     assert np.all(np.abs(got - ref) <= 2.0 ** (-7 if dtype == ElemType.BF16 else -10) * np.maximum(np.abs(ref), 1e-3) + 1e-5 * k)
 
 
+@pytest.mark.parametrize("m,n,k,batch,trans_b", [(512, 128, 512, 32, True), (512, 128, 512, 32, False), (128, 1024, 512, 16, True), (1024, 96, 1024, 16, False),
+                                                   (1000, 72, 512, 16, True)])
+def test_batched_thin_products_on_one_round_of_192_tiles(client, oracle, m, n, k, batch, trans_b):
+    """Late round 6 (gemm.cpp select, the "thin, 65-128" rule over batches): heads x [seq x 128 x seq] and its transposes take the 192 x 192 tile where the
+    128 x 128 kernel would split K -- AUTO's choice is checked and its output held to the oracle, batch by batch."""
+    d = N.GemmDesc(m=m, n=n, k=k, batch=batch, lda=k, ldb=k if trans_b else n, ldc=n, stride_a=m * k, stride_b=n * k, stride_c=m * n,
+                   dtype_ab=N.DTYPE_BF16, dtype_c=N.DTYPE_BF16, trans_b=1 if trans_b else 0)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_192X192
+    run_case(client, oracle, m, n, k, ElemType.BF16, ElemType.BF16, trans_b, ALGOS["auto"], batch=batch)
+
+
 def test_row_major_b_refusals_of_the_tile_kernel(client, oracle):
     """N not a multiple of 8 (a 16-byte DMA piece would straddle the row end) or rows of B not 16-byte aligned: the 256x256
     kernel refuses when forced, AUTO re-lays B out and still lands on an MFMA kernel."""
