@@ -1504,7 +1504,7 @@ def test_output_bound_shapes_select_the_small_tile(client):
     assert sel(48, 512, 8192) == sel(64, 512, 8192) == N.GEMM_ALGO_LP_128   # rounds 3 and 4
     # (until late round 6 17-32 rows left the streaming kernel from 768 workgroups, up to 16 from 2048: profiles/r06_stream_large_grids_ab.txt -- 32 x 57344
     #  x 4096 85.8 us against 87.3, 32 x 57344 x 8192 149.9 / 157.1, 16 x 128256 x 4096 163.9 / 197.1, 32 x 28672 x 4096 level)
-    assert sel(32, 28672, 4096) == sel(32, 57344, 4096) == sel(16, 128256, 4096) == sel(4, 152064, 8192) == N.GEMM_ALGO_STREAM64
+    assert sel(32, 57344, 4096) == sel(16, 128256, 4096) == sel(4, 152064, 8192) == N.GEMM_ALGO_STREAM64 and sel(32, 28672, 4096) == N.GEMM_ALGO_LP_128   # (224 column tiles: one round of the 128 x 128 kernel)
     assert sel(32, 90000, 4096) == sel(16, 200000, 4096) == N.GEMM_ALGO_LP_128       # past the measured grids (2560 / 4800 workgroups)
     assert sel(64, 8192, 28672) == sel(64, 28672, 8192) == N.GEMM_ALGO_LP_128        # small operand past 2 MiB / 64 rows over more than 512 workgroups
     assert sel(8192, 32, 8192) == N.GEMM_ALGO_STREAM64 and sel(8192, 32, 14336) == N.GEMM_ALGO_LP_128   # few columns: K past 8192 goes to split-K (round 4)
