@@ -38,6 +38,17 @@ TABLE = [
     ("f32, 64 columns", (8192, 64, 8192, F32, F32, 0, 1, 1), "STREAM64", (0, 0)),
     ("f32, 16 rows, K off the 64 grid: the 128x128 f32 tile", (16, 4096, 4000, F32, F32, 0, 1, 1), "F32_MFMA", (0, 0)),
     ("f32, 65 rows: the 128x128 f32 tile", (65, 4096, 4096, F32, F32, 0, 1, 1), "F32_MFMA", (0, 0)),
+    ("f32, one full round of square tiles + a strip of 17 whose K the launcher splits: the square tile, priced with the split", (4160, 4096, 4096, F32, F32, 0, 0, 1), "LP_256W4", (0, 0)),
+    ("f32, 19 x 16 ragged square tiles = two rounds, no split: the fitted f32 table hands it to the small tile (late round 6; 1 441 us / 1 823)", (4672, 3968, 4096, F32, F32, 0, 1, 1), "F32_MFMA", (0, 0)),
+    ("f32, 3072^3: 144 square tiles, the small tile (645 us / 684)", (3072, 3072, 3072, F32, F32, 0, 1, 1), "F32_MFMA", (0, 0)),
+    ("f32, 6144^3: 2.25 rounds of square tiles still ahead (3 184 us / 3 896)", (6144, 6144, 6144, F32, F32, 0, 1, 1), "LP_256W4", (0, 0)),
+    ("f32, 27 rows, K = 64 against 18104 streamed rows: the tile (10.6 -> 7.9 us)", (27, 18104, 64, F32, F32, 0, 1, 1), "F32_MFMA", (0, 0)),
+    ("f32, 7 rows, K = 64 against 49648: the tile, not the FMA kernel (43 us) nor the streaming form (20.4 -> 12.1)", (7, 49648, 64, F32, F32, 0, 1, 1), "F32_MFMA", (0, 0)),
+    ("f32, 15 rows, K = 64 against 14168: below the bound, streams (5.7 us / 7.9)", (15, 14168, 64, F32, F32, 0, 1, 1), "STREAM64", (0, 0)),
+    ("f32, 64 columns, K = 128 against 16072: streams (8.7 us / 14.5)", (16072, 64, 128, F32, F32, 0, 1, 1), "STREAM64", (0, 0)),
+    ("f32, 53 rows, K = 128 against 25000: the tile (21.2 -> 14.8 us)", (53, 25000, 128, F32, F32, 0, 1, 1), "F32_MFMA", (0, 0)),
+    ("f32, 4 rows x a small row-major weight: the strip kernel from 2^15 values (7.3 -> 4.3 us)", (4, 768, 64, F32, F32, 0, 0, 1), "NNROWS", (0, 0)),
+    ("f32, 15 rows x a long K = 64 row-major weight: the tile (12.9 -> 8.1 us)", (15, 21712, 64, F32, F32, 0, 0, 1), "F32_MFMA", (0, 0)),
     ("C5: 512 x 2048^3 bf16 on one GPU: dripped stores on 16x16x32 MFMAs (round 6: 1 275 -> 1 340 TFLOP/s)", (2048, 2048, 2048, BF, None, 0, 1, 512), "LP_256QM", (0, 0)),
     ("C5 with an f32 C: the persistent kernel without them", (2048, 2048, 2048, BF, F32, 0, 1, 512), "LP_256P", (0, 0)),
     ("C5, row-major rhs: the same kernel's transposing-read form (round 6)", (2048, 2048, 2048, BF, None, 0, 0, 512), "LP_256QM", (0, 0)),

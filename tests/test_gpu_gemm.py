@@ -1006,8 +1006,11 @@ def test_auto_selection_and_errors(client):
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
     d.trans_b, d.ldb = 0, 4096
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
-    d.m = 4096 + 64
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    d.m = 4096 + 64                                                    # 17 x 16 square tiles: the launcher splits the 17-tile strip's K (plan_tail_split), and the
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4          # fitted f32 table (late round 6) prices the square tile with that split
+    d.m, d.n, d.ldb, d.ldc = 4672, 3968, 3968, 3968                     # 19 x 16 ragged square tiles, no split possible: two rounds -- the 128 x 128 tile
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_F32_MFMA          # (1 441 us against 1 823)
+    d.m, d.n, d.ldb, d.ldc = 4096 + 64, 4096, 4096, 4096
     d.k = 4096 + 16                                                    # K not a multiple of the 32-wide f32 K-tile:
     assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4          # zero-padded scratch copies, still the MFMA kernel
     d = N.GemmDesc(m=2048, n=2048, k=2048, batch=1, lda=2048, ldb=2048, ldc=2048, dtype_ab=N.DTYPE_BF16,
