@@ -22,7 +22,12 @@ TABLE = [
     ("C3 with an f32 C: the one-tile-per-workgroup kernel on 16x16x32 MFMAs (round 5)", (8192, 8192, 8192, BF, F32, 0, 1, 1), "LP_256M16", (0, 0)),
     ("ragged tiles, four rounds: the one-tile-per-workgroup 16x16x32 kernel", (8200, 8200, 8192, BF, None, 0, 1, 1), "LP_256M16", (0, 0)),
     ("1.5 rounds of full 256^2 tiles, 16-bit C: the persistent 16x16x32 loop (round 6; until then the 32x32x16 kernel)", (6144, 4096, 8192, BF, None, 0, 1, 1), "LP_256QM", (0, 0)),
-    ("... with an f32 C, not yet power-bound: the 32x32x16 kernel", (6144, 4096, 8192, BF, F32, 0, 1, 1), "LP_256W4", (0, 0)),
+    ("... with an f32 C: the one-tile-per-workgroup 16x16x32 kernel wherever the square tile is the choice (late round 6, the f32-C audit: 0.90 ... 0.98 of the 32x32x16 kernel)", (6144, 4096, 8192, BF, F32, 0, 1, 1), "LP_256M16", (0, 0)),
+    ("... ragged tiles too (7680 x 3776 x 6144: 256.6 us / 275.2)", (7680, 3776, 6144, BF, F32, 0, 1, 1), "LP_256M16", (0, 0)),
+    ("... a row-major rhs stays on the 32x32x16 kernel (the 16x16x32 one-tile kernel has no transposing-read form)", (6144, 4096, 8192, BF, F32, 0, 0, 1), "LP_256W4", (0, 0)),
+    ("f32 C, K = 256 on 1932 tiles: the single-stage 128x128 kernel past the 16-bit-C tile bound (99.4 us / 115.4)", (11712, 10624, 256, BF, F32, 0, 1, 1), "LP_128", (0, 0)),
+    ("f32 C, a batch of full tiles at K = 128: the persistent kernel's overlapped stores (28.4 us / 33.7)", (2048, 2048, 128, BF, F32, 0, 1, 8), "LP_256P", (0, 0)),
+    ("... 16-bit C: the single-stage 128x128 kernel as before", (2048, 2048, 128, BF, None, 0, 1, 8), "LP_128", (0, 0)),
     ("C3 with the reference's default rhs layout: the persistent 16x16x32 kernel's transposing-read form (round 6, second K loop: 1 474 -> 1 617 TFLOP/s)", (8192, 8192, 8192, BF, None, 0, 0, 1), "LP_256QM", (0, 0)),
     ("... at K = 4096: the persistent 16x16x32 kernel's row-major form (1 401 -> 1 444 TFLOP/s)", (8192, 8192, 4096, BF, None, 0, 0, 1), "LP_256QM", (0, 0)),
     ("C2: 4096^3 f32", (4096, 4096, 4096, F32, F32, 0, 1, 1), "LP_256W4", (0, 0)),
@@ -50,7 +55,8 @@ TABLE = [
     ("f32, 4 rows x a small row-major weight: the strip kernel from 2^15 values (7.3 -> 4.3 us)", (4, 768, 64, F32, F32, 0, 0, 1), "NNROWS", (0, 0)),
     ("f32, 15 rows x a long K = 64 row-major weight: the tile (12.9 -> 8.1 us)", (15, 21712, 64, F32, F32, 0, 0, 1), "F32_MFMA", (0, 0)),
     ("C5: 512 x 2048^3 bf16 on one GPU: dripped stores on 16x16x32 MFMAs (round 6: 1 275 -> 1 340 TFLOP/s)", (2048, 2048, 2048, BF, None, 0, 1, 512), "LP_256QM", (0, 0)),
-    ("C5 with an f32 C: the persistent kernel without them", (2048, 2048, 2048, BF, F32, 0, 1, 512), "LP_256P", (0, 0)),
+    ("C5 with an f32 C: the one-tile 16x16x32 kernel (late round 6; the 64-matrix shard 911 us against 927 on the persistent 32x32x16 kernel, 984 on the plain one)", (2048, 2048, 2048, BF, F32, 0, 1, 512), "LP_256M16", (0, 0)),
+    ("C5 with an f32 C, row-major rhs: the persistent kernel without dripped stores", (2048, 2048, 2048, BF, F32, 0, 0, 512), "LP_256P", (0, 0)),
     ("C5, row-major rhs: the same kernel's transposing-read form (round 6)", (2048, 2048, 2048, BF, None, 0, 0, 512), "LP_256QM", (0, 0)),
     ("the 64-matrix shard of an 8-GPU C5", (2048, 2048, 2048, BF, None, 0, 1, 64), "LP_256QM", (0, 0)),
     ("two rounds, K = 640: the same loop with four stores per K-tile (1 067 -> 1 083; lp256p 961)", (8192, 8192, 640, BF, None, 0, 1, 1), "LP_256QM", (0, 0)),

@@ -23,23 +23,24 @@ NAMES = {"auto": 0, "generic": 1, "f32": 2, "lp128": 3, "lp256": 4, "lp256w4": 5
 BY_ID = {v: k for k, v in NAMES.items()}
 
 
-def measure(client, ev, shapes, algos, rounds=5, nn=False, iters=20, cold=True, f32=False):
+def measure(client, ev, shapes, algos, rounds=5, nn=False, iters=20, cold=True, f32=False, c32=False):
     lib, ctx = client.lib, client.ctx
     et, dt, esz = (ElemType.F32, N.DTYPE_F32, 4) if f32 else (ElemType.BF16, N.DTYPE_BF16, 2)
+    dtc, csz = (N.DTYPE_F32, 4) if c32 else (dt, esz)          # c32: 16-bit operands, f32 C (the cmma tests' accumulator type as the output)
     out = {}
     for (m, n, k) in shapes:
-        fp = esz * (m * k + n * k + m * n)
+        fp = esz * (m * k + n * k) + csz * m * n
         nsets = max(1, min(8, -(-(768 << 20) // fp))) if cold else 1
         sets = [(TensorHandle.uniform(client, (m, k), et, 1, 2 * i + 1, -1.0, 1.0),
-                 TensorHandle.uniform(client, (n, k), et, 1, 2 * i + 2, -1.0, 1.0), client.empty(m * n * esz)) for i in range(nsets)]
+                 TensorHandle.uniform(client, (n, k), et, 1, 2 * i + 2, -1.0, 1.0), client.empty(m * n * csz)) for i in range(nsets)]
         times = {a: [] for a in algos}
         sel = C.c_int32()
-        d0 = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=(n if nn else k), ldc=n, dtype_ab=dt, dtype_c=dt, trans_b=0 if nn else 1, algo=0)
+        d0 = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=(n if nn else k), ldc=n, dtype_ab=dt, dtype_c=dtc, trans_b=0 if nn else 1, algo=0)
         lib.mi355_gemm_select(ctx, C.byref(d0), C.byref(sel))
         turn = [0]
         for _ in range(rounds):
             for a in algos:
-                d = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=(n if nn else k), ldc=n, dtype_ab=dt, dtype_c=dt,
+                d = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=(n if nn else k), ldc=n, dtype_ab=dt, dtype_c=dtc,
                                trans_b=0 if nn else 1, algo=NAMES[a])
 
                 def call():

@@ -30,7 +30,7 @@ F32 = bool(os.environ.get("AUDIT_F32"))                 # f32 operands and outpu
 if F32: ALGOS = ["auto", "f32", "lp256w4", "lp256p", "skinny", "stream64"]
 for nn in (False, True):
     algos = ALGOS + (["nnrows"] if nn else [])
-    res = ab_algos.measure(cl, ev, shapes, algos, rounds=3, iters=10, nn=nn, f32=F32)
+    res = ab_algos.measure(cl, ev, shapes, algos, rounds=3, iters=10, nn=nn, f32=F32, c32=bool(os.environ.get("AUDIT_C32")))   # AUDIT_C32: bf16 operands, f32 C
     print(f"== rhs {'row-major [K][N]' if nn else '[N][K]'}: {len(shapes)} shapes (seed {seed})")
     for (m, n, k), r in res.items():
         us = {a: t for a, t in r["us"].items() if t == t}
