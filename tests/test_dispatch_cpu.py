@@ -26,8 +26,10 @@ TABLE = [
     ("... ragged tiles too (7680 x 3776 x 6144: 256.6 us / 275.2)", (7680, 3776, 6144, BF, F32, 0, 1, 1), "LP_256M16", (0, 0)),
     ("... a row-major rhs stays on the 32x32x16 kernel (the 16x16x32 one-tile kernel has no transposing-read form)", (6144, 4096, 8192, BF, F32, 0, 0, 1), "LP_256W4", (0, 0)),
     ("f32 C, K = 256 on 1932 tiles: the single-stage 128x128 kernel past the 16-bit-C tile bound (99.4 us / 115.4)", (11712, 10624, 256, BF, F32, 0, 1, 1), "LP_128", (0, 0)),
-    ("f32 C, a batch of full tiles at K = 128: the persistent kernel's overlapped stores (28.4 us / 33.7)", (2048, 2048, 128, BF, F32, 0, 1, 8), "LP_256P", (0, 0)),
-    ("... 16-bit C: the single-stage 128x128 kernel as before", (2048, 2048, 128, BF, None, 0, 1, 8), "LP_128", (0, 0)),
+    ("f32 C, a batch of full tiles at K = 128: the single-stage 128x128 kernel, as with a 16-bit C (the persistent kernel measured ahead on four batched shapes and behind on two: no rule)", (2048, 2048, 128, BF, F32, 0, 1, 8), "LP_128", (0, 0)),
+    ("f32 C, K = 256 on 135 square tiles: the 128x128 kernel up to 176 of them (14.2 us / 18.7)", (11304, 720, 256, BF, F32, 0, 1, 1), "LP_128", (0, 0)),
+    ("f32 C, few columns x one K-tile: the streaming kernel below 16384 along the long side (5.4 -> 3.8 us)", (9168, 18, 64, BF, F32, 0, 1, 1), "STREAM64", (0, 0)),
+    ("... 16-bit C: the 128x128 kernel from 4096", (9168, 18, 64, BF, None, 0, 1, 1), "LP_128", (0, 0)),
     ("C3 with the reference's default rhs layout: the persistent 16x16x32 kernel's transposing-read form (round 6, second K loop: 1 474 -> 1 617 TFLOP/s)", (8192, 8192, 8192, BF, None, 0, 0, 1), "LP_256QM", (0, 0)),
     ("... at K = 4096: the persistent 16x16x32 kernel's row-major form (1 401 -> 1 444 TFLOP/s)", (8192, 8192, 4096, BF, None, 0, 0, 1), "LP_256QM", (0, 0)),
     ("C2: 4096^3 f32", (4096, 4096, 4096, F32, F32, 0, 1, 1), "LP_256W4", (0, 0)),
