@@ -120,6 +120,9 @@ TABLE = [
     ("transposed lhs, rows of C not a multiple of 8", (516, 512, 1024, BF, None, 1, 0, 1), "LP_128", (1, 0)),
     ("fp8", (8192, 8192, 8192, E4, BF, 0, 1, 1), "LP_256W4", (0, 0)),
     ("fp8, mid size", (2048, 2048, 2048, E4, BF, 0, 1, 1), "LP_128", (0, 0)),
+    ("fp8, four K-tiles of 128 values on 1152 square tiles: the 128x128 kernel (late round 6, the fp8 audit: 50.7 us / 59.2)", (8128, 9024, 512, E4, BF, 0, 1, 1), "LP_128", (0, 0)),
+    ("fp8, K = 1024: the square tile from here (0.82 ... 0.93 of the 128x128 kernel's time)", (7424, 7680, 1024, E4, BF, 0, 1, 1), "LP_256W4", (0, 0)),
+    ("fp8, 64 columns: the 128x128 kernel at any K (16.9 us / 19.4)", (48424, 64, 1024, E4, BF, 0, 1, 1), "LP_128", (0, 0)),
     ("fp8 with a row-major rhs", (4096, 4096, 4096, E4, BF, 0, 0, 1), "LP_256W4", (0, 1)),
     ("K not a multiple of the K-tile: zero-padded copies", (512, 512, 1000, F16, F32, 0, 1, 1), "LP_128", (1, 1)),
     ("four rows on a small grid", (4, 2048, 4096, BF, None, 0, 1, 1), "SKINNY", (0, 0)),

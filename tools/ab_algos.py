@@ -23,10 +23,11 @@ NAMES = {"auto": 0, "generic": 1, "f32": 2, "lp128": 3, "lp256": 4, "lp256w4": 5
 BY_ID = {v: k for k, v in NAMES.items()}
 
 
-def measure(client, ev, shapes, algos, rounds=5, nn=False, iters=20, cold=True, f32=False, c32=False):
+def measure(client, ev, shapes, algos, rounds=5, nn=False, iters=20, cold=True, f32=False, c32=False, fp8=False):
     lib, ctx = client.lib, client.ctx
     et, dt, esz = (ElemType.F32, N.DTYPE_F32, 4) if f32 else (ElemType.BF16, N.DTYPE_BF16, 2)
-    dtc, csz = (N.DTYPE_F32, 4) if c32 else (dt, esz)          # c32: 16-bit operands, f32 C (the cmma tests' accumulator type as the output)
+    if fp8: et, dt, esz = ElemType.F8E4M3, N.DTYPE_F8E4M3, 1          # fp8 operands; C bf16 (or f32 with c32)
+    dtc, csz = (N.DTYPE_F32, 4) if c32 else (N.DTYPE_BF16, 2) if fp8 else (dt, esz)          # c32: 16-bit operands, f32 C (the cmma tests' accumulator type as the output)
     out = {}
     for (m, n, k) in shapes:
         fp = esz * (m * k + n * k) + csz * m * n

@@ -23,14 +23,17 @@ while len(shapes) < count:
     elif kind == "big": m, n = dim(2048, 12288, 64), dim(2048, 12288, 64)
     else: m, n = dim(4096, 65536, 8), dim(64, 1024, 8)
     k = 64 * rng.choice([1, 2, 4, 8, 16, 24, 32, 48, 64, 96, 128, 224])
+    if os.environ.get("AUDIT_FP8"): k *= 2                                            # (a K-tile = 128 fp8 values)
     if 2.0 * m * n * k > (3e11 if os.environ.get("AUDIT_F32") else 3e12) or 2.0 * (m * k + n * k + m * n) > (6e8 if os.environ.get("AUDIT_F32") else 1.2e9): continue
     shapes.append((m, n, k))
 ALGOS = ["auto", "lp128", "lp256x128", "lp256w4", "lp256p", "lp256q", "stream64", "skinny", "lp256x192", "lp192x192", "lp256m16", "lp256qm"]
 F32 = bool(os.environ.get("AUDIT_F32"))                 # f32 operands and output: the kernels that take them
 if F32: ALGOS = ["auto", "f32", "lp256w4", "lp256p", "skinny", "stream64"]
+FP8 = bool(os.environ.get("AUDIT_FP8"))                 # fp8 (e4m3) operands, bf16 C: the kernels that take them
+if FP8: ALGOS = ["auto", "lp128", "lp256w4", "lp256p"]
 for nn in (False, True):
     algos = ALGOS + (["nnrows"] if nn else [])
-    res = ab_algos.measure(cl, ev, shapes, algos, rounds=3, iters=10, nn=nn, f32=F32, c32=bool(os.environ.get("AUDIT_C32")))   # AUDIT_C32: bf16 operands, f32 C
+    res = ab_algos.measure(cl, ev, shapes, algos, rounds=3, iters=10, nn=nn, f32=F32, c32=bool(os.environ.get("AUDIT_C32")), fp8=FP8)   # AUDIT_C32: bf16 operands, f32 C
     print(f"== rhs {'row-major [K][N]' if nn else '[N][K]'}: {len(shapes)} shapes (seed {seed})")
     for (m, n, k), r in res.items():
         us = {a: t for a, t in r["us"].items() if t == t}
