@@ -1119,8 +1119,10 @@ def test_fp8_128x128_kernel_every_pipeline_form(client, oracle, dtype, m, n, k, 
     """1, 2, 9, 5 ... K-tiles through the 2-stage and the 4-stage ring, ragged edges, the split-K slabs, batches."""
     out = ElemType.BF16 if (m + n) % 3 else ElemType.F32
     run_case(client, oracle, m, n, k, dtype, out, True, N.GEMM_ALGO_LP_128, batch=batch)
-    d = N.GemmDesc(m=3072, n=3072, k=512, batch=1, lda=512, ldb=512, ldc=3072, dtype_ab=int(dtype), dtype_c=N.DTYPE_BF16, trans_b=1)
-    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4                  # 144 tiles of 256^2
+    d = N.GemmDesc(m=3072, n=3072, k=1024, batch=1, lda=1024, ldb=1024, ldc=3072, dtype_ab=int(dtype), dtype_c=N.DTYPE_BF16, trans_b=1)
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4                  # 144 tiles of 256^2, eight K-tiles of 128 values
+    d.k = d.lda = d.ldb = 512                                                  # four K-tiles: the 128x128 kernel (late round 6, the fp8 audit: level or ahead on 19 of 21
+    assert ops.gemm_select(client, d) == N.GEMM_ALGO_LP_128                    # shapes past 100 square tiles at K = 512)
 
 
 def test_fp8_identity_returns_operand_values_and_batches(client, oracle):
