@@ -114,7 +114,10 @@ TABLE = [
     ("weight gradient lhs^T . grad: native", (512, 512, 8192, BF, None, 1, 0, 1), "LP_128", (0, 0)),
     ("weight gradient, mid size: native", (2048, 2048, 8192, BF, None, 1, 0, 1), "LP_128", (0, 0)),
     ("transposed lhs on a 256-tile shape: native on the 256^2 kernel as well", (8192, 8192, 8192, BF, None, 1, 0, 1), "LP_256W4", (0, 0)),
-    ("transposed lhs where a narrow tile would run: A through scratch, B stays", (4096, 2048, 4096, BF, None, 1, 0, 1), "LP_192X192", (1, 0)),
+    ("transposed lhs where a narrow tile would run for a K-contiguous A: the cheaper native form by the table's rows (late round 6, the audit of this layout: the scratch pass was never paid back, up to 3.2 x)", (4096, 2048, 4096, BF, None, 1, 0, 1), "LP_256W4", (0, 0)),
+    ("... tall, 144 columns: native on the square tile (400.9 us re-laid out + 192^2 / 126.6)", (42320, 144, 6144, BF, None, 1, 0, 1), "LP_256W4", (0, 0)),
+    ("... short K, few row tiles: native on the 128x128 kernel (20.5 us / 12.6)", (744, 5432, 512, BF, None, 1, 0, 1), "LP_128", (0, 0)),
+    ("transposed lhs x 64 columns of a row-major rhs: the 128x128 kernel takes it as it is (22 us; the scalar kernel ran before: 447)", (10376, 64, 2048, BF, None, 1, 0, 1), "LP_128", (0, 0)),
     ("transposed lhs, many short tiles: the one-tile kernel, not the persistent forms", (2048, 2048, 2048, BF, None, 1, 0, 64), "LP_256W4", (0, 0)),
     ("both transposed", (512, 512, 1024, BF, None, 1, 1, 1), "LP_128", (1, 0)),
     ("transposed lhs, rows of C not a multiple of 8", (516, 512, 1024, BF, None, 1, 0, 1), "LP_128", (1, 0)),

@@ -1702,6 +1702,9 @@ def _tn_desc(m, n, k, dtype, out, lda=None, ldb=None, batch=1, algo=N.GEMM_ALGO_
     (4104, 3080, 448, 1, 4112, False, "lp256w4"),     # ... edge tiles in both directions, padded rows of A, f32 C
     (2304, 2560, 1024, 2, None, True, "lp256w4"),     # ... batches
     (4096, 4096, 4096, 1, None, True, "auto256"),     # a weight gradient of a large layer: AUTO takes the 256 x 256 kernel natively
+    (4096, 2048, 4096, 1, None, True, "auto256"),     # (late round 6) ... and where a narrow tile would run for a K-contiguous A: no scratch transposition any more
+    (744, 5432, 512, 1, None, True, "auto"),          # ... the 128 x 128 kernel where the table's rows say so
+    (10376, 64, 2048, 1, None, False, "auto"),        # ... 64 columns of a row-major rhs: as it is on the 128 x 128 kernel
 ])
 def test_transposed_a_with_row_major_b_is_staged_natively_and_gives_the_bits_of_the_k_contiguous_form(client, oracle, dtype, m, n, k, batch, lda,
                                                                                                      out16, algo):
@@ -1741,12 +1744,15 @@ def test_transposed_a_with_row_major_b_is_staged_natively_and_gives_the_bits_of_
 
 def test_transposed_a_selection_and_refusals(client, oracle):
     bf = ElemType.BF16
-    # a 256-tile shape is native on the 256 x 256 kernel; where a narrower tile would run (they stage a K-contiguous A only), A is
-    # transposed into scratch and the row-major B stays where it is
+    # a 256-tile shape is native on the 256 x 256 kernel; where a narrower tile would run for a K-contiguous A (they stage that form only), the
+    # cheaper of the two native forms (late round 6: the scratch transposition of A was never paid back by the better tile -- 42320 x 144 x 6144
+    # 400.9 us re-laid out against 126.6 native, profiles/r06_random_audit_ta.txt)
     d = _tn_desc(8192, 8192, 8192, bf, bf)
     assert ops.gemm_relayout_plan(client, d) == (False, False) and ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
     d = _tn_desc(4096, 2048, 4096, bf, bf)
-    assert ops.gemm_relayout_plan(client, d) == (True, False) and ops.gemm_select(client, d) == N.GEMM_ALGO_LP_192X192
+    assert ops.gemm_relayout_plan(client, d) == (False, False) and ops.gemm_select(client, d) == N.GEMM_ALGO_LP_256W4
+    d = _tn_desc(744, 5432, 512, bf, bf)
+    assert ops.gemm_relayout_plan(client, d) == (False, False) and ops.gemm_select(client, d) == N.GEMM_ALGO_LP_128
     # rows of C not a multiple of 8 / A and B both transposed: no native form
     assert ops.gemm_relayout_plan(client, _tn_desc(516, 512, 1024, bf, bf)) == (True, False)
     assert ops.gemm_relayout_plan(client, _tn_desc(512, 512, 1024, bf, bf, trans_b=1)) == (True, False)

@@ -23,7 +23,7 @@ NAMES = {"auto": 0, "generic": 1, "f32": 2, "lp128": 3, "lp256": 4, "lp256w4": 5
 BY_ID = {v: k for k, v in NAMES.items()}
 
 
-def measure(client, ev, shapes, algos, rounds=5, nn=False, iters=20, cold=True, f32=False, c32=False, fp8=False):
+def measure(client, ev, shapes, algos, rounds=5, nn=False, iters=20, cold=True, f32=False, c32=False, fp8=False, ta=False):
     lib, ctx = client.lib, client.ctx
     et, dt, esz = (ElemType.F32, N.DTYPE_F32, 4) if f32 else (ElemType.BF16, N.DTYPE_BF16, 2)
     if fp8: et, dt, esz = ElemType.F8E4M3, N.DTYPE_F8E4M3, 1          # fp8 operands; C bf16 (or f32 with c32)
@@ -36,12 +36,12 @@ def measure(client, ev, shapes, algos, rounds=5, nn=False, iters=20, cold=True, 
                  TensorHandle.uniform(client, (n, k), et, 1, 2 * i + 2, -1.0, 1.0), client.empty(m * n * csz)) for i in range(nsets)]
         times = {a: [] for a in algos}
         sel = C.c_int32()
-        d0 = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=(n if nn else k), ldc=n, dtype_ab=dt, dtype_c=dtc, trans_b=0 if nn else 1, algo=0)
+        d0 = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=(m if ta else k), trans_a=1 if ta else 0, ldb=(n if nn else k), ldc=n, dtype_ab=dt, dtype_c=dtc, trans_b=0 if nn else 1, algo=0)
         lib.mi355_gemm_select(ctx, C.byref(d0), C.byref(sel))
         turn = [0]
         for _ in range(rounds):
             for a in algos:
-                d = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=(n if nn else k), ldc=n, dtype_ab=dt, dtype_c=dtc,
+                d = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=(m if ta else k), trans_a=1 if ta else 0, ldb=(n if nn else k), ldc=n, dtype_ab=dt, dtype_c=dtc,
                                trans_b=0 if nn else 1, algo=NAMES[a])
 
                 def call():

@@ -31,9 +31,11 @@ F32 = bool(os.environ.get("AUDIT_F32"))                 # f32 operands and outpu
 if F32: ALGOS = ["auto", "f32", "lp256w4", "lp256p", "skinny", "stream64"]
 FP8 = bool(os.environ.get("AUDIT_FP8"))                 # fp8 (e4m3) operands, bf16 C: the kernels that take them
 if FP8: ALGOS = ["auto", "lp128", "lp256w4", "lp256p"]
-for nn in (False, True):
+TA = bool(os.environ.get("AUDIT_TA"))                   # lhs stored [K][M] (MatrixBatchLayout::MildlyPermuted { transposed: true }) x row-major rhs: lhs^T . grad_out, the weight-gradient product
+if TA: ALGOS = ["auto", "lp128", "lp256w4"]
+for nn in ((True,) if TA else (False, True)):
     algos = ALGOS + (["nnrows"] if nn else [])
-    res = ab_algos.measure(cl, ev, shapes, algos, rounds=3, iters=10, nn=nn, f32=F32, c32=bool(os.environ.get("AUDIT_C32")), fp8=FP8)   # AUDIT_C32: bf16 operands, f32 C
+    res = ab_algos.measure(cl, ev, shapes, algos, rounds=3, iters=10, nn=nn, f32=F32, c32=bool(os.environ.get("AUDIT_C32")), fp8=FP8, ta=TA)   # AUDIT_C32: bf16 operands, f32 C
     print(f"== rhs {'row-major [K][N]' if nn else '[N][K]'}: {len(shapes)} shapes (seed {seed})")
     for (m, n, k), r in res.items():
         us = {a: t for a, t in r["us"].items() if t == t}

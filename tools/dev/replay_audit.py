@@ -2,7 +2,7 @@
 """Replays a seeded audit's timed cases (AUDIT_ALL_TIMES=1 tools/dev/random_audit.py: every kernel's time for every shape; AUDIT_F32=1 f32 operands, AUDIT_C32=1 bf16
 operands with an f32 C) against the dispatcher as built now:
 `mi355_gemm_select` is a host function of the descriptor alone (ctx may be NULL), so what AUTO would pick today -- and how far behind the fastest timed kernel that pick is --
-can be counted without a GPU.  usage: python tools/dev/replay_audit.py [--f32 | --c32 | --bf16 | --fp8] [files ...]   (default: --f32 on the two f32 files)"""
+can be counted without a GPU.  usage: python tools/dev/replay_audit.py [--f32 | --c32 | --bf16 | --fp8 | --ta] [files ...]   (default: --f32 on the two f32 files)"""
 import os, sys, re, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -13,7 +13,8 @@ NAME = {N.GEMM_ALGO_F32_MFMA: "f32", N.GEMM_ALGO_LP_256W4: "lp256w4", N.GEMM_ALG
         N.GEMM_ALGO_LP_256X192: "lp256x192", N.GEMM_ALGO_LP_192X192: "lp192x192", N.GEMM_ALGO_LP_256M16: "lp256m16", N.GEMM_ALGO_LP_256QM: "lp256qm"}
 args = [x for x in sys.argv[1:] if not x.startswith("--")]
 mode = ([x for x in sys.argv[1:] if x.startswith("--")] or ["--f32"])[0]
-DT_AB, DT_C = {"--f32": (N.DTYPE_F32, N.DTYPE_F32), "--c32": (N.DTYPE_BF16, N.DTYPE_F32), "--bf16": (N.DTYPE_BF16, N.DTYPE_BF16), "--fp8": (N.DTYPE_F8E4M3, N.DTYPE_BF16)}[mode]
+DT_AB, DT_C = {"--f32": (N.DTYPE_F32, N.DTYPE_F32), "--c32": (N.DTYPE_BF16, N.DTYPE_F32), "--bf16": (N.DTYPE_BF16, N.DTYPE_BF16), "--fp8": (N.DTYPE_F8E4M3, N.DTYPE_BF16), "--ta": (N.DTYPE_BF16, N.DTYPE_BF16)}[mode]
+TA = mode == "--ta"                                     # lhs stored [K][M]
 files = args or ["profiles/r06_audit_times_f32_fit.txt", "profiles/r06_audit_times_f32_held_out.txt"]
 for path in files:
     nn, cases, behind, untimed, regret = 0, 0, [], 0, 0.0
@@ -26,8 +27,8 @@ for path in files:
         # the forced 256 x 256 launch is the plain one; AUTO's is split where the launcher plans a tail split: where AUTO chose the square tile when the file was
         # taken, its time is what a pick of the square tile gets today
         if mt.group(4) == "lp256w4" and "lp256w4" in us: us["lp256w4"] = min(us["lp256w4"], float(mt.group(5)))
-        d = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=k, ldb=n if nn else k, ldc=n, stride_a=m * k, stride_b=n * k, stride_c=m * n, dtype_ab=DT_AB, dtype_c=DT_C,
-                       trans_a=0, trans_b=0 if nn else 1, algo=N.GEMM_ALGO_AUTO)
+        d = N.GemmDesc(m=m, n=n, k=k, batch=1, lda=m if TA else k, ldb=n if nn else k, ldc=n, stride_a=m * k, stride_b=n * k, stride_c=m * n, dtype_ab=DT_AB, dtype_c=DT_C,
+                       trans_a=1 if TA else 0, trans_b=0 if nn else 1, algo=N.GEMM_ALGO_AUTO)
         algo = C.c_int32(-1)
         assert lib.mi355_gemm_select(None, C.byref(d), C.byref(algo)) == N.OK
         pick = NAME.get(algo.value, str(algo.value))
