@@ -51,6 +51,15 @@ ALGOS_NN = ["auto", "lp128", "nnrows"]
 GRID_F32 = [(1, 8192, 8192), (4, 8192, 8192), (8, 8192, 8192), (16, 8192, 8192), (32, 4096, 4096), (64, 8192, 8192), (16, 28672, 4096),
             (4096, 32, 4096), (16, 1024, 1024), (8192, 8, 8192), (128, 4096, 4096)]
 ALGOS_F32 = ["auto", "f32", "skinny", "stream64"]
+# late round 6: the layouts / types the seeded audits had never run -- each shape decided by 15 % or more in its audit (profiles/dispatch_rules.md)
+GRID_F32_TILES = [(4672, 3968, 4096), (4160, 4096, 4096), (3072, 3072, 3072), (96, 57504, 512), (27, 18104, 64), (7, 49648, 64), (15, 14168, 64)]   # f32 tile table, short-K rules
+ALGOS_F32_TILES = ["auto", "f32", "lp256w4", "stream64"]
+GRID_C32 = [(7680, 3776, 6144), (10944, 5184, 512), (11712, 10624, 256), (11304, 720, 256), (9168, 18, 64), (6144, 4096, 8192)]                    # bf16 operands, f32 C
+ALGOS_C32 = ["auto", "lp128", "lp256w4", "lp256m16", "stream64", "lp256x192"]
+GRID_FP8 = [(2304, 8000, 128), (10688, 3136, 256), (8128, 9024, 512), (7424, 7680, 1024), (48448, 64, 256), (6976, 8448, 2048)]                      # e4m3 operands, bf16 C
+ALGOS_FP8 = ["auto", "lp128", "lp256w4"]
+GRID_TA = [(42320, 144, 6144), (37648, 192, 4096), (60544, 696, 6144), (744, 5432, 512), (10376, 64, 2048), (4096, 2048, 4096), (8192, 8192, 2048)]   # lhs stored [K][M] x row-major rhs
+ALGOS_TA = ["auto", "lp128", "lp256w4"]
 BAR_RATIO, BAR_US = 1.10, 2.0
 
 
@@ -66,13 +75,29 @@ def test_auto_on_f32_few_rows(client):
     audit(client, GRID_F32, ALGOS_F32, False, "select_audit_f32.txt", f32=True)
 
 
-def audit(client, grid, algos, nn, log_name, f32=False):
+def test_auto_on_f32_tiles_and_short_k(client):
+    audit(client, GRID_F32_TILES, ALGOS_F32_TILES, False, "select_audit_f32_tiles.txt", f32=True)
+
+
+def test_auto_with_an_f32_c(client):
+    audit(client, GRID_C32, ALGOS_C32, False, "select_audit_c32.txt", c32=True)
+
+
+def test_auto_on_fp8(client):
+    audit(client, GRID_FP8, ALGOS_FP8, False, "select_audit_fp8.txt", fp8=True)
+
+
+def test_auto_on_a_transposed_lhs(client):
+    audit(client, GRID_TA, ALGOS_TA, True, "select_audit_ta.txt", ta=True)
+
+
+def audit(client, grid, algos, nn, log_name, f32=False, **kind):
     sys.path.insert(0, str(ROOT / "tools"))
     sys.path.insert(0, str(ROOT))
     import ab_algos
     import bench
     ev = bench.Events(client)
-    res = ab_algos.measure(client, ev, grid, algos, rounds=3, iters=10, nn=nn, f32=f32)
+    res = ab_algos.measure(client, ev, grid, algos, rounds=3, iters=10, nn=nn, f32=f32, **kind)
 
     def is_behind(r):
         us = {a: t for a, t in r["us"].items() if t == t}
@@ -81,7 +106,7 @@ def audit(client, grid, algos, nn, log_name, f32=False):
     # a shape that looks behind is measured once more, longer, before it counts (a 20 us launch beside a DVFS step is noisy)
     suspects = [shape for shape, r in res.items() if is_behind(r)]
     if suspects:
-        res.update(ab_algos.measure(client, ev, suspects, algos, rounds=7, iters=20, nn=nn, f32=f32))
+        res.update(ab_algos.measure(client, ev, suspects, algos, rounds=7, iters=20, nn=nn, f32=f32, **kind))
     lines, behind = [], []
     for (m, n, k), r in res.items():
         us = {a: t for a, t in r["us"].items() if t == t}
