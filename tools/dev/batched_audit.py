@@ -24,8 +24,10 @@ if os.environ.get("AUDIT_ORDER"):            # dev: another measurement order (i
     ALGOS = os.environ["AUDIT_ORDER"].split(",")
 C32 = bool(os.environ.get("AUDIT_C32"))          # bf16 operands, f32 C
 CSZ, DTC = (4, N.DTYPE_F32) if C32 else (2, N.DTYPE_BF16)
+TA = bool(os.environ.get("AUDIT_TA"))            # lhs stored [K][M] per matrix x row-major rhs (the weight-gradient / attention-backward products)
+if TA: ALGOS = ["auto", "lp128", "lp256w4"]
 behind = total = 0
-for nn in (False, True):
+for nn in ((True,) if TA else (False, True)):
     print(f"== rhs {'row-major [K][N]' if nn else '[N][K]'}: {len(SHAPES)} shapes  (batch x M x N x K)")
     for (bt, m, n, k) in SHAPES:
         fp = 2 * bt * (m * k + n * k) + CSZ * bt * m * n
@@ -33,7 +35,7 @@ for nn in (False, True):
         sets = [(TensorHandle.uniform(cl, (bt * m, k), ElemType.BF16, 1, 2 * i + 1, -1.0, 1.0),
                  TensorHandle.uniform(cl, (bt * n, k), ElemType.BF16, 1, 2 * i + 2, -1.0, 1.0), cl.empty(bt * m * n * CSZ)) for i in range(nsets)]
         def desc(algo):
-            return N.GemmDesc(m=m, n=n, k=k, batch=bt, lda=k, ldb=(n if nn else k), ldc=n, stride_a=m * k, stride_b=n * k, stride_c=m * n,
+            return N.GemmDesc(m=m, n=n, k=k, batch=bt, lda=(m if TA else k), trans_a=1 if TA else 0, ldb=(n if nn else k), ldc=n, stride_a=m * k, stride_b=n * k, stride_c=m * n,
                               dtype_ab=N.DTYPE_BF16, dtype_c=DTC, trans_b=0 if nn else 1, algo=algo)
         sel = C.c_int32(); lib.mi355_gemm_select(ctx, C.byref(desc(0)), C.byref(sel))
         times = {a: [] for a in ALGOS}; turn = [0]
