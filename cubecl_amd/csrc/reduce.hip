@@ -728,8 +728,11 @@ template <int OP> struct axis_op {
 template <int THREADS, int OP, int DT = MI355_DTYPE_F32>
 __global__ void __launch_bounds__(THREADS)
 reduce_rows(const typename red_in<DT>::elem *__restrict__ in, float *__restrict__ out_sum, uint32_t *__restrict__ out_idx, uint64_t rows,
-            uint64_t cols, uint64_t row_stride, int vec_ok)
+            uint64_t cols_all, uint64_t row_stride, int vec_ok, uint32_t segs = 1, uint64_t seg_len = 0, float *__restrict__ part_val = nullptr,
+            uint32_t *__restrict__ part_key = nullptr, uint64_t *__restrict__ part_idx = nullptr)
 {
+    // (late round 6) segs > 1: few, long rows -- every row is cut into `segs` spans of `seg_len` elements (the last one shorter), a workgroup folds one span and leaves the
+    // raw fold (value + NaN flag, or key + index in the row) in library scratch; fold_row_segments finishes the rows.  13 x 992618 f32 ran on 13 workgroups: 270 us for 52 MB.
     typedef axis_op<OP> O;
     typedef typename O::V V;
     constexpr bool ARG = O::ARG;
@@ -741,8 +744,16 @@ reduce_rows(const typename red_in<DT>::elem *__restrict__ in, float *__restrict_
     __shared__ float s_sum[WAVES];
     __shared__ uint32_t s_key[WAVES];
     __shared__ uint64_t s_idx[WAVES];
-    for (uint64_t row = blockIdx.x; row < rows; row += gridDim.x) {
-        const typename RI::elem *__restrict__ p = in + row * row_stride;
+    for (uint64_t vr = blockIdx.x; vr < rows * segs; vr += gridDim.x) {
+        const uint64_t row = segs > 1 ? vr / segs : vr, first = segs > 1 ? (vr % segs) * seg_len : 0;
+        const uint64_t cols = segs > 1 ? (cols_all - first < seg_len ? cols_all - first : seg_len) : cols_all;      // (the host leaves no span empty)
+        const typename RI::elem *__restrict__ p = in + row * row_stride + first;
+        auto put_val = [&](float t, bool nan) {
+            if (segs > 1) { part_val[vr] = t; part_key[vr] = nan ? 1u : 0u; } else out_sum[row] = O::finish(t, nan, cols);
+        };
+        auto put_idx = [&](uint32_t k, uint64_t ix) {
+            if (segs > 1) { part_key[vr] = k; part_idx[vr] = ix + first; } else out_idx[row] = cols ? (uint32_t)ix : 0u;
+        };
         float a0 = V::identity(), a1 = V::identity(), a2 = V::identity(), a3 = V::identity();
         bool nan_seen = false;
         uint32_t key = 0u; uint64_t idx = ~0ull;
@@ -752,10 +763,15 @@ reduce_rows(const typename red_in<DT>::elem *__restrict__ in, float *__restrict_
         constexpr float NAN_LEADS = AMIN ? -__builtin_inff() : __builtin_inff();
         typedef vop<AMIN ? VOP_MIN : VOP_MAX> X;
         float best_val = -NAN_LEADS;
-        uint64_t done = 0;
+        // (late round 6: the 16-byte body starts at the ROW's own first aligned element -- until then one flag covered the launch, and a row length that is not a
+        //  multiple of the vector (or a base off the 16-byte grid) sent every row through the scalar loop: 1404 x 133719 bf16 188 us = 0.25 of HBM, 635518 x 250 156 us)
+        uint64_t head = cols, done = cols;
         if (vec_ok) {
-            const u32x4r *__restrict__ vp = reinterpret_cast<const u32x4r *>(p);
-            const uint64_t nv = cols / EPV;
+            head = ((16u - (uint32_t)(reinterpret_cast<uintptr_t>(p) & 15u)) & 15u) / (uint32_t)sizeof(typename RI::elem);
+            // (a short row off the grid stays on the scalar loop as before: under 2 KiB the peel costs more than the vectors save -- 48382 x 147 bf16 8.1 us -> 14.9 with it)
+            if (head > cols || (head != 0 && cols * sizeof(typename RI::elem) < 2048)) head = cols;
+            const u32x4r *__restrict__ vp = reinterpret_cast<const u32x4r *>(p + head);
+            const uint64_t nv = (cols - head) / EPV;
             constexpr int UL = 4;                                   // 16-byte loads in flight per lane (the data is read once: non-temporal)
             for (uint64_t i0 = tid; i0 < nv; i0 += (uint64_t)THREADS * UL) {
                 u32x4r raw[UL];
@@ -788,43 +804,46 @@ reduce_rows(const typename red_in<DT>::elem *__restrict__ in, float *__restrict_
 #pragma unroll
                             for (int c = 0; c < EPV; ++c) {
                                 const uint32_t k = arg_key<O::AOP>(v[c]);
-                                if (k > key) { key = k; idx = i * EPV + c; best_val = (k == 0xFFFFFFFFu) ? NAN_LEADS : v[c]; }
+                                if (k > key) { key = k; idx = head + i * EPV + c; best_val = (k == 0xFFFFFFFFu) ? NAN_LEADS : v[c]; }
                             }
                         }
                     }
                 }
             }
-            done = nv * EPV;
+            done = head + nv * EPV;
         }
-        for (uint64_t i = done + tid; i < cols; i += THREADS) {
-            const float v = RI::widen(p[i]);
+        // the elements before the first and after the last whole vector (every element when the base is off its element grid).  A lane meets the head's
+        // indices after its body's: equal keys keep the lower index explicitly
+        for (uint64_t i = tid; i < head + (cols - done); i += THREADS) {
+            const uint64_t e = i < head ? i : done + (i - head);
+            const float v = RI::widen(p[e]);
             if (!ARG) { a0 = V::apply(a0, v); if (V::TRACKS_NAN) nan_seen |= (v != v); }
-            else { const uint32_t k = arg_key<O::AOP>(v); if (k > key) { key = k; idx = i; } }
+            else { const uint32_t k = arg_key<O::AOP>(v); if (k > key || (k == key && e < idx)) { key = k; idx = e; } }
         }
         if (!ARG) {
             float s = wave_fold<O::VOP>(V::apply(V::apply(a0, a1), V::apply(a2, a3)));
             const bool wave_nan = V::TRACKS_NAN ? (bool)__any(nan_seen) : false;
-            if (WAVES == 1) { if (lane == 0) out_sum[row] = O::finish(s, wave_nan, cols); }
+            if (WAVES == 1) { if (lane == 0) put_val(s, wave_nan); }
             else {
                 if (lane == 0) { s_sum[wave] = s; s_key[wave] = wave_nan ? 1u : 0u; }
                 __syncthreads();
                 if (tid == 0) {
                     float t = V::identity(); uint32_t nn = 0u;
                     for (int w = 0; w < WAVES; ++w) { t = V::apply(t, s_sum[w]); nn |= s_key[w]; }
-                    out_sum[row] = O::finish(t, nn != 0u, cols);
+                    put_val(t, nn != 0u);
                 }
                 __syncthreads();
             }
         } else {
             wave_argmax(key, idx);
-            if (WAVES == 1) { if (lane == 0) out_idx[row] = cols ? (uint32_t)idx : 0u; }
+            if (WAVES == 1) { if (lane == 0) put_idx(key, idx); }
             else {
                 if (lane == 0) { s_key[wave] = key; s_idx[wave] = idx; }
                 __syncthreads();
                 if (tid == 0) {
                     uint32_t k = s_key[0]; uint64_t ix = s_idx[0];
                     for (int w = 1; w < WAVES; ++w) arg_combine(k, ix, s_key[w], s_idx[w]);
-                    out_idx[row] = cols ? (uint32_t)ix : 0u;
+                    put_idx(k, ix);
                 }
                 __syncthreads();
             }
@@ -1090,6 +1109,28 @@ int32_t run_mid(mi355_ctx *ctx, mi355_stream stream, const typename red_in<DT>::
     return MI355_OK;
 }
 
+// the rows of a segmented reduce_rows launch: one thread per row walks its spans in order (at most 1024 of them)
+template <int OP>
+__global__ void __launch_bounds__(64)
+fold_row_segments(const float *__restrict__ part_val, const uint32_t *__restrict__ part_key, const uint64_t *__restrict__ part_idx, uint32_t segs,
+                  uint64_t rows, uint64_t cols, float *__restrict__ out_sum, uint32_t *__restrict__ out_idx)
+{
+    typedef axis_op<OP> O;
+    typedef typename O::V V;
+    const uint64_t row = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (row >= rows) return;
+    const uint64_t at = row * segs;
+    if constexpr (!O::ARG) {
+        float t = V::identity(); uint32_t nn = 0u;
+        for (uint32_t g = 0; g < segs; ++g) { t = V::apply(t, part_val[at + g]); nn |= part_key[at + g]; }
+        out_sum[row] = O::finish(t, nn != 0u, cols);
+    } else {
+        uint32_t k = part_key[at]; uint64_t ix = part_idx[at];
+        for (uint32_t g = 1; g < segs; ++g) arg_combine(k, ix, part_key[at + g], part_idx[at + g]);
+        out_idx[row] = (uint32_t)ix;
+    }
+}
+
 template <int OP, int DT = MI355_DTYPE_F32>
 int32_t run_rows(mi355_ctx *ctx, mi355_stream stream, const typename red_in<DT>::elem *in, float *out_sum, uint32_t *out_idx,
                  uint64_t rows, uint64_t cols, uint64_t row_stride, const char *what)
@@ -1105,9 +1146,33 @@ int32_t run_rows(mi355_ctx *ctx, mi355_stream stream, const typename red_in<DT>:
     if (ARG && cols > 0xFFFFFFFFull)
         return fail(ctx, MI355_E_UNSUPPORTED, "%s: cols exceed u32 index range", what);
     hipStream_t s = stream_of(ctx, stream);
-    const int vec_ok = ((reinterpret_cast<uintptr_t>(in) & 15u) == 0 && (row_stride % red_in<DT>::EPV) == 0) ? 1 : 0;
+    const int vec_ok = (reinterpret_cast<uintptr_t>(in) & (sizeof(typename red_in<DT>::elem) - 1)) == 0 ? 1 : 0;   // (each row finds its own first 16-byte boundary)
     const uint64_t cus = ctx->props.num_streaming_multiprocessors;
     const uint64_t cols32 = cols * sizeof(typename red_in<DT>::elem) / 4;        // row length in f32-equivalents (bytes / 4)
+    // few, long rows (late round 6, the seeded roofline audit of the axis reductions: 13 x 992618 f32 270 us = 0.02 of HBM on 13 workgroups): spans of at least 32 KiB, about
+    // eight workgroups of 256 threads per CU; not inside a capture window without scratch (the unsplit launch below is always valid)
+    if (cols32 >= 32768 && rows < cus * 2) {
+        uint64_t segs = std::min<uint64_t>({(cus * 8 + rows - 1) / rows, cols32 / 8192, 1024});
+        if (segs >= 2) {
+            constexpr uint64_t GRAIN = 1024;                                       // span length: whole 16-byte vectors for every lane of a wave
+            const uint64_t seg_len = ((cols + segs - 1) / segs + GRAIN - 1) / GRAIN * GRAIN;
+            segs = (cols + seg_len - 1) / seg_len;
+            void *scratch = nullptr;
+            const uint64_t vrows = rows * segs;
+            if (segs >= 2 && scratch_get(ctx, s, SCRATCH_REDUCE_AXIS, (size_t)vrows * 16, &scratch) == MI355_OK) {
+                uint64_t *part_idx = static_cast<uint64_t *>(scratch);
+                float *part_val = reinterpret_cast<float *>(part_idx + vrows);
+                uint32_t *part_key = reinterpret_cast<uint32_t *>(part_val + vrows);
+                const uint32_t grid = (uint32_t)std::min<uint64_t>(vrows, cus * 8);
+                hipLaunchKernelGGL((reduce_rows<256, OP, DT>), dim3(grid), dim3(256), 0, s, in, out_sum, out_idx, rows, cols, row_stride, vec_ok, (uint32_t)segs, seg_len,
+                                   part_val, part_key, part_idx);
+                hipLaunchKernelGGL((fold_row_segments<OP>), dim3((uint32_t)((rows + 63) / 64)), dim3(64), 0, s, part_val, part_key, part_idx, (uint32_t)segs, rows, cols,
+                                   out_sum, out_idx);
+                check_launch(ctx, what);
+                return MI355_OK;
+            }
+        }
+    }
     if (cols32 <= 2048) {
         const uint32_t grid = (uint32_t)std::min<uint64_t>(rows, cus * 32);
         hipLaunchKernelGGL((reduce_rows<64, OP, DT>), dim3(grid), dim3(64), 0, s, in, out_sum, out_idx, rows, cols,

@@ -744,7 +744,9 @@ def test_value_reduction_rules_nan_signed_zero_misaligned_and_bad_ops(client, or
 @pytest.mark.parametrize("dtype", [ElemType.F32, ElemType.BF16])
 @pytest.mark.parametrize("shape,axis", [((512, 8192), 1), ((128, 32768), 1), ((64, 256, 1024), 2), ((64, 64, 4096), 2),      # the book's shapes
                                         ((64, 256, 1024), 1), ((64, 256, 1024), 0), ((512, 8192), 0), ((3, 1000, 7), 1), ((1, 5, 1), 1),
-                                        ((2048, 33), 0), ((37, 1001), -1), ((5, 4, 3, 2), 2), ((1, 200_003), 1), ((1000, 1), 1)])
+                                        ((2048, 33), 0), ((37, 1001), -1), ((5, 4, 3, 2), 2), ((1, 200_003), 1), ((1000, 1), 1),
+                                        # (late round 6) few long rows cut into spans, rows that start off the 16-byte grid
+                                        ((13, 300_007), 1), ((3, 70_001), 1), ((130, 40_003), 1), ((257, 250), 1), ((1000, 133), 1)])
 def test_every_reduce_operation_over_any_axis(client, oracle, dtype, shape, axis):
     """mi355_reduce_axis / mi355_argreduce_axis over the book's shapes (cubecl-book/src/getting-started/src/bin/v7-gpu.rs:59-77)
     and the shapes of the sum / argmax axis tests: last axis (one wave / one workgroup per row), middle and first axis."""
@@ -783,6 +785,45 @@ def test_every_reduce_operation_over_any_axis(client, oracle, dtype, shape, axis
             assert np.array_equal(oi.to_numpy(client).reshape(out_shape or (1,)), oracle.reduce_axis_argmin(vals, ax).reshape(out_shape or (1,)))
             ops.argreduce_axis(client, t, oi, axis, "argmax")
             assert np.array_equal(oi.to_numpy(client).reshape(out_shape or (1,)), oracle.reduce_axis_argmax(vals, ax).reshape(out_shape or (1,)))
+
+
+@pytest.mark.parametrize("dtype", [ElemType.F32, ElemType.BF16])
+def test_long_rows_cut_into_spans_keep_the_index_rules(client, oracle, dtype):
+    """reduce_rows with segs > 1 (late round 6): equal extremes in different spans and in a row's unaligned head resolve to the lowest index, a NaN anywhere leads an index
+    operation and poisons max / min, and every row of an odd-length matrix (each starting at another offset from the 16-byte grid) gives the oracle's indices."""
+    rows, cols = 5, 131_075
+    x = (oracle.fill_uniform(rows * cols, 77, -1.0, 1.0) * np.float32(0.5)).reshape(rows, cols)
+    x[0, [3, 40_000, 131_074]] = 2.0                 # ties across the head, a middle span and the tail
+    x[1, [90_001, 90_002]] = -3.0                    # argmin ties inside one vector
+    x[2, 100_000] = np.nan                           # a NaN in a late span
+    x[2, 5] = 7.0
+    x[3, 131_074] = 9.0                              # the very last element
+    x[4, 0] = -9.0                                   # the very first
+    if dtype == ElemType.F32:
+        bits, vals = x, x
+    else:
+        bits = oracle.to_bf16(x.reshape(-1)).reshape(rows, cols)
+        vals = oracle.from_bf16(bits.reshape(-1)).reshape(rows, cols)
+    t = TensorHandle.from_numpy(client, bits, dtype)
+    o = TensorHandle.new_contiguous((rows,), client.empty(rows * 4), ElemType.F32)
+    oi = TensorHandle.new_contiguous((rows,), client.empty(rows * 4), ElemType.U32)
+    ops.argreduce_axis(client, t, oi, 1, "argmax")
+    assert np.array_equal(oi.to_numpy(client), oracle.reduce_axis_argmax(vals, 1)) and list(oi.to_numpy(client)[[0, 2, 3]]) == [3, 100_000, 131_074]
+    ops.argreduce_axis(client, t, oi, 1, "argmin")
+    assert np.array_equal(oi.to_numpy(client), oracle.reduce_axis_argmin(vals, 1)) and list(oi.to_numpy(client)[[1, 2, 4]]) == [90_001, 100_000, 0]
+    for op in ("max", "min"):
+        ops.reduce_axis(client, t, o, 1, op)
+        assert np.array_equal(o.to_numpy(client).view(np.uint32), oracle.reduce_axis_value(vals, 1, op).astype(np.float32).view(np.uint32)), op
+    for op in ("sum", "mean"):
+        ops.reduce_axis(client, t, o, 1, op)
+        got, want = o.to_numpy(client).astype(np.float64), oracle.reduce_axis_value(vals, 1, op)
+        keep = [0, 1, 3, 4]
+        bound = np.abs(vals[keep]).astype(np.float64).sum(axis=1) / (cols if op == "mean" else 1)
+        assert np.all(np.abs(got[keep] - want[keep]) <= REL * bound + 1e-30) and np.isnan(got[2]), op
+    first = o.to_numpy(client).view(np.uint32).copy()                    # the same tree every launch
+    for _ in range(3):
+        ops.reduce_axis(client, t, o, 1, "mean")
+        assert np.array_equal(o.to_numpy(client).view(np.uint32), first)
 
 
 def test_axis_value_rules_nan_ties_and_zero(client, oracle):
