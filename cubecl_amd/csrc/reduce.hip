@@ -744,15 +744,17 @@ reduce_rows(const typename red_in<DT>::elem *__restrict__ in, float *__restrict_
     __shared__ float s_sum[WAVES];
     __shared__ uint32_t s_key[WAVES];
     __shared__ uint64_t s_idx[WAVES];
-    for (uint64_t vr = blockIdx.x; vr < rows * segs; vr += gridDim.x) {
-        const uint64_t row = segs > 1 ? vr / segs : vr, first = segs > 1 ? (vr % segs) * seg_len : 0;
-        const uint64_t cols = segs > 1 ? (cols_all - first < seg_len ? cols_all - first : seg_len) : cols_all;      // (the host leaves no span empty)
+    constexpr bool SEG = THREADS == 256;                  // (only the 256-thread form is launched with spans: the others keep their per-row cost)
+    const uint64_t vrows = SEG ? rows * segs : rows;
+    for (uint64_t vr = blockIdx.x; vr < vrows; vr += gridDim.x) {
+        const uint64_t row = (SEG && segs > 1) ? vr / segs : vr, first = (SEG && segs > 1) ? (vr % segs) * seg_len : 0;
+        const uint64_t cols = (SEG && segs > 1) ? (cols_all - first < seg_len ? cols_all - first : seg_len) : cols_all;      // (the host leaves no span empty)
         const typename RI::elem *__restrict__ p = in + row * row_stride + first;
         auto put_val = [&](float t, bool nan) {
-            if (segs > 1) { part_val[vr] = t; part_key[vr] = nan ? 1u : 0u; } else out_sum[row] = O::finish(t, nan, cols);
+            if ((SEG && segs > 1)) { part_val[vr] = t; part_key[vr] = nan ? 1u : 0u; } else out_sum[row] = O::finish(t, nan, cols);
         };
         auto put_idx = [&](uint32_t k, uint64_t ix) {
-            if (segs > 1) { part_key[vr] = k; part_idx[vr] = ix + first; } else out_idx[row] = cols ? (uint32_t)ix : 0u;
+            if ((SEG && segs > 1)) { part_key[vr] = k; part_idx[vr] = ix + first; } else out_idx[row] = cols ? (uint32_t)ix : 0u;
         };
         float a0 = V::identity(), a1 = V::identity(), a2 = V::identity(), a3 = V::identity();
         bool nan_seen = false;
@@ -765,11 +767,12 @@ reduce_rows(const typename red_in<DT>::elem *__restrict__ in, float *__restrict_
         float best_val = -NAN_LEADS;
         // (late round 6: the 16-byte body starts at the ROW's own first aligned element -- until then one flag covered the launch, and a row length that is not a
         //  multiple of the vector (or a base off the 16-byte grid) sent every row through the scalar loop: 1404 x 133719 bf16 188 us = 0.25 of HBM, 635518 x 250 156 us)
-        uint64_t head = cols, done = cols;
-        if (vec_ok) {
-            head = ((16u - (uint32_t)(reinterpret_cast<uintptr_t>(p) & 15u)) & 15u) / (uint32_t)sizeof(typename RI::elem);
-            // (a short row off the grid stays on the scalar loop as before: under 2 KiB the peel costs more than the vectors save -- 48382 x 147 bf16 8.1 us -> 14.9 with it)
-            if (head > cols || (head != 0 && cols * sizeof(typename RI::elem) < 2048)) head = cols;
+        uint64_t head = 0, done = 0;           // (a row left to the scalar loop: no head, nothing done -- the plain increasing walk below)
+        const uint64_t to_grid = ((16u - (uint32_t)(reinterpret_cast<uintptr_t>(p) & 15u)) & 15u) / (uint32_t)sizeof(typename RI::elem);
+        // (a short row off the grid stays on the scalar loop as before: under 2 KiB the peel costs more than the vectors save -- 48382 x 147 bf16 8.1 us -> 14.9 with it --
+        //  and rows of such a matrix that happen to start on the grid share their last cache line with the next row: non-temporal vectors fetch it twice -- 199410 x 316 bf16 46 -> 69 us)
+        if ((vec_ok & 1) && to_grid <= cols && ((vec_ok & 2) || cols * sizeof(typename RI::elem) >= 2048)) {
+            head = to_grid;
             const u32x4r *__restrict__ vp = reinterpret_cast<const u32x4r *>(p + head);
             const uint64_t nv = (cols - head) / EPV;
             constexpr int UL = 4;                                   // 16-byte loads in flight per lane (the data is read once: non-temporal)
@@ -814,11 +817,15 @@ reduce_rows(const typename red_in<DT>::elem *__restrict__ in, float *__restrict_
         }
         // the elements before the first and after the last whole vector (every element when the base is off its element grid).  A lane meets the head's
         // indices after its body's: equal keys keep the lower index explicitly
-        for (uint64_t i = tid; i < head + (cols - done); i += THREADS) {
-            const uint64_t e = i < head ? i : done + (i - head);
-            const float v = RI::widen(p[e]);
+        for (uint64_t i = tid; i < head; i += THREADS) {
+            const float v = RI::widen(p[i]);
             if (!ARG) { a0 = V::apply(a0, v); if (V::TRACKS_NAN) nan_seen |= (v != v); }
-            else { const uint32_t k = arg_key<O::AOP>(v); if (k > key || (k == key && e < idx)) { key = k; idx = e; } }
+            else { const uint32_t k = arg_key<O::AOP>(v); if (k > key || (k == key && i < idx)) { key = k; idx = i; } }
+        }
+        for (uint64_t i = done + tid; i < cols; i += THREADS) {
+            const float v = RI::widen(p[i]);
+            if (!ARG) { a0 = V::apply(a0, v); if (V::TRACKS_NAN) nan_seen |= (v != v); }
+            else { const uint32_t k = arg_key<O::AOP>(v); if (k > key) { key = k; idx = i; } }
         }
         if (!ARG) {
             float s = wave_fold<O::VOP>(V::apply(V::apply(a0, a1), V::apply(a2, a3)));
@@ -1146,7 +1153,9 @@ int32_t run_rows(mi355_ctx *ctx, mi355_stream stream, const typename red_in<DT>:
     if (ARG && cols > 0xFFFFFFFFull)
         return fail(ctx, MI355_E_UNSUPPORTED, "%s: cols exceed u32 index range", what);
     hipStream_t s = stream_of(ctx, stream);
-    const int vec_ok = (reinterpret_cast<uintptr_t>(in) & (sizeof(typename red_in<DT>::elem) - 1)) == 0 ? 1 : 0;   // (each row finds its own first 16-byte boundary)
+    // bit 0: the base is on its element grid (each row finds its own first 16-byte boundary); bit 1: every row starts on the 16-byte grid
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(in) & (sizeof(typename red_in<DT>::elem) - 1)) == 0 ? 1 : 0) |
+                       (((reinterpret_cast<uintptr_t>(in) & 15u) == 0 && (row_stride % red_in<DT>::EPV) == 0) ? 2 : 0);
     const uint64_t cus = ctx->props.num_streaming_multiprocessors;
     const uint64_t cols32 = cols * sizeof(typename red_in<DT>::elem) / 4;        // row length in f32-equivalents (bytes / 4)
     // few, long rows (late round 6, the seeded roofline audit of the axis reductions: 13 x 992618 f32 270 us = 0.02 of HBM on 13 workgroups): spans of at least 32 KiB, about
