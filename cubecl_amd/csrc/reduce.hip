@@ -1116,6 +1116,57 @@ int32_t run_mid(mi355_ctx *ctx, mi355_stream stream, const typename red_in<DT>::
     return MI355_OK;
 }
 
+// Rows of at most 512 elements (end of round 6): one wave per row has one or two loads per lane in flight and then folds -- a chain of load latency + butterfly per
+// row, 635518 x 250 bf16 at 0.25 of HBM.  Here a wave takes FOUR rows at a time: all their elements are requested first (16 or 32 plain loads per lane -- any alignment, and
+// neighbouring rows share cache lines), then each row is folded the usual way (the reference's plane_reduce butterfly; lowest index among equal keys).
+template <int OP, int DT, int J>
+__global__ void __launch_bounds__(64)
+reduce_short_rows(const typename red_in<DT>::elem *__restrict__ in, float *__restrict__ out_sum, uint32_t *__restrict__ out_idx, uint64_t rows, uint32_t cols,
+                  uint64_t row_stride)
+{
+    typedef axis_op<OP> O;
+    typedef typename O::V V;
+    typedef red_in<DT> RI;
+    constexpr int R = 4;                     // (J: 64-element slices of a row, 4 up to 256 elements, 8 up to 512)
+    const uint32_t lane = threadIdx.x;
+    for (uint64_t r0 = (uint64_t)blockIdx.x * R; r0 < rows; r0 += (uint64_t)gridDim.x * R) {
+        float v[R][J];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint64_t row = r0 + r < rows ? r0 + r : rows - 1;            // (a row past the end re-reads the last one; its result is not written)
+            const typename RI::elem *__restrict__ p = in + row * row_stride;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const uint32_t c = lane + 64u * j;
+                v[r][j] = RI::widen(p[c < cols ? c : 0]);                      // (unconditional loads: all sixteen are in flight before the first use)
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (r0 + r >= rows) break;
+            if constexpr (!O::ARG) {
+                float a = V::identity();
+                bool nan_seen = false;
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+                    if (lane + 64u * j < cols) { a = V::apply(a, v[r][j]); if (V::TRACKS_NAN) nan_seen |= (v[r][j] != v[r][j]); }
+                const float s = wave_fold<O::VOP>(a);
+                const bool wave_nan = V::TRACKS_NAN ? (bool)__any(nan_seen) : false;
+                if (lane == 0) out_sum[r0 + r] = O::finish(s, wave_nan, cols);
+            } else {
+                uint32_t key = 0u; uint64_t idx = ~0ull;
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const uint32_t c = lane + 64u * j;
+                    if (c < cols) { const uint32_t k = arg_key<O::AOP>(v[r][j]); if (k > key) { key = k; idx = c; } }
+                }
+                wave_argmax(key, idx);
+                if (lane == 0) out_idx[r0 + r] = cols ? (uint32_t)idx : 0u;
+            }
+        }
+    }
+}
+
 // the rows of a segmented reduce_rows launch: one thread per row walks its spans in order (at most 1024 of them)
 template <int OP>
 __global__ void __launch_bounds__(64)
@@ -1182,7 +1233,11 @@ int32_t run_rows(mi355_ctx *ctx, mi355_stream stream, const typename red_in<DT>:
             }
         }
     }
-    if (cols32 <= 2048) {
+    if (cols <= 512 && cols > 0 && rows >= 4) {
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((rows + 3) / 4, cus * 32);
+        if (cols <= 256) hipLaunchKernelGGL((reduce_short_rows<OP, DT, 4>), dim3(grid), dim3(64), 0, s, in, out_sum, out_idx, rows, (uint32_t)cols, row_stride);
+        else hipLaunchKernelGGL((reduce_short_rows<OP, DT, 8>), dim3(grid), dim3(64), 0, s, in, out_sum, out_idx, rows, (uint32_t)cols, row_stride);
+    } else if (cols32 <= 2048) {
         const uint32_t grid = (uint32_t)std::min<uint64_t>(rows, cus * 32);
         hipLaunchKernelGGL((reduce_rows<64, OP, DT>), dim3(grid), dim3(64), 0, s, in, out_sum, out_idx, rows, cols,
                            row_stride, vec_ok);

@@ -746,7 +746,9 @@ def test_value_reduction_rules_nan_signed_zero_misaligned_and_bad_ops(client, or
                                         ((64, 256, 1024), 1), ((64, 256, 1024), 0), ((512, 8192), 0), ((3, 1000, 7), 1), ((1, 5, 1), 1),
                                         ((2048, 33), 0), ((37, 1001), -1), ((5, 4, 3, 2), 2), ((1, 200_003), 1), ((1000, 1), 1),
                                         # (late round 6) few long rows cut into spans, rows that start off the 16-byte grid
-                                        ((13, 300_007), 1), ((3, 70_001), 1), ((130, 40_003), 1), ((257, 250), 1), ((1000, 133), 1)])
+                                        ((13, 300_007), 1), ((3, 70_001), 1), ((130, 40_003), 1), ((257, 250), 1), ((1000, 133), 1),
+                                        # four short rows per wave (up to 256 / 512 elements), a last group of fewer than four
+                                        ((1003, 300), 1), ((5, 512), 1), ((66, 129), 1), ((3, 200), 1)])
 def test_every_reduce_operation_over_any_axis(client, oracle, dtype, shape, axis):
     """mi355_reduce_axis / mi355_argreduce_axis over the book's shapes (cubecl-book/src/getting-started/src/bin/v7-gpu.rs:59-77)
     and the shapes of the sum / argmax axis tests: last axis (one wave / one workgroup per row), middle and first axis."""
@@ -785,6 +787,42 @@ def test_every_reduce_operation_over_any_axis(client, oracle, dtype, shape, axis
             assert np.array_equal(oi.to_numpy(client).reshape(out_shape or (1,)), oracle.reduce_axis_argmin(vals, ax).reshape(out_shape or (1,)))
             ops.argreduce_axis(client, t, oi, axis, "argmax")
             assert np.array_equal(oi.to_numpy(client).reshape(out_shape or (1,)), oracle.reduce_axis_argmax(vals, ax).reshape(out_shape or (1,)))
+
+
+@pytest.mark.parametrize("dtype", [ElemType.F32, ElemType.BF16])
+@pytest.mark.parametrize("cols", [130, 256, 257, 500])
+def test_short_rows_four_to_a_wave_keep_the_index_rules(client, oracle, dtype, cols):
+    """reduce_short_rows (end of round 6): ties inside a lane's slices and across lanes resolve to the lowest index, a NaN leads the index operations and poisons max / min
+    of ITS row only, and the rows of a group do not leak into each other."""
+    rows = 11
+    x = (oracle.fill_uniform(rows * cols, 78, -1.0, 1.0) * np.float32(0.5)).reshape(rows, cols)
+    x[0, [cols - 1, 64, 1]] = 2.0                    # ties: last element, the second slice of lane 0, lane 1
+    x[1, [65, 129]] = -3.0                           # argmin ties in two slices of one lane
+    x[2, cols - 2] = np.nan
+    x[4, 0] = 5.0
+    x[5, :] = 0.25                                   # a constant row: index 0
+    x[10, cols - 1] = -7.0                           # the group of fewer than four rows
+    if dtype == ElemType.F32:
+        bits, vals = x, x
+    else:
+        bits = oracle.to_bf16(x.reshape(-1)).reshape(rows, cols)
+        vals = oracle.from_bf16(bits.reshape(-1)).reshape(rows, cols)
+    t = TensorHandle.from_numpy(client, bits, dtype)
+    o = TensorHandle.new_contiguous((rows,), client.empty(rows * 4), ElemType.F32)
+    oi = TensorHandle.new_contiguous((rows,), client.empty(rows * 4), ElemType.U32)
+    ops.argreduce_axis(client, t, oi, 1, "argmax")
+    got = oi.to_numpy(client)
+    assert np.array_equal(got, oracle.reduce_axis_argmax(vals, 1)) and list(got[[0, 2, 4, 5]]) == [1, cols - 2, 0, 0]
+    ops.argreduce_axis(client, t, oi, 1, "argmin")
+    got = oi.to_numpy(client)
+    assert np.array_equal(got, oracle.reduce_axis_argmin(vals, 1)) and list(got[[1, 2, 10]]) == [65, cols - 2, cols - 1]
+    for op in ("max", "min"):
+        ops.reduce_axis(client, t, o, 1, op)
+        assert np.array_equal(o.to_numpy(client).view(np.uint32), oracle.reduce_axis_value(vals, 1, op).astype(np.float32).view(np.uint32)), op
+    ops.reduce_axis(client, t, o, 1, "sum")
+    got, want = o.to_numpy(client).astype(np.float64), oracle.reduce_axis_value(vals, 1, "sum")
+    keep = [r for r in range(rows) if r != 2]
+    assert np.all(np.abs(got[keep] - want[keep]) <= REL * np.abs(vals[keep]).astype(np.float64).sum(axis=1) + 1e-30) and np.isnan(got[2])
 
 
 @pytest.mark.parametrize("dtype", [ElemType.F32, ElemType.BF16])
