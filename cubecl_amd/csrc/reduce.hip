@@ -990,7 +990,24 @@ reduce_axis_tiled(axis_args a)
             s_b[tid * W + e] = ARG ? idx[e] : ((nanbits >> e) & 1u);
         }
         __syncthreads();
-        if (ty == 0) {
+        if constexpr (ARG) {
+            // (end of round 6) index operations: a tree over ty instead of the ty == 0 thread's walk -- arg_combine is a total order (larger key, then lower index), so the
+            // tree gives the walk's answer bit for bit; the walk's 255 dependent compare-and-select steps per column were most of the kernel under a narrow `inner`
+            // (744 x 2651 x 4 f32: argmax 83 us where the sum takes 12.5).  Value operations keep the walk: their result depends on the order.
+            for (uint32_t half = TY >> 1; half >= 1; half >>= 1) {
+                if (ty < half) {
+                    const uint32_t other = (oy << (a.log2_tx + a.log2_ty)) + ((ty + half) << a.log2_tx) + tx;
+#pragma unroll
+                    for (int e = 0; e < W; ++e) arg_combine_u32(key[e], idx[e], s_a[other * W + e], s_b[other * W + e]);
+                }
+                __syncthreads();
+                if (ty < half) {
+#pragma unroll
+                    for (int e = 0; e < W; ++e) { s_a[tid * W + e] = key[e]; s_b[tid * W + e] = idx[e]; }
+                }
+                __syncthreads();
+            }
+        } else if (ty == 0) {
             for (uint32_t t = 1; t < TY; ++t) {
                 const uint32_t other = (oy << (a.log2_tx + a.log2_ty)) + (t << a.log2_tx) + tx;
 #pragma unroll
